@@ -1,0 +1,219 @@
+/* klara_hip.h — C ABI of libklara_hip.so: the many-chain MCMC transition path of Klara.jl on MI355X.
+ *
+ * What this replaces.  Klara.jl has no FFI (it is 100 % Julia); the hot path sits behind Julia
+ * multiple dispatch:
+ *     run(job::BasicMCJob)                               src/jobs/BasicMCJob.jl:212-244
+ *       iterate!(job, typeof(job.sampler), variate_form)  src/jobs/BasicMCJob.jl:224
+ *         iterate!(::BasicMCJob, ::Type{MH|MALA|HMC|SliceSampler}, ::Type{Multivariate})
+ *                                                         src/samplers/iterate/{MH,MALA,HMC,SliceSampler}.jl
+ *         job.parameter.logtarget! / gradlogtarget! / uptogradlogtarget!
+ *                                                         src/variables/parameters/BasicContMuvParameter.jl:174-279
+ * One klara_handle stands for N independent BasicMCJobs (N chains of one model); klara_run() is the
+ * `for i in 1:nsteps iterate!(...)` loop of BasicMCJob.jl:219-238 executed for all chains at once on
+ * the GPU.  The Julia-side binding a maintainer would add is shown in INTEGRATION.md (ccall stubs).
+ *
+ * Conventions: plain C, caller-owned host buffers copied at the call, library-owned device buffers
+ * inside the handle, every entry point returns klara_status (never aborts).  Matrices are row-major
+ * (nchains x ndims): chain c's D-vector is contiguous — the transpose of Klara's per-chain
+ * NState.value (ndims x nsaved, src/nstates/ParameterNStates/BasicContMuvParameterNState.jl:1-21);
+ * klara_get_chain() returns one chain in Klara's own column-major layout.
+ *
+ * There is no CPU implementation behind this ABI: if no HIP device is present klara_create() fails
+ * with KLARA_ERR_HIP.
+ */
+#ifndef KLARA_HIP_H
+#define KLARA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KLARA_ABI_VERSION 1
+
+typedef enum klara_status {
+    KLARA_OK = 0,
+    KLARA_ERR_INVALID_ARG = 1,     /* mirrors the reference's @assert argument checks                */
+    KLARA_ERR_NONFINITE_INIT = 2,  /* MH.jl:83 / MALA.jl:83-89 / HMC.jl:113-119: non-finite start     */
+    KLARA_ERR_HIP = 3,             /* HIP runtime failure or no device                                */
+    KLARA_ERR_NOMEM = 4,
+    KLARA_ERR_UNSUPPORTED = 5,     /* valid Klara option that this build does not cover (see DESIGN)  */
+    KLARA_ERR_STATE = 6,           /* call order (e.g. run before set_state)                          */
+    KLARA_ERR_SLICE_STUCK = 7      /* iterate/SliceSampler.jl:102 "Shrunk to current position ..."   */
+} klara_status;
+
+/* src/samplers/{MH,MALA,HMC,SliceSampler}.jl */
+typedef enum klara_sampler {
+    KLARA_SAMPLER_MH = 0,      /* MH(sigma): symmetric normal random walk, MH.jl:63-66            */
+    KLARA_SAMPLER_MALA = 1,    /* MALA(driftstep), MALA.jl:61-70                                   */
+    KLARA_SAMPLER_HMC = 2,     /* HMC(leapstep, nleaps), HMC.jl:89-100                             */
+    KLARA_SAMPLER_SLICE = 3    /* SliceSampler(widths, stepout), SliceSampler.jl:22-34             */
+} klara_sampler;
+
+/* Target families evaluated on device (stand-ins for the user closures of
+ * BasicContMuvParameter.jl:383-411; arbitrary Julia closures cannot run on the GPU). */
+typedef enum klara_target {
+    /* lt = c - sum_i w_i (x_i - mu_i)^2 ; grad_i = -2 w_i (x_i - mu_i).
+     * README.md:23,155 is w=1, mu=0, c=0; MvNormal(mu, sigma I) of test/BasicContMuvParameter.jl:39-56
+     * is w = 1/(2 sigma^2), c = -D/2 log(2 pi) - D log sigma. */
+    KLARA_TARGET_GAUSS_DIAG = 0,
+    /* lt = c - 1/2 (x-mu)' P (x-mu) ; grad = -P (x-mu).  P = dense precision matrix (D x D). */
+    KLARA_TARGET_GAUSS_DENSE = 1,
+    /* Bayesian logistic regression of doc/examples/swiss/MALA/analytical.jl:11-18:
+     * lt = dot(Xp, y) - sum(log(1+exp(Xp))) - 0.5 (p.p/lambda + D log(2 pi lambda)). */
+    KLARA_TARGET_LOGISTIC = 2
+} klara_target;
+
+/* src/tuners/{VanillaMCTuner,AcceptanceRateMCTuner}.jl */
+typedef enum klara_tuner {
+    KLARA_TUNER_VANILLA = 0,
+    KLARA_TUNER_ACCEPT_RATE = 1
+} klara_tuner;
+
+typedef enum klara_tuner_mode {
+    KLARA_TUNE_PER_CHAIN = 0,   /* reference semantics: one BasicMCTune per job = per chain      */
+    KLARA_TUNE_POOLED = 1       /* one tune state per GPU, rate pooled over the GPU's chains      */
+} klara_tuner_mode;
+
+/* monitor flags (jobs.jl:9-43 outopts :monitor / :diagnostics / :destination) */
+#define KLARA_MON_ACCEPT    0x1u  /* keep the per-step accept diagnostics (u8 per step per chain)  */
+#define KLARA_MON_HISTORY   0x2u  /* :destination=>:nstate — keep value at every postrange step    */
+#define KLARA_MON_SUMMARIES 0x4u  /* accumulate sum x, sum x^2 over postrange steps on device      */
+
+typedef struct klara_desc {
+    uint32_t struct_size;        /* = sizeof(klara_desc), ABI check                                  */
+    uint32_t abi_version;        /* = KLARA_ABI_VERSION                                              */
+
+    int32_t  sampler;            /* klara_sampler                                                    */
+    int32_t  target;             /* klara_target                                                     */
+    int32_t  tuner;              /* klara_tuner                                                      */
+    int32_t  tuner_mode;         /* klara_tuner_mode                                                 */
+
+    int64_t  nchains;            /* chains owned by this handle (this GPU's shard)                   */
+    int64_t  chain_offset;       /* global id of local chain 0 (RNG subsequence = offset + local id) */
+    int32_t  ndims;              /* D                                                                */
+    int32_t  device;             /* HIP device ordinal                                               */
+
+    /* sampler parameters */
+    const double* mh_sigma;      /* MH: proposal std-devs, D doubles (MH.jl:63: MvNormal(x, sigma))   */
+    double   driftstep;          /* MALA (MALA.jl:65: > 0)                                           */
+    double   leapstep;           /* HMC  (HMC.jl:94: > 0)                                            */
+    int32_t  nleaps;             /* HMC  (HMC.jl:95: > 0)                                            */
+    int32_t  slice_stepout;      /* SliceSampler.stepout                                             */
+    const double* slice_widths;  /* SliceSampler.widths, D doubles (> 0, SliceSampler.jl:27)         */
+
+    /* tuner (AcceptanceRateMCTuner.jl:38-44; VanillaMCTuner: only period/verbose are used) */
+    double   targetrate;         /* in (0,1)                                                         */
+    double   score_k;            /* steepness of logistic_rate_score (default 7)                     */
+    int32_t  period;             /* > 0, default 100                                                 */
+    int32_t  verbose;            /* counts proposals the way the reference's verbose tuners do      */
+
+    /* range (BasicMCRange.jl:17-36) */
+    int64_t  nsteps;
+    int64_t  burnin;
+    int64_t  thinning;
+
+    /* target parameters (host pointers, copied at create) */
+    const double* gauss_w;       /* DIAG: D weights (NULL = all 1)                                   */
+    const double* gauss_mu;      /* DIAG/DENSE: D means (NULL = 0)                                   */
+    double   gauss_const;        /* DIAG/DENSE: additive constant c                                  */
+    const double* gauss_prec;    /* DENSE: D*D row-major precision matrix                            */
+    const double* logit_X;       /* LOGISTIC: ndata x D row-major design matrix                      */
+    const double* logit_y;       /* LOGISTIC: ndata outcomes                                         */
+    int32_t  logit_ndata;
+    int32_t  reserved0;
+    double   logit_lambda;       /* LOGISTIC: prior variance (v[1] of the example)                   */
+
+    uint64_t seed;               /* Philox key                                                       */
+    uint32_t monitor;            /* KLARA_MON_* bits                                                 */
+    int32_t  steps_per_launch;   /* transitions fused in one kernel launch (>=1; 0 = library default) */
+    void*    stream;             /* hipStream_t to launch on, or NULL for a library-owned stream     */
+} klara_desc;
+
+typedef struct klara_handle klara_handle;
+
+/* Lifetime.  klara_create validates the descriptor the way the Julia constructors do and uploads the
+ * target data.  (BasicMCJob inner ctor, BasicMCJob.jl:24-104.) */
+klara_status klara_create(const klara_desc* desc, klara_handle** out);
+klara_status klara_destroy(klara_handle* h);
+
+/* Initial values (v0 of BasicMCJob.jl:156-185), nchains x ndims row-major.  Evaluates the target and
+ * (MALA/HMC) its gradient on device and applies the reference's finiteness asserts
+ * (MH.jl:72-85, MALA.jl:76-90, HMC.jl:106-120, SliceSampler.jl:40-48).  Also (re)initialises the tuner
+ * state (samplers.jl:29-45: accepted=proposed=0, totproposed=period) and the step counter. */
+klara_status klara_set_state(klara_handle* h, const double* x_host);
+/* Same, x0 ~ N(0, I) drawn on device from the handle's Philox stream (transition index -1). */
+klara_status klara_init_state_normal(klara_handle* h);
+
+/* The transition loop: nsteps calls of iterate! for every chain (BasicMCJob.jl:219-238), including the
+ * tuning block and the save rule.  Synchronous w.r.t. the host on return. */
+klara_status klara_run(klara_handle* h, int64_t nsteps);
+/* Same, but returns immediately after enqueueing (for overlap / external event timing). */
+klara_status klara_run_async(klara_handle* h, int64_t nsteps);
+klara_status klara_synchronize(klara_handle* h);
+
+/* reset(job[, x]) of BasicMCJob.jl:187-201: rewind sampler/tuner state and counters; x_host may be
+ * NULL (keep the current values, re-evaluate the target). */
+klara_status klara_reset(klara_handle* h, const double* x_host);
+
+/* Read-back.  Any pointer may be NULL. */
+klara_status klara_get_state(klara_handle* h, double* x, double* logtarget, double* gradlogtarget);
+/* accept diagnostics of the transitions run so far since set_state/reset: steps x nchains bytes,
+ * step-major (requires KLARA_MON_ACCEPT).  *nsteps_out receives the number of recorded steps. */
+klara_status klara_get_accept_mask(klara_handle* h, uint8_t* mask, int64_t capacity_steps,
+                                   int64_t* nsteps_out);
+/* per-chain accepted-transition counts over all steps since set_state/reset */
+klara_status klara_get_accept_counts(klara_handle* h, uint64_t* naccept, uint64_t* nsteps_out);
+/* per-chain sums over saved (postrange) steps: sum[c*D+d], sumsq[c*D+d]; *nsaved_out = count */
+klara_status klara_get_chain_sums(klara_handle* h, double* sum, double* sumsq, int64_t* nsaved_out);
+/* sums pooled over this handle's chains (reduced on device): sum[D], sumsq[D], total accepted,
+ * total transitions, saved samples per chain. */
+klara_status klara_get_pooled_summaries(klara_handle* h, double* sum, double* sumsq,
+                                        uint64_t* naccept, uint64_t* ntransitions,
+                                        int64_t* nsaved_out);
+/* one chain of the stored history in Klara's NState layout: value[d + D*i], i = saved step
+ * (BasicContMuvParameterNState.jl:89-119); requires KLARA_MON_HISTORY. */
+klara_status klara_get_chain(klara_handle* h, int64_t local_chain, double* value, int64_t capacity_cols,
+                             int64_t* ncols_out);
+/* tuner state per chain (tuners.jl:5-10). In pooled mode every chain reports the shared state. */
+klara_status klara_get_tune(klara_handle* h, double* step, int64_t* accepted, int64_t* proposed,
+                            int64_t* totproposed);
+
+/* Measurement: duration (ms, HIP events on the launch stream) and launch count of the transition
+ * kernels enqueued by the last klara_run / klara_run_async (after synchronisation). */
+klara_status klara_last_run_ms(klara_handle* h, double* kernel_ms, int64_t* nlaunches);
+
+/* Raw device pointers of the state (for zero-copy consumers on the same device, e.g. a torch tensor
+ * wrapper or an RCCL gather): x, logtarget, gradlogtarget.  Library keeps ownership. */
+klara_status klara_device_ptrs(klara_handle* h, void** x, void** logtarget, void** gradlogtarget);
+
+/* The lane layout the kernels use for this handle (needed by the CPU oracle to sum in the same
+ * order): kind 0 = contiguous E elements per lane over G lanes; kind 1 = MFMA-transposed layout
+ * (element i on lane-quarter i%4).  See DESIGN.md §Layout. */
+klara_status klara_get_layout(klara_handle* h, int32_t* kind, int32_t* lanes_per_chain,
+                              int32_t* elems_per_lane);
+
+/* Self-test hook: writes nblocks Philox4x32-10 blocks produced by rocRAND's device engine
+ * (rocrand_device::philox4x32_10_engine, seed/subsequence/offset = 4*first_block) into out[4*nblocks];
+ * tests compare this with the library's own in-kernel generator and with the CPU oracle. */
+klara_status klara_selftest_rocrand_blocks(int32_t device, uint64_t seed, uint64_t subsequence,
+                                           uint64_t first_block, int32_t nblocks, uint32_t* out);
+/* Self-test hook: evaluates the deterministic device math (log, exp, sincos2pi, normal pair) on n
+ * inputs so tests can compare bits with the CPU build of the same header. op: 0 log, 1 exp,
+ * 2 sin2pi, 3 cos2pi, 4 sqrt, 5 div (in[i] / in2[i]). */
+klara_status klara_selftest_math(int32_t device, int32_t op, int64_t n, const double* in,
+                                 const double* in2, double* out);
+
+/* Self-test hook: D(16x16) = A(16x4) * B(4x16) + C(16x16), all row-major, through ONE
+ * v_mfma_f64_16x16x4_f64 — pins the instruction's accumulation order for the dense-target parity. */
+klara_status klara_selftest_mfma_f64(int32_t device, const double* A, const double* B, const double* C,
+                                     double* D);
+
+const char* klara_strerror(klara_status s);
+int32_t klara_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KLARA_HIP_H */

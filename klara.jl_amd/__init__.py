@@ -1,0 +1,17 @@
+"""klara_jl_amd — MI355X-native many-chain MCMC transition path behind Klara.jl's job/sampler API.
+
+The package directory is `klara.jl_amd/` (not importable by that name); import it as
+`klara_jl_amd` through the loader module at the repository root.
+"""
+from . import _lib  # noqa: F401
+from ._lib import KlaraError  # noqa: F401
+from .engine import Engine, GaussDenseTarget, GaussDiagTarget, LogisticTarget  # noqa: F401
+from .api import (  # noqa: F401
+    HMC, MALA, MH, AcceptanceRateMCTuner, BasicContMuvParameter, BasicMCJob, BasicMCRange, GenericModel,
+    MuvChains, SliceSampler, VanillaMCTuner, acceptance, likelihood_model, logistic, logistic_rate_score,
+    mcvar_iid, mean, output, reset, run,
+)
+from .distributed import allreduce_summaries, gather_engine_summaries, shard_chains  # noqa: F401
+from .build import build_library, build_oracle  # noqa: F401
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,130 @@
+"""ctypes binding of libklara_hip.so (include/klara_hip.h).
+
+The library is the product: there is no Python/NumPy/CPU implementation of the transition path behind
+this module.  If the shared object is missing, `load()` raises; if no HIP device is present,
+`klara_create` returns KLARA_ERR_HIP and `KlaraError` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libklara_hip.so"
+
+KLARA_ABI_VERSION = 1
+
+# klara_status
+OK, ERR_INVALID_ARG, ERR_NONFINITE_INIT, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_STATE, ERR_SLICE_STUCK = range(8)
+# klara_sampler
+SAMPLER_MH, SAMPLER_MALA, SAMPLER_HMC, SAMPLER_SLICE = range(4)
+# klara_target
+TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC = range(3)
+# klara_tuner / mode
+TUNER_VANILLA, TUNER_ACCEPT_RATE = 0, 1
+TUNE_PER_CHAIN, TUNE_POOLED = 0, 1
+MON_ACCEPT, MON_HISTORY, MON_SUMMARIES = 0x1, 0x2, 0x4
+
+_dp = C.POINTER(C.c_double)
+
+
+class KlaraDesc(C.Structure):
+    """struct klara_desc (include/klara_hip.h) — field order and types must match exactly."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
+        ("sampler", C.c_int32), ("target", C.c_int32), ("tuner", C.c_int32), ("tuner_mode", C.c_int32),
+        ("nchains", C.c_int64), ("chain_offset", C.c_int64), ("ndims", C.c_int32), ("device", C.c_int32),
+        ("mh_sigma", _dp), ("driftstep", C.c_double), ("leapstep", C.c_double),
+        ("nleaps", C.c_int32), ("slice_stepout", C.c_int32), ("slice_widths", _dp),
+        ("targetrate", C.c_double), ("score_k", C.c_double), ("period", C.c_int32), ("verbose", C.c_int32),
+        ("nsteps", C.c_int64), ("burnin", C.c_int64), ("thinning", C.c_int64),
+        ("gauss_w", _dp), ("gauss_mu", _dp), ("gauss_const", C.c_double), ("gauss_prec", _dp),
+        ("logit_X", _dp), ("logit_y", _dp), ("logit_ndata", C.c_int32), ("reserved0", C.c_int32),
+        ("logit_lambda", C.c_double),
+        ("seed", C.c_uint64), ("monitor", C.c_uint32), ("steps_per_launch", C.c_int32),
+        ("stream", C.c_void_p),
+    ]
+
+
+class KlaraError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = int(status)
+        msg = _strerror(status)
+        super().__init__(f"{where}: klara_status {int(status)} ({msg})")
+
+
+# every symbol include/klara_hip.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "klara_create", "klara_destroy", "klara_set_state", "klara_init_state_normal", "klara_run",
+    "klara_run_async", "klara_synchronize", "klara_reset", "klara_get_state", "klara_get_accept_mask",
+    "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
+    "klara_get_tune", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
+    "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_mfma_f64", "klara_strerror",
+    "klara_abi_version",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libklara_hip.so (built in-tree by __graft_entry__.build() / klara.jl_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("KLARA_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise FileNotFoundError(
+            f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+            f"or make -C klara.jl_amd/csrc). There is no CPU fallback for the transition path.")
+    lib = C.CDLL(str(path))
+    H = C.c_void_p
+    i64p, u64p, u8p = C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
+    sig = {
+        "klara_create": [C.POINTER(KlaraDesc), C.POINTER(H)],
+        "klara_destroy": [H],
+        "klara_set_state": [H, C.c_void_p],
+        "klara_init_state_normal": [H],
+        "klara_run": [H, C.c_int64],
+        "klara_run_async": [H, C.c_int64],
+        "klara_synchronize": [H],
+        "klara_reset": [H, C.c_void_p],
+        "klara_get_state": [H, C.c_void_p, C.c_void_p, C.c_void_p],
+        "klara_get_accept_mask": [H, C.c_void_p, C.c_int64, i64p],
+        "klara_get_accept_counts": [H, C.c_void_p, u64p],
+        "klara_get_chain_sums": [H, C.c_void_p, C.c_void_p, i64p],
+        "klara_get_pooled_summaries": [H, C.c_void_p, C.c_void_p, u64p, u64p, i64p],
+        "klara_get_chain": [H, C.c_int64, C.c_void_p, C.c_int64, i64p],
+        "klara_get_tune": [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+        "klara_last_run_ms": [H, C.POINTER(C.c_double), i64p],
+        "klara_device_ptrs": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
+        "klara_get_layout": [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+        "klara_selftest_rocrand_blocks": [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p],
+        "klara_selftest_math": [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
+        "klara_selftest_mfma_f64": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.klara_strerror.argtypes = [C.c_int]
+    lib.klara_strerror.restype = C.c_char_p
+    lib.klara_abi_version.argtypes = []
+    lib.klara_abi_version.restype = C.c_int32
+    if lib.klara_abi_version() != KLARA_ABI_VERSION:
+        raise RuntimeError("libklara_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _strerror(status: int) -> str:
+    try:
+        return load().klara_strerror(int(status)).decode()
+    except Exception:  # library missing: still give a readable message
+        return "libklara_hip.so unavailable"
+
+
+def check(status: int, where: str) -> None:
+    if status != OK:
+        raise KlaraError(status, where)

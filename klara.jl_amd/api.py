@@ -1,0 +1,312 @@
+"""Host-side mirror of Klara.jl's job / sampler / tuner / range API for the many-chain GPU path.
+
+Julia is not installed in the build image, so the host side above the C ABI is Python with
+the same names, argument meaning and error behaviour as the reference's constructors:
+
+    p       = BasicContMuvParameter("p", logtarget=GaussDiagTarget.negdot(2))   # README.md:29
+    model   = likelihood_model(p, False)                                        # README.md:34
+    sampler = MH(np.ones(2))                                                    # README.md:38
+    mcrange = BasicMCRange(nsteps=10000, burnin=1000)                           # README.md:42
+    job     = BasicMCJob(model, sampler, mcrange, {"p": [5.1, -0.9]})           # README.md:50
+    run(job); chain = output(job); mean(chain); acceptance(chain)               # README.md:54-66
+
+Differences forced by the device: `logtarget=` takes a *target family object* (engine.GaussDiagTarget,
+GaussDenseTarget, LogisticTarget) instead of an arbitrary closure, and `v0[key]` may be an
+(nchains x D) matrix — one BasicMCJob then stands for nchains independent jobs
+(`run(job::Vector) = map(run, job)`, src/jobs/jobs.jl:212, executed as one launch).
+The Julia package a maintainer would ship is sketched in INTEGRATION.md.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .engine import Engine, GaussDenseTarget, GaussDiagTarget, LogisticTarget
+
+
+# ------------------------------------------------------------------ range (src/ranges/BasicMCRange.jl)
+class BasicMCRange:
+    """BasicMCRange(nsteps=100, burnin=0, thinning=1) — BasicMCRange.jl:36; asserts :22-24."""
+
+    def __init__(self, nsteps: int = 100, burnin: int = 0, thinning: int = 1):
+        assert burnin >= 0, "Number of burn-in iterations should be non-negative"
+        assert thinning >= 1, "Thinning should be >= 1"
+        assert nsteps > burnin, "Total number of MCMC iterations should be greater than number of burn-in iterations"
+        self.burnin, self.thinning = int(burnin), int(thinning)
+        self.postrange = range(self.burnin + 1, int(nsteps) + 1, self.thinning)  # (burnin+1):thinning:nsteps
+        # Julia's StepRange normalises `last` (BasicMCRange.jl:20: nsteps = last(postrange))
+        self.nsteps = self.postrange[-1]
+        self.npoststeps = len(self.postrange)
+
+    def __repr__(self):
+        return f"BasicMCRange: number of steps = {self.nsteps}, burnin = {self.burnin}, thinning = {self.thinning}"
+
+
+# ------------------------------------------------------------------ samplers (src/samplers/*.jl)
+class MCSampler:
+    pass
+
+
+class MH(MCSampler):
+    """MH(sigma::Vector): symmetric, normalised MvNormal(x, sigma) random walk — MH.jl:63-66."""
+
+    def __init__(self, sigma):
+        self.sigma = np.atleast_1d(np.asarray(sigma, dtype=np.float64)).copy()
+        self.symmetric, self.normalised = True, True
+
+    kind = L.SAMPLER_MH
+
+
+class MALA(MCSampler):
+    """MALA(driftstep=1.) — MALA.jl:61-70."""
+    kind = L.SAMPLER_MALA
+
+    def __init__(self, driftstep: float = 1.0):
+        assert driftstep > 0, "Drift step is not positive"
+        self.driftstep = float(driftstep)
+
+
+class HMC(MCSampler):
+    """HMC(leapstep=0.1, nleaps=10) — HMC.jl:89-100."""
+    kind = L.SAMPLER_HMC
+
+    def __init__(self, leapstep: float = 0.1, nleaps: int = 10):
+        assert leapstep > 0, "Leapfrog step is not positive"
+        assert nleaps > 0, "Number of leapfrog steps is not positive"
+        self.leapstep, self.nleaps = float(leapstep), int(nleaps)
+
+
+class SliceSampler(MCSampler):
+    """SliceSampler(widths, stepout=true) / SliceSampler(width=1., n=1, stepout=true) — SliceSampler.jl:22-34."""
+    kind = L.SAMPLER_SLICE
+
+    def __init__(self, widths=1.0, n: Optional[int] = None, stepout: bool = True):
+        if np.ndim(widths) == 0:
+            widths = np.full(int(n) if n is not None else 1, float(widths))
+        self.widths = np.asarray(widths, dtype=np.float64).copy()
+        assert np.all(self.widths > 0), "All widths must be positive"
+        self.stepout = bool(stepout)
+
+
+# ------------------------------------------------------------------ tuners (src/tuners/*.jl)
+class MCTuner:
+    pass
+
+
+class VanillaMCTuner(MCTuner):
+    """VanillaMCTuner(period=100, verbose=false) — VanillaMCTuner.jl; defaults test/VanillaMCTuner.jl:6-9."""
+    kind = L.TUNER_VANILLA
+
+    def __init__(self, period: int = 100, verbose: bool = False):
+        assert period > 0, "Tuning period should be positive"
+        self.period, self.verbose = int(period), bool(verbose)
+
+
+def logistic(x, l=1.0, k=1.0, x0=0.0, y0=0.0):
+    """stats/logistic.jl:11 (host convenience; the device uses its own deterministic exp)."""
+    return l / (1.0 + np.exp(-k * (x - x0))) + y0
+
+
+def logistic_rate_score(x, k=7.0):
+    """AcceptanceRateMCTuner.jl:9."""
+    return logistic(x, 2.0, k, 0.0, 0.0)
+
+
+class AcceptanceRateMCTuner(MCTuner):
+    """AcceptanceRateMCTuner(targetrate; score=logistic_rate_score, period=100, verbose=false) — :38-44.
+
+    `mode="per_chain"` keeps the reference's one-tune-per-job semantics; `mode="pooled"` shares one step
+    per GPU with the acceptance rate pooled over that GPU's chains (BASELINE cfg 5).
+    Only the logistic score runs on device; `score_k` is its steepness (default 7).
+    """
+    kind = L.TUNER_ACCEPT_RATE
+
+    def __init__(self, targetrate: float, score=logistic_rate_score, period: int = 100, verbose: bool = False,
+                 score_k: float = 7.0, mode: str = "per_chain"):
+        assert 0 < targetrate < 1, "Target acceptance rate should be between 0 and 1"
+        assert period > 0, "Tuning period should be positive"
+        if score is not logistic_rate_score:
+            raise NotImplementedError("only logistic_rate_score is available on device (erf_rate_score: next round)")
+        assert mode in ("per_chain", "pooled")
+        self.targetrate, self.period, self.verbose = float(targetrate), int(period), bool(verbose)
+        self.score_k, self.mode = float(score_k), mode
+
+
+# ------------------------------------------------------------------ parameter / model
+class BasicContMuvParameter:
+    """BasicContMuvParameter(key; logtarget=...) — BasicContMuvParameter.jl:383-411.
+
+    `logtarget` is a device target family; for LogisticTarget it plays the role of
+    loglikelihood+logprior+gradlogtarget of doc/examples/swiss/MALA/analytical.jl:20-26.
+    """
+
+    def __init__(self, key: str, logtarget=None, **unsupported):
+        if logtarget is None:
+            raise ValueError("logtarget (a target family object) is required")
+        if unsupported:
+            raise NotImplementedError(f"closure fields not available on device: {sorted(unsupported)}")
+        if not isinstance(logtarget, (GaussDiagTarget, GaussDenseTarget, LogisticTarget)):
+            raise TypeError("logtarget must be GaussDiagTarget, GaussDenseTarget or LogisticTarget")
+        self.key = str(key).lstrip(":")
+        self.target = logtarget
+
+
+@dataclass
+class GenericModel:
+    """Just enough of src/models/GenericModel.jl to route v0[key] to the parameter (BasicMCJob.jl:156-185)."""
+    vertices: list
+    ofkey: Dict[str, int] = field(default_factory=dict)
+
+
+def likelihood_model(p, isindexed: bool = True) -> GenericModel:
+    """likelihood_model(vs, isindexed) — src/models/generators.jl:5-18 (single-parameter form)."""
+    vs = list(p) if isinstance(p, (list, tuple)) else [p]
+    return GenericModel(vs, {v.key: i for i, v in enumerate(vs) if hasattr(v, "key")})
+
+
+# ------------------------------------------------------------------ chain container
+class MuvChains:
+    """Output of a job: the BasicContMuvParameterNState of every chain
+    (src/nstates/ParameterNStates/BasicContMuvParameterNState.jl:1-21).
+
+    value(c)            (ndims x n) column-major matrix of chain c (requires :value monitored)
+    diagnosticvalues    (nsaved_steps x nchains) accept flags over the postrange when :accept requested
+    """
+
+    def __init__(self, job: "BasicMCJob"):
+        self._job = job
+        eng = job.engine
+        self.size, self.nchains = eng.ndims, eng.nchains
+        self.n = job.range.npoststeps
+        self.diagnostickeys = list(job.outopts.get("diagnostics", []))
+        self._sums = eng.chain_sums() if eng.monitor & L.MON_SUMMARIES else None
+        self._acc = None
+        if eng.monitor & L.MON_ACCEPT:
+            m = eng.accept_mask()
+            post = np.asarray(job.range.postrange) - 1
+            self._acc = m[post[post < m.shape[0]]]
+
+    def value(self, chain: int = 0) -> np.ndarray:
+        return self._job.engine.chain(chain)
+
+    @property
+    def diagnosticvalues(self):
+        return self._acc
+
+
+def mean(chains: MuvChains, chain: Optional[int] = None) -> np.ndarray:
+    """mean(s::VariableNState{Multivariate}) — stats/mean.jl:7-11: per-dimension mean over saved steps.
+    chain=None returns (nchains x D) from the on-device running sums; chain=c reads that chain's history."""
+    if chain is not None and chains._sums is None:
+        return chains.value(chain).mean(axis=1)
+    s, _, n = chains._sums
+    m = s / n
+    return m if chain is None else m[chain]
+
+
+def mcvar_iid(chains: MuvChains) -> np.ndarray:
+    """mcvar(s, Val{:iid}) = var(v)/length(v) — stats/variance/mcvar.jl:5 (per chain, per dimension)."""
+    s, q, n = chains._sums
+    var = (q - s * s / n) / (n - 1)
+    return var / n
+
+
+def acceptance(chains: MuvChains, diagnostics: bool = True) -> np.ndarray:
+    """acceptance(s::MultivariateParameterNState; key=:accept) — stats/acceptance.jl:28-34:
+    mean of the accept diagnostics over the saved steps (per chain)."""
+    if chains._acc is None:
+        raise ValueError("request outopts diagnostics=['accept'] to record the accept diagnostics")
+    return chains._acc.mean(axis=0)
+
+
+# ------------------------------------------------------------------ job (src/jobs/BasicMCJob.jl)
+class BasicMCJob:
+    """BasicMCJob(model, sampler, range, v0; tuner=VanillaMCTuner(), outopts=...) — BasicMCJob.jl:107-185.
+
+    outopts keys follow jobs.jl:9-43: destination in {"nstate", "none"}, monitor (["value"]),
+    diagnostics ([] or ["accept"]).  Extra keyword arguments pick the shard: `chain_offset` (global id of
+    the first chain), `device`, `seed`, `steps_per_launch`.
+    """
+
+    def __init__(self, model: GenericModel, sampler: MCSampler, mcrange: BasicMCRange, v0: Dict[str, Sequence],
+                 tuner: Optional[MCTuner] = None, outopts: Optional[dict] = None, *, seed: int = 20260927,
+                 chain_offset: int = 0, device: int = 0, steps_per_launch: int = 0, summaries: bool = True):
+        self.model, self.sampler, self.range = model, sampler, mcrange
+        self.tuner = tuner if tuner is not None else VanillaMCTuner()
+        self.outopts = dict(outopts) if outopts is not None else {}
+        self.outopts.setdefault("destination", "nstate")              # jobs.jl:10
+        if self.outopts["destination"] != "none":
+            self.outopts.setdefault("monitor", ["value"])             # jobs.jl:13-15
+            self.outopts.setdefault("diagnostics", [])                # jobs.jl:37-39
+        if self.outopts["destination"] not in ("nstate", "none"):
+            raise NotImplementedError(":iostream destination is out of scope this round (SURVEY §8(f)4)")
+        params = [v for v in model.vertices if isinstance(v, BasicContMuvParameter)]
+        if len(params) != 1:
+            raise ValueError("model must hold exactly one BasicContMuvParameter")
+        self.parameter = params[0]
+        x0 = np.asarray(v0[self.parameter.key] if self.parameter.key in v0 else v0[":" + self.parameter.key],
+                        dtype=np.float64)
+        x0 = np.atleast_2d(x0)
+        nchains, ndims = x0.shape
+        if ndims != self.parameter.target.ndims:
+            raise ValueError("v0 has the wrong number of dimensions for the target")
+        monitor = 0
+        if "accept" in self.outopts.get("diagnostics", []):
+            monitor |= L.MON_ACCEPT
+        if self.outopts["destination"] == "nstate" and "value" in self.outopts.get("monitor", []):
+            monitor |= L.MON_HISTORY
+        if summaries:
+            monitor |= L.MON_SUMMARIES
+        kw = dict(sampler=sampler.kind, target=self.parameter.target, nchains=nchains, nsteps=mcrange.nsteps,
+                  burnin=mcrange.burnin, thinning=mcrange.thinning, tuner=self.tuner.kind,
+                  period=self.tuner.period, verbose=self.tuner.verbose, seed=seed, chain_offset=chain_offset,
+                  device=device, monitor=monitor, steps_per_launch=steps_per_launch)
+        if isinstance(sampler, MH):
+            kw["mh_sigma"] = sampler.sigma
+        elif isinstance(sampler, MALA):
+            kw["driftstep"] = sampler.driftstep
+        elif isinstance(sampler, HMC):
+            kw["leapstep"], kw["nleaps"] = sampler.leapstep, sampler.nleaps
+        elif isinstance(sampler, SliceSampler):
+            kw["slice_widths"], kw["slice_stepout"] = sampler.widths, sampler.stepout
+        if isinstance(self.tuner, AcceptanceRateMCTuner):
+            kw["targetrate"], kw["score_k"] = self.tuner.targetrate, self.tuner.score_k
+            kw["tuner_mode"] = L.TUNE_POOLED if self.tuner.mode == "pooled" else L.TUNE_PER_CHAIN
+        self.engine = Engine(**kw)
+        # initialize!(pstate, parameter, sampler, outopts): BasicMCJob.jl:73 (finite asserts on device)
+        try:
+            self.engine.set_state(x0)
+        except L.KlaraError as e:
+            if e.status == L.ERR_NONFINITE_INIT:
+                raise AssertionError("Log-target (or its gradient) not finite: initial values out of support") from e
+            raise
+        self._ran = False
+
+    def close(self):
+        self.engine.close()
+
+
+def run(job):
+    """run(job::BasicMCJob) — BasicMCJob.jl:212-244; run(jobs::Vector) = map(run, jobs) — jobs.jl:212."""
+    if isinstance(job, (list, tuple)):
+        return [run(j) for j in job]
+    job.engine.run(job.range.nsteps)
+    job._ran = True
+    return job
+
+
+def output(job: BasicMCJob) -> MuvChains:
+    """output(job) — BasicMCJob.jl:279."""
+    return MuvChains(job)
+
+
+def reset(job: BasicMCJob, x=None):
+    """reset(job[, x]) — BasicMCJob.jl:187-201."""
+    if x is not None:
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    job.engine.reset(x)
+    job._ran = False
+    return job

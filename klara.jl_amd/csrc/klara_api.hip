@@ -1,0 +1,727 @@
+// klara_api.hip — host side of libklara_hip.so: handle management, validation, launches, read-back.
+// The ABI and the reference lines each entry point replaces are documented in include/klara_hip.h.
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_kernel.h>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "klara_launch.h"
+
+#define HIPCHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess) return (e__ == hipErrorOutOfMemory) ? KLARA_ERR_NOMEM : KLARA_ERR_HIP; \
+    } while (0)
+
+struct klara_handle {
+    klara_desc d;
+    // layout
+    int kind, G, E;            // kind 0: group layout (G lanes x E elems); kind 1: MFMA (E = NE)
+    // owned copies of host parameter vectors
+    std::vector<double> h_vec;
+    // device buffers
+    double *X = nullptr, *GR = nullptr, *LT = nullptr;
+    double* tune_step = nullptr;
+    long long *tune_acc = nullptr, *tune_prop = nullptr, *tune_tot = nullptr;
+    unsigned long long* pooled_acc = nullptr;
+    uint8_t* accept = nullptr; long long accept_cap = 0;
+    unsigned long long* naccept = nullptr;
+    double *sum = nullptr, *sumsq = nullptr;
+    double* hist = nullptr; long long hist_cols = 0;
+    int* err = nullptr;
+    double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr;
+    double* pooled_out = nullptr;   // 2*D doubles + 1 u64 scratch for pooled summaries
+    double lpconst = 0.0;
+    // run state
+    bool have_state = false;
+    long long steps_done = 0;       // transitions since set_state/reset (= global transition index)
+    long long nsaved = 0;           // postrange steps passed so far
+    // host mirror of the pooled tuner counters (decides where launches must end)
+    long long m_prop = 0, m_tot = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; long long last_launches = 0; bool timed = false;
+};
+
+static int cnt_predicate(const klara_desc& d)
+{
+    if (d.sampler == KLARA_SAMPLER_MH || d.sampler == KLARA_SAMPLER_SLICE) return d.verbose != 0;
+    return (d.tuner == KLARA_TUNER_VANILLA && d.verbose) || d.tuner == KLARA_TUNER_ACCEPT_RATE;
+}
+
+static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E)
+{
+    const int D = d.ndims;
+    if (d.target == KLARA_TARGET_GAUSS_DENSE) {
+        *kind = 1; *G = 4;
+        if (D <= 32) *E = 8; else if (D <= 64) *E = 16; else if (D <= 100) *E = 25; else if (D <= 128) *E = 32;
+        else return KLARA_ERR_UNSUPPORTED;
+        return KLARA_OK;
+    }
+    *kind = 0;
+    if (d.target == KLARA_TARGET_LOGISTIC) {
+        *G = 1;
+        if (D <= 2) *E = 2; else if (D <= 4) *E = 4; else if (D <= 8) *E = 8; else return KLARA_ERR_UNSUPPORTED;
+        return KLARA_OK;
+    }
+    // diagonal Gaussian: E elements per lane, G lanes; optional override for layout experiments
+    int e = (D <= 128) ? 2 : (D <= 256) ? 4 : (D <= 512) ? 8 : 0;
+    if (const char* s = getenv("KLARA_LAYOUT_E")) {
+        const int v = atoi(s);
+        if ((v == 2 || v == 4 || v == 8) && (D + v - 1) / v <= 64) e = v;
+    }
+    if (e == 0) return KLARA_ERR_UNSUPPORTED;
+    *E = e; *G = pow2ceil((D + e - 1) / e);
+    return KLARA_OK;
+}
+
+static klara_status validate(const klara_desc* d)
+{
+    if (!d) return KLARA_ERR_INVALID_ARG;
+    if (d->struct_size != sizeof(klara_desc) || d->abi_version != KLARA_ABI_VERSION) return KLARA_ERR_INVALID_ARG;
+    if (d->nchains <= 0 || d->ndims <= 0 || d->chain_offset < 0) return KLARA_ERR_INVALID_ARG;
+    if (d->sampler < KLARA_SAMPLER_MH || d->sampler > KLARA_SAMPLER_SLICE) return KLARA_ERR_INVALID_ARG;
+    if (d->target < KLARA_TARGET_GAUSS_DIAG || d->target > KLARA_TARGET_LOGISTIC) return KLARA_ERR_INVALID_ARG;
+    if (d->tuner != KLARA_TUNER_VANILLA && d->tuner != KLARA_TUNER_ACCEPT_RATE) return KLARA_ERR_INVALID_ARG;
+    if (d->tuner_mode != KLARA_TUNE_PER_CHAIN && d->tuner_mode != KLARA_TUNE_POOLED) return KLARA_ERR_INVALID_ARG;
+    // BasicMCRange.jl:22-24
+    if (d->burnin < 0 || d->thinning < 1 || d->nsteps <= d->burnin) return KLARA_ERR_INVALID_ARG;
+    // VanillaMCTuner / AcceptanceRateMCTuner.jl:32-33
+    if (d->period <= 0) return KLARA_ERR_INVALID_ARG;
+    if (d->tuner == KLARA_TUNER_ACCEPT_RATE && !(d->targetrate > 0.0 && d->targetrate < 1.0)) return KLARA_ERR_INVALID_ARG;
+    switch (d->sampler) {
+    case KLARA_SAMPLER_MH:
+        if (!d->mh_sigma) return KLARA_ERR_INVALID_ARG;
+        for (int i = 0; i < d->ndims; ++i) if (!(d->mh_sigma[i] > 0.0)) return KLARA_ERR_INVALID_ARG;
+        break;
+    case KLARA_SAMPLER_MALA:                                     // MALA.jl:65
+        if (!(d->driftstep > 0.0)) return KLARA_ERR_INVALID_ARG;
+        break;
+    case KLARA_SAMPLER_HMC:                                      // HMC.jl:94-95
+        if (!(d->leapstep > 0.0) || d->nleaps <= 0) return KLARA_ERR_INVALID_ARG;
+        break;
+    default:                                                     // SliceSampler.jl:27
+        if (!d->slice_widths) return KLARA_ERR_INVALID_ARG;
+        for (int i = 0; i < d->ndims; ++i) if (!(d->slice_widths[i] > 0.0)) return KLARA_ERR_INVALID_ARG;
+        break;
+    }
+    if (d->target == KLARA_TARGET_GAUSS_DENSE && !d->gauss_prec) return KLARA_ERR_INVALID_ARG;
+    if (d->target == KLARA_TARGET_LOGISTIC &&
+        (!d->logit_X || !d->logit_y || d->logit_ndata <= 0 || !(d->logit_lambda > 0.0)))
+        return KLARA_ERR_INVALID_ARG;
+    if (d->steps_per_launch < 0) return KLARA_ERR_INVALID_ARG;
+    return KLARA_OK;
+}
+
+template <class T>
+static hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
+
+static klara_status upload(double** dst, const double* src, size_t n)
+{
+    HIPCHK(dalloc(dst, n));
+    HIPCHK(hipMemcpy(*dst, src, n * sizeof(double), hipMemcpyHostToDevice));
+    return KLARA_OK;
+}
+
+static void free_all(klara_handle* h)
+{
+    hipFree(h->X); hipFree(h->GR); hipFree(h->LT); hipFree(h->tune_step); hipFree(h->tune_acc);
+    hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->pooled_acc); hipFree(h->accept);
+    hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->hist); hipFree(h->err);
+    hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly);
+    hipFree(h->Pfrag); hipFree(h->pooled_out);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+}
+
+extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
+{
+    if (!out) return KLARA_ERR_INVALID_ARG;
+    *out = nullptr;
+    klara_status st = validate(desc);
+    if (st != KLARA_OK) return st;
+    int kind, G, E;
+    st = select_layout(*desc, &kind, &G, &E);
+    if (st != KLARA_OK) return st;
+    if (desc->target == KLARA_TARGET_GAUSS_DENSE &&
+        (desc->sampler == KLARA_SAMPLER_SLICE || desc->gauss_mu != nullptr))
+        return KLARA_ERR_UNSUPPORTED;
+    if (desc->tuner_mode == KLARA_TUNE_POOLED && desc->sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || desc->device < 0 || desc->device >= ndev)
+        return KLARA_ERR_HIP;
+    HIPCHK(hipSetDevice(desc->device));
+
+    klara_handle* h = new (std::nothrow) klara_handle();
+    if (!h) return KLARA_ERR_NOMEM;
+    h->d = *desc; h->kind = kind; h->G = G; h->E = E;
+    const size_t N = (size_t)desc->nchains, D = (size_t)desc->ndims;
+    const bool pooled = desc->tuner_mode == KLARA_TUNE_POOLED;
+    const size_t NT = pooled ? 1 : N;
+
+#define CK(call) do { klara_status s__ = (call); if (s__ != KLARA_OK) { free_all(h); delete h; return s__; } } while (0)
+#define CKH(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { free_all(h); delete h; \
+        return e__ == hipErrorOutOfMemory ? KLARA_ERR_NOMEM : KLARA_ERR_HIP; } } while (0)
+
+    if (desc->stream) { h->stream = (hipStream_t)desc->stream; h->own_stream = false; }
+    else { CKH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    CKH(hipEventCreate(&h->ev0)); CKH(hipEventCreate(&h->ev1));
+
+    CKH(dalloc(&h->X, N * D)); CKH(dalloc(&h->GR, N * D)); CKH(dalloc(&h->LT, N));
+    CKH(dalloc(&h->tune_step, NT)); CKH(dalloc(&h->tune_acc, NT)); CKH(dalloc(&h->tune_prop, NT));
+    CKH(dalloc(&h->tune_tot, NT)); CKH(dalloc(&h->pooled_acc, 1)); CKH(dalloc(&h->naccept, N));
+    CKH(dalloc(&h->err, 1)); CKH(dalloc(&h->pooled_out, 2 * D + 2));
+    CKH(hipMemset(h->err, 0, sizeof(int)));
+    if (desc->monitor & KLARA_MON_SUMMARIES) { CKH(dalloc(&h->sum, N * D)); CKH(dalloc(&h->sumsq, N * D)); }
+    if (desc->monitor & KLARA_MON_ACCEPT) {
+        h->accept_cap = desc->nsteps;
+        CKH(dalloc(&h->accept, (size_t)desc->nsteps * N));
+    }
+    if (desc->monitor & KLARA_MON_HISTORY) {
+        // npoststeps = length((burnin+1):thinning:nsteps)  (BasicMCRange.jl:26)
+        h->hist_cols = (desc->nsteps - desc->burnin - 1) / desc->thinning + 1;
+        CKH(dalloc(&h->hist, (size_t)h->hist_cols * N * D));
+    }
+    if (desc->sampler == KLARA_SAMPLER_MH) CK(upload(&h->vecparam, desc->mh_sigma, D));
+    if (desc->sampler == KLARA_SAMPLER_SLICE) CK(upload(&h->vecparam, desc->slice_widths, D));
+    if (desc->target == KLARA_TARGET_GAUSS_DIAG) {
+        if (desc->gauss_w) CK(upload(&h->gw, desc->gauss_w, D));
+        if (desc->gauss_mu) CK(upload(&h->gmu, desc->gauss_mu, D));
+    } else if (desc->target == KLARA_TARGET_LOGISTIC) {
+        CK(upload(&h->lX, desc->logit_X, (size_t)desc->logit_ndata * D));
+        CK(upload(&h->ly, desc->logit_y, (size_t)desc->logit_ndata));
+        // length(p)*log(2*pi*v[1])  (doc/examples/swiss/MALA/analytical.jl:16)
+        h->lpconst = (double)desc->ndims * kd_log(2.0 * 3.141592653589793 * desc->logit_lambda);
+    } else {
+        // fragment-ordered, zero-padded P for the MFMA A operand (klara_dense.h)
+        const int NE = E, MT = (NE + 3) / 4;
+        std::vector<double> frag((size_t)MT * NE * 64, 0.0);
+        for (int t = 0; t < MT; ++t)
+            for (int kk = 0; kk < NE; ++kk)
+                for (int l = 0; l < 64; ++l) {
+                    const size_t row = 16 * (size_t)t + (l & 15), col = 4 * (size_t)kk + (l >> 4);
+                    if (row < D && col < D) frag[((size_t)t * NE + kk) * 64 + l] = desc->gauss_prec[row * D + col];
+                }
+        CK(upload(&h->Pfrag, frag.data(), frag.size()));
+    }
+    // the descriptor's host pointers are not retained
+    h->d.mh_sigma = nullptr; h->d.slice_widths = nullptr; h->d.gauss_w = nullptr; h->d.gauss_mu = nullptr;
+    h->d.gauss_prec = nullptr; h->d.logit_X = nullptr; h->d.logit_y = nullptr; h->d.stream = nullptr;
+#undef CK
+#undef CKH
+    *out = h;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_destroy(klara_handle* h)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    hipSetDevice(h->d.device);
+    hipStreamSynchronize(h->stream);
+    free_all(h);
+    delete h;
+    return KLARA_OK;
+}
+
+static KParams make_params(klara_handle* h)
+{
+    KParams p;
+    memset(&p, 0, sizeof(p));
+    const klara_desc& d = h->d;
+    p.X = h->X; p.GR = h->GR; p.LT = h->LT;
+    p.tune_step = h->tune_step; p.tune_accepted = h->tune_acc; p.tune_proposed = h->tune_prop;
+    p.tune_totproposed = h->tune_tot; p.pooled_accepted = h->pooled_acc;
+    p.accept = nullptr; p.naccept = h->naccept; p.sum = h->sum; p.sumsq = h->sumsq;
+    p.hist = h->hist; p.hist_cols = h->hist_cols; p.error_flag = h->err;
+    p.nchains = d.nchains; p.chain_offset = d.chain_offset; p.D = d.ndims; p.G = h->G;
+    p.pooled = d.tuner_mode == KLARA_TUNE_POOLED;
+    p.seed = d.seed; p.t0 = 0; p.nsteps = 0;
+    p.vecparam = h->vecparam; p.nleaps = d.nleaps; p.stepout = d.slice_stepout;
+    p.tuner = d.tuner; p.cnt = cnt_predicate(d); p.targetrate = d.targetrate;
+    p.score_k = d.score_k; p.period = d.period; p.is_mh = d.sampler == KLARA_SAMPLER_MH;
+    p.burnin = d.burnin; p.thinning = d.thinning; p.nsteps_total = d.nsteps;
+    p.gw = h->gw; p.gmu = h->gmu; p.gconst = d.gauss_const;
+    p.lX = h->lX; p.ly = h->ly; p.ndata = d.logit_ndata; p.lambda = d.logit_lambda; p.lpconst = h->lpconst;
+    return p;
+}
+
+static dim3 grid_for(const klara_handle* h)
+{
+    const long long cpw = h->kind == 1 ? 16 : 64 / h->G;
+    const long long waves = (h->d.nchains + cpw - 1) / cpw;
+    const long long wpb = h->kind == 1 ? 8 : 4;
+    return dim3((unsigned)((waves + wpb - 1) / wpb));
+}
+
+static size_t lds_for(const klara_handle* h)
+{
+    if (h->kind == 0 && h->d.target == KLARA_TARGET_LOGISTIC)
+        return sizeof(double) * (size_t)h->d.logit_ndata * (size_t)(h->d.ndims + 1);
+    return 0;
+}
+
+// ---- init kernels (group layout) instantiated here
+template <int TARGET>
+static hipError_t launch_init_t(const KParams& p, int E, int G, int needgrad, dim3 grid, size_t lds, hipStream_t st)
+{
+    const dim3 blk(256);
+    if (E == 2 && G == 64 && TARGET == KLARA_TARGET_GAUSS_DIAG) hipLaunchKernelGGL((k_init<TARGET, 2, 64>), grid, blk, lds, st, p, needgrad);
+    else if (E == 2) hipLaunchKernelGGL((k_init<TARGET, 2, 0>), grid, blk, lds, st, p, needgrad);
+    else if (E == 4) hipLaunchKernelGGL((k_init<TARGET, 4, 0>), grid, blk, lds, st, p, needgrad);
+    else if (E == 8) hipLaunchKernelGGL((k_init<TARGET, 8, 0>), grid, blk, lds, st, p, needgrad);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+__global__ void k_fill_tune(double* step, long long* acc, long long* prop, long long* tot, long long n,
+                            double step0, long long period)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { step[i] = step0; acc[i] = 0; prop[i] = 0; tot[i] = period; }
+}
+
+// pooled tuner update after a launch of `k` transitions: tuners.jl:27-32, AcceptanceRateMCTuner.jl:46
+// with the rate pooled over the GPU's chains (KLARA_TUNE_POOLED; SURVEY §7 hard part 5).
+__global__ void k_pooled_tune(KParams p, int k)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!p.cnt) return;
+    long long prop = p.tune_proposed[0] + k;
+    long long acc = p.tune_accepted[0] + (long long)(*p.pooled_accepted);
+    long long tot = p.tune_totproposed[0];
+    double step = p.tune_step[0];
+    *p.pooled_accepted = 0ull;
+    if (tot <= p.burnin && (prop % p.period) == 0) {
+        const double rate = (double)acc / (double)(prop * p.nchains);
+        if (p.tuner == KLARA_TUNER_ACCEPT_RATE && !p.is_mh) {
+            const double xr = rate - p.targetrate;
+            step *= 2.0 / (1.0 + kd_exp(-p.score_k * (xr - 0.0))) + 0.0;
+        }
+        tot += prop; acc = 0; prop = 0;
+    }
+    p.tune_step[0] = step; p.tune_accepted[0] = acc; p.tune_proposed[0] = prop; p.tune_totproposed[0] = tot;
+}
+
+static klara_status init_common(klara_handle* h)
+{
+    const klara_desc& d = h->d;
+    const size_t N = (size_t)d.nchains, D = (size_t)d.ndims;
+    const bool pooled = d.tuner_mode == KLARA_TUNE_POOLED;
+    const long long NT = pooled ? 1 : (long long)N;
+    hipStream_t st = h->stream;
+    HIPCHK(hipMemsetAsync(h->err, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(h->naccept, 0, N * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(h->pooled_acc, 0, sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(h->GR, 0, N * D * sizeof(double), st));
+    if (h->sum) { HIPCHK(hipMemsetAsync(h->sum, 0, N * D * sizeof(double), st)); HIPCHK(hipMemsetAsync(h->sumsq, 0, N * D * sizeof(double), st)); }
+    // tuner_state: samplers.jl:29-45 — step per sampler, accepted = proposed = 0, totproposed = period
+    const double step0 = d.sampler == KLARA_SAMPLER_MH ? 1.0
+                       : d.sampler == KLARA_SAMPLER_MALA ? d.driftstep
+                       : d.sampler == KLARA_SAMPLER_HMC ? d.leapstep : (double)NAN;
+    hipLaunchKernelGGL(k_fill_tune, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, st, h->tune_step,
+                       h->tune_acc, h->tune_prop, h->tune_tot, NT, step0, (long long)d.period);
+    HIPCHK(hipGetLastError());
+    const int needgrad = d.sampler == KLARA_SAMPLER_MALA || d.sampler == KLARA_SAMPLER_HMC;
+    KParams p = make_params(h);
+    hipError_t e;
+    if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, needgrad, grid_for(h), st);
+    else if (d.target == KLARA_TARGET_GAUSS_DIAG)
+        e = launch_init_t<KLARA_TARGET_GAUSS_DIAG>(p, h->E, h->G, needgrad, grid_for(h), lds_for(h), st);
+    else e = launch_init_t<KLARA_TARGET_LOGISTIC>(p, h->E, h->G, needgrad, grid_for(h), lds_for(h), st);
+    HIPCHK(e);
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, h->err, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    h->steps_done = 0; h->nsaved = 0; h->m_prop = 0; h->m_tot = d.period; h->timed = false;
+    if (flag != 0) { h->have_state = false; return (klara_status)flag; }
+    h->have_state = true;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_set_state(klara_handle* h, const double* x_host)
+{
+    if (!h || !x_host) return KLARA_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->d.device));
+    const size_t n = (size_t)h->d.nchains * (size_t)h->d.ndims;
+    HIPCHK(hipMemcpyAsync(h->X, x_host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return init_common(h);
+}
+
+extern "C" klara_status klara_init_state_normal(klara_handle* h)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->d.device));
+    // drawn with the E=2 group layout irrespective of the sampling layout (the stream is layout-free)
+    KParams p = make_params(h);
+    const int D = h->d.ndims;
+    if (D > 128) {
+        // TODO(round 2): device init for D > 128; host fallback is not allowed in the product path
+        return KLARA_ERR_UNSUPPORTED;
+    }
+    const int G = pow2ceil((D + 1) / 2);
+    p.G = G;
+    const long long cpw = 64 / G, waves = (h->d.nchains + cpw - 1) / cpw;
+    hipLaunchKernelGGL((k_init_normal<2, 0>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, h->stream, p);
+    HIPCHK(hipGetLastError());
+    return init_common(h);
+}
+
+extern "C" klara_status klara_reset(klara_handle* h, const double* x_host)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (x_host) return klara_set_state(h, x_host);
+    if (!h->have_state) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    return init_common(h);
+}
+
+static hipError_t launch_steps(klara_handle* h, const KParams& p)
+{
+    const klara_desc& d = h->d;
+    if (h->kind == 1) return klara_launch_dense(p, d.sampler, h->E, h->Pfrag, grid_for(h), h->stream);
+    switch (d.sampler) {
+    case KLARA_SAMPLER_MH: return klara_launch_mh(p, d.target, h->E, h->G, grid_for(h), lds_for(h), h->stream);
+    case KLARA_SAMPLER_MALA: return klara_launch_mala(p, d.target, h->E, h->G, grid_for(h), lds_for(h), h->stream);
+    case KLARA_SAMPLER_HMC: return klara_launch_hmc(p, d.target, h->E, h->G, grid_for(h), lds_for(h), h->stream);
+    default: return klara_launch_slice(p, d.target, h->E, h->G, grid_for(h), lds_for(h), h->stream);
+    }
+}
+
+extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
+{
+    if (!h || nsteps < 0) return KLARA_ERR_INVALID_ARG;
+    if (!h->have_state) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    const klara_desc& d = h->d;
+    if ((d.monitor & KLARA_MON_ACCEPT) && h->steps_done + nsteps > h->accept_cap) return KLARA_ERR_STATE;
+    const bool pooled = d.tuner_mode == KLARA_TUNE_POOLED;
+    const int cnt = cnt_predicate(d);
+    long long spl = d.steps_per_launch > 0 ? d.steps_per_launch : 16;
+    KParams p = make_params(h);
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    long long remaining = nsteps, launches = 0;
+    while (remaining > 0) {
+        long long k = remaining < spl ? remaining : spl;
+        if (pooled && cnt && h->m_tot <= d.burnin) {
+            const long long to_boundary = d.period - (h->m_prop % d.period);
+            if (k > to_boundary) k = to_boundary;
+        }
+        p.t0 = (unsigned long long)h->steps_done;
+        p.nsteps = (int)k;
+        p.accept = h->accept ? h->accept + (size_t)h->steps_done * (size_t)d.nchains : nullptr;
+        HIPCHK(launch_steps(h, p));
+        if (pooled && cnt) {
+            hipLaunchKernelGGL(k_pooled_tune, dim3(1), dim3(64), 0, h->stream, p, (int)k);
+            HIPCHK(hipGetLastError());
+            h->m_prop += k;
+            if (h->m_tot <= d.burnin && (h->m_prop % d.period) == 0) { h->m_tot += h->m_prop; h->m_prop = 0; }
+        }
+        h->steps_done += k; remaining -= k; ++launches;
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->last_launches = launches; h->timed = true;
+    // saved-sample bookkeeping: count of i in postrange with i <= steps_done
+    const long long sd = h->steps_done < d.nsteps ? h->steps_done : d.nsteps;
+    h->nsaved = sd > d.burnin ? (sd - d.burnin - 1) / d.thinning + 1 : 0;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_synchronize(klara_handle* h)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->d.device));
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, h->err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (flag != 0) return (klara_status)flag;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_run(klara_handle* h, int64_t nsteps)
+{
+    klara_status s = klara_run_async(h, nsteps);
+    if (s != KLARA_OK) return s;
+    return klara_synchronize(h);
+}
+
+extern "C" klara_status klara_last_run_ms(klara_handle* h, double* kernel_ms, int64_t* nlaunches)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->timed) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (kernel_ms) *kernel_ms = (double)ms;
+    if (nlaunches) *nlaunches = h->last_launches;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_state(klara_handle* h, double* x, double* logtarget, double* gradlogtarget)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->have_state) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    const size_t N = (size_t)h->d.nchains, D = (size_t)h->d.ndims;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (x) HIPCHK(hipMemcpy(x, h->X, N * D * sizeof(double), hipMemcpyDeviceToHost));
+    if (logtarget) HIPCHK(hipMemcpy(logtarget, h->LT, N * sizeof(double), hipMemcpyDeviceToHost));
+    if (gradlogtarget) HIPCHK(hipMemcpy(gradlogtarget, h->GR, N * D * sizeof(double), hipMemcpyDeviceToHost));
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_accept_mask(klara_handle* h, uint8_t* mask, int64_t capacity_steps,
+                                              int64_t* nsteps_out)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->accept) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const long long n = h->steps_done < capacity_steps ? h->steps_done : capacity_steps;
+    if (mask && n > 0) HIPCHK(hipMemcpy(mask, h->accept, (size_t)n * (size_t)h->d.nchains, hipMemcpyDeviceToHost));
+    if (nsteps_out) *nsteps_out = h->steps_done;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_accept_counts(klara_handle* h, uint64_t* naccept, uint64_t* nsteps_out)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->have_state) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (naccept) HIPCHK(hipMemcpy(naccept, h->naccept, (size_t)h->d.nchains * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (nsteps_out) *nsteps_out = (uint64_t)h->steps_done;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_chain_sums(klara_handle* h, double* sum, double* sumsq, int64_t* nsaved_out)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->sum || !h->have_state) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->d.nchains * (size_t)h->d.ndims;
+    if (sum) HIPCHK(hipMemcpy(sum, h->sum, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (sumsq) HIPCHK(hipMemcpy(sumsq, h->sumsq, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (nsaved_out) *nsaved_out = h->nsaved;
+    return KLARA_OK;
+}
+
+// pooled (over chains) per-dimension sums: one block per dimension, fixed-shape tree => deterministic
+__global__ __launch_bounds__(256) void k_pool_sums(const double* sum, const double* sumsq, long long N, int D,
+                                                   double* out)
+{
+    __shared__ double s1[256], s2[256];
+    const int d = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (long long c = threadIdx.x; c < N; c += 256) { a += sum[c * D + d]; b += sumsq[c * D + d]; }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) { s1[threadIdx.x] += s1[threadIdx.x + m]; s2[threadIdx.x] += s2[threadIdx.x + m]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[d] = s1[0]; out[D + d] = s2[0]; }
+}
+__global__ __launch_bounds__(256) void k_pool_accept(const unsigned long long* nacc, long long N,
+                                                     unsigned long long* out)
+{
+    __shared__ unsigned long long s[256];
+    unsigned long long a = 0;
+    for (long long c = threadIdx.x; c < N; c += 256) a += nacc[c];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) { if ((int)threadIdx.x < m) s[threadIdx.x] += s[threadIdx.x + m]; __syncthreads(); }
+    if (threadIdx.x == 0) *out = s[0];
+}
+
+extern "C" klara_status klara_get_pooled_summaries(klara_handle* h, double* sum, double* sumsq,
+                                                   uint64_t* naccept, uint64_t* ntransitions,
+                                                   int64_t* nsaved_out)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->have_state) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    const int D = h->d.ndims;
+    if (sum || sumsq) {
+        if (!h->sum) return KLARA_ERR_STATE;
+        hipLaunchKernelGGL(k_pool_sums, dim3(D), dim3(256), 0, h->stream, h->sum, h->sumsq,
+                           (long long)h->d.nchains, D, h->pooled_out);
+        HIPCHK(hipGetLastError());
+    }
+    unsigned long long* accout = reinterpret_cast<unsigned long long*>(h->pooled_out + 2 * D);
+    hipLaunchKernelGGL(k_pool_accept, dim3(1), dim3(256), 0, h->stream, h->naccept, (long long)h->d.nchains, accout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (sum) HIPCHK(hipMemcpy(sum, h->pooled_out, D * sizeof(double), hipMemcpyDeviceToHost));
+    if (sumsq) HIPCHK(hipMemcpy(sumsq, h->pooled_out + D, D * sizeof(double), hipMemcpyDeviceToHost));
+    if (naccept) HIPCHK(hipMemcpy(naccept, accout, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (ntransitions) *ntransitions = (uint64_t)h->steps_done * (uint64_t)h->d.nchains;
+    if (nsaved_out) *nsaved_out = h->nsaved;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_chain(klara_handle* h, int64_t local_chain, double* value,
+                                        int64_t capacity_cols, int64_t* ncols_out)
+{
+    if (!h || local_chain < 0 || local_chain >= h->d.nchains) return KLARA_ERR_INVALID_ARG;
+    if (!h->hist) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t N = (size_t)h->d.nchains, D = (size_t)h->d.ndims;
+    const long long n = h->nsaved < capacity_cols ? h->nsaved : capacity_cols;
+    // device layout [col][chain][D] -> Klara NState.value (D x n) column-major = n contiguous D-vectors
+    if (value && n > 0)
+        HIPCHK(hipMemcpy2D(value, D * sizeof(double), h->hist + (size_t)local_chain * D, N * D * sizeof(double),
+                           D * sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
+    if (ncols_out) *ncols_out = h->nsaved;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_tune(klara_handle* h, double* step, int64_t* accepted, int64_t* proposed,
+                                       int64_t* totproposed)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->have_state) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t N = (size_t)h->d.nchains;
+    if (h->d.tuner_mode == KLARA_TUNE_POOLED) {
+        double s; long long a, pr, t;
+        HIPCHK(hipMemcpy(&s, h->tune_step, sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&a, h->tune_acc, sizeof(long long), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&pr, h->tune_prop, sizeof(long long), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&t, h->tune_tot, sizeof(long long), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; ++i) {
+            if (step) step[i] = s;
+            if (accepted) accepted[i] = a;
+            if (proposed) proposed[i] = pr;
+            if (totproposed) totproposed[i] = t;
+        }
+        return KLARA_OK;
+    }
+    if (step) HIPCHK(hipMemcpy(step, h->tune_step, N * sizeof(double), hipMemcpyDeviceToHost));
+    if (accepted) HIPCHK(hipMemcpy(accepted, h->tune_acc, N * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (proposed) HIPCHK(hipMemcpy(proposed, h->tune_prop, N * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (totproposed) HIPCHK(hipMemcpy(totproposed, h->tune_tot, N * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_device_ptrs(klara_handle* h, void** x, void** logtarget, void** gradlogtarget)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (x) *x = h->X;
+    if (logtarget) *logtarget = h->LT;
+    if (gradlogtarget) *gradlogtarget = h->GR;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_layout(klara_handle* h, int32_t* kind, int32_t* lanes_per_chain,
+                                         int32_t* elems_per_lane)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (kind) *kind = h->kind;
+    if (lanes_per_chain) *lanes_per_chain = h->G;
+    if (elems_per_lane) *elems_per_lane = h->E;
+    return KLARA_OK;
+}
+
+// ---- self tests --------------------------------------------------------------------------------
+__global__ void k_rocrand_blocks(unsigned long long seed, unsigned long long subseq,
+                                 unsigned long long first_block, int nblocks, unsigned int* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(seed, subseq, 4ull * (first_block + (unsigned long long)i), &st);
+    const uint4 r = rocrand4(&st);
+    out[4 * i + 0] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+
+extern "C" klara_status klara_selftest_rocrand_blocks(int32_t device, uint64_t seed, uint64_t subsequence,
+                                                      uint64_t first_block, int32_t nblocks, uint32_t* out)
+{
+    if (!out || nblocks <= 0) return KLARA_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(device));
+    unsigned int* d = nullptr;
+    HIPCHK(dalloc(&d, (size_t)4 * nblocks));
+    hipLaunchKernelGGL(k_rocrand_blocks, dim3((nblocks + 63) / 64), dim3(64), 0, 0, (unsigned long long)seed,
+                       (unsigned long long)subsequence, (unsigned long long)first_block, nblocks, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, d, sizeof(uint32_t) * 4 * (size_t)nblocks, hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
+}
+
+__global__ void k_math(int op, long long n, const double* in, const double* in2, double* out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s, c;
+    switch (op) {
+    case 0: out[i] = kd_log(in[i]); break;
+    case 1: out[i] = kd_exp(in[i]); break;
+    case 2: kd_sincos2pi(in[i], &s, &c); out[i] = s; break;
+    case 3: kd_sincos2pi(in[i], &s, &c); out[i] = c; break;
+    case 4: out[i] = __builtin_sqrt(in[i]); break;
+    default: out[i] = in[i] / in2[i]; break;
+    }
+}
+
+extern "C" klara_status klara_selftest_math(int32_t device, int32_t op, int64_t n, const double* in,
+                                            const double* in2, double* out)
+{
+    if (!in || !out || n <= 0) return KLARA_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(device));
+    double *di = nullptr, *di2 = nullptr, *dout = nullptr;
+    hipError_t e = dalloc(&di, (size_t)n);
+    if (e == hipSuccess) e = dalloc(&di2, (size_t)n);
+    if (e == hipSuccess) e = dalloc(&dout, (size_t)n);
+    if (e == hipSuccess) e = hipMemcpy(di, in, sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(di2, in2 ? in2 : in, sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, (long long)n, di, di2, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
+    hipFree(di); hipFree(di2); hipFree(dout);
+    return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
+}
+
+extern "C" klara_status klara_selftest_mfma_f64(int32_t device, const double* A, const double* B,
+                                                const double* C, double* D)
+{
+    if (!A || !B || !C || !D) return KLARA_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(device));
+    double* buf = nullptr;
+    HIPCHK(dalloc(&buf, 64 + 64 + 256 + 256));
+    hipError_t e = hipMemcpy(buf, A, 64 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(buf + 64, B, 64 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(buf + 128, C, 256 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = klara_launch_mfma_probe(buf, buf + 64, buf + 128, buf + 384, 0);
+    if (e == hipSuccess) e = hipMemcpy(D, buf + 384, 256 * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(buf);
+    return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
+}
+
+extern "C" const char* klara_strerror(klara_status s)
+{
+    switch (s) {
+    case KLARA_OK: return "ok";
+    case KLARA_ERR_INVALID_ARG: return "invalid argument";
+    case KLARA_ERR_NONFINITE_INIT: return "log-target (or its gradient) not finite at the initial values";
+    case KLARA_ERR_HIP: return "HIP runtime error or no device";
+    case KLARA_ERR_NOMEM: return "out of device memory";
+    case KLARA_ERR_UNSUPPORTED: return "option not supported by this build";
+    case KLARA_ERR_STATE: return "call order / missing state";
+    case KLARA_ERR_SLICE_STUCK: return "slice sampler shrunk to current position and still not acceptable";
+    default: return "unknown status";
+    }
+}
+
+extern "C" int32_t klara_abi_version(void) { return KLARA_ABI_VERSION; }

@@ -1,0 +1,364 @@
+// klara_dense.h — dense-Gaussian target on the FP64 matrix cores (layout kind 1, "MFMA-transposed").
+//
+// Target (builder-defined; Klara ships no dense example — SURVEY F8, §8(d) cfg 3):
+//     lt(x) = c - 1/2 x' P x,   grad(x) = -P x,   P = D x D precision matrix (mu = 0).
+//
+// One wavefront carries 16 chains.  Lane l = (q = l >> 4, cl = l & 15) belongs to chain cl of the tile
+// and holds the NE = ceil(D/4) elements { 4e + q : e = 0..NE-1 } of every per-chain vector.  The
+// gradient of all 16 chains is one transposed GEMM  G' = P * X'  (M = D rows of P, N = 16 chains,
+// K = D) on v_mfma_f64_16x16x4_f64:
+//     A operand (one f64/lane) = P[16t + (l&15)][4kk + (l>>4)]        from LDS, fragment-ordered
+//     B operand (one f64/lane) = x[chain l&15][4kk + (l>>4)]           = the lane's own element kk
+//     D (4 f64/lane), tile t, reg r: row (l>>4) + 4r, col l&15         = element 4t+r of the lane
+// so the accumulator registers ARE the lane's gradient elements in the same distribution the next
+// leapfrog needs as its B operand: no transpose, no LDS round trip for the state.  K = D exactly
+// (no padding on K for D % 4 == 0); M is padded to 16*ceil(D/16) rows of zeros.
+// Accumulation order per output element = one fma chain over k ascending (checked on hardware against
+// the oracle's chain, tests/test_gpu_parity.py::test_mfma_f64_order).
+//
+// Registers: the kernel keeps only the proposal (xp, gp=accumulators, momentum) live; the current
+// state stays in HBM/L2 and is re-read on reject, which keeps NE = 25 under 256 VGPRs (2 waves/SIMD).
+#pragma once
+#include "klara_kernels.h"
+
+typedef double kd_double4 __attribute__((ext_vector_type(4)));
+
+template <int NE>
+struct MfmaCtx {
+    static constexpr int MT = (NE + 3) / 4;
+    int lane, q, cl;
+    long long chain;
+    bool chain_ok;
+    bool valid[NE];
+};
+
+template <int NE>
+__device__ __forceinline__ MfmaCtx<NE> make_mctx(const KParams& p)
+{
+    MfmaCtx<NE> c;
+    c.lane = threadIdx.x & 63;
+    c.q = c.lane >> 4;
+    c.cl = c.lane & 15;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    c.chain = wave * 16 + c.cl;
+    c.chain_ok = c.chain < p.nchains;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) c.valid[e] = c.chain_ok && (4 * e + c.q < p.D);
+    return c;
+}
+
+template <int NE>
+__device__ __forceinline__ void mload(const MfmaCtx<NE>& c, const double* base, int D, double (&v)[NE])
+{
+    const double* row = base + c.chain * D + c.q;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] = c.valid[e] ? row[4 * e] : 0.0;
+}
+template <int NE>
+__device__ __forceinline__ void mstore(const MfmaCtx<NE>& c, double* base, int D, const double (&v)[NE])
+{
+    double* row = base + c.chain * D + c.q;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) if (c.valid[e]) row[4 * e] = v[e];
+}
+
+// all-reduce over the 4 lanes (q = 0..3) of a chain: xor 16 then xor 32 — the canonical tree
+// (q0+q1)+(q2+q3) of the oracle's kind-1 layout.
+template <int N>
+__device__ __forceinline__ void mreduce(double (&v)[N], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] + bperm_xor(v[i], lane, 16);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] + bperm_xor(v[i], lane, 32);
+}
+
+// normals for the lane's elements: element e <-> dim i = 4e+q <-> slot i>>1 = 2e + (q>>1),
+// branch q&1 (cos for even dims, sin for odd dims)
+template <int NE>
+__device__ __forceinline__ void mnormals(const MfmaCtx<NE>& c, unsigned long long seed,
+                                         unsigned long long gchain, unsigned long long t,
+                                         double (&z)[NE])
+{
+    const uint32_t sh = (uint32_t)(c.q >> 1);
+    const bool odd = (c.q & 1) != 0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        double z0, z1;
+        kd_normal_pair(kd_stream_block(seed, gchain, t, 2u * (uint32_t)e + sh), &z0, &z1);
+        z[e] = odd ? z1 : z0;
+        __builtin_amdgcn_sched_barrier(0);   // keep the 25 unrolled Philox/Box-Muller bodies from interleaving (VGPR pressure)
+    }
+}
+
+// g = -(P x) for the wave's 16 chains.  ldsP: fragment-ordered P, (MT*NE) fragments of 64 doubles.
+template <int NE>
+__device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int lane,
+                                           const double (&x)[NE], double (&g)[4 * ((NE + 3) / 4)])
+{
+    constexpr int MT = (NE + 3) / 4;
+    kd_double4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };
+    // software pipeline: the A fragments of k-step kk+1 are fetched from LDS while the MT MFMAs of
+    // k-step kk issue; sched_barrier keeps hipcc from hoisting all NE*MT LDS reads (VGPR blow-up).
+    double a_cur[MT], a_nxt[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a_cur[t] = ldsP[(t * NE) * 64 + lane];
+#pragma unroll
+    for (int kk = 0; kk < NE; ++kk) {
+        const double b = x[kk];
+        if (kk + 1 < NE) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a_nxt[t] = ldsP[(t * NE + kk + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[t], b, acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a_cur[t] = a_nxt[t];
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        g[4 * t + 0] = -acc[t][0]; g[4 * t + 1] = -acc[t][1];
+        g[4 * t + 2] = -acc[t][2]; g[4 * t + 3] = -acc[t][3];
+    }
+}
+
+template <int SAMPLER, int NE>
+__global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, const double* __restrict__ Pfrag)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = (NE + 3) / 4;
+    constexpr int NG = 4 * MT;
+    double* ldsP = reinterpret_cast<double*>(smem);
+    for (int i = threadIdx.x; i < MT * NE * 64; i += blockDim.x) ldsP[i] = Pfrag[i];
+    __syncthreads();
+
+    const MfmaCtx<NE> cx = make_mctx<NE>(p);
+    const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
+    const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
+    TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix] };
+    double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
+    unsigned long long nacc = 0;
+    const bool do_sum = p.sum != nullptr;
+
+    for (int s = 0; s < p.nsteps; ++s) {
+        const unsigned long long t = p.t0 + (unsigned long long)s;
+        if (p.cnt) tn.proposed += 1;
+        bool acc = false;
+        double xp[NE], gp[NG];
+        double ltp = lt;
+        mload<NE>(cx, p.X, p.D, xp);                                   // current value
+
+        if (SAMPLER == KLARA_SAMPLER_HMC) {
+            // iterate/HMC.jl:124-201, leapfrog! samplers.jl:122-134
+            double mom[NE], red[2];
+            {
+                double g0[NE];
+                mload<NE>(cx, p.GR, p.D, g0);                           // HMC.jl:140
+#pragma unroll
+                for (int e = 0; e < NE; ++e) gp[e] = g0[e];
+            }
+            mnormals<NE>(cx, p.seed, gchain, t, mom);                  // HMC.jl:135
+            double k0[1] = { 0.0 };
+#pragma unroll
+            for (int e = 0; e < NE; ++e) k0[0] = k0[0] + (cx.valid[e] ? mom[e] * mom[e] : 0.0);
+            mreduce<1>(k0, cx.lane);
+            const double H0 = lt - 0.5 * k0[0];                        // HMC.jl:137
+            const double eps = tn.step, halfe = 0.5 * eps;
+            for (int l = 0; l < p.nleaps; ++l) {                       // HMC.jl:146-155
+#pragma unroll
+                for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];   // samplers.jl:130
+#pragma unroll
+                for (int e = 0; e < NE; ++e) xp[e] = xp[e] + eps * mom[e];      // samplers.jl:131
+                dense_grad<NE>(ldsP, cx.lane, xp, gp);                          // samplers.jl:132
+#pragma unroll
+                for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];   // samplers.jl:133
+            }
+            double l1 = 0.0, k1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                l1 = l1 + (cx.valid[e] ? xp[e] * gp[e] : 0.0);         // lt' = c + 1/2 x'.g'   (HMC.jl:157)
+                k1 = k1 + (cx.valid[e] ? mom[e] * mom[e] : 0.0);
+            }
+            red[0] = l1; red[1] = k1;
+            mreduce<2>(red, cx.lane);
+            ltp = p.gconst + 0.5 * red[0];
+            const double H1 = ltp - 0.5 * red[1];                      // HMC.jl:159
+            const double ratio = H1 - H0;                              // HMC.jl:161
+            const double ex = kd_exp(ratio);
+            const double a = 1.0 < ex ? 1.0 : ex;                      // HMC.jl:163
+            const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+            acc = u < a;                                               // HMC.jl:165
+        } else if (SAMPLER == KLARA_SAMPLER_MALA) {
+            // iterate/MALA.jl:78-128
+            double z[NE], xc[NE], red[3];
+            const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h);
+            mnormals<NE>(cx, p.seed, gchain, t, z);
+            double s1 = 0.0;
+            {
+                double g0[NE];
+                mload<NE>(cx, p.GR, p.D, g0);
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    xc[e] = xp[e];
+                    const double mu = xc[e] + halfh * g0[e];           // MALA.jl:83
+                    xp[e] = mu + sq * z[e];                            // MALA.jl:84
+                    const double q1 = mu - xp[e];
+                    s1 = s1 + (cx.valid[e] ? 0.5 * ((q1 * q1) / h) : 0.0);      // MALA.jl:90
+                }
+            }
+            dense_grad<NE>(ldsP, cx.lane, xp, gp);                     // MALA.jl:86
+            double l1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                l1 = l1 + (cx.valid[e] ? xp[e] * gp[e] : 0.0);
+                const double mup = xp[e] + halfh * gp[e];              // MALA.jl:91
+                const double q2 = mup - xc[e];
+                s2 = s2 + (cx.valid[e] ? 0.5 * ((q2 * q2) / h) : 0.0);          // MALA.jl:92
+            }
+            red[0] = l1; red[1] = s1; red[2] = s2;
+            mreduce<3>(red, cx.lane);
+            ltp = p.gconst + 0.5 * red[0];
+            double ratio = ltp - lt;                                   // MALA.jl:88
+            ratio += red[1];
+            ratio -= red[2];
+            acc = ratio > 0.0;                                         // MALA.jl:94
+            if (!acc) {
+                const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+                acc = ratio > kd_log(u);
+            }
+        } else {
+            // iterate/MH.jl:72-124
+            double z[NE], sg[NE], red[1];
+            mnormals<NE>(cx, p.seed, gchain, t, z);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                sg[e] = (4 * e + cx.q < p.D) ? p.vecparam[4 * e + cx.q] : 0.0;
+                xp[e] = xp[e] + sg[e] * z[e];                          // MH.jl:79
+            }
+            dense_grad<NE>(ldsP, cx.lane, xp, gp);                     // MH.jl:81
+            double l1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) l1 = l1 + (cx.valid[e] ? xp[e] * gp[e] : 0.0);
+            red[0] = l1;
+            mreduce<1>(red, cx.lane);
+            ltp = p.gconst + 0.5 * red[0];
+            const double ratio = ltp - lt;                             // MH.jl:83
+            acc = ratio > 0.0;                                         // MH.jl:97
+            if (!acc) {
+                const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+                acc = ratio > kd_log(u);
+            }
+        }
+
+        if (acc) {
+            mstore<NE>(cx, p.X, p.D, xp);
+            if (SAMPLER != KLARA_SAMPLER_MH) {
+                double gs[NE];
+#pragma unroll
+                for (int e = 0; e < NE; ++e) gs[e] = gp[e];
+                mstore<NE>(cx, p.GR, p.D, gs);
+            }
+            lt = ltp;
+        }
+        nacc += acc ? 1ull : 0ull;
+        if (p.cnt && acc) tn.accepted += 1;
+        if (p.accept != nullptr && cx.chain_ok && cx.q == 0)
+            p.accept[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
+        if (!p.pooled) tuning_block(p, tn);
+        const long long i1 = (long long)t + 1;
+        if (i1 > p.burnin && ((i1 - p.burnin - 1) % p.thinning) == 0 && i1 <= p.nsteps_total) {
+            if (do_sum || p.hist != nullptr) {
+                double xs[NE];
+                if (acc) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) xs[e] = xp[e];
+                } else {
+                    mload<NE>(cx, p.X, p.D, xs);
+                }
+                if (do_sum) {
+                    double* sr = p.sum + cx.chain * p.D + cx.q;
+                    double* qr = p.sumsq + cx.chain * p.D + cx.q;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) if (cx.valid[e]) {
+                        sr[4 * e] = sr[4 * e] + xs[e];
+                        qr[4 * e] = qr[4 * e] + xs[e] * xs[e];
+                    }
+                }
+                if (p.hist != nullptr) {
+                    const long long col = (i1 - p.burnin - 1) / p.thinning;
+                    if (col < p.hist_cols) {
+                        double* dst = p.hist + (col * p.nchains + cx.chain) * p.D + cx.q;
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) if (cx.valid[e]) dst[4 * e] = xs[e];
+                    }
+                }
+            }
+        }
+    }
+
+    if (cx.chain_ok && cx.q == 0) {
+        p.LT[cx.chain] = lt;
+        p.naccept[cx.chain] += nacc;
+        if (!p.pooled) {
+            p.tune_step[cx.chain] = tn.step;
+            p.tune_accepted[cx.chain] = tn.accepted;
+            p.tune_proposed[cx.chain] = tn.proposed;
+            p.tune_totproposed[cx.chain] = tn.totproposed;
+        } else if (p.cnt) {
+            atomicAdd(p.pooled_accepted, (unsigned long long)tn.accepted - (unsigned long long)p.tune_accepted[0]);
+        }
+    }
+}
+
+// initialize! for the dense target: g = -P x, lt = c + 1/2 x.g, finiteness asserts
+template <int NE>
+__global__ __launch_bounds__(512) void k_dense_init(const KParams p, const double* __restrict__ Pfrag, int needgrad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = (NE + 3) / 4;
+    double* ldsP = reinterpret_cast<double*>(smem);
+    for (int i = threadIdx.x; i < MT * NE * 64; i += blockDim.x) ldsP[i] = Pfrag[i];
+    __syncthreads();
+    const MfmaCtx<NE> cx = make_mctx<NE>(p);
+    double x[NE], g[4 * MT], red[1];
+    mload<NE>(cx, p.X, p.D, x);
+    dense_grad<NE>(ldsP, cx.lane, x, g);
+    double l1 = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        l1 = l1 + (cx.valid[e] ? x[e] * g[e] : 0.0);
+        if (needgrad) bad = bad || (cx.valid[e] && !kfinite(g[e]));
+    }
+    red[0] = l1;
+    mreduce<1>(red, cx.lane);
+    const double lt = p.gconst + 0.5 * red[0];
+    bad = bad || (cx.chain_ok && !kfinite(lt));
+    if (needgrad) {
+        double gs[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) gs[e] = g[e];
+        mstore<NE>(cx, p.GR, p.D, gs);
+    }
+    if (cx.chain_ok && cx.q == 0) p.LT[cx.chain] = lt;
+    if (bad) atomicMax(p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
+}
+
+// test hook: D[16x16] = A[16x4] * B[4x16] + C through one v_mfma_f64_16x16x4_f64, to pin the
+// accumulation order of the instruction (one wave).
+__global__ void k_mfma_f64_probe(const double* A, const double* B, const double* C, double* Dout)
+{
+    const int lane = threadIdx.x & 63;
+    const double a = A[(lane & 15) * 4 + (lane >> 4)];        // A[i][k]
+    const double b = B[(lane >> 4) * 16 + (lane & 15)];       // B[k][j]
+    kd_double4 c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = C[((lane >> 4) + 4 * r) * 16 + (lane & 15)];
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Dout[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = c[r];
+}

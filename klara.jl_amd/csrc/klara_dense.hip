@@ -1,0 +1,68 @@
+// klara_dense.hip — instantiates the dense-Gaussian FP64-MFMA kernels for gfx950.
+#include "klara_launch.h"
+#include "klara_dense.h"
+
+template <int SAMPLER>
+static hipError_t launch_dense_s(const KParams& p, int NE, const double* Pfrag, dim3 grid, hipStream_t st)
+{
+    const dim3 blk(512);
+#define KLARA_DENSE_CASE(N)                                                                            \
+    case N: {                                                                                          \
+        constexpr size_t lds = sizeof(double) * 64 * (size_t)N * (size_t)((N + 3) / 4);                \
+        hipError_t e = hipFuncSetAttribute((const void*)k_dense_transitions<SAMPLER, N>,               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        if (e != hipSuccess) return e;                                                                 \
+        hipLaunchKernelGGL((k_dense_transitions<SAMPLER, N>), grid, blk, lds, st, p, Pfrag);           \
+        break;                                                                                         \
+    }
+    switch (NE) {
+        KLARA_DENSE_CASE(8)
+        KLARA_DENSE_CASE(16)
+        KLARA_DENSE_CASE(25)
+        KLARA_DENSE_CASE(32)
+    default: return hipErrorInvalidValue;
+    }
+#undef KLARA_DENSE_CASE
+    return hipGetLastError();
+}
+
+hipError_t klara_launch_dense(const KParams& p, int sampler, int NE, const double* Pfrag, dim3 grid,
+                              hipStream_t st)
+{
+    switch (sampler) {
+    case KLARA_SAMPLER_MH: return launch_dense_s<KLARA_SAMPLER_MH>(p, NE, Pfrag, grid, st);
+    case KLARA_SAMPLER_MALA: return launch_dense_s<KLARA_SAMPLER_MALA>(p, NE, Pfrag, grid, st);
+    case KLARA_SAMPLER_HMC: return launch_dense_s<KLARA_SAMPLER_HMC>(p, NE, Pfrag, grid, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag, int needgrad, dim3 grid,
+                                   hipStream_t st)
+{
+    const dim3 blk(512);
+#define KLARA_DENSE_CASE(N)                                                                            \
+    case N: {                                                                                          \
+        constexpr size_t lds = sizeof(double) * 64 * (size_t)N * (size_t)((N + 3) / 4);                \
+        hipError_t e = hipFuncSetAttribute((const void*)k_dense_init<N>,                               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        if (e != hipSuccess) return e;                                                                 \
+        hipLaunchKernelGGL((k_dense_init<N>), grid, blk, lds, st, p, Pfrag, needgrad);                 \
+        break;                                                                                         \
+    }
+    switch (NE) {
+        KLARA_DENSE_CASE(8)
+        KLARA_DENSE_CASE(16)
+        KLARA_DENSE_CASE(25)
+        KLARA_DENSE_CASE(32)
+    default: return hipErrorInvalidValue;
+    }
+#undef KLARA_DENSE_CASE
+    return hipGetLastError();
+}
+
+hipError_t klara_launch_mfma_probe(const double* A, const double* B, const double* C, double* D, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_mfma_f64_probe, dim3(1), dim3(64), 0, st, A, B, C, D);
+    return hipGetLastError();
+}

@@ -1,0 +1,618 @@
+// klara_kernels.h — gfx950 device code for the many-chain transition kernels ("group layout").
+//
+// Layout (kind 0).  A chain's D-vector is spread over G = 2^k lanes of a wavefront,
+// E contiguous elements per lane (element i lives on lane i / E of its group); a 64-lane wavefront
+// carries 64 / G chains.  D = 100 -> E = 2, G = 64: one chain per wavefront, lanes 0..49 hold (2q, 2q+1),
+// so one Philox4x32-10 block per lane yields exactly that lane's two proposal normals.
+// D = 4 (swiss logistic regression) -> E = 4, G = 1: one chain per lane, no cross-lane traffic at all.
+// State matrices are (nchains x D) row-major in HBM: a wavefront reads/writes contiguous rows.
+//
+// Reductions over a chain (dot, sum) are: lane partial over its E elements (ascending), then an xor
+// butterfly over the G lanes — DPP quad_perm / row_half_mirror / row_mirror for strides 1,2,4,8 and
+// ds_bpermute for 16,32.  The CPU oracle sums in the same order (oracle/klara_oracle.c ko_reduce).
+//
+// The transition arithmetic restates src/samplers/iterate/{MH,MALA,HMC,SliceSampler}.jl expression by
+// expression (no fma contraction: build with -ffp-contract=off); citations are on each step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "detmath.h"
+#include "../../include/klara_hip.h"
+
+#define KLARA_SLICE_ATT_BITS 14
+#define KLARA_SLICE_MAX_ATT ((1 << KLARA_SLICE_ATT_BITS) - 1)
+#define KLARA_INIT_TRANSITION ((((uint64_t)1) << 40) - 1)
+
+// Kernel parameter block (by value).  All pointers are device pointers.
+struct KParams {
+    double* X; double* GR; double* LT;         // state: value nchains x D, gradlogtarget nchains x D, logtarget nchains
+    double* tune_step;                         // per chain (or [0] in pooled mode)
+    long long* tune_accepted; long long* tune_proposed; long long* tune_totproposed;
+    unsigned long long* pooled_accepted;       // pooled mode: device-wide accepted counter
+    uint8_t* accept;                           // [launch step][nchains] or null
+    unsigned long long* naccept;               // per chain
+    double* sum; double* sumsq;                // per chain x D or null
+    double* hist; long long hist_cols;         // [col][nchains][D] or null
+    int* error_flag;                           // set to klara_status on device-detected errors
+    long long nchains; long long chain_offset;
+    int D; int G; int pooled;
+    unsigned long long seed; unsigned long long t0; int nsteps;
+    // sampler
+    const double* vecparam;                    // MH sigma[D] / slice widths[D]
+    int nleaps; int stepout;
+    // tuner
+    int tuner; int cnt; double targetrate; double score_k; int period; int is_mh;
+    long long burnin; long long thinning; long long nsteps_total;
+    // targets
+    const double* gw; const double* gmu; double gconst;      // diag (gw/gmu may be null)
+    const double* lX; const double* ly; int ndata; double lambda; double lpconst;   // logistic
+};
+
+// ------------------------------------------------------------------------------------------------
+// cross-lane helpers
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    const uint64_t u = kd_d2u(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+    return kd_u2d(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ double bperm_xor(double v, int lane, int m)
+{
+    const uint64_t u = kd_d2u(v);
+    const int addr = (lane ^ m) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)u);
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(u >> 32));
+    return kd_u2d(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ double lane_bcast(double v, int src_lane)
+{
+    const uint64_t u = kd_d2u(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)u);
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(u >> 32));
+    return kd_u2d(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// xor-butterfly all-reduce over the G lanes of a group; N values at once for ILP.
+template <int N>
+__device__ __forceinline__ void group_allreduce(double (&v)[N], int G, int lane)
+{
+    if (G > 1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_mov<0xB1>(v[i]);    // quad_perm [1,0,3,2]
+    }
+    if (G > 2) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_mov<0x4E>(v[i]);    // quad_perm [2,3,0,1]
+    }
+    if (G > 4) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_mov<0x141>(v[i]);   // row_half_mirror
+    }
+    if (G > 8) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_mov<0x140>(v[i]);   // row_mirror
+    }
+    if (G > 16) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = v[i] + bperm_xor(v[i], lane, 16);
+    }
+    if (G > 32) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = v[i] + bperm_xor(v[i], lane, 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lane context
+// ------------------------------------------------------------------------------------------------
+template <int E>
+struct LaneCtx {
+    int lane;          // 0..63
+    int G;             // lanes per chain
+    int q;             // lane within group
+    int i0;            // first element index owned (E*q)
+    long long chain;   // local chain index (may be >= nchains: inactive group)
+    bool chain_ok;
+    bool valid[E];     // element i0+e < D and chain_ok
+};
+
+template <int E, int GT>
+__device__ __forceinline__ LaneCtx<E> make_ctx(const KParams& p)
+{
+    LaneCtx<E> c;
+    const int G = GT ? GT : p.G;
+    c.G = G;
+    c.lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    c.q = c.lane & (G - 1);
+    const int grp = c.lane / G;
+    c.chain = wave * (64 / G) + grp;
+    c.chain_ok = c.chain < p.nchains;
+    c.i0 = E * c.q;
+#pragma unroll
+    for (int e = 0; e < E; ++e) c.valid[e] = c.chain_ok && (c.i0 + e < p.D);
+    return c;
+}
+
+template <int E>
+__device__ __forceinline__ void load_vec(const LaneCtx<E>& c, const double* base, int D, double (&v)[E])
+{
+    const double* row = base + c.chain * D + c.i0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = c.valid[e] ? row[e] : 0.0;
+}
+template <int E>
+__device__ __forceinline__ void store_vec(const LaneCtx<E>& c, double* base, int D, const double (&v)[E])
+{
+    double* row = base + c.chain * D + c.i0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) if (c.valid[e]) row[e] = v[e];
+}
+template <int E>
+__device__ __forceinline__ void load_param(const LaneCtx<E>& c, const double* base, int D, double dflt,
+                                           double (&v)[E])
+{
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        v[e] = dflt;
+        if (base != nullptr && c.i0 + e < D) v[e] = base[c.i0 + e];
+    }
+}
+
+// proposal normals of this lane's E elements for transition t: element i <- block slot i>>1,
+// cos branch for even i, sin branch for odd i (E is even, i0 is even).
+template <int E>
+__device__ __forceinline__ void lane_normals(const LaneCtx<E>& c, unsigned long long seed,
+                                             unsigned long long gchain, unsigned long long t,
+                                             double (&z)[E])
+{
+    static_assert(E % 2 == 0, "E must be even");
+#pragma unroll
+    for (int j = 0; j < E / 2; ++j) {
+        const kd_u32x4 b = kd_stream_block(seed, gchain, t, (uint32_t)((c.i0 >> 1) + j));
+        kd_normal_pair(b, &z[2 * j], &z[2 * j + 1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// targets.  eval<WANT_LT, WANT_GRAD>(ctx, x, ltpart, g): ltpart is the lane partial of the reduction
+// term; lt = finalize(group sum of ltpart).
+// ------------------------------------------------------------------------------------------------
+// KLARA_TARGET_GAUSS_DIAG: lt = c - sum_i w_i (x_i - mu_i)^2, grad_i = (-2 w_i)(x_i - mu_i)
+// (README.md:23 `-dot(z,z)`, README.md:155 `-2*z`; test/BasicContMuvParameter.jl:39-56 MvNormal).
+template <int E>
+struct DiagTarget {
+    double w[E], mu[E], c;
+    __device__ __forceinline__ void init(const KParams& p, const LaneCtx<E>& cx, double*)
+    {
+        load_param<E>(cx, p.gw, p.D, 1.0, w);
+        load_param<E>(cx, p.gmu, p.D, 0.0, mu);
+        c = p.gconst;
+    }
+    static __device__ __forceinline__ size_t lds_bytes(const KParams&) { return 0; }
+    template <bool WANT_LT, bool WANT_GRAD>
+    __device__ __forceinline__ void eval(const LaneCtx<E>& cx, const double (&x)[E], double& ltpart,
+                                         double (&g)[E]) const
+    {
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double dd = x[e] - mu[e];
+            if (WANT_LT) acc = acc + (cx.valid[e] ? w[e] * (dd * dd) : 0.0);
+            if (WANT_GRAD) g[e] = (-2.0 * w[e]) * dd;
+        }
+        ltpart = acc;
+    }
+    __device__ __forceinline__ double finalize(double red) const { return c - red; }
+};
+
+// KLARA_TARGET_LOGISTIC (doc/examples/swiss/MALA/analytical.jl:11-18), one chain per lane (G == 1):
+// the design matrix and outcomes sit in LDS, every lane walks the ndata rows sequentially
+// (same-address LDS reads broadcast), so no cross-lane reduction exists.
+template <int E>
+struct LogisticTarget {
+    const double* sX; const double* sy; int ndata; int D; double lambda, lpconst;
+    static __device__ __forceinline__ size_t lds_bytes(const KParams& p)
+    {
+        return sizeof(double) * (size_t)p.ndata * (size_t)(p.D + 1);
+    }
+    __device__ __forceinline__ void init(const KParams& p, const LaneCtx<E>&, double* lds)
+    {
+        double* X = lds; double* y = lds + (size_t)p.ndata * p.D;
+        for (int i = threadIdx.x; i < p.ndata * p.D; i += blockDim.x) X[i] = p.lX[i];
+        for (int i = threadIdx.x; i < p.ndata; i += blockDim.x) y[i] = p.ly[i];
+        __syncthreads();
+        sX = X; sy = y; ndata = p.ndata; D = p.D; lambda = p.lambda; lpconst = p.lpconst;
+    }
+    template <bool WANT_LT, bool WANT_GRAD>
+    __device__ __forceinline__ void eval(const LaneCtx<E>& cx, const double (&x)[E], double& ltpart,
+                                         double (&g)[E]) const
+    {
+        double dotxy = 0.0, slog = 0.0, gacc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) gacc[e] = 0.0;
+        for (int r = 0; r < ndata; ++r) {
+            const double* row = sX + r * D;
+            double xp = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (e < D) xp = kd_fma(row[e], x[e], xp);   // Xp = v[2]*p
+            const double yr = sy[r];
+            if (WANT_LT) {
+                dotxy = dotxy + xp * yr;                                          // dot(Xp, v[3])
+                slog = slog + kd_log(1.0 + kd_exp(xp));                           // sum(log(1+exp(Xp)))
+            }
+            if (WANT_GRAD) {
+                const double res = yr - 1.0 / (1.0 + kd_exp(-xp));                // v[3]-1./(1+exp(-Xp))
+#pragma unroll
+                for (int e = 0; e < E; ++e) if (e < D) gacc[e] = kd_fma(row[e], res, gacc[e]);
+            }
+        }
+        if (WANT_LT) {
+            double dotpp = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) dotpp = dotpp + (cx.valid[e] ? x[e] * x[e] : 0.0);
+            const double ll = dotxy - slog;
+            const double lp = -0.5 * (dotpp / lambda + lpconst);                  // plogprior
+            ltpart = ll + lp;
+        }
+        if (WANT_GRAD) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) g[e] = gacc[e] - x[e] / lambda;           // -p/v[1]
+        }
+    }
+    __device__ __forceinline__ double finalize(double red) const { return red; }
+};
+
+template <int TARGET, int E> struct TargetSel;
+template <int E> struct TargetSel<KLARA_TARGET_GAUSS_DIAG, E> { using type = DiagTarget<E>; };
+template <int E> struct TargetSel<KLARA_TARGET_LOGISTIC, E> { using type = LogisticTarget<E>; };
+
+__device__ __forceinline__ bool kfinite(double v) { return (v == v) && (v - v == 0.0); }
+
+// full logtarget of a vector (one reduction)
+template <class T, int E>
+__device__ __forceinline__ double eval_lt(const T& tg, const LaneCtx<E>& cx, const double (&x)[E])
+{
+    double part[1], gdummy[E];
+    tg.template eval<true, false>(cx, x, part[0], gdummy);
+    group_allreduce<1>(part, cx.G, cx.lane);
+    return tg.finalize(part[0]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-chain tuner state in registers (tuners.jl:5-10), uniform across the group's lanes
+// ------------------------------------------------------------------------------------------------
+struct TuneRegs { double step; long long accepted, proposed, totproposed; };
+
+// tuning block: iterate/MALA.jl:130-152, iterate/HMC.jl:203-224, iterate/MH.jl:116-131;
+// rate!/reset_burnin! tuners.jl:27-32; tune! AcceptanceRateMCTuner.jl:46 with logistic_rate_score
+// (AcceptanceRateMCTuner.jl:9, stats/logistic.jl:11).
+__device__ __forceinline__ void tuning_block(const KParams& p, TuneRegs& tn)
+{
+    if (!p.cnt) return;
+    if (tn.totproposed <= p.burnin && (tn.proposed % p.period) == 0) {
+        const double rate = (double)tn.accepted / (double)tn.proposed;
+        if (p.tuner == KLARA_TUNER_ACCEPT_RATE && !p.is_mh) {
+            const double xr = rate - p.targetrate;
+            tn.step *= 2.0 / (1.0 + kd_exp(-p.score_k * (xr - 0.0))) + 0.0;
+        }
+        tn.totproposed += tn.proposed;
+        tn.accepted = 0; tn.proposed = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// transitions.  Each returns the accept flag (uniform across the group) and updates x, g, lt.
+// ------------------------------------------------------------------------------------------------
+// iterate!(job, MH, Multivariate) — iterate/MH.jl:72-124 (symmetric normalised branch)
+template <class T, int E>
+__device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const LaneCtx<E>& cx,
+                                        unsigned long long gchain, unsigned long long t,
+                                        const double (&sigma)[E], double (&x)[E], double& lt)
+{
+    double z[E], xp[E], gd[E], red[1];
+    lane_normals<E>(cx, p.seed, gchain, t, z);
+#pragma unroll
+    for (int e = 0; e < E; ++e) xp[e] = x[e] + sigma[e] * z[e];                       // MH.jl:79
+    tg.template eval<true, false>(cx, xp, red[0], gd);                                // :81
+    group_allreduce<1>(red, cx.G, cx.lane);
+    const double ltp = tg.finalize(red[0]);
+    const double ratio = ltp - lt;                                                    // :83
+    bool acc = ratio > 0.0;                                                           // :97
+    if (!acc) {
+        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+        acc = ratio > kd_log(u);
+    }
+    if (acc) {                                                                        // :98-100
+#pragma unroll
+        for (int e = 0; e < E; ++e) x[e] = xp[e];
+        lt = ltp;
+    }
+    return acc;
+}
+
+// iterate!(job, MALA, Multivariate) — iterate/MALA.jl:78-128
+template <class T, int E>
+__device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const LaneCtx<E>& cx,
+                                          unsigned long long gchain, unsigned long long t, double h,
+                                          double (&x)[E], double (&g)[E], double& lt)
+{
+    double z[E], mu[E], xp[E], gp[E], red[3];
+    lane_normals<E>(cx, p.seed, gchain, t, z);
+    const double halfh = 0.5 * h, sq = __builtin_sqrt(h);
+#pragma unroll
+    for (int e = 0; e < E; ++e) mu[e] = x[e] + halfh * g[e];                          // :83
+#pragma unroll
+    for (int e = 0; e < E; ++e) xp[e] = mu[e] + sq * z[e];                            // :84
+    tg.template eval<true, true>(cx, xp, red[0], gp);                                 // :86
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double q1 = mu[e] - xp[e];
+        s1 = s1 + (cx.valid[e] ? 0.5 * ((q1 * q1) / h) : 0.0);                        // :90
+        const double mup = xp[e] + halfh * gp[e];                                     // :91
+        const double q2 = mup - x[e];
+        s2 = s2 + (cx.valid[e] ? 0.5 * ((q2 * q2) / h) : 0.0);                        // :92
+    }
+    red[1] = s1; red[2] = s2;
+    group_allreduce<3>(red, cx.G, cx.lane);
+    const double ltp = tg.finalize(red[0]);
+    double ratio = ltp - lt;                                                          // :88
+    ratio += red[1];                                                                  // :90
+    ratio -= red[2];                                                                  // :92
+    bool acc = ratio > 0.0;                                                           // :94
+    if (!acc) {
+        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+        acc = ratio > kd_log(u);
+    }
+    if (acc) {                                                                        // :95-105
+#pragma unroll
+        for (int e = 0; e < E; ++e) { x[e] = xp[e]; g[e] = gp[e]; }
+        lt = ltp;
+    }
+    return acc;
+}
+
+// iterate!(job, HMC, Multivariate) — iterate/HMC.jl:124-201; leapfrog! samplers.jl:122-134;
+// hamiltonian samplers.jl:103
+template <class T, int E>
+__device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const LaneCtx<E>& cx,
+                                         unsigned long long gchain, unsigned long long t, double eps,
+                                         double (&x)[E], double (&g)[E], double& lt)
+{
+    double mom[E], xp[E], gp[E], red[2], dummy;
+    lane_normals<E>(cx, p.seed, gchain, t, mom);                                      // :135
+    double k0[1] = { 0.0 };
+#pragma unroll
+    for (int e = 0; e < E; ++e) k0[0] = k0[0] + (cx.valid[e] ? mom[e] * mom[e] : 0.0);
+    group_allreduce<1>(k0, cx.G, cx.lane);
+    const double H0 = lt - 0.5 * k0[0];                                               // :137
+#pragma unroll
+    for (int e = 0; e < E; ++e) { xp[e] = x[e]; gp[e] = g[e]; }                       // :139-140
+    const double halfe = 0.5 * eps;
+    for (int l = 0; l < p.nleaps; ++l) {                                              // :146-155
+#pragma unroll
+        for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];                  // samplers.jl:130
+#pragma unroll
+        for (int e = 0; e < E; ++e) xp[e] = xp[e] + eps * mom[e];                     // samplers.jl:131
+        tg.template eval<false, true>(cx, xp, dummy, gp);                             // samplers.jl:132
+#pragma unroll
+        for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];                  // samplers.jl:133
+    }
+    double gd[E];
+    tg.template eval<true, false>(cx, xp, red[0], gd);                                // :157
+    double k1 = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) k1 = k1 + (cx.valid[e] ? mom[e] * mom[e] : 0.0);
+    red[1] = k1;
+    group_allreduce<2>(red, cx.G, cx.lane);
+    const double ltp = tg.finalize(red[0]);
+    const double H1 = ltp - 0.5 * red[1];                                             // :159
+    const double ratio = H1 - H0;                                                     // :161
+    const double ex = kd_exp(ratio);
+    const double a = 1.0 < ex ? 1.0 : ex;                                             // :163
+    const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+    const bool acc = u < a;                                                           // :165
+    if (acc) {                                                                        // :166-176
+#pragma unroll
+        for (int e = 0; e < E; ++e) { x[e] = xp[e]; g[e] = gp[e]; }
+        lt = ltp;
+    }
+    return acc;
+}
+
+// iterate!(job, SliceSampler, Multivariate) — iterate/SliceSampler.jl:60-109.
+// Coordinates are visited serially; the step-out and shrink loops have per-chain trip counts, so when
+// a wavefront carries several chains the loops run until every chain is done (wave-uniform control
+// flow via __any; finished chains are masked).
+template <class T, int E>
+__device__ __forceinline__ bool step_slice(const KParams& p, const T& tg, const LaneCtx<E>& cx,
+                                           unsigned long long gchain, unsigned long long t,
+                                           const double (&widths)[E], double (&x)[E], double& lt,
+                                           bool& stuck)
+{
+    const int group_base = cx.lane - cx.q;
+    for (int i = 0; i < p.D; ++i) {                                                   // :65
+        const int qo = i / E, eo = i - qo * E;
+        const bool owner = (cx.q == qo);
+        // coordinate value and width, broadcast from the owner lane
+        double xi_l = 0.0, w_l = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (e == eo) { xi_l = x[e]; w_l = widths[e]; }
+        const double xi = (cx.G > 1) ? lane_bcast(xi_l, group_base + qo) : xi_l;
+        const double w = (cx.G > 1) ? lane_bcast(w_l, group_base + qo) : w_l;
+        const uint32_t base = (uint32_t)i << KLARA_SLICE_ATT_BITS;
+        const kd_u32x4 b0 = kd_stream_block(p.seed, gchain, t, base);
+        const double logu = kd_log(kd_uniform_xy(b0)) + lt;                           // :66
+        const double ru = kd_uniform_zw(b0);                                          // :71
+        double Li = xi - ru * w;                                                      // :72
+        double Ri = xi + (1.0 - ru) * w;                                              // :73
+        double tmp[E];
+        auto lt_with = [&](double cand) -> double {
+#pragma unroll
+            for (int e = 0; e < E; ++e) tmp[e] = (owner && e == eo) ? cand : x[e];
+            return eval_lt<T, E>(tg, cx, tmp);
+        };
+        if (p.stepout) {                                                              // :75-89
+            double l = lt_with(Li);
+            int guard = 0;
+            while (true) {
+                bool go = cx.chain_ok && !stuck && (l > logu);
+                if (go && ++guard > KLARA_SLICE_MAX_ATT) { stuck = true; go = false; }
+                if (!__any(go)) break;
+                const double Ln = Li - w;
+                const double ln = lt_with(go ? Ln : Li);
+                if (go) { Li = Ln; l = ln; }
+            }
+            double r = lt_with(Ri);
+            guard = 0;
+            while (true) {
+                bool go = cx.chain_ok && !stuck && (r > logu);
+                if (go && ++guard > KLARA_SLICE_MAX_ATT) { stuck = true; go = false; }
+                if (!__any(go)) break;
+                const double Rn = Ri + w;
+                const double rn = lt_with(go ? Rn : Ri);
+                if (go) { Ri = Rn; r = rn; }
+            }
+        }
+        double xprime = xi, ltnew = lt;
+        bool done = !cx.chain_ok || stuck;
+        for (uint32_t a = 1;; ++a) {                                                  // :91-106
+            if (!done && a > KLARA_SLICE_MAX_ATT) { stuck = true; done = true; }
+            if (!__any(!done)) break;
+            const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, base | a));
+            const double cand = u * (Ri - Li) + Li;                                   // :92-93
+            const double lc = lt_with(done ? xprime : cand);                          // :94
+            if (!done) {
+                xprime = cand; ltnew = lc;
+                if (lc > logu) done = true;                                           // :95
+                else if (cand > xi) Ri = cand;                                        // :98
+                else if (cand < xi) Li = cand;                                        // :100
+                else { stuck = true; done = true; }                                   // :102
+            }
+        }
+        if (!stuck) {
+            lt = ltnew;
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (owner && e == eo) x[e] = xprime;          // :108
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the transition kernel: run(job) loop of BasicMCJob.jl:219-238 for p.nsteps transitions
+// ------------------------------------------------------------------------------------------------
+template <int SAMPLER, int TARGET, int E, int GT>
+__global__ __launch_bounds__(256) void k_transitions(const KParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using T = typename TargetSel<TARGET, E>::type;
+    const LaneCtx<E> cx = make_ctx<E, GT>(p);
+    T tg;
+    tg.init(p, cx, reinterpret_cast<double*>(smem));
+
+    constexpr bool NEEDG = (SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_HMC);
+    double x[E], g[E], vp[E], sm[E], sq[E];
+    load_vec<E>(cx, p.X, p.D, x);
+    if (NEEDG) load_vec<E>(cx, p.GR, p.D, g);
+    if (SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_SLICE) load_param<E>(cx, p.vecparam, p.D, 1.0, vp);
+    double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
+    const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
+    TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix] };
+    const bool do_sum = p.sum != nullptr;
+    if (do_sum) { load_vec<E>(cx, p.sum, p.D, sm); load_vec<E>(cx, p.sumsq, p.D, sq); }
+    const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
+    unsigned long long nacc = 0;
+    bool stuck = false;
+
+    for (int s = 0; s < p.nsteps; ++s) {
+        const unsigned long long t = p.t0 + (unsigned long long)s;
+        if (p.cnt) tn.proposed += 1;
+        bool acc;
+        if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E>(p, tg, cx, gchain, t, vp, x, lt);
+        else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E>(p, tg, cx, gchain, t, tn.step, x, g, lt);
+        else if (SAMPLER == KLARA_SAMPLER_HMC) acc = step_hmc<T, E>(p, tg, cx, gchain, t, tn.step, x, g, lt);
+        else acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, x, lt, stuck);
+        nacc += acc ? 1ull : 0ull;
+        if (p.cnt && acc) tn.accepted += 1;
+        if (p.accept != nullptr && cx.chain_ok && cx.q == 0)
+            p.accept[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
+        if (!p.pooled) tuning_block(p, tn);
+        // save rule: BasicMCJob.jl:226-231 with postrange = (burnin+1):thinning:nsteps (BasicMCRange.jl:36)
+        const long long i1 = (long long)t + 1;
+        if (i1 > p.burnin && ((i1 - p.burnin - 1) % p.thinning) == 0 && i1 <= p.nsteps_total) {
+            if (do_sum) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) { sm[e] = sm[e] + x[e]; sq[e] = sq[e] + x[e] * x[e]; }
+            }
+            if (p.hist != nullptr) {
+                const long long col = (i1 - p.burnin - 1) / p.thinning;
+                if (col < p.hist_cols) {
+                    double* dst = p.hist + (col * p.nchains + cx.chain) * p.D + cx.i0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) if (cx.valid[e]) dst[e] = x[e];
+                }
+            }
+        }
+    }
+
+    store_vec<E>(cx, p.X, p.D, x);
+    if (NEEDG) store_vec<E>(cx, p.GR, p.D, g);
+    if (do_sum) { store_vec<E>(cx, p.sum, p.D, sm); store_vec<E>(cx, p.sumsq, p.D, sq); }
+    if (cx.chain_ok && cx.q == 0) {
+        p.LT[cx.chain] = lt;
+        p.naccept[cx.chain] += nacc;
+        if (!p.pooled) {
+            p.tune_step[cx.chain] = tn.step;
+            p.tune_accepted[cx.chain] = tn.accepted;
+            p.tune_proposed[cx.chain] = tn.proposed;
+            p.tune_totproposed[cx.chain] = tn.totproposed;
+        } else if (p.cnt) {
+            atomicAdd(p.pooled_accepted, (unsigned long long)tn.accepted - (unsigned long long)p.tune_accepted[0]);
+        }
+        if (stuck) atomicMax(p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
+    }
+}
+
+// initialize!(pstate, parameter, sampler): evaluate lt (and gradient) at X and check finiteness —
+// MH.jl:72-85, MALA.jl:76-90, HMC.jl:106-120, SliceSampler.jl:40-48
+template <int TARGET, int E, int GT>
+__global__ __launch_bounds__(256) void k_init(const KParams p, int needgrad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using T = typename TargetSel<TARGET, E>::type;
+    const LaneCtx<E> cx = make_ctx<E, GT>(p);
+    T tg;
+    tg.init(p, cx, reinterpret_cast<double*>(smem));
+    double x[E], g[E], red[1];
+    load_vec<E>(cx, p.X, p.D, x);
+    tg.template eval<true, true>(cx, x, red[0], g);
+    group_allreduce<1>(red, cx.G, cx.lane);
+    const double lt = tg.finalize(red[0]);
+    bool bad = cx.chain_ok && !kfinite(lt);
+    if (needgrad) {
+        store_vec<E>(cx, p.GR, p.D, g);
+#pragma unroll
+        for (int e = 0; e < E; ++e) bad = bad || (cx.valid[e] && !kfinite(g[e]));
+    }
+    if (cx.chain_ok && cx.q == 0) p.LT[cx.chain] = lt;
+    if (bad) atomicMax(p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
+}
+
+// x0 ~ N(0, I) from the init stream (transition index 2^40-1)
+template <int E, int GT>
+__global__ __launch_bounds__(256) void k_init_normal(const KParams p)
+{
+    const LaneCtx<E> cx = make_ctx<E, GT>(p);
+    double z[E];
+    lane_normals<E>(cx, p.seed, (unsigned long long)(p.chain_offset + cx.chain), KLARA_INIT_TRANSITION, z);
+    store_vec<E>(cx, p.X, p.D, z);
+}
+
+// launcher signature shared by the per-sampler translation units
+typedef void (*klara_launch_fn)(const KParams& p, int target, int E, int G, dim3 grid, size_t lds,
+                                hipStream_t stream);

@@ -1,0 +1,35 @@
+// klara_launch.h — launcher prototypes implemented by the per-sampler translation units
+#pragma once
+#include "klara_kernels.h"
+
+// group-layout transition kernels; target in {GAUSS_DIAG, LOGISTIC}; E in {2,4,8}; G = lanes per chain
+hipError_t klara_launch_mh(const KParams& p, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
+hipError_t klara_launch_mala(const KParams& p, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
+hipError_t klara_launch_hmc(const KParams& p, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
+hipError_t klara_launch_slice(const KParams& p, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
+// dense (MFMA) kernels; NE in {8,16,25,32}
+hipError_t klara_launch_dense(const KParams& p, int sampler, int NE, const double* Pfrag, dim3 grid,
+                              hipStream_t st);
+hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag, int needgrad, dim3 grid,
+                                   hipStream_t st);
+hipError_t klara_launch_mfma_probe(const double* A, const double* B, const double* C, double* D,
+                                   hipStream_t st);
+
+// dispatch helper used by every group-layout launcher
+#define KLARA_DISPATCH_GROUP(KERNEL_EXPR_PREFIX, SAMPLER)                                              \
+    do {                                                                                               \
+        const dim3 blk(256);                                                                           \
+        if (target == KLARA_TARGET_GAUSS_DIAG) {                                                       \
+            if (E == 2 && G == 64) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 2, 64>), grid, blk, lds, st, p); \
+            else if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 2, 0>), grid, blk, lds, st, p);       \
+            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 4, 0>), grid, blk, lds, st, p);       \
+            else if (E == 8) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 8, 0>), grid, blk, lds, st, p);       \
+            else return hipErrorInvalidValue;                                                          \
+        } else if (target == KLARA_TARGET_LOGISTIC) {                                                  \
+            if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 2, 0>), grid, blk, lds, st, p);              \
+            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 4, 0>), grid, blk, lds, st, p);         \
+            else if (E == 8) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 8, 0>), grid, blk, lds, st, p);         \
+            else return hipErrorInvalidValue;                                                          \
+        } else return hipErrorInvalidValue;                                                            \
+        return hipGetLastError();                                                                      \
+    } while (0)

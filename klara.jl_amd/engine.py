@@ -1,0 +1,249 @@
+"""Thin object wrapper over the C ABI (one Engine = one klara_handle = N chains on one GPU).
+
+Host buffers are NumPy arrays; nothing here computes a transition — every call forwards to
+libklara_hip.so (see include/klara_hip.h for the reference lines each entry point replaces).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+# ------------------------------------------------------------------ target families
+@dataclass
+class GaussDiagTarget:
+    """lt = c - sum_i w_i (x_i - mu_i)^2 (KLARA_TARGET_GAUSS_DIAG).
+
+    README.md:23 `plogtarget(z) = -dot(z, z)` is `GaussDiagTarget.negdot(D)`;
+    MvNormal(mu, sigma) closures of test/BasicContMuvParameter.jl:39-56,88-100 are `mvnormal(mu, sigma)`.
+    """
+    ndims: int
+    w: Optional[np.ndarray] = None
+    mu: Optional[np.ndarray] = None
+    const: float = 0.0
+    kind = L.TARGET_GAUSS_DIAG
+
+    @classmethod
+    def negdot(cls, ndims: int) -> "GaussDiagTarget":
+        return cls(int(ndims))
+
+    @classmethod
+    def mvnormal(cls, mu, sigma) -> "GaussDiagTarget":
+        mu = _f64(mu).ravel()
+        sigma = np.broadcast_to(_f64(sigma).ravel(), mu.shape).astype(np.float64)
+        d = mu.size
+        const = -0.5 * d * np.log(2.0 * np.pi) - float(np.sum(np.log(sigma)))
+        return cls(d, w=1.0 / (2.0 * sigma * sigma), mu=mu.copy(), const=float(const))
+
+
+@dataclass
+class GaussDenseTarget:
+    """lt = c - 1/2 x' P x with a dense D x D precision matrix (KLARA_TARGET_GAUSS_DENSE, FP64 MFMA)."""
+    precision: np.ndarray
+    const: float = 0.0
+    kind = L.TARGET_GAUSS_DENSE
+
+    def __post_init__(self):
+        self.precision = _f64(self.precision)
+        if self.precision.ndim != 2 or self.precision.shape[0] != self.precision.shape[1]:
+            raise ValueError("precision must be square")
+
+    @property
+    def ndims(self) -> int:
+        return int(self.precision.shape[0])
+
+    @classmethod
+    def compound_symmetric(cls, ndims: int, rho: float = 0.5) -> "GaussDenseTarget":
+        """Sigma = (1-rho) I + rho 11' ; closed-form inverse (SURVEY §8(d) cfg 3)."""
+        d = int(ndims)
+        prec = (np.eye(d) - (rho / (1.0 - rho + d * rho)) * np.ones((d, d))) / (1.0 - rho)
+        return cls(prec)
+
+
+@dataclass
+class LogisticTarget:
+    """Bayesian logistic regression, N(0, lambda I) prior (doc/examples/swiss/MALA/analytical.jl:11-18)."""
+    X: np.ndarray
+    y: np.ndarray
+    lam: float = 100.0
+    kind = L.TARGET_LOGISTIC
+
+    def __post_init__(self):
+        self.X = _f64(self.X)
+        self.y = _f64(self.y).ravel()
+        if self.X.ndim != 2 or self.X.shape[0] != self.y.size:
+            raise ValueError("X must be (ndata, D) and y (ndata,)")
+
+    @property
+    def ndims(self) -> int:
+        return int(self.X.shape[1])
+
+
+# ------------------------------------------------------------------ engine
+class Engine:
+    def __init__(self, *, sampler: int, target, nchains: int, nsteps: int, burnin: int = 0, thinning: int = 1,
+                 mh_sigma=None, driftstep: float = 1.0, leapstep: float = 0.1, nleaps: int = 10,
+                 slice_widths=None, slice_stepout: bool = True,
+                 tuner: int = L.TUNER_VANILLA, tuner_mode: int = L.TUNE_PER_CHAIN, targetrate: float = 0.0,
+                 score_k: float = 7.0, period: int = 100, verbose: bool = False,
+                 seed: int = 20260927, chain_offset: int = 0, device: int = 0, monitor: int = 0,
+                 steps_per_launch: int = 0, stream: int = 0):
+        self._lib = L.load()
+        self.target = target
+        self.ndims = int(target.ndims)
+        self.nchains = int(nchains)
+        self.nsteps, self.burnin, self.thinning = int(nsteps), int(burnin), int(thinning)
+        self.sampler = int(sampler)
+        self.monitor = int(monitor)
+        d = L.KlaraDesc()
+        d.struct_size = C.sizeof(L.KlaraDesc)
+        d.abi_version = L.KLARA_ABI_VERSION
+        d.sampler, d.target, d.tuner, d.tuner_mode = int(sampler), int(target.kind), int(tuner), int(tuner_mode)
+        d.nchains, d.chain_offset, d.ndims, d.device = self.nchains, int(chain_offset), self.ndims, int(device)
+        keep = []  # keep host arrays alive until klara_create returns
+        if mh_sigma is not None:
+            a = _f64(np.broadcast_to(_f64(mh_sigma).ravel(), (self.ndims,))); keep.append(a); d.mh_sigma = _ptr(a)
+        if slice_widths is not None:
+            a = _f64(np.broadcast_to(_f64(slice_widths).ravel(), (self.ndims,))); keep.append(a); d.slice_widths = _ptr(a)
+        d.driftstep, d.leapstep, d.nleaps, d.slice_stepout = float(driftstep), float(leapstep), int(nleaps), int(bool(slice_stepout))
+        d.targetrate, d.score_k, d.period, d.verbose = float(targetrate), float(score_k), int(period), int(bool(verbose))
+        d.nsteps, d.burnin, d.thinning = self.nsteps, self.burnin, self.thinning
+        if isinstance(target, GaussDiagTarget):
+            if target.w is not None:
+                a = _f64(target.w, (self.ndims,)); keep.append(a); d.gauss_w = _ptr(a)
+            if target.mu is not None:
+                a = _f64(target.mu, (self.ndims,)); keep.append(a); d.gauss_mu = _ptr(a)
+            d.gauss_const = float(target.const)
+        elif isinstance(target, GaussDenseTarget):
+            a = _f64(target.precision); keep.append(a); d.gauss_prec = _ptr(a)
+            d.gauss_const = float(target.const)
+        elif isinstance(target, LogisticTarget):
+            a = _f64(target.X); keep.append(a); d.logit_X = _ptr(a)
+            b = _f64(target.y); keep.append(b); d.logit_y = _ptr(b)
+            d.logit_ndata, d.logit_lambda = int(target.X.shape[0]), float(target.lam)
+        else:
+            raise TypeError(f"unknown target family {type(target).__name__}")
+        d.seed, d.monitor, d.steps_per_launch = int(seed), self.monitor, int(steps_per_launch)
+        d.stream = C.c_void_p(int(stream)) if stream else None
+        self._h = C.c_void_p()
+        L.check(self._lib.klara_create(C.byref(d), C.byref(self._h)), "klara_create")
+        del keep
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.klara_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- state
+    def set_state(self, x):
+        x = _f64(x, (self.nchains, self.ndims))
+        L.check(self._lib.klara_set_state(self._h, x.ctypes.data), "klara_set_state")
+
+    def init_state_normal(self):
+        L.check(self._lib.klara_init_state_normal(self._h), "klara_init_state_normal")
+
+    def reset(self, x=None):
+        if x is None:
+            L.check(self._lib.klara_reset(self._h, None), "klara_reset")
+        else:
+            x = _f64(x, (self.nchains, self.ndims))
+            L.check(self._lib.klara_reset(self._h, x.ctypes.data), "klara_reset")
+
+    def run(self, nsteps: int):
+        L.check(self._lib.klara_run(self._h, int(nsteps)), "klara_run")
+
+    def run_async(self, nsteps: int):
+        L.check(self._lib.klara_run_async(self._h, int(nsteps)), "klara_run_async")
+
+    def synchronize(self):
+        L.check(self._lib.klara_synchronize(self._h), "klara_synchronize")
+
+    # -- read-back
+    def state(self):
+        x = np.empty((self.nchains, self.ndims)); lt = np.empty(self.nchains); g = np.empty((self.nchains, self.ndims))
+        L.check(self._lib.klara_get_state(self._h, x.ctypes.data, lt.ctypes.data, g.ctypes.data), "klara_get_state")
+        return x, lt, g
+
+    def accept_mask(self) -> np.ndarray:
+        n = C.c_int64(0)
+        L.check(self._lib.klara_get_accept_mask(self._h, None, 0, C.byref(n)), "klara_get_accept_mask")
+        m = np.empty((n.value, self.nchains), dtype=np.uint8)
+        L.check(self._lib.klara_get_accept_mask(self._h, m.ctypes.data, n.value, C.byref(n)), "klara_get_accept_mask")
+        return m
+
+    def accept_counts(self):
+        a = np.empty(self.nchains, dtype=np.uint64); n = C.c_uint64(0)
+        L.check(self._lib.klara_get_accept_counts(self._h, a.ctypes.data, C.byref(n)), "klara_get_accept_counts")
+        return a, int(n.value)
+
+    def chain_sums(self):
+        s = np.empty((self.nchains, self.ndims)); q = np.empty((self.nchains, self.ndims)); n = C.c_int64(0)
+        L.check(self._lib.klara_get_chain_sums(self._h, s.ctypes.data, q.ctypes.data, C.byref(n)), "klara_get_chain_sums")
+        return s, q, int(n.value)
+
+    def pooled_summaries(self, with_sums: bool = True):
+        s = np.empty(self.ndims) if with_sums else None
+        q = np.empty(self.ndims) if with_sums else None
+        na, nt, ns = C.c_uint64(0), C.c_uint64(0), C.c_int64(0)
+        L.check(self._lib.klara_get_pooled_summaries(
+            self._h, s.ctypes.data if with_sums else None, q.ctypes.data if with_sums else None,
+            C.byref(na), C.byref(nt), C.byref(ns)), "klara_get_pooled_summaries")
+        return s, q, int(na.value), int(nt.value), int(ns.value)
+
+    def chain(self, local_chain: int) -> np.ndarray:
+        """One chain's saved values in Klara's NState layout: (ndims, nsaved), column-major."""
+        n = C.c_int64(0)
+        L.check(self._lib.klara_get_chain(self._h, int(local_chain), None, 0, C.byref(n)), "klara_get_chain")
+        v = np.empty((self.ndims, n.value), order="F")
+        L.check(self._lib.klara_get_chain(self._h, int(local_chain), v.ctypes.data, n.value, C.byref(n)), "klara_get_chain")
+        return v
+
+    def tune(self):
+        step = np.empty(self.nchains); a = np.empty(self.nchains, dtype=np.int64)
+        p = np.empty(self.nchains, dtype=np.int64); t = np.empty(self.nchains, dtype=np.int64)
+        L.check(self._lib.klara_get_tune(self._h, step.ctypes.data, a.ctypes.data, p.ctypes.data, t.ctypes.data), "klara_get_tune")
+        return step, a, p, t
+
+    def last_run_ms(self):
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        L.check(self._lib.klara_last_run_ms(self._h, C.byref(ms), C.byref(n)), "klara_last_run_ms")
+        return float(ms.value), int(n.value)
+
+    def layout(self):
+        k, g, e = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        L.check(self._lib.klara_get_layout(self._h, C.byref(k), C.byref(g), C.byref(e)), "klara_get_layout")
+        return int(k.value), int(g.value), int(e.value)
+
+    def device_ptrs(self):
+        x, lt, g = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.check(self._lib.klara_device_ptrs(self._h, C.byref(x), C.byref(lt), C.byref(g)), "klara_device_ptrs")
+        return x.value, lt.value, g.value

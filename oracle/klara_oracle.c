@@ -1,0 +1,561 @@
+/* klara_oracle.c — CPU restatement of Klara.jl's sampler transition path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product (libklara_hip.so and the klara_jl_amd host package) never links, imports or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" for sampler trajectories — the reference holds no golden sampler
+ * outputs (test/runtests.jl:1-17 runs no sampler/job test) and never seeds its RNG
+ * (iterate/MH.jl:79,97; MALA.jl:84,94; HMC.jl:135,165; SliceSampler.jl:66,71,93), and Julia is not
+ * installed here, so the reference cannot be run.  Pinned pieces: the tuner score functions
+ * (test/common.jl:6, test/AcceptanceRateMCTuner.jl:8-14), the Gaussian target closures
+ * (test/BasicContMuvParameter.jl:39-56,62-80,...), the NState column layout
+ * (test/ParameterNStates.jl:139-146), Philox4x32-10 (Random123 known-answer vectors) — see
+ * tests/test_oracle_kats.py.  Beyond that the oracle is checked against analytic posterior moments.
+ *
+ * Each function cites the reference lines it restates.  Arithmetic follows the Julia expressions
+ * literally (no fma contraction, same association); the only liberty is the summation order of
+ * `sum`/`dot` (unspecified in Julia: BLAS ddot / pairwise SIMD sum), which is fixed to the order the
+ * gfx950 kernels use (lane partials, then a pairwise tree over lanes — see ko_layout).
+ *
+ * Random stream (build-defined; the reference's is unseeded MT19937): Philox4x32-10, key = seed,
+ * counter = (transition << 24 | slot, global chain id) — detmath.h kd_stream_block.
+ *   normals of a transition: element i <- block slot (i >> 1), Box-Muller cos branch for even i,
+ *     sin branch for odd i;
+ *   accept uniform (MH, MALA, HMC): slot ceil(D/2), words (x,y);
+ *   slice sampler, coordinate i: slot (i << 14): words (x,y) -> log-uniform, (z,w) -> runiform;
+ *     shrink attempt a >= 1: slot (i << 14) | a, words (x,y).
+ *   initial state x0 ~ N(0,I): transition index 2^40 - 1 ("-1"), same element -> slot mapping.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include "../include/klara_hip.h"
+#include "../klara.jl_amd/csrc/detmath.h"
+
+#define KO_MAXD 1024
+#define KO_SLICE_ATT_BITS 14
+#define KO_SLICE_MAX_ATT ((1 << KO_SLICE_ATT_BITS) - 1)
+#define KO_INIT_TRANSITION ((((uint64_t)1) << 40) - 1)
+
+/* lane layout of the device kernels — determines summation order only */
+typedef struct ko_layout {
+    int32_t kind; /* 0: element i on lane i / E (E contiguous elements per lane), G lanes per chain
+                     1: element i on lane-quarter i % 4 (MFMA-transposed), 4 lanes per chain     */
+    int32_t G;
+    int32_t E;
+} ko_layout;
+
+static double ko_reduce(const ko_layout* L, const double* terms, int D)
+{
+    double part[64], nw[64];
+    const int G = (L->kind == 1) ? 4 : L->G;
+    for (int l = 0; l < G; ++l) part[l] = 0.0;
+    for (int i = 0; i < D; ++i) {
+        const int lane = (L->kind == 1) ? (i & 3) : (i / L->E);
+        part[lane] = part[lane] + terms[i];
+    }
+    for (int m = 1; m < G; m <<= 1) {
+        for (int l = 0; l < G; ++l) nw[l] = part[l] + part[l ^ m];
+        memcpy(part, nw, sizeof(double) * (size_t)G);
+    }
+    return part[0];
+}
+
+/* ------------------------------------------------------------------ tuner scores */
+/* src/stats/logistic.jl:11  logistic(x, l, k, x0, y0) = l/(1+exp(-k*(x-x0)))+y0 */
+double ko_logistic(double x, double l, double k, double x0, double y0)
+{
+    return l / (1.0 + kd_exp(-k * (x - x0))) + y0;
+}
+/* src/tuners/AcceptanceRateMCTuner.jl:9  logistic_rate_score(x, k=7.) = logistic(x, 2., k, 0., 0.) */
+double ko_logistic_rate_score(double x, double k) { return ko_logistic(x, 2.0, k, 0.0, 0.0); }
+/* src/tuners/AcceptanceRateMCTuner.jl:17 erf_rate_score(x, k=3.) = erf(k*x)+1  (libm erf; host-only) */
+double ko_erf_rate_score(double x, double k) { return erf(k * x) + 1.0; }
+
+/* ------------------------------------------------------------------ targets */
+typedef struct ko_target_ctx {
+    const klara_desc* d;
+    const ko_layout* L;
+    double logit_lpconst; /* D*log(2*pi*lambda) */
+} ko_target_ctx;
+
+/* README.md:23 `-dot(z,z)`, :155 `-2*z`; MvNormal forms of test/BasicContMuvParameter.jl:39-56 */
+static double ko_diag_lt(const ko_target_ctx* c, const double* x, double* scratch)
+{
+    const klara_desc* d = c->d;
+    for (int i = 0; i < d->ndims; ++i) {
+        const double mu = d->gauss_mu ? d->gauss_mu[i] : 0.0;
+        const double w = d->gauss_w ? d->gauss_w[i] : 1.0;
+        const double dd = x[i] - mu;
+        scratch[i] = w * (dd * dd);
+    }
+    return d->gauss_const - ko_reduce(c->L, scratch, d->ndims);
+}
+static void ko_diag_grad(const ko_target_ctx* c, const double* x, double* g)
+{
+    const klara_desc* d = c->d;
+    for (int i = 0; i < d->ndims; ++i) {
+        const double mu = d->gauss_mu ? d->gauss_mu[i] : 0.0;
+        const double w = d->gauss_w ? d->gauss_w[i] : 1.0;
+        g[i] = (-2.0 * w) * (x[i] - mu);
+    }
+}
+
+/* dense Gaussian: builder-defined target (SURVEY F8/§8(d) cfg 3). g = -(P d) as a k-ascending fma
+ * chain per row (the order of v_mfma_f64_16x16x4_f64 accumulation); lt = c + 1/2 sum_i d_i g_i. */
+static void ko_dense_grad(const ko_target_ctx* c, const double* x, double* g)
+{
+    const klara_desc* d = c->d;
+    const int D = d->ndims;
+    double dd[KO_MAXD];
+    for (int i = 0; i < D; ++i) dd[i] = x[i] - (d->gauss_mu ? d->gauss_mu[i] : 0.0);
+    for (int i = 0; i < D; ++i) {
+        double acc = 0.0;
+        const double* row = d->gauss_prec + (size_t)i * D;
+        for (int k = 0; k < D; ++k) acc = kd_fma(row[k], dd[k], acc);
+        g[i] = -acc;
+    }
+}
+static double ko_dense_lt_from_grad(const ko_target_ctx* c, const double* x, const double* g, double* scratch)
+{
+    const klara_desc* d = c->d;
+    for (int i = 0; i < d->ndims; ++i) {
+        const double dd = x[i] - (d->gauss_mu ? d->gauss_mu[i] : 0.0);
+        scratch[i] = dd * g[i];
+    }
+    return d->gauss_const + 0.5 * ko_reduce(c->L, scratch, d->ndims);
+}
+
+/* doc/examples/swiss/MALA/analytical.jl:11-18 (ploglikelihood, plogprior, pgradlogtarget);
+ * lt = loglikelihood + logprior (BasicContMuvParameter.jl:184-189).  Row sums are sequential over
+ * the data index (the device evaluates one chain per lane). */
+static void ko_logit_eval(const ko_target_ctx* c, const double* p, double* lt, double* g)
+{
+    const klara_desc* d = c->d;
+    const int D = d->ndims, n = d->logit_ndata;
+    double dotxy = 0.0, slog = 0.0, gacc[KO_MAXD];
+    for (int k = 0; k < D; ++k) gacc[k] = 0.0;
+    for (int r = 0; r < n; ++r) {
+        const double* row = d->logit_X + (size_t)r * D;
+        double xp = 0.0;
+        for (int k = 0; k < D; ++k) xp = kd_fma(row[k], p[k], xp);            /* Xp = v[2]*p        */
+        if (lt) {
+            dotxy = dotxy + xp * d->logit_y[r];                                 /* dot(Xp, v[3])      */
+            slog = slog + kd_log(1.0 + kd_exp(xp));                             /* sum(log(1+exp(Xp)))*/
+        }
+        if (g) {
+            const double res = d->logit_y[r] - 1.0 / (1.0 + kd_exp(-xp));       /* v[3]-1./(1+exp(-Xp)) */
+            for (int k = 0; k < D; ++k) gacc[k] = kd_fma(row[k], res, gacc[k]); /* v[2]'*(...)        */
+        }
+    }
+    if (lt) {
+        double pp[KO_MAXD];
+        for (int k = 0; k < D; ++k) pp[k] = p[k] * p[k];
+        const double dotpp = ko_reduce(c->L, pp, D);
+        const double ll = dotxy - slog;
+        const double lp = -0.5 * (dotpp / d->logit_lambda + c->logit_lpconst);  /* plogprior          */
+        *lt = ll + lp;
+    }
+    if (g) for (int k = 0; k < D; ++k) g[k] = gacc[k] - p[k] / d->logit_lambda; /* -p/v[1]            */
+}
+
+/* logtarget!(state) — BasicContMuvParameter.jl:174-201 */
+static double ko_logtarget(const ko_target_ctx* c, const double* x, double* scratch)
+{
+    switch (c->d->target) {
+    case KLARA_TARGET_GAUSS_DIAG: return ko_diag_lt(c, x, scratch);
+    case KLARA_TARGET_GAUSS_DENSE: {
+        double g[KO_MAXD];
+        ko_dense_grad(c, x, g);
+        return ko_dense_lt_from_grad(c, x, g, scratch);
+    }
+    default: { double lt; ko_logit_eval(c, x, &lt, NULL); return lt; }
+    }
+}
+/* gradlogtarget!(state) — BasicContMuvParameter.jl:192-201 */
+static void ko_gradlogtarget(const ko_target_ctx* c, const double* x, double* g)
+{
+    switch (c->d->target) {
+    case KLARA_TARGET_GAUSS_DIAG: ko_diag_grad(c, x, g); break;
+    case KLARA_TARGET_GAUSS_DENSE: ko_dense_grad(c, x, g); break;
+    default: ko_logit_eval(c, x, NULL, g); break;
+    }
+}
+/* uptogradlogtarget!(state) = logtarget! then gradlogtarget! — BasicContMuvParameter.jl:270-274 */
+static double ko_uptograd(const ko_target_ctx* c, const double* x, double* g, double* scratch)
+{
+    switch (c->d->target) {
+    case KLARA_TARGET_GAUSS_DIAG: ko_diag_grad(c, x, g); return ko_diag_lt(c, x, scratch);
+    case KLARA_TARGET_GAUSS_DENSE: ko_dense_grad(c, x, g); return ko_dense_lt_from_grad(c, x, g, scratch);
+    default: { double lt; ko_logit_eval(c, x, &lt, g); return lt; }
+    }
+}
+
+/* ------------------------------------------------------------------ random draws */
+static void ko_normals(uint64_t seed, uint64_t chain, uint64_t t, int D, double* z)
+{
+    for (int j = 0; 2 * j < D; ++j) {
+        double z0, z1;
+        kd_normal_pair(kd_stream_block(seed, chain, t, (uint32_t)j), &z0, &z1);
+        z[2 * j] = z0;
+        if (2 * j + 1 < D) z[2 * j + 1] = z1;
+    }
+}
+static double ko_accept_uniform(uint64_t seed, uint64_t chain, uint64_t t, int D)
+{
+    return kd_uniform_xy(kd_stream_block(seed, chain, t, (uint32_t)((D + 1) / 2)));
+}
+
+/* ------------------------------------------------------------------ per-chain state bundle */
+typedef struct ko_tune { double step; int64_t accepted, proposed, totproposed; double rate; } ko_tune;
+
+static int ko_isfinite(double v) { return v == v && v - v == 0.0; }
+
+/* rate!(tune), reset_burnin!(tune) — src/tuners/tuners.jl:27-32; tune!(tune, tuner) —
+ * src/tuners/AcceptanceRateMCTuner.jl:46.  pool = number of chains sharing the tune (1 per-chain). */
+static void ko_tuning_block(const klara_desc* d, ko_tune* tn, int cnt, int64_t pool)
+{
+    if (!cnt) return;
+    if (tn->totproposed <= d->burnin && (tn->proposed % d->period) == 0) {   /* MALA.jl:131 / HMC.jl:204 */
+        tn->rate = (double)tn->accepted / (double)(tn->proposed * pool);      /* rate!                    */
+        if (d->tuner == KLARA_TUNER_ACCEPT_RATE && d->sampler != KLARA_SAMPLER_MH)
+            tn->step *= ko_logistic_rate_score(tn->rate - d->targetrate, d->score_k); /* tune!            */
+        tn->totproposed += tn->proposed;                                      /* reset_burnin!            */
+        tn->accepted = 0; tn->proposed = 0; tn->rate = NAN;
+    }
+}
+
+/* CNT predicate ("count proposals/accepts"): MH.jl(iterate):73 `tuner.verbose`;
+ * MALA.jl(iterate):79 / HMC.jl(iterate):129-133 `(Vanilla && verbose) || AcceptanceRate`. */
+static int ko_cnt(const klara_desc* d)
+{
+    if (d->sampler == KLARA_SAMPLER_MH || d->sampler == KLARA_SAMPLER_SLICE) return d->verbose != 0;
+    return (d->tuner == KLARA_TUNER_VANILLA && d->verbose) || d->tuner == KLARA_TUNER_ACCEPT_RATE;
+}
+
+/* ------------------------------------------------------------------ transitions */
+/* iterate!(job, MH, Multivariate) — src/samplers/iterate/MH.jl:72-124, symmetric normalised branch */
+static int ko_mh(const ko_target_ctx* c, uint64_t chain, uint64_t t, double* x, double* lt)
+{
+    const klara_desc* d = c->d;
+    const int D = d->ndims;
+    double z[KO_MAXD], xp[KO_MAXD], scratch[KO_MAXD];
+    ko_normals(d->seed, chain, t, D, z);
+    for (int i = 0; i < D; ++i) xp[i] = x[i] + d->mh_sigma[i] * z[i];  /* :79 rand(MvNormal(x, sigma)) */
+    const double ltp = ko_logtarget(c, xp, scratch);                    /* :81 */
+    const double ratio = ltp - *lt;                                     /* :83 */
+    int acc = ratio > 0.0;                                              /* :97 */
+    if (!acc) acc = ratio > kd_log(ko_accept_uniform(d->seed, chain, t, D));
+    if (acc) { memcpy(x, xp, sizeof(double) * (size_t)D); *lt = ltp; }  /* :98-100 */
+    return acc;
+}
+
+/* iterate!(job, MALA, Multivariate) — src/samplers/iterate/MALA.jl:78-128 */
+static int ko_mala(const ko_target_ctx* c, uint64_t chain, uint64_t t, double h,
+                   double* x, double* g, double* lt)
+{
+    const klara_desc* d = c->d;
+    const int D = d->ndims;
+    double z[KO_MAXD], mu[KO_MAXD], xp[KO_MAXD], gp[KO_MAXD], s1[KO_MAXD], s2[KO_MAXD], scratch[KO_MAXD];
+    ko_normals(d->seed, chain, t, D, z);
+    const double halfh = 0.5 * h, sq = sqrt(h);
+    for (int i = 0; i < D; ++i) mu[i] = x[i] + halfh * g[i];            /* :83 */
+    for (int i = 0; i < D; ++i) xp[i] = mu[i] + sq * z[i];              /* :84 */
+    const double ltp = ko_uptograd(c, xp, gp, scratch);                  /* :86 */
+    double ratio = ltp - *lt;                                            /* :88 */
+    for (int i = 0; i < D; ++i) { const double q = mu[i] - xp[i]; s1[i] = 0.5 * ((q * q) / h); }
+    ratio += ko_reduce(c->L, s1, D);                                     /* :90 */
+    for (int i = 0; i < D; ++i) {
+        const double mup = xp[i] + halfh * gp[i];                        /* :91 */
+        const double q = mup - x[i];
+        s2[i] = 0.5 * ((q * q) / h);
+    }
+    ratio -= ko_reduce(c->L, s2, D);                                     /* :92 */
+    int acc = ratio > 0.0;                                               /* :94 */
+    if (!acc) acc = ratio > kd_log(ko_accept_uniform(d->seed, chain, t, D));
+    if (acc) {                                                           /* :95-105 */
+        memcpy(x, xp, sizeof(double) * (size_t)D);
+        memcpy(g, gp, sizeof(double) * (size_t)D);
+        *lt = ltp;
+    }
+    return acc;
+}
+
+/* iterate!(job, HMC, Multivariate) — src/samplers/iterate/HMC.jl:124-201;
+ * leapfrog! — src/samplers/samplers.jl:122-134; hamiltonian — samplers.jl:103 */
+static int ko_hmc(const ko_target_ctx* c, uint64_t chain, uint64_t t, double eps, int nleaps,
+                  double* x, double* g, double* lt)
+{
+    const klara_desc* d = c->d;
+    const int D = d->ndims;
+    double p[KO_MAXD], xp[KO_MAXD], gp[KO_MAXD], sc[KO_MAXD], scratch[KO_MAXD];
+    ko_normals(d->seed, chain, t, D, p);                                 /* :135 */
+    for (int i = 0; i < D; ++i) sc[i] = p[i] * p[i];
+    const double H0 = *lt - 0.5 * ko_reduce(c->L, sc, D);                /* :137 */
+    memcpy(xp, x, sizeof(double) * (size_t)D);                           /* :139 */
+    memcpy(gp, g, sizeof(double) * (size_t)D);                           /* :140 */
+    const double halfe = 0.5 * eps;
+    for (int l = 0; l < nleaps; ++l) {                                   /* :146-155 */
+        for (int i = 0; i < D; ++i) p[i] = p[i] + halfe * gp[i];         /* samplers.jl:130 */
+        for (int i = 0; i < D; ++i) xp[i] = xp[i] + eps * p[i];          /* samplers.jl:131 */
+        ko_gradlogtarget(c, xp, gp);                                     /* samplers.jl:132 */
+        for (int i = 0; i < D; ++i) p[i] = p[i] + halfe * gp[i];         /* samplers.jl:133 */
+    }
+    double ltp;                                                          /* :157 logtarget!(x') */
+    if (d->target == KLARA_TARGET_GAUSS_DENSE) ltp = ko_dense_lt_from_grad(c, xp, gp, scratch);
+    else ltp = ko_logtarget(c, xp, scratch);
+    for (int i = 0; i < D; ++i) sc[i] = p[i] * p[i];
+    const double H1 = ltp - 0.5 * ko_reduce(c->L, sc, D);                /* :159 */
+    const double ratio = H1 - H0;                                        /* :161 */
+    const double e = kd_exp(ratio);
+    const double a = 1.0 < e ? 1.0 : e;                                  /* :163 min(1., exp(ratio)) */
+    const double u = ko_accept_uniform(d->seed, chain, t, D);            /* :165 rand() always drawn */
+    const int acc = u < a;
+    if (acc) {
+        memcpy(x, xp, sizeof(double) * (size_t)D);
+        memcpy(g, gp, sizeof(double) * (size_t)D);
+        *lt = ltp;
+    }
+    return acc;
+}
+
+/* iterate!(job, SliceSampler, Multivariate) — src/samplers/iterate/SliceSampler.jl:60-109 */
+static int ko_slice(const ko_target_ctx* c, uint64_t chain, uint64_t t, double* x, double* lt, int* stuck)
+{
+    const klara_desc* d = c->d;
+    const int D = d->ndims;
+    double tmp[KO_MAXD], scratch[KO_MAXD];
+    for (int i = 0; i < D; ++i) {                                        /* :65 */
+        const uint32_t base = (uint32_t)i << KO_SLICE_ATT_BITS;
+        const kd_u32x4 b0 = kd_stream_block(d->seed, chain, t, base);
+        const double logu = kd_log(kd_uniform_xy(b0)) + *lt;             /* :66 */
+        const double ru = kd_uniform_zw(b0);                             /* :71 */
+        const double w = d->slice_widths[i], xi = x[i];
+        double Li = xi - ru * w;                                         /* :72 */
+        double Ri = xi + (1.0 - ru) * w;                                 /* :73 */
+        memcpy(tmp, x, sizeof(double) * (size_t)D);
+        if (d->slice_stepout) {                                          /* :75-89 */
+            int guard = 0;
+            tmp[i] = Li;
+            double l = ko_logtarget(c, tmp, scratch);
+            while (l > logu) {
+                Li -= w; tmp[i] = Li; l = ko_logtarget(c, tmp, scratch);
+                if (++guard > KO_SLICE_MAX_ATT) { *stuck = 1; return 0; }
+            }
+            guard = 0;
+            tmp[i] = Ri;
+            l = ko_logtarget(c, tmp, scratch);
+            while (l > logu) {
+                Ri += w; tmp[i] = Ri; l = ko_logtarget(c, tmp, scratch);
+                if (++guard > KO_SLICE_MAX_ATT) { *stuck = 1; return 0; }
+            }
+        }
+        double xprime = xi;
+        for (uint32_t a = 1;; ++a) {                                     /* :91-106 */
+            if (a > KO_SLICE_MAX_ATT) { *stuck = 1; return 0; }
+            const double u = kd_uniform_xy(kd_stream_block(d->seed, chain, t, base | a));
+            xprime = u * (Ri - Li) + Li;                                 /* :92-93 */
+            tmp[i] = xprime;
+            *lt = ko_logtarget(c, tmp, scratch);                         /* :94 */
+            if (*lt > logu) break;                                       /* :95 */
+            if (xprime > xi) Ri = xprime;                                /* :98 */
+            else if (xprime < xi) Li = xprime;                           /* :100 */
+            else { *stuck = 1; return 0; }                               /* :102 */
+        }
+        x[i] = xprime;                                                   /* :108 */
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------ public entry points */
+static void ko_ctx_init(ko_target_ctx* c, const klara_desc* d, const ko_layout* L)
+{
+    c->d = d; c->L = L;
+    c->logit_lpconst = 0.0;
+    if (d->target == KLARA_TARGET_LOGISTIC)
+        c->logit_lpconst = (double)d->ndims * kd_log(2.0 * 3.141592653589793 * d->logit_lambda);
+}
+
+/* initialize!(pstate, parameter, sampler) — MH.jl:72-85, MALA.jl:76-90, HMC.jl:106-120,
+ * SliceSampler.jl:40-48; tuner_state — samplers.jl:29-45 (totproposed starts at tuner.period). */
+int ko_init(const klara_desc* d, const ko_layout* L, const double* X, double* G, double* LT,
+            double* step, int64_t* accepted, int64_t* proposed, int64_t* totproposed)
+{
+    ko_target_ctx c; ko_ctx_init(&c, d, L);
+    const int D = d->ndims;
+    if (D > KO_MAXD) return KLARA_ERR_UNSUPPORTED;
+    const int needgrad = d->sampler == KLARA_SAMPLER_MALA || d->sampler == KLARA_SAMPLER_HMC;
+    int bad = 0;
+    for (int64_t n = 0; n < d->nchains; ++n) {
+        double scratch[KO_MAXD];
+        const double* x = X + n * D;
+        if (needgrad) {
+            LT[n] = ko_uptograd(&c, x, G + n * D, scratch);
+            for (int i = 0; i < D; ++i) if (!ko_isfinite(G[n * D + i])) bad = 1;
+        } else {
+            LT[n] = ko_logtarget(&c, x, scratch);
+        }
+        if (!ko_isfinite(LT[n])) bad = 1;
+        const int pooled = d->tuner_mode == KLARA_TUNE_POOLED;
+        if (!pooled || n == 0) {
+            const int64_t k = pooled ? 0 : n;
+            step[k] = d->sampler == KLARA_SAMPLER_MH ? 1.0
+                    : d->sampler == KLARA_SAMPLER_MALA ? d->driftstep
+                    : d->sampler == KLARA_SAMPLER_HMC ? d->leapstep : NAN;
+            accepted[k] = 0; proposed[k] = 0; totproposed[k] = d->period;
+        }
+    }
+    return bad ? KLARA_ERR_NONFINITE_INIT : KLARA_OK;
+}
+
+/* x0 ~ N(0, I) from the init stream */
+void ko_init_state_normal(const klara_desc* d, double* X)
+{
+    for (int64_t n = 0; n < d->nchains; ++n)
+        ko_normals(d->seed, (uint64_t)(d->chain_offset + n), KO_INIT_TRANSITION, d->ndims, X + n * d->ndims);
+}
+
+/* one transition of one chain; returns accept flag */
+static int ko_transition(const ko_target_ctx* c, uint64_t gchain, uint64_t t, double step,
+                         double* x, double* g, double* lt, int* stuck)
+{
+    const klara_desc* d = c->d;
+    switch (d->sampler) {
+    case KLARA_SAMPLER_MH: return ko_mh(c, gchain, t, x, lt);
+    case KLARA_SAMPLER_MALA: return ko_mala(c, gchain, t, step, x, g, lt);
+    case KLARA_SAMPLER_HMC: return ko_hmc(c, gchain, t, step, d->nleaps, x, g, lt);
+    default: return ko_slice(c, gchain, t, x, lt, stuck);
+    }
+}
+
+/* run(job) — src/jobs/BasicMCJob.jl:212-244 for every chain.  t0 = number of transitions already
+ * done (the global 0-based index of the first transition of this call).  Outputs may be NULL:
+ *   accept_out[s * nchains + n]      diagnosticvalues[:accept] of transition t0+s
+ *   sum/sumsq[n * D + i]             accumulated over postrange steps (BasicMCRange.jl:17-36)
+ *   naccept[n]                       accepted transitions
+ *   hist[(col * nchains + n) * D + i] value saved as column `col` (save rule BasicMCJob.jl:226-231)
+ * Tuner arrays have nchains entries (per-chain mode) or 1 entry (pooled mode). */
+int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double* LT,
+           double* step, int64_t* accepted, int64_t* proposed, int64_t* totproposed,
+           int64_t t0, int64_t nsteps, uint8_t* accept_out, double* sum, double* sumsq,
+           uint64_t* naccept, double* hist, int64_t hist_cols)
+{
+    ko_target_ctx c; ko_ctx_init(&c, d, L);
+    const int D = d->ndims;
+    if (D > KO_MAXD) return KLARA_ERR_UNSUPPORTED;
+    const int cnt = ko_cnt(d);
+    const int pooled = d->tuner_mode == KLARA_TUNE_POOLED;
+    int stuck_any = 0;
+
+    if (!pooled) {
+#pragma omp parallel for schedule(static) reduction(| : stuck_any)
+        for (int64_t n = 0; n < d->nchains; ++n) {
+            double* x = X + n * D; double* g = G + n * D;
+            ko_tune tn = { step[n], accepted[n], proposed[n], totproposed[n], NAN };
+            int stuck = 0;
+            for (int64_t s = 0; s < nsteps && !stuck; ++s) {
+                const int64_t t = t0 + s;
+                if (cnt) tn.proposed += 1;
+                const int acc = ko_transition(&c, (uint64_t)(d->chain_offset + n), (uint64_t)t,
+                                              tn.step, x, g, &LT[n], &stuck);
+                if (stuck) break;
+                if (acc && cnt) tn.accepted += 1;
+                if (accept_out) accept_out[s * d->nchains + n] = (uint8_t)acc;
+                if (naccept) naccept[n] += (uint64_t)acc;
+                ko_tuning_block(d, &tn, cnt, 1);
+                const int64_t i1 = t + 1;                       /* 1-based step index i of run() */
+                if (i1 > d->burnin && (i1 - d->burnin - 1) % d->thinning == 0 && i1 <= d->nsteps) {
+                    const int64_t col = (i1 - d->burnin - 1) / d->thinning;
+                    if (sum) for (int i = 0; i < D; ++i) {
+                        sum[n * D + i] = sum[n * D + i] + x[i];
+                        sumsq[n * D + i] = sumsq[n * D + i] + x[i] * x[i];
+                    }
+                    if (hist && col < hist_cols)
+                        memcpy(hist + ((size_t)col * (size_t)d->nchains + (size_t)n) * (size_t)D, x,
+                               sizeof(double) * (size_t)D);
+                }
+            }
+            step[n] = tn.step; accepted[n] = tn.accepted; proposed[n] = tn.proposed;
+            totproposed[n] = tn.totproposed;
+            stuck_any |= stuck;
+        }
+    } else {
+        ko_tune tn = { step[0], accepted[0], proposed[0], totproposed[0], NAN };
+        for (int64_t s = 0; s < nsteps && !stuck_any; ++s) {
+            const int64_t t = t0 + s;
+            if (cnt) tn.proposed += 1;
+            int64_t nacc = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nacc) reduction(| : stuck_any)
+            for (int64_t n = 0; n < d->nchains; ++n) {
+                int stuck = 0;
+                double* x = X + n * D; double* g = G + n * D;
+                const int acc = ko_transition(&c, (uint64_t)(d->chain_offset + n), (uint64_t)t,
+                                              tn.step, x, g, &LT[n], &stuck);
+                stuck_any |= stuck;
+                nacc += acc;
+                if (accept_out) accept_out[s * d->nchains + n] = (uint8_t)acc;
+                if (naccept) naccept[n] += (uint64_t)acc;
+                const int64_t i1 = t + 1;
+                if (i1 > d->burnin && (i1 - d->burnin - 1) % d->thinning == 0 && i1 <= d->nsteps) {
+                    const int64_t col = (i1 - d->burnin - 1) / d->thinning;
+                    if (sum) for (int i = 0; i < D; ++i) {
+                        sum[n * D + i] = sum[n * D + i] + x[i];
+                        sumsq[n * D + i] = sumsq[n * D + i] + x[i] * x[i];
+                    }
+                    if (hist && col < hist_cols)
+                        memcpy(hist + ((size_t)col * (size_t)d->nchains + (size_t)n) * (size_t)D, x,
+                               sizeof(double) * (size_t)D);
+                }
+            }
+            if (cnt) tn.accepted += nacc;
+            ko_tuning_block(d, &tn, cnt, d->nchains);
+        }
+        step[0] = tn.step; accepted[0] = tn.accepted; proposed[0] = tn.proposed;
+        totproposed[0] = tn.totproposed;
+    }
+    return stuck_any ? KLARA_ERR_SLICE_STUCK : KLARA_OK;
+}
+
+/* ------------------------------------------------------------------ small exports for KATs */
+void ko_philox_block(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    const kd_u32x4 r = kd_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+void ko_stream_block(uint64_t seed, uint64_t chain, uint64_t t, uint32_t slot, uint32_t out[4])
+{
+    const kd_u32x4 r = kd_stream_block(seed, chain, t, slot);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+void ko_math(int op, int64_t n, const double* in, const double* in2, double* out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        double s, c;
+        switch (op) {
+        case 0: out[i] = kd_log(in[i]); break;
+        case 1: out[i] = kd_exp(in[i]); break;
+        case 2: kd_sincos2pi(in[i], &s, &c); out[i] = s; break;
+        case 3: kd_sincos2pi(in[i], &s, &c); out[i] = c; break;
+        case 4: out[i] = sqrt(in[i]); break;
+        default: out[i] = in[i] / in2[i]; break;
+        }
+    }
+}
+void ko_normal_pair(const uint32_t blk[4], double out[2])
+{
+    kd_u32x4 b = { blk[0], blk[1], blk[2], blk[3] };
+    kd_normal_pair(b, &out[0], &out[1]);
+}
+double ko_u52(uint32_t hi, uint32_t lo) { return kd_u52(hi, lo); }
+
+/* target closures for KATs: evaluates lt and gradient of one point */
+int ko_eval_target(const klara_desc* d, const ko_layout* L, const double* x, double* lt, double* g)
+{
+    ko_target_ctx c; ko_ctx_init(&c, d, L);
+    double scratch[KO_MAXD];
+    if (d->ndims > KO_MAXD) return KLARA_ERR_UNSUPPORTED;
+    *lt = ko_uptograd(&c, x, g, scratch);
+    return KLARA_OK;
+}

@@ -1,0 +1,132 @@
+"""Shared parity cases: the same configuration dict drives the product Engine (GPU) and the CPU oracle."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+import klara_jl_amd as K
+from klara_jl_amd import _lib as L
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def swiss_data():
+    """Swiss banknote design matrix, standardised as doc/examples/swiss/MALA/analytical.jl:3-9 does
+    ((x - mean) / std with the n-1 sample std), from the committed fixture of the reference's data files."""
+    raw = np.load(GOLDEN / "swiss.npz")
+    X = raw["measurements"]
+    X = (X - X.mean(axis=0)) / X.std(axis=0, ddof=1)
+    return np.ascontiguousarray(X), np.ascontiguousarray(raw["status"].astype(np.float64))
+
+
+def compound_symmetric_precision(d, rho=0.5):
+    return (np.eye(d) - (rho / (1.0 - rho + d * rho)) * np.ones((d, d))) / (1.0 - rho)
+
+
+def make_case(name):
+    """name -> dict(engine kwargs..., target=<family object>, x0=None|array)."""
+    c = {}
+    if name == "mh_readme":            # BASELINE cfg 1 (README.md:23-50), replicated over 8 chains
+        c = dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(2), nchains=8, nsteps=400, burnin=100,
+                 mh_sigma=[1.0, 1.0], x0=np.tile([5.1, -0.9], (8, 1)))
+    elif name == "mh_d100":
+        c = dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(100), nchains=70, nsteps=60, burnin=10,
+                 mh_sigma=np.full(100, 0.1))
+    elif name == "mh_mvnormal_d7":     # odd D, per-dim weights and means
+        mu = np.linspace(-2, 3, 7); sg = np.linspace(0.5, 2.0, 7)
+        c = dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.mvnormal(mu, sg), nchains=33, nsteps=80, burnin=0,
+                 mh_sigma=sg * 0.8)
+    elif name == "mala_d100":          # BASELINE cfg 2 shape at parity-test size
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=130, nsteps=50, burnin=10,
+                 driftstep=0.9)
+    elif name == "mala_d100_small_step":
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=66, nsteps=60, burnin=20,
+                 thinning=3, driftstep=0.05)
+    elif name == "mala_d3_tuned":      # AcceptanceRate tuner, per chain, several tuning events
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(3), nchains=50, nsteps=260, burnin=200,
+                 driftstep=1.5, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=25)
+    elif name == "mala_d300":          # E=4 layout
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(300), nchains=9, nsteps=20, burnin=0,
+                 driftstep=0.02)
+    elif name == "hmc_d100":           # north-star sampler on the README target
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.negdot(100), nchains=70, nsteps=30, burnin=5,
+                 leapstep=0.1, nleaps=10)
+    elif name == "hmc_d10_tuned_pooled":
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.negdot(10), nchains=40, nsteps=120, burnin=90,
+                 leapstep=0.9, nleaps=5, tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.65,
+                 period=20)
+    elif name == "hmc_dense_d100":     # BASELINE cfg 3 shape at parity-test size (FP64 MFMA path)
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(compound_symmetric_precision(100)), nchains=40,
+                 nsteps=12, burnin=2, leapstep=0.1, nleaps=10)
+    elif name == "hmc_dense_d37":      # ragged D (not a multiple of 4 or 16), random SPD precision
+        rng = np.random.default_rng(5)
+        a = rng.standard_normal((37, 37)); p = a @ a.T / 37 + np.eye(37)
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(p), nchains=19, nsteps=15, burnin=0,
+                 leapstep=0.15, nleaps=4)
+    elif name == "mala_dense_d100":
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDenseTarget(compound_symmetric_precision(100)), nchains=35,
+                 nsteps=20, burnin=0, driftstep=0.3)
+    elif name == "mh_dense_d20":
+        c = dict(sampler=L.SAMPLER_MH, target=K.GaussDenseTarget(compound_symmetric_precision(20, 0.3)), nchains=21,
+                 nsteps=40, burnin=0, mh_sigma=np.full(20, 0.3))
+    elif name == "mala_swiss":         # BASELINE cfg 4 shape at parity-test size
+        X, y = swiss_data()
+        x0 = np.array([5.1, -0.9, 8.2, -4.5])
+        c = dict(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, 100.0), nchains=70, nsteps=40, burnin=10,
+                 driftstep=0.1, x0=x0[None, :] + 0.1 * np.random.default_rng(1).standard_normal((70, 4)))
+    elif name == "hmc_swiss":
+        X, y = swiss_data()
+        c = dict(sampler=L.SAMPLER_HMC, target=K.LogisticTarget(X, y, 100.0), nchains=65, nsteps=12, burnin=0,
+                 leapstep=0.05, nleaps=6, x0=0.1 * np.random.default_rng(2).standard_normal((65, 4)))
+    elif name == "slice_d5":           # test/SliceSampler.jl-style: SliceSampler(1., 5)
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.negdot(5), nchains=40, nsteps=30, burnin=5,
+                 slice_widths=np.full(5, 1.0), slice_stepout=True)
+    elif name == "slice_d100_nostepout":
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.negdot(100), nchains=6, nsteps=4, burnin=0,
+                 slice_widths=np.full(100, 3.0), slice_stepout=False)
+    elif name == "slice_swiss":        # doc/examples/swiss/SliceSampler.jl shape
+        X, y = swiss_data()
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.LogisticTarget(X, y, 100.0), nchains=70, nsteps=6, burnin=0,
+                 slice_widths=np.full(4, 1.0), x0=0.1 * np.random.default_rng(3).standard_normal((70, 4)))
+    else:
+        raise KeyError(name)
+    c.setdefault("x0", None)
+    c.setdefault("seed", 20260927)
+    c["name"] = name
+    return c
+
+
+ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_small_step", "mala_d3_tuned",
+             "mala_d300", "hmc_d100", "hmc_d10_tuned_pooled", "hmc_dense_d100", "hmc_dense_d37", "mala_dense_d100",
+             "mh_dense_d20", "mala_swiss", "hmc_swiss", "slice_d5", "slice_d100_nostepout", "slice_swiss"]
+# cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
+GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
+                "mala_d3_tuned", "hmc_d10_tuned_pooled"]
+
+
+def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):
+    """Translate a case into OracleJob keyword arguments."""
+    t = case["target"]
+    kw = {k: v for k, v in case.items() if k not in ("target", "x0", "name")}
+    kw["target_kind"] = t.kind
+    kw["ndims"] = t.ndims
+    if isinstance(t, K.GaussDiagTarget):
+        kw.update(gauss_w=t.w, gauss_mu=t.mu, gauss_const=t.const)
+    elif isinstance(t, K.GaussDenseTarget):
+        kw.update(gauss_prec=t.precision, gauss_const=t.const)
+    else:
+        kw.update(logit_X=t.X, logit_y=t.y, logit_lambda=t.lam)
+    kw["layout"] = layout
+    kw["chain_offset"] = chain_offset
+    if nchains is not None:
+        kw["nchains"] = nchains
+    return kw
+
+
+def engine_kwargs(case, monitor=L.MON_ACCEPT | L.MON_SUMMARIES, **over):
+    kw = {k: v for k, v in case.items() if k not in ("x0", "name")}
+    kw["monitor"] = monitor
+    kw.update(over)
+    return kw

@@ -1,0 +1,43 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+if str(ROOT / "tests") not in sys.path:
+    sys.path.insert(0, str(ROOT / "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available() -> bool:
+    try:
+        import torch
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure): built on demand with gcc, loaded via ctypes."""
+    import oracle_ffi
+    return oracle_ffi.load()
+
+
+@pytest.fixture(scope="session")
+def klib():
+    """libklara_hip.so through the product's own binding; must already be built (build() does it)."""
+    import klara_jl_amd
+    return klara_jl_amd._lib.load()
+
+
+@pytest.fixture(scope="session")
+def gpu_required():
+    if not _gpu_available():
+        pytest.fail("-m gpu tests need a GPU: torch.cuda.is_available() is False")

@@ -1,0 +1,198 @@
+"""ctypes access to oracle/libklara_oracle.so — TEST INFRASTRUCTURE (never imported by the product).
+
+`run_oracle(**cfg)` executes the CPU restatement of the reference transition path on the same
+descriptor the product's C ABI takes and returns everything the parity tests compare.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+SO = ROOT / "oracle" / "libklara_oracle.so"
+
+import klara_jl_amd  # noqa: E402  (struct definition + enums only)
+from klara_jl_amd import _lib as L  # noqa: E402
+
+
+class KoLayout(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("G", C.c_int32), ("E", C.c_int32)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    srcs = [ROOT / "oracle" / "klara_oracle.c", ROOT / "include" / "klara_hip.h",
+            ROOT / "klara.jl_amd" / "csrc" / "detmath.h"]
+    if not SO.exists() or any(s.stat().st_mtime > SO.stat().st_mtime for s in srcs):
+        r = subprocess.run(["make", "-C", str(ROOT / "oracle")], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    lib = C.CDLL(str(SO))
+    vp = C.c_void_p
+    lib.ko_init.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout)] + [vp] * 7
+    lib.ko_init.restype = C.c_int
+    lib.ko_init_state_normal.argtypes = [C.POINTER(L.KlaraDesc), vp]
+    lib.ko_init_state_normal.restype = None
+    lib.ko_run.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout)] + [vp] * 7 + [C.c_int64, C.c_int64] + [vp] * 5 + [C.c_int64]
+    lib.ko_run.restype = C.c_int
+    lib.ko_philox_block.argtypes = [vp, vp, vp]
+    lib.ko_stream_block.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]
+    lib.ko_math.argtypes = [C.c_int, C.c_int64, vp, vp, vp]
+    lib.ko_normal_pair.argtypes = [vp, vp]
+    lib.ko_u52.argtypes = [C.c_uint32, C.c_uint32]
+    lib.ko_u52.restype = C.c_double
+    lib.ko_eval_target.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout), vp, vp, vp]
+    lib.ko_eval_target.restype = C.c_int
+    for name in ("ko_logistic",):
+        getattr(lib, name).argtypes = [C.c_double] * 5
+        getattr(lib, name).restype = C.c_double
+    for name in ("ko_logistic_rate_score", "ko_erf_rate_score"):
+        getattr(lib, name).argtypes = [C.c_double] * 2
+        getattr(lib, name).restype = C.c_double
+    _lib = lib
+    return lib
+
+
+def default_layout(target_kind: int, ndims: int):
+    """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box)."""
+    d = int(ndims)
+    if target_kind == L.TARGET_GAUSS_DENSE:
+        ne = 8 if d <= 32 else 16 if d <= 64 else 25 if d <= 100 else 32
+        return (1, 4, ne)
+    if target_kind == L.TARGET_LOGISTIC:
+        return (0, 1, 2 if d <= 2 else 4 if d <= 4 else 8)
+    e = 2 if d <= 128 else 4 if d <= 256 else 8
+    g = 1
+    while g < (d + e - 1) // e:
+        g *= 2
+    return (0, g, e)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class OracleJob:
+    """Holds a descriptor + state and steps it with ko_run."""
+
+    def __init__(self, *, sampler, target_kind, nchains, ndims, nsteps, burnin=0, thinning=1,
+                 mh_sigma=None, driftstep=1.0, leapstep=0.1, nleaps=10, slice_widths=None, slice_stepout=True,
+                 tuner=0, tuner_mode=0, targetrate=0.0, score_k=7.0, period=100, verbose=False,
+                 seed=20260927, chain_offset=0, gauss_w=None, gauss_mu=None, gauss_const=0.0, gauss_prec=None,
+                 logit_X=None, logit_y=None, logit_lambda=100.0, layout=None,
+                 want_accept=True, want_sums=True, want_hist=False):
+        self.lib = load()
+        self.N, self.D = int(nchains), int(ndims)
+        d = L.KlaraDesc()
+        d.struct_size = C.sizeof(L.KlaraDesc); d.abi_version = 1
+        d.sampler, d.target, d.tuner, d.tuner_mode = int(sampler), int(target_kind), int(tuner), int(tuner_mode)
+        d.nchains, d.chain_offset, d.ndims = self.N, int(chain_offset), self.D
+        self._keep = []
+
+        def ptr(a, n=None):
+            if a is None:
+                return None
+            a = _f64(np.broadcast_to(_f64(a).ravel(), (n,)) if n is not None else a)
+            self._keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_double))
+
+        d.mh_sigma = ptr(mh_sigma, self.D)
+        d.slice_widths = ptr(slice_widths, self.D)
+        d.driftstep, d.leapstep, d.nleaps, d.slice_stepout = float(driftstep), float(leapstep), int(nleaps), int(bool(slice_stepout))
+        d.targetrate, d.score_k, d.period, d.verbose = float(targetrate), float(score_k), int(period), int(bool(verbose))
+        d.nsteps, d.burnin, d.thinning = int(nsteps), int(burnin), int(thinning)
+        d.gauss_w, d.gauss_mu, d.gauss_const = ptr(gauss_w, self.D), ptr(gauss_mu, self.D), float(gauss_const)
+        d.gauss_prec = ptr(gauss_prec)
+        d.logit_X, d.logit_y = ptr(logit_X), ptr(logit_y)
+        d.logit_ndata = 0 if logit_y is None else int(np.size(logit_y))
+        d.logit_lambda = float(logit_lambda)
+        d.seed = int(seed)
+        self.desc = d
+        k, g, e = layout if layout is not None else default_layout(int(target_kind), self.D)
+        self.layout = KoLayout(k, g, e)
+        nt = 1 if tuner_mode == L.TUNE_POOLED else self.N
+        self.X = np.zeros((self.N, self.D)); self.G = np.zeros((self.N, self.D)); self.LT = np.zeros(self.N)
+        self.step = np.zeros(nt); self.accepted = np.zeros(nt, np.int64)
+        self.proposed = np.zeros(nt, np.int64); self.totproposed = np.zeros(nt, np.int64)
+        self.t = 0
+        self.naccept = np.zeros(self.N, np.uint64)
+        self.sum = np.zeros((self.N, self.D)) if want_sums else None
+        self.sumsq = np.zeros((self.N, self.D)) if want_sums else None
+        self.hist_cols = (int(nsteps) - int(burnin) - 1) // int(thinning) + 1
+        self.hist = np.zeros((self.hist_cols, self.N, self.D)) if want_hist else None
+        self.want_accept = want_accept
+        self.accept = np.zeros((0, self.N), np.uint8)
+
+    def _p(self, a):
+        return None if a is None else a.ctypes.data
+
+    def set_state(self, x) -> int:
+        self.X[...] = _f64(x).reshape(self.N, self.D)
+        return self._init()
+
+    def init_state_normal(self) -> int:
+        self.lib.ko_init_state_normal(C.byref(self.desc), self.X.ctypes.data)
+        return self._init()
+
+    def _init(self) -> int:
+        self.G[...] = 0.0
+        self.t = 0
+        self.naccept[...] = 0
+        if self.sum is not None:
+            self.sum[...] = 0.0; self.sumsq[...] = 0.0
+        self.accept = np.zeros((0, self.N), np.uint8)
+        return self.lib.ko_init(C.byref(self.desc), C.byref(self.layout), self._p(self.X), self._p(self.G),
+                                self._p(self.LT), self._p(self.step), self._p(self.accepted),
+                                self._p(self.proposed), self._p(self.totproposed))
+
+    def run(self, nsteps: int) -> int:
+        acc = np.zeros((nsteps, self.N), np.uint8) if self.want_accept else None
+        st = self.lib.ko_run(C.byref(self.desc), C.byref(self.layout), self._p(self.X), self._p(self.G),
+                             self._p(self.LT), self._p(self.step), self._p(self.accepted), self._p(self.proposed),
+                             self._p(self.totproposed), self.t, int(nsteps), self._p(acc), self._p(self.sum),
+                             self._p(self.sumsq), self._p(self.naccept), self._p(self.hist), self.hist_cols)
+        self.t += int(nsteps)
+        if acc is not None:
+            self.accept = np.concatenate([self.accept, acc], axis=0)
+        return st
+
+    def eval_target(self, x):
+        x = _f64(x).ravel()
+        lt = C.c_double(0.0)
+        g = np.zeros(self.D)
+        st = self.lib.ko_eval_target(C.byref(self.desc), C.byref(self.layout), x.ctypes.data, C.byref(lt), g.ctypes.data)
+        assert st == 0
+        return lt.value, g
+
+
+def philox_block(ctr, key):
+    lib = load()
+    c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+    lib.ko_philox_block(c, k, o)
+    return list(o)
+
+
+def stream_blocks(seed, chain, t, slots):
+    lib = load()
+    out = np.zeros((len(slots), 4), np.uint32)
+    o = (C.c_uint32 * 4)()
+    for i, s in enumerate(slots):
+        lib.ko_stream_block(int(seed), int(chain), int(t), int(s), o)
+        out[i] = list(o)
+    return out
+
+
+def math_op(op, x, y=None):
+    lib = load()
+    x = _f64(x); out = np.empty_like(x)
+    y = x if y is None else _f64(y)
+    lib.ko_math(int(op), x.size, x.ctypes.data, y.ctypes.data, out.ctypes.data)
+    return out

@@ -1,0 +1,59 @@
+"""world_size-2 gloo test of the only collective on the path: the all-reduce of pooled chain summaries."""
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    import torch.distributed as dist
+    import klara_jl_amd as K
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    off, cnt = K.shard_chains(10, rank, world)
+    rng = np.random.default_rng(100)            # same stream on both ranks; each takes its block
+    allx = rng.standard_normal((10, 50, 3))     # chains x saved steps x D
+    mine = allx[off:off + cnt]
+    local = {"sum": mine.sum((0, 1)), "sumsq": (mine ** 2).sum((0, 1)), "naccept": 7 * cnt,
+             "ntransitions": 60 * cnt, "nsamples": 50 * cnt}
+    out = K.allreduce_summaries(local)
+    q.put((rank, out["mean"], out["var"], out["acceptance"], out["nsamples"]))
+    dist.destroy_process_group()
+
+
+def test_summary_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    allx = np.random.default_rng(100).standard_normal((10, 50, 3)).reshape(-1, 3)
+    for _, m, v, a, ns in res:
+        assert ns == 500
+        assert np.allclose(m, allx.mean(0)) and np.allclose(v, allx.var(0))
+        assert a == 7 / 60
+
+
+def test_allreduce_single_process_derives_moments():
+    import klara_jl_amd as K
+    x = np.random.default_rng(1).standard_normal((40, 2))
+    out = K.allreduce_summaries({"sum": x.sum(0), "sumsq": (x ** 2).sum(0), "naccept": 10, "ntransitions": 40,
+                                 "nsamples": 40})
+    assert np.allclose(out["mean"], x.mean(0)) and np.allclose(out["var"], x.var(0)) and out["acceptance"] == 0.25

@@ -1,0 +1,111 @@
+"""CPU tests of the host-side mirror of the reference API and of the C-ABI library surface."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import klara_jl_amd as K
+from klara_jl_amd import _lib as L
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol(klib):
+    header = (ROOT / "include" / "klara_hip.h").read_text()
+    declared = set(re.findall(r"\b(klara_[a-z0-9_]+)\s*\(", header)) - {"klara_status"}
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    for name in declared:
+        assert hasattr(klib, name), name
+    assert klib.klara_abi_version() == 1
+
+
+def test_desc_struct_matches_header_layout():
+    # 8-byte aligned, no surprises: the struct is what INTEGRATION.md's ccall stub mirrors field by field
+    assert C.sizeof(L.KlaraDesc) % 8 == 0
+    assert L.KlaraDesc.nchains.offset == 24 and L.KlaraDesc.mh_sigma.offset == 48
+    assert L.KlaraDesc.stream.offset == C.sizeof(L.KlaraDesc) - 8
+
+
+def test_strerror(klib):
+    assert klib.klara_strerror(0) == b"ok"
+    assert b"finite" in klib.klara_strerror(L.ERR_NONFINITE_INIT)
+
+
+def test_create_validates_like_the_reference_constructors(klib):
+    def status(**over):
+        kw = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(2), nchains=4, nsteps=10)
+        kw.update(over)
+        try:
+            K.Engine(**kw).close()
+        except K.KlaraError as e:
+            return e.status
+        return 0
+    # invalid arguments are rejected before any device is touched (MALA.jl:65, HMC.jl:94-95,
+    # SliceSampler.jl:27, BasicMCRange.jl:22-24, AcceptanceRateMCTuner.jl:32-33)
+    assert status(driftstep=-1.0) == L.ERR_INVALID_ARG
+    assert status(sampler=L.SAMPLER_HMC, leapstep=0.0) == L.ERR_INVALID_ARG
+    assert status(sampler=L.SAMPLER_HMC, nleaps=0) == L.ERR_INVALID_ARG
+    assert status(sampler=L.SAMPLER_SLICE, slice_widths=[1.0, -1.0]) == L.ERR_INVALID_ARG
+    assert status(sampler=L.SAMPLER_MH) == L.ERR_INVALID_ARG            # sigma missing
+    assert status(nsteps=5, burnin=5) == L.ERR_INVALID_ARG
+    assert status(thinning=0) == L.ERR_INVALID_ARG
+    assert status(period=0) == L.ERR_INVALID_ARG
+    assert status(tuner=L.TUNER_ACCEPT_RATE, targetrate=1.5) == L.ERR_INVALID_ARG
+    assert status(nchains=0) == L.ERR_INVALID_ARG
+    assert status(target=K.GaussDiagTarget.negdot(600)) == L.ERR_UNSUPPORTED
+
+
+def test_no_cpu_fallback_without_gpu(klib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(K.KlaraError) as ei:
+        K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(2), nchains=4, nsteps=10)
+    assert ei.value.status == L.ERR_HIP
+
+
+def test_basic_mc_range():
+    r = K.BasicMCRange(nsteps=10000, burnin=1000)
+    assert (r.nsteps, r.burnin, r.thinning, r.npoststeps) == (10000, 1000, 1, 9000)
+    r = K.BasicMCRange(nsteps=100, burnin=10, thinning=7)     # StepRange normalises last: 11:7:100 -> last 95
+    assert list(r.postrange)[:2] == [11, 18] and r.nsteps == 95 and r.npoststeps == 13
+    for bad in (dict(nsteps=5, burnin=5), dict(burnin=-1), dict(thinning=0)):
+        with pytest.raises(AssertionError):
+            K.BasicMCRange(**bad)
+
+
+def test_sampler_and_tuner_constructors():
+    assert (K.HMC().leapstep, K.HMC().nleaps) == (0.1, 10)             # HMC.jl:100
+    assert K.MALA().driftstep == 1.0                                   # MALA.jl:70
+    assert (K.VanillaMCTuner().period, K.VanillaMCTuner().verbose) == (100, False)   # test/VanillaMCTuner.jl:6-9
+    t = K.AcceptanceRateMCTuner(0.234)
+    assert (t.period, t.verbose) == (100, False)                       # test/AcceptanceRateMCTuner.jl:21-23
+    assert list(K.SliceSampler(1.0, 5).widths) == [1.0] * 5            # test/SliceSampler.jl:13
+    for ctor in (lambda: K.MALA(0.0), lambda: K.HMC(-0.1), lambda: K.HMC(0.1, 0), lambda: K.SliceSampler([1.0, 0.0]),
+                 lambda: K.AcceptanceRateMCTuner(1.0), lambda: K.VanillaMCTuner(0)):
+        with pytest.raises(AssertionError):
+            ctor()
+    assert K.logistic(0.7, 3, 4, 2.1, 1.4) == pytest.approx(1.4110527196983078, rel=1e-15)
+    assert K.logistic_rate_score(0.25) == pytest.approx(1.7039056039366212, rel=1e-15)
+
+
+def test_target_families():
+    t = K.GaussDiagTarget.mvnormal([6.11, -8.5], 1.0)
+    assert t.ndims == 2 and np.allclose(t.w, 0.5) and t.const == pytest.approx(-np.log(2 * np.pi))
+    p = K.GaussDenseTarget.compound_symmetric(6, 0.5).precision
+    sigma = 0.5 * np.eye(6) + 0.5 * np.ones((6, 6))
+    assert np.allclose(p @ sigma, np.eye(6))
+    with pytest.raises(ValueError):
+        K.GaussDenseTarget(np.zeros((2, 3)))
+    with pytest.raises(TypeError):
+        K.BasicContMuvParameter("p", logtarget=lambda z: -z @ z)       # arbitrary closures cannot run on device
+
+
+def test_shard_chains_is_a_partition():
+    for n, w in ((65536, 8), (10, 4), (7, 8), (262144, 8)):
+        parts = [K.shard_chains(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+        for (o1, c1), (o2, _) in zip(parts, parts[1:]):
+            assert o1 + c1 == o2

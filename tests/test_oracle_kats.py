@@ -1,0 +1,228 @@
+"""CPU tests: pin the oracle (and the shared deterministic primitives) against every known-answer the
+reference's own tests hold for this path and against published vectors."""
+import math
+
+import numpy as np
+import pytest
+from scipy import stats
+
+import cases
+import oracle_ffi as O
+from klara_jl_amd import _lib as L
+
+
+def test_philox4x32_10_random123_kat():
+    # Random123 kat_vectors (philox4x32 10 rounds): the published known-answer vectors
+    assert O.philox_block([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox_block([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox_block([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_stream_block_counter_layout():
+    # kd_stream_block = Philox with key=seed, counter=(t<<24|slot, chain): rocRAND's (seed, subsequence, offset/4)
+    seed, chain, t, slot = 0x0123456789abcdef, 0x1_0000_0005, 7, 51
+    blk = (t << 24) | slot
+    ref = O.philox_block([blk & 0xffffffff, blk >> 32, chain & 0xffffffff, chain >> 32],
+                         [seed & 0xffffffff, seed >> 32])
+    assert list(O.stream_blocks(seed, chain, t, [slot])[0]) == ref
+
+
+def test_uniform_is_exact_and_open(oracle):
+    assert oracle.ko_u52(0, 0) == 2.0 ** -53
+    assert oracle.ko_u52(0xffffffff, 0xffffffff) == 1.0 - 2.0 ** -53
+    assert oracle.ko_u52(0x80000000, 0) == 0.5 + 2.0 ** -53
+
+
+def _ulps(a, b):
+    return np.max(np.abs(a - b) / np.spacing(np.abs(b)))
+
+
+def test_detmath_accuracy_vs_libm():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.random(200000), np.exp(rng.uniform(-700, 700, 200000)), 1 + rng.uniform(-1e-3, 1e-3, 20000)])
+    assert _ulps(O.math_op(0, x), np.log(x)) <= 1.0
+    x = np.concatenate([rng.uniform(-700, 700, 200000), rng.uniform(-1, 1, 200000)])
+    assert _ulps(O.math_op(1, x), np.exp(x)) <= 1.0
+    u = rng.random(400000)
+    ul = u.astype(np.longdouble)
+    pi_l = np.longdouble("3.14159265358979323846264338327950288")
+    assert np.max(np.abs(O.math_op(2, u) - np.sin(2 * pi_l * ul).astype(np.float64))) <= 2.3e-16
+    assert np.max(np.abs(O.math_op(3, u) - np.cos(2 * pi_l * ul).astype(np.float64))) <= 2.3e-16
+    sp = O.math_op(0, [0.0, -1.0, np.inf, 1.0])
+    assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and sp[3] == 0.0
+    se = O.math_op(1, [0.0, -1e9, 1e9, -745.0])
+    assert se[0] == 1.0 and se[1] == 0.0 and se[2] == np.inf and se[3] == 5e-324
+
+
+def test_box_muller_moments():
+    n = 200000
+    blocks = O.stream_blocks(12345, 3, 0, range(n))
+    lib = O.load()
+    out = np.zeros((n, 2))
+    import ctypes as C
+    for i in range(0, n, 1):
+        lib.ko_normal_pair(blocks[i].ctypes.data, out[i].ctypes.data)
+    z = out.ravel()
+    assert abs(z.mean()) < 4 / math.sqrt(z.size)
+    assert abs(z.var() - 1) < 0.01
+    assert abs(np.corrcoef(out[:, 0], out[:, 1])[0, 1]) < 0.01
+    assert stats.kstest(z[:50000], "norm").pvalue > 1e-3
+
+
+def test_tuner_score_kats(oracle):
+    # test/common.jl:6 (runs) and test/AcceptanceRateMCTuner.jl:8-14 (stale file, live functions)
+    assert oracle.ko_logistic(0.7, 3, 4, 2.1, 1.4) == 1.4110527196983078
+    assert oracle.ko_logistic_rate_score(0.25, 7.0) == 1.7039056039366212
+    assert oracle.ko_logistic_rate_score(0.5, 11.0) == 1.991859724568208
+    assert oracle.ko_erf_rate_score(-0.1, 3.0) == 0.6713732405408726
+    assert oracle.ko_erf_rate_score(0.93, 2.0) == 1.9914724883356396
+
+
+def _diag_job(mu, sigma):
+    import klara_jl_amd as K
+    t = K.GaussDiagTarget.mvnormal(mu, sigma)
+    return O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=t.kind, nchains=1, ndims=t.ndims, nsteps=1,
+                       gauss_w=t.w, gauss_mu=t.mu, gauss_const=t.const)
+
+
+@pytest.mark.parametrize("x,mu,sigma", [
+    ([5.18, -7.76], [6.11, -8.5], 1.0),          # test/BasicContMuvParameter.jl:39-51
+    ([-11.87, -13.44], [-20.2, -18.91], 1.0),    # :62-75
+    ([3.79, 4.64], [5.4, 5.3], 1.0),             # :143-156
+    ([-1.91, -0.9], [0.12, 0.99], 1.0),          # :167-180
+    ([1.25, 1.8], [0.0, 0.0], [10.0, 2.0]),      # :88-100 diagonal prior
+    ([-0.21, 0.98], [0.0, 0.0], [1.0, 1.0]),     # :114-127
+])
+def test_mvnormal_target_closures(x, mu, sigma):
+    """logtarget!/gradlogtarget! synthesised from MvNormal: lt == logpdf, glt == gradlogpdf."""
+    lt, g = _diag_job(mu, sigma).eval_target(x)
+    sg = np.broadcast_to(np.asarray(sigma, float), (2,))
+    assert lt == pytest.approx(stats.multivariate_normal(mu, np.diag(sg ** 2)).logpdf(x), rel=1e-13, abs=1e-13)
+    assert np.allclose(g, -(np.asarray(x) - np.asarray(mu)) / sg ** 2, rtol=1e-14, atol=0)
+
+
+def test_mvnormal_first_kat_value():
+    lt, g = _diag_job([6.11, -8.5], 1.0).eval_target([5.18, -7.76])
+    assert lt == pytest.approx(-2.544127066409346, rel=1e-14)
+    assert np.allclose(g, [0.93, -0.74], rtol=1e-13)
+
+
+def test_unnormalised_target_closure():
+    # test/BasicContMuvParameter.jl:539-563: lt = -(x-mu).(x-mu), glt = -2(x-mu)
+    import klara_jl_amd as K
+    x, mu = np.array([-4.29, 2.91]), np.array([2.2, 2.02])
+    t = K.GaussDiagTarget(2, mu=mu)
+    job = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=t.kind, nchains=1, ndims=2, nsteps=1, gauss_mu=mu)
+    lt, g = job.eval_target(x)
+    ref = stats.multivariate_normal(mu, np.eye(2)).logpdf(x)
+    assert 0.5 * (lt - 2 * math.log(2 * math.pi)) == pytest.approx(ref, rel=1e-12)
+    assert np.allclose(0.5 * g, -(x - mu))
+
+
+def test_logistic_target_matches_numpy():
+    X, y = cases.swiss_data()
+    p = np.array([5.1, -0.9, 8.2, -4.5])
+    job = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=L.TARGET_LOGISTIC, nchains=1, ndims=4, nsteps=1,
+                      logit_X=X, logit_y=y, logit_lambda=100.0)
+    lt, g = job.eval_target(p)
+    xp = X @ p
+    ref_lt = xp @ y - np.sum(np.log(1 + np.exp(xp))) - 0.5 * (p @ p / 100.0 + 4 * np.log(2 * np.pi * 100.0))
+    ref_g = X.T @ (y - 1 / (1 + np.exp(-xp))) - p / 100.0
+    assert lt == pytest.approx(ref_lt, rel=1e-12)
+    assert np.allclose(g, ref_g, rtol=1e-11)
+
+
+def test_tuner_cadence_and_counters():
+    """samplers.jl:29-45: totproposed starts at period => exactly burnin/period tuning events
+    (10 for 1000/100); after burn-in `proposed` keeps growing (iterate/MALA.jl:130-152)."""
+    job = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=L.TARGET_GAUSS_DIAG, nchains=3, ndims=2, nsteps=1300,
+                      burnin=1000, driftstep=1.0, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=100)
+    assert job.set_state(np.zeros((3, 2))) == 0
+    assert list(job.totproposed) == [100] * 3
+    steps = [job.step.copy()]
+    for _ in range(13):
+        job.run(100)
+        steps.append(job.step.copy())
+    changes = sum(int(np.any(steps[i + 1] != steps[i])) for i in range(13))
+    assert changes == 10
+    assert list(job.totproposed) == [1100] * 3
+    assert list(job.proposed) == [300] * 3
+
+
+def test_vanilla_nonverbose_never_counts():
+    job = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=L.TARGET_GAUSS_DIAG, nchains=2, ndims=2, nsteps=300,
+                      burnin=100, driftstep=0.5)
+    job.set_state(np.ones((2, 2)))
+    job.run(300)
+    assert list(job.proposed) == [0, 0] and list(job.accepted) == [0, 0] and list(job.totproposed) == [100, 100]
+
+
+def test_nonfinite_init_is_reported():
+    job = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=L.TARGET_GAUSS_DIAG, nchains=2, ndims=2, nsteps=10,
+                      driftstep=0.5)
+    assert job.set_state([[0.0, 1.0], [np.inf, 0.0]]) == L.ERR_NONFINITE_INIT
+
+
+def test_results_do_not_depend_on_sharding():
+    """Philox key uses the GLOBAL chain id, so chains [4,8) of an 8-chain job equal
+    a 4-chain job with chain_offset=4."""
+    c = cases.make_case("mala_d100")
+    full = O.OracleJob(**cases.oracle_kwargs(c, nchains=8)); full.init_state_normal(); full.run(20)
+    part = O.OracleJob(**cases.oracle_kwargs(c, nchains=4, chain_offset=4)); part.init_state_normal(); part.run(20)
+    assert np.array_equal(full.X[4:], part.X) and np.array_equal(full.accept[:, 4:], part.accept)
+
+
+def test_run_is_resumable():
+    c = cases.make_case("hmc_d100")
+    a = O.OracleJob(**cases.oracle_kwargs(c)); a.init_state_normal(); a.run(30)
+    b = O.OracleJob(**cases.oracle_kwargs(c)); b.init_state_normal(); b.run(7); b.run(23)
+    assert np.array_equal(a.X, b.X) and np.array_equal(a.accept, b.accept) and np.array_equal(a.sum, b.sum)
+
+
+@pytest.mark.parametrize("name", cases.GOLDEN_CASES)
+def test_oracle_reproduces_golden(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", cases.GOLDEN / "make_golden.py")
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    out = mg.run_case(name)
+    gold = np.load(cases.GOLDEN / f"{name}.npz")
+    for k in gold.files:
+        assert np.array_equal(out[k], gold[k], equal_nan=True), (name, k)
+
+
+def test_posterior_moments_mh_readme():
+    """BASELINE cfg 1: README MH example, truth mean 0, var 1/2 (lt = -|x|^2). 64 replicas x 10000 steps."""
+    job = O.OracleJob(sampler=L.SAMPLER_MH, target_kind=L.TARGET_GAUSS_DIAG, nchains=64, ndims=2, nsteps=10000,
+                      burnin=1000, mh_sigma=[1.0, 1.0], want_accept=False)
+    job.set_state(np.tile([5.1, -0.9], (64, 1)))
+    job.run(10000)
+    n = 9000 * 64
+    m = job.sum.sum(0) / n
+    v = job.sumsq.sum(0) / n - m * m
+    assert np.all(np.abs(m) < 0.01) and np.all(np.abs(v - 0.5) < 0.01)
+    assert 0.35 < job.naccept.mean() / 10000 < 0.5
+
+
+def test_posterior_moments_hmc_dense():
+    d = 16
+    p = cases.compound_symmetric_precision(d, 0.5)
+    job = O.OracleJob(sampler=L.SAMPLER_HMC, target_kind=L.TARGET_GAUSS_DENSE, nchains=256, ndims=d, nsteps=600,
+                      burnin=100, leapstep=0.3, nleaps=5, gauss_prec=p, want_accept=False)
+    job.init_state_normal()
+    job.run(600)
+    n = 500 * 256
+    m = job.sum.sum(0) / n
+    v = job.sumsq.sum(0) / n - m * m
+    assert np.all(np.abs(m) < 0.03) and np.all(np.abs(v - 1.0) < 0.05)
+
+
+def test_slice_sampler_moments():
+    job = O.OracleJob(sampler=L.SAMPLER_SLICE, target_kind=L.TARGET_GAUSS_DIAG, nchains=64, ndims=5, nsteps=1100,
+                      burnin=100, slice_widths=[1.0] * 5, want_accept=False)
+    job.init_state_normal()
+    assert job.run(1100) == 0
+    n = 1000 * 64
+    m = job.sum.sum(0) / n
+    v = job.sumsq.sum(0) / n - m * m
+    assert np.all(np.abs(m) < 0.02) and np.all(np.abs(v - 0.5) < 0.02)
