@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job MCMC transition throughput on MI355X (BASELINE.json metric).
+
+Workload at N=1 (BASELINE.json configs[1]): MALA driftstep=0.9, lt = -|x|^2 on D=100, 65,536 chains,
+x0 ~ N(0, I) from the Philox init stream, VanillaMCTuner, state resident in HBM before the timed region.
+A "step" is one transition (one `iterate!`) of every chain.  With --gpus N every rank owns its own
+65,536-chain shard (weak scaling, global chain ids = rank*65536 + local), no data-path collective; the
+only exchange is the end-of-run all-reduce of pooled chain summaries over RCCL, inside the timed region.
+
+Prints ONE JSON line (rank 0).  Extra keys beyond the driver's contract:
+  roofline      dominant transition kernel: algorithmic HBM bytes per launch / mean launch duration from
+                HIP events on the launch stream (DESIGN.md §Measurement gives the per-unit figures)
+  cpu_baseline  the CPU oracle ("port" of the reference path) timed on this box's host cores on a bounded
+                sample of the same workload (N=1 only)
+  extra         secondary measurements outside the timed region (fused launches, HMC leapfrog rate)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+NCHAINS_PER_GPU = 65536
+NDIMS = 100
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP64_MFMA_PEAK_TF = 78.6    # FP64 matrix = FP64 vector peak on MI355X
+
+
+def algorithmic_bytes_per_launch(nchains, d, sampler, spl, summaries):
+    """carried state S = 2*D*8+8 (x, g, lt) for MALA/HMC, D*8+8 for MH/Slice; one launch reads
+    and writes it once whatever the number of fused transitions.  Per-chain counters (8 B RMW) and, when on,
+    the running sums (2 arrays RMW) are counted too."""
+    s = (2 * d * 8 + 8) if sampler in ("mala", "hmc") else (d * 8 + 8)
+    b = 2 * s + 16
+    if summaries:
+        b += 4 * d * 8
+    return nchains * b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--spl", type=int, default=1, help="transitions fused per kernel launch (1 = one iterate! per launch)")
+    ap.add_argument("--chains", type=int, default=NCHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import klara_jl_amd as K
+    from klara_jl_amd import _lib as L
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the transition path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n = args.chains
+    total_steps = args.warmup + args.steps
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=total_steps,
+                   burnin=0, driftstep=0.9, seed=20260927, chain_offset=rank * n, device=local_rank,
+                   monitor=0, steps_per_launch=args.spl, stream=stream)
+    eng.init_state_normal()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.run(args.warmup)
+    if dist is not None:   # warm the communicator outside the timed region
+        t = torch.zeros(4, device="cuda"); dist.all_reduce(t)
+    barrier()
+    t0 = time.perf_counter()
+    eng.run(args.steps)
+    if dist is not None:
+        summ = K.gather_engine_summaries(eng)          # RCCL all-reduce of chain summaries only
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    kernel_ms, nlaunch = eng.last_run_ms()
+    _, _, nacc, ntr, _ = eng.pooled_summaries(with_sums=False)
+
+    out = None
+    if rank == 0:
+        transitions = float(n) * world * args.steps
+        value = transitions / elapsed
+        alg = algorithmic_bytes_per_launch(n, NDIMS, "mala", args.spl, False)
+        launch_s = kernel_ms * 1e-3 / max(nlaunch, 1)
+        achieved = alg / launch_s / 1e9
+        out = {
+            "metric": "MCMC transitions/sec (whole node), 100-dim Gaussian, 65k chains",
+            "value": value, "unit": "transitions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: MALA driftstep=0.9, lt=-|x|^2, D=100, 65,536 chains per GPU, "
+                                   "VanillaMCTuner, x0~N(0,I)",
+                       "nchains_per_gpu": n, "ndims": NDIMS, "steps_per_launch": args.spl,
+                       "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
+                       "acceptance_rate": nacc / max(ntr, 1)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_transitions<MALA, GAUSS_DIAG, E=2, G=64>",
+                         "algorithmic_bytes_per_launch": alg, "launch_us": launch_s * 1e6, "launches": nlaunch},
+        }
+    eng.close()
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        out["extra"] = extra_measurements(K, L, n, stream)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(L)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def extra_measurements(K, L, n, stream):
+    """Outside the timed region: fused launches of the same workload, and the north-star HMC rates."""
+    import numpy as np
+    ex = {}
+    for spl in (16,):
+        e = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=100000,
+                     driftstep=0.9, steps_per_launch=spl, stream=stream)
+        e.init_state_normal(); e.run(64)
+        t0 = time.perf_counter(); e.run(512); dt = time.perf_counter() - t0
+        ex[f"mala_iso_spl{spl}_transitions_per_s"] = n * 512 / dt
+        e.close()
+    # HMC L=10 eps=0.1 on the README target (HBM/VALU-bound) and on the dense target (FP64-MFMA-bound; cfg 3)
+    for key, target in (("hmc_iso", K.GaussDiagTarget.negdot(NDIMS)),
+                        ("hmc_dense", K.GaussDenseTarget.compound_symmetric(NDIMS, 0.5))):
+        e = K.Engine(sampler=L.SAMPLER_HMC, target=target, nchains=n, nsteps=100000, leapstep=0.1, nleaps=10,
+                     steps_per_launch=4, stream=stream)
+        e.init_state_normal(); e.run(8)
+        steps = 64
+        t0 = time.perf_counter(); e.run(steps); dt = time.perf_counter() - t0
+        ms, nl = e.last_run_ms()
+        ex[f"{key}_leapfrog_chain_per_s"] = n * steps * 10 / dt
+        ex[f"{key}_transitions_per_s"] = n * steps / dt
+        if key == "hmc_dense":
+            flops = n * steps * 10 * (2 * NDIMS * NDIMS + 6 * NDIMS)
+            ex["hmc_dense_fp64_tflops"] = flops / (ms * 1e-3) / 1e12
+            ex["hmc_dense_frac_of_fp64_mfma_peak"] = ex["hmc_dense_fp64_tflops"] / FP64_MFMA_PEAK_TF
+        e.close()
+    return ex
+
+
+def cpu_baseline(L):
+    """CPU oracle (restatement of the reference path, OpenMP over chains) on a bounded sample of the workload."""
+    import numpy as np
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_ffi as O
+    cores = usable_cores()
+    lib = O.load()
+    lib.ko_set_num_threads(int(cores))
+    nch, chunk = 32 * cores, 25
+    job = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=L.TARGET_GAUSS_DIAG, nchains=nch, ndims=NDIMS,
+                      nsteps=10 ** 9, driftstep=0.9, want_accept=False, want_sums=False)
+    job.init_state_normal()
+    job.run(chunk)                                   # warm-up (thread pool, caches)
+    # bounded sample: fixed-size chunks until ~12 s of wall time have been spent
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 12.0:
+        job.run(chunk); steps += chunk
+    dt = time.perf_counter() - t0
+    return {"value": nch * steps / dt, "unit": "transitions/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/libklara_oracle.so (C restatement, gcc -O2, OpenMP over chains, {cores} threads): "
+                      f"MALA driftstep=0.9, D=100, {nch} chains x {steps} transitions in {dt:.1f} s"}
+
+
+def usable_cores():
+    """Host threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,10 @@ KD_FN double kd_u52(uint32_t whi, uint32_t wlo)
     return kd_fma(m, 0x1p-52, 0x1p-53);          /* (m + 0.5) * 2^-52, exact (53 bits) */
 }
 
+/* kd_log(u) >= kd_log(2^-53) = -36.7368005696771 for every uniform kd_u52 can return, so a Metropolis ratio at
+ * or below this guard is rejected whatever the uniform is (lets the kernels skip the draw; same result). */
+#define KD_LOG_UMIN_GUARD (-36.74)
+
 /* ---------------------------------------------------------------- log */
 /* Algorithm: FreeBSD msun e_log.c reduction x = 2^k * (1+f), sqrt(1/2) <= 1+f < sqrt(2),
  * s = f/(2+f), log(1+f) = f - hfsq + s*(hfsq + R(s^2)); single code path for every f. */

@@ -88,7 +88,7 @@ static klara_status validate(const klara_desc* d)
     if (d->tuner != KLARA_TUNER_VANILLA && d->tuner != KLARA_TUNER_ACCEPT_RATE) return KLARA_ERR_INVALID_ARG;
     if (d->tuner_mode != KLARA_TUNE_PER_CHAIN && d->tuner_mode != KLARA_TUNE_POOLED) return KLARA_ERR_INVALID_ARG;
     // BasicMCRange.jl:22-24
-    if (d->burnin < 0 || d->thinning < 1 || d->nsteps <= d->burnin) return KLARA_ERR_INVALID_ARG;
+    if (d->burnin < 0 || d->thinning < 1 || d->thinning > 0x7fffffff || d->nsteps <= d->burnin) return KLARA_ERR_INVALID_ARG;
     // VanillaMCTuner / AcceptanceRateMCTuner.jl:32-33
     if (d->period <= 0) return KLARA_ERR_INVALID_ARG;
     if (d->tuner == KLARA_TUNER_ACCEPT_RATE && !(d->targetrate > 0.0 && d->targetrate < 1.0)) return KLARA_ERR_INVALID_ARG;
@@ -356,17 +356,18 @@ extern "C" klara_status klara_init_state_normal(klara_handle* h)
 {
     if (!h) return KLARA_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(h->d.device));
-    // drawn with the E=2 group layout irrespective of the sampling layout (the stream is layout-free)
+    // the stream is layout-free (element i <- slot i>>1), so any group layout draws the same x0:
+    // use the handle's own (kind 0) or E=2 lanes for the MFMA layout (D <= 128 there)
     KParams p = make_params(h);
     const int D = h->d.ndims;
-    if (D > 128) {
-        // TODO(round 2): device init for D > 128; host fallback is not allowed in the product path
-        return KLARA_ERR_UNSUPPORTED;
-    }
-    const int G = pow2ceil((D + 1) / 2);
+    int E = 2, G = pow2ceil((D + 1) / 2);
+    if (h->kind == 0) { E = h->E; G = h->G; }
     p.G = G;
     const long long cpw = 64 / G, waves = (h->d.nchains + cpw - 1) / cpw;
-    hipLaunchKernelGGL((k_init_normal<2, 0>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, h->stream, p);
+    const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+    if (E == 2) hipLaunchKernelGGL((k_init_normal<2, 0>), grid, blk, 0, h->stream, p);
+    else if (E == 4) hipLaunchKernelGGL((k_init_normal<4, 0>), grid, blk, 0, h->stream, p);
+    else hipLaunchKernelGGL((k_init_normal<8, 0>), grid, blk, 0, h->stream, p);
     HIPCHK(hipGetLastError());
     return init_common(h);
 }
@@ -413,6 +414,11 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
         }
         p.t0 = (unsigned long long)h->steps_done;
         p.nsteps = (int)k;
+        // save rule bookkeeping (BasicMCRange.jl:36 postrange = (burnin+1):thinning:nsteps), done on the host so
+        // the kernels carry no 64-bit division: phase of the first post-burn-in step of this launch and the
+        // number of columns already saved
+        p.save_phase0 = h->steps_done >= d.burnin ? (int)((h->steps_done - d.burnin) % d.thinning) : 0;
+        p.save_col0 = h->steps_done > d.burnin ? (h->steps_done - d.burnin - 1) / d.thinning + 1 : 0;
         p.accept = h->accept ? h->accept + (size_t)h->steps_done * (size_t)d.nchains : nullptr;
         HIPCHK(launch_steps(h, p));
         if (pooled && cnt) {

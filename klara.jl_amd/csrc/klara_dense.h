@@ -139,14 +139,17 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
     const MfmaCtx<NE> cx = make_mctx<NE>(p);
     const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
     const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
-    TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix] };
+    TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0 };
+    tn.phase = p.cnt ? (int)(tn.proposed % p.period) : 0;
+    int sphase = p.save_phase0;
+    long long scol = p.save_col0;
     double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
     unsigned long long nacc = 0;
     const bool do_sum = p.sum != nullptr;
 
     for (int s = 0; s < p.nsteps; ++s) {
         const unsigned long long t = p.t0 + (unsigned long long)s;
-        if (p.cnt) tn.proposed += 1;
+        if (p.cnt) tune_count_proposal(p, tn);
         bool acc = false;
         double xp[NE], gp[NG];
         double ltp = lt;
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
             ratio += red[1];
             ratio -= red[2];
             acc = ratio > 0.0;                                         // MALA.jl:94
-            if (!acc) {
+            if (!acc && ratio > KD_LOG_UMIN_GUARD) {
                 const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
                 acc = ratio > kd_log(u);
             }
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
             ltp = p.gconst + 0.5 * red[0];
             const double ratio = ltp - lt;                             // MH.jl:83
             acc = ratio > 0.0;                                         // MH.jl:97
-            if (!acc) {
+            if (!acc && ratio > KD_LOG_UMIN_GUARD) {
                 const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
                 acc = ratio > kd_log(u);
             }
@@ -270,7 +273,11 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
             p.accept[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
         if (!p.pooled) tuning_block(p, tn);
         const long long i1 = (long long)t + 1;
-        if (i1 > p.burnin && ((i1 - p.burnin - 1) % p.thinning) == 0 && i1 <= p.nsteps_total) {
+        const bool in_post = i1 > p.burnin && i1 <= p.nsteps_total;
+        const bool save_now = in_post && sphase == 0;
+        if (in_post) sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
+        if (save_now) {
+            const long long col = scol++;
             if (do_sum || p.hist != nullptr) {
                 double xs[NE];
                 if (acc) {
@@ -289,7 +296,6 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
                     }
                 }
                 if (p.hist != nullptr) {
-                    const long long col = (i1 - p.burnin - 1) / p.thinning;
                     if (col < p.hist_cols) {
                         double* dst = p.hist + (col * p.nchains + cx.chain) * p.D + cx.q;
 #pragma unroll

@@ -43,6 +43,8 @@ struct KParams {
     // tuner
     int tuner; int cnt; double targetrate; double score_k; int period; int is_mh;
     long long burnin; long long thinning; long long nsteps_total;
+    int save_phase0; long long save_col0;      // host-computed: (i1-burnin-1) % thinning of the first post-burn-in step of
+                                               // this launch, and the number of columns saved before it (no device division)
     // targets
     const double* gw; const double* gmu; double gconst;      // diag (gw/gmu may be null)
     const double* lX; const double* ly; int ndata; double lambda; double lpconst;   // logistic
@@ -140,9 +142,14 @@ __device__ __forceinline__ LaneCtx<E> make_ctx(const KParams& p)
 template <int E>
 __device__ __forceinline__ void load_vec(const LaneCtx<E>& c, const double* base, int D, double (&v)[E])
 {
-    const double* row = base + c.chain * D + c.i0;
+    // out-of-range lanes read element 0 of a valid row (always in bounds) and discard it: a select
+    // instead of an exec-masked branch per element
+    const double* row = base + (c.chain_ok ? c.chain : 0) * D;
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = c.valid[e] ? row[e] : 0.0;
+    for (int e = 0; e < E; ++e) {
+        const double t = row[c.valid[e] ? c.i0 + e : 0];
+        v[e] = c.valid[e] ? t : 0.0;
+    }
 }
 template <int E>
 __device__ __forceinline__ void store_vec(const LaneCtx<E>& c, double* base, int D, const double (&v)[E])
@@ -285,7 +292,13 @@ __device__ __forceinline__ double eval_lt(const T& tg, const LaneCtx<E>& cx, con
 // ------------------------------------------------------------------------------------------------
 // per-chain tuner state in registers (tuners.jl:5-10), uniform across the group's lanes
 // ------------------------------------------------------------------------------------------------
-struct TuneRegs { double step; long long accepted, proposed, totproposed; };
+struct TuneRegs { double step; long long accepted, proposed, totproposed; int phase; /* proposed % period */ };
+
+__device__ __forceinline__ void tune_count_proposal(const KParams& p, TuneRegs& tn)
+{
+    tn.proposed += 1;
+    tn.phase = (tn.phase + 1 == p.period) ? 0 : tn.phase + 1;
+}
 
 // tuning block: iterate/MALA.jl:130-152, iterate/HMC.jl:203-224, iterate/MH.jl:116-131;
 // rate!/reset_burnin! tuners.jl:27-32; tune! AcceptanceRateMCTuner.jl:46 with logistic_rate_score
@@ -293,14 +306,14 @@ struct TuneRegs { double step; long long accepted, proposed, totproposed; };
 __device__ __forceinline__ void tuning_block(const KParams& p, TuneRegs& tn)
 {
     if (!p.cnt) return;
-    if (tn.totproposed <= p.burnin && (tn.proposed % p.period) == 0) {
+    if (tn.totproposed <= p.burnin && tn.phase == 0) {                // mod(proposed, period) == 0
         const double rate = (double)tn.accepted / (double)tn.proposed;
         if (p.tuner == KLARA_TUNER_ACCEPT_RATE && !p.is_mh) {
             const double xr = rate - p.targetrate;
             tn.step *= 2.0 / (1.0 + kd_exp(-p.score_k * (xr - 0.0))) + 0.0;
         }
         tn.totproposed += tn.proposed;
-        tn.accepted = 0; tn.proposed = 0;
+        tn.accepted = 0; tn.proposed = 0; tn.phase = 0;
     }
 }
 
@@ -322,7 +335,7 @@ __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const Lan
     const double ltp = tg.finalize(red[0]);
     const double ratio = ltp - lt;                                                    // :83
     bool acc = ratio > 0.0;                                                           // :97
-    if (!acc) {
+    if (!acc && ratio > KD_LOG_UMIN_GUARD) {   // below the guard no uniform of the stream can accept
         const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
         acc = ratio > kd_log(u);
     }
@@ -364,7 +377,7 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
     ratio += red[1];                                                                  // :90
     ratio -= red[2];                                                                  // :92
     bool acc = ratio > 0.0;                                                           // :94
-    if (!acc) {
+    if (!acc && ratio > KD_LOG_UMIN_GUARD) {   // below the guard no uniform of the stream can accept
         const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
         acc = ratio > kd_log(u);
     }
@@ -522,7 +535,10 @@ __global__ __launch_bounds__(256) void k_transitions(const KParams p)
     if (SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_SLICE) load_param<E>(cx, p.vecparam, p.D, 1.0, vp);
     double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
     const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
-    TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix] };
+    TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0 };
+    tn.phase = p.cnt ? (int)(tn.proposed % p.period) : 0;
+    int sphase = p.save_phase0;
+    long long scol = p.save_col0;
     const bool do_sum = p.sum != nullptr;
     if (do_sum) { load_vec<E>(cx, p.sum, p.D, sm); load_vec<E>(cx, p.sumsq, p.D, sq); }
     const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
@@ -531,32 +547,33 @@ __global__ __launch_bounds__(256) void k_transitions(const KParams p)
 
     for (int s = 0; s < p.nsteps; ++s) {
         const unsigned long long t = p.t0 + (unsigned long long)s;
-        if (p.cnt) tn.proposed += 1;
+        if (p.cnt) tune_count_proposal(p, tn);
         bool acc;
         if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E>(p, tg, cx, gchain, t, vp, x, lt);
         else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E>(p, tg, cx, gchain, t, tn.step, x, g, lt);
         else if (SAMPLER == KLARA_SAMPLER_HMC) acc = step_hmc<T, E>(p, tg, cx, gchain, t, tn.step, x, g, lt);
         else acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, x, lt, stuck);
         nacc += acc ? 1ull : 0ull;
-        if (p.cnt && acc) tn.accepted += 1;
+        if (p.cnt && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;   // the slice sampler never counts accepts
         if (p.accept != nullptr && cx.chain_ok && cx.q == 0)
             p.accept[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
         if (!p.pooled) tuning_block(p, tn);
         // save rule: BasicMCJob.jl:226-231 with postrange = (burnin+1):thinning:nsteps (BasicMCRange.jl:36)
         const long long i1 = (long long)t + 1;
-        if (i1 > p.burnin && ((i1 - p.burnin - 1) % p.thinning) == 0 && i1 <= p.nsteps_total) {
-            if (do_sum) {
+        if (i1 > p.burnin && i1 <= p.nsteps_total) {
+            if (sphase == 0) {
+                if (do_sum) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) { sm[e] = sm[e] + x[e]; sq[e] = sq[e] + x[e] * x[e]; }
-            }
-            if (p.hist != nullptr) {
-                const long long col = (i1 - p.burnin - 1) / p.thinning;
-                if (col < p.hist_cols) {
-                    double* dst = p.hist + (col * p.nchains + cx.chain) * p.D + cx.i0;
+                    for (int e = 0; e < E; ++e) { sm[e] = sm[e] + x[e]; sq[e] = sq[e] + x[e] * x[e]; }
+                }
+                if (p.hist != nullptr && scol < p.hist_cols) {
+                    double* dst = p.hist + (scol * p.nchains + cx.chain) * p.D + cx.i0;
 #pragma unroll
                     for (int e = 0; e < E; ++e) if (cx.valid[e]) dst[e] = x[e];
                 }
+                ++scol;
             }
+            sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
         }
     }
 

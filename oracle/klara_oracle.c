@@ -461,7 +461,7 @@ int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double
                 const int acc = ko_transition(&c, (uint64_t)(d->chain_offset + n), (uint64_t)t,
                                               tn.step, x, g, &LT[n], &stuck);
                 if (stuck) break;
-                if (acc && cnt) tn.accepted += 1;
+                if (acc && cnt && d->sampler != KLARA_SAMPLER_SLICE) tn.accepted += 1;
                 if (accept_out) accept_out[s * d->nchains + n] = (uint8_t)acc;
                 if (naccept) naccept[n] += (uint64_t)acc;
                 ko_tuning_block(d, &tn, cnt, 1);
@@ -517,6 +517,16 @@ int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double
     }
     return stuck_any ? KLARA_ERR_SLICE_STUCK : KLARA_OK;
 }
+
+/* thread control for the cpu_baseline leg of bench.py (OpenMP over chains) */
+#ifdef _OPENMP
+#include <omp.h>
+void ko_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int ko_get_max_threads(void) { return omp_get_max_threads(); }
+#else
+void ko_set_num_threads(int n) { (void)n; }
+int ko_get_max_threads(void) { return 1; }
+#endif
 
 /* ------------------------------------------------------------------ small exports for KATs */
 void ko_philox_block(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])

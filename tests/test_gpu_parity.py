@@ -1,0 +1,287 @@
+"""GPU parity tests (-m gpu): libklara_hip.so through its C ABI vs the CPU oracle and the golden vectors.
+
+Bar: bit-exact accept masks, states, log-targets, gradients, per-chain sums and tuner state (the
+arithmetic is IEEE-identical by construction: shared Philox stream, shared deterministic log/exp/sincos,
+same summation order); pooled moments within the tolerance stated in each test.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_ffi as O
+import klara_jl_amd as K
+from klara_jl_amd import _lib as L
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gpu_required")]
+
+
+# ------------------------------------------------------------------ primitives
+def test_device_math_bit_exact(klib):
+    rng = np.random.default_rng(7)
+    n = 1 << 18
+    sets = {
+        0: np.concatenate([rng.random(n), np.exp(rng.uniform(-700, 700, n)), [1.0, 2.0 ** -53, 5e-324]]),
+        1: np.concatenate([rng.uniform(-745, 709, n), rng.uniform(-2, 2, n), [0.0, -800.0, 800.0]]),
+        2: rng.random(n), 3: rng.random(n),
+        4: np.concatenate([rng.random(n) * 1e3, np.exp(rng.uniform(-700, 700, n))]),
+        5: np.exp(rng.uniform(-300, 300, n)),
+    }
+    for op, x in sets.items():
+        x = np.ascontiguousarray(x)
+        y = np.ascontiguousarray(np.exp(rng.uniform(-300, 300, x.size)))
+        out = np.empty_like(x)
+        L.check(klib.klara_selftest_math(0, op, x.size, x.ctypes.data, y.ctypes.data, out.ctypes.data), "selftest_math")
+        ref = O.math_op(op, x, y)
+        assert np.array_equal(out.view(np.uint64), ref.view(np.uint64)), f"op {op}: device math differs from host"
+
+
+def test_stream_is_rocrand_philox(klib):
+    """In-kernel generator == CPU oracle == rocRAND's device philox4x32_10 engine
+    (seed, subsequence = global chain id, offset = 4 * (transition << 24 | slot))."""
+    seed, chain, t = 20260927, (1 << 33) + 17, 12345
+    first = t << 24
+    out = np.zeros((64, 4), np.uint32)
+    L.check(klib.klara_selftest_rocrand_blocks(0, seed, chain, first, 64, out.ctypes.data), "selftest_rocrand")
+    assert np.array_equal(out, O.stream_blocks(seed, chain, t, range(64)))
+
+
+def test_mfma_f64_order(klib):
+    """v_mfma_f64_16x16x4_f64 accumulates each output as one fma chain over k ascending from C —
+    the order the oracle's dense gradient uses."""
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((16, 4)) * np.exp(rng.uniform(-20, 20, (16, 4)))
+    B = rng.standard_normal((4, 16)) * np.exp(rng.uniform(-20, 20, (4, 16)))
+    Cm = rng.standard_normal((16, 16))
+    D = np.empty((16, 16))
+    L.check(klib.klara_selftest_mfma_f64(0, A.ctypes.data, B.ctypes.data, Cm.ctypes.data, D.ctypes.data), "selftest_mfma")
+    import math
+    ref = np.empty((16, 16))
+    for i in range(16):
+        for j in range(16):
+            acc = Cm[i, j]
+            for k in range(4):
+                acc = math.fma(A[i, k], B[k, j], acc) if hasattr(math, "fma") else _fma(A[i, k], B[k, j], acc)
+            ref[i, j] = acc
+    assert np.array_equal(D, ref)
+
+
+def _fma(a, b, c):
+    # exact fma via the oracle's libm-free path: use numpy longdouble (64-bit mantissa) is not exact in
+    # general, so go through fractions
+    from fractions import Fraction
+    return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+
+# ------------------------------------------------------------------ sampler parity
+def _run_pair(case, splits=None, spl=0, chain_offset=0):
+    eng = K.Engine(**cases.engine_kwargs(case, steps_per_launch=spl, chain_offset=chain_offset))
+    layout = eng.layout()
+    job = O.OracleJob(**cases.oracle_kwargs(case, layout=layout, chain_offset=chain_offset))
+    if case["x0"] is None:
+        eng.init_state_normal(); st = job.init_state_normal()
+    else:
+        eng.set_state(case["x0"]); st = job.set_state(case["x0"])
+    assert st == 0
+    x, lt, g = eng.state()
+    assert np.array_equal(x, job.X), "initial values differ"
+    assert np.array_equal(lt, job.LT), "initial log-target differs"
+    if case["sampler"] in (L.SAMPLER_MALA, L.SAMPLER_HMC):
+        assert np.array_equal(g, job.G), "initial gradient differs"
+    for n in (splits or [case["nsteps"]]):
+        eng.run(n)
+        assert job.run(n) == 0
+    return eng, job
+
+
+def _assert_same(eng, job, case):
+    name = case["name"]
+    mask = eng.accept_mask()
+    assert mask.shape == job.accept.shape
+    assert np.array_equal(mask, job.accept), f"{name}: accept mask differs at {np.argwhere(mask != job.accept)[:5]}"
+    x, lt, g = eng.state()
+    assert np.array_equal(x, job.X), f"{name}: values differ"
+    assert np.array_equal(lt, job.LT), f"{name}: log-target differs"
+    if case["sampler"] in (L.SAMPLER_MALA, L.SAMPLER_HMC):
+        assert np.array_equal(g, job.G), f"{name}: gradient differs"
+    s, q, nsaved = eng.chain_sums()
+    assert np.array_equal(s, job.sum) and np.array_equal(q, job.sumsq), f"{name}: per-chain sums differ"
+    assert nsaved == len(range(case.get("burnin", 0) + 1, case["nsteps"] + 1, case.get("thinning", 1)))
+    na, nst = eng.accept_counts()
+    assert np.array_equal(na, job.naccept) and nst == case["nsteps"]
+    step, acc, prop, tot = eng.tune()
+    if case.get("tuner_mode", 0) == L.TUNE_POOLED:
+        assert step[0] == job.step[0] and acc[0] == job.accepted[0] and prop[0] == job.proposed[0] and tot[0] == job.totproposed[0]
+    else:
+        assert np.array_equal(step, job.step, equal_nan=True), f"{name}: tuned step differs"
+        assert np.array_equal(acc, job.accepted) and np.array_equal(prop, job.proposed) and np.array_equal(tot, job.totproposed)
+    # pooled summaries: device tree-sum vs numpy sum — tolerance 1e-12 relative (different association)
+    ps, pq, pna, pnt, pns = eng.pooled_summaries()
+    assert np.allclose(ps, job.sum.sum(0), rtol=1e-12, atol=1e-9) and np.allclose(pq, job.sumsq.sum(0), rtol=1e-12)
+    assert pna == int(job.naccept.sum()) and pnt == case["nsteps"] * case["nchains"] and pns == nsaved
+
+
+@pytest.mark.parametrize("name", cases.ALL_CASES)
+def test_parity_with_oracle(name):
+    case = cases.make_case(name)
+    eng, job = _run_pair(case)
+    _assert_same(eng, job, case)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", cases.GOLDEN_CASES)
+def test_parity_with_golden_vectors(name):
+    """Same comparison against the committed vectors (independent of the oracle build on this box)."""
+    case = cases.make_case(name)
+    gold = np.load(cases.GOLDEN / f"{name}.npz")
+    eng = K.Engine(**cases.engine_kwargs(case))
+    assert list(eng.layout()) == list(gold["layout"])
+    eng.set_state(gold["x0"])
+    eng.run(case["nsteps"])
+    x, lt, g = eng.state()
+    assert np.array_equal(eng.accept_mask(), gold["accept"])
+    assert np.array_equal(x, gold["x"]) and np.array_equal(lt, gold["lt"])
+    s, q, _ = eng.chain_sums()
+    assert np.array_equal(s, gold["sum"]) and np.array_equal(q, gold["sumsq"])
+    step = eng.tune()[0]
+    if case.get("tuner_mode", 0) == L.TUNE_POOLED:
+        assert step[0] == gold["step"][0]
+    else:
+        assert np.array_equal(step, gold["step"], equal_nan=True)
+    eng.close()
+
+
+@pytest.mark.parametrize("name,splits,spl", [
+    ("mala_d100", [1, 7, 42], 1), ("mala_d100", [50], 5), ("hmc_d100", [13, 17], 4),
+    ("hmc_dense_d100", [5, 7], 3), ("mala_d3_tuned", [100, 60, 100], 7), ("hmc_d10_tuned_pooled", [33, 87], 16),
+    ("slice_d5", [11, 19], 2), ("mala_swiss", [40], 1),
+])
+def test_launch_splitting_does_not_change_results(name, splits, spl):
+    """K transitions per launch / multiple klara_run calls are invisible in the results."""
+    case = cases.make_case(name)
+    eng, job = _run_pair(case, splits=splits, spl=spl)
+    _assert_same(eng, job, case)
+    eng.close()
+
+
+def test_sharding_invariance():
+    """Rank r's shard (chain_offset) reproduces the same chains as the single-GPU job."""
+    case = cases.make_case("mala_d100")
+    full = K.Engine(**cases.engine_kwargs(case)); full.init_state_normal(); full.run(case["nsteps"])
+    xf = full.state()[0]; mf = full.accept_mask()
+    off, cnt = K.shard_chains(case["nchains"], 1, 2)
+    part = K.Engine(**cases.engine_kwargs(dict(case, nchains=cnt), chain_offset=off))
+    part.init_state_normal(); part.run(case["nsteps"])
+    assert np.array_equal(part.state()[0], xf[off:off + cnt]) and np.array_equal(part.accept_mask(), mf[:, off:off + cnt])
+    full.close(); part.close()
+
+
+def test_reset_rewinds_the_job():
+    """reset(job) / reset(job, x) — BasicMCJob.jl:187-201."""
+    case = cases.make_case("hmc_d100")
+    eng = K.Engine(**cases.engine_kwargs(case)); eng.init_state_normal()
+    x0 = eng.state()[0]
+    eng.run(case["nsteps"]); x1 = eng.state()[0]; m1 = eng.accept_mask()
+    eng.reset(x0); eng.run(case["nsteps"])
+    assert np.array_equal(eng.state()[0], x1) and np.array_equal(eng.accept_mask(), m1)
+    eng.close()
+
+
+def test_nonfinite_initial_values_are_rejected():
+    eng = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(3), nchains=5, nsteps=10, driftstep=0.1)
+    x = np.zeros((5, 3)); x[3, 1] = np.nan
+    with pytest.raises(K.KlaraError) as ei:
+        eng.set_state(x)
+    assert ei.value.status == L.ERR_NONFINITE_INIT
+    with pytest.raises(K.KlaraError):
+        eng.run(1)                                     # no state -> KLARA_ERR_STATE
+    eng.close()
+
+
+def test_history_layout_matches_nstate():
+    """:destination=>:nstate — value is (D x npoststeps) per chain, column i = i-th saved step
+    (test/ParameterNStates.jl:139-146,176-185; save rule BasicMCJob.jl:226-231)."""
+    case = cases.make_case("mala_d100_small_step")
+    eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_HISTORY | L.MON_SUMMARIES | L.MON_ACCEPT))
+    job = O.OracleJob(**cases.oracle_kwargs(case, layout=eng.layout()), want_hist=True)
+    eng.init_state_normal(); job.init_state_normal()
+    eng.run(case["nsteps"]); job.run(case["nsteps"])
+    npost = len(range(case["burnin"] + 1, case["nsteps"] + 1, case["thinning"]))
+    for c in (0, 17, case["nchains"] - 1):
+        v = eng.chain(c)
+        assert v.shape == (100, npost) and v.flags.f_contiguous
+        assert np.array_equal(v, job.hist[:, c, :].T)
+    # mean(chain) of stats/mean.jl:7-11 from the stored history == from the running sums (same order)
+    s, _, n = eng.chain_sums()
+    assert np.allclose(eng.chain(3).mean(axis=1), s[3] / n, rtol=1e-13)
+    eng.close()
+
+
+# ------------------------------------------------------------------ reference-API level
+def test_readme_flow_basic_mc_job():
+    """README.md:23-66 through the host mirror: MH on lt = -dot(z,z), 10000 steps, burnin 1000."""
+    p = K.BasicContMuvParameter("p", logtarget=K.GaussDiagTarget.negdot(2))
+    model = K.likelihood_model(p, False)
+    job = K.BasicMCJob(model, K.MH(np.ones(2)), K.BasicMCRange(nsteps=10000, burnin=1000),
+                       {"p": np.tile([5.1, -0.9], (256, 1))}, outopts={"diagnostics": ["accept"]})
+    K.run(job)
+    chain = K.output(job)
+    m = K.mean(chain)                         # (nchains x D)
+    assert chain.value(0).shape == (2, 9000)
+    assert np.allclose(K.mean(chain, 0), chain.value(0).mean(axis=1), rtol=1e-12)
+    assert abs(m.mean()) < 0.01                                 # truth 0
+    s, q, n = chain._sums
+    assert np.all(np.abs(q.sum(0) / (n * 256) - 0.5) < 0.01)    # truth var 1/2
+    acc = K.acceptance(chain)
+    assert acc.shape == (256,) and 0.35 < acc.mean() < 0.5
+    # one replica against the oracle bit for bit (BASELINE cfg 1 is the reference's CPU-runnable case)
+    o = O.OracleJob(sampler=L.SAMPLER_MH, target_kind=L.TARGET_GAUSS_DIAG, nchains=1, ndims=2, nsteps=10000,
+                    burnin=1000, mh_sigma=[1.0, 1.0], layout=job.engine.layout())
+    o.set_state([[5.1, -0.9]]); o.run(10000)
+    assert np.array_equal(o.sum[0], s[0]) and np.array_equal(o.accept[:, 0], job.engine.accept_mask()[:, 0])
+    job.close()
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE shapes)
+def test_full_size_mala_properties():
+    """BASELINE cfg 2 shape (65,536 chains x 100 dims): determinism, launch-split invariance, and pooled
+    posterior moments.  Truth for lt = -|x|^2: mean 0, var 1/2.  The drift step is tuned per chain
+    (AcceptanceRate 0.574) because drift 0.9 accepts ~2% at D=100 and has not mixed in a test-sized run;
+    tolerance 1e-2 on var (Monte-Carlo error of 65,536 x 200 correlated samples), 5e-3 on mean."""
+    n, d = 65536, 100
+    kw = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(d), nchains=n, nsteps=500, burnin=300,
+              driftstep=0.9, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=25, monitor=L.MON_SUMMARIES)
+    a = K.Engine(steps_per_launch=25, **kw); a.init_state_normal(); a.run(500)
+    b = K.Engine(steps_per_launch=4, **kw); b.init_state_normal(); b.run(123); b.run(377)
+    xa, lta, _ = a.state(); xb, ltb, _ = b.state()
+    assert np.array_equal(xa, xb) and np.array_equal(lta, ltb)
+    s, q, na, nt, ns = a.pooled_summaries()
+    cnt = ns * n
+    mean = s / cnt; var = q / cnt - mean * mean
+    assert np.max(np.abs(mean)) < 5e-3, np.max(np.abs(mean))
+    assert np.max(np.abs(var - 0.5)) < 1e-2, (var.min(), var.max())
+    step = a.tune()[0]
+    assert 0.3 < np.median(step) < 0.9 * 0.9 and 0.4 < na / nt < 0.75
+    a.close(); b.close()
+
+
+def test_full_size_hmc_dense_properties():
+    """BASELINE cfg 3 shape (65,536 chains, D=100, dense precision, L=10, eps=0.1): the FP64-MFMA path.
+    Energy error of a leapfrog trajectory is O(eps^2): acceptance > 0.9; starting from x0 ~ N(0, I) the
+    pooled variance moves towards the truth (1.0 on the diagonal); lt stays consistent with x:
+    lt == -1/2 x'Px recomputed on the host to 1e-10 relative."""
+    n, d = 65536, 100
+    t = K.GaussDenseTarget.compound_symmetric(d, 0.5)
+    eng = K.Engine(sampler=L.SAMPLER_HMC, target=t, nchains=n, nsteps=40, burnin=20, leapstep=0.1, nleaps=10,
+                   monitor=L.MON_SUMMARIES, steps_per_launch=5)
+    eng.init_state_normal(); eng.run(40)
+    x, lt, g = eng.state()
+    ref_lt = -0.5 * np.einsum("ni,ij,nj->n", x[:512], t.precision, x[:512])
+    assert np.allclose(lt[:512], ref_lt, rtol=1e-10, atol=1e-10)
+    assert np.allclose(g[:512], -x[:512] @ t.precision, rtol=1e-10, atol=1e-10)
+    s, q, na, nt, ns = eng.pooled_summaries()
+    assert na / nt > 0.9
+    mean = s / (ns * n)
+    assert np.max(np.abs(mean)) < 0.02
+    eng.close()
