@@ -244,18 +244,34 @@ static KParams make_params(klara_handle* h)
     p.vecparam = h->vecparam; p.nleaps = d.nleaps; p.stepout = d.slice_stepout;
     p.tuner = d.tuner; p.cnt = cnt_predicate(d); p.targetrate = d.targetrate;
     p.score_k = d.score_k; p.period = d.period; p.is_mh = d.sampler == KLARA_SAMPLER_MH;
+    p.step0 = d.sampler == KLARA_SAMPLER_MH ? 1.0 : d.sampler == KLARA_SAMPLER_MALA ? d.driftstep
+            : d.sampler == KLARA_SAMPLER_HMC ? d.leapstep : (double)NAN;
     p.burnin = d.burnin; p.thinning = d.thinning; p.nsteps_total = d.nsteps;
     p.gw = h->gw; p.gmu = h->gmu; p.gconst = d.gauss_const;
     p.lX = h->lX; p.ly = h->ly; p.ndata = d.logit_ndata; p.lambda = d.logit_lambda; p.lpconst = h->lpconst;
     return p;
 }
 
+// one wave per chain group for the init kernels and the MFMA kernels
 static dim3 grid_for(const klara_handle* h)
 {
     const long long cpw = h->kind == 1 ? 16 : 64 / h->G;
     const long long waves = (h->d.nchains + cpw - 1) / cpw;
     const long long wpb = h->kind == 1 ? 8 : 4;
     return dim3((unsigned)((waves + wpb - 1) / wpb));
+}
+
+// group-layout transition kernels are persistent over `groups_per_wave` chain groups (prefetch of the
+// next group's state overlaps the current group's compute); keep >= ~8 waves per SIMD of work for balance
+static dim3 grid_for_transitions(const klara_handle* h)
+{
+    const long long cpw = 64 / h->G;
+    const long long groups = (h->d.nchains + cpw - 1) / cpw;
+    long long gpw = 4;
+    if (const char* s = getenv("KLARA_GROUPS_PER_WAVE")) { const long long v = atoll(s); if (v >= 1 && v <= 64) gpw = v; }
+    while (gpw > 1 && groups / gpw < 8192) gpw >>= 1;
+    const long long waves = (groups + gpw - 1) / gpw;
+    return dim3((unsigned)((waves + 3) / 4));
 }
 
 static size_t lds_for(const klara_handle* h)
@@ -386,10 +402,10 @@ static hipError_t launch_steps(klara_handle* h, const KParams& p)
     const klara_desc& d = h->d;
     if (h->kind == 1) return klara_launch_dense(p, d.sampler, h->E, h->Pfrag, grid_for(h), h->stream);
     switch (d.sampler) {
-    case KLARA_SAMPLER_MH: return klara_launch_mh(p, d.target, h->E, h->G, grid_for(h), lds_for(h), h->stream);
-    case KLARA_SAMPLER_MALA: return klara_launch_mala(p, d.target, h->E, h->G, grid_for(h), lds_for(h), h->stream);
-    case KLARA_SAMPLER_HMC: return klara_launch_hmc(p, d.target, h->E, h->G, grid_for(h), lds_for(h), h->stream);
-    default: return klara_launch_slice(p, d.target, h->E, h->G, grid_for(h), lds_for(h), h->stream);
+    case KLARA_SAMPLER_MH: return klara_launch_mh(p, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
+    case KLARA_SAMPLER_MALA: return klara_launch_mala(p, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
+    case KLARA_SAMPLER_HMC: return klara_launch_hmc(p, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
+    default: return klara_launch_slice(p, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
     }
 }
 

@@ -42,6 +42,7 @@ struct KParams {
     int nleaps; int stepout;
     // tuner
     int tuner; int cnt; double targetrate; double score_k; int period; int is_mh;
+    double step0;                              // initial step (samplers.jl:29-45); the step of every chain when nothing is tuned
     long long burnin; long long thinning; long long nsteps_total;
     int save_phase0; long long save_col0;      // host-computed: (i1-burnin-1) % thinning of the first post-burn-in step of
                                                // this launch, and the number of columns saved before it (no device division)
@@ -324,10 +325,9 @@ __device__ __forceinline__ void tuning_block(const KParams& p, TuneRegs& tn)
 template <class T, int E>
 __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const LaneCtx<E>& cx,
                                         unsigned long long gchain, unsigned long long t,
-                                        const double (&sigma)[E], double (&x)[E], double& lt)
+                                        const double (&z)[E], const double (&sigma)[E], double (&x)[E], double& lt)
 {
-    double z[E], xp[E], gd[E], red[1];
-    lane_normals<E>(cx, p.seed, gchain, t, z);
+    double xp[E], gd[E], red[1];
 #pragma unroll
     for (int e = 0; e < E; ++e) xp[e] = x[e] + sigma[e] * z[e];                       // MH.jl:79
     tg.template eval<true, false>(cx, xp, red[0], gd);                                // :81
@@ -350,11 +350,11 @@ __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const Lan
 // iterate!(job, MALA, Multivariate) — iterate/MALA.jl:78-128
 template <class T, int E>
 __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const LaneCtx<E>& cx,
-                                          unsigned long long gchain, unsigned long long t, double h,
+                                          unsigned long long gchain, unsigned long long t,
+                                          const double (&z)[E], double h,
                                           double (&x)[E], double (&g)[E], double& lt)
 {
-    double z[E], mu[E], xp[E], gp[E], red[3];
-    lane_normals<E>(cx, p.seed, gchain, t, z);
+    double mu[E], xp[E], gp[E], red[3];
     const double halfh = 0.5 * h, sq = __builtin_sqrt(h);
 #pragma unroll
     for (int e = 0; e < E; ++e) mu[e] = x[e] + halfh * g[e];                          // :83
@@ -393,11 +393,13 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
 // hamiltonian samplers.jl:103
 template <class T, int E>
 __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const LaneCtx<E>& cx,
-                                         unsigned long long gchain, unsigned long long t, double eps,
+                                         unsigned long long gchain, unsigned long long t,
+                                         const double (&z)[E], double eps,
                                          double (&x)[E], double (&g)[E], double& lt)
 {
     double mom[E], xp[E], gp[E], red[2], dummy;
-    lane_normals<E>(cx, p.seed, gchain, t, mom);                                      // :135
+#pragma unroll
+    for (int e = 0; e < E; ++e) mom[e] = z[e];                                        // :135
     double k0[1] = { 0.0 };
 #pragma unroll
     for (int e = 0; e < E; ++e) k0[0] = k0[0] + (cx.valid[e] ? mom[e] * mom[e] : 0.0);
@@ -519,79 +521,149 @@ __device__ __forceinline__ bool step_slice(const KParams& p, const T& tg, const 
 // ------------------------------------------------------------------------------------------------
 // the transition kernel: run(job) loop of BasicMCJob.jl:219-238 for p.nsteps transitions
 // ------------------------------------------------------------------------------------------------
+// Per-chain registers that travel between HBM and the transition loop.
+template <int E>
+struct ChainRegs {
+    double x[E], g[E];
+    double lt;
+    double step; long long accepted, proposed, totproposed;
+};
+
+template <int E, bool NEEDG>
+__device__ __forceinline__ void load_chain(const KParams& p, const LaneCtx<E>& cx, ChainRegs<E>& r)
+{
+    load_vec<E>(cx, p.X, p.D, r.x);
+    if (NEEDG) load_vec<E>(cx, p.GR, p.D, r.g);
+    const long long c0 = cx.chain_ok ? cx.chain : 0;
+    r.lt = p.LT[c0];
+    if (p.cnt && !p.pooled) {            // per-chain tuner state (tuners.jl:5-10) only when something counts
+        r.step = p.tune_step[c0]; r.accepted = p.tune_accepted[c0];
+        r.proposed = p.tune_proposed[c0]; r.totproposed = p.tune_totproposed[c0];
+    }
+}
+
+template <int E, int GT>
+__device__ __forceinline__ void set_chain(const KParams& p, LaneCtx<E>& c, long long group_index)
+{
+    c.chain = group_index * (64 / c.G) + (c.lane / c.G);
+    c.chain_ok = c.chain < p.nchains;
+#pragma unroll
+    for (int e = 0; e < E; ++e) c.valid[e] = c.chain_ok && (c.i0 + e < p.D);
+}
+
+// The transition kernel: run(job) loop of BasicMCJob.jl:219-238 for p.nsteps transitions of every chain.
+//
+// A wavefront is persistent over several chain groups (group index = wave + k * total_waves): the HBM
+// loads of the NEXT group are issued before the current group's transitions are computed, and the
+// first step's proposal normals (Philox + Box-Muller, independent of the state) are generated before
+// the loaded registers are first touched, so HBM latency overlaps the RNG/ALU work instead of
+// serialising with it (one-launch-per-transition mode is otherwise latency-bound at 3 waves/SIMD).
 template <int SAMPLER, int TARGET, int E, int GT>
-__global__ __launch_bounds__(256) void k_transitions(const KParams p)
+__global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? 2 : 1))) void k_transitions(const KParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = typename TargetSel<TARGET, E>::type;
-    const LaneCtx<E> cx = make_ctx<E, GT>(p);
+    constexpr bool NEEDG = (SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_HMC);
+    constexpr bool NEEDZ = (SAMPLER != KLARA_SAMPLER_SLICE);
+
+    LaneCtx<E> cx = make_ctx<E, GT>(p);
     T tg;
     tg.init(p, cx, reinterpret_cast<double*>(smem));
-
-    constexpr bool NEEDG = (SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_HMC);
-    double x[E], g[E], vp[E], sm[E], sq[E];
-    load_vec<E>(cx, p.X, p.D, x);
-    if (NEEDG) load_vec<E>(cx, p.GR, p.D, g);
+    double vp[E];
     if (SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_SLICE) load_param<E>(cx, p.vecparam, p.D, 1.0, vp);
-    double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
-    const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
-    TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0 };
-    tn.phase = p.cnt ? (int)(tn.proposed % p.period) : 0;
-    int sphase = p.save_phase0;
-    long long scol = p.save_col0;
+
+    const int cpw = 64 / cx.G;
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    long long grp = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const bool do_sum = p.sum != nullptr;
-    if (do_sum) { load_vec<E>(cx, p.sum, p.D, sm); load_vec<E>(cx, p.sumsq, p.D, sq); }
-    const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
-    unsigned long long nacc = 0;
-    bool stuck = false;
+    const bool per_chain_tune = p.cnt && !p.pooled;
 
-    for (int s = 0; s < p.nsteps; ++s) {
-        const unsigned long long t = p.t0 + (unsigned long long)s;
-        if (p.cnt) tune_count_proposal(p, tn);
-        bool acc;
-        if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E>(p, tg, cx, gchain, t, vp, x, lt);
-        else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E>(p, tg, cx, gchain, t, tn.step, x, g, lt);
-        else if (SAMPLER == KLARA_SAMPLER_HMC) acc = step_hmc<T, E>(p, tg, cx, gchain, t, tn.step, x, g, lt);
-        else acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, x, lt, stuck);
-        nacc += acc ? 1ull : 0ull;
-        if (p.cnt && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;   // the slice sampler never counts accepts
-        if (p.accept != nullptr && cx.chain_ok && cx.q == 0)
-            p.accept[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
-        if (!p.pooled) tuning_block(p, tn);
-        // save rule: BasicMCJob.jl:226-231 with postrange = (burnin+1):thinning:nsteps (BasicMCRange.jl:36)
-        const long long i1 = (long long)t + 1;
-        if (i1 > p.burnin && i1 <= p.nsteps_total) {
-            if (sphase == 0) {
-                if (do_sum) {
+    ChainRegs<E> cur;
+    set_chain<E, GT>(p, cx, grp);
+    load_chain<E, NEEDG>(p, cx, cur);
+
+    while (true) {
+        // prefetch the next group this wave owns
+        const long long grp_next = grp + nwaves;
+        const bool has_next = grp_next * cpw < p.nchains;
+        LaneCtx<E> cxn = cx;
+        ChainRegs<E> nxt;
+        if (has_next) {
+            set_chain<E, GT>(p, cxn, grp_next);
+            load_chain<E, NEEDG>(p, cxn, nxt);
+        }
+
+        const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
+        // running sums are first needed at the end of a transition: not prefetched (saves 4E VGPRs)
+        double sm[E], sq[E];
+        if (do_sum) { load_vec<E>(cx, p.sum, p.D, sm); load_vec<E>(cx, p.sumsq, p.D, sq); }
+        double z[E];
+        if (NEEDZ) lane_normals<E>(cx, p.seed, gchain, p.t0, z);        // before the loaded state is touched
+
+        TuneRegs tn;
+        if (per_chain_tune) tn = { cur.step, cur.accepted, cur.proposed, cur.totproposed, 0 };
+        else if (p.pooled) tn = { p.tune_step[0], p.tune_accepted[0], 0, 0, 0 };
+        else tn = { p.step0, 0, 0, 0, 0 };
+        const long long acc0 = tn.accepted;
+        tn.phase = per_chain_tune ? (int)(tn.proposed % p.period) : 0;
+        int sphase = p.save_phase0;
+        long long scol = p.save_col0;
+        unsigned long long nacc = 0;
+        bool stuck = false;
+
+        for (int s = 0; s < p.nsteps; ++s) {
+            const unsigned long long t = p.t0 + (unsigned long long)s;
+            if (p.cnt) tune_count_proposal(p, tn);
+            bool acc;
+            if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E>(p, tg, cx, gchain, t, z, vp, cur.x, cur.lt);
+            else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E>(p, tg, cx, gchain, t, z, tn.step, cur.x, cur.g, cur.lt);
+            else if (SAMPLER == KLARA_SAMPLER_HMC) acc = step_hmc<T, E>(p, tg, cx, gchain, t, z, tn.step, cur.x, cur.g, cur.lt);
+            else acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, cur.x, cur.lt, stuck);
+            nacc += acc ? 1ull : 0ull;
+            if (p.cnt && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;   // the slice sampler never counts accepts
+            if (p.accept != nullptr && cx.chain_ok && cx.q == 0)
+                p.accept[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
+            if (per_chain_tune) tuning_block(p, tn);
+            // save rule: BasicMCJob.jl:226-231 with postrange = (burnin+1):thinning:nsteps (BasicMCRange.jl:36)
+            const long long i1 = (long long)t + 1;
+            if (i1 > p.burnin && i1 <= p.nsteps_total) {
+                if (sphase == 0) {
+                    if (do_sum) {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) { sm[e] = sm[e] + x[e]; sq[e] = sq[e] + x[e] * x[e]; }
-                }
-                if (p.hist != nullptr && scol < p.hist_cols) {
-                    double* dst = p.hist + (scol * p.nchains + cx.chain) * p.D + cx.i0;
+                        for (int e = 0; e < E; ++e) { sm[e] = sm[e] + cur.x[e]; sq[e] = sq[e] + cur.x[e] * cur.x[e]; }
+                    }
+                    if (p.hist != nullptr && scol < p.hist_cols) {
+                        double* dst = p.hist + (scol * p.nchains + cx.chain) * p.D + cx.i0;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) if (cx.valid[e]) dst[e] = x[e];
+                        for (int e = 0; e < E; ++e) if (cx.valid[e]) dst[e] = cur.x[e];
+                    }
+                    ++scol;
                 }
-                ++scol;
+                sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
             }
-            sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
+            if (NEEDZ && s + 1 < p.nsteps) lane_normals<E>(cx, p.seed, gchain, t + 1, z);
         }
-    }
 
-    store_vec<E>(cx, p.X, p.D, x);
-    if (NEEDG) store_vec<E>(cx, p.GR, p.D, g);
-    if (do_sum) { store_vec<E>(cx, p.sum, p.D, sm); store_vec<E>(cx, p.sumsq, p.D, sq); }
-    if (cx.chain_ok && cx.q == 0) {
-        p.LT[cx.chain] = lt;
-        p.naccept[cx.chain] += nacc;
-        if (!p.pooled) {
-            p.tune_step[cx.chain] = tn.step;
-            p.tune_accepted[cx.chain] = tn.accepted;
-            p.tune_proposed[cx.chain] = tn.proposed;
-            p.tune_totproposed[cx.chain] = tn.totproposed;
-        } else if (p.cnt) {
-            atomicAdd(p.pooled_accepted, (unsigned long long)tn.accepted - (unsigned long long)p.tune_accepted[0]);
+        if (nacc != 0 || SAMPLER == KLARA_SAMPLER_SLICE || p.nsteps > 1) {
+            // (with one transition per launch a rejected proposal leaves x, g untouched: skip the write-back)
+            store_vec<E>(cx, p.X, p.D, cur.x);
+            if (NEEDG) store_vec<E>(cx, p.GR, p.D, cur.g);
         }
-        if (stuck) atomicMax(p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
+        if (do_sum) { store_vec<E>(cx, p.sum, p.D, sm); store_vec<E>(cx, p.sumsq, p.D, sq); }
+        if (cx.chain_ok && cx.q == 0) {
+            if (nacc != 0) { p.LT[cx.chain] = cur.lt; p.naccept[cx.chain] += nacc; }
+            if (per_chain_tune) {
+                p.tune_step[cx.chain] = tn.step;
+                p.tune_accepted[cx.chain] = tn.accepted;
+                p.tune_proposed[cx.chain] = tn.proposed;
+                p.tune_totproposed[cx.chain] = tn.totproposed;
+            } else if (p.pooled && p.cnt) {
+                atomicAdd(p.pooled_accepted, (unsigned long long)(tn.accepted - acc0));
+            }
+            if (stuck) atomicMax(p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
+        }
+        if (!has_next) break;
+        cur = nxt; cx = cxn; grp = grp_next;
     }
 }
 
