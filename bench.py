@@ -103,6 +103,7 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     kernel_ms, nlaunch = eng.last_run_ms()
+    lay_kind, lay_g, lay_e = eng.layout()
     _, _, nacc, ntr, _ = eng.pooled_summaries(with_sums=False)
 
     out = None
@@ -124,7 +125,8 @@ def main():
                        "acceptance_rate": nacc / max(ntr, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_transitions<MALA, GAUSS_DIAG, E=2, G=64>",
+                         "kernel": f"k_transitions<MALA, GAUSS_DIAG, E={lay_e}> ({lay_g} lanes x {lay_e} elements per chain, "
+                                   f"{64 // lay_g} chains per wavefront)",
                          "algorithmic_bytes_per_launch": alg, "launch_us": launch_s * 1e6, "launches": nlaunch},
         }
     eng.close()

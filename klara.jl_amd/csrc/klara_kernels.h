@@ -181,7 +181,13 @@ __device__ __forceinline__ void lane_normals(const LaneCtx<E>& c, unsigned long 
 #pragma unroll
     for (int j = 0; j < E / 2; ++j) {
         const kd_u32x4 b = kd_stream_block(seed, gchain, t, (uint32_t)((c.i0 >> 1) + j));
-        kd_normal_pair(b, &z[2 * j], &z[2 * j + 1]);
+        double z0, z1;
+        kd_normal_pair(b, &z0, &z1);
+        // padding elements (index >= D, or lanes of a group past the last chain) get z = 0.  With x = g = 0
+        // loaded there too, every per-element term downstream (proposal, gradient, kinetic/Metropolis sums)
+        // is exactly +-0, so the reductions need no per-term masking: x + 0 keeps the oracle's bits.
+        z[2 * j] = c.valid[2 * j] ? z0 : 0.0;
+        z[2 * j + 1] = c.valid[2 * j + 1] ? z1 : 0.0;
     }
 }
 
@@ -209,7 +215,7 @@ struct DiagTarget {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const double dd = x[e] - mu[e];
-            if (WANT_LT) acc = acc + (cx.valid[e] ? w[e] * (dd * dd) : 0.0);
+            if (WANT_LT) acc = acc + w[e] * (dd * dd);   // padding lanes hold x = mu = 0: the term is exactly 0
             if (WANT_GRAD) g[e] = (-2.0 * w[e]) * dd;
         }
         ltpart = acc;
@@ -261,7 +267,7 @@ struct LogisticTarget {
         if (WANT_LT) {
             double dotpp = 0.0;
 #pragma unroll
-            for (int e = 0; e < E; ++e) dotpp = dotpp + (cx.valid[e] ? x[e] * x[e] : 0.0);
+            for (int e = 0; e < E; ++e) dotpp = dotpp + x[e] * x[e];
             const double ll = dotxy - slog;
             const double lp = -0.5 * (dotpp / lambda + lpconst);                  // plogprior
             ltpart = ll + lp;
@@ -365,10 +371,10 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const double q1 = mu[e] - xp[e];
-        s1 = s1 + (cx.valid[e] ? 0.5 * ((q1 * q1) / h) : 0.0);                        // :90
+        s1 = s1 + 0.5 * ((q1 * q1) / h);                        // :90
         const double mup = xp[e] + halfh * gp[e];                                     // :91
         const double q2 = mup - x[e];
-        s2 = s2 + (cx.valid[e] ? 0.5 * ((q2 * q2) / h) : 0.0);                        // :92
+        s2 = s2 + 0.5 * ((q2 * q2) / h);                        // :92
     }
     red[1] = s1; red[2] = s2;
     group_allreduce<3>(red, cx.G, cx.lane);
@@ -402,7 +408,7 @@ __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const La
     for (int e = 0; e < E; ++e) mom[e] = z[e];                                        // :135
     double k0[1] = { 0.0 };
 #pragma unroll
-    for (int e = 0; e < E; ++e) k0[0] = k0[0] + (cx.valid[e] ? mom[e] * mom[e] : 0.0);
+    for (int e = 0; e < E; ++e) k0[0] = k0[0] + mom[e] * mom[e];
     group_allreduce<1>(k0, cx.G, cx.lane);
     const double H0 = lt - 0.5 * k0[0];                                               // :137
 #pragma unroll
@@ -421,7 +427,7 @@ __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const La
     tg.template eval<true, false>(cx, xp, red[0], gd);                                // :157
     double k1 = 0.0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) k1 = k1 + (cx.valid[e] ? mom[e] * mom[e] : 0.0);
+    for (int e = 0; e < E; ++e) k1 = k1 + mom[e] * mom[e];
     red[1] = k1;
     group_allreduce<2>(red, cx.G, cx.lane);
     const double ltp = tg.finalize(red[0]);

@@ -69,11 +69,15 @@ def default_layout(target_kind: int, ndims: int):
         return (1, 4, ne)
     if target_kind == L.TARGET_LOGISTIC:
         return (0, 1, 2 if d <= 2 else 4 if d <= 4 else 8)
-    e = 2 if d <= 128 else 4 if d <= 256 else 8
-    g = 1
-    while g < (d + e - 1) // e:
-        g *= 2
-    return (0, g, e)
+    def p2(v):
+        g = 1
+        while g < v:
+            g *= 2
+        return g
+    e = 4 if d <= 256 else 8
+    if d <= 128 and p2((d + 1) // 2) * 2 < p2((d + 3) // 4) * 4:
+        e = 2
+    return (0, p2((d + e - 1) // e), e)
 
 
 def _f64(a):
