@@ -131,6 +131,17 @@ def main():
         }
     eng.close()
 
+    if rank == 0:
+        # HBM bytes per launch from the PMC passes of the same command (profiles/, see scripts/profile_bench.sh);
+        # only reported when this run's configuration is the profiled one
+        try:
+            tr = json.loads((ROOT / "profiles" / "r1_bench_mala_traffic.json").read_text())
+            if (tr["nchains"], tr["ndims"], tr["steps_per_launch"]) == (n, NDIMS, args.spl) and f"{lay_e}, 0>" in tr["kernel"]:
+                out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r1_bench_mala_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
+        except Exception:
+            pass
+
     if rank == 0 and world == 1 and not args.no_extra:
         out["extra"] = extra_measurements(K, L, n, stream)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,61 @@
+# KlaraHIP.jl — ccall binding of libklara_hip.so (see INTEGRATION.md). UNTESTED in the build image (no Julia).
+module KlaraHIP
+const lib = "libklara_hip"            # klara.jl_amd/lib/libklara_hip.so on LD_LIBRARY_PATH
+
+# struct klara_desc — field order/types exactly as include/klara_hip.h
+struct KlaraDesc
+    struct_size::UInt32; abi_version::UInt32
+    sampler::Int32; target::Int32; tuner::Int32; tuner_mode::Int32
+    nchains::Int64; chain_offset::Int64; ndims::Int32; device::Int32
+    mh_sigma::Ptr{Float64}; driftstep::Float64; leapstep::Float64
+    nleaps::Int32; slice_stepout::Int32; slice_widths::Ptr{Float64}
+    targetrate::Float64; score_k::Float64; period::Int32; verbose::Int32
+    nsteps::Int64; burnin::Int64; thinning::Int64
+    gauss_w::Ptr{Float64}; gauss_mu::Ptr{Float64}; gauss_const::Float64; gauss_prec::Ptr{Float64}
+    logit_X::Ptr{Float64}; logit_y::Ptr{Float64}; logit_ndata::Int32; reserved0::Int32; logit_lambda::Float64
+    seed::UInt64; monitor::UInt32; steps_per_launch::Int32; stream::Ptr{Cvoid}
+end
+
+check(st::Cint, what) = st == 0 || error(what, ": ", unsafe_string(ccall((:klara_strerror, lib), Cstring, (Cint,), st)))
+
+mutable struct HIPMCJob            # stands for N BasicMCJobs of one model
+    handle::Ptr{Cvoid}; nchains::Int; ndims::Int; range   # range::BasicMCRange
+end
+
+# samplers/tuners are Klara's own structs: MH(σ), MALA(h), HMC(ε, L), SliceSampler(w, stepout),
+# VanillaMCTuner(), AcceptanceRateMCTuner(rate)
+function HIPMCJob(desc::KlaraDesc, X0::Matrix{Float64}, range)   # X0 is D × N (column = chain) == N×D row-major
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:klara_create, lib), Cint, (Ref{KlaraDesc}, Ref{Ptr{Cvoid}}), desc, h), "klara_create")
+    job = HIPMCJob(h[], size(X0, 2), size(X0, 1), range)
+    finalizer(j -> ccall((:klara_destroy, lib), Cint, (Ptr{Cvoid},), j.handle), job)
+    check(ccall((:klara_set_state, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), job.handle, X0), "klara_set_state")
+    job
+end
+
+run(job::HIPMCJob) =                                     # BasicMCJob.jl:212-244 for all chains
+    check(ccall((:klara_run, lib), Cint, (Ptr{Cvoid}, Clonglong), job.handle, job.range.nsteps), "klara_run")
+
+reset(job::HIPMCJob) = check(ccall((:klara_reset, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), job.handle, C_NULL), "klara_reset")
+reset(job::HIPMCJob, X::Matrix{Float64}) =
+    check(ccall((:klara_reset, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), job.handle, X), "klara_reset")
+
+# output(job)[c]: value matrix of chain c exactly as BasicContMuvParameterNState.value (D × npoststeps)
+function chainvalue(job::HIPMCJob, c::Integer)
+    n = Ref{Clonglong}(0)
+    ccall((:klara_get_chain, lib), Cint, (Ptr{Cvoid}, Clonglong, Ptr{Float64}, Clonglong, Ref{Clonglong}),
+          job.handle, c - 1, C_NULL, 0, n)
+    v = Matrix{Float64}(undef, job.ndims, n[])
+    check(ccall((:klara_get_chain, lib), Cint, (Ptr{Cvoid}, Clonglong, Ptr{Float64}, Clonglong, Ref{Clonglong}),
+                job.handle, c - 1, v, n[], n), "klara_get_chain")
+    v
+end
+
+# mean(chain) for every chain from the on-device running sums (stats/mean.jl:7-11): D × N
+function chainmeans(job::HIPMCJob)
+    s = Matrix{Float64}(undef, job.ndims, job.nchains); q = similar(s); n = Ref{Clonglong}(0)
+    check(ccall((:klara_get_chain_sums, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{Clonglong}),
+                job.handle, s, q, n), "klara_get_chain_sums")
+    s ./ n[]
+end
+end # module

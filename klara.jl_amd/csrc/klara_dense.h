@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
         } else if (SAMPLER == KLARA_SAMPLER_MALA) {
             // iterate/MALA.jl:78-128
             double z[NE], xc[NE], red[3];
-            const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h);
+            const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h), inv_h = 1.0 / h;
             mnormals<NE>(cx, p.seed, gchain, t, z);
             double s1 = 0.0;
             {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
                     const double mu = xc[e] + halfh * g0[e];           // MALA.jl:83
                     xp[e] = mu + sq * z[e];                            // MALA.jl:84
                     const double q1 = mu - xp[e];
-                    s1 = s1 + (cx.valid[e] ? 0.5 * ((q1 * q1) / h) : 0.0);      // MALA.jl:90
+                    s1 = s1 + (cx.valid[e] ? 0.5 * ((q1 * q1) * inv_h) : 0.0);      // MALA.jl:90
                 }
             }
             dense_grad<NE>(ldsP, cx.lane, xp, gp);                     // MALA.jl:86
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
                 l1 = l1 + (cx.valid[e] ? xp[e] * gp[e] : 0.0);
                 const double mup = xp[e] + halfh * gp[e];              // MALA.jl:91
                 const double q2 = mup - xc[e];
-                s2 = s2 + (cx.valid[e] ? 0.5 * ((q2 * q2) / h) : 0.0);          // MALA.jl:92
+                s2 = s2 + (cx.valid[e] ? 0.5 * ((q2 * q2) * inv_h) : 0.0);          // MALA.jl:92
             }
             red[0] = l1; red[1] = s1; red[2] = s2;
             mreduce<3>(red, cx.lane);

@@ -1,0 +1,66 @@
+// ubench.hip — per-primitive VALU cost on gfx950 (issue cycles per wave-instruction sequence).
+// Not part of the product: a measuring tool.  Build+run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off scripts/ubench.hip -o /tmp/ubench && /tmp/ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "../klara.jl_amd/csrc/klara_kernels.h"
+
+#define ITERS 2000
+template <int OP>
+__global__ __launch_bounds__(256) void k_op(double* out, double seedv, int G)
+{
+    const int lane = threadIdx.x & 63;
+    double a = seedv + 1e-3 * lane, b = 0.5 + 1e-4 * lane, acc = 0.0;
+    uint32_t c0 = threadIdx.x, c1 = blockIdx.x;
+    for (int i = 0; i < ITERS; ++i) {
+        if (OP == 0) { kd_u32x4 r = kd_philox4x32_10(c0, c1, 7u, i, 1u, 2u); c0 = r.x; c1 = r.y ^ r.z ^ r.w; }
+        else if (OP == 1) { a = kd_log(a) + 3.0; }
+        else if (OP == 2) { a = kd_exp(a * 1e-3) + 0.1; }
+        else if (OP == 3) { double s, c; kd_sincos2pi(b, &s, &c); b = 0.5 + 0.25 * s * c; }
+        else if (OP == 4) { a = __builtin_sqrt(a) + 2.0; }
+        else if (OP == 5) { a = 3.0 / a + 1.0; }
+        else if (OP == 6) { kd_u32x4 r = kd_philox4x32_10(c0, c1, 7u, i, 1u, 2u); double z0, z1; kd_normal_pair(r, &z0, &z1); acc += z0 * z1; c0 = r.x; c1 = r.y; }
+        else if (OP == 7) { double v[3] = { a, b, acc }; group_allreduce<3>(v, G, lane); a = v[0] * 1e-2 + 1.0; b = v[1] * 1e-3 + 0.5; acc = v[2] * 1e-3; }
+        else if (OP == 8) { a = kd_fma(a, 0.999, 0.001); }
+        else if (OP == 9) { c0 = c0 * 0x9E3779B9u + c1; }   // v_mul_lo_u32 chain
+        else if (OP == 10) { uint64_t p = (uint64_t)c0 * 0xD2511F53u; c0 = (uint32_t)(p >> 32) ^ (uint32_t)p ^ c1; }  // mad_u64_u32
+        else if (OP == 11) { double u = kd_u52(c0, c1); a += u; c0 += 77; }
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = a + b + acc + c0 + c1;
+}
+
+template <int OP>
+static void run(const char* name, int G = 64)
+{
+    double* d; hipMalloc(&d, sizeof(double) * 256 * 1024 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int blocks = 256 * 4;   // 4 blocks of 4 waves per CU -> 4 waves per SIMD
+    hipLaunchKernelGGL(k_op<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.5, G);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_op<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.5, G);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    // each SIMD ran 4 waves x ITERS ops back to back; assume 2.4 GHz
+    const double cyc = ms * 1e-3 * 2.4e9 / (4.0 * ITERS);
+    printf("%-28s %8.1f cycles per wave-op (4 waves/SIMD, %.3f ms)\n", name, cyc, ms);
+    hipFree(d);
+}
+
+int main()
+{
+    run<8>("fma_f64 (dependent)");
+    run<9>("mul_lo_u32 chain");
+    run<10>("mad_u64_u32+2xor");
+    run<0>("philox4x32_10");
+    run<11>("u52");
+    run<1>("kd_log");
+    run<2>("kd_exp");
+    run<3>("kd_sincos2pi");
+    run<4>("sqrt_f64");
+    run<5>("div_f64");
+    run<6>("philox+normal_pair");
+    run<7>("allreduce<3> G=64", 64);
+    run<7>("allreduce<3> G=32", 32);
+    run<7>("allreduce<3> G=16", 16);
+    return 0;
+}
