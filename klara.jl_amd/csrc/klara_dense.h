@@ -82,12 +82,24 @@ __device__ __forceinline__ void mnormals(const MfmaCtx<NE>& c, unsigned long lon
 {
     const uint32_t sh = (uint32_t)(c.q >> 1);
     const bool odd = (c.q & 1) != 0;
+    // Lanes q and q^1 (lane ^ 16) of a chain need the two halves of the SAME Box-Muller pairs (even dims take the
+    // cos half, odd dims the sin half).  Instead of both lanes evaluating every pair, elements are taken two at a
+    // time: the even-q lane evaluates the pair of element e, the odd-q lane the pair of element e+1, and they swap
+    // the halves the partner needs with one ds_bpermute — half the Philox/log/sincos work, identical values.
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
+    for (int e = 0; e + 1 < NE; e += 2) {
         double z0, z1;
-        kd_normal_pair(kd_stream_block(seed, gchain, t, 2u * (uint32_t)e + sh), &z0, &z1);
-        z[e] = odd ? z1 : z0;
-        __builtin_amdgcn_sched_barrier(0);   // keep the 25 unrolled Philox/Box-Muller bodies from interleaving (VGPR pressure)
+        const uint32_t mine = 2u * (uint32_t)(odd ? e + 1 : e) + sh;
+        kd_normal_pair(kd_stream_block(seed, gchain, t, mine), &z0, &z1);
+        const double recv = bperm_xor(odd ? z0 : z1, c.lane, 16);
+        z[e] = odd ? recv : z0;          // even q: cos half of pair(e);   odd q: sin half of pair(e) from the partner
+        z[e + 1] = odd ? z1 : recv;      // even q: cos half of pair(e+1) from the partner; odd q: sin half of pair(e+1)
+        __builtin_amdgcn_sched_barrier(0);   // keep the unrolled Philox/Box-Muller bodies from interleaving (VGPR pressure)
+    }
+    if (NE & 1) {
+        double z0, z1;
+        kd_normal_pair(kd_stream_block(seed, gchain, t, 2u * (uint32_t)(NE - 1) + sh), &z0, &z1);
+        z[NE - 1] = odd ? z1 : z0;
     }
 }
 

@@ -19,6 +19,9 @@
 #include "detmath.h"
 #include "../../include/klara_hip.h"
 
+#ifndef KLARA_E4_WAVES
+#define KLARA_E4_WAVES 2   // min waves per SIMD requested for the E=4 kernels (register budget 256)
+#endif
 #define KLARA_SLICE_ATT_BITS 14
 #define KLARA_SLICE_MAX_ATT ((1 << KLARA_SLICE_ATT_BITS) - 1)
 #define KLARA_INIT_TRANSITION ((((uint64_t)1) << 40) - 1)
@@ -568,7 +571,7 @@ __device__ __forceinline__ void set_chain(const KParams& p, LaneCtx<E>& c, long 
 // the loaded registers are first touched, so HBM latency overlaps the RNG/ALU work instead of
 // serialising with it (one-launch-per-transition mode is otherwise latency-bound at 3 waves/SIMD).
 template <int SAMPLER, int TARGET, int E, int GT>
-__global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? 2 : 1))) void k_transitions(const KParams p)
+__global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1))) void k_transitions(const KParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = typename TargetSel<TARGET, E>::type;
