@@ -62,7 +62,14 @@ typedef enum klara_target {
     KLARA_TARGET_GAUSS_DENSE = 1,
     /* Bayesian logistic regression of doc/examples/swiss/MALA/analytical.jl:11-18:
      * lt = dot(Xp, y) - sum(log(1+exp(Xp))) - 0.5 (p.p/lambda + D log(2 pi lambda)). */
-    KLARA_TARGET_LOGISTIC = 2
+    KLARA_TARGET_LOGISTIC = 2,
+    /* Hierarchical normal growth-curve model for data/rats/{weight,age}.csv (BASELINE cfg 5).  The reference
+     * ships the data but no model (doc/examples/rats/Gibbs.jl:1-7 is a stub), so the target is builder-defined:
+     * the BUGS "Rats" model  Y_ij ~ N(alpha_i + beta_i xc_j, sigma_c^2),  alpha_i ~ N(alpha_c, sigma_a^2),
+     * beta_i ~ N(beta_c, sigma_b^2),  alpha_c, beta_c ~ N(0, 1/prior_prec),  1/sigma_k^2 ~ Gamma(a, b),
+     * sampled in theta = (alpha_1, beta_1, ..., alpha_R, beta_R, alpha_c, beta_c, log sigma_c, log sigma_a,
+     * log sigma_b), D = 2R + 5 (65 for the 30 rats).  See DESIGN.md for the log-density. */
+    KLARA_TARGET_HIER_NORMAL = 3
 } klara_target;
 
 /* src/tuners/{VanillaMCTuner,AcceptanceRateMCTuner}.jl */
@@ -124,6 +131,13 @@ typedef struct klara_desc {
     int32_t  logit_ndata;
     int32_t  reserved0;
     double   logit_lambda;       /* LOGISTIC: prior variance (v[1] of the example)                   */
+    const double* hier_Y;        /* HIER_NORMAL: R x T row-major observations                        */
+    const double* hier_xc;       /* HIER_NORMAL: T centred covariate values (age_j - 22 for rats)    */
+    int32_t  hier_nunits;        /* R (D must equal 2R + 5)                                          */
+    int32_t  hier_ntimes;        /* T (<= 16)                                                        */
+    double   hier_prior_prec;    /* precision of the N(0, .) priors on alpha_c, beta_c               */
+    double   hier_gamma_a;       /* Gamma(a, b) prior on the three precisions                        */
+    double   hier_gamma_b;
 
     uint64_t seed;               /* Philox key                                                       */
     uint32_t monitor;            /* KLARA_MON_* bits                                                 */

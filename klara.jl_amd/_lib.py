@@ -20,7 +20,7 @@ OK, ERR_INVALID_ARG, ERR_NONFINITE_INIT, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ER
 # klara_sampler
 SAMPLER_MH, SAMPLER_MALA, SAMPLER_HMC, SAMPLER_SLICE = range(4)
 # klara_target
-TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC = range(3)
+TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET_HIER_NORMAL = range(4)
 # klara_tuner / mode
 TUNER_VANILLA, TUNER_ACCEPT_RATE = 0, 1
 TUNE_PER_CHAIN, TUNE_POOLED = 0, 1
@@ -43,6 +43,8 @@ class KlaraDesc(C.Structure):
         ("gauss_w", _dp), ("gauss_mu", _dp), ("gauss_const", C.c_double), ("gauss_prec", _dp),
         ("logit_X", _dp), ("logit_y", _dp), ("logit_ndata", C.c_int32), ("reserved0", C.c_int32),
         ("logit_lambda", C.c_double),
+        ("hier_Y", _dp), ("hier_xc", _dp), ("hier_nunits", C.c_int32), ("hier_ntimes", C.c_int32),
+        ("hier_prior_prec", C.c_double), ("hier_gamma_a", C.c_double), ("hier_gamma_b", C.c_double),
         ("seed", C.c_uint64), ("monitor", C.c_uint32), ("steps_per_launch", C.c_int32),
         ("stream", C.c_void_p),
     ]

@@ -24,7 +24,7 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 
 from . import _lib as L
-from .engine import Engine, GaussDenseTarget, GaussDiagTarget, LogisticTarget
+from .engine import Engine, GaussDenseTarget, GaussDiagTarget, HierNormalTarget, LogisticTarget
 
 
 # ------------------------------------------------------------------ range (src/ranges/BasicMCRange.jl)
@@ -148,8 +148,8 @@ class BasicContMuvParameter:
             raise ValueError("logtarget (a target family object) is required")
         if unsupported:
             raise NotImplementedError(f"closure fields not available on device: {sorted(unsupported)}")
-        if not isinstance(logtarget, (GaussDiagTarget, GaussDenseTarget, LogisticTarget)):
-            raise TypeError("logtarget must be GaussDiagTarget, GaussDenseTarget or LogisticTarget")
+        if not isinstance(logtarget, (GaussDiagTarget, GaussDenseTarget, LogisticTarget, HierNormalTarget)):
+            raise TypeError("logtarget must be GaussDiagTarget, GaussDenseTarget, LogisticTarget or HierNormalTarget")
         self.key = str(key).lstrip(":")
         self.target = logtarget
 

@@ -31,7 +31,8 @@ struct klara_handle {
     double *sum = nullptr, *sumsq = nullptr;
     double* hist = nullptr; long long hist_cols = 0;
     int* err = nullptr;
-    double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr;
+    double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr,
+           *hY = nullptr, *hxc = nullptr;
     double* pooled_out = nullptr;   // 2*D doubles + 1 u64 scratch for pooled summaries
     double lpconst = 0.0;
     // run state
@@ -76,7 +77,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
         const int v = atoi(s);
         if ((v == 2 || v == 4 || v == 8) && (D + v - 1) / v <= 64) e = v;
     }
-    if (e == 0) return KLARA_ERR_UNSUPPORTED;
+    if (e == 0 || (d.target == KLARA_TARGET_HIER_NORMAL && e > 4)) return KLARA_ERR_UNSUPPORTED;
     *E = e; *G = pow2ceil((D + e - 1) / e);
     return KLARA_OK;
 }
@@ -87,7 +88,7 @@ static klara_status validate(const klara_desc* d)
     if (d->struct_size != sizeof(klara_desc) || d->abi_version != KLARA_ABI_VERSION) return KLARA_ERR_INVALID_ARG;
     if (d->nchains <= 0 || d->ndims <= 0 || d->chain_offset < 0) return KLARA_ERR_INVALID_ARG;
     if (d->sampler < KLARA_SAMPLER_MH || d->sampler > KLARA_SAMPLER_SLICE) return KLARA_ERR_INVALID_ARG;
-    if (d->target < KLARA_TARGET_GAUSS_DIAG || d->target > KLARA_TARGET_LOGISTIC) return KLARA_ERR_INVALID_ARG;
+    if (d->target < KLARA_TARGET_GAUSS_DIAG || d->target > KLARA_TARGET_HIER_NORMAL) return KLARA_ERR_INVALID_ARG;
     if (d->tuner != KLARA_TUNER_VANILLA && d->tuner != KLARA_TUNER_ACCEPT_RATE) return KLARA_ERR_INVALID_ARG;
     if (d->tuner_mode != KLARA_TUNE_PER_CHAIN && d->tuner_mode != KLARA_TUNE_POOLED) return KLARA_ERR_INVALID_ARG;
     // BasicMCRange.jl:22-24
@@ -112,6 +113,11 @@ static klara_status validate(const klara_desc* d)
         break;
     }
     if (d->target == KLARA_TARGET_GAUSS_DENSE && !d->gauss_prec) return KLARA_ERR_INVALID_ARG;
+    if (d->target == KLARA_TARGET_HIER_NORMAL &&
+        (!d->hier_Y || !d->hier_xc || d->hier_nunits <= 0 || d->hier_ntimes <= 0 || d->hier_ntimes > 16 ||
+         d->ndims != 2 * d->hier_nunits + 5 || !(d->hier_prior_prec >= 0.0) || !(d->hier_gamma_a >= 0.0) ||
+         !(d->hier_gamma_b >= 0.0)))
+        return KLARA_ERR_INVALID_ARG;
     if (d->target == KLARA_TARGET_LOGISTIC &&
         (!d->logit_X || !d->logit_y || d->logit_ndata <= 0 || !(d->logit_lambda > 0.0)))
         return KLARA_ERR_INVALID_ARG;
@@ -134,7 +140,7 @@ static void free_all(klara_handle* h)
     hipFree(h->X); hipFree(h->GR); hipFree(h->LT); hipFree(h->tune_step); hipFree(h->tune_acc);
     hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->pooled_acc); hipFree(h->accept);
     hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->hist); hipFree(h->err);
-    hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly);
+    hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
     hipFree(h->Pfrag); hipFree(h->pooled_out);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -195,6 +201,9 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     if (desc->target == KLARA_TARGET_GAUSS_DIAG) {
         if (desc->gauss_w) CK(upload(&h->gw, desc->gauss_w, D));
         if (desc->gauss_mu) CK(upload(&h->gmu, desc->gauss_mu, D));
+    } else if (desc->target == KLARA_TARGET_HIER_NORMAL) {
+        CK(upload(&h->hY, desc->hier_Y, (size_t)desc->hier_nunits * (size_t)desc->hier_ntimes));
+        CK(upload(&h->hxc, desc->hier_xc, (size_t)desc->hier_ntimes));
     } else if (desc->target == KLARA_TARGET_LOGISTIC) {
         CK(upload(&h->lX, desc->logit_X, (size_t)desc->logit_ndata * D));
         CK(upload(&h->ly, desc->logit_y, (size_t)desc->logit_ndata));
@@ -214,7 +223,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     }
     // the descriptor's host pointers are not retained
     h->d.mh_sigma = nullptr; h->d.slice_widths = nullptr; h->d.gauss_w = nullptr; h->d.gauss_mu = nullptr;
-    h->d.gauss_prec = nullptr; h->d.logit_X = nullptr; h->d.logit_y = nullptr; h->d.stream = nullptr;
+    h->d.gauss_prec = nullptr; h->d.logit_X = nullptr; h->d.logit_y = nullptr; h->d.hier_Y = nullptr; h->d.hier_xc = nullptr; h->d.stream = nullptr;
 #undef CK
 #undef CKH
     *out = h;
@@ -252,6 +261,8 @@ static KParams make_params(klara_handle* h)
     p.burnin = d.burnin; p.thinning = d.thinning; p.nsteps_total = d.nsteps;
     p.gw = h->gw; p.gmu = h->gmu; p.gconst = d.gauss_const;
     p.lX = h->lX; p.ly = h->ly; p.ndata = d.logit_ndata; p.lambda = d.logit_lambda; p.lpconst = h->lpconst;
+    p.hY = h->hY; p.hxc = h->hxc; p.hR = d.hier_nunits; p.hT = d.hier_ntimes; p.hp0 = d.hier_prior_prec;
+    p.ha0 = d.hier_gamma_a; p.hb0 = d.hier_gamma_b;
     return p;
 }
 
@@ -281,6 +292,8 @@ static size_t lds_for(const klara_handle* h)
 {
     if (h->kind == 0 && h->d.target == KLARA_TARGET_LOGISTIC)
         return sizeof(double) * (size_t)h->d.logit_ndata * (size_t)(h->d.ndims + 1);
+    if (h->kind == 0 && h->d.target == KLARA_TARGET_HIER_NORMAL)
+        return sizeof(double) * ((size_t)h->d.hier_nunits * (size_t)h->d.hier_ntimes + (size_t)h->d.hier_ntimes);
     return 0;
 }
 
@@ -292,7 +305,7 @@ static hipError_t launch_init_t(const KParams& p, int E, int G, int needgrad, di
     if (E == 2 && G == 64 && TARGET == KLARA_TARGET_GAUSS_DIAG) hipLaunchKernelGGL((k_init<TARGET, 2, 64>), grid, blk, lds, st, p, needgrad);
     else if (E == 2) hipLaunchKernelGGL((k_init<TARGET, 2, 0>), grid, blk, lds, st, p, needgrad);
     else if (E == 4) hipLaunchKernelGGL((k_init<TARGET, 4, 0>), grid, blk, lds, st, p, needgrad);
-    else if (E == 8) hipLaunchKernelGGL((k_init<TARGET, 8, 0>), grid, blk, lds, st, p, needgrad);
+    else if (E == 8 && TARGET != KLARA_TARGET_HIER_NORMAL) hipLaunchKernelGGL((k_init<TARGET, (TARGET == KLARA_TARGET_HIER_NORMAL ? 4 : 8), 0>), grid, blk, lds, st, p, needgrad);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -351,6 +364,8 @@ static klara_status init_common(klara_handle* h)
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, needgrad, grid_for(h), st);
     else if (d.target == KLARA_TARGET_GAUSS_DIAG)
         e = launch_init_t<KLARA_TARGET_GAUSS_DIAG>(p, h->E, h->G, needgrad, grid_for(h), lds_for(h), st);
+    else if (d.target == KLARA_TARGET_HIER_NORMAL)
+        e = launch_init_t<KLARA_TARGET_HIER_NORMAL>(p, h->E, h->G, needgrad, grid_for(h), lds_for(h), st);
     else e = launch_init_t<KLARA_TARGET_LOGISTIC>(p, h->E, h->G, needgrad, grid_for(h), lds_for(h), st);
     HIPCHK(e);
     int flag = 0;

@@ -52,6 +52,7 @@ struct KParams {
     // targets
     const double* gw; const double* gmu; double gconst;      // diag (gw/gmu may be null)
     const double* lX; const double* ly; int ndata; double lambda; double lpconst;   // logistic
+    const double* hY; const double* hxc; int hR; int hT; double hp0; double ha0; double hb0;   // hierarchical normal
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -283,9 +284,108 @@ struct LogisticTarget {
     __device__ __forceinline__ double finalize(double red) const { return red; }
 };
 
+// KLARA_TARGET_HIER_NORMAL (BUGS "Rats", builder-defined — include/klara_hip.h, oracle ko_hier_eval).
+// theta = (a_1, b_1, ..., a_R, b_R, a_c, b_c, s_c, s_a, s_b): a lane's E contiguous elements are E/2 whole rats
+// (or part of the 5-element hyper block), so the residual sums of a rat are lane-local; the data (R x T
+// observations, T centred ages) sit in LDS.  Per evaluation: the five hyper-parameters are broadcast from their
+// owner lanes (ds_bpermute), the three precisions exp(-2 s_k) are evaluated ONCE per group (lane l takes k = l % 3,
+// results broadcast back) and the five sums over rats go through one 5-value butterfly.
+template <int E>
+struct HierTarget {
+    const double* sY; const double* sxc;
+    int R, T, i0, hl[5], he[5];          // owner lane (within the group) and element slot of each hyper-parameter
+    double p0, a0, b0;
+    static __device__ __forceinline__ size_t lds_bytes(const KParams& p)
+    {
+        return sizeof(double) * ((size_t)p.hR * (size_t)p.hT + (size_t)p.hT);
+    }
+    __device__ __forceinline__ void init(const KParams& p, const LaneCtx<E>& cx, double* lds)
+    {
+        double* Y = lds; double* xc = lds + (size_t)p.hR * p.hT;
+        for (int i = threadIdx.x; i < p.hR * p.hT; i += blockDim.x) Y[i] = p.hY[i];
+        for (int i = threadIdx.x; i < p.hT; i += blockDim.x) xc[i] = p.hxc[i];
+        __syncthreads();
+        sY = Y; sxc = xc; R = p.hR; T = p.hT; p0 = p.hp0; a0 = p.ha0; b0 = p.hb0; i0 = cx.i0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { hl[k] = (2 * R + k) / E; he[k] = (2 * R + k) % E; }
+    }
+    template <bool WANT_LT, bool WANT_GRAD>
+    __device__ __forceinline__ void eval(const LaneCtx<E>& cx, const double (&x)[E], double& ltpart,
+                                         double (&g)[E]) const
+    {
+        const int gb = cx.lane - cx.q;
+        // hyper-parameters: a_c, b_c, s_c, s_a, s_b
+        double hv[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            double v = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (e == he[k]) v = x[e];
+            hv[k] = (cx.G > 1) ? lane_bcast(v, gb + hl[k]) : v;
+        }
+        const double ac = hv[0], bc = hv[1], sc = hv[2], sa = hv[3], sb = hv[4];
+        double wc, wa, wb;
+        if (cx.G >= 4) {
+            const int k3 = cx.q % 3;
+            const double w = kd_exp(-2.0 * (k3 == 0 ? sc : (k3 == 1 ? sa : sb)));
+            wc = lane_bcast(w, gb); wa = lane_bcast(w, gb + 1); wb = lane_bcast(w, gb + 2);
+        } else {
+            wc = kd_exp(-2.0 * sc); wa = kd_exp(-2.0 * sa); wb = kd_exp(-2.0 * sb);
+        }
+        double red[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };     // A1, B1, A2, B2, C2 lane partials
+#pragma unroll
+        for (int pr = 0; pr < E / 2; ++pr) {
+            const int ia = i0 + 2 * pr;                  // element index of a_i; the rat is ia >> 1
+            const bool israt = ia < 2 * R;
+            const int rat = israt ? (ia >> 1) : 0;
+            const double ai = x[2 * pr], bi = x[2 * pr + 1];
+            const double da = ai - ac, db = bi - bc;
+            double S1 = 0.0, Sx = 0.0, S2 = 0.0;
+            const double* yrow = sY + rat * T;
+            for (int j = 0; j < T; ++j) {
+                const double xj = sxc[j];
+                const double r = (yrow[j] - ai) - bi * xj;
+                S1 = S1 + r; Sx = Sx + r * xj; S2 = S2 + r * r;
+            }
+            if (WANT_GRAD) { g[2 * pr] = wc * S1 - wa * da; g[2 * pr + 1] = wc * Sx - wb * db; }
+            // element order within the lane: a-slot terms then b-slot terms, exactly the oracle's term arrays
+            red[0] = red[0] + (israt ? da : 0.0);        red[1] = red[1] + 0.0;
+            red[2] = red[2] + (israt ? da * da : 0.0);   red[3] = red[3] + 0.0;
+            red[4] = red[4] + (israt ? S2 : 0.0);
+            red[0] = red[0] + 0.0;                       red[1] = red[1] + (israt ? db : 0.0);
+            red[2] = red[2] + 0.0;                       red[3] = red[3] + (israt ? db * db : 0.0);
+            red[4] = red[4] + 0.0;
+        }
+        group_allreduce<5>(red, cx.G, cx.lane);
+        const double A1 = red[0], B1 = red[1], A2 = red[2], B2 = red[3], C2 = red[4];
+        const double RT = (double)R * (double)T, Rd = (double)R;
+        if (WANT_GRAD) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = i0 + e;
+                if (i == 2 * R) g[e] = wa * A1 - p0 * ac;
+                else if (i == 2 * R + 1) g[e] = wb * B1 - p0 * bc;
+                else if (i == 2 * R + 2) g[e] = ((wc * C2 - RT) - 2.0 * a0) + (2.0 * b0) * wc;
+                else if (i == 2 * R + 3) g[e] = ((wa * A2 - Rd) - 2.0 * a0) + (2.0 * b0) * wa;
+                else if (i == 2 * R + 4) g[e] = ((wb * B2 - Rd) - 2.0 * a0) + (2.0 * b0) * wb;
+                else if (i > 2 * R + 4) g[e] = 0.0;
+            }
+        }
+        if (WANT_LT) {
+            const double l_c = (-RT * sc - 0.5 * (wc * C2)) + (-2.0 * a0 * sc - b0 * wc);
+            const double l_a = (-Rd * sa - 0.5 * (wa * A2)) + (-2.0 * a0 * sa - b0 * wa);
+            const double l_b = (-Rd * sb - 0.5 * (wb * B2)) + (-2.0 * a0 * sb - b0 * wb);
+            const double lt = ((l_c + l_a) + l_b) - (0.5 * p0) * (ac * ac + bc * bc);
+            ltpart = (cx.q == 0) ? lt : 0.0;            // the caller's butterfly then returns lt itself
+        }
+    }
+    __device__ __forceinline__ double finalize(double red) const { return red; }
+};
+
 template <int TARGET, int E> struct TargetSel;
 template <int E> struct TargetSel<KLARA_TARGET_GAUSS_DIAG, E> { using type = DiagTarget<E>; };
 template <int E> struct TargetSel<KLARA_TARGET_LOGISTIC, E> { using type = LogisticTarget<E>; };
+template <int E> struct TargetSel<KLARA_TARGET_HIER_NORMAL, E> { using type = HierTarget<E>; };
 
 __device__ __forceinline__ bool kfinite(double v) { return (v == v) && (v - v == 0.0); }
 

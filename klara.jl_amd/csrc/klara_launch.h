@@ -30,6 +30,10 @@ hipError_t klara_launch_mfma_probe(const double* A, const double* B, const doubl
             else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 4, 0>), grid, blk, lds, st, p);         \
             else if (E == 8) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 8, 0>), grid, blk, lds, st, p);         \
             else return hipErrorInvalidValue;                                                          \
+        } else if (target == KLARA_TARGET_HIER_NORMAL) {                                               \
+            if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_HIER_NORMAL, 2, 0>), grid, blk, lds, st, p);           \
+            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_HIER_NORMAL, 4, 0>), grid, blk, lds, st, p);      \
+            else return hipErrorInvalidValue;                                                          \
         } else return hipErrorInvalidValue;                                                            \
         return hipGetLastError();                                                                      \
     } while (0)

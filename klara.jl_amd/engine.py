@@ -95,6 +95,49 @@ class LogisticTarget:
         return int(self.X.shape[1])
 
 
+@dataclass
+class HierNormalTarget:
+    """Hierarchical normal growth-curve model (BUGS "Rats"; BASELINE cfg 5, data/rats/*.csv).
+
+    theta = (alpha_1, beta_1, ..., alpha_R, beta_R, alpha_c, beta_c, log sigma_c, log sigma_alpha, log sigma_beta),
+    D = 2R + 5.  Builder-defined: the reference ships only the data (doc/examples/rats/Gibbs.jl is a stub).
+    """
+    Y: np.ndarray                 # (R, T) observations
+    xc: np.ndarray                # (T,) centred covariate (age - 22 for the rats)
+    prior_prec: float = 1e-4      # alpha_c, beta_c ~ N(0, 1/prior_prec)
+    gamma_a: float = 1e-3         # precisions ~ Gamma(a, b)
+    gamma_b: float = 1e-3
+    kind = L.TARGET_HIER_NORMAL
+
+    def __post_init__(self):
+        self.Y = _f64(self.Y)
+        self.xc = _f64(self.xc).ravel()
+        if self.Y.ndim != 2 or self.Y.shape[1] != self.xc.size:
+            raise ValueError("Y must be (R, T) and xc (T,)")
+
+    @property
+    def ndims(self) -> int:
+        return 2 * int(self.Y.shape[0]) + 5
+
+    def least_squares_start(self) -> np.ndarray:
+        """Per-unit OLS fit -> a reasonable initial theta (SURVEY §8(d) cfg 5: 'least-squares fit + jitter')."""
+        r, t = self.Y.shape
+        sxx = float(self.xc @ self.xc)
+        xbar = float(self.xc.mean())
+        beta = ((self.Y - self.Y.mean(axis=1, keepdims=True)) @ (self.xc - xbar)) / float((self.xc - xbar) @ (self.xc - xbar))
+        alpha = self.Y.mean(axis=1) - beta * xbar
+        resid = self.Y - alpha[:, None] - beta[:, None] * self.xc[None, :]
+        th = np.empty(2 * r + 5)
+        th[0:2 * r:2] = alpha
+        th[1:2 * r:2] = beta
+        th[2 * r] = alpha.mean(); th[2 * r + 1] = beta.mean()
+        th[2 * r + 2] = np.log(resid.std(ddof=2) + 1e-12)
+        th[2 * r + 3] = np.log(alpha.std(ddof=1) + 1e-12)
+        th[2 * r + 4] = np.log(beta.std(ddof=1) + 1e-12)
+        del sxx, t
+        return th
+
+
 # ------------------------------------------------------------------ engine
 class Engine:
     def __init__(self, *, sampler: int, target, nchains: int, nsteps: int, burnin: int = 0, thinning: int = 1,
@@ -137,6 +180,11 @@ class Engine:
             a = _f64(target.X); keep.append(a); d.logit_X = _ptr(a)
             b = _f64(target.y); keep.append(b); d.logit_y = _ptr(b)
             d.logit_ndata, d.logit_lambda = int(target.X.shape[0]), float(target.lam)
+        elif isinstance(target, HierNormalTarget):
+            a = _f64(target.Y); keep.append(a); d.hier_Y = _ptr(a)
+            b = _f64(target.xc); keep.append(b); d.hier_xc = _ptr(b)
+            d.hier_nunits, d.hier_ntimes = int(target.Y.shape[0]), int(target.Y.shape[1])
+            d.hier_prior_prec, d.hier_gamma_a, d.hier_gamma_b = float(target.prior_prec), float(target.gamma_a), float(target.gamma_b)
         else:
             raise TypeError(f"unknown target family {type(target).__name__}")
         d.seed, d.monitor, d.steps_per_launch = int(seed), self.monitor, int(steps_per_launch)

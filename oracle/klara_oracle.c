@@ -161,6 +161,53 @@ static void ko_logit_eval(const ko_target_ctx* c, const double* p, double* lt, d
     if (g) for (int k = 0; k < D; ++k) g[k] = gacc[k] - p[k] / d->logit_lambda; /* -p/v[1]            */
 }
 
+/* KLARA_TARGET_HIER_NORMAL — builder-defined (the reference ships data/rats/*.csv but no model:
+ * doc/examples/rats/Gibbs.jl:1-7 is a stub).  BUGS "Rats" in theta = (a_1, b_1, ..., a_R, b_R,
+ * a_c, b_c, s_c, s_a, s_b), s = log sigma; w_k = exp(-2 s_k) = 1/sigma_k^2:
+ *   lt = -R T s_c - 1/2 w_c sum_ij r_ij^2 - R s_a - 1/2 w_a sum_i (a_i-a_c)^2 - R s_b - 1/2 w_b sum_i (b_i-b_c)^2
+ *        - 1/2 p0 (a_c^2 + b_c^2) + sum_k (-2 a0 s_k - b0 w_k),        r_ij = (Y_ij - a_i) - b_i xc_j
+ * (Gamma(a0, b0) prior on each precision, Jacobian of s = log sigma included, additive constants dropped).
+ * The five sums over rats are reduced in the device's lane order with the rat-i terms at element 2i (a-slots)
+ * or 2i+1 (b-slots); per-rat sums over j are sequential. */
+static double ko_hier_eval(const ko_target_ctx* c, const double* th, double* g, double* scratch)
+{
+    const klara_desc* d = c->d;
+    const int R = d->hier_nunits, T = d->hier_ntimes, D = d->ndims;
+    const double p0 = d->hier_prior_prec, a0 = d->hier_gamma_a, b0 = d->hier_gamma_b;
+    const double ac = th[2 * R], bc = th[2 * R + 1], sc = th[2 * R + 2], sa = th[2 * R + 3], sb = th[2 * R + 4];
+    const double wc = kd_exp(-2.0 * sc), wa = kd_exp(-2.0 * sa), wb = kd_exp(-2.0 * sb);
+    double tA1[KO_MAXD], tB1[KO_MAXD], tA2[KO_MAXD], tB2[KO_MAXD], tC2[KO_MAXD];
+    (void)scratch;
+    for (int i = 0; i < D; ++i) tA1[i] = tB1[i] = tA2[i] = tB2[i] = tC2[i] = 0.0;
+    for (int i = 0; i < R; ++i) {
+        const double ai = th[2 * i], bi = th[2 * i + 1];
+        const double da = ai - ac, db = bi - bc;
+        double S1 = 0.0, Sx = 0.0, S2 = 0.0;
+        for (int j = 0; j < T; ++j) {
+            const double xj = d->hier_xc[j];
+            const double r = (d->hier_Y[i * T + j] - ai) - bi * xj;
+            S1 = S1 + r; Sx = Sx + r * xj; S2 = S2 + r * r;
+        }
+        if (g) { g[2 * i] = wc * S1 - wa * da; g[2 * i + 1] = wc * Sx - wb * db; }
+        tA1[2 * i] = da; tA2[2 * i] = da * da; tC2[2 * i] = S2;
+        tB1[2 * i + 1] = db; tB2[2 * i + 1] = db * db;
+    }
+    const double A1 = ko_reduce(c->L, tA1, D), B1 = ko_reduce(c->L, tB1, D);
+    const double A2 = ko_reduce(c->L, tA2, D), B2 = ko_reduce(c->L, tB2, D), C2 = ko_reduce(c->L, tC2, D);
+    const double RT = (double)R * (double)T, Rd = (double)R;
+    if (g) {
+        g[2 * R] = wa * A1 - p0 * ac;
+        g[2 * R + 1] = wb * B1 - p0 * bc;
+        g[2 * R + 2] = ((wc * C2 - RT) - 2.0 * a0) + (2.0 * b0) * wc;
+        g[2 * R + 3] = ((wa * A2 - Rd) - 2.0 * a0) + (2.0 * b0) * wa;
+        g[2 * R + 4] = ((wb * B2 - Rd) - 2.0 * a0) + (2.0 * b0) * wb;
+    }
+    const double l_c = (-RT * sc - 0.5 * (wc * C2)) + (-2.0 * a0 * sc - b0 * wc);
+    const double l_a = (-Rd * sa - 0.5 * (wa * A2)) + (-2.0 * a0 * sa - b0 * wa);
+    const double l_b = (-Rd * sb - 0.5 * (wb * B2)) + (-2.0 * a0 * sb - b0 * wb);
+    return ((l_c + l_a) + l_b) - (0.5 * p0) * (ac * ac + bc * bc);
+}
+
 /* logtarget!(state) — BasicContMuvParameter.jl:174-201 */
 static double ko_logtarget(const ko_target_ctx* c, const double* x, double* scratch)
 {
@@ -171,6 +218,7 @@ static double ko_logtarget(const ko_target_ctx* c, const double* x, double* scra
         ko_dense_grad(c, x, g);
         return ko_dense_lt_from_grad(c, x, g, scratch);
     }
+    case KLARA_TARGET_HIER_NORMAL: return ko_hier_eval(c, x, NULL, scratch);
     default: { double lt; ko_logit_eval(c, x, &lt, NULL); return lt; }
     }
 }
@@ -180,6 +228,7 @@ static void ko_gradlogtarget(const ko_target_ctx* c, const double* x, double* g)
     switch (c->d->target) {
     case KLARA_TARGET_GAUSS_DIAG: ko_diag_grad(c, x, g); break;
     case KLARA_TARGET_GAUSS_DENSE: ko_dense_grad(c, x, g); break;
+    case KLARA_TARGET_HIER_NORMAL: { double sc[1]; (void)ko_hier_eval(c, x, g, sc); break; }
     default: ko_logit_eval(c, x, NULL, g); break;
     }
 }
@@ -189,6 +238,7 @@ static double ko_uptograd(const ko_target_ctx* c, const double* x, double* g, do
     switch (c->d->target) {
     case KLARA_TARGET_GAUSS_DIAG: ko_diag_grad(c, x, g); return ko_diag_lt(c, x, scratch);
     case KLARA_TARGET_GAUSS_DENSE: ko_dense_grad(c, x, g); return ko_dense_lt_from_grad(c, x, g, scratch);
+    case KLARA_TARGET_HIER_NORMAL: return ko_hier_eval(c, x, g, scratch);
     default: { double lt; ko_logit_eval(c, x, &lt, g); return lt; }
     }
 }

@@ -21,6 +21,12 @@ def swiss_data():
     return np.ascontiguousarray(X), np.ascontiguousarray(raw["status"].astype(np.float64))
 
 
+def rats_target():
+    """data/rats/{weight,age}.csv of the reference (fixture tests/golden/rats.npz); ages centred at 22 as in BUGS."""
+    raw = np.load(GOLDEN / "rats.npz")
+    return K.HierNormalTarget(raw["weight"], raw["age"] - 22.0)
+
+
 def compound_symmetric_precision(d, rho=0.5):
     return (np.eye(d) - (rho / (1.0 - rho + d * rho)) * np.ones((d, d))) / (1.0 - rho)
 
@@ -80,6 +86,23 @@ def make_case(name):
         X, y = swiss_data()
         c = dict(sampler=L.SAMPLER_HMC, target=K.LogisticTarget(X, y, 100.0), nchains=65, nsteps=12, burnin=0,
                  leapstep=0.05, nleaps=6, x0=0.1 * np.random.default_rng(2).standard_normal((65, 4)))
+    elif name == "hmc_rats":          # BASELINE cfg 5 shape at parity-test size (L reduced from 32 to 8)
+        t = rats_target()
+        x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(4).standard_normal((37, t.ndims))
+        c = dict(sampler=L.SAMPLER_HMC, target=t, nchains=37, nsteps=30, burnin=5, leapstep=0.01, nleaps=8, x0=x0)
+    elif name == "hmc_rats_pooled":   # per-GPU pooled AcceptanceRateMCTuner, as cfg 5 asks
+        t = rats_target()
+        x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(5).standard_normal((70, t.ndims))
+        c = dict(sampler=L.SAMPLER_HMC, target=t, nchains=70, nsteps=90, burnin=60, leapstep=0.02, nleaps=6,
+                 tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.65, period=20, x0=x0)
+    elif name == "mala_rats":
+        t = rats_target()
+        x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(6).standard_normal((33, t.ndims))
+        c = dict(sampler=L.SAMPLER_MALA, target=t, nchains=33, nsteps=40, burnin=0, driftstep=1e-4, x0=x0)
+    elif name == "slice_rats":
+        t = rats_target()
+        x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(7).standard_normal((6, t.ndims))
+        c = dict(sampler=L.SAMPLER_SLICE, target=t, nchains=6, nsteps=3, burnin=0, slice_widths=np.full(t.ndims, 0.5), x0=x0)
     elif name == "slice_d5":           # test/SliceSampler.jl-style: SliceSampler(1., 5)
         c = dict(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.negdot(5), nchains=40, nsteps=30, burnin=5,
                  slice_widths=np.full(5, 1.0), slice_stepout=True)
@@ -100,10 +123,11 @@ def make_case(name):
 
 ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_small_step", "mala_d3_tuned",
              "mala_d300", "hmc_d100", "hmc_d10_tuned_pooled", "hmc_dense_d100", "hmc_dense_d37", "mala_dense_d100",
-             "mh_dense_d20", "mala_swiss", "hmc_swiss", "slice_d5", "slice_d100_nostepout", "slice_swiss"]
+             "mh_dense_d20", "mala_swiss", "hmc_swiss", "slice_d5", "slice_d100_nostepout", "slice_swiss",
+             "hmc_rats", "hmc_rats_pooled", "mala_rats", "slice_rats"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
-                "mala_d3_tuned", "hmc_d10_tuned_pooled"]
+                "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats"]
 
 
 def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):
@@ -116,6 +140,8 @@ def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):
         kw.update(gauss_w=t.w, gauss_mu=t.mu, gauss_const=t.const)
     elif isinstance(t, K.GaussDenseTarget):
         kw.update(gauss_prec=t.precision, gauss_const=t.const)
+    elif isinstance(t, K.HierNormalTarget):
+        kw.update(hier_Y=t.Y, hier_xc=t.xc, hier_prior_prec=t.prior_prec, hier_gamma_a=t.gamma_a, hier_gamma_b=t.gamma_b)
     else:
         kw.update(logit_X=t.X, logit_y=t.y, logit_lambda=t.lam)
     kw["layout"] = layout

@@ -91,7 +91,8 @@ class OracleJob:
                  mh_sigma=None, driftstep=1.0, leapstep=0.1, nleaps=10, slice_widths=None, slice_stepout=True,
                  tuner=0, tuner_mode=0, targetrate=0.0, score_k=7.0, period=100, verbose=False,
                  seed=20260927, chain_offset=0, gauss_w=None, gauss_mu=None, gauss_const=0.0, gauss_prec=None,
-                 logit_X=None, logit_y=None, logit_lambda=100.0, layout=None,
+                 logit_X=None, logit_y=None, logit_lambda=100.0, hier_Y=None, hier_xc=None, hier_prior_prec=1e-4,
+                 hier_gamma_a=1e-3, hier_gamma_b=1e-3, layout=None,
                  want_accept=True, want_sums=True, want_hist=False):
         self.lib = load()
         self.N, self.D = int(nchains), int(ndims)
@@ -118,6 +119,10 @@ class OracleJob:
         d.logit_X, d.logit_y = ptr(logit_X), ptr(logit_y)
         d.logit_ndata = 0 if logit_y is None else int(np.size(logit_y))
         d.logit_lambda = float(logit_lambda)
+        d.hier_Y, d.hier_xc = ptr(hier_Y), ptr(hier_xc)
+        if hier_Y is not None:
+            d.hier_nunits, d.hier_ntimes = int(np.shape(hier_Y)[0]), int(np.shape(hier_Y)[1])
+        d.hier_prior_prec, d.hier_gamma_a, d.hier_gamma_b = float(hier_prior_prec), float(hier_gamma_a), float(hier_gamma_b)
         d.seed = int(seed)
         self.desc = d
         k, g, e = layout if layout is not None else default_layout(int(target_kind), self.D)

@@ -133,6 +133,31 @@ def test_logistic_target_matches_numpy():
     assert np.allclose(g, ref_g, rtol=1e-11)
 
 
+def test_hierarchical_rats_target_matches_numpy_and_finite_differences():
+    """Builder-defined BUGS 'Rats' target on the reference's data files (data/rats/*.csv): closed form in
+    NumPy for lt, central differences for the gradient."""
+    t = cases.rats_target()
+    th = t.least_squares_start() + 0.01 * np.random.default_rng(0).standard_normal(t.ndims)
+    c = cases.make_case("hmc_rats")
+    lt, g = O.OracleJob(**cases.oracle_kwargs(c)).eval_target(th)
+
+    def lt_np(v):
+        a, b = v[0:60:2], v[1:60:2]
+        ac, bc, sc, sa, sb = v[60:]
+        r = t.Y - a[:, None] - b[:, None] * t.xc[None, :]
+        wc, wa, wb = np.exp(-2 * sc), np.exp(-2 * sa), np.exp(-2 * sb)
+        return (-150 * sc - 0.5 * wc * (r ** 2).sum() - 30 * sa - 0.5 * wa * ((a - ac) ** 2).sum()
+                - 30 * sb - 0.5 * wb * ((b - bc) ** 2).sum() - 0.5 * t.prior_prec * (ac ** 2 + bc ** 2)
+                + sum(-2 * t.gamma_a * s - t.gamma_b * np.exp(-2 * s) for s in (sc, sa, sb)))
+
+    assert lt == pytest.approx(lt_np(th), rel=1e-13)
+    for i in range(th.size):
+        h = 1e-6 * max(1.0, abs(th[i]))
+        e = np.zeros_like(th); e[i] = h
+        fd = (lt_np(th + e) - lt_np(th - e)) / (2 * h)
+        assert g[i] == pytest.approx(fd, rel=2e-5, abs=1e-5), i
+
+
 def test_tuner_cadence_and_counters():
     """samplers.jl:29-45: totproposed starts at period => exactly burnin/period tuning events
     (10 for 1000/100); after burn-in `proposed` keeps growing (iterate/MALA.jl:130-152)."""
