@@ -87,6 +87,8 @@ typedef enum klara_tuner_mode {
 #define KLARA_MON_ACCEPT    0x1u  /* keep the per-step accept diagnostics (u8 per step per chain)  */
 #define KLARA_MON_HISTORY   0x2u  /* :destination=>:nstate — keep value at every postrange step    */
 #define KLARA_MON_SUMMARIES 0x4u  /* accumulate sum x, sum x^2 over postrange steps on device      */
+#define KLARA_MON_HIST_LT   0x8u  /* :monitor=>[:logtarget]: keep logtarget at every postrange step */
+#define KLARA_MON_HIST_GRAD 0x10u /* :monitor=>[:gradlogtarget] (MALA/HMC only)                    */
 
 typedef struct klara_desc {
     uint32_t struct_size;        /* = sizeof(klara_desc), ABI check                                  */
@@ -190,6 +192,10 @@ klara_status klara_get_pooled_summaries(klara_handle* h, double* sum, double* su
  * (BasicContMuvParameterNState.jl:89-119); requires KLARA_MON_HISTORY. */
 klara_status klara_get_chain(klara_handle* h, int64_t local_chain, double* value, int64_t capacity_cols,
                              int64_t* ncols_out);
+/* the other monitored NState fields of one chain (BasicContMuvParameterNState.jl:1-21): logtarget[i] (n values,
+ * KLARA_MON_HIST_LT) and gradlogtarget[d + D*i] (KLARA_MON_HIST_GRAD); either pointer may be NULL. */
+klara_status klara_get_chain_fields(klara_handle* h, int64_t local_chain, double* logtarget,
+                                    double* gradlogtarget, int64_t capacity_cols, int64_t* ncols_out);
 /* tuner state per chain (tuners.jl:5-10). In pooled mode every chain reports the shared state. */
 klara_status klara_get_tune(klara_handle* h, double* step, int64_t* accepted, int64_t* proposed,
                             int64_t* totproposed);

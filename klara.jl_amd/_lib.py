@@ -24,7 +24,7 @@ TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET_HIER_NORMAL = ran
 # klara_tuner / mode
 TUNER_VANILLA, TUNER_ACCEPT_RATE = 0, 1
 TUNE_PER_CHAIN, TUNE_POOLED = 0, 1
-MON_ACCEPT, MON_HISTORY, MON_SUMMARIES = 0x1, 0x2, 0x4
+MON_ACCEPT, MON_HISTORY, MON_SUMMARIES, MON_HIST_LT, MON_HIST_GRAD = 0x1, 0x2, 0x4, 0x8, 0x10
 
 _dp = C.POINTER(C.c_double)
 
@@ -62,7 +62,7 @@ EXPORTS = [
     "klara_create", "klara_destroy", "klara_set_state", "klara_init_state_normal", "klara_run",
     "klara_run_async", "klara_synchronize", "klara_reset", "klara_get_state", "klara_get_accept_mask",
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
-    "klara_get_tune", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
+    "klara_get_chain_fields", "klara_get_tune", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
     "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_mfma_f64", "klara_strerror",
     "klara_abi_version",
 ]
@@ -98,6 +98,7 @@ def load() -> C.CDLL:
         "klara_get_chain_sums": [H, C.c_void_p, C.c_void_p, i64p],
         "klara_get_pooled_summaries": [H, C.c_void_p, C.c_void_p, u64p, u64p, i64p],
         "klara_get_chain": [H, C.c_int64, C.c_void_p, C.c_int64, i64p],
+        "klara_get_chain_fields": [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, i64p],
         "klara_get_tune": [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_last_run_ms": [H, C.POINTER(C.c_double), i64p],
         "klara_device_ptrs": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],

@@ -18,6 +18,7 @@ The Julia package a maintainer would ship is sketched in INTEGRATION.md.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Sequence
 
@@ -192,6 +193,12 @@ class MuvChains:
     def value(self, chain: int = 0) -> np.ndarray:
         return self._job.engine.chain(chain)
 
+    def logtarget(self, chain: int = 0) -> np.ndarray:
+        return self._job.engine.chain_fields(chain, True, False)[0]
+
+    def gradlogtarget(self, chain: int = 0) -> np.ndarray:
+        return self._job.engine.chain_fields(chain, False, True)[1]
+
     @property
     def diagnosticvalues(self):
         return self._acc
@@ -241,8 +248,12 @@ class BasicMCJob:
         if self.outopts["destination"] != "none":
             self.outopts.setdefault("monitor", ["value"])             # jobs.jl:13-15
             self.outopts.setdefault("diagnostics", [])                # jobs.jl:37-39
-        if self.outopts["destination"] not in ("nstate", "none"):
-            raise NotImplementedError(":iostream destination is out of scope this round (SURVEY §8(f)4)")
+        if self.outopts["destination"] not in ("nstate", "iostream", "none"):
+            raise ValueError("outopts destination must be nstate, iostream or none")
+        if self.outopts["destination"] == "iostream":                  # jobs.jl:17-29
+            self.outopts.setdefault("filepath", "")
+            self.outopts.setdefault("filesuffix", "csv")
+            self.outopts.setdefault("flush", False)
         params = [v for v in model.vertices if isinstance(v, BasicContMuvParameter)]
         if len(params) != 1:
             raise ValueError("model must hold exactly one BasicContMuvParameter")
@@ -256,8 +267,17 @@ class BasicMCJob:
         monitor = 0
         if "accept" in self.outopts.get("diagnostics", []):
             monitor |= L.MON_ACCEPT
-        if self.outopts["destination"] == "nstate" and "value" in self.outopts.get("monitor", []):
-            monitor |= L.MON_HISTORY
+        if self.outopts["destination"] in ("nstate", "iostream"):
+            mon = [str(m).lstrip(":") for m in self.outopts.get("monitor", [])]
+            known = {"value", "logtarget", "gradlogtarget"}
+            if set(mon) - known:
+                raise NotImplementedError(f"monitor fields not kept on device: {sorted(set(mon) - known)}")
+            if "value" in mon:
+                monitor |= L.MON_HISTORY
+            if "logtarget" in mon:
+                monitor |= L.MON_HIST_LT
+            if "gradlogtarget" in mon:
+                monitor |= L.MON_HIST_GRAD
         if summaries:
             monitor |= L.MON_SUMMARIES
         kw = dict(sampler=sampler.kind, target=self.parameter.target, nchains=nchains, nsteps=mcrange.nsteps,
@@ -295,7 +315,30 @@ def run(job):
         return [run(j) for j in job]
     job.engine.run(job.range.nsteps)
     job._ran = True
+    if job.outopts["destination"] == "iostream":
+        _write_iostream(job)
     return job
+
+
+def _write_iostream(job: "BasicMCJob") -> None:
+    """:destination => :iostream — CSV files per monitored field (jobs.jl:193-202; BasicContParamIOStream.jl:152-159)."""
+    from .iostream import write_chain
+    eng = job.engine
+    base = job.outopts.get("filepath", "") or "."
+    suffix = job.outopts.get("filesuffix", "csv")
+    acc = None
+    if eng.monitor & L.MON_ACCEPT:
+        m = eng.accept_mask()
+        post = np.asarray(job.range.postrange) - 1
+        acc = m[post[post < m.shape[0]]]
+    width = len(str(eng.nchains))
+    for c in range(eng.nchains):
+        d = base if eng.nchains == 1 else os.path.join(base, f"chain_{c + 1:0{width}d}")
+        value = eng.chain(c) if eng.monitor & L.MON_HISTORY else None
+        lt, g = (None, None)
+        if eng.monitor & (L.MON_HIST_LT | L.MON_HIST_GRAD):
+            lt, g = eng.chain_fields(c, bool(eng.monitor & L.MON_HIST_LT), bool(eng.monitor & L.MON_HIST_GRAD))
+        write_chain(d, suffix, value, lt, g, None if acc is None else acc[:, c])
 
 
 def output(job: BasicMCJob) -> MuvChains:

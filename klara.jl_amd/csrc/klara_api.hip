@@ -30,6 +30,7 @@ struct klara_handle {
     unsigned long long* naccept = nullptr;
     double *sum = nullptr, *sumsq = nullptr;
     double* hist = nullptr; long long hist_cols = 0;
+    double *hist_lt = nullptr, *hist_g = nullptr;
     int* err = nullptr;
     double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr,
            *hY = nullptr, *hxc = nullptr;
@@ -139,7 +140,7 @@ static void free_all(klara_handle* h)
 {
     hipFree(h->X); hipFree(h->GR); hipFree(h->LT); hipFree(h->tune_step); hipFree(h->tune_acc);
     hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->pooled_acc); hipFree(h->accept);
-    hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->hist); hipFree(h->err);
+    hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->hist); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->err);
     hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
     hipFree(h->Pfrag); hipFree(h->pooled_out);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -191,10 +192,17 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         h->accept_cap = desc->nsteps;
         CKH(dalloc(&h->accept, (size_t)desc->nsteps * N));
     }
-    if (desc->monitor & KLARA_MON_HISTORY) {
+    if (desc->monitor & (KLARA_MON_HISTORY | KLARA_MON_HIST_LT | KLARA_MON_HIST_GRAD)) {
         // npoststeps = length((burnin+1):thinning:nsteps)  (BasicMCRange.jl:26)
         h->hist_cols = (desc->nsteps - desc->burnin - 1) / desc->thinning + 1;
-        CKH(dalloc(&h->hist, (size_t)h->hist_cols * N * D));
+        if (desc->monitor & KLARA_MON_HISTORY) CKH(dalloc(&h->hist, (size_t)h->hist_cols * N * D));
+        if (desc->monitor & KLARA_MON_HIST_LT) CKH(dalloc(&h->hist_lt, (size_t)h->hist_cols * N));
+        if (desc->monitor & KLARA_MON_HIST_GRAD) {
+            if (desc->sampler != KLARA_SAMPLER_MALA && desc->sampler != KLARA_SAMPLER_HMC) {
+                free_all(h); delete h; return KLARA_ERR_INVALID_ARG;   // no gradient is carried by MH / slice
+            }
+            CKH(dalloc(&h->hist_g, (size_t)h->hist_cols * N * D));
+        }
     }
     if (desc->sampler == KLARA_SAMPLER_MH) CK(upload(&h->vecparam, desc->mh_sigma, D));
     if (desc->sampler == KLARA_SAMPLER_SLICE) CK(upload(&h->vecparam, desc->slice_widths, D));
@@ -250,6 +258,7 @@ static KParams make_params(klara_handle* h)
     p.tune_totproposed = h->tune_tot; p.pooled_accepted = h->pooled_acc;
     p.accept = nullptr; p.naccept = h->naccept; p.sum = h->sum; p.sumsq = h->sumsq;
     p.hist = h->hist; p.hist_cols = h->hist_cols; p.error_flag = h->err;
+    p.hist_lt = h->hist_lt; p.hist_g = h->hist_g;
     p.nchains = d.nchains; p.chain_offset = d.chain_offset; p.D = d.ndims; p.G = h->G;
     p.pooled = d.tuner_mode == KLARA_TUNE_POOLED;
     p.seed = d.seed; p.t0 = 0; p.nsteps = 0;
@@ -619,6 +628,25 @@ extern "C" klara_status klara_get_chain(klara_handle* h, int64_t local_chain, do
     if (value && n > 0)
         HIPCHK(hipMemcpy2D(value, D * sizeof(double), h->hist + (size_t)local_chain * D, N * D * sizeof(double),
                            D * sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
+    if (ncols_out) *ncols_out = h->nsaved;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_chain_fields(klara_handle* h, int64_t local_chain, double* logtarget,
+                                               double* gradlogtarget, int64_t capacity_cols, int64_t* ncols_out)
+{
+    if (!h || local_chain < 0 || local_chain >= h->d.nchains) return KLARA_ERR_INVALID_ARG;
+    if ((logtarget && !h->hist_lt) || (gradlogtarget && !h->hist_g) || (!h->hist_lt && !h->hist_g)) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t N = (size_t)h->d.nchains, D = (size_t)h->d.ndims;
+    const long long n = h->nsaved < capacity_cols ? h->nsaved : capacity_cols;
+    if (logtarget && n > 0)
+        HIPCHK(hipMemcpy2D(logtarget, sizeof(double), h->hist_lt + (size_t)local_chain, N * sizeof(double),
+                           sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
+    if (gradlogtarget && n > 0)
+        HIPCHK(hipMemcpy2D(gradlogtarget, D * sizeof(double), h->hist_g + (size_t)local_chain * D,
+                           N * D * sizeof(double), D * sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
     if (ncols_out) *ncols_out = h->nsaved;
     return KLARA_OK;
 }

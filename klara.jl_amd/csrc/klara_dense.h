@@ -315,6 +315,20 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
                     }
                 }
             }
+            if (p.hist_lt != nullptr && col < p.hist_cols && cx.chain_ok && cx.q == 0)
+                p.hist_lt[col * p.nchains + cx.chain] = lt;
+            if (SAMPLER != KLARA_SAMPLER_MH && p.hist_g != nullptr && col < p.hist_cols) {
+                double gs[NE];
+                if (acc) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) gs[e] = gp[e];
+                } else {
+                    mload<NE>(cx, p.GR, p.D, gs);
+                }
+                double* dst = p.hist_g + (col * p.nchains + cx.chain) * p.D + cx.q;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) if (cx.valid[e]) dst[4 * e] = gs[e];
+            }
         }
     }
 

@@ -36,6 +36,7 @@ struct KParams {
     unsigned long long* naccept;               // per chain
     double* sum; double* sumsq;                // per chain x D or null
     double* hist; long long hist_cols;         // [col][nchains][D] or null
+    double* hist_lt; double* hist_g;           // [col][nchains] / [col][nchains][D] or null
     int* error_flag;                           // set to klara_status on device-detected errors
     long long nchains; long long chain_offset;
     int D; int G; int pooled;
@@ -748,6 +749,13 @@ __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1))) 
                         double* dst = p.hist + (scol * p.nchains + cx.chain) * p.D + cx.i0;
 #pragma unroll
                         for (int e = 0; e < E; ++e) if (cx.valid[e]) dst[e] = cur.x[e];
+                    }
+                    if (p.hist_lt != nullptr && scol < p.hist_cols && cx.chain_ok && cx.q == 0)
+                        p.hist_lt[scol * p.nchains + cx.chain] = cur.lt;
+                    if (NEEDG && p.hist_g != nullptr && scol < p.hist_cols) {
+                        double* dst = p.hist_g + (scol * p.nchains + cx.chain) * p.D + cx.i0;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) if (cx.valid[e]) dst[e] = cur.g[e];
                     }
                     ++scol;
                 }

@@ -275,6 +275,17 @@ class Engine:
         L.check(self._lib.klara_get_chain(self._h, int(local_chain), v.ctypes.data, n.value, C.byref(n)), "klara_get_chain")
         return v
 
+    def chain_fields(self, local_chain: int, logtarget: bool = True, gradlogtarget: bool = False):
+        """logtarget (n,) and/or gradlogtarget (ndims, n) of one chain over the saved steps (NState fields)."""
+        n = C.c_int64(0)
+        L.check(self._lib.klara_get_chain_fields(self._h, int(local_chain), None, None, 0, C.byref(n)), "klara_get_chain_fields")
+        lt = np.empty(n.value) if logtarget else None
+        g = np.empty((self.ndims, n.value), order="F") if gradlogtarget else None
+        L.check(self._lib.klara_get_chain_fields(self._h, int(local_chain), lt.ctypes.data if logtarget else None,
+                                                 g.ctypes.data if gradlogtarget else None, n.value, C.byref(n)),
+                "klara_get_chain_fields")
+        return lt, g
+
     def tune(self):
         step = np.empty(self.nchains); a = np.empty(self.nchains, dtype=np.int64)
         p = np.empty(self.nchains, dtype=np.int64); t = np.empty(self.nchains, dtype=np.int64)

@@ -1,0 +1,64 @@
+"""`:destination => :iostream` — CSV sink in the reference's on-disk format.
+
+Reference: one file per monitored field in `filepath` — `value.csv`, `logtarget.csv`, `gradlogtarget.csv`,
+`diagnosticvalues.csv` — one line per saved step, fields comma-joined with Julia's shortest round-trip float
+printing and `true`/`false` for the accept diagnostics
+(src/iostreams/ParameterIOStreams/BasicContParamIOStream.jl:64-82 file names, :152-159 `write(iostream, state)`;
+src/jobs/jobs.jl:193-202).  One job with N chains writes one such directory per chain: `filepath` itself when
+N == 1 (identical to the reference), `filepath/chain_<c>` (1-based, zero-padded) otherwise.
+"""
+from __future__ import annotations
+
+import math
+import os
+from decimal import Decimal
+from typing import Iterable, Optional
+
+import numpy as np
+
+
+def julia_float_repr(x: float) -> str:
+    """Julia's `string(::Float64)`: shortest round-trip digits; fixed notation for 1e-4 <= |x| < 1e6, else
+    `d.ddde±x`; always at least one fractional digit."""
+    if math.isnan(x):
+        return "NaN"
+    if math.isinf(x):
+        return "Inf" if x > 0 else "-Inf"
+    if x == 0.0:
+        return "-0.0" if math.copysign(1.0, x) < 0 else "0.0"
+    sign = "-" if x < 0 else ""
+    t = Decimal(repr(abs(x))).as_tuple()           # Python's repr is also the shortest round-trip representation
+    ds = "".join(map(str, t.digits)).rstrip("0") or "0"
+    pt = len(t.digits) + t.exponent                # digits before the decimal point
+    if -4 < pt <= 6:                               # 0.0001 -> "0.0001", 0.00001 -> "1.0e-5", 999999.0 fixed, 1.0e6
+        if pt <= 0:
+            body = "0." + "0" * (-pt) + ds
+        elif pt >= len(ds):
+            body = ds + "0" * (pt - len(ds)) + ".0"
+        else:
+            body = ds[:pt] + "." + ds[pt:]
+    else:
+        body = ds[0] + "." + (ds[1:] or "0") + "e" + str(pt - 1)
+    return sign + body
+
+
+def _line(values: Iterable[float]) -> str:
+    return ",".join(julia_float_repr(float(v)) for v in values) + "\n"
+
+
+def write_chain(directory: str, suffix: str, value: Optional[np.ndarray], logtarget: Optional[np.ndarray],
+                gradlogtarget: Optional[np.ndarray], accept: Optional[np.ndarray]) -> None:
+    """value / gradlogtarget: (D, n) as in the NState; logtarget: (n,); accept: (n,) bools."""
+    os.makedirs(directory, exist_ok=True)
+    if value is not None:
+        with open(os.path.join(directory, f"value.{suffix}"), "w") as f:
+            f.writelines(_line(value[:, i]) for i in range(value.shape[1]))
+    if logtarget is not None:
+        with open(os.path.join(directory, f"logtarget.{suffix}"), "w") as f:
+            f.writelines(julia_float_repr(float(v)) + "\n" for v in logtarget)
+    if gradlogtarget is not None:
+        with open(os.path.join(directory, f"gradlogtarget.{suffix}"), "w") as f:
+            f.writelines(_line(gradlogtarget[:, i]) for i in range(gradlogtarget.shape[1]))
+    if accept is not None:
+        with open(os.path.join(directory, f"diagnosticvalues.{suffix}"), "w") as f:
+            f.writelines(("true" if a else "false") + "\n" for a in accept)

@@ -494,7 +494,7 @@ static int ko_transition(const ko_target_ctx* c, uint64_t gchain, uint64_t t, do
 int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double* LT,
            double* step, int64_t* accepted, int64_t* proposed, int64_t* totproposed,
            int64_t t0, int64_t nsteps, uint8_t* accept_out, double* sum, double* sumsq,
-           uint64_t* naccept, double* hist, int64_t hist_cols)
+           uint64_t* naccept, double* hist, int64_t hist_cols, double* hist_lt, double* hist_g)
 {
     ko_target_ctx c; ko_ctx_init(&c, d, L);
     const int D = d->ndims;
@@ -529,6 +529,10 @@ int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double
                     if (hist && col < hist_cols)
                         memcpy(hist + ((size_t)col * (size_t)d->nchains + (size_t)n) * (size_t)D, x,
                                sizeof(double) * (size_t)D);
+                    if (hist_lt && col < hist_cols) hist_lt[(size_t)col * (size_t)d->nchains + (size_t)n] = LT[n];
+                    if (hist_g && col < hist_cols)
+                        memcpy(hist_g + ((size_t)col * (size_t)d->nchains + (size_t)n) * (size_t)D, g,
+                               sizeof(double) * (size_t)D);
                 }
             }
             step[n] = tn.step; accepted[n] = tn.accepted; proposed[n] = tn.proposed;
@@ -560,6 +564,10 @@ int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double
                     }
                     if (hist && col < hist_cols)
                         memcpy(hist + ((size_t)col * (size_t)d->nchains + (size_t)n) * (size_t)D, x,
+                               sizeof(double) * (size_t)D);
+                    if (hist_lt && col < hist_cols) hist_lt[(size_t)col * (size_t)d->nchains + (size_t)n] = LT[n];
+                    if (hist_g && col < hist_cols)
+                        memcpy(hist_g + ((size_t)col * (size_t)d->nchains + (size_t)n) * (size_t)D, g,
                                sizeof(double) * (size_t)D);
                 }
             }

@@ -41,7 +41,7 @@ def load() -> C.CDLL:
     lib.ko_init.restype = C.c_int
     lib.ko_init_state_normal.argtypes = [C.POINTER(L.KlaraDesc), vp]
     lib.ko_init_state_normal.restype = None
-    lib.ko_run.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout)] + [vp] * 7 + [C.c_int64, C.c_int64] + [vp] * 5 + [C.c_int64]
+    lib.ko_run.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout)] + [vp] * 7 + [C.c_int64, C.c_int64] + [vp] * 5 + [C.c_int64, vp, vp]
     lib.ko_run.restype = C.c_int
     lib.ko_philox_block.argtypes = [vp, vp, vp]
     lib.ko_stream_block.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]
@@ -137,6 +137,8 @@ class OracleJob:
         self.sumsq = np.zeros((self.N, self.D)) if want_sums else None
         self.hist_cols = (int(nsteps) - int(burnin) - 1) // int(thinning) + 1
         self.hist = np.zeros((self.hist_cols, self.N, self.D)) if want_hist else None
+        self.hist_lt = np.zeros((self.hist_cols, self.N)) if want_hist else None
+        self.hist_g = np.zeros((self.hist_cols, self.N, self.D)) if want_hist else None
         self.want_accept = want_accept
         self.accept = np.zeros((0, self.N), np.uint8)
 
@@ -167,7 +169,8 @@ class OracleJob:
         st = self.lib.ko_run(C.byref(self.desc), C.byref(self.layout), self._p(self.X), self._p(self.G),
                              self._p(self.LT), self._p(self.step), self._p(self.accepted), self._p(self.proposed),
                              self._p(self.totproposed), self.t, int(nsteps), self._p(acc), self._p(self.sum),
-                             self._p(self.sumsq), self._p(self.naccept), self._p(self.hist), self.hist_cols)
+                             self._p(self.sumsq), self._p(self.naccept), self._p(self.hist), self.hist_cols,
+                             self._p(self.hist_lt), self._p(self.hist_g))
         self.t += int(nsteps)
         if acc is not None:
             self.accept = np.concatenate([self.accept, acc], axis=0)

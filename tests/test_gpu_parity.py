@@ -218,6 +218,53 @@ def test_history_layout_matches_nstate():
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["hmc_dense_d37", "mala_dense_d100", "hmc_d100", "hmc_rats"])
+def test_history_of_all_monitored_fields(name):
+    case = cases.make_case(name)
+    mon = L.MON_HISTORY | L.MON_HIST_LT | L.MON_HIST_GRAD | L.MON_SUMMARIES | L.MON_ACCEPT
+    eng = K.Engine(**cases.engine_kwargs(case, monitor=mon, steps_per_launch=3))
+    job = O.OracleJob(**cases.oracle_kwargs(case, layout=eng.layout()), want_hist=True)
+    if case["x0"] is None:
+        eng.init_state_normal(); job.init_state_normal()
+    else:
+        eng.set_state(case["x0"]); job.set_state(case["x0"])
+    eng.run(case["nsteps"]); job.run(case["nsteps"])
+    for c in (0, case["nchains"] // 2, case["nchains"] - 1):
+        lt, g = eng.chain_fields(c, True, True)
+        assert np.array_equal(eng.chain(c), job.hist[:, c, :].T)
+        assert np.array_equal(lt, job.hist_lt[:, c]) and np.array_equal(g, job.hist_g[:, c, :].T)
+    eng.close()
+
+
+def test_monitored_fields_and_iostream_sink(tmp_path):
+    """doc/examples/swiss/MALA/analytical.jl:36-44: monitor [:value, :logtarget, :gradlogtarget], diagnostics
+    [:accept] — kept per saved step on device, bit-equal to the oracle, and written by the :iostream destination
+    in the reference's CSV layout."""
+    case = cases.make_case("mala_swiss")
+    X, y = cases.swiss_data()
+    p = K.BasicContMuvParameter("p", logtarget=K.LogisticTarget(X, y, 100.0))
+    job = K.BasicMCJob(K.likelihood_model(p, False), K.MALA(0.1), K.BasicMCRange(nsteps=40, burnin=10), {"p": case["x0"]},
+                       outopts={"destination": "iostream", "filepath": str(tmp_path), "monitor": ["value", "logtarget", "gradlogtarget"],
+                                "diagnostics": ["accept"]})
+    o = O.OracleJob(**cases.oracle_kwargs(case, layout=job.engine.layout()), want_hist=True)
+    o.set_state(case["x0"]); o.run(40)
+    K.run(job)
+    chain = K.output(job)
+    for c in (0, 41, 69):
+        assert np.array_equal(chain.value(c), o.hist[:, c, :].T)
+        assert np.array_equal(chain.logtarget(c), o.hist_lt[:, c])
+        assert np.array_equal(chain.gradlogtarget(c), o.hist_g[:, c, :].T)
+    d = tmp_path / "chain_42"
+    from klara_jl_amd.iostream import julia_float_repr as j
+    lines = (d / "value.csv").read_text().splitlines()
+    assert len(lines) == 30 and lines[0] == ",".join(j(v) for v in o.hist[0, 41])
+    assert (d / "logtarget.csv").read_text().splitlines()[29] == j(o.hist_lt[29, 41])
+    assert (d / "gradlogtarget.csv").read_text().splitlines()[3] == ",".join(j(v) for v in o.hist_g[3, 41])
+    assert (d / "diagnosticvalues.csv").read_text().splitlines() == ["true" if a else "false" for a in o.accept[10:, 41]]
+    assert np.allclose(K.acceptance(chain), o.accept[10:].mean(axis=0))
+    job.close()
+
+
 # ------------------------------------------------------------------ reference-API level
 def test_readme_flow_basic_mc_job():
     """README.md:23-66 through the host mirror: MH on lt = -dot(z,z), 10000 steps, burnin 1000."""

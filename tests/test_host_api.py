@@ -103,6 +103,26 @@ def test_target_families():
         K.BasicContMuvParameter("p", logtarget=lambda z: -z @ z)       # arbitrary closures cannot run on device
 
 
+def test_iostream_csv_format(tmp_path):
+    """One comma-joined line per saved step with Julia's float printing
+    (BasicContParamIOStream.jl:152-159: `join(getfield(state, field), ',')`)."""
+    from klara_jl_amd.iostream import julia_float_repr as j, write_chain
+    known = {5.1: "5.1", -0.9: "-0.9", 1e-5: "1.0e-5", 0.0001: "0.0001", 1e6: "1.0e6", 123456.0: "123456.0",
+             1234567.0: "1.234567e6", 0.1 + 0.2: "0.30000000000000004", 1e22: "1.0e22", 100.0: "100.0",
+             1.5e-7: "1.5e-7", -2.5e-10: "-2.5e-10", 1.0: "1.0", 0.0: "0.0", float("inf"): "Inf", float("nan"): "NaN"}
+    for x, s in known.items():
+        assert j(x) == s, (x, j(x), s)
+    rng = np.random.default_rng(0)
+    for x in np.concatenate([rng.standard_normal(200), np.exp(rng.uniform(-30, 30, 200))]):
+        assert float(j(x)) == x                                   # round-trips
+    v = np.array([[5.1, 1e-5], [-0.9, 2.0]])                      # (D=2, n=2): columns are saved steps
+    write_chain(str(tmp_path), "csv", v, np.array([-1.5, 2e7]), None, np.array([1, 0], dtype=np.uint8))
+    assert (tmp_path / "value.csv").read_text() == "5.1,-0.9\n1.0e-5,2.0\n"
+    assert (tmp_path / "logtarget.csv").read_text() == "-1.5\n2.0e7\n"
+    assert (tmp_path / "diagnosticvalues.csv").read_text() == "true\nfalse\n"
+    assert not (tmp_path / "gradlogtarget.csv").exists()
+
+
 def test_shard_chains_is_a_partition():
     for n, w in ((65536, 8), (10, 4), (7, 8), (262144, 8)):
         parts = [K.shard_chains(n, r, w) for r in range(w)]
