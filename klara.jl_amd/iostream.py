@@ -20,6 +20,7 @@ import numpy as np
 def julia_float_repr(x: float) -> str:
     """Julia's `string(::Float64)`: shortest round-trip digits; fixed notation for 1e-4 <= |x| < 1e6, else
     `d.ddde±x`; always at least one fractional digit."""
+    x = float(x)                                   # numpy scalars repr() as 'np.float64(..)'
     if math.isnan(x):
         return "NaN"
     if math.isinf(x):
