@@ -75,7 +75,11 @@ typedef enum klara_target {
 /* src/tuners/{VanillaMCTuner,AcceptanceRateMCTuner}.jl */
 typedef enum klara_tuner {
     KLARA_TUNER_VANILLA = 0,
-    KLARA_TUNER_ACCEPT_RATE = 1
+    KLARA_TUNER_ACCEPT_RATE = 1,
+    /* DualAveragingMCTuner (src/tuners/DualAveragingMCTuner.jl:54-101), HMC only (HMC.jl:124-133): Nesterov dual
+     * averaging of the leapfrog step during the first da_nadapt transitions, nleaps = max(1, round(lambda/step))
+     * per transition (iterate/HMC.jl:142-144), step = eps_bar afterwards (iterate/HMC.jl:246-248).  Per chain. */
+    KLARA_TUNER_DUAL_AVERAGING = 2
 } klara_tuner;
 
 typedef enum klara_tuner_mode {
@@ -117,6 +121,14 @@ typedef struct klara_desc {
     double   score_k;            /* steepness of logistic_rate_score (default 7)                     */
     int32_t  period;             /* > 0, default 100                                                 */
     int32_t  verbose;            /* counts proposals the way the reference's verbose tuners do      */
+    /* DualAveragingMCTuner(targetrate, nadapt; e0bar=1, h0bar=0, gamma=0.05, t0=10, kappa=0.75) */
+    int64_t  da_nadapt;          /* > 0                                                              */
+    double   da_eps0bar;         /* > 0                                                              */
+    double   da_h0bar;
+    double   da_gamma;
+    double   da_kappa;
+    int32_t  da_t0;              /* > 0                                                              */
+    int32_t  reserved1;
 
     /* range (BasicMCRange.jl:17-36) */
     int64_t  nsteps;
@@ -199,6 +211,8 @@ klara_status klara_get_chain_fields(klara_handle* h, int64_t local_chain, double
 /* tuner state per chain (tuners.jl:5-10). In pooled mode every chain reports the shared state. */
 klara_status klara_get_tune(klara_handle* h, double* step, int64_t* accepted, int64_t* proposed,
                             int64_t* totproposed);
+/* dual-averaging state per chain (DualAveragingMCTune: eps_bar, h_bar); KLARA_TUNER_DUAL_AVERAGING only */
+klara_status klara_get_dual_averaging(klara_handle* h, double* epsbar, double* hbar);
 
 /* Measurement: duration (ms, HIP events on the launch stream) and launch count of the transition
  * kernels enqueued by the last klara_run / klara_run_async (after synchronisation). */

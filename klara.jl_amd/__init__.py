@@ -7,7 +7,7 @@ from . import _lib  # noqa: F401
 from ._lib import KlaraError  # noqa: F401
 from .engine import Engine, GaussDenseTarget, GaussDiagTarget, HierNormalTarget, LogisticTarget  # noqa: F401
 from .api import (  # noqa: F401
-    HMC, MALA, MH, AcceptanceRateMCTuner, BasicContMuvParameter, BasicMCJob, BasicMCRange, GenericModel,
+    HMC, MALA, MH, AcceptanceRateMCTuner, DualAveragingMCTuner, BasicContMuvParameter, BasicMCJob, BasicMCRange, GenericModel,
     MuvChains, SliceSampler, VanillaMCTuner, acceptance, likelihood_model, logistic, logistic_rate_score,
     mcvar_iid, mean, output, reset, run,
 )

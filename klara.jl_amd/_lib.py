@@ -22,7 +22,7 @@ SAMPLER_MH, SAMPLER_MALA, SAMPLER_HMC, SAMPLER_SLICE = range(4)
 # klara_target
 TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET_HIER_NORMAL = range(4)
 # klara_tuner / mode
-TUNER_VANILLA, TUNER_ACCEPT_RATE = 0, 1
+TUNER_VANILLA, TUNER_ACCEPT_RATE, TUNER_DUAL_AVERAGING = 0, 1, 2
 TUNE_PER_CHAIN, TUNE_POOLED = 0, 1
 MON_ACCEPT, MON_HISTORY, MON_SUMMARIES, MON_HIST_LT, MON_HIST_GRAD = 0x1, 0x2, 0x4, 0x8, 0x10
 
@@ -39,6 +39,8 @@ class KlaraDesc(C.Structure):
         ("mh_sigma", _dp), ("driftstep", C.c_double), ("leapstep", C.c_double),
         ("nleaps", C.c_int32), ("slice_stepout", C.c_int32), ("slice_widths", _dp),
         ("targetrate", C.c_double), ("score_k", C.c_double), ("period", C.c_int32), ("verbose", C.c_int32),
+        ("da_nadapt", C.c_int64), ("da_eps0bar", C.c_double), ("da_h0bar", C.c_double), ("da_gamma", C.c_double),
+        ("da_kappa", C.c_double), ("da_t0", C.c_int32), ("reserved1", C.c_int32),
         ("nsteps", C.c_int64), ("burnin", C.c_int64), ("thinning", C.c_int64),
         ("gauss_w", _dp), ("gauss_mu", _dp), ("gauss_const", C.c_double), ("gauss_prec", _dp),
         ("logit_X", _dp), ("logit_y", _dp), ("logit_ndata", C.c_int32), ("reserved0", C.c_int32),
@@ -62,7 +64,7 @@ EXPORTS = [
     "klara_create", "klara_destroy", "klara_set_state", "klara_init_state_normal", "klara_run",
     "klara_run_async", "klara_synchronize", "klara_reset", "klara_get_state", "klara_get_accept_mask",
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
-    "klara_get_chain_fields", "klara_get_tune", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
+    "klara_get_chain_fields", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
     "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_mfma_f64", "klara_strerror",
     "klara_abi_version",
 ]
@@ -100,6 +102,7 @@ def load() -> C.CDLL:
         "klara_get_chain": [H, C.c_int64, C.c_void_p, C.c_int64, i64p],
         "klara_get_chain_fields": [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, i64p],
         "klara_get_tune": [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+        "klara_get_dual_averaging": [H, C.c_void_p, C.c_void_p],
         "klara_last_run_ms": [H, C.POINTER(C.c_double), i64p],
         "klara_device_ptrs": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
         "klara_get_layout": [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],

@@ -136,6 +136,22 @@ class AcceptanceRateMCTuner(MCTuner):
         self.score_k, self.mode = float(score_k), mode
 
 
+class DualAveragingMCTuner(MCTuner):
+    """DualAveragingMCTuner(targetrate, nadapt; ε0bar=1., h0bar=0., γ=0.05, t0=10, κ=0.75, period=100, verbose=false)
+    — DualAveragingMCTuner.jl:54-93.  HMC only (as in the reference: HMC.jl:124-133)."""
+    kind = L.TUNER_DUAL_AVERAGING
+
+    def __init__(self, targetrate: float, nadapt: int, eps0bar: float = 1.0, h0bar: float = 0.0, gamma: float = 0.05,
+                 t0: int = 10, kappa: float = 0.75, period: int = 100, verbose: bool = False):
+        assert 0 < targetrate < 1, "Target acceptance rate should be between 0 and 1"
+        assert nadapt > 0, "Number of adaptation steps should be positive"
+        assert eps0bar > 0, "ε0bar should be positive"
+        assert period > 0, "Period over which acceptance rate is reported in verbose mode should be positive"
+        assert t0 > 0, "t0 should be positive"
+        self.targetrate, self.nadapt, self.eps0bar, self.h0bar = float(targetrate), int(nadapt), float(eps0bar), float(h0bar)
+        self.gamma, self.t0, self.kappa, self.period, self.verbose = float(gamma), int(t0), float(kappa), int(period), bool(verbose)
+
+
 # ------------------------------------------------------------------ parameter / model
 class BasicContMuvParameter:
     """BasicContMuvParameter(key; logtarget=...) — BasicContMuvParameter.jl:383-411.
@@ -292,6 +308,11 @@ class BasicMCJob:
             kw["leapstep"], kw["nleaps"] = sampler.leapstep, sampler.nleaps
         elif isinstance(sampler, SliceSampler):
             kw["slice_widths"], kw["slice_stepout"] = sampler.widths, sampler.stepout
+        if isinstance(self.tuner, DualAveragingMCTuner):
+            if not isinstance(sampler, HMC):
+                raise NotImplementedError("DualAveragingMCTuner is wired into HMC only (HMC.jl:124-133)")
+            kw.update(targetrate=self.tuner.targetrate, da_nadapt=self.tuner.nadapt, da_eps0bar=self.tuner.eps0bar,
+                      da_h0bar=self.tuner.h0bar, da_gamma=self.tuner.gamma, da_t0=self.tuner.t0, da_kappa=self.tuner.kappa)
         if isinstance(self.tuner, AcceptanceRateMCTuner):
             kw["targetrate"], kw["score_k"] = self.tuner.targetrate, self.tuner.score_k
             kw["tuner_mode"] = L.TUNE_POOLED if self.tuner.mode == "pooled" else L.TUNE_PER_CHAIN

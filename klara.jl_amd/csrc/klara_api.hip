@@ -25,6 +25,7 @@ struct klara_handle {
     double *X = nullptr, *GR = nullptr, *LT = nullptr;
     double* tune_step = nullptr;
     long long *tune_acc = nullptr, *tune_prop = nullptr, *tune_tot = nullptr;
+    double *da_epsbar = nullptr, *da_hbar = nullptr;
     unsigned long long* pooled_acc = nullptr;
     uint8_t* accept = nullptr; long long accept_cap = 0;
     unsigned long long* naccept = nullptr;
@@ -49,7 +50,8 @@ struct klara_handle {
 static int cnt_predicate(const klara_desc& d)
 {
     if (d.sampler == KLARA_SAMPLER_MH || d.sampler == KLARA_SAMPLER_SLICE) return d.verbose != 0;
-    return (d.tuner == KLARA_TUNER_VANILLA && d.verbose) || d.tuner == KLARA_TUNER_ACCEPT_RATE;
+    return (d.tuner == KLARA_TUNER_VANILLA && d.verbose) || d.tuner == KLARA_TUNER_ACCEPT_RATE ||
+           (d.tuner == KLARA_TUNER_DUAL_AVERAGING && d.verbose);
 }
 
 static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -90,7 +92,13 @@ static klara_status validate(const klara_desc* d)
     if (d->nchains <= 0 || d->ndims <= 0 || d->chain_offset < 0) return KLARA_ERR_INVALID_ARG;
     if (d->sampler < KLARA_SAMPLER_MH || d->sampler > KLARA_SAMPLER_SLICE) return KLARA_ERR_INVALID_ARG;
     if (d->target < KLARA_TARGET_GAUSS_DIAG || d->target > KLARA_TARGET_HIER_NORMAL) return KLARA_ERR_INVALID_ARG;
-    if (d->tuner != KLARA_TUNER_VANILLA && d->tuner != KLARA_TUNER_ACCEPT_RATE) return KLARA_ERR_INVALID_ARG;
+    if (d->tuner < KLARA_TUNER_VANILLA || d->tuner > KLARA_TUNER_DUAL_AVERAGING) return KLARA_ERR_INVALID_ARG;
+    if (d->tuner == KLARA_TUNER_DUAL_AVERAGING) {                // DualAveragingMCTuner.jl:65-70
+        if (!(d->targetrate > 0.0 && d->targetrate < 1.0) || d->da_nadapt <= 0 || !(d->da_eps0bar > 0.0) || d->da_t0 <= 0 ||
+            !(d->da_gamma > 0.0))
+            return KLARA_ERR_INVALID_ARG;
+        if (d->sampler != KLARA_SAMPLER_HMC || d->tuner_mode != KLARA_TUNE_PER_CHAIN) return KLARA_ERR_UNSUPPORTED;
+    }
     if (d->tuner_mode != KLARA_TUNE_PER_CHAIN && d->tuner_mode != KLARA_TUNE_POOLED) return KLARA_ERR_INVALID_ARG;
     // BasicMCRange.jl:22-24
     if (d->burnin < 0 || d->thinning < 1 || d->thinning > 0x7fffffff || d->nsteps <= d->burnin) return KLARA_ERR_INVALID_ARG;
@@ -139,7 +147,7 @@ static klara_status upload(double** dst, const double* src, size_t n)
 static void free_all(klara_handle* h)
 {
     hipFree(h->X); hipFree(h->GR); hipFree(h->LT); hipFree(h->tune_step); hipFree(h->tune_acc);
-    hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->pooled_acc); hipFree(h->accept);
+    hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->da_epsbar); hipFree(h->da_hbar); hipFree(h->pooled_acc); hipFree(h->accept);
     hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->hist); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->err);
     hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
     hipFree(h->Pfrag); hipFree(h->pooled_out);
@@ -184,7 +192,8 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
 
     CKH(dalloc(&h->X, N * D)); CKH(dalloc(&h->GR, N * D)); CKH(dalloc(&h->LT, N));
     CKH(dalloc(&h->tune_step, NT)); CKH(dalloc(&h->tune_acc, NT)); CKH(dalloc(&h->tune_prop, NT));
-    CKH(dalloc(&h->tune_tot, NT)); CKH(dalloc(&h->pooled_acc, 1)); CKH(dalloc(&h->naccept, N));
+    CKH(dalloc(&h->tune_tot, NT));
+    if (desc->tuner == KLARA_TUNER_DUAL_AVERAGING) { CKH(dalloc(&h->da_epsbar, NT)); CKH(dalloc(&h->da_hbar, NT)); } CKH(dalloc(&h->pooled_acc, 1)); CKH(dalloc(&h->naccept, N));
     CKH(dalloc(&h->err, 1)); CKH(dalloc(&h->pooled_out, 2 * D + 2));
     CKH(hipMemset(h->err, 0, sizeof(int)));
     if (desc->monitor & KLARA_MON_SUMMARIES) { CKH(dalloc(&h->sum, N * D)); CKH(dalloc(&h->sumsq, N * D)); }
@@ -265,6 +274,10 @@ static KParams make_params(klara_handle* h)
     p.vecparam = h->vecparam; p.nleaps = d.nleaps; p.stepout = d.slice_stepout;
     p.tuner = d.tuner; p.cnt = cnt_predicate(d); p.targetrate = d.targetrate;
     p.score_k = d.score_k; p.period = d.period; p.is_mh = d.sampler == KLARA_SAMPLER_MH;
+    p.da_epsbar = h->da_epsbar; p.da_hbar = h->da_hbar; p.da_nadapt = d.da_nadapt; p.da_gamma = d.da_gamma;
+    p.da_kappa = d.da_kappa; p.da_t0 = d.da_t0;
+    // sampler_state(..., tuner::DualAveragingMCTuner): lambda = nleaps*leapstep, mu = log(10*step) (HMC.jl:124-133,192-213)
+    p.da_lambda = (double)d.nleaps * d.leapstep; p.da_mu = kd_log(10.0 * d.leapstep);
     p.step0 = d.sampler == KLARA_SAMPLER_MH ? 1.0 : d.sampler == KLARA_SAMPLER_MALA ? d.driftstep
             : d.sampler == KLARA_SAMPLER_HMC ? d.leapstep : (double)NAN;
     p.burnin = d.burnin; p.thinning = d.thinning; p.nsteps_total = d.nsteps;
@@ -326,6 +339,12 @@ __global__ void k_fill_tune(double* step, long long* acc, long long* prop, long 
     if (i < n) { step[i] = step0; acc[i] = 0; prop[i] = 0; tot[i] = period; }
 }
 
+__global__ void k_fill2(double* a, double* b, long long n, double va, double vb)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = va; b[i] = vb; }
+}
+
 // pooled tuner update after a launch of `k` transitions: tuners.jl:27-32, AcceptanceRateMCTuner.jl:46
 // with the rate pooled over the GPU's chains (KLARA_TUNE_POOLED; SURVEY §7 hard part 5).
 __global__ void k_pooled_tune(KParams p, int k)
@@ -367,6 +386,11 @@ static klara_status init_common(klara_handle* h)
     hipLaunchKernelGGL(k_fill_tune, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, st, h->tune_step,
                        h->tune_acc, h->tune_prop, h->tune_tot, NT, step0, (long long)d.period);
     HIPCHK(hipGetLastError());
+    if (h->da_epsbar) {
+        hipLaunchKernelGGL(k_fill2, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, st, h->da_epsbar, h->da_hbar, NT,
+                           d.da_eps0bar, d.da_h0bar);
+        HIPCHK(hipGetLastError());
+    }
     const int needgrad = d.sampler == KLARA_SAMPLER_MALA || d.sampler == KLARA_SAMPLER_HMC;
     KParams p = make_params(h);
     hipError_t e;
@@ -677,6 +701,18 @@ extern "C" klara_status klara_get_tune(klara_handle* h, double* step, int64_t* a
     if (accepted) HIPCHK(hipMemcpy(accepted, h->tune_acc, N * sizeof(int64_t), hipMemcpyDeviceToHost));
     if (proposed) HIPCHK(hipMemcpy(proposed, h->tune_prop, N * sizeof(int64_t), hipMemcpyDeviceToHost));
     if (totproposed) HIPCHK(hipMemcpy(totproposed, h->tune_tot, N * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_dual_averaging(klara_handle* h, double* epsbar, double* hbar)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->have_state || !h->da_epsbar) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t N = (size_t)h->d.nchains;
+    if (epsbar) HIPCHK(hipMemcpy(epsbar, h->da_epsbar, N * sizeof(double), hipMemcpyDeviceToHost));
+    if (hbar) HIPCHK(hipMemcpy(hbar, h->da_hbar, N * sizeof(double), hipMemcpyDeviceToHost));
     return KLARA_OK;
 }
 

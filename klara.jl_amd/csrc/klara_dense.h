@@ -138,7 +138,7 @@ __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int 
     }
 }
 
-template <int SAMPLER, int NE>
+template <int SAMPLER, int NE, bool DA>
 __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, const double* __restrict__ Pfrag)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,7 +151,9 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
     const MfmaCtx<NE> cx = make_mctx<NE>(p);
     const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
     const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
-    TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0 };
+    constexpr bool da = DA;   // dual averaging is a separate instantiation: the masked leapfrog loop costs registers
+    TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0, 0.0, 0.0 };
+    if (da) { tn.epsbar = p.da_epsbar[tix]; tn.hbar = p.da_hbar[tix]; }
     tn.phase = p.cnt ? (int)(tn.proposed % p.period) : 0;
     int sphase = p.save_phase0;
     long long scol = p.save_col0;
@@ -183,14 +185,38 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
             mreduce<1>(k0, cx.lane);
             const double H0 = lt - 0.5 * k0[0];                        // HMC.jl:137
             const double eps = tn.step, halfe = 0.5 * eps;
-            for (int l = 0; l < p.nleaps; ++l) {                       // HMC.jl:146-155
+            // dual averaging: per-chain trip count (iterate/HMC.jl:142-144); the 16 chains of the tile run to the
+            // longest trajectory, a finished chain's lanes re-use their frozen state (its MFMA columns are
+            // recomputed but discarded)
+            if (!da) {
+                for (int l = 0; l < p.nleaps; ++l) {                   // HMC.jl:146-155
 #pragma unroll
-                for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];   // samplers.jl:130
+                    for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];   // samplers.jl:130
 #pragma unroll
-                for (int e = 0; e < NE; ++e) xp[e] = xp[e] + eps * mom[e];      // samplers.jl:131
-                dense_grad<NE>(ldsP, cx.lane, xp, gp);                          // samplers.jl:132
+                    for (int e = 0; e < NE; ++e) xp[e] = xp[e] + eps * mom[e];      // samplers.jl:131
+                    dense_grad<NE>(ldsP, cx.lane, xp, gp);                          // samplers.jl:132
 #pragma unroll
-                for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];   // samplers.jl:133
+                    for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];   // samplers.jl:133
+                }
+            } else {
+                const int nl = da_nleaps(p, eps);
+                for (int l = 0; __any(l < nl); ++l) {
+                    const bool go = l < nl;
+                    if (go) {
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) xp[e] = xp[e] + eps * mom[e];
+                    }
+                    double gn[NG];
+                    dense_grad<NE>(ldsP, cx.lane, xp, gn);
+                    if (go) {
+#pragma unroll
+                        for (int e = 0; e < NG; ++e) gp[e] = gn[e];
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];
+                    }
+                }
             }
             double l1 = 0.0, k1 = 0.0;
 #pragma unroll
@@ -207,6 +233,7 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
             const double a = 1.0 < ex ? 1.0 : ex;                      // HMC.jl:163
             const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
             acc = u < a;                                               // HMC.jl:165
+            if (da) da_update(p, tn, (long long)t + 1, a);             // HMC.jl:225-249
         } else if (SAMPLER == KLARA_SAMPLER_MALA) {
             // iterate/MALA.jl:78-128
             double z[NE], xc[NE], red[3];
@@ -283,7 +310,10 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
         if (p.cnt && acc) tn.accepted += 1;
         if (p.accept != nullptr && cx.chain_ok && cx.q == 0)
             p.accept[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
-        if (!p.pooled) tuning_block(p, tn);
+        if (!p.pooled && !da) tuning_block(p, tn);
+        else if (da && p.cnt && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {
+            tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
+        }
         const long long i1 = (long long)t + 1;
         const bool in_post = i1 > p.burnin && i1 <= p.nsteps_total;
         const bool save_now = in_post && sphase == 0;
@@ -335,6 +365,7 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
     if (cx.chain_ok && cx.q == 0) {
         p.LT[cx.chain] = lt;
         p.naccept[cx.chain] += nacc;
+        if (da) { p.da_epsbar[cx.chain] = tn.epsbar; p.da_hbar[cx.chain] = tn.hbar; }
         if (!p.pooled) {
             p.tune_step[cx.chain] = tn.step;
             p.tune_accepted[cx.chain] = tn.accepted;

@@ -2,17 +2,17 @@
 #include "klara_launch.h"
 #include "klara_dense.h"
 
-template <int SAMPLER>
+template <int SAMPLER, bool DA>
 static hipError_t launch_dense_s(const KParams& p, int NE, const double* Pfrag, dim3 grid, hipStream_t st)
 {
     const dim3 blk(512);
 #define KLARA_DENSE_CASE(N)                                                                            \
     case N: {                                                                                          \
         constexpr size_t lds = sizeof(double) * 64 * (size_t)N * (size_t)((N + 3) / 4);                \
-        hipError_t e = hipFuncSetAttribute((const void*)k_dense_transitions<SAMPLER, N>,               \
+        hipError_t e = hipFuncSetAttribute((const void*)k_dense_transitions<SAMPLER, N, DA>,               \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return e;                                                                 \
-        hipLaunchKernelGGL((k_dense_transitions<SAMPLER, N>), grid, blk, lds, st, p, Pfrag);           \
+        hipLaunchKernelGGL((k_dense_transitions<SAMPLER, N, DA>), grid, blk, lds, st, p, Pfrag);           \
         break;                                                                                         \
     }
     switch (NE) {
@@ -30,9 +30,11 @@ hipError_t klara_launch_dense(const KParams& p, int sampler, int NE, const doubl
                               hipStream_t st)
 {
     switch (sampler) {
-    case KLARA_SAMPLER_MH: return launch_dense_s<KLARA_SAMPLER_MH>(p, NE, Pfrag, grid, st);
-    case KLARA_SAMPLER_MALA: return launch_dense_s<KLARA_SAMPLER_MALA>(p, NE, Pfrag, grid, st);
-    case KLARA_SAMPLER_HMC: return launch_dense_s<KLARA_SAMPLER_HMC>(p, NE, Pfrag, grid, st);
+    case KLARA_SAMPLER_MH: return launch_dense_s<KLARA_SAMPLER_MH, false>(p, NE, Pfrag, grid, st);
+    case KLARA_SAMPLER_MALA: return launch_dense_s<KLARA_SAMPLER_MALA, false>(p, NE, Pfrag, grid, st);
+    case KLARA_SAMPLER_HMC:
+        if (p.tuner == KLARA_TUNER_DUAL_AVERAGING) return launch_dense_s<KLARA_SAMPLER_HMC, true>(p, NE, Pfrag, grid, st);
+        return launch_dense_s<KLARA_SAMPLER_HMC, false>(p, NE, Pfrag, grid, st);
     default: return hipErrorInvalidValue;
     }
 }

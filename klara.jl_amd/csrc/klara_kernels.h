@@ -46,6 +46,9 @@ struct KParams {
     int nleaps; int stepout;
     // tuner
     int tuner; int cnt; double targetrate; double score_k; int period; int is_mh;
+    // DualAveragingMCTuner (KLARA_TUNER_DUAL_AVERAGING): per-chain eps_bar / h_bar arrays and constants
+    double* da_epsbar; double* da_hbar; long long da_nadapt; double da_gamma; double da_kappa; int da_t0;
+    double da_mu; double da_lambda;            // mu = log(10*leapstep), lambda = nleaps*leapstep (HMC.jl:124-133,192-213)
     double step0;                              // initial step (samplers.jl:29-45); the step of every chain when nothing is tuned
     long long burnin; long long thinning; long long nsteps_total;
     int save_phase0; long long save_col0;      // host-computed: (i1-burnin-1) % thinning of the first post-burn-in step of
@@ -403,7 +406,8 @@ __device__ __forceinline__ double eval_lt(const T& tg, const LaneCtx<E>& cx, con
 // ------------------------------------------------------------------------------------------------
 // per-chain tuner state in registers (tuners.jl:5-10), uniform across the group's lanes
 // ------------------------------------------------------------------------------------------------
-struct TuneRegs { double step; long long accepted, proposed, totproposed; int phase; /* proposed % period */ };
+struct TuneRegs { double step; long long accepted, proposed, totproposed; int phase; /* proposed % period */
+                  double epsbar, hbar; /* dual averaging */ };
 
 __device__ __forceinline__ void tune_count_proposal(const KParams& p, TuneRegs& tn)
 {
@@ -425,6 +429,28 @@ __device__ __forceinline__ void tuning_block(const KParams& p, TuneRegs& tn)
         }
         tn.totproposed += tn.proposed;
         tn.accepted = 0; tn.proposed = 0; tn.phase = 0;
+    }
+}
+
+// nleaps of a transition under dual averaging: max(1, Int(round(lambda/step))) — iterate/HMC.jl:142-144
+// (round = ties to even; capped at 65536, non-finite quotient -> cap).
+__device__ __forceinline__ int da_nleaps(const KParams& p, double step)
+{
+    const double q = p.da_lambda / step;
+    long long nl = (q == q && q < 65536.0) ? (long long)__builtin_rint(q) : 65536ll;
+    return (int)(nl < 1 ? 1 : nl);
+}
+// tune!(tune, tuner, count, a) — DualAveragingMCTuner.jl:95-101; after nadapt: step = eps_bar (iterate/HMC.jl:247)
+__device__ __forceinline__ void da_update(const KParams& p, TuneRegs& tn, long long count, double a)
+{
+    if (count <= p.da_nadapt) {
+        const double hweight = 1.0 / (double)(count + p.da_t0);
+        tn.hbar = (1.0 - hweight) * tn.hbar + hweight * (p.targetrate - a);
+        tn.step = kd_exp(p.da_mu - __builtin_sqrt((double)count) * tn.hbar / p.da_gamma);
+        const double eweight = kd_exp(-p.da_kappa * kd_log((double)count));        // count^(-kappa)
+        tn.epsbar = kd_exp((1.0 - eweight) * kd_log(tn.epsbar) + eweight * kd_log(tn.step));
+    } else {
+        tn.step = tn.epsbar;
     }
 }
 
@@ -507,7 +533,7 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
 template <class T, int E>
 __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const LaneCtx<E>& cx,
                                          unsigned long long gchain, unsigned long long t,
-                                         const double (&z)[E], double eps,
+                                         const double (&z)[E], double eps, int nleaps, double& a_out,
                                          double (&x)[E], double (&g)[E], double& lt)
 {
     double mom[E], xp[E], gp[E], red[2], dummy;
@@ -521,14 +547,37 @@ __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const La
 #pragma unroll
     for (int e = 0; e < E; ++e) { xp[e] = x[e]; gp[e] = g[e]; }                       // :139-140
     const double halfe = 0.5 * eps;
-    for (int l = 0; l < p.nleaps; ++l) {                                              // :146-155
+    if (p.tuner != KLARA_TUNER_DUAL_AVERAGING) {
+        for (int l = 0; l < p.nleaps; ++l) {                                          // :146-155
 #pragma unroll
-        for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];                  // samplers.jl:130
+            for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];              // samplers.jl:130
 #pragma unroll
-        for (int e = 0; e < E; ++e) xp[e] = xp[e] + eps * mom[e];                     // samplers.jl:131
-        tg.template eval<false, true>(cx, xp, dummy, gp);                             // samplers.jl:132
+            for (int e = 0; e < E; ++e) xp[e] = xp[e] + eps * mom[e];                 // samplers.jl:131
+            tg.template eval<false, true>(cx, xp, dummy, gp);                         // samplers.jl:132
 #pragma unroll
-        for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];                  // samplers.jl:133
+            for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];              // samplers.jl:133
+        }
+    } else {
+        // dual averaging: the trip count differs per chain (iterate/HMC.jl:142-144); the wavefront runs to the
+        // longest trajectory it carries and finished chains are masked (the target evaluation may use
+        // cross-lane collectives, so control flow stays wave-uniform)
+        for (int l = 0; __any(l < nleaps); ++l) {
+            const bool go = l < nleaps;
+            double mo[E], xo[E], go_[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) { mo[e] = mom[e]; xo[e] = xp[e]; go_[e] = gp[e]; }
+#pragma unroll
+            for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];
+#pragma unroll
+            for (int e = 0; e < E; ++e) xp[e] = xp[e] + eps * mom[e];
+            tg.template eval<false, true>(cx, xp, dummy, gp);
+#pragma unroll
+            for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];
+            if (!go) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) { mom[e] = mo[e]; xp[e] = xo[e]; gp[e] = go_[e]; }
+            }
+        }
     }
     double gd[E];
     tg.template eval<true, false>(cx, xp, red[0], gd);                                // :157
@@ -542,6 +591,7 @@ __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const La
     const double ratio = H1 - H0;                                                     // :161
     const double ex = kd_exp(ratio);
     const double a = 1.0 < ex ? 1.0 : ex;                                             // :163
+    a_out = a;
     const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
     const bool acc = u < a;                                                           // :165
     if (acc) {                                                                        // :166-176
@@ -640,6 +690,7 @@ struct ChainRegs {
     double x[E], g[E];
     double lt;
     double step; long long accepted, proposed, totproposed;
+    double epsbar, hbar;
 };
 
 template <int E, bool NEEDG>
@@ -652,7 +703,10 @@ __device__ __forceinline__ void load_chain(const KParams& p, const LaneCtx<E>& c
     if (p.cnt && !p.pooled) {            // per-chain tuner state (tuners.jl:5-10) only when something counts
         r.step = p.tune_step[c0]; r.accepted = p.tune_accepted[c0];
         r.proposed = p.tune_proposed[c0]; r.totproposed = p.tune_totproposed[c0];
+    } else if (p.tuner == KLARA_TUNER_DUAL_AVERAGING) {
+        r.step = p.tune_step[c0];
     }
+    if (p.tuner == KLARA_TUNER_DUAL_AVERAGING) { r.epsbar = p.da_epsbar[c0]; r.hbar = p.da_hbar[c0]; }
 }
 
 template <int E, int GT>
@@ -690,6 +744,7 @@ __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1))) 
     long long grp = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const bool do_sum = p.sum != nullptr;
     const bool per_chain_tune = p.cnt && !p.pooled;
+    const bool da = p.tuner == KLARA_TUNER_DUAL_AVERAGING;
 
     ChainRegs<E> cur;
     set_chain<E, GT>(p, cx, grp);
@@ -714,9 +769,10 @@ __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1))) 
         if (NEEDZ) lane_normals<E>(cx, p.seed, gchain, p.t0, z);        // before the loaded state is touched
 
         TuneRegs tn;
-        if (per_chain_tune) tn = { cur.step, cur.accepted, cur.proposed, cur.totproposed, 0 };
-        else if (p.pooled) tn = { p.tune_step[0], p.tune_accepted[0], 0, 0, 0 };
-        else tn = { p.step0, 0, 0, 0, 0 };
+        if (per_chain_tune) tn = { cur.step, cur.accepted, cur.proposed, cur.totproposed, 0, 0.0, 0.0 };
+        else if (p.pooled) tn = { p.tune_step[0], p.tune_accepted[0], 0, 0, 0, 0.0, 0.0 };
+        else tn = { da ? cur.step : p.step0, 0, 0, 0, 0, 0.0, 0.0 };
+        if (da) { tn.epsbar = cur.epsbar; tn.hbar = cur.hbar; }
         const long long acc0 = tn.accepted;
         tn.phase = per_chain_tune ? (int)(tn.proposed % p.period) : 0;
         int sphase = p.save_phase0;
@@ -730,13 +786,21 @@ __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1))) 
             bool acc;
             if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E>(p, tg, cx, gchain, t, z, vp, cur.x, cur.lt);
             else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E>(p, tg, cx, gchain, t, z, tn.step, cur.x, cur.g, cur.lt);
-            else if (SAMPLER == KLARA_SAMPLER_HMC) acc = step_hmc<T, E>(p, tg, cx, gchain, t, z, tn.step, cur.x, cur.g, cur.lt);
+            else if (SAMPLER == KLARA_SAMPLER_HMC) {
+                double a_prob = 0.0;
+                acc = step_hmc<T, E>(p, tg, cx, gchain, t, z, tn.step, da ? da_nleaps(p, tn.step) : p.nleaps, a_prob,
+                                     cur.x, cur.g, cur.lt);
+                if (da) da_update(p, tn, (long long)t + 1, a_prob);                   // iterate/HMC.jl:225-249
+            }
             else acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, cur.x, cur.lt, stuck);
             nacc += acc ? 1ull : 0ull;
             if (p.cnt && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;   // the slice sampler never counts accepts
             if (p.accept != nullptr && cx.chain_ok && cx.q == 0)
                 p.accept[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
-            if (per_chain_tune) tuning_block(p, tn);
+            if (per_chain_tune && !da) tuning_block(p, tn);
+            else if (per_chain_tune && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {   // verbose report block, iterate/HMC.jl:229-243
+                tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
+            }
             // save rule: BasicMCJob.jl:226-231 with postrange = (burnin+1):thinning:nsteps (BasicMCRange.jl:36)
             const long long i1 = (long long)t + 1;
             if (i1 > p.burnin && i1 <= p.nsteps_total) {
@@ -772,6 +836,7 @@ __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1))) 
         if (do_sum) { store_vec<E>(cx, p.sum, p.D, sm); store_vec<E>(cx, p.sumsq, p.D, sq); }
         if (cx.chain_ok && cx.q == 0) {
             if (nacc != 0) { p.LT[cx.chain] = cur.lt; p.naccept[cx.chain] += nacc; }
+            if (da) { p.tune_step[cx.chain] = tn.step; p.da_epsbar[cx.chain] = tn.epsbar; p.da_hbar[cx.chain] = tn.hbar; }
             if (per_chain_tune) {
                 p.tune_step[cx.chain] = tn.step;
                 p.tune_accepted[cx.chain] = tn.accepted;

@@ -145,6 +145,8 @@ class Engine:
                  slice_widths=None, slice_stepout: bool = True,
                  tuner: int = L.TUNER_VANILLA, tuner_mode: int = L.TUNE_PER_CHAIN, targetrate: float = 0.0,
                  score_k: float = 7.0, period: int = 100, verbose: bool = False,
+                 da_nadapt: int = 0, da_eps0bar: float = 1.0, da_h0bar: float = 0.0, da_gamma: float = 0.05,
+                 da_t0: int = 10, da_kappa: float = 0.75,
                  seed: int = 20260927, chain_offset: int = 0, device: int = 0, monitor: int = 0,
                  steps_per_launch: int = 0, stream: int = 0):
         self._lib = L.load()
@@ -167,6 +169,8 @@ class Engine:
         d.driftstep, d.leapstep, d.nleaps, d.slice_stepout = float(driftstep), float(leapstep), int(nleaps), int(bool(slice_stepout))
         d.targetrate, d.score_k, d.period, d.verbose = float(targetrate), float(score_k), int(period), int(bool(verbose))
         d.nsteps, d.burnin, d.thinning = self.nsteps, self.burnin, self.thinning
+        d.da_nadapt, d.da_eps0bar, d.da_h0bar = int(da_nadapt), float(da_eps0bar), float(da_h0bar)
+        d.da_gamma, d.da_kappa, d.da_t0 = float(da_gamma), float(da_kappa), int(da_t0)
         if isinstance(target, GaussDiagTarget):
             if target.w is not None:
                 a = _f64(target.w, (self.ndims,)); keep.append(a); d.gauss_w = _ptr(a)
@@ -291,6 +295,11 @@ class Engine:
         p = np.empty(self.nchains, dtype=np.int64); t = np.empty(self.nchains, dtype=np.int64)
         L.check(self._lib.klara_get_tune(self._h, step.ctypes.data, a.ctypes.data, p.ctypes.data, t.ctypes.data), "klara_get_tune")
         return step, a, p, t
+
+    def dual_averaging(self):
+        eb = np.empty(self.nchains); hb = np.empty(self.nchains)
+        L.check(self._lib.klara_get_dual_averaging(self._h, eb.ctypes.data, hb.ctypes.data), "klara_get_dual_averaging")
+        return eb, hb
 
     def last_run_ms(self):
         ms, n = C.c_double(0.0), C.c_int64(0)

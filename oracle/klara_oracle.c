@@ -282,7 +282,8 @@ static void ko_tuning_block(const klara_desc* d, ko_tune* tn, int cnt, int64_t p
 static int ko_cnt(const klara_desc* d)
 {
     if (d->sampler == KLARA_SAMPLER_MH || d->sampler == KLARA_SAMPLER_SLICE) return d->verbose != 0;
-    return (d->tuner == KLARA_TUNER_VANILLA && d->verbose) || d->tuner == KLARA_TUNER_ACCEPT_RATE;
+    return (d->tuner == KLARA_TUNER_VANILLA && d->verbose) || d->tuner == KLARA_TUNER_ACCEPT_RATE ||
+           (d->tuner == KLARA_TUNER_DUAL_AVERAGING && d->verbose);      /* HMC.jl(iterate):129-133 */
 }
 
 /* ------------------------------------------------------------------ transitions */
@@ -339,8 +340,8 @@ static int ko_mala(const ko_target_ctx* c, uint64_t chain, uint64_t t, double h,
 
 /* iterate!(job, HMC, Multivariate) — src/samplers/iterate/HMC.jl:124-201;
  * leapfrog! — src/samplers/samplers.jl:122-134; hamiltonian — samplers.jl:103 */
-static int ko_hmc(const ko_target_ctx* c, uint64_t chain, uint64_t t, double eps, int nleaps,
-                  double* x, double* g, double* lt)
+static int ko_hmc(const ko_target_ctx* c, uint64_t chain, uint64_t t, double eps, int64_t nleaps,
+                  double* x, double* g, double* lt, double* a_out)
 {
     const klara_desc* d = c->d;
     const int D = d->ndims;
@@ -351,7 +352,7 @@ static int ko_hmc(const ko_target_ctx* c, uint64_t chain, uint64_t t, double eps
     memcpy(xp, x, sizeof(double) * (size_t)D);                           /* :139 */
     memcpy(gp, g, sizeof(double) * (size_t)D);                           /* :140 */
     const double halfe = 0.5 * eps;
-    for (int l = 0; l < nleaps; ++l) {                                   /* :146-155 */
+    for (int64_t l = 0; l < nleaps; ++l) {                               /* :146-155 */
         for (int i = 0; i < D; ++i) p[i] = p[i] + halfe * gp[i];         /* samplers.jl:130 */
         for (int i = 0; i < D; ++i) xp[i] = xp[i] + eps * p[i];          /* samplers.jl:131 */
         ko_gradlogtarget(c, xp, gp);                                     /* samplers.jl:132 */
@@ -367,6 +368,7 @@ static int ko_hmc(const ko_target_ctx* c, uint64_t chain, uint64_t t, double eps
     const double a = 1.0 < e ? 1.0 : e;                                  /* :163 min(1., exp(ratio)) */
     const double u = ko_accept_uniform(d->seed, chain, t, D);            /* :165 rand() always drawn */
     const int acc = u < a;
+    if (a_out) *a_out = a;
     if (acc) {
         memcpy(x, xp, sizeof(double) * (size_t)D);
         memcpy(g, gp, sizeof(double) * (size_t)D);
@@ -435,7 +437,8 @@ static void ko_ctx_init(ko_target_ctx* c, const klara_desc* d, const ko_layout* 
 /* initialize!(pstate, parameter, sampler) — MH.jl:72-85, MALA.jl:76-90, HMC.jl:106-120,
  * SliceSampler.jl:40-48; tuner_state — samplers.jl:29-45 (totproposed starts at tuner.period). */
 int ko_init(const klara_desc* d, const ko_layout* L, const double* X, double* G, double* LT,
-            double* step, int64_t* accepted, int64_t* proposed, int64_t* totproposed)
+            double* step, int64_t* accepted, int64_t* proposed, int64_t* totproposed,
+            double* da_epsbar, double* da_hbar)
 {
     ko_target_ctx c; ko_ctx_init(&c, d, L);
     const int D = d->ndims;
@@ -459,6 +462,8 @@ int ko_init(const klara_desc* d, const ko_layout* L, const double* X, double* G,
                     : d->sampler == KLARA_SAMPLER_MALA ? d->driftstep
                     : d->sampler == KLARA_SAMPLER_HMC ? d->leapstep : NAN;
             accepted[k] = 0; proposed[k] = 0; totproposed[k] = d->period;
+            /* tuner_state(parameter, sampler::HMC, tuner::DualAveragingMCTuner) — HMC.jl:124-133 */
+            if (d->tuner == KLARA_TUNER_DUAL_AVERAGING && da_epsbar) { da_epsbar[k] = d->da_eps0bar; da_hbar[k] = d->da_h0bar; }
         }
     }
     return bad ? KLARA_ERR_NONFINITE_INIT : KLARA_OK;
@@ -472,14 +477,14 @@ void ko_init_state_normal(const klara_desc* d, double* X)
 }
 
 /* one transition of one chain; returns accept flag */
-static int ko_transition(const ko_target_ctx* c, uint64_t gchain, uint64_t t, double step,
-                         double* x, double* g, double* lt, int* stuck)
+static int ko_transition(const ko_target_ctx* c, uint64_t gchain, uint64_t t, double step, int64_t nleaps,
+                         double* x, double* g, double* lt, int* stuck, double* a_out)
 {
     const klara_desc* d = c->d;
     switch (d->sampler) {
     case KLARA_SAMPLER_MH: return ko_mh(c, gchain, t, x, lt);
     case KLARA_SAMPLER_MALA: return ko_mala(c, gchain, t, step, x, g, lt);
-    case KLARA_SAMPLER_HMC: return ko_hmc(c, gchain, t, step, d->nleaps, x, g, lt);
+    case KLARA_SAMPLER_HMC: return ko_hmc(c, gchain, t, step, nleaps, x, g, lt, a_out);
     default: return ko_slice(c, gchain, t, x, lt, stuck);
     }
 }
@@ -494,13 +499,20 @@ static int ko_transition(const ko_target_ctx* c, uint64_t gchain, uint64_t t, do
 int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double* LT,
            double* step, int64_t* accepted, int64_t* proposed, int64_t* totproposed,
            int64_t t0, int64_t nsteps, uint8_t* accept_out, double* sum, double* sumsq,
-           uint64_t* naccept, double* hist, int64_t hist_cols, double* hist_lt, double* hist_g)
+           uint64_t* naccept, double* hist, int64_t hist_cols, double* hist_lt, double* hist_g,
+           double* da_epsbar, double* da_hbar)
 {
     ko_target_ctx c; ko_ctx_init(&c, d, L);
     const int D = d->ndims;
     if (D > KO_MAXD) return KLARA_ERR_UNSUPPORTED;
     const int cnt = ko_cnt(d);
     const int pooled = d->tuner_mode == KLARA_TUNE_POOLED;
+    const int da = d->tuner == KLARA_TUNER_DUAL_AVERAGING && d->sampler == KLARA_SAMPLER_HMC;
+    /* sampler_state(...::DualAveragingMCTuner), HMC.jl:192-213: lambda = nleaps*leapstep, mu = log(10*step).
+     * initialize_step! (samplers.jl:170-202) returns step0 in the reference as shipped: the proposal state's
+     * logtarget is never evaluated (NaN), every comparison is false and the loop body (which would crash on the
+     * undefined `moment`, samplers.jl:195) is never entered.  That effective behaviour is what is restated. */
+    const double da_lambda = (double)d->nleaps * d->leapstep, da_mu = kd_log(10.0 * d->leapstep);
     int stuck_any = 0;
 
     if (!pooled) {
@@ -512,13 +524,35 @@ int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double
             for (int64_t s = 0; s < nsteps && !stuck; ++s) {
                 const int64_t t = t0 + s;
                 if (cnt) tn.proposed += 1;
+                int64_t nl = d->nleaps;
+                double a_prob = 0.0;
+                if (da) {                                       /* iterate/HMC.jl:142-144 */
+                    const double q = da_lambda / tn.step;
+                    nl = (q == q && q < 65536.0) ? (int64_t)nearbyint(q) : 65536;   /* Int(round(.)), ties to even; capped */
+                    if (nl < 1) nl = 1;
+                }
                 const int acc = ko_transition(&c, (uint64_t)(d->chain_offset + n), (uint64_t)t,
-                                              tn.step, x, g, &LT[n], &stuck);
+                                              tn.step, nl, x, g, &LT[n], &stuck, &a_prob);
                 if (stuck) break;
+                if (da) {                                       /* iterate/HMC.jl:225-249 */
+                    const int64_t count = t + 1;                /* job.sstate.count, incremented at :125-127 */
+                    if (count <= d->da_nadapt) {                /* tune!(tune, tuner, count, a) DualAveragingMCTuner.jl:95-101 */
+                        const double hweight = 1.0 / (double)(count + d->da_t0);
+                        da_hbar[n] = (1.0 - hweight) * da_hbar[n] + hweight * (d->targetrate - a_prob);
+                        tn.step = kd_exp(da_mu - sqrt((double)count) * da_hbar[n] / d->da_gamma);
+                        const double eweight = kd_exp(-d->da_kappa * kd_log((double)count));   /* count^(-kappa) */
+                        da_epsbar[n] = kd_exp((1.0 - eweight) * kd_log(da_epsbar[n]) + eweight * kd_log(tn.step));
+                    } else {
+                        tn.step = da_epsbar[n];                 /* :247 */
+                    }
+                }
                 if (acc && cnt && d->sampler != KLARA_SAMPLER_SLICE) tn.accepted += 1;
                 if (accept_out) accept_out[s * d->nchains + n] = (uint8_t)acc;
                 if (naccept) naccept[n] += (uint64_t)acc;
-                ko_tuning_block(d, &tn, cnt, 1);
+                if (!da) ko_tuning_block(d, &tn, cnt, 1);
+                else if (cnt && (tn.proposed % d->period) == 0 && t + 1 <= d->da_nadapt) {   /* verbose report block :229-243 */
+                    tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
+                }
                 const int64_t i1 = t + 1;                       /* 1-based step index i of run() */
                 if (i1 > d->burnin && (i1 - d->burnin - 1) % d->thinning == 0 && i1 <= d->nsteps) {
                     const int64_t col = (i1 - d->burnin - 1) / d->thinning;
@@ -550,7 +584,7 @@ int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double
                 int stuck = 0;
                 double* x = X + n * D; double* g = G + n * D;
                 const int acc = ko_transition(&c, (uint64_t)(d->chain_offset + n), (uint64_t)t,
-                                              tn.step, x, g, &LT[n], &stuck);
+                                              tn.step, d->nleaps, x, g, &LT[n], &stuck, NULL);
                 stuck_any |= stuck;
                 nacc += acc;
                 if (accept_out) accept_out[s * d->nchains + n] = (uint8_t)acc;

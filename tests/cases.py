@@ -63,6 +63,19 @@ def make_case(name):
         c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.negdot(10), nchains=40, nsteps=120, burnin=90,
                  leapstep=0.9, nleaps=5, tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.65,
                  period=20)
+    elif name == "hmc_d10_dualavg":    # DualAveragingMCTuner: per-chain step AND per-chain nleaps (iterate/HMC.jl:142-144)
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.negdot(10), nchains=45, nsteps=80, burnin=50,
+                 leapstep=0.3, nleaps=6, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=50)
+    elif name == "hmc_dense_d37_dualavg":
+        rng = np.random.default_rng(5)
+        a = rng.standard_normal((37, 37)); p = a @ a.T / 37 + np.eye(37)
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(p), nchains=21, nsteps=40, burnin=0, leapstep=0.2,
+                 nleaps=4, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.8, da_nadapt=25, verbose=True, period=10)
+    elif name == "hmc_rats_dualavg":
+        t = rats_target()
+        x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(8).standard_normal((18, t.ndims))
+        c = dict(sampler=L.SAMPLER_HMC, target=t, nchains=18, nsteps=40, burnin=30, leapstep=0.02, nleaps=5,
+                 tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=30, x0=x0)
     elif name == "hmc_dense_d100":     # BASELINE cfg 3 shape at parity-test size (FP64 MFMA path)
         c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(compound_symmetric_precision(100)), nchains=40,
                  nsteps=12, burnin=2, leapstep=0.1, nleaps=10)
@@ -124,10 +137,11 @@ def make_case(name):
 ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_small_step", "mala_d3_tuned",
              "mala_d300", "hmc_d100", "hmc_d10_tuned_pooled", "hmc_dense_d100", "hmc_dense_d37", "mala_dense_d100",
              "mh_dense_d20", "mala_swiss", "hmc_swiss", "slice_d5", "slice_d100_nostepout", "slice_swiss",
-             "hmc_rats", "hmc_rats_pooled", "mala_rats", "slice_rats"]
+             "hmc_rats", "hmc_rats_pooled", "mala_rats", "slice_rats", "hmc_d10_dualavg", "hmc_dense_d37_dualavg",
+             "hmc_rats_dualavg"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
-                "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats"]
+                "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg"]
 
 
 def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):

@@ -30,7 +30,7 @@ def run_case(name):
     assert job.run(c["nsteps"]) == 0
     return dict(x0=x0, x=job.X, lt=job.LT, g=job.G, accept=job.accept, sum=job.sum, sumsq=job.sumsq,
                 naccept=job.naccept, step=job.step, accepted=job.accepted, proposed=job.proposed,
-                totproposed=job.totproposed, layout=np.array([job.layout.kind, job.layout.G, job.layout.E]))
+                totproposed=job.totproposed, da_epsbar=job.da_epsbar, da_hbar=job.da_hbar, layout=np.array([job.layout.kind, job.layout.G, job.layout.E]))
 
 
 if __name__ == "__main__":

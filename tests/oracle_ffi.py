@@ -37,11 +37,11 @@ def load() -> C.CDLL:
             raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
     lib = C.CDLL(str(SO))
     vp = C.c_void_p
-    lib.ko_init.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout)] + [vp] * 7
+    lib.ko_init.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout)] + [vp] * 9
     lib.ko_init.restype = C.c_int
     lib.ko_init_state_normal.argtypes = [C.POINTER(L.KlaraDesc), vp]
     lib.ko_init_state_normal.restype = None
-    lib.ko_run.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout)] + [vp] * 7 + [C.c_int64, C.c_int64] + [vp] * 5 + [C.c_int64, vp, vp]
+    lib.ko_run.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout)] + [vp] * 7 + [C.c_int64, C.c_int64] + [vp] * 5 + [C.c_int64, vp, vp, vp, vp]
     lib.ko_run.restype = C.c_int
     lib.ko_philox_block.argtypes = [vp, vp, vp]
     lib.ko_stream_block.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]
@@ -90,6 +90,7 @@ class OracleJob:
     def __init__(self, *, sampler, target_kind, nchains, ndims, nsteps, burnin=0, thinning=1,
                  mh_sigma=None, driftstep=1.0, leapstep=0.1, nleaps=10, slice_widths=None, slice_stepout=True,
                  tuner=0, tuner_mode=0, targetrate=0.0, score_k=7.0, period=100, verbose=False,
+                 da_nadapt=0, da_eps0bar=1.0, da_h0bar=0.0, da_gamma=0.05, da_t0=10, da_kappa=0.75,
                  seed=20260927, chain_offset=0, gauss_w=None, gauss_mu=None, gauss_const=0.0, gauss_prec=None,
                  logit_X=None, logit_y=None, logit_lambda=100.0, hier_Y=None, hier_xc=None, hier_prior_prec=1e-4,
                  hier_gamma_a=1e-3, hier_gamma_b=1e-3, layout=None,
@@ -114,6 +115,8 @@ class OracleJob:
         d.driftstep, d.leapstep, d.nleaps, d.slice_stepout = float(driftstep), float(leapstep), int(nleaps), int(bool(slice_stepout))
         d.targetrate, d.score_k, d.period, d.verbose = float(targetrate), float(score_k), int(period), int(bool(verbose))
         d.nsteps, d.burnin, d.thinning = int(nsteps), int(burnin), int(thinning)
+        d.da_nadapt, d.da_eps0bar, d.da_h0bar = int(da_nadapt), float(da_eps0bar), float(da_h0bar)
+        d.da_gamma, d.da_kappa, d.da_t0 = float(da_gamma), float(da_kappa), int(da_t0)
         d.gauss_w, d.gauss_mu, d.gauss_const = ptr(gauss_w, self.D), ptr(gauss_mu, self.D), float(gauss_const)
         d.gauss_prec = ptr(gauss_prec)
         d.logit_X, d.logit_y = ptr(logit_X), ptr(logit_y)
@@ -131,6 +134,7 @@ class OracleJob:
         self.X = np.zeros((self.N, self.D)); self.G = np.zeros((self.N, self.D)); self.LT = np.zeros(self.N)
         self.step = np.zeros(nt); self.accepted = np.zeros(nt, np.int64)
         self.proposed = np.zeros(nt, np.int64); self.totproposed = np.zeros(nt, np.int64)
+        self.da_epsbar = np.zeros(nt); self.da_hbar = np.zeros(nt)
         self.t = 0
         self.naccept = np.zeros(self.N, np.uint64)
         self.sum = np.zeros((self.N, self.D)) if want_sums else None
@@ -162,7 +166,8 @@ class OracleJob:
         self.accept = np.zeros((0, self.N), np.uint8)
         return self.lib.ko_init(C.byref(self.desc), C.byref(self.layout), self._p(self.X), self._p(self.G),
                                 self._p(self.LT), self._p(self.step), self._p(self.accepted),
-                                self._p(self.proposed), self._p(self.totproposed))
+                                self._p(self.proposed), self._p(self.totproposed), self._p(self.da_epsbar),
+                                self._p(self.da_hbar))
 
     def run(self, nsteps: int) -> int:
         acc = np.zeros((nsteps, self.N), np.uint8) if self.want_accept else None
@@ -170,7 +175,7 @@ class OracleJob:
                              self._p(self.LT), self._p(self.step), self._p(self.accepted), self._p(self.proposed),
                              self._p(self.totproposed), self.t, int(nsteps), self._p(acc), self._p(self.sum),
                              self._p(self.sumsq), self._p(self.naccept), self._p(self.hist), self.hist_cols,
-                             self._p(self.hist_lt), self._p(self.hist_g))
+                             self._p(self.hist_lt), self._p(self.hist_g), self._p(self.da_epsbar), self._p(self.da_hbar))
         self.t += int(nsteps)
         if acc is not None:
             self.accept = np.concatenate([self.accept, acc], axis=0)

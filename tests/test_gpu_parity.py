@@ -116,6 +116,9 @@ def _assert_same(eng, job, case):
     else:
         assert np.array_equal(step, job.step, equal_nan=True), f"{name}: tuned step differs"
         assert np.array_equal(acc, job.accepted) and np.array_equal(prop, job.proposed) and np.array_equal(tot, job.totproposed)
+    if case.get("tuner", 0) == L.TUNER_DUAL_AVERAGING:
+        eb, hb = eng.dual_averaging()
+        assert np.array_equal(eb, job.da_epsbar) and np.array_equal(hb, job.da_hbar), f"{name}: dual-averaging state differs"
     # pooled summaries: device tree-sum vs numpy sum — tolerance 1e-12 relative (different association)
     ps, pq, pna, pnt, pns = eng.pooled_summaries()
     assert np.allclose(ps, job.sum.sum(0), rtol=1e-12, atol=1e-9) and np.allclose(pq, job.sumsq.sum(0), rtol=1e-12)
