@@ -128,7 +128,7 @@ typedef struct klara_desc {
     double   da_gamma;
     double   da_kappa;
     int32_t  da_t0;              /* > 0                                                              */
-    int32_t  reserved1;
+    int32_t  tuner_score;        /* AcceptanceRate score: 0 logistic_rate_score(x, score_k) (default k 7), 1 erf_rate_score(x, score_k) (default k 3) */
 
     /* range (BasicMCRange.jl:17-36) */
     int64_t  nsteps;
@@ -235,7 +235,7 @@ klara_status klara_selftest_rocrand_blocks(int32_t device, uint64_t seed, uint64
                                            uint64_t first_block, int32_t nblocks, uint32_t* out);
 /* Self-test hook: evaluates the deterministic device math (log, exp, sincos2pi, normal pair) on n
  * inputs so tests can compare bits with the CPU build of the same header. op: 0 log, 1 exp,
- * 2 sin2pi, 3 cos2pi, 4 sqrt, 5 div (in[i] / in2[i]). */
+ * 2 sin2pi, 3 cos2pi, 4 sqrt, 5 div (in[i] / in2[i]), 6 erf. */
 klara_status klara_selftest_math(int32_t device, int32_t op, int64_t n, const double* in,
                                  const double* in2, double* out);
 

@@ -11,7 +11,7 @@ struct KlaraDesc
     nleaps::Int32; slice_stepout::Int32; slice_widths::Ptr{Float64}
     targetrate::Float64; score_k::Float64; period::Int32; verbose::Int32
     da_nadapt::Int64; da_eps0bar::Float64; da_h0bar::Float64; da_gamma::Float64; da_kappa::Float64
-    da_t0::Int32; reserved1::Int32
+    da_t0::Int32; tuner_score::Int32
     nsteps::Int64; burnin::Int64; thinning::Int64
     gauss_w::Ptr{Float64}; gauss_mu::Ptr{Float64}; gauss_const::Float64; gauss_prec::Ptr{Float64}
     logit_X::Ptr{Float64}; logit_y::Ptr{Float64}; logit_ndata::Int32; reserved0::Int32; logit_lambda::Float64

@@ -40,7 +40,7 @@ class KlaraDesc(C.Structure):
         ("nleaps", C.c_int32), ("slice_stepout", C.c_int32), ("slice_widths", _dp),
         ("targetrate", C.c_double), ("score_k", C.c_double), ("period", C.c_int32), ("verbose", C.c_int32),
         ("da_nadapt", C.c_int64), ("da_eps0bar", C.c_double), ("da_h0bar", C.c_double), ("da_gamma", C.c_double),
-        ("da_kappa", C.c_double), ("da_t0", C.c_int32), ("reserved1", C.c_int32),
+        ("da_kappa", C.c_double), ("da_t0", C.c_int32), ("tuner_score", C.c_int32),
         ("nsteps", C.c_int64), ("burnin", C.c_int64), ("thinning", C.c_int64),
         ("gauss_w", _dp), ("gauss_mu", _dp), ("gauss_const", C.c_double), ("gauss_prec", _dp),
         ("logit_X", _dp), ("logit_y", _dp), ("logit_ndata", C.c_int32), ("reserved0", C.c_int32),

@@ -116,12 +116,18 @@ def logistic_rate_score(x, k=7.0):
     return logistic(x, 2.0, k, 0.0, 0.0)
 
 
+def erf_rate_score(x, k=3.0):
+    """AcceptanceRateMCTuner.jl:17."""
+    from math import erf
+    return erf(k * x) + 1.0
+
+
 class AcceptanceRateMCTuner(MCTuner):
     """AcceptanceRateMCTuner(targetrate; score=logistic_rate_score, period=100, verbose=false) — :38-44.
 
     `mode="per_chain"` keeps the reference's one-tune-per-job semantics; `mode="pooled"` shares one step
     per GPU with the acceptance rate pooled over that GPU's chains (BASELINE cfg 5).
-    Only the logistic score runs on device; `score_k` is its steepness (default 7).
+    `score` is logistic_rate_score or erf_rate_score; `score_k` is its steepness (defaults 7 and 3).
     """
     kind = L.TUNER_ACCEPT_RATE
 
@@ -129,8 +135,11 @@ class AcceptanceRateMCTuner(MCTuner):
                  score_k: float = 7.0, mode: str = "per_chain"):
         assert 0 < targetrate < 1, "Target acceptance rate should be between 0 and 1"
         assert period > 0, "Tuning period should be positive"
-        if score is not logistic_rate_score:
-            raise NotImplementedError("only logistic_rate_score is available on device (erf_rate_score: next round)")
+        if score not in (logistic_rate_score, erf_rate_score):
+            raise NotImplementedError("device scores: logistic_rate_score, erf_rate_score")
+        if score is erf_rate_score and score_k == 7.0:
+            score_k = 3.0                       # erf_rate_score's own default steepness (AcceptanceRateMCTuner.jl:17)
+        self.score_kind = 1 if score is erf_rate_score else 0
         assert mode in ("per_chain", "pooled")
         self.targetrate, self.period, self.verbose = float(targetrate), int(period), bool(verbose)
         self.score_k, self.mode = float(score_k), mode
@@ -315,6 +324,7 @@ class BasicMCJob:
                       da_h0bar=self.tuner.h0bar, da_gamma=self.tuner.gamma, da_t0=self.tuner.t0, da_kappa=self.tuner.kappa)
         if isinstance(self.tuner, AcceptanceRateMCTuner):
             kw["targetrate"], kw["score_k"] = self.tuner.targetrate, self.tuner.score_k
+            kw["tuner_score"] = self.tuner.score_kind
             kw["tuner_mode"] = L.TUNE_POOLED if self.tuner.mode == "pooled" else L.TUNE_PER_CHAIN
         self.engine = Engine(**kw)
         # initialize!(pstate, parameter, sampler, outopts): BasicMCJob.jl:73 (finite asserts on device)

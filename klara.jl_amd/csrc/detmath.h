@@ -166,6 +166,40 @@ KD_FN double kd_exp(double x)
     return res;
 }
 
+/* ---------------------------------------------------------------- erf */
+/* erf for the tuner's erf_rate_score (src/tuners/AcceptanceRateMCTuner.jl:17).  Evaluated rarely (once per tuning
+ * period), so a plain, fixed-trip-count formulation is used instead of the msun rational approximations:
+ *   |x| < 3 : erf(x) = 2/sqrt(pi) * exp(-x^2) * sum_{n>=0} x^(2n+1) 2^n / (2n+1)!!      (all terms positive)
+ *   |x| >= 3: erfc(x) = exp(-x^2)/sqrt(pi) * 1/(x + (1/2)/(x + 1/(x + (3/2)/(x + ...))))  (60 levels, bottom-up)
+ *   |x| >= 6: +-1.                       Accuracy: <= 20 ulp against libm (tests/test_oracle_kats.py) — ample for a step-size score. */
+KD_FN double kd_erf(double x)
+{
+    const double two_over_sqrtpi = 1.12837916709551257390e+00, one_over_sqrtpi = 5.64189583547756286948e-01;
+    const double ax = x < 0.0 ? -x : x;
+    double r;
+    /* exp(-x^2) with the rounding error of x*x folded back in: exp(-(x2 + lo)) = exp(-x2) * (1 - lo) */
+    const double x2 = ax * ax;
+    const double x2lo = kd_fma(ax, ax, -x2);
+    double ex = kd_exp(-x2);
+    ex = ex - ex * x2lo;
+    if (ax < 3.0) {
+        double term = ax, sum = ax;
+        for (int n = 0; n < 100; ++n) {
+            term = term * (2.0 * x2) / (double)(2 * n + 3);
+            sum = sum + term;
+        }
+        r = two_over_sqrtpi * ex * sum;
+    } else if (ax < 6.0) {
+        double f = ax;
+        for (int k = 60; k >= 1; --k) f = ax + (0.5 * (double)k) / f;
+        r = 1.0 - ex * one_over_sqrtpi / f;
+    } else {
+        r = 1.0;
+    }
+    if (x != x) return x;
+    return x < 0.0 ? -r : r;
+}
+
 /* ---------------------------------------------------------------- sin/cos(2*pi*u) */
 /* a = 4u in [0,4); q = nearest integer; r = a - q in [-1/2, 1/2] (exact); y = r*pi/2 in [-pi/4, pi/4];
  * msun __kernel_sin/__kernel_cos polynomials on y; quadrant fix-up by q & 3. */

@@ -130,7 +130,7 @@ static klara_status validate(const klara_desc* d)
     if (d->target == KLARA_TARGET_LOGISTIC &&
         (!d->logit_X || !d->logit_y || d->logit_ndata <= 0 || !(d->logit_lambda > 0.0)))
         return KLARA_ERR_INVALID_ARG;
-    if (d->steps_per_launch < 0) return KLARA_ERR_INVALID_ARG;
+    if (d->steps_per_launch < 0 || d->tuner_score < 0 || d->tuner_score > 1) return KLARA_ERR_INVALID_ARG;
     return KLARA_OK;
 }
 
@@ -273,7 +273,7 @@ static KParams make_params(klara_handle* h)
     p.seed = d.seed; p.t0 = 0; p.nsteps = 0;
     p.vecparam = h->vecparam; p.nleaps = d.nleaps; p.stepout = d.slice_stepout;
     p.tuner = d.tuner; p.cnt = cnt_predicate(d); p.targetrate = d.targetrate;
-    p.score_k = d.score_k; p.period = d.period; p.is_mh = d.sampler == KLARA_SAMPLER_MH;
+    p.tuner_score = d.tuner_score; p.score_k = d.score_k; p.period = d.period; p.is_mh = d.sampler == KLARA_SAMPLER_MH;
     p.da_epsbar = h->da_epsbar; p.da_hbar = h->da_hbar; p.da_nadapt = d.da_nadapt; p.da_gamma = d.da_gamma;
     p.da_kappa = d.da_kappa; p.da_t0 = d.da_t0;
     // sampler_state(..., tuner::DualAveragingMCTuner): lambda = nleaps*leapstep, mu = log(10*step) (HMC.jl:124-133,192-213)
@@ -360,7 +360,7 @@ __global__ void k_pooled_tune(KParams p, int k)
         const double rate = (double)acc / (double)(prop * p.nchains);
         if (p.tuner == KLARA_TUNER_ACCEPT_RATE && !p.is_mh) {
             const double xr = rate - p.targetrate;
-            step *= 2.0 / (1.0 + kd_exp(-p.score_k * (xr - 0.0))) + 0.0;
+            step *= rate_score(p, xr);
         }
         tot += prop; acc = 0; prop = 0;
     }
@@ -773,6 +773,7 @@ __global__ void k_math(int op, long long n, const double* in, const double* in2,
     case 2: kd_sincos2pi(in[i], &s, &c); out[i] = s; break;
     case 3: kd_sincos2pi(in[i], &s, &c); out[i] = c; break;
     case 4: out[i] = __builtin_sqrt(in[i]); break;
+    case 6: out[i] = kd_erf(in[i]); break;
     default: out[i] = in[i] / in2[i]; break;
     }
 }

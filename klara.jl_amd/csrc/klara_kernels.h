@@ -45,7 +45,7 @@ struct KParams {
     const double* vecparam;                    // MH sigma[D] / slice widths[D]
     int nleaps; int stepout;
     // tuner
-    int tuner; int cnt; double targetrate; double score_k; int period; int is_mh;
+    int tuner; int cnt; double targetrate; double score_k; int period; int is_mh; int tuner_score;
     // DualAveragingMCTuner (KLARA_TUNER_DUAL_AVERAGING): per-chain eps_bar / h_bar arrays and constants
     double* da_epsbar; double* da_hbar; long long da_nadapt; double da_gamma; double da_kappa; int da_t0;
     double da_mu; double da_lambda;            // mu = log(10*leapstep), lambda = nleaps*leapstep (HMC.jl:124-133,192-213)
@@ -415,6 +415,13 @@ __device__ __forceinline__ void tune_count_proposal(const KParams& p, TuneRegs& 
     tn.phase = (tn.phase + 1 == p.period) ? 0 : tn.phase + 1;
 }
 
+// score functions of AcceptanceRateMCTuner.jl:9,17: logistic(x, 2, k, 0, 0) (stats/logistic.jl:11) or erf(k x) + 1
+__device__ __forceinline__ double rate_score(const KParams& p, double x)
+{
+    if (p.tuner_score == 1) return kd_erf(p.score_k * x) + 1.0;
+    return 2.0 / (1.0 + kd_exp(-p.score_k * (x - 0.0))) + 0.0;
+}
+
 // tuning block: iterate/MALA.jl:130-152, iterate/HMC.jl:203-224, iterate/MH.jl:116-131;
 // rate!/reset_burnin! tuners.jl:27-32; tune! AcceptanceRateMCTuner.jl:46 with logistic_rate_score
 // (AcceptanceRateMCTuner.jl:9, stats/logistic.jl:11).
@@ -425,7 +432,7 @@ __device__ __forceinline__ void tuning_block(const KParams& p, TuneRegs& tn)
         const double rate = (double)tn.accepted / (double)tn.proposed;
         if (p.tuner == KLARA_TUNER_ACCEPT_RATE && !p.is_mh) {
             const double xr = rate - p.targetrate;
-            tn.step *= 2.0 / (1.0 + kd_exp(-p.score_k * (xr - 0.0))) + 0.0;
+            tn.step *= rate_score(p, xr);
         }
         tn.totproposed += tn.proposed;
         tn.accepted = 0; tn.proposed = 0; tn.phase = 0;

@@ -144,7 +144,7 @@ class Engine:
                  mh_sigma=None, driftstep: float = 1.0, leapstep: float = 0.1, nleaps: int = 10,
                  slice_widths=None, slice_stepout: bool = True,
                  tuner: int = L.TUNER_VANILLA, tuner_mode: int = L.TUNE_PER_CHAIN, targetrate: float = 0.0,
-                 score_k: float = 7.0, period: int = 100, verbose: bool = False,
+                 score_k: float = 7.0, tuner_score: int = 0, period: int = 100, verbose: bool = False,
                  da_nadapt: int = 0, da_eps0bar: float = 1.0, da_h0bar: float = 0.0, da_gamma: float = 0.05,
                  da_t0: int = 10, da_kappa: float = 0.75,
                  seed: int = 20260927, chain_offset: int = 0, device: int = 0, monitor: int = 0,
@@ -171,6 +171,7 @@ class Engine:
         d.nsteps, d.burnin, d.thinning = self.nsteps, self.burnin, self.thinning
         d.da_nadapt, d.da_eps0bar, d.da_h0bar = int(da_nadapt), float(da_eps0bar), float(da_h0bar)
         d.da_gamma, d.da_kappa, d.da_t0 = float(da_gamma), float(da_kappa), int(da_t0)
+        d.tuner_score = int(tuner_score)
         if isinstance(target, GaussDiagTarget):
             if target.w is not None:
                 a = _f64(target.w, (self.ndims,)); keep.append(a); d.gauss_w = _ptr(a)

@@ -71,8 +71,8 @@ double ko_logistic(double x, double l, double k, double x0, double y0)
 }
 /* src/tuners/AcceptanceRateMCTuner.jl:9  logistic_rate_score(x, k=7.) = logistic(x, 2., k, 0., 0.) */
 double ko_logistic_rate_score(double x, double k) { return ko_logistic(x, 2.0, k, 0.0, 0.0); }
-/* src/tuners/AcceptanceRateMCTuner.jl:17 erf_rate_score(x, k=3.) = erf(k*x)+1  (libm erf; host-only) */
-double ko_erf_rate_score(double x, double k) { return erf(k * x) + 1.0; }
+/* src/tuners/AcceptanceRateMCTuner.jl:17 erf_rate_score(x, k=3.) = erf(k*x)+1  (detmath kd_erf, <= 4 ulp of libm) */
+double ko_erf_rate_score(double x, double k) { return kd_erf(k * x) + 1.0; }
 
 /* ------------------------------------------------------------------ targets */
 typedef struct ko_target_ctx {
@@ -271,7 +271,8 @@ static void ko_tuning_block(const klara_desc* d, ko_tune* tn, int cnt, int64_t p
     if (tn->totproposed <= d->burnin && (tn->proposed % d->period) == 0) {   /* MALA.jl:131 / HMC.jl:204 */
         tn->rate = (double)tn->accepted / (double)(tn->proposed * pool);      /* rate!                    */
         if (d->tuner == KLARA_TUNER_ACCEPT_RATE && d->sampler != KLARA_SAMPLER_MH)
-            tn->step *= ko_logistic_rate_score(tn->rate - d->targetrate, d->score_k); /* tune!            */
+            tn->step *= d->tuner_score == 1 ? ko_erf_rate_score(tn->rate - d->targetrate, d->score_k)
+                                            : ko_logistic_rate_score(tn->rate - d->targetrate, d->score_k); /* tune! */
         tn->totproposed += tn->proposed;                                      /* reset_burnin!            */
         tn->accepted = 0; tn->proposed = 0; tn->rate = NAN;
     }
@@ -645,6 +646,7 @@ void ko_math(int op, int64_t n, const double* in, const double* in2, double* out
         case 2: kd_sincos2pi(in[i], &s, &c); out[i] = s; break;
         case 3: kd_sincos2pi(in[i], &s, &c); out[i] = c; break;
         case 4: out[i] = sqrt(in[i]); break;
+        case 6: out[i] = kd_erf(in[i]); break;
         default: out[i] = in[i] / in2[i]; break;
         }
     }

@@ -53,6 +53,9 @@ def make_case(name):
     elif name == "mala_d3_tuned":      # AcceptanceRate tuner, per chain, several tuning events
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(3), nchains=50, nsteps=260, burnin=200,
                  driftstep=1.5, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=25)
+    elif name == "mala_d3_tuned_erf":  # erf_rate_score(x, 3) instead of the logistic score
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(3), nchains=50, nsteps=260, burnin=200,
+                 driftstep=1.5, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=25, tuner_score=1, score_k=3.0)
     elif name == "mala_d300":          # E=4 layout
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(300), nchains=9, nsteps=20, burnin=0,
                  driftstep=0.02)
@@ -138,7 +141,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "mala_d300", "hmc_d100", "hmc_d10_tuned_pooled", "hmc_dense_d100", "hmc_dense_d37", "mala_dense_d100",
              "mh_dense_d20", "mala_swiss", "hmc_swiss", "slice_d5", "slice_d100_nostepout", "slice_swiss",
              "hmc_rats", "hmc_rats_pooled", "mala_rats", "slice_rats", "hmc_d10_dualavg", "hmc_dense_d37_dualavg",
-             "hmc_rats_dualavg"]
+             "hmc_rats_dualavg", "mala_d3_tuned_erf"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg"]

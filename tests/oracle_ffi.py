@@ -90,7 +90,7 @@ class OracleJob:
     def __init__(self, *, sampler, target_kind, nchains, ndims, nsteps, burnin=0, thinning=1,
                  mh_sigma=None, driftstep=1.0, leapstep=0.1, nleaps=10, slice_widths=None, slice_stepout=True,
                  tuner=0, tuner_mode=0, targetrate=0.0, score_k=7.0, period=100, verbose=False,
-                 da_nadapt=0, da_eps0bar=1.0, da_h0bar=0.0, da_gamma=0.05, da_t0=10, da_kappa=0.75,
+                 da_nadapt=0, da_eps0bar=1.0, da_h0bar=0.0, da_gamma=0.05, da_t0=10, da_kappa=0.75, tuner_score=0,
                  seed=20260927, chain_offset=0, gauss_w=None, gauss_mu=None, gauss_const=0.0, gauss_prec=None,
                  logit_X=None, logit_y=None, logit_lambda=100.0, hier_Y=None, hier_xc=None, hier_prior_prec=1e-4,
                  hier_gamma_a=1e-3, hier_gamma_b=1e-3, layout=None,
@@ -117,6 +117,7 @@ class OracleJob:
         d.nsteps, d.burnin, d.thinning = int(nsteps), int(burnin), int(thinning)
         d.da_nadapt, d.da_eps0bar, d.da_h0bar = int(da_nadapt), float(da_eps0bar), float(da_h0bar)
         d.da_gamma, d.da_kappa, d.da_t0 = float(da_gamma), float(da_kappa), int(da_t0)
+        d.tuner_score = int(tuner_score)
         d.gauss_w, d.gauss_mu, d.gauss_const = ptr(gauss_w, self.D), ptr(gauss_mu, self.D), float(gauss_const)
         d.gauss_prec = ptr(gauss_prec)
         d.logit_X, d.logit_y = ptr(logit_X), ptr(logit_y)

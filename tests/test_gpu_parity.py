@@ -27,6 +27,7 @@ def test_device_math_bit_exact(klib):
         2: rng.random(n), 3: rng.random(n),
         4: np.concatenate([rng.random(n) * 1e3, np.exp(rng.uniform(-700, 700, n))]),
         5: np.exp(rng.uniform(-300, 300, n)),
+        6: np.concatenate([rng.uniform(-7, 7, n), [0.0, np.inf, -np.inf]]),
     }
     for op, x in sets.items():
         x = np.ascontiguousarray(x)
