@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--chains", type=int, default=NCHAINS_PER_GPU, help="chains per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for logic tests)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="logic test only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -65,12 +68,18 @@ def main():
             raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the transition path has no CPU fallback)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    cdev = "cuda" if args.backend == "nccl" else "cpu"     # where the (tiny) collectives' tensors live
 
     n = args.chains
     total_steps = args.warmup + args.steps
@@ -87,7 +96,7 @@ def main():
 
     eng.run(args.warmup)
     if dist is not None:   # warm the communicator outside the timed region
-        t = torch.zeros(4, device="cuda"); dist.all_reduce(t)
+        t = torch.zeros(4, device=cdev); dist.all_reduce(t)
     barrier()
     t0 = time.perf_counter()
     eng.run(args.steps)
@@ -99,7 +108,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        te = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     kernel_ms, nlaunch = eng.last_run_ms()

@@ -36,6 +36,7 @@ struct klara_handle {
     double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr,
            *hY = nullptr, *hxc = nullptr;
     double* pooled_out = nullptr;   // 2*D doubles + 1 u64 scratch for pooled summaries
+    KParams* d_params = nullptr;    // device copy of the handle's static kernel parameters
     double lpconst = 0.0;
     // run state
     bool have_state = false;
@@ -150,11 +151,13 @@ static void free_all(klara_handle* h)
     hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->da_epsbar); hipFree(h->da_hbar); hipFree(h->pooled_acc); hipFree(h->accept);
     hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->hist); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->err);
     hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
-    hipFree(h->Pfrag); hipFree(h->pooled_out);
+    hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->d_params);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
 }
+
+static KParams make_params(klara_handle* h);
 
 extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
 {
@@ -241,6 +244,11 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     // the descriptor's host pointers are not retained
     h->d.mh_sigma = nullptr; h->d.slice_widths = nullptr; h->d.gauss_w = nullptr; h->d.gauss_mu = nullptr;
     h->d.gauss_prec = nullptr; h->d.logit_X = nullptr; h->d.logit_y = nullptr; h->d.hier_Y = nullptr; h->d.hier_xc = nullptr; h->d.stream = nullptr;
+    {   // static kernel parameters live in device memory (read with scalar loads at the point of use)
+        const KParams hp = make_params(h);
+        CKH(dalloc(&h->d_params, 1));
+        CKH(hipMemcpy(h->d_params, &hp, sizeof(KParams), hipMemcpyHostToDevice));
+    }
 #undef CK
 #undef CKH
     *out = h;
@@ -265,12 +273,12 @@ static KParams make_params(klara_handle* h)
     p.X = h->X; p.GR = h->GR; p.LT = h->LT;
     p.tune_step = h->tune_step; p.tune_accepted = h->tune_acc; p.tune_proposed = h->tune_prop;
     p.tune_totproposed = h->tune_tot; p.pooled_accepted = h->pooled_acc;
-    p.accept = nullptr; p.naccept = h->naccept; p.sum = h->sum; p.sumsq = h->sumsq;
+    p.accept = h->accept; p.naccept = h->naccept; p.sum = h->sum; p.sumsq = h->sumsq;
     p.hist = h->hist; p.hist_cols = h->hist_cols; p.error_flag = h->err;
     p.hist_lt = h->hist_lt; p.hist_g = h->hist_g;
     p.nchains = d.nchains; p.chain_offset = d.chain_offset; p.D = d.ndims; p.G = h->G;
     p.pooled = d.tuner_mode == KLARA_TUNE_POOLED;
-    p.seed = d.seed; p.t0 = 0; p.nsteps = 0;
+    p.seed = d.seed;
     p.vecparam = h->vecparam; p.nleaps = d.nleaps; p.stepout = d.slice_stepout;
     p.tuner = d.tuner; p.cnt = cnt_predicate(d); p.targetrate = d.targetrate;
     p.tuner_score = d.tuner_score; p.score_k = d.score_k; p.period = d.period; p.is_mh = d.sampler == KLARA_SAMPLER_MH;
@@ -304,8 +312,8 @@ static dim3 grid_for_transitions(const klara_handle* h)
     const long long cpw = 64 / h->G;
     const long long groups = (h->d.nchains + cpw - 1) / cpw;
     long long gpw = 4;
-    if (const char* s = getenv("KLARA_GROUPS_PER_WAVE")) { const long long v = atoll(s); if (v >= 1 && v <= 64) gpw = v; }
     while (gpw > 1 && groups / gpw < 8192) gpw >>= 1;
+    if (const char* s = getenv("KLARA_GROUPS_PER_WAVE")) { const long long v = atoll(s); if (v >= 1 && v <= 1024) gpw = v; }
     const long long waves = (groups + gpw - 1) / gpw;
     return dim3((unsigned)((waves + 3) / 4));
 }
@@ -448,15 +456,16 @@ extern "C" klara_status klara_reset(klara_handle* h, const double* x_host)
     return init_common(h);
 }
 
-static hipError_t launch_steps(klara_handle* h, const KParams& p)
+static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
 {
     const klara_desc& d = h->d;
-    if (h->kind == 1) return klara_launch_dense(p, d.sampler, h->E, h->Pfrag, grid_for(h), h->stream);
+    const KParams* p = h->d_params;
+    if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, h->E, h->Pfrag, grid_for(h), h->stream);
     switch (d.sampler) {
-    case KLARA_SAMPLER_MH: return klara_launch_mh(p, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
-    case KLARA_SAMPLER_MALA: return klara_launch_mala(p, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
-    case KLARA_SAMPLER_HMC: return klara_launch_hmc(p, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
-    default: return klara_launch_slice(p, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
+    case KLARA_SAMPLER_MH: return klara_launch_mh(p, kl, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
+    case KLARA_SAMPLER_MALA: return klara_launch_mala(p, kl, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
+    case KLARA_SAMPLER_HMC: return klara_launch_hmc(p, kl, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
+    default: return klara_launch_slice(p, kl, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
     }
 }
 
@@ -479,15 +488,15 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
             const long long to_boundary = d.period - (h->m_prop % d.period);
             if (k > to_boundary) k = to_boundary;
         }
-        p.t0 = (unsigned long long)h->steps_done;
-        p.nsteps = (int)k;
+        KLaunch kl;
+        kl.t0 = (unsigned long long)h->steps_done;
+        kl.nsteps = (int)k;
         // save rule bookkeeping (BasicMCRange.jl:36 postrange = (burnin+1):thinning:nsteps), done on the host so
         // the kernels carry no 64-bit division: phase of the first post-burn-in step of this launch and the
         // number of columns already saved
-        p.save_phase0 = h->steps_done >= d.burnin ? (int)((h->steps_done - d.burnin) % d.thinning) : 0;
-        p.save_col0 = h->steps_done > d.burnin ? (h->steps_done - d.burnin - 1) / d.thinning + 1 : 0;
-        p.accept = h->accept ? h->accept + (size_t)h->steps_done * (size_t)d.nchains : nullptr;
-        HIPCHK(launch_steps(h, p));
+        kl.save_phase0 = h->steps_done >= d.burnin ? (int)((h->steps_done - d.burnin) % d.thinning) : 0;
+        kl.save_col0 = h->steps_done > d.burnin ? (h->steps_done - d.burnin - 1) / d.thinning + 1 : 0;
+        HIPCHK(launch_steps(h, kl));
         if (pooled && cnt) {
             hipLaunchKernelGGL(k_pooled_tune, dim3(1), dim3(64), 0, h->stream, p, (int)k);
             HIPCHK(hipGetLastError());

@@ -139,8 +139,11 @@ __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int 
 }
 
 template <int SAMPLER, int NE, bool DA>
-__global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, const double* __restrict__ Pfrag)
+__global__ __launch_bounds__(512)
+void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
 {
+    const KParams& p = *pp;
+    uint8_t* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = (NE + 3) / 4;
     constexpr int NG = 4 * MT;
@@ -155,14 +158,14 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
     TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0, 0.0, 0.0 };
     if (da) { tn.epsbar = p.da_epsbar[tix]; tn.hbar = p.da_hbar[tix]; }
     tn.phase = p.cnt ? (int)(tn.proposed % p.period) : 0;
-    int sphase = p.save_phase0;
-    long long scol = p.save_col0;
+    int sphase = kl.save_phase0;
+    long long scol = kl.save_col0;
     double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
     unsigned long long nacc = 0;
     const bool do_sum = p.sum != nullptr;
 
-    for (int s = 0; s < p.nsteps; ++s) {
-        const unsigned long long t = p.t0 + (unsigned long long)s;
+    for (int s = 0; s < kl.nsteps; ++s) {
+        const unsigned long long t = kl.t0 + (unsigned long long)s;
         if (p.cnt) tune_count_proposal(p, tn);
         bool acc = false;
         double xp[NE], gp[NG];
@@ -308,8 +311,8 @@ __global__ __launch_bounds__(512) void k_dense_transitions(const KParams p, cons
         }
         nacc += acc ? 1ull : 0ull;
         if (p.cnt && acc) tn.accepted += 1;
-        if (p.accept != nullptr && cx.chain_ok && cx.q == 0)
-            p.accept[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
+        if (accept_out != nullptr && cx.chain_ok && cx.q == 0)
+            accept_out[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
         if (!p.pooled && !da) tuning_block(p, tn);
         else if (da && p.cnt && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {
             tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;

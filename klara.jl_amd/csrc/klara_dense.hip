@@ -3,7 +3,7 @@
 #include "klara_dense.h"
 
 template <int SAMPLER, bool DA>
-static hipError_t launch_dense_s(const KParams& p, int NE, const double* Pfrag, dim3 grid, hipStream_t st)
+static hipError_t launch_dense_s(const KParams* p, const KLaunch& kl, int NE, const double* Pfrag, dim3 grid, hipStream_t st)
 {
     const dim3 blk(512);
 #define KLARA_DENSE_CASE(N)                                                                            \
@@ -12,7 +12,7 @@ static hipError_t launch_dense_s(const KParams& p, int NE, const double* Pfrag, 
         hipError_t e = hipFuncSetAttribute((const void*)k_dense_transitions<SAMPLER, N, DA>,               \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return e;                                                                 \
-        hipLaunchKernelGGL((k_dense_transitions<SAMPLER, N, DA>), grid, blk, lds, st, p, Pfrag);           \
+        hipLaunchKernelGGL((k_dense_transitions<SAMPLER, N, DA>), grid, blk, lds, st, p, kl, Pfrag);       \
         break;                                                                                         \
     }
     switch (NE) {
@@ -26,15 +26,15 @@ static hipError_t launch_dense_s(const KParams& p, int NE, const double* Pfrag, 
     return hipGetLastError();
 }
 
-hipError_t klara_launch_dense(const KParams& p, int sampler, int NE, const double* Pfrag, dim3 grid,
-                              hipStream_t st)
+hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, int NE, const double* Pfrag,
+                              dim3 grid, hipStream_t st)
 {
     switch (sampler) {
-    case KLARA_SAMPLER_MH: return launch_dense_s<KLARA_SAMPLER_MH, false>(p, NE, Pfrag, grid, st);
-    case KLARA_SAMPLER_MALA: return launch_dense_s<KLARA_SAMPLER_MALA, false>(p, NE, Pfrag, grid, st);
+    case KLARA_SAMPLER_MH: return launch_dense_s<KLARA_SAMPLER_MH, false>(p, kl, NE, Pfrag, grid, st);
+    case KLARA_SAMPLER_MALA: return launch_dense_s<KLARA_SAMPLER_MALA, false>(p, kl, NE, Pfrag, grid, st);
     case KLARA_SAMPLER_HMC:
-        if (p.tuner == KLARA_TUNER_DUAL_AVERAGING) return launch_dense_s<KLARA_SAMPLER_HMC, true>(p, NE, Pfrag, grid, st);
-        return launch_dense_s<KLARA_SAMPLER_HMC, false>(p, NE, Pfrag, grid, st);
+        if (tuner == KLARA_TUNER_DUAL_AVERAGING) return launch_dense_s<KLARA_SAMPLER_HMC, true>(p, kl, NE, Pfrag, grid, st);
+        return launch_dense_s<KLARA_SAMPLER_HMC, false>(p, kl, NE, Pfrag, grid, st);
     default: return hipErrorInvalidValue;
     }
 }

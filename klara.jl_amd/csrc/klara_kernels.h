@@ -40,7 +40,7 @@ struct KParams {
     int* error_flag;                           // set to klara_status on device-detected errors
     long long nchains; long long chain_offset;
     int D; int G; int pooled;
-    unsigned long long seed; unsigned long long t0; int nsteps;
+    unsigned long long seed;
     // sampler
     const double* vecparam;                    // MH sigma[D] / slice widths[D]
     int nleaps; int stepout;
@@ -51,12 +51,20 @@ struct KParams {
     double da_mu; double da_lambda;            // mu = log(10*leapstep), lambda = nleaps*leapstep (HMC.jl:124-133,192-213)
     double step0;                              // initial step (samplers.jl:29-45); the step of every chain when nothing is tuned
     long long burnin; long long thinning; long long nsteps_total;
-    int save_phase0; long long save_col0;      // host-computed: (i1-burnin-1) % thinning of the first post-burn-in step of
-                                               // this launch, and the number of columns saved before it (no device division)
     // targets
     const double* gw; const double* gmu; double gconst;      // diag (gw/gmu may be null)
     const double* lX; const double* ly; int ndata; double lambda; double lpconst;   // logistic
     const double* hY; const double* hxc; int hR; int hT; double hp0; double ha0; double hb0;   // hierarchical normal
+};
+
+// Per-launch values, passed by value.  Everything else (KParams) is static for a handle and lives in device memory:
+// the kernels read it through a `const KParams* __restrict__` with scalar loads at the point of use, which keeps
+// the ~100 dwords of configuration out of the SGPR file (passed by value they were spilled to VGPR lanes:
+// 600+ v_readlane/v_writelane in the transition kernel).
+struct KLaunch {
+    unsigned long long t0;                     // global index of the first transition of this launch
+    int nsteps;                                // transitions in this launch
+    int save_phase0; long long save_col0;      // save-rule bookkeeping computed on the host (no device division)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -733,8 +741,11 @@ __device__ __forceinline__ void set_chain(const KParams& p, LaneCtx<E>& c, long 
 // the loaded registers are first touched, so HBM latency overlaps the RNG/ALU work instead of
 // serialising with it (one-launch-per-transition mode is otherwise latency-bound at 3 waves/SIMD).
 template <int SAMPLER, int TARGET, int E, int GT>
-__global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1))) void k_transitions(const KParams p)
+__global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1)))
+void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 {
+    const KParams& p = *pp;
+    uint8_t* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = typename TargetSel<TARGET, E>::type;
     constexpr bool NEEDG = (SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_HMC);
@@ -773,7 +784,7 @@ __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1))) 
         double sm[E], sq[E];
         if (do_sum) { load_vec<E>(cx, p.sum, p.D, sm); load_vec<E>(cx, p.sumsq, p.D, sq); }
         double z[E];
-        if (NEEDZ) lane_normals<E>(cx, p.seed, gchain, p.t0, z);        // before the loaded state is touched
+        if (NEEDZ) lane_normals<E>(cx, p.seed, gchain, kl.t0, z);        // before the loaded state is touched
 
         TuneRegs tn;
         if (per_chain_tune) tn = { cur.step, cur.accepted, cur.proposed, cur.totproposed, 0, 0.0, 0.0 };
@@ -782,13 +793,13 @@ __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1))) 
         if (da) { tn.epsbar = cur.epsbar; tn.hbar = cur.hbar; }
         const long long acc0 = tn.accepted;
         tn.phase = per_chain_tune ? (int)(tn.proposed % p.period) : 0;
-        int sphase = p.save_phase0;
-        long long scol = p.save_col0;
+        int sphase = kl.save_phase0;
+        long long scol = kl.save_col0;
         unsigned long long nacc = 0;
         bool stuck = false;
 
-        for (int s = 0; s < p.nsteps; ++s) {
-            const unsigned long long t = p.t0 + (unsigned long long)s;
+        for (int s = 0; s < kl.nsteps; ++s) {
+            const unsigned long long t = kl.t0 + (unsigned long long)s;
             if (p.cnt) tune_count_proposal(p, tn);
             bool acc;
             if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E>(p, tg, cx, gchain, t, z, vp, cur.x, cur.lt);
@@ -802,8 +813,8 @@ __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1))) 
             else acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, cur.x, cur.lt, stuck);
             nacc += acc ? 1ull : 0ull;
             if (p.cnt && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;   // the slice sampler never counts accepts
-            if (p.accept != nullptr && cx.chain_ok && cx.q == 0)
-                p.accept[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
+            if (accept_out != nullptr && cx.chain_ok && cx.q == 0)
+                accept_out[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
             if (per_chain_tune && !da) tuning_block(p, tn);
             else if (per_chain_tune && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {   // verbose report block, iterate/HMC.jl:229-243
                 tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
@@ -832,10 +843,10 @@ __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1))) 
                 }
                 sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
             }
-            if (NEEDZ && s + 1 < p.nsteps) lane_normals<E>(cx, p.seed, gchain, t + 1, z);
+            if (NEEDZ && s + 1 < kl.nsteps) lane_normals<E>(cx, p.seed, gchain, t + 1, z);
         }
 
-        if (nacc != 0 || SAMPLER == KLARA_SAMPLER_SLICE || p.nsteps > 1) {
+        if (nacc != 0 || SAMPLER == KLARA_SAMPLER_SLICE || kl.nsteps > 1) {
             // (with one transition per launch a rejected proposal leaves x, g untouched: skip the write-back)
             store_vec<E>(cx, p.X, p.D, cur.x);
             if (NEEDG) store_vec<E>(cx, p.GR, p.D, cur.g);

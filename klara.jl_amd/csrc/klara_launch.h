@@ -3,13 +3,13 @@
 #include "klara_kernels.h"
 
 // group-layout transition kernels; target in {GAUSS_DIAG, LOGISTIC}; E in {2,4,8}; G = lanes per chain
-hipError_t klara_launch_mh(const KParams& p, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
-hipError_t klara_launch_mala(const KParams& p, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
-hipError_t klara_launch_hmc(const KParams& p, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
-hipError_t klara_launch_slice(const KParams& p, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
+hipError_t klara_launch_mh(const KParams* p, const KLaunch& kl, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
+hipError_t klara_launch_mala(const KParams* p, const KLaunch& kl, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
+hipError_t klara_launch_hmc(const KParams* p, const KLaunch& kl, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
+hipError_t klara_launch_slice(const KParams* p, const KLaunch& kl, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
 // dense (MFMA) kernels; NE in {8,16,25,32}
-hipError_t klara_launch_dense(const KParams& p, int sampler, int NE, const double* Pfrag, dim3 grid,
-                              hipStream_t st);
+hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, int NE, const double* Pfrag,
+                              dim3 grid, hipStream_t st);
 hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag, int needgrad, dim3 grid,
                                    hipStream_t st);
 hipError_t klara_launch_mfma_probe(const double* A, const double* B, const double* C, double* D,
@@ -20,19 +20,19 @@ hipError_t klara_launch_mfma_probe(const double* A, const double* B, const doubl
     do {                                                                                               \
         const dim3 blk(256);                                                                           \
         if (target == KLARA_TARGET_GAUSS_DIAG) {                                                       \
-            if (E == 2 && G == 64) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 2, 64>), grid, blk, lds, st, p); \
-            else if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 2, 0>), grid, blk, lds, st, p);       \
-            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 4, 0>), grid, blk, lds, st, p);       \
-            else if (E == 8) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 8, 0>), grid, blk, lds, st, p);       \
+            if (E == 2 && G == 64) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 2, 64>), grid, blk, lds, st, p, kl); \
+            else if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 2, 0>), grid, blk, lds, st, p, kl);       \
+            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 4, 0>), grid, blk, lds, st, p, kl);       \
+            else if (E == 8) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 8, 0>), grid, blk, lds, st, p, kl);       \
             else return hipErrorInvalidValue;                                                          \
         } else if (target == KLARA_TARGET_LOGISTIC) {                                                  \
-            if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 2, 0>), grid, blk, lds, st, p);              \
-            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 4, 0>), grid, blk, lds, st, p);         \
-            else if (E == 8) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 8, 0>), grid, blk, lds, st, p);         \
+            if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 2, 0>), grid, blk, lds, st, p, kl);              \
+            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 4, 0>), grid, blk, lds, st, p, kl);         \
+            else if (E == 8) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 8, 0>), grid, blk, lds, st, p, kl);         \
             else return hipErrorInvalidValue;                                                          \
         } else if (target == KLARA_TARGET_HIER_NORMAL) {                                               \
-            if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_HIER_NORMAL, 2, 0>), grid, blk, lds, st, p);           \
-            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_HIER_NORMAL, 4, 0>), grid, blk, lds, st, p);      \
+            if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_HIER_NORMAL, 2, 0>), grid, blk, lds, st, p, kl);           \
+            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_HIER_NORMAL, 4, 0>), grid, blk, lds, st, p, kl);      \
             else return hipErrorInvalidValue;                                                          \
         } else return hipErrorInvalidValue;                                                            \
         return hipGetLastError();                                                                      \

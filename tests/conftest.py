@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Make sure the in-tree shared objects are current (a no-op `make` when they are): libklara_hip.so
+    (hipcc, gfx950 — cross-compiles without a GPU) and the CPU oracle (gcc)."""
+    import shutil
+    import subprocess
+    if shutil.which("make") is None:
+        return
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.run(["make", "-C", str(ROOT / "klara.jl_amd" / "csrc"), "-j8"], capture_output=True)
+    subprocess.run(["make", "-C", str(ROOT / "oracle")], capture_output=True)
+
+
 def _gpu_available() -> bool:
     try:
         import torch
