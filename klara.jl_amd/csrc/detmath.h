@@ -238,15 +238,23 @@ KD_FN void kd_sincos2pi(double u, double* sn, double* cs)
 /* One Philox block (4 x 32 bit) -> two independent N(0,1):
  *   u1 = u52(x, y), u2 = u52(z, w); rad = sqrt(-2 log u1); z0 = rad cos(2 pi u2); z1 = rad sin(2 pi u2).
  * Element i of a D-vector uses block (i >> 1) of its transition and takes z0 if i is even, z1 if odd. */
-KD_FN void kd_normal_pair(kd_u32x4 b, double* z0, double* z1)
+KD_FN void kd_normal_pair_ex(kd_u32x4 b, double* z0, double* z1, double* u1_out, double* logu1_out)
 {
     const double u1 = kd_u52(b.x, b.y);
     const double u2 = kd_u52(b.z, b.w);
-    const double rad = __builtin_sqrt(-2.0 * kd_log(u1));
+    const double lg = kd_log(u1);
+    const double rad = __builtin_sqrt(-2.0 * lg);
     double sn, cs;
     kd_sincos2pi(u2, &sn, &cs);
     *z0 = rad * cs;
     *z1 = rad * sn;
+    *u1_out = u1;            /* = kd_uniform_xy(b): the same words feed the accept uniform of slot ceil(D/2) */
+    *logu1_out = lg;
+}
+KD_FN void kd_normal_pair(kd_u32x4 b, double* z0, double* z1)
+{
+    double u1, lg;
+    kd_normal_pair_ex(b, z0, z1, &u1, &lg);
 }
 
 /* uniform for accept tests / slice sampler: words (x,y) of a block (or (z,w) for the second) */

@@ -288,6 +288,7 @@ static KParams make_params(klara_handle* h)
     p.da_lambda = (double)d.nleaps * d.leapstep; p.da_mu = kd_log(10.0 * d.leapstep);
     p.step0 = d.sampler == KLARA_SAMPLER_MH ? 1.0 : d.sampler == KLARA_SAMPLER_MALA ? d.driftstep
             : d.sampler == KLARA_SAMPLER_HMC ? d.leapstep : (double)NAN;
+    p.sqrt_step0 = std::sqrt(p.step0); p.inv_step0 = 1.0 / p.step0;
     p.burnin = d.burnin; p.thinning = d.thinning; p.nsteps_total = d.nsteps;
     p.gw = h->gw; p.gmu = h->gmu; p.gconst = d.gauss_const;
     p.lX = h->lX; p.ly = h->ly; p.ndata = d.logit_ndata; p.lambda = d.logit_lambda; p.lpconst = h->lpconst;

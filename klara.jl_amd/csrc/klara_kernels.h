@@ -49,6 +49,7 @@ struct KParams {
     // DualAveragingMCTuner (KLARA_TUNER_DUAL_AVERAGING): per-chain eps_bar / h_bar arrays and constants
     double* da_epsbar; double* da_hbar; long long da_nadapt; double da_gamma; double da_kappa; int da_t0;
     double da_mu; double da_lambda;            // mu = log(10*leapstep), lambda = nleaps*leapstep (HMC.jl:124-133,192-213)
+    double sqrt_step0, inv_step0;              // sqrt(step0), 1/step0 (MALA with an untuned step)
     double step0;                              // initial step (samplers.jl:29-45); the step of every chain when nothing is tuned
     long long burnin; long long thinning; long long nsteps_total;
     // targets
@@ -188,17 +189,24 @@ __device__ __forceinline__ void load_param(const LaneCtx<E>& c, const double* ba
 
 // proposal normals of this lane's E elements for transition t: element i <- block slot i>>1,
 // cos branch for even i, sin branch for odd i (E is even, i0 is even).
+// The accept uniform of a transition is words (x,y) of block slot S = ceil(D/2), the first block past the proposal
+// normals.  Whenever the layout has padding (G*E > D, e.g. D = 100 on 32 lanes x 4) some lane evaluates that very
+// block as one of its (unused) normal pairs, and Box-Muller has already formed u = u52(x,y) and log(u) for it: the
+// accept test then costs one ds_bpermute instead of a Philox block plus a log.  Same words, same kd_log -> same bits.
+struct AccDraw { double u, logu; };
+
 template <int E>
 __device__ __forceinline__ void lane_normals(const LaneCtx<E>& c, unsigned long long seed,
                                              unsigned long long gchain, unsigned long long t,
-                                             double (&z)[E])
+                                             double (&z)[E], AccDraw& ad, int acc_slot)
 {
     static_assert(E % 2 == 0, "E must be even");
 #pragma unroll
     for (int j = 0; j < E / 2; ++j) {
         const kd_u32x4 b = kd_stream_block(seed, gchain, t, (uint32_t)((c.i0 >> 1) + j));
-        double z0, z1;
-        kd_normal_pair(b, &z0, &z1);
+        double z0, z1, u1, lg1;
+        kd_normal_pair_ex(b, &z0, &z1, &u1, &lg1);
+        if ((c.i0 >> 1) + j == acc_slot) { ad.u = u1; ad.logu = lg1; }
         // padding elements (index >= D, or lanes of a group past the last chain) get z = 0.  With x = g = 0
         // loaded there too, every per-element term downstream (proposal, gradient, kinetic/Metropolis sums)
         // is exactly +-0, so the reductions need no per-term masking: x + 0 keeps the oracle's bits.
@@ -472,11 +480,29 @@ __device__ __forceinline__ void da_update(const KParams& p, TuneRegs& tn, long l
 // ------------------------------------------------------------------------------------------------
 // transitions.  Each returns the accept flag (uniform across the group) and updates x, g, lt.
 // ------------------------------------------------------------------------------------------------
+// accept iff ratio > 0 || ratio > log(rand())  (iterate/MH.jl:97, iterate/MALA.jl:94); `acc` holds ratio > 0.
+template <int E>
+__device__ __forceinline__ bool accept_log_test(const KParams& p, const LaneCtx<E>& cx, unsigned long long gchain,
+                                                unsigned long long t, const AccDraw& ad, bool acc, double ratio)
+{
+    const int acc_owner = ((p.D + 1) >> 1) / (E / 2);          // lane (within the group) whose normals used slot ceil(D/2)
+    if (acc_owner < cx.G) {                                    // free: log(u) was formed by that lane's Box-Muller
+        const double logu = cx.G > 1 ? lane_bcast(ad.logu, (cx.lane - cx.q) + acc_owner) : ad.logu;
+        return acc || ratio > logu;
+    }
+    if (!acc && ratio > KD_LOG_UMIN_GUARD) {   // below the guard no uniform of the stream can accept
+        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+        acc = ratio > kd_log(u);
+    }
+    return acc;
+}
+
 // iterate!(job, MH, Multivariate) — iterate/MH.jl:72-124 (symmetric normalised branch)
 template <class T, int E>
 __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const LaneCtx<E>& cx,
                                         unsigned long long gchain, unsigned long long t,
-                                        const double (&z)[E], const double (&sigma)[E], double (&x)[E], double& lt)
+                                        const double (&z)[E], const AccDraw& ad, const double (&sigma)[E],
+                                        double (&x)[E], double& lt)
 {
     double xp[E], gd[E], red[1];
 #pragma unroll
@@ -486,10 +512,7 @@ __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const Lan
     const double ltp = tg.finalize(red[0]);
     const double ratio = ltp - lt;                                                    // :83
     bool acc = ratio > 0.0;                                                           // :97
-    if (!acc && ratio > KD_LOG_UMIN_GUARD) {   // below the guard no uniform of the stream can accept
-        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
-        acc = ratio > kd_log(u);
-    }
+    acc = accept_log_test<E>(p, cx, gchain, t, ad, acc, ratio);
     if (acc) {                                                                        // :98-100
 #pragma unroll
         for (int e = 0; e < E; ++e) x[e] = xp[e];
@@ -502,14 +525,15 @@ __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const Lan
 template <class T, int E>
 __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const LaneCtx<E>& cx,
                                           unsigned long long gchain, unsigned long long t,
-                                          const double (&z)[E], double h,
+                                          const double (&z)[E], const AccDraw& ad, double h,
                                           double (&x)[E], double (&g)[E], double& lt)
 {
     double mu[E], xp[E], gp[E], red[3];
-    const double halfh = 0.5 * h, sq = __builtin_sqrt(h);
+    // sqrt(step) and 1/step come precomputed from the host while nothing tunes the step (same IEEE results)
+    const double halfh = 0.5 * h, sq = p.cnt ? __builtin_sqrt(h) : p.sqrt_step0;
     // abs2(.)/step of MALA.jl:90,92 is evaluated as abs2(.) * (1/step): one f64 division per transition instead
     // of 2 per element (a division is ~70 issue cycles per wave on gfx950); the oracle does the same.
-    const double inv_h = 1.0 / h;
+    const double inv_h = p.cnt ? 1.0 / h : p.inv_step0;
 #pragma unroll
     for (int e = 0; e < E; ++e) mu[e] = x[e] + halfh * g[e];                          // :83
 #pragma unroll
@@ -531,10 +555,7 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
     ratio += red[1];                                                                  // :90
     ratio -= red[2];                                                                  // :92
     bool acc = ratio > 0.0;                                                           // :94
-    if (!acc && ratio > KD_LOG_UMIN_GUARD) {   // below the guard no uniform of the stream can accept
-        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
-        acc = ratio > kd_log(u);
-    }
+    acc = accept_log_test<E>(p, cx, gchain, t, ad, acc, ratio);
     if (acc) {                                                                        // :95-105
 #pragma unroll
         for (int e = 0; e < E; ++e) { x[e] = xp[e]; g[e] = gp[e]; }
@@ -548,7 +569,7 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
 template <class T, int E>
 __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const LaneCtx<E>& cx,
                                          unsigned long long gchain, unsigned long long t,
-                                         const double (&z)[E], double eps, int nleaps, double& a_out,
+                                         const double (&z)[E], const AccDraw& ad, double eps, int nleaps, double& a_out,
                                          double (&x)[E], double (&g)[E], double& lt)
 {
     double mom[E], xp[E], gp[E], red[2], dummy;
@@ -607,7 +628,10 @@ __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const La
     const double ex = kd_exp(ratio);
     const double a = 1.0 < ex ? 1.0 : ex;                                             // :163
     a_out = a;
-    const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+    const int acc_owner = ((p.D + 1) >> 1) / (E / 2);
+    const double u = (acc_owner < cx.G)
+        ? (cx.G > 1 ? lane_bcast(ad.u, (cx.lane - cx.q) + acc_owner) : ad.u)
+        : kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
     const bool acc = u < a;                                                           // :165
     if (acc) {                                                                        // :166-176
 #pragma unroll
@@ -784,7 +808,9 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
         double sm[E], sq[E];
         if (do_sum) { load_vec<E>(cx, p.sum, p.D, sm); load_vec<E>(cx, p.sumsq, p.D, sq); }
         double z[E];
-        if (NEEDZ) lane_normals<E>(cx, p.seed, gchain, kl.t0, z);        // before the loaded state is touched
+        AccDraw ad = { 0.5, 0.0 };
+        const int acc_slot = (p.D + 1) >> 1;
+        if (NEEDZ) lane_normals<E>(cx, p.seed, gchain, kl.t0, z, ad, acc_slot);   // before the loaded state is touched
 
         TuneRegs tn;
         if (per_chain_tune) tn = { cur.step, cur.accepted, cur.proposed, cur.totproposed, 0, 0.0, 0.0 };
@@ -802,11 +828,11 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             const unsigned long long t = kl.t0 + (unsigned long long)s;
             if (p.cnt) tune_count_proposal(p, tn);
             bool acc;
-            if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E>(p, tg, cx, gchain, t, z, vp, cur.x, cur.lt);
-            else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E>(p, tg, cx, gchain, t, z, tn.step, cur.x, cur.g, cur.lt);
+            if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E>(p, tg, cx, gchain, t, z, ad, vp, cur.x, cur.lt);
+            else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E>(p, tg, cx, gchain, t, z, ad, tn.step, cur.x, cur.g, cur.lt);
             else if (SAMPLER == KLARA_SAMPLER_HMC) {
                 double a_prob = 0.0;
-                acc = step_hmc<T, E>(p, tg, cx, gchain, t, z, tn.step, da ? da_nleaps(p, tn.step) : p.nleaps, a_prob,
+                acc = step_hmc<T, E>(p, tg, cx, gchain, t, z, ad, tn.step, da ? da_nleaps(p, tn.step) : p.nleaps, a_prob,
                                      cur.x, cur.g, cur.lt);
                 if (da) da_update(p, tn, (long long)t + 1, a_prob);                   // iterate/HMC.jl:225-249
             }
@@ -843,7 +869,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
                 }
                 sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
             }
-            if (NEEDZ && s + 1 < kl.nsteps) lane_normals<E>(cx, p.seed, gchain, t + 1, z);
+            if (NEEDZ && s + 1 < kl.nsteps) lane_normals<E>(cx, p.seed, gchain, t + 1, z, ad, acc_slot);
         }
 
         if (nacc != 0 || SAMPLER == KLARA_SAMPLER_SLICE || kl.nsteps > 1) {
@@ -901,7 +927,8 @@ __global__ __launch_bounds__(256) void k_init_normal(const KParams p)
 {
     const LaneCtx<E> cx = make_ctx<E, GT>(p);
     double z[E];
-    lane_normals<E>(cx, p.seed, (unsigned long long)(p.chain_offset + cx.chain), KLARA_INIT_TRANSITION, z);
+    AccDraw ad;
+    lane_normals<E>(cx, p.seed, (unsigned long long)(p.chain_offset + cx.chain), KLARA_INIT_TRANSITION, z, ad, -1);
     store_vec<E>(cx, p.X, p.D, z);
 }
 
