@@ -270,19 +270,19 @@ static KParams make_params(klara_handle* h)
     KParams p;
     memset(&p, 0, sizeof(p));
     const klara_desc& d = h->d;
-    p.X = h->X; p.GR = h->GR; p.LT = h->LT;
-    p.tune_step = h->tune_step; p.tune_accepted = h->tune_acc; p.tune_proposed = h->tune_prop;
-    p.tune_totproposed = h->tune_tot; p.pooled_accepted = h->pooled_acc;
-    p.accept = h->accept; p.naccept = h->naccept; p.sum = h->sum; p.sumsq = h->sumsq;
-    p.hist = h->hist; p.hist_cols = h->hist_cols; p.error_flag = h->err;
-    p.hist_lt = h->hist_lt; p.hist_g = h->hist_g;
+    p.X = (decltype(p.X))h->X; p.GR = (decltype(p.GR))h->GR; p.LT = (decltype(p.LT))h->LT;
+    p.tune_step = (decltype(p.tune_step))h->tune_step; p.tune_accepted = (decltype(p.tune_accepted))h->tune_acc; p.tune_proposed = (decltype(p.tune_proposed))h->tune_prop;
+    p.tune_totproposed = (decltype(p.tune_totproposed))h->tune_tot; p.pooled_accepted = (decltype(p.pooled_accepted))h->pooled_acc;
+    p.accept = (decltype(p.accept))h->accept; p.naccept = (decltype(p.naccept))h->naccept; p.sum = (decltype(p.sum))h->sum; p.sumsq = (decltype(p.sumsq))h->sumsq;
+    p.hist = (decltype(p.hist))h->hist; p.hist_cols = h->hist_cols; p.error_flag = (decltype(p.error_flag))h->err;
+    p.hist_lt = (decltype(p.hist_lt))h->hist_lt; p.hist_g = (decltype(p.hist_g))h->hist_g;
     p.nchains = d.nchains; p.chain_offset = d.chain_offset; p.D = d.ndims; p.G = h->G;
     p.pooled = d.tuner_mode == KLARA_TUNE_POOLED;
     p.seed = d.seed;
-    p.vecparam = h->vecparam; p.nleaps = d.nleaps; p.stepout = d.slice_stepout;
+    p.vecparam = (decltype(p.vecparam))h->vecparam; p.nleaps = d.nleaps; p.stepout = d.slice_stepout;
     p.tuner = d.tuner; p.cnt = cnt_predicate(d); p.targetrate = d.targetrate;
     p.tuner_score = d.tuner_score; p.score_k = d.score_k; p.period = d.period; p.is_mh = d.sampler == KLARA_SAMPLER_MH;
-    p.da_epsbar = h->da_epsbar; p.da_hbar = h->da_hbar; p.da_nadapt = d.da_nadapt; p.da_gamma = d.da_gamma;
+    p.da_epsbar = (decltype(p.da_epsbar))h->da_epsbar; p.da_hbar = (decltype(p.da_hbar))h->da_hbar; p.da_nadapt = d.da_nadapt; p.da_gamma = d.da_gamma;
     p.da_kappa = d.da_kappa; p.da_t0 = d.da_t0;
     // sampler_state(..., tuner::DualAveragingMCTuner): lambda = nleaps*leapstep, mu = log(10*step) (HMC.jl:124-133,192-213)
     p.da_lambda = (double)d.nleaps * d.leapstep; p.da_mu = kd_log(10.0 * d.leapstep);
@@ -290,9 +290,9 @@ static KParams make_params(klara_handle* h)
             : d.sampler == KLARA_SAMPLER_HMC ? d.leapstep : (double)NAN;
     p.sqrt_step0 = std::sqrt(p.step0); p.inv_step0 = 1.0 / p.step0;
     p.burnin = d.burnin; p.thinning = d.thinning; p.nsteps_total = d.nsteps;
-    p.gw = h->gw; p.gmu = h->gmu; p.gconst = d.gauss_const;
-    p.lX = h->lX; p.ly = h->ly; p.ndata = d.logit_ndata; p.lambda = d.logit_lambda; p.lpconst = h->lpconst;
-    p.hY = h->hY; p.hxc = h->hxc; p.hR = d.hier_nunits; p.hT = d.hier_ntimes; p.hp0 = d.hier_prior_prec;
+    p.gw = (decltype(p.gw))h->gw; p.gmu = (decltype(p.gmu))h->gmu; p.gconst = d.gauss_const;
+    p.lX = (decltype(p.lX))h->lX; p.ly = (decltype(p.ly))h->ly; p.ndata = d.logit_ndata; p.lambda = d.logit_lambda; p.lpconst = h->lpconst;
+    p.hY = (decltype(p.hY))h->hY; p.hxc = (decltype(p.hxc))h->hxc; p.hR = d.hier_nunits; p.hT = d.hier_ntimes; p.hp0 = d.hier_prior_prec;
     p.ha0 = d.hier_gamma_a; p.hb0 = d.hier_gamma_b;
     return p;
 }

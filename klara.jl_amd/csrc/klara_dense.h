@@ -48,16 +48,16 @@ __device__ __forceinline__ MfmaCtx<NE> make_mctx(const KParams& p)
 }
 
 template <int NE>
-__device__ __forceinline__ void mload(const MfmaCtx<NE>& c, const double* base, int D, double (&v)[NE])
+__device__ __forceinline__ void mload(const MfmaCtx<NE>& c, const gdouble* base, int D, double (&v)[NE])
 {
-    const double* row = base + c.chain * D + c.q;
+    const gdouble* row = base + c.chain * D + c.q;
 #pragma unroll
     for (int e = 0; e < NE; ++e) v[e] = c.valid[e] ? row[4 * e] : 0.0;
 }
 template <int NE>
-__device__ __forceinline__ void mstore(const MfmaCtx<NE>& c, double* base, int D, const double (&v)[NE])
+__device__ __forceinline__ void mstore(const MfmaCtx<NE>& c, gdouble* base, int D, const double (&v)[NE])
 {
-    double* row = base + c.chain * D + c.q;
+    gdouble* row = base + c.chain * D + c.q;
 #pragma unroll
     for (int e = 0; e < NE; ++e) if (c.valid[e]) row[4 * e] = v[e];
 }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512)
 void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
 {
     const KParams& p = *pp;
-    uint8_t* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
+    guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = (NE + 3) / 4;
     constexpr int NG = 4 * MT;
@@ -332,8 +332,8 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                     mload<NE>(cx, p.X, p.D, xs);
                 }
                 if (do_sum) {
-                    double* sr = p.sum + cx.chain * p.D + cx.q;
-                    double* qr = p.sumsq + cx.chain * p.D + cx.q;
+                    gdouble* sr = p.sum + cx.chain * p.D + cx.q;
+                    gdouble* qr = p.sumsq + cx.chain * p.D + cx.q;
 #pragma unroll
                     for (int e = 0; e < NE; ++e) if (cx.valid[e]) {
                         sr[4 * e] = sr[4 * e] + xs[e];
@@ -342,7 +342,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 }
                 if (p.hist != nullptr) {
                     if (col < p.hist_cols) {
-                        double* dst = p.hist + (col * p.nchains + cx.chain) * p.D + cx.q;
+                        gdouble* dst = p.hist + (col * p.nchains + cx.chain) * p.D + cx.q;
 #pragma unroll
                         for (int e = 0; e < NE; ++e) if (cx.valid[e]) dst[4 * e] = xs[e];
                     }
@@ -358,7 +358,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 } else {
                     mload<NE>(cx, p.GR, p.D, gs);
                 }
-                double* dst = p.hist_g + (col * p.nchains + cx.chain) * p.D + cx.q;
+                gdouble* dst = p.hist_g + (col * p.nchains + cx.chain) * p.D + cx.q;
 #pragma unroll
                 for (int e = 0; e < NE; ++e) if (cx.valid[e]) dst[4 * e] = gs[e];
             }
@@ -375,7 +375,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             p.tune_proposed[cx.chain] = tn.proposed;
             p.tune_totproposed[cx.chain] = tn.totproposed;
         } else if (p.cnt) {
-            atomicAdd(p.pooled_accepted, (unsigned long long)tn.accepted - (unsigned long long)p.tune_accepted[0]);
+            atomicAdd((unsigned long long*)p.pooled_accepted, (unsigned long long)tn.accepted - (unsigned long long)p.tune_accepted[0]);
         }
     }
 }
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512) void k_dense_init(const KParams p, const doubl
         mstore<NE>(cx, p.GR, p.D, gs);
     }
     if (cx.chain_ok && cx.q == 0) p.LT[cx.chain] = lt;
-    if (bad) atomicMax(p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
+    if (bad) atomicMax((int*)p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
 }
 
 // test hook: D[16x16] = A[16x4] * B[4x16] + C through one v_mfma_f64_16x16x4_f64, to pin the

@@ -26,36 +26,51 @@
 #define KLARA_SLICE_MAX_ATT ((1 << KLARA_SLICE_ATT_BITS) - 1)
 #define KLARA_INIT_TRANSITION ((((uint64_t)1) << 40) - 1)
 
-// Kernel parameter block (by value).  All pointers are device pointers.
+// Device pointers inside KParams are typed as address space 1 (global) in device compilation: the struct is read
+// from memory, and without the qualifier hipcc treats the loaded pointers as generic and emits flat_load/flat_store
+// (vmcnt + lgkmcnt, 64-bit VGPR addresses) instead of global_load v, v_off32, s[base:base+1].  Host code sees plain
+// pointers of the same size.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KGLOBAL __attribute__((address_space(1)))
+#else
+#define KGLOBAL
+#endif
+typedef KGLOBAL double gdouble;
+typedef KGLOBAL long long glong;
+typedef KGLOBAL unsigned long long gulong;
+typedef KGLOBAL uint8_t guchar;
+typedef KGLOBAL int gint;
+
+// Kernel parameter block.  All pointers are device pointers.
 struct KParams {
-    double* X; double* GR; double* LT;         // state: value nchains x D, gradlogtarget nchains x D, logtarget nchains
-    double* tune_step;                         // per chain (or [0] in pooled mode)
-    long long* tune_accepted; long long* tune_proposed; long long* tune_totproposed;
-    unsigned long long* pooled_accepted;       // pooled mode: device-wide accepted counter
-    uint8_t* accept;                           // [launch step][nchains] or null
-    unsigned long long* naccept;               // per chain
-    double* sum; double* sumsq;                // per chain x D or null
-    double* hist; long long hist_cols;         // [col][nchains][D] or null
-    double* hist_lt; double* hist_g;           // [col][nchains] / [col][nchains][D] or null
-    int* error_flag;                           // set to klara_status on device-detected errors
+    gdouble* X; gdouble* GR; gdouble* LT;         // state: value nchains x D, gradlogtarget nchains x D, logtarget nchains
+    gdouble* tune_step;                         // per chain (or [0] in pooled mode)
+    glong* tune_accepted; glong* tune_proposed; glong* tune_totproposed;
+    gulong* pooled_accepted;       // pooled mode: device-wide accepted counter
+    guchar* accept;                           // [launch step][nchains] or null
+    gulong* naccept;               // per chain
+    gdouble* sum; gdouble* sumsq;                // per chain x D or null
+    gdouble* hist; long long hist_cols;         // [col][nchains][D] or null
+    gdouble* hist_lt; gdouble* hist_g;           // [col][nchains] / [col][nchains][D] or null
+    gint* error_flag;                           // set to klara_status on device-detected errors
     long long nchains; long long chain_offset;
     int D; int G; int pooled;
     unsigned long long seed;
     // sampler
-    const double* vecparam;                    // MH sigma[D] / slice widths[D]
+    const gdouble* vecparam;                    // MH sigma[D] / slice widths[D]
     int nleaps; int stepout;
     // tuner
     int tuner; int cnt; double targetrate; double score_k; int period; int is_mh; int tuner_score;
     // DualAveragingMCTuner (KLARA_TUNER_DUAL_AVERAGING): per-chain eps_bar / h_bar arrays and constants
-    double* da_epsbar; double* da_hbar; long long da_nadapt; double da_gamma; double da_kappa; int da_t0;
+    gdouble* da_epsbar; gdouble* da_hbar; long long da_nadapt; double da_gamma; double da_kappa; int da_t0;
     double da_mu; double da_lambda;            // mu = log(10*leapstep), lambda = nleaps*leapstep (HMC.jl:124-133,192-213)
     double sqrt_step0, inv_step0;              // sqrt(step0), 1/step0 (MALA with an untuned step)
     double step0;                              // initial step (samplers.jl:29-45); the step of every chain when nothing is tuned
     long long burnin; long long thinning; long long nsteps_total;
     // targets
-    const double* gw; const double* gmu; double gconst;      // diag (gw/gmu may be null)
-    const double* lX; const double* ly; int ndata; double lambda; double lpconst;   // logistic
-    const double* hY; const double* hxc; int hR; int hT; double hp0; double ha0; double hb0;   // hierarchical normal
+    const gdouble* gw; const gdouble* gmu; double gconst;      // diag (gw/gmu may be null)
+    const gdouble* lX; const gdouble* ly; int ndata; double lambda; double lpconst;   // logistic
+    const gdouble* hY; const gdouble* hxc; int hR; int hT; double hp0; double ha0; double hb0;   // hierarchical normal
 };
 
 // Per-launch values, passed by value.  Everything else (KParams) is static for a handle and lives in device memory:
@@ -157,12 +172,14 @@ __device__ __forceinline__ LaneCtx<E> make_ctx(const KParams& p)
     return c;
 }
 
+typedef double kd_double2 __attribute__((ext_vector_type(2)));
+
 template <int E>
-__device__ __forceinline__ void load_vec(const LaneCtx<E>& c, const double* base, int D, double (&v)[E])
+__device__ __forceinline__ void load_vec(const LaneCtx<E>& c, const gdouble* base, int D, double (&v)[E])
 {
     // out-of-range lanes read element 0 of a valid row (always in bounds) and discard it: a select
     // instead of an exec-masked branch per element
-    const double* row = base + (c.chain_ok ? c.chain : 0) * D;
+    const gdouble* row = base + (c.chain_ok ? c.chain : 0) * D;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const double t = row[c.valid[e] ? c.i0 + e : 0];
@@ -170,14 +187,14 @@ __device__ __forceinline__ void load_vec(const LaneCtx<E>& c, const double* base
     }
 }
 template <int E>
-__device__ __forceinline__ void store_vec(const LaneCtx<E>& c, double* base, int D, const double (&v)[E])
+__device__ __forceinline__ void store_vec(const LaneCtx<E>& c, gdouble* base, int D, const double (&v)[E])
 {
-    double* row = base + c.chain * D + c.i0;
+    gdouble* row = base + c.chain * D + c.i0;
 #pragma unroll
     for (int e = 0; e < E; ++e) if (c.valid[e]) row[e] = v[e];
 }
 template <int E>
-__device__ __forceinline__ void load_param(const LaneCtx<E>& c, const double* base, int D, double dflt,
+__device__ __forceinline__ void load_param(const LaneCtx<E>& c, const gdouble* base, int D, double dflt,
                                            double (&v)[E])
 {
 #pragma unroll
@@ -769,7 +786,7 @@ __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1)))
 void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 {
     const KParams& p = *pp;
-    uint8_t* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
+    guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = typename TargetSel<TARGET, E>::type;
     constexpr bool NEEDG = (SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_HMC);
@@ -854,14 +871,14 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
                         for (int e = 0; e < E; ++e) { sm[e] = sm[e] + cur.x[e]; sq[e] = sq[e] + cur.x[e] * cur.x[e]; }
                     }
                     if (p.hist != nullptr && scol < p.hist_cols) {
-                        double* dst = p.hist + (scol * p.nchains + cx.chain) * p.D + cx.i0;
+                        gdouble* dst = p.hist + (scol * p.nchains + cx.chain) * p.D + cx.i0;
 #pragma unroll
                         for (int e = 0; e < E; ++e) if (cx.valid[e]) dst[e] = cur.x[e];
                     }
                     if (p.hist_lt != nullptr && scol < p.hist_cols && cx.chain_ok && cx.q == 0)
                         p.hist_lt[scol * p.nchains + cx.chain] = cur.lt;
                     if (NEEDG && p.hist_g != nullptr && scol < p.hist_cols) {
-                        double* dst = p.hist_g + (scol * p.nchains + cx.chain) * p.D + cx.i0;
+                        gdouble* dst = p.hist_g + (scol * p.nchains + cx.chain) * p.D + cx.i0;
 #pragma unroll
                         for (int e = 0; e < E; ++e) if (cx.valid[e]) dst[e] = cur.g[e];
                     }
@@ -887,9 +904,9 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
                 p.tune_proposed[cx.chain] = tn.proposed;
                 p.tune_totproposed[cx.chain] = tn.totproposed;
             } else if (p.pooled && p.cnt) {
-                atomicAdd(p.pooled_accepted, (unsigned long long)(tn.accepted - acc0));
+                atomicAdd((unsigned long long*)p.pooled_accepted, (unsigned long long)(tn.accepted - acc0));
             }
-            if (stuck) atomicMax(p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
+            if (stuck) atomicMax((int*)p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
         }
         if (!has_next) break;
         cur = nxt; cx = cxn; grp = grp_next;
@@ -918,7 +935,7 @@ __global__ __launch_bounds__(256) void k_init(const KParams p, int needgrad)
         for (int e = 0; e < E; ++e) bad = bad || (cx.valid[e] && !kfinite(g[e]));
     }
     if (cx.chain_ok && cx.q == 0) p.LT[cx.chain] = lt;
-    if (bad) atomicMax(p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
+    if (bad) atomicMax((int*)p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
 }
 
 // x0 ~ N(0, I) from the init stream (transition index 2^40-1)
