@@ -176,9 +176,9 @@ def extra_measurements(K, L, n, stream):
     for key, target in (("hmc_iso", K.GaussDiagTarget.negdot(NDIMS)),
                         ("hmc_dense", K.GaussDenseTarget.compound_symmetric(NDIMS, 0.5))):
         e = K.Engine(sampler=L.SAMPLER_HMC, target=target, nchains=n, nsteps=100000, leapstep=0.1, nleaps=10,
-                     steps_per_launch=4, stream=stream)
-        e.init_state_normal(); e.run(8)
-        steps = 64
+                     steps_per_launch=16, stream=stream)      # 16 = the library's default fusion
+        e.init_state_normal(); e.run(16)
+        steps = 128
         t0 = time.perf_counter(); e.run(steps); dt = time.perf_counter() - t0
         ms, nl = e.last_run_ms()
         ex[f"{key}_leapfrog_chain_per_s"] = n * steps * 10 / dt
