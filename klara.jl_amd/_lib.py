@@ -84,7 +84,7 @@ def load() -> C.CDLL:
             f"or make -C klara.jl_amd/csrc). There is no CPU fallback for the transition path.")
     lib = C.CDLL(str(path))
     H = C.c_void_p
-    i64p, u64p, u8p = C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
+    i64p, u64p = C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
     sig = {
         "klara_create": [C.POINTER(KlaraDesc), C.POINTER(H)],
         "klara_destroy": [H],

@@ -19,8 +19,6 @@ struct klara_handle {
     klara_desc d;
     // layout
     int kind, G, E;            // kind 0: group layout (G lanes x E elems); kind 1: MFMA (E = NE)
-    // owned copies of host parameter vectors
-    std::vector<double> h_vec;
     // device buffers
     double *X = nullptr, *GR = nullptr, *LT = nullptr;
     double* tune_step = nullptr;

@@ -2,8 +2,9 @@
 //
 // Layout (kind 0).  A chain's D-vector is spread over G = 2^k lanes of a wavefront,
 // E contiguous elements per lane (element i lives on lane i / E of its group); a 64-lane wavefront
-// carries 64 / G chains.  D = 100 -> E = 2, G = 64: one chain per wavefront, lanes 0..49 hold (2q, 2q+1),
-// so one Philox4x32-10 block per lane yields exactly that lane's two proposal normals.
+// carries 64 / G chains.  D = 100 -> E = 4, G = 32: two chains per wavefront, lanes 0..24 of each half hold
+// (4q..4q+3), so two Philox4x32-10 blocks per lane yield exactly that lane's four proposal normals (E = 2, G = 64 is
+// the one-chain-per-wavefront variant; klara_api.hip select_layout picks E).
 // D = 4 (swiss logistic regression) -> E = 4, G = 1: one chain per lane, no cross-lane traffic at all.
 // State matrices are (nchains x D) row-major in HBM: a wavefront reads/writes contiguous rows.
 //
@@ -948,7 +949,3 @@ __global__ __launch_bounds__(256) void k_init_normal(const KParams p)
     lane_normals<E>(cx, p.seed, (unsigned long long)(p.chain_offset + cx.chain), KLARA_INIT_TRANSITION, z, ad, -1);
     store_vec<E>(cx, p.X, p.D, z);
 }
-
-// launcher signature shared by the per-sampler translation units
-typedef void (*klara_launch_fn)(const KParams& p, int target, int E, int G, dim3 grid, size_t lds,
-                                hipStream_t stream);

@@ -203,6 +203,47 @@ def test_nonfinite_initial_values_are_rejected():
     eng.close()
 
 
+def test_error_paths():
+    """Status codes instead of aborts: call order, capacity, unsupported combinations, slice sampler that cannot move."""
+    eng = K.Engine(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(2), nchains=4, nsteps=5, mh_sigma=[1.0, 1.0],
+                   monitor=L.MON_ACCEPT)
+    with pytest.raises(K.KlaraError) as ei:
+        eng.run(1)                                             # run before set_state
+    assert ei.value.status == L.ERR_STATE
+    eng.set_state(np.zeros((4, 2)))
+    eng.run(5)
+    with pytest.raises(K.KlaraError) as ei:
+        eng.run(1)                                             # accept diagnostics are sized for range.nsteps
+    assert ei.value.status == L.ERR_STATE
+    with pytest.raises(K.KlaraError) as ei:
+        eng.chain(0)                                           # history not monitored
+    assert ei.value.status == L.ERR_STATE
+    eng.close()
+    for kw in (dict(sampler=L.SAMPLER_SLICE, slice_widths=np.ones(8), target=K.GaussDenseTarget(np.eye(8))),
+               dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(4), tuner=L.TUNER_DUAL_AVERAGING,
+                    targetrate=0.6, da_nadapt=10),
+               dict(sampler=L.SAMPLER_SLICE, slice_widths=np.ones(4), target=K.GaussDiagTarget.negdot(4),
+                    tuner=L.TUNER_ACCEPT_RATE, targetrate=0.5, tuner_mode=L.TUNE_POOLED)):
+        with pytest.raises(K.KlaraError) as ei:
+            K.Engine(nchains=4, nsteps=5, **kw)
+        assert ei.value.status == L.ERR_UNSUPPORTED
+    with pytest.raises(K.KlaraError) as ei:                    # gradient history needs a gradient-carrying sampler
+        K.Engine(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(2), nchains=4, nsteps=5, mh_sigma=[1.0, 1.0],
+                 monitor=L.MON_HIST_GRAD)
+    assert ei.value.status == L.ERR_INVALID_ARG
+    # a flat log-target region at -inf: the slice never contains an acceptable point other than the current one
+    w = np.array([1e300, 1.0])
+    eng = K.Engine(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget(2, w=np.array([1e300, 1.0])), nchains=3, nsteps=2,
+                   slice_widths=[1e-300, 1.0], slice_stepout=False)
+    eng.set_state(np.zeros((3, 2)))
+    try:
+        eng.run(2)                                             # either moves or reports KLARA_ERR_SLICE_STUCK — never hangs
+    except K.KlaraError as e:
+        assert e.status == L.ERR_SLICE_STUCK
+    eng.close()
+    del w
+
+
 def test_history_layout_matches_nstate():
     """:destination=>:nstate — value is (D x npoststeps) per chain, column i = i-th saved step
     (test/ParameterNStates.jl:139-146,176-185; save rule BasicMCJob.jl:226-231)."""
