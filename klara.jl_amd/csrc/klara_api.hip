@@ -18,7 +18,8 @@
 struct klara_handle {
     klara_desc d;
     // layout
-    int kind, G, E;            // kind 0: group layout (G lanes x E elems); kind 1: MFMA (E = NE)
+    int kind, G, E;            // kind 0: group layout (G lanes x E elems); kind 1: MFMA (E = NE); kind 2: logistic row split
+    int RS = 1;                // kind 2: lanes sharing one chain's data rows (G = 1 there)
     // device buffers
     double *X = nullptr, *GR = nullptr, *LT = nullptr;
     double* tune_step = nullptr;
@@ -66,7 +67,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     }
     *kind = 0;
     if (d.target == KLARA_TARGET_LOGISTIC) {
-        *G = 1;
+        *G = 1;   // every lane holds the whole parameter vector; klara_create may turn on the row split (kind 2)
         if (D <= 2) *E = 2; else if (D <= 4) *E = 4; else if (D <= 8) *E = 8; else return KLARA_ERR_UNSUPPORTED;
         return KLARA_OK;
     }
@@ -179,6 +180,14 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     klara_handle* h = new (std::nothrow) klara_handle();
     if (!h) return KLARA_ERR_NOMEM;
     h->d = *desc; h->kind = kind; h->G = G; h->E = E;
+    if (desc->target == KLARA_TARGET_LOGISTIC) {
+        // D <= 8 parameters cannot fill a wavefront's lanes usefully, the ndata-row likelihood can: RS lanes share a chain
+        // and each takes every RS-th row (fixed by ndata alone, so results do not depend on how chains are sharded)
+        int rs = desc->logit_ndata >= 64 ? 4 : 1;
+        if (const char* s = getenv("KLARA_LOGIT_ROWSPLIT")) { const int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) rs = v; }
+        h->RS = rs;
+        if (rs > 1) h->kind = 2;
+    }
     const size_t N = (size_t)desc->nchains, D = (size_t)desc->ndims;
     const bool pooled = desc->tuner_mode == KLARA_TUNE_POOLED;
     const size_t NT = pooled ? 1 : N;
@@ -274,7 +283,7 @@ static KParams make_params(klara_handle* h)
     p.accept = (decltype(p.accept))h->accept; p.naccept = (decltype(p.naccept))h->naccept; p.sum = (decltype(p.sum))h->sum; p.sumsq = (decltype(p.sumsq))h->sumsq;
     p.hist = (decltype(p.hist))h->hist; p.hist_cols = h->hist_cols; p.error_flag = (decltype(p.error_flag))h->err;
     p.hist_lt = (decltype(p.hist_lt))h->hist_lt; p.hist_g = (decltype(p.hist_g))h->hist_g;
-    p.nchains = d.nchains; p.chain_offset = d.chain_offset; p.D = d.ndims; p.G = h->G;
+    p.nchains = d.nchains; p.chain_offset = d.chain_offset; p.D = d.ndims; p.G = h->G; p.rs = h->RS;
     p.pooled = d.tuner_mode == KLARA_TUNE_POOLED;
     p.seed = d.seed;
     p.vecparam = (decltype(p.vecparam))h->vecparam; p.nleaps = d.nleaps; p.stepout = d.slice_stepout;
@@ -298,7 +307,7 @@ static KParams make_params(klara_handle* h)
 // one wave per chain group for the init kernels and the MFMA kernels
 static dim3 grid_for(const klara_handle* h)
 {
-    const long long cpw = h->kind == 1 ? 16 : 64 / h->G;
+    const long long cpw = h->kind == 1 ? 16 : 64 / (h->G * h->RS);
     const long long waves = (h->d.nchains + cpw - 1) / cpw;
     const long long wpb = h->kind == 1 ? 8 : 4;
     return dim3((unsigned)((waves + wpb - 1) / wpb));
@@ -308,7 +317,7 @@ static dim3 grid_for(const klara_handle* h)
 // next group's state overlaps the current group's compute); keep >= ~8 waves per SIMD of work for balance
 static dim3 grid_for_transitions(const klara_handle* h)
 {
-    const long long cpw = 64 / h->G;
+    const long long cpw = 64 / (h->G * h->RS);
     const long long groups = (h->d.nchains + cpw - 1) / cpw;
     long long gpw = 4;
     while (gpw > 1 && groups / gpw < 8192) gpw >>= 1;
@@ -319,7 +328,7 @@ static dim3 grid_for_transitions(const klara_handle* h)
 
 static size_t lds_for(const klara_handle* h)
 {
-    if (h->kind == 0 && h->d.target == KLARA_TARGET_LOGISTIC)
+    if (h->kind != 1 && h->d.target == KLARA_TARGET_LOGISTIC)
         return sizeof(double) * (size_t)h->d.logit_ndata * (size_t)(h->d.ndims + 1);
     if (h->kind == 0 && h->d.target == KLARA_TARGET_HIER_NORMAL)
         return sizeof(double) * ((size_t)h->d.hier_nunits * (size_t)h->d.hier_ntimes + (size_t)h->d.hier_ntimes);
@@ -435,8 +444,8 @@ extern "C" klara_status klara_init_state_normal(klara_handle* h)
     KParams p = make_params(h);
     const int D = h->d.ndims;
     int E = 2, G = pow2ceil((D + 1) / 2);
-    if (h->kind == 0) { E = h->E; G = h->G; }
-    p.G = G;
+    if (h->kind != 1) { E = h->E; G = h->G; }
+    p.G = G; p.rs = 1;     // the init stream is drawn without the row split (same values, any layout)
     const long long cpw = 64 / G, waves = (h->d.nchains + cpw - 1) / cpw;
     const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
     if (E == 2) hipLaunchKernelGGL((k_init_normal<2, 0>), grid, blk, 0, h->stream, p);
@@ -738,7 +747,7 @@ extern "C" klara_status klara_get_layout(klara_handle* h, int32_t* kind, int32_t
 {
     if (!h) return KLARA_ERR_INVALID_ARG;
     if (kind) *kind = h->kind;
-    if (lanes_per_chain) *lanes_per_chain = h->G;
+    if (lanes_per_chain) *lanes_per_chain = h->kind == 2 ? h->RS : h->G;
     if (elems_per_lane) *elems_per_lane = h->E;
     return KLARA_OK;
 }

@@ -56,6 +56,7 @@ struct KParams {
     gint* error_flag;                           // set to klara_status on device-detected errors
     long long nchains; long long chain_offset;
     int D; int G; int pooled;
+    int rs;                                    // logistic target: data rows split over rs lanes per chain (1 = off)
     unsigned long long seed;
     // sampler
     const gdouble* vecparam;                    // MH sigma[D] / slice widths[D]
@@ -153,6 +154,8 @@ struct LaneCtx {
     long long chain;   // local chain index (may be >= nchains: inactive group)
     bool chain_ok;
     bool valid[E];     // element i0+e < D and chain_ok
+    int RS;            // row split (logistic target): RS lanes share one chain, each holding ALL E elements (G == 1)
+    int rq;            // lane within the row-split group
 };
 
 template <int E, int GT>
@@ -163,9 +166,11 @@ __device__ __forceinline__ LaneCtx<E> make_ctx(const KParams& p)
     c.G = G;
     c.lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    c.q = c.lane & (G - 1);
-    const int grp = c.lane / G;
-    c.chain = wave * (64 / G) + grp;
+    c.RS = p.rs > 1 ? p.rs : 1;
+    c.rq = c.lane & (c.RS - 1);
+    c.q = (c.lane / c.RS) & (G - 1);
+    const int grp = c.lane / (G * c.RS);
+    c.chain = wave * (64 / (G * c.RS)) + grp;
     c.chain_ok = c.chain < p.nchains;
     c.i0 = E * c.q;
 #pragma unroll
@@ -192,7 +197,7 @@ __device__ __forceinline__ void store_vec(const LaneCtx<E>& c, gdouble* base, in
 {
     gdouble* row = base + c.chain * D + c.i0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) if (c.valid[e]) row[e] = v[e];
+    for (int e = 0; e < E; ++e) if (c.valid[e] && c.rq == 0) row[e] = v[e];
 }
 template <int E>
 __device__ __forceinline__ void load_param(const LaneCtx<E>& c, const gdouble* base, int D, double dflt,
@@ -287,10 +292,12 @@ struct LogisticTarget {
     __device__ __forceinline__ void eval(const LaneCtx<E>& cx, const double (&x)[E], double& ltpart,
                                          double (&g)[E]) const
     {
+        // rows r = rq, rq + RS, ... of the design matrix belong to this lane (RS = 1: all of them); the RS lane
+        // partials are combined by one xor butterfly below (the oracle sums in the same order, layout kind 2)
         double dotxy = 0.0, slog = 0.0, gacc[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) gacc[e] = 0.0;
-        for (int r = 0; r < ndata; ++r) {
+        for (int r = cx.rq; r < ndata; r += cx.RS) {
             const double* row = sX + r * D;
             double xp = 0.0;
 #pragma unroll
@@ -305,6 +312,16 @@ struct LogisticTarget {
 #pragma unroll
                 for (int e = 0; e < E; ++e) if (e < D) gacc[e] = kd_fma(row[e], res, gacc[e]);
             }
+        }
+        if (cx.RS > 1) {
+            double red[E + 2];
+            red[0] = dotxy; red[1] = slog;
+#pragma unroll
+            for (int e = 0; e < E; ++e) red[2 + e] = gacc[e];
+            group_allreduce<E + 2>(red, cx.RS, cx.lane);
+            dotxy = red[0]; slog = red[1];
+#pragma unroll
+            for (int e = 0; e < E; ++e) gacc[e] = red[2 + e];
         }
         if (WANT_LT) {
             double dotpp = 0.0;
@@ -769,7 +786,7 @@ __device__ __forceinline__ void load_chain(const KParams& p, const LaneCtx<E>& c
 template <int E, int GT>
 __device__ __forceinline__ void set_chain(const KParams& p, LaneCtx<E>& c, long long group_index)
 {
-    c.chain = group_index * (64 / c.G) + (c.lane / c.G);
+    c.chain = group_index * (64 / (c.G * c.RS)) + (c.lane / (c.G * c.RS));
     c.chain_ok = c.chain < p.nchains;
 #pragma unroll
     for (int e = 0; e < E; ++e) c.valid[e] = c.chain_ok && (c.i0 + e < p.D);
@@ -799,7 +816,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
     double vp[E];
     if (SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_SLICE) load_param<E>(cx, p.vecparam, p.D, 1.0, vp);
 
-    const int cpw = 64 / cx.G;
+    const int cpw = 64 / (cx.G * cx.RS);
     const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
     long long grp = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const bool do_sum = p.sum != nullptr;
@@ -857,7 +874,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             else acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, cur.x, cur.lt, stuck);
             nacc += acc ? 1ull : 0ull;
             if (p.cnt && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;   // the slice sampler never counts accepts
-            if (accept_out != nullptr && cx.chain_ok && cx.q == 0)
+            if (accept_out != nullptr && cx.chain_ok && cx.q == 0 && cx.rq == 0)
                 accept_out[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
             if (per_chain_tune && !da) tuning_block(p, tn);
             else if (per_chain_tune && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {   // verbose report block, iterate/HMC.jl:229-243
@@ -874,14 +891,14 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
                     if (p.hist != nullptr && scol < p.hist_cols) {
                         gdouble* dst = p.hist + (scol * p.nchains + cx.chain) * p.D + cx.i0;
 #pragma unroll
-                        for (int e = 0; e < E; ++e) if (cx.valid[e]) dst[e] = cur.x[e];
+                        for (int e = 0; e < E; ++e) if (cx.valid[e] && cx.rq == 0) dst[e] = cur.x[e];
                     }
-                    if (p.hist_lt != nullptr && scol < p.hist_cols && cx.chain_ok && cx.q == 0)
+                    if (p.hist_lt != nullptr && scol < p.hist_cols && cx.chain_ok && cx.q == 0 && cx.rq == 0)
                         p.hist_lt[scol * p.nchains + cx.chain] = cur.lt;
                     if (NEEDG && p.hist_g != nullptr && scol < p.hist_cols) {
                         gdouble* dst = p.hist_g + (scol * p.nchains + cx.chain) * p.D + cx.i0;
 #pragma unroll
-                        for (int e = 0; e < E; ++e) if (cx.valid[e]) dst[e] = cur.g[e];
+                        for (int e = 0; e < E; ++e) if (cx.valid[e] && cx.rq == 0) dst[e] = cur.g[e];
                     }
                     ++scol;
                 }
@@ -896,7 +913,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             if (NEEDG) store_vec<E>(cx, p.GR, p.D, cur.g);
         }
         if (do_sum) { store_vec<E>(cx, p.sum, p.D, sm); store_vec<E>(cx, p.sumsq, p.D, sq); }
-        if (cx.chain_ok && cx.q == 0) {
+        if (cx.chain_ok && cx.q == 0 && cx.rq == 0) {
             if (nacc != 0) { p.LT[cx.chain] = cur.lt; p.naccept[cx.chain] += nacc; }
             if (da) { p.tune_step[cx.chain] = tn.step; p.da_epsbar[cx.chain] = tn.epsbar; p.da_hbar[cx.chain] = tn.hbar; }
             if (per_chain_tune) {
@@ -935,7 +952,7 @@ __global__ __launch_bounds__(256) void k_init(const KParams p, int needgrad)
 #pragma unroll
         for (int e = 0; e < E; ++e) bad = bad || (cx.valid[e] && !kfinite(g[e]));
     }
-    if (cx.chain_ok && cx.q == 0) p.LT[cx.chain] = lt;
+    if (cx.chain_ok && cx.q == 0 && cx.rq == 0) p.LT[cx.chain] = lt;
     if (bad) atomicMax((int*)p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
 }
 

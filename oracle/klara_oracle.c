@@ -42,7 +42,9 @@
 /* lane layout of the device kernels — determines summation order only */
 typedef struct ko_layout {
     int32_t kind; /* 0: element i on lane i / E (E contiguous elements per lane), G lanes per chain
-                     1: element i on lane-quarter i % 4 (MFMA-transposed), 4 lanes per chain     */
+                     1: element i on lane-quarter i % 4 (MFMA-transposed), 4 lanes per chain
+                     2: logistic row split: every lane holds all elements (sums over elements are sequential),
+                        the data rows are dealt round-robin to G lanes and combined by the xor tree       */
     int32_t G;
     int32_t E;
 } ko_layout;
@@ -50,10 +52,10 @@ typedef struct ko_layout {
 static double ko_reduce(const ko_layout* L, const double* terms, int D)
 {
     double part[64], nw[64];
-    const int G = (L->kind == 1) ? 4 : L->G;
+    const int G = (L->kind == 1) ? 4 : (L->kind == 2 ? 1 : L->G);
     for (int l = 0; l < G; ++l) part[l] = 0.0;
     for (int i = 0; i < D; ++i) {
-        const int lane = (L->kind == 1) ? (i & 3) : (i / L->E);
+        const int lane = (L->kind == 1) ? (i & 3) : (L->kind == 2 ? 0 : i / L->E);
         part[lane] = part[lane] + terms[i];
     }
     for (int m = 1; m < G; m <<= 1) {
@@ -135,21 +137,37 @@ static void ko_logit_eval(const ko_target_ctx* c, const double* p, double* lt, d
 {
     const klara_desc* d = c->d;
     const int D = d->ndims, n = d->logit_ndata;
-    double dotxy = 0.0, slog = 0.0, gacc[KO_MAXD];
-    for (int k = 0; k < D; ++k) gacc[k] = 0.0;
+    /* row split: row r belongs to lane r % RS; lane partials are then combined pairwise (xor tree) */
+    const int RS = (c->L->kind == 2) ? c->L->G : 1;
+    double pdot[64], plog[64], pg[64][16];
+    if (D > 16 || RS > 64) { if (lt) *lt = NAN; return; }
+    for (int q = 0; q < RS; ++q) { pdot[q] = 0.0; plog[q] = 0.0; for (int k = 0; k < D; ++k) pg[q][k] = 0.0; }
     for (int r = 0; r < n; ++r) {
+        const int q = r % RS;
         const double* row = d->logit_X + (size_t)r * D;
         double xp = 0.0;
         for (int k = 0; k < D; ++k) xp = kd_fma(row[k], p[k], xp);            /* Xp = v[2]*p        */
         if (lt) {
-            dotxy = dotxy + xp * d->logit_y[r];                                 /* dot(Xp, v[3])      */
-            slog = slog + kd_log(1.0 + kd_exp(xp));                             /* sum(log(1+exp(Xp)))*/
+            pdot[q] = pdot[q] + xp * d->logit_y[r];                             /* dot(Xp, v[3])      */
+            plog[q] = plog[q] + kd_log(1.0 + kd_exp(xp));                       /* sum(log(1+exp(Xp)))*/
         }
         if (g) {
             const double res = d->logit_y[r] - 1.0 / (1.0 + kd_exp(-xp));       /* v[3]-1./(1+exp(-Xp)) */
-            for (int k = 0; k < D; ++k) gacc[k] = kd_fma(row[k], res, gacc[k]); /* v[2]'*(...)        */
+            for (int k = 0; k < D; ++k) pg[q][k] = kd_fma(row[k], res, pg[q][k]); /* v[2]'*(...)      */
         }
     }
+    for (int m = 1; m < RS; m <<= 1) {
+        double nd[64], nl[64], ng[64][16];
+        for (int q = 0; q < RS; ++q) {
+            nd[q] = pdot[q] + pdot[q ^ m]; nl[q] = plog[q] + plog[q ^ m];
+            for (int k = 0; k < D; ++k) ng[q][k] = pg[q][k] + pg[q ^ m][k];
+        }
+        memcpy(pdot, nd, sizeof(double) * (size_t)RS); memcpy(plog, nl, sizeof(double) * (size_t)RS);
+        memcpy(pg, ng, sizeof(double) * 16 * (size_t)RS);
+    }
+    const double dotxy = pdot[0], slog = plog[0];
+    double gacc[KO_MAXD];
+    for (int k = 0; k < D; ++k) gacc[k] = pg[0][k];
     if (lt) {
         double pp[KO_MAXD];
         for (int k = 0; k < D; ++k) pp[k] = p[k] * p[k];

@@ -61,14 +61,15 @@ def load() -> C.CDLL:
     return lib
 
 
-def default_layout(target_kind: int, ndims: int):
+def default_layout(target_kind: int, ndims: int, ndata: int = 0):
     """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box)."""
     d = int(ndims)
     if target_kind == L.TARGET_GAUSS_DENSE:
         ne = 8 if d <= 32 else 16 if d <= 64 else 25 if d <= 100 else 32
         return (1, 4, ne)
     if target_kind == L.TARGET_LOGISTIC:
-        return (0, 1, 2 if d <= 2 else 4 if d <= 4 else 8)
+        e = 2 if d <= 2 else 4 if d <= 4 else 8
+        return (2, 4, e) if ndata >= 64 else (0, 1, e)
     def p2(v):
         g = 1
         while g < v:
@@ -129,7 +130,7 @@ class OracleJob:
         d.hier_prior_prec, d.hier_gamma_a, d.hier_gamma_b = float(hier_prior_prec), float(hier_gamma_a), float(hier_gamma_b)
         d.seed = int(seed)
         self.desc = d
-        k, g, e = layout if layout is not None else default_layout(int(target_kind), self.D)
+        k, g, e = layout if layout is not None else default_layout(int(target_kind), self.D, int(d.logit_ndata))
         self.layout = KoLayout(k, g, e)
         nt = 1 if tuner_mode == L.TUNE_POOLED else self.N
         self.X = np.zeros((self.N, self.D)); self.G = np.zeros((self.N, self.D)); self.LT = np.zeros(self.N)
