@@ -350,6 +350,11 @@ struct HierTarget {
     const double* sY; const double* sxc;
     int R, T, i0, hl[5], he[5];          // owner lane (within the group) and element slot of each hyper-parameter
     double p0, a0, b0;
+    // T <= 8 (rats: 5): the lane's own observation rows and the centred covariate live in registers for the whole
+    // kernel, so an evaluation touches LDS only for the cross-lane traffic
+    static constexpr int TR = 8;
+    double yreg[E / 2][TR], xreg[TR];
+    bool regpath;
     static __device__ __forceinline__ size_t lds_bytes(const KParams& p)
     {
         return sizeof(double) * ((size_t)p.hR * (size_t)p.hT + (size_t)p.hT);
@@ -363,6 +368,17 @@ struct HierTarget {
         sY = Y; sxc = xc; R = p.hR; T = p.hT; p0 = p.hp0; a0 = p.ha0; b0 = p.hb0; i0 = cx.i0;
 #pragma unroll
         for (int k = 0; k < 5; ++k) { hl[k] = (2 * R + k) / E; he[k] = (2 * R + k) % E; }
+        regpath = T <= TR;
+#pragma unroll
+        for (int j = 0; j < TR; ++j) {
+            xreg[j] = (regpath && j < T) ? xc[j] : 0.0;
+#pragma unroll
+            for (int pr = 0; pr < E / 2; ++pr) {
+                const int ia = i0 + 2 * pr;
+                const int rat = ia < 2 * R ? (ia >> 1) : 0;
+                yreg[pr][j] = (regpath && j < T) ? Y[rat * T + j] : 0.0;
+            }
+        }
     }
     template <bool WANT_LT, bool WANT_GRAD>
     __device__ __forceinline__ void eval(const LaneCtx<E>& cx, const double (&x)[E], double& ltpart,
@@ -396,11 +412,22 @@ struct HierTarget {
             const double ai = x[2 * pr], bi = x[2 * pr + 1];
             const double da = ai - ac, db = bi - bc;
             double S1 = 0.0, Sx = 0.0, S2 = 0.0;
-            const double* yrow = sY + rat * T;
-            for (int j = 0; j < T; ++j) {
-                const double xj = sxc[j];
-                const double r = (yrow[j] - ai) - bi * xj;
-                S1 = S1 + r; Sx = Sx + r * xj; S2 = S2 + r * r;
+            if (regpath) {
+#pragma unroll
+                for (int j = 0; j < TR; ++j) {
+                    if (j < T) {
+                        const double xj = xreg[j];
+                        const double r = (yreg[pr][j] - ai) - bi * xj;
+                        S1 = S1 + r; Sx = Sx + r * xj; S2 = S2 + r * r;
+                    }
+                }
+            } else {
+                const double* yrow = sY + rat * T;
+                for (int j = 0; j < T; ++j) {
+                    const double xj = sxc[j];
+                    const double r = (yrow[j] - ai) - bi * xj;
+                    S1 = S1 + r; Sx = Sx + r * xj; S2 = S2 + r * r;
+                }
             }
             if (WANT_GRAD) { g[2 * pr] = wc * S1 - wa * da; g[2 * pr + 1] = wc * Sx - wb * db; }
             // element order within the lane: a-slot terms then b-slot terms, exactly the oracle's term arrays
