@@ -208,6 +208,12 @@ klara_status klara_get_chain(klara_handle* h, int64_t local_chain, double* value
  * KLARA_MON_HIST_LT) and gradlogtarget[d + D*i] (KLARA_MON_HIST_GRAD); either pointer may be NULL. */
 klara_status klara_get_chain_fields(klara_handle* h, int64_t local_chain, double* logtarget,
                                     double* gradlogtarget, int64_t capacity_cols, int64_t* ncols_out);
+/* Monte Carlo variance of every (chain, dimension) series of the stored history, computed on device
+ * (src/stats/variance/mcvar.jl): iid (:5), batch means with `batchlen` (:35-41), Geyer's initial monotone sequence
+ * estimator up to `maxlag` (<= 0: n-1) (:75-105).  Each output is nchains x ndims or NULL; requires KLARA_MON_HISTORY.
+ * ess = n * iid / imse and iact = imse / iid (src/stats/convergence/{ess,iact}.jl:3) follow on the host. */
+klara_status klara_get_chain_mcvar(klara_handle* h, int64_t batchlen, int64_t maxlag, double* mcvar_iid,
+                                   double* mcvar_bm, double* mcvar_imse);
 /* tuner state per chain (tuners.jl:5-10). In pooled mode every chain reports the shared state. */
 klara_status klara_get_tune(klara_handle* h, double* step, int64_t* accepted, int64_t* proposed,
                             int64_t* totproposed);

@@ -8,7 +8,7 @@ from ._lib import KlaraError  # noqa: F401
 from .engine import Engine, GaussDenseTarget, GaussDiagTarget, HierNormalTarget, LogisticTarget  # noqa: F401
 from .api import (  # noqa: F401
     HMC, MALA, MH, AcceptanceRateMCTuner, DualAveragingMCTuner, BasicContMuvParameter, BasicMCJob, BasicMCRange, GenericModel,
-    MuvChains, SliceSampler, VanillaMCTuner, acceptance, erf_rate_score, likelihood_model, logistic, logistic_rate_score,
+    MuvChains, SliceSampler, VanillaMCTuner, acceptance, chain_ess, chain_iact, chain_mcvar, erf_rate_score, likelihood_model, logistic, logistic_rate_score,
     mcvar_iid, mean, output, reset, run,
 )
 from .distributed import allreduce_summaries, gather_engine_summaries, shard_chains  # noqa: F401

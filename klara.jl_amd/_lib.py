@@ -64,7 +64,7 @@ EXPORTS = [
     "klara_create", "klara_destroy", "klara_set_state", "klara_init_state_normal", "klara_run",
     "klara_run_async", "klara_synchronize", "klara_reset", "klara_get_state", "klara_get_accept_mask",
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
-    "klara_get_chain_fields", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
+    "klara_get_chain_fields", "klara_get_chain_mcvar", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
     "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_mfma_f64", "klara_strerror",
     "klara_abi_version",
 ]
@@ -101,6 +101,7 @@ def load() -> C.CDLL:
         "klara_get_pooled_summaries": [H, C.c_void_p, C.c_void_p, u64p, u64p, i64p],
         "klara_get_chain": [H, C.c_int64, C.c_void_p, C.c_int64, i64p],
         "klara_get_chain_fields": [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, i64p],
+        "klara_get_chain_mcvar": [H, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_get_tune": [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_get_dual_averaging": [H, C.c_void_p, C.c_void_p],
         "klara_last_run_ms": [H, C.POINTER(C.c_double), i64p],

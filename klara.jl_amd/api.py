@@ -246,6 +246,25 @@ def mcvar_iid(chains: MuvChains) -> np.ndarray:
     return var / n
 
 
+def chain_mcvar(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, maxlag: int = 0) -> np.ndarray:
+    """mcvar(s, Val{vtype}) for EVERY chain and dimension at once, computed on device over the stored history
+    (stats/variance/mcvar.jl:5,35-41,75-105).  Returns (nchains x D); vtype in {"iid", "bm", "imse"}."""
+    iid, bm, imse = chains._job.engine.chain_mcvar(batchlen, maxlag)
+    return {"iid": iid, "bm": bm, "imse": imse}[vtype]
+
+
+def chain_ess(chains: MuvChains, vtype: str = "imse", batchlen: int = 100) -> np.ndarray:
+    """ess(s, vtype) = n * mcvar_iid / mcvar_vtype (stats/convergence/ess.jl:3) for every chain and dimension."""
+    iid, bm, imse = chains._job.engine.chain_mcvar(batchlen, 0)
+    return chains.n * iid / {"bm": bm, "imse": imse}[vtype]
+
+
+def chain_iact(chains: MuvChains, vtype: str = "imse", batchlen: int = 100) -> np.ndarray:
+    """iact(s, vtype) = mcvar_vtype / mcvar_iid (stats/convergence/iact.jl:3) for every chain and dimension."""
+    iid, bm, imse = chains._job.engine.chain_mcvar(batchlen, 0)
+    return {"bm": bm, "imse": imse}[vtype] / iid
+
+
 def acceptance(chains: MuvChains, diagnostics: bool = True) -> np.ndarray:
     """acceptance(s::MultivariateParameterNState; key=:accept) — stats/acceptance.jl:28-34:
     mean of the accept diagnostics over the saved steps (per chain)."""

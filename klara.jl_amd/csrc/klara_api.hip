@@ -692,6 +692,86 @@ extern "C" klara_status klara_get_chain_fields(klara_handle* h, int64_t local_ch
     return KLARA_OK;
 }
 
+// Post-hoc Monte Carlo variance estimators of src/stats/variance/mcvar.jl over the stored history, one thread per
+// (chain, dimension) series; consecutive threads read consecutive dimensions of one chain (coalesced).
+//   iid  : var(v)/n                                   (mcvar.jl:5)
+//   bm   : batchlen * var(batch means) / nbsamples    (mcvar.jl:35-41, Flegal & Jones)
+//   imse : Geyer's initial monotone sequence estimator on the empirical autocovariance (mcvar.jl:75-105);
+//          autocov(v, k) = sum_t (v_t - m)(v_{t+k} - m) / n  (StatsBase, demean = true), evaluated lag pair by lag
+//          pair until the first non-positive pair sum, so the cost is O(n * stopping lag) instead of O(n^2).
+__global__ __launch_bounds__(256) void k_chain_stats(const double* __restrict__ hist, long long ncols, long long N, int D,
+                                                     long long batchlen, long long maxlag, double* iid, double* bm,
+                                                     double* imse)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * D) return;
+    const double* v = hist + i;                 // v[t * stride]
+    const long long stride = N * D, n = ncols;
+    double m = 0.0;
+    for (long long t = 0; t < n; ++t) m += v[t * stride];
+    m /= (double)n;
+    double acv0 = 0.0;
+    for (long long t = 0; t < n; ++t) { const double z = v[t * stride] - m; acv0 += z * z; }
+    if (iid) iid[i] = (n > 1) ? acv0 / (double)(n - 1) / (double)n : NAN;
+    if (bm) {
+        const long long nb = batchlen > 0 ? n / batchlen : 0;
+        if (nb > 1) {
+            double sb = 0.0, sb2 = 0.0;                       // two-pass over batch means for stability
+            for (long long b = 0; b < nb; ++b) {
+                double a = 0.0;
+                for (long long t = 0; t < batchlen; ++t) a += v[(b * batchlen + t) * stride];
+                sb += a / (double)batchlen;
+            }
+            const double mb = sb / (double)nb;
+            for (long long b = 0; b < nb; ++b) {
+                double a = 0.0;
+                for (long long t = 0; t < batchlen; ++t) a += v[(b * batchlen + t) * stride];
+                const double dm = a / (double)batchlen - mb;
+                sb2 += dm * dm;
+            }
+            bm[i] = (double)batchlen * (sb2 / (double)(nb - 1)) / (double)(nb * batchlen);
+        } else bm[i] = NAN;                                   // "Choose batch size such that the number of batches is > 1"
+    }
+    if (imse) {
+        const long long ml = maxlag < n - 1 ? maxlag : n - 1;
+        const long long k = (ml - 1) / 2;                     // floor((maxlag-1)/2), mcvar.jl:76
+        double gsum = 0.0, gprev = 0.0;
+        for (long long j = 0; j <= k; ++j) {
+            double a0 = 0.0, a1 = 0.0;
+            const long long l0 = 2 * j, l1 = 2 * j + 1;
+            if (j == 0) a0 = acv0;
+            else for (long long t = 0; t + l0 < n; ++t) a0 += (v[t * stride] - m) * (v[(t + l0) * stride] - m);
+            for (long long t = 0; t + l1 < n; ++t) a1 += (v[t * stride] - m) * (v[(t + l1) * stride] - m);
+            double gj = (a0 + a1) / (double)n;
+            if (gj <= 0.0) break;                             // m = j (mcvar.jl:87-90)
+            if (j > 0 && gj > gprev) gj = gprev;              // monotone sequence (mcvar.jl:94-100)
+            gsum += gj; gprev = gj;
+        }
+        imse[i] = (-acv0 / (double)n + 2.0 * gsum) / (double)n;
+    }
+}
+
+extern "C" klara_status klara_get_chain_mcvar(klara_handle* h, int64_t batchlen, int64_t maxlag, double* mcvar_iid,
+                                              double* mcvar_bm, double* mcvar_imse)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->hist || !h->have_state || h->nsaved < 2) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    const long long N = h->d.nchains, D = h->d.ndims, total = N * D;
+    double* buf = nullptr;
+    HIPCHK(dalloc(&buf, (size_t)3 * total));
+    hipLaunchKernelGGL(k_chain_stats, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->hist,
+                       (long long)h->nsaved, N, (int)D, (long long)batchlen, (long long)(maxlag > 0 ? maxlag : h->nsaved - 1),
+                       mcvar_iid ? buf : nullptr, mcvar_bm ? buf + total : nullptr, mcvar_imse ? buf + 2 * total : nullptr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && mcvar_iid) e = hipMemcpy(mcvar_iid, buf, total * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && mcvar_bm) e = hipMemcpy(mcvar_bm, buf + total, total * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && mcvar_imse) e = hipMemcpy(mcvar_imse, buf + 2 * total, total * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(buf);
+    return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
+}
+
 extern "C" klara_status klara_get_tune(klara_handle* h, double* step, int64_t* accepted, int64_t* proposed,
                                        int64_t* totproposed)
 {

@@ -291,6 +291,13 @@ class Engine:
                 "klara_get_chain_fields")
         return lt, g
 
+    def chain_mcvar(self, batchlen: int = 100, maxlag: int = 0):
+        """(mcvar_iid, mcvar_bm, mcvar_imse), each (nchains, ndims), from the on-device history (mcvar.jl)."""
+        out = [np.empty((self.nchains, self.ndims)) for _ in range(3)]
+        L.check(self._lib.klara_get_chain_mcvar(self._h, int(batchlen), int(maxlag), out[0].ctypes.data,
+                                                out[1].ctypes.data, out[2].ctypes.data), "klara_get_chain_mcvar")
+        return tuple(out)
+
     def tune(self):
         step = np.empty(self.nchains); a = np.empty(self.nchains, dtype=np.int64)
         p = np.empty(self.nchains, dtype=np.int64); t = np.empty(self.nchains, dtype=np.int64)

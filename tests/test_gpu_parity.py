@@ -310,6 +310,27 @@ def test_monitored_fields_and_iostream_sink(tmp_path):
     job.close()
 
 
+def test_device_mcvar_matches_host_estimators():
+    """stats/variance/mcvar.jl (:iid, :bm, :imse), convergence/ess.jl, iact.jl on device for all chains at once vs
+    the NumPy restatement (klara_jl_amd.stats) on individual chains; tolerance 1e-9 relative (different summation)."""
+    p = K.BasicContMuvParameter("p", logtarget=K.GaussDiagTarget.negdot(3))
+    job = K.BasicMCJob(K.likelihood_model(p, False), K.MH(np.full(3, 0.6)), K.BasicMCRange(nsteps=2600, burnin=100),
+                       {"p": np.zeros((70, 3))})
+    K.run(job)
+    chain = K.output(job)
+    iid, bm, imse = (K.chain_mcvar(chain, t, batchlen=50) for t in ("iid", "bm", "imse"))
+    ess, iact = K.chain_ess(chain), K.chain_iact(chain)
+    assert iid.shape == (70, 3)
+    for c in (0, 33, 69):
+        v = chain.value(c)
+        assert np.allclose(iid[c], K.stats.mcvar_chain(v, "iid"), rtol=1e-9)
+        assert np.allclose(bm[c], K.stats.mcvar_chain(v, "bm", 50), rtol=1e-9)
+        assert np.allclose(imse[c], K.stats.mcvar_chain(v, "imse"), rtol=1e-7)
+        assert np.allclose(ess[c], K.stats.ess_chain(v), rtol=1e-7) and np.allclose(iact[c], K.stats.iact_chain(v), rtol=1e-7)
+    assert np.all(iact > 1.0) and np.all(ess < 2500)          # a random-walk chain is autocorrelated
+    job.close()
+
+
 # ------------------------------------------------------------------ reference-API level
 def test_readme_flow_basic_mc_job():
     """README.md:23-66 through the host mirror: MH on lt = -dot(z,z), 10000 steps, burnin 1000."""
