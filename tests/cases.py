@@ -53,6 +53,19 @@ def make_case(name):
     elif name == "mala_d3_tuned":      # AcceptanceRate tuner, per chain, several tuning events
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(3), nchains=50, nsteps=260, burnin=200,
                  driftstep=1.5, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=25)
+    elif name == "mala_d1":            # the univariate case is the D-vector kernel with D = 1
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(1), nchains=100, nsteps=60, burnin=10, driftstep=0.8)
+    elif name == "hmc_d128_full":      # no padding lane: G*E == D, so the accept uniform takes the explicit path
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.negdot(128), nchains=21, nsteps=15, burnin=0,
+                 leapstep=0.08, nleaps=5)
+    elif name == "mala_d129":          # E=4 on all 64 lanes (33 busy), one chain per wavefront
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(129), nchains=7, nsteps=20, burnin=0, driftstep=0.03)
+    elif name == "mh_d512":            # E=8, the largest supported diagonal target
+        c = dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(512), nchains=5, nsteps=25, burnin=0,
+                 mh_sigma=np.full(512, 0.03))
+    elif name == "slice_d2_mvnormal":  # G=1: one chain per lane with divergent step-out / shrink loops
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.mvnormal([1.0, -2.0], [0.5, 3.0]), nchains=130,
+                 nsteps=25, burnin=5, slice_widths=[0.3, 4.0])
     elif name == "mala_d3_tuned_erf":  # erf_rate_score(x, 3) instead of the logistic score
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(3), nchains=50, nsteps=260, burnin=200,
                  driftstep=1.5, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=25, tuner_score=1, score_k=3.0)
@@ -141,7 +154,8 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "mala_d300", "hmc_d100", "hmc_d10_tuned_pooled", "hmc_dense_d100", "hmc_dense_d37", "mala_dense_d100",
              "mh_dense_d20", "mala_swiss", "hmc_swiss", "slice_d5", "slice_d100_nostepout", "slice_swiss",
              "hmc_rats", "hmc_rats_pooled", "mala_rats", "slice_rats", "hmc_d10_dualavg", "hmc_dense_d37_dualavg",
-             "hmc_rats_dualavg", "mala_d3_tuned_erf"]
+             "hmc_rats_dualavg", "mala_d3_tuned_erf", "mala_d1", "hmc_d128_full", "mala_d129", "mh_d512",
+             "slice_d2_mvnormal"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg"]
