@@ -482,6 +482,12 @@ __device__ __forceinline__ double eval_lt(const T& tg, const LaneCtx<E>& cx, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// PLAIN kernels are the instantiation for the common job (VanillaMCTuner, not verbose: nothing counts, nothing tunes):
+// the mode flags below fold to constants there, which removes the tuner bookkeeping from the generated code.
+#define KCNT (PLAIN ? 0 : p.cnt)
+#define KPOOLED (PLAIN ? 0 : p.pooled)
+#define KDA (!PLAIN && p.tuner == KLARA_TUNER_DUAL_AVERAGING)
+
 // per-chain tuner state in registers (tuners.jl:5-10), uniform across the group's lanes
 // ------------------------------------------------------------------------------------------------
 struct TuneRegs { double step; long long accepted, proposed, totproposed; int phase; /* proposed % period */
@@ -584,7 +590,7 @@ __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const Lan
 }
 
 // iterate!(job, MALA, Multivariate) — iterate/MALA.jl:78-128
-template <class T, int E>
+template <class T, int E, bool PLAIN>
 __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const LaneCtx<E>& cx,
                                           unsigned long long gchain, unsigned long long t,
                                           const double (&z)[E], const AccDraw& ad, double h,
@@ -592,10 +598,10 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
 {
     double mu[E], xp[E], gp[E], red[3];
     // sqrt(step) and 1/step come precomputed from the host while nothing tunes the step (same IEEE results)
-    const double halfh = 0.5 * h, sq = p.cnt ? __builtin_sqrt(h) : p.sqrt_step0;
+    const double halfh = 0.5 * h, sq = KCNT ? __builtin_sqrt(h) : p.sqrt_step0;
     // abs2(.)/step of MALA.jl:90,92 is evaluated as abs2(.) * (1/step): one f64 division per transition instead
     // of 2 per element (a division is ~70 issue cycles per wave on gfx950); the oracle does the same.
-    const double inv_h = p.cnt ? 1.0 / h : p.inv_step0;
+    const double inv_h = KCNT ? 1.0 / h : p.inv_step0;
 #pragma unroll
     for (int e = 0; e < E; ++e) mu[e] = x[e] + halfh * g[e];                          // :83
 #pragma unroll
@@ -628,7 +634,7 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
 
 // iterate!(job, HMC, Multivariate) — iterate/HMC.jl:124-201; leapfrog! samplers.jl:122-134;
 // hamiltonian samplers.jl:103
-template <class T, int E>
+template <class T, int E, bool PLAIN>
 __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const LaneCtx<E>& cx,
                                          unsigned long long gchain, unsigned long long t,
                                          const double (&z)[E], const AccDraw& ad, double eps, int nleaps, double& a_out,
@@ -645,7 +651,7 @@ __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const La
 #pragma unroll
     for (int e = 0; e < E; ++e) { xp[e] = x[e]; gp[e] = g[e]; }                       // :139-140
     const double halfe = 0.5 * eps;
-    if (p.tuner != KLARA_TUNER_DUAL_AVERAGING) {
+    if (!KDA) {
         for (int l = 0; l < p.nleaps; ++l) {                                          // :146-155
 #pragma unroll
             for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];              // samplers.jl:130
@@ -794,20 +800,20 @@ struct ChainRegs {
     double epsbar, hbar;
 };
 
-template <int E, bool NEEDG>
+template <int E, bool NEEDG, bool PLAIN>
 __device__ __forceinline__ void load_chain(const KParams& p, const LaneCtx<E>& cx, ChainRegs<E>& r)
 {
     load_vec<E>(cx, p.X, p.D, r.x);
     if (NEEDG) load_vec<E>(cx, p.GR, p.D, r.g);
     const long long c0 = cx.chain_ok ? cx.chain : 0;
     r.lt = p.LT[c0];
-    if (p.cnt && !p.pooled) {            // per-chain tuner state (tuners.jl:5-10) only when something counts
+    if (KCNT && !KPOOLED) {              // per-chain tuner state (tuners.jl:5-10) only when something counts
         r.step = p.tune_step[c0]; r.accepted = p.tune_accepted[c0];
         r.proposed = p.tune_proposed[c0]; r.totproposed = p.tune_totproposed[c0];
-    } else if (p.tuner == KLARA_TUNER_DUAL_AVERAGING) {
+    } else if (KDA) {
         r.step = p.tune_step[c0];
     }
-    if (p.tuner == KLARA_TUNER_DUAL_AVERAGING) { r.epsbar = p.da_epsbar[c0]; r.hbar = p.da_hbar[c0]; }
+    if (KDA) { r.epsbar = p.da_epsbar[c0]; r.hbar = p.da_hbar[c0]; }
 }
 
 template <int E, int GT>
@@ -826,7 +832,7 @@ __device__ __forceinline__ void set_chain(const KParams& p, LaneCtx<E>& c, long 
 // first step's proposal normals (Philox + Box-Muller, independent of the state) are generated before
 // the loaded registers are first touched, so HBM latency overlaps the RNG/ALU work instead of
 // serialising with it (one-launch-per-transition mode is otherwise latency-bound at 3 waves/SIMD).
-template <int SAMPLER, int TARGET, int E, int GT>
+template <int SAMPLER, int TARGET, int E, int GT, bool PLAIN>
 __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1)))
 void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 {
@@ -847,12 +853,12 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
     const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
     long long grp = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const bool do_sum = p.sum != nullptr;
-    const bool per_chain_tune = p.cnt && !p.pooled;
-    const bool da = p.tuner == KLARA_TUNER_DUAL_AVERAGING;
+    const bool per_chain_tune = KCNT && !KPOOLED;
+    const bool da = KDA;
 
     ChainRegs<E> cur;
     set_chain<E, GT>(p, cx, grp);
-    load_chain<E, NEEDG>(p, cx, cur);
+    load_chain<E, NEEDG, PLAIN>(p, cx, cur);
 
     while (true) {
         // prefetch the next group this wave owns
@@ -862,7 +868,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
         ChainRegs<E> nxt;
         if (has_next) {
             set_chain<E, GT>(p, cxn, grp_next);
-            load_chain<E, NEEDG>(p, cxn, nxt);
+            load_chain<E, NEEDG, PLAIN>(p, cxn, nxt);
         }
 
         const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
@@ -876,7 +882,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 
         TuneRegs tn;
         if (per_chain_tune) tn = { cur.step, cur.accepted, cur.proposed, cur.totproposed, 0, 0.0, 0.0 };
-        else if (p.pooled) tn = { p.tune_step[0], p.tune_accepted[0], 0, 0, 0, 0.0, 0.0 };
+        else if (KPOOLED) tn = { p.tune_step[0], p.tune_accepted[0], 0, 0, 0, 0.0, 0.0 };
         else tn = { da ? cur.step : p.step0, 0, 0, 0, 0, 0.0, 0.0 };
         if (da) { tn.epsbar = cur.epsbar; tn.hbar = cur.hbar; }
         const long long acc0 = tn.accepted;
@@ -888,19 +894,19 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 
         for (int s = 0; s < kl.nsteps; ++s) {
             const unsigned long long t = kl.t0 + (unsigned long long)s;
-            if (p.cnt) tune_count_proposal(p, tn);
+            if (KCNT) tune_count_proposal(p, tn);
             bool acc;
             if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E>(p, tg, cx, gchain, t, z, ad, vp, cur.x, cur.lt);
-            else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E>(p, tg, cx, gchain, t, z, ad, tn.step, cur.x, cur.g, cur.lt);
+            else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E, PLAIN>(p, tg, cx, gchain, t, z, ad, tn.step, cur.x, cur.g, cur.lt);
             else if (SAMPLER == KLARA_SAMPLER_HMC) {
                 double a_prob = 0.0;
-                acc = step_hmc<T, E>(p, tg, cx, gchain, t, z, ad, tn.step, da ? da_nleaps(p, tn.step) : p.nleaps, a_prob,
+                acc = step_hmc<T, E, PLAIN>(p, tg, cx, gchain, t, z, ad, tn.step, da ? da_nleaps(p, tn.step) : p.nleaps, a_prob,
                                      cur.x, cur.g, cur.lt);
                 if (da) da_update(p, tn, (long long)t + 1, a_prob);                   // iterate/HMC.jl:225-249
             }
             else acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, cur.x, cur.lt, stuck);
             nacc += acc ? 1ull : 0ull;
-            if (p.cnt && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;   // the slice sampler never counts accepts
+            if (KCNT && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;   // the slice sampler never counts accepts
             if (accept_out != nullptr && cx.chain_ok && cx.q == 0 && cx.rq == 0)
                 accept_out[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
             if (per_chain_tune && !da) tuning_block(p, tn);
@@ -948,7 +954,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
                 p.tune_accepted[cx.chain] = tn.accepted;
                 p.tune_proposed[cx.chain] = tn.proposed;
                 p.tune_totproposed[cx.chain] = tn.totproposed;
-            } else if (p.pooled && p.cnt) {
+            } else if (KPOOLED && KCNT) {
                 atomicAdd((unsigned long long*)p.pooled_accepted, (unsigned long long)(tn.accepted - acc0));
             }
             if (stuck) atomicMax((int*)p.error_flag, (int)KLARA_ERR_SLICE_STUCK);

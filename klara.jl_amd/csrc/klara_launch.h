@@ -3,10 +3,14 @@
 #include "klara_kernels.h"
 
 // group-layout transition kernels; target in {GAUSS_DIAG, LOGISTIC}; E in {2,4,8}; G = lanes per chain
-hipError_t klara_launch_mh(const KParams* p, const KLaunch& kl, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
-hipError_t klara_launch_mala(const KParams* p, const KLaunch& kl, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
-hipError_t klara_launch_hmc(const KParams* p, const KLaunch& kl, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
-hipError_t klara_launch_slice(const KParams* p, const KLaunch& kl, int target, int E, int G, dim3 grid, size_t lds, hipStream_t st);
+hipError_t klara_launch_mh(const KParams* p, const KLaunch& kl, bool plain, int target, int E, int G, dim3 grid, size_t lds,
+                           hipStream_t st);
+hipError_t klara_launch_mala(const KParams* p, const KLaunch& kl, bool plain, int target, int E, int G, dim3 grid, size_t lds,
+                           hipStream_t st);
+hipError_t klara_launch_hmc(const KParams* p, const KLaunch& kl, bool plain, int target, int E, int G, dim3 grid, size_t lds,
+                           hipStream_t st);
+hipError_t klara_launch_slice(const KParams* p, const KLaunch& kl, bool plain, int target, int E, int G, dim3 grid, size_t lds,
+                           hipStream_t st);
 // dense (MFMA) kernels; NE in {8,16,25,32}
 hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, int NE, const double* Pfrag,
                               dim3 grid, hipStream_t st);
@@ -15,24 +19,32 @@ hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag
 hipError_t klara_launch_mfma_probe(const double* A, const double* B, const double* C, double* D,
                                    hipStream_t st);
 
+// PLAIN (nothing counts / tunes) and general instantiation of one kernel
+#define KLARA_LAUNCH_T(S, T, E_, G_)                                                                    \
+    do {                                                                                               \
+        if (plain) hipLaunchKernelGGL((k_transitions<S, T, E_, G_, true>), grid, blk, lds, st, p, kl);  \
+        else hipLaunchKernelGGL((k_transitions<S, T, E_, G_, false>), grid, blk, lds, st, p, kl);       \
+    } while (0)
+
 // dispatch helper used by every group-layout launcher
 #define KLARA_DISPATCH_GROUP(KERNEL_EXPR_PREFIX, SAMPLER)                                              \
     do {                                                                                               \
         const dim3 blk(256);                                                                           \
         if (target == KLARA_TARGET_GAUSS_DIAG) {                                                       \
-            if (E == 2 && G == 64) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 2, 64>), grid, blk, lds, st, p, kl); \
-            else if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 2, 0>), grid, blk, lds, st, p, kl);       \
-            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 4, 0>), grid, blk, lds, st, p, kl);       \
-            else if (E == 8) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_GAUSS_DIAG, 8, 0>), grid, blk, lds, st, p, kl);       \
+            if (E == 2 && G == 64) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_GAUSS_DIAG, 2, 64); \
+            else if (E == 2) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_GAUSS_DIAG, 2, 0);       \
+            else if (E == 4 && G == 32) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_GAUSS_DIAG, 4, 32); \
+            else if (E == 4) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_GAUSS_DIAG, 4, 0);       \
+            else if (E == 8) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_GAUSS_DIAG, 8, 0);       \
             else return hipErrorInvalidValue;                                                          \
         } else if (target == KLARA_TARGET_LOGISTIC) {                                                  \
-            if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 2, 0>), grid, blk, lds, st, p, kl);              \
-            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 4, 0>), grid, blk, lds, st, p, kl);         \
-            else if (E == 8) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_LOGISTIC, 8, 0>), grid, blk, lds, st, p, kl);         \
+            if (E == 2) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_LOGISTIC, 2, 0);              \
+            else if (E == 4) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_LOGISTIC, 4, 0);         \
+            else if (E == 8) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_LOGISTIC, 8, 0);         \
             else return hipErrorInvalidValue;                                                          \
         } else if (target == KLARA_TARGET_HIER_NORMAL) {                                               \
-            if (E == 2) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_HIER_NORMAL, 2, 0>), grid, blk, lds, st, p, kl);           \
-            else if (E == 4) hipLaunchKernelGGL((k_transitions<SAMPLER, KLARA_TARGET_HIER_NORMAL, 4, 0>), grid, blk, lds, st, p, kl);      \
+            if (E == 2) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_HIER_NORMAL, 2, 0);           \
+            else if (E == 4) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_HIER_NORMAL, 4, 0);      \
             else return hipErrorInvalidValue;                                                          \
         } else return hipErrorInvalidValue;                                                            \
         return hipGetLastError();                                                                      \
