@@ -470,12 +470,13 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
     const KParams* p = h->d_params;
     // PLAIN kernels: nothing counts proposals, nothing tunes (VanillaMCTuner, not verbose)
     const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
+    const int mode = (plain ? 1 : 0) | ((plain && d.monitor == 0) ? 2 : 0);   // 3: no monitors either
     if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, h->E, h->Pfrag, grid_for(h), h->stream);
     switch (d.sampler) {
-    case KLARA_SAMPLER_MH: return klara_launch_mh(p, kl, plain, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
-    case KLARA_SAMPLER_MALA: return klara_launch_mala(p, kl, plain, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
-    case KLARA_SAMPLER_HMC: return klara_launch_hmc(p, kl, plain, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
-    default: return klara_launch_slice(p, kl, plain, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
+    case KLARA_SAMPLER_MH: return klara_launch_mh(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
+    case KLARA_SAMPLER_MALA: return klara_launch_mala(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
+    case KLARA_SAMPLER_HMC: return klara_launch_hmc(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
+    default: return klara_launch_slice(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
     }
 }
 

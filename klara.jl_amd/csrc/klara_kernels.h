@@ -158,7 +158,7 @@ struct LaneCtx {
     int rq;            // lane within the row-split group
 };
 
-template <int E, int GT>
+template <int E, int GT, bool RSPL = true>
 __device__ __forceinline__ LaneCtx<E> make_ctx(const KParams& p)
 {
     LaneCtx<E> c;
@@ -166,7 +166,7 @@ __device__ __forceinline__ LaneCtx<E> make_ctx(const KParams& p)
     c.G = G;
     c.lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    c.RS = p.rs > 1 ? p.rs : 1;
+    c.RS = (RSPL && p.rs > 1) ? p.rs : 1;      // only the logistic target splits data rows over lanes
     c.rq = c.lane & (c.RS - 1);
     c.q = (c.lane / c.RS) & (G - 1);
     const int grp = c.lane / (G * c.RS);
@@ -816,10 +816,11 @@ __device__ __forceinline__ void load_chain(const KParams& p, const LaneCtx<E>& c
     if (KDA) { r.epsbar = p.da_epsbar[c0]; r.hbar = p.da_hbar[c0]; }
 }
 
-template <int E, int GT>
+template <int E, int GT, bool RSPL = true>
 __device__ __forceinline__ void set_chain(const KParams& p, LaneCtx<E>& c, long long group_index)
 {
-    c.chain = group_index * (64 / (c.G * c.RS)) + (c.lane / (c.G * c.RS));
+    const int W = RSPL ? c.G * c.RS : c.G;
+    c.chain = group_index * (64 / W) + (c.lane / W);
     c.chain_ok = c.chain < p.nchains;
 #pragma unroll
     for (int e = 0; e < E; ++e) c.valid[e] = c.chain_ok && (c.i0 + e < p.D);
@@ -832,18 +833,25 @@ __device__ __forceinline__ void set_chain(const KParams& p, LaneCtx<E>& c, long 
 // first step's proposal normals (Philox + Box-Muller, independent of the state) are generated before
 // the loaded registers are first touched, so HBM latency overlaps the RNG/ALU work instead of
 // serialising with it (one-launch-per-transition mode is otherwise latency-bound at 3 waves/SIMD).
-template <int SAMPLER, int TARGET, int E, int GT, bool PLAIN>
+// MODE bit 0 (PLAIN): nothing counts / tunes.  MODE bit 1 (NOMON): no monitor at all (no accept mask, running sums or
+// history) — the save-rule bookkeeping disappears from the generated code.
+template <int SAMPLER, int TARGET, int E, int GT, int MODE>
 __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1)))
 void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 {
+    constexpr bool PLAIN = (MODE & 1) != 0, NOMON = (MODE & 2) != 0;
+    constexpr bool RSPL = TARGET == KLARA_TARGET_LOGISTIC;
     const KParams& p = *pp;
-    guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
+    guchar* const accept_out = (!NOMON && p.accept != nullptr) ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
+    gdouble* const hist = NOMON ? nullptr : p.hist;
+    gdouble* const hist_lt = NOMON ? nullptr : p.hist_lt;
+    gdouble* const hist_g = NOMON ? nullptr : p.hist_g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = typename TargetSel<TARGET, E>::type;
     constexpr bool NEEDG = (SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_HMC);
     constexpr bool NEEDZ = (SAMPLER != KLARA_SAMPLER_SLICE);
 
-    LaneCtx<E> cx = make_ctx<E, GT>(p);
+    LaneCtx<E> cx = make_ctx<E, GT, RSPL>(p);
     T tg;
     tg.init(p, cx, reinterpret_cast<double*>(smem));
     double vp[E];
@@ -852,12 +860,12 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
     const int cpw = 64 / (cx.G * cx.RS);
     const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
     long long grp = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    const bool do_sum = p.sum != nullptr;
+    const bool do_sum = !NOMON && p.sum != nullptr;
     const bool per_chain_tune = KCNT && !KPOOLED;
     const bool da = KDA;
 
     ChainRegs<E> cur;
-    set_chain<E, GT>(p, cx, grp);
+    set_chain<E, GT, RSPL>(p, cx, grp);
     load_chain<E, NEEDG, PLAIN>(p, cx, cur);
 
     while (true) {
@@ -867,7 +875,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
         LaneCtx<E> cxn = cx;
         ChainRegs<E> nxt;
         if (has_next) {
-            set_chain<E, GT>(p, cxn, grp_next);
+            set_chain<E, GT, RSPL>(p, cxn, grp_next);
             load_chain<E, NEEDG, PLAIN>(p, cxn, nxt);
         }
 
@@ -915,21 +923,21 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             }
             // save rule: BasicMCJob.jl:226-231 with postrange = (burnin+1):thinning:nsteps (BasicMCRange.jl:36)
             const long long i1 = (long long)t + 1;
-            if (i1 > p.burnin && i1 <= p.nsteps_total) {
+            if (!NOMON && i1 > p.burnin && i1 <= p.nsteps_total) {
                 if (sphase == 0) {
                     if (do_sum) {
 #pragma unroll
                         for (int e = 0; e < E; ++e) { sm[e] = sm[e] + cur.x[e]; sq[e] = sq[e] + cur.x[e] * cur.x[e]; }
                     }
-                    if (p.hist != nullptr && scol < p.hist_cols) {
-                        gdouble* dst = p.hist + (scol * p.nchains + cx.chain) * p.D + cx.i0;
+                    if (hist != nullptr && scol < p.hist_cols) {
+                        gdouble* dst = hist + (scol * p.nchains + cx.chain) * p.D + cx.i0;
 #pragma unroll
                         for (int e = 0; e < E; ++e) if (cx.valid[e] && cx.rq == 0) dst[e] = cur.x[e];
                     }
-                    if (p.hist_lt != nullptr && scol < p.hist_cols && cx.chain_ok && cx.q == 0 && cx.rq == 0)
-                        p.hist_lt[scol * p.nchains + cx.chain] = cur.lt;
-                    if (NEEDG && p.hist_g != nullptr && scol < p.hist_cols) {
-                        gdouble* dst = p.hist_g + (scol * p.nchains + cx.chain) * p.D + cx.i0;
+                    if (hist_lt != nullptr && scol < p.hist_cols && cx.chain_ok && cx.q == 0 && cx.rq == 0)
+                        hist_lt[scol * p.nchains + cx.chain] = cur.lt;
+                    if (NEEDG && hist_g != nullptr && scol < p.hist_cols) {
+                        gdouble* dst = hist_g + (scol * p.nchains + cx.chain) * p.D + cx.i0;
 #pragma unroll
                         for (int e = 0; e < E; ++e) if (cx.valid[e] && cx.rq == 0) dst[e] = cur.g[e];
                     }

@@ -3,13 +3,13 @@
 #include "klara_kernels.h"
 
 // group-layout transition kernels; target in {GAUSS_DIAG, LOGISTIC}; E in {2,4,8}; G = lanes per chain
-hipError_t klara_launch_mh(const KParams* p, const KLaunch& kl, bool plain, int target, int E, int G, dim3 grid, size_t lds,
+hipError_t klara_launch_mh(const KParams* p, const KLaunch& kl, int mode, int target, int E, int G, dim3 grid, size_t lds,
                            hipStream_t st);
-hipError_t klara_launch_mala(const KParams* p, const KLaunch& kl, bool plain, int target, int E, int G, dim3 grid, size_t lds,
+hipError_t klara_launch_mala(const KParams* p, const KLaunch& kl, int mode, int target, int E, int G, dim3 grid, size_t lds,
                            hipStream_t st);
-hipError_t klara_launch_hmc(const KParams* p, const KLaunch& kl, bool plain, int target, int E, int G, dim3 grid, size_t lds,
+hipError_t klara_launch_hmc(const KParams* p, const KLaunch& kl, int mode, int target, int E, int G, dim3 grid, size_t lds,
                            hipStream_t st);
-hipError_t klara_launch_slice(const KParams* p, const KLaunch& kl, bool plain, int target, int E, int G, dim3 grid, size_t lds,
+hipError_t klara_launch_slice(const KParams* p, const KLaunch& kl, int mode, int target, int E, int G, dim3 grid, size_t lds,
                            hipStream_t st);
 // dense (MFMA) kernels; NE in {8,16,25,32}
 hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, int NE, const double* Pfrag,
@@ -19,11 +19,12 @@ hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag
 hipError_t klara_launch_mfma_probe(const double* A, const double* B, const double* C, double* D,
                                    hipStream_t st);
 
-// PLAIN (nothing counts / tunes) and general instantiation of one kernel
+// mode 3: nothing counts/tunes and nothing is monitored; mode 1: nothing counts/tunes; mode 0: general
 #define KLARA_LAUNCH_T(S, T, E_, G_)                                                                    \
     do {                                                                                               \
-        if (plain) hipLaunchKernelGGL((k_transitions<S, T, E_, G_, true>), grid, blk, lds, st, p, kl);  \
-        else hipLaunchKernelGGL((k_transitions<S, T, E_, G_, false>), grid, blk, lds, st, p, kl);       \
+        if (mode == 3) hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 3>), grid, blk, lds, st, p, kl);      \
+        else if (mode & 1) hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 1>), grid, blk, lds, st, p, kl);  \
+        else hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 0>), grid, blk, lds, st, p, kl);                \
     } while (0)
 
 // dispatch helper used by every group-layout launcher
