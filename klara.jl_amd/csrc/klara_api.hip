@@ -470,7 +470,8 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
     const KParams* p = h->d_params;
     // PLAIN kernels: nothing counts proposals, nothing tunes (VanillaMCTuner, not verbose)
     const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
-    const int mode = (plain ? 1 : 0) | ((plain && d.monitor == 0) ? 2 : 0);   // 3: no monitors either
+    int mode = (plain ? 1 : 0) | ((plain && d.monitor == 0) ? 2 : 0);         // 3: no monitors either
+    if (mode == 3 && kl.nsteps == 1) mode = 7;                                 // one iterate! per launch
     if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, h->E, h->Pfrag, grid_for(h), h->stream);
     switch (d.sampler) {
     case KLARA_SAMPLER_MH: return klara_launch_mh(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);

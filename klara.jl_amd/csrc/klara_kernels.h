@@ -23,6 +23,9 @@
 #ifndef KLARA_E4_WAVES
 #define KLARA_E4_WAVES 2   // min waves per SIMD requested for the E=4 kernels (register budget 256)
 #endif
+#ifndef KLARA_E4_WAVES_PLAIN
+#define KLARA_E4_WAVES_PLAIN 3   // the specialised (no tuner, no monitor) E=4 kernels fit 168 VGPRs
+#endif
 #define KLARA_SLICE_ATT_BITS 14
 #define KLARA_SLICE_MAX_ATT ((1 << KLARA_SLICE_ATT_BITS) - 1)
 #define KLARA_INIT_TRANSITION ((((uint64_t)1) << 40) - 1)
@@ -836,10 +839,12 @@ __device__ __forceinline__ void set_chain(const KParams& p, LaneCtx<E>& c, long 
 // MODE bit 0 (PLAIN): nothing counts / tunes.  MODE bit 1 (NOMON): no monitor at all (no accept mask, running sums or
 // history) — the save-rule bookkeeping disappears from the generated code.
 template <int SAMPLER, int TARGET, int E, int GT, int MODE>
-__global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? KLARA_E4_WAVES : 1)))
+__global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? ((MODE & 3) == 3 ? KLARA_E4_WAVES_PLAIN : KLARA_E4_WAVES) : 1)))
 void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 {
     constexpr bool PLAIN = (MODE & 1) != 0, NOMON = (MODE & 2) != 0;
+    constexpr bool ONESTEP = (MODE & 4) != 0;          // exactly one transition per launch (= one iterate!)
+    const int nsteps = ONESTEP ? 1 : kl.nsteps;
     constexpr bool RSPL = TARGET == KLARA_TARGET_LOGISTIC;
     const KParams& p = *pp;
     guchar* const accept_out = (!NOMON && p.accept != nullptr) ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
@@ -900,7 +905,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
         unsigned long long nacc = 0;
         bool stuck = false;
 
-        for (int s = 0; s < kl.nsteps; ++s) {
+        for (int s = 0; s < nsteps; ++s) {
             const unsigned long long t = kl.t0 + (unsigned long long)s;
             if (KCNT) tune_count_proposal(p, tn);
             bool acc;
@@ -945,10 +950,10 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
                 }
                 sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
             }
-            if (NEEDZ && s + 1 < kl.nsteps) lane_normals<E>(cx, p.seed, gchain, t + 1, z, ad, acc_slot);
+            if (!ONESTEP && NEEDZ && s + 1 < nsteps) lane_normals<E>(cx, p.seed, gchain, t + 1, z, ad, acc_slot);
         }
 
-        if (nacc != 0 || SAMPLER == KLARA_SAMPLER_SLICE || kl.nsteps > 1) {
+        if (nacc != 0 || SAMPLER == KLARA_SAMPLER_SLICE || nsteps > 1) {
             // (with one transition per launch a rejected proposal leaves x, g untouched: skip the write-back)
             store_vec<E>(cx, p.X, p.D, cur.x);
             if (NEEDG) store_vec<E>(cx, p.GR, p.D, cur.g);

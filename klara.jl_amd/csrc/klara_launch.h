@@ -19,10 +19,12 @@ hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag
 hipError_t klara_launch_mfma_probe(const double* A, const double* B, const double* C, double* D,
                                    hipStream_t st);
 
-// mode 3: nothing counts/tunes and nothing is monitored; mode 1: nothing counts/tunes; mode 0: general
+// mode 7: mode 3 with exactly one transition per launch; mode 3: nothing counts/tunes and nothing is monitored;
+// mode 1: nothing counts/tunes; mode 0: general
 #define KLARA_LAUNCH_T(S, T, E_, G_)                                                                    \
     do {                                                                                               \
-        if (mode == 3) hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 3>), grid, blk, lds, st, p, kl);      \
+        if (mode == 7) hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 7>), grid, blk, lds, st, p, kl);      \
+        else if ((mode & 3) == 3) hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 3>), grid, blk, lds, st, p, kl); \
         else if (mode & 1) hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 1>), grid, blk, lds, st, p, kl);  \
         else hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 0>), grid, blk, lds, st, p, kl);                \
     } while (0)
