@@ -145,8 +145,9 @@ def main():
         # only reported when this run's configuration is the profiled one
         try:
             tr = json.loads((ROOT / "profiles" / "r1_bench_mala_traffic.json").read_text())
-            if (tr["nchains"], tr["ndims"], tr["steps_per_launch"]) == (n, NDIMS, args.spl) and f"{lay_e}, 0>" in tr["kernel"]:
+            if (tr["nchains"], tr["ndims"], tr["steps_per_launch"]) == (n, NDIMS, args.spl) and tr.get("layout_e") == lay_e:
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_gbs"] = tr["traffic_bytes_per_launch"] / launch_s / 1e9
                 out["roofline"]["traffic_source"] = "profiles/r1_bench_mala_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
         except Exception:
             pass
