@@ -17,7 +17,8 @@
  *                      (/opt/rocm/include/rocrand/rocrand_philox4x32_10.h: seed(), discard_*_impl()).
  *   kd_u52             two 32-bit words -> uniform double strictly inside (0,1), exact.
  *   kd_log, kd_exp     FreeBSD-msun-style log/exp (<1 ulp), branch-light, built from + * / fma.
- *   kd_sincos2pi       sin(2*pi*u), cos(2*pi*u) for u in [0,1).
+ *   kd_log_u01         table-driven, division-free log for the uniforms (radius and Metropolis tests).
+ *   kd_sincos2pi       sin(2*pi*u), cos(2*pi*u) for u in [0,1): 256-entry table + rotation.
  *   kd_normal_pair     Box-Muller: one Philox block -> two N(0,1) doubles.
  *
  * This header is NOT a restatement of any reference file; the samplers' arithmetic is written
@@ -82,16 +83,21 @@ KD_FN kd_u32x4 kd_stream_block(uint64_t seed, uint64_t chain, uint64_t transitio
 }
 
 /* ---------------------------------------------------------------- uniform (0,1) */
-/* 52 random bits m -> (m + 0.5) * 2^-52: exact in binary64, never 0 and never 1. */
+/* 52 random bits m = whi:wlo>>12 -> (m + 0.5) * 2^-52: exact in binary64, never 0 and never 1.
+ * Built without int->double conversions: uu = 1 + m 2^-52 is assembled in [1,2) from the bits, and
+ * uu - (1 - 2^-53) = (2m + 1) 2^-53 is representable, so the subtraction is exact. */
+KD_FN uint64_t kd_unit_bits(uint32_t whi, uint32_t wlo)      /* bits of 1 + m 2^-52 */
+{
+    const uint32_t uh = 0x3ff00000u | (whi >> 12);
+    const uint32_t ul = (whi << 20) | (wlo >> 12);
+    return ((uint64_t)uh << 32) | (uint64_t)ul;
+}
 KD_FN double kd_u52(uint32_t whi, uint32_t wlo)
 {
-    const double hi = (double)whi;               /* exact */
-    const double lo = (double)(wlo >> 12);       /* exact, 20 bits */
-    const double m  = kd_fma(hi, 1048576.0, lo); /* hi*2^20 + lo < 2^52, exact */
-    return kd_fma(m, 0x1p-52, 0x1p-53);          /* (m + 0.5) * 2^-52, exact (53 bits) */
+    return kd_u2d(kd_unit_bits(whi, wlo)) - 0x1.fffffffffffffp-1;
 }
 
-/* kd_log(u) >= kd_log(2^-53) = -36.7368005696771 for every uniform kd_u52 can return, so a Metropolis ratio at
+/* kd_log_u01(u) >= kd_log_u01(2^-53) = -36.7368005696771 for every uniform kd_u52 can return, so a Metropolis ratio at
  * or below this guard is rejected whatever the uniform is (lets the kernels skip the draw; same result). */
 #define KD_LOG_UMIN_GUARD (-36.74)
 
@@ -131,6 +137,52 @@ KD_FN double kd_log(double x)
     if (x_in < 0.0) r = __builtin_nan("");
     if (!(x_in < __builtin_inf())) r = x_in + x_in;   /* +inf, NaN */
     return r;
+}
+
+/* ---------------------------------------------------------------- log of a uniform */
+/* kd_log_u01(x) for positive normal finite x (every kd_u52 value): the logarithm the Box-Muller radius and the
+ * Metropolis tests use.  Division-free table method (the scheme of Arm's optimized-routines log, restated):
+ *   x = 2^k z, z in [0.6875, 1.375); bin i = leading 7 mantissa bits of z relative to 0.6875;
+ *   r = z*invc_i - 1 (one fma, |r| <= 2^-7);  log x = (k ln2_hi + logc_i) + r + [k ln2_lo - r^2/2 + r^3 q(r)]
+ * with q the degree-5 Taylor tail of log1p.  The two bins touching 1 have c = 1, logc = 0, so r = x - 1 exactly and
+ * the result keeps its relative accuracy as x -> 1.  < 1 ulp (tests/test_oracle_kats.py).  No special cases:
+ * zero, subnormal, negative, inf and NaN inputs are outside its contract (kd_log handles those). */
+#include "detmath_tables.h"
+#if defined(__HIPCC__)
+static __device__ const double kd_logtab_dev[256] __attribute__((aligned(16))) = KD_LOGTAB_INIT;
+static __device__ const double kd_sctab_dev[512] __attribute__((aligned(16))) = KD_SCTAB_INIT;
+#endif
+static const double kd_logtab_host[256] __attribute__((aligned(16))) = KD_LOGTAB_INIT;
+static const double kd_sctab_host[512] __attribute__((aligned(16))) = KD_SCTAB_INIT;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KD_LOGTAB(i) kd_logtab_dev[i]
+#define KD_SCTAB(i) kd_sctab_dev[i]
+#else
+#define KD_LOGTAB(i) kd_logtab_host[i]
+#define KD_SCTAB(i) kd_sctab_host[i]
+#endif
+
+KD_FN double kd_log_u01(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;  /* ln2_hi: 32 trailing zero bits */
+    const double B0 = 0x1.5555555555555p-2, B1 = -0.25, B2 = 0x1.999999999999ap-3, B3 = -0x1.5555555555555p-3,
+                 B4 = 0x1.2492492492492p-3, B5 = -0.125;
+    const uint64_t ux = kd_d2u(x);
+    const uint32_t hx = (uint32_t)(ux >> 32);
+    const uint32_t tmp = hx - 0x3fe60000u;
+    const uint32_t i = (tmp >> 13) & 127u;
+    const int k = (int32_t)tmp >> 20;                     /* arithmetic shift: floor */
+    const uint32_t hz = hx - (tmp & 0xfff00000u);
+    const double z = kd_u2d(((uint64_t)hz << 32) | (ux & 0xffffffffull));
+    const double invc = KD_LOGTAB(2 * i), logc = KD_LOGTAB(2 * i + 1);
+    const double r = kd_fma(z, invc, -1.0);
+    const double dk = (double)k;
+    const double w = kd_fma(dk, ln2_hi, logc);            /* dk*ln2_hi exact */
+    const double hi = w + r;
+    const double lo = kd_fma(dk, ln2_lo, (w - hi) + r);   /* Fast2Sum: |w| >= |r| or w == 0 */
+    const double r2 = r * r;
+    const double q = kd_fma(r2, kd_fma(r2, kd_fma(r, B5, B4), kd_fma(r, B3, B2)), kd_fma(r, B1, B0));
+    return hi + kd_fma(r * r2, q, kd_fma(r2, -0.5, lo));
 }
 
 /* ---------------------------------------------------------------- exp */
@@ -201,37 +253,32 @@ KD_FN double kd_erf(double x)
 }
 
 /* ---------------------------------------------------------------- sin/cos(2*pi*u) */
-/* a = 4u in [0,4); q = nearest integer; r = a - q in [-1/2, 1/2] (exact); y = r*pi/2 in [-pi/4, pi/4];
- * msun __kernel_sin/__kernel_cos polynomials on y; quadrant fix-up by q & 3. */
+/* The angle is taken from the bits of uu = 1 + m 2^-52 (u = uu - 1 + 2^-53 is the kd_u52 uniform): j = leading 8 bits
+ * of m picks the table angle 2 pi (j + 1/2)/256, t = uu - (1 + (j + 1/2)/256) is exact with |t| <= 2^-9, and
+ * y = 2 pi (t + 2^-53), |y| <= 0.0123, is rotated onto the table entry:
+ *   cos(a + y) = C cos y - S sin y,  sin(a + y) = S cos y + C sin y,  sin y / cos y - 1 by short Taylor polynomials
+ * (dropped terms < 2e-20).  Absolute error < 2^-52; no quadrant logic, no division. */
+KD_FN void kd_sincos2pi_bits(uint64_t uu_bits, double* sn, double* cs)
+{
+    const double S1 = -0x1.5555555555555p-3, S2 = 0x1.1111111111111p-7, S3 = -0x1.a01a01a01a01ap-13;
+    const double C2 = 0x1.5555555555555p-5, C3 = -0x1.6c16c16c16c17p-10;
+    const uint32_t uh = (uint32_t)(uu_bits >> 32);
+    const uint32_t j = (uh >> 12) & 255u;
+    const double uu = kd_u2d(uu_bits);
+    const double cc = kd_u2d((uint64_t)((uh & 0xfffff000u) | 0x00000800u) << 32);
+    const double t = uu - cc;
+    const double y = kd_fma(t, KD_TWOPI_HI, kd_fma(t, KD_TWOPI_LO, KD_TWOPI_2M53));
+    const double z = y * y;
+    const double sy = kd_fma(y * z, kd_fma(z, kd_fma(z, S3, S2), S1), y);       /* sin y */
+    const double dc = z * kd_fma(z, kd_fma(z, C3, C2), -0.5);                   /* cos y - 1 */
+    const double C = KD_SCTAB(2 * j), S = KD_SCTAB(2 * j + 1);
+    *cs = kd_fma(-S, sy, kd_fma(C, dc, C));
+    *sn = kd_fma(C, sy, kd_fma(S, dc, S));
+}
+/* double-argument form for u in [0,1): u + (1 - 2^-53) is exact for every kd_u52 value (rounded otherwise) */
 KD_FN void kd_sincos2pi(double u, double* sn, double* cs)
 {
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
-    const double a = 4.0 * u;
-    const int q = (int)(a + 0.5);
-    const double r = a - (double)q;
-    const double y = kd_fma(r, pio2_hi, r * pio2_lo);
-    const double z = y * y;
-    const double w = z * z;
-    /* sin(y) */
-    const double rs = kd_fma(z, kd_fma(z, S4, S3), S2) + z * w * kd_fma(z, S6, S5);
-    const double v = z * y;
-    const double sy = kd_fma(v, kd_fma(z, rs, S1), y);
-    /* cos(y) */
-    const double rc = z * kd_fma(z, kd_fma(z, C3, C2), C1) + w * w * kd_fma(z, kd_fma(z, C6, C5), C4);
-    const double hz = 0.5 * z;
-    const double w1 = 1.0 - hz;
-    const double cy = w1 + (((1.0 - w1) - hz) + z * rc);
-    const int qq = q & 3;
-    const double s_sel = (qq & 1) ? cy : sy;
-    const double c_sel = (qq & 1) ? sy : cy;
-    *sn = (qq == 2 || qq == 3) ? -s_sel : s_sel;
-    *cs = (qq == 1 || qq == 2) ? -c_sel : c_sel;
+    kd_sincos2pi_bits(kd_d2u(u + 0x1.fffffffffffffp-1), sn, cs);
 }
 
 /* ---------------------------------------------------------------- Box-Muller */
@@ -241,11 +288,10 @@ KD_FN void kd_sincos2pi(double u, double* sn, double* cs)
 KD_FN void kd_normal_pair_ex(kd_u32x4 b, double* z0, double* z1, double* u1_out, double* logu1_out)
 {
     const double u1 = kd_u52(b.x, b.y);
-    const double u2 = kd_u52(b.z, b.w);
-    const double lg = kd_log(u1);
+    const double lg = kd_log_u01(u1);
     const double rad = __builtin_sqrt(-2.0 * lg);
     double sn, cs;
-    kd_sincos2pi(u2, &sn, &cs);
+    kd_sincos2pi_bits(kd_unit_bits(b.z, b.w), &sn, &cs);          /* angle 2 pi u2, u2 = kd_u52(z, w) */
     *z0 = rad * cs;
     *z1 = rad * sn;
     *u1_out = u1;            /* = kd_uniform_xy(b): the same words feed the accept uniform of slot ceil(D/2) */

@@ -875,6 +875,7 @@ __global__ void k_math(int op, long long n, const double* in, const double* in2,
     case 3: kd_sincos2pi(in[i], &s, &c); out[i] = c; break;
     case 4: out[i] = __builtin_sqrt(in[i]); break;
     case 6: out[i] = kd_erf(in[i]); break;
+    case 7: out[i] = kd_log_u01(in[i]); break;
     default: out[i] = in[i] / in2[i]; break;
     }
 }

@@ -273,7 +273,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             acc = ratio > 0.0;                                         // MALA.jl:94
             if (!acc && ratio > KD_LOG_UMIN_GUARD) {
                 const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
-                acc = ratio > kd_log(u);
+                acc = ratio > kd_log_u01(u);
             }
         } else {
             // iterate/MH.jl:72-124
@@ -295,7 +295,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             acc = ratio > 0.0;                                         // MH.jl:97
             if (!acc && ratio > KD_LOG_UMIN_GUARD) {
                 const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
-                acc = ratio > kd_log(u);
+                acc = ratio > kd_log_u01(u);
             }
         }
 

@@ -563,7 +563,7 @@ __device__ __forceinline__ bool accept_log_test(const KParams& p, const LaneCtx<
     }
     if (!acc && ratio > KD_LOG_UMIN_GUARD) {   // below the guard no uniform of the stream can accept
         const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
-        acc = ratio > kd_log(u);
+        acc = ratio > kd_log_u01(u);
     }
     return acc;
 }
@@ -734,7 +734,7 @@ __device__ __forceinline__ bool step_slice(const KParams& p, const T& tg, const 
         const double w = (cx.G > 1) ? lane_bcast(w_l, group_base + qo) : w_l;
         const uint32_t base = (uint32_t)i << KLARA_SLICE_ATT_BITS;
         const kd_u32x4 b0 = kd_stream_block(p.seed, gchain, t, base);
-        const double logu = kd_log(kd_uniform_xy(b0)) + lt;                           // :66
+        const double logu = kd_log_u01(kd_uniform_xy(b0)) + lt;                           // :66
         const double ru = kd_uniform_zw(b0);                                          // :71
         double Li = xi - ru * w;                                                      // :72
         double Ri = xi + (1.0 - ru) * w;                                              // :73

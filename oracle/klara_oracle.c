@@ -317,7 +317,7 @@ static int ko_mh(const ko_target_ctx* c, uint64_t chain, uint64_t t, double* x, 
     const double ltp = ko_logtarget(c, xp, scratch);                    /* :81 */
     const double ratio = ltp - *lt;                                     /* :83 */
     int acc = ratio > 0.0;                                              /* :97 */
-    if (!acc) acc = ratio > kd_log(ko_accept_uniform(d->seed, chain, t, D));
+    if (!acc) acc = ratio > kd_log_u01(ko_accept_uniform(d->seed, chain, t, D));
     if (acc) { memcpy(x, xp, sizeof(double) * (size_t)D); *lt = ltp; }  /* :98-100 */
     return acc;
 }
@@ -348,7 +348,7 @@ static int ko_mala(const ko_target_ctx* c, uint64_t chain, uint64_t t, double h,
     }
     ratio -= ko_reduce(c->L, s2, D);                                     /* :92 */
     int acc = ratio > 0.0;                                               /* :94 */
-    if (!acc) acc = ratio > kd_log(ko_accept_uniform(d->seed, chain, t, D));
+    if (!acc) acc = ratio > kd_log_u01(ko_accept_uniform(d->seed, chain, t, D));
     if (acc) {                                                           /* :95-105 */
         memcpy(x, xp, sizeof(double) * (size_t)D);
         memcpy(g, gp, sizeof(double) * (size_t)D);
@@ -405,7 +405,7 @@ static int ko_slice(const ko_target_ctx* c, uint64_t chain, uint64_t t, double* 
     for (int i = 0; i < D; ++i) {                                        /* :65 */
         const uint32_t base = (uint32_t)i << KO_SLICE_ATT_BITS;
         const kd_u32x4 b0 = kd_stream_block(d->seed, chain, t, base);
-        const double logu = kd_log(kd_uniform_xy(b0)) + *lt;             /* :66 */
+        const double logu = kd_log_u01(kd_uniform_xy(b0)) + *lt;             /* :66 */
         const double ru = kd_uniform_zw(b0);                             /* :71 */
         const double w = d->slice_widths[i], xi = x[i];
         double Li = xi - ru * w;                                         /* :72 */
@@ -665,6 +665,7 @@ void ko_math(int op, int64_t n, const double* in, const double* in2, double* out
         case 3: kd_sincos2pi(in[i], &s, &c); out[i] = c; break;
         case 4: out[i] = sqrt(in[i]); break;
         case 6: out[i] = kd_erf(in[i]); break;
+    case 7: out[i] = kd_log_u01(in[i]); break;
         default: out[i] = in[i] / in2[i]; break;
         }
     }

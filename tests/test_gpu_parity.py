@@ -28,6 +28,8 @@ def test_device_math_bit_exact(klib):
         4: np.concatenate([rng.random(n) * 1e3, np.exp(rng.uniform(-700, 700, n))]),
         5: np.exp(rng.uniform(-300, 300, n)),
         6: np.concatenate([rng.uniform(-7, 7, n), [0.0, np.inf, -np.inf]]),
+        7: np.concatenate([(rng.integers(0, 2 ** 52, n).astype(np.float64) + 0.5) * 2.0 ** -52, np.exp(rng.uniform(-700, 700, n)),
+                           [1.0, 2.0 ** -53, 1.0 - 2.0 ** -53, 0.6875, 1.375]]),
     }
     for op, x in sets.items():
         x = np.ascontiguousarray(x)

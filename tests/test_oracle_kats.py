@@ -44,11 +44,19 @@ def test_detmath_accuracy_vs_libm():
     assert _ulps(O.math_op(0, x), np.log(x)) <= 1.0
     x = np.concatenate([rng.uniform(-700, 700, 200000), rng.uniform(-1, 1, 200000)])
     assert _ulps(O.math_op(1, x), np.exp(x)) <= 1.0
-    u = rng.random(400000)
+    # the uniforms' own log (table method, detmath.h kd_log_u01): every kd_u52 value is a positive normal number
+    m = np.concatenate([rng.integers(0, 2 ** 52, 400000), [0, 1, 2 ** 52 - 1, 2 ** 51, 2 ** 51 - 1, 2 ** 52 - 2 ** 30]]).astype(np.uint64)
+    u = (m.astype(np.float64) + 0.5) * 2.0 ** -52          # exactly the kd_u52 lattice
+    assert _ulps(O.math_op(7, u), np.log(u)) <= 1.0
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 100000)), 1 + rng.uniform(-2e-2, 2e-2, 100000)])
+    assert _ulps(O.math_op(7, x), np.log(x)) <= 1.0
+    # sin/cos(2 pi u) on the lattice (table + rotation): absolute error < 2^-52
     ul = u.astype(np.longdouble)
     pi_l = np.longdouble("3.14159265358979323846264338327950288")
     assert np.max(np.abs(O.math_op(2, u) - np.sin(2 * pi_l * ul).astype(np.float64))) <= 2.3e-16
     assert np.max(np.abs(O.math_op(3, u) - np.cos(2 * pi_l * ul).astype(np.float64))) <= 2.3e-16
+    s2, c2 = O.math_op(2, u), O.math_op(3, u)
+    assert np.max(np.abs(s2 * s2 + c2 * c2 - 1.0)) <= 5e-16
     sp = O.math_op(0, [0.0, -1.0, np.inf, 1.0])
     assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and sp[3] == 0.0
     se = O.math_op(1, [0.0, -1e9, 1e9, -745.0])
