@@ -159,6 +159,8 @@ struct LaneCtx {
     bool valid[E];     // element i0+e < D and chain_ok
     int RS;            // row split (logistic target): RS lanes share one chain, each holding ALL E elements (G == 1)
     int rq;            // lane within the row-split group
+    unsigned voff0;    // byte offset of element i0 inside this wave's chain-group window (group-invariant), see GroupWin
+    bool aligned;      // D % E == 0: a lane's E elements are all valid or all padding, and 16-byte aligned
 };
 
 template <int E, int GT, bool RSPL = true>
@@ -178,6 +180,8 @@ __device__ __forceinline__ LaneCtx<E> make_ctx(const KParams& p)
     c.i0 = E * c.q;
 #pragma unroll
     for (int e = 0; e < E; ++e) c.valid[e] = c.chain_ok && (c.i0 + e < p.D);
+    c.voff0 = (unsigned)((grp * p.D + c.i0) * 8);
+    c.aligned = (p.D % E) == 0;
     return c;
 }
 
@@ -210,6 +214,60 @@ __device__ __forceinline__ void load_param(const LaneCtx<E>& c, const gdouble* b
     for (int e = 0; e < E; ++e) {
         v[e] = dflt;
         if (base != nullptr && c.i0 + e < D) v[e] = base[c.i0 + e];
+    }
+}
+
+// ---- chain-group windows ------------------------------------------------------------------------
+// The D-vectors of the chains one wavefront works on are contiguous in HBM: [first chain * D, (first + cpw) * D).
+// k_transitions addresses them through a buffer resource built per group in SGPRs (base = array + first*D, num_records
+// = the bytes of the chains that exist) plus a per-lane byte offset that never changes while the wave walks over its
+// groups.  Padding lanes carry an offset past num_records: the hardware returns 0 for their loads and drops their
+// stores, and the lanes of chains beyond nchains in the last group fall off the end of the window by themselves — so
+// the loop spends no VALU on addresses, bounds selects or exec masks.
+#define KLARA_BUF_OOB 0x80000000u
+typedef unsigned int kd_uint2 __attribute__((ext_vector_type(2)));
+typedef unsigned int kd_uint4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t group_window(const gdouble* base, long long first_chain, int nchains_here, int D)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + first_chain * D), 0, nchains_here * D * 8, 0x00020000);
+}
+template <int E>
+__device__ __forceinline__ unsigned elem_off(const LaneCtx<E>& c, int D, int e, bool store)
+{
+    return (c.i0 + e < D && !(store && c.rq != 0)) ? c.voff0 + 8u * (unsigned)e : KLARA_BUF_OOB;
+}
+template <int E>
+__device__ __forceinline__ void load_win(const LaneCtx<E>& c, __amdgpu_buffer_rsrc_t w, int D, double (&v)[E])
+{
+    if (c.aligned) {
+        const unsigned o = c.i0 < D ? c.voff0 : KLARA_BUF_OOB;
+#pragma unroll
+        for (int e = 0; e < E; e += 2) {
+            const kd_uint4 t = __builtin_amdgcn_raw_buffer_load_b128(w, o + 8u * (unsigned)e, 0, 0);
+            v[e] = __builtin_bit_cast(double, kd_uint2{ t.x, t.y });
+            v[e + 1] = __builtin_bit_cast(double, kd_uint2{ t.z, t.w });
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            v[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(w, elem_off<E>(c, D, e, false), 0, 0));
+    }
+}
+template <int E>
+__device__ __forceinline__ void store_win(const LaneCtx<E>& c, __amdgpu_buffer_rsrc_t w, int D, const double (&v)[E])
+{
+    if (c.aligned) {
+        const unsigned o = (c.i0 < D && c.rq == 0) ? c.voff0 : KLARA_BUF_OOB;
+#pragma unroll
+        for (int e = 0; e < E; e += 2) {
+            const kd_uint2 a = __builtin_bit_cast(kd_uint2, v[e]), b = __builtin_bit_cast(kd_uint2, v[e + 1]);
+            __builtin_amdgcn_raw_buffer_store_b128(kd_uint4{ a.x, a.y, b.x, b.y }, w, o + 8u * (unsigned)e, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, v[e]), w, elem_off<E>(c, D, e, true), 0, 0);
     }
 }
 
@@ -804,10 +862,10 @@ struct ChainRegs {
 };
 
 template <int E, bool NEEDG, bool PLAIN>
-__device__ __forceinline__ void load_chain(const KParams& p, const LaneCtx<E>& cx, ChainRegs<E>& r)
+__device__ __forceinline__ void load_chain(const KParams& p, const LaneCtx<E>& cx, ChainRegs<E>& r, long long first_chain, int here)
 {
-    load_vec<E>(cx, p.X, p.D, r.x);
-    if (NEEDG) load_vec<E>(cx, p.GR, p.D, r.g);
+    load_win<E>(cx, group_window(p.X, first_chain, here, p.D), p.D, r.x);
+    if (NEEDG) load_win<E>(cx, group_window(p.GR, first_chain, here, p.D), p.D, r.g);
     const long long c0 = cx.chain_ok ? cx.chain : 0;
     r.lt = p.LT[c0];
     if (KCNT && !KPOOLED) {              // per-chain tuner state (tuners.jl:5-10) only when something counts
@@ -869,9 +927,11 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
     const bool per_chain_tune = KCNT && !KPOOLED;
     const bool da = KDA;
 
+    // chains of group g: [g*cpw, g*cpw + here), here = the ones that exist (the last group may be short)
+    const auto here_of = [&](long long g) { const long long left = p.nchains - g * cpw; return left < cpw ? (left > 0 ? (int)left : 0) : cpw; };
     ChainRegs<E> cur;
     set_chain<E, GT, RSPL>(p, cx, grp);
-    load_chain<E, NEEDG, PLAIN>(p, cx, cur);
+    load_chain<E, NEEDG, PLAIN>(p, cx, cur, grp * cpw, here_of(grp));
 
     while (true) {
         // prefetch the next group this wave owns
@@ -881,13 +941,18 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
         ChainRegs<E> nxt;
         if (has_next) {
             set_chain<E, GT, RSPL>(p, cxn, grp_next);
-            load_chain<E, NEEDG, PLAIN>(p, cxn, nxt);
+            load_chain<E, NEEDG, PLAIN>(p, cxn, nxt, grp_next * cpw, here_of(grp_next));
         }
+        const long long first_chain = grp * cpw;
+        const int here = here_of(grp);
 
         const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
         // running sums are first needed at the end of a transition: not prefetched (saves 4E VGPRs)
         double sm[E], sq[E];
-        if (do_sum) { load_vec<E>(cx, p.sum, p.D, sm); load_vec<E>(cx, p.sumsq, p.D, sq); }
+        if (do_sum) {
+            load_win<E>(cx, group_window(p.sum, first_chain, here, p.D), p.D, sm);
+            load_win<E>(cx, group_window(p.sumsq, first_chain, here, p.D), p.D, sq);
+        }
         double z[E];
         AccDraw ad = { 0.5, 0.0 };
         const int acc_slot = (p.D + 1) >> 1;
@@ -955,10 +1020,13 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 
         if (nacc != 0 || SAMPLER == KLARA_SAMPLER_SLICE || nsteps > 1) {
             // (with one transition per launch a rejected proposal leaves x, g untouched: skip the write-back)
-            store_vec<E>(cx, p.X, p.D, cur.x);
-            if (NEEDG) store_vec<E>(cx, p.GR, p.D, cur.g);
+            store_win<E>(cx, group_window(p.X, first_chain, here, p.D), p.D, cur.x);
+            if (NEEDG) store_win<E>(cx, group_window(p.GR, first_chain, here, p.D), p.D, cur.g);
         }
-        if (do_sum) { store_vec<E>(cx, p.sum, p.D, sm); store_vec<E>(cx, p.sumsq, p.D, sq); }
+        if (do_sum) {
+            store_win<E>(cx, group_window(p.sum, first_chain, here, p.D), p.D, sm);
+            store_win<E>(cx, group_window(p.sumsq, first_chain, here, p.D), p.D, sq);
+        }
         if (cx.chain_ok && cx.q == 0 && cx.rq == 0) {
             if (nacc != 0) { p.LT[cx.chain] = cur.lt; p.naccept[cx.chain] += nacc; }
             if (da) { p.tune_step[cx.chain] = tn.step; p.da_epsbar[cx.chain] = tn.epsbar; p.da_hbar[cx.chain] = tn.hbar; }
