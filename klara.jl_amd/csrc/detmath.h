@@ -148,15 +148,25 @@ KD_FN double kd_log(double x)
  * the result keeps its relative accuracy as x -> 1.  < 1 ulp (tests/test_oracle_kats.py).  No special cases:
  * zero, subnormal, negative, inf and NaN inputs are outside its contract (kd_log handles those). */
 #include "detmath_tables.h"
-#if defined(__HIPCC__)
-static __device__ const double kd_logtab_dev[256] __attribute__((aligned(16))) = KD_LOGTAB_INIT;
-static __device__ const double kd_sctab_dev[512] __attribute__((aligned(16))) = KD_SCTAB_INIT;
-#endif
 static const double kd_logtab_host[256] __attribute__((aligned(16))) = KD_LOGTAB_INIT;
 static const double kd_sctab_host[512] __attribute__((aligned(16))) = KD_SCTAB_INIT;
+#if defined(__HIPCC__)
+/* On the GPU the tables live in LDS (6 KB per workgroup): the lookups are per-lane gathers, and as DS reads they are
+ * tracked by lgkmcnt, so waiting for one never drains the HBM prefetch that is in flight on vmcnt.  Every kernel that
+ * draws normals or takes a uniform's log calls kd_tables_to_lds() once, first thing. */
+static __device__ const double kd_logtab_dev[256] __attribute__((aligned(16))) = KD_LOGTAB_INIT;
+static __device__ const double kd_sctab_dev[512] __attribute__((aligned(16))) = KD_SCTAB_INIT;
+__shared__ double kd_tab_lds[768] __attribute__((aligned(16)));
+__device__ __forceinline__ void kd_tables_to_lds()
+{
+    for (int i = (int)threadIdx.x; i < 768; i += (int)blockDim.x)
+        kd_tab_lds[i] = i < 256 ? kd_logtab_dev[i] : kd_sctab_dev[i - 256];
+    __syncthreads();
+}
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
-#define KD_LOGTAB(i) kd_logtab_dev[i]
-#define KD_SCTAB(i) kd_sctab_dev[i]
+#define KD_LOGTAB(i) kd_tab_lds[i]
+#define KD_SCTAB(i) kd_tab_lds[256 + (i)]
 #else
 #define KD_LOGTAB(i) kd_logtab_host[i]
 #define KD_SCTAB(i) kd_sctab_host[i]

@@ -865,6 +865,7 @@ extern "C" klara_status klara_selftest_rocrand_blocks(int32_t device, uint64_t s
 
 __global__ void k_math(int op, long long n, const double* in, const double* in2, double* out)
 {
+    kd_tables_to_lds();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s, c;

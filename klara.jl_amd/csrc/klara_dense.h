@@ -149,7 +149,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
     constexpr int NG = 4 * MT;
     double* ldsP = reinterpret_cast<double*>(smem);
     for (int i = threadIdx.x; i < MT * NE * 64; i += blockDim.x) ldsP[i] = Pfrag[i];
-    __syncthreads();
+    kd_tables_to_lds();          // (also the barrier for ldsP)
 
     const MfmaCtx<NE> cx = make_mctx<NE>(p);
     const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
@@ -240,7 +240,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
         } else if (SAMPLER == KLARA_SAMPLER_MALA) {
             // iterate/MALA.jl:78-128
             double z[NE], xc[NE], red[3];
-            const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h), inv_h = 1.0 / h;
+            const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h), inv_h = 1.0 / h, half_inv_h = 0.5 * inv_h;
             mnormals<NE>(cx, p.seed, gchain, t, z);
             double s1 = 0.0;
             {
@@ -252,7 +252,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                     const double mu = xc[e] + halfh * g0[e];           // MALA.jl:83
                     xp[e] = mu + sq * z[e];                            // MALA.jl:84
                     const double q1 = mu - xp[e];
-                    s1 = s1 + (cx.valid[e] ? 0.5 * ((q1 * q1) * inv_h) : 0.0);      // MALA.jl:90
+                    s1 = s1 + (cx.valid[e] ? (q1 * q1) * half_inv_h : 0.0);      // MALA.jl:90
                 }
             }
             dense_grad<NE>(ldsP, cx.lane, xp, gp);                     // MALA.jl:86
@@ -262,7 +262,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 l1 = l1 + (cx.valid[e] ? xp[e] * gp[e] : 0.0);
                 const double mup = xp[e] + halfh * gp[e];              // MALA.jl:91
                 const double q2 = mup - xc[e];
-                s2 = s2 + (cx.valid[e] ? 0.5 * ((q2 * q2) * inv_h) : 0.0);          // MALA.jl:92
+                s2 = s2 + (cx.valid[e] ? (q2 * q2) * half_inv_h : 0.0);          // MALA.jl:92
             }
             red[0] = l1; red[1] = s1; red[2] = s2;
             mreduce<3>(red, cx.lane);

@@ -95,8 +95,9 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v)
 {
     const uint64_t u = kd_d2u(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+    // every lane has a valid source under these controls, so no "old" value needs to be materialised
+    const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)u, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
     return kd_u2d(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 __device__ __forceinline__ double bperm_xor(double v, int lane, int m)
@@ -626,12 +627,18 @@ __device__ __forceinline__ bool accept_log_test(const KParams& p, const LaneCtx<
     return acc;
 }
 
+// What a transition proposed.  With COMMIT = false (one transition per launch, nothing monitored) the step functions
+// leave the chain registers alone and hand the proposal back, and the kernel writes an accepted proposal straight from
+// these registers to HBM — no conditional register copies.
+template <int E>
+struct Proposal { double x[E], g[E], lt; };
+
 // iterate!(job, MH, Multivariate) — iterate/MH.jl:72-124 (symmetric normalised branch)
-template <class T, int E>
+template <class T, int E, bool COMMIT = true>
 __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const LaneCtx<E>& cx,
                                         unsigned long long gchain, unsigned long long t,
                                         const double (&z)[E], const AccDraw& ad, const double (&sigma)[E],
-                                        double (&x)[E], double& lt)
+                                        double (&x)[E], double& lt, Proposal<E>& prop)
 {
     double xp[E], gd[E], red[1];
 #pragma unroll
@@ -642,7 +649,11 @@ __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const Lan
     const double ratio = ltp - lt;                                                    // :83
     bool acc = ratio > 0.0;                                                           // :97
     acc = accept_log_test<E>(p, cx, gchain, t, ad, acc, ratio);
-    if (acc) {                                                                        // :98-100
+    if (!COMMIT) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) prop.x[e] = xp[e];
+        prop.lt = ltp;
+    } else if (acc) {                                                                 // :98-100
 #pragma unroll
         for (int e = 0; e < E; ++e) x[e] = xp[e];
         lt = ltp;
@@ -651,11 +662,11 @@ __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const Lan
 }
 
 // iterate!(job, MALA, Multivariate) — iterate/MALA.jl:78-128
-template <class T, int E, bool PLAIN>
+template <class T, int E, bool PLAIN, bool COMMIT = true>
 __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const LaneCtx<E>& cx,
                                           unsigned long long gchain, unsigned long long t,
                                           const double (&z)[E], const AccDraw& ad, double h,
-                                          double (&x)[E], double (&g)[E], double& lt)
+                                          double (&x)[E], double (&g)[E], double& lt, Proposal<E>& prop)
 {
     double mu[E], xp[E], gp[E], red[3];
     // sqrt(step) and 1/step come precomputed from the host while nothing tunes the step (same IEEE results)
@@ -663,6 +674,7 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
     // abs2(.)/step of MALA.jl:90,92 is evaluated as abs2(.) * (1/step): one f64 division per transition instead
     // of 2 per element (a division is ~70 issue cycles per wave on gfx950); the oracle does the same.
     const double inv_h = KCNT ? 1.0 / h : p.inv_step0;
+    const double half_inv_h = 0.5 * inv_h;                           // 0.5*(abs2(.)*inv_h) == abs2(.)*(0.5*inv_h): halving is exact
 #pragma unroll
     for (int e = 0; e < E; ++e) mu[e] = x[e] + halfh * g[e];                          // :83
 #pragma unroll
@@ -672,10 +684,10 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const double q1 = mu[e] - xp[e];
-        s1 = s1 + 0.5 * ((q1 * q1) * inv_h);                        // :90
+        s1 = s1 + (q1 * q1) * half_inv_h;                        // :90
         const double mup = xp[e] + halfh * gp[e];                                     // :91
         const double q2 = mup - x[e];
-        s2 = s2 + 0.5 * ((q2 * q2) * inv_h);                        // :92
+        s2 = s2 + (q2 * q2) * half_inv_h;                        // :92
     }
     red[1] = s1; red[2] = s2;
     group_allreduce<3>(red, cx.G, cx.lane);
@@ -685,7 +697,11 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
     ratio -= red[2];                                                                  // :92
     bool acc = ratio > 0.0;                                                           // :94
     acc = accept_log_test<E>(p, cx, gchain, t, ad, acc, ratio);
-    if (acc) {                                                                        // :95-105
+    if (!COMMIT) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { prop.x[e] = xp[e]; prop.g[e] = gp[e]; }
+        prop.lt = ltp;
+    } else if (acc) {                                                                 // :95-105
 #pragma unroll
         for (int e = 0; e < E; ++e) { x[e] = xp[e]; g[e] = gp[e]; }
         lt = ltp;
@@ -695,11 +711,11 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
 
 // iterate!(job, HMC, Multivariate) — iterate/HMC.jl:124-201; leapfrog! samplers.jl:122-134;
 // hamiltonian samplers.jl:103
-template <class T, int E, bool PLAIN>
+template <class T, int E, bool PLAIN, bool COMMIT = true>
 __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const LaneCtx<E>& cx,
                                          unsigned long long gchain, unsigned long long t,
                                          const double (&z)[E], const AccDraw& ad, double eps, int nleaps, double& a_out,
-                                         double (&x)[E], double (&g)[E], double& lt)
+                                         double (&x)[E], double (&g)[E], double& lt, Proposal<E>& prop)
 {
     double mom[E], xp[E], gp[E], red[2], dummy;
 #pragma unroll
@@ -762,7 +778,11 @@ __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const La
         ? (cx.G > 1 ? lane_bcast(ad.u, (cx.lane - cx.q) + acc_owner) : ad.u)
         : kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
     const bool acc = u < a;                                                           // :165
-    if (acc) {                                                                        // :166-176
+    if (!COMMIT) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { prop.x[e] = xp[e]; prop.g[e] = gp[e]; }
+        prop.lt = ltp;
+    } else if (acc) {                                                                 // :166-176
 #pragma unroll
         for (int e = 0; e < E; ++e) { x[e] = xp[e]; g[e] = gp[e]; }
         lt = ltp;
@@ -904,7 +924,10 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
     constexpr bool ONESTEP = (MODE & 4) != 0;          // exactly one transition per launch (= one iterate!)
     const int nsteps = ONESTEP ? 1 : kl.nsteps;
     constexpr bool RSPL = TARGET == KLARA_TARGET_LOGISTIC;
+    // single unmonitored transition: an accepted proposal goes from the proposal registers straight to HBM
+    constexpr bool DIRECT = ONESTEP && NOMON && SAMPLER != KLARA_SAMPLER_SLICE;
     const KParams& p = *pp;
+    kd_tables_to_lds();
     guchar* const accept_out = (!NOMON && p.accept != nullptr) ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
     gdouble* const hist = NOMON ? nullptr : p.hist;
     gdouble* const hist_lt = NOMON ? nullptr : p.hist_lt;
@@ -968,22 +991,24 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
         int sphase = kl.save_phase0;
         long long scol = kl.save_col0;
         unsigned long long nacc = 0;
-        bool stuck = false;
+        bool stuck = false, last_acc = false;
+        Proposal<E> prop;
 
         for (int s = 0; s < nsteps; ++s) {
             const unsigned long long t = kl.t0 + (unsigned long long)s;
             if (KCNT) tune_count_proposal(p, tn);
             bool acc;
-            if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E>(p, tg, cx, gchain, t, z, ad, vp, cur.x, cur.lt);
-            else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E, PLAIN>(p, tg, cx, gchain, t, z, ad, tn.step, cur.x, cur.g, cur.lt);
+            if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E, !DIRECT>(p, tg, cx, gchain, t, z, ad, vp, cur.x, cur.lt, prop);
+            else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E, PLAIN, !DIRECT>(p, tg, cx, gchain, t, z, ad, tn.step, cur.x, cur.g, cur.lt, prop);
             else if (SAMPLER == KLARA_SAMPLER_HMC) {
                 double a_prob = 0.0;
-                acc = step_hmc<T, E, PLAIN>(p, tg, cx, gchain, t, z, ad, tn.step, da ? da_nleaps(p, tn.step) : p.nleaps, a_prob,
-                                     cur.x, cur.g, cur.lt);
+                acc = step_hmc<T, E, PLAIN, !DIRECT>(p, tg, cx, gchain, t, z, ad, tn.step, da ? da_nleaps(p, tn.step) : p.nleaps, a_prob,
+                                     cur.x, cur.g, cur.lt, prop);
                 if (da) da_update(p, tn, (long long)t + 1, a_prob);                   // iterate/HMC.jl:225-249
             }
             else acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, cur.x, cur.lt, stuck);
             nacc += acc ? 1ull : 0ull;
+            last_acc = acc;
             if (KCNT && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;   // the slice sampler never counts accepts
             if (accept_out != nullptr && cx.chain_ok && cx.q == 0 && cx.rq == 0)
                 accept_out[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
@@ -1018,7 +1043,13 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             if (!ONESTEP && NEEDZ && s + 1 < nsteps) lane_normals<E>(cx, p.seed, gchain, t + 1, z, ad, acc_slot);
         }
 
-        if (nacc != 0 || SAMPLER == KLARA_SAMPLER_SLICE || nsteps > 1) {
+        if (DIRECT) {
+            if (last_acc) {
+                store_win<E>(cx, group_window(p.X, first_chain, here, p.D), p.D, prop.x);
+                if (NEEDG) store_win<E>(cx, group_window(p.GR, first_chain, here, p.D), p.D, prop.g);
+                cur.lt = prop.lt;
+            }
+        } else if (nacc != 0 || SAMPLER == KLARA_SAMPLER_SLICE || nsteps > 1) {
             // (with one transition per launch a rejected proposal leaves x, g untouched: skip the write-back)
             store_win<E>(cx, group_window(p.X, first_chain, here, p.D), p.D, cur.x);
             if (NEEDG) store_win<E>(cx, group_window(p.GR, first_chain, here, p.D), p.D, cur.g);
@@ -1074,6 +1105,7 @@ __global__ __launch_bounds__(256) void k_init(const KParams p, int needgrad)
 template <int E, int GT>
 __global__ __launch_bounds__(256) void k_init_normal(const KParams p)
 {
+    kd_tables_to_lds();
     const LaneCtx<E> cx = make_ctx<E, GT>(p);
     double z[E];
     AccDraw ad;

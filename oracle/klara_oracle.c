@@ -334,17 +334,17 @@ static int ko_mala(const ko_target_ctx* c, uint64_t chain, uint64_t t, double h,
     /* DEVIATION from the literal `abs2.(...)/step` of MALA.jl:90,92: the quotient is formed as abs2(.)*(1/step)
      * (<= 1 ulp per element from the literal expression) because the gfx950 kernels do so to save two f64
      * divisions per element; the reference's own summation order is unspecified anyway (header). */
-    const double inv_h = 1.0 / h;
+    const double inv_h = 1.0 / h, half_inv_h = 0.5 * inv_h;   /* 0.5*(abs2(.)/h) as abs2(.)*(0.5/h): the halving is exact */
     for (int i = 0; i < D; ++i) mu[i] = x[i] + halfh * g[i];            /* :83 */
     for (int i = 0; i < D; ++i) xp[i] = mu[i] + sq * z[i];              /* :84 */
     const double ltp = ko_uptograd(c, xp, gp, scratch);                  /* :86 */
     double ratio = ltp - *lt;                                            /* :88 */
-    for (int i = 0; i < D; ++i) { const double q = mu[i] - xp[i]; s1[i] = 0.5 * ((q * q) * inv_h); }
+    for (int i = 0; i < D; ++i) { const double q = mu[i] - xp[i]; s1[i] = (q * q) * half_inv_h; }
     ratio += ko_reduce(c->L, s1, D);                                     /* :90 */
     for (int i = 0; i < D; ++i) {
         const double mup = xp[i] + halfh * gp[i];                        /* :91 */
         const double q = mup - x[i];
-        s2[i] = 0.5 * ((q * q) * inv_h);
+        s2[i] = (q * q) * half_inv_h;
     }
     ratio -= ko_reduce(c->L, s2, D);                                     /* :92 */
     int acc = ratio > 0.0;                                               /* :94 */
