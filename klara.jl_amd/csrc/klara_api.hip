@@ -56,6 +56,18 @@ static int cnt_predicate(const klara_desc& d)
 
 static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// layout kind 3 serves the jobs whose transition is pure elementwise work plus three sums (see klara_diagt.h)
+static bool diagt_eligible(const klara_desc& d)
+{
+    if (d.target != KLARA_TARGET_GAUSS_DIAG || d.sampler == KLARA_SAMPLER_SLICE) return false;
+    if ((d.ndims & 1) || d.ndims > 16 * KLARA_DIAGT_NP_MAX) return false;
+    const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
+    if (!plain || (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0) return false;
+    if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
+    if (getenv("KLARA_LAYOUT_E")) return false;
+    return true;
+}
+
 static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E)
 {
     const int D = d.ndims;
@@ -70,6 +82,16 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
         *G = 1;   // every lane holds the whole parameter vector; klara_create may turn on the row split (kind 2)
         if (D <= 2) *E = 2; else if (D <= 4) *E = 4; else if (D <= 8) *E = 8; else return KLARA_ERR_UNSUPPORTED;
         return KLARA_OK;
+    }
+    // diagonal Gaussian, nothing tunes and nothing but the accept mask is monitored: the pair-transposed layout
+    // (klara_diagt.h), Q = 8 lanes per chain, NP element pairs per lane
+    if (diagt_eligible(d)) {
+        const int need = (D + 15) / 16;
+        int np = 0;
+#define X(NP_) if (np == 0 && NP_ >= need) np = NP_;
+        KLARA_DIAGT_NP_MENU_DO(X)
+#undef X
+        if (np != 0) { *kind = 3; *G = KLARA_DIAGT_Q; *E = 2 * np; return KLARA_OK; }
     }
     // diagonal Gaussian: E elements per lane, G lanes; optional override for layout experiments
     // D <= 128: E = 2 or 4, whichever wastes fewer lanes; on a tie E = 4 (twice the chains per wavefront
@@ -411,6 +433,7 @@ static klara_status init_common(klara_handle* h)
     KParams p = make_params(h);
     hipError_t e;
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, needgrad, grid_for(h), st);
+    else if (h->kind == 3) e = klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st);
     else if (d.target == KLARA_TARGET_GAUSS_DIAG)
         e = launch_init_t<KLARA_TARGET_GAUSS_DIAG>(p, h->E, h->G, needgrad, grid_for(h), lds_for(h), st);
     else if (d.target == KLARA_TARGET_HIER_NORMAL)
@@ -444,7 +467,7 @@ extern "C" klara_status klara_init_state_normal(klara_handle* h)
     KParams p = make_params(h);
     const int D = h->d.ndims;
     int E = 2, G = pow2ceil((D + 1) / 2);
-    if (h->kind != 1) { E = h->E; G = h->G; }
+    if (h->kind == 0 || h->kind == 2) { E = h->E; G = h->G; }
     p.G = G; p.rs = 1;     // the init stream is drawn without the row split (same values, any layout)
     const long long cpw = 64 / G, waves = (h->d.nchains + cpw - 1) / cpw;
     const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
@@ -473,6 +496,15 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
     int mode = (plain ? 1 : 0) | ((plain && d.monitor == 0) ? 2 : 0);         // 3: no monitors either
     if (mode == 3 && kl.nsteps == 1) mode = 7;                                 // one iterate! per launch
     if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, h->E, h->Pfrag, grid_for(h), h->stream);
+    if (h->kind == 3) {
+        const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
+        const dim3 grid = grid_for_transitions(h);
+        switch (d.sampler) {
+        case KLARA_SAMPLER_MH: return klara_launch_diagt_mh(p, kl, h->E / 2, onestep, unitw, grid, h->stream);
+        case KLARA_SAMPLER_MALA: return klara_launch_diagt_mala(p, kl, h->E / 2, onestep, unitw, grid, h->stream);
+        default: return klara_launch_diagt_hmc(p, kl, h->E / 2, onestep, unitw, grid, h->stream);
+        }
+    }
     switch (d.sampler) {
     case KLARA_SAMPLER_MH: return klara_launch_mh(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
     case KLARA_SAMPLER_MALA: return klara_launch_mala(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);

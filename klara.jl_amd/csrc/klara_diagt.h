@@ -1,0 +1,301 @@
+// klara_diagt.h — "pair-transposed" transition kernels for the diagonal Gaussian target (layout kind 3).
+//
+// The reference evaluates one chain's iterate! as whole-vector Julia expressions (MH.jl:72-124, MALA.jl:78-128,
+// HMC.jl:124-201).  For lt = c - sum_i w_i (x_i - mu_i)^2 every one of those expressions is elementwise except the
+// three sums that enter the Metropolis ratio, so a chain needs only a handful of lanes: here Q lanes (Q = 8) share a
+// chain and a wavefront carries 64/Q chains.  Lane q of a chain owns the element PAIRS P = p*Q + q, p = 0..NP-1
+// (elements 2P, 2P+1): a pair is one Philox block / one Box-Muller evaluation (element i <- slot i>>1, cos for even i,
+// sin for odd i — the same stream as every other layout) and one 16-byte access, and for fixed p the Q lanes of a chain
+// touch Q*16 contiguous bytes.  Against the group layout (32 lanes x 4 elements at D = 100) the per-wavefront fixed
+// work — cross-lane reductions, the accept test, addressing, the loop — is shared by 8 chains instead of 2, the
+// reduction tree is 3 DPP steps instead of 5, and 89% instead of 78% of the lane slots hold real elements.
+//
+// Scope: nothing tunes and nothing is monitored except (optionally) the accept mask, i.e. the VanillaMCTuner jobs that
+// the throughput figures are quoted on; D even, D <= 16*NP.  Everything else runs on the group layout (klara_kernels.h).
+// Sums are taken per lane in ascending element order and then over the Q lanes by an xor butterfly — the oracle mirrors
+// this order for layout kind 3 (oracle/klara_oracle.c ko_reduce).
+#pragma once
+#include "klara_kernels.h"
+
+#define KLARA_DIAGT_Q 8
+
+template <int NP, int Q>
+struct PairCtx {
+    int lane, q, cw;        // lane in the wavefront, lane within the chain, chain within the wavefront
+    unsigned off0;          // byte offset of pair p = 0 inside the wavefront's chain window; pair p adds p*Q*16
+    bool last_ok;           // the last pair (p = NP-1) holds real elements (all earlier pairs always do)
+};
+
+template <int NP, int Q>
+__device__ __forceinline__ PairCtx<NP, Q> make_pctx(int D)
+{
+    PairCtx<NP, Q> c;
+    c.lane = threadIdx.x & 63;
+    c.q = c.lane & (Q - 1);
+    c.cw = c.lane / Q;
+    c.off0 = (unsigned)((c.cw * D + 2 * c.q) * 8);
+    c.last_ok = 2 * ((NP - 1) * Q + c.q) < D;
+    return c;
+}
+template <int NP, int Q>
+__device__ __forceinline__ unsigned pair_off(const PairCtx<NP, Q>& c, int p)
+{
+    const unsigned o = c.off0 + (unsigned)(p * Q * 16);
+    return (p == NP - 1 && !c.last_ok) ? KLARA_BUF_OOB : o;
+}
+template <int NP, int Q>
+__device__ __forceinline__ void load_pairs(const PairCtx<NP, Q>& c, __amdgpu_buffer_rsrc_t w, double (&v)[2 * NP])
+{
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const kd_uint4 t = __builtin_amdgcn_raw_buffer_load_b128(w, pair_off<NP, Q>(c, p), 0, 0);
+        v[2 * p] = __builtin_bit_cast(double, kd_uint2{ t.x, t.y });
+        v[2 * p + 1] = __builtin_bit_cast(double, kd_uint2{ t.z, t.w });
+    }
+}
+template <int NP, int Q>
+__device__ __forceinline__ void store_pairs(const PairCtx<NP, Q>& c, __amdgpu_buffer_rsrc_t w, const double (&v)[2 * NP])
+{
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const kd_uint2 a = __builtin_bit_cast(kd_uint2, v[2 * p]), b = __builtin_bit_cast(kd_uint2, v[2 * p + 1]);
+        __builtin_amdgcn_raw_buffer_store_b128(kd_uint4{ a.x, a.y, b.x, b.y }, w, pair_off<NP, Q>(c, p), 0, 0);
+    }
+}
+// per-element parameter vector (weights, means, proposal scales): element 2P+h of the lane's pair p
+template <int NP, int Q>
+__device__ __forceinline__ void load_pair_param(const PairCtx<NP, Q>& c, const gdouble* base, int D, double dflt, double (&v)[2 * NP])
+{
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int i = 2 * (p * Q + c.q);
+        v[2 * p] = dflt; v[2 * p + 1] = dflt;
+        if (base != nullptr && i < D) { v[2 * p] = base[i]; v[2 * p + 1] = base[i + 1]; }
+    }
+}
+
+// proposal normals of pair p for transition t; padding pairs get z = 0 (their x, g, parameters are 0 / defaults, so
+// every term they contribute is exactly 0).  (u1, log u1) of the block are handed back: the last pair's are the accept
+// draw when the slot ceil(D/2) falls on it (see AccDraw in klara_kernels.h).
+template <int NP, int Q>
+__device__ __forceinline__ void pair_normals(const PairCtx<NP, Q>& c, unsigned long long seed, unsigned long long gchain,
+                                             unsigned long long t, int p, double& z0, double& z1, double& u1, double& lg1)
+{
+    kd_normal_pair_ex(kd_stream_block(seed, gchain, t, (uint32_t)(p * Q + c.q)), &z0, &z1, &u1, &lg1);
+    if (p == NP - 1 && !c.last_ok) { z0 = 0.0; z1 = 0.0; }
+}
+
+// The diagonal target on one element (klara_kernels.h DiagTarget, same operations in the same order).  UNITW: w = 1 and
+// mu = 0 (README.md:23 -dot(z,z)): x - 0, 1*(.) and (-2*1)*(.) are exact, so dropping them changes no bit.
+template <bool UNITW>
+__device__ __forceinline__ void diag_elem(double x, double w, double m, double& term, double& grad)
+{
+    const double dd = UNITW ? x : x - m;
+    term = UNITW ? dd * dd : w * (dd * dd);
+    grad = UNITW ? -2.0 * dd : (-2.0 * w) * dd;
+}
+
+template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW>
+__global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? 3 : 2) : 1))
+void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
+{
+    constexpr int E = 2 * NP, CPW = 64 / Q;
+    constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;
+    const KParams& p = *pp;
+    kd_tables_to_lds();
+    const int D = p.D;
+    const PairCtx<NP, Q> cx = make_pctx<NP, Q>(D);
+    const int nsteps = ONESTEP ? 1 : kl.nsteps;
+    guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
+
+    double w[E], mu[E], sig[E];          // (unused ones vanish: UNITW needs no w/mu, only MH has proposal scales)
+    if (!UNITW) {
+        load_pair_param<NP, Q>(cx, p.gw, D, 1.0, w);
+        load_pair_param<NP, Q>(cx, p.gmu, D, 0.0, mu);
+    }
+    if (SAMPLER == KLARA_SAMPLER_MH) load_pair_param<NP, Q>(cx, p.vecparam, D, 1.0, sig);
+    const double gconst = p.gconst;
+
+    // accept draw: slot S = ceil(D/2) = D/2.  (NP-1)*Q < D/2 <= NP*Q, so when the layout has padding (D/2 < NP*Q) the
+    // slot is the last pair of lane S % Q and its Box-Muller already formed u and log(u).
+    const int acc_slot = (D + 1) >> 1;
+    const bool acc_free = acc_slot < NP * Q;
+    const int acc_lane = (cx.lane - cx.q) + (acc_slot & (Q - 1));
+
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    const long long wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    for (long long grp = wave0; grp * CPW < p.nchains; grp += nwaves) {
+        const long long first_chain = grp * CPW;
+        const long long left = p.nchains - first_chain;
+        const int here = left < CPW ? (int)left : CPW;
+        const bool chain_ok = cx.cw < here;
+        const long long chain = first_chain + cx.cw;
+        const unsigned long long gchain = (unsigned long long)(p.chain_offset + chain);
+        const __amdgpu_buffer_rsrc_t wx = group_window(p.X, first_chain, here, D);
+        const __amdgpu_buffer_rsrc_t wg = group_window(p.GR, first_chain, here, D);
+
+        double x[E], g[E];
+        load_pairs<NP, Q>(cx, wx, x);
+        if (NEEDG) load_pairs<NP, Q>(cx, wg, g);
+        double lt = p.LT[chain_ok ? chain : 0];
+        unsigned long long nacc = 0;
+
+        for (int s = 0; s < nsteps; ++s) {
+            const unsigned long long t = kl.t0 + (unsigned long long)s;
+            double xp[E], gp[E];
+            double red[3] = { 0.0, 0.0, 0.0 }, red1[1], red2[2];
+            double u_last = 0.5, lg_last = 0.0;
+            bool acc;
+            double ltp;
+
+            if (SAMPLER == KLARA_SAMPLER_MH) {                                     // iterate/MH.jl:72-124
+#pragma unroll
+                for (int pi = 0; pi < NP; ++pi) {
+                    double z[2];
+                    pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z[0], z[1], u_last, lg_last);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int e = 2 * pi + h;
+                        xp[e] = x[e] + sig[e] * z[h];                                          // MH.jl:79
+                        double term, gd;
+                        diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gd);   // :81
+                        red[0] = red[0] + term;
+                    }
+                }
+                red1[0] = red[0];
+                group_allreduce<1>(red1, Q, cx.lane);
+                ltp = gconst - red1[0];
+                const double ratio = ltp - lt;                                                 // :83
+                acc = ratio > 0.0;                                                             // :97
+                if (acc_free) acc = acc || ratio > lane_bcast(lg_last, acc_lane);
+                else if (!acc && ratio > KD_LOG_UMIN_GUARD)
+                    acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot)));
+            } else if (SAMPLER == KLARA_SAMPLER_MALA) {                            // iterate/MALA.jl:78-128
+                const double h_ = p.step0, halfh = 0.5 * h_, sq = p.sqrt_step0, half_inv_h = 0.5 * p.inv_step0;
+#pragma unroll
+                for (int pi = 0; pi < NP; ++pi) {
+                    double z[2];
+                    pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z[0], z[1], u_last, lg_last);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int e = 2 * pi + h;
+                        const double m_ = x[e] + halfh * g[e];                                 // :83
+                        xp[e] = m_ + sq * z[h];                                                // :84
+                        double term;
+                        diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gp[e]);   // :86
+                        red[0] = red[0] + term;
+                        const double q1 = m_ - xp[e];
+                        red[1] = red[1] + (q1 * q1) * half_inv_h;                              // :90
+                        const double mup = xp[e] + halfh * gp[e];                              // :91
+                        const double q2 = mup - x[e];
+                        red[2] = red[2] + (q2 * q2) * half_inv_h;                              // :92
+                    }
+                }
+                group_allreduce<3>(red, Q, cx.lane);
+                ltp = gconst - red[0];
+                double ratio = ltp - lt;                                                       // :88
+                ratio += red[1];                                                               // :90
+                ratio -= red[2];                                                               // :92
+                acc = ratio > 0.0;                                                             // :94
+                if (acc_free) acc = acc || ratio > lane_bcast(lg_last, acc_lane);
+                else if (!acc && ratio > KD_LOG_UMIN_GUARD)
+                    acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot)));
+            } else {                                                               // iterate/HMC.jl:124-201
+                const double eps = p.step0, halfe = 0.5 * eps;
+                double mom[E];
+                double k0[1] = { 0.0 };
+#pragma unroll
+                for (int pi = 0; pi < NP; ++pi) {
+                    pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, mom[2 * pi], mom[2 * pi + 1], u_last, lg_last);   // :135
+                    k0[0] = k0[0] + mom[2 * pi] * mom[2 * pi];
+                    k0[0] = k0[0] + mom[2 * pi + 1] * mom[2 * pi + 1];
+                }
+                group_allreduce<1>(k0, Q, cx.lane);
+                const double H0 = lt - 0.5 * k0[0];                                            // :137
+#pragma unroll
+                for (int e = 0; e < E; ++e) { xp[e] = x[e]; gp[e] = g[e]; }                    // :139-140
+                for (int l = 0; l < p.nleaps; ++l) {                                           // :146-155, samplers.jl:122-134
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        mom[e] = mom[e] + halfe * gp[e];
+                        xp[e] = xp[e] + eps * mom[e];
+                        double term;
+                        diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gp[e]);
+                        mom[e] = mom[e] + halfe * gp[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    double term, gd;
+                    diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gd);   // :157
+                    red[0] = red[0] + term;
+                    red[1] = red[1] + mom[e] * mom[e];
+                }
+                red2[0] = red[0]; red2[1] = red[1];
+                group_allreduce<2>(red2, Q, cx.lane);
+                ltp = gconst - red2[0];
+                const double H1 = ltp - 0.5 * red2[1];                                         // :159
+                const double ratio = H1 - H0;                                                  // :161
+                const double ex = kd_exp(ratio);
+                const double a = 1.0 < ex ? 1.0 : ex;                                          // :163
+                const double u = acc_free ? lane_bcast(u_last, acc_lane)
+                                          : kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot));
+                acc = u < a;                                                                   // :165
+            }
+
+            if (accept_out != nullptr && chain_ok && cx.q == 0) accept_out[(long long)s * p.nchains + chain] = acc ? 1 : 0;
+            if (ONESTEP) {
+                if (acc) {                               // accepted proposal: registers -> HBM, nothing else moves
+                    store_pairs<NP, Q>(cx, wx, xp);
+                    if (NEEDG) store_pairs<NP, Q>(cx, wg, gp);
+                    if (chain_ok && cx.q == 0) { p.LT[chain] = ltp; p.naccept[chain] += 1ull; }
+                }
+            } else {
+                nacc += acc ? 1ull : 0ull;
+                if (acc) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { x[e] = xp[e]; if (NEEDG) g[e] = gp[e]; }
+                    lt = ltp;
+                }
+            }
+        }
+        if (!ONESTEP && nacc != 0) {
+            store_pairs<NP, Q>(cx, wx, x);
+            if (NEEDG) store_pairs<NP, Q>(cx, wg, g);
+            if (chain_ok && cx.q == 0) { p.LT[chain] = lt; p.naccept[chain] += nacc; }
+        }
+    }
+}
+
+// initialize!(pstate, parameter, sampler) for layout kind 3: lt (and the gradient) at X, finiteness check
+template <int NP, int Q>
+__global__ __launch_bounds__(256) void k_diagt_init(const KParams p, int needgrad)
+{
+    constexpr int E = 2 * NP, CPW = 64 / Q;
+    const int D = p.D;
+    const PairCtx<NP, Q> cx = make_pctx<NP, Q>(D);
+    const long long grp = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long first_chain = grp * CPW;
+    const long long left = p.nchains - first_chain;
+    const int here = left < CPW ? (left > 0 ? (int)left : 0) : CPW;
+    const bool chain_ok = cx.cw < here;
+    const long long chain = first_chain + cx.cw;
+    double w[E], mu[E], x[E], g[E], red[1] = { 0.0 };
+    load_pair_param<NP, Q>(cx, p.gw, D, 1.0, w);
+    load_pair_param<NP, Q>(cx, p.gmu, D, 0.0, mu);
+    load_pairs<NP, Q>(cx, group_window(p.X, first_chain, here, D), x);
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        double term;
+        diag_elem<false>(x[e], w[e], mu[e], term, g[e]);
+        red[0] = red[0] + term;
+        bad = bad || !kfinite(g[e]);
+    }
+    group_allreduce<1>(red, Q, cx.lane);
+    const double lt = p.gconst - red[0];
+    bad = chain_ok && ((needgrad && bad) || !kfinite(lt));
+    if (needgrad) store_pairs<NP, Q>(cx, group_window(p.GR, first_chain, here, D), g);
+    if (chain_ok && cx.q == 0) p.LT[chain] = lt;
+    if (bad) atomicMax((int*)p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
+}

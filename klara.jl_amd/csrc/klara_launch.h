@@ -1,6 +1,7 @@
 // klara_launch.h — launcher prototypes implemented by the per-sampler translation units
 #pragma once
 #include "klara_kernels.h"
+#include "klara_diagt.h"
 
 // group-layout transition kernels; target in {GAUSS_DIAG, LOGISTIC}; E in {2,4,8}; G = lanes per chain
 hipError_t klara_launch_mh(const KParams* p, const KLaunch& kl, int mode, int target, int E, int G, dim3 grid, size_t lds,
@@ -18,6 +19,33 @@ hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag
                                    hipStream_t st);
 hipError_t klara_launch_mfma_probe(const double* A, const double* B, const double* C, double* D,
                                    hipStream_t st);
+
+// pair-transposed diagonal-Gaussian kernels (layout kind 3, klara_diagt.h); NP in KLARA_DIAGT_NP_MENU, Q = KLARA_DIAGT_Q
+hipError_t klara_launch_diagt_mh(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_mala(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_hmc(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_init(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
+// pairs per lane the kernels are instantiated for (D <= 16*NP); a job takes the smallest one that fits
+#define KLARA_DIAGT_NP_MENU_DO(X) X(1) X(2) X(4) X(6) X(7) X(8)
+#define KLARA_DIAGT_NP_MAX 8
+
+#define KLARA_DIAGT_CASE(S, NP_)                                                                                   \
+    case NP_:                                                                                                      \
+        if (onestep && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, true, true>), grid, blk, 0, st, p, kl);        \
+        else if (onestep) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, true, false>), grid, blk, 0, st, p, kl);           \
+        else if (unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true>), grid, blk, 0, st, p, kl);             \
+        else hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false>), grid, blk, 0, st, p, kl);                       \
+        break;
+#define KLARA_DISPATCH_DIAGT(S)                                                                                    \
+    do {                                                                                                           \
+        const dim3 blk(256);                                                                                       \
+        switch (NP) {                                                                                              \
+            KLARA_DIAGT_CASE(S, 1) KLARA_DIAGT_CASE(S, 2) KLARA_DIAGT_CASE(S, 4)                                   \
+            KLARA_DIAGT_CASE(S, 6) KLARA_DIAGT_CASE(S, 7) KLARA_DIAGT_CASE(S, 8)                                   \
+            default: return hipErrorInvalidValue;                                                                  \
+        }                                                                                                          \
+        return hipGetLastError();                                                                                  \
+    } while (0)
 
 // mode 7: mode 3 with exactly one transition per launch; mode 3: nothing counts/tunes and nothing is monitored;
 // mode 1: nothing counts/tunes; mode 0: general

@@ -55,7 +55,8 @@ static double ko_reduce(const ko_layout* L, const double* terms, int D)
     const int G = (L->kind == 1) ? 4 : (L->kind == 2 ? 1 : L->G);
     for (int l = 0; l < G; ++l) part[l] = 0.0;
     for (int i = 0; i < D; ++i) {
-        const int lane = (L->kind == 1) ? (i & 3) : (L->kind == 2 ? 0 : i / L->E);
+        /* kind 3 (pair-transposed, klara_diagt.h): element pair P = i>>1 belongs to lane P % G */
+        const int lane = (L->kind == 1) ? (i & 3) : (L->kind == 2 ? 0 : (L->kind == 3 ? ((i >> 1) % L->G) : i / L->E));
         part[lane] = part[lane] + terms[i];
     }
     for (int m = 1; m < G; m <<= 1) {

@@ -142,6 +142,35 @@ def make_case(name):
         X, y = swiss_data()
         c = dict(sampler=L.SAMPLER_SLICE, target=K.LogisticTarget(X, y, 100.0), nchains=70, nsteps=6, burnin=0,
                  slice_widths=np.full(4, 1.0), x0=0.1 * np.random.default_rng(3).standard_normal((70, 4)))
+    # ---- pair-transposed layout (kind 3): VanillaMCTuner jobs on diagonal Gaussians that monitor at most the accept mask
+    elif name == "dt_mala_d100":       # BASELINE cfg 2 shape; 130 chains = 16 full wavefront groups + 2 chains
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=130, nsteps=40, burnin=0, driftstep=0.9)
+    elif name == "dt_mala_d100_small_step":
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=67, nsteps=40, burnin=0, driftstep=0.05)
+    elif name == "dt_mala_d112_full":  # D/2 = 7*8: no padding pair, the accept uniform takes the explicit path
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(112), nchains=19, nsteps=30, burnin=0, driftstep=0.04)
+    elif name == "dt_mala_mvnormal_d30":
+        mu = np.linspace(-1, 2, 30); sg = np.linspace(0.6, 1.7, 30)
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.mvnormal(mu, sg), nchains=45, nsteps=50, burnin=0, driftstep=0.3)
+    elif name == "dt_mala_d2":
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(2), nchains=100, nsteps=60, burnin=0, driftstep=0.8)
+    elif name == "dt_mh_d100":
+        c = dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(100), nchains=70, nsteps=60, burnin=0,
+                 mh_sigma=np.full(100, 0.1))
+    elif name == "dt_mh_mvnormal_d8":
+        mu = np.linspace(-2, 3, 8); sg = np.linspace(0.5, 2.0, 8)
+        c = dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.mvnormal(mu, sg), nchains=33, nsteps=80, burnin=0,
+                 mh_sigma=sg * 0.8)
+    elif name == "dt_hmc_d100":
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.negdot(100), nchains=70, nsteps=20, burnin=0,
+                 leapstep=0.1, nleaps=10)
+    elif name == "dt_hmc_d128_full":   # D/2 = 8*8: no padding pair
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.negdot(128), nchains=21, nsteps=15, burnin=0,
+                 leapstep=0.3, nleaps=5)
+    elif name == "dt_hmc_mvnormal_d96":
+        mu = np.linspace(-1, 1, 96); sg = np.linspace(0.7, 1.4, 96)
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.mvnormal(mu, sg), nchains=29, nsteps=15, burnin=0,
+                 leapstep=0.15, nleaps=7)
     else:
         raise KeyError(name)
     c.setdefault("x0", None)
@@ -149,6 +178,9 @@ def make_case(name):
     c["name"] = name
     return c
 
+
+DIAGT_CASES = ["dt_mala_d100", "dt_mala_d100_small_step", "dt_mala_d112_full", "dt_mala_mvnormal_d30", "dt_mala_d2",
+               "dt_mh_d100", "dt_mh_mvnormal_d8", "dt_hmc_d100", "dt_hmc_d128_full", "dt_hmc_mvnormal_d96"]
 
 ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_small_step", "mala_d3_tuned",
              "mala_d300", "hmc_d100", "hmc_d10_tuned_pooled", "hmc_dense_d100", "hmc_dense_d37", "mala_dense_d100",

@@ -61,9 +61,19 @@ def load() -> C.CDLL:
     return lib
 
 
-def default_layout(target_kind: int, ndims: int, ndata: int = 0):
-    """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box)."""
+DIAGT_NP_MENU = (1, 2, 4, 6, 7, 8)      # klara_launch.h KLARA_DIAGT_NP_MENU_DO
+DIAGT_Q = 8
+
+
+def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, plain=False, monitor=None):
+    """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box).
+    `sampler`, `plain` (VanillaMCTuner, not verbose) and `monitor` are only needed to recognise the pair-transposed
+    layout (kind 3) of diagonal-Gaussian jobs that monitor at most the accept mask."""
     d = int(ndims)
+    if (target_kind == L.TARGET_GAUSS_DIAG and sampler is not None and sampler != L.SAMPLER_SLICE and plain
+            and monitor is not None and (monitor & ~L.MON_ACCEPT) == 0 and d % 2 == 0 and d <= 16 * DIAGT_NP_MENU[-1]):
+        np_ = next(v for v in DIAGT_NP_MENU if v >= (d + 15) // 16)
+        return (3, DIAGT_Q, 2 * np_)
     if target_kind == L.TARGET_GAUSS_DENSE:
         ne = 8 if d <= 32 else 16 if d <= 64 else 25 if d <= 100 else 32
         return (1, 4, ne)

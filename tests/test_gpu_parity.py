@@ -6,6 +6,8 @@ same summation order); pooled moments within the tolerance stated in each test.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -126,6 +128,52 @@ def _assert_same(eng, job, case):
     ps, pq, pna, pnt, pns = eng.pooled_summaries()
     assert np.allclose(ps, job.sum.sum(0), rtol=1e-12, atol=1e-9) and np.allclose(pq, job.sumsq.sum(0), rtol=1e-12)
     assert pna == int(job.naccept.sum()) and pnt == case["nsteps"] * case["nchains"] and pns == nsaved
+
+
+@pytest.mark.parametrize("mode", ["one_launch", "launch_per_transition", "mixed"])
+@pytest.mark.parametrize("name", cases.DIAGT_CASES)
+def test_parity_pair_transposed_layout(name, mode):
+    """Layout kind 3 (klara_diagt.h): 8 lanes per chain, element pairs dealt round-robin.  Accept mask, state,
+    log-target, gradient and accept counts are bit-identical to the oracle run with the same summation order, whether
+    the transitions go in one launch (multi-step kernel), one launch each (single-transition kernel) or a mix."""
+    case = cases.make_case(name)
+    n = case["nsteps"]
+    eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_ACCEPT, steps_per_launch={"one_launch": 0, "launch_per_transition": 1, "mixed": 7}[mode]))
+    layout = eng.layout()
+    assert layout[0] == 3 and layout[1] == 8, layout
+    assert tuple(layout) == tuple(O.default_layout(case["target"].kind, case["target"].ndims, sampler=case["sampler"], plain=True, monitor=L.MON_ACCEPT))
+    job = O.OracleJob(**cases.oracle_kwargs(case, layout=layout))
+    eng.init_state_normal(); assert job.init_state_normal() == 0
+    x, lt, g = eng.state()
+    assert np.array_equal(x, job.X) and np.array_equal(lt, job.LT)
+    if case["sampler"] != L.SAMPLER_MH:
+        assert np.array_equal(g, job.G), "initial gradient differs"
+    for k in ([n] if mode != "mixed" else [1, n - 4, 3]):
+        eng.run(k); assert job.run(k) == 0
+    mask = eng.accept_mask()
+    assert np.array_equal(mask, job.accept), f"{name}: accept mask differs at {np.argwhere(mask != job.accept)[:5]}"
+    assert 0 < mask.sum() < mask.size or name == "dt_mala_d100"        # both outcomes occur (drift 0.9 at D=100 rarely accepts)
+    x, lt, g = eng.state()
+    assert np.array_equal(x, job.X) and np.array_equal(lt, job.LT), f"{name}: state differs"
+    if case["sampler"] != L.SAMPLER_MH:
+        assert np.array_equal(g, job.G), f"{name}: gradient differs"
+    na, nst = eng.accept_counts()
+    assert np.array_equal(na, job.naccept) and nst == n
+    eng.close()
+
+
+def test_pair_transposed_layout_is_optional():
+    """Summaries, tuners, odd D or the slice sampler keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
+    case = cases.make_case("dt_mala_d100")
+    e = K.Engine(**cases.engine_kwargs(case)); assert e.layout()[0] == 0; e.close()                  # monitors summaries
+    e = K.Engine(**cases.engine_kwargs(case, monitor=0)); assert e.layout()[0] == 3; e.close()
+    e = K.Engine(**cases.engine_kwargs(case, monitor=0, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.5)); assert e.layout()[0] == 0; e.close()
+    e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d129"), monitor=0)); assert e.layout()[0] == 0; e.close()
+    os.environ["KLARA_LAYOUT_KIND"] = "0"
+    try:
+        e = K.Engine(**cases.engine_kwargs(case, monitor=0)); assert e.layout()[0] == 0; e.close()
+    finally:
+        del os.environ["KLARA_LAYOUT_KIND"]
 
 
 @pytest.mark.parametrize("name", cases.ALL_CASES)
