@@ -134,8 +134,10 @@ def main():
                        "acceptance_rate": nacc / max(ntr, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": f"k_transitions<MALA, GAUSS_DIAG, E={lay_e}> ({lay_g} lanes x {lay_e} elements per chain, "
-                                   f"{64 // lay_g} chains per wavefront)",
+                         "kernel": (f"k_diagt<MALA, NP={lay_e // 2}, Q={lay_g}> (pair-transposed layout: {lay_g} lanes x {lay_e // 2} element "
+                                    f"pairs per chain, {64 // lay_g} chains per wavefront)") if lay_kind == 3 else
+                                   (f"k_transitions<MALA, GAUSS_DIAG, E={lay_e}> ({lay_g} lanes x {lay_e} elements per chain, "
+                                    f"{64 // lay_g} chains per wavefront)"),
                          "algorithmic_bytes_per_launch": alg, "launch_us": launch_s * 1e6, "launches": nlaunch},
         }
     eng.close()
@@ -145,7 +147,8 @@ def main():
         # only reported when this run's configuration is the profiled one
         try:
             tr = json.loads((ROOT / "profiles" / "r1_bench_mala_traffic.json").read_text())
-            if (tr["nchains"], tr["ndims"], tr["steps_per_launch"]) == (n, NDIMS, args.spl) and tr.get("layout_e") == lay_e:
+            kname = f"k_diagt<1, {lay_e // 2}, {lay_g}," if lay_kind == 3 else f"k_transitions<1, 0, {lay_e},"
+            if (tr["nchains"], tr["ndims"], tr["steps_per_launch"]) == (n, NDIMS, args.spl) and kname in tr["kernel"]:
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_gbs"] = tr["traffic_bytes_per_launch"] / launch_s / 1e9
                 out["roofline"]["traffic_source"] = "profiles/r1_bench_mala_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"

@@ -498,7 +498,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
     if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, h->E, h->Pfrag, grid_for(h), h->stream);
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
-        const dim3 grid = grid_for_transitions(h);
+        const dim3 grid = grid_for(h);          // one wavefront per group of 8 chains
         switch (d.sampler) {
         case KLARA_SAMPLER_MH: return klara_launch_diagt_mh(p, kl, h->E / 2, onestep, unitw, grid, h->stream);
         case KLARA_SAMPLER_MALA: return klara_launch_diagt_mala(p, kl, h->E / 2, onestep, unitw, grid, h->stream);

@@ -18,6 +18,20 @@
 #include "klara_kernels.h"
 
 #define KLARA_DIAGT_Q 8
+// Keeps the instruction scheduler from hoisting every pair's Philox/Box-Muller ahead of the elementwise work (which
+// costs ~60 VGPRs and an occupancy step): pairs are processed KLARA_DT_FENCE_EVERY at a time.
+#ifndef KLARA_DT_FENCE_EVERY
+#define KLARA_DT_FENCE_EVERY 2
+#endif
+#ifndef KLARA_DT_W1
+#define KLARA_DT_W1 4
+#endif
+#ifdef KLARA_DT_PERSISTENT
+#define KLARA_DT_GROUP_LOOP for (long long grp = wave0; grp * CPW < p.nchains; grp += nwaves)
+#else
+#define KLARA_DT_GROUP_LOOP const long long grp = wave0; if (grp * CPW < p.nchains)
+#endif
+#define KLARA_DT_PAIR_FENCE(pi) do { if (KLARA_DT_FENCE_EVERY > 0 && ((pi) + 1) % KLARA_DT_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
 
 template <int NP, int Q>
 struct PairCtx {
@@ -96,7 +110,7 @@ __device__ __forceinline__ void diag_elem(double x, double w, double m, double& 
 }
 
 template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW>
-__global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? 3 : 2) : 1))
+__global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? (UNITW ? KLARA_DT_W1 : 3) : 2) : 1))
 void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 {
     constexpr int E = 2 * NP, CPW = 64 / Q;
@@ -124,7 +138,9 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 
     const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
     const long long wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    for (long long grp = wave0; grp * CPW < p.nchains; grp += nwaves) {
+    // one chain group per wavefront (the launcher sizes the grid for it); a persistent loop here makes the compiler
+    // park the polynomial constants in VGPRs for the whole kernel
+    KLARA_DT_GROUP_LOOP {
         const long long first_chain = grp * CPW;
         const long long left = p.nchains - first_chain;
         const int here = left < CPW ? (int)left : CPW;
@@ -148,19 +164,23 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             bool acc;
             double ltp;
 
-            if (SAMPLER == KLARA_SAMPLER_MH) {                                     // iterate/MH.jl:72-124
+            // All proposal normals of the transition are drawn first: they do not depend on the chain state, so the
+            // Philox/Box-Muller work (~4000 issue cycles) runs while the state loads issued above are still in flight.
+            double z[E];
+            if (SAMPLER != KLARA_SAMPLER_HMC) {
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
-                    double z[2];
-                    pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z[0], z[1], u_last, lg_last);
+                    pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z[2 * pi], z[2 * pi + 1], u_last, lg_last);
+                    KLARA_DT_PAIR_FENCE(pi);
+                }
+            }
+            if (SAMPLER == KLARA_SAMPLER_MH) {                                     // iterate/MH.jl:72-124
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int e = 2 * pi + h;
-                        xp[e] = x[e] + sig[e] * z[h];                                          // MH.jl:79
-                        double term, gd;
-                        diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gd);   // :81
-                        red[0] = red[0] + term;
-                    }
+                for (int e = 0; e < E; ++e) {
+                    xp[e] = x[e] + sig[e] * z[e];                                              // MH.jl:79
+                    double term, gd;
+                    diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gd);       // :81
+                    red[0] = red[0] + term;
                 }
                 red1[0] = red[0];
                 group_allreduce<1>(red1, Q, cx.lane);
@@ -173,23 +193,17 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             } else if (SAMPLER == KLARA_SAMPLER_MALA) {                            // iterate/MALA.jl:78-128
                 const double h_ = p.step0, halfh = 0.5 * h_, sq = p.sqrt_step0, half_inv_h = 0.5 * p.inv_step0;
 #pragma unroll
-                for (int pi = 0; pi < NP; ++pi) {
-                    double z[2];
-                    pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z[0], z[1], u_last, lg_last);
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int e = 2 * pi + h;
-                        const double m_ = x[e] + halfh * g[e];                                 // :83
-                        xp[e] = m_ + sq * z[h];                                                // :84
-                        double term;
-                        diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gp[e]);   // :86
-                        red[0] = red[0] + term;
-                        const double q1 = m_ - xp[e];
-                        red[1] = red[1] + (q1 * q1) * half_inv_h;                              // :90
-                        const double mup = xp[e] + halfh * gp[e];                              // :91
-                        const double q2 = mup - x[e];
-                        red[2] = red[2] + (q2 * q2) * half_inv_h;                              // :92
-                    }
+                for (int e = 0; e < E; ++e) {
+                    const double m_ = x[e] + halfh * g[e];                                     // :83
+                    xp[e] = m_ + sq * z[e];                                                    // :84
+                    double term;
+                    diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gp[e]);    // :86
+                    red[0] = red[0] + term;
+                    const double q1 = m_ - xp[e];
+                    red[1] = red[1] + (q1 * q1) * half_inv_h;                                  // :90
+                    const double mup = xp[e] + halfh * gp[e];                                  // :91
+                    const double q2 = mup - x[e];
+                    red[2] = red[2] + (q2 * q2) * half_inv_h;                                  // :92
                 }
                 group_allreduce<3>(red, Q, cx.lane);
                 ltp = gconst - red[0];

@@ -27,15 +27,15 @@ def mean_counter(sub, counter):
 
 
 fetch, write = mean_counter("pmc_fetch", "FETCH_SIZE"), mean_counter("pmc_write", "WRITE_SIZE")
-kt = max((k for k in fetch if "k_transitions" in k), key=lambda k: fetch[k])
-ki = next(k for k in fetch if k.startswith("void k_init<") or k.startswith("k_init<"))
+kt = max((k for k in fetch if "k_transitions" in k or "k_diagt<" in k), key=lambda k: fetch[k])
+ki = next(k for k in fetch if "k_init<" in k or "k_diagt_init<" in k)
 x_kb = NCH * D * 8 / 1024
 corr = 2.0
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (scripts/profile_bench.sh), bench.py --steps 200 --warmup 20",
-    "kernel": kt, "layout_e": int(kt.split("<")[1].split(",")[2]), "nchains": NCH, "ndims": D, "steps_per_launch": 1,
+    "kernel": kt, "nchains": NCH, "ndims": D, "steps_per_launch": 1,
     "FETCH_SIZE_raw_kb_per_launch": fetch[kt], "WRITE_SIZE_raw_kb_per_launch": write[kt], "fetch_correction": corr,
-    "calibration": (f"{ki} reads X = {x_kb:.0f} KiB and reports FETCH_SIZE {fetch[ki]:.1f} (x{corr} = {fetch[ki] * corr:.1f}); it writes "
+    "calibration": (f"{ki} (the init kernel) reads X = {x_kb:.0f} KiB and reports FETCH_SIZE {fetch[ki]:.1f} (x{corr} = {fetch[ki] * corr:.1f}); it writes "
                     f"G + LT = {x_kb + NCH * 8 / 1024:.0f} KiB and reports WRITE_SIZE {write[ki]:.1f}. So FETCH_SIZE is doubled "
                     "(MI355X_MICROARCH.md HBM section) and WRITE_SIZE is taken as is, both in KiB."),
     "traffic_bytes_per_launch": (fetch[kt] * corr + write[kt]) * 1024,

@@ -17,7 +17,7 @@ for f in sorted(glob.glob(os.path.join(out,'*','**','*counter_collection.csv'),r
     agg=defaultdict(lambda: defaultdict(lambda:[0,0.0]))
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name'][:60]
-        if 'k_transitions' not in k: continue
+        if 'k_transitions' not in k and 'k_diagt<' not in k: continue
         a=agg[k][r['Counter_Name']]; a[0]+=1; a[1]+=float(r['Counter_Value'])
     for k,d in agg.items():
         print(k)

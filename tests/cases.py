@@ -190,7 +190,8 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "slice_d2_mvnormal"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
-                "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg"]
+                "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",
+                "dt_mala_d100_small_step", "dt_hmc_d100", "dt_mh_mvnormal_d8"]
 
 
 def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):

@@ -19,11 +19,16 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 
 import cases  # noqa: E402
 import oracle_ffi as O  # noqa: E402
+from klara_jl_amd import _lib as L  # noqa: E402
 
 
 def run_case(name):
     c = cases.make_case(name)
-    job = O.OracleJob(**cases.oracle_kwargs(c))
+    layout = None
+    if name in cases.DIAGT_CASES:      # pair-transposed layout (kind 3): the job monitors only the accept mask
+        layout = O.default_layout(c["target"].kind, c["target"].ndims, sampler=c["sampler"], plain=True, monitor=L.MON_ACCEPT)
+        assert layout[0] == 3
+    job = O.OracleJob(**cases.oracle_kwargs(c, layout=layout))
     st = job.init_state_normal() if c["x0"] is None else job.set_state(c["x0"])
     assert st == 0, (name, st)
     x0 = job.X.copy()
