@@ -48,6 +48,13 @@ KD_FN double   kd_fma(double a, double b, double c) { return __builtin_fma(a, b,
 
 typedef struct { uint32_t x, y, z, w; } kd_u32x4;
 
+/* a ^ b ^ c: one v_bitop3_b32 (truth table 0x96) on gfx950 instead of two v_xor_b32 — 20 fewer VALU issues per block */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KD_XOR3(a, b, c) ((uint32_t)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96))
+#else
+#define KD_XOR3(a, b, c) ((a) ^ (b) ^ (c))
+#endif
+
 KD_FN kd_u32x4 kd_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                 uint32_t k0, uint32_t k1)
 {
@@ -57,9 +64,9 @@ KD_FN kd_u32x4 kd_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t 
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)KD_PHILOX_M0 * (uint64_t)c0;
         const uint64_t p1 = (uint64_t)KD_PHILOX_M1 * (uint64_t)c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n0 = KD_XOR3((uint32_t)(p1 >> 32), c1, k0);
         const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n2 = KD_XOR3((uint32_t)(p0 >> 32), c3, k1);
         const uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += KD_PHILOX_W0; k1 += KD_PHILOX_W1;

@@ -45,6 +45,10 @@ struct klara_handle {
     long long m_prop = 0, m_tot = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; long long last_launches = 0; bool timed = false;
+    // layout kind 3: the chain groups are cut into `nparts` contiguous partitions, partition j > 0 runs on its own
+    // internal stream.  Chains are independent, so partition j's transition t+1 only follows its own transition t; the
+    // streams drift apart and one partition's kernel fills the SIMDs while the other's drains / ramps up.
+    int nparts = 1; hipStream_t side[3] = { nullptr, nullptr, nullptr }; hipEvent_t fork_ev = nullptr, join_ev[3] = { nullptr, nullptr, nullptr };
 };
 
 static int cnt_predicate(const klara_desc& d)
@@ -175,6 +179,8 @@ static void free_all(klara_handle* h)
     hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->d_params);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    for (int j = 0; j < 3; ++j) { if (h->side[j]) hipStreamDestroy(h->side[j]); if (h->join_ev[j]) hipEventDestroy(h->join_ev[j]); }
+    if (h->fork_ev) hipEventDestroy(h->fork_ev);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
 }
 
@@ -221,6 +227,18 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     if (desc->stream) { h->stream = (hipStream_t)desc->stream; h->own_stream = false; }
     else { CKH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     CKH(hipEventCreate(&h->ev0)); CKH(hipEventCreate(&h->ev1));
+    if (h->kind == 3) {
+        const long long groups = (desc->nchains + 7) / 8;
+        int np = groups >= 4096 ? 2 : 1;                       // >= one full round of wavefronts (4 per SIMD) per partition
+        if (const char* s = getenv("KLARA_STREAMS")) { const int v = atoi(s); if (v >= 1 && v <= 4) np = v; }
+        if (np > groups) np = (int)groups;
+        h->nparts = np;
+        if (np > 1) CKH(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+        for (int j = 0; j + 1 < np; ++j) {
+            CKH(hipStreamCreateWithFlags(&h->side[j], hipStreamNonBlocking));
+            CKH(hipEventCreateWithFlags(&h->join_ev[j], hipEventDisableTiming));
+        }
+    }
 
     CKH(dalloc(&h->X, N * D)); CKH(dalloc(&h->GR, N * D)); CKH(dalloc(&h->LT, N));
     CKH(dalloc(&h->tune_step, NT)); CKH(dalloc(&h->tune_acc, NT)); CKH(dalloc(&h->tune_prop, NT));
@@ -498,12 +516,22 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
     if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, h->E, h->Pfrag, grid_for(h), h->stream);
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
-        const dim3 grid = grid_for(h);          // one wavefront per group of 8 chains
-        switch (d.sampler) {
-        case KLARA_SAMPLER_MH: return klara_launch_diagt_mh(p, kl, h->E / 2, onestep, unitw, grid, h->stream);
-        case KLARA_SAMPLER_MALA: return klara_launch_diagt_mala(p, kl, h->E / 2, onestep, unitw, grid, h->stream);
-        default: return klara_launch_diagt_hmc(p, kl, h->E / 2, onestep, unitw, grid, h->stream);
+        const long long groups = (d.nchains + 7) / 8, per = (groups + h->nparts - 1) / h->nparts;
+        for (int j = 0; j < h->nparts; ++j) {
+            KLaunch kp = kl;
+            kp.group0 = j * per; kp.group_end = (j + 1) * per < groups ? (j + 1) * per : groups;
+            if (kp.group0 >= kp.group_end) break;
+            const dim3 grid((unsigned)((kp.group_end - kp.group0 + 3) / 4));      // one wavefront per group of 8 chains
+            hipStream_t st = j == 0 ? h->stream : h->side[j - 1];
+            hipError_t e;
+            switch (d.sampler) {
+            case KLARA_SAMPLER_MH: e = klara_launch_diagt_mh(p, kp, h->E / 2, onestep, unitw, grid, st); break;
+            case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala(p, kp, h->E / 2, onestep, unitw, grid, st); break;
+            default: e = klara_launch_diagt_hmc(p, kp, h->E / 2, onestep, unitw, grid, st); break;
+            }
+            if (e != hipSuccess) return e;
         }
+        return hipSuccess;
     }
     switch (d.sampler) {
     case KLARA_SAMPLER_MH: return klara_launch_mh(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
@@ -525,6 +553,10 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
     long long spl = d.steps_per_launch > 0 ? d.steps_per_launch : 16;
     KParams p = make_params(h);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
+    if (h->nparts > 1) {                                   // fork: the partition streams start after everything queued so far
+        HIPCHK(hipEventRecord(h->fork_ev, h->stream));
+        for (int j = 0; j + 1 < h->nparts; ++j) HIPCHK(hipStreamWaitEvent(h->side[j], h->fork_ev, 0));
+    }
     long long remaining = nsteps, launches = 0;
     while (remaining > 0) {
         long long k = remaining < spl ? remaining : spl;
@@ -533,6 +565,7 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
             if (k > to_boundary) k = to_boundary;
         }
         KLaunch kl;
+        kl.group0 = 0; kl.group_end = 0x7fffffffffffffffll;
         kl.t0 = (unsigned long long)h->steps_done;
         kl.nsteps = (int)k;
         // save rule bookkeeping (BasicMCRange.jl:36 postrange = (burnin+1):thinning:nsteps), done on the host so
@@ -548,6 +581,10 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
             if (h->m_tot <= d.burnin && (h->m_prop % d.period) == 0) { h->m_tot += h->m_prop; h->m_prop = 0; }
         }
         h->steps_done += k; remaining -= k; ++launches;
+    }
+    for (int j = 0; j + 1 < h->nparts; ++j) {              // join: the caller's stream continues when every partition is done
+        HIPCHK(hipEventRecord(h->join_ev[j], h->side[j]));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev[j], 0));
     }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->last_launches = launches; h->timed = true;

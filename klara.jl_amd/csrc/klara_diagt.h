@@ -27,9 +27,9 @@
 #define KLARA_DT_W1 4
 #endif
 #ifdef KLARA_DT_PERSISTENT
-#define KLARA_DT_GROUP_LOOP for (long long grp = wave0; grp * CPW < p.nchains; grp += nwaves)
+#define KLARA_DT_GROUP_LOOP for (long long grp = kl.group0 + wave0; grp < kl.group_end && grp * CPW < p.nchains; grp += nwaves)
 #else
-#define KLARA_DT_GROUP_LOOP const long long grp = wave0; if (grp * CPW < p.nchains)
+#define KLARA_DT_GROUP_LOOP const long long grp = kl.group0 + wave0; if (grp < kl.group_end && grp * CPW < p.nchains)
 #endif
 #define KLARA_DT_PAIR_FENCE(pi) do { if (KLARA_DT_FENCE_EVERY > 0 && ((pi) + 1) % KLARA_DT_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
 

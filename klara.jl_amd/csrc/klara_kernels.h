@@ -86,6 +86,7 @@ struct KLaunch {
     unsigned long long t0;                     // global index of the first transition of this launch
     int nsteps;                                // transitions in this launch
     int save_phase0; long long save_col0;      // save-rule bookkeeping computed on the host (no device division)
+    long long group0, group_end;               // layout kind 3: the chain groups [group0, group_end) this launch covers
 };
 
 // ------------------------------------------------------------------------------------------------
