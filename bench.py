@@ -30,12 +30,14 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s a
 FP64_MFMA_PEAK_TF = 78.6    # FP64 matrix = FP64 vector peak on MI355X
 
 
-def algorithmic_bytes_per_launch(nchains, d, sampler, spl, summaries):
-    """carried state S = 2*D*8+8 (x, g, lt) for MALA/HMC, D*8+8 for MH/Slice; one launch reads
-    and writes it once whatever the number of fused transitions.  Per-chain counters (8 B RMW) and, when on,
-    the running sums (2 arrays RMW) are counted too."""
+def algorithmic_bytes_per_launch(nchains, d, sampler, spl, summaries, accept_rate=1.0):
+    """SURVEY §8(d): carried state S = 2*D*8+8 (x, g, lt) for MALA/HMC, D*8+8 for MH/Slice.  A launch reads it once;
+    it has to write it back only for the chains that moved (a rejected proposal leaves x, g, lt as they were), so the
+    write side is scaled by the measured fraction of chains that accepted at least once in the launch (for one
+    transition per launch: the acceptance rate; SURVEY's 2*S+1 figure is the accept_rate = 1 upper end).
+    The per-chain accept counter (8 B RMW, accepted chains only) and, when on, the running sums (2 arrays RMW) count too."""
     s = (2 * d * 8 + 8) if sampler in ("mala", "hmc") else (d * 8 + 8)
-    b = 2 * s + 16
+    b = s + accept_rate * (s + 16)
     if summaries:
         b += 4 * d * 8
     return nchains * b
@@ -48,6 +50,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--spl", type=int, default=1, help="transitions fused per kernel launch (1 = one iterate! per launch)")
     ap.add_argument("--chains", type=int, default=NCHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="internal streams for independent chain partitions (0 = library default, 1 = every launch on the caller's stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for logic tests)")
@@ -86,7 +90,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     eng = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=total_steps,
                    burnin=0, driftstep=0.9, seed=20260927, chain_offset=rank * n, device=local_rank,
-                   monitor=0, steps_per_launch=args.spl, stream=stream)
+                   monitor=0, steps_per_launch=args.spl, stream=stream, nstreams=args.streams)
     eng.init_state_normal()
 
     def barrier():
@@ -114,14 +118,12 @@ def main():
     kernel_ms, nlaunch = eng.last_run_ms()
     lay_kind, lay_g, lay_e = eng.layout()
     _, _, nacc, ntr, _ = eng.pooled_summaries(with_sums=False)
+    acc_rate = nacc / max(ntr, 1)
 
     out = None
     if rank == 0:
         transitions = float(n) * world * args.steps
         value = transitions / elapsed
-        alg = algorithmic_bytes_per_launch(n, NDIMS, "mala", args.spl, False)
-        launch_s = kernel_ms * 1e-3 / max(nlaunch, 1)
-        achieved = alg / launch_s / 1e9
         out = {
             "metric": "MCMC transitions/sec (whole node), 100-dim Gaussian, 65k chains",
             "value": value, "unit": "transitions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -131,30 +133,14 @@ def main():
                                    "VanillaMCTuner, x0~N(0,I)",
                        "nchains_per_gpu": n, "ndims": NDIMS, "steps_per_launch": args.spl,
                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
-                       "acceptance_rate": nacc / max(ntr, 1)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": (f"k_diagt<MALA, NP={lay_e // 2}, Q={lay_g}> (pair-transposed layout: {lay_g} lanes x {lay_e // 2} element "
-                                    f"pairs per chain, {64 // lay_g} chains per wavefront)") if lay_kind == 3 else
-                                   (f"k_transitions<MALA, GAUSS_DIAG, E={lay_e}> ({lay_g} lanes x {lay_e} elements per chain, "
-                                    f"{64 // lay_g} chains per wavefront)"),
-                         "algorithmic_bytes_per_launch": alg, "launch_us": launch_s * 1e6, "launches": nlaunch},
+                       "streams": "library default (2 chain partitions on 2 HIP streams)" if args.streams == 0 else args.streams,
+                       "acceptance_rate": acc_rate,
+                       "timed_region_kernel_ms_per_step": kernel_ms / max(nlaunch, 1) * (1 if args.spl <= 1 else 1.0 / args.spl)},
         }
     eng.close()
 
     if rank == 0:
-        # HBM bytes per launch from the PMC passes of the same command (profiles/, see scripts/profile_bench.sh);
-        # only reported when this run's configuration is the profiled one
-        try:
-            tr = json.loads((ROOT / "profiles" / "r1_bench_mala_traffic.json").read_text())
-            kname = f"k_diagt<1, {lay_e // 2}, {lay_g}," if lay_kind == 3 else f"k_transitions<1, 0, {lay_e},"
-            if (tr["nchains"], tr["ndims"], tr["steps_per_launch"]) == (n, NDIMS, args.spl) and kname in tr["kernel"]:
-                out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_gbs"] = tr["traffic_bytes_per_launch"] / launch_s / 1e9
-                out["roofline"]["traffic_source"] = "profiles/r1_bench_mala_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
-        except Exception:
-            pass
-
+        out["roofline"] = roofline_pass(K, L, n, args.spl, rank, local_rank, stream, acc_rate)
     if rank == 0 and world == 1 and not args.no_extra:
         out["extra"] = extra_measurements(K, L, n, stream)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -163,6 +149,45 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def roofline_pass(K, L, n, spl, rank, local_rank, stream, acc_rate):
+    """Duration of the dominant kernel, one launch at a time: the same workload with every launch on the caller's
+    stream (nstreams=1; the timed region above overlaps two half-size launches on two streams, which says nothing
+    about a single launch), HIP events around 200 launches on that stream.  achieved = algorithmic bytes / duration."""
+    e = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=100000, burnin=0,
+                 driftstep=0.9, seed=20260927, chain_offset=rank * n, device=local_rank, monitor=0, steps_per_launch=spl,
+                 stream=stream, nstreams=1)
+    e.init_state_normal()
+    e.run(40 * max(spl, 1)); e.run(200 * max(spl, 1))
+    kernel_ms, nlaunch = e.last_run_ms()
+    lay_kind, lay_g, lay_e = e.layout()
+    e.close()
+    launch_s = kernel_ms * 1e-3 / max(nlaunch, 1)
+    alg = algorithmic_bytes_per_launch(n, NDIMS, "mala", spl, False, acc_rate if spl <= 1 else 1.0)
+    achieved = alg / launch_s / 1e9
+    rf = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+          "traffic": None,
+          "kernel": (f"k_diagt<MALA, NP={lay_e // 2}, Q={lay_g}> (pair-transposed layout: {lay_g} lanes x {lay_e // 2} element "
+                     f"pairs per chain, {64 // lay_g} chains per wavefront)") if lay_kind == 3 else
+                    (f"k_transitions<MALA, GAUSS_DIAG, E={lay_e}> ({lay_g} lanes x {lay_e} elements per chain, "
+                     f"{64 // lay_g} chains per wavefront)"),
+          "algorithmic_bytes_per_launch": alg, "launch_us": launch_s * 1e6, "launches": nlaunch,
+          "chains_per_launch": n, "accept_rate_used": acc_rate if spl <= 1 else 1.0,
+          "survey_2S_plus_1_bytes_per_launch": n * (2 * (2 * NDIMS * 8 + 8) + 1),
+          "note": ("the kernel is bound by FP64/INT VALU issue (in-kernel Philox + Box-Muller), not by HBM: see DESIGN.md "
+                   "section 5; measured with nstreams=1, one launch at a time")}
+    # HBM bytes per launch from the PMC passes of the same workload (profiles/, scripts/profile_bench.sh)
+    try:
+        tr = json.loads((ROOT / "profiles" / "r1_bench_mala_traffic.json").read_text())
+        kname = f"k_diagt<1, {lay_e // 2}, {lay_g}," if lay_kind == 3 else f"k_transitions<1, 0, {lay_e},"
+        if (tr["nchains"], tr["ndims"], tr["steps_per_launch"]) == (n, NDIMS, spl) and kname in tr["kernel"]:
+            rf["traffic"] = tr["traffic_bytes_per_launch"]
+            rf["traffic_gbs"] = tr["traffic_bytes_per_launch"] / launch_s / 1e9
+            rf["traffic_source"] = "profiles/r1_bench_mala_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
+    except Exception:
+        pass
+    return rf
 
 
 def extra_measurements(K, L, n, stream):

@@ -143,7 +143,8 @@ typedef struct klara_desc {
     const double* logit_X;       /* LOGISTIC: ndata x D row-major design matrix                      */
     const double* logit_y;       /* LOGISTIC: ndata outcomes                                         */
     int32_t  logit_ndata;
-    int32_t  reserved0;
+    int32_t  nstreams;           /* internal HIP streams for independent chain partitions (pair-transposed layout only):
+                                    0 = automatic (2 when a partition still fills the GPU), 1..4 = forced        */
     double   logit_lambda;       /* LOGISTIC: prior variance (v[1] of the example)                   */
     const double* hier_Y;        /* HIER_NORMAL: R x T row-major observations                        */
     const double* hier_xc;       /* HIER_NORMAL: T centred covariate values (age_j - 22 for rats)    */

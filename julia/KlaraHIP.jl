@@ -14,7 +14,7 @@ struct KlaraDesc
     da_t0::Int32; tuner_score::Int32
     nsteps::Int64; burnin::Int64; thinning::Int64
     gauss_w::Ptr{Float64}; gauss_mu::Ptr{Float64}; gauss_const::Float64; gauss_prec::Ptr{Float64}
-    logit_X::Ptr{Float64}; logit_y::Ptr{Float64}; logit_ndata::Int32; reserved0::Int32; logit_lambda::Float64
+    logit_X::Ptr{Float64}; logit_y::Ptr{Float64}; logit_ndata::Int32; nstreams::Int32; logit_lambda::Float64
     hier_Y::Ptr{Float64}; hier_xc::Ptr{Float64}; hier_nunits::Int32; hier_ntimes::Int32
     hier_prior_prec::Float64; hier_gamma_a::Float64; hier_gamma_b::Float64
     seed::UInt64; monitor::UInt32; steps_per_launch::Int32; stream::Ptr{Cvoid}

@@ -43,7 +43,7 @@ class KlaraDesc(C.Structure):
         ("da_kappa", C.c_double), ("da_t0", C.c_int32), ("tuner_score", C.c_int32),
         ("nsteps", C.c_int64), ("burnin", C.c_int64), ("thinning", C.c_int64),
         ("gauss_w", _dp), ("gauss_mu", _dp), ("gauss_const", C.c_double), ("gauss_prec", _dp),
-        ("logit_X", _dp), ("logit_y", _dp), ("logit_ndata", C.c_int32), ("reserved0", C.c_int32),
+        ("logit_X", _dp), ("logit_y", _dp), ("logit_ndata", C.c_int32), ("nstreams", C.c_int32),
         ("logit_lambda", C.c_double),
         ("hier_Y", _dp), ("hier_xc", _dp), ("hier_nunits", C.c_int32), ("hier_ntimes", C.c_int32),
         ("hier_prior_prec", C.c_double), ("hier_gamma_a", C.c_double), ("hier_gamma_b", C.c_double),

@@ -130,6 +130,7 @@ static klara_status validate(const klara_desc* d)
     if (d->burnin < 0 || d->thinning < 1 || d->thinning > 0x7fffffff || d->nsteps <= d->burnin) return KLARA_ERR_INVALID_ARG;
     // VanillaMCTuner / AcceptanceRateMCTuner.jl:32-33
     if (d->period <= 0) return KLARA_ERR_INVALID_ARG;
+    if (d->nstreams < 0 || d->nstreams > 4) return KLARA_ERR_INVALID_ARG;
     if (d->tuner == KLARA_TUNER_ACCEPT_RATE && !(d->targetrate > 0.0 && d->targetrate < 1.0)) return KLARA_ERR_INVALID_ARG;
     switch (d->sampler) {
     case KLARA_SAMPLER_MH:
@@ -230,6 +231,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     if (h->kind == 3) {
         const long long groups = (desc->nchains + 7) / 8;
         int np = groups >= 4096 ? 2 : 1;                       // >= one full round of wavefronts (4 per SIMD) per partition
+        if (desc->nstreams >= 1 && desc->nstreams <= 4) np = desc->nstreams;
         if (const char* s = getenv("KLARA_STREAMS")) { const int v = atoi(s); if (v >= 1 && v <= 4) np = v; }
         if (np > groups) np = (int)groups;
         h->nparts = np;

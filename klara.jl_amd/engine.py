@@ -148,7 +148,7 @@ class Engine:
                  da_nadapt: int = 0, da_eps0bar: float = 1.0, da_h0bar: float = 0.0, da_gamma: float = 0.05,
                  da_t0: int = 10, da_kappa: float = 0.75,
                  seed: int = 20260927, chain_offset: int = 0, device: int = 0, monitor: int = 0,
-                 steps_per_launch: int = 0, stream: int = 0):
+                 steps_per_launch: int = 0, stream: int = 0, nstreams: int = 0):
         self._lib = L.load()
         self.target = target
         self.ndims = int(target.ndims)
@@ -193,6 +193,7 @@ class Engine:
         else:
             raise TypeError(f"unknown target family {type(target).__name__}")
         d.seed, d.monitor, d.steps_per_launch = int(seed), self.monitor, int(steps_per_launch)
+        d.nstreams = int(nstreams)
         d.stream = C.c_void_p(int(stream)) if stream else None
         self._h = C.c_void_p()
         L.check(self._lib.klara_create(C.byref(d), C.byref(self._h)), "klara_create")

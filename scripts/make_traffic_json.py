@@ -32,7 +32,7 @@ ki = next(k for k in fetch if "k_init<" in k or "k_diagt_init<" in k)
 x_kb = NCH * D * 8 / 1024
 corr = 2.0
 out = {
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (scripts/profile_bench.sh), bench.py --steps 200 --warmup 20",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (scripts/profile_bench.sh), bench.py --steps 200 --warmup 20 --streams 1",
     "kernel": kt, "nchains": NCH, "ndims": D, "steps_per_launch": 1,
     "FETCH_SIZE_raw_kb_per_launch": fetch[kt], "WRITE_SIZE_raw_kb_per_launch": write[kt], "fetch_correction": corr,
     "calibration": (f"{ki} (the init kernel) reads X = {x_kb:.0f} KiB and reports FETCH_SIZE {fetch[ki]:.1f} (x{corr} = {fetch[ki] * corr:.1f}); it writes "

@@ -9,7 +9,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 200 --warmup 20 --no-extra --no-cpu-baseline $*"
+ARGS="--steps 200 --warmup 20 --streams 1 --no-extra --no-cpu-baseline $*"   # one launch at a time: kernel durations = roofline.launch_us
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/trace" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/bench_fetch.log" 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/bench_write.log" 2>&1

@@ -6,7 +6,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 100 --warmup 10 --no-extra --no-cpu-baseline $*"
+ARGS="--steps 100 --warmup 10 --streams 1 --no-extra --no-cpu-baseline $*"
 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU --kernel-trace -d "$OUT/a" -o b -- python "$REPO/bench.py" $ARGS > "$OUT/a.log" 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/b" -o b -- python "$REPO/bench.py" $ARGS > "$OUT/b.log" 2>&1
 python - "$OUT" <<'PY'
