@@ -9,6 +9,7 @@
 template <int OP>
 __global__ __launch_bounds__(256) void k_op(double* out, double seedv, int G)
 {
+    kd_tables_to_lds();
     const int lane = threadIdx.x & 63;
     double a = seedv + 1e-3 * lane, b = 0.5 + 1e-4 * lane, acc = 0.0;
     uint32_t c0 = threadIdx.x, c1 = blockIdx.x;
@@ -25,6 +26,7 @@ __global__ __launch_bounds__(256) void k_op(double* out, double seedv, int G)
         else if (OP == 9) { c0 = c0 * 0x9E3779B9u + c1; }   // v_mul_lo_u32 chain
         else if (OP == 10) { uint64_t p = (uint64_t)c0 * 0xD2511F53u; c0 = (uint32_t)(p >> 32) ^ (uint32_t)p ^ c1; }  // mad_u64_u32
         else if (OP == 11) { double u = kd_u52(c0, c1); a += u; c0 += 77; }
+        else if (OP == 12) { a = kd_log_u01(a) + 3.0; }
     }
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = a + b + acc + c0 + c1;
 }
@@ -86,13 +88,15 @@ int main()
     run<0>("philox4x32_10");
     run<11>("u52");
     run<1>("kd_log");
+    run<12>("kd_log_u01 (table)");
     run<2>("kd_exp");
-    run<3>("kd_sincos2pi");
+    run<3>("kd_sincos2pi (table)");
     run<4>("sqrt_f64");
     run<5>("div_f64");
     run<6>("philox+normal_pair");
     run<7>("allreduce<3> G=64", 64);
     run<7>("allreduce<3> G=32", 32);
     run<7>("allreduce<3> G=16", 16);
+    run<7>("allreduce<3> G=8", 8);
     return 0;
 }
