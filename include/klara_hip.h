@@ -243,7 +243,8 @@ klara_status klara_selftest_rocrand_blocks(int32_t device, uint64_t seed, uint64
                                            uint64_t first_block, int32_t nblocks, uint32_t* out);
 /* Self-test hook: evaluates the deterministic device math (log, exp, sincos2pi, normal pair) on n
  * inputs so tests can compare bits with the CPU build of the same header. op: 0 log, 1 exp,
- * 2 sin2pi, 3 cos2pi, 4 sqrt, 5 div (in[i] / in2[i]), 6 erf, 7 log_u01 (log of a positive normal number). */
+ * 2 sin2pi, 3 cos2pi, 4 sqrt, 5 div (in[i] / in2[i]), 6 erf, 7 log_u01 (log of a positive normal number),
+ * 8 sqrt of a Box-Muller radicand (positive normal numbers in [1e-16, 1e2]). */
 klara_status klara_selftest_math(int32_t device, int32_t op, int64_t n, const double* in,
                                  const double* in2, double* out);
 

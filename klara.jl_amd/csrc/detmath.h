@@ -298,6 +298,28 @@ KD_FN void kd_sincos2pi(double u, double* sn, double* cs)
     kd_sincos2pi_bits(kd_d2u(u + 0x1.fffffffffffffp-1), sn, cs);
 }
 
+/* ---------------------------------------------------------------- sqrt of the Box-Muller radicand */
+/* y = -2 log(u) lies in [2.2e-16, 73.5]: positive, normal, far from overflow.  The compiler's IEEE f64 sqrt on gfx950
+ * is v_rsq_f64 + a Goldschmidt/Newton sequence wrapped in input scaling (ldexp, compare, selects) and a class check for
+ * 0/inf/NaN; for this range the wrapper is dead weight (6 of 16 instructions).  Same core sequence, same correctly
+ * rounded result as the host's sqrt (tests/test_gpu_parity.py::test_device_math_bit_exact, op 8). */
+KD_FN double kd_sqrt_radicand(double y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = __builtin_amdgcn_rsq(y);
+    double g = y * r, h = 0.5 * r;
+    const double e = kd_fma(-h, g, 0.5);
+    g = kd_fma(g, e, g);
+    h = kd_fma(h, e, h);
+    double d = kd_fma(-g, g, y);
+    g = kd_fma(d, h, g);
+    d = kd_fma(-g, g, y);
+    return kd_fma(d, h, g);
+#else
+    return __builtin_sqrt(y);
+#endif
+}
+
 /* ---------------------------------------------------------------- Box-Muller */
 /* One Philox block (4 x 32 bit) -> two independent N(0,1):
  *   u1 = u52(x, y), u2 = u52(z, w); rad = sqrt(-2 log u1); z0 = rad cos(2 pi u2); z1 = rad sin(2 pi u2).
@@ -306,7 +328,7 @@ KD_FN void kd_normal_pair_ex(kd_u32x4 b, double* z0, double* z1, double* u1_out,
 {
     const double u1 = kd_u52(b.x, b.y);
     const double lg = kd_log_u01(u1);
-    const double rad = __builtin_sqrt(-2.0 * lg);
+    const double rad = kd_sqrt_radicand(-2.0 * lg);
     double sn, cs;
     kd_sincos2pi_bits(kd_unit_bits(b.z, b.w), &sn, &cs);          /* angle 2 pi u2, u2 = kd_u52(z, w) */
     *z0 = rad * cs;

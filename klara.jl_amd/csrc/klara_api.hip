@@ -64,7 +64,7 @@ static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static bool diagt_eligible(const klara_desc& d)
 {
     if (d.target != KLARA_TARGET_GAUSS_DIAG || d.sampler == KLARA_SAMPLER_SLICE) return false;
-    if ((d.ndims & 1) || d.ndims > 16 * KLARA_DIAGT_NP_MAX) return false;
+    if ((d.ndims & 1) || d.ndims > 2 * KLARA_DIAGT_Q * KLARA_DIAGT_NP_MAX) return false;
     const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
     if (!plain || (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0) return false;
     if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
@@ -90,7 +90,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     // diagonal Gaussian, nothing tunes and nothing but the accept mask is monitored: the pair-transposed layout
     // (klara_diagt.h), Q = 8 lanes per chain, NP element pairs per lane
     if (diagt_eligible(d)) {
-        const int need = (D + 15) / 16;
+        const int need = (D + 2 * KLARA_DIAGT_Q - 1) / (2 * KLARA_DIAGT_Q);
         int np = 0;
 #define X(NP_) if (np == 0 && NP_ >= need) np = NP_;
         KLARA_DIAGT_NP_MENU_DO(X)
@@ -229,7 +229,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     else { CKH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     CKH(hipEventCreate(&h->ev0)); CKH(hipEventCreate(&h->ev1));
     if (h->kind == 3) {
-        const long long groups = (desc->nchains + 7) / 8;
+        const long long groups = (desc->nchains + KLARA_DIAGT_CPW - 1) / KLARA_DIAGT_CPW;
         int np = groups >= 4096 ? 2 : 1;                       // >= one full round of wavefronts (4 per SIMD) per partition
         if (desc->nstreams >= 1 && desc->nstreams <= 4) np = desc->nstreams;
         if (const char* s = getenv("KLARA_STREAMS")) { const int v = atoi(s); if (v >= 1 && v <= 4) np = v; }
@@ -518,7 +518,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
     if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, h->E, h->Pfrag, grid_for(h), h->stream);
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
-        const long long groups = (d.nchains + 7) / 8, per = (groups + h->nparts - 1) / h->nparts;
+        const long long groups = (d.nchains + KLARA_DIAGT_CPW - 1) / KLARA_DIAGT_CPW, per = (groups + h->nparts - 1) / h->nparts;
         for (int j = 0; j < h->nparts; ++j) {
             KLaunch kp = kl;
             kp.group0 = j * per; kp.group_end = (j + 1) * per < groups ? (j + 1) * per : groups;
@@ -948,6 +948,7 @@ __global__ void k_math(int op, long long n, const double* in, const double* in2,
     case 4: out[i] = __builtin_sqrt(in[i]); break;
     case 6: out[i] = kd_erf(in[i]); break;
     case 7: out[i] = kd_log_u01(in[i]); break;
+    case 8: out[i] = kd_sqrt_radicand(in[i]); break;
     default: out[i] = in[i] / in2[i]; break;
     }
 }

@@ -17,7 +17,10 @@
 #pragma once
 #include "klara_kernels.h"
 
-#define KLARA_DIAGT_Q 8
+#ifndef KLARA_DIAGT_Q
+#define KLARA_DIAGT_Q 8                       // lanes per chain
+#endif
+#define KLARA_DIAGT_CPW (64 / KLARA_DIAGT_Q)  // chains per wavefront
 // Keeps the instruction scheduler from hoisting every pair's Philox/Box-Muller ahead of the elementwise work (which
 // costs ~60 VGPRs and an occupancy step): pairs are processed KLARA_DT_FENCE_EVERY at a time.
 #ifndef KLARA_DT_FENCE_EVERY

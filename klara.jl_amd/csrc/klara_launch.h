@@ -26,8 +26,13 @@ hipError_t klara_launch_diagt_mala(const KParams* p, const KLaunch& kl, int NP, 
 hipError_t klara_launch_diagt_hmc(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, dim3 grid, hipStream_t st);
 hipError_t klara_launch_diagt_init(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
 // pairs per lane the kernels are instantiated for (D <= 16*NP); a job takes the smallest one that fits
+#if KLARA_DIAGT_Q == 4     // experiment: 4 lanes per chain, 16 chains per wavefront (D = 100 -> 13 pairs per lane, no padding)
+#define KLARA_DIAGT_NP_MENU_DO(X) X(2) X(4) X(8) X(13) X(16)
+#define KLARA_DIAGT_NP_MAX 16
+#else
 #define KLARA_DIAGT_NP_MENU_DO(X) X(1) X(2) X(4) X(6) X(7) X(8)
 #define KLARA_DIAGT_NP_MAX 8
+#endif
 
 #define KLARA_DIAGT_CASE(S, NP_)                                                                                   \
     case NP_:                                                                                                      \
@@ -36,12 +41,14 @@ hipError_t klara_launch_diagt_init(const KParams& p, int NP, int needgrad, dim3 
         else if (unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true>), grid, blk, 0, st, p, kl);             \
         else hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false>), grid, blk, 0, st, p, kl);                       \
         break;
+#define KLARA_DIAGT_CASE_KLARA_SAMPLER_MH(NP_) KLARA_DIAGT_CASE(KLARA_SAMPLER_MH, NP_)
+#define KLARA_DIAGT_CASE_KLARA_SAMPLER_MALA(NP_) KLARA_DIAGT_CASE(KLARA_SAMPLER_MALA, NP_)
+#define KLARA_DIAGT_CASE_KLARA_SAMPLER_HMC(NP_) KLARA_DIAGT_CASE(KLARA_SAMPLER_HMC, NP_)
 #define KLARA_DISPATCH_DIAGT(S)                                                                                    \
     do {                                                                                                           \
         const dim3 blk(256);                                                                                       \
         switch (NP) {                                                                                              \
-            KLARA_DIAGT_CASE(S, 1) KLARA_DIAGT_CASE(S, 2) KLARA_DIAGT_CASE(S, 4)                                   \
-            KLARA_DIAGT_CASE(S, 6) KLARA_DIAGT_CASE(S, 7) KLARA_DIAGT_CASE(S, 8)                                   \
+            KLARA_DIAGT_NP_MENU_DO(KLARA_DIAGT_CASE_##S)                                                           \
             default: return hipErrorInvalidValue;                                                                  \
         }                                                                                                          \
         return hipGetLastError();                                                                                  \

@@ -667,6 +667,7 @@ void ko_math(int op, int64_t n, const double* in, const double* in2, double* out
         case 4: out[i] = sqrt(in[i]); break;
         case 6: out[i] = kd_erf(in[i]); break;
     case 7: out[i] = kd_log_u01(in[i]); break;
+    case 8: out[i] = kd_sqrt_radicand(in[i]); break;
         default: out[i] = in[i] / in2[i]; break;
         }
     }

@@ -32,6 +32,12 @@ def test_device_math_bit_exact(klib):
         6: np.concatenate([rng.uniform(-7, 7, n), [0.0, np.inf, -np.inf]]),
         7: np.concatenate([(rng.integers(0, 2 ** 52, n).astype(np.float64) + 0.5) * 2.0 ** -52, np.exp(rng.uniform(-700, 700, n)),
                            [1.0, 2.0 ** -53, 1.0 - 2.0 ** -53, 0.6875, 1.375]]),
+        # the Box-Muller radicand -2 log(u): every magnitude it can take, plus values one ulp either side of exact squares
+        8: np.concatenate([-2.0 * np.log((rng.integers(0, 2 ** 52, 4 * n).astype(np.float64) + 0.5) * 2.0 ** -52),
+                           np.exp(rng.uniform(np.log(2e-16), np.log(74.0), 2 * n)),
+                           np.nextafter(np.arange(1, 2000, dtype=np.float64) ** 2 / 64.0, 0.0),
+                           np.nextafter(np.arange(1, 2000, dtype=np.float64) ** 2 / 64.0, 100.0),
+                           np.arange(1, 2000, dtype=np.float64) ** 2 / 64.0, [2.2e-16, 73.47]]),
     }
     for op, x in sets.items():
         x = np.ascontiguousarray(x)
