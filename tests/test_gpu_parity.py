@@ -446,6 +446,57 @@ def test_full_size_bit_exact_on_sampled_chains(name, kw, nsteps):
     eng.close()
 
 
+@pytest.mark.parametrize("name,kw,nsteps,spl", [
+    ("cfg2_mala_1step", dict(sampler=L.SAMPLER_MALA, driftstep=0.9), 30, 1),
+    ("mala_small_step_fused", dict(sampler=L.SAMPLER_MALA, driftstep=0.05), 24, 8),
+    ("hmc_iso_1step", dict(sampler=L.SAMPLER_HMC, leapstep=0.1, nleaps=10), 8, 1),
+])
+def test_full_size_pair_transposed_on_sampled_chains(name, kw, nsteps, spl):
+    """The bench configuration itself (65,536-chain shape, nothing monitored but the accept mask -> layout kind 3, two
+    chain partitions on two streams): blocks of 16 chains at the start, across the partition boundary and in the ragged
+    last wavefront group are replayed by the oracle and compared bit for bit."""
+    n, d = 65536 - 5, 100
+    target = K.GaussDiagTarget.negdot(d)
+    eng = K.Engine(target=target, nchains=n, nsteps=nsteps, monitor=L.MON_ACCEPT, steps_per_launch=spl, **kw)
+    assert eng.layout()[0] == 3
+    eng.init_state_normal()
+    eng.run(nsteps)
+    x, lt, g = eng.state()
+    mask = eng.accept_mask()
+    na, _ = eng.accept_counts()
+    assert np.array_equal(na, mask.sum(axis=0))
+    groups = (n + 7) // 8
+    boundary = ((groups + 1) // 2) * 8                    # first chain of the second partition
+    case = dict(kw, target=target, nchains=16, nsteps=nsteps, name=name, x0=None, seed=20260927)
+    for off in (0, boundary - 8, n - 16):
+        job = O.OracleJob(**cases.oracle_kwargs(case, layout=eng.layout(), chain_offset=off))
+        job.init_state_normal(); job.run(nsteps)
+        sl = slice(off, off + 16)
+        assert np.array_equal(mask[:, sl], job.accept), (name, off)
+        assert np.array_equal(x[sl], job.X) and np.array_equal(lt[sl], job.LT) and np.array_equal(g[sl], job.G), (name, off)
+    eng.close()
+
+
+def test_full_size_pair_transposed_hmc_moments():
+    """65,536 chains x 100 dims on layout kind 3, HMC L=10 eps=0.1 (mixes in a few transitions): the ensemble of final
+    states has the target's moments (mean 0, var 1/2 per coordinate; tolerances = 5 standard errors of 65,536 draws,
+    maximum over 100 coordinates), lt and the gradient are consistent with x, and one stream or two give the same bits."""
+    n, d = 65536, 100
+    kw = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.negdot(d), nchains=n, nsteps=60, leapstep=0.1, nleaps=10, monitor=0)
+    a = K.Engine(steps_per_launch=16, **kw); a.init_state_normal(); a.run(60)
+    b = K.Engine(steps_per_launch=1, nstreams=1, **kw); b.init_state_normal(); b.run(60)
+    assert a.layout()[0] == 3
+    xa, lta, ga = a.state(); xb, ltb, gb = b.state()
+    assert np.array_equal(xa, xb) and np.array_equal(lta, ltb) and np.array_equal(ga, gb)
+    assert np.allclose(lta, -(xa * xa).sum(axis=1), rtol=1e-12) and np.array_equal(ga, -2.0 * xa)
+    mean = xa.mean(axis=0); var = xa.var(axis=0)
+    assert np.max(np.abs(mean)) < 5 * np.sqrt(0.5 / n), np.max(np.abs(mean))
+    assert np.max(np.abs(var - 0.5)) < 5 * 0.5 * np.sqrt(2.0 / n), (var.min(), var.max())
+    na, nt = a.accept_counts()
+    assert nt == 60 and 0.8 < na.mean() / 60 <= 1.0
+    a.close(); b.close()
+
+
 # ------------------------------------------------------------------ full-size properties (BASELINE shapes)
 def test_full_size_mala_properties():
     """BASELINE cfg 2 shape (65,536 chains x 100 dims): determinism, launch-split invariance, and pooled
