@@ -230,16 +230,39 @@ def test_launch_splitting_does_not_change_results(name, splits, spl):
     eng.close()
 
 
-def test_sharding_invariance():
-    """Rank r's shard (chain_offset) reproduces the same chains as the single-GPU job."""
-    case = cases.make_case("mala_d100")
-    full = K.Engine(**cases.engine_kwargs(case)); full.init_state_normal(); full.run(case["nsteps"])
+@pytest.mark.parametrize("name,monitor", [("mala_d100", L.MON_ACCEPT | L.MON_SUMMARIES), ("dt_mala_d100_small_step", L.MON_ACCEPT),
+                                          ("dt_hmc_d100", L.MON_ACCEPT)])
+def test_sharding_invariance(name, monitor):
+    """Rank r's shard (chain_offset) reproduces the same chains as the single-GPU job — group layout and
+    pair-transposed layout (the shard boundary does not fall on a wavefront-group boundary there)."""
+    case = cases.make_case(name)
+    full = K.Engine(**cases.engine_kwargs(case, monitor=monitor)); full.init_state_normal(); full.run(case["nsteps"])
     xf = full.state()[0]; mf = full.accept_mask()
-    off, cnt = K.shard_chains(case["nchains"], 1, 2)
-    part = K.Engine(**cases.engine_kwargs(dict(case, nchains=cnt), chain_offset=off))
-    part.init_state_normal(); part.run(case["nsteps"])
-    assert np.array_equal(part.state()[0], xf[off:off + cnt]) and np.array_equal(part.accept_mask(), mf[:, off:off + cnt])
-    full.close(); part.close()
+    for rank in (0, 1, 2):
+        off, cnt = K.shard_chains(case["nchains"], rank, 3)
+        part = K.Engine(**cases.engine_kwargs(dict(case, nchains=cnt), monitor=monitor, chain_offset=off))
+        assert part.layout() == full.layout()
+        part.init_state_normal(); part.run(case["nsteps"])
+        assert np.array_equal(part.state()[0], xf[off:off + cnt]) and np.array_equal(part.accept_mask(), mf[:, off:off + cnt])
+        part.close()
+    full.close()
+
+
+def test_reset_and_error_paths_on_pair_transposed_layout():
+    case = cases.make_case("dt_mala_d100_small_step")
+    eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_ACCEPT)); eng.init_state_normal()
+    assert eng.layout()[0] == 3
+    x0 = eng.state()[0]
+    eng.run(case["nsteps"]); x1 = eng.state()[0]; m1 = eng.accept_mask()
+    with pytest.raises(K.KlaraError):
+        eng.run(1)                                  # beyond nsteps: the accept-mask buffer is full (KLARA_ERR_STATE)
+    eng.reset(x0); eng.run(case["nsteps"])
+    assert np.array_equal(eng.state()[0], x1) and np.array_equal(eng.accept_mask(), m1)
+    bad = x0.copy(); bad[5, 7] = np.inf
+    with pytest.raises(K.KlaraError) as ei:
+        eng.set_state(bad)
+    assert ei.value.status == L.ERR_NONFINITE_INIT
+    eng.close()
 
 
 def test_reset_rewinds_the_job():
