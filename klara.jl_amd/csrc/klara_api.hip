@@ -60,13 +60,14 @@ static int cnt_predicate(const klara_desc& d)
 
 static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-// layout kind 3 serves the jobs whose transition is pure elementwise work plus three sums (see klara_diagt.h)
+// layout kind 3 serves the jobs whose transition is pure elementwise work plus three sums (see klara_diagt.h):
+// diagonal Gaussian, MH / MALA / HMC, nothing tunes (VanillaMCTuner, not verbose), any monitor
 static bool diagt_eligible(const klara_desc& d)
 {
     if (d.target != KLARA_TARGET_GAUSS_DIAG || d.sampler == KLARA_SAMPLER_SLICE) return false;
     if ((d.ndims & 1) || d.ndims > 2 * KLARA_DIAGT_Q * KLARA_DIAGT_NP_MAX) return false;
     const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
-    if (!plain || (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0) return false;
+    if (!plain) return false;
     if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
     if (getenv("KLARA_LAYOUT_E")) return false;
     return true;
@@ -87,7 +88,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
         if (D <= 2) *E = 2; else if (D <= 4) *E = 4; else if (D <= 8) *E = 8; else return KLARA_ERR_UNSUPPORTED;
         return KLARA_OK;
     }
-    // diagonal Gaussian, nothing tunes and nothing but the accept mask is monitored: the pair-transposed layout
+    // diagonal Gaussian and nothing tunes: the pair-transposed layout
     // (klara_diagt.h), Q = 8 lanes per chain, NP element pairs per lane
     if (diagt_eligible(d)) {
         const int need = (D + 2 * KLARA_DIAGT_Q - 1) / (2 * KLARA_DIAGT_Q);
@@ -518,6 +519,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
     if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, h->E, h->Pfrag, grid_for(h), h->stream);
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
+        const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on
         const long long groups = (d.nchains + KLARA_DIAGT_CPW - 1) / KLARA_DIAGT_CPW, per = (groups + h->nparts - 1) / h->nparts;
         for (int j = 0; j < h->nparts; ++j) {
             KLaunch kp = kl;
@@ -527,9 +529,9 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
             hipStream_t st = j == 0 ? h->stream : h->side[j - 1];
             hipError_t e;
             switch (d.sampler) {
-            case KLARA_SAMPLER_MH: e = klara_launch_diagt_mh(p, kp, h->E / 2, onestep, unitw, grid, st); break;
-            case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala(p, kp, h->E / 2, onestep, unitw, grid, st); break;
-            default: e = klara_launch_diagt_hmc(p, kp, h->E / 2, onestep, unitw, grid, st); break;
+            case KLARA_SAMPLER_MH: e = klara_launch_diagt_mh(p, kp, h->E / 2, onestep, unitw, mon, grid, st); break;
+            case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala(p, kp, h->E / 2, onestep, unitw, mon, grid, st); break;
+            default: e = klara_launch_diagt_hmc(p, kp, h->E / 2, onestep, unitw, mon, grid, st); break;
             }
             if (e != hipSuccess) return e;
         }

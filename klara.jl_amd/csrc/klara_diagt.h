@@ -10,8 +10,9 @@
 // work — cross-lane reductions, the accept test, addressing, the loop — is shared by 8 chains instead of 2, the
 // reduction tree is 3 DPP steps instead of 5, and 89% instead of 78% of the lane slots hold real elements.
 //
-// Scope: nothing tunes and nothing is monitored except (optionally) the accept mask, i.e. the VanillaMCTuner jobs that
-// the throughput figures are quoted on; D even, D <= 16*NP.  Everything else runs on the group layout (klara_kernels.h).
+// Scope: nothing tunes (VanillaMCTuner, not verbose — the jobs the throughput figures are quoted on); any monitor
+// (accept mask, running sums, value / logtarget / gradlogtarget history); D even, D <= 16*NP.  Everything else runs on
+// the group layout (klara_kernels.h).
 // Sums are taken per lane in ascending element order and then over the Q lanes by an xor butterfly — the oracle mirrors
 // this order for layout kind 3 (oracle/klara_oracle.c ko_reduce).
 #pragma once
@@ -112,10 +113,14 @@ __device__ __forceinline__ void diag_elem(double x, double w, double m, double& 
     grad = UNITW ? -2.0 * dd : (-2.0 * w) * dd;
 }
 
-template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW>
+// ONESTEP: exactly one transition per launch and no saved-sample monitor (the accepted proposal goes straight from its
+// registers to HBM).  MON: the save rule of BasicMCJob.jl:226-231 runs after every transition — per-chain running sums,
+// value / logtarget / gradlogtarget history — on the committed state (never together with ONESTEP).
+template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON>
 __global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? (UNITW ? KLARA_DT_W1 : 3) : 2) : 1))
 void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 {
+    static_assert(!(ONESTEP && MON), "monitored jobs run the committing kernel");
     constexpr int E = 2 * NP, CPW = 64 / Q;
     constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;
     const KParams& p = *pp;
@@ -158,6 +163,15 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
         if (NEEDG) load_pairs<NP, Q>(cx, wg, g);
         double lt = p.LT[chain_ok ? chain : 0];
         unsigned long long nacc = 0;
+        // saved-sample monitors (MON): running sums stay in registers over the launch's transitions
+        const bool do_sum = MON && p.sum != nullptr;
+        double sm[E], sq[E];
+        if (do_sum) {
+            load_pairs<NP, Q>(cx, group_window(p.sum, first_chain, here, D), sm);
+            load_pairs<NP, Q>(cx, group_window(p.sumsq, first_chain, here, D), sq);
+        }
+        int sphase = kl.save_phase0;
+        long long scol = kl.save_col0;
 
         for (int s = 0; s < nsteps; ++s) {
             const unsigned long long t = kl.t0 + (unsigned long long)s;
@@ -275,6 +289,29 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                     lt = ltp;
                 }
             }
+            // save rule: BasicMCJob.jl:226-231 with postrange = (burnin+1):thinning:nsteps (BasicMCRange.jl:36); the
+            // phase / column bookkeeping comes from the host (klara_run_async), as in the group-layout kernel
+            const long long i1 = (long long)t + 1;
+            if (MON && i1 > p.burnin && i1 <= p.nsteps_total) {
+                if (sphase == 0) {
+                    if (do_sum) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) { sm[e] = sm[e] + x[e]; sq[e] = sq[e] + x[e] * x[e]; }
+                    }
+                    if (scol < p.hist_cols) {
+                        const long long col0 = scol * p.nchains + first_chain;
+                        if (p.hist != nullptr) store_pairs<NP, Q>(cx, group_window(p.hist, col0, here, D), x);
+                        if (NEEDG && p.hist_g != nullptr) store_pairs<NP, Q>(cx, group_window(p.hist_g, col0, here, D), g);
+                        if (p.hist_lt != nullptr && chain_ok && cx.q == 0) p.hist_lt[scol * p.nchains + chain] = lt;
+                    }
+                    ++scol;
+                }
+                sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
+            }
+        }
+        if (do_sum) {
+            store_pairs<NP, Q>(cx, group_window(p.sum, first_chain, here, D), sm);
+            store_pairs<NP, Q>(cx, group_window(p.sumsq, first_chain, here, D), sq);
         }
         if (!ONESTEP && nacc != 0) {
             store_pairs<NP, Q>(cx, wx, x);

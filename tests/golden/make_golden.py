@@ -24,11 +24,10 @@ from klara_jl_amd import _lib as L  # noqa: E402
 
 def run_case(name):
     c = cases.make_case(name)
-    layout = None
-    if name in cases.DIAGT_CASES:      # pair-transposed layout (kind 3): the job monitors only the accept mask
-        layout = O.default_layout(c["target"].kind, c["target"].ndims, sampler=c["sampler"], plain=True, monitor=L.MON_ACCEPT)
-        assert layout[0] == 3
+    layout = None                      # the oracle mirrors the product's layout choice (oracle_ffi.default_layout)
     job = O.OracleJob(**cases.oracle_kwargs(c, layout=layout))
+    if name in cases.DIAGT_CASES:
+        assert job.layout.kind == 3
     st = job.init_state_normal() if c["x0"] is None else job.set_state(c["x0"])
     assert st == 0, (name, st)
     x0 = job.X.copy()

@@ -6,6 +6,7 @@ descriptor the product's C ABI takes and returns everything the parity tests com
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -65,14 +66,19 @@ DIAGT_NP_MENU = (1, 2, 4, 6, 7, 8)      # klara_launch.h KLARA_DIAGT_NP_MENU_DO
 DIAGT_Q = 8
 
 
-def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, plain=False, monitor=None):
-    """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box).
-    `sampler`, `plain` (VanillaMCTuner, not verbose) and `monitor` are only needed to recognise the pair-transposed
-    layout (kind 3) of diagonal-Gaussian jobs that monitor at most the accept mask."""
+def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, tuner=0, tuner_mode=0, verbose=False):
+    """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box).  `sampler`, `tuner`,
+    `tuner_mode` and `verbose` are only needed to recognise the pair-transposed layout (kind 3): diagonal Gaussian,
+    MH / MALA / HMC, even D <= 128, and nothing counts proposals or tunes (klara_api.hip diagt_eligible)."""
     d = int(ndims)
+    if sampler is not None:
+        counts = bool(verbose) if sampler in (L.SAMPLER_MH, L.SAMPLER_SLICE) else (bool(verbose) or tuner == L.TUNER_ACCEPT_RATE)
+        plain = (not counts) and tuner_mode == L.TUNE_PER_CHAIN and tuner != L.TUNER_DUAL_AVERAGING
+    else:
+        plain = False
     if (target_kind == L.TARGET_GAUSS_DIAG and sampler is not None and sampler != L.SAMPLER_SLICE and plain
-            and monitor is not None and (monitor & ~L.MON_ACCEPT) == 0 and d % 2 == 0 and d <= 16 * DIAGT_NP_MENU[-1]):
-        np_ = next(v for v in DIAGT_NP_MENU if v >= (d + 15) // 16)
+            and d % 2 == 0 and d <= 2 * DIAGT_Q * DIAGT_NP_MENU[-1] and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0"):
+        np_ = next(v for v in DIAGT_NP_MENU if v >= (d + 2 * DIAGT_Q - 1) // (2 * DIAGT_Q))
         return (3, DIAGT_Q, 2 * np_)
     if target_kind == L.TARGET_GAUSS_DENSE:
         ne = 8 if d <= 32 else 16 if d <= 64 else 25 if d <= 100 else 32
@@ -140,7 +146,8 @@ class OracleJob:
         d.hier_prior_prec, d.hier_gamma_a, d.hier_gamma_b = float(hier_prior_prec), float(hier_gamma_a), float(hier_gamma_b)
         d.seed = int(seed)
         self.desc = d
-        k, g, e = layout if layout is not None else default_layout(int(target_kind), self.D, int(d.logit_ndata))
+        k, g, e = layout if layout is not None else default_layout(int(target_kind), self.D, int(d.logit_ndata), sampler=int(sampler),
+                                                                   tuner=int(tuner), tuner_mode=int(tuner_mode), verbose=bool(verbose))
         self.layout = KoLayout(k, g, e)
         nt = 1 if tuner_mode == L.TUNE_POOLED else self.N
         self.X = np.zeros((self.N, self.D)); self.G = np.zeros((self.N, self.D)); self.LT = np.zeros(self.N)

@@ -147,7 +147,7 @@ def test_parity_pair_transposed_layout(name, mode):
     eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_ACCEPT, steps_per_launch={"one_launch": 0, "launch_per_transition": 1, "mixed": 7}[mode]))
     layout = eng.layout()
     assert layout[0] == 3 and layout[1] == 8, layout
-    assert tuple(layout) == tuple(O.default_layout(case["target"].kind, case["target"].ndims, sampler=case["sampler"], plain=True, monitor=L.MON_ACCEPT))
+    assert tuple(layout) == tuple(O.default_layout(case["target"].kind, case["target"].ndims, sampler=case["sampler"]))
     job = O.OracleJob(**cases.oracle_kwargs(case, layout=layout))
     eng.init_state_normal(); assert job.init_state_normal() == 0
     x, lt, g = eng.state()
@@ -169,15 +169,35 @@ def test_parity_pair_transposed_layout(name, mode):
 
 
 def test_pair_transposed_layout_is_optional():
-    """Summaries, tuners, odd D or the slice sampler keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
+    """Tuners, odd D, D > 128 or the slice sampler keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
     case = cases.make_case("dt_mala_d100")
-    e = K.Engine(**cases.engine_kwargs(case)); assert e.layout()[0] == 0; e.close()                  # monitors summaries
+    e = K.Engine(**cases.engine_kwargs(case)); assert e.layout()[0] == 3; e.close()                  # any monitor
     e = K.Engine(**cases.engine_kwargs(case, monitor=0)); assert e.layout()[0] == 3; e.close()
     e = K.Engine(**cases.engine_kwargs(case, monitor=0, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.5)); assert e.layout()[0] == 0; e.close()
+    e = K.Engine(**cases.engine_kwargs(case, monitor=0, verbose=True)); assert e.layout()[0] == 0; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d129"), monitor=0)); assert e.layout()[0] == 0; e.close()
+    e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d300"), monitor=0)); assert e.layout()[0] == 0; e.close()
+    e = K.Engine(**cases.engine_kwargs(cases.make_case("slice_d100_nostepout"), monitor=0)); assert e.layout()[0] == 0; e.close()
     os.environ["KLARA_LAYOUT_KIND"] = "0"
     try:
         e = K.Engine(**cases.engine_kwargs(case, monitor=0)); assert e.layout()[0] == 0; e.close()
+    finally:
+        del os.environ["KLARA_LAYOUT_KIND"]
+
+
+# VanillaMCTuner jobs on even-D diagonal Gaussians run on the pair-transposed layout by default; the same cases forced
+# onto the group layout keep that path covered (both compared with the oracle told the respective summation order)
+GROUP_FORCED = [n for n in cases.ALL_CASES if n in ("mh_readme", "mh_d100", "mala_d100", "mala_d100_small_step", "hmc_d100", "hmc_d128_full")]
+
+
+@pytest.mark.parametrize("name", GROUP_FORCED)
+def test_parity_with_oracle_group_layout_forced(name):
+    os.environ["KLARA_LAYOUT_KIND"] = "0"
+    try:
+        case = cases.make_case(name)
+        eng, job = _run_pair(case)
+        assert eng.layout()[0] == 0
+        _assert_same(eng, job, case)
     finally:
         del os.environ["KLARA_LAYOUT_KIND"]
 
