@@ -61,13 +61,12 @@ static int cnt_predicate(const klara_desc& d)
 static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // layout kind 3 serves the jobs whose transition is pure elementwise work plus three sums (see klara_diagt.h):
-// diagonal Gaussian, MH / MALA / HMC, nothing tunes (VanillaMCTuner, not verbose), any monitor
+// diagonal Gaussian, MH / MALA / HMC, Vanilla or AcceptanceRate tuner (per chain or pooled), any monitor
 static bool diagt_eligible(const klara_desc& d)
 {
     if (d.target != KLARA_TARGET_GAUSS_DIAG || d.sampler == KLARA_SAMPLER_SLICE) return false;
     if ((d.ndims & 1) || d.ndims > 2 * KLARA_DIAGT_Q * KLARA_DIAGT_NP_MAX) return false;
-    const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
-    if (!plain) return false;
+    if (d.tuner == KLARA_TUNER_DUAL_AVERAGING) return false;              // per-chain trajectory lengths: group layout
     if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
     if (getenv("KLARA_LAYOUT_E")) return false;
     return true;
@@ -234,6 +233,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         int np = groups >= 4096 ? 2 : 1;                       // >= one full round of wavefronts (4 per SIMD) per partition
         if (desc->nstreams >= 1 && desc->nstreams <= 4) np = desc->nstreams;
         if (const char* s = getenv("KLARA_STREAMS")) { const int v = atoi(s); if (v >= 1 && v <= 4) np = v; }
+        if (desc->tuner_mode == KLARA_TUNE_POOLED) np = 1;     // the pooled tuner update sits between launches, on one stream
         if (np > groups) np = (int)groups;
         h->nparts = np;
         if (np > 1) CKH(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
@@ -520,6 +520,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on
+        const bool tune = !plain;                                                              // something counts proposals / tunes
         const long long groups = (d.nchains + KLARA_DIAGT_CPW - 1) / KLARA_DIAGT_CPW, per = (groups + h->nparts - 1) / h->nparts;
         for (int j = 0; j < h->nparts; ++j) {
             KLaunch kp = kl;
@@ -529,9 +530,9 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
             hipStream_t st = j == 0 ? h->stream : h->side[j - 1];
             hipError_t e;
             switch (d.sampler) {
-            case KLARA_SAMPLER_MH: e = klara_launch_diagt_mh(p, kp, h->E / 2, onestep, unitw, mon, grid, st); break;
-            case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala(p, kp, h->E / 2, onestep, unitw, mon, grid, st); break;
-            default: e = klara_launch_diagt_hmc(p, kp, h->E / 2, onestep, unitw, mon, grid, st); break;
+            case KLARA_SAMPLER_MH: e = klara_launch_diagt_mh(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, grid, st); break;
+            case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, grid, st); break;
+            default: e = klara_launch_diagt_hmc(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, grid, st); break;
             }
             if (e != hipSuccess) return e;
         }

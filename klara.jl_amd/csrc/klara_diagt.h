@@ -10,7 +10,7 @@
 // work — cross-lane reductions, the accept test, addressing, the loop — is shared by 8 chains instead of 2, the
 // reduction tree is 3 DPP steps instead of 5, and 89% instead of 78% of the lane slots hold real elements.
 //
-// Scope: nothing tunes (VanillaMCTuner, not verbose — the jobs the throughput figures are quoted on); any monitor
+// Scope: VanillaMCTuner (the jobs the throughput figures are quoted on) or AcceptanceRateMCTuner, per chain or pooled; any monitor
 // (accept mask, running sums, value / logtarget / gradlogtarget history); D even, D <= 16*NP.  Everything else runs on
 // the group layout (klara_kernels.h).
 // Sums are taken per lane in ascending element order and then over the Q lanes by an xor butterfly — the oracle mirrors
@@ -116,11 +116,14 @@ __device__ __forceinline__ void diag_elem(double x, double w, double m, double& 
 // ONESTEP: exactly one transition per launch and no saved-sample monitor (the accepted proposal goes straight from its
 // registers to HBM).  MON: the save rule of BasicMCJob.jl:226-231 runs after every transition — per-chain running sums,
 // value / logtarget / gradlogtarget history — on the committed state (never together with ONESTEP).
-template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON>
+// TUNE: the tuner bookkeeping of the group-layout kernel (proposal / accept counters, AcceptanceRateMCTuner per chain or
+// pooled per GPU, verbose counting) — the same device functions, per-chain state in registers over the launch.
+template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false>
 __global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? (UNITW ? KLARA_DT_W1 : 3) : 2) : 1))
 void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 {
-    static_assert(!(ONESTEP && MON), "monitored jobs run the committing kernel");
+    static_assert(!(ONESTEP && (MON || TUNE)), "monitored / tuned jobs run the committing kernel");
+    constexpr bool PLAIN = !TUNE;              // KCNT / KPOOLED (klara_kernels.h) fold to 0 when nothing counts
     constexpr int E = 2 * NP, CPW = 64 / Q;
     constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;
     const KParams& p = *pp;
@@ -172,9 +175,19 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
         }
         int sphase = kl.save_phase0;
         long long scol = kl.save_col0;
+        // tuner state (tuners.jl:5-10): per chain, or one pooled entry per GPU
+        const bool per_chain_tune = KCNT && !KPOOLED;
+        const long long c0 = chain_ok ? chain : 0;
+        TuneRegs tn;
+        if (per_chain_tune) tn = { p.tune_step[c0], p.tune_accepted[c0], p.tune_proposed[c0], p.tune_totproposed[c0], 0, 0.0, 0.0 };
+        else if (KPOOLED) tn = { p.tune_step[0], p.tune_accepted[0], 0, 0, 0, 0.0, 0.0 };
+        else tn = { p.step0, 0, 0, 0, 0, 0.0, 0.0 };
+        const long long acc0 = tn.accepted;
+        tn.phase = per_chain_tune ? (int)(tn.proposed % p.period) : 0;
 
         for (int s = 0; s < nsteps; ++s) {
             const unsigned long long t = kl.t0 + (unsigned long long)s;
+            if (KCNT) tune_count_proposal(p, tn);
             double xp[E], gp[E];
             double red[3] = { 0.0, 0.0, 0.0 }, red1[1], red2[2];
             double u_last = 0.5, lg_last = 0.0;
@@ -208,7 +221,8 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                 else if (!acc && ratio > KD_LOG_UMIN_GUARD)
                     acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot)));
             } else if (SAMPLER == KLARA_SAMPLER_MALA) {                            // iterate/MALA.jl:78-128
-                const double h_ = p.step0, halfh = 0.5 * h_, sq = p.sqrt_step0, half_inv_h = 0.5 * p.inv_step0;
+                const double h_ = tn.step, halfh = 0.5 * h_, sq = KCNT ? __builtin_sqrt(h_) : p.sqrt_step0;
+                const double half_inv_h = 0.5 * (KCNT ? 1.0 / h_ : p.inv_step0);
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const double m_ = x[e] + halfh * g[e];                                     // :83
@@ -232,7 +246,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                 else if (!acc && ratio > KD_LOG_UMIN_GUARD)
                     acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot)));
             } else {                                                               // iterate/HMC.jl:124-201
-                const double eps = p.step0, halfe = 0.5 * eps;
+                const double eps = tn.step, halfe = 0.5 * eps;
                 double mom[E];
                 double k0[1] = { 0.0 };
 #pragma unroll
@@ -275,6 +289,8 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             }
 
             if (accept_out != nullptr && chain_ok && cx.q == 0) accept_out[(long long)s * p.nchains + chain] = acc ? 1 : 0;
+            if (KCNT && acc) tn.accepted += 1;
+            if (per_chain_tune) tuning_block(p, tn);                    // iterate/MALA.jl:130-152, HMC.jl:203-224
             if (ONESTEP) {
                 if (acc) {                               // accepted proposal: registers -> HBM, nothing else moves
                     store_pairs<NP, Q>(cx, wx, xp);
@@ -317,6 +333,14 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             store_pairs<NP, Q>(cx, wx, x);
             if (NEEDG) store_pairs<NP, Q>(cx, wg, g);
             if (chain_ok && cx.q == 0) { p.LT[chain] = lt; p.naccept[chain] += nacc; }
+        }
+        if (TUNE && chain_ok && cx.q == 0) {
+            if (per_chain_tune) {
+                p.tune_step[chain] = tn.step; p.tune_accepted[chain] = tn.accepted;
+                p.tune_proposed[chain] = tn.proposed; p.tune_totproposed[chain] = tn.totproposed;
+            } else if (KPOOLED && KCNT) {
+                atomicAdd((unsigned long long*)p.pooled_accepted, (unsigned long long)(tn.accepted - acc0));
+            }
         }
     }
 }

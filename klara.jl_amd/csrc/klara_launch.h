@@ -21,9 +21,9 @@ hipError_t klara_launch_mfma_probe(const double* A, const double* B, const doubl
                                    hipStream_t st);
 
 // pair-transposed diagonal-Gaussian kernels (layout kind 3, klara_diagt.h); NP in KLARA_DIAGT_NP_MENU, Q = KLARA_DIAGT_Q
-hipError_t klara_launch_diagt_mh(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, dim3 grid, hipStream_t st);
-hipError_t klara_launch_diagt_mala(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, dim3 grid, hipStream_t st);
-hipError_t klara_launch_diagt_hmc(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_mh(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_mala(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_hmc(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st);
 hipError_t klara_launch_diagt_init(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
 // pairs per lane the kernels are instantiated for (D <= 16*NP); a job takes the smallest one that fits
 #if KLARA_DIAGT_Q == 4     // experiment: 4 lanes per chain, 16 chains per wavefront (D = 100 -> 13 pairs per lane, no padding)
@@ -36,7 +36,9 @@ hipError_t klara_launch_diagt_init(const KParams& p, int NP, int needgrad, dim3 
 
 #define KLARA_DIAGT_CASE(S, NP_)                                                                                   \
     case NP_:                                                                                                      \
-        if (mon && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true>), grid, blk, 0, st, p, kl);     \
+        if (tune && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true, true>), grid, blk, 0, st, p, kl);  \
+        else if (tune) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, true, true>), grid, blk, 0, st, p, kl);  \
+        else if (mon && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true>), grid, blk, 0, st, p, kl); \
         else if (mon) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, true>), grid, blk, 0, st, p, kl);        \
         else if (onestep && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, true, true, false>), grid, blk, 0, st, p, kl);  \
         else if (onestep) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, true, false, false>), grid, blk, 0, st, p, kl);    \

@@ -53,6 +53,15 @@ def make_case(name):
     elif name == "mala_d3_tuned":      # AcceptanceRate tuner, per chain, several tuning events
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(3), nchains=50, nsteps=260, burnin=200,
                  driftstep=1.5, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=25)
+    elif name == "mala_d20_tuned":     # AcceptanceRate per chain on an even-D diagonal target (pair-transposed layout)
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(20), nchains=43, nsteps=260, burnin=200,
+                 driftstep=1.2, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=25)
+    elif name == "hmc_d100_tuned":     # AcceptanceRate per chain, HMC: the step enters every leapfrog
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, 100), np.linspace(0.5, 1.5, 100)),
+                 nchains=21, nsteps=90, burnin=60, leapstep=0.25, nleaps=6, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.8, period=15)
+    elif name == "mala_d100_verbose":  # VanillaMCTuner(verbose=true): proposals are counted, nothing tunes
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=20, nsteps=70, burnin=30,
+                 driftstep=0.05, verbose=True, period=20)
     elif name == "mala_d1":            # the univariate case is the D-vector kernel with D = 1
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(1), nchains=100, nsteps=60, burnin=10, driftstep=0.8)
     elif name == "hmc_d128_full":      # no padding lane: G*E == D, so the accept uniform takes the explicit path
@@ -187,7 +196,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "mh_dense_d20", "mala_swiss", "hmc_swiss", "slice_d5", "slice_d100_nostepout", "slice_swiss",
              "hmc_rats", "hmc_rats_pooled", "mala_rats", "slice_rats", "hmc_d10_dualavg", "hmc_dense_d37_dualavg",
              "hmc_rats_dualavg", "mala_d3_tuned_erf", "mala_d1", "hmc_d128_full", "mala_d129", "mh_d512",
-             "slice_d2_mvnormal"]
+             "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",

@@ -69,13 +69,9 @@ DIAGT_Q = 8
 def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, tuner=0, tuner_mode=0, verbose=False):
     """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box).  `sampler`, `tuner`,
     `tuner_mode` and `verbose` are only needed to recognise the pair-transposed layout (kind 3): diagonal Gaussian,
-    MH / MALA / HMC, even D <= 128, and nothing counts proposals or tunes (klara_api.hip diagt_eligible)."""
+    MH / MALA / HMC, even D <= 128, Vanilla or AcceptanceRate tuner (klara_api.hip diagt_eligible)."""
     d = int(ndims)
-    if sampler is not None:
-        counts = bool(verbose) if sampler in (L.SAMPLER_MH, L.SAMPLER_SLICE) else (bool(verbose) or tuner == L.TUNER_ACCEPT_RATE)
-        plain = (not counts) and tuner_mode == L.TUNE_PER_CHAIN and tuner != L.TUNER_DUAL_AVERAGING
-    else:
-        plain = False
+    plain = sampler is not None and tuner != L.TUNER_DUAL_AVERAGING      # (name kept: any Vanilla / AcceptanceRate job)
     if (target_kind == L.TARGET_GAUSS_DIAG and sampler is not None and sampler != L.SAMPLER_SLICE and plain
             and d % 2 == 0 and d <= 2 * DIAGT_Q * DIAGT_NP_MENU[-1] and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0"):
         np_ = next(v for v in DIAGT_NP_MENU if v >= (d + 2 * DIAGT_Q - 1) // (2 * DIAGT_Q))

@@ -169,12 +169,14 @@ def test_parity_pair_transposed_layout(name, mode):
 
 
 def test_pair_transposed_layout_is_optional():
-    """Tuners, odd D, D > 128 or the slice sampler keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
+    """Dual averaging, odd D, D > 128 or the slice sampler keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
     case = cases.make_case("dt_mala_d100")
     e = K.Engine(**cases.engine_kwargs(case)); assert e.layout()[0] == 3; e.close()                  # any monitor
     e = K.Engine(**cases.engine_kwargs(case, monitor=0)); assert e.layout()[0] == 3; e.close()
-    e = K.Engine(**cases.engine_kwargs(case, monitor=0, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.5)); assert e.layout()[0] == 0; e.close()
-    e = K.Engine(**cases.engine_kwargs(case, monitor=0, verbose=True)); assert e.layout()[0] == 0; e.close()
+    e = K.Engine(**cases.engine_kwargs(case, monitor=0, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.5)); assert e.layout()[0] == 3; e.close()
+    e = K.Engine(**cases.engine_kwargs(case, monitor=0, verbose=True)); assert e.layout()[0] == 3; e.close()
+    e = K.Engine(**cases.engine_kwargs(dict(case, sampler=L.SAMPLER_HMC), monitor=0, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=10))
+    assert e.layout()[0] == 0; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d129"), monitor=0)); assert e.layout()[0] == 0; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d300"), monitor=0)); assert e.layout()[0] == 0; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("slice_d100_nostepout"), monitor=0)); assert e.layout()[0] == 0; e.close()
@@ -185,9 +187,10 @@ def test_pair_transposed_layout_is_optional():
         del os.environ["KLARA_LAYOUT_KIND"]
 
 
-# VanillaMCTuner jobs on even-D diagonal Gaussians run on the pair-transposed layout by default; the same cases forced
+# Vanilla / AcceptanceRate jobs on even-D diagonal Gaussians run on the pair-transposed layout by default; the same cases forced
 # onto the group layout keep that path covered (both compared with the oracle told the respective summation order)
-GROUP_FORCED = [n for n in cases.ALL_CASES if n in ("mh_readme", "mh_d100", "mala_d100", "mala_d100_small_step", "hmc_d100", "hmc_d128_full")]
+GROUP_FORCED = [n for n in cases.ALL_CASES if n in ("mh_readme", "mh_d100", "mala_d100", "mala_d100_small_step", "hmc_d100", "hmc_d128_full",
+                                                   "hmc_d10_tuned_pooled", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose")]
 
 
 @pytest.mark.parametrize("name", GROUP_FORCED)
