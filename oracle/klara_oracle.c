@@ -44,7 +44,9 @@ typedef struct ko_layout {
     int32_t kind; /* 0: element i on lane i / E (E contiguous elements per lane), G lanes per chain
                      1: element i on lane-quarter i % 4 (MFMA-transposed), 4 lanes per chain
                      2: logistic row split: every lane holds all elements (sums over elements are sequential),
-                        the data rows are dealt round-robin to G lanes and combined by the xor tree       */
+                        the data rows are dealt round-robin to G lanes and combined by the xor tree
+                     3: pair-transposed (klara_diagt.h): element pair i/2 on lane (i/2) % G, lane partials in
+                        ascending element order, xor tree over the G lanes                                 */
     int32_t G;
     int32_t E;
 } ko_layout;
