@@ -119,7 +119,7 @@ __device__ __forceinline__ void diag_elem(double x, double w, double m, double& 
 // TUNE: the tuner bookkeeping of the group-layout kernel (proposal / accept counters, AcceptanceRateMCTuner per chain or
 // pooled per GPU, verbose counting) — the same device functions, per-chain state in registers over the launch.
 template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false>
-__global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? (UNITW ? KLARA_DT_W1 : 3) : 2) : 1))
+__global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? KLARA_DT_W1 : 2) : 1))
 void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 {
     static_assert(!(ONESTEP && (MON || TUNE)), "monitored / tuned jobs run the committing kernel");
@@ -127,17 +127,28 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
     constexpr int E = 2 * NP, CPW = 64 / Q;
     constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;
     const KParams& p = *pp;
-    kd_tables_to_lds();
+    // weights and means of a non-unit diagonal: one LDS copy per workgroup (element i at [i], padding = (1, 0)) instead
+    // of 4*NP registers per lane; a pair's (w, mu) values are 16-byte LDS reads where they are used
+    __shared__ __attribute__((aligned(16))) double lds_w[UNITW ? 2 : 2 * NP * Q];
+    __shared__ __attribute__((aligned(16))) double lds_mu[UNITW ? 2 : 2 * NP * Q];
+    if (!UNITW) {
+        for (int i = (int)threadIdx.x; i < 2 * NP * Q; i += (int)blockDim.x) {
+            lds_w[i] = (p.gw != nullptr && i < p.D) ? p.gw[i] : 1.0;
+            lds_mu[i] = (p.gmu != nullptr && i < p.D) ? p.gmu[i] : 0.0;
+        }
+    }
+    kd_tables_to_lds();          // (ends with the workgroup barrier)
     const int D = p.D;
     const PairCtx<NP, Q> cx = make_pctx<NP, Q>(D);
     const int nsteps = ONESTEP ? 1 : kl.nsteps;
     guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
 
-    double w[E], mu[E], sig[E];          // (unused ones vanish: UNITW needs no w/mu, only MH has proposal scales)
-    if (!UNITW) {
-        load_pair_param<NP, Q>(cx, p.gw, D, 1.0, w);
-        load_pair_param<NP, Q>(cx, p.gmu, D, 0.0, mu);
-    }
+    double sig[E];                       // (only MH has proposal scales)
+    const auto wv = [&](int e) { return UNITW ? 1.0 : lds_w[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
+    const auto mv = [&](int e) { return UNITW ? 0.0 : lds_mu[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
+    // inside the leapfrog loop the reads are volatile: otherwise they are hoisted out of the loop into 4*NP registers
+    const auto wvl = [&](int e) { return UNITW ? 1.0 : *(volatile const double*)&lds_w[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
+    const auto mvl = [&](int e) { return UNITW ? 0.0 : *(volatile const double*)&lds_mu[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
     if (SAMPLER == KLARA_SAMPLER_MH) load_pair_param<NP, Q>(cx, p.vecparam, D, 1.0, sig);
     const double gconst = p.gconst;
 
@@ -209,7 +220,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                 for (int e = 0; e < E; ++e) {
                     xp[e] = x[e] + sig[e] * z[e];                                              // MH.jl:79
                     double term, gd;
-                    diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gd);       // :81
+                    diag_elem<UNITW>(xp[e], wv(e), mv(e), term, gd);       // :81
                     red[0] = red[0] + term;
                 }
                 red1[0] = red[0];
@@ -228,7 +239,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                     const double m_ = x[e] + halfh * g[e];                                     // :83
                     xp[e] = m_ + sq * z[e];                                                    // :84
                     double term;
-                    diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gp[e]);    // :86
+                    diag_elem<UNITW>(xp[e], wv(e), mv(e), term, gp[e]);    // :86
                     red[0] = red[0] + term;
                     const double q1 = m_ - xp[e];
                     red[1] = red[1] + (q1 * q1) * half_inv_h;                                  // :90
@@ -265,14 +276,14 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                         mom[e] = mom[e] + halfe * gp[e];
                         xp[e] = xp[e] + eps * mom[e];
                         double term;
-                        diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gp[e]);
+                        diag_elem<UNITW>(xp[e], wvl(e), mvl(e), term, gp[e]);
                         mom[e] = mom[e] + halfe * gp[e];
                     }
                 }
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     double term, gd;
-                    diag_elem<UNITW>(xp[e], UNITW ? 1.0 : w[e], UNITW ? 0.0 : mu[e], term, gd);   // :157
+                    diag_elem<UNITW>(xp[e], wv(e), mv(e), term, gd);   // :157
                     red[0] = red[0] + term;
                     red[1] = red[1] + mom[e] * mom[e];
                 }
