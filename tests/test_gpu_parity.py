@@ -168,6 +168,20 @@ def test_parity_pair_transposed_layout(name, mode):
     eng.close()
 
 
+def test_layout_choice_matches_its_mirror():
+    """tests/oracle_ffi.default_layout (what the CPU-side golden generator assumes) is the product's choice for every
+    dimension and tuner it can meet."""
+    for d in list(range(1, 140)) + [200, 256, 257, 400, 512]:
+        for sampler, extra in ((L.SAMPLER_MALA, dict(driftstep=0.1)), (L.SAMPLER_MH, dict(mh_sigma=np.ones(d))),
+                               (L.SAMPLER_SLICE, dict(slice_widths=np.ones(d)))):
+            for tuner in (L.TUNER_VANILLA, L.TUNER_ACCEPT_RATE):
+                if sampler == L.SAMPLER_SLICE and d > 64:
+                    continue
+                e = K.Engine(sampler=sampler, target=K.GaussDiagTarget.negdot(d), nchains=5, nsteps=2, tuner=tuner, targetrate=0.5, **extra)
+                assert tuple(e.layout()) == tuple(O.default_layout(L.TARGET_GAUSS_DIAG, d, sampler=sampler, tuner=tuner)), (d, sampler, tuner)
+                e.close()
+
+
 def test_pair_transposed_layout_is_optional():
     """Dual averaging, odd D, D > 128 or the slice sampler keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
     case = cases.make_case("dt_mala_d100")
