@@ -16,7 +16,7 @@
  *                      counter = (block_lo, block_hi, subsequence_lo, subsequence_hi)
  *                      (/opt/rocm/include/rocrand/rocrand_philox4x32_10.h: seed(), discard_*_impl()).
  *   kd_u52             two 32-bit words -> uniform double strictly inside (0,1), exact.
- *   kd_log, kd_exp     FreeBSD-msun-style log/exp (<1 ulp), branch-light, built from + * / fma.
+ *   kd_log             FreeBSD-msun-style log (<1 ulp), every special case; kd_exp: 128-entry table, division-free (<1 ulp).
  *   kd_log_u01         table-driven, division-free log for the uniforms (radius and Metropolis tests).
  *   kd_sincos2pi       sin(2*pi*u), cos(2*pi*u) for u in [0,1): 256-entry table + rotation.
  *   kd_normal_pair     Box-Muller: one Philox block -> two N(0,1) doubles.
@@ -157,26 +157,30 @@ KD_FN double kd_log(double x)
 #include "detmath_tables.h"
 static const double kd_logtab_host[256] __attribute__((aligned(16))) = KD_LOGTAB_INIT;
 static const double kd_sctab_host[512] __attribute__((aligned(16))) = KD_SCTAB_INIT;
+static const double kd_exptab_host[256] __attribute__((aligned(16))) = KD_EXPTAB_INIT;
 #if defined(__HIPCC__)
-/* On the GPU the tables live in LDS (6 KB per workgroup): the lookups are per-lane gathers, and as DS reads they are
+/* On the GPU the tables live in LDS (8 KB per workgroup): the lookups are per-lane gathers, and as DS reads they are
  * tracked by lgkmcnt, so waiting for one never drains the HBM prefetch that is in flight on vmcnt.  Every kernel that
- * draws normals or takes a uniform's log calls kd_tables_to_lds() once, first thing. */
+ * draws normals, takes a uniform's log or calls kd_exp calls kd_tables_to_lds() once, first thing. */
 static __device__ const double kd_logtab_dev[256] __attribute__((aligned(16))) = KD_LOGTAB_INIT;
 static __device__ const double kd_sctab_dev[512] __attribute__((aligned(16))) = KD_SCTAB_INIT;
-__shared__ double kd_tab_lds[768] __attribute__((aligned(16)));
+static __device__ const double kd_exptab_dev[256] __attribute__((aligned(16))) = KD_EXPTAB_INIT;
+__shared__ double kd_tab_lds[1024] __attribute__((aligned(16)));
 __device__ __forceinline__ void kd_tables_to_lds()
 {
-    for (int i = (int)threadIdx.x; i < 768; i += (int)blockDim.x)
-        kd_tab_lds[i] = i < 256 ? kd_logtab_dev[i] : kd_sctab_dev[i - 256];
+    for (int i = (int)threadIdx.x; i < 1024; i += (int)blockDim.x)
+        kd_tab_lds[i] = i < 256 ? kd_logtab_dev[i] : (i < 768 ? kd_sctab_dev[i - 256] : kd_exptab_dev[i - 768]);
     __syncthreads();
 }
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KD_LOGTAB(i) kd_tab_lds[i]
 #define KD_SCTAB(i) kd_tab_lds[256 + (i)]
+#define KD_EXPTAB(i) kd_tab_lds[768 + (i)]
 #else
 #define KD_LOGTAB(i) kd_logtab_host[i]
 #define KD_SCTAB(i) kd_sctab_host[i]
+#define KD_EXPTAB(i) kd_exptab_host[i]
 #endif
 
 KD_FN double kd_log_u01(double x)
@@ -203,36 +207,44 @@ KD_FN double kd_log_u01(double x)
 }
 
 /* ---------------------------------------------------------------- exp */
-/* Algorithm: FreeBSD msun e_exp.c.  x = k*ln2 + r, |r| <= 0.5 ln2, exp(r) = 1 + r*c/(2-c) ... */
+/* Division-free table method (the scheme of Arm's optimized-routines exp, restated): x = k ln2/128 + r, |r| <= ln2/256;
+ * exp(x) = 2^(k>>7) * T[k & 127] * (1 + p(r)), T = 2^(i/128) as a (hi, lo) pair, p = r + r^2/2 + ... + r^5/120.
+ * < 1 ulp (tests/test_oracle_kats.py).  Overflow -> +inf, underflow -> subnormals / 0 through a two-factor power-of-two
+ * scaling (one rounding), NaN -> NaN. */
 KD_FN double kd_exp(double x)
 {
-    const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
-                 invln2 = 1.44269504088896338700e+00,
-                 P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
-                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
-                 P5 = 4.13813679705723846039e-08;
+    const double C2 = 0.5, C3 = 0x1.5555555555555p-3, C4 = 0x1.5555555555555p-5, C5 = 0x1.1111111111111p-7;
     /* clamp so that (int) conversion is defined; specials fixed at the end */
     double xc = x;
     if (!(xc > -800.0)) xc = -800.0;   /* also catches NaN */
     if (xc > 800.0) xc = 800.0;
-    const int k = (int)(invln2 * xc + (xc < 0.0 ? -0.5 : 0.5));
+    const int k = (int)(KD_INVLN2N * xc + (xc < 0.0 ? -0.5 : 0.5));
     const double dk = (double)k;
-    const double hi = xc - dk * ln2hi;
-    const double lo = dk * ln2lo;
-    const double r = hi - lo;
-    const double xx = r * r;
-    const double c = r - xx * kd_fma(xx, kd_fma(xx, kd_fma(xx, kd_fma(xx, P5, P4), P3), P2), P1);
-    const double y = 1.0 + (r * c / (2.0 - c) - lo + hi);
-    /* scale by 2^k in two exact-power steps (handles subnormal results with one final rounding
+    const double r = kd_fma(dk, -KD_LN2N_LO, kd_fma(dk, -KD_LN2N_HI, xc));     /* dk*LN2N_HI is exact (32-bit constant) */
+    const int idx = k & 127, e = k >> 7;                                      /* arithmetic shift: floor */
+    const double th = KD_EXPTAB(2 * idx), tl = KD_EXPTAB(2 * idx + 1);
+    const double r2 = r * r;
+    const double p = kd_fma(r2 * r2, kd_fma(r, C5, C4), kd_fma(r2, kd_fma(r, C3, C2), r));
+    const double y = th + kd_fma(th, p, tl);
+    /* scale by 2^e in two exact-power steps (handles subnormal results with one final rounding
      * in the second multiply, like scalbn) */
-    const int k1 = k / 2, k2 = k - k1;
-    const double s1 = kd_u2d((uint64_t)(0x3ff + k1) << 52);
-    const double s2 = kd_u2d((uint64_t)(0x3ff + k2) << 52);
+    const int e1 = e / 2, e2 = e - e1;
+    const double s1 = kd_u2d((uint64_t)(0x3ff + e1) << 52);
+    const double s2 = kd_u2d((uint64_t)(0x3ff + e2) << 52);
     double res = y * s1 * s2;
     if (x > 709.782712893383973096) res = __builtin_inf();
     if (x < -745.13321910194110842) res = 0.0;
     if (x != x) res = x;
     return res;
+}
+
+/* log of a positive number that may be +inf or NaN (1 + exp(.) of the logistic target): the table log plus the two
+ * pass-through cases */
+KD_FN double kd_log_pos(double x)
+{
+    double r = kd_log_u01(x < __builtin_inf() ? x : 1.0);
+    if (!(x < __builtin_inf())) r = x + x;          /* +inf, NaN */
+    return r;
 }
 
 /* ---------------------------------------------------------------- erf */

@@ -408,6 +408,7 @@ __global__ void k_fill2(double* a, double* b, long long n, double va, double vb)
 // with the rate pooled over the GPU's chains (KLARA_TUNE_POOLED; SURVEY §7 hard part 5).
 __global__ void k_pooled_tune(KParams p, int k)
 {
+    kd_tables_to_lds();            // rate_score -> kd_exp reads its table from LDS
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (!p.cnt) return;
     long long prop = p.tune_proposed[0] + k;

@@ -368,7 +368,7 @@ struct LogisticTarget {
             const double yr = sy[r];
             if (WANT_LT) {
                 dotxy = dotxy + xp * yr;                                          // dot(Xp, v[3])
-                slog = slog + kd_log(1.0 + kd_exp(xp));                           // sum(log(1+exp(Xp)))
+                slog = slog + kd_log_pos(1.0 + kd_exp(xp));                           // sum(log(1+exp(Xp)))
             }
             if (WANT_GRAD) {
                 const double res = yr - 1.0 / (1.0 + kd_exp(-xp));                // v[3]-1./(1+exp(-Xp))
@@ -1082,6 +1082,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 template <int TARGET, int E, int GT>
 __global__ __launch_bounds__(256) void k_init(const KParams p, int needgrad)
 {
+    kd_tables_to_lds();            // the logistic / hierarchical targets call kd_exp (table in LDS)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = typename TargetSel<TARGET, E>::type;
     const LaneCtx<E> cx = make_ctx<E, GT>(p);

@@ -152,7 +152,7 @@ static void ko_logit_eval(const ko_target_ctx* c, const double* p, double* lt, d
         for (int k = 0; k < D; ++k) xp = kd_fma(row[k], p[k], xp);            /* Xp = v[2]*p        */
         if (lt) {
             pdot[q] = pdot[q] + xp * d->logit_y[r];                             /* dot(Xp, v[3])      */
-            plog[q] = plog[q] + kd_log(1.0 + kd_exp(xp));                       /* sum(log(1+exp(Xp)))*/
+            plog[q] = plog[q] + kd_log_pos(1.0 + kd_exp(xp));                       /* sum(log(1+exp(Xp)))*/
         }
         if (g) {
             const double res = d->logit_y[r] - 1.0 / (1.0 + kd_exp(-xp));       /* v[3]-1./(1+exp(-Xp)) */
