@@ -168,6 +168,19 @@ def test_parity_pair_transposed_layout(name, mode):
     eng.close()
 
 
+@pytest.mark.parametrize("nchains", [1, 3, 9])
+@pytest.mark.parametrize("sampler,kw", [(L.SAMPLER_MALA, dict(driftstep=0.3)), (L.SAMPLER_HMC, dict(leapstep=0.2, nleaps=4)),
+                                        (L.SAMPLER_MH, dict(mh_sigma=np.full(10, 0.4)))])
+def test_pair_transposed_tiny_jobs(nchains, sampler, kw):
+    """Fewer chains than one wavefront group carries (8), D = 10 (one pair per lane, three padding lanes per chain)."""
+    case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, 10), np.linspace(0.5, 2, 10)), nchains=nchains,
+                nsteps=25, burnin=5, thinning=2, x0=None, seed=7, name="tiny", **kw)
+    eng, job = _run_pair(case, splits=[1, 9, 15], spl=4)
+    assert eng.layout()[0] == 3
+    _assert_same(eng, job, case)
+    eng.close()
+
+
 def test_layout_choice_matches_its_mirror():
     """tests/oracle_ffi.default_layout (what the CPU-side golden generator assumes) is the product's choice for every
     dimension and tuner it can meet."""
