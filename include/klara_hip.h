@@ -254,6 +254,12 @@ klara_status klara_selftest_math(int32_t device, int32_t op, int64_t n, const do
 klara_status klara_selftest_mfma_f64(int32_t device, const double* A, const double* B, const double* C,
                                      double* D);
 
+/* One v_mfma_f64_4x4x4_4b with raw per-lane operands (64 doubles each): A_b[i][k] on lane 16k + 4b + i, B_b[k][j] on
+ * lane 16k + 4b + j, C/D_b[i][j] on lane 16i + 4b + j.  Pins the lane layout and the accumulation order the dense
+ * kernel's 4-row tail tile relies on (klara_dense.h). */
+klara_status klara_selftest_mfma_f64_4x4x4(int32_t device, const double* A, const double* B, const double* C,
+                                           double* D);
+
 const char* klara_strerror(klara_status s);
 int32_t klara_abi_version(void);
 

@@ -65,7 +65,7 @@ EXPORTS = [
     "klara_run_async", "klara_synchronize", "klara_reset", "klara_get_state", "klara_get_accept_mask",
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
     "klara_get_chain_fields", "klara_get_chain_mcvar", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
-    "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_mfma_f64", "klara_strerror",
+    "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
     "klara_abi_version",
 ]
 
@@ -110,6 +110,7 @@ def load() -> C.CDLL:
         "klara_selftest_rocrand_blocks": [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p],
         "klara_selftest_math": [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_selftest_mfma_f64": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+        "klara_selftest_mfma_f64_4x4x4": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)

@@ -283,10 +283,12 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         // fragment-ordered, zero-padded P for the MFMA A operand (klara_dense.h)
         const int NE = E, MT = (NE + 3) / 4;
         std::vector<double> frag((size_t)MT * NE * 64, 0.0);
+        // (NE % 4 == 1: the last tile is the 4-row tail for v_mfma_f64_4x4x4_4b, A_b[i][k] on lane 16k + 4b + i)
+        const bool tail = (NE % 4) == 1;
         for (int t = 0; t < MT; ++t)
             for (int kk = 0; kk < NE; ++kk)
                 for (int l = 0; l < 64; ++l) {
-                    const size_t row = 16 * (size_t)t + (l & 15), col = 4 * (size_t)kk + (l >> 4);
+                    const size_t row = 16 * (size_t)t + ((tail && t == MT - 1) ? (l & 3) : (l & 15)), col = 4 * (size_t)kk + (l >> 4);
                     if (row < D && col < D) frag[((size_t)t * NE + kk) * 64 + l] = desc->gauss_prec[row * D + col];
                 }
         CK(upload(&h->Pfrag, frag.data(), frag.size()));
@@ -989,6 +991,22 @@ extern "C" klara_status klara_selftest_mfma_f64(int32_t device, const double* A,
     if (e == hipSuccess) e = hipMemcpy(buf + 128, C, 256 * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = klara_launch_mfma_probe(buf, buf + 64, buf + 128, buf + 384, 0);
     if (e == hipSuccess) e = hipMemcpy(D, buf + 384, 256 * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(buf);
+    return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
+}
+
+extern "C" klara_status klara_selftest_mfma_f64_4x4x4(int32_t device, const double* A, const double* B,
+                                                      const double* C, double* D)
+{
+    if (!A || !B || !C || !D) return KLARA_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(device));
+    double* buf = nullptr;
+    HIPCHK(dalloc(&buf, 256));
+    hipError_t e = hipMemcpy(buf, A, 64 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(buf + 64, B, 64 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(buf + 128, C, 64 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = klara_launch_mfma4_probe(buf, buf + 64, buf + 128, buf + 192, 0);
+    if (e == hipSuccess) e = hipMemcpy(D, buf + 192, 64 * sizeof(double), hipMemcpyDeviceToHost);
     hipFree(buf);
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }

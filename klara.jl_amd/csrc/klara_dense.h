@@ -104,14 +104,26 @@ __device__ __forceinline__ void mnormals(const MfmaCtx<NE>& c, unsigned long lon
 }
 
 // g = -(P x) for the wave's 16 chains.  ldsP: fragment-ordered P, (MT*NE) fragments of 64 doubles.
+//
+// Tail tile.  When NE % 4 == 1 (D = 97..100 -> NE = 25) the last 16-row tile would hold only 4 real rows — one element
+// per lane — and 12 rows of zeros.  Those 4 rows go through v_mfma_f64_4x4x4_4b instead (4 blocks of 4x4x4, 16 cycles
+// instead of 64): on gfx950 its operands sit on lane 16k + 4b + i (A_b[i][k]), 16k + 4b + j (B_b[k][j]) and its result on
+// lane 16i + 4b + j (D_b[i][j]) (scripts/probe_mfma4.hip), so with block b = chains 4b..4b+3 the B operand is again the
+// lane's own element kk, and the result D_b[i][j] = g_{16*MTF + i} of chain 4b + j lands on lane (q = i, chain) — the
+// lane that owns that element.  No shuffle, no extra registers (one f64 accumulator instead of four), the same LDS
+// footprint (the tail's A fragments take the place of the padded tile's), 10.7 % less matrix-pipe time at D = 100.
+// Its accumulation order is the same k-ascending fma chain (tests/test_gpu_parity.py::test_mfma_f64_4x4x4_order).
 template <int NE>
 __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int lane,
                                            const double (&x)[NE], double (&g)[4 * ((NE + 3) / 4)])
 {
     constexpr int MT = (NE + 3) / 4;
-    kd_double4 acc[MT];
+    constexpr bool TAIL = (NE % 4) == 1;
+    constexpr int MTF = TAIL ? MT - 1 : MT;         // tiles on v_mfma_f64_16x16x4
+    kd_double4 acc[MTF];
+    double acc_t = 0.0;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };
+    for (int t = 0; t < MTF; ++t) acc[t] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };
     // software pipeline: the A fragments of k-step kk+1 are fetched from LDS while the MT MFMAs of
     // k-step kk issue; sched_barrier keeps hipcc from hoisting all NE*MT LDS reads (VGPR blow-up).
     double a_cur[MT], a_nxt[MT];
@@ -125,17 +137,19 @@ __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int 
             for (int t = 0; t < MT; ++t) a_nxt[t] = ldsP[(t * NE + kk + 1) * 64 + lane];
         }
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+        for (int t = 0; t < MTF; ++t)
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[t], b, acc[t], 0, 0, 0);
+        if (TAIL) acc_t = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[MT - 1], b, acc_t, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < MT; ++t) a_cur[t] = a_nxt[t];
     }
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
+    for (int t = 0; t < MTF; ++t) {
         g[4 * t + 0] = -acc[t][0]; g[4 * t + 1] = -acc[t][1];
         g[4 * t + 2] = -acc[t][2]; g[4 * t + 3] = -acc[t][3];
     }
+    if (TAIL) { g[4 * MTF + 0] = -acc_t; g[4 * MTF + 1] = 0.0; g[4 * MTF + 2] = 0.0; g[4 * MTF + 3] = 0.0; }
 }
 
 template <int SAMPLER, int NE, bool DA>
@@ -412,6 +426,13 @@ __global__ __launch_bounds__(512) void k_dense_init(const KParams p, const doubl
     }
     if (cx.chain_ok && cx.q == 0) p.LT[cx.chain] = lt;
     if (bad) atomicMax((int*)p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
+}
+
+// test hook: one v_mfma_f64_4x4x4_4b with per-lane operands (lane layout and accumulation order are pinned by tests)
+__global__ void k_mfma_f64_4x4x4_probe(const double* A, const double* B, const double* C, double* Dout)
+{
+    const int lane = threadIdx.x & 63;
+    Dout[lane] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[lane], B[lane], C[lane], 0, 0, 0);
 }
 
 // test hook: D[16x16] = A[16x4] * B[4x16] + C through one v_mfma_f64_16x16x4_f64, to pin the

@@ -68,3 +68,9 @@ hipError_t klara_launch_mfma_probe(const double* A, const double* B, const doubl
     hipLaunchKernelGGL(k_mfma_f64_probe, dim3(1), dim3(64), 0, st, A, B, C, D);
     return hipGetLastError();
 }
+
+hipError_t klara_launch_mfma4_probe(const double* A, const double* B, const double* C, double* D, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_mfma_f64_4x4x4_probe, dim3(1), dim3(64), 0, st, A, B, C, D);
+    return hipGetLastError();
+}

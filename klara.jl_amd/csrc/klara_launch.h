@@ -19,6 +19,7 @@ hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag
                                    hipStream_t st);
 hipError_t klara_launch_mfma_probe(const double* A, const double* B, const double* C, double* D,
                                    hipStream_t st);
+hipError_t klara_launch_mfma4_probe(const double* A, const double* B, const double* C, double* D, hipStream_t st);
 
 // pair-transposed diagonal-Gaussian kernels (layout kind 3, klara_diagt.h); NP in KLARA_DIAGT_NP_MENU, Q = KLARA_DIAGT_Q
 hipError_t klara_launch_diagt_mh(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st);

@@ -78,6 +78,30 @@ def test_mfma_f64_order(klib):
     assert np.array_equal(D, ref)
 
 
+def test_mfma_f64_4x4x4_order(klib):
+    """v_mfma_f64_4x4x4_4b (the dense kernel's 4-row tail tile): operand lanes A_b[i][k] = 16k+4b+i, B_b[k][j] = 16k+4b+j,
+    result lane D_b[i][j] = 16i+4b+j, and every output element is ONE fma chain over k ascending starting from C —
+    the order the oracle's dense gradient uses for every row."""
+    import math
+    rng = np.random.default_rng(11)
+    for trial in range(20):
+        A = rng.standard_normal(64) * 10.0 ** rng.integers(-8, 8, 64)
+        B = rng.standard_normal(64) * 10.0 ** rng.integers(-8, 8, 64)
+        Cm = rng.standard_normal(64) * 10.0 ** rng.integers(-8, 8, 64)
+        D = np.empty(64)
+        L.check(klib.klara_selftest_mfma_f64_4x4x4(0, A.ctypes.data, B.ctypes.data, Cm.ctypes.data, D.ctypes.data), "selftest_mfma4")
+        ref = np.empty(64)
+        for b in range(4):
+            for i in range(4):
+                for j in range(4):
+                    acc = Cm[16 * i + 4 * b + j]
+                    for k in range(4):
+                        x, y = A[16 * k + 4 * b + i], B[16 * k + 4 * b + j]
+                        acc = math.fma(x, y, acc) if hasattr(math, "fma") else _fma(x, y, acc)
+                    ref[16 * i + 4 * b + j] = acc
+        assert np.array_equal(D, ref), trial
+
+
 def _fma(a, b, c):
     # exact fma via the oracle's libm-free path: use numpy longdouble (64-bit mantissa) is not exact in
     # general, so go through fractions
