@@ -232,6 +232,24 @@ def test_oracle_reproduces_golden(name):
         assert np.array_equal(out[k], gold[k], equal_nan=True), (name, k)
 
 
+def test_layout_changes_only_the_summation_order():
+    """The lane layout a handle reports (klara_get_layout) fixes the order of the per-chain sums and nothing else: the
+    same MALA job replayed by the oracle under the group layout (kind 0) and the pair-transposed layout (kind 3) draws
+    the same normals, takes the same decisions (a flip would need a Metropolis ratio within an ulp of log u) and ends
+    with log-targets equal to rounding."""
+    case = cases.make_case("dt_mala_d100_small_step")
+    a = O.OracleJob(**cases.oracle_kwargs(case, layout=(0, 32, 4)))
+    b = O.OracleJob(**cases.oracle_kwargs(case, layout=(3, 8, 14)))
+    for j in (a, b):
+        assert j.init_state_normal() == 0
+    assert np.array_equal(a.X, b.X) and np.allclose(a.LT, b.LT, rtol=1e-14)
+    for j in (a, b):
+        assert j.run(case["nsteps"]) == 0
+    assert np.array_equal(a.accept, b.accept)
+    assert np.allclose(a.X, b.X, rtol=0, atol=0) and np.allclose(a.LT, b.LT, rtol=1e-13)
+    assert not np.array_equal(a.LT, b.LT)           # ...but the sums really are taken in a different order
+
+
 def test_posterior_moments_mh_readme():
     """BASELINE cfg 1: README MH example, truth mean 0, var 1/2 (lt = -|x|^2). 64 replicas x 10000 steps."""
     job = O.OracleJob(sampler=L.SAMPLER_MH, target_kind=L.TARGET_GAUSS_DIAG, nchains=64, ndims=2, nsteps=10000,
