@@ -105,12 +105,13 @@ __device__ __forceinline__ void pair_normals(const PairCtx<NP, Q>& c, unsigned l
 
 // The diagonal target on one element (klara_kernels.h DiagTarget, same operations in the same order).  UNITW: w = 1 and
 // mu = 0 (README.md:23 -dot(z,z)): x - 0, 1*(.) and (-2*1)*(.) are exact, so dropping them changes no bit.
+// m2w = -2.0 * w, formed once per workgroup (the same product DiagTarget forms per evaluation).
 template <bool UNITW>
-__device__ __forceinline__ void diag_elem(double x, double w, double m, double& term, double& grad)
+__device__ __forceinline__ void diag_elem(double x, double w, double m2w, double m, double& term, double& grad)
 {
     const double dd = UNITW ? x : x - m;
     term = UNITW ? dd * dd : w * (dd * dd);
-    grad = UNITW ? -2.0 * dd : (-2.0 * w) * dd;
+    grad = UNITW ? -2.0 * dd : m2w * dd;
 }
 
 // ONESTEP: exactly one transition per launch and no saved-sample monitor (the accepted proposal goes straight from its
@@ -131,10 +132,12 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
     // of 4*NP registers per lane; a pair's (w, mu) values are 16-byte LDS reads where they are used
     __shared__ __attribute__((aligned(16))) double lds_w[UNITW ? 2 : 2 * NP * Q];
     __shared__ __attribute__((aligned(16))) double lds_mu[UNITW ? 2 : 2 * NP * Q];
+    __shared__ __attribute__((aligned(16))) double lds_m2w[UNITW ? 2 : 2 * NP * Q];
     if (!UNITW) {
         for (int i = (int)threadIdx.x; i < 2 * NP * Q; i += (int)blockDim.x) {
             lds_w[i] = (p.gw != nullptr && i < p.D) ? p.gw[i] : 1.0;
             lds_mu[i] = (p.gmu != nullptr && i < p.D) ? p.gmu[i] : 0.0;
+            lds_m2w[i] = -2.0 * lds_w[i];
         }
     }
     kd_tables_to_lds();          // (ends with the workgroup barrier)
@@ -146,9 +149,11 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
     double sig[E];                       // (only MH has proposal scales)
     const auto wv = [&](int e) { return UNITW ? 1.0 : lds_w[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
     const auto mv = [&](int e) { return UNITW ? 0.0 : lds_mu[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
+    const auto m2wv = [&](int e) { return UNITW ? -2.0 : lds_m2w[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
     // inside the leapfrog loop the reads are volatile: otherwise they are hoisted out of the loop into 4*NP registers
     const auto wvl = [&](int e) { return UNITW ? 1.0 : *(volatile const double*)&lds_w[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
     const auto mvl = [&](int e) { return UNITW ? 0.0 : *(volatile const double*)&lds_mu[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
+    const auto m2wvl = [&](int e) { return UNITW ? -2.0 : *(volatile const double*)&lds_m2w[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
     if (SAMPLER == KLARA_SAMPLER_MH) load_pair_param<NP, Q>(cx, p.vecparam, D, 1.0, sig);
     const double gconst = p.gconst;
 
@@ -220,7 +225,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                 for (int e = 0; e < E; ++e) {
                     xp[e] = x[e] + sig[e] * z[e];                                              // MH.jl:79
                     double term, gd;
-                    diag_elem<UNITW>(xp[e], wv(e), mv(e), term, gd);       // :81
+                    diag_elem<UNITW>(xp[e], wv(e), m2wv(e), mv(e), term, gd);       // :81
                     red[0] = red[0] + term;
                 }
                 red1[0] = red[0];
@@ -239,7 +244,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                     const double m_ = x[e] + halfh * g[e];                                     // :83
                     xp[e] = m_ + sq * z[e];                                                    // :84
                     double term;
-                    diag_elem<UNITW>(xp[e], wv(e), mv(e), term, gp[e]);    // :86
+                    diag_elem<UNITW>(xp[e], wv(e), m2wv(e), mv(e), term, gp[e]);    // :86
                     red[0] = red[0] + term;
                     const double q1 = m_ - xp[e];
                     red[1] = red[1] + (q1 * q1) * half_inv_h;                                  // :90
@@ -276,14 +281,14 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                         mom[e] = mom[e] + halfe * gp[e];
                         xp[e] = xp[e] + eps * mom[e];
                         double term;
-                        diag_elem<UNITW>(xp[e], wvl(e), mvl(e), term, gp[e]);
+                        diag_elem<UNITW>(xp[e], 1.0, m2wvl(e), mvl(e), term, gp[e]);     // (term unused in the leapfrog)
                         mom[e] = mom[e] + halfe * gp[e];
                     }
                 }
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     double term, gd;
-                    diag_elem<UNITW>(xp[e], wv(e), mv(e), term, gd);   // :157
+                    diag_elem<UNITW>(xp[e], wv(e), m2wv(e), mv(e), term, gd);   // :157
                     red[0] = red[0] + term;
                     red[1] = red[1] + mom[e] * mom[e];
                 }
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256) void k_diagt_init(const KParams p, int needgra
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         double term;
-        diag_elem<false>(x[e], w[e], mu[e], term, g[e]);
+        diag_elem<false>(x[e], w[e], -2.0 * w[e], mu[e], term, g[e]);
         red[0] = red[0] + term;
         bad = bad || !kfinite(g[e]);
     }
