@@ -72,8 +72,20 @@ static bool diagt_eligible(const klara_desc& d)
     return true;
 }
 
+// layout kind 4 (klara_hiert.h): HMC on the hierarchical target, 8 lanes per chain, 4 units per lane
+static bool hiert_eligible(const klara_desc& d)
+{
+    if (d.target != KLARA_TARGET_HIER_NORMAL || d.sampler != KLARA_SAMPLER_HMC) return false;
+    if (d.tuner == KLARA_TUNER_DUAL_AVERAGING) return false;
+    if (d.hier_nunits < 9 || d.hier_nunits > 32 || d.hier_ntimes != 5) return false;
+    if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
+    if (getenv("KLARA_LAYOUT_E")) return false;
+    return true;
+}
+
 static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E)
 {
+    if (hiert_eligible(d)) { *kind = 4; *G = 8; *E = 8; return KLARA_OK; }
     const int D = d.ndims;
     if (d.target == KLARA_TARGET_GAUSS_DENSE) {
         *kind = 1; *G = 4;
@@ -458,6 +470,7 @@ static klara_status init_common(klara_handle* h)
     hipError_t e;
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, needgrad, grid_for(h), st);
     else if (h->kind == 3) e = klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st);
+    else if (h->kind == 4) e = klara_launch_hiert_init(p, h->E / 2, d.hier_ntimes, needgrad, grid_for(h), st);
     else if (d.target == KLARA_TARGET_GAUSS_DIAG)
         e = launch_init_t<KLARA_TARGET_GAUSS_DIAG>(p, h->E, h->G, needgrad, grid_for(h), lds_for(h), st);
     else if (d.target == KLARA_TARGET_HIER_NORMAL)
@@ -540,6 +553,10 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
+    }
+    if (h->kind == 4) {
+        const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;
+        return klara_launch_hiert_hmc(p, kl, h->E / 2, d.hier_ntimes, mon, !plain, grid_for(h), h->stream);
     }
     switch (d.sampler) {
     case KLARA_SAMPLER_MH: return klara_launch_mh(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);

@@ -1,0 +1,314 @@
+// klara_hiert.h — HMC on the hierarchical normal target (KLARA_TARGET_HIER_NORMAL, BUGS "Rats") with few lanes per chain
+// (layout kind 4).
+//
+// The group layout spreads a chain's D = 2R + 5 = 65 parameters over 32 lanes (17 busy) and pays the five-value
+// butterfly, the hyper-parameter broadcasts and the exp(-2 s) evaluations of every gradient once per TWO chains:
+// ~200 VALU instructions per chain and leapfrog step (PMC), of which the arithmetic is a fraction.  Here a chain takes
+// Q = 8 lanes and a wavefront carries 8 chains: lane q owns the RPL = 4 units (rats) 4q..4q+3 — their (a_i, b_i), the
+// T observations of each and the centred covariate in registers — and every lane keeps its own copy of the five
+// hyper-parameters (a_c, b_c, s_c, s_a, s_b) with their momenta and gradients.  Per gradient: residual sums lane-local,
+// one 5-value butterfly over 8 lanes (3 DPP steps), one exp per lane (lanes 0..2 take s_c, s_a, s_b; three broadcasts),
+// the hyper-parameter gradient recomputed identically by all lanes from the reduced sums — no broadcast of the state.
+// Transition arithmetic: iterate/HMC.jl:124-201 with leapfrog! samplers.jl:122-134; target: oracle ko_hier_eval
+// (include/klara_hip.h gives the model).  Sums: lane partial over the lane's units ascending (for sum(p.*p) over its
+// elements ascending, lane 0 then adds the five hyper terms), then the xor butterfly over the 8 lanes — oracle
+// ko_reduce kind 4.
+//
+// Scope: HMC with the Vanilla or AcceptanceRate tuner (per chain or pooled per GPU), any monitor; 9 <= R <= 32 units,
+// T = 5 observations per unit.  Everything else stays on the group layout.
+#pragma once
+#include "klara_kernels.h"
+#include "klara_diagt.h"      // group_window / buffer helpers, kd_uint4
+
+#define KLARA_HIERT_Q 8
+
+template <int RPL, int NT>
+struct HierLane {
+    int lane, q, cw;
+    int R, D;
+    bool rv[RPL];              // unit RPL*q + k exists
+    unsigned roff[RPL];        // byte offset of (a_i, b_i) inside the wavefront's chain window (OOB for missing units)
+    unsigned hoff;             // byte offset of the hyper block (same for the 8 lanes of a chain)
+    double Y[RPL][NT], xc[NT]; // this lane's observations and the centred covariate
+    double p0, a0, b0;
+};
+
+template <int RPL, int NT>
+__device__ __forceinline__ HierLane<RPL, NT> make_hlane(const KParams& p)
+{
+    HierLane<RPL, NT> c;
+    c.lane = threadIdx.x & 63;
+    c.q = c.lane & (KLARA_HIERT_Q - 1);
+    c.cw = c.lane / KLARA_HIERT_Q;
+    c.R = p.hR; c.D = p.D;
+    c.p0 = p.hp0; c.a0 = p.ha0; c.b0 = p.hb0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) c.xc[j] = p.hxc[j];
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+        const int r = RPL * c.q + k;
+        c.rv[k] = r < c.R;
+        c.roff[k] = c.rv[k] ? (unsigned)((c.cw * c.D + 2 * r) * 8) : KLARA_BUF_OOB;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) c.Y[k][j] = c.rv[k] ? p.hY[r * NT + j] : 0.0;
+    }
+    c.hoff = (unsigned)((c.cw * c.D + 2 * c.R) * 8);
+    return c;
+}
+
+// state of one chain as this lane sees it: its units' (a, b) and a private copy of the hyper block
+template <int RPL>
+struct HierVec { double a[RPL], b[RPL], h[5]; };
+
+template <int RPL, int NT>
+__device__ __forceinline__ void hload(const HierLane<RPL, NT>& c, __amdgpu_buffer_rsrc_t w, HierVec<RPL>& v)
+{
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+        const kd_uint4 t = __builtin_amdgcn_raw_buffer_load_b128(w, c.roff[k], 0, 0);
+        v.a[k] = __builtin_bit_cast(double, kd_uint2{ t.x, t.y });
+        v.b[k] = __builtin_bit_cast(double, kd_uint2{ t.z, t.w });
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        v.h[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(w, c.hoff + 8u * (unsigned)k, 0, 0));
+}
+template <int RPL, int NT>
+__device__ __forceinline__ void hstore(const HierLane<RPL, NT>& c, __amdgpu_buffer_rsrc_t w, const HierVec<RPL>& v)
+{
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+        const kd_uint2 a = __builtin_bit_cast(kd_uint2, v.a[k]), b = __builtin_bit_cast(kd_uint2, v.b[k]);
+        __builtin_amdgcn_raw_buffer_store_b128(kd_uint4{ a.x, a.y, b.x, b.y }, w, c.roff[k], 0, 0);
+    }
+    const unsigned ho = c.q == 0 ? c.hoff : KLARA_BUF_OOB;       // the hyper block is written once per chain
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, v.h[k]), w, ho + 8u * (unsigned)k, 0, 0);
+}
+
+// lt and/or gradient at th (oracle ko_hier_eval, operation for operation)
+template <int RPL, int NT, bool WANT_LT, bool WANT_GRAD>
+__device__ __forceinline__ double hier_eval(const HierLane<RPL, NT>& c, const HierVec<RPL>& th, HierVec<RPL>& g)
+{
+    const double ac = th.h[0], bc = th.h[1], sc = th.h[2], sa = th.h[3], sb = th.h[4];
+    // exp(-2 s_k): lane q of the chain evaluates k = q (q < 3), the other lanes idle along; three broadcasts
+    const int gb = c.lane - c.q;
+    const double w = kd_exp(-2.0 * (c.q == 0 ? sc : (c.q == 1 ? sa : sb)));
+    const double wc = lane_bcast(w, gb), wa = lane_bcast(w, gb + 1), wb = lane_bcast(w, gb + 2);
+    double red[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };        // A1, B1, A2, B2, C2 lane partials over this lane's units
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+        const double ai = th.a[k], bi = th.b[k];
+        const double da = ai - ac, db = bi - bc;
+        double S1 = 0.0, Sx = 0.0, S2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const double xj = c.xc[j];
+            const double r = (c.Y[k][j] - ai) - bi * xj;
+            S1 = S1 + r; Sx = Sx + r * xj; S2 = S2 + r * r;
+        }
+        // (a missing unit keeps zero gradient, hence zero momentum and value: it never enters a sum)
+        if (WANT_GRAD) { g.a[k] = c.rv[k] ? wc * S1 - wa * da : 0.0; g.b[k] = c.rv[k] ? wc * Sx - wb * db : 0.0; }
+        red[0] = red[0] + (c.rv[k] ? da : 0.0);       red[1] = red[1] + (c.rv[k] ? db : 0.0);
+        red[2] = red[2] + (c.rv[k] ? da * da : 0.0);  red[3] = red[3] + (c.rv[k] ? db * db : 0.0);
+        red[4] = red[4] + (c.rv[k] ? S2 : 0.0);
+    }
+    group_allreduce<5>(red, KLARA_HIERT_Q, c.lane);
+    const double A1 = red[0], B1 = red[1], A2 = red[2], B2 = red[3], C2 = red[4];
+    const double RT = (double)c.R * (double)NT, Rd = (double)c.R;
+    if (WANT_GRAD) {
+        g.h[0] = wa * A1 - c.p0 * ac;
+        g.h[1] = wb * B1 - c.p0 * bc;
+        g.h[2] = ((wc * C2 - RT) - 2.0 * c.a0) + (2.0 * c.b0) * wc;
+        g.h[3] = ((wa * A2 - Rd) - 2.0 * c.a0) + (2.0 * c.b0) * wa;
+        g.h[4] = ((wb * B2 - Rd) - 2.0 * c.a0) + (2.0 * c.b0) * wb;
+    }
+    double lt = 0.0;
+    if (WANT_LT) {
+        const double l_c = (-RT * sc - 0.5 * (wc * C2)) + (-2.0 * c.a0 * sc - c.b0 * wc);
+        const double l_a = (-Rd * sa - 0.5 * (wa * A2)) + (-2.0 * c.a0 * sa - c.b0 * wa);
+        const double l_b = (-Rd * sb - 0.5 * (wb * B2)) + (-2.0 * c.a0 * sb - c.b0 * wb);
+        lt = ((l_c + l_a) + l_b) - (0.5 * c.p0) * (ac * ac + bc * bc);
+    }
+    return lt;
+}
+
+// sum(p .* p) over the chain's D elements: lane partial over its units (a then b, ascending), lane 0 adds the five hyper
+// terms, butterfly over the 8 lanes
+template <int RPL, int NT>
+__device__ __forceinline__ double hier_sumsq(const HierLane<RPL, NT>& c, const HierVec<RPL>& m)
+{
+    double s[1] = { 0.0 };
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) { s[0] = s[0] + m.a[k] * m.a[k]; s[0] = s[0] + m.b[k] * m.b[k]; }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[0] = s[0] + (c.q == 0 ? m.h[k] * m.h[k] : 0.0);
+    group_allreduce<1>(s, KLARA_HIERT_Q, c.lane);
+    return s[0];
+}
+
+template <int RPL, int NT, bool MON, bool TUNE>
+__global__ __launch_bounds__(256, 2)
+void k_hiert_hmc(const KParams* __restrict__ pp, const KLaunch kl)
+{
+    constexpr int Q = KLARA_HIERT_Q, CPW = 64 / Q;
+    constexpr bool PLAIN = !TUNE;
+    const KParams& p = *pp;
+    kd_tables_to_lds();
+    const HierLane<RPL, NT> cx = make_hlane<RPL, NT>(p);
+    const int D = p.D, R = p.hR;
+    guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
+
+    const long long grp = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (grp * CPW >= p.nchains) return;
+    const long long first_chain = grp * CPW;
+    const long long left = p.nchains - first_chain;
+    const int here = left < CPW ? (int)left : CPW;
+    const bool chain_ok = cx.cw < here;
+    const long long chain = first_chain + cx.cw;
+    const unsigned long long gchain = (unsigned long long)(p.chain_offset + chain);
+    const __amdgpu_buffer_rsrc_t wx = group_window(p.X, first_chain, here, D);
+    const __amdgpu_buffer_rsrc_t wg = group_window(p.GR, first_chain, here, D);
+
+    HierVec<RPL> x, g;
+    hload<RPL, NT>(cx, wx, x);
+    hload<RPL, NT>(cx, wg, g);
+    const long long c0 = chain_ok ? chain : 0;
+    double lt = p.LT[c0];
+    unsigned long long nacc = 0;
+    const bool do_sum = MON && p.sum != nullptr;
+    HierVec<RPL> sm, sq;
+    if (do_sum) {
+        hload<RPL, NT>(cx, group_window(p.sum, first_chain, here, D), sm);
+        hload<RPL, NT>(cx, group_window(p.sumsq, first_chain, here, D), sq);
+    }
+    int sphase = kl.save_phase0;
+    long long scol = kl.save_col0;
+    const bool per_chain_tune = KCNT && !KPOOLED;
+    TuneRegs tn;
+    if (per_chain_tune) tn = { p.tune_step[c0], p.tune_accepted[c0], p.tune_proposed[c0], p.tune_totproposed[c0], 0, 0.0, 0.0 };
+    else if (KPOOLED) tn = { p.tune_step[0], p.tune_accepted[0], 0, 0, 0, 0.0, 0.0 };
+    else tn = { p.step0, 0, 0, 0, 0, 0.0, 0.0 };
+    const long long acc0 = tn.accepted;
+    tn.phase = per_chain_tune ? (int)(tn.proposed % p.period) : 0;
+
+    for (int s = 0; s < kl.nsteps; ++s) {
+        const unsigned long long t = kl.t0 + (unsigned long long)s;
+        if (KCNT) tune_count_proposal(p, tn);
+        // momentum ~ N(0, I) (iterate/HMC.jl:135): unit i = elements 2i, 2i+1 = one Philox block (slot i); the hyper block
+        // (elements 2R..2R+4) takes slots R, R+1, R+2; the accept uniform is slot ceil(D/2) = R + 3
+        HierVec<RPL> mom;
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            kd_normal_pair(kd_stream_block(p.seed, gchain, t, (uint32_t)(RPL * cx.q + k)), &mom.a[k], &mom.b[k]);
+            if (!cx.rv[k]) { mom.a[k] = 0.0; mom.b[k] = 0.0; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            double z0, z1;
+            kd_normal_pair(kd_stream_block(p.seed, gchain, t, (uint32_t)R), &mom.h[0], &mom.h[1]);
+            kd_normal_pair(kd_stream_block(p.seed, gchain, t, (uint32_t)(R + 1)), &mom.h[2], &mom.h[3]);
+            kd_normal_pair(kd_stream_block(p.seed, gchain, t, (uint32_t)(R + 2)), &z0, &z1);
+            mom.h[4] = z0;
+        }
+        const double H0 = lt - 0.5 * hier_sumsq<RPL, NT>(cx, mom);                     // :137
+        HierVec<RPL> xp = x, gp = g;                                                  // :139-140
+        const double eps = tn.step, halfe = 0.5 * eps;
+        for (int l = 0; l < p.nleaps; ++l) {                                          // :146-155, samplers.jl:122-134
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) {
+                mom.a[k] = mom.a[k] + halfe * gp.a[k]; mom.b[k] = mom.b[k] + halfe * gp.b[k];
+                xp.a[k] = xp.a[k] + eps * mom.a[k];    xp.b[k] = xp.b[k] + eps * mom.b[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { mom.h[k] = mom.h[k] + halfe * gp.h[k]; xp.h[k] = xp.h[k] + eps * mom.h[k]; }
+            (void)hier_eval<RPL, NT, false, true>(cx, xp, gp);
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) { mom.a[k] = mom.a[k] + halfe * gp.a[k]; mom.b[k] = mom.b[k] + halfe * gp.b[k]; }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) mom.h[k] = mom.h[k] + halfe * gp.h[k];
+        }
+        HierVec<RPL> gdummy;
+        const double ltp = hier_eval<RPL, NT, true, false>(cx, xp, gdummy);           // :157
+        const double H1 = ltp - 0.5 * hier_sumsq<RPL, NT>(cx, mom);                   // :159
+        const double ratio = H1 - H0;                                                 // :161
+        const double ex = kd_exp(ratio);
+        const double a = 1.0 < ex ? 1.0 : ex;                                         // :163
+        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((D + 1) >> 1)));
+        const bool acc = u < a;                                                       // :165
+        if (acc) { x = xp; g = gp; lt = ltp; }                                        // :166-176
+        nacc += acc ? 1ull : 0ull;
+        if (accept_out != nullptr && chain_ok && cx.q == 0) accept_out[(long long)s * p.nchains + chain] = acc ? 1 : 0;
+        if (KCNT && acc) tn.accepted += 1;
+        if (per_chain_tune) tuning_block(p, tn);                                      // iterate/HMC.jl:203-224
+        // save rule: BasicMCJob.jl:226-231 with postrange = (burnin+1):thinning:nsteps (BasicMCRange.jl:36)
+        const long long i1 = (long long)t + 1;
+        if (MON && i1 > p.burnin && i1 <= p.nsteps_total) {
+            if (sphase == 0) {
+                if (do_sum) {
+#pragma unroll
+                    for (int k = 0; k < RPL; ++k) {
+                        sm.a[k] = sm.a[k] + x.a[k]; sq.a[k] = sq.a[k] + x.a[k] * x.a[k];
+                        sm.b[k] = sm.b[k] + x.b[k]; sq.b[k] = sq.b[k] + x.b[k] * x.b[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) { sm.h[k] = sm.h[k] + x.h[k]; sq.h[k] = sq.h[k] + x.h[k] * x.h[k]; }
+                }
+                if (scol < p.hist_cols) {
+                    const long long col0 = scol * p.nchains + first_chain;
+                    if (p.hist != nullptr) hstore<RPL, NT>(cx, group_window(p.hist, col0, here, D), x);
+                    if (p.hist_g != nullptr) hstore<RPL, NT>(cx, group_window(p.hist_g, col0, here, D), g);
+                    if (p.hist_lt != nullptr && chain_ok && cx.q == 0) p.hist_lt[scol * p.nchains + chain] = lt;
+                }
+                ++scol;
+            }
+            sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
+        }
+    }
+    if (do_sum) {
+        hstore<RPL, NT>(cx, group_window(p.sum, first_chain, here, D), sm);
+        hstore<RPL, NT>(cx, group_window(p.sumsq, first_chain, here, D), sq);
+    }
+    if (nacc != 0) {
+        hstore<RPL, NT>(cx, wx, x);
+        hstore<RPL, NT>(cx, wg, g);
+        if (chain_ok && cx.q == 0) { p.LT[chain] = lt; p.naccept[chain] += nacc; }
+    }
+    if (TUNE && chain_ok && cx.q == 0) {
+        if (per_chain_tune) {
+            p.tune_step[chain] = tn.step; p.tune_accepted[chain] = tn.accepted;
+            p.tune_proposed[chain] = tn.proposed; p.tune_totproposed[chain] = tn.totproposed;
+        } else if (KPOOLED && KCNT) {
+            atomicAdd((unsigned long long*)p.pooled_accepted, (unsigned long long)(tn.accepted - acc0));
+        }
+    }
+}
+
+// initialize!(pstate, parameter, sampler) for layout kind 4: lt and gradient at X, finiteness check (HMC.jl:106-120)
+template <int RPL, int NT>
+__global__ __launch_bounds__(256) void k_hiert_init(const KParams p, int needgrad)
+{
+    constexpr int CPW = 64 / KLARA_HIERT_Q;
+    kd_tables_to_lds();
+    const HierLane<RPL, NT> cx = make_hlane<RPL, NT>(p);
+    const long long grp = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long first_chain = grp * CPW;
+    const long long left = p.nchains - first_chain;
+    const int here = left < CPW ? (left > 0 ? (int)left : 0) : CPW;
+    const bool chain_ok = cx.cw < here;
+    const long long chain = first_chain + cx.cw;
+    HierVec<RPL> x, g;
+    hload<RPL, NT>(cx, group_window(p.X, first_chain, here, p.D), x);
+    const double lt = hier_eval<RPL, NT, true, true>(cx, x, g);
+    bool bad = !kfinite(lt);
+    if (needgrad) {
+        hstore<RPL, NT>(cx, group_window(p.GR, first_chain, here, p.D), g);
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) bad = bad || (cx.rv[k] && (!kfinite(g.a[k]) || !kfinite(g.b[k])));
+#pragma unroll
+        for (int k = 0; k < 5; ++k) bad = bad || !kfinite(g.h[k]);
+    }
+    if (chain_ok && cx.q == 0) p.LT[chain] = lt;
+    if (chain_ok && bad) atomicMax((int*)p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
+}

@@ -46,7 +46,9 @@ typedef struct ko_layout {
                      2: logistic row split: every lane holds all elements (sums over elements are sequential),
                         the data rows are dealt round-robin to G lanes and combined by the xor tree
                      3: pair-transposed (klara_diagt.h): element pair i/2 on lane (i/2) % G, lane partials in
-                        ascending element order, xor tree over the G lanes                                 */
+                        ascending element order, xor tree over the G lanes
+                     4: hierarchical target, few lanes per chain (klara_hiert.h): unit r on lane r / (E/2), the
+                        hyper block on lane 0 (after its units); per-unit sums skip the other parameter's slot   */
     int32_t G;
     int32_t E;
 } ko_layout;
@@ -58,7 +60,9 @@ static double ko_reduce(const ko_layout* L, const double* terms, int D)
     for (int l = 0; l < G; ++l) part[l] = 0.0;
     for (int i = 0; i < D; ++i) {
         /* kind 3 (pair-transposed, klara_diagt.h): element pair P = i>>1 belongs to lane P % G */
-        const int lane = (L->kind == 1) ? (i & 3) : (L->kind == 2 ? 0 : (L->kind == 3 ? ((i >> 1) % L->G) : i / L->E));
+        /* kind 4 (klara_hiert.h, D = 2R + 5): unit i/2 on lane (i/2) / (E/2); the five hyper elements on lane 0 */
+        const int lane = (L->kind == 1) ? (i & 3) : (L->kind == 2 ? 0 : (L->kind == 3 ? ((i >> 1) % L->G) :
+                         (L->kind == 4 ? (i < D - 5 ? (i >> 1) / (L->E / 2) : 0) : i / L->E)));
         part[lane] = part[lane] + terms[i];
     }
     for (int m = 1; m < G; m <<= 1) {
@@ -213,8 +217,18 @@ static double ko_hier_eval(const ko_target_ctx* c, const double* th, double* g, 
         tA1[2 * i] = da; tA2[2 * i] = da * da; tC2[2 * i] = S2;
         tB1[2 * i + 1] = db; tB2[2 * i + 1] = db * db;
     }
-    const double A1 = ko_reduce(c->L, tA1, D), B1 = ko_reduce(c->L, tB1, D);
-    const double A2 = ko_reduce(c->L, tA2, D), B2 = ko_reduce(c->L, tB2, D), C2 = ko_reduce(c->L, tC2, D);
+    double A1, B1, A2, B2, C2;
+    if (c->L->kind == 4) {
+        /* lane partial over the lane's units, ascending, one term per unit (no zero slots), then the xor tree */
+        double uA1[KO_MAXD], uB1[KO_MAXD], uA2[KO_MAXD], uB2[KO_MAXD], uC2[KO_MAXD];
+        for (int i = 0; i < R; ++i) { uA1[i] = tA1[2 * i]; uA2[i] = tA2[2 * i]; uC2[i] = tC2[2 * i]; uB1[i] = tB1[2 * i + 1]; uB2[i] = tB2[2 * i + 1]; }
+        const ko_layout U = { 0, c->L->G, c->L->E / 2 };      /* unit r on lane r / (E/2): the contiguous rule */
+        A1 = ko_reduce(&U, uA1, R); B1 = ko_reduce(&U, uB1, R);
+        A2 = ko_reduce(&U, uA2, R); B2 = ko_reduce(&U, uB2, R); C2 = ko_reduce(&U, uC2, R);
+    } else {
+        A1 = ko_reduce(c->L, tA1, D); B1 = ko_reduce(c->L, tB1, D);
+        A2 = ko_reduce(c->L, tA2, D); B2 = ko_reduce(c->L, tB2, D); C2 = ko_reduce(c->L, tC2, D);
+    }
     const double RT = (double)R * (double)T, Rd = (double)R;
     if (g) {
         g[2 * R] = wa * A1 - p0 * ac;

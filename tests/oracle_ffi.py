@@ -66,7 +66,8 @@ DIAGT_NP_MENU = (1, 2, 4, 6, 7, 8)      # klara_launch.h KLARA_DIAGT_NP_MENU_DO
 DIAGT_Q = 8
 
 
-def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, tuner=0, tuner_mode=0, verbose=False):
+def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, tuner=0, tuner_mode=0, verbose=False,
+                   hier_nunits: int = 0, hier_ntimes: int = 0):
     """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box).  `sampler`, `tuner`,
     `tuner_mode` and `verbose` are only needed to recognise the pair-transposed layout (kind 3): diagonal Gaussian,
     MH / MALA / HMC, even D <= 128, Vanilla or AcceptanceRate tuner (klara_api.hip diagt_eligible)."""
@@ -76,6 +77,9 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
             and d % 2 == 0 and d <= 2 * DIAGT_Q * DIAGT_NP_MENU[-1] and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0"):
         np_ = next(v for v in DIAGT_NP_MENU if v >= (d + 2 * DIAGT_Q - 1) // (2 * DIAGT_Q))
         return (3, DIAGT_Q, 2 * np_)
+    if (target_kind == L.TARGET_HIER_NORMAL and sampler == L.SAMPLER_HMC and tuner != L.TUNER_DUAL_AVERAGING
+            and 9 <= hier_nunits <= 32 and hier_ntimes == 5 and os.environ.get("KLARA_LAYOUT_KIND", "4") != "0"):
+        return (4, 8, 8)              # klara_hiert.h: 8 lanes per chain, 4 units per lane
     if target_kind == L.TARGET_GAUSS_DENSE:
         ne = 8 if d <= 32 else 16 if d <= 64 else 25 if d <= 100 else 32
         return (1, 4, ne)
@@ -143,7 +147,8 @@ class OracleJob:
         d.seed = int(seed)
         self.desc = d
         k, g, e = layout if layout is not None else default_layout(int(target_kind), self.D, int(d.logit_ndata), sampler=int(sampler),
-                                                                   tuner=int(tuner), tuner_mode=int(tuner_mode), verbose=bool(verbose))
+                                                                   tuner=int(tuner), tuner_mode=int(tuner_mode), verbose=bool(verbose),
+                                                                   hier_nunits=int(d.hier_nunits), hier_ntimes=int(d.hier_ntimes))
         self.layout = KoLayout(k, g, e)
         nt = 1 if tuner_mode == L.TUNE_POOLED else self.N
         self.X = np.zeros((self.N, self.D)); self.G = np.zeros((self.N, self.D)); self.LT = np.zeros(self.N)
