@@ -23,6 +23,9 @@
 #ifndef KLARA_E4_WAVES
 #define KLARA_E4_WAVES 2   // min waves per SIMD requested for the E=4 kernels (register budget 256)
 #endif
+#ifndef KLARA_LOGIT_UNROLL
+#define KLARA_LOGIT_UNROLL 4
+#endif
 #ifndef KLARA_E4_WAVES_PLAIN
 #define KLARA_E4_WAVES_PLAIN 3   // the specialised (no tuner, no monitor) E=4 kernels fit 168 VGPRs
 #endif
@@ -360,6 +363,9 @@ struct LogisticTarget {
         double dotxy = 0.0, slog = 0.0, gacc[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) gacc[e] = 0.0;
+        // rows are independent until the accumulations: unrolling lets two rows' exp/log chains interleave (the kernel runs
+        // at 2 wavefronts per SIMD for cfg 4's per-GPU share, so dependent-issue latency is otherwise exposed)
+#pragma unroll KLARA_LOGIT_UNROLL
         for (int r = cx.rq; r < ndata; r += cx.RS) {
             const double* row = sX + r * D;
             double xp = 0.0;
