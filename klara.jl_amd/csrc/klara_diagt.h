@@ -11,7 +11,7 @@
 // reduction tree is 3 DPP steps instead of 5, and 89% instead of 78% of the lane slots hold real elements.
 //
 // Scope: VanillaMCTuner (the jobs the throughput figures are quoted on) or AcceptanceRateMCTuner, per chain or pooled; any monitor
-// (accept mask, running sums, value / logtarget / gradlogtarget history); D even, D <= 16*NP.  Everything else runs on
+// (accept mask, running sums, value / logtarget / gradlogtarget history); D even, 18 <= D <= 16*NP.  Everything else runs on
 // the group layout (klara_kernels.h).
 // Sums are taken per lane in ascending element order and then over the Q lanes by an xor butterfly — the oracle mirrors
 // this order for layout kind 3 (oracle/klara_oracle.c ko_reduce).

@@ -31,7 +31,7 @@ hipError_t klara_launch_diagt_init(const KParams& p, int NP, int needgrad, dim3 
 #define KLARA_DIAGT_NP_MENU_DO(X) X(2) X(4) X(8) X(13) X(16)
 #define KLARA_DIAGT_NP_MAX 16
 #else
-#define KLARA_DIAGT_NP_MENU_DO(X) X(1) X(2) X(4) X(6) X(7) X(8)
+#define KLARA_DIAGT_NP_MENU_DO(X) X(2) X(4) X(6) X(7) X(8)
 #define KLARA_DIAGT_NP_MAX 8
 #endif
 

@@ -161,15 +161,15 @@ def make_case(name):
     elif name == "dt_mala_mvnormal_d30":
         mu = np.linspace(-1, 2, 30); sg = np.linspace(0.6, 1.7, 30)
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.mvnormal(mu, sg), nchains=45, nsteps=50, burnin=0, driftstep=0.3)
-    elif name == "dt_mala_d2":
-        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(2), nchains=100, nsteps=60, burnin=0, driftstep=0.8)
+    elif name == "dt_mala_d18":        # smallest dimension on this layout (below it the group layout packs 16..64 chains per wavefront)
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(18), nchains=100, nsteps=60, burnin=0, driftstep=0.5)
     elif name == "dt_mh_d100":
         c = dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(100), nchains=70, nsteps=60, burnin=0,
                  mh_sigma=np.full(100, 0.1))
-    elif name == "dt_mh_mvnormal_d8":
-        mu = np.linspace(-2, 3, 8); sg = np.linspace(0.5, 2.0, 8)
+    elif name == "dt_mh_mvnormal_d20":
+        mu = np.linspace(-2, 3, 20); sg = np.linspace(0.5, 2.0, 20)
         c = dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.mvnormal(mu, sg), nchains=33, nsteps=80, burnin=0,
-                 mh_sigma=sg * 0.8)
+                 mh_sigma=sg * 0.4)
     elif name == "dt_hmc_d100":
         c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.negdot(100), nchains=70, nsteps=20, burnin=0,
                  leapstep=0.1, nleaps=10)
@@ -188,8 +188,8 @@ def make_case(name):
     return c
 
 
-DIAGT_CASES = ["dt_mala_d100", "dt_mala_d100_small_step", "dt_mala_d112_full", "dt_mala_mvnormal_d30", "dt_mala_d2",
-               "dt_mh_d100", "dt_mh_mvnormal_d8", "dt_hmc_d100", "dt_hmc_d128_full", "dt_hmc_mvnormal_d96"]
+DIAGT_CASES = ["dt_mala_d100", "dt_mala_d100_small_step", "dt_mala_d112_full", "dt_mala_mvnormal_d30", "dt_mala_d18",
+               "dt_mh_d100", "dt_mh_mvnormal_d20", "dt_hmc_d100", "dt_hmc_d128_full", "dt_hmc_mvnormal_d96"]
 
 ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_small_step", "mala_d3_tuned",
              "mala_d300", "hmc_d100", "hmc_d10_tuned_pooled", "hmc_dense_d100", "hmc_dense_d37", "mala_dense_d100",
@@ -200,7 +200,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",
-                "dt_mala_d100_small_step", "dt_hmc_d100", "dt_mh_mvnormal_d8"]
+                "dt_mala_d100_small_step", "dt_hmc_d100", "dt_mh_mvnormal_d20"]
 
 
 def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):

@@ -194,10 +194,10 @@ def test_parity_pair_transposed_layout(name, mode):
 
 @pytest.mark.parametrize("nchains", [1, 3, 9])
 @pytest.mark.parametrize("sampler,kw", [(L.SAMPLER_MALA, dict(driftstep=0.3)), (L.SAMPLER_HMC, dict(leapstep=0.2, nleaps=4)),
-                                        (L.SAMPLER_MH, dict(mh_sigma=np.full(10, 0.4)))])
+                                        (L.SAMPLER_MH, dict(mh_sigma=np.full(22, 0.3)))])
 def test_pair_transposed_tiny_jobs(nchains, sampler, kw):
-    """Fewer chains than one wavefront group carries (8), D = 10 (one pair per lane, three padding lanes per chain)."""
-    case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, 10), np.linspace(0.5, 2, 10)), nchains=nchains,
+    """Fewer chains than one wavefront group carries (8), D = 22 (two pairs per lane, the last five of them padding)."""
+    case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, 22), np.linspace(0.5, 2, 22)), nchains=nchains,
                 nsteps=25, burnin=5, thinning=2, x0=None, seed=7, name="tiny", **kw)
     eng, job = _run_pair(case, splits=[1, 9, 15], spl=4)
     assert eng.layout()[0] == 3
@@ -241,8 +241,8 @@ def test_pair_transposed_layout_is_optional():
 # Vanilla / AcceptanceRate jobs on even-D diagonal Gaussians run on the pair-transposed layout by default (HMC on the
 # hierarchical target: layout kind 4); the same cases forced
 # onto the group layout keep that path covered (both compared with the oracle told the respective summation order)
-GROUP_FORCED = [n for n in cases.ALL_CASES if n in ("mh_readme", "mh_d100", "mala_d100", "mala_d100_small_step", "hmc_d100", "hmc_d128_full",
-                                                   "hmc_d10_tuned_pooled", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose",
+GROUP_FORCED = [n for n in cases.ALL_CASES if n in ("mh_d100", "mala_d100", "mala_d100_small_step", "hmc_d100", "hmc_d128_full",
+                                                   "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose",
                                                    "hmc_rats", "hmc_rats_pooled")]
 
 
