@@ -217,6 +217,36 @@ def extra_measurements(K, L, n, stream):
             ex["hmc_dense_fp64_tflops"] = flops / (ms * 1e-3) / 1e12
             ex["hmc_dense_frac_of_fp64_mfma_peak"] = ex["hmc_dense_fp64_tflops"] / FP64_MFMA_PEAK_TF
         e.close()
+    # the two data-model configurations of BASELINE.json at their per-GPU share (cfg 4: 262,144 / 8 chains of the swiss
+    # logistic regression, MALA h = 0.1; cfg 5: 1,048,576 / 8 chains of the rats hierarchical model, HMC L = 32 with the
+    # per-GPU pooled AcceptanceRate tuner).  Data: the reference's own files as committed fixtures (tests/golden/*.npz).
+    try:
+        gold = ROOT / "tests" / "golden"
+        sw = np.load(gold / "swiss.npz")
+        X = sw["measurements"]; X = np.ascontiguousarray((X - X.mean(axis=0)) / X.std(axis=0, ddof=1))
+        y = np.ascontiguousarray(sw["status"].astype(np.float64))
+        nc = 32768
+        x0 = np.array([5.1, -0.9, 8.2, -4.5])[None, :] + 0.1 * np.random.default_rng(0).standard_normal((nc, 4))
+        e = K.Engine(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, 100.0), nchains=nc, nsteps=10 ** 6, driftstep=0.1,
+                     steps_per_launch=50, monitor=0, stream=stream)
+        e.set_state(x0); e.run(100)
+        t0 = time.perf_counter(); e.run(500); dt = time.perf_counter() - t0
+        ex["cfg4_swiss_logistic_mala_transitions_per_s_per_gpu"] = nc * 500 / dt
+        e.close()
+        rats = np.load(gold / "rats.npz")
+        t = K.HierNormalTarget(rats["weight"], rats["age"] - 22.0)
+        nc = 131072
+        x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(1).standard_normal((nc, t.ndims))
+        e = K.Engine(sampler=L.SAMPLER_HMC, target=t, nchains=nc, nsteps=2000, burnin=1000, leapstep=0.02, nleaps=32,
+                     tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.65, period=100, steps_per_launch=10,
+                     monitor=L.MON_SUMMARIES, stream=stream)
+        e.set_state(x0); e.run(100)
+        t0 = time.perf_counter(); e.run(200); dt = time.perf_counter() - t0
+        ex["cfg5_rats_hmc_L32_leapfrog_chain_per_s_per_gpu"] = nc * 200 * 32 / dt
+        ex["cfg5_rats_hmc_L32_transitions_per_s_per_gpu"] = nc * 200 / dt
+        e.close()
+    except Exception as exc:      # the fixtures are part of the repository; a failure here must not lose the headline line
+        ex["model_configs_error"] = repr(exc)
     return ex
 
 
