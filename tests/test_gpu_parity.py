@@ -205,6 +205,36 @@ def test_pair_transposed_tiny_jobs(nchains, sampler, kw):
     eng.close()
 
 
+@pytest.mark.parametrize("R,nchains,tuner_kw", [(9, 11, {}), (13, 5, dict(tuner=L.TUNER_ACCEPT_RATE, targetrate=0.7, period=8)),
+                                                (30, 64, dict(tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.65, period=10)),
+                                                (32, 19, {})])
+def test_hier_few_lanes_layout_other_unit_counts(R, nchains, tuner_kw):
+    """Layout kind 4 (klara_hiert.h) on synthetic growth-curve data: unit counts with a partly filled last lane (9, 13, 30)
+    and a full one (32), ragged chain counts, the per-chain and the pooled AcceptanceRate tuner, history of every field."""
+    rng = np.random.default_rng(R)
+    xc = np.array([-14.0, -7.0, 0.0, 7.0, 14.0])
+    a = 240.0 + 15.0 * rng.standard_normal(R); b = 6.0 + 0.5 * rng.standard_normal(R)
+    Y = a[:, None] + b[:, None] * xc[None, :] + 6.0 * rng.standard_normal((R, 5))
+    t = K.HierNormalTarget(Y, xc)
+    x0 = t.least_squares_start()[None, :] + 0.05 * rng.standard_normal((nchains, t.ndims))
+    case = dict(sampler=L.SAMPLER_HMC, target=t, nchains=nchains, nsteps=24, burnin=16, thinning=2, leapstep=0.01, nleaps=6, x0=x0,
+                seed=99, name=f"hier_R{R}", **tuner_kw)
+    eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT | L.MON_HIST_GRAD,
+                                         steps_per_launch=5))
+    assert tuple(eng.layout()) == (4, 8, 8)
+    job = O.OracleJob(**cases.oracle_kwargs(case, layout=eng.layout()), want_hist=True)
+    eng.set_state(x0); assert job.set_state(x0) == 0
+    assert np.array_equal(eng.state()[1], job.LT) and np.array_equal(eng.state()[2], job.G)
+    for k in (1, 14, 9):
+        eng.run(k); assert job.run(k) == 0
+    _assert_same(eng, job, case)
+    c = nchains // 2
+    ltc, gc = eng.chain_fields(c, logtarget=True, gradlogtarget=True)
+    assert np.array_equal(eng.chain(c), job.hist[:, c, :].T)
+    assert np.array_equal(ltc, job.hist_lt[:, c]) and np.array_equal(gc, job.hist_g[:, c, :].T)
+    eng.close()
+
+
 def test_layout_choice_matches_its_mirror():
     """tests/oracle_ffi.default_layout (what the CPU-side golden generator assumes) is the product's choice for every
     dimension and tuner it can meet."""
