@@ -100,19 +100,20 @@ __device__ __forceinline__ double hier_eval(const HierLane<RPL, NT>& c, const Hi
 #pragma unroll
     for (int k = 0; k < RPL; ++k) {
         const double ai = th.a[k], bi = th.b[k];
-        const double da = ai - ac, db = bi - bc;
+        // a missing unit (the last lane of a chain when R % 4 != 0) is masked once, at its five per-unit quantities: its
+        // sums and its gradient are then exactly 0, so its momentum and value stay 0 and it never enters a sum
+        const double da = c.rv[k] ? ai - ac : 0.0, db = c.rv[k] ? bi - bc : 0.0;
         double S1 = 0.0, Sx = 0.0, S2 = 0.0;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const double xj = c.xc[j];
-            const double r = (c.Y[k][j] - ai) - bi * xj;
+            const double r = (c.Y[k][j] - ai) - bi * xj;       // (missing unit: Y = a = b = 0, so r = S1 = Sx = S2 = 0)
             S1 = S1 + r; Sx = Sx + r * xj; S2 = S2 + r * r;
         }
-        // (a missing unit keeps zero gradient, hence zero momentum and value: it never enters a sum)
-        if (WANT_GRAD) { g.a[k] = c.rv[k] ? wc * S1 - wa * da : 0.0; g.b[k] = c.rv[k] ? wc * Sx - wb * db : 0.0; }
-        red[0] = red[0] + (c.rv[k] ? da : 0.0);       red[1] = red[1] + (c.rv[k] ? db : 0.0);
-        red[2] = red[2] + (c.rv[k] ? da * da : 0.0);  red[3] = red[3] + (c.rv[k] ? db * db : 0.0);
-        red[4] = red[4] + (c.rv[k] ? S2 : 0.0);
+        if (WANT_GRAD) { g.a[k] = wc * S1 - wa * da; g.b[k] = wc * Sx - wb * db; }
+        red[0] = red[0] + da;       red[1] = red[1] + db;
+        red[2] = red[2] + da * da;  red[3] = red[3] + db * db;
+        red[4] = red[4] + S2;
     }
     group_allreduce<5>(red, KLARA_HIERT_Q, c.lane);
     const double A1 = red[0], B1 = red[1], A2 = red[2], B2 = red[3], C2 = red[4];
