@@ -14,7 +14,7 @@
 // elements ascending, lane 0 then adds the five hyper terms), then the xor butterfly over the 8 lanes — oracle
 // ko_reduce kind 4.
 //
-// Scope: HMC with the Vanilla or AcceptanceRate tuner (per chain or pooled per GPU), any monitor; 9 <= R <= 32 units,
+// Scope: HMC with the Vanilla, AcceptanceRate (per chain or pooled per GPU) or DualAveraging tuner, any monitor; 9 <= R <= 32 units,
 // T = 5 observations per unit.  Everything else stays on the group layout.
 #pragma once
 #include "klara_kernels.h"
@@ -149,11 +149,14 @@ __device__ __forceinline__ double hier_sumsq(const HierLane<RPL, NT>& c, const H
     return s[0];
 }
 
-template <int RPL, int NT, bool MON, bool TUNE>
+// DA: DualAveragingMCTuner (iterate/HMC.jl:142-144, 225-249): per-chain step and per-chain trajectory length; the wavefront
+// runs to the longest trajectory among its 8 chains and a finished chain's lanes keep their state (selects).
+template <int RPL, int NT, bool MON, bool TUNE, bool DA = false>
 __global__ __launch_bounds__(256, 2)
 void k_hiert_hmc(const KParams* __restrict__ pp, const KLaunch kl)
 {
     constexpr int Q = KLARA_HIERT_Q, CPW = 64 / Q;
+    static_assert(!DA || TUNE, "dual averaging is a tuned instantiation");
     constexpr bool PLAIN = !TUNE;
     const KParams& p = *pp;
     kd_tables_to_lds();
@@ -190,7 +193,8 @@ void k_hiert_hmc(const KParams* __restrict__ pp, const KLaunch kl)
     TuneRegs tn;
     if (per_chain_tune) tn = { p.tune_step[c0], p.tune_accepted[c0], p.tune_proposed[c0], p.tune_totproposed[c0], 0, 0.0, 0.0 };
     else if (KPOOLED) tn = { p.tune_step[0], p.tune_accepted[0], 0, 0, 0, 0.0, 0.0 };
-    else tn = { p.step0, 0, 0, 0, 0, 0.0, 0.0 };
+    else tn = { DA ? p.tune_step[c0] : p.step0, 0, 0, 0, 0, 0.0, 0.0 };
+    if (DA) { tn.epsbar = p.da_epsbar[c0]; tn.hbar = p.da_hbar[c0]; }
     const long long acc0 = tn.accepted;
     tn.phase = per_chain_tune ? (int)(tn.proposed % p.period) : 0;
 
@@ -216,19 +220,37 @@ void k_hiert_hmc(const KParams* __restrict__ pp, const KLaunch kl)
         const double H0 = lt - 0.5 * hier_sumsq<RPL, NT>(cx, mom);                     // :137
         HierVec<RPL> xp = x, gp = g;                                                  // :139-140
         const double eps = tn.step, halfe = 0.5 * eps;
-        for (int l = 0; l < p.nleaps; ++l) {                                          // :146-155, samplers.jl:122-134
+        const int nl = DA ? da_nleaps(p, eps) : p.nleaps;                             // iterate/HMC.jl:142-144
+        for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {                         // :146-155, samplers.jl:122-134
+            const bool go = !DA || l < nl;                                            // (a finished chain keeps its state)
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
-                mom.a[k] = mom.a[k] + halfe * gp.a[k]; mom.b[k] = mom.b[k] + halfe * gp.b[k];
-                xp.a[k] = xp.a[k] + eps * mom.a[k];    xp.b[k] = xp.b[k] + eps * mom.b[k];
+                const double ma = mom.a[k] + halfe * gp.a[k], mb = mom.b[k] + halfe * gp.b[k];
+                mom.a[k] = go ? ma : mom.a[k]; mom.b[k] = go ? mb : mom.b[k];
+                const double xa = xp.a[k] + eps * mom.a[k], xb = xp.b[k] + eps * mom.b[k];
+                xp.a[k] = go ? xa : xp.a[k]; xp.b[k] = go ? xb : xp.b[k];
             }
 #pragma unroll
-            for (int k = 0; k < 5; ++k) { mom.h[k] = mom.h[k] + halfe * gp.h[k]; xp.h[k] = xp.h[k] + eps * mom.h[k]; }
-            (void)hier_eval<RPL, NT, false, true>(cx, xp, gp);
+            for (int k = 0; k < 5; ++k) {
+                const double mh = mom.h[k] + halfe * gp.h[k];
+                mom.h[k] = go ? mh : mom.h[k];
+                const double xh = xp.h[k] + eps * mom.h[k];
+                xp.h[k] = go ? xh : xp.h[k];
+            }
+            HierVec<RPL> gn;
+            (void)hier_eval<RPL, NT, false, true>(cx, xp, gn);
 #pragma unroll
-            for (int k = 0; k < RPL; ++k) { mom.a[k] = mom.a[k] + halfe * gp.a[k]; mom.b[k] = mom.b[k] + halfe * gp.b[k]; }
+            for (int k = 0; k < RPL; ++k) {
+                gp.a[k] = go ? gn.a[k] : gp.a[k]; gp.b[k] = go ? gn.b[k] : gp.b[k];
+                const double ma = mom.a[k] + halfe * gp.a[k], mb = mom.b[k] + halfe * gp.b[k];
+                mom.a[k] = go ? ma : mom.a[k]; mom.b[k] = go ? mb : mom.b[k];
+            }
 #pragma unroll
-            for (int k = 0; k < 5; ++k) mom.h[k] = mom.h[k] + halfe * gp.h[k];
+            for (int k = 0; k < 5; ++k) {
+                gp.h[k] = go ? gn.h[k] : gp.h[k];
+                const double mh = mom.h[k] + halfe * gp.h[k];
+                mom.h[k] = go ? mh : mom.h[k];
+            }
         }
         HierVec<RPL> gdummy;
         const double ltp = hier_eval<RPL, NT, true, false>(cx, xp, gdummy);           // :157
@@ -242,7 +264,11 @@ void k_hiert_hmc(const KParams* __restrict__ pp, const KLaunch kl)
         nacc += acc ? 1ull : 0ull;
         if (accept_out != nullptr && chain_ok && cx.q == 0) accept_out[(long long)s * p.nchains + chain] = acc ? 1 : 0;
         if (KCNT && acc) tn.accepted += 1;
-        if (per_chain_tune) tuning_block(p, tn);                                      // iterate/HMC.jl:203-224
+        if (DA) da_update(p, tn, (long long)t + 1, a);                                // iterate/HMC.jl:225-249
+        if (per_chain_tune && !DA) tuning_block(p, tn);                               // iterate/HMC.jl:203-224
+        else if (DA && per_chain_tune && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {   // verbose report block, :229-243
+            tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
+        }
         // save rule: BasicMCJob.jl:226-231 with postrange = (burnin+1):thinning:nsteps (BasicMCRange.jl:36)
         const long long i1 = (long long)t + 1;
         if (MON && i1 > p.burnin && i1 <= p.nsteps_total) {
@@ -277,6 +303,7 @@ void k_hiert_hmc(const KParams* __restrict__ pp, const KLaunch kl)
         if (chain_ok && cx.q == 0) { p.LT[chain] = lt; p.naccept[chain] += nacc; }
     }
     if (TUNE && chain_ok && cx.q == 0) {
+        if (DA) { p.tune_step[chain] = tn.step; p.da_epsbar[chain] = tn.epsbar; p.da_hbar[chain] = tn.hbar; }
         if (per_chain_tune) {
             p.tune_step[chain] = tn.step; p.tune_accepted[chain] = tn.accepted;
             p.tune_proposed[chain] = tn.proposed; p.tune_totproposed[chain] = tn.totproposed;

@@ -273,7 +273,7 @@ def test_pair_transposed_layout_is_optional():
 # onto the group layout keep that path covered (both compared with the oracle told the respective summation order)
 GROUP_FORCED = [n for n in cases.ALL_CASES if n in ("mh_d100", "mala_d100", "mala_d100_small_step", "hmc_d100", "hmc_d128_full",
                                                    "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose",
-                                                   "hmc_rats", "hmc_rats_pooled")]
+                                                   "hmc_rats", "hmc_rats_pooled", "hmc_rats_dualavg")]
 
 
 @pytest.mark.parametrize("name", GROUP_FORCED)
