@@ -61,13 +61,12 @@ static int cnt_predicate(const klara_desc& d)
 static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // layout kind 3 serves the jobs whose transition is pure elementwise work plus three sums (see klara_diagt.h):
-// diagonal Gaussian, MH / MALA / HMC, Vanilla or AcceptanceRate tuner (per chain or pooled), any monitor
+// diagonal Gaussian, MH / MALA / HMC, every tuner, any monitor
 static bool diagt_eligible(const klara_desc& d)
 {
     if (d.target != KLARA_TARGET_GAUSS_DIAG || d.sampler == KLARA_SAMPLER_SLICE) return false;
     // (D <= 16: the group layout already puts a chain on <= 4 lanes, 16..64 chains per wavefront)
     if ((d.ndims & 1) || d.ndims < 18 || d.ndims > 2 * KLARA_DIAGT_Q * KLARA_DIAGT_NP_MAX) return false;
-    if (d.tuner == KLARA_TUNER_DUAL_AVERAGING) return false;              // per-chain trajectory lengths: group layout
     if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
     if (getenv("KLARA_LAYOUT_E")) return false;
     return true;
@@ -102,9 +101,9 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     // diagonal Gaussian and nothing tunes: the pair-transposed layout
     // (klara_diagt.h), Q = 8 lanes per chain, NP element pairs per lane
     if (diagt_eligible(d)) {
-        const int need = (D + 2 * KLARA_DIAGT_Q - 1) / (2 * KLARA_DIAGT_Q);
+        const int need = (D + 2 * KLARA_DIAGT_Q - 1) / (2 * KLARA_DIAGT_Q);      // NP = ceil(D/2 / Q) exactly (see klara_diagt.h)
         int np = 0;
-#define X(NP_) if (np == 0 && NP_ >= need) np = NP_;
+#define X(NP_) if (NP_ == need) np = NP_;
         KLARA_DIAGT_NP_MENU_DO(X)
 #undef X
         if (np != 0) { *kind = 3; *G = KLARA_DIAGT_Q; *E = 2 * np; return KLARA_OK; }
@@ -536,7 +535,8 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on
-        const bool tune = !plain;                                                              // something counts proposals / tunes
+        const bool da = d.tuner == KLARA_TUNER_DUAL_AVERAGING;                                 // (HMC only: validate())
+        const bool tune = !plain || da;                                                        // something counts proposals / tunes
         const long long groups = (d.nchains + KLARA_DIAGT_CPW - 1) / KLARA_DIAGT_CPW, per = (groups + h->nparts - 1) / h->nparts;
         for (int j = 0; j < h->nparts; ++j) {
             KLaunch kp = kl;
@@ -546,9 +546,9 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
             hipStream_t st = j == 0 ? h->stream : h->side[j - 1];
             hipError_t e;
             switch (d.sampler) {
-            case KLARA_SAMPLER_MH: e = klara_launch_diagt_mh(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, grid, st); break;
-            case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, grid, st); break;
-            default: e = klara_launch_diagt_hmc(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, grid, st); break;
+            case KLARA_SAMPLER_MH: e = klara_launch_diagt_mh(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;
+            case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;
+            default: e = klara_launch_diagt_hmc(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;
             }
             if (e != hipSuccess) return e;
         }

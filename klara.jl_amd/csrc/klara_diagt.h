@@ -119,11 +119,14 @@ __device__ __forceinline__ void diag_elem(double x, double w, double m2w, double
 // value / logtarget / gradlogtarget history — on the committed state (never together with ONESTEP).
 // TUNE: the tuner bookkeeping of the group-layout kernel (proposal / accept counters, AcceptanceRateMCTuner per chain or
 // pooled per GPU, verbose counting) — the same device functions, per-chain state in registers over the launch.
-template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false>
+// DA (HMC only): DualAveragingMCTuner — per-chain step and trajectory length (iterate/HMC.jl:142-144, 225-249); the
+// wavefront runs to the longest trajectory of its chains, a finished chain's lanes keep their state.
+template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false, bool DA = false>
 __global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? KLARA_DT_W1 : 2) : 1))
 void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 {
     static_assert(!(ONESTEP && (MON || TUNE)), "monitored / tuned jobs run the committing kernel");
+    static_assert(!DA || (TUNE && SAMPLER == KLARA_SAMPLER_HMC), "dual averaging: tuned HMC");
     constexpr bool PLAIN = !TUNE;              // KCNT / KPOOLED (klara_kernels.h) fold to 0 when nothing counts
     constexpr int E = 2 * NP, CPW = 64 / Q;
     constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;
@@ -197,7 +200,8 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
         TuneRegs tn;
         if (per_chain_tune) tn = { p.tune_step[c0], p.tune_accepted[c0], p.tune_proposed[c0], p.tune_totproposed[c0], 0, 0.0, 0.0 };
         else if (KPOOLED) tn = { p.tune_step[0], p.tune_accepted[0], 0, 0, 0, 0.0, 0.0 };
-        else tn = { p.step0, 0, 0, 0, 0, 0.0, 0.0 };
+        else tn = { DA ? p.tune_step[c0] : p.step0, 0, 0, 0, 0, 0.0, 0.0 };
+        if (DA) { tn.epsbar = p.da_epsbar[c0]; tn.hbar = p.da_hbar[c0]; }
         const long long acc0 = tn.accepted;
         tn.phase = per_chain_tune ? (int)(tn.proposed % p.period) : 0;
 
@@ -208,7 +212,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             double red[3] = { 0.0, 0.0, 0.0 }, red1[1], red2[2];
             double u_last = 0.5, lg_last = 0.0;
             bool acc;
-            double ltp;
+            double ltp, a_da = 0.0;
 
             // All proposal normals of the transition are drawn first: they do not depend on the chain state, so the
             // Philox/Box-Muller work (~4000 issue cycles) runs while the state loads issued above are still in flight.
@@ -275,14 +279,17 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                 const double H0 = lt - 0.5 * k0[0];                                            // :137
 #pragma unroll
                 for (int e = 0; e < E; ++e) { xp[e] = x[e]; gp[e] = g[e]; }                    // :139-140
-                for (int l = 0; l < p.nleaps; ++l) {                                           // :146-155, samplers.jl:122-134
+                const int nl = DA ? da_nleaps(p, eps) : p.nleaps;                              // :142-144
+                for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {                          // :146-155, samplers.jl:122-134
+                    const bool go = !DA || l < nl;
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
-                        mom[e] = mom[e] + halfe * gp[e];
-                        xp[e] = xp[e] + eps * mom[e];
-                        double term;
-                        diag_elem<UNITW>(xp[e], 1.0, m2wvl(e), mvl(e), term, gp[e]);     // (term unused in the leapfrog)
-                        mom[e] = mom[e] + halfe * gp[e];
+                        const double m1 = mom[e] + halfe * gp[e];
+                        const double x1 = xp[e] + eps * m1;
+                        double term, g1;
+                        diag_elem<UNITW>(x1, 1.0, m2wvl(e), mvl(e), term, g1);           // (term unused in the leapfrog)
+                        const double m2 = m1 + halfe * g1;
+                        mom[e] = go ? m2 : mom[e]; xp[e] = go ? x1 : xp[e]; gp[e] = go ? g1 : gp[e];
                     }
                 }
 #pragma unroll
@@ -299,6 +306,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                 const double ratio = H1 - H0;                                                  // :161
                 const double ex = kd_exp(ratio);
                 const double a = 1.0 < ex ? 1.0 : ex;                                          // :163
+                a_da = a;
                 const double u = acc_free ? lane_bcast(u_last, acc_lane)
                                           : kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot));
                 acc = u < a;                                                                   // :165
@@ -306,7 +314,11 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 
             if (accept_out != nullptr && chain_ok && cx.q == 0) accept_out[(long long)s * p.nchains + chain] = acc ? 1 : 0;
             if (KCNT && acc) tn.accepted += 1;
-            if (per_chain_tune) tuning_block(p, tn);                    // iterate/MALA.jl:130-152, HMC.jl:203-224
+            if (DA) da_update(p, tn, (long long)t + 1, a_da);           // iterate/HMC.jl:225-249
+            if (per_chain_tune && !DA) tuning_block(p, tn);             // iterate/MALA.jl:130-152, HMC.jl:203-224
+            else if (DA && per_chain_tune && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {   // verbose report block
+                tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
+            }
             if (ONESTEP) {
                 if (acc) {                               // accepted proposal: registers -> HBM, nothing else moves
                     store_pairs<NP, Q>(cx, wx, xp);
@@ -351,6 +363,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             if (chain_ok && cx.q == 0) { p.LT[chain] = lt; p.naccept[chain] += nacc; }
         }
         if (TUNE && chain_ok && cx.q == 0) {
+            if (DA) { p.tune_step[chain] = tn.step; p.da_epsbar[chain] = tn.epsbar; p.da_hbar[chain] = tn.hbar; }
             if (per_chain_tune) {
                 p.tune_step[chain] = tn.step; p.tune_accepted[chain] = tn.accepted;
                 p.tune_proposed[chain] = tn.proposed; p.tune_totproposed[chain] = tn.totproposed;

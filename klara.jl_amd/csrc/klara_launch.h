@@ -22,22 +22,25 @@ hipError_t klara_launch_mfma_probe(const double* A, const double* B, const doubl
 hipError_t klara_launch_mfma4_probe(const double* A, const double* B, const double* C, double* D, hipStream_t st);
 
 // pair-transposed diagonal-Gaussian kernels (layout kind 3, klara_diagt.h); NP in KLARA_DIAGT_NP_MENU, Q = KLARA_DIAGT_Q
-hipError_t klara_launch_diagt_mh(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st);
-hipError_t klara_launch_diagt_mala(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st);
-hipError_t klara_launch_diagt_hmc(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_mh(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_mala(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_hmc(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
 hipError_t klara_launch_diagt_init(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
-// pairs per lane the kernels are instantiated for (D <= 16*NP); a job takes the smallest one that fits
+// pairs per lane the kernels are instantiated for (D <= 16*NP); a job takes NP = ceil(D / 16)
 #if KLARA_DIAGT_Q == 4     // experiment: 4 lanes per chain, 16 chains per wavefront (D = 100 -> 13 pairs per lane, no padding)
 #define KLARA_DIAGT_NP_MENU_DO(X) X(2) X(4) X(8) X(13) X(16)
 #define KLARA_DIAGT_NP_MAX 16
 #else
-#define KLARA_DIAGT_NP_MENU_DO(X) X(2) X(4) X(6) X(7) X(8)
+// (every value: the kernels rely on NP = ceil(D/2 / Q), i.e. only the LAST pair of a lane can be padding)
+#define KLARA_DIAGT_NP_MENU_DO(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #define KLARA_DIAGT_NP_MAX 8
 #endif
 
 #define KLARA_DIAGT_CASE(S, NP_)                                                                                   \
     case NP_:                                                                                                      \
-        if (tune && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true, true>), grid, blk, 0, st, p, kl);  \
+        if (da && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true, true, (S == KLARA_SAMPLER_HMC)>), grid, blk, 0, st, p, kl); \
+        else if (da) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, true, true, (S == KLARA_SAMPLER_HMC)>), grid, blk, 0, st, p, kl); \
+        else if (tune && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true, true>), grid, blk, 0, st, p, kl);  \
         else if (tune) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, true, true>), grid, blk, 0, st, p, kl);  \
         else if (mon && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true>), grid, blk, 0, st, p, kl); \
         else if (mon) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, true>), grid, blk, 0, st, p, kl);        \

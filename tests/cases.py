@@ -91,6 +91,12 @@ def make_case(name):
     elif name == "hmc_d10_dualavg":    # DualAveragingMCTuner: per-chain step AND per-chain nleaps (iterate/HMC.jl:142-144)
         c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.negdot(10), nchains=45, nsteps=80, burnin=50,
                  leapstep=0.3, nleaps=6, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=50)
+    elif name == "hmc_d40_dualavg":    # dual averaging on the pair-transposed layout (D >= 18), non-unit diagonal, verbose counting
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, 40), np.linspace(0.6, 1.6, 40)), nchains=27,
+                 nsteps=70, burnin=40, leapstep=0.25, nleaps=5, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=40, verbose=True, period=10)
+    elif name == "hmc_d100_dualavg":   # unit weights, NP = 7
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.negdot(100), nchains=19, nsteps=50, burnin=30,
+                 leapstep=0.2, nleaps=4, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.7, da_nadapt=30)
     elif name == "hmc_dense_d37_dualavg":
         rng = np.random.default_rng(5)
         a = rng.standard_normal((37, 37)); p = a @ a.T / 37 + np.eye(37)
@@ -196,7 +202,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "mh_dense_d20", "mala_swiss", "hmc_swiss", "slice_d5", "slice_d100_nostepout", "slice_swiss",
              "hmc_rats", "hmc_rats_pooled", "mala_rats", "slice_rats", "hmc_d10_dualavg", "hmc_dense_d37_dualavg",
              "hmc_rats_dualavg", "mala_d3_tuned_erf", "mala_d1", "hmc_d128_full", "mala_d129", "mh_d512",
-             "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose"]
+             "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",

@@ -62,7 +62,7 @@ def load() -> C.CDLL:
     return lib
 
 
-DIAGT_NP_MENU = (2, 4, 6, 7, 8)      # klara_launch.h KLARA_DIAGT_NP_MENU_DO
+DIAGT_NP_MENU = (2, 3, 4, 5, 6, 7, 8)      # klara_launch.h KLARA_DIAGT_NP_MENU_DO
 DIAGT_Q = 8
 
 
@@ -72,7 +72,7 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     `tuner_mode` and `verbose` are only needed to recognise the pair-transposed layout (kind 3): diagonal Gaussian,
     MH / MALA / HMC, even D <= 128, Vanilla or AcceptanceRate tuner (klara_api.hip diagt_eligible)."""
     d = int(ndims)
-    plain = sampler is not None and tuner != L.TUNER_DUAL_AVERAGING      # (name kept: any Vanilla / AcceptanceRate job)
+    plain = sampler is not None      # (name kept from when the layout excluded tuned jobs)
     if (target_kind == L.TARGET_GAUSS_DIAG and sampler is not None and sampler != L.SAMPLER_SLICE and plain
             and d % 2 == 0 and 18 <= d <= 2 * DIAGT_Q * DIAGT_NP_MENU[-1] and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0"):
         np_ = next(v for v in DIAGT_NP_MENU if v >= (d + 2 * DIAGT_Q - 1) // (2 * DIAGT_Q))

@@ -192,6 +192,20 @@ def test_parity_pair_transposed_layout(name, mode):
     eng.close()
 
 
+@pytest.mark.parametrize("d", [18, 34, 36, 50, 66, 82, 98, 114, 126])
+@pytest.mark.parametrize("sampler", [L.SAMPLER_MALA, L.SAMPLER_HMC])
+def test_pair_transposed_every_pairs_per_lane(d, sampler):
+    """NP = ceil(D/16) = 2..8, each at a dimension where part of the last pair row is padding (the kernels assume that only
+    the LAST pair of a lane can be padding, which holds because NP is exactly the ceiling)."""
+    kw = dict(driftstep=0.25) if sampler == L.SAMPLER_MALA else dict(leapstep=0.2, nleaps=3)
+    case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=13, nsteps=12,
+                burnin=2, x0=None, seed=5, name=f"np_d{d}", **kw)
+    eng, job = _run_pair(case, splits=[5, 7], spl=3)
+    assert eng.layout()[0] == 3 and eng.layout()[2] == 2 * ((d + 15) // 16)
+    _assert_same(eng, job, case)
+    eng.close()
+
+
 @pytest.mark.parametrize("nchains", [1, 3, 9])
 @pytest.mark.parametrize("sampler,kw", [(L.SAMPLER_MALA, dict(driftstep=0.3)), (L.SAMPLER_HMC, dict(leapstep=0.2, nleaps=4)),
                                         (L.SAMPLER_MH, dict(mh_sigma=np.full(22, 0.3)))])
@@ -250,14 +264,14 @@ def test_layout_choice_matches_its_mirror():
 
 
 def test_pair_transposed_layout_is_optional():
-    """Dual averaging, odd D, D > 128 or the slice sampler keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
+    """Odd D, D < 18, D > 128 or the slice sampler keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
     case = cases.make_case("dt_mala_d100")
     e = K.Engine(**cases.engine_kwargs(case)); assert e.layout()[0] == 3; e.close()                  # any monitor
     e = K.Engine(**cases.engine_kwargs(case, monitor=0)); assert e.layout()[0] == 3; e.close()
     e = K.Engine(**cases.engine_kwargs(case, monitor=0, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.5)); assert e.layout()[0] == 3; e.close()
     e = K.Engine(**cases.engine_kwargs(case, monitor=0, verbose=True)); assert e.layout()[0] == 3; e.close()
     e = K.Engine(**cases.engine_kwargs(dict(case, sampler=L.SAMPLER_HMC), monitor=0, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=10))
-    assert e.layout()[0] == 0; e.close()
+    assert e.layout()[0] == 3; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d129"), monitor=0)); assert e.layout()[0] == 0; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d300"), monitor=0)); assert e.layout()[0] == 0; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("slice_d100_nostepout"), monitor=0)); assert e.layout()[0] == 0; e.close()
@@ -273,7 +287,7 @@ def test_pair_transposed_layout_is_optional():
 # onto the group layout keep that path covered (both compared with the oracle told the respective summation order)
 GROUP_FORCED = [n for n in cases.ALL_CASES if n in ("mh_d100", "mala_d100", "mala_d100_small_step", "hmc_d100", "hmc_d128_full",
                                                    "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose",
-                                                   "hmc_rats", "hmc_rats_pooled", "hmc_rats_dualavg")]
+                                                   "hmc_rats", "hmc_rats_pooled", "hmc_rats_dualavg", "hmc_d40_dualavg", "hmc_d100_dualavg")]
 
 
 @pytest.mark.parametrize("name", GROUP_FORCED)
