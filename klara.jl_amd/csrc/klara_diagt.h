@@ -10,7 +10,8 @@
 // work — cross-lane reductions, the accept test, addressing, the loop — is shared by 8 chains instead of 2, the
 // reduction tree is 3 DPP steps instead of 5, and 89% instead of 78% of the lane slots hold real elements.
 //
-// Scope: VanillaMCTuner (the jobs the throughput figures are quoted on) or AcceptanceRateMCTuner, per chain or pooled; any monitor
+// Scope: every tuner (Vanilla — the jobs the throughput figures are quoted on —, AcceptanceRate per chain or pooled,
+// DualAveraging for HMC); any monitor
 // (accept mask, running sums, value / logtarget / gradlogtarget history); D even, 18 <= D <= 16*NP.  Everything else runs on
 // the group layout (klara_kernels.h).
 // Sums are taken per lane in ascending element order and then over the Q lanes by an xor butterfly — the oracle mirrors
