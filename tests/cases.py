@@ -115,6 +115,11 @@ def make_case(name):
         a = rng.standard_normal((37, 37)); p = a @ a.T / 37 + np.eye(37)
         c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(p), nchains=19, nsteps=15, burnin=0,
                  leapstep=0.15, nleaps=4)
+    elif name in ("hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128"):   # NE = 25 with 2 of the 4 tail rows / with none; NE = 32
+        d = int(name[-3:].lstrip("d")) if name != "hmc_dense_d98" and name != "hmc_dense_d70" else int(name[-2:])
+        rng = np.random.default_rng(d)
+        a = rng.standard_normal((d, d)); p = a @ a.T / d + np.eye(d)
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(p), nchains=21, nsteps=10, burnin=0, leapstep=0.12, nleaps=3)
     elif name == "mala_dense_d100":
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDenseTarget(compound_symmetric_precision(100)), nchains=35,
                  nsteps=20, burnin=0, driftstep=0.3)
@@ -202,7 +207,8 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "mh_dense_d20", "mala_swiss", "hmc_swiss", "slice_d5", "slice_d100_nostepout", "slice_swiss",
              "hmc_rats", "hmc_rats_pooled", "mala_rats", "slice_rats", "hmc_d10_dualavg", "hmc_dense_d37_dualavg",
              "hmc_rats_dualavg", "mala_d3_tuned_erf", "mala_d1", "hmc_d128_full", "mala_d129", "mh_d512",
-             "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg"]
+             "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg",
+             "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",
