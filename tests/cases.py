@@ -131,6 +131,14 @@ def make_case(name):
         x0 = np.array([5.1, -0.9, 8.2, -4.5])
         c = dict(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, 100.0), nchains=70, nsteps=40, burnin=10,
                  driftstep=0.1, x0=x0[None, :] + 0.1 * np.random.default_rng(1).standard_normal((70, 4)))
+    elif name in ("mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small"):   # synthetic logistic data: E = 2 / 8, with and without row split
+        d, nd = {"mala_logit_d2": (2, 90), "hmc_logit_d7": (7, 131), "mh_logit_d8_small": (8, 30)}[name]
+        rng = np.random.default_rng(d)
+        X = rng.standard_normal((nd, d)); beta = rng.standard_normal(d)
+        y = (rng.random(nd) < 1.0 / (1.0 + np.exp(-X @ beta))).astype(np.float64)
+        kw = {"mala_logit_d2": dict(sampler=L.SAMPLER_MALA, driftstep=0.05), "hmc_logit_d7": dict(sampler=L.SAMPLER_HMC, leapstep=0.05, nleaps=4),
+              "mh_logit_d8_small": dict(sampler=L.SAMPLER_MH, mh_sigma=np.full(8, 0.2))}[name]
+        c = dict(target=K.LogisticTarget(X, y, 10.0), nchains=45, nsteps=25, burnin=5, x0=0.1 * rng.standard_normal((45, d)), **kw)
     elif name == "hmc_swiss":
         X, y = swiss_data()
         c = dict(sampler=L.SAMPLER_HMC, target=K.LogisticTarget(X, y, 100.0), nchains=65, nsteps=12, burnin=0,
@@ -208,7 +216,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_rats", "hmc_rats_pooled", "mala_rats", "slice_rats", "hmc_d10_dualavg", "hmc_dense_d37_dualavg",
              "hmc_rats_dualavg", "mala_d3_tuned_erf", "mala_d1", "hmc_d128_full", "mala_d129", "mh_d512",
              "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg",
-             "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128"]
+             "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",
