@@ -192,6 +192,37 @@ def test_parity_pair_transposed_layout(name, mode):
     eng.close()
 
 
+def test_group_layout_dimension_sweep():
+    """Every dimension 1..72 and a few larger ones on the group layout (E = 2 / 4 / 8 elements per lane, 1..64 lanes per
+    chain), MALA with a per-dimension target: state, log-target, gradient and accept counts bit-identical to the oracle."""
+    os.environ["KLARA_LAYOUT_KIND"] = "0"
+    try:
+        for d in list(range(1, 73)) + [100, 127, 128, 129, 200, 255, 256, 257, 400, 511, 512]:
+            case = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=5,
+                        nsteps=6, burnin=0, driftstep=0.3 if d < 130 else 0.1, x0=None, seed=d, name=f"sweep_d{d}")
+            eng, job = _run_pair(case, spl=2)
+            assert eng.layout()[0] == 0
+            x, lt, g = eng.state()
+            assert np.array_equal(x, job.X) and np.array_equal(lt, job.LT) and np.array_equal(g, job.G), d
+            assert np.array_equal(eng.accept_counts()[0], job.naccept), d
+            eng.close()
+    finally:
+        del os.environ["KLARA_LAYOUT_KIND"]
+
+
+def test_pair_transposed_dimension_sweep():
+    """Every even dimension 18..128 on the pair-transposed layout."""
+    for d in range(18, 130, 2):
+        case = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=11,
+                    nsteps=6, burnin=0, driftstep=0.3, x0=None, seed=d, name=f"sweep3_d{d}")
+        eng, job = _run_pair(case, spl=2)
+        assert eng.layout()[0] == 3
+        x, lt, g = eng.state()
+        assert np.array_equal(x, job.X) and np.array_equal(lt, job.LT) and np.array_equal(g, job.G), d
+        assert np.array_equal(eng.accept_counts()[0], job.naccept), d
+        eng.close()
+
+
 @pytest.mark.parametrize("d", [18, 34, 36, 50, 66, 82, 98, 114, 126])
 @pytest.mark.parametrize("sampler", [L.SAMPLER_MALA, L.SAMPLER_HMC])
 def test_pair_transposed_every_pairs_per_lane(d, sampler):
