@@ -210,15 +210,20 @@ def test_group_layout_dimension_sweep():
         del os.environ["KLARA_LAYOUT_KIND"]
 
 
-def test_pair_transposed_dimension_sweep():
-    """Every even dimension 18..128 on the pair-transposed layout."""
-    for d in range(18, 130, 2):
-        case = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=11,
-                    nsteps=6, burnin=0, driftstep=0.3, x0=None, seed=d, name=f"sweep3_d{d}")
+@pytest.mark.parametrize("sampler,kw,step", [(L.SAMPLER_MALA, dict(driftstep=0.3), 2), (L.SAMPLER_HMC, dict(leapstep=0.2, nleaps=3), 6),
+                                             (L.SAMPLER_MH, None, 6)])
+def test_pair_transposed_dimension_sweep(sampler, kw, step):
+    """Even dimensions 18..128 on the pair-transposed layout (every one for MALA, every third for HMC and MH): with and
+    without padding pairs, i.e. both ways of obtaining the accept draw."""
+    for d in range(18, 130, step):
+        skw = kw if kw is not None else dict(mh_sigma=np.full(d, 0.2))
+        case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=11,
+                    nsteps=6, burnin=0, x0=None, seed=d, name=f"sweep3_d{d}", **skw)
         eng, job = _run_pair(case, spl=2)
         assert eng.layout()[0] == 3
         x, lt, g = eng.state()
-        assert np.array_equal(x, job.X) and np.array_equal(lt, job.LT) and np.array_equal(g, job.G), d
+        assert np.array_equal(x, job.X) and np.array_equal(lt, job.LT), d
+        assert sampler == L.SAMPLER_MH or np.array_equal(g, job.G), d
         assert np.array_equal(eng.accept_counts()[0], job.naccept), d
         eng.close()
 
