@@ -228,6 +228,30 @@ def test_pair_transposed_dimension_sweep(sampler, kw, step):
         eng.close()
 
 
+@pytest.mark.parametrize("nstreams", [0, 3])
+def test_few_lanes_layouts_chain_count_sweep(nstreams):
+    """1..20 chains (every fill level of the last 8-chain wavefront group) on layout kinds 3 and 4; with three chain
+    partitions requested even when there are fewer groups than partitions."""
+    rng = np.random.default_rng(3)
+    xc = np.array([-14.0, -7.0, 0.0, 7.0, 14.0]); R = 12
+    Y = (240.0 + 15.0 * rng.standard_normal(R))[:, None] + (6.0 + 0.5 * rng.standard_normal(R))[:, None] * xc[None, :] + 6.0 * rng.standard_normal((R, 5))
+    ht = K.HierNormalTarget(Y, xc)
+    for n in range(1, 21):
+        case = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(30), nchains=n, nsteps=7, burnin=0, driftstep=0.3, x0=None,
+                    seed=n, name=f"chains{n}")
+        eng = K.Engine(**cases.engine_kwargs(case, steps_per_launch=2, nstreams=nstreams))
+        job = O.OracleJob(**cases.oracle_kwargs(case, layout=eng.layout()))
+        assert eng.layout()[0] == 3
+        eng.init_state_normal(); job.init_state_normal(); eng.run(7); job.run(7)
+        _assert_same(eng, job, case); eng.close()
+        if nstreams == 0:
+            x0 = ht.least_squares_start()[None, :] + 0.05 * rng.standard_normal((n, ht.ndims))
+            case = dict(sampler=L.SAMPLER_HMC, target=ht, nchains=n, nsteps=5, burnin=0, leapstep=0.01, nleaps=3, x0=x0, seed=n, name=f"hchains{n}")
+            eng, job = _run_pair(case, spl=2)
+            assert eng.layout()[0] == 4
+            _assert_same(eng, job, case); eng.close()
+
+
 @pytest.mark.parametrize("d", [18, 34, 36, 50, 66, 82, 98, 114, 126])
 @pytest.mark.parametrize("sampler", [L.SAMPLER_MALA, L.SAMPLER_HMC])
 def test_pair_transposed_every_pairs_per_lane(d, sampler):
