@@ -28,6 +28,38 @@ def test_desc_struct_matches_header_layout():
     assert L.KlaraDesc.stream.offset == C.sizeof(L.KlaraDesc) - 8
 
 
+def test_desc_fields_agree_across_header_ctypes_and_julia_stub():
+    """struct klara_desc: the C header, the ctypes mirror (klara.jl_amd/_lib.py) and the Julia ccall stub
+    (julia/KlaraHIP.jl, also printed in INTEGRATION.md) list the same fields in the same order with matching widths."""
+    import re
+    hdr = (ROOT / "include" / "klara_hip.h").read_text()
+    body = hdr[hdr.index("typedef struct klara_desc"):]
+    body = body[body.index("{") + 1:body.index("} klara_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    cfields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(const )?([A-Za-z_0-9]+)( ?\*)? ?([A-Za-z_0-9]+)$", decl)
+        assert m, decl
+        ctype = "ptr" if m.group(3) else m.group(2)
+        cfields.append((m.group(4), ctype))
+    width = {"uint32_t": 4, "int32_t": 4, "int64_t": 8, "uint64_t": 8, "double": 8, "ptr": 8, "void": 8}
+    py = [(n, C.sizeof(t)) for n, t in L.KlaraDesc._fields_]
+    assert [n for n, _ in cfields] == [n for n, _ in py]
+    assert [width[t] for _, t in cfields] == [w for _, w in py]
+    jl = (ROOT / "julia" / "KlaraHIP.jl").read_text()
+    jbody = jl[jl.index("struct KlaraDesc") + len("struct KlaraDesc"):]
+    jbody = jbody[:jbody.index("\nend")]
+    jfields = re.findall(r"([A-Za-z_0-9]+)::([A-Za-z0-9{}]+)", jbody)
+    jwidth = {"UInt32": 4, "Int32": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "Ptr{Float64}": 8, "Ptr{Cvoid}": 8}
+    assert [n for n, _ in jfields] == [n for n, _ in py]
+    assert [jwidth[t] for _, t in jfields] == [w for _, w in py]
+    integ = (ROOT / "INTEGRATION.md").read_text()
+    assert all(f"{n}::{t}" in integ for n, t in jfields)
+
+
 def test_strerror(klib):
     assert klib.klara_strerror(0) == b"ok"
     assert b"finite" in klib.klara_strerror(L.ERR_NONFINITE_INIT)
