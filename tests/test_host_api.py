@@ -60,6 +60,14 @@ def test_desc_fields_agree_across_header_ctypes_and_julia_stub():
     assert all(f"{n}::{t}" in integ for n, t in jfields)
 
 
+def test_julia_stub_binds_only_declared_symbols():
+    import re
+    jl = (ROOT / "julia" / "KlaraHIP.jl").read_text()
+    names = set(re.findall(r"ccall\(\(:([a-z_0-9]+), lib\)", jl))
+    assert names and names <= set(L.EXPORTS), names - set(L.EXPORTS)
+    assert {"klara_create", "klara_set_state", "klara_run", "klara_reset", "klara_destroy", "klara_get_chain"} <= names
+
+
 def test_strerror(klib):
     assert klib.klara_strerror(0) == b"ok"
     assert b"finite" in klib.klara_strerror(L.ERR_NONFINITE_INIT)
