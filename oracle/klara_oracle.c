@@ -12,6 +12,14 @@
  * (test/ParameterNStates.jl:139-146), Philox4x32-10 (Random123 known-answer vectors) — see
  * tests/test_oracle_kats.py.  Beyond that the oracle is checked against analytic posterior moments.
  *
+ * Third-party pieces of the reference's arithmetic that are NOT in /root/reference (REQUIRE lists version floors only,
+ * there is no lockfile): Julia Base `randn`/`rand` (dSFMT + ziggurat, unseeded — replaced by the build-defined stream
+ * below), Base `sum`/`dot` (order unspecified — fixed to the kernels' order below) and Distributions.jl (>= 0.4.7)
+ * `rand(::MvNormal)`, `logpdf`/`gradlogpdf(::MvNormal)` at the call sites iterate/MH.jl:79,86,91 and
+ * BasicContMuvParameter.jl:163,195: their published definitions are restated (x = mu + sigma .* randn(D) for a diagonal
+ * covariance; logpdf = -1/2 (|x-mu|^2/sigma^2 + D log 2 pi) - sum log sigma; gradlogpdf = -(x-mu)/sigma^2) and pinned by
+ * the reference's own test values (tests/test_oracle_kats.py::test_mvnormal_target_closures).
+ *
  * Each function cites the reference lines it restates.  Arithmetic follows the Julia expressions
  * literally (no fma contraction, same association); the only liberty is the summation order of
  * `sum`/`dot` (unspecified in Julia: BLAS ddot / pairwise SIMD sum), which is fixed to the order the
