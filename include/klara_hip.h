@@ -201,6 +201,22 @@ klara_status klara_get_chain_sums(klara_handle* h, double* sum, double* sumsq, i
 klara_status klara_get_pooled_summaries(klara_handle* h, double* sum, double* sumsq,
                                         uint64_t* naccept, uint64_t* ntransitions,
                                         int64_t* nsaved_out);
+/* ---- multi-GPU without a host framework (SURVEY section 8(b),(e)): one process (or thread) per GPU, chains sharded by
+ * klara_desc.chain_offset, and ONE exchange: the all-reduce of the pooled chain summaries over RCCL / xGMI.  (The Python host
+ * does the same through torch.distributed, klara.jl_amd/distributed.py.)  librccl.so is loaded on first use (dlopen), a
+ * single-GPU user never touches it.  The 128-byte id is RCCL's ncclUniqueId: rank 0 creates it, the caller ships it to the
+ * other ranks by whatever it has (file, socket, MPI, Julia Distributed). */
+#define KLARA_COMM_ID_BYTES 128
+typedef struct klara_comm klara_comm;
+klara_status klara_comm_unique_id(uint8_t id[KLARA_COMM_ID_BYTES]);
+klara_status klara_comm_init(klara_comm** out, int32_t nranks, int32_t rank, const uint8_t id[KLARA_COMM_ID_BYTES],
+                             int32_t device);
+klara_status klara_comm_destroy(klara_comm* comm);
+/* Sum over all ranks of klara_get_pooled_summaries: sum[D], sumsq[D] (NULL unless KLARA_MON_SUMMARIES is on), accepted
+ * transitions, transitions, saved samples (= saved steps x chains), chains.  Collective: every rank calls it. */
+klara_status klara_gather_summaries(klara_handle* h, klara_comm* comm, double* sum, double* sumsq, uint64_t* naccept,
+                                    uint64_t* ntransitions, uint64_t* nsamples, uint64_t* nchains);
+
 /* one chain of the stored history in Klara's NState layout: value[d + D*i], i = saved step
  * (BasicContMuvParameterNState.jl:89-119); requires KLARA_MON_HISTORY. */
 klara_status klara_get_chain(klara_handle* h, int64_t local_chain, double* value, int64_t capacity_cols,

@@ -2,6 +2,8 @@
 // The ABI and the reference lines each entry point replaces are documented in include/klara_hip.h.
 #include <hip/hip_runtime.h>
 #include <rocrand/rocrand_kernel.h>
+#include <rccl/rccl.h>      // types only: librccl.so is dlopen'ed on first use (klara_comm_*)
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -752,6 +754,106 @@ extern "C" klara_status klara_get_pooled_summaries(klara_handle* h, double* sum,
     if (naccept) HIPCHK(hipMemcpy(naccept, accout, sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (ntransitions) *ntransitions = (uint64_t)h->steps_done * (uint64_t)h->d.nchains;
     if (nsaved_out) *nsaved_out = h->nsaved;
+    return KLARA_OK;
+}
+
+// ---- RCCL summary all-reduce behind the C ABI (librccl.so loaded lazily; see include/klara_hip.h)
+struct klara_comm {
+    void* dl = nullptr;
+    ncclComm_t comm = nullptr;
+    int nranks = 0, rank = 0, device = 0;
+    double* buf = nullptr; size_t cap = 0;                      // device staging: 2D doubles + 4 u64
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+};
+static void* rccl_dl()
+{
+    static void* dl = nullptr;
+    if (!dl) dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!dl) dl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!dl) dl = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    return dl;
+}
+extern "C" klara_status klara_comm_unique_id(uint8_t id[KLARA_COMM_ID_BYTES])
+{
+    static_assert(KLARA_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!id) return KLARA_ERR_INVALID_ARG;
+    void* dl = rccl_dl();
+    if (!dl) return KLARA_ERR_UNSUPPORTED;
+    auto get = reinterpret_cast<ncclResult_t (*)(ncclUniqueId*)>(dlsym(dl, "ncclGetUniqueId"));
+    ncclUniqueId u;
+    if (!get || get(&u) != ncclSuccess) return KLARA_ERR_HIP;
+    memcpy(id, u.internal, KLARA_COMM_ID_BYTES);
+    return KLARA_OK;
+}
+extern "C" klara_status klara_comm_init(klara_comm** out, int32_t nranks, int32_t rank, const uint8_t id[KLARA_COMM_ID_BYTES],
+                                        int32_t device)
+{
+    if (!out || !id || nranks <= 0 || rank < 0 || rank >= nranks) return KLARA_ERR_INVALID_ARG;
+    void* dl = rccl_dl();
+    if (!dl) return KLARA_ERR_UNSUPPORTED;
+    HIPCHK(hipSetDevice(device));
+    auto init = reinterpret_cast<ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int)>(dlsym(dl, "ncclCommInitRank"));
+    klara_comm* c = new (std::nothrow) klara_comm();
+    if (!c) return KLARA_ERR_NOMEM;
+    c->dl = dl; c->nranks = nranks; c->rank = rank; c->device = device;
+    c->AllReduce = reinterpret_cast<decltype(c->AllReduce)>(dlsym(dl, "ncclAllReduce"));
+    c->CommDestroy = reinterpret_cast<decltype(c->CommDestroy)>(dlsym(dl, "ncclCommDestroy"));
+    ncclUniqueId u;
+    memcpy(u.internal, id, KLARA_COMM_ID_BYTES);
+    if (!init || !c->AllReduce || !c->CommDestroy || init(&c->comm, nranks, u, rank) != ncclSuccess) { delete c; return KLARA_ERR_HIP; }
+    *out = c;
+    return KLARA_OK;
+}
+extern "C" klara_status klara_comm_destroy(klara_comm* c)
+{
+    if (!c) return KLARA_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    if (c->comm) c->CommDestroy(c->comm);
+    if (c->buf) hipFree(c->buf);
+    delete c;
+    return KLARA_OK;
+}
+extern "C" klara_status klara_gather_summaries(klara_handle* h, klara_comm* c, double* sum, double* sumsq, uint64_t* naccept,
+                                               uint64_t* ntransitions, uint64_t* nsamples, uint64_t* nchains)
+{
+    if (!h || !c) return KLARA_ERR_INVALID_ARG;
+    if (!h->have_state) return KLARA_ERR_STATE;
+    if ((sum || sumsq) && !h->sum) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    const size_t D = (size_t)h->d.ndims;
+    if (c->cap < 2 * D + 4) {
+        if (c->buf) hipFree(c->buf);
+        c->buf = nullptr; c->cap = 0;
+        HIPCHK(dalloc(&c->buf, 2 * D + 4));
+        c->cap = 2 * D + 4;
+    }
+    HIPCHK(hipMemsetAsync(c->buf, 0, (2 * D + 4) * sizeof(double), h->stream));
+    if (h->sum) {
+        hipLaunchKernelGGL(k_pool_sums, dim3((unsigned)D), dim3(256), 0, h->stream, h->sum, h->sumsq, (long long)h->d.nchains, (int)D, c->buf);
+        HIPCHK(hipGetLastError());
+    }
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(c->buf + 2 * D);
+    hipLaunchKernelGGL(k_pool_accept, dim3(1), dim3(256), 0, h->stream, h->naccept, (long long)h->d.nchains, cnt);
+    HIPCHK(hipGetLastError());
+    const unsigned long long local[3] = { (unsigned long long)h->steps_done * (unsigned long long)h->d.nchains,
+                                          (unsigned long long)h->nsaved * (unsigned long long)h->d.nchains,
+                                          (unsigned long long)h->d.nchains };
+    HIPCHK(hipMemcpyAsync(cnt + 1, local, sizeof(local), hipMemcpyHostToDevice, h->stream));
+    // two in-place all-reduces on the job's stream: 2D doubles, 4 counters — (2D + 4) x 8 B per rank, latency-bound
+    if (c->AllReduce(c->buf, c->buf, 2 * D, ncclDouble, ncclSum, c->comm, h->stream) != ncclSuccess) return KLARA_ERR_HIP;
+    if (c->AllReduce(cnt, cnt, 4, ncclUint64, ncclSum, c->comm, h->stream) != ncclSuccess) return KLARA_ERR_HIP;
+    std::vector<double> host(2 * D + 4);
+    HIPCHK(hipMemcpyAsync(host.data(), c->buf, (2 * D + 4) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (sum) memcpy(sum, host.data(), D * sizeof(double));
+    if (sumsq) memcpy(sumsq, host.data() + D, D * sizeof(double));
+    unsigned long long out[4];
+    memcpy(out, host.data() + 2 * D, sizeof(out));
+    if (naccept) *naccept = out[0];
+    if (ntransitions) *ntransitions = out[1];
+    if (nsamples) *nsamples = out[2];
+    if (nchains) *nchains = out[3];
     return KLARA_OK;
 }
 

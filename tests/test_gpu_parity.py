@@ -309,6 +309,29 @@ def test_hier_few_lanes_layout_other_unit_counts(R, nchains, tuner_kw):
     eng.close()
 
 
+def test_c_abi_summary_allreduce_over_rccl_single_rank(klib):
+    """klara_comm_* / klara_gather_summaries: the C-ABI form of the one multi-GPU exchange (an RCCL all-reduce of the
+    pooled summaries).  One box has one GPU, so the communicator has a single rank: the call sequence, the lazy librccl
+    load and the packing are exercised, and the result must equal klara_get_pooled_summaries."""
+    case = cases.make_case("mala_d100_small_step")
+    eng = K.Engine(**cases.engine_kwargs(case)); eng.init_state_normal(); eng.run(case["nsteps"])
+    uid = (C.c_uint8 * 128)()
+    L.check(klib.klara_comm_unique_id(uid), "comm_unique_id")
+    comm = C.c_void_p()
+    L.check(klib.klara_comm_init(C.byref(comm), 1, 0, uid, 0), "comm_init")
+    d = case["target"].ndims
+    s = np.empty(d); q = np.empty(d)
+    na, nt, ns, nc = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    for _ in range(2):          # collective is repeatable
+        L.check(klib.klara_gather_summaries(eng._h, comm, s.ctypes.data, q.ctypes.data, C.byref(na), C.byref(nt), C.byref(ns), C.byref(nc)),
+                "gather_summaries")
+    ps, pq, pna, pnt, pns = eng.pooled_summaries()
+    assert np.array_equal(s, ps) and np.array_equal(q, pq)
+    assert (na.value, nt.value, ns.value, nc.value) == (pna, pnt, pns * case["nchains"], case["nchains"])
+    L.check(klib.klara_comm_destroy(comm), "comm_destroy")
+    eng.close()
+
+
 def test_layout_choice_matches_its_mirror():
     """tests/oracle_ffi.default_layout (what the CPU-side golden generator assumes) is the product's choice for every
     dimension and tuner it can meet."""
