@@ -62,4 +62,27 @@ function chainmeans(job::HIPMCJob)
                 job.handle, s, q, n), "klara_get_chain_sums")
     s ./ n[]
 end
+# ---- multi-GPU: one process per GPU; the only exchange is the all-reduce of the pooled summaries (RCCL over xGMI)
+mutable struct HIPComm; handle::Ptr{Cvoid}; end
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:klara_comm_unique_id, lib), Cint, (Ptr{UInt8},), id), "klara_comm_unique_id")
+    id
+end
+function HIPComm(nranks::Integer, rank::Integer, id::Vector{UInt8}, device::Integer)
+    c = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:klara_comm_init, lib), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Ptr{UInt8}, Cint), c, nranks, rank, id, device), "klara_comm_init")
+    comm = HIPComm(c[])
+    finalizer(x -> ccall((:klara_comm_destroy, lib), Cint, (Ptr{Cvoid},), x.handle), comm)
+    comm
+end
+# (sum x, sum x^2 per dimension over every chain of every GPU, accepted, transitions, saved samples, chains)
+function gather_summaries(job::HIPMCJob, comm::HIPComm)
+    s = Vector{Float64}(undef, job.ndims); q = similar(s)
+    na = Ref{UInt64}(0); nt = Ref{UInt64}(0); ns = Ref{UInt64}(0); nc = Ref{UInt64}(0)
+    check(ccall((:klara_gather_summaries, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}),
+                job.handle, comm.handle, s, q, na, nt, ns, nc), "klara_gather_summaries")
+    (s, q, na[], nt[], ns[], nc[])
+end
 end # module
