@@ -8,11 +8,14 @@ A "step" is one transition (one `iterate!`) of every chain.  With --gpus N every
 only exchange is the end-of-run all-reduce of pooled chain summaries over RCCL, inside the timed region.
 
 Prints ONE JSON line (rank 0).  Extra keys beyond the driver's contract:
-  roofline      dominant transition kernel: algorithmic HBM bytes per launch / mean launch duration from
-                HIP events on the launch stream (DESIGN.md §Measurement gives the per-unit figures)
+  roofline      dominant transition kernel (k_diagt<MALA>, layout kind 3): algorithmic HBM bytes per launch / mean launch
+                duration from HIP events on the launch stream, measured in a separate pass with every launch on one stream
+                (the timed region overlaps two half-size launches on two streams: config.streams); DESIGN.md sections 4-5
+                give the per-unit figures; `traffic` = PMC bytes of the same command (profiles/)
   cpu_baseline  the CPU oracle ("port" of the reference path) timed on this box's host cores on a bounded
                 sample of the same workload (N=1 only)
-  extra         secondary measurements outside the timed region (fused launches, HMC leapfrog rate)
+  extra         secondary measurements outside the timed region: fused launches, HMC leapfrog rates (diagonal and dense /
+                FP64-MFMA target), and BASELINE configs 4 and 5 at their per-GPU share
 """
 import argparse
 import json
