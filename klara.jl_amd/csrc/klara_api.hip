@@ -63,10 +63,10 @@ static int cnt_predicate(const klara_desc& d)
 static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // layout kind 3 serves the jobs whose transition is pure elementwise work plus three sums (see klara_diagt.h):
-// diagonal Gaussian, MH / MALA / HMC, every tuner, any monitor
+// diagonal Gaussian, every sampler, every tuner, any monitor
 static bool diagt_eligible(const klara_desc& d)
 {
-    if (d.target != KLARA_TARGET_GAUSS_DIAG || d.sampler == KLARA_SAMPLER_SLICE) return false;
+    if (d.target != KLARA_TARGET_GAUSS_DIAG) return false;
     // (D <= 16: the group layout already puts a chain on <= 4 lanes, 16..64 chains per wavefront)
     if ((d.ndims & 1) || d.ndims < 18 || d.ndims > 2 * KLARA_DIAGT_Q * KLARA_DIAGT_NP_MAX) return false;
     if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
@@ -549,6 +549,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
             hipError_t e;
             switch (d.sampler) {
             case KLARA_SAMPLER_MH: e = klara_launch_diagt_mh(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;
+            case KLARA_SAMPLER_SLICE: e = klara_launch_diagt_slice(p, kp, h->E / 2, unitw, mon, tune, grid, st); break;
             case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;
             default: e = klara_launch_diagt_hmc(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;
             }

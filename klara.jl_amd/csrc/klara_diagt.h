@@ -11,7 +11,7 @@
 // reduction tree is 3 DPP steps instead of 5, and 89% instead of 78% of the lane slots hold real elements.
 //
 // Scope: every tuner (Vanilla — the jobs the throughput figures are quoted on —, AcceptanceRate per chain or pooled,
-// DualAveraging for HMC); any monitor
+// DualAveraging for HMC); MH, MALA, HMC and the slice sampler; any monitor
 // (accept mask, running sums, value / logtarget / gradlogtarget history); D even, 18 <= D <= 16*NP.  Everything else runs on
 // the group layout (klara_kernels.h).
 // Sums are taken per lane in ascending element order and then over the Q lanes by an xor butterfly — the oracle mirrors
@@ -130,7 +130,9 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
     static_assert(!DA || (TUNE && SAMPLER == KLARA_SAMPLER_HMC), "dual averaging: tuned HMC");
     constexpr bool PLAIN = !TUNE;              // KCNT / KPOOLED (klara_kernels.h) fold to 0 when nothing counts
     constexpr int E = 2 * NP, CPW = 64 / Q;
-    constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;
+    constexpr bool NEEDG = SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_HMC;
+    constexpr bool SLICE = SAMPLER == KLARA_SAMPLER_SLICE;
+    static_assert(!(SLICE && ONESTEP), "the slice sampler moves every chain: it runs the committing kernel");
     const KParams& p = *pp;
     // weights and means of a non-unit diagonal: one LDS copy per workgroup (element i at [i], padding = (1, 0)) instead
     // of 4*NP registers per lane; a pair's (w, mu) values are 16-byte LDS reads where they are used
@@ -158,7 +160,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
     const auto wvl = [&](int e) { return UNITW ? 1.0 : *(volatile const double*)&lds_w[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
     const auto mvl = [&](int e) { return UNITW ? 0.0 : *(volatile const double*)&lds_mu[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
     const auto m2wvl = [&](int e) { return UNITW ? -2.0 : *(volatile const double*)&lds_m2w[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
-    if (SAMPLER == KLARA_SAMPLER_MH) load_pair_param<NP, Q>(cx, p.vecparam, D, 1.0, sig);
+    if (SAMPLER == KLARA_SAMPLER_MH || SLICE) load_pair_param<NP, Q>(cx, p.vecparam, D, 1.0, sig);   // proposal scales / slice widths
     const double gconst = p.gconst;
 
     // accept draw: slot S = ceil(D/2) = D/2.  (NP-1)*Q < D/2 <= NP*Q, so when the layout has padding (D/2 < NP*Q) the
@@ -186,6 +188,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
         if (NEEDG) load_pairs<NP, Q>(cx, wg, g);
         double lt = p.LT[chain_ok ? chain : 0];
         unsigned long long nacc = 0;
+        bool stuck = false;                                // slice sampler: step-out / shrink ran out of attempts
         // saved-sample monitors (MON): running sums stay in registers over the launch's transitions
         const bool do_sum = MON && p.sum != nullptr;
         double sm[E], sq[E];
@@ -218,14 +221,95 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             // All proposal normals of the transition are drawn first: they do not depend on the chain state, so the
             // Philox/Box-Muller work (~4000 issue cycles) runs while the state loads issued above are still in flight.
             double z[E];
-            if (SAMPLER != KLARA_SAMPLER_HMC) {
+            if (SAMPLER != KLARA_SAMPLER_HMC && !SLICE) {
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
                     pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z[2 * pi], z[2 * pi + 1], u_last, lg_last);
                     KLARA_DT_PAIR_FENCE(pi);
                 }
             }
-            if (SAMPLER == KLARA_SAMPLER_MH) {                                     // iterate/MH.jl:72-124
+            if (SLICE) {                                                           // iterate/SliceSampler.jl:60-109
+                // Coordinates are visited in turn.  Coordinate i lives on lane (i/2) % Q of its chain as register
+                // 2*((i/2)/Q) + (i&1); everything scalar (the slice level, the interval, the probes' log-targets) is computed
+                // redundantly by the chain's Q lanes, and loops run until every chain of the wavefront is done (__any).
+                // Per coordinate the per-element terms w (x - mu)^2 of the other coordinates are formed once; a probe only
+                // re-forms the moving term and re-adds the lane's terms in ascending order (the order of a full evaluation).
+                acc = true; ltp = lt;
+                const int gb = cx.lane - cx.q;
+                for (int i = 0; i < D; ++i) {                                                  // :65
+                    const int P = i >> 1, qo = P & (Q - 1), eo = 2 * (P / Q) + (i & 1);
+                    const bool owner = cx.q == qo;
+                    double xi_l = 0.0, w_l = 0.0, term[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if (e == eo) { xi_l = x[e]; w_l = sig[e]; }
+                        double gd;
+                        diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), term[e], gd);
+                    }
+                    const double xi = lane_bcast(xi_l, gb + qo), wd = lane_bcast(w_l, gb + qo);
+                    const double wi_t = lane_bcast(UNITW ? 1.0 : wv(eo), gb + qo), mi_t = lane_bcast(UNITW ? 0.0 : mv(eo), gb + qo);
+                    const uint32_t base = (uint32_t)i << KLARA_SLICE_ATT_BITS;
+                    const kd_u32x4 b0 = kd_stream_block(p.seed, gchain, t, base);
+                    const double logu = kd_log_u01(kd_uniform_xy(b0)) + lt;                    // :66
+                    const double ru = kd_uniform_zw(b0);                                       // :71
+                    double Li = xi - ru * wd;                                                  // :72
+                    double Ri = xi + (1.0 - ru) * wd;                                          // :73
+                    const auto lt_with = [&](double cand) -> double {
+                        double tc, gd, part[1] = { 0.0 };
+                        diag_elem<UNITW>(cand, wi_t, -2.0 * wi_t, mi_t, tc, gd);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) part[0] = part[0] + ((owner && e == eo) ? tc : term[e]);
+                        group_allreduce<1>(part, Q, cx.lane);
+                        return gconst - part[0];
+                    };
+                    if (p.stepout) {                                                           // :75-89
+                        double l = lt_with(Li);
+                        int guard = 0;
+                        while (true) {
+                            bool go = chain_ok && !stuck && (l > logu);
+                            if (go && ++guard > KLARA_SLICE_MAX_ATT) { stuck = true; go = false; }
+                            if (!__any(go)) break;
+                            const double Ln = Li - wd;
+                            const double ln = lt_with(go ? Ln : Li);
+                            if (go) { Li = Ln; l = ln; }
+                        }
+                        double r = lt_with(Ri);
+                        guard = 0;
+                        while (true) {
+                            bool go = chain_ok && !stuck && (r > logu);
+                            if (go && ++guard > KLARA_SLICE_MAX_ATT) { stuck = true; go = false; }
+                            if (!__any(go)) break;
+                            const double Rn = Ri + wd;
+                            const double rn = lt_with(go ? Rn : Ri);
+                            if (go) { Ri = Rn; r = rn; }
+                        }
+                    }
+                    double xprime = xi, ltnew = lt;
+                    bool done = !chain_ok || stuck;
+                    for (uint32_t a = 1;; ++a) {                                               // :91-106
+                        if (!done && a > KLARA_SLICE_MAX_ATT) { stuck = true; done = true; }
+                        if (!__any(!done)) break;
+                        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, base | a));
+                        const double cand = u * (Ri - Li) + Li;                                // :92-93
+                        const double lc = lt_with(done ? xprime : cand);                       // :94
+                        if (!done) {
+                            xprime = cand; ltnew = lc;
+                            if (lc > logu) done = true;                                        // :95
+                            else if (cand > xi) Ri = cand;                                     // :98
+                            else if (cand < xi) Li = cand;                                     // :100
+                            else { stuck = true; done = true; }                                // :102
+                        }
+                    }
+                    if (!stuck) {
+                        lt = ltnew;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) if (owner && e == eo) x[e] = xprime;       // :108
+                    }
+                }
+                ltp = lt;
+#pragma unroll
+                for (int e = 0; e < E; ++e) xp[e] = x[e];          // (the commit below is then a no-op)
+            } else if (SAMPLER == KLARA_SAMPLER_MH) {                              // iterate/MH.jl:72-124
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     xp[e] = x[e] + sig[e] * z[e];                                              // MH.jl:79
@@ -314,7 +398,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             }
 
             if (accept_out != nullptr && chain_ok && cx.q == 0) accept_out[(long long)s * p.nchains + chain] = acc ? 1 : 0;
-            if (KCNT && acc) tn.accepted += 1;
+            if (KCNT && acc && !SLICE) tn.accepted += 1;                // (the slice sampler never counts accepts)
             if (DA) da_update(p, tn, (long long)t + 1, a_da);           // iterate/HMC.jl:225-249
             if (per_chain_tune && !DA) tuning_block(p, tn);             // iterate/MALA.jl:130-152, HMC.jl:203-224
             else if (DA && per_chain_tune && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {   // verbose report block
@@ -358,6 +442,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             store_pairs<NP, Q>(cx, group_window(p.sum, first_chain, here, D), sm);
             store_pairs<NP, Q>(cx, group_window(p.sumsq, first_chain, here, D), sq);
         }
+        if (SLICE && stuck && chain_ok && cx.q == 0) atomicMax((int*)p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
         if (!ONESTEP && nacc != 0) {
             store_pairs<NP, Q>(cx, wx, x);
             if (NEEDG) store_pairs<NP, Q>(cx, wg, g);

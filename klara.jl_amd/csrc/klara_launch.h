@@ -25,6 +25,7 @@ hipError_t klara_launch_mfma4_probe(const double* A, const double* B, const doub
 hipError_t klara_launch_diagt_mh(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
 hipError_t klara_launch_diagt_mala(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
 hipError_t klara_launch_diagt_hmc(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_slice(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st);
 hipError_t klara_launch_diagt_init(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
 // pairs per lane the kernels are instantiated for (D <= 16*NP); a job takes NP = ceil(D / 16)
 #if KLARA_DIAGT_Q == 4     // experiment: 4 lanes per chain, 16 chains per wavefront (D = 100 -> 13 pairs per lane, no padding)

@@ -73,7 +73,7 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     MH / MALA / HMC, even D <= 128, Vanilla or AcceptanceRate tuner (klara_api.hip diagt_eligible)."""
     d = int(ndims)
     plain = sampler is not None      # (name kept from when the layout excluded tuned jobs)
-    if (target_kind == L.TARGET_GAUSS_DIAG and sampler is not None and sampler != L.SAMPLER_SLICE and plain
+    if (target_kind == L.TARGET_GAUSS_DIAG and sampler is not None and plain
             and d % 2 == 0 and 18 <= d <= 2 * DIAGT_Q * DIAGT_NP_MENU[-1] and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0"):
         np_ = next(v for v in DIAGT_NP_MENU if v >= (d + 2 * DIAGT_Q - 1) // (2 * DIAGT_Q))
         return (3, DIAGT_Q, 2 * np_)

@@ -339,15 +339,13 @@ def test_layout_choice_matches_its_mirror():
         for sampler, extra in ((L.SAMPLER_MALA, dict(driftstep=0.1)), (L.SAMPLER_MH, dict(mh_sigma=np.ones(d))),
                                (L.SAMPLER_SLICE, dict(slice_widths=np.ones(d)))):
             for tuner in (L.TUNER_VANILLA, L.TUNER_ACCEPT_RATE):
-                if sampler == L.SAMPLER_SLICE and d > 64:
-                    continue
                 e = K.Engine(sampler=sampler, target=K.GaussDiagTarget.negdot(d), nchains=5, nsteps=2, tuner=tuner, targetrate=0.5, **extra)
                 assert tuple(e.layout()) == tuple(O.default_layout(L.TARGET_GAUSS_DIAG, d, sampler=sampler, tuner=tuner)), (d, sampler, tuner)
                 e.close()
 
 
 def test_pair_transposed_layout_is_optional():
-    """Odd D, D < 18, D > 128 or the slice sampler keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
+    """Odd D, D < 18 or D > 128 keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
     case = cases.make_case("dt_mala_d100")
     e = K.Engine(**cases.engine_kwargs(case)); assert e.layout()[0] == 3; e.close()                  # any monitor
     e = K.Engine(**cases.engine_kwargs(case, monitor=0)); assert e.layout()[0] == 3; e.close()
@@ -357,7 +355,8 @@ def test_pair_transposed_layout_is_optional():
     assert e.layout()[0] == 3; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d129"), monitor=0)); assert e.layout()[0] == 0; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d300"), monitor=0)); assert e.layout()[0] == 0; e.close()
-    e = K.Engine(**cases.engine_kwargs(cases.make_case("slice_d100_nostepout"), monitor=0)); assert e.layout()[0] == 0; e.close()
+    e = K.Engine(**cases.engine_kwargs(cases.make_case("slice_d100_nostepout"), monitor=0)); assert e.layout()[0] == 3; e.close()
+    e = K.Engine(**cases.engine_kwargs(cases.make_case("slice_d5"), monitor=0)); assert e.layout()[0] == 0; e.close()
     os.environ["KLARA_LAYOUT_KIND"] = "0"
     try:
         e = K.Engine(**cases.engine_kwargs(case, monitor=0)); assert e.layout()[0] == 0; e.close()
@@ -370,7 +369,8 @@ def test_pair_transposed_layout_is_optional():
 # onto the group layout keep that path covered (both compared with the oracle told the respective summation order)
 GROUP_FORCED = [n for n in cases.ALL_CASES if n in ("mh_d100", "mala_d100", "mala_d100_small_step", "hmc_d100", "hmc_d128_full",
                                                    "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose",
-                                                   "hmc_rats", "hmc_rats_pooled", "hmc_rats_dualavg", "hmc_d40_dualavg", "hmc_d100_dualavg")]
+                                                   "hmc_rats", "hmc_rats_pooled", "hmc_rats_dualavg", "hmc_d40_dualavg", "hmc_d100_dualavg",
+                                                   "slice_d100_nostepout", "slice_d20_stepout")]
 
 
 @pytest.mark.parametrize("name", GROUP_FORCED)
