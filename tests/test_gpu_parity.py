@@ -703,6 +703,22 @@ def test_full_size_pair_transposed_on_sampled_chains(name, kw, nsteps, spl):
     eng.close()
 
 
+def test_pair_transposed_slice_sampler_moments():
+    """Slice sampler on layout kind 3, MvNormal(mu, sigma) with D = 20, 16,384 chains x 60 transitions from x0 ~ N(0, I): the
+    ensemble of final states has the target's mean and standard deviation (tolerance 5 standard errors, max over coordinates)."""
+    n, d = 16384, 20
+    mu = np.linspace(-1, 2, d); sg = np.linspace(0.5, 2.0, d)
+    eng = K.Engine(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.mvnormal(mu, sg), nchains=n, nsteps=60, slice_widths=2.0 * sg,
+                   monitor=0, steps_per_launch=10)
+    assert eng.layout()[0] == 3
+    eng.init_state_normal(); eng.run(60)
+    x, lt, _ = eng.state()
+    assert np.allclose(lt, -0.5 * (((x - mu) / sg) ** 2).sum(axis=1) - 0.5 * d * np.log(2 * np.pi) - np.log(sg).sum(), rtol=1e-12)
+    assert np.max(np.abs(x.mean(axis=0) - mu) / sg) < 5 / np.sqrt(n), np.max(np.abs(x.mean(axis=0) - mu) / sg)
+    assert np.max(np.abs(x.std(axis=0) / sg - 1.0)) < 5 / np.sqrt(2 * n), np.max(np.abs(x.std(axis=0) / sg - 1.0))
+    eng.close()
+
+
 def test_full_size_pair_transposed_hmc_moments():
     """65,536 chains x 100 dims on layout kind 3, HMC L=10 eps=0.1 (mixes in a few transitions): the ensemble of final
     states has the target's moments (mean 0, var 1/2 per coordinate; tolerances = 5 standard errors of 65,536 draws,
