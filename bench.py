@@ -271,9 +271,19 @@ def cpu_baseline(L):
     while time.perf_counter() - t0 < 12.0:
         job.run(chunk); steps += chunk
     dt = time.perf_counter() - t0
-    return {"value": nch * steps / dt, "unit": "transitions/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/libklara_oracle.so (C restatement, gcc -O2, OpenMP over chains, {cores} threads): "
-                      f"MALA driftstep=0.9, D=100, {nch} chains x {steps} transitions in {dt:.1f} s"}
+    out = {"value": nch * steps / dt, "unit": "transitions/s", "cores": cores, "kind": "port",
+           "sample": f"oracle/libklara_oracle.so (C restatement, gcc -O2, OpenMP over chains, {cores} threads): "
+                     f"MALA driftstep=0.9, D=100, {nch} chains x {steps} transitions in {dt:.1f} s"}
+    # the reference's own execution model is one chain after another on one thread (BasicMCJob.jl:212-244): 3 s sample
+    lib.ko_set_num_threads(1)
+    one = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=L.TARGET_GAUSS_DIAG, nchains=32, ndims=NDIMS, nsteps=10 ** 9,
+                      driftstep=0.9, want_accept=False, want_sums=False)
+    one.init_state_normal(); one.run(chunk)
+    steps1, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 3.0:
+        one.run(chunk); steps1 += chunk
+    out["single_thread_value"] = 32 * steps1 / (time.perf_counter() - t0)
+    return out
 
 
 def usable_cores():
