@@ -74,10 +74,10 @@ static bool diagt_eligible(const klara_desc& d)
     return true;
 }
 
-// layout kind 4 (klara_hiert.h): HMC on the hierarchical target, 8 lanes per chain, 4 units per lane
+// layout kind 4 (klara_hiert.h): MH / MALA / HMC on the hierarchical target, 8 lanes per chain, 4 units per lane
 static bool hiert_eligible(const klara_desc& d)
 {
-    if (d.target != KLARA_TARGET_HIER_NORMAL || d.sampler != KLARA_SAMPLER_HMC) return false;
+    if (d.target != KLARA_TARGET_HIER_NORMAL || d.sampler == KLARA_SAMPLER_SLICE) return false;
     if (d.hier_nunits < 9 || d.hier_nunits > 32 || d.hier_ntimes != 5) return false;
     if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
     if (getenv("KLARA_LAYOUT_E")) return false;
@@ -560,7 +560,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
     if (h->kind == 4) {
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;
         const bool da = d.tuner == KLARA_TUNER_DUAL_AVERAGING;
-        return klara_launch_hiert_hmc(p, kl, h->E / 2, d.hier_ntimes, mon, !plain || da, da, grid_for(h), h->stream);
+        return klara_launch_hiert(p, kl, d.sampler, h->E / 2, d.hier_ntimes, mon, !plain || da, da, grid_for(h), h->stream);
     }
     switch (d.sampler) {
     case KLARA_SAMPLER_MH: return klara_launch_mh(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);

@@ -1,4 +1,4 @@
-// klara_hiert.h — HMC on the hierarchical normal target (KLARA_TARGET_HIER_NORMAL, BUGS "Rats") with few lanes per chain
+// klara_hiert.h — HMC (and MALA, MH) on the hierarchical normal target (KLARA_TARGET_HIER_NORMAL, BUGS "Rats") with few lanes per chain
 // (layout kind 4).
 //
 // The group layout spreads a chain's D = 2R + 5 = 65 parameters over 32 lanes (17 busy) and pays the five-value
@@ -14,7 +14,8 @@
 // elements ascending, lane 0 then adds the five hyper terms), then the xor butterfly over the 8 lanes — oracle
 // ko_reduce kind 4.
 //
-// Scope: HMC with the Vanilla, AcceptanceRate (per chain or pooled per GPU) or DualAveraging tuner, any monitor; 9 <= R <= 32 units,
+// Scope: HMC, MALA and MH with the Vanilla, AcceptanceRate (per chain or pooled per GPU) or (HMC) DualAveraging tuner, any monitor;
+// 9 <= R <= 32 units,
 // T = 5 observations per unit.  Everything else stays on the group layout.
 #pragma once
 #include "klara_kernels.h"
@@ -151,12 +152,41 @@ __device__ __forceinline__ double hier_sumsq(const HierLane<RPL, NT>& c, const H
 
 // DA: DualAveragingMCTuner (iterate/HMC.jl:142-144, 225-249): per-chain step and per-chain trajectory length; the wavefront
 // runs to the longest trajectory among its 8 chains and a finished chain's lanes keep their state (selects).
-template <int RPL, int NT, bool MON, bool TUNE, bool DA = false>
+// sum over the chain's D elements of an elementwise term vector: same order as hier_sumsq
+template <int RPL, int NT>
+__device__ __forceinline__ double hier_sumvec(const HierLane<RPL, NT>& c, const HierVec<RPL>& tv)
+{
+    double s[1] = { 0.0 };
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) { s[0] = s[0] + tv.a[k]; s[0] = s[0] + tv.b[k]; }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[0] = s[0] + (c.q == 0 ? tv.h[k] : 0.0);
+    group_allreduce<1>(s, KLARA_HIERT_Q, c.lane);
+    return s[0];
+}
+
+// a per-element host vector of length D (proposal scales) as this lane sees it
+template <int RPL, int NT>
+__device__ __forceinline__ void hload_param(const HierLane<RPL, NT>& c, const gdouble* base, double dflt, HierVec<RPL>& v)
+{
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+        const int r = RPL * c.q + k;
+        v.a[k] = (base != nullptr && c.rv[k]) ? base[2 * r] : dflt;
+        v.b[k] = (base != nullptr && c.rv[k]) ? base[2 * r + 1] : dflt;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v.h[k] = base != nullptr ? base[2 * c.R + k] : dflt;
+}
+
+template <int SAMPLER, int RPL, int NT, bool MON, bool TUNE, bool DA = false>
 __global__ __launch_bounds__(256, 2)
-void k_hiert_hmc(const KParams* __restrict__ pp, const KLaunch kl)
+void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
 {
     constexpr int Q = KLARA_HIERT_Q, CPW = 64 / Q;
-    static_assert(!DA || TUNE, "dual averaging is a tuned instantiation");
+    static_assert(!DA || (TUNE && SAMPLER == KLARA_SAMPLER_HMC), "dual averaging is a tuned HMC instantiation");
+    static_assert(SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_HMC, "sampler");
+    constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;
     constexpr bool PLAIN = !TUNE;
     const KParams& p = *pp;
     kd_tables_to_lds();
@@ -175,9 +205,10 @@ void k_hiert_hmc(const KParams* __restrict__ pp, const KLaunch kl)
     const __amdgpu_buffer_rsrc_t wx = group_window(p.X, first_chain, here, D);
     const __amdgpu_buffer_rsrc_t wg = group_window(p.GR, first_chain, here, D);
 
-    HierVec<RPL> x, g;
+    HierVec<RPL> x, g, sig;
     hload<RPL, NT>(cx, wx, x);
-    hload<RPL, NT>(cx, wg, g);
+    if (NEEDG) hload<RPL, NT>(cx, wg, g);
+    if (SAMPLER == KLARA_SAMPLER_MH) hload_param<RPL, NT>(cx, p.vecparam, 1.0, sig);
     const long long c0 = chain_ok ? chain : 0;
     double lt = p.LT[c0];
     unsigned long long nacc = 0;
@@ -217,55 +248,104 @@ void k_hiert_hmc(const KParams* __restrict__ pp, const KLaunch kl)
             kd_normal_pair(kd_stream_block(p.seed, gchain, t, (uint32_t)(R + 2)), &z0, &z1);
             mom.h[4] = z0;
         }
-        const double H0 = lt - 0.5 * hier_sumsq<RPL, NT>(cx, mom);                     // :137
-        HierVec<RPL> xp = x, gp = g;                                                  // :139-140
-        const double eps = tn.step, halfe = 0.5 * eps;
-        const int nl = DA ? da_nleaps(p, eps) : p.nleaps;                             // iterate/HMC.jl:142-144
-        for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {                         // :146-155, samplers.jl:122-134
-            const bool go = !DA || l < nl;                                            // (a finished chain keeps its state)
+        HierVec<RPL> xp, gp;
+        double ltp, a = 0.0;
+        bool acc;
+        if (SAMPLER == KLARA_SAMPLER_HMC) {
+            const double H0 = lt - 0.5 * hier_sumsq<RPL, NT>(cx, mom);                     // :137
+            xp = x; gp = g;                                                               // :139-140
+            const double eps = tn.step, halfe = 0.5 * eps;
+            const int nl = DA ? da_nleaps(p, eps) : p.nleaps;                             // iterate/HMC.jl:142-144
+            for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {                         // :146-155, samplers.jl:122-134
+                const bool go = !DA || l < nl;                                            // (a finished chain keeps its state)
+    #pragma unroll
+                for (int k = 0; k < RPL; ++k) {
+                    const double ma = mom.a[k] + halfe * gp.a[k], mb = mom.b[k] + halfe * gp.b[k];
+                    mom.a[k] = go ? ma : mom.a[k]; mom.b[k] = go ? mb : mom.b[k];
+                    const double xa = xp.a[k] + eps * mom.a[k], xb = xp.b[k] + eps * mom.b[k];
+                    xp.a[k] = go ? xa : xp.a[k]; xp.b[k] = go ? xb : xp.b[k];
+                }
+    #pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const double mh = mom.h[k] + halfe * gp.h[k];
+                    mom.h[k] = go ? mh : mom.h[k];
+                    const double xh = xp.h[k] + eps * mom.h[k];
+                    xp.h[k] = go ? xh : xp.h[k];
+                }
+                HierVec<RPL> gn;
+                (void)hier_eval<RPL, NT, false, true>(cx, xp, gn);
+    #pragma unroll
+                for (int k = 0; k < RPL; ++k) {
+                    gp.a[k] = go ? gn.a[k] : gp.a[k]; gp.b[k] = go ? gn.b[k] : gp.b[k];
+                    const double ma = mom.a[k] + halfe * gp.a[k], mb = mom.b[k] + halfe * gp.b[k];
+                    mom.a[k] = go ? ma : mom.a[k]; mom.b[k] = go ? mb : mom.b[k];
+                }
+    #pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    gp.h[k] = go ? gn.h[k] : gp.h[k];
+                    const double mh = mom.h[k] + halfe * gp.h[k];
+                    mom.h[k] = go ? mh : mom.h[k];
+                }
+            }
+            HierVec<RPL> gdummy;
+            ltp = hier_eval<RPL, NT, true, false>(cx, xp, gdummy);                        // :157
+            const double H1 = ltp - 0.5 * hier_sumsq<RPL, NT>(cx, mom);                   // :159
+            const double ratio = H1 - H0;                                                 // :161
+            const double ex = kd_exp(ratio);
+            a = 1.0 < ex ? 1.0 : ex;                                                      // :163
+            const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((D + 1) >> 1)));
+            acc = u < a;                                                                  // :165
+        } else if (SAMPLER == KLARA_SAMPLER_MALA) {                                   // iterate/MALA.jl:78-128 (mom holds z)
+            const double h_ = tn.step, halfh = 0.5 * h_, sqh = KCNT ? __builtin_sqrt(h_) : p.sqrt_step0;
+            const double half_inv_h = 0.5 * (KCNT ? 1.0 / h_ : p.inv_step0);
+            HierVec<RPL> mu_, t1, t2;
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
-                const double ma = mom.a[k] + halfe * gp.a[k], mb = mom.b[k] + halfe * gp.b[k];
-                mom.a[k] = go ? ma : mom.a[k]; mom.b[k] = go ? mb : mom.b[k];
-                const double xa = xp.a[k] + eps * mom.a[k], xb = xp.b[k] + eps * mom.b[k];
-                xp.a[k] = go ? xa : xp.a[k]; xp.b[k] = go ? xb : xp.b[k];
+                mu_.a[k] = x.a[k] + halfh * g.a[k]; mu_.b[k] = x.b[k] + halfh * g.b[k];         // :83
+                xp.a[k] = mu_.a[k] + sqh * mom.a[k]; xp.b[k] = mu_.b[k] + sqh * mom.b[k];       // :84
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { mu_.h[k] = x.h[k] + halfh * g.h[k]; xp.h[k] = mu_.h[k] + sqh * mom.h[k]; }
+            ltp = hier_eval<RPL, NT, true, true>(cx, xp, gp);                                  // :86
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) {
+                const double qa = mu_.a[k] - xp.a[k], qb = mu_.b[k] - xp.b[k];
+                t1.a[k] = (qa * qa) * half_inv_h; t1.b[k] = (qb * qb) * half_inv_h;             // :90
+                const double ma = xp.a[k] + halfh * gp.a[k], mb = xp.b[k] + halfh * gp.b[k];    // :91
+                const double ra = ma - x.a[k], rb = mb - x.b[k];
+                t2.a[k] = (ra * ra) * half_inv_h; t2.b[k] = (rb * rb) * half_inv_h;             // :92
             }
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                const double mh = mom.h[k] + halfe * gp.h[k];
-                mom.h[k] = go ? mh : mom.h[k];
-                const double xh = xp.h[k] + eps * mom.h[k];
-                xp.h[k] = go ? xh : xp.h[k];
+                const double qh = mu_.h[k] - xp.h[k];
+                t1.h[k] = (qh * qh) * half_inv_h;
+                const double mh = xp.h[k] + halfh * gp.h[k];
+                const double rh = mh - x.h[k];
+                t2.h[k] = (rh * rh) * half_inv_h;
             }
-            HierVec<RPL> gn;
-            (void)hier_eval<RPL, NT, false, true>(cx, xp, gn);
+            double ratio = ltp - lt;                                                           // :88
+            ratio += hier_sumvec<RPL, NT>(cx, t1);                                             // :90
+            ratio -= hier_sumvec<RPL, NT>(cx, t2);                                             // :92
+            acc = ratio > 0.0;                                                                 // :94
+            if (!acc && ratio > KD_LOG_UMIN_GUARD)
+                acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((D + 1) >> 1))));
+        } else {                                                                       // iterate/MH.jl:72-124 (mom holds z)
 #pragma unroll
-            for (int k = 0; k < RPL; ++k) {
-                gp.a[k] = go ? gn.a[k] : gp.a[k]; gp.b[k] = go ? gn.b[k] : gp.b[k];
-                const double ma = mom.a[k] + halfe * gp.a[k], mb = mom.b[k] + halfe * gp.b[k];
-                mom.a[k] = go ? ma : mom.a[k]; mom.b[k] = go ? mb : mom.b[k];
-            }
+            for (int k = 0; k < RPL; ++k) { xp.a[k] = x.a[k] + sig.a[k] * mom.a[k]; xp.b[k] = x.b[k] + sig.b[k] * mom.b[k]; }   // :79
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                gp.h[k] = go ? gn.h[k] : gp.h[k];
-                const double mh = mom.h[k] + halfe * gp.h[k];
-                mom.h[k] = go ? mh : mom.h[k];
-            }
+            for (int k = 0; k < 5; ++k) xp.h[k] = x.h[k] + sig.h[k] * mom.h[k];
+            ltp = hier_eval<RPL, NT, true, false>(cx, xp, gp);                                 // :81
+            const double ratio = ltp - lt;                                                     // :83
+            acc = ratio > 0.0;                                                                 // :97
+            if (!acc && ratio > KD_LOG_UMIN_GUARD)
+                acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((D + 1) >> 1))));
         }
-        HierVec<RPL> gdummy;
-        const double ltp = hier_eval<RPL, NT, true, false>(cx, xp, gdummy);           // :157
-        const double H1 = ltp - 0.5 * hier_sumsq<RPL, NT>(cx, mom);                   // :159
-        const double ratio = H1 - H0;                                                 // :161
-        const double ex = kd_exp(ratio);
-        const double a = 1.0 < ex ? 1.0 : ex;                                         // :163
-        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((D + 1) >> 1)));
-        const bool acc = u < a;                                                       // :165
-        if (acc) { x = xp; g = gp; lt = ltp; }                                        // :166-176
+        if (acc) { x = xp; if (NEEDG) g = gp; lt = ltp; }                             // commit (HMC.jl:166-176, MALA.jl:95-105, MH.jl:98-100)
         nacc += acc ? 1ull : 0ull;
         if (accept_out != nullptr && chain_ok && cx.q == 0) accept_out[(long long)s * p.nchains + chain] = acc ? 1 : 0;
         if (KCNT && acc) tn.accepted += 1;
         if (DA) da_update(p, tn, (long long)t + 1, a);                                // iterate/HMC.jl:225-249
-        if (per_chain_tune && !DA) tuning_block(p, tn);                               // iterate/HMC.jl:203-224
+        if (per_chain_tune && !DA) tuning_block(p, tn);                               // iterate/HMC.jl:203-224, MALA.jl:130-152
         else if (DA && per_chain_tune && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {   // verbose report block, :229-243
             tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
         }
@@ -285,7 +365,7 @@ void k_hiert_hmc(const KParams* __restrict__ pp, const KLaunch kl)
                 if (scol < p.hist_cols) {
                     const long long col0 = scol * p.nchains + first_chain;
                     if (p.hist != nullptr) hstore<RPL, NT>(cx, group_window(p.hist, col0, here, D), x);
-                    if (p.hist_g != nullptr) hstore<RPL, NT>(cx, group_window(p.hist_g, col0, here, D), g);
+                    if (NEEDG && p.hist_g != nullptr) hstore<RPL, NT>(cx, group_window(p.hist_g, col0, here, D), g);
                     if (p.hist_lt != nullptr && chain_ok && cx.q == 0) p.hist_lt[scol * p.nchains + chain] = lt;
                 }
                 ++scol;
@@ -299,7 +379,7 @@ void k_hiert_hmc(const KParams* __restrict__ pp, const KLaunch kl)
     }
     if (nacc != 0) {
         hstore<RPL, NT>(cx, wx, x);
-        hstore<RPL, NT>(cx, wg, g);
+        if (NEEDG) hstore<RPL, NT>(cx, wg, g);
         if (chain_ok && cx.q == 0) { p.LT[chain] = lt; p.naccept[chain] += nacc; }
     }
     if (TUNE && chain_ok && cx.q == 0) {

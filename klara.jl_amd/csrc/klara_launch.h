@@ -63,8 +63,9 @@ hipError_t klara_launch_diagt_init(const KParams& p, int NP, int needgrad, dim3 
         return hipGetLastError();                                                                                  \
     } while (0)
 
-// HMC on the hierarchical target, 8 lanes per chain (layout kind 4, klara_hiert.h); RPL = 4 units per lane, NT = 5
-hipError_t klara_launch_hiert_hmc(const KParams* p, const KLaunch& kl, int RPL, int NT, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
+// MH / MALA / HMC on the hierarchical target, 8 lanes per chain (layout kind 4, klara_hiert.h); RPL = 4 units per lane, NT = 5
+hipError_t klara_launch_hiert(const KParams* p, const KLaunch& kl, int sampler, int RPL, int NT, bool mon, bool tune, bool da, dim3 grid,
+                              hipStream_t st);
 hipError_t klara_launch_hiert_init(const KParams& p, int RPL, int NT, int needgrad, dim3 grid, hipStream_t st);
 
 // mode 7: mode 3 with exactly one transition per launch; mode 3: nothing counts/tunes and nothing is monitored;

@@ -166,6 +166,15 @@ def make_case(name):
     elif name == "slice_d100_nostepout":
         c = dict(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.negdot(100), nchains=6, nsteps=4, burnin=0,
                  slice_widths=np.full(100, 3.0), slice_stepout=False)
+    elif name == "mh_rats":            # MH on the hierarchical model (per-element proposal scales), few-lanes layout
+        t = rats_target()
+        x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(9).standard_normal((29, t.ndims))
+        c = dict(sampler=L.SAMPLER_MH, target=t, nchains=29, nsteps=40, burnin=5, mh_sigma=np.linspace(0.02, 0.2, t.ndims), x0=x0)
+    elif name == "mala_rats_tuned":    # AcceptanceRate per chain on the few-lanes layout
+        t = rats_target()
+        x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(10).standard_normal((21, t.ndims))
+        c = dict(sampler=L.SAMPLER_MALA, target=t, nchains=21, nsteps=60, burnin=40, driftstep=2e-3, tuner=L.TUNER_ACCEPT_RATE,
+                 targetrate=0.574, period=10, x0=x0)
     elif name == "slice_d20_stepout":  # pair-transposed layout: step-out and shrink loops with per-chain trip counts, non-unit diagonal
         c = dict(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 2, 20), np.linspace(0.5, 3.0, 20)), nchains=37,
                  nsteps=8, burnin=2, slice_widths=np.linspace(0.2, 4.0, 20))
@@ -220,7 +229,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_rats_dualavg", "mala_d3_tuned_erf", "mala_d1", "hmc_d128_full", "mala_d129", "mh_d512",
              "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg",
              "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
-             "slice_d20_stepout"]
+             "slice_d20_stepout", "mh_rats", "mala_rats_tuned"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",

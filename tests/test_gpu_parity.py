@@ -370,7 +370,7 @@ def test_pair_transposed_layout_is_optional():
 GROUP_FORCED = [n for n in cases.ALL_CASES if n in ("mh_d100", "mala_d100", "mala_d100_small_step", "hmc_d100", "hmc_d128_full",
                                                    "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose",
                                                    "hmc_rats", "hmc_rats_pooled", "hmc_rats_dualavg", "hmc_d40_dualavg", "hmc_d100_dualavg",
-                                                   "slice_d100_nostepout", "slice_d20_stepout")]
+                                                   "slice_d100_nostepout", "slice_d20_stepout", "mala_rats", "mh_rats", "mala_rats_tuned")]
 
 
 @pytest.mark.parametrize("name", GROUP_FORCED)
