@@ -68,7 +68,7 @@ static bool diagt_eligible(const klara_desc& d)
 {
     if (d.target != KLARA_TARGET_GAUSS_DIAG) return false;
     // (D <= 16: the group layout already puts a chain on <= 4 lanes, 16..64 chains per wavefront)
-    if ((d.ndims & 1) || d.ndims < 18 || d.ndims > 2 * KLARA_DIAGT_Q * KLARA_DIAGT_NP_MAX) return false;
+    if (d.ndims < 17 || d.ndims > 2 * KLARA_DIAGT_Q * KLARA_DIAGT_NP_MAX) return false;
     if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
     if (getenv("KLARA_LAYOUT_E")) return false;
     return true;

@@ -11,8 +11,9 @@
 // reduction tree is 3 DPP steps instead of 5, and 89% instead of 78% of the lane slots hold real elements.
 //
 // Scope: every tuner (Vanilla — the jobs the throughput figures are quoted on —, AcceptanceRate per chain or pooled,
-// DualAveraging for HMC); MH, MALA, HMC and the slice sampler; any monitor
-// (accept mask, running sums, value / logtarget / gradlogtarget history); D even, 18 <= D <= 16*NP.  Everything else runs on
+// DualAveraging for HMC); MH, MALA, HMC and the slice sampler; any monitor; 17 <= D <= 16*NP (odd D: the pair holding the last
+// element has no second element)
+// (accept mask, running sums, value / logtarget / gradlogtarget history).  Everything else runs on
 // the group layout (klara_kernels.h).
 // Sums are taken per lane in ascending element order and then over the Q lanes by an xor butterfly — the oracle mirrors
 // this order for layout kind 3 (oracle/klara_oracle.c ko_reduce).
@@ -43,6 +44,7 @@ struct PairCtx {
     int lane, q, cw;        // lane in the wavefront, lane within the chain, chain within the wavefront
     unsigned off0;          // byte offset of pair p = 0 inside the wavefront's chain window; pair p adds p*Q*16
     bool last_ok;           // the last pair (p = NP-1) holds real elements (all earlier pairs always do)
+    bool last_full;         // ... both of them (odd D: the pair that holds element D-1 has no second element)
 };
 
 template <int NP, int Q>
@@ -54,6 +56,7 @@ __device__ __forceinline__ PairCtx<NP, Q> make_pctx(int D)
     c.cw = c.lane / Q;
     c.off0 = (unsigned)((c.cw * D + 2 * c.q) * 8);
     c.last_ok = 2 * ((NP - 1) * Q + c.q) < D;
+    c.last_full = 2 * ((NP - 1) * Q + c.q) + 1 < D;
     return c;
 }
 template <int NP, int Q>
@@ -70,6 +73,7 @@ __device__ __forceinline__ void load_pairs(const PairCtx<NP, Q>& c, __amdgpu_buf
         const kd_uint4 t = __builtin_amdgcn_raw_buffer_load_b128(w, pair_off<NP, Q>(c, p), 0, 0);
         v[2 * p] = __builtin_bit_cast(double, kd_uint2{ t.x, t.y });
         v[2 * p + 1] = __builtin_bit_cast(double, kd_uint2{ t.z, t.w });
+        if (p == NP - 1 && !c.last_full) v[2 * p + 1] = 0.0;     // (odd D: those 8 bytes belong to the next chain)
     }
 }
 template <int NP, int Q>
@@ -78,7 +82,13 @@ __device__ __forceinline__ void store_pairs(const PairCtx<NP, Q>& c, __amdgpu_bu
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const kd_uint2 a = __builtin_bit_cast(kd_uint2, v[2 * p]), b = __builtin_bit_cast(kd_uint2, v[2 * p + 1]);
-        __builtin_amdgcn_raw_buffer_store_b128(kd_uint4{ a.x, a.y, b.x, b.y }, w, pair_off<NP, Q>(c, p), 0, 0);
+        if (p < NP - 1) {
+            __builtin_amdgcn_raw_buffer_store_b128(kd_uint4{ a.x, a.y, b.x, b.y }, w, pair_off<NP, Q>(c, p), 0, 0);
+        } else {                                                 // the last pair may be half a pair (odd D): two 8-byte stores
+            const unsigned o = pair_off<NP, Q>(c, p);
+            __builtin_amdgcn_raw_buffer_store_b64(a, w, o, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(b, w, c.last_full ? o + 8u : KLARA_BUF_OOB, 0, 0);
+        }
     }
 }
 // per-element parameter vector (weights, means, proposal scales): element 2P+h of the lane's pair p
@@ -89,7 +99,8 @@ __device__ __forceinline__ void load_pair_param(const PairCtx<NP, Q>& c, const g
     for (int p = 0; p < NP; ++p) {
         const int i = 2 * (p * Q + c.q);
         v[2 * p] = dflt; v[2 * p + 1] = dflt;
-        if (base != nullptr && i < D) { v[2 * p] = base[i]; v[2 * p + 1] = base[i + 1]; }
+        if (base != nullptr && i < D) v[2 * p] = base[i];
+        if (base != nullptr && i + 1 < D) v[2 * p + 1] = base[i + 1];
     }
 }
 
@@ -101,7 +112,8 @@ __device__ __forceinline__ void pair_normals(const PairCtx<NP, Q>& c, unsigned l
                                              unsigned long long t, int p, double& z0, double& z1, double& u1, double& lg1)
 {
     kd_normal_pair_ex(kd_stream_block(seed, gchain, t, (uint32_t)(p * Q + c.q)), &z0, &z1, &u1, &lg1);
-    if (p == NP - 1 && !c.last_ok) { z0 = 0.0; z1 = 0.0; }
+    if (p == NP - 1 && !c.last_ok) z0 = 0.0;
+    if (p == NP - 1 && !c.last_full) z1 = 0.0;
 }
 
 // The diagonal target on one element (klara_kernels.h DiagTarget, same operations in the same order).  UNITW: w = 1 and

@@ -74,7 +74,7 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     d = int(ndims)
     plain = sampler is not None      # (name kept from when the layout excluded tuned jobs)
     if (target_kind == L.TARGET_GAUSS_DIAG and sampler is not None and plain
-            and d % 2 == 0 and 18 <= d <= 2 * DIAGT_Q * DIAGT_NP_MENU[-1] and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0"):
+            and 17 <= d <= 2 * DIAGT_Q * DIAGT_NP_MENU[-1] and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0"):
         np_ = next(v for v in DIAGT_NP_MENU if v >= (d + 2 * DIAGT_Q - 1) // (2 * DIAGT_Q))
         return (3, DIAGT_Q, 2 * np_)
     if (target_kind == L.TARGET_HIER_NORMAL and sampler in (L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC)

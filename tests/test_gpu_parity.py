@@ -210,13 +210,14 @@ def test_group_layout_dimension_sweep():
         del os.environ["KLARA_LAYOUT_KIND"]
 
 
-@pytest.mark.parametrize("sampler,kw,step", [(L.SAMPLER_MALA, dict(driftstep=0.3), 2), (L.SAMPLER_HMC, dict(leapstep=0.2, nleaps=3), 6),
-                                             (L.SAMPLER_MH, None, 6)])
+@pytest.mark.parametrize("sampler,kw,step", [(L.SAMPLER_MALA, dict(driftstep=0.3), 1), (L.SAMPLER_HMC, dict(leapstep=0.2, nleaps=3), 3),
+                                             (L.SAMPLER_MH, None, 3), (L.SAMPLER_SLICE, "slice", 7)])
 def test_pair_transposed_dimension_sweep(sampler, kw, step):
-    """Even dimensions 18..128 on the pair-transposed layout (every one for MALA, every third for HMC and MH): with and
-    without padding pairs, i.e. both ways of obtaining the accept draw."""
-    for d in range(18, 130, step):
-        skw = kw if kw is not None else dict(mh_sigma=np.full(d, 0.2))
+    """Dimensions 17..128, odd ones included, on the pair-transposed layout (every one for MALA, every third for HMC and MH,
+    every seventh for the slice sampler): with and without padding pairs / a half pair, i.e. every way of obtaining the
+    accept draw and of storing the last pair."""
+    for d in range(17, 129, step):
+        skw = dict(slice_widths=np.full(d, 1.5)) if kw == "slice" else (kw if kw is not None else dict(mh_sigma=np.full(d, 0.2)))
         case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=11,
                     nsteps=6, burnin=0, x0=None, seed=d, name=f"sweep3_d{d}", **skw)
         eng, job = _run_pair(case, spl=2)
@@ -261,7 +262,7 @@ def test_pair_transposed_every_pairs_per_lane(d, sampler):
     case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=13, nsteps=12,
                 burnin=2, x0=None, seed=5, name=f"np_d{d}", **kw)
     eng, job = _run_pair(case, splits=[5, 7], spl=3)
-    assert eng.layout()[0] == 3 and eng.layout()[2] == 2 * ((d + 15) // 16)
+    assert eng.layout()[0] == 3 and eng.layout()[2] == 2 * ((d + 15) // 16)      # NP = ceil(ceil(d/2)/8)
     _assert_same(eng, job, case)
     eng.close()
 
@@ -345,7 +346,7 @@ def test_layout_choice_matches_its_mirror():
 
 
 def test_pair_transposed_layout_is_optional():
-    """Odd D, D < 18 or D > 128 keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
+    """D < 17 or D > 128 keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
     case = cases.make_case("dt_mala_d100")
     e = K.Engine(**cases.engine_kwargs(case)); assert e.layout()[0] == 3; e.close()                  # any monitor
     e = K.Engine(**cases.engine_kwargs(case, monitor=0)); assert e.layout()[0] == 3; e.close()
@@ -354,6 +355,7 @@ def test_pair_transposed_layout_is_optional():
     e = K.Engine(**cases.engine_kwargs(dict(case, sampler=L.SAMPLER_HMC), monitor=0, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=10))
     assert e.layout()[0] == 3; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d129"), monitor=0)); assert e.layout()[0] == 0; e.close()
+    e = K.Engine(**cases.engine_kwargs(cases.make_case("mh_mvnormal_d7"), monitor=0)); assert e.layout()[0] == 0; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d300"), monitor=0)); assert e.layout()[0] == 0; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("slice_d100_nostepout"), monitor=0)); assert e.layout()[0] == 3; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("slice_d5"), monitor=0)); assert e.layout()[0] == 0; e.close()
