@@ -213,6 +213,10 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         (desc->sampler == KLARA_SAMPLER_SLICE || desc->gauss_mu != nullptr))
         return KLARA_ERR_UNSUPPORTED;
     if (desc->tuner_mode == KLARA_TUNE_POOLED && desc->sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
+    // the logistic kernels keep the data rows in LDS next to the 8 KB of math tables, inside the 64 KB a launch gets
+    // without raising the per-kernel limit: ndata * (D + 1) doubles <= 56 KB (swiss: 200 x 5 doubles = 8 KB)
+    if (desc->target == KLARA_TARGET_LOGISTIC && (size_t)desc->logit_ndata * (size_t)(desc->ndims + 1) > 7168u)
+        return KLARA_ERR_UNSUPPORTED;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || desc->device < 0 || desc->device >= ndev)

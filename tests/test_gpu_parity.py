@@ -516,6 +516,17 @@ def test_error_paths():
         with pytest.raises(K.KlaraError) as ei:
             K.Engine(nchains=4, nsteps=5, **kw)
         assert ei.value.status == L.ERR_UNSUPPORTED
+    rng = np.random.default_rng(3)
+    for ndata, ok in ((1433, True), (1434, False)):            # logistic data rows live in LDS: ndata * (D + 1) <= 7168 doubles
+        tgt = K.LogisticTarget(rng.standard_normal((ndata, 4)), (rng.random(ndata) < 0.5).astype(float))
+        if ok:
+            with K.Engine(sampler=L.SAMPLER_MALA, target=tgt, nchains=8, nsteps=2, driftstep=0.01) as e:
+                e.set_state(np.zeros((8, 4))); e.run(2)
+                assert np.isfinite(e.state()[1]).all()
+        else:
+            with pytest.raises(K.KlaraError) as ei:
+                K.Engine(sampler=L.SAMPLER_MALA, target=tgt, nchains=8, nsteps=2, driftstep=0.01)
+            assert ei.value.status == L.ERR_UNSUPPORTED
     with pytest.raises(K.KlaraError) as ei:                    # gradient history needs a gradient-carrying sampler
         K.Engine(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(2), nchains=4, nsteps=5, mh_sigma=[1.0, 1.0],
                  monitor=L.MON_HIST_GRAD)
