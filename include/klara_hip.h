@@ -24,13 +24,15 @@
 #ifndef KLARA_HIP_H
 #define KLARA_HIP_H
 
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define KLARA_ABI_VERSION 1
+#define KLARA_ABI_VERSION 2
 
 typedef enum klara_status {
     KLARA_OK = 0,
@@ -40,7 +42,8 @@ typedef enum klara_status {
     KLARA_ERR_NOMEM = 4,
     KLARA_ERR_UNSUPPORTED = 5,     /* valid Klara option that this build does not cover (see DESIGN)  */
     KLARA_ERR_STATE = 6,           /* call order (e.g. run before set_state)                          */
-    KLARA_ERR_SLICE_STUCK = 7      /* iterate/SliceSampler.jl:102 "Shrunk to current position ..."   */
+    KLARA_ERR_SLICE_STUCK = 7,     /* iterate/SliceSampler.jl:102 "Shrunk to current position ..."   */
+    KLARA_ERR_COMPILE = 8          /* CUSTOM target: the user's source did not compile (klara_compile_log) */
 } klara_status;
 
 /* src/samplers/{MH,MALA,HMC,SliceSampler}.jl */
@@ -69,7 +72,18 @@ typedef enum klara_target {
      * beta_i ~ N(beta_c, sigma_b^2),  alpha_c, beta_c ~ N(0, 1/prior_prec),  1/sigma_k^2 ~ Gamma(a, b),
      * sampled in theta = (alpha_1, beta_1, ..., alpha_R, beta_R, alpha_c, beta_c, log sigma_c, log sigma_a,
      * log sigma_b), D = 2R + 5 (65 for the 30 rats).  See DESIGN.md for the log-density. */
-    KLARA_TARGET_HIER_NORMAL = 3
+    KLARA_TARGET_HIER_NORMAL = 3,
+    /* User-defined target — the device form of BasicContMuvParameter(:p, logtarget=f, gradlogtarget=g)
+     * (BasicContMuvParameter.jl:174-201,264-279; uptogradlogtarget! = logtarget!; gradlogtarget!, :270-274).
+     * klara_desc.custom_src is source text in the C subset accepted by hipcc and by a host C compiler; it defines
+     *   KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata);
+     *   KLARA_USER_FN void   klara_user_gradlogtarget(const double* x, int D, const double* data, long long ndata,
+     *                                                 double* g);           (needed by MALA / HMC only)
+     * and is compiled for gfx950 at klara_create (hiprtc) into the group-layout transition kernels, one chain per lane
+     * (D <= 32, the whole vector in registers; KLARA_D is predefined to D so that loops unroll).  kd_exp, kd_log,
+     * kd_fma, kd_erf (klara.jl_amd/csrc/detmath.h) and IEEE + - * / sqrt give the same bits on host and device;
+     * `data` is custom_data (custom_ndata doubles, copied to the device at create). */
+    KLARA_TARGET_CUSTOM = 4
 } klara_target;
 
 /* src/tuners/{VanillaMCTuner,AcceptanceRateMCTuner}.jl */
@@ -153,6 +167,9 @@ typedef struct klara_desc {
     double   hier_prior_prec;    /* precision of the N(0, .) priors on alpha_c, beta_c               */
     double   hier_gamma_a;       /* Gamma(a, b) prior on the three precisions                        */
     double   hier_gamma_b;
+    const char*   custom_src;    /* CUSTOM: NUL-terminated source text (see KLARA_TARGET_CUSTOM)     */
+    const double* custom_data;   /* CUSTOM: read-only data block handed to the user functions, or NULL */
+    int64_t  custom_ndata;       /* CUSTOM: doubles in custom_data                                   */
 
     uint64_t seed;               /* Philox key                                                       */
     uint32_t monitor;            /* KLARA_MON_* bits                                                 */
@@ -276,6 +293,13 @@ klara_status klara_selftest_mfma_f64(int32_t device, const double* A, const doub
  * kernel's 4-row tail tile relies on (klara_dense.h). */
 klara_status klara_selftest_mfma_f64_4x4x4(int32_t device, const double* A, const double* B, const double* C,
                                            double* D);
+
+/* CUSTOM target: compile `src` for gfx950 exactly as klara_create would for this sampler and dimension, without creating
+ * a handle and without needing a GPU (a user checks a closure before submitting a job).  KLARA_OK or KLARA_ERR_COMPILE. */
+klara_status klara_check_custom_target(const char* src, int32_t sampler, int32_t ndims);
+/* Compiler output of the calling thread's last klara_create / klara_check_custom_target that compiled a CUSTOM target
+ * ("" if none); valid until the thread's next such call. */
+const char* klara_compile_log(void);
 
 const char* klara_strerror(klara_status s);
 int32_t klara_abi_version(void);

@@ -5,7 +5,7 @@ The package directory is `klara.jl_amd/` (not importable by that name); import i
 """
 from . import _lib  # noqa: F401
 from ._lib import KlaraError  # noqa: F401
-from .engine import Engine, GaussDenseTarget, GaussDiagTarget, HierNormalTarget, LogisticTarget  # noqa: F401
+from .engine import CustomTarget, Engine, GaussDenseTarget, GaussDiagTarget, HierNormalTarget, LogisticTarget  # noqa: F401
 from .api import (  # noqa: F401
     HMC, MALA, MH, AcceptanceRateMCTuner, DualAveragingMCTuner, BasicContMuvParameter, BasicMCJob, BasicMCRange, GenericModel,
     MuvChains, SliceSampler, VanillaMCTuner, acceptance, chain_ess, chain_iact, chain_mcvar, erf_rate_score, likelihood_model, logistic, logistic_rate_score,

@@ -13,14 +13,14 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libklara_hip.so"
 
-KLARA_ABI_VERSION = 1
+KLARA_ABI_VERSION = 2
 
 # klara_status
-OK, ERR_INVALID_ARG, ERR_NONFINITE_INIT, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_STATE, ERR_SLICE_STUCK = range(8)
+OK, ERR_INVALID_ARG, ERR_NONFINITE_INIT, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_STATE, ERR_SLICE_STUCK, ERR_COMPILE = range(9)
 # klara_sampler
 SAMPLER_MH, SAMPLER_MALA, SAMPLER_HMC, SAMPLER_SLICE = range(4)
 # klara_target
-TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET_HIER_NORMAL = range(4)
+TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET_HIER_NORMAL, TARGET_CUSTOM = range(5)
 # klara_tuner / mode
 TUNER_VANILLA, TUNER_ACCEPT_RATE, TUNER_DUAL_AVERAGING = 0, 1, 2
 TUNE_PER_CHAIN, TUNE_POOLED = 0, 1
@@ -47,6 +47,7 @@ class KlaraDesc(C.Structure):
         ("logit_lambda", C.c_double),
         ("hier_Y", _dp), ("hier_xc", _dp), ("hier_nunits", C.c_int32), ("hier_ntimes", C.c_int32),
         ("hier_prior_prec", C.c_double), ("hier_gamma_a", C.c_double), ("hier_gamma_b", C.c_double),
+        ("custom_src", C.c_char_p), ("custom_data", _dp), ("custom_ndata", C.c_int64),
         ("seed", C.c_uint64), ("monitor", C.c_uint32), ("steps_per_launch", C.c_int32),
         ("stream", C.c_void_p),
     ]
@@ -56,7 +57,13 @@ class KlaraError(RuntimeError):
     def __init__(self, status: int, where: str):
         self.status = int(status)
         msg = _strerror(status)
-        super().__init__(f"{where}: klara_status {int(status)} ({msg})")
+        self.log = ""
+        if self.status == ERR_COMPILE:                 # the compiler's message for a user-defined target
+            try:
+                self.log = load().klara_compile_log().decode(errors="replace")
+            except Exception:
+                pass
+        super().__init__(f"{where}: klara_status {int(status)} ({msg})" + (("\n" + self.log) if self.log else ""))
 
 
 # every symbol include/klara_hip.h declares (tests check the .so exports all of them)
@@ -67,7 +74,7 @@ EXPORTS = [
     "klara_get_chain_fields", "klara_get_chain_mcvar", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
     "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
     "klara_comm_unique_id", "klara_comm_init", "klara_comm_destroy", "klara_gather_summaries",
-    "klara_abi_version",
+    "klara_check_custom_target", "klara_compile_log", "klara_abi_version",
 ]
 
 _lib = None
@@ -117,6 +124,7 @@ def load() -> C.CDLL:
         "klara_comm_destroy": [C.c_void_p],
         "klara_gather_summaries": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+        "klara_check_custom_target": [C.c_char_p, C.c_int32, C.c_int32],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -124,6 +132,8 @@ def load() -> C.CDLL:
         fn.restype = C.c_int
     lib.klara_strerror.argtypes = [C.c_int]
     lib.klara_strerror.restype = C.c_char_p
+    lib.klara_compile_log.argtypes = []
+    lib.klara_compile_log.restype = C.c_char_p
     lib.klara_abi_version.argtypes = []
     lib.klara_abi_version.restype = C.c_int32
     if lib.klara_abi_version() != KLARA_ABI_VERSION:

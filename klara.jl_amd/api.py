@@ -25,7 +25,7 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 
 from . import _lib as L
-from .engine import Engine, GaussDenseTarget, GaussDiagTarget, HierNormalTarget, LogisticTarget
+from .engine import CustomTarget, Engine, GaussDenseTarget, GaussDiagTarget, HierNormalTarget, LogisticTarget
 
 
 # ------------------------------------------------------------------ range (src/ranges/BasicMCRange.jl)
@@ -174,8 +174,8 @@ class BasicContMuvParameter:
             raise ValueError("logtarget (a target family object) is required")
         if unsupported:
             raise NotImplementedError(f"closure fields not available on device: {sorted(unsupported)}")
-        if not isinstance(logtarget, (GaussDiagTarget, GaussDenseTarget, LogisticTarget, HierNormalTarget)):
-            raise TypeError("logtarget must be GaussDiagTarget, GaussDenseTarget, LogisticTarget or HierNormalTarget")
+        if not isinstance(logtarget, (GaussDiagTarget, GaussDenseTarget, LogisticTarget, HierNormalTarget, CustomTarget)):
+            raise TypeError("logtarget must be GaussDiagTarget, GaussDenseTarget, LogisticTarget, HierNormalTarget or CustomTarget")
         self.key = str(key).lstrip(":")
         self.target = logtarget
 

@@ -27,7 +27,9 @@
 #ifndef KLARA_DETMATH_H
 #define KLARA_DETMATH_H
 
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #if defined(__HIPCC__)
 #define KD_FN __host__ __device__ __forceinline__

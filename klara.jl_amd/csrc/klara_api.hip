@@ -37,6 +37,7 @@ struct klara_handle {
     double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr,
            *hY = nullptr, *hxc = nullptr;
     double* pooled_out = nullptr;   // 2*D doubles + 1 u64 scratch for pooled summaries
+    double* cdata = nullptr; KlaraJit* jit = nullptr;   // user-defined target: data block, run-time compiled kernels
     KParams* d_params = nullptr;    // device copy of the handle's static kernel parameters
     double lpconst = 0.0;
     // run state
@@ -95,6 +96,10 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
         return KLARA_OK;
     }
     *kind = 0;
+    if (d.target == KLARA_TARGET_CUSTOM) {       // one chain per lane, the whole vector in registers (klara_custom.h)
+        *G = 1; *E = pow2ceil(D < 2 ? 2 : D);
+        return D <= 32 ? KLARA_OK : KLARA_ERR_UNSUPPORTED;
+    }
     if (d.target == KLARA_TARGET_LOGISTIC) {
         *G = 1;   // every lane holds the whole parameter vector; klara_create may turn on the row split (kind 2)
         if (D <= 2) *E = 2; else if (D <= 4) *E = 4; else if (D <= 8) *E = 8; else return KLARA_ERR_UNSUPPORTED;
@@ -130,7 +135,7 @@ static klara_status validate(const klara_desc* d)
     if (d->struct_size != sizeof(klara_desc) || d->abi_version != KLARA_ABI_VERSION) return KLARA_ERR_INVALID_ARG;
     if (d->nchains <= 0 || d->ndims <= 0 || d->chain_offset < 0) return KLARA_ERR_INVALID_ARG;
     if (d->sampler < KLARA_SAMPLER_MH || d->sampler > KLARA_SAMPLER_SLICE) return KLARA_ERR_INVALID_ARG;
-    if (d->target < KLARA_TARGET_GAUSS_DIAG || d->target > KLARA_TARGET_HIER_NORMAL) return KLARA_ERR_INVALID_ARG;
+    if (d->target < KLARA_TARGET_GAUSS_DIAG || d->target > KLARA_TARGET_CUSTOM) return KLARA_ERR_INVALID_ARG;
     if (d->tuner < KLARA_TUNER_VANILLA || d->tuner > KLARA_TUNER_DUAL_AVERAGING) return KLARA_ERR_INVALID_ARG;
     if (d->tuner == KLARA_TUNER_DUAL_AVERAGING) {                // DualAveragingMCTuner.jl:65-70
         if (!(d->targetrate > 0.0 && d->targetrate < 1.0) || d->da_nadapt <= 0 || !(d->da_eps0bar > 0.0) || d->da_t0 <= 0 ||
@@ -170,6 +175,8 @@ static klara_status validate(const klara_desc* d)
     if (d->target == KLARA_TARGET_LOGISTIC &&
         (!d->logit_X || !d->logit_y || d->logit_ndata <= 0 || !(d->logit_lambda > 0.0)))
         return KLARA_ERR_INVALID_ARG;
+    if (d->target == KLARA_TARGET_CUSTOM && (!d->custom_src || d->custom_ndata < 0 || (d->custom_ndata > 0 && !d->custom_data)))
+        return KLARA_ERR_INVALID_ARG;
     if (d->steps_per_launch < 0 || d->tuner_score < 0 || d->tuner_score > 1) return KLARA_ERR_INVALID_ARG;
     return KLARA_OK;
 }
@@ -190,7 +197,8 @@ static void free_all(klara_handle* h)
     hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->da_epsbar); hipFree(h->da_hbar); hipFree(h->pooled_acc); hipFree(h->accept);
     hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->hist); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->err);
     hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
-    hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->d_params);
+    hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->d_params); hipFree(h->cdata);
+    klara_jit_destroy(h->jit);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     for (int j = 0; j < 3; ++j) { if (h->side[j]) hipStreamDestroy(h->side[j]); if (h->join_ev[j]) hipEventDestroy(h->join_ev[j]); }
@@ -199,6 +207,16 @@ static void free_all(klara_handle* h)
 }
 
 static KParams make_params(klara_handle* h);
+
+// the k_transitions MODE values a job can launch (see launch_steps): nothing counts/tunes and nothing is monitored -> 3 and
+// its one-transition-per-launch form 7; nothing counts/tunes -> 1; general -> 0
+static int kernel_modes(const klara_desc& d, int (&modes)[2])
+{
+    const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
+    if (plain && d.monitor == 0) { modes[0] = 3; modes[1] = 7; return 2; }
+    modes[0] = plain ? 1 : 0;
+    return 1;
+}
 
 extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
 {
@@ -291,6 +309,11 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     } else if (desc->target == KLARA_TARGET_HIER_NORMAL) {
         CK(upload(&h->hY, desc->hier_Y, (size_t)desc->hier_nunits * (size_t)desc->hier_ntimes));
         CK(upload(&h->hxc, desc->hier_xc, (size_t)desc->hier_ntimes));
+    } else if (desc->target == KLARA_TARGET_CUSTOM) {
+        if (desc->custom_ndata > 0) CK(upload(&h->cdata, desc->custom_data, (size_t)desc->custom_ndata));
+        int modes[2];
+        const int nmodes = kernel_modes(*desc, modes);
+        CK(klara_jit_create(desc->custom_src, desc->sampler, desc->ndims, E, modes, nmodes, true, &h->jit));
     } else if (desc->target == KLARA_TARGET_LOGISTIC) {
         CK(upload(&h->lX, desc->logit_X, (size_t)desc->logit_ndata * D));
         CK(upload(&h->ly, desc->logit_y, (size_t)desc->logit_ndata));
@@ -313,6 +336,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     // the descriptor's host pointers are not retained
     h->d.mh_sigma = nullptr; h->d.slice_widths = nullptr; h->d.gauss_w = nullptr; h->d.gauss_mu = nullptr;
     h->d.gauss_prec = nullptr; h->d.logit_X = nullptr; h->d.logit_y = nullptr; h->d.hier_Y = nullptr; h->d.hier_xc = nullptr; h->d.stream = nullptr;
+    h->d.custom_src = nullptr; h->d.custom_data = nullptr;
     {   // static kernel parameters live in device memory (read with scalar loads at the point of use)
         const KParams hp = make_params(h);
         CKH(dalloc(&h->d_params, 1));
@@ -363,6 +387,7 @@ static KParams make_params(klara_handle* h)
     p.lX = (decltype(p.lX))h->lX; p.ly = (decltype(p.ly))h->ly; p.ndata = d.logit_ndata; p.lambda = d.logit_lambda; p.lpconst = h->lpconst;
     p.hY = (decltype(p.hY))h->hY; p.hxc = (decltype(p.hxc))h->hxc; p.hR = d.hier_nunits; p.hT = d.hier_ntimes; p.hp0 = d.hier_prior_prec;
     p.ha0 = d.hier_gamma_a; p.hb0 = d.hier_gamma_b;
+    p.cdata = (decltype(p.cdata))h->cdata; p.cndata = d.custom_ndata;
     return p;
 }
 
@@ -476,6 +501,7 @@ static klara_status init_common(klara_handle* h)
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, needgrad, grid_for(h), st);
     else if (h->kind == 3) e = klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st);
     else if (h->kind == 4) e = klara_launch_hiert_init(p, h->E / 2, d.hier_ntimes, needgrad, grid_for(h), st);
+    else if (d.target == KLARA_TARGET_CUSTOM) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), st);
     else if (d.target == KLARA_TARGET_GAUSS_DIAG)
         e = launch_init_t<KLARA_TARGET_GAUSS_DIAG>(p, h->E, h->G, needgrad, grid_for(h), lds_for(h), st);
     else if (d.target == KLARA_TARGET_HIER_NORMAL)
@@ -509,7 +535,7 @@ extern "C" klara_status klara_init_state_normal(klara_handle* h)
     KParams p = make_params(h);
     const int D = h->d.ndims;
     int E = 2, G = pow2ceil((D + 1) / 2);
-    if (h->kind == 0 || h->kind == 2) { E = h->E; G = h->G; }
+    if ((h->kind == 0 || h->kind == 2) && h->d.target != KLARA_TARGET_CUSTOM) { E = h->E; G = h->G; }
     p.G = G; p.rs = 1;     // the init stream is drawn without the row split (same values, any layout)
     const long long cpw = 64 / G, waves = (h->d.nchains + cpw - 1) / cpw;
     const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
@@ -566,6 +592,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
         const bool da = d.tuner == KLARA_TUNER_DUAL_AVERAGING;
         return klara_launch_hiert(p, kl, d.sampler, h->E / 2, d.hier_ntimes, mon, !plain || da, da, grid_for(h), h->stream);
     }
+    if (d.target == KLARA_TARGET_CUSTOM) return klara_jit_launch(h->jit, mode, p, kl, grid_for_transitions(h), h->stream);
     switch (d.sampler) {
     case KLARA_SAMPLER_MH: return klara_launch_mh(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
     case KLARA_SAMPLER_MALA: return klara_launch_mala(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
@@ -1136,6 +1163,16 @@ extern "C" klara_status klara_selftest_mfma_f64_4x4x4(int32_t device, const doub
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }
 
+extern "C" klara_status klara_check_custom_target(const char* src, int32_t sampler, int32_t ndims)
+{
+    if (!src || sampler < KLARA_SAMPLER_MH || sampler > KLARA_SAMPLER_SLICE || ndims <= 0) return KLARA_ERR_INVALID_ARG;
+    if (ndims > 32) return KLARA_ERR_UNSUPPORTED;
+    const int modes[1] = { 0 };
+    return klara_jit_create(src, sampler, ndims, pow2ceil(ndims < 2 ? 2 : ndims), modes, 1, false, nullptr);
+}
+
+extern "C" const char* klara_compile_log(void) { return klara_jit_log(); }
+
 extern "C" const char* klara_strerror(klara_status s)
 {
     switch (s) {
@@ -1147,6 +1184,7 @@ extern "C" const char* klara_strerror(klara_status s)
     case KLARA_ERR_UNSUPPORTED: return "option not supported by this build";
     case KLARA_ERR_STATE: return "call order / missing state";
     case KLARA_ERR_SLICE_STUCK: return "slice sampler shrunk to current position and still not acceptable";
+    case KLARA_ERR_COMPILE: return "user-defined target did not compile (see klara_compile_log)";
     default: return "unknown status";
     }
 }

@@ -1,0 +1,43 @@
+// klara_custom.h — user-defined target for the group-layout kernels, compiled at run time (hiprtc) together with
+// klara_kernels.h and the user's source.  This is the device form of the reference's target closures
+// (`BasicContMuvParameter(:p, logtarget=f, gradlogtarget=g)`, src/variables/parameters/BasicContMuvParameter.jl:174-201,
+// 264-279; `uptogradlogtarget!` falls back to `logtarget!; gradlogtarget!`, :270-274): the user's source text defines
+//
+//   KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata);
+//   KLARA_USER_FN void   klara_user_gradlogtarget(const double* x, int D, const double* data, long long ndata, double* g);
+//
+// in the C subset both hipcc and a host C compiler accept (KLARA_D is predefined to the job's dimension so that loops
+// unroll and x / g stay in registers; kd_exp, kd_log, kd_fma, kd_erf and IEEE + - * / sqrt are bit-reproducible on host and
+// device, libm calls are not).  One chain per lane (G = 1, E = pow2ceil(D) <= 32 elements in registers), so the user's
+// function sees the whole parameter vector and no cross-lane reduction exists; `data` is the job's read-only block
+// (klara_desc.custom_data) in device memory.
+//
+// This file is only ever compiled by the run-time compiler, after klara_kernels.h and the user's source.
+#pragma once
+
+template <int E>
+struct CustomTarget {
+    const double* data; long long ndata; int D;
+    static __device__ __forceinline__ size_t lds_bytes(const KParams&) { return 0; }
+    __device__ __forceinline__ void init(const KParams& p, const LaneCtx<E>&, double*)
+    {
+        data = (const double*)p.cdata; ndata = p.cndata; D = p.D;
+    }
+    template <bool WANT_LT, bool WANT_GRAD>
+    __device__ __forceinline__ void eval(const LaneCtx<E>&, const double (&x)[E], double& ltpart, double (&g)[E]) const
+    {
+        if (WANT_LT) ltpart = klara_user_logtarget(x, D, data, ndata);
+        if (WANT_GRAD) {
+#ifdef KLARA_CUSTOM_NOGRAD                                           // MH / slice sampler: no gradient closure is required
+#pragma unroll
+            for (int e = 0; e < E; ++e) g[e] = 0.0;
+#else
+            klara_user_gradlogtarget(x, D, data, ndata, g);
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (e >= D) g[e] = 0.0;     // padding elements stay exactly zero
+#endif
+        }
+    }
+    __device__ __forceinline__ double finalize(double red) const { return red; }
+};
+template <int E> struct TargetSel<KLARA_TARGET_CUSTOM, E> { using type = CustomTarget<E>; };

@@ -1,0 +1,191 @@
+// klara_jit.hip — run-time compilation of user-defined targets (KLARA_TARGET_CUSTOM) for gfx950.
+//
+// The reference's targets are arbitrary Julia closures (BasicContMuvParameter.jl:174-201,264-279).  Their device form
+// here is source text: klara_create hands it to hiprtc together with the transition kernels of klara_kernels.h (embedded
+// in this library at build time), instantiates k_init / k_transitions for the job's sampler and element count only, and
+// loads the code object as a HIP module.  Compilation needs no GPU (klara_check_custom_target); code objects are cached
+// per process by (source, sampler, D, kernel modes).  libhiprtc.so is loaded on first use.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+#include "klara_launch.h"
+#include "klara_jit_headers.inc"
+
+namespace {
+
+struct Rtc {
+    void* dl = nullptr;
+    hiprtcResult (*CreateProgram)(hiprtcProgram*, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+    hiprtcResult (*AddNameExpression)(hiprtcProgram, const char*) = nullptr;
+    hiprtcResult (*CompileProgram)(hiprtcProgram, int, const char* const*) = nullptr;
+    hiprtcResult (*GetProgramLogSize)(hiprtcProgram, size_t*) = nullptr;
+    hiprtcResult (*GetProgramLog)(hiprtcProgram, char*) = nullptr;
+    hiprtcResult (*GetLoweredName)(hiprtcProgram, const char*, const char**) = nullptr;
+    hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
+    hiprtcResult (*GetCode)(hiprtcProgram, char*) = nullptr;
+    hiprtcResult (*DestroyProgram)(hiprtcProgram*) = nullptr;
+    bool ok = false;
+};
+
+Rtc* rtc()
+{
+    static Rtc r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = { "libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so" };
+        for (const char* n : names) { r.dl = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.dl) break; }
+        if (!r.dl) return;
+#define SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.dl, "hiprtc" #f))
+        SYM(CreateProgram); SYM(AddNameExpression); SYM(CompileProgram); SYM(GetProgramLogSize); SYM(GetProgramLog);
+        SYM(GetLoweredName); SYM(GetCodeSize); SYM(GetCode); SYM(DestroyProgram);
+#undef SYM
+        r.ok = r.CreateProgram && r.AddNameExpression && r.CompileProgram && r.GetProgramLogSize && r.GetProgramLog &&
+               r.GetLoweredName && r.GetCodeSize && r.GetCode && r.DestroyProgram;
+    });
+    return &r;
+}
+
+struct CodeObject {
+    std::vector<char> code;
+    std::string init_name;
+    std::map<int, std::string> trans_names;      // kernel mode -> lowered name
+};
+
+std::mutex g_cache_mutex;
+std::map<std::string, CodeObject> g_cache;
+thread_local std::string g_log;
+
+std::string trans_expr(int sampler, int E, int mode)
+{
+    char b[128];
+    snprintf(b, sizeof b, "k_transitions<%d, KLARA_TARGET_CUSTOM, %d, 1, %d>", sampler, E, mode);
+    return b;
+}
+std::string init_expr(int E)
+{
+    char b[96];
+    snprintf(b, sizeof b, "k_init<KLARA_TARGET_CUSTOM, %d, 1>", E);
+    return b;
+}
+
+// compile (or fetch) the code object of one (source, sampler, D, modes) combination
+klara_status compile(const char* src, int sampler, int D, int E, const int* modes, int nmodes, const CodeObject** out)
+{
+    g_log.clear();
+    Rtc* r = rtc();
+    if (!r->ok) { g_log = "libhiprtc.so could not be loaded"; return KLARA_ERR_UNSUPPORTED; }
+    std::string key = std::to_string(sampler) + "/" + std::to_string(D) + "/";
+    for (int i = 0; i < nmodes; ++i) key += std::to_string(modes[i]) + ",";
+    key += "\n"; key += src;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mutex);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) { *out = &it->second; return KLARA_OK; }
+    }
+    const bool needgrad = sampler == KLARA_SAMPLER_MALA || sampler == KLARA_SAMPLER_HMC;
+    std::string tu;
+    tu += "#define KLARA_D " + std::to_string(D) + "\n";
+    if (!needgrad) tu += "#define KLARA_CUSTOM_NOGRAD 1\n";
+    // (the run-time compiler has no <stdint.h>; its own fixed-width types live in a private namespace)
+    tu += "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
+          "typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;\n";
+    tu += "#include \"klara_kernels.h\"\n"
+          "#define KLARA_USER_FN static __device__ __forceinline__\n"
+          "#line 1 \"klara_user_target\"\n";
+    tu += src;
+    tu += "\n#line 1 \"klara_custom_glue\"\n#include \"klara_custom.h\"\n";
+
+    hiprtcProgram prog;
+    if (r->CreateProgram(&prog, tu.c_str(), "klara_custom_target.hip", klara_jit_nheaders, klara_jit_header_sources,
+                         klara_jit_header_names) != HIPRTC_SUCCESS) {
+        g_log = "hiprtcCreateProgram failed";
+        return KLARA_ERR_COMPILE;
+    }
+    const std::string ie = init_expr(E);
+    r->AddNameExpression(prog, ie.c_str());
+    std::vector<std::string> te;
+    for (int i = 0; i < nmodes; ++i) { te.push_back(trans_expr(sampler, E, modes[i])); r->AddNameExpression(prog, te.back().c_str()); }
+    // same arithmetic contract as the ahead-of-time kernels: no contraction of a*b+c
+    const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value",
+                           "-Wno-unused-variable", "-Wno-unused-function" };
+    const hiprtcResult cr = r->CompileProgram(prog, (int)(sizeof opts / sizeof *opts), opts);
+    size_t ls = 0;
+    if (r->GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) { g_log.resize(ls); r->GetProgramLog(prog, &g_log[0]); }
+    if (cr != HIPRTC_SUCCESS) { r->DestroyProgram(&prog); if (g_log.empty()) g_log = "compilation failed"; return KLARA_ERR_COMPILE; }
+    CodeObject co;
+    const char* low = nullptr;
+    bool ok = r->GetLoweredName(prog, ie.c_str(), &low) == HIPRTC_SUCCESS && low;
+    if (ok) co.init_name = low;
+    for (int i = 0; ok && i < nmodes; ++i) {
+        ok = r->GetLoweredName(prog, te[i].c_str(), &low) == HIPRTC_SUCCESS && low;
+        if (ok) co.trans_names[modes[i]] = low;
+    }
+    size_t cs = 0;
+    ok = ok && r->GetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0;
+    if (ok) { co.code.resize(cs); ok = r->GetCode(prog, co.code.data()) == HIPRTC_SUCCESS; }
+    r->DestroyProgram(&prog);
+    if (!ok) { g_log += "\n(could not retrieve the code object)"; return KLARA_ERR_COMPILE; }
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    auto ins = g_cache.emplace(key, std::move(co));
+    *out = &ins.first->second;
+    return KLARA_OK;
+}
+
+}  // namespace
+
+struct KlaraJit {
+    hipModule_t mod = nullptr;
+    hipFunction_t init = nullptr;
+    std::map<int, hipFunction_t> trans;
+};
+
+klara_status klara_jit_create(const char* src, int sampler, int D, int E, const int* modes, int nmodes, bool load, KlaraJit** out)
+{
+    const CodeObject* co = nullptr;
+    klara_status st = compile(src, sampler, D, E, modes, nmodes, &co);
+    if (st != KLARA_OK || !load) return st;
+    KlaraJit* j = new (std::nothrow) KlaraJit();
+    if (!j) return KLARA_ERR_NOMEM;
+    bool ok = hipModuleLoadData(&j->mod, co->code.data()) == hipSuccess;
+    ok = ok && hipModuleGetFunction(&j->init, j->mod, co->init_name.c_str()) == hipSuccess;
+    for (auto it = co->trans_names.begin(); ok && it != co->trans_names.end(); ++it) {
+        hipFunction_t f = nullptr;
+        ok = hipModuleGetFunction(&f, j->mod, it->second.c_str()) == hipSuccess;
+        j->trans[it->first] = f;
+    }
+    if (!ok) { klara_jit_destroy(j); return KLARA_ERR_HIP; }
+    *out = j;
+    return KLARA_OK;
+}
+
+void klara_jit_destroy(KlaraJit* j)
+{
+    if (!j) return;
+    if (j->mod) hipModuleUnload(j->mod);
+    delete j;
+}
+
+hipError_t klara_jit_launch_init(KlaraJit* j, const KParams& p, int needgrad, dim3 grid, hipStream_t st)
+{
+    KParams pv = p;
+    void* args[] = { &pv, &needgrad };
+    return hipModuleLaunchKernel(j->init, grid.x, 1, 1, 256, 1, 1, 0, st, args, nullptr);
+}
+
+hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, dim3 grid, hipStream_t st)
+{
+    auto it = j->trans.find(mode == 7 ? 7 : (mode & 3) == 3 ? 3 : (mode & 1) ? 1 : 0);
+    if (it == j->trans.end()) return hipErrorInvalidValue;
+    KLaunch klv = kl;
+    void* args[] = { &p, &klv };
+    return hipModuleLaunchKernel(it->second, grid.x, 1, 1, 256, 1, 1, 0, st, args, nullptr);
+}
+
+const char* klara_jit_log() { return g_log.c_str(); }

@@ -15,10 +15,15 @@
 // The transition arithmetic restates src/samplers/iterate/{MH,MALA,HMC,SliceSampler}.jl expression by
 // expression (no fma contraction: build with -ffp-contract=off); citations are on each step.
 #pragma once
+#ifdef __HIPCC_RTC__                 // run-time compilation of a user-defined target (klara_custom.h): flat header names
+#include "detmath.h"
+#include "klara_hip.h"
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "detmath.h"
 #include "../../include/klara_hip.h"
+#endif
 
 #ifndef KLARA_E4_WAVES
 #define KLARA_E4_WAVES 2   // min waves per SIMD requested for the E=4 kernels (register budget 256)
@@ -79,6 +84,7 @@ struct KParams {
     const gdouble* gw; const gdouble* gmu; double gconst;      // diag (gw/gmu may be null)
     const gdouble* lX; const gdouble* ly; int ndata; double lambda; double lpconst;   // logistic
     const gdouble* hY; const gdouble* hxc; int hR; int hT; double hp0; double ha0; double hb0;   // hierarchical normal
+    const gdouble* cdata; long long cndata;                      // user-defined target (klara_custom.h): read-only data block
 };
 
 // Per-launch values, passed by value.  Everything else (KParams) is static for a handle and lives in device memory:

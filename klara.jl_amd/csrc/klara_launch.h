@@ -68,6 +68,15 @@ hipError_t klara_launch_hiert(const KParams* p, const KLaunch& kl, int sampler, 
                               hipStream_t st);
 hipError_t klara_launch_hiert_init(const KParams& p, int RPL, int NT, int needgrad, dim3 grid, hipStream_t st);
 
+// user-defined targets (KLARA_TARGET_CUSTOM): run-time compiled instantiations of k_init / k_transitions (klara_jit.hip);
+// `modes` are the k_transitions MODE values the job can launch; load = false only compiles (no GPU needed)
+struct KlaraJit;
+klara_status klara_jit_create(const char* src, int sampler, int D, int E, const int* modes, int nmodes, bool load, KlaraJit** out);
+void klara_jit_destroy(KlaraJit* j);
+hipError_t klara_jit_launch_init(KlaraJit* j, const KParams& p, int needgrad, dim3 grid, hipStream_t st);
+hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, dim3 grid, hipStream_t st);
+const char* klara_jit_log();
+
 // mode 7: mode 3 with exactly one transition per launch; mode 3: nothing counts/tunes and nothing is monitored;
 // mode 1: nothing counts/tunes; mode 0: general
 #define KLARA_LAUNCH_T(S, T, E_, G_)                                                                    \

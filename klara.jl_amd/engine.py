@@ -96,6 +96,31 @@ class LogisticTarget:
 
 
 @dataclass
+class CustomTarget:
+    """User-defined target: the device form of `BasicContMuvParameter(:p, logtarget=f, gradlogtarget=g)`
+    (BasicContMuvParameter.jl:174-201,264-279).  `source` is C text defining
+
+        KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata);
+        KLARA_USER_FN void   klara_user_gradlogtarget(const double* x, int D, const double* data, long long ndata, double* g);
+
+    (the gradient only for MALA / HMC); it is compiled for gfx950 when the job is created (include/klara_hip.h,
+    KLARA_TARGET_CUSTOM).  `data` is an optional read-only block of doubles handed to both functions."""
+    ndims: int
+    source: str
+    data: Optional[np.ndarray] = None
+    kind = L.TARGET_CUSTOM
+
+    def __post_init__(self):
+        self.ndims = int(self.ndims)
+        if self.data is not None:
+            self.data = _f64(self.data).ravel()
+
+    def check(self, sampler: int) -> None:
+        """Compile only (no GPU needed); raises KlaraError with the compiler's log on failure."""
+        L.check(L.load().klara_check_custom_target(self.source.encode(), int(sampler), self.ndims), "klara_check_custom_target")
+
+
+@dataclass
 class HierNormalTarget:
     """Hierarchical normal growth-curve model (BUGS "Rats"; BASELINE cfg 5, data/rats/*.csv).
 
@@ -190,6 +215,10 @@ class Engine:
             b = _f64(target.xc); keep.append(b); d.hier_xc = _ptr(b)
             d.hier_nunits, d.hier_ntimes = int(target.Y.shape[0]), int(target.Y.shape[1])
             d.hier_prior_prec, d.hier_gamma_a, d.hier_gamma_b = float(target.prior_prec), float(target.gamma_a), float(target.gamma_b)
+        elif isinstance(target, CustomTarget):
+            src = target.source.encode(); keep.append(src); d.custom_src = src
+            if target.data is not None and target.data.size:
+                a = _f64(target.data); keep.append(a); d.custom_data = _ptr(a); d.custom_ndata = int(a.size)
         else:
             raise TypeError(f"unknown target family {type(target).__name__}")
         d.seed, d.monitor, d.steps_per_launch = int(seed), self.monitor, int(steps_per_launch)

@@ -251,6 +251,15 @@ static double ko_hier_eval(const ko_target_ctx* c, const double* th, double* g, 
     return ((l_c + l_a) + l_b) - (0.5 * p0) * (ac * ac + bc * bc);
 }
 
+/* KLARA_TARGET_CUSTOM: the user's closures (BasicContMuvParameter(:p, logtarget=f, gradlogtarget=g),
+ * BasicContMuvParameter.jl:174-201,264-279).  The test harness compiles the same C text the device path compiles
+ * (tests/oracle_ffi.py, gcc -ffp-contract=off with detmath.h) and registers the two functions here. */
+typedef double (*ko_user_lt_fn)(const double* x, int D, const double* data, long long ndata);
+typedef void (*ko_user_grad_fn)(const double* x, int D, const double* data, long long ndata, double* g);
+static ko_user_lt_fn ko_user_lt = NULL;
+static ko_user_grad_fn ko_user_grad = NULL;
+void ko_set_custom_target(ko_user_lt_fn lt, ko_user_grad_fn grad) { ko_user_lt = lt; ko_user_grad = grad; }
+
 /* logtarget!(state) — BasicContMuvParameter.jl:174-201 */
 static double ko_logtarget(const ko_target_ctx* c, const double* x, double* scratch)
 {
@@ -262,6 +271,7 @@ static double ko_logtarget(const ko_target_ctx* c, const double* x, double* scra
         return ko_dense_lt_from_grad(c, x, g, scratch);
     }
     case KLARA_TARGET_HIER_NORMAL: return ko_hier_eval(c, x, NULL, scratch);
+    case KLARA_TARGET_CUSTOM: return ko_user_lt(x, c->d->ndims, c->d->custom_data, (long long)c->d->custom_ndata);
     default: { double lt; ko_logit_eval(c, x, &lt, NULL); return lt; }
     }
 }
@@ -272,6 +282,10 @@ static void ko_gradlogtarget(const ko_target_ctx* c, const double* x, double* g)
     case KLARA_TARGET_GAUSS_DIAG: ko_diag_grad(c, x, g); break;
     case KLARA_TARGET_GAUSS_DENSE: ko_dense_grad(c, x, g); break;
     case KLARA_TARGET_HIER_NORMAL: { double sc[1]; (void)ko_hier_eval(c, x, g, sc); break; }
+    case KLARA_TARGET_CUSTOM:      /* (MH / slice jobs need no gradient closure; their init evaluates none) */
+        if (ko_user_grad) ko_user_grad(x, c->d->ndims, c->d->custom_data, (long long)c->d->custom_ndata, g);
+        else for (int i = 0; i < c->d->ndims; ++i) g[i] = 0.0;
+        break;
     default: ko_logit_eval(c, x, NULL, g); break;
     }
 }
@@ -282,6 +296,7 @@ static double ko_uptograd(const ko_target_ctx* c, const double* x, double* g, do
     case KLARA_TARGET_GAUSS_DIAG: ko_diag_grad(c, x, g); return ko_diag_lt(c, x, scratch);
     case KLARA_TARGET_GAUSS_DENSE: ko_dense_grad(c, x, g); return ko_dense_lt_from_grad(c, x, g, scratch);
     case KLARA_TARGET_HIER_NORMAL: return ko_hier_eval(c, x, g, scratch);
+    case KLARA_TARGET_CUSTOM: { const double lt = ko_logtarget(c, x, scratch); ko_gradlogtarget(c, x, g); return lt; }
     default: { double lt; ko_logit_eval(c, x, &lt, g); return lt; }
     }
 }

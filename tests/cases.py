@@ -31,6 +31,102 @@ def compound_symmetric_precision(d, rho=0.5):
     return (np.eye(d) - (rho / (1.0 - rho + d * rho)) * np.ones((d, d))) / (1.0 - rho)
 
 
+# ---- user-defined targets (KLARA_TARGET_CUSTOM): C text compiled by hiprtc for the device and by gcc for the oracle
+SRC_NEGDOT = r"""
+/* README.md:23,155: plogtarget(z) = -dot(z, z), pgradlogtarget(z) = -2*z */
+KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata)
+{
+    double s = 0.0;
+    for (int i = 0; i < KLARA_D; ++i) s = s + x[i] * x[i];
+    return 0.0 - s;
+}
+KLARA_USER_FN void klara_user_gradlogtarget(const double* x, int D, const double* data, long long ndata, double* g)
+{
+    for (int i = 0; i < KLARA_D; ++i) g[i] = -2.0 * x[i];
+}
+"""
+
+SRC_BANANA = r"""
+/* a curved two-dimensional density: lt = -(1 - x0)^2 / 20 - (x1 - x0^2)^2 */
+KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata)
+{
+    const double a = 1.0 - x[0], b = x[1] - x[0] * x[0];
+    return -(a * a) / 20.0 - b * b;
+}
+KLARA_USER_FN void klara_user_gradlogtarget(const double* x, int D, const double* data, long long ndata, double* g)
+{
+    const double a = 1.0 - x[0], b = x[1] - x[0] * x[0];
+    g[0] = a / 10.0 + 4.0 * (b * x[0]);
+    g[1] = -2.0 * b;
+}
+"""
+
+SRC_BANANA_LT_ONLY = SRC_BANANA[:SRC_BANANA.index("KLARA_USER_FN void")]     # MH / slice need no gradient closure
+
+SRC_LOGIT = r"""
+/* doc/examples/swiss/MALA/analytical.jl:11-18 written as a user closure; data = [X (n x D row-major), y (n), lambda] */
+KLARA_USER_FN double klara_user_logtarget(const double* p, int D, const double* data, long long ndata)
+{
+    const int n = (int)((ndata - 1) / (KLARA_D + 1));
+    const double* X = data; const double* y = data + (long long)n * KLARA_D; const double lambda = data[ndata - 1];
+    double dotxy = 0.0, slog = 0.0;
+    for (int r = 0; r < n; ++r) {
+        double xp = 0.0;
+        for (int e = 0; e < KLARA_D; ++e) xp = kd_fma(X[r * KLARA_D + e], p[e], xp);
+        dotxy = dotxy + xp * y[r];
+        slog = slog + kd_log_pos(1.0 + kd_exp(xp));
+    }
+    double dotpp = 0.0;
+    for (int e = 0; e < KLARA_D; ++e) dotpp = dotpp + p[e] * p[e];
+    return (dotxy - slog) + -0.5 * (dotpp / lambda + (double)KLARA_D * kd_log(2.0 * 3.141592653589793 * lambda));
+}
+KLARA_USER_FN void klara_user_gradlogtarget(const double* p, int D, const double* data, long long ndata, double* g)
+{
+    const int n = (int)((ndata - 1) / (KLARA_D + 1));
+    const double* X = data; const double* y = data + (long long)n * KLARA_D; const double lambda = data[ndata - 1];
+    for (int e = 0; e < KLARA_D; ++e) g[e] = 0.0;
+    for (int r = 0; r < n; ++r) {
+        double xp = 0.0;
+        for (int e = 0; e < KLARA_D; ++e) xp = kd_fma(X[r * KLARA_D + e], p[e], xp);
+        const double res = y[r] - 1.0 / (1.0 + kd_exp(-xp));
+        for (int e = 0; e < KLARA_D; ++e) g[e] = kd_fma(X[r * KLARA_D + e], res, g[e]);
+    }
+    for (int e = 0; e < KLARA_D; ++e) g[e] = g[e] - p[e] / lambda;
+}
+"""
+
+SRC_QUARTIC_CHAIN = r"""
+/* non-Gaussian, coupled: lt = -sum_i (x_i^2 / 2 + c x_i^4) - k/2 sum_i (x_{i+1} - x_i)^2, data = [c, k] */
+KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata)
+{
+    const double c = data[0], k = data[1];
+    double s = 0.0;
+    for (int i = 0; i < KLARA_D; ++i) { const double q = x[i] * x[i]; s = s + (0.5 * q + c * (q * q)); }
+    double t = 0.0;
+    for (int i = 0; i + 1 < KLARA_D; ++i) { const double d = x[i + 1] - x[i]; t = t + d * d; }
+    return -s - (0.5 * k) * t;
+}
+KLARA_USER_FN void klara_user_gradlogtarget(const double* x, int D, const double* data, long long ndata, double* g)
+{
+    const double c = data[0], k = data[1];
+    for (int i = 0; i < KLARA_D; ++i) {
+        const double q = x[i] * x[i];
+        double v = -(x[i] + (4.0 * c) * (q * x[i]));
+        if (i + 1 < KLARA_D) v = v + k * (x[i + 1] - x[i]);
+        if (i > 0) v = v - k * (x[i] - x[i - 1]);
+        g[i] = v;
+    }
+}
+"""
+
+
+def synthetic_logit(n, d, seed=5):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d))
+    y = (rng.random(n) < 1.0 / (1.0 + np.exp(-(X @ np.linspace(-1.0, 1.0, d))))).astype(np.float64)
+    return np.ascontiguousarray(X), y
+
+
 def make_case(name):
     """name -> dict(engine kwargs..., target=<family object>, x0=None|array)."""
     c = {}
@@ -211,6 +307,33 @@ def make_case(name):
         mu = np.linspace(-1, 1, 96); sg = np.linspace(0.7, 1.4, 96)
         c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.mvnormal(mu, sg), nchains=29, nsteps=15, burnin=0,
                  leapstep=0.15, nleaps=7)
+    elif name == "custom_negdot_mala_d3":     # same arithmetic as the built-in diagonal target at D = 3 (E = 4, one chain per lane)
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(3, SRC_NEGDOT), nchains=70, nsteps=60, burnin=10, driftstep=0.8)
+    elif name == "custom_banana_mh":          # logtarget closure only
+        c = dict(sampler=L.SAMPLER_MH, target=K.CustomTarget(2, SRC_BANANA_LT_ONLY), nchains=130, nsteps=80, burnin=20,
+                 mh_sigma=[0.7, 0.9], x0=np.tile([0.5, 0.2], (130, 1)))
+    elif name == "custom_banana_hmc":
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(2, SRC_BANANA), nchains=67, nsteps=60, burnin=10, leapstep=0.15, nleaps=7,
+                 x0=np.tile([0.5, 0.2], (67, 1)))
+    elif name == "custom_banana_slice":
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget(2, SRC_BANANA_LT_ONLY), nchains=65, nsteps=30, burnin=5,
+                 slice_widths=[1.0, 2.0], x0=np.tile([0.5, 0.2], (65, 1)))
+    elif name == "custom_logit_mala_d4":      # the swiss example's closures on 40 synthetic rows (= built-in LogisticTarget without row split)
+        X, y = synthetic_logit(40, 4)
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(4, SRC_LOGIT, np.concatenate([X.ravel(), y, [100.0]])),
+                 nchains=64, nsteps=50, burnin=10, driftstep=0.05, x0=np.zeros((64, 4)))
+    elif name == "custom_quartic_hmc_d10_dualavg":
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(10, SRC_QUARTIC_CHAIN, [0.1, 0.7]), nchains=40, nsteps=70, burnin=0,
+                 leapstep=0.1, nleaps=6, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=40)
+    elif name == "custom_quartic_mala_d20_pooled":
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(20, SRC_QUARTIC_CHAIN, [0.05, 0.3]), nchains=48, nsteps=130, burnin=100,
+                 driftstep=0.2, tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.574, period=20)
+    elif name == "custom_quartic_hmc_d32":    # the largest user-defined dimension: 32 elements per lane
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(32, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=70, nsteps=25, burnin=5,
+                 leapstep=0.1, nleaps=4)
+    elif name == "custom_quartic_slice_d7":
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget(7, SRC_QUARTIC_CHAIN, [0.1, 0.4]), nchains=66, nsteps=12, burnin=2,
+                 slice_widths=np.full(7, 1.5))
     else:
         raise KeyError(name)
     c.setdefault("x0", None)
@@ -229,11 +352,14 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_rats_dualavg", "mala_d3_tuned_erf", "mala_d1", "hmc_d128_full", "mala_d129", "mh_d512",
              "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg",
              "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
-             "slice_d20_stepout", "mh_rats", "mala_rats_tuned"]
+             "slice_d20_stepout", "mh_rats", "mala_rats_tuned"] + [
+             "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
+             "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",
-                "dt_mala_d100_small_step", "dt_hmc_d100", "dt_mh_mvnormal_d20"]
+                "dt_mala_d100_small_step", "dt_hmc_d100", "dt_mh_mvnormal_d20", "custom_banana_hmc",
+                "custom_quartic_mala_d20_pooled"]
 
 
 def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):
@@ -246,6 +372,8 @@ def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):
         kw.update(gauss_w=t.w, gauss_mu=t.mu, gauss_const=t.const)
     elif isinstance(t, K.GaussDenseTarget):
         kw.update(gauss_prec=t.precision, gauss_const=t.const)
+    elif isinstance(t, K.CustomTarget):
+        kw.update(custom_src=t.source, custom_data=t.data)
     elif isinstance(t, K.HierNormalTarget):
         kw.update(hier_Y=t.Y, hier_xc=t.xc, hier_prior_prec=t.prior_prec, hier_gamma_a=t.gamma_a, hier_gamma_b=t.gamma_b)
     else:

@@ -6,6 +6,7 @@ descriptor the product's C ABI takes and returns everything the parity tests com
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
 import subprocess
 from pathlib import Path
@@ -52,6 +53,8 @@ def load() -> C.CDLL:
     lib.ko_u52.restype = C.c_double
     lib.ko_eval_target.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout), vp, vp, vp]
     lib.ko_eval_target.restype = C.c_int
+    lib.ko_set_custom_target.argtypes = [vp, vp]
+    lib.ko_set_custom_target.restype = None
     for name in ("ko_logistic",):
         getattr(lib, name).argtypes = [C.c_double] * 5
         getattr(lib, name).restype = C.c_double
@@ -60,6 +63,31 @@ def load() -> C.CDLL:
         getattr(lib, name).restype = C.c_double
     _lib = lib
     return lib
+
+
+_user_libs = {}
+
+
+def compile_user_target(src: str, ndims: int):
+    """Host form of a user-defined target (KLARA_TARGET_CUSTOM): the same C text the product hands to hiprtc, compiled by
+    gcc with the same arithmetic contract (-ffp-contract=off, detmath.h for kd_*).  Returns (lib, lt_ptr, grad_ptr|None)."""
+    key = hashlib.sha1(f"{ndims}\n{src}".encode()).hexdigest()[:16]
+    if key in _user_libs:
+        return _user_libs[key]
+    out = ROOT / "oracle" / "_user"
+    out.mkdir(exist_ok=True)
+    so, c = out / f"user_{key}.so", out / f"user_{key}.c"
+    if not so.exists():
+        c.write_text(f'#include "detmath.h"\n#define KLARA_D {int(ndims)}\n#define KLARA_USER_FN\n#line 1 "klara_user_target"\n{src}\n')
+        r = subprocess.run(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-shared", "-I", str(ROOT / "klara.jl_amd" / "csrc"),
+                            "-o", str(so), str(c), "-lm"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("user target did not compile on the host:\n" + r.stderr)
+    lib = C.CDLL(str(so))
+    lt = C.cast(lib.klara_user_logtarget, C.c_void_p)
+    grad = C.cast(lib.klara_user_gradlogtarget, C.c_void_p) if hasattr(lib, "klara_user_gradlogtarget") else None
+    _user_libs[key] = (lib, lt, grad)
+    return _user_libs[key]
 
 
 DIAGT_NP_MENU = (2, 3, 4, 5, 6, 7, 8)      # klara_launch.h KLARA_DIAGT_NP_MENU_DO
@@ -80,6 +108,11 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     if (target_kind == L.TARGET_HIER_NORMAL and sampler in (L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC)
             and 9 <= hier_nunits <= 32 and hier_ntimes == 5 and os.environ.get("KLARA_LAYOUT_KIND", "4") != "0"):
         return (4, 8, 8)              # klara_hiert.h: 8 lanes per chain, 4 units per lane
+    if target_kind == L.TARGET_CUSTOM:        # one chain per lane, pow2ceil(D) elements in registers (klara_custom.h)
+        e = 2
+        while e < d:
+            e *= 2
+        return (0, 1, e)
     if target_kind == L.TARGET_GAUSS_DENSE:
         ne = 8 if d <= 32 else 16 if d <= 64 else 25 if d <= 100 else 32
         return (1, 4, ne)
@@ -110,12 +143,12 @@ class OracleJob:
                  da_nadapt=0, da_eps0bar=1.0, da_h0bar=0.0, da_gamma=0.05, da_t0=10, da_kappa=0.75, tuner_score=0,
                  seed=20260927, chain_offset=0, gauss_w=None, gauss_mu=None, gauss_const=0.0, gauss_prec=None,
                  logit_X=None, logit_y=None, logit_lambda=100.0, hier_Y=None, hier_xc=None, hier_prior_prec=1e-4,
-                 hier_gamma_a=1e-3, hier_gamma_b=1e-3, layout=None,
+                 hier_gamma_a=1e-3, hier_gamma_b=1e-3, custom_src=None, custom_data=None, layout=None,
                  want_accept=True, want_sums=True, want_hist=False):
         self.lib = load()
         self.N, self.D = int(nchains), int(ndims)
         d = L.KlaraDesc()
-        d.struct_size = C.sizeof(L.KlaraDesc); d.abi_version = 1
+        d.struct_size = C.sizeof(L.KlaraDesc); d.abi_version = L.KLARA_ABI_VERSION
         d.sampler, d.target, d.tuner, d.tuner_mode = int(sampler), int(target_kind), int(tuner), int(tuner_mode)
         d.nchains, d.chain_offset, d.ndims = self.N, int(chain_offset), self.D
         self._keep = []
@@ -144,6 +177,11 @@ class OracleJob:
         if hier_Y is not None:
             d.hier_nunits, d.hier_ntimes = int(np.shape(hier_Y)[0]), int(np.shape(hier_Y)[1])
         d.hier_prior_prec, d.hier_gamma_a, d.hier_gamma_b = float(hier_prior_prec), float(hier_gamma_a), float(hier_gamma_b)
+        self._user = None
+        if custom_src is not None:
+            self._user = compile_user_target(custom_src, self.D)
+            if custom_data is not None and np.size(custom_data):
+                d.custom_data = ptr(custom_data); d.custom_ndata = int(np.size(custom_data))
         d.seed = int(seed)
         self.desc = d
         k, g, e = layout if layout is not None else default_layout(int(target_kind), self.D, int(d.logit_ndata), sampler=int(sampler),
@@ -169,6 +207,10 @@ class OracleJob:
     def _p(self, a):
         return None if a is None else a.ctypes.data
 
+    def _bind_user(self):
+        if self._user is not None:             # (process-global in the oracle: bound before every call that evaluates the target)
+            self.lib.ko_set_custom_target(self._user[1], self._user[2])
+
     def set_state(self, x) -> int:
         self.X[...] = _f64(x).reshape(self.N, self.D)
         return self._init()
@@ -184,6 +226,7 @@ class OracleJob:
         if self.sum is not None:
             self.sum[...] = 0.0; self.sumsq[...] = 0.0
         self.accept = np.zeros((0, self.N), np.uint8)
+        self._bind_user()
         return self.lib.ko_init(C.byref(self.desc), C.byref(self.layout), self._p(self.X), self._p(self.G),
                                 self._p(self.LT), self._p(self.step), self._p(self.accepted),
                                 self._p(self.proposed), self._p(self.totproposed), self._p(self.da_epsbar),
@@ -191,6 +234,7 @@ class OracleJob:
 
     def run(self, nsteps: int) -> int:
         acc = np.zeros((nsteps, self.N), np.uint8) if self.want_accept else None
+        self._bind_user()
         st = self.lib.ko_run(C.byref(self.desc), C.byref(self.layout), self._p(self.X), self._p(self.G),
                              self._p(self.LT), self._p(self.step), self._p(self.accepted), self._p(self.proposed),
                              self._p(self.totproposed), self.t, int(nsteps), self._p(acc), self._p(self.sum),
@@ -205,6 +249,7 @@ class OracleJob:
         x = _f64(x).ravel()
         lt = C.c_double(0.0)
         g = np.zeros(self.D)
+        self._bind_user()
         st = self.lib.ko_eval_target(C.byref(self.desc), C.byref(self.layout), x.ctypes.data, C.byref(lt), g.ctypes.data)
         assert st == 0
         return lt.value, g

@@ -656,6 +656,79 @@ def test_readme_flow_basic_mc_job():
     job.close()
 
 
+# ------------------------------------------------------------------ user-defined targets (KLARA_TARGET_CUSTOM)
+def _run_engine(case, **over):
+    eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_ACCEPT | L.MON_SUMMARIES, **over))
+    eng.set_state(case["x0"]) if case.get("x0") is not None else eng.init_state_normal()
+    eng.run(case["nsteps"])
+    out = (eng.state(), eng.accept_mask(), eng.chain_sums()[:2], eng.layout())
+    eng.close()
+    return out
+
+
+def test_custom_target_equals_builtin_families():
+    """The README closure (-dot(z,z), -2z) and the swiss example's closures, handed over as user source and compiled at
+    klara_create, give bit for bit what the built-in diagonal / logistic families give (same lane layout: one chain per
+    lane, so even the summation order is the same)."""
+    c = cases.make_case("custom_negdot_mala_d3")
+    b = dict(c, target=K.GaussDiagTarget.negdot(3))
+    X, y = cases.synthetic_logit(40, 4)
+    c2 = cases.make_case("custom_logit_mala_d4")
+    b2 = dict(c2, target=K.LogisticTarget(X, y, 100.0))
+    for cu, bu in ((c, b), (c2, b2)):
+        (sc, mc, qc, lc), (sb, mb, qb, lb) = _run_engine(cu), _run_engine(bu)
+        assert lc == lb and lc[0] == 0 and lc[1] == 1
+        assert all(np.array_equal(u, v) for u, v in zip(sc, sb))
+        assert np.array_equal(mc, mb) and 0 < mc.sum() < mc.size
+        assert all(np.array_equal(u, v) for u, v in zip(qc, qb))
+
+
+def test_custom_target_compile_error_and_limits():
+    with pytest.raises(K.KlaraError) as ei:
+        K.Engine(sampler=L.SAMPLER_MH, target=K.CustomTarget(2, "double klara_user_logtarget(const double* x) { return x[0] }"),
+                 nchains=4, nsteps=5, mh_sigma=[1.0, 1.0])
+    assert ei.value.status == L.ERR_COMPILE and "klara_user_target:1" in ei.value.log
+    with pytest.raises(K.KlaraError) as ei:               # MALA needs the gradient closure
+        K.Engine(sampler=L.SAMPLER_MALA, target=K.CustomTarget(2, cases.SRC_BANANA_LT_ONLY), nchains=4, nsteps=5, driftstep=0.1)
+    assert ei.value.status == L.ERR_COMPILE and "klara_user_gradlogtarget" in ei.value.log
+    with pytest.raises(K.KlaraError) as ei:               # D <= 32: the whole vector lives in one lane's registers
+        K.Engine(sampler=L.SAMPLER_MH, target=K.CustomTarget(33, cases.SRC_NEGDOT), nchains=4, nsteps=5, mh_sigma=np.ones(33))
+    assert ei.value.status == L.ERR_UNSUPPORTED
+    # a closure that is not finite at the start: the reference's initialize! assert (MH.jl:83)
+    src = "KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata) { return kd_log(x[0]); }"
+    eng = K.Engine(sampler=L.SAMPLER_MH, target=K.CustomTarget(1, src), nchains=4, nsteps=5, mh_sigma=[1.0])
+    with pytest.raises(K.KlaraError) as ei:
+        eng.set_state(-np.ones((4, 1)))
+    assert ei.value.status == L.ERR_NONFINITE_INIT
+    eng.set_state(np.ones((4, 1))); eng.run(5)            # log-density of x > 0 only: proposals at x <= 0 are rejected (NaN ratio)
+    assert (eng.state()[0] > 0).all()
+    eng.close()
+
+
+def test_custom_target_through_the_job_api():
+    """BasicContMuvParameter(:p, logtarget=..., gradlogtarget=...) with user closures through the host mirror: HMC on the
+    curved 2-d density, every chain's saved history against the oracle."""
+    tgt = K.CustomTarget(2, cases.SRC_BANANA)
+    p = K.BasicContMuvParameter("p", logtarget=tgt)
+    job = K.BasicMCJob(K.likelihood_model(p, False), K.HMC(0.15, 7), K.BasicMCRange(nsteps=300, burnin=50, thinning=2),
+                       {"p": np.tile([0.5, 0.2], (96, 1))}, outopts={"diagnostics": ["accept"]})
+    K.run(job)
+    chain = K.output(job)
+    assert chain.value(3).shape == (2, 125)
+    assert job.range.nsteps == 299                                # last(51:2:300), BasicMCRange.jl:17
+    o = O.OracleJob(sampler=L.SAMPLER_HMC, target_kind=L.TARGET_CUSTOM, nchains=96, ndims=2, nsteps=299, burnin=50, thinning=2,
+                    leapstep=0.15, nleaps=7, custom_src=cases.SRC_BANANA, layout=job.engine.layout(), want_hist=True)
+    o.set_state(np.tile([0.5, 0.2], (96, 1))); o.run(299)
+    for c in (0, 3, 95):
+        assert np.array_equal(chain.value(c), o.hist[:, c, :].T)
+    assert np.array_equal(job.engine.accept_mask(), o.accept)
+    # the sampler explores the curved ridge: E[x1 - x0^2] = 0 and Var[x1 - x0^2] = 1/2 under the target
+    v = np.stack([chain.value(c) for c in range(96)])           # (chains, 2, n)
+    r = v[:, 1, :] - v[:, 0, :] ** 2
+    assert abs(r.mean()) < 0.1 and abs(r.var() - 0.5) < 0.1
+    job.close()
+
+
 # ------------------------------------------------------------------ full-size parity on sampled chains
 @pytest.mark.parametrize("name,kw,nsteps", [
     ("cfg2_mala", dict(sampler=L.SAMPLER_MALA, driftstep=0.9), 40),

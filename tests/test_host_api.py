@@ -14,11 +14,12 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def test_library_exports_every_declared_symbol(klib):
     header = (ROOT / "include" / "klara_hip.h").read_text()
-    declared = set(re.findall(r"\b(klara_[a-z0-9_]+)\s*\(", header)) - {"klara_status"}
+    # (klara_user_*: the two functions a user-defined target's source defines, named in a comment — not library symbols)
+    declared = set(re.findall(r"\b(klara_[a-z0-9_]+)\s*\(", header)) - {"klara_status", "klara_user_logtarget", "klara_user_gradlogtarget"}
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(klib, name), name
-    assert klib.klara_abi_version() == 1
+    assert klib.klara_abi_version() == L.KLARA_ABI_VERSION == 2
 
 
 def test_desc_struct_matches_header_layout():
@@ -45,7 +46,7 @@ def test_desc_fields_agree_across_header_ctypes_and_julia_stub():
         assert m, decl
         ctype = "ptr" if m.group(3) else m.group(2)
         cfields.append((m.group(4), ctype))
-    width = {"uint32_t": 4, "int32_t": 4, "int64_t": 8, "uint64_t": 8, "double": 8, "ptr": 8, "void": 8}
+    width = {"uint32_t": 4, "int32_t": 4, "int64_t": 8, "uint64_t": 8, "double": 8, "ptr": 8, "void": 8, "char": 8}
     py = [(n, C.sizeof(t)) for n, t in L.KlaraDesc._fields_]
     assert [n for n, _ in cfields] == [n for n, _ in py]
     assert [width[t] for _, t in cfields] == [w for _, w in py]
@@ -53,7 +54,7 @@ def test_desc_fields_agree_across_header_ctypes_and_julia_stub():
     jbody = jl[jl.index("struct KlaraDesc") + len("struct KlaraDesc"):]
     jbody = jbody[:jbody.index("\nend")]
     jfields = re.findall(r"([A-Za-z_0-9]+)::([A-Za-z0-9{}]+)", jbody)
-    jwidth = {"UInt32": 4, "Int32": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "Ptr{Float64}": 8, "Ptr{Cvoid}": 8}
+    jwidth = {"UInt32": 4, "Int32": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "Ptr{Float64}": 8, "Ptr{Cvoid}": 8, "Cstring": 8}
     assert [n for n, _ in jfields] == [n for n, _ in py]
     assert [jwidth[t] for _, t in jfields] == [w for _, w in py]
     integ = (ROOT / "INTEGRATION.md").read_text()
@@ -169,3 +170,21 @@ def test_shard_chains_is_a_partition():
         assert parts[0][0] == 0 and sum(c for _, c in parts) == n
         for (o1, c1), (o2, _) in zip(parts, parts[1:]):
             assert o1 + c1 == o2
+
+
+def test_custom_target_source_compiles_without_a_gpu():
+    """klara_check_custom_target: the user's closures are compiled for gfx950 exactly as klara_create would (hiprtc needs no
+    device), so a source error is reported with the user's own line numbers before a job is ever submitted."""
+    import cases
+    for sampler, d, src in ((L.SAMPLER_MALA, 3, cases.SRC_NEGDOT), (L.SAMPLER_HMC, 32, cases.SRC_QUARTIC_CHAIN),
+                            (L.SAMPLER_MH, 2, cases.SRC_BANANA_LT_ONLY), (L.SAMPLER_SLICE, 4, cases.SRC_LOGIT)):
+        K.CustomTarget(d, src).check(sampler)
+    with pytest.raises(K.KlaraError) as ei:
+        K.CustomTarget(2, "KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long n)\n{\n    return x[0] +;\n}").check(L.SAMPLER_MH)
+    assert ei.value.status == L.ERR_COMPILE and "klara_user_target:3" in ei.value.log
+    with pytest.raises(K.KlaraError) as ei:               # MALA / HMC need the gradient closure
+        K.CustomTarget(2, cases.SRC_BANANA_LT_ONLY).check(L.SAMPLER_HMC)
+    assert ei.value.status == L.ERR_COMPILE and "klara_user_gradlogtarget" in ei.value.log
+    with pytest.raises(K.KlaraError) as ei:
+        K.CustomTarget(40, cases.SRC_NEGDOT).check(L.SAMPLER_MH)
+    assert ei.value.status == L.ERR_UNSUPPORTED
