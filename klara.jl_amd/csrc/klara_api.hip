@@ -11,6 +11,11 @@
 #include <vector>
 #include "klara_launch.h"
 
+// user-defined targets keep the whole vector in one lane (klara_custom.h): pow2ceil(D) elements per lane
+#ifndef KLARA_CUSTOM_MAXD
+#define KLARA_CUSTOM_MAXD 64
+#endif
+
 #define HIPCHK(expr)                                                                   \
     do {                                                                               \
         hipError_t e__ = (expr);                                                       \
@@ -98,7 +103,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     *kind = 0;
     if (d.target == KLARA_TARGET_CUSTOM) {       // one chain per lane, the whole vector in registers (klara_custom.h)
         *G = 1; *E = pow2ceil(D < 2 ? 2 : D);
-        return D <= 32 ? KLARA_OK : KLARA_ERR_UNSUPPORTED;
+        return D <= KLARA_CUSTOM_MAXD ? KLARA_OK : KLARA_ERR_UNSUPPORTED;
     }
     if (d.target == KLARA_TARGET_LOGISTIC) {
         *G = 1;   // every lane holds the whole parameter vector; klara_create may turn on the row split (kind 2)
@@ -1166,7 +1171,7 @@ extern "C" klara_status klara_selftest_mfma_f64_4x4x4(int32_t device, const doub
 extern "C" klara_status klara_check_custom_target(const char* src, int32_t sampler, int32_t ndims)
 {
     if (!src || sampler < KLARA_SAMPLER_MH || sampler > KLARA_SAMPLER_SLICE || ndims <= 0) return KLARA_ERR_INVALID_ARG;
-    if (ndims > 32) return KLARA_ERR_UNSUPPORTED;
+    if (ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
     const int modes[1] = { 0 };
     return klara_jit_create(src, sampler, ndims, pow2ceil(ndims < 2 ? 2 : ndims), modes, 1, false, nullptr);
 }

@@ -21,7 +21,7 @@ def rate(target, n, x0, steps=400, **kw):
 
 
 n = 1 << 20
-for d in (3, 10, 32):
+for d in (3, 10, 32, 64):
     x0 = np.random.default_rng(1).standard_normal((n, d)) * 0.5
     for name, tgt in (("built-in diag", K.GaussDiagTarget.negdot(d)), ("user source ", K.CustomTarget(d, cases.SRC_NEGDOT))):
         r, lay, tc = rate(tgt, n, x0, sampler=L.SAMPLER_MALA, driftstep=0.5)

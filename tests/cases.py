@@ -328,9 +328,15 @@ def make_case(name):
     elif name == "custom_quartic_mala_d20_pooled":
         c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(20, SRC_QUARTIC_CHAIN, [0.05, 0.3]), nchains=48, nsteps=130, burnin=100,
                  driftstep=0.2, tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.574, period=20)
-    elif name == "custom_quartic_hmc_d32":    # the largest user-defined dimension: 32 elements per lane
+    elif name == "custom_quartic_hmc_d32":    # 32 elements per lane: still register-resident
         c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(32, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=70, nsteps=25, burnin=5,
                  leapstep=0.1, nleaps=4)
+    elif name == "custom_quartic_mala_d64":   # the largest user-defined dimension: 64 elements per lane (scratch-backed)
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(64, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=70, nsteps=20, burnin=5,
+                 driftstep=0.05)
+    elif name == "custom_quartic_hmc_d50":
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(50, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=33, nsteps=12, burnin=2,
+                 leapstep=0.08, nleaps=5)
     elif name == "custom_quartic_slice_d7":
         c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget(7, SRC_QUARTIC_CHAIN, [0.1, 0.4]), nchains=66, nsteps=12, burnin=2,
                  slice_widths=np.full(7, 1.5))
@@ -354,7 +360,8 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
              "slice_d20_stepout", "mh_rats", "mala_rats_tuned"] + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
-             "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7"]
+             "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
+             "custom_quartic_mala_d64", "custom_quartic_hmc_d50"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",

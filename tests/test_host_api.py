@@ -186,5 +186,5 @@ def test_custom_target_source_compiles_without_a_gpu():
         K.CustomTarget(2, cases.SRC_BANANA_LT_ONLY).check(L.SAMPLER_HMC)
     assert ei.value.status == L.ERR_COMPILE and "klara_user_gradlogtarget" in ei.value.log
     with pytest.raises(K.KlaraError) as ei:
-        K.CustomTarget(40, cases.SRC_NEGDOT).check(L.SAMPLER_MH)
+        K.CustomTarget(65, cases.SRC_NEGDOT).check(L.SAMPLER_MH)
     assert ei.value.status == L.ERR_UNSUPPORTED
