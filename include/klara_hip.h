@@ -170,6 +170,9 @@ typedef struct klara_desc {
     const char*   custom_src;    /* CUSTOM: NUL-terminated source text (see KLARA_TARGET_CUSTOM)     */
     const double* custom_data;   /* CUSTOM: read-only data block handed to the user functions, or NULL */
     int64_t  custom_ndata;       /* CUSTOM: doubles in custom_data                                   */
+    int64_t  bm_batchlen;        /* > 0: streaming batch means over the saved samples (needs KLARA_MON_SUMMARIES):
+                                    every bm_batchlen saved samples a batch of every (chain, dimension) series is closed on
+                                    device; klara_get_chain_bm then gives mcvar(:bm) (mcvar.jl:35-41) with no stored history */
 
     uint64_t seed;               /* Philox key                                                       */
     uint32_t monitor;            /* KLARA_MON_* bits                                                 */
@@ -248,6 +251,11 @@ klara_status klara_get_chain_fields(klara_handle* h, int64_t local_chain, double
  * ess = n * iid / imse and iact = imse / iid (src/stats/convergence/{ess,iact}.jl:3) follow on the host. */
 klara_status klara_get_chain_mcvar(klara_handle* h, int64_t batchlen, int64_t maxlag, double* mcvar_iid,
                                    double* mcvar_bm, double* mcvar_imse);
+/* Streaming form of mcvar(v, Val{:bm}) (src/stats/variance/mcvar.jl:35-41: batchlen * var(batch means) / (nbatches *
+ * batchlen)) for klara_desc.bm_batchlen > 0: batch means are formed from the running sums at every batch boundary and
+ * their mean / sum of squared deviations are updated in place (Welford), so no history is stored — 3 x nchains x ndims
+ * doubles however long the run.  mcvar_bm is nchains x ndims (NaN while fewer than two batches are closed). */
+klara_status klara_get_chain_bm(klara_handle* h, double* mcvar_bm, int64_t* nbatches_out);
 /* tuner state per chain (tuners.jl:5-10). In pooled mode every chain reports the shared state. */
 klara_status klara_get_tune(klara_handle* h, double* step, int64_t* accepted, int64_t* proposed,
                             int64_t* totproposed);

@@ -17,7 +17,7 @@ struct KlaraDesc
     logit_X::Ptr{Float64}; logit_y::Ptr{Float64}; logit_ndata::Int32; nstreams::Int32; logit_lambda::Float64
     hier_Y::Ptr{Float64}; hier_xc::Ptr{Float64}; hier_nunits::Int32; hier_ntimes::Int32
     hier_prior_prec::Float64; hier_gamma_a::Float64; hier_gamma_b::Float64
-    custom_src::Cstring; custom_data::Ptr{Float64}; custom_ndata::Int64
+    custom_src::Cstring; custom_data::Ptr{Float64}; custom_ndata::Int64; bm_batchlen::Int64
     seed::UInt64; monitor::UInt32; steps_per_launch::Int32; stream::Ptr{Cvoid}
 end
 

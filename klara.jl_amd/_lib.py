@@ -47,7 +47,7 @@ class KlaraDesc(C.Structure):
         ("logit_lambda", C.c_double),
         ("hier_Y", _dp), ("hier_xc", _dp), ("hier_nunits", C.c_int32), ("hier_ntimes", C.c_int32),
         ("hier_prior_prec", C.c_double), ("hier_gamma_a", C.c_double), ("hier_gamma_b", C.c_double),
-        ("custom_src", C.c_char_p), ("custom_data", _dp), ("custom_ndata", C.c_int64),
+        ("custom_src", C.c_char_p), ("custom_data", _dp), ("custom_ndata", C.c_int64), ("bm_batchlen", C.c_int64),
         ("seed", C.c_uint64), ("monitor", C.c_uint32), ("steps_per_launch", C.c_int32),
         ("stream", C.c_void_p),
     ]
@@ -71,7 +71,7 @@ EXPORTS = [
     "klara_create", "klara_destroy", "klara_set_state", "klara_init_state_normal", "klara_run",
     "klara_run_async", "klara_synchronize", "klara_reset", "klara_get_state", "klara_get_accept_mask",
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
-    "klara_get_chain_fields", "klara_get_chain_mcvar", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
+    "klara_get_chain_fields", "klara_get_chain_mcvar", "klara_get_chain_bm", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
     "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
     "klara_comm_unique_id", "klara_comm_init", "klara_comm_destroy", "klara_gather_summaries",
     "klara_check_custom_target", "klara_compile_log", "klara_abi_version",
@@ -125,6 +125,7 @@ def load() -> C.CDLL:
         "klara_gather_summaries": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "klara_check_custom_target": [C.c_char_p, C.c_int32, C.c_int32],
+        "klara_get_chain_bm": [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)

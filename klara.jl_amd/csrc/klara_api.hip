@@ -43,6 +43,8 @@ struct klara_handle {
            *hY = nullptr, *hxc = nullptr;
     double* pooled_out = nullptr;   // 2*D doubles + 1 u64 scratch for pooled summaries
     double* cdata = nullptr; KlaraJit* jit = nullptr;   // user-defined target: data block, run-time compiled kernels
+    // streaming batch means (bm_batchlen > 0): running sum at the last batch boundary, Welford mean / M2 of the batch means
+    double *bm_prev = nullptr, *bm_mean = nullptr, *bm_m2 = nullptr; long long bm_count = 0;
     KParams* d_params = nullptr;    // device copy of the handle's static kernel parameters
     double lpconst = 0.0;
     // run state
@@ -182,6 +184,7 @@ static klara_status validate(const klara_desc* d)
         return KLARA_ERR_INVALID_ARG;
     if (d->target == KLARA_TARGET_CUSTOM && (!d->custom_src || d->custom_ndata < 0 || (d->custom_ndata > 0 && !d->custom_data)))
         return KLARA_ERR_INVALID_ARG;
+    if (d->bm_batchlen < 0 || (d->bm_batchlen > 0 && !(d->monitor & KLARA_MON_SUMMARIES))) return KLARA_ERR_INVALID_ARG;
     if (d->steps_per_launch < 0 || d->tuner_score < 0 || d->tuner_score > 1) return KLARA_ERR_INVALID_ARG;
     return KLARA_OK;
 }
@@ -203,6 +206,7 @@ static void free_all(klara_handle* h)
     hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->hist); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->err);
     hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
     hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->d_params); hipFree(h->cdata);
+    hipFree(h->bm_prev); hipFree(h->bm_mean); hipFree(h->bm_m2);
     klara_jit_destroy(h->jit);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -290,6 +294,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     CKH(dalloc(&h->err, 1)); CKH(dalloc(&h->pooled_out, 2 * D + 2));
     CKH(hipMemset(h->err, 0, sizeof(int)));
     if (desc->monitor & KLARA_MON_SUMMARIES) { CKH(dalloc(&h->sum, N * D)); CKH(dalloc(&h->sumsq, N * D)); }
+    if (desc->bm_batchlen > 0) { CKH(dalloc(&h->bm_prev, N * D)); CKH(dalloc(&h->bm_mean, N * D)); CKH(dalloc(&h->bm_m2, N * D)); }
     if (desc->monitor & KLARA_MON_ACCEPT) {
         h->accept_cap = desc->nsteps;
         CKH(dalloc(&h->accept, (size_t)desc->nsteps * N));
@@ -488,6 +493,11 @@ static klara_status init_common(klara_handle* h)
     HIPCHK(hipMemsetAsync(h->pooled_acc, 0, sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(h->GR, 0, N * D * sizeof(double), st));
     if (h->sum) { HIPCHK(hipMemsetAsync(h->sum, 0, N * D * sizeof(double), st)); HIPCHK(hipMemsetAsync(h->sumsq, 0, N * D * sizeof(double), st)); }
+    if (h->bm_prev) {
+        HIPCHK(hipMemsetAsync(h->bm_prev, 0, N * D * sizeof(double), st)); HIPCHK(hipMemsetAsync(h->bm_mean, 0, N * D * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(h->bm_m2, 0, N * D * sizeof(double), st));
+    }
+    h->bm_count = 0;
     // tuner_state: samplers.jl:29-45 — step per sampler, accepted = proposed = 0, totproposed = period
     const double step0 = d.sampler == KLARA_SAMPLER_MH ? 1.0
                        : d.sampler == KLARA_SAMPLER_MALA ? d.driftstep
@@ -606,6 +616,42 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
     }
 }
 
+// Closes one batch of every (chain, dimension) series in [i0, i1): batch mean from the running sums at the two batch
+// boundaries, then Welford's update of the mean and the sum of squared deviations of the batch means (count = batches closed
+// before this one).  mcvar.jl:35-41 takes var(batch means); the history-free form never revisits a sample.
+__global__ __launch_bounds__(256) void k_bm_close(const double* __restrict__ sum, double* __restrict__ prev, double* __restrict__ mean,
+                                                  double* __restrict__ m2, long long i0, long long i1, long long count, double batchlen)
+{
+    const long long i = i0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= i1) return;
+    const double s = sum[i];
+    const double b = (s - prev[i]) / batchlen;
+    prev[i] = s;
+    const double delta = b - mean[i];
+    const double mn = mean[i] + delta / (double)(count + 1);
+    mean[i] = mn;
+    m2[i] = m2[i] + delta * (b - mn);
+}
+
+// every partition closes its own chains on its own stream (layout kind 3 runs chain partitions on internal streams)
+static hipError_t launch_bm_close(klara_handle* h)
+{
+    const long long N = h->d.nchains, D = h->d.ndims;
+    const int np = h->kind == 3 ? h->nparts : 1;
+    const long long groups = (N + KLARA_DIAGT_CPW - 1) / KLARA_DIAGT_CPW, per = (groups + np - 1) / np;
+    for (int j = 0; j < np; ++j) {
+        long long c0 = 0, c1 = N;
+        if (np > 1) { c0 = j * per * KLARA_DIAGT_CPW; c1 = (j + 1) * per * KLARA_DIAGT_CPW; if (c1 > N) c1 = N; }
+        if (c0 >= c1) break;
+        const long long n = (c1 - c0) * D;
+        hipLaunchKernelGGL(k_bm_close, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, j == 0 ? h->stream : h->side[j - 1], h->sum,
+                           h->bm_prev, h->bm_mean, h->bm_m2, c0 * D, c1 * D, h->bm_count, (double)h->d.bm_batchlen);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
 {
     if (!h || nsteps < 0) return KLARA_ERR_INVALID_ARG;
@@ -629,6 +675,14 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
             const long long to_boundary = d.period - (h->m_prop % d.period);
             if (k > to_boundary) k = to_boundary;
         }
+        // streaming batch means: a launch ends where the next batch of saved samples closes — saved sample number S is
+        // transition burnin + (S - 1) * thinning + 1 (BasicMCRange.jl:36)
+        long long bm_close_at = -1;
+        if (h->bm_prev) {
+            bm_close_at = d.burnin + ((h->bm_count + 1) * d.bm_batchlen - 1) * d.thinning + 1;
+            if (bm_close_at > d.nsteps) bm_close_at = -1;
+            else if (bm_close_at > h->steps_done && k > bm_close_at - h->steps_done) k = bm_close_at - h->steps_done;
+        }
         KLaunch kl;
         kl.group0 = 0; kl.group_end = 0x7fffffffffffffffll;
         kl.t0 = (unsigned long long)h->steps_done;
@@ -646,6 +700,7 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
             if (h->m_tot <= d.burnin && (h->m_prop % d.period) == 0) { h->m_tot += h->m_prop; h->m_prop = 0; }
         }
         h->steps_done += k; remaining -= k; ++launches;
+        if (bm_close_at >= 0 && h->steps_done == bm_close_at) { HIPCHK(launch_bm_close(h)); ++h->bm_count; }
     }
     for (int j = 0; j + 1 < h->nparts; ++j) {              // join: the caller's stream continues when every partition is done
         HIPCHK(hipEventRecord(h->join_ev[j], h->side[j]));
@@ -1008,6 +1063,24 @@ extern "C" klara_status klara_get_chain_mcvar(klara_handle* h, int64_t batchlen,
     if (e == hipSuccess && mcvar_imse) e = hipMemcpy(mcvar_imse, buf + 2 * total, total * sizeof(double), hipMemcpyDeviceToHost);
     hipFree(buf);
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
+}
+
+extern "C" klara_status klara_get_chain_bm(klara_handle* h, double* mcvar_bm, int64_t* nbatches_out)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->bm_prev || !h->have_state) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->d.nchains * (size_t)h->d.ndims;
+    const long long nb = h->bm_count;
+    if (mcvar_bm) {
+        HIPCHK(hipMemcpy(mcvar_bm, h->bm_m2, n * sizeof(double), hipMemcpyDeviceToHost));
+        // batchlen * var(batch means) / (nbatches * batchlen)  (mcvar.jl:39-41), var = M2 / (nbatches - 1)
+        for (size_t i = 0; i < n; ++i)
+            mcvar_bm[i] = nb > 1 ? (double)h->d.bm_batchlen * (mcvar_bm[i] / (double)(nb - 1)) / (double)(nb * h->d.bm_batchlen) : (double)NAN;
+    }
+    if (nbatches_out) *nbatches_out = nb;
+    return KLARA_OK;
 }
 
 extern "C" klara_status klara_get_tune(klara_handle* h, double* step, int64_t* accepted, int64_t* proposed,

@@ -173,7 +173,7 @@ class Engine:
                  da_nadapt: int = 0, da_eps0bar: float = 1.0, da_h0bar: float = 0.0, da_gamma: float = 0.05,
                  da_t0: int = 10, da_kappa: float = 0.75,
                  seed: int = 20260927, chain_offset: int = 0, device: int = 0, monitor: int = 0,
-                 steps_per_launch: int = 0, stream: int = 0, nstreams: int = 0):
+                 steps_per_launch: int = 0, stream: int = 0, nstreams: int = 0, bm_batchlen: int = 0):
         self._lib = L.load()
         self.target = target
         self.ndims = int(target.ndims)
@@ -223,6 +223,7 @@ class Engine:
             raise TypeError(f"unknown target family {type(target).__name__}")
         d.seed, d.monitor, d.steps_per_launch = int(seed), self.monitor, int(steps_per_launch)
         d.nstreams = int(nstreams)
+        d.bm_batchlen = int(bm_batchlen)
         d.stream = C.c_void_p(int(stream)) if stream else None
         self._h = C.c_void_p()
         L.check(self._lib.klara_create(C.byref(d), C.byref(self._h)), "klara_create")
@@ -327,6 +328,12 @@ class Engine:
         L.check(self._lib.klara_get_chain_mcvar(self._h, int(batchlen), int(maxlag), out[0].ctypes.data,
                                                 out[1].ctypes.data, out[2].ctypes.data), "klara_get_chain_mcvar")
         return tuple(out)
+
+    def chain_bm(self):
+        """(mcvar_bm (nchains, ndims), nbatches): streaming batch means (bm_batchlen > 0), no stored history (mcvar.jl:35-41)."""
+        out = np.empty((self.nchains, self.ndims)); nb = C.c_int64(0)
+        L.check(self._lib.klara_get_chain_bm(self._h, out.ctypes.data, C.byref(nb)), "klara_get_chain_bm")
+        return out, int(nb.value)
 
     def tune(self):
         step = np.empty(self.nchains); a = np.empty(self.nchains, dtype=np.int64)

@@ -484,6 +484,23 @@ static int ko_slice(const ko_target_ctx* c, uint64_t chain, uint64_t t, double* 
     return 1;
 }
 
+/* Streaming batch means (klara_desc.bm_batchlen): mcvar(v, Val{:bm}) of src/stats/variance/mcvar.jl:35-41 takes
+ * var(batch means); the history-free form closes a batch from the running sums at its two boundaries and updates the mean
+ * and the sum of squared deviations of the batch means in place (Welford).  n = nchains * D series, count = batches closed
+ * before this call. */
+void ko_bm_close(const double* sum, double* prev, double* mean, double* m2, int64_t n, int64_t count, int64_t batchlen)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const double s = sum[i];
+        const double b = (s - prev[i]) / (double)batchlen;
+        prev[i] = s;
+        const double delta = b - mean[i];
+        const double mn = mean[i] + delta / (double)(count + 1);
+        mean[i] = mn;
+        m2[i] = m2[i] + delta * (b - mn);
+    }
+}
+
 /* ------------------------------------------------------------------ public entry points */
 static void ko_ctx_init(ko_target_ctx* c, const klara_desc* d, const ko_layout* L)
 {

@@ -53,6 +53,8 @@ def load() -> C.CDLL:
     lib.ko_u52.restype = C.c_double
     lib.ko_eval_target.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout), vp, vp, vp]
     lib.ko_eval_target.restype = C.c_int
+    lib.ko_bm_close.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64]
+    lib.ko_bm_close.restype = None
     lib.ko_set_custom_target.argtypes = [vp, vp]
     lib.ko_set_custom_target.restype = None
     for name in ("ko_logistic",):
@@ -244,6 +246,24 @@ class OracleJob:
         if acc is not None:
             self.accept = np.concatenate([self.accept, acc], axis=0)
         return st
+
+    def run_with_batch_means(self, nsteps: int, batchlen: int):
+        """Steps to nsteps, closing a batch of saved samples every `batchlen` of them (klara_desc.bm_batchlen);
+        returns (mcvar_bm (N x D), nbatches) — mcvar.jl:35-41."""
+        d = self.desc
+        prev = np.zeros_like(self.sum); mean = np.zeros_like(self.sum); m2 = np.zeros_like(self.sum)
+        nb = 0
+        while self.t < nsteps:
+            close_at = d.burnin + ((nb + 1) * batchlen - 1) * d.thinning + 1
+            k = nsteps - self.t
+            if self.t < close_at <= d.nsteps:
+                k = min(k, close_at - self.t)
+            assert self.run(k) == 0
+            if self.t == close_at and close_at <= d.nsteps:
+                self.lib.ko_bm_close(self._p(self.sum), self._p(prev), self._p(mean), self._p(m2), self.sum.size, nb, int(batchlen))
+                nb += 1
+        mcvar = batchlen * (m2 / (nb - 1)) / (nb * batchlen) if nb > 1 else np.full_like(m2, np.nan)
+        return mcvar, nb
 
     def eval_target(self, x):
         x = _f64(x).ravel()

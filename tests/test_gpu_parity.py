@@ -656,6 +656,57 @@ def test_readme_flow_basic_mc_job():
     job.close()
 
 
+# ------------------------------------------------------------------ streaming batch means
+@pytest.mark.parametrize("name,batchlen,streams", [("mala_d100", 7, 0), ("dt_hmc_d100", 5, 2), ("hmc_dense_d37", 6, 0),
+                                                    ("mala_swiss", 9, 0), ("hmc_rats", 4, 0), ("slice_d5", 3, 0),
+                                                    ("custom_banana_hmc", 8, 0)])
+def test_streaming_batch_means(name, batchlen, streams):
+    """klara_desc.bm_batchlen: mcvar(:bm) (mcvar.jl:35-41) without stored history.  Bit-exact against the oracle closing the
+    same batches from the same running sums, and equal (to rounding) to the post-hoc estimator over the stored history —
+    on every layout kind, across launch splitting, thinning and chain partitions on two streams."""
+    c = dict(cases.make_case(name)); c.update(nsteps=max(c["nsteps"], 120), thinning=2, burnin=11)
+    if c.get("da_nadapt"):
+        c["da_nadapt"] = 40
+    eng = K.Engine(**cases.engine_kwargs(c, monitor=L.MON_SUMMARIES | L.MON_HISTORY, bm_batchlen=batchlen, steps_per_launch=7,
+                                         nstreams=streams))
+    eng.set_state(c["x0"]) if c.get("x0") is not None else eng.init_state_normal()
+    xstart = eng.state()[0]
+    eng.run(50); eng.run(c["nsteps"] - 50)                 # a batch boundary inside each call and across the two
+    bm, nb = eng.chain_bm()
+    nsaved = (c["nsteps"] - 11 - 1) // 2 + 1
+    assert nb == nsaved // batchlen and nb >= 2
+    job = O.OracleJob(**cases.oracle_kwargs(c, layout=eng.layout()))
+    job.set_state(c["x0"]) if c.get("x0") is not None else job.init_state_normal()
+    obm, onb = job.run_with_batch_means(c["nsteps"], batchlen)
+    assert onb == nb and np.array_equal(bm, obm)
+    posthoc = eng.chain_mcvar(batchlen, 0)[1]              # k_chain_stats over the history: first nb*batchlen samples, two-pass
+    assert np.allclose(bm, posthoc, rtol=1e-8, atol=1e-24)   # (a chain that never moved: 0 against rounding noise of 1e-32)
+    # reset clears the accumulators; other launch boundaries, same batches
+    eng.reset(xstart); eng.run(c["nsteps"])
+    bm2, nb2 = eng.chain_bm()
+    assert nb2 == nb and np.array_equal(bm2, bm)
+    eng.close()
+
+
+def test_streaming_batch_means_errors():
+    with pytest.raises(K.KlaraError) as ei:                # needs the running sums
+        K.Engine(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(2), nchains=4, nsteps=50, mh_sigma=[1.0, 1.0], bm_batchlen=5)
+    assert ei.value.status == L.ERR_INVALID_ARG
+    eng = K.Engine(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(2), nchains=4, nsteps=50, mh_sigma=[1.0, 1.0],
+                   monitor=L.MON_SUMMARIES)
+    eng.set_state(np.zeros((4, 2))); eng.run(10)
+    with pytest.raises(K.KlaraError) as ei:
+        eng.chain_bm()
+    assert ei.value.status == L.ERR_STATE
+    eng.close()
+    eng = K.Engine(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(2), nchains=4, nsteps=50, mh_sigma=[1.0, 1.0],
+                   monitor=L.MON_SUMMARIES, bm_batchlen=30)
+    eng.set_state(np.zeros((4, 2))); eng.run(50)
+    bm, nb = eng.chain_bm()
+    assert nb == 1 and np.isnan(bm).all()                  # "Choose batch size such that the number of batches is > 1"
+    eng.close()
+
+
 # ------------------------------------------------------------------ user-defined targets (KLARA_TARGET_CUSTOM)
 def _run_engine(case, **over):
     eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_ACCEPT | L.MON_SUMMARIES, **over))
