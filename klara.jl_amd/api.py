@@ -249,7 +249,10 @@ def mcvar_iid(chains: MuvChains) -> np.ndarray:
 def chain_mcvar(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, maxlag: int = 0) -> np.ndarray:
     """mcvar(s, Val{vtype}) for EVERY chain and dimension at once, computed on device over the stored history
     (stats/variance/mcvar.jl:5,35-41,75-105).  Returns (nchains x D); vtype in {"iid", "bm", "imse"}."""
-    iid, bm, imse = chains._job.engine.chain_mcvar(batchlen, maxlag)
+    job = chains._job
+    if vtype == "bm" and job.bm_batchlen == batchlen and not (job.engine.monitor & L.MON_HISTORY):
+        return job.engine.chain_bm()[0]            # streaming batch means: no history was stored
+    iid, bm, imse = job.engine.chain_mcvar(batchlen, maxlag)
     return {"iid": iid, "bm": bm, "imse": imse}[vtype]
 
 
@@ -279,12 +282,14 @@ class BasicMCJob:
 
     outopts keys follow jobs.jl:9-43: destination in {"nstate", "none"}, monitor (["value"]),
     diagnostics ([] or ["accept"]).  Extra keyword arguments pick the shard: `chain_offset` (global id of
-    the first chain), `device`, `seed`, `steps_per_launch`.
+    the first chain), `device`, `seed`, `steps_per_launch`; `bm_batchlen` > 0 keeps streaming batch means so that
+    `chain_mcvar(chain, "bm", bm_batchlen)` needs no stored history (destination "none").
     """
 
     def __init__(self, model: GenericModel, sampler: MCSampler, mcrange: BasicMCRange, v0: Dict[str, Sequence],
                  tuner: Optional[MCTuner] = None, outopts: Optional[dict] = None, *, seed: int = 20260927,
-                 chain_offset: int = 0, device: int = 0, steps_per_launch: int = 0, summaries: bool = True):
+                 chain_offset: int = 0, device: int = 0, steps_per_launch: int = 0, summaries: bool = True,
+                 bm_batchlen: int = 0):
         self.model, self.sampler, self.range = model, sampler, mcrange
         self.tuner = tuner if tuner is not None else VanillaMCTuner()
         self.outopts = dict(outopts) if outopts is not None else {}
@@ -327,7 +332,8 @@ class BasicMCJob:
         kw = dict(sampler=sampler.kind, target=self.parameter.target, nchains=nchains, nsteps=mcrange.nsteps,
                   burnin=mcrange.burnin, thinning=mcrange.thinning, tuner=self.tuner.kind,
                   period=self.tuner.period, verbose=self.tuner.verbose, seed=seed, chain_offset=chain_offset,
-                  device=device, monitor=monitor, steps_per_launch=steps_per_launch)
+                  device=device, monitor=monitor, steps_per_launch=steps_per_launch, bm_batchlen=int(bm_batchlen))
+        self.bm_batchlen = int(bm_batchlen)
         if isinstance(sampler, MH):
             kw["mh_sigma"] = sampler.sigma
         elif isinstance(sampler, MALA):

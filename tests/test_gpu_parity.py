@@ -688,6 +688,22 @@ def test_streaming_batch_means(name, batchlen, streams):
     eng.close()
 
 
+def test_streaming_batch_means_through_the_job_api():
+    """mcvar(chain, :bm) for 4,096 chains with destination none (nothing stored): the Monte Carlo standard error of the
+    chain means predicts the spread of those means across independent chains."""
+    p = K.BasicContMuvParameter("p", logtarget=K.GaussDiagTarget.negdot(3))
+    job = K.BasicMCJob(K.likelihood_model(p, False), K.MALA(0.9), K.BasicMCRange(nsteps=6000, burnin=1000),
+                       {"p": np.zeros((4096, 3))}, outopts={"destination": "none"}, bm_batchlen=100)
+    K.run(job)
+    chain = K.output(job)
+    v = K.chain_mcvar(chain, "bm", 100)                    # (chains, D): variance of each chain's mean
+    means = K.mean(chain)
+    assert v.shape == (4096, 3) and job.engine.chain_bm()[1] == 50
+    ratio = means.var(axis=0) / v.mean(axis=0)             # batch means slightly underestimate at finite batch length
+    assert np.all((0.9 < ratio) & (ratio < 1.25)), ratio
+    job.close()
+
+
 def test_streaming_batch_means_errors():
     with pytest.raises(K.KlaraError) as ei:                # needs the running sums
         K.Engine(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(2), nchains=4, nsteps=50, mh_sigma=[1.0, 1.0], bm_batchlen=5)
