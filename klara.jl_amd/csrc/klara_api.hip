@@ -427,8 +427,6 @@ static size_t lds_for(const klara_handle* h)
 {
     if (h->kind != 1 && h->d.target == KLARA_TARGET_LOGISTIC)
         return sizeof(double) * (size_t)h->d.logit_ndata * (size_t)(h->d.ndims + 1);
-    if (h->kind == 0 && h->d.target == KLARA_TARGET_HIER_NORMAL)
-        return sizeof(double) * ((size_t)h->d.hier_nunits * (size_t)h->d.hier_ntimes + (size_t)h->d.hier_ntimes);
     return 0;
 }
 

@@ -30,7 +30,9 @@ struct HierLane {
     bool rv[RPL];              // unit RPL*q + k exists
     unsigned roff[RPL];        // byte offset of (a_i, b_i) inside the wavefront's chain window (OOB for missing units)
     unsigned hoff;             // byte offset of the hyper block (same for the 8 lanes of a chain)
-    double Y[RPL][NT], xc[NT]; // this lane's observations and the centred covariate
+    // sufficient statistics of this lane's units (sum_j y, -2 sum_j y, sum_j y x, -2 sum_j y x, sum_j y^2) and of the centred
+    // covariate (sum_j x, sum_j x^2): the residual sums of an evaluation are formed from these, not from the observations
+    double Sy[RPL], m2Sy[RPL], Sxy[RPL], m2Sxy[RPL], Syy[RPL], X1, X2, Td;
     double p0, a0, b0;
 };
 
@@ -43,15 +45,22 @@ __device__ __forceinline__ HierLane<RPL, NT> make_hlane(const KParams& p)
     c.cw = c.lane / KLARA_HIERT_Q;
     c.R = p.hR; c.D = p.D;
     c.p0 = p.hp0; c.a0 = p.ha0; c.b0 = p.hb0;
+    double xc[NT];
+    c.X1 = 0.0; c.X2 = 0.0; c.Td = (double)NT;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) c.xc[j] = p.hxc[j];
+    for (int j = 0; j < NT; ++j) { xc[j] = p.hxc[j]; c.X1 = c.X1 + xc[j]; c.X2 = kd_fma(xc[j], xc[j], c.X2); }
 #pragma unroll
     for (int k = 0; k < RPL; ++k) {
         const int r = RPL * c.q + k;
         c.rv[k] = r < c.R;
         c.roff[k] = c.rv[k] ? (unsigned)((c.cw * c.D + 2 * r) * 8) : KLARA_BUF_OOB;
+        double sy = 0.0, sxy = 0.0, syy = 0.0;               // (a missing unit: all zero)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) c.Y[k][j] = c.rv[k] ? p.hY[r * NT + j] : 0.0;
+        for (int j = 0; j < NT; ++j) {
+            const double y = c.rv[k] ? p.hY[r * NT + j] : 0.0;
+            sy = sy + y; sxy = kd_fma(y, xc[j], sxy); syy = kd_fma(y, y, syy);
+        }
+        c.Sy[k] = sy; c.m2Sy[k] = -2.0 * sy; c.Sxy[k] = sxy; c.m2Sxy[k] = -2.0 * sxy; c.Syy[k] = syy;
     }
     c.hoff = (unsigned)((c.cw * c.D + 2 * c.R) * 8);
     return c;
@@ -104,13 +113,14 @@ __device__ __forceinline__ double hier_eval(const HierLane<RPL, NT>& c, const Hi
         // a missing unit (the last lane of a chain when R % 4 != 0) is masked once, at its five per-unit quantities: its
         // sums and its gradient are then exactly 0, so its momentum and value stay 0 and it never enters a sum
         const double da = c.rv[k] ? ai - ac : 0.0, db = c.rv[k] ? bi - bc : 0.0;
-        double S1 = 0.0, Sx = 0.0, S2 = 0.0;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const double xj = c.xc[j];
-            const double r = (c.Y[k][j] - ai) - bi * xj;       // (missing unit: Y = a = b = 0, so r = S1 = Sx = S2 = 0)
-            S1 = S1 + r; Sx = Sx + r * xj; S2 = S2 + r * r;
-        }
+        // residual sums r_j = y_j - a - b x_j from the unit's sufficient statistics (oracle ko_hier_eval):
+        //   sum r = Sy - T a - b X1;  sum r x = Sxy - a X1 - b X2;  sum r^2 = Syy + a (T a - 2 Sy) + b (b X2 + 2 a X1 - 2 Sxy)
+        // (missing unit: statistics = a = b = 0, so all three are 0)
+        const double S1 = kd_fma(-bi, c.X1, kd_fma(-c.Td, ai, c.Sy[k]));
+        const double Sx = kd_fma(-bi, c.X2, kd_fma(-ai, c.X1, c.Sxy[k]));
+        const double u = kd_fma(c.Td, ai, c.m2Sy[k]);
+        const double v = kd_fma(bi, c.X2, kd_fma(2.0 * ai, c.X1, c.m2Sxy[k]));
+        const double S2 = kd_fma(bi, v, kd_fma(ai, u, c.Syy[k]));
         if (WANT_GRAD) { g.a[k] = wc * S1 - wa * da; g.b[k] = wc * Sx - wb * db; }
         red[0] = red[0] + da;       red[1] = red[1] + db;
         red[2] = red[2] + da * da;  red[3] = red[3] + db * db;

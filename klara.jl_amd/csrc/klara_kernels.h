@@ -416,43 +416,34 @@ struct LogisticTarget {
 
 // KLARA_TARGET_HIER_NORMAL (BUGS "Rats", builder-defined — include/klara_hip.h, oracle ko_hier_eval).
 // theta = (a_1, b_1, ..., a_R, b_R, a_c, b_c, s_c, s_a, s_b): a lane's E contiguous elements are E/2 whole rats
-// (or part of the 5-element hyper block), so the residual sums of a rat are lane-local; the data (R x T
-// observations, T centred ages) sit in LDS.  Per evaluation: the five hyper-parameters are broadcast from their
+// (or part of the 5-element hyper block), so the residual sums of a rat are lane-local and are formed from the rat's
+// sufficient statistics (sum y, sum y x, sum y^2 — registers, computed once per launch).  Per evaluation: the five hyper-parameters are broadcast from their
 // owner lanes (ds_bpermute), the three precisions exp(-2 s_k) are evaluated ONCE per group (lane l takes k = l % 3,
 // results broadcast back) and the five sums over rats go through one 5-value butterfly.
 template <int E>
 struct HierTarget {
-    const double* sY; const double* sxc;
     int R, T, i0, hl[5], he[5];          // owner lane (within the group) and element slot of each hyper-parameter
     double p0, a0, b0;
-    // T <= 8 (rats: 5): the lane's own observation rows and the centred covariate live in registers for the whole
-    // kernel, so an evaluation touches LDS only for the cross-lane traffic
-    static constexpr int TR = 8;
-    double yreg[E / 2][TR], xreg[TR];
-    bool regpath;
-    static __device__ __forceinline__ size_t lds_bytes(const KParams& p)
+    // sufficient statistics of the lane's own units and of the centred covariate (oracle ko_hier_eval)
+    double Sy[E / 2], Sxy[E / 2], Syy[E / 2], X1, X2, Td;
+    static __device__ __forceinline__ size_t lds_bytes(const KParams&) { return 0; }
+    __device__ __forceinline__ void init(const KParams& p, const LaneCtx<E>& cx, double*)
     {
-        return sizeof(double) * ((size_t)p.hR * (size_t)p.hT + (size_t)p.hT);
-    }
-    __device__ __forceinline__ void init(const KParams& p, const LaneCtx<E>& cx, double* lds)
-    {
-        double* Y = lds; double* xc = lds + (size_t)p.hR * p.hT;
-        for (int i = threadIdx.x; i < p.hR * p.hT; i += blockDim.x) Y[i] = p.hY[i];
-        for (int i = threadIdx.x; i < p.hT; i += blockDim.x) xc[i] = p.hxc[i];
-        __syncthreads();
-        sY = Y; sxc = xc; R = p.hR; T = p.hT; p0 = p.hp0; a0 = p.ha0; b0 = p.hb0; i0 = cx.i0;
+        R = p.hR; T = p.hT; p0 = p.hp0; a0 = p.ha0; b0 = p.hb0; i0 = cx.i0;
 #pragma unroll
         for (int k = 0; k < 5; ++k) { hl[k] = (2 * R + k) / E; he[k] = (2 * R + k) % E; }
-        regpath = T <= TR;
+        X1 = 0.0; X2 = 0.0; Td = (double)T;
+        for (int j = 0; j < T; ++j) { const double xj = p.hxc[j]; X1 = X1 + xj; X2 = kd_fma(xj, xj, X2); }
 #pragma unroll
-        for (int j = 0; j < TR; ++j) {
-            xreg[j] = (regpath && j < T) ? xc[j] : 0.0;
-#pragma unroll
-            for (int pr = 0; pr < E / 2; ++pr) {
-                const int ia = i0 + 2 * pr;
-                const int rat = ia < 2 * R ? (ia >> 1) : 0;
-                yreg[pr][j] = (regpath && j < T) ? Y[rat * T + j] : 0.0;
+        for (int pr = 0; pr < E / 2; ++pr) {
+            const int ia = i0 + 2 * pr;
+            const int rat = ia < 2 * R ? (ia >> 1) : 0;
+            double sy = 0.0, sxy = 0.0, syy = 0.0;
+            for (int j = 0; j < T; ++j) {
+                const double y = p.hY[rat * T + j];
+                sy = sy + y; sxy = kd_fma(y, p.hxc[j], sxy); syy = kd_fma(y, y, syy);
             }
+            Sy[pr] = sy; Sxy[pr] = sxy; Syy[pr] = syy;
         }
     }
     template <bool WANT_LT, bool WANT_GRAD>
@@ -486,24 +477,12 @@ struct HierTarget {
             const int rat = israt ? (ia >> 1) : 0;
             const double ai = x[2 * pr], bi = x[2 * pr + 1];
             const double da = ai - ac, db = bi - bc;
-            double S1 = 0.0, Sx = 0.0, S2 = 0.0;
-            if (regpath) {
-#pragma unroll
-                for (int j = 0; j < TR; ++j) {
-                    if (j < T) {
-                        const double xj = xreg[j];
-                        const double r = (yreg[pr][j] - ai) - bi * xj;
-                        S1 = S1 + r; Sx = Sx + r * xj; S2 = S2 + r * r;
-                    }
-                }
-            } else {
-                const double* yrow = sY + rat * T;
-                for (int j = 0; j < T; ++j) {
-                    const double xj = sxc[j];
-                    const double r = (yrow[j] - ai) - bi * xj;
-                    S1 = S1 + r; Sx = Sx + r * xj; S2 = S2 + r * r;
-                }
-            }
+            // sum r, sum r x, sum r^2 of r_j = y_j - a - b x_j from the unit's sufficient statistics
+            const double S1 = kd_fma(-bi, X1, kd_fma(-Td, ai, Sy[pr]));
+            const double Sx = kd_fma(-bi, X2, kd_fma(-ai, X1, Sxy[pr]));
+            const double u = kd_fma(Td, ai, -2.0 * Sy[pr]);
+            const double v = kd_fma(bi, X2, kd_fma(2.0 * ai, X1, -2.0 * Sxy[pr]));
+            const double S2 = kd_fma(bi, v, kd_fma(ai, u, Syy[pr]));
             if (WANT_GRAD) { g[2 * pr] = wc * S1 - wa * da; g[2 * pr + 1] = wc * Sx - wb * db; }
             // element order within the lane: a-slot terms then b-slot terms, exactly the oracle's term arrays
             red[0] = red[0] + (israt ? da : 0.0);        red[1] = red[1] + 0.0;

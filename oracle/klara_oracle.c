@@ -212,15 +212,25 @@ static double ko_hier_eval(const ko_target_ctx* c, const double* th, double* g, 
     double tA1[KO_MAXD], tB1[KO_MAXD], tA2[KO_MAXD], tB2[KO_MAXD], tC2[KO_MAXD];
     (void)scratch;
     for (int i = 0; i < D; ++i) tA1[i] = tB1[i] = tA2[i] = tB2[i] = tC2[i] = 0.0;
+    /* The residuals r_ij = Y_ij - a_i - b_i xc_j enter only through three sums per unit, which are formed from the
+     * unit's sufficient statistics (ascending j):  sum r = Sy - T a - b X1,  sum r x = Sxy - a X1 - b X2,
+     * sum r^2 = Syy + a (T a - 2 Sy) + b (b X2 + 2 a X1 - 2 Sxy),  with X1 = sum x, X2 = sum x^2. */
+    double X1 = 0.0, X2 = 0.0;
+    const double Td = (double)T;
+    for (int j = 0; j < T; ++j) { X1 = X1 + d->hier_xc[j]; X2 = kd_fma(d->hier_xc[j], d->hier_xc[j], X2); }
     for (int i = 0; i < R; ++i) {
         const double ai = th[2 * i], bi = th[2 * i + 1];
         const double da = ai - ac, db = bi - bc;
-        double S1 = 0.0, Sx = 0.0, S2 = 0.0;
+        double Sy = 0.0, Sxy = 0.0, Syy = 0.0;
         for (int j = 0; j < T; ++j) {
-            const double xj = d->hier_xc[j];
-            const double r = (d->hier_Y[i * T + j] - ai) - bi * xj;
-            S1 = S1 + r; Sx = Sx + r * xj; S2 = S2 + r * r;
+            const double y = d->hier_Y[i * T + j];
+            Sy = Sy + y; Sxy = kd_fma(y, d->hier_xc[j], Sxy); Syy = kd_fma(y, y, Syy);
         }
+        const double S1 = kd_fma(-bi, X1, kd_fma(-Td, ai, Sy));
+        const double Sx = kd_fma(-bi, X2, kd_fma(-ai, X1, Sxy));
+        const double u = kd_fma(Td, ai, -2.0 * Sy);
+        const double v = kd_fma(bi, X2, kd_fma(2.0 * ai, X1, -2.0 * Sxy));
+        const double S2 = kd_fma(bi, v, kd_fma(ai, u, Syy));
         if (g) { g[2 * i] = wc * S1 - wa * da; g[2 * i + 1] = wc * Sx - wb * db; }
         tA1[2 * i] = da; tA2[2 * i] = da * da; tC2[2 * i] = S2;
         tB1[2 * i + 1] = db; tB2[2 * i + 1] = db * db;
