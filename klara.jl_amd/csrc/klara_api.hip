@@ -86,7 +86,7 @@ static bool diagt_eligible(const klara_desc& d)
 static bool hiert_eligible(const klara_desc& d)
 {
     if (d.target != KLARA_TARGET_HIER_NORMAL || d.sampler == KLARA_SAMPLER_SLICE) return false;
-    if (d.hier_nunits < 9 || d.hier_nunits > 32 || d.hier_ntimes != 5) return false;
+    if (d.hier_nunits < 9 || d.hier_nunits > 32) return false;
     if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
     if (getenv("KLARA_LAYOUT_E")) return false;
     return true;

@@ -15,8 +15,8 @@
 // ko_reduce kind 4.
 //
 // Scope: HMC, MALA and MH with the Vanilla, AcceptanceRate (per chain or pooled per GPU) or (HMC) DualAveraging tuner, any monitor;
-// 9 <= R <= 32 units,
-// T = 5 observations per unit.  Everything else stays on the group layout.
+// 9 <= R <= 32 units, any number of observations per unit (they enter through sufficient statistics).  Everything else stays
+// on the group layout.
 #pragma once
 #include "klara_kernels.h"
 #include "klara_diagt.h"      // group_window / buffer helpers, kd_uint4
@@ -45,20 +45,19 @@ __device__ __forceinline__ HierLane<RPL, NT> make_hlane(const KParams& p)
     c.cw = c.lane / KLARA_HIERT_Q;
     c.R = p.hR; c.D = p.D;
     c.p0 = p.hp0; c.a0 = p.ha0; c.b0 = p.hb0;
-    double xc[NT];
-    c.X1 = 0.0; c.X2 = 0.0; c.Td = (double)NT;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { xc[j] = p.hxc[j]; c.X1 = c.X1 + xc[j]; c.X2 = kd_fma(xc[j], xc[j], c.X2); }
+    // (the number of observations per unit only matters here, once per launch: NT is no longer a code-shape parameter)
+    const int T = p.hT;
+    c.X1 = 0.0; c.X2 = 0.0; c.Td = (double)T;
+    for (int j = 0; j < T; ++j) { const double xj = p.hxc[j]; c.X1 = c.X1 + xj; c.X2 = kd_fma(xj, xj, c.X2); }
 #pragma unroll
     for (int k = 0; k < RPL; ++k) {
         const int r = RPL * c.q + k;
         c.rv[k] = r < c.R;
         c.roff[k] = c.rv[k] ? (unsigned)((c.cw * c.D + 2 * r) * 8) : KLARA_BUF_OOB;
         double sy = 0.0, sxy = 0.0, syy = 0.0;               // (a missing unit: all zero)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const double y = c.rv[k] ? p.hY[r * NT + j] : 0.0;
-            sy = sy + y; sxy = kd_fma(y, xc[j], sxy); syy = kd_fma(y, y, syy);
+        for (int j = 0; j < T; ++j) {
+            const double y = c.rv[k] ? p.hY[r * T + j] : 0.0;
+            sy = sy + y; sxy = kd_fma(y, p.hxc[j], sxy); syy = kd_fma(y, y, syy);
         }
         c.Sy[k] = sy; c.m2Sy[k] = -2.0 * sy; c.Sxy[k] = sxy; c.m2Sxy[k] = -2.0 * sxy; c.Syy[k] = syy;
     }
@@ -128,7 +127,7 @@ __device__ __forceinline__ double hier_eval(const HierLane<RPL, NT>& c, const Hi
     }
     group_allreduce<5>(red, KLARA_HIERT_Q, c.lane);
     const double A1 = red[0], B1 = red[1], A2 = red[2], B2 = red[3], C2 = red[4];
-    const double RT = (double)c.R * (double)NT, Rd = (double)c.R;
+    const double RT = (double)c.R * c.Td, Rd = (double)c.R;
     if (WANT_GRAD) {
         g.h[0] = wa * A1 - c.p0 * ac;
         g.h[1] = wb * B1 - c.p0 * bc;

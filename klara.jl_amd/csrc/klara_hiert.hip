@@ -15,7 +15,7 @@ static hipError_t launch_hiert(const KParams* p, const KLaunch& kl, bool mon, bo
 hipError_t klara_launch_hiert(const KParams* p, const KLaunch& kl, int sampler, int RPL, int NT, bool mon, bool tune, bool da, dim3 grid,
                               hipStream_t st)
 {
-    if (RPL != 4 || NT != 5) return hipErrorInvalidValue;
+    if (RPL != 4 || NT < 1) return hipErrorInvalidValue;      // (the kernels read the observation count from KParams; NT = 5 names the instantiation)
     switch (sampler) {
     case KLARA_SAMPLER_MH: return launch_hiert<KLARA_SAMPLER_MH>(p, kl, mon, tune, grid, st);
     case KLARA_SAMPLER_MALA: return launch_hiert<KLARA_SAMPLER_MALA>(p, kl, mon, tune, grid, st);
@@ -31,7 +31,7 @@ hipError_t klara_launch_hiert(const KParams* p, const KLaunch& kl, int sampler, 
 
 hipError_t klara_launch_hiert_init(const KParams& p, int RPL, int NT, int needgrad, dim3 grid, hipStream_t st)
 {
-    if (RPL != 4 || NT != 5) return hipErrorInvalidValue;
+    if (RPL != 4 || NT < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_hiert_init<4, 5>), grid, dim3(256), 0, st, p, needgrad);
     return hipGetLastError();
 }

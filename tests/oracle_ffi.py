@@ -108,7 +108,7 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
         np_ = next(v for v in DIAGT_NP_MENU if v >= (d + 2 * DIAGT_Q - 1) // (2 * DIAGT_Q))
         return (3, DIAGT_Q, 2 * np_)
     if (target_kind == L.TARGET_HIER_NORMAL and sampler in (L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC)
-            and 9 <= hier_nunits <= 32 and hier_ntimes == 5 and os.environ.get("KLARA_LAYOUT_KIND", "4") != "0"):
+            and 9 <= hier_nunits <= 32 and os.environ.get("KLARA_LAYOUT_KIND", "4") != "0"):
         return (4, 8, 8)              # klara_hiert.h: 8 lanes per chain, 4 units per lane
     if target_kind == L.TARGET_CUSTOM:        # one chain per lane, pow2ceil(D) elements in registers (klara_custom.h)
         e = 2

@@ -280,16 +280,17 @@ def test_pair_transposed_tiny_jobs(nchains, sampler, kw):
     eng.close()
 
 
-@pytest.mark.parametrize("R,nchains,tuner_kw", [(9, 11, {}), (13, 5, dict(tuner=L.TUNER_ACCEPT_RATE, targetrate=0.7, period=8)),
-                                                (30, 64, dict(tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.65, period=10)),
-                                                (32, 19, {})])
-def test_hier_few_lanes_layout_other_unit_counts(R, nchains, tuner_kw):
-    """Layout kind 4 (klara_hiert.h) on synthetic growth-curve data: unit counts with a partly filled last lane (9, 13, 30)
-    and a full one (32), ragged chain counts, the per-chain and the pooled AcceptanceRate tuner, history of every field."""
+@pytest.mark.parametrize("R,T,nchains,tuner_kw", [(9, 5, 11, {}), (13, 3, 5, dict(tuner=L.TUNER_ACCEPT_RATE, targetrate=0.7, period=8)),
+                                                  (30, 8, 64, dict(tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.65, period=10)),
+                                                  (32, 12, 19, {}), (17, 2, 8, {})])
+def test_hier_few_lanes_layout_other_unit_counts(R, T, nchains, tuner_kw):
+    """Layout kind 4 (klara_hiert.h) on synthetic growth-curve data: unit counts with a partly filled last lane (9, 13, 17, 30)
+    and a full one (32), 2 to 12 observations per unit on a covariate that is not centred, ragged chain counts, the
+    per-chain and the pooled AcceptanceRate tuner, history of every field."""
     rng = np.random.default_rng(R)
-    xc = np.array([-14.0, -7.0, 0.0, 7.0, 14.0])
+    xc = np.linspace(-14.0, 14.0, T) + (0.0 if T == 5 else 1.5)
     a = 240.0 + 15.0 * rng.standard_normal(R); b = 6.0 + 0.5 * rng.standard_normal(R)
-    Y = a[:, None] + b[:, None] * xc[None, :] + 6.0 * rng.standard_normal((R, 5))
+    Y = a[:, None] + b[:, None] * xc[None, :] + 6.0 * rng.standard_normal((R, T))
     t = K.HierNormalTarget(Y, xc)
     x0 = t.least_squares_start()[None, :] + 0.05 * rng.standard_normal((nchains, t.ndims))
     case = dict(sampler=L.SAMPLER_HMC, target=t, nchains=nchains, nsteps=24, burnin=16, thinning=2, leapstep=0.01, nleaps=6, x0=x0,
