@@ -63,6 +63,20 @@ function chainmeans(job::HIPMCJob)
                 job.handle, s, q, n), "klara_get_chain_sums")
     s ./ n[]
 end
+# mcvar(chain, Val{:bm}) for every chain and dimension from the streaming batch means (desc.bm_batchlen > 0): D × N, nbatches
+function chainmcvar_bm(job::HIPMCJob)
+    v = Matrix{Float64}(undef, job.ndims, job.nchains); nb = Ref{Clonglong}(0)
+    check(ccall((:klara_get_chain_bm, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Clonglong}), job.handle, v, nb), "klara_get_chain_bm")
+    (v, nb[])
+end
+
+# user-defined target (desc.target = 4): compile the closures' C text without a GPU; the compiler's message on failure
+function check_custom_target(src::String, sampler::Integer, ndims::Integer)
+    st = ccall((:klara_check_custom_target, lib), Cint, (Cstring, Cint, Cint), src, sampler, ndims)
+    st == 0 || error(unsafe_string(ccall((:klara_compile_log, lib), Cstring, ())))
+    true
+end
+
 # ---- multi-GPU: one process per GPU; the only exchange is the all-reduce of the pooled summaries (RCCL over xGMI)
 mutable struct HIPComm; handle::Ptr{Cvoid}; end
 function comm_unique_id()
