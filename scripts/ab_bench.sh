@@ -1,3 +1,8 @@
+#!/bin/bash
+# Same-box A/B of two builds of the library (box-to-box variation on the pool is +-3 %, more than most kernel changes):
+#   make -C klara.jl_amd/csrc OUT=../lib/libklara_hip_old.so OBJDIR=../../build/csrc_old   (at the older commit)
+#   gpurun -- 'bash scripts/ab_bench.sh'
+# prints ms per transition of all chains (bench value) and the single-launch duration for 1 and 2 streams, alternating.
 for i in 1 2 3; do
 for lib in libklara_hip_old.so libklara_hip.so; do
 for s in 1 2; do
