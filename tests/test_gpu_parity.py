@@ -657,6 +657,107 @@ def test_readme_flow_basic_mc_job():
     job.close()
 
 
+# ------------------------------------------------------------------ randomized configurations
+def _random_case(seed):
+    """One job drawn from the whole configuration space the library accepts: target family and size, sampler, tuner,
+    range, chain count (valid combinations only — the refused ones are in test_error_paths)."""
+    rng = np.random.default_rng(1000 + seed)
+    fam = rng.choice(["diag_unit", "diag", "dense", "logit", "hier", "custom"], p=[0.2, 0.25, 0.15, 0.13, 0.14, 0.13])
+    if fam == "diag_unit":
+        d = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 19, 31, 40, 63, 77, 100, 128, 129, 200, 300]))
+        target = K.GaussDiagTarget.negdot(d)
+    elif fam == "diag":
+        d = int(rng.choice([2, 4, 7, 16, 18, 23, 48, 65, 96, 127, 140]))
+        target = K.GaussDiagTarget.mvnormal(rng.uniform(-2, 2, d), rng.uniform(0.5, 2.0, d))
+    elif fam == "dense":
+        d = int(rng.choice([3, 8, 20, 33, 50]))
+        target = K.GaussDenseTarget(cases.compound_symmetric_precision(d, float(rng.uniform(0.1, 0.7))))
+    elif fam == "logit":
+        d = int(rng.choice([1, 2, 3, 4, 6, 8])); n = int(rng.choice([5, 30, 63, 64, 100]))
+        X, y = cases.synthetic_logit(n, d, seed=seed)
+        target = K.LogisticTarget(X, y, float(rng.choice([1.0, 100.0])))
+    elif fam == "hier":
+        R = int(rng.choice([2, 5, 8, 9, 12, 21, 32, 40])); T = int(rng.integers(2, 8))
+        xc = np.linspace(-10.0, 10.0, T) + float(rng.uniform(-1, 1))
+        a = 200.0 + 10.0 * rng.standard_normal(R); b = 5.0 + 0.5 * rng.standard_normal(R)
+        target = K.HierNormalTarget(a[:, None] + b[:, None] * xc[None, :] + 5.0 * rng.standard_normal((R, T)), xc)
+        d = target.ndims
+    else:
+        d = int(rng.choice([2, 5, 9, 16, 24]))
+        target = K.CustomTarget(d, cases.SRC_QUARTIC_CHAIN, [float(rng.uniform(0.01, 0.2)), float(rng.uniform(0.1, 0.8))])
+    samplers = [L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC] + ([] if fam == "dense" else [L.SAMPLER_SLICE])
+    sampler = int(rng.choice(samplers))
+    scale = 0.02 if fam == "hier" else (0.05 if fam == "logit" else 0.3)
+    c = dict(sampler=sampler, target=target, nchains=int(rng.choice([1, 2, 7, 8, 9, 33, 64, 100, 131])), x0=None, seed=int(rng.integers(1, 2 ** 40)),
+             name=f"random_{seed}_{fam}")
+    if sampler == L.SAMPLER_MH:
+        c["mh_sigma"] = np.full(d, scale) * rng.uniform(0.5, 1.5, d)
+    elif sampler == L.SAMPLER_MALA:
+        c["driftstep"] = float(scale * scale * rng.uniform(0.5, 2.0))
+    elif sampler == L.SAMPLER_HMC:
+        c["leapstep"] = float(scale * rng.uniform(0.3, 0.8)); c["nleaps"] = int(rng.integers(1, 7))
+    else:
+        c["slice_widths"] = np.full(d, 4 * scale) * rng.uniform(0.5, 1.5, d); c["slice_stepout"] = bool(rng.integers(0, 2))
+    c["burnin"] = int(rng.choice([0, 3, 20])); c["thinning"] = int(rng.choice([1, 1, 2, 5]))
+    c["nsteps"] = c["burnin"] + int(rng.integers(6, 40))
+    tun = rng.choice(["vanilla", "verbose", "rate", "rate_erf", "pooled", "da"])
+    if tun == "verbose":
+        c.update(verbose=True, period=int(rng.integers(3, 12)))
+    elif tun in ("rate", "rate_erf", "pooled") and not (tun == "pooled" and sampler == L.SAMPLER_SLICE):
+        c.update(tuner=L.TUNER_ACCEPT_RATE, targetrate=float(rng.uniform(0.3, 0.8)), period=int(rng.integers(3, 12)))
+        if tun == "rate_erf":
+            c.update(tuner_score=1, score_k=3.0)
+        if tun == "pooled":
+            c.update(tuner_mode=L.TUNE_POOLED)
+    elif tun == "da" and sampler == L.SAMPLER_HMC:
+        c.update(tuner=L.TUNER_DUAL_AVERAGING, targetrate=float(rng.uniform(0.5, 0.8)), da_nadapt=int(rng.integers(5, 30)))
+    if fam in ("hier", "logit"):
+        if fam == "hier":
+            c["x0"] = target.least_squares_start()[None, :] + 0.02 * rng.standard_normal((c["nchains"], d))
+        else:
+            c["x0"] = 0.1 * rng.standard_normal((c["nchains"], d))
+    return c, rng
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KLARA_RANDOM_CASES", "96"))))
+def test_random_configurations(seed):
+    """96 jobs (KLARA_RANDOM_CASES overrides the count) drawn at random from the accepted configuration space, run in randomly sized pieces with a random number of
+    transitions per launch and every monitor on: accept mask, state, sums, tuner state and one chain's full history must
+    equal the oracle's bit for bit."""
+    c, rng = _random_case(seed)
+    mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT
+    if c["sampler"] in (L.SAMPLER_MALA, L.SAMPLER_HMC):
+        mon |= L.MON_HIST_GRAD
+    eng = K.Engine(**cases.engine_kwargs(c, monitor=mon, steps_per_launch=int(rng.choice([0, 1, 2, 5, 16])),
+                                         nstreams=int(rng.choice([0, 1, 3]))))
+    job = O.OracleJob(**cases.oracle_kwargs(c, layout=eng.layout()), want_hist=True)
+    if c["x0"] is None:
+        eng.init_state_normal(); assert job.init_state_normal() == 0
+    else:
+        eng.set_state(c["x0"]); assert job.set_state(c["x0"]) == 0
+    left = c["nsteps"]
+    while left > 0:
+        k = int(rng.integers(1, left + 1)); left -= k
+        ost = job.run(k)
+        try:
+            eng.run(k); gst = 0
+        except K.KlaraError as e:
+            gst = e.status
+        assert gst == ost, (gst, ost)
+        if ost != 0:                          # a slice that shrank onto the current point (SliceSampler.jl:102): both sides say so
+            assert ost == L.ERR_SLICE_STUCK
+            eng.close()
+            return
+    _assert_same(eng, job, c)
+    ch = int(rng.integers(0, c["nchains"]))
+    assert np.array_equal(eng.chain(ch), job.hist[:, ch, :].T), "history differs"
+    lt, g = eng.chain_fields(ch, logtarget=True, gradlogtarget=bool(mon & L.MON_HIST_GRAD))
+    assert np.array_equal(lt, job.hist_lt[:, ch])
+    if mon & L.MON_HIST_GRAD:
+        assert np.array_equal(g, job.hist_g[:, ch, :].T)
+    eng.close()
+
+
 # ------------------------------------------------------------------ streaming batch means
 @pytest.mark.parametrize("name,batchlen,streams", [("mala_d100", 7, 0), ("dt_hmc_d100", 5, 2), ("hmc_dense_d37", 6, 0),
                                                     ("mala_swiss", 9, 0), ("hmc_rats", 4, 0), ("slice_d5", 3, 0),
