@@ -728,9 +728,10 @@ def test_random_configurations(seed):
     mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT
     if c["sampler"] in (L.SAMPLER_MALA, L.SAMPLER_HMC):
         mon |= L.MON_HIST_GRAD
+    off = int(rng.choice([0, 0, 5, (1 << 33) + 12345]))          # this shard's first global chain id (Philox subsequence)
     eng = K.Engine(**cases.engine_kwargs(c, monitor=mon, steps_per_launch=int(rng.choice([0, 1, 2, 5, 16])),
-                                         nstreams=int(rng.choice([0, 1, 3]))))
-    job = O.OracleJob(**cases.oracle_kwargs(c, layout=eng.layout()), want_hist=True)
+                                         nstreams=int(rng.choice([0, 1, 3])), chain_offset=off))
+    job = O.OracleJob(**cases.oracle_kwargs(c, layout=eng.layout(), chain_offset=off), want_hist=True)
     if c["x0"] is None:
         eng.init_state_normal(); assert job.init_state_normal() == 0
     else:
