@@ -274,7 +274,7 @@ klara_status klara_device_ptrs(klara_handle* h, void** x, void** logtarget, void
  * order): kind 0 = contiguous E elements per lane over G lanes; kind 1 = MFMA-transposed layout
  * (element i on lane-quarter i%4); kind 2 = logistic row split (every lane holds all E elements, the data
  * rows are dealt round-robin to `lanes_per_chain` lanes); kind 3 = pair-transposed layout of the diagonal Gaussian
- * (element pair P = i/2 on lane P % lanes_per_chain, elements_per_lane/2 pairs per lane); kind 4 = hierarchical target
+ * (element pair P = i/2 on lane P % lanes_per_chain, elements_per_lane/2 pairs per lane; 8, 16 or 32 lanes per chain for D <= 128 / 256 / 512); kind 4 = hierarchical target
  * with few lanes per chain (unit r on lane r / (elements_per_lane/2), hyper block replicated).  See DESIGN.md section 3. */
 klara_status klara_get_layout(klara_handle* h, int32_t* kind, int32_t* lanes_per_chain,
                               int32_t* elems_per_lane);

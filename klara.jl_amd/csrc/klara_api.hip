@@ -76,7 +76,7 @@ static bool diagt_eligible(const klara_desc& d)
 {
     if (d.target != KLARA_TARGET_GAUSS_DIAG) return false;
     // (D <= 16: the group layout already puts a chain on <= 4 lanes, 16..64 chains per wavefront)
-    if (d.ndims < 17 || d.ndims > 2 * KLARA_DIAGT_Q * KLARA_DIAGT_NP_MAX) return false;
+    if (d.ndims < 17 || d.ndims > 2 * 32 * KLARA_DIAGT_NP_MAX) return false;       // (Q = 8, 16 or 32 lanes per chain)
     if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
     if (getenv("KLARA_LAYOUT_E")) return false;
     return true;
@@ -115,12 +115,9 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     // diagonal Gaussian and nothing tunes: the pair-transposed layout
     // (klara_diagt.h), Q = 8 lanes per chain, NP element pairs per lane
     if (diagt_eligible(d)) {
-        const int need = (D + 2 * KLARA_DIAGT_Q - 1) / (2 * KLARA_DIAGT_Q);      // NP = ceil(D/2 / Q) exactly (see klara_diagt.h)
-        int np = 0;
-#define X(NP_) if (NP_ == need) np = NP_;
-        KLARA_DIAGT_NP_MENU_DO(X)
-#undef X
-        if (np != 0) { *kind = 3; *G = KLARA_DIAGT_Q; *E = 2 * np; return KLARA_OK; }
+        const int Q = D <= 128 ? 8 : (D <= 256 ? 16 : 32);                        // lanes per chain
+        const int np = (D + 2 * Q - 1) / (2 * Q);                                 // NP = ceil(D/2 / Q) exactly (see klara_diagt.h): 2..8
+        if (np >= 2 && np <= KLARA_DIAGT_NP_MAX) { *kind = 3; *G = Q; *E = 2 * np; return KLARA_OK; }
     }
     // diagonal Gaussian: E elements per lane, G lanes; optional override for layout experiments
     // D <= 128: E = 2 or 4, whichever wastes fewer lanes; on a tie E = 4 (twice the chains per wavefront
@@ -273,7 +270,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     else { CKH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     CKH(hipEventCreate(&h->ev0)); CKH(hipEventCreate(&h->ev1));
     if (h->kind == 3) {
-        const long long groups = (desc->nchains + KLARA_DIAGT_CPW - 1) / KLARA_DIAGT_CPW;
+        const long long cpw = 64 / G, groups = (desc->nchains + cpw - 1) / cpw;
         int np = groups >= 4096 ? 2 : 1;                       // >= one full round of wavefronts (4 per SIMD) per partition
         if (desc->nstreams >= 1 && desc->nstreams <= 4) np = desc->nstreams;
         if (const char* s = getenv("KLARA_STREAMS")) { const int v = atoi(s); if (v >= 1 && v <= 4) np = v; }
@@ -512,7 +509,10 @@ static klara_status init_common(klara_handle* h)
     KParams p = make_params(h);
     hipError_t e;
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, needgrad, grid_for(h), st);
-    else if (h->kind == 3) e = klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st);
+    else if (h->kind == 3)
+        e = h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
+          : h->G == 16 ? klara_launch_diagt_init_q16(p, h->E / 2, needgrad, grid_for(h), st)
+                       : klara_launch_diagt_init_q32(p, h->E / 2, needgrad, grid_for(h), st);
     else if (h->kind == 4) e = klara_launch_hiert_init(p, h->E / 2, d.hier_ntimes, needgrad, grid_for(h), st);
     else if (d.target == KLARA_TARGET_CUSTOM) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), st);
     else if (d.target == KLARA_TARGET_GAUSS_DIAG)
@@ -544,10 +544,10 @@ extern "C" klara_status klara_init_state_normal(klara_handle* h)
     if (!h) return KLARA_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(h->d.device));
     // the stream is layout-free (element i <- slot i>>1), so any group layout draws the same x0:
-    // use the handle's own (kind 0) or E=2 lanes for the MFMA layout (D <= 128 there)
+    // use the handle's own (kind 0) or a group layout that fits the wavefront for the other kinds
     KParams p = make_params(h);
     const int D = h->d.ndims;
-    int E = 2, G = pow2ceil((D + 1) / 2);
+    int E = D <= 128 ? 2 : (D <= 256 ? 4 : 8), G = pow2ceil((D + E - 1) / E);       // (at most 64 lanes per chain)
     if ((h->kind == 0 || h->kind == 2) && h->d.target != KLARA_TARGET_CUSTOM) { E = h->E; G = h->G; }
     p.G = G; p.rs = 1;     // the init stream is drawn without the row split (same values, any layout)
     const long long cpw = 64 / G, waves = (h->d.nchains + cpw - 1) / cpw;
@@ -582,7 +582,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on
         const bool da = d.tuner == KLARA_TUNER_DUAL_AVERAGING;                                 // (HMC only: validate())
         const bool tune = !plain || da;                                                        // something counts proposals / tunes
-        const long long groups = (d.nchains + KLARA_DIAGT_CPW - 1) / KLARA_DIAGT_CPW, per = (groups + h->nparts - 1) / h->nparts;
+        const long long cpw = 64 / h->G, groups = (d.nchains + cpw - 1) / cpw, per = (groups + h->nparts - 1) / h->nparts;
         for (int j = 0; j < h->nparts; ++j) {
             KLaunch kp = kl;
             kp.group0 = j * per; kp.group_end = (j + 1) * per < groups ? (j + 1) * per : groups;
@@ -590,12 +590,15 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
             const dim3 grid((unsigned)((kp.group_end - kp.group0 + 3) / 4));      // one wavefront per group of 8 chains
             hipStream_t st = j == 0 ? h->stream : h->side[j - 1];
             hipError_t e;
-            switch (d.sampler) {
-            case KLARA_SAMPLER_MH: e = klara_launch_diagt_mh(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;
-            case KLARA_SAMPLER_SLICE: e = klara_launch_diagt_slice(p, kp, h->E / 2, unitw, mon, tune, grid, st); break;
-            case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;
-            default: e = klara_launch_diagt_hmc(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;
+#define KLARA_DIAGT_LAUNCH(SUFFIX)                                                                                                          \
+            switch (d.sampler) {                                                                                                              \
+            case KLARA_SAMPLER_MH: e = klara_launch_diagt_mh##SUFFIX(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;    \
+            case KLARA_SAMPLER_SLICE: e = klara_launch_diagt_slice##SUFFIX(p, kp, h->E / 2, unitw, mon, tune, grid, st); break;                    \
+            case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala##SUFFIX(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break; \
+            default: e = klara_launch_diagt_hmc##SUFFIX(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;                 \
             }
+            if (h->G == 8) { KLARA_DIAGT_LAUNCH() } else if (h->G == 16) { KLARA_DIAGT_LAUNCH(_q16) } else { KLARA_DIAGT_LAUNCH(_q32) }
+#undef KLARA_DIAGT_LAUNCH
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
@@ -636,10 +639,10 @@ static hipError_t launch_bm_close(klara_handle* h)
 {
     const long long N = h->d.nchains, D = h->d.ndims;
     const int np = h->kind == 3 ? h->nparts : 1;
-    const long long groups = (N + KLARA_DIAGT_CPW - 1) / KLARA_DIAGT_CPW, per = (groups + np - 1) / np;
+    const long long cpw = h->kind == 3 ? 64 / h->G : 8, groups = (N + cpw - 1) / cpw, per = (groups + np - 1) / np;
     for (int j = 0; j < np; ++j) {
         long long c0 = 0, c1 = N;
-        if (np > 1) { c0 = j * per * KLARA_DIAGT_CPW; c1 = (j + 1) * per * KLARA_DIAGT_CPW; if (c1 > N) c1 = N; }
+        if (np > 1) { c0 = j * per * cpw; c1 = (j + 1) * per * cpw; if (c1 > N) c1 = N; }
         if (c0 >= c1) break;
         const long long n = (c1 - c0) * D;
         hipLaunchKernelGGL(k_bm_close, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, j == 0 ? h->stream : h->side[j - 1], h->sum,

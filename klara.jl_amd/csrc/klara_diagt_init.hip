@@ -1,7 +1,7 @@
 // klara_diagt_init.hip — initialize! for layout kind 3 (lt and gradient at X).
 #include "klara_launch.h"
 
-hipError_t klara_launch_diagt_init(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st)
+hipError_t KLARA_DIAGT_FN(klara_launch_diagt_init)(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st)
 {
     const dim3 blk(256);
     switch (NP) {

@@ -11,7 +11,7 @@
         else hipLaunchKernelGGL((k_diagt<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, false, false>), grid, blk, 0, st, p, kl);                      \
         break;
 
-hipError_t klara_launch_diagt_slice(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st)
+hipError_t KLARA_DIAGT_FN(klara_launch_diagt_slice)(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st)
 {
     const dim3 blk(256);
     switch (NP) {

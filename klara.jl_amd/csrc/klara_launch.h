@@ -21,21 +21,37 @@ hipError_t klara_launch_mfma_probe(const double* A, const double* B, const doubl
                                    hipStream_t st);
 hipError_t klara_launch_mfma4_probe(const double* A, const double* B, const double* C, double* D, hipStream_t st);
 
-// pair-transposed diagonal-Gaussian kernels (layout kind 3, klara_diagt.h); NP in KLARA_DIAGT_NP_MENU, Q = KLARA_DIAGT_Q
-hipError_t klara_launch_diagt_mh(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
-hipError_t klara_launch_diagt_mala(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
-hipError_t klara_launch_diagt_hmc(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
-hipError_t klara_launch_diagt_slice(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st);
-hipError_t klara_launch_diagt_init(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
-// pairs per lane the kernels are instantiated for (D <= 16*NP); a job takes NP = ceil(D / 16)
+// pair-transposed diagonal-Gaussian kernels (layout kind 3, klara_diagt.h).  The translation units klara_diagt_*.hip are
+// compiled three times: Q = 8 lanes per chain (17 <= D <= 128, NP = ceil(D/16) in 2..8), Q = 16 (129 <= D <= 256) and Q = 32
+// (257 <= D <= 512), the latter two with NP in 5..8; the launchers of the wider variants carry a _q16 / _q32 suffix.
+#if KLARA_DIAGT_Q == 8
+#define KLARA_DIAGT_FN(name) name
+#elif KLARA_DIAGT_Q == 16
+#define KLARA_DIAGT_FN(name) name##_q16
+#elif KLARA_DIAGT_Q == 32
+#define KLARA_DIAGT_FN(name) name##_q32
+#else
+#define KLARA_DIAGT_FN(name) name          // (experimental lane counts replace the Q = 8 set)
+#endif
+#define KLARA_DIAGT_DECLARE(SUFFIX)                                                                                                                       \
+    hipError_t klara_launch_diagt_mh##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);   \
+    hipError_t klara_launch_diagt_mala##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st); \
+    hipError_t klara_launch_diagt_hmc##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);  \
+    hipError_t klara_launch_diagt_slice##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st);                      \
+    hipError_t klara_launch_diagt_init##SUFFIX(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
+KLARA_DIAGT_DECLARE()
+KLARA_DIAGT_DECLARE(_q16)
+KLARA_DIAGT_DECLARE(_q32)
+// pairs per lane the kernels are instantiated for; a job takes NP = ceil(ceil(D/2) / Q) exactly (only the LAST pair of a lane
+// can be padding)
 #if KLARA_DIAGT_Q == 4     // experiment: 4 lanes per chain, 16 chains per wavefront (D = 100 -> 13 pairs per lane, no padding)
 #define KLARA_DIAGT_NP_MENU_DO(X) X(2) X(4) X(8) X(13) X(16)
-#define KLARA_DIAGT_NP_MAX 16
-#else
-// (every value: the kernels rely on NP = ceil(D/2 / Q), i.e. only the LAST pair of a lane can be padding)
+#elif KLARA_DIAGT_Q == 8
 #define KLARA_DIAGT_NP_MENU_DO(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
-#define KLARA_DIAGT_NP_MAX 8
+#else                      // Q = 16 / 32 start where the narrower variant ends: NP = 5..8
+#define KLARA_DIAGT_NP_MENU_DO(X) X(5) X(6) X(7) X(8)
 #endif
+#define KLARA_DIAGT_NP_MAX 8
 
 #define KLARA_DIAGT_CASE(S, NP_)                                                                                   \
     case NP_:                                                                                                      \

@@ -104,9 +104,9 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     d = int(ndims)
     plain = sampler is not None      # (name kept from when the layout excluded tuned jobs)
     if (target_kind == L.TARGET_GAUSS_DIAG and sampler is not None and plain
-            and 17 <= d <= 2 * DIAGT_Q * DIAGT_NP_MENU[-1] and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0"):
-        np_ = next(v for v in DIAGT_NP_MENU if v >= (d + 2 * DIAGT_Q - 1) // (2 * DIAGT_Q))
-        return (3, DIAGT_Q, 2 * np_)
+            and 17 <= d <= 512 and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0" and "KLARA_LAYOUT_E" not in os.environ):
+        q = 8 if d <= 128 else (16 if d <= 256 else 32)          # lanes per chain (klara_api.hip select_layout)
+        return (3, q, 2 * ((d + 2 * q - 1) // (2 * q)))
     if (target_kind == L.TARGET_HIER_NORMAL and sampler in (L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC)
             and 9 <= hier_nunits <= 32 and os.environ.get("KLARA_LAYOUT_KIND", "4") != "0"):
         return (4, 8, 8)              # klara_hiert.h: 8 lanes per chain, 4 units per lane

@@ -213,15 +213,16 @@ def test_group_layout_dimension_sweep():
 @pytest.mark.parametrize("sampler,kw,step", [(L.SAMPLER_MALA, dict(driftstep=0.3), 1), (L.SAMPLER_HMC, dict(leapstep=0.2, nleaps=3), 3),
                                              (L.SAMPLER_MH, None, 3), (L.SAMPLER_SLICE, "slice", 7)])
 def test_pair_transposed_dimension_sweep(sampler, kw, step):
-    """Dimensions 17..128, odd ones included, on the pair-transposed layout (every one for MALA, every third for HMC and MH,
-    every seventh for the slice sampler): with and without padding pairs / a half pair, i.e. every way of obtaining the
-    accept draw and of storing the last pair."""
-    for d in range(17, 129, step):
+    """Dimensions 17..128 (8 lanes per chain), odd ones included, on the pair-transposed layout (every one for MALA, every
+    third for HMC and MH, every seventh for the slice sampler), then 129..512 (16 and 32 lanes per chain) in coarser steps:
+    with and without padding pairs / a half pair, i.e. every way of obtaining the accept draw and of storing the last pair."""
+    wide = {1: 3, 3: 13, 7: 61}[step]
+    for d in list(range(17, 129, step)) + list(range(129, 513, wide)) + [256, 257, 511, 512]:
         skw = dict(slice_widths=np.full(d, 1.5)) if kw == "slice" else (kw if kw is not None else dict(mh_sigma=np.full(d, 0.2)))
         case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=11,
                     nsteps=6, burnin=0, x0=None, seed=d, name=f"sweep3_d{d}", **skw)
         eng, job = _run_pair(case, spl=2)
-        assert eng.layout()[0] == 3
+        assert eng.layout()[:2] == (3, 8 if d <= 128 else 16 if d <= 256 else 32)
         x, lt, g = eng.state()
         assert np.array_equal(x, job.X) and np.array_equal(lt, job.LT), d
         assert sampler == L.SAMPLER_MH or np.array_equal(g, job.G), d
@@ -347,7 +348,7 @@ def test_layout_choice_matches_its_mirror():
 
 
 def test_pair_transposed_layout_is_optional():
-    """D < 17 or D > 128 keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
+    """D < 17 or D > 512 keep the group layout; KLARA_LAYOUT_KIND=0 forces it."""
     case = cases.make_case("dt_mala_d100")
     e = K.Engine(**cases.engine_kwargs(case)); assert e.layout()[0] == 3; e.close()                  # any monitor
     e = K.Engine(**cases.engine_kwargs(case, monitor=0)); assert e.layout()[0] == 3; e.close()
@@ -355,9 +356,10 @@ def test_pair_transposed_layout_is_optional():
     e = K.Engine(**cases.engine_kwargs(case, monitor=0, verbose=True)); assert e.layout()[0] == 3; e.close()
     e = K.Engine(**cases.engine_kwargs(dict(case, sampler=L.SAMPLER_HMC), monitor=0, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=10))
     assert e.layout()[0] == 3; e.close()
-    e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d129"), monitor=0)); assert e.layout()[0] == 0; e.close()
+    e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d129"), monitor=0)); assert e.layout() == (3, 16, 10); e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("mh_mvnormal_d7"), monitor=0)); assert e.layout()[0] == 0; e.close()
-    e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d300"), monitor=0)); assert e.layout()[0] == 0; e.close()
+    e = K.Engine(**cases.engine_kwargs(cases.make_case("mala_d300"), monitor=0)); assert e.layout() == (3, 32, 10); e.close()
+    e = K.Engine(**cases.engine_kwargs(cases.make_case("mh_d512"), monitor=0)); assert e.layout() == (3, 32, 16); e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("slice_d100_nostepout"), monitor=0)); assert e.layout()[0] == 3; e.close()
     e = K.Engine(**cases.engine_kwargs(cases.make_case("slice_d5"), monitor=0)); assert e.layout()[0] == 0; e.close()
     os.environ["KLARA_LAYOUT_KIND"] = "0"
@@ -373,7 +375,8 @@ def test_pair_transposed_layout_is_optional():
 GROUP_FORCED = [n for n in cases.ALL_CASES if n in ("mh_d100", "mala_d100", "mala_d100_small_step", "hmc_d100", "hmc_d128_full",
                                                    "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose",
                                                    "hmc_rats", "hmc_rats_pooled", "hmc_rats_dualavg", "hmc_d40_dualavg", "hmc_d100_dualavg",
-                                                   "slice_d100_nostepout", "slice_d20_stepout", "mala_rats", "mh_rats", "mala_rats_tuned")]
+                                                   "slice_d100_nostepout", "slice_d20_stepout", "mala_rats", "mh_rats", "mala_rats_tuned",
+                                                   "mala_d129", "mala_d300", "mh_d512")]
 
 
 @pytest.mark.parametrize("name", GROUP_FORCED)
