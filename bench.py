@@ -179,7 +179,9 @@ def roofline_pass(K, L, n, spl, rank, local_rank, stream, acc_rate):
           "chains_per_launch": n, "accept_rate_used": acc_rate if spl <= 1 else 1.0,
           "survey_2S_plus_1_bytes_per_launch": n * (2 * (2 * NDIMS * 8 + 8) + 1),
           "note": ("the kernel is bound by FP64/INT VALU issue (in-kernel Philox + Box-Muller), not by HBM: see DESIGN.md "
-                   "section 5; measured with nstreams=1, one launch at a time")}
+                   "section 5; measured with nstreams=1, one launch at a time.  The algorithmic bytes are the algorithm's "
+                   "(x, gradient and log-target read per chain); the kernel re-forms the gradient from x instead of reading "
+                   "it, so the measured traffic is about half of them")}
     # HBM bytes per launch from the PMC passes of the same workload (profiles/, scripts/profile_bench.sh)
     try:
         tr = json.loads((ROOT / "profiles" / "r1_bench_mala_traffic.json").read_text())

@@ -197,7 +197,12 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 
         double x[E], g[E];
         load_pairs<NP, Q>(cx, wx, x);
+        // The gradient of this target family is a function of the value alone and GR always holds gradlogtarget(X) (set by
+        // initialize! and by every accepted transition), so it is re-formed from x below — the same operations that produced the
+        // stored bits — instead of being loaded: half the state read, and 4*NP fewer registers reserved while the normals are drawn.
+#ifdef KLARA_DT_LOAD_GRAD
         if (NEEDG) load_pairs<NP, Q>(cx, wg, g);
+#endif
         double lt = p.LT[chain_ok ? chain : 0];
         unsigned long long nacc = 0;
         bool stuck = false;                                // slice sampler: step-out / shrink ran out of attempts
@@ -240,6 +245,12 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                     KLARA_DT_PAIR_FENCE(pi);
                 }
             }
+#ifndef KLARA_DT_LOAD_GRAD
+            if (NEEDG && s == 0) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) { double term_; diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), term_, g[e]); }
+            }
+#endif
             if (SLICE) {                                                           // iterate/SliceSampler.jl:60-109
                 // Coordinates are visited in turn.  Coordinate i lives on lane (i/2) % Q of its chain as register
                 // 2*((i/2)/Q) + (i&1); everything scalar (the slice level, the interval, the probes' log-targets) is computed
