@@ -4,11 +4,17 @@
 // here is source text: klara_create hands it to hiprtc together with the transition kernels of klara_kernels.h (embedded
 // in this library at build time), instantiates k_init / k_transitions for the job's sampler and element count only, and
 // loads the code object as a HIP module.  Compilation needs no GPU (klara_check_custom_target); code objects are cached
-// per process by (source, sampler, D, kernel modes).  libhiprtc.so is loaded on first use.
+// per process by (source, sampler, D, kernel modes) and on disk ($KLARA_JIT_CACHE_DIR, else $XDG_CACHE_HOME/klara_hip, else
+// ~/.cache/klara_hip; KLARA_JIT_CACHE=0 turns the disk cache off), keyed additionally by the embedded kernel headers so that a
+// rebuilt library never picks up a stale code object.  libhiprtc.so is loaded on first use.
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -62,6 +68,92 @@ std::mutex g_cache_mutex;
 std::map<std::string, CodeObject> g_cache;
 thread_local std::string g_log;
 
+// ---- disk cache ------------------------------------------------------------------------------------------------------
+uint64_t fnv1a(const void* data, size_t n, uint64_t h)
+{
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+std::string cache_dir()
+{
+    if (const char* off = getenv("KLARA_JIT_CACHE")) { if (off[0] == '0') return ""; }
+    std::string d;
+    if (const char* e = getenv("KLARA_JIT_CACHE_DIR")) d = e;
+    else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/klara_hip";
+    else if (const char* h = getenv("HOME")) { d = std::string(h) + "/.cache"; mkdir(d.c_str(), 0755); d += "/klara_hip"; }
+    if (d.empty()) return d;
+    mkdir(d.c_str(), 0755);                          // (EEXIST is fine; an unusable directory just disables the cache)
+    return d;
+}
+
+// file name of a (key, options) combination: two 64-bit FNV-1a hashes over the key, the compile options and every embedded header
+std::string cache_file(const std::string& key, const std::string& opts)
+{
+    const std::string dir = cache_dir();
+    if (dir.empty()) return "";
+    uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;
+    const auto mix = [&](const void* p, size_t n) { h1 = fnv1a(p, n, h1); h2 = fnv1a(p, n, h2 ^ 0x9e3779b97f4a7c15ull); };
+    mix(key.data(), key.size()); mix(opts.data(), opts.size());
+    for (int i = 0; i < klara_jit_nheaders; ++i) mix(klara_jit_header_sources[i], strlen(klara_jit_header_sources[i]));
+    char name[64];
+    snprintf(name, sizeof name, "/%016llx%016llx.kjit", (unsigned long long)h1, (unsigned long long)h2);
+    return dir + name;
+}
+
+// layout: "KJIT1\n", u32 count, count x (i32 mode (-1: init kernel), u32 length, name bytes), u64 code size, code, u64 FNV-1a of all before
+bool cache_read(const std::string& path, CodeObject& co)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<char> buf;
+    char chunk[65536];
+    size_t n;
+    while ((n = fread(chunk, 1, sizeof chunk, f)) > 0) buf.insert(buf.end(), chunk, chunk + n);
+    fclose(f);
+    if (buf.size() < 6 + 4 + 8 + 8 || memcmp(buf.data(), "KJIT1\n", 6) != 0) return false;
+    uint64_t sum;
+    memcpy(&sum, buf.data() + buf.size() - 8, 8);
+    if (sum != fnv1a(buf.data(), buf.size() - 8, 0xcbf29ce484222325ull)) return false;
+    size_t o = 6;
+    const auto take = [&](void* dst, size_t k) { if (o + k > buf.size() - 8) return false; memcpy(dst, buf.data() + o, k); o += k; return true; };
+    uint32_t cnt;
+    if (!take(&cnt, 4) || cnt > 16) return false;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        int32_t mode; uint32_t len;
+        if (!take(&mode, 4) || !take(&len, 4) || len > 4096 || o + len > buf.size() - 8) return false;
+        std::string nm(buf.data() + o, len); o += len;
+        if (mode < 0) co.init_name = nm; else co.trans_names[mode] = nm;
+    }
+    uint64_t cs;
+    if (!take(&cs, 8) || o + cs != buf.size() - 8) return false;
+    co.code.assign(buf.begin() + (long)o, buf.begin() + (long)(o + cs));
+    return !co.init_name.empty() && !co.code.empty();
+}
+
+void cache_write(const std::string& path, const CodeObject& co)
+{
+    std::vector<char> buf;
+    const auto put = [&](const void* p, size_t k) { const char* c = static_cast<const char*>(p); buf.insert(buf.end(), c, c + k); };
+    put("KJIT1\n", 6);
+    const uint32_t cnt = 1 + (uint32_t)co.trans_names.size();
+    put(&cnt, 4);
+    const auto put_name = [&](int32_t mode, const std::string& nm) { const uint32_t len = (uint32_t)nm.size(); put(&mode, 4); put(&len, 4); put(nm.data(), len); };
+    put_name(-1, co.init_name);
+    for (const auto& kv : co.trans_names) put_name(kv.first, kv.second);
+    const uint64_t cs = co.code.size();
+    put(&cs, 8); put(co.code.data(), co.code.size());
+    const uint64_t sum = fnv1a(buf.data(), buf.size(), 0xcbf29ce484222325ull);
+    put(&sum, 8);
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());     // (atomic publish; a concurrent writer produces the same bytes)
+}
+
 std::string trans_expr(int sampler, int E, int mode)
 {
     char b[128];
@@ -89,6 +181,25 @@ klara_status compile(const char* src, int sampler, int D, int E, const int* mode
         auto it = g_cache.find(key);
         if (it != g_cache.end()) { *out = &it->second; return KLARA_OK; }
     }
+    // same arithmetic contract as the ahead-of-time kernels: no contraction of a*b+c
+    const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value",
+                           "-Wno-unused-variable", "-Wno-unused-function" };
+    std::string optstr;
+    for (const char* o : opts) { optstr += o; optstr += ' '; }
+    const std::string disk = cache_file(key, optstr);
+    if (!disk.empty()) {
+        CodeObject cached;
+        if (cache_read(disk, cached)) {
+            bool complete = true;
+            for (int i = 0; i < nmodes; ++i) complete = complete && cached.trans_names.count(modes[i]) == 1;
+            if (complete) {
+                std::lock_guard<std::mutex> lk(g_cache_mutex);
+                auto ins = g_cache.emplace(key, std::move(cached));
+                *out = &ins.first->second;
+                return KLARA_OK;
+            }
+        }
+    }
     const bool needgrad = sampler == KLARA_SAMPLER_MALA || sampler == KLARA_SAMPLER_HMC;
     std::string tu;
     tu += "#define KLARA_D " + std::to_string(D) + "\n";
@@ -112,9 +223,6 @@ klara_status compile(const char* src, int sampler, int D, int E, const int* mode
     r->AddNameExpression(prog, ie.c_str());
     std::vector<std::string> te;
     for (int i = 0; i < nmodes; ++i) { te.push_back(trans_expr(sampler, E, modes[i])); r->AddNameExpression(prog, te.back().c_str()); }
-    // same arithmetic contract as the ahead-of-time kernels: no contraction of a*b+c
-    const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value",
-                           "-Wno-unused-variable", "-Wno-unused-function" };
     const hiprtcResult cr = r->CompileProgram(prog, (int)(sizeof opts / sizeof *opts), opts);
     size_t ls = 0;
     if (r->GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) { g_log.resize(ls); r->GetProgramLog(prog, &g_log[0]); }
@@ -132,6 +240,7 @@ klara_status compile(const char* src, int sampler, int D, int E, const int* mode
     if (ok) { co.code.resize(cs); ok = r->GetCode(prog, co.code.data()) == HIPRTC_SUCCESS; }
     r->DestroyProgram(&prog);
     if (!ok) { g_log += "\n(could not retrieve the code object)"; return KLARA_ERR_COMPILE; }
+    if (!disk.empty()) cache_write(disk, co);
     std::lock_guard<std::mutex> lk(g_cache_mutex);
     auto ins = g_cache.emplace(key, std::move(co));
     *out = &ins.first->second;

@@ -11,6 +11,10 @@ if str(ROOT / "tests") not in sys.path:
     sys.path.insert(0, str(ROOT / "tests"))
 
 
+# run-time compiled code objects of user-defined targets: cached inside the repository tree (git-ignored), never in $HOME
+os.environ.setdefault("KLARA_JIT_CACHE_DIR", str(ROOT / "build" / "jit_cache"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -188,3 +188,29 @@ def test_custom_target_source_compiles_without_a_gpu():
     with pytest.raises(K.KlaraError) as ei:
         K.CustomTarget(65, cases.SRC_NEGDOT).check(L.SAMPLER_MH)
     assert ei.value.status == L.ERR_UNSUPPORTED
+
+
+def test_custom_target_disk_cache(tmp_path):
+    """Run-time compiled code objects are cached on disk (KLARA_JIT_CACHE_DIR): a second process finds the entry instead of
+    compiling, a damaged entry is ignored and replaced, KLARA_JIT_CACHE=0 writes nothing."""
+    import os, subprocess, sys, time
+    code = ("import sys, time; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import cases, klara_jl_amd as K\nfrom klara_jl_amd import _lib as L\n"
+            "t0 = time.time(); K.CustomTarget(24, cases.SRC_QUARTIC_CHAIN).check(L.SAMPLER_HMC); print(time.time() - t0)\n"
+            % (str(ROOT), str(ROOT / "tests")))
+    def run(**env):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr
+        return float(r.stdout.strip().splitlines()[-1])
+    cache = tmp_path / "jit"
+    t_cold = run(KLARA_JIT_CACHE_DIR=str(cache))
+    files = list(cache.glob("*.kjit"))
+    assert len(files) == 1 and files[0].stat().st_size > 10000
+    t_warm = run(KLARA_JIT_CACHE_DIR=str(cache))
+    assert t_warm < 0.5 * t_cold, (t_cold, t_warm)
+    blob = bytearray(files[0].read_bytes()); blob[len(blob) // 2] ^= 0xFF; files[0].write_bytes(bytes(blob))
+    run(KLARA_JIT_CACHE_DIR=str(cache))                      # checksum mismatch -> recompiled and rewritten
+    assert files[0].read_bytes() != bytes(blob)
+    off = tmp_path / "off"
+    run(KLARA_JIT_CACHE_DIR=str(off), KLARA_JIT_CACHE="0")
+    assert not off.exists() or not list(off.glob("*.kjit"))
