@@ -302,6 +302,14 @@ klara_status klara_selftest_mfma_f64(int32_t device, const double* A, const doub
 klara_status klara_selftest_mfma_f64_4x4x4(int32_t device, const double* A, const double* B, const double* C,
                                            double* D);
 
+/* Self-test hook, no device needed: the launches a sequence of klara_run calls of the given lengths issues on a fresh job of
+ * this descriptor — transitions per launch k[i], the save-rule bookkeeping handed to the kernels (columns already saved,
+ * thinning phase of the launch's first post-burn-in transition) and flags (bit 0: a pooled tuner update follows, bit 1: a batch
+ * of the streaming batch means closes, bit 2: last launch of its klara_run call).  Launches end after steps_per_launch
+ * transitions, at the pooled tuner's events (tuners.jl:27-32) and at batch boundaries, whichever comes first. */
+klara_status klara_selftest_plan(const klara_desc* desc, int32_t nruns, const int64_t* run_lengths, int64_t capacity, int64_t* k,
+                                 int64_t* save_col0, int32_t* save_phase0, int32_t* flags, int64_t* nlaunches);
+
 /* CUSTOM target: compile `src` for gfx950 exactly as klara_create would for this sampler and dimension, without creating
  * a handle and without needing a GPU (a user checks a closure before submitting a job).  KLARA_OK or KLARA_ERR_COMPILE. */
 klara_status klara_check_custom_target(const char* src, int32_t sampler, int32_t ndims);

@@ -653,6 +653,50 @@ static hipError_t launch_bm_close(klara_handle* h)
     return hipSuccess;
 }
 
+// ---- launch planning: pure host logic (no device), shared by klara_run_async and klara_selftest_plan ------------------------
+// Where the next launch of a run ends: after steps_per_launch transitions (library default 16), at the next event of the pooled
+// tuner (tuners.jl:27-32 — the rate is pooled over the GPU's chains between launches) or where the next batch of saved samples
+// closes (streaming batch means), whichever comes first; plus the save-rule bookkeeping the kernels take from the host
+// (BasicMCRange.jl:36 postrange = (burnin+1):thinning:nsteps), so that they carry no 64-bit division.
+struct RunCursor { long long steps_done, m_prop, m_tot, bm_count; };
+struct PlannedLaunch { long long k; int save_phase0; long long save_col0; bool tune_after, bm_close_after; };
+
+static PlannedLaunch plan_launch(const klara_desc& d, const RunCursor& c, long long remaining)
+{
+    PlannedLaunch pl;
+    const bool pooled_cnt = d.tuner_mode == KLARA_TUNE_POOLED && cnt_predicate(d);
+    const long long spl = d.steps_per_launch > 0 ? d.steps_per_launch : 16;
+    long long k = remaining < spl ? remaining : spl;
+    if (pooled_cnt && c.m_tot <= d.burnin) {
+        const long long to_boundary = d.period - (c.m_prop % d.period);
+        if (k > to_boundary) k = to_boundary;
+    }
+    // saved sample number S is transition burnin + (S - 1) * thinning + 1
+    long long bm_close_at = -1;
+    if (d.bm_batchlen > 0) {
+        bm_close_at = d.burnin + ((c.bm_count + 1) * d.bm_batchlen - 1) * d.thinning + 1;
+        if (bm_close_at > d.nsteps) bm_close_at = -1;
+        else if (bm_close_at > c.steps_done && k > bm_close_at - c.steps_done) k = bm_close_at - c.steps_done;
+    }
+    pl.k = k;
+    // phase of the first post-burn-in step of this launch and the number of columns already saved
+    pl.save_phase0 = c.steps_done >= d.burnin ? (int)((c.steps_done - d.burnin) % d.thinning) : 0;
+    pl.save_col0 = c.steps_done > d.burnin ? (c.steps_done - d.burnin - 1) / d.thinning + 1 : 0;
+    pl.tune_after = pooled_cnt;
+    pl.bm_close_after = bm_close_at >= 0 && c.steps_done + k == bm_close_at;
+    return pl;
+}
+
+static void advance_cursor(const klara_desc& d, RunCursor& c, const PlannedLaunch& pl)
+{
+    if (pl.tune_after) {
+        c.m_prop += pl.k;
+        if (c.m_tot <= d.burnin && (c.m_prop % d.period) == 0) { c.m_tot += c.m_prop; c.m_prop = 0; }
+    }
+    c.steps_done += pl.k;
+    if (pl.bm_close_after) ++c.bm_count;
+}
+
 extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
 {
     if (!h || nsteps < 0) return KLARA_ERR_INVALID_ARG;
@@ -660,9 +704,6 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
     HIPCHK(hipSetDevice(h->d.device));
     const klara_desc& d = h->d;
     if ((d.monitor & KLARA_MON_ACCEPT) && h->steps_done + nsteps > h->accept_cap) return KLARA_ERR_STATE;
-    const bool pooled = d.tuner_mode == KLARA_TUNE_POOLED;
-    const int cnt = cnt_predicate(d);
-    long long spl = d.steps_per_launch > 0 ? d.steps_per_launch : 16;
     KParams p = make_params(h);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     if (h->nparts > 1) {                                   // fork: the partition streams start after everything queued so far
@@ -670,38 +711,24 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
         for (int j = 0; j + 1 < h->nparts; ++j) HIPCHK(hipStreamWaitEvent(h->side[j], h->fork_ev, 0));
     }
     long long remaining = nsteps, launches = 0;
+    RunCursor cur = { h->steps_done, h->m_prop, h->m_tot, h->bm_count };
     while (remaining > 0) {
-        long long k = remaining < spl ? remaining : spl;
-        if (pooled && cnt && h->m_tot <= d.burnin) {
-            const long long to_boundary = d.period - (h->m_prop % d.period);
-            if (k > to_boundary) k = to_boundary;
-        }
-        // streaming batch means: a launch ends where the next batch of saved samples closes — saved sample number S is
-        // transition burnin + (S - 1) * thinning + 1 (BasicMCRange.jl:36)
-        long long bm_close_at = -1;
-        if (h->bm_prev) {
-            bm_close_at = d.burnin + ((h->bm_count + 1) * d.bm_batchlen - 1) * d.thinning + 1;
-            if (bm_close_at > d.nsteps) bm_close_at = -1;
-            else if (bm_close_at > h->steps_done && k > bm_close_at - h->steps_done) k = bm_close_at - h->steps_done;
-        }
+        const PlannedLaunch pl = plan_launch(d, cur, remaining);
         KLaunch kl;
         kl.group0 = 0; kl.group_end = 0x7fffffffffffffffll;
-        kl.t0 = (unsigned long long)h->steps_done;
-        kl.nsteps = (int)k;
-        // save rule bookkeeping (BasicMCRange.jl:36 postrange = (burnin+1):thinning:nsteps), done on the host so
-        // the kernels carry no 64-bit division: phase of the first post-burn-in step of this launch and the
-        // number of columns already saved
-        kl.save_phase0 = h->steps_done >= d.burnin ? (int)((h->steps_done - d.burnin) % d.thinning) : 0;
-        kl.save_col0 = h->steps_done > d.burnin ? (h->steps_done - d.burnin - 1) / d.thinning + 1 : 0;
+        kl.t0 = (unsigned long long)cur.steps_done;
+        kl.nsteps = (int)pl.k;
+        kl.save_phase0 = pl.save_phase0;
+        kl.save_col0 = pl.save_col0;
         HIPCHK(launch_steps(h, kl));
-        if (pooled && cnt) {
-            hipLaunchKernelGGL(k_pooled_tune, dim3(1), dim3(64), 0, h->stream, p, (int)k);
+        if (pl.tune_after) {
+            hipLaunchKernelGGL(k_pooled_tune, dim3(1), dim3(64), 0, h->stream, p, (int)pl.k);
             HIPCHK(hipGetLastError());
-            h->m_prop += k;
-            if (h->m_tot <= d.burnin && (h->m_prop % d.period) == 0) { h->m_tot += h->m_prop; h->m_prop = 0; }
         }
-        h->steps_done += k; remaining -= k; ++launches;
-        if (bm_close_at >= 0 && h->steps_done == bm_close_at) { HIPCHK(launch_bm_close(h)); ++h->bm_count; }
+        if (pl.bm_close_after) HIPCHK(launch_bm_close(h));                 // (reads h->bm_count: batches closed before this one)
+        advance_cursor(d, cur, pl);
+        h->steps_done = cur.steps_done; h->m_prop = cur.m_prop; h->m_tot = cur.m_tot; h->bm_count = cur.bm_count;
+        remaining -= pl.k; ++launches;
     }
     for (int j = 0; j + 1 < h->nparts; ++j) {              // join: the caller's stream continues when every partition is done
         HIPCHK(hipEventRecord(h->join_ev[j], h->side[j]));
@@ -1251,6 +1278,33 @@ extern "C" klara_status klara_check_custom_target(const char* src, int32_t sampl
 }
 
 extern "C" const char* klara_compile_log(void) { return klara_jit_log(); }
+
+extern "C" klara_status klara_selftest_plan(const klara_desc* desc, int32_t nruns, const int64_t* run_lengths, int64_t capacity,
+                                            int64_t* k, int64_t* save_col0, int32_t* save_phase0, int32_t* flags, int64_t* nlaunches)
+{
+    if (!run_lengths || nruns <= 0 || !nlaunches) return KLARA_ERR_INVALID_ARG;
+    const klara_status st = validate(desc);
+    if (st != KLARA_OK) return st;
+    RunCursor cur = { 0, 0, desc->period, 0 };           // tuner_state: totproposed starts at period (samplers.jl:39-45)
+    long long n = 0;
+    for (int r = 0; r < nruns; ++r) {
+        long long remaining = run_lengths[r];
+        if (remaining < 0) return KLARA_ERR_INVALID_ARG;
+        while (remaining > 0) {
+            const PlannedLaunch pl = plan_launch(*desc, cur, remaining);
+            if (n < capacity) {
+                if (k) k[n] = pl.k;
+                if (save_col0) save_col0[n] = pl.save_col0;
+                if (save_phase0) save_phase0[n] = pl.save_phase0;
+                if (flags) flags[n] = (pl.tune_after ? 1 : 0) | (pl.bm_close_after ? 2 : 0) | (remaining == pl.k ? 4 : 0);
+            }
+            advance_cursor(*desc, cur, pl);
+            remaining -= pl.k; ++n;
+        }
+    }
+    *nlaunches = n;
+    return KLARA_OK;
+}
 
 extern "C" const char* klara_strerror(klara_status s)
 {

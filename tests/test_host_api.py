@@ -214,3 +214,63 @@ def test_custom_target_disk_cache(tmp_path):
     off = tmp_path / "off"
     run(KLARA_JIT_CACHE_DIR=str(off), KLARA_JIT_CACHE="0")
     assert not off.exists() or not list(off.glob("*.kjit"))
+
+
+def _plan(klib, runs, **kw):
+    d = L.KlaraDesc()
+    d.struct_size = C.sizeof(L.KlaraDesc); d.abi_version = L.KLARA_ABI_VERSION
+    d.sampler, d.target, d.nchains, d.ndims = L.SAMPLER_MALA, L.TARGET_GAUSS_DIAG, 8, 3
+    d.driftstep, d.period, d.thinning, d.nsteps = 0.5, 100, 1, sum(runs)
+    for key, v in kw.items():
+        setattr(d, key, v)
+    runs_a = np.asarray(runs, np.int64)
+    cap = int(sum(runs)) + 8
+    k = np.zeros(cap, np.int64); col = np.zeros(cap, np.int64); ph = np.zeros(cap, np.int32); fl = np.zeros(cap, np.int32)
+    n = C.c_int64(0)
+    L.check(klib.klara_selftest_plan(C.byref(d), len(runs), runs_a.ctypes.data, cap, k.ctypes.data, col.ctypes.data, ph.ctypes.data,
+                                     fl.ctypes.data, C.byref(n)), "selftest_plan")
+    n = int(n.value)
+    return k[:n], col[:n], ph[:n], fl[:n]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_launch_planning_is_pure_host_logic(klib, seed):
+    """klara_run's launch splitting, checked without a device against a step-by-step model: every launch stays within
+    steps_per_launch, never crosses an event of the pooled tuner (tuners.jl:27-32: every `period` proposals while
+    totproposed <= burnin, totproposed starting at period) or a batch boundary of the streaming batch means, and carries the
+    save-rule bookkeeping of BasicMCRange.jl:36 ((burnin+1):thinning:nsteps)."""
+    rng = np.random.default_rng(seed)
+    burnin, thinning, period = int(rng.choice([0, 5, 30, 100])), int(rng.choice([1, 2, 7])), int(rng.choice([3, 10, 25]))
+    spl = int(rng.choice([0, 1, 4, 16, 50]))
+    pooled = bool(rng.integers(0, 2)); bm = int(rng.choice([0, 0, 3, 10]))
+    runs = [int(v) for v in rng.integers(1, 120, int(rng.integers(1, 5)))]
+    total = sum(runs)
+    if total <= burnin:
+        runs.append(burnin + 1); total = sum(runs)
+    kw = dict(burnin=burnin, thinning=thinning, period=period, steps_per_launch=spl, bm_batchlen=bm)
+    if pooled:
+        kw.update(tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.5)
+    if bm:
+        kw.update(monitor=L.MON_SUMMARIES)
+    k, col, ph, fl = _plan(klib, runs, **kw)
+    assert k.sum() == total and (k >= 1).all() and (k <= (spl or 16)).all()
+    ends = np.cumsum(k); starts = ends - k
+    # launches never straddle two klara_run calls
+    run_ends = np.cumsum(runs)
+    assert set(run_ends) <= set(ends) and np.array_equal(ends[(fl & 4) != 0], run_ends)
+    # step-by-step model of the pooled tuner's events and of the batch boundaries
+    tune_events, prop, tot = set(), 0, period
+    for t in range(1, total + 1):
+        prop += 1
+        if pooled and tot <= burnin and prop % period == 0:
+            tune_events.add(t); tot += prop; prop = 0
+    saved = [t for t in range(burnin + 1, total + 1, thinning)]
+    batch_ends = {saved[i] for i in range(bm - 1, len(saved), bm)} if bm else set()
+    for a, b in zip(starts, ends):
+        assert not any(a < e < b for e in tune_events | batch_ends), (a, b)
+    assert {int(e) for e, f in zip(ends, fl) if f & 2} == batch_ends
+    assert ((fl & 1) != 0).all() == pooled and ((fl & 1) != 0).any() == pooled
+    # save rule: columns saved before the launch, and the thinning phase of its first post-burn-in transition
+    for a, c, p_ in zip(starts, col, ph):
+        assert c == len([t for t in saved if t <= a])
+        assert p_ == ((a - burnin) % thinning if a >= burnin else 0)
