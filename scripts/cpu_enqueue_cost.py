@@ -1,3 +1,4 @@
+"""Host cost of enqueueing 2,000 one-transition launches (klara_run_async) against the time the GPU needs to run them."""
 import sys, time
 from pathlib import Path; sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import klara_jl_amd as K

@@ -1,3 +1,4 @@
+"""The cfg 5 workload alone (rats HMC L=32, pooled tuner, 131,072 chains), for rocprofv3 counter passes."""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
