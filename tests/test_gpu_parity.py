@@ -1040,3 +1040,15 @@ def test_full_size_hmc_dense_properties():
     mean = s / (ns * n)
     assert np.max(np.abs(mean)) < 0.02
     eng.close()
+
+
+def test_c_example_runs_the_readme_job(tmp_path):
+    """examples/readme_job.c (plain C99 against the C ABI): the README job for 4,096 chains reproduces the target's moments."""
+    import re, subprocess
+    from test_host_api import _build_c_example
+    r = subprocess.run([str(_build_c_example(tmp_path)), "4096"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"mean = \(([-0-9.]+), ([-0-9.]+)\).*E\[z1\^2\] = ([0-9.]+).*acceptance = ([0-9.]+)", r.stdout)
+    assert m, r.stdout
+    m0, m1, v0, acc = map(float, m.groups())
+    assert abs(m0) < 0.01 and abs(m1) < 0.01 and abs(v0 - 0.5) < 0.01 and 0.35 < acc < 0.5

@@ -274,3 +274,24 @@ def test_launch_planning_is_pure_host_logic(klib, seed):
     for a, c, p_ in zip(starts, col, ph):
         assert c == len([t for t in saved if t <= a])
         assert p_ == ((a - burnin) % thinning if a >= burnin else 0)
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = tmp_path / "readme_job"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-I", str(ROOT / "include"),
+                        str(ROOT / "examples" / "readme_job.c"), "-L", str(ROOT / "klara.jl_amd" / "lib"), "-lklara_hip",
+                        f"-Wl,-rpath,{ROOT / 'klara.jl_amd' / 'lib'}", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c99_and_the_c_example_links(tmp_path):
+    """include/klara_hip.h is a C header (no C++, no torch types): examples/readme_job.c builds with gcc -std=c99 -pedantic
+    -Werror against the shared library.  Without a GPU klara_create reports a status code — it never aborts."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([str(exe), "8"], capture_output=True, text=True)
+        assert r.returncode == 1 and "HIP runtime error or no device" in r.stderr
