@@ -96,6 +96,20 @@ def test_create_validates_like_the_reference_constructors(klib):
     assert status(tuner=L.TUNER_ACCEPT_RATE, targetrate=1.5) == L.ERR_INVALID_ARG
     assert status(nchains=0) == L.ERR_INVALID_ARG
     assert status(target=K.GaussDiagTarget.negdot(600)) == L.ERR_UNSUPPORTED
+    # the later additions to the descriptor are validated in the same place
+    assert status(bm_batchlen=10) == L.ERR_INVALID_ARG                   # streaming batch means need the running sums
+    assert status(bm_batchlen=-1, monitor=L.MON_SUMMARIES) == L.ERR_INVALID_ARG
+    assert status(nstreams=5) == L.ERR_INVALID_ARG
+    assert status(tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.6, da_nadapt=10) == L.ERR_UNSUPPORTED      # HMC only (HMC.jl:124-133)
+    assert status(sampler=L.SAMPLER_HMC, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.6, da_nadapt=0) == L.ERR_INVALID_ARG
+    assert status(sampler=L.SAMPLER_MH, mh_sigma=[1.0, 1.0], monitor=L.MON_HIST_GRAD) in (L.ERR_INVALID_ARG, L.ERR_HIP)
+    import cases
+    assert status(target=K.CustomTarget(65, cases.SRC_NEGDOT)) == L.ERR_UNSUPPORTED                    # one lane holds the vector: D <= 64
+    assert status(target=K.CustomTarget(2, cases.SRC_NEGDOT, data=np.zeros(0))) in (0, L.ERR_HIP)       # empty data block is fine
+    rng = np.random.default_rng(0)
+    big = K.LogisticTarget(rng.standard_normal((1434, 4)), np.zeros(1434))
+    assert status(target=big, driftstep=0.01) == L.ERR_UNSUPPORTED                                     # data rows must fit the LDS budget
+    assert status(sampler=L.SAMPLER_SLICE, slice_widths=np.ones(8), target=K.GaussDenseTarget(np.eye(8))) == L.ERR_UNSUPPORTED
 
 
 def test_no_cpu_fallback_without_gpu(klib):
