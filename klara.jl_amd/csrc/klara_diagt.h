@@ -32,6 +32,9 @@
 #ifndef KLARA_DT_W1
 #define KLARA_DT_W1 4
 #endif
+#ifndef KLARA_DT_WF
+#define KLARA_DT_WF 2     // wavefronts per SIMD requested for the fused / monitored / tuned instantiations
+#endif
 #ifdef KLARA_DT_PERSISTENT
 #define KLARA_DT_GROUP_LOOP for (long long grp = kl.group0 + wave0; grp < kl.group_end && grp * CPW < p.nchains; grp += nwaves)
 #else
@@ -135,7 +138,7 @@ __device__ __forceinline__ void diag_elem(double x, double w, double m2w, double
 // DA (HMC only): DualAveragingMCTuner — per-chain step and trajectory length (iterate/HMC.jl:142-144, 225-249); the
 // wavefront runs to the longest trajectory of its chains, a finished chain's lanes keep their state.
 template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false, bool DA = false>
-__global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? KLARA_DT_W1 : 2) : 1))
+__global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? KLARA_DT_W1 : KLARA_DT_WF) : 1))
 void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 {
     static_assert(!(ONESTEP && (MON || TUNE)), "monitored / tuned jobs run the committing kernel");
