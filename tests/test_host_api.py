@@ -309,3 +309,26 @@ def test_header_is_plain_c99_and_the_c_example_links(tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([str(exe), "8"], capture_output=True, text=True)
         assert r.returncode == 1 and "HIP runtime error or no device" in r.stderr
+
+
+def test_bench_kernel_register_budget(tmp_path):
+    """Occupancy guard that needs no GPU: the headline kernel k_diagt<MALA, NP=7, Q=8, ONESTEP, UNITW> must fit 4 wavefronts per
+    SIMD (<= 128 VGPRs) without scratch, and its fused sibling 2 (<= 256) without scratch."""
+    import re, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    out = tmp_path / "k.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", str(ROOT / "klara.jl_amd" / "csrc"),
+                        "-S", "--cuda-device-only", "-o", str(out), str(ROOT / "klara.jl_amd" / "csrc" / "klara_diagt_mala.hip")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    meta = {}
+    for blk in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", out.read_text(), re.S):
+        t = blk.group(0)
+        name = re.search(r"\.name:\s+(\S+)", t).group(1)
+        meta[name] = {k: int(re.search(r"\." + k + r":\s+(\d+)", t).group(1)) for k in ("vgpr_count", "private_segment_fixed_size")}
+    one = next(v for k, v in meta.items() if k.startswith("_Z7k_diagtILi1ELi7ELi8ELb1ELb1ELb0ELb0ELb0E"))
+    fused = next(v for k, v in meta.items() if k.startswith("_Z7k_diagtILi1ELi7ELi8ELb0ELb1ELb0ELb0ELb0E"))
+    assert one["vgpr_count"] <= 128 and one["private_segment_fixed_size"] == 0, one
+    assert fused["vgpr_count"] <= 256 and fused["private_segment_fixed_size"] == 0, fused
