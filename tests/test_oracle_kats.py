@@ -285,3 +285,36 @@ def test_slice_sampler_moments():
     m = job.sum.sum(0) / n
     v = job.sumsq.sum(0) / n - m * m
     assert np.all(np.abs(m) < 0.02) and np.all(np.abs(v - 0.5) < 0.02)
+
+
+def test_hierarchical_target_accuracy_against_200_bit_arithmetic():
+    """The hierarchical target forms a unit's residual sums from its sufficient statistics (sum y, sum y x, sum y^2); the
+    cancellation in sum r^2 = Syy + a (T a - 2 Sy) + b (...) costs little: log-target and gradient agree with a 200-bit
+    evaluation of the model as written (r_ij = Y_ij - a_i - b_i xc_j) to ~1e-14 relative around the rats posterior."""
+    mp = pytest.importorskip("mpmath")
+    t = cases.rats_target()
+    Y, xc = t.Y, t.xc
+    R, T = Y.shape
+    rng = np.random.default_rng(0)
+    x0 = t.least_squares_start()
+    job = O.OracleJob(sampler=L.SAMPLER_HMC, target_kind=L.TARGET_HIER_NORMAL, nchains=1, ndims=t.ndims, nsteps=10, hier_Y=Y, hier_xc=xc)
+    mp.mp.prec = 200
+    p0, a0, b0 = mp.mpf(1e-4), mp.mpf(1e-3), mp.mpf(1e-3)
+    for _ in range(12):
+        th = x0 + 0.05 * rng.standard_normal(t.ndims)
+        lt, g = job.eval_target(th)
+        a = [mp.mpf(v) for v in th[0:2 * R:2]]; b = [mp.mpf(v) for v in th[1:2 * R:2]]
+        ac, bc, sc, sa, sb = [mp.mpf(v) for v in th[2 * R:]]
+        wc, wa, wb = mp.e ** (-2 * sc), mp.e ** (-2 * sa), mp.e ** (-2 * sb)
+        res = [[mp.mpf(Y[i, j]) - a[i] - b[i] * mp.mpf(xc[j]) for j in range(T)] for i in range(R)]
+        C2 = sum(r * r for row in res for r in row)
+        A2 = sum((a[i] - ac) ** 2 for i in range(R)); B2 = sum((b[i] - bc) ** 2 for i in range(R))
+        ref = ((-R * T * sc - wc * C2 / 2) + (-2 * a0 * sc - b0 * wc) + (-R * sa - wa * A2 / 2) + (-2 * a0 * sa - b0 * wa)
+               + (-R * sb - wb * B2 / 2) + (-2 * a0 * sb - b0 * wb) - p0 / 2 * (ac ** 2 + bc ** 2))
+        assert abs((mp.mpf(lt) - ref) / ref) < 1e-12
+        for i in range(R):
+            ga = wc * sum(res[i]) - wa * (a[i] - ac)
+            gb = wc * sum(res[i][j] * mp.mpf(xc[j]) for j in range(T)) - wb * (b[i] - bc)
+            assert abs(mp.mpf(g[2 * i]) - ga) < 1e-12 * (abs(ga) + 1) and abs(mp.mpf(g[2 * i + 1]) - gb) < 1e-12 * (abs(gb) + 1)
+        gsc = (wc * C2 - R * T - 2 * a0) + 2 * b0 * wc
+        assert abs(mp.mpf(g[2 * R + 2]) - gsc) < 1e-11 * (abs(gsc) + 1)
