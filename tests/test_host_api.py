@@ -121,6 +121,17 @@ def test_no_cpu_fallback_without_gpu(klib):
     assert ei.value.status == L.ERR_HIP
 
 
+def test_bench_and_smoke_refuse_to_run_without_a_gpu():
+    """The measured path and the smoke check have no CPU fallback either: both stop with an error on a box without a GPU."""
+    import subprocess, sys, torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True)
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True, text=True, cwd=str(ROOT))
+    assert r.returncode != 0 and "KlaraError" in r.stderr
+
+
 def test_basic_mc_range():
     r = K.BasicMCRange(nsteps=10000, burnin=1000)
     assert (r.nsteps, r.burnin, r.thinning, r.npoststeps) == (10000, 1000, 1, 9000)
