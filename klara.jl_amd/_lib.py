@@ -72,7 +72,7 @@ EXPORTS = [
     "klara_run_async", "klara_synchronize", "klara_reset", "klara_get_state", "klara_get_accept_mask",
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
     "klara_get_chain_fields", "klara_get_chain_mcvar", "klara_get_chain_bm", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
-    "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
+    "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_normal_tail", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
     "klara_comm_unique_id", "klara_comm_init", "klara_comm_destroy", "klara_gather_summaries",
     "klara_check_custom_target", "klara_compile_log", "klara_selftest_plan", "klara_abi_version",
 ]
@@ -117,6 +117,7 @@ def load() -> C.CDLL:
         "klara_get_layout": [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
         "klara_selftest_rocrand_blocks": [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p],
         "klara_selftest_math": [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
+        "klara_selftest_normal_tail": [C.c_int32, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_selftest_mfma_f64": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_selftest_mfma_f64_4x4x4": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_comm_unique_id": [C.c_void_p],

@@ -1237,6 +1237,58 @@ extern "C" klara_status klara_selftest_math(int32_t device, int32_t op, int64_t 
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }
 
+// |z| exceedance counts and raw power sums of the proposal normals, drawn exactly as the transition kernels draw them
+// (kd_normal_pair of kd_stream_block(seed, chain, transition, slot 0)); one thread per chain, wave-level ballots feed one
+// atomic per wavefront and threshold.  counts[k] = #{|z| > thr[k]} over 2 * nchains * ntransitions normals.
+__global__ __launch_bounds__(256) void k_normal_tail(unsigned long long seed, unsigned long long first_chain, long long nchains,
+                                                     long long ntransitions, int nthr, const double* __restrict__ thr,
+                                                     unsigned long long* __restrict__ counts, double* __restrict__ moments)
+{
+    kd_tables_to_lds();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < nchains;
+    unsigned long long c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    double s1 = 0.0, s2 = 0.0, s4 = 0.0, mx = 0.0;
+    for (long long t = 0; t < ntransitions; ++t) {
+        double z0, z1;
+        kd_normal_pair(kd_stream_block(seed, first_chain + (unsigned long long)(ok ? i : 0), (unsigned long long)t, 0u), &z0, &z1);
+        if (!ok) continue;
+        const double a0 = z0 < 0.0 ? -z0 : z0, a1 = z1 < 0.0 ? -z1 : z1;
+        for (int k = 0; k < 8; ++k) if (k < nthr) c[k] += (a0 > thr[k] ? 1ull : 0ull) + (a1 > thr[k] ? 1ull : 0ull);
+        s1 += z0 + z1; s2 += z0 * z0 + z1 * z1; s4 += (z0 * z0) * (z0 * z0) + (z1 * z1) * (z1 * z1);
+        mx = a0 > mx ? a0 : mx; mx = a1 > mx ? a1 : mx;
+    }
+    for (int k = 0; k < 8; ++k) if (k < nthr && c[k] != 0) atomicAdd(&counts[k], c[k]);
+    if (ok) {
+        atomicAdd(&moments[0], s1); atomicAdd(&moments[1], s2); atomicAdd(&moments[2], s4);
+        atomicMax((unsigned long long*)&moments[3], (unsigned long long)__double_as_longlong(mx));   // (non-negative doubles order like integers)
+    }
+}
+
+extern "C" klara_status klara_selftest_normal_tail(int32_t device, uint64_t seed, uint64_t first_chain, int64_t nchains,
+                                                   int64_t ntransitions, int32_t nthr, const double* thr, uint64_t* counts,
+                                                   double* moments)
+{
+    if (!thr || !counts || nthr <= 0 || nthr > 8 || nchains <= 0 || ntransitions <= 0) return KLARA_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(device));
+    double* dthr = nullptr; unsigned long long* dc = nullptr; double* dm = nullptr;
+    hipError_t e = dalloc(&dthr, 8);
+    if (e == hipSuccess) e = dalloc(&dc, 8);
+    if (e == hipSuccess) e = dalloc(&dm, 4);
+    if (e == hipSuccess) e = hipMemcpy(dthr, thr, sizeof(double) * (size_t)nthr, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dc, 0, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(dm, 0, 4 * sizeof(double));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_normal_tail, dim3((unsigned)((nchains + 255) / 256)), dim3(256), 0, 0, (unsigned long long)seed,
+                           (unsigned long long)first_chain, (long long)nchains, (long long)ntransitions, (int)nthr, dthr, dc, dm);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(counts, dc, sizeof(uint64_t) * (size_t)nthr, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && moments) e = hipMemcpy(moments, dm, 4 * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dthr); hipFree(dc); hipFree(dm);
+    return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
+}
+
 extern "C" klara_status klara_selftest_mfma_f64(int32_t device, const double* A, const double* B,
                                                 const double* C, double* D)
 {

@@ -744,6 +744,34 @@ void ko_normal_pair(const uint32_t blk[4], double out[2])
     kd_normal_pair(b, &out[0], &out[1]);
 }
 double ko_u52(uint32_t hi, uint32_t lo) { return kd_u52(hi, lo); }
+/* batch form (n blocks -> 2n normals) and the CPU mirror of klara_selftest_normal_tail (same blocks, same counts) */
+void ko_normal_pairs(int64_t n, const uint32_t* blk, double* out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        kd_u32x4 b = { blk[4 * i], blk[4 * i + 1], blk[4 * i + 2], blk[4 * i + 3] };
+        kd_normal_pair(b, &out[2 * i], &out[2 * i + 1]);
+    }
+}
+void ko_normal_tail(uint64_t seed, uint64_t first_chain, int64_t nchains, int64_t ntransitions, int32_t nthr, const double* thr,
+                    uint64_t* counts, double* moments)
+{
+    uint64_t c[8] = { 0 };
+    double s1 = 0.0, s2 = 0.0, s4 = 0.0, mx = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : c[:8], s1, s2, s4) reduction(max : mx)
+    for (int64_t i = 0; i < nchains; ++i)
+        for (int64_t t = 0; t < ntransitions; ++t) {
+            double z[2];
+            kd_normal_pair(kd_stream_block(seed, first_chain + (uint64_t)i, (uint64_t)t, 0u), &z[0], &z[1]);
+            for (int h = 0; h < 2; ++h) {
+                const double a = fabs(z[h]);
+                for (int k = 0; k < nthr && k < 8; ++k) c[k] += a > thr[k];
+                s1 += z[h]; s2 += z[h] * z[h]; s4 += (z[h] * z[h]) * (z[h] * z[h]);
+                if (a > mx) mx = a;
+            }
+        }
+    for (int k = 0; k < nthr && k < 8; ++k) counts[k] = c[k];
+    if (moments) { moments[0] = s1; moments[1] = s2; moments[2] = s4; moments[3] = mx; }
+}
 
 /* target closures for KATs: evaluates lt and gradient of one point */
 int ko_eval_target(const klara_desc* d, const ko_layout* L, const double* x, double* lt, double* g)

@@ -78,6 +78,69 @@ def test_box_muller_moments():
     assert stats.kstest(z[:50000], "norm").pvalue > 1e-3
 
 
+def _blocks_from_mantissas(m1, m2):
+    """Philox words (x, y, z, w) whose kd_u52 uniforms have the 52-bit mantissas m1 (radius) and m2 (angle)."""
+    m1 = np.asarray(m1, dtype=np.uint64); m2 = np.asarray(m2, dtype=np.uint64)
+    b = np.empty((m1.size, 4), np.uint32)
+    b[:, 0] = (m1 >> np.uint64(20)).astype(np.uint32); b[:, 1] = ((m1 & np.uint64(0xfffff)) << np.uint64(12)).astype(np.uint32)
+    b[:, 2] = (m2 >> np.uint64(20)).astype(np.uint32); b[:, 3] = ((m2 & np.uint64(0xfffff)) << np.uint64(12)).astype(np.uint32)
+    return b
+
+
+def test_normal_pair_against_independent_high_precision_box_muller():
+    """kd_normal_pair (detmath.h: the one source of proposal normals on the device AND in the oracle) against an independent
+    evaluation of the same definition from the same Philox words: u = (2m + 1) 2^-53, z0 = sqrt(-2 ln u1) cos(2 pi u2),
+    z1 = sqrt(-2 ln u1) sin(2 pi u2) in mpmath at 160 bits — 100,000 random blocks plus the extreme points of the 52-bit
+    lattice (smallest / largest radius uniform, angles at and next to every multiple of pi/2).
+
+    Bound: |z - exact| <= 2.5 ulp(radius).  (Measured: 2.02.)  ulp(z) is the wrong yardstick next to the zeros of sin / cos:
+    kd_sincos2pi is accurate to 2^-52 ABSOLUTE, so where |cos| ~ 1e-15 the product is off by a few 1e-16 — 30 % of a value
+    that is itself 1e-15 of a standard deviation.  Where the trigonometric factor is >= 1/2 in magnitude the error is also
+    asserted in ulps of z itself (<= 4.5: two binades of radius ulps)."""
+    import mpmath as mp
+    rng = np.random.default_rng(20260927)
+    n = 100000
+    top = (1 << 52) - 1
+    edge1 = [0, 1, 2, top, top - 1, 1 << 51, (1 << 51) - 1, 1 << 40, 12345]
+    edge2 = [0, 1, top, top - 1] + [q * (1 << 50) + d for q in (1, 2, 3) for d in (-2, -1, 0, 1)] + [(j << 44) + d for j in (1, 77, 128, 255) for d in (-1, 0)]
+    m1 = np.concatenate([rng.integers(0, 1 << 52, n, dtype=np.uint64), np.repeat(np.array(edge1, np.uint64), len(edge2))])
+    m2 = np.concatenate([rng.integers(0, 1 << 52, n, dtype=np.uint64), np.tile(np.array(edge2, np.uint64), len(edge1))])
+    blk = _blocks_from_mantissas(m1, m2)
+    out = np.zeros((blk.shape[0], 2))
+    O.load().ko_normal_pairs(blk.shape[0], blk.ctypes.data, out.ctypes.data)
+    worst_rad = worst_z = 0.0
+    with mp.workprec(160):
+        two53, twopi = mp.mpf(2) ** -53, 2 * mp.pi
+        for i in range(blk.shape[0]):
+            u1 = (2 * int(m1[i]) + 1) * two53; u2 = (2 * int(m2[i]) + 1) * two53
+            rad = mp.sqrt(-2 * mp.log(u1)); a = twopi * u2
+            ulp_rad = mp.mpf(float(np.spacing(float(rad))))
+            for h, trig in ((0, mp.cos(a)), (1, mp.sin(a))):
+                err = abs(mp.mpf(float(out[i, h])) - rad * trig)
+                worst_rad = max(worst_rad, float(err / ulp_rad))
+                if abs(trig) >= 0.5:
+                    worst_z = max(worst_z, float(err / mp.mpf(float(np.spacing(abs(float(rad * trig)))))))
+    assert worst_rad <= 2.5, worst_rad
+    assert worst_z <= 4.5, worst_z
+    # the largest normal the generator can produce: u1 = 2^-53 -> sqrt(2 * 53 ln 2) = 8.5718...
+    assert abs(np.abs(out[n:]).max() - math.sqrt(106 * math.log(2))) < 1e-13
+
+
+def test_normal_tail_mass_on_the_host():
+    """Tail mass of the generator as the kernels call it (stream blocks of consecutive chains / transitions): 2 x 10^7 draws,
+    counts of |z| > 1, 2, 3, 4 within 4.5 binomial standard deviations of the normal law, second and fourth moments 1 and 3."""
+    lib = O.load()
+    thr = np.array([1.0, 2.0, 3.0, 4.0]); cnt = np.zeros(4, np.uint64); mom = np.zeros(4)
+    nch, nt = 10000, 1000
+    lib.ko_normal_tail(987654321, 5, nch, nt, 4, thr.ctypes.data, cnt.ctypes.data, mom.ctypes.data)
+    ndraw = 2 * nch * nt
+    p = 2 * stats.norm.sf(thr)
+    assert np.all(np.abs(cnt.astype(float) - ndraw * p) < 4.5 * np.sqrt(ndraw * p * (1 - p))), (cnt, ndraw * p)
+    assert abs(mom[0] / ndraw) < 4.5 / math.sqrt(ndraw)
+    assert abs(mom[1] / ndraw - 1.0) < 4.5 * math.sqrt(2.0 / ndraw) and abs(mom[2] / ndraw - 3.0) < 4.5 * math.sqrt(96.0 / ndraw)
+    assert mom[3] < 8.58
+
+
 def test_tuner_score_kats(oracle):
     # test/common.jl:6 (runs) and test/AcceptanceRateMCTuner.jl:8-14 (stale file, live functions)
     assert oracle.ko_logistic(0.7, 3, 4, 2.1, 1.4) == 1.4110527196983078
