@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — whole-job MCMC transition throughput on MI355X (BASELINE.json metric).
 
-Workload at N=1 (BASELINE.json configs[1]): MALA driftstep=0.9, lt = -|x|^2 on D=100, 65,536 chains,
-x0 ~ N(0, I) from the Philox init stream, VanillaMCTuner, state resident in HBM before the timed region.
-A "step" is one transition (one `iterate!`) of every chain.  With --gpus N every rank owns its own
-65,536-chain shard (weak scaling, global chain ids = rank*65536 + local), no data-path collective; the
-only exchange is the end-of-run all-reduce of pooled chain summaries over RCCL, inside the timed region.
+Workload at N = 1 (BASELINE.json configs[1]): MALA driftstep = 0.9, lt = -|x|^2 on D = 100, 65,536 chains, x0 ~ N(0, I) from the
+Philox init stream, VanillaMCTuner, state resident in HBM before the timed region.  A "step" is one transition (one `iterate!`,
+src/samplers/iterate/MALA.jl:78-153) of every chain INCLUDING the save rule of `run(job)` (BasicMCJob.jl:226-231): every step is
+in the post-burn-in range and is accumulated into the per-chain running sums (KLARA_MON_SUMMARIES) that `mean(chain)` reads.
+`klara_run` IS the `for i in 1:nsteps` loop (BasicMCJob.jl:219-238): the library's default of 16 transitions per kernel launch is
+the headline (config.steps_per_launch), one transition per launch is reported in `extra`.
 
-Prints ONE JSON line (rank 0).  Extra keys beyond the driver's contract:
-  roofline      dominant transition kernel (k_diagt<MALA>, layout kind 3): algorithmic HBM bytes per launch / mean launch
-                duration from HIP events on the launch stream, measured in a separate pass with every launch on one stream
-                (the timed region overlaps two half-size launches on two streams: config.streams); DESIGN.md sections 4-5
-                give the per-unit figures; `traffic` = PMC bytes of the same command (profiles/)
-  cpu_baseline  the CPU oracle ("port" of the reference path) timed on this box's host cores on a bounded
-                sample of the same workload (N=1 only)
-  extra         secondary measurements outside the timed region: fused launches, HMC leapfrog rates (diagonal and dense /
-                FP64-MFMA target), and BASELINE configs 4 and 5 at their per-GPU share
+Timed region: `--reps` (5) repetitions of exactly `--steps` transitions, each bracketed by a barrier + torch.cuda.synchronize()
+on both sides (max over ranks per repetition); `value` uses the MEDIAN repetition.  With --gpus N every rank owns its own shard
+(weak scaling: 65,536 chains per GPU, global chain ids = rank * 65,536 + local; `--scaling strong`: `--total-chains` sharded over
+the ranks), no data-path collective; the only exchange is the end-of-run reduction of the chain summaries — pooled on the device
+and, for N > 1, all-reduced over RCCL — once, after the job's last transition; it is timed on its own (config.summary_gather_ms:
+an end-of-run cost of ~0.1 ms does not belong inside a timed region that the driver may make 20 transitions short).
+
+Prints ONE JSON line (rank 0).  Keys beyond the driver's contract:
+  roofline      the dominant transition kernel.  `bound` = "valu": the kernel is bound by vector-ALU issue (in-kernel Philox +
+                Box-Muller), so `achieved` = VALU-busy SIMD-cycles per second = SQ_ACTIVE_INST_VALU (quad-cycles, x 4) per launch,
+                taken from the committed PMC summary profiles/r2_pmc_kernels.json of this command, / the mean launch duration
+                measured HERE with HIP events on the launch stream (one launch at a time, nstreams = 1); `peak` = 1024 SIMDs x
+                2.4 GHz.  `hbm` gives the byte side: SURVEY section 8(d)'s contract bytes, the bytes this kernel has to move,
+                the PMC traffic and the fraction of 8 TB/s each amounts to.
+  cpu_baseline  the CPU oracle ("port" of the reference path, OpenMP over chains) on a bounded sample of the same workload
+  extra         the other configurations, each with its own {bound, frac, kernel, source} object
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -31,30 +40,57 @@ NCHAINS_PER_GPU = 65536
 NDIMS = 100
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP64_MFMA_PEAK_TF = 78.6    # FP64 matrix = FP64 vector peak on MI355X
+CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock; 256 CUs x 4 SIMDs
+NSIMD = 1024
+PMC_JSON = ROOT / "profiles" / "r2_pmc_kernels.json"
 
 
-def algorithmic_bytes_per_launch(nchains, d, sampler, spl, summaries, accept_rate=1.0):
-    """SURVEY §8(d): carried state S = 2*D*8+8 (x, g, lt) for MALA/HMC, D*8+8 for MH/Slice.  A launch reads it once;
-    it has to write it back only for the chains that moved (a rejected proposal leaves x, g, lt as they were), so the
-    write side is scaled by the measured fraction of chains that accepted at least once in the launch (for one
-    transition per launch: the acceptance rate; SURVEY's 2*S+1 figure is the accept_rate = 1 upper end).
-    The per-chain accept counter (8 B RMW, accepted chains only) and, when on, the running sums (2 arrays RMW) count too."""
-    s = (2 * d * 8 + 8) if sampler in ("mala", "hmc") else (d * 8 + 8)
-    b = s + accept_rate * (s + 16)
-    if summaries:
-        b += 4 * d * 8
-    return nchains * b
+def pmc_lookup(kernel_sub, grid=None):
+    """Mean per-launch counters of the kernel whose name contains `kernel_sub` (and whose grid matches) from the committed PMC
+    summary (scripts/profile_round.sh -> scripts/make_pmc_json.py).  None when the file has no such kernel."""
+    try:
+        rows = json.loads(PMC_JSON.read_text())["kernels"]
+    except Exception:
+        return None
+    best = None
+    for r in rows:
+        if kernel_sub in r["kernel"] and (grid is None or r.get("grid") == grid):
+            if best is None or r["counters"].get("SQ_INSTS_VALU", {}).get("n", 0) > best["counters"].get("SQ_INSTS_VALU", {}).get("n", 0):
+                best = r
+    return best
+
+
+def valu_roofline(kernel_sub, launch_s, grid=None, label=None):
+    """{bound: valu, achieved, peak, frac}: VALU-busy SIMD-cycles per launch (PMC) / launch duration (live)."""
+    rf = {"bound": "valu", "achieved": None, "peak": NSIMD * CLOCK_HZ, "unit": "VALU-busy SIMD-cycle/s", "frac": None,
+          "kernel": label or kernel_sub, "launch_us": launch_s * 1e6,
+          "source": "SQ_ACTIVE_INST_VALU (quad-cycles x 4, summed over the chip) per launch from profiles/r2_pmc_kernels.json / "
+                    "launch duration from HIP events in this run; peak = 1024 SIMDs x 2.4 GHz"}
+    row = pmc_lookup(kernel_sub, grid)
+    if row is None or "SQ_ACTIVE_INST_VALU" not in row["counters"]:
+        rf["source"] += " — NO PMC ROW for this kernel in the committed summary: frac not available"
+        return rf
+    c = row["counters"]
+    busy = 4.0 * c["SQ_ACTIVE_INST_VALU"]["mean"]
+    rf.update(achieved=busy / launch_s, frac=busy / launch_s / (NSIMD * CLOCK_HZ), pmc_kernel=row["kernel"],
+              valu_busy_cycles_per_simd=busy / NSIMD, valu_insts_per_launch=c.get("SQ_INSTS_VALU", {}).get("mean"),
+              waves_per_launch=c.get("SQ_WAVES", {}).get("mean"))
+    return rf
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--spl", type=int, default=1, help="transitions fused per kernel launch (1 = one iterate! per launch)")
-    ap.add_argument("--chains", type=int, default=NCHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region; the median is reported")
+    ap.add_argument("--spl", type=int, default=0, help="transitions per kernel launch (0 = library default 16; 1 = one iterate! per launch)")
+    ap.add_argument("--chains", type=int, default=NCHAINS_PER_GPU, help="chains per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--total-chains", type=int, default=NCHAINS_PER_GPU, help="--scaling strong: chains of the whole job, sharded over the ranks")
     ap.add_argument("--streams", type=int, default=0,
                     help="internal streams for independent chain partitions (0 = library default, 1 = every launch on the caller's stream)")
+    ap.add_argument("--no-save", action="store_true", help="drop the save rule (no running sums): the transition kernel alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for logic tests)")
@@ -88,12 +124,18 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     cdev = "cuda" if args.backend == "nccl" else "cpu"     # where the (tiny) collectives' tensors live
 
-    n = args.chains
-    total_steps = args.warmup + args.steps
+    if args.scaling == "strong":
+        offset, n = K.shard_chains(args.total_chains, rank, world)
+        n_total = args.total_chains
+    else:
+        n, offset, n_total = args.chains, rank * args.chains, args.chains * world
+    spl = args.spl if args.spl > 0 else 16
+    monitor = 0 if args.no_save else L.MON_SUMMARIES
+    total_steps = args.warmup + args.reps * args.steps
     stream = torch.cuda.current_stream().cuda_stream
     eng = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=total_steps,
-                   burnin=0, driftstep=0.9, seed=20260927, chain_offset=rank * n, device=local_rank,
-                   monitor=0, steps_per_launch=args.spl, stream=stream, nstreams=args.streams)
+                   burnin=0, driftstep=0.9, seed=20260927, chain_offset=offset, device=local_rank,
+                   monitor=monitor, steps_per_launch=spl, stream=stream, nstreams=args.streams)
     eng.init_state_normal()
 
     def barrier():
@@ -104,46 +146,62 @@ def main():
     eng.run(args.warmup)
     if dist is not None:   # warm the communicator outside the timed region
         t = torch.zeros(4, device=cdev); dist.all_reduce(t)
+    K.gather_engine_summaries(eng)
+    times, kernel_ms_per_step, summ = [], [], None
+    for _ in range(args.reps):
+        barrier()
+        t0 = time.perf_counter()
+        eng.run(args.steps)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            te = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed = float(te.item())
+        times.append(elapsed)
+        kms, nl = eng.last_run_ms()
+        kernel_ms_per_step.append(kms / args.steps)
+    elapsed = statistics.median(times)
+    # the job's one exchange, after its last transition: chain summaries pooled on the device (+ RCCL all-reduce for N > 1)
     barrier()
     t0 = time.perf_counter()
-    eng.run(args.steps)
-    if dist is not None:
-        summ = K.gather_engine_summaries(eng)          # RCCL all-reduce of chain summaries only
+    summ = K.gather_engine_summaries(eng)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    kernel_ms, nlaunch = eng.last_run_ms()
+    gather_ms = (time.perf_counter() - t0) * 1e3
     lay_kind, lay_g, lay_e = eng.layout()
-    _, _, nacc, ntr, _ = eng.pooled_summaries(with_sums=False)
-    acc_rate = nacc / max(ntr, 1)
+    acc_rate = float(summ["acceptance"]) if summ is not None and "acceptance" in summ else None
+    ranks_seen = int(round(float(summ["nsamples"]) / max(1, (args.warmup + args.reps * args.steps) * n))) if (summ is not None and monitor) else world
 
     out = None
     if rank == 0:
-        transitions = float(n) * world * args.steps
-        value = transitions / elapsed
+        value = float(n_total) * args.steps / elapsed
         out = {
             "metric": "MCMC transitions/sec (whole node), 100-dim Gaussian, 65k chains",
             "value": value, "unit": "transitions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: MALA driftstep=0.9, lt=-|x|^2, D=100, 65,536 chains per GPU, "
-                                   "VanillaMCTuner, x0~N(0,I)",
-                       "nchains_per_gpu": n, "ndims": NDIMS, "steps_per_launch": args.spl,
-                       "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
+                                   "VanillaMCTuner, x0~N(0,I); every step saved into per-chain running sums (save rule of run(job))"
+                                   if not args.no_save else
+                                   "BASELINE configs[1] without the save rule: MALA driftstep=0.9, lt=-|x|^2, D=100, VanillaMCTuner, x0~N(0,I)",
+                       "nchains_per_gpu": n, "nchains_total": n_total, "ndims": NDIMS, "steps_per_launch": spl,
+                       "save_rule": "running sums (KLARA_MON_SUMMARIES), burnin 0, thinning 1" if monitor else "off",
+                       "parallelism": f"chains sharded over {world} GPU(s), no data-path collective; summaries pooled on device"
+                                      + (" and all-reduced over RCCL" if world > 1 else ""),
                        "streams": "library default (2 chain partitions on 2 HIP streams)" if args.streams == 0 else args.streams,
-                       "acceptance_rate": acc_rate,
-                       "timed_region_kernel_ms_per_step": kernel_ms / max(nlaunch, 1) * (1 if args.spl <= 1 else 1.0 / args.spl)},
+                       "timed_region": f"median of {args.reps} repetitions of {args.steps} transitions",
+                       "repetition_ms_per_step": [t_ * 1e3 / args.steps for t_ in times],
+                       "acceptance_rate": acc_rate, "rccl_ranks_seen": ranks_seen, "summary_gather_ms": gather_ms,
+                       "timed_region_kernel_ms_per_step": statistics.median(kernel_ms_per_step)},
         }
     eng.close()
 
     if rank == 0:
-        out["roofline"] = roofline_pass(K, L, n, args.spl, rank, local_rank, stream, acc_rate)
+        out["roofline"] = roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream)
     if rank == 0 and world == 1 and not args.no_extra:
         out["extra"] = extra_measurements(K, L, n, stream)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -154,75 +212,131 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_pass(K, L, n, spl, rank, local_rank, stream, acc_rate):
-    """Duration of the dominant kernel, one launch at a time: the same workload with every launch on the caller's
-    stream (nstreams=1; the timed region above overlaps two half-size launches on two streams, which says nothing
-    about a single launch), HIP events around 200 launches on that stream.  achieved = algorithmic bytes / duration."""
-    e = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=100000, burnin=0,
-                 driftstep=0.9, seed=20260927, chain_offset=rank * n, device=local_rank, monitor=0, steps_per_launch=spl,
+def diagt_kernel_name(sampler_id, lay_g, lay_e, onestep, unitw, mon, tune=False, da=False):
+    b = lambda v: "true" if v else "false"
+    return f"k_diagt<{sampler_id}, {lay_e // 2}, {lay_g}, {b(onestep)}, {b(unitw)}, {b(mon)}, {b(tune)}, {b(da)}>"
+
+
+def launch_duration(e, spl, nlaunch=48, warm=8):
+    """Mean duration of one launch: HIP events (klara_last_run_ms) around `nlaunch` back-to-back launches on ONE stream."""
+    e.run(warm * spl)
+    e.run(nlaunch * spl)
+    kernel_ms, nl = e.last_run_ms()
+    return kernel_ms * 1e-3 / max(nl, 1), nl
+
+
+def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
+    """The dominant kernel, one launch at a time: same workload with every launch on the caller's stream (nstreams = 1; the timed
+    region overlaps two half-size launches on two streams, which says nothing about a single launch)."""
+    e = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=10 ** 7, burnin=0,
+                 driftstep=0.9, seed=20260927, chain_offset=offset, device=local_rank, monitor=monitor, steps_per_launch=spl,
                  stream=stream, nstreams=1)
     e.init_state_normal()
-    e.run(40 * max(spl, 1)); e.run(200 * max(spl, 1))
-    kernel_ms, nlaunch = e.last_run_ms()
+    launch_s, nlaunch = launch_duration(e, spl, nlaunch=64 if spl > 1 else 256)
     lay_kind, lay_g, lay_e = e.layout()
+    _, _, nacc, ntr, _ = e.pooled_summaries(with_sums=False)
     e.close()
-    launch_s = kernel_ms * 1e-3 / max(nlaunch, 1)
-    alg = algorithmic_bytes_per_launch(n, NDIMS, "mala", spl, False, acc_rate if spl <= 1 else 1.0)
-    achieved = alg / launch_s / 1e9
-    rf = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-          "traffic": None,
-          "kernel": (f"k_diagt<MALA, NP={lay_e // 2}, Q={lay_g}> (pair-transposed layout: {lay_g} lanes x {lay_e // 2} element "
-                     f"pairs per chain, {64 // lay_g} chains per wavefront)") if lay_kind == 3 else
-                    (f"k_transitions<MALA, GAUSS_DIAG, E={lay_e}> ({lay_g} lanes x {lay_e} elements per chain, "
-                     f"{64 // lay_g} chains per wavefront)"),
-          "algorithmic_bytes_per_launch": alg, "launch_us": launch_s * 1e6, "launches": nlaunch,
-          "chains_per_launch": n, "accept_rate_used": acc_rate if spl <= 1 else 1.0,
-          "survey_2S_plus_1_bytes_per_launch": n * (2 * (2 * NDIMS * 8 + 8) + 1),
-          "note": ("the kernel is bound by FP64/INT VALU issue (in-kernel Philox + Box-Muller), not by HBM: see DESIGN.md "
-                   "section 5; measured with nstreams=1, one launch at a time.  The algorithmic bytes are the algorithm's "
-                   "(x, gradient and log-target read per chain); the kernel re-forms the gradient from x instead of reading "
-                   "it, so the measured traffic is about half of them")}
-    # HBM bytes per launch from the PMC passes of the same workload (profiles/, scripts/profile_bench.sh)
-    try:
-        tr = json.loads((ROOT / "profiles" / "r1_bench_mala_traffic.json").read_text())
-        kname = f"k_diagt<1, {lay_e // 2}, {lay_g}," if lay_kind == 3 else f"k_transitions<1, 0, {lay_e},"
-        if (tr["nchains"], tr["ndims"], tr["steps_per_launch"]) == (n, NDIMS, spl) and kname in tr["kernel"]:
-            rf["traffic"] = tr["traffic_bytes_per_launch"]
-            rf["traffic_gbs"] = tr["traffic_bytes_per_launch"] / launch_s / 1e9
-            rf["traffic_source"] = "profiles/r1_bench_mala_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
-    except Exception:
-        pass
+    if lay_kind == 3:
+        kname = diagt_kernel_name(1, lay_g, lay_e, spl == 1 and not monitor, True, bool(monitor))
+        label = (f"{kname} (pair-transposed layout: {lay_g} lanes x {lay_e // 2} element pairs per chain, {64 // lay_g} chains per "
+                 f"wavefront; {spl} transitions per launch" + (", running sums" if monitor else "") + ")")
+    else:
+        kname, label = "k_transitions<1, 0,", f"k_transitions<MALA, GAUSS_DIAG, E={lay_e}>"
+    rf = valu_roofline(kname, launch_s, label=label)
+    rf.update(launches=nlaunch, chains_per_launch=n, transitions_per_launch=spl)
+    # the byte side.  S = 2*D*8 + 8 (x, gradient, log-target); SURVEY 8(d): B_K = (2 S + 1) / K per transition and chain.
+    s_state = 2 * NDIMS * 8 + 8
+    contract = n * (2 * s_state + 1)                               # per launch of K fused transitions: state in, state out, accepts
+    # what this kernel has to move per launch: x and lt in (the gradient is re-formed from x); x, gradient, lt and the accept
+    # counter out for the chains that moved during the launch; running sums in and out when the save rule is on
+    moved = min(1.0, 1.0 - (1.0 - nacc / max(ntr, 1)) ** spl)
+    minimal = n * ((NDIMS * 8 + 8) + moved * (s_state + 16) + (4 * NDIMS * 8 if monitor else 0))
+    hbm = {"contract_2S_plus_1_bytes_per_launch": contract, "minimal_bytes_per_launch": minimal,
+           "contract_frac_of_8TBs": contract / launch_s / 1e9 / HBM_PEAK_GBS, "minimal_frac_of_8TBs": minimal / launch_s / 1e9 / HBM_PEAK_GBS,
+           "fraction_of_chains_that_moved": moved, "traffic_bytes_per_launch": None}
+    row = pmc_lookup(kname)
+    if row is not None and "FETCH_SIZE" in row["counters"] and "WRITE_SIZE" in row["counters"]:
+        tb = (2.0 * row["counters"]["FETCH_SIZE"]["mean"] + row["counters"]["WRITE_SIZE"]["mean"]) * 1024.0
+        hbm.update(traffic_bytes_per_launch=tb, traffic_frac_of_8TBs=tb / launch_s / 1e9 / HBM_PEAK_GBS, traffic_over_minimal=tb / minimal,
+                   traffic_source="profiles/r2_pmc_kernels.json: FETCH_SIZE x 2 + WRITE_SIZE (KiB), separate --pmc passes; calibrated on "
+                                  "the init kernel (profiles/README.md)")
+    rf["traffic"] = hbm["traffic_bytes_per_launch"]
+    rf["hbm"] = hbm
+    rf["note"] = ("VALU-issue bound: ~1,070 VALU instructions per wavefront and transition, 70 % of them the in-kernel Philox4x32-10 + "
+                  "Box-Muller of the proposal normals (DESIGN.md section 5); HBM moves a fraction of its peak (hbm.*)")
     return rf
 
 
+def timed_rate(e, n, warm, steps):
+    e.run(warm)
+    t0 = time.perf_counter(); e.run(steps); dt = time.perf_counter() - t0
+    ms, nl = e.last_run_ms()
+    return n * steps / dt, ms * 1e-3 / max(nl, 1), nl
+
+
 def extra_measurements(K, L, n, stream):
-    """Outside the timed region: fused launches of the same workload, and the north-star HMC rates."""
+    """Outside the timed region: the other launch modes of the headline workload and the other BASELINE configurations, each with
+    the roofline that bounds its kernel."""
     import numpy as np
     ex = {}
-    for spl in (16,):
-        e = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=100000,
-                     driftstep=0.9, steps_per_launch=spl, stream=stream)
-        e.init_state_normal(); e.run(64)
-        t0 = time.perf_counter(); e.run(512); dt = time.perf_counter() - t0
-        ex[f"mala_iso_spl{spl}_transitions_per_s"] = n * 512 / dt
+    neg = K.GaussDiagTarget.negdot(NDIMS)
+    # -- the headline workload in its other modes
+    for key, kw in (("mala_one_transition_per_launch_no_save", dict(steps_per_launch=1, monitor=0)),
+                    ("mala_16_per_launch_no_save", dict(steps_per_launch=16, monitor=0)),
+                    ("mala_one_transition_per_launch_with_save", dict(steps_per_launch=1, monitor=L.MON_SUMMARIES))):
+        e = K.Engine(sampler=L.SAMPLER_MALA, target=neg, nchains=n, nsteps=10 ** 7, driftstep=0.9, stream=stream, **kw)
+        e.init_state_normal()
+        rate, _, _ = timed_rate(e, n, 64, 1024)
+        ex[f"{key}_transitions_per_s"] = rate
         e.close()
-    # HMC L=10 eps=0.1 on the README target (HBM/VALU-bound) and on the dense target (FP64-MFMA-bound; cfg 3)
-    for key, target in (("hmc_iso", K.GaussDiagTarget.negdot(NDIMS)),
-                        ("hmc_dense", K.GaussDenseTarget.compound_symmetric(NDIMS, 0.5))):
-        e = K.Engine(sampler=L.SAMPLER_HMC, target=target, nchains=n, nsteps=100000, leapstep=0.1, nleaps=10,
-                     steps_per_launch=16, stream=stream)      # 16 = the library's default fusion
-        e.init_state_normal(); e.run(16)
-        steps = 128
-        t0 = time.perf_counter(); e.run(steps); dt = time.perf_counter() - t0
-        ms, nl = e.last_run_ms()
-        ex[f"{key}_leapfrog_chain_per_s"] = n * steps * 10 / dt
-        ex[f"{key}_transitions_per_s"] = n * steps / dt
-        if key == "hmc_dense":
-            flops = n * steps * 10 * (2 * NDIMS * NDIMS + 6 * NDIMS)
-            ex["hmc_dense_fp64_tflops"] = flops / (ms * 1e-3) / 1e12
-            ex["hmc_dense_frac_of_fp64_mfma_peak"] = ex["hmc_dense_fp64_tflops"] / FP64_MFMA_PEAK_TF
-        e.close()
-    # the two data-model configurations of BASELINE.json at their per-GPU share (cfg 4: 262,144 / 8 chains of the swiss
+    # one launch at a time for the single-transition kernel (round 1's roofline kernel)
+    e = K.Engine(sampler=L.SAMPLER_MALA, target=neg, nchains=n, nsteps=10 ** 7, driftstep=0.9, stream=stream, steps_per_launch=1,
+                 monitor=0, nstreams=1)
+    e.init_state_normal()
+    ls, _ = launch_duration(e, 1, nlaunch=256)
+    lay = e.layout(); e.close()
+    ex["mala_one_transition_per_launch_roofline"] = valu_roofline(diagt_kernel_name(1, lay[1], lay[2], True, True, False), ls)
+
+    # -- HMC L=10 eps=0.1 on the README target (VALU) and on the dense target (FP64 MFMA; cfg 3)
+    e = K.Engine(sampler=L.SAMPLER_HMC, target=neg, nchains=n, nsteps=10 ** 7, leapstep=0.1, nleaps=10, steps_per_launch=16,
+                 stream=stream, nstreams=1)
+    e.init_state_normal()
+    rate, ls, _ = timed_rate(e, n, 16, 128)
+    lay = e.layout(); e.close()
+    ex["hmc_iso_leapfrog_chain_per_s"] = rate * 10
+    ex["hmc_iso_roofline"] = valu_roofline(diagt_kernel_name(2, lay[1], lay[2], False, True, False), ls)
+
+    e = K.Engine(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget.compound_symmetric(NDIMS, 0.5), nchains=n, nsteps=10 ** 7,
+                 leapstep=0.1, nleaps=10, steps_per_launch=16, stream=stream)
+    e.init_state_normal()
+    rate, ls, _ = timed_rate(e, n, 16, 128)
+    e.close()
+    flops_per_launch = n * 16 * 10 * (2 * NDIMS * NDIMS + 6 * NDIMS)         # SURVEY 8(d): 2 D^2 + 6 D per leapfrog and chain
+    tf = flops_per_launch / ls / 1e12
+    ex["cfg3_hmc_dense_leapfrog_chain_per_s"] = rate * 10
+    ex["cfg3_hmc_dense_transitions_per_s"] = rate
+    rf = {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF,
+          "kernel": "k_dense_transitions<HMC, NE=25> (v_mfma_f64_16x16x4 + v_mfma_f64_4x4x4_4b tail tile), 16 transitions per launch",
+          "launch_us": ls * 1e6,
+          "source": "algorithmic flops (2 D^2 + 6 D per leapfrog and chain, SURVEY 8(d)) / launch duration from HIP events in this run"}
+    row = pmc_lookup("k_dense_transitions<2")
+    if row is not None and "SQ_VALU_MFMA_BUSY_CYCLES" in row["counters"]:
+        busy = row["counters"]["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"]
+        rf["mfma_pipe_busy_frac"] = busy / NSIMD / (ls * CLOCK_HZ)
+        rf["mfma_pipe_source"] = "SQ_VALU_MFMA_BUSY_CYCLES per launch (profiles/r2_pmc_kernels.json) / 1024 SIMDs / (launch duration x 2.4 GHz)"
+    ex["cfg3_hmc_dense_roofline"] = rf
+
+    # -- slice sampler on the README target, D = 100
+    e = K.Engine(sampler=L.SAMPLER_SLICE, target=neg, nchains=n, nsteps=10 ** 7, slice_widths=np.full(NDIMS, 1.0), steps_per_launch=4,
+                 stream=stream, nstreams=1)
+    e.init_state_normal()
+    rate, ls, _ = timed_rate(e, n, 4, 16)
+    lay = e.layout(); e.close()
+    ex["slice_d100_transitions_per_s"] = rate
+    ex["slice_d100_coordinate_updates_per_s"] = rate * NDIMS
+    ex["slice_d100_roofline"] = valu_roofline(f"k_diagt<3, {lay[2] // 2}, {lay[1]},", ls)
+
+    # -- the two data-model configurations of BASELINE.json at their per-GPU share (cfg 4: 262,144 / 8 chains of the swiss
     # logistic regression, MALA h = 0.1; cfg 5: 1,048,576 / 8 chains of the rats hierarchical model, HMC L = 32 with the
     # per-GPU pooled AcceptanceRate tuner).  Data: the reference's own files as committed fixtures (tests/golden/*.npz).
     try:
@@ -232,12 +346,13 @@ def extra_measurements(K, L, n, stream):
         y = np.ascontiguousarray(sw["status"].astype(np.float64))
         nc = 32768
         x0 = np.array([5.1, -0.9, 8.2, -4.5])[None, :] + 0.1 * np.random.default_rng(0).standard_normal((nc, 4))
-        e = K.Engine(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, 100.0), nchains=nc, nsteps=10 ** 6, driftstep=0.1,
-                     steps_per_launch=50, monitor=0, stream=stream)
-        e.set_state(x0); e.run(100)
-        t0 = time.perf_counter(); e.run(500); dt = time.perf_counter() - t0
-        ex["cfg4_swiss_logistic_mala_transitions_per_s_per_gpu"] = nc * 500 / dt
+        e = K.Engine(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, 100.0), nchains=nc, nsteps=10 ** 6, burnin=1000, driftstep=0.1,
+                     steps_per_launch=50, monitor=L.MON_SUMMARIES, stream=stream)
+        e.set_state(x0)
+        rate, ls, _ = timed_rate(e, nc, 100, 500)
         e.close()
+        ex["cfg4_swiss_logistic_mala_transitions_per_s_per_gpu"] = rate
+        ex["cfg4_roofline"] = valu_roofline("k_transitions<1, 2,", ls)
         rats = np.load(gold / "rats.npz")
         t = K.HierNormalTarget(rats["weight"], rats["age"] - 22.0)
         nc = 131072
@@ -245,18 +360,20 @@ def extra_measurements(K, L, n, stream):
         e = K.Engine(sampler=L.SAMPLER_HMC, target=t, nchains=nc, nsteps=2000, burnin=1000, leapstep=0.02, nleaps=32,
                      tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.65, period=100, steps_per_launch=10,
                      monitor=L.MON_SUMMARIES, stream=stream)
-        e.set_state(x0); e.run(100)
-        t0 = time.perf_counter(); e.run(200); dt = time.perf_counter() - t0
-        ex["cfg5_rats_hmc_L32_leapfrog_chain_per_s_per_gpu"] = nc * 200 * 32 / dt
-        ex["cfg5_rats_hmc_L32_transitions_per_s_per_gpu"] = nc * 200 / dt
+        e.set_state(x0)
+        rate, ls, _ = timed_rate(e, nc, 100, 200)
         e.close()
+        ex["cfg5_rats_hmc_L32_leapfrog_chain_per_s_per_gpu"] = rate * 32
+        ex["cfg5_rats_hmc_L32_transitions_per_s_per_gpu"] = rate
+        ex["cfg5_roofline"] = valu_roofline("k_hiert<2,", ls)
     except Exception as exc:      # the fixtures are part of the repository; a failure here must not lose the headline line
         ex["model_configs_error"] = repr(exc)
     return ex
 
 
 def cpu_baseline(L):
-    """CPU oracle (restatement of the reference path, OpenMP over chains) on a bounded sample of the workload."""
+    """CPU oracle (restatement of the reference path, OpenMP over chains) on a bounded sample of the workload (no save rule: the
+    oracle's transition loop alone — the baseline is not charged for it)."""
     import numpy as np
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_ffi as O
@@ -274,7 +391,7 @@ def cpu_baseline(L):
         job.run(chunk); steps += chunk
     dt = time.perf_counter() - t0
     out = {"value": nch * steps / dt, "unit": "transitions/s", "cores": cores, "kind": "port",
-           "sample": f"oracle/libklara_oracle.so (C restatement, gcc -O2, OpenMP over chains, {cores} threads): "
+           "sample": f"oracle/libklara_oracle.so (C restatement, gcc -O3 -mavx2 -mfma -ffp-contract=off, OpenMP over chains, {cores} threads): "
                      f"MALA driftstep=0.9, D=100, {nch} chains x {steps} transitions in {dt:.1f} s"}
     # the reference's own execution model is one chain after another on one thread (BasicMCJob.jl:212-244): 3 s sample
     lib.ko_set_num_threads(1)

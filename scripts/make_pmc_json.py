@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 PMC passes of scripts/profile_round.sh into one JSON (and a readable text summary on stdout):
+per kernel (full name, grid, workgroup): mean, min, max and dispatch count of every collected counter.  rocprofv3 sums a counter
+over its hardware instances, so SQ_* values are chip totals and GRBM_GUI_ACTIVE is the sum over the 8 XCDs.
+usage: make_pmc_json.py <prof dir> <out json>"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+prof, outp = sys.argv[1], sys.argv[2]
+KEEP = ("k_diagt", "k_transitions", "k_hiert", "k_dense", "k_init", "k_pool", "k_pooled", "k_bm_close", "k_chain")
+agg = defaultdict(lambda: defaultdict(list))          # (kernel, grid, wg) -> counter -> values
+meta = {}
+for f in sorted(glob.glob(os.path.join(prof, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            name = r["Kernel_Name"]
+            if not any(k in name for k in KEEP):
+                continue
+            key = (name, int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+            agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[key] = {"vgpr": int(r["VGPR_Count"]), "accum_vgpr": int(r["Accum_VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
+                         "lds": int(r["LDS_Block_Size"]), "scratch": int(r["Scratch_Size"])}
+rows = []
+for key, cs in sorted(agg.items(), key=lambda kv: -len(next(iter(kv[1].values())))):
+    name, grid, wg = key
+    counters = {c: {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "n": len(v)} for c, v in sorted(cs.items())}
+    rows.append({"kernel": name, "grid": grid, "workgroup": wg, **meta[key], "counters": counters})
+out = {"source": "rocprofv3 --pmc passes of scripts/profile_round.sh (bench.py --steps 64 --warmup 16 --reps 1 --no-cpu-baseline), one counter "
+                 "group per run, --kernel-trace only; means per dispatch, chip totals (GRBM_GUI_ACTIVE: sum over the 8 XCDs); "
+                 "FETCH_SIZE / WRITE_SIZE in KiB as reported (FETCH_SIZE is doubled by the reader, see profiles/README.md)",
+       "kernels": rows}
+json.dump(out, open(outp, "w"), indent=1)
+for r in rows:
+    print(f"{r['kernel'][:110]}  grid={r['grid']} wg={r['workgroup']} vgpr={r['vgpr']} scratch={r['scratch']} lds={r['lds']}")
+    for c, v in r["counters"].items():
+        print(f"    {c:28s} mean {v['mean']:18.1f}   (n = {v['n']})")
