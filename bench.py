@@ -5,7 +5,7 @@ Workload at N = 1 (BASELINE.json configs[1]): MALA driftstep = 0.9, lt = -|x|^2 
 Philox init stream, VanillaMCTuner, state resident in HBM before the timed region.  A "step" is one transition (one `iterate!`,
 src/samplers/iterate/MALA.jl:78-153) of every chain INCLUDING the save rule of `run(job)` (BasicMCJob.jl:226-231): every step is
 in the post-burn-in range and is accumulated into the per-chain running sums (KLARA_MON_SUMMARIES) that `mean(chain)` reads.
-`klara_run` IS the `for i in 1:nsteps` loop (BasicMCJob.jl:219-238): the library's default of 16 transitions per kernel launch is
+`klara_run` IS the `for i in 1:nsteps` loop (BasicMCJob.jl:219-238): the library's default of 32 transitions per kernel launch is
 the headline (config.steps_per_launch), one transition per launch is reported in `extra`.
 
 Timed region: `--reps` (5) repetitions of exactly `--steps` transitions, each bracketed by a barrier + torch.cuda.synchronize()
@@ -43,13 +43,19 @@ FP64_MFMA_PEAK_TF = 78.6    # FP64 matrix = FP64 vector peak on MI355X (SURVEY Â
 CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock; 256 CUs x 4 SIMDs
 NSIMD = 1024
 PMC_JSON = ROOT / "profiles" / "r2_pmc_kernels.json"
+PMC_EXPECT = {}             # filled by main(): the launch length the committed counters must have been collected at
 
 
 def pmc_lookup(kernel_sub, grid=None):
     """Mean per-launch counters of the kernel whose name contains `kernel_sub` (and whose grid matches) from the committed PMC
     summary (scripts/profile_round.sh -> scripts/make_pmc_json.py).  None when the file has no such kernel."""
     try:
-        rows = json.loads(PMC_JSON.read_text())["kernels"]
+        doc = json.loads(PMC_JSON.read_text())
+        rows = doc["kernels"]
+        # the per-launch counters of the headline kernel only hold for the launch length they were collected at
+        if "k_diagt<1" in kernel_sub and doc.get("bench_config", {}).get("steps_per_launch") not in (None, PMC_EXPECT.get("steps_per_launch")) \
+                and "false, true, true" in kernel_sub:
+            return None
     except Exception:
         return None
     best = None
@@ -84,7 +90,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region; the median is reported")
-    ap.add_argument("--spl", type=int, default=0, help="transitions per kernel launch (0 = library default 16; 1 = one iterate! per launch)")
+    ap.add_argument("--spl", type=int, default=0, help="transitions per kernel launch (0 = library default 32; 1 = one iterate! per launch)")
     ap.add_argument("--chains", type=int, default=NCHAINS_PER_GPU, help="chains per GPU (weak scaling)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--total-chains", type=int, default=NCHAINS_PER_GPU, help="--scaling strong: chains of the whole job, sharded over the ranks")
@@ -129,7 +135,8 @@ def main():
         n_total = args.total_chains
     else:
         n, offset, n_total = args.chains, rank * args.chains, args.chains * world
-    spl = args.spl if args.spl > 0 else 16
+    spl = args.spl if args.spl > 0 else L.DEFAULT_STEPS_PER_LAUNCH
+    PMC_EXPECT["steps_per_launch"] = spl
     monitor = 0 if args.no_save else L.MON_SUMMARIES
     total_steps = args.warmup + args.reps * args.steps
     stream = torch.cuda.current_stream().cuda_stream
@@ -217,6 +224,12 @@ def diagt_kernel_name(sampler_id, lay_g, lay_e, onestep, unitw, mon, tune=False,
     return f"k_diagt<{sampler_id}, {lay_e // 2}, {lay_g}, {b(onestep)}, {b(unitw)}, {b(mon)}, {b(tune)}, {b(da)}>"
 
 
+def diagt_grid(n, lay_g):
+    """threads of one whole-job launch of the pair-transposed kernels: one wavefront per group of 64 / lay_g chains, 4 per block"""
+    cpw = 64 // lay_g
+    return 256 * ((((n + cpw - 1) // cpw) + 3) // 4)
+
+
 def launch_duration(e, spl, nlaunch=48, warm=8):
     """Mean duration of one launch: HIP events (klara_last_run_ms) around `nlaunch` back-to-back launches on ONE stream."""
     e.run(warm * spl)
@@ -242,7 +255,8 @@ def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
                  f"wavefront; {spl} transitions per launch" + (", running sums" if monitor else "") + ")")
     else:
         kname, label = "k_transitions<1, 0,", f"k_transitions<MALA, GAUSS_DIAG, E={lay_e}>"
-    rf = valu_roofline(kname, launch_s, label=label)
+    grid = diagt_grid(n, lay_g) if lay_kind == 3 else None
+    rf = valu_roofline(kname, launch_s, grid=grid, label=label)
     rf.update(launches=nlaunch, chains_per_launch=n, transitions_per_launch=spl)
     # the byte side.  S = 2*D*8 + 8 (x, gradient, log-target); SURVEY 8(d): B_K = (2 S + 1) / K per transition and chain.
     s_state = 2 * NDIMS * 8 + 8
@@ -254,7 +268,7 @@ def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
     hbm = {"contract_2S_plus_1_bytes_per_launch": contract, "minimal_bytes_per_launch": minimal,
            "contract_frac_of_8TBs": contract / launch_s / 1e9 / HBM_PEAK_GBS, "minimal_frac_of_8TBs": minimal / launch_s / 1e9 / HBM_PEAK_GBS,
            "fraction_of_chains_that_moved": moved, "traffic_bytes_per_launch": None}
-    row = pmc_lookup(kname)
+    row = pmc_lookup(kname, grid)
     if row is not None and "FETCH_SIZE" in row["counters"] and "WRITE_SIZE" in row["counters"]:
         tb = (2.0 * row["counters"]["FETCH_SIZE"]["mean"] + row["counters"]["WRITE_SIZE"]["mean"]) * 1024.0
         hbm.update(traffic_bytes_per_launch=tb, traffic_frac_of_8TBs=tb / launch_s / 1e9 / HBM_PEAK_GBS, traffic_over_minimal=tb / minimal,
@@ -282,7 +296,7 @@ def extra_measurements(K, L, n, stream):
     neg = K.GaussDiagTarget.negdot(NDIMS)
     # -- the headline workload in its other modes
     for key, kw in (("mala_one_transition_per_launch_no_save", dict(steps_per_launch=1, monitor=0)),
-                    ("mala_16_per_launch_no_save", dict(steps_per_launch=16, monitor=0)),
+                    ("mala_fused_no_save", dict(steps_per_launch=0, monitor=0)),
                     ("mala_one_transition_per_launch_with_save", dict(steps_per_launch=1, monitor=L.MON_SUMMARIES))):
         e = K.Engine(sampler=L.SAMPLER_MALA, target=neg, nchains=n, nsteps=10 ** 7, driftstep=0.9, stream=stream, **kw)
         e.init_state_normal()
@@ -295,7 +309,7 @@ def extra_measurements(K, L, n, stream):
     e.init_state_normal()
     ls, _ = launch_duration(e, 1, nlaunch=256)
     lay = e.layout(); e.close()
-    ex["mala_one_transition_per_launch_roofline"] = valu_roofline(diagt_kernel_name(1, lay[1], lay[2], True, True, False), ls)
+    ex["mala_one_transition_per_launch_roofline"] = valu_roofline(diagt_kernel_name(1, lay[1], lay[2], True, True, False), ls, grid=diagt_grid(n, lay[1]))
 
     # -- HMC L=10 eps=0.1 on the README target (VALU) and on the dense target (FP64 MFMA; cfg 3)
     e = K.Engine(sampler=L.SAMPLER_HMC, target=neg, nchains=n, nsteps=10 ** 7, leapstep=0.1, nleaps=10, steps_per_launch=16,
@@ -304,7 +318,7 @@ def extra_measurements(K, L, n, stream):
     rate, ls, _ = timed_rate(e, n, 16, 128)
     lay = e.layout(); e.close()
     ex["hmc_iso_leapfrog_chain_per_s"] = rate * 10
-    ex["hmc_iso_roofline"] = valu_roofline(diagt_kernel_name(2, lay[1], lay[2], False, True, False), ls)
+    ex["hmc_iso_roofline"] = valu_roofline(diagt_kernel_name(2, lay[1], lay[2], False, True, False), ls, grid=diagt_grid(n, lay[1]))
 
     e = K.Engine(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget.compound_symmetric(NDIMS, 0.5), nchains=n, nsteps=10 ** 7,
                  leapstep=0.1, nleaps=10, steps_per_launch=16, stream=stream)

@@ -33,6 +33,9 @@ extern "C" {
 #endif
 
 #define KLARA_ABI_VERSION 2
+/* klara_desc.steps_per_launch = 0 selects this many transitions per kernel launch (launches also end at the pooled tuner's
+ * events and at batch boundaries of the streaming batch means, whichever comes first) */
+#define KLARA_DEFAULT_STEPS_PER_LAUNCH 32
 
 typedef enum klara_status {
     KLARA_OK = 0,

@@ -14,6 +14,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libklara_hip.so"
 
 KLARA_ABI_VERSION = 2
+DEFAULT_STEPS_PER_LAUNCH = 32     # KLARA_DEFAULT_STEPS_PER_LAUNCH
 
 # klara_status
 OK, ERR_INVALID_ARG, ERR_NONFINITE_INIT, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_STATE, ERR_SLICE_STUCK, ERR_COMPILE = range(9)

@@ -42,6 +42,7 @@ struct klara_handle {
     double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr,
            *hY = nullptr, *hxc = nullptr;
     double* pooled_out = nullptr;   // 2*D doubles + 1 u64 scratch for pooled summaries
+    double* pool_partial = nullptr; // KLARA_POOL_BLOCKS x (2 D doubles + 1 u64): stage-1 partials of the pooled summaries
     double* cdata = nullptr; KlaraJit* jit = nullptr;   // user-defined target: data block, run-time compiled kernels
     // streaming batch means (bm_batchlen > 0): running sum at the last batch boundary, Welford mean / M2 of the batch means
     double *bm_prev = nullptr, *bm_mean = nullptr, *bm_m2 = nullptr; long long bm_count = 0;
@@ -202,7 +203,7 @@ static void free_all(klara_handle* h)
     hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->da_epsbar); hipFree(h->da_hbar); hipFree(h->pooled_acc); hipFree(h->accept);
     hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->hist); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->err);
     hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
-    hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->d_params); hipFree(h->cdata);
+    hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->pool_partial); hipFree(h->d_params); hipFree(h->cdata);
     hipFree(h->bm_prev); hipFree(h->bm_mean); hipFree(h->bm_m2);
     klara_jit_destroy(h->jit);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -288,7 +289,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     CKH(dalloc(&h->tune_step, NT)); CKH(dalloc(&h->tune_acc, NT)); CKH(dalloc(&h->tune_prop, NT));
     CKH(dalloc(&h->tune_tot, NT));
     if (desc->tuner == KLARA_TUNER_DUAL_AVERAGING) { CKH(dalloc(&h->da_epsbar, NT)); CKH(dalloc(&h->da_hbar, NT)); } CKH(dalloc(&h->pooled_acc, 1)); CKH(dalloc(&h->naccept, N));
-    CKH(dalloc(&h->err, 1)); CKH(dalloc(&h->pooled_out, 2 * D + 2));
+    CKH(dalloc(&h->err, 1)); CKH(dalloc(&h->pooled_out, 2 * D + 2)); CKH(dalloc(&h->pool_partial, (size_t)1024 * (2 * D + 1)));
     CKH(hipMemset(h->err, 0, sizeof(int)));
     if (desc->monitor & KLARA_MON_SUMMARIES) { CKH(dalloc(&h->sum, N * D)); CKH(dalloc(&h->sumsq, N * D)); }
     if (desc->bm_batchlen > 0) { CKH(dalloc(&h->bm_prev, N * D)); CKH(dalloc(&h->bm_mean, N * D)); CKH(dalloc(&h->bm_m2, N * D)); }
@@ -654,7 +655,7 @@ static hipError_t launch_bm_close(klara_handle* h)
 }
 
 // ---- launch planning: pure host logic (no device), shared by klara_run_async and klara_selftest_plan ------------------------
-// Where the next launch of a run ends: after steps_per_launch transitions (library default 16), at the next event of the pooled
+// Where the next launch of a run ends: after steps_per_launch transitions (library default KLARA_DEFAULT_STEPS_PER_LAUNCH), at the next event of the pooled
 // tuner (tuners.jl:27-32 — the rate is pooled over the GPU's chains between launches) or where the next batch of saved samples
 // closes (streaming batch means), whichever comes first; plus the save-rule bookkeeping the kernels take from the host
 // (BasicMCRange.jl:36 postrange = (burnin+1):thinning:nsteps), so that they carry no 64-bit division.
@@ -665,7 +666,7 @@ static PlannedLaunch plan_launch(const klara_desc& d, const RunCursor& c, long l
 {
     PlannedLaunch pl;
     const bool pooled_cnt = d.tuner_mode == KLARA_TUNE_POOLED && cnt_predicate(d);
-    const long long spl = d.steps_per_launch > 0 ? d.steps_per_launch : 16;
+    const long long spl = d.steps_per_launch > 0 ? d.steps_per_launch : KLARA_DEFAULT_STEPS_PER_LAUNCH;
     long long k = remaining < spl ? remaining : spl;
     if (pooled_cnt && c.m_tot <= d.burnin) {
         const long long to_boundary = d.period - (c.m_prop % d.period);
@@ -823,32 +824,60 @@ extern "C" klara_status klara_get_chain_sums(klara_handle* h, double* sum, doubl
     return KLARA_OK;
 }
 
-// pooled (over chains) per-dimension sums: one block per dimension, fixed-shape tree => deterministic
-__global__ __launch_bounds__(256) void k_pool_sums(const double* sum, const double* sumsq, long long N, int D,
-                                                   double* out)
+// Pooled (over chains) per-dimension sums and the accepted-transition total, two stages of fixed shape => deterministic for a
+// given chain count: block b of KLARA_POOL_BLOCKS adds the chains c = b, b + NB, ... column by column (a chain's D values are
+// contiguous: coalesced) into partial[b][0..2D) and their accept counters into partial_acc[b]; one small block then adds the
+// partials in ascending b.  (100 blocks striding over 105 MB took 167 us at 65,536 x 100; this takes ~25.)
+#define KLARA_POOL_BLOCKS 1024
+__global__ __launch_bounds__(256) void k_pool_stage1(const double* __restrict__ sum, const double* __restrict__ sumsq,
+                                                     const unsigned long long* __restrict__ nacc, long long N, int D, int nb,
+                                                     double* __restrict__ partial, unsigned long long* __restrict__ partial_acc)
 {
-    __shared__ double s1[256], s2[256];
-    const int d = blockIdx.x;
-    double a = 0.0, b = 0.0;
-    for (long long c = threadIdx.x; c < N; c += 256) { a += sum[c * D + d]; b += sumsq[c * D + d]; }
-    s1[threadIdx.x] = a; s2[threadIdx.x] = b;
-    __syncthreads();
-    for (int m = 128; m > 0; m >>= 1) {
-        if ((int)threadIdx.x < m) { s1[threadIdx.x] += s1[threadIdx.x + m]; s2[threadIdx.x] += s2[threadIdx.x + m]; }
-        __syncthreads();
+    const int b = blockIdx.x;
+    if (sum != nullptr) {
+        for (int j = threadIdx.x; j < 2 * D; j += 256) {
+            const double* src = j < D ? sum + j : sumsq + (j - D);
+            double a = 0.0;
+            for (long long c = b; c < N; c += nb) a += src[c * D];
+            partial[(long long)b * 2 * D + j] = a;
+        }
     }
-    if (threadIdx.x == 0) { out[d] = s1[0]; out[D + d] = s2[0]; }
-}
-__global__ __launch_bounds__(256) void k_pool_accept(const unsigned long long* nacc, long long N,
-                                                     unsigned long long* out)
-{
     __shared__ unsigned long long s[256];
     unsigned long long a = 0;
-    for (long long c = threadIdx.x; c < N; c += 256) a += nacc[c];
+    for (long long c = (long long)b + (long long)threadIdx.x * nb; c < N; c += 256ll * nb) a += nacc[c];
     s[threadIdx.x] = a;
     __syncthreads();
     for (int m = 128; m > 0; m >>= 1) { if ((int)threadIdx.x < m) s[threadIdx.x] += s[threadIdx.x + m]; __syncthreads(); }
-    if (threadIdx.x == 0) *out = s[0];
+    if (threadIdx.x == 0) partial_acc[b] = s[0];
+}
+__global__ __launch_bounds__(256) void k_pool_stage2(const double* __restrict__ partial, const unsigned long long* __restrict__ partial_acc,
+                                                     int D, int nb, bool with_sums, double* __restrict__ out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (with_sums && j < 2 * D) {
+        double a = 0.0;
+        for (int b = 0; b < nb; ++b) a += partial[(long long)b * 2 * D + j];
+        out[j] = a;
+    }
+    if (j == 0) {
+        unsigned long long a = 0;
+        for (int b = 0; b < nb; ++b) a += partial_acc[b];
+        *reinterpret_cast<unsigned long long*>(out + 2 * D) = a;
+    }
+}
+// out: 2 D doubles (sum, sumsq; untouched unless with_sums) followed by the u64 accept total; on the handle's stream
+static hipError_t pool_summaries_async(klara_handle* h, bool with_sums, double* out)
+{
+    const int D = h->d.ndims;
+    const long long N = h->d.nchains;
+    const int nb = (int)(N < KLARA_POOL_BLOCKS ? N : KLARA_POOL_BLOCKS);
+    hipLaunchKernelGGL(k_pool_stage1, dim3(nb), dim3(256), 0, h->stream, with_sums ? h->sum : nullptr, h->sumsq, h->naccept, N, D, nb,
+                       h->pool_partial, reinterpret_cast<unsigned long long*>(h->pool_partial + (size_t)KLARA_POOL_BLOCKS * 2 * D));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pool_stage2, dim3((2 * D + 255) / 256), dim3(256), 0, h->stream, h->pool_partial,
+                       reinterpret_cast<const unsigned long long*>(h->pool_partial + (size_t)KLARA_POOL_BLOCKS * 2 * D), D, nb, with_sums, out);
+    return hipGetLastError();
 }
 
 extern "C" klara_status klara_get_pooled_summaries(klara_handle* h, double* sum, double* sumsq,
@@ -859,19 +888,14 @@ extern "C" klara_status klara_get_pooled_summaries(klara_handle* h, double* sum,
     if (!h->have_state) return KLARA_ERR_STATE;
     HIPCHK(hipSetDevice(h->d.device));
     const int D = h->d.ndims;
-    if (sum || sumsq) {
-        if (!h->sum) return KLARA_ERR_STATE;
-        hipLaunchKernelGGL(k_pool_sums, dim3(D), dim3(256), 0, h->stream, h->sum, h->sumsq,
-                           (long long)h->d.nchains, D, h->pooled_out);
-        HIPCHK(hipGetLastError());
-    }
-    unsigned long long* accout = reinterpret_cast<unsigned long long*>(h->pooled_out + 2 * D);
-    hipLaunchKernelGGL(k_pool_accept, dim3(1), dim3(256), 0, h->stream, h->naccept, (long long)h->d.nchains, accout);
-    HIPCHK(hipGetLastError());
+    if ((sum || sumsq) && !h->sum) return KLARA_ERR_STATE;
+    HIPCHK(pool_summaries_async(h, sum || sumsq, h->pooled_out));
+    std::vector<double> host(2 * (size_t)D + 1);
+    HIPCHK(hipMemcpyAsync(host.data(), h->pooled_out, (2 * (size_t)D + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));   // one copy
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (sum) HIPCHK(hipMemcpy(sum, h->pooled_out, D * sizeof(double), hipMemcpyDeviceToHost));
-    if (sumsq) HIPCHK(hipMemcpy(sumsq, h->pooled_out + D, D * sizeof(double), hipMemcpyDeviceToHost));
-    if (naccept) HIPCHK(hipMemcpy(naccept, accout, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (sum) memcpy(sum, host.data(), D * sizeof(double));
+    if (sumsq) memcpy(sumsq, host.data() + D, D * sizeof(double));
+    if (naccept) memcpy(naccept, host.data() + 2 * D, sizeof(uint64_t));
     if (ntransitions) *ntransitions = (uint64_t)h->steps_done * (uint64_t)h->d.nchains;
     if (nsaved_out) *nsaved_out = h->nsaved;
     return KLARA_OK;
@@ -949,13 +973,8 @@ extern "C" klara_status klara_gather_summaries(klara_handle* h, klara_comm* c, d
         c->cap = 2 * D + 4;
     }
     HIPCHK(hipMemsetAsync(c->buf, 0, (2 * D + 4) * sizeof(double), h->stream));
-    if (h->sum) {
-        hipLaunchKernelGGL(k_pool_sums, dim3((unsigned)D), dim3(256), 0, h->stream, h->sum, h->sumsq, (long long)h->d.nchains, (int)D, c->buf);
-        HIPCHK(hipGetLastError());
-    }
+    HIPCHK(pool_summaries_async(h, h->sum != nullptr, c->buf));
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(c->buf + 2 * D);
-    hipLaunchKernelGGL(k_pool_accept, dim3(1), dim3(256), 0, h->stream, h->naccept, (long long)h->d.nchains, cnt);
-    HIPCHK(hipGetLastError());
     const unsigned long long local[3] = { (unsigned long long)h->steps_done * (unsigned long long)h->d.nchains,
                                           (unsigned long long)h->nsaved * (unsigned long long)h->d.nchains,
                                           (unsigned long long)h->d.nchains };

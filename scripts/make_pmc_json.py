@@ -29,7 +29,13 @@ for key, cs in sorted(agg.items(), key=lambda kv: -len(next(iter(kv[1].values())
     name, grid, wg = key
     counters = {c: {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "n": len(v)} for c, v in sorted(cs.items())}
     rows.append({"kernel": name, "grid": grid, "workgroup": wg, **meta[key], "counters": counters})
-out = {"source": "rocprofv3 --pmc passes of scripts/profile_round.sh (bench.py --steps 64 --warmup 16 --reps 1 --no-cpu-baseline), one counter "
+bench_cfg = {}
+try:
+    line = json.loads(open(os.path.join(prof, "bench_line_sq.json")).read())
+    bench_cfg = {k: line["config"][k] for k in ("steps_per_launch", "nchains_per_gpu", "ndims", "save_rule")}
+except Exception as exc:
+    bench_cfg = {"error": repr(exc)}
+out = {"bench_config": bench_cfg, "source": "rocprofv3 --pmc passes of scripts/profile_round.sh (bench.py --steps 64 --warmup 16 --reps 1 --no-cpu-baseline), one counter "
                  "group per run, --kernel-trace only; means per dispatch, chip totals (GRBM_GUI_ACTIVE: sum over the 8 XCDs); "
                  "FETCH_SIZE / WRITE_SIZE in KiB as reported (FETCH_SIZE is doubled by the reader, see profiles/README.md)",
        "kernels": rows}

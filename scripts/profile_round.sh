@@ -19,9 +19,9 @@ timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE
 timeout 300 rocprofv3 --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM --kernel-trace -d "$OUT/pmc_mem" -o bench -- python "$REPO/bench.py" $PMC_ARGS > "$OUT/bench_mem.log" 2>&1
 timeout 300 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o bench -- python "$REPO/bench.py" $PMC_ARGS > "$OUT/bench_fetch.log" 2>&1
 timeout 300 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o bench -- python "$REPO/bench.py" $PMC_ARGS > "$OUT/bench_write.log" 2>&1
+for l in trace sq mem fetch write; do grep '^{"metric"' "$OUT/bench_$l.log" | tail -1 > "$OUT/bench_line_$l.json"; done
 python "$REPO/scripts/make_pmc_json.py" "$OUT" "$OUT/pmc_kernels.json" > "$OUT/pmc_summary.txt" 2>&1
 f=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv"
-for l in trace sq mem fetch write; do tail -c 6000 "$OUT/bench_$l.log" | grep '^{"metric"' > "$OUT/bench_line_$l.json"; done
 # keep only small files for the merge back
 find "$OUT" -name "*.db" -delete 2>/dev/null
 find "$OUT" -name "*kernel_trace.csv" -size +1M -delete 2>/dev/null

@@ -278,7 +278,7 @@ def test_launch_planning_is_pure_host_logic(klib, seed):
     if bm:
         kw.update(monitor=L.MON_SUMMARIES)
     k, col, ph, fl = _plan(klib, runs, **kw)
-    assert k.sum() == total and (k >= 1).all() and (k <= (spl or 16)).all()
+    assert k.sum() == total and (k >= 1).all() and (k <= (spl or 32)).all()
     ends = np.cumsum(k); starts = ends - k
     # launches never straddle two klara_run calls
     run_ends = np.cumsum(runs)
