@@ -36,6 +36,7 @@ struct klara_handle {
     uint8_t* accept = nullptr; long long accept_cap = 0;
     unsigned long long* naccept = nullptr;
     double *sum = nullptr, *sumsq = nullptr;
+    long long* held = nullptr;      // running sums in sojourn form: saved steps at the current state not yet in sum / sumsq (KParams::held)
     double* hist = nullptr; long long hist_cols = 0;
     double *hist_lt = nullptr, *hist_g = nullptr;
     int* err = nullptr;
@@ -201,7 +202,7 @@ static void free_all(klara_handle* h)
 {
     hipFree(h->X); hipFree(h->GR); hipFree(h->LT); hipFree(h->tune_step); hipFree(h->tune_acc);
     hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->da_epsbar); hipFree(h->da_hbar); hipFree(h->pooled_acc); hipFree(h->accept);
-    hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->hist); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->err);
+    hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->held); hipFree(h->hist); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->err);
     hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
     hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->pool_partial); hipFree(h->d_params); hipFree(h->cdata);
     hipFree(h->bm_prev); hipFree(h->bm_mean); hipFree(h->bm_m2);
@@ -291,7 +292,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     if (desc->tuner == KLARA_TUNER_DUAL_AVERAGING) { CKH(dalloc(&h->da_epsbar, NT)); CKH(dalloc(&h->da_hbar, NT)); } CKH(dalloc(&h->pooled_acc, 1)); CKH(dalloc(&h->naccept, N));
     CKH(dalloc(&h->err, 1)); CKH(dalloc(&h->pooled_out, 2 * D + 2)); CKH(dalloc(&h->pool_partial, (size_t)1024 * (2 * D + 1)));
     CKH(hipMemset(h->err, 0, sizeof(int)));
-    if (desc->monitor & KLARA_MON_SUMMARIES) { CKH(dalloc(&h->sum, N * D)); CKH(dalloc(&h->sumsq, N * D)); }
+    if (desc->monitor & KLARA_MON_SUMMARIES) { CKH(dalloc(&h->sum, N * D)); CKH(dalloc(&h->sumsq, N * D)); CKH(dalloc(&h->held, N)); }
     if (desc->bm_batchlen > 0) { CKH(dalloc(&h->bm_prev, N * D)); CKH(dalloc(&h->bm_mean, N * D)); CKH(dalloc(&h->bm_m2, N * D)); }
     if (desc->monitor & KLARA_MON_ACCEPT) {
         h->accept_cap = desc->nsteps;
@@ -374,7 +375,7 @@ static KParams make_params(klara_handle* h)
     p.X = (decltype(p.X))h->X; p.GR = (decltype(p.GR))h->GR; p.LT = (decltype(p.LT))h->LT;
     p.tune_step = (decltype(p.tune_step))h->tune_step; p.tune_accepted = (decltype(p.tune_accepted))h->tune_acc; p.tune_proposed = (decltype(p.tune_proposed))h->tune_prop;
     p.tune_totproposed = (decltype(p.tune_totproposed))h->tune_tot; p.pooled_accepted = (decltype(p.pooled_accepted))h->pooled_acc;
-    p.accept = (decltype(p.accept))h->accept; p.naccept = (decltype(p.naccept))h->naccept; p.sum = (decltype(p.sum))h->sum; p.sumsq = (decltype(p.sumsq))h->sumsq;
+    p.accept = (decltype(p.accept))h->accept; p.naccept = (decltype(p.naccept))h->naccept; p.sum = (decltype(p.sum))h->sum; p.sumsq = (decltype(p.sumsq))h->sumsq; p.held = (decltype(p.held))h->held;
     p.hist = (decltype(p.hist))h->hist; p.hist_cols = h->hist_cols; p.error_flag = (decltype(p.error_flag))h->err;
     p.hist_lt = (decltype(p.hist_lt))h->hist_lt; p.hist_g = (decltype(p.hist_g))h->hist_g;
     p.nchains = d.nchains; p.chain_offset = d.chain_offset; p.D = d.ndims; p.G = h->G; p.rs = h->RS;
@@ -488,7 +489,10 @@ static klara_status init_common(klara_handle* h)
     HIPCHK(hipMemsetAsync(h->naccept, 0, N * sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(h->pooled_acc, 0, sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(h->GR, 0, N * D * sizeof(double), st));
-    if (h->sum) { HIPCHK(hipMemsetAsync(h->sum, 0, N * D * sizeof(double), st)); HIPCHK(hipMemsetAsync(h->sumsq, 0, N * D * sizeof(double), st)); }
+    if (h->sum) {
+        HIPCHK(hipMemsetAsync(h->sum, 0, N * D * sizeof(double), st)); HIPCHK(hipMemsetAsync(h->sumsq, 0, N * D * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(h->held, 0, N * sizeof(long long), st));
+    }
     if (h->bm_prev) {
         HIPCHK(hipMemsetAsync(h->bm_prev, 0, N * D * sizeof(double), st)); HIPCHK(hipMemsetAsync(h->bm_mean, 0, N * D * sizeof(double), st));
         HIPCHK(hipMemsetAsync(h->bm_m2, 0, N * D * sizeof(double), st));
@@ -621,12 +625,14 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
 // Closes one batch of every (chain, dimension) series in [i0, i1): batch mean from the running sums at the two batch
 // boundaries, then Welford's update of the mean and the sum of squared deviations of the batch means (count = batches closed
 // before this one).  mcvar.jl:35-41 takes var(batch means); the history-free form never revisits a sample.
-__global__ __launch_bounds__(256) void k_bm_close(const double* __restrict__ sum, double* __restrict__ prev, double* __restrict__ mean,
+__global__ __launch_bounds__(256) void k_bm_close(const double* __restrict__ sum, const double* __restrict__ X, const long long* __restrict__ held,
+                                                  int D, double* __restrict__ prev, double* __restrict__ mean,
                                                   double* __restrict__ m2, long long i0, long long i1, long long count, double batchlen)
 {
     const long long i = i0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= i1) return;
-    const double s = sum[i];
+    const long long hd = held[i / D];
+    const double s = hd > 0 ? sum[i] + (double)hd * X[i] : sum[i];       // the running sum over the saved steps (sojourn form)
     const double b = (s - prev[i]) / batchlen;
     prev[i] = s;
     const double delta = b - mean[i];
@@ -646,7 +652,7 @@ static hipError_t launch_bm_close(klara_handle* h)
         if (np > 1) { c0 = j * per * cpw; c1 = (j + 1) * per * cpw; if (c1 > N) c1 = N; }
         if (c0 >= c1) break;
         const long long n = (c1 - c0) * D;
-        hipLaunchKernelGGL(k_bm_close, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, j == 0 ? h->stream : h->side[j - 1], h->sum,
+        hipLaunchKernelGGL(k_bm_close, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, j == 0 ? h->stream : h->side[j - 1], h->sum, h->X, h->held, (int)D,
                            h->bm_prev, h->bm_mean, h->bm_m2, c0 * D, c1 * D, h->bm_count, (double)h->d.bm_batchlen);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -811,15 +817,41 @@ extern "C" klara_status klara_get_accept_counts(klara_handle* h, uint64_t* nacce
     return KLARA_OK;
 }
 
+// sums over the saved steps from their sojourn form: out = part + held * x  (sq: x -> x * x); one product, one sum
+__global__ __launch_bounds__(256) void k_sum_view(const double* __restrict__ part, const double* __restrict__ X, const long long* __restrict__ held,
+                                                  long long n, int D, int sq, double* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long hd = held[i / D];
+    const double x = X[i], v = sq ? x * x : x;
+    out[i] = hd > 0 ? part[i] + (double)hd * v : part[i];
+}
+
 extern "C" klara_status klara_get_chain_sums(klara_handle* h, double* sum, double* sumsq, int64_t* nsaved_out)
 {
     if (!h) return KLARA_ERR_INVALID_ARG;
     if (!h->sum || !h->have_state) return KLARA_ERR_STATE;
     HIPCHK(hipSetDevice(h->d.device));
-    HIPCHK(hipStreamSynchronize(h->stream));
     const size_t n = (size_t)h->d.nchains * (size_t)h->d.ndims;
-    if (sum) HIPCHK(hipMemcpy(sum, h->sum, n * sizeof(double), hipMemcpyDeviceToHost));
-    if (sumsq) HIPCHK(hipMemcpy(sumsq, h->sumsq, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (sum || sumsq) {
+        double* view = nullptr;
+        HIPCHK(dalloc(&view, n));
+        hipError_t e = hipSuccess;
+        for (int sq = 0; sq < 2 && e == hipSuccess; ++sq) {
+            double* dst = sq ? sumsq : sum;
+            if (!dst) continue;
+            hipLaunchKernelGGL(k_sum_view, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, sq ? h->sumsq : h->sum, h->X, h->held,
+                               (long long)n, h->d.ndims, sq, view);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(dst, view, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        }
+        hipFree(view);
+        if (e != hipSuccess) return KLARA_ERR_HIP;
+    } else {
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     if (nsaved_out) *nsaved_out = h->nsaved;
     return KLARA_OK;
 }
@@ -830,15 +862,22 @@ extern "C" klara_status klara_get_chain_sums(klara_handle* h, double* sum, doubl
 // partials in ascending b.  (100 blocks striding over 105 MB took 167 us at 65,536 x 100; this takes ~25.)
 #define KLARA_POOL_BLOCKS 1024
 __global__ __launch_bounds__(256) void k_pool_stage1(const double* __restrict__ sum, const double* __restrict__ sumsq,
+                                                     const double* __restrict__ X, const long long* __restrict__ held,
                                                      const unsigned long long* __restrict__ nacc, long long N, int D, int nb,
                                                      double* __restrict__ partial, unsigned long long* __restrict__ partial_acc)
 {
     const int b = blockIdx.x;
     if (sum != nullptr) {
         for (int j = threadIdx.x; j < 2 * D; j += 256) {
-            const double* src = j < D ? sum + j : sumsq + (j - D);
+            const bool sq = j >= D;
+            const double* src = sq ? sumsq + (j - D) : sum + j;
+            const double* xs = X + (sq ? j - D : j);
             double a = 0.0;
-            for (long long c = b; c < N; c += nb) a += src[c * D];
+            for (long long c = b; c < N; c += nb) {                         // (a chain's sum over its saved steps: part + held * x)
+                const long long hd = held[c];
+                const double x = xs[c * D], v = sq ? x * x : x;
+                a += hd > 0 ? src[c * D] + (double)hd * v : src[c * D];
+            }
             partial[(long long)b * 2 * D + j] = a;
         }
     }
@@ -871,7 +910,7 @@ static hipError_t pool_summaries_async(klara_handle* h, bool with_sums, double* 
     const int D = h->d.ndims;
     const long long N = h->d.nchains;
     const int nb = (int)(N < KLARA_POOL_BLOCKS ? N : KLARA_POOL_BLOCKS);
-    hipLaunchKernelGGL(k_pool_stage1, dim3(nb), dim3(256), 0, h->stream, with_sums ? h->sum : nullptr, h->sumsq, h->naccept, N, D, nb,
+    hipLaunchKernelGGL(k_pool_stage1, dim3(nb), dim3(256), 0, h->stream, with_sums ? h->sum : nullptr, h->sumsq, h->X, h->held, h->naccept, N, D, nb,
                        h->pool_partial, reinterpret_cast<unsigned long long*>(h->pool_partial + (size_t)KLARA_POOL_BLOCKS * 2 * D));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

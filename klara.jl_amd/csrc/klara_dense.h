@@ -177,6 +177,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
     double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
     unsigned long long nacc = 0;
     const bool do_sum = p.sum != nullptr;
+    long long held = do_sum ? p.held[cx.chain_ok ? cx.chain : 0] : 0;        // running sums in sojourn form (KParams::held)
 
     for (int s = 0; s < kl.nsteps; ++s) {
         const unsigned long long t = kl.t0 + (unsigned long long)s;
@@ -313,6 +314,21 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             }
         }
 
+        if (do_sum && __any(acc && held > 0)) {          // leaving a state after `held` saved steps: fold it into the sums
+            if (acc && held > 0) {
+                const double hf = (double)held;
+                double xo[NE];
+                mload<NE>(cx, p.X, p.D, xo);
+                gdouble* sr = p.sum + cx.chain * p.D + cx.q;
+                gdouble* qr = p.sumsq + cx.chain * p.D + cx.q;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) if (cx.valid[e]) {
+                    sr[4 * e] = sr[4 * e] + hf * xo[e];
+                    qr[4 * e] = qr[4 * e] + hf * (xo[e] * xo[e]);
+                }
+                held = 0;
+            }
+        }
         if (acc) {
             mstore<NE>(cx, p.X, p.D, xp);
             if (SAMPLER != KLARA_SAMPLER_MH) {
@@ -337,7 +353,8 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
         if (in_post) sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
         if (save_now) {
             const long long col = scol++;
-            if (do_sum || p.hist != nullptr) {
+            if (do_sum) held += 1;
+            if (p.hist != nullptr) {
                 double xs[NE];
                 if (acc) {
 #pragma unroll
@@ -345,16 +362,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 } else {
                     mload<NE>(cx, p.X, p.D, xs);
                 }
-                if (do_sum) {
-                    gdouble* sr = p.sum + cx.chain * p.D + cx.q;
-                    gdouble* qr = p.sumsq + cx.chain * p.D + cx.q;
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) if (cx.valid[e]) {
-                        sr[4 * e] = sr[4 * e] + xs[e];
-                        qr[4 * e] = qr[4 * e] + xs[e] * xs[e];
-                    }
-                }
-                if (p.hist != nullptr) {
+                {
                     if (col < p.hist_cols) {
                         gdouble* dst = p.hist + (col * p.nchains + cx.chain) * p.D + cx.q;
 #pragma unroll
@@ -382,6 +390,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
     if (cx.chain_ok && cx.q == 0) {
         p.LT[cx.chain] = lt;
         p.naccept[cx.chain] += nacc;
+        if (do_sum) p.held[cx.chain] = held;
         if (da) { p.da_epsbar[cx.chain] = tn.epsbar; p.da_hbar[cx.chain] = tn.hbar; }
         if (!p.pooled) {
             p.tune_step[cx.chain] = tn.step;

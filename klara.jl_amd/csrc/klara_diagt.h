@@ -94,6 +94,58 @@ __device__ __forceinline__ void store_pairs(const PairCtx<NP, Q>& c, __amdgpu_bu
         }
     }
 }
+// the same accesses for the lanes with `on` only (the others read zeros / store nothing: their offsets fall outside the window)
+template <int NP, int Q>
+__device__ __forceinline__ void load_pairs_if(const PairCtx<NP, Q>& c, __amdgpu_buffer_rsrc_t w, bool on, double (&v)[2 * NP])
+{
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const kd_uint4 t = __builtin_amdgcn_raw_buffer_load_b128(w, on ? pair_off<NP, Q>(c, p) : KLARA_BUF_OOB, 0, 0);
+        v[2 * p] = __builtin_bit_cast(double, kd_uint2{ t.x, t.y });
+        v[2 * p + 1] = __builtin_bit_cast(double, kd_uint2{ t.z, t.w });
+        if (p == NP - 1 && !c.last_full) v[2 * p + 1] = 0.0;
+    }
+}
+template <int NP, int Q>
+__device__ __forceinline__ void store_pairs_if(const PairCtx<NP, Q>& c, __amdgpu_buffer_rsrc_t w, bool on, const double (&v)[2 * NP])
+{
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const kd_uint2 a = __builtin_bit_cast(kd_uint2, v[2 * p]), b = __builtin_bit_cast(kd_uint2, v[2 * p + 1]);
+        const unsigned o = on ? pair_off<NP, Q>(c, p) : KLARA_BUF_OOB;
+        if (p < NP - 1) {
+            __builtin_amdgcn_raw_buffer_store_b128(kd_uint4{ a.x, a.y, b.x, b.y }, w, o, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b64(a, w, o, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(b, w, (on && c.last_full) ? o + 8u : KLARA_BUF_OOB, 0, 0);
+        }
+    }
+}
+// A chain leaves the state x after `held` saved steps (KParams::held): sum += held * x, sumsq += held * (x * x), held = 0, for
+// the lanes with `fold`; their chain's sums are fetched first if this is the first time in the launch.  (Behind a wave-uniform
+// branch at the call site: it runs on a few per cent of the transitions of the headline job.)
+template <int NP, int Q>
+__device__ __forceinline__ void diagt_fold(const PairCtx<NP, Q>& c, __amdgpu_buffer_rsrc_t wsum, __amdgpu_buffer_rsrc_t wsq, bool fold,
+                                        bool& loaded, long long& held, const double (&x)[2 * NP], double (&sm)[2 * NP], double (&sq)[2 * NP])
+{
+    const bool need = fold && !loaded;
+    if (__any(need)) {
+        double ts[2 * NP], tq[2 * NP];
+        load_pairs_if<NP, Q>(c, wsum, need, ts);
+        load_pairs_if<NP, Q>(c, wsq, need, tq);
+#pragma unroll
+        for (int e = 0; e < 2 * NP; ++e) { sm[e] = need ? ts[e] : sm[e]; sq[e] = need ? tq[e] : sq[e]; }
+        loaded = loaded || need;
+    }
+    const double hf = fold ? (double)held : 0.0;
+#pragma unroll
+    for (int e = 0; e < 2 * NP; ++e) {
+        const double a = sm[e] + hf * x[e], b = sq[e] + hf * (x[e] * x[e]);
+        sm[e] = fold ? a : sm[e]; sq[e] = fold ? b : sq[e];
+    }
+    held = fold ? 0 : held;
+}
+
 // per-element parameter vector (weights, means, proposal scales): element 2P+h of the lane's pair p
 template <int NP, int Q>
 __device__ __forceinline__ void load_pair_param(const PairCtx<NP, Q>& c, const gdouble* base, int D, double dflt, double (&v)[2 * NP])
@@ -198,23 +250,35 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
         const __amdgpu_buffer_rsrc_t wx = group_window(p.X, first_chain, here, D);
         const __amdgpu_buffer_rsrc_t wg = group_window(p.GR, first_chain, here, D);
 
-        double x[E], g[E];
+        double x[E];
         load_pairs<NP, Q>(cx, wx, x);
         // The gradient of this target family is a function of the value alone and GR always holds gradlogtarget(X) (set by
-        // initialize! and by every accepted transition), so it is re-formed from x below — the same operations that produced the
-        // stored bits — instead of being loaded: half the state read, and 4*NP fewer registers reserved while the normals are drawn.
-#ifdef KLARA_DT_LOAD_GRAD
-        if (NEEDG) load_pairs<NP, Q>(cx, wg, g);
-#endif
+        // initialize! and by every accepted transition).  It is therefore neither loaded nor kept: wherever iterate! reads
+        // the current gradient it is re-formed from x — the same operations that produced the stored bits — and the
+        // proposal's gradient is formed from the proposal when it is written out.  Half the state read, and 8*NP fewer
+        // registers over the launch (x, proposal, normals and running sums are what a lane holds).
+        const auto grad_of = [&](const double (&v)[E], double (&out)[E]) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) { double term_; diag_elem<UNITW>(v[e], wv(e), m2wv(e), mv(e), term_, out[e]); }
+        };
         double lt = p.LT[chain_ok ? chain : 0];
         unsigned long long nacc = 0;
         bool stuck = false;                                // slice sampler: step-out / shrink ran out of attempts
-        // saved-sample monitors (MON): running sums stay in registers over the launch's transitions
+        // saved-sample monitors (MON).  Running sums are kept in sojourn form (KParams::held): the save rule only counts the saved
+        // steps a chain spends at its current state, and the state is folded into sum / sumsq (held * x, held * x^2) when the
+        // chain leaves it.  A chain's sums are loaded the first time that happens in the launch and written back only then, so
+        // a chain that does not move (98-99.6 % of the transitions of the drift-0.9 job) costs no running-sum traffic at all:
+        // 210 MB per launch of 65,536 x 100 otherwise, 40-90 us of every launch.
         const bool do_sum = MON && p.sum != nullptr;
         double sm[E], sq[E];
+        bool sums_loaded = false;                          // (per chain: uniform over the chain's Q lanes)
+        long long held = 0;
+        __amdgpu_buffer_rsrc_t wsum = wx, wsq = wx;
         if (do_sum) {
-            load_pairs<NP, Q>(cx, group_window(p.sum, first_chain, here, D), sm);
-            load_pairs<NP, Q>(cx, group_window(p.sumsq, first_chain, here, D), sq);
+#pragma unroll
+            for (int e = 0; e < E; ++e) { sm[e] = 0.0; sq[e] = 0.0; }
+            wsum = group_window(p.sum, first_chain, here, D); wsq = group_window(p.sumsq, first_chain, here, D);
+            held = p.held[chain_ok ? chain : 0];
         }
         int sphase = kl.save_phase0;
         long long scol = kl.save_col0;
@@ -232,7 +296,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
         for (int s = 0; s < nsteps; ++s) {
             const unsigned long long t = kl.t0 + (unsigned long long)s;
             if (KCNT) tune_count_proposal(p, tn);
-            double xp[E], gp[E];
+            double xp[E];
             double red[3] = { 0.0, 0.0, 0.0 }, red1[1], red2[2];
             double u_last = 0.5, lg_last = 0.0;
             bool acc;
@@ -248,12 +312,8 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                     KLARA_DT_PAIR_FENCE(pi);
                 }
             }
-#ifndef KLARA_DT_LOAD_GRAD
-            if (NEEDG && s == 0) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) { double term_; diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), term_, g[e]); }
-            }
-#endif
+            if (SLICE && do_sum && __any(held > 0))                                // the slice sampler always moves: fold first
+                diagt_fold<NP, Q>(cx, wsum, wsq, held > 0, sums_loaded, held, x, sm, sq);
             if (SLICE) {                                                           // iterate/SliceSampler.jl:60-109
                 // Coordinates are visited in turn.  Coordinate i lives on lane (i/2) % Q of its chain as register
                 // 2*((i/2)/Q) + (i&1); everything scalar (the slice level, the interval, the probes' log-targets) is computed
@@ -356,14 +416,15 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                 const double half_inv_h = 0.5 * (KCNT ? 1.0 / h_ : p.inv_step0);
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const double m_ = x[e] + halfh * g[e];                                     // :83
+                    double term, ge, gpe;
+                    diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), term, ge);        // (the current gradient, re-formed)
+                    const double m_ = x[e] + halfh * ge;                                       // :83
                     xp[e] = m_ + sq * z[e];                                                    // :84
-                    double term;
-                    diag_elem<UNITW>(xp[e], wv(e), m2wv(e), mv(e), term, gp[e]);    // :86
+                    diag_elem<UNITW>(xp[e], wv(e), m2wv(e), mv(e), term, gpe);      // :86
                     red[0] = red[0] + term;
                     const double q1 = m_ - xp[e];
                     red[1] = red[1] + (q1 * q1) * half_inv_h;                                  // :90
-                    const double mup = xp[e] + halfh * gp[e];                                  // :91
+                    const double mup = xp[e] + halfh * gpe;                                    // :91
                     const double q2 = mup - x[e];
                     red[2] = red[2] + (q2 * q2) * half_inv_h;                                  // :92
                 }
@@ -378,7 +439,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                     acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot)));
             } else {                                                               // iterate/HMC.jl:124-201
                 const double eps = tn.step, halfe = 0.5 * eps;
-                double mom[E];
+                double mom[E], gp[E];
                 double k0[1] = { 0.0 };
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
@@ -389,7 +450,8 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                 group_allreduce<1>(k0, Q, cx.lane);
                 const double H0 = lt - 0.5 * k0[0];                                            // :137
 #pragma unroll
-                for (int e = 0; e < E; ++e) { xp[e] = x[e]; gp[e] = g[e]; }                    // :139-140
+                for (int e = 0; e < E; ++e) xp[e] = x[e];                                      // :139
+                grad_of(x, gp);                                                                // :140 (re-formed)
                 const int nl = DA ? da_nleaps(p, eps) : p.nleaps;                              // :142-144
                 for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {                          // :146-155, samplers.jl:122-134
                     const bool go = !DA || l < nl;
@@ -433,14 +495,18 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             if (ONESTEP) {
                 if (acc) {                               // accepted proposal: registers -> HBM, nothing else moves
                     store_pairs<NP, Q>(cx, wx, xp);
-                    if (NEEDG) store_pairs<NP, Q>(cx, wg, gp);
+                    if (NEEDG) { double gq[E]; grad_of(xp, gq); store_pairs<NP, Q>(cx, wg, gq); }
                     if (chain_ok && cx.q == 0) { p.LT[chain] = ltp; p.naccept[chain] += 1ull; }
                 }
             } else {
                 nacc += acc ? 1ull : 0ull;
+                if (!SLICE && do_sum && __any(acc && held > 0)) {          // a chain of this wavefront leaves its state
+                    const bool fold = acc && held > 0;
+                    diagt_fold<NP, Q>(cx, wsum, wsq, fold, sums_loaded, held, x, sm, sq);
+                }
                 if (acc) {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) { x[e] = xp[e]; if (NEEDG) g[e] = gp[e]; }
+                    for (int e = 0; e < E; ++e) x[e] = xp[e];
                     lt = ltp;
                 }
             }
@@ -449,14 +515,11 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             const long long i1 = (long long)t + 1;
             if (MON && i1 > p.burnin && i1 <= p.nsteps_total) {
                 if (sphase == 0) {
-                    if (do_sum) {
-#pragma unroll
-                        for (int e = 0; e < E; ++e) { sm[e] = sm[e] + x[e]; sq[e] = sq[e] + x[e] * x[e]; }
-                    }
+                    if (do_sum) held += 1;
                     if (scol < p.hist_cols) {
                         const long long col0 = scol * p.nchains + first_chain;
                         if (p.hist != nullptr) store_pairs<NP, Q>(cx, group_window(p.hist, col0, here, D), x);
-                        if (NEEDG && p.hist_g != nullptr) store_pairs<NP, Q>(cx, group_window(p.hist_g, col0, here, D), g);
+                        if (NEEDG && p.hist_g != nullptr) { double gq[E]; grad_of(x, gq); store_pairs<NP, Q>(cx, group_window(p.hist_g, col0, here, D), gq); }
                         if (p.hist_lt != nullptr && chain_ok && cx.q == 0) p.hist_lt[scol * p.nchains + chain] = lt;
                     }
                     ++scol;
@@ -465,13 +528,16 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             }
         }
         if (do_sum) {
-            store_pairs<NP, Q>(cx, group_window(p.sum, first_chain, here, D), sm);
-            store_pairs<NP, Q>(cx, group_window(p.sumsq, first_chain, here, D), sq);
+            if (__any(sums_loaded)) {                      // only the chains that left a state during the launch write their sums back
+                store_pairs_if<NP, Q>(cx, wsum, sums_loaded, sm);
+                store_pairs_if<NP, Q>(cx, wsq, sums_loaded, sq);
+            }
+            if (chain_ok && cx.q == 0) p.held[chain] = held;
         }
         if (SLICE && stuck && chain_ok && cx.q == 0) atomicMax((int*)p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
         if (!ONESTEP && nacc != 0) {
             store_pairs<NP, Q>(cx, wx, x);
-            if (NEEDG) store_pairs<NP, Q>(cx, wg, g);
+            if (NEEDG) { double gq[E]; grad_of(x, gq); store_pairs<NP, Q>(cx, wg, gq); }
             if (chain_ok && cx.q == 0) { p.LT[chain] = lt; p.naccept[chain] += nacc; }
         }
         if (TUNE && chain_ok && cx.q == 0) {

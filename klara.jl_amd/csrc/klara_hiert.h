@@ -221,11 +221,26 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
     const long long c0 = chain_ok ? chain : 0;
     double lt = p.LT[c0];
     unsigned long long nacc = 0;
+    // Running sums (sojourn form, KParams::held) live in LDS for the launch, one private column per lane — [wavefront][slot][lane],
+    // 2 * (2 RPL + 5) slots, conflict-free 8-byte accesses — instead of 4 RPL + 10 registers per lane that the 256-register budget
+    // of two wavefronts per SIMD does not have (they were spilled: 272 B of scratch).  They are touched when a chain leaves a state.
+    constexpr int NSLOT = 2 * RPL + 5;
+    __shared__ double lds_sums[MON ? 4 * 2 * NSLOT * 64 : 1];
+    double* const my_sums = &lds_sums[MON ? ((threadIdx.x >> 6) * 2 * NSLOT) * 64 + (threadIdx.x & 63) : 0];
     const bool do_sum = MON && p.sum != nullptr;
-    HierVec<RPL> sm, sq;
+    long long held = 0;
     if (do_sum) {
+        HierVec<RPL> sm, sq;
         hload<RPL, NT>(cx, group_window(p.sum, first_chain, here, D), sm);
         hload<RPL, NT>(cx, group_window(p.sumsq, first_chain, here, D), sq);
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            my_sums[(2 * k) * 64] = sm.a[k]; my_sums[(2 * k + 1) * 64] = sm.b[k];
+            my_sums[(NSLOT + 2 * k) * 64] = sq.a[k]; my_sums[(NSLOT + 2 * k + 1) * 64] = sq.b[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { my_sums[(2 * RPL + k) * 64] = sm.h[k]; my_sums[(NSLOT + 2 * RPL + k) * 64] = sq.h[k]; }
+        held = p.held[chain_ok ? chain : 0];
     }
     int sphase = kl.save_phase0;
     long long scol = kl.save_col0;
@@ -349,6 +364,25 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
             if (!acc && ratio > KD_LOG_UMIN_GUARD)
                 acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((D + 1) >> 1))));
         }
+        if (do_sum && __any(acc && held > 0)) {                                       // leaving a state after `held` saved steps
+            const bool fold = acc && held > 0;
+            const double hf = fold ? (double)held : 0.0;
+            if (fold) {
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) {
+                    my_sums[(2 * k) * 64] = my_sums[(2 * k) * 64] + hf * x.a[k];
+                    my_sums[(2 * k + 1) * 64] = my_sums[(2 * k + 1) * 64] + hf * x.b[k];
+                    my_sums[(NSLOT + 2 * k) * 64] = my_sums[(NSLOT + 2 * k) * 64] + hf * (x.a[k] * x.a[k]);
+                    my_sums[(NSLOT + 2 * k + 1) * 64] = my_sums[(NSLOT + 2 * k + 1) * 64] + hf * (x.b[k] * x.b[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    my_sums[(2 * RPL + k) * 64] = my_sums[(2 * RPL + k) * 64] + hf * x.h[k];
+                    my_sums[(NSLOT + 2 * RPL + k) * 64] = my_sums[(NSLOT + 2 * RPL + k) * 64] + hf * (x.h[k] * x.h[k]);
+                }
+                held = 0;
+            }
+        }
         if (acc) { x = xp; if (NEEDG) g = gp; lt = ltp; }                             // commit (HMC.jl:166-176, MALA.jl:95-105, MH.jl:98-100)
         nacc += acc ? 1ull : 0ull;
         if (accept_out != nullptr && chain_ok && cx.q == 0) accept_out[(long long)s * p.nchains + chain] = acc ? 1 : 0;
@@ -362,15 +396,7 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
         const long long i1 = (long long)t + 1;
         if (MON && i1 > p.burnin && i1 <= p.nsteps_total) {
             if (sphase == 0) {
-                if (do_sum) {
-#pragma unroll
-                    for (int k = 0; k < RPL; ++k) {
-                        sm.a[k] = sm.a[k] + x.a[k]; sq.a[k] = sq.a[k] + x.a[k] * x.a[k];
-                        sm.b[k] = sm.b[k] + x.b[k]; sq.b[k] = sq.b[k] + x.b[k] * x.b[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) { sm.h[k] = sm.h[k] + x.h[k]; sq.h[k] = sq.h[k] + x.h[k] * x.h[k]; }
-                }
+                if (do_sum) held += 1;
                 if (scol < p.hist_cols) {
                     const long long col0 = scol * p.nchains + first_chain;
                     if (p.hist != nullptr) hstore<RPL, NT>(cx, group_window(p.hist, col0, here, D), x);
@@ -383,8 +409,17 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
         }
     }
     if (do_sum) {
+        HierVec<RPL> sm, sq;
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            sm.a[k] = my_sums[(2 * k) * 64]; sm.b[k] = my_sums[(2 * k + 1) * 64];
+            sq.a[k] = my_sums[(NSLOT + 2 * k) * 64]; sq.b[k] = my_sums[(NSLOT + 2 * k + 1) * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { sm.h[k] = my_sums[(2 * RPL + k) * 64]; sq.h[k] = my_sums[(NSLOT + 2 * RPL + k) * 64]; }
         hstore<RPL, NT>(cx, group_window(p.sum, first_chain, here, D), sm);
         hstore<RPL, NT>(cx, group_window(p.sumsq, first_chain, here, D), sq);
+        if (chain_ok && cx.q == 0) p.held[chain] = held;
     }
     if (nacc != 0) {
         hstore<RPL, NT>(cx, wx, x);

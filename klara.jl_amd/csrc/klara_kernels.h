@@ -61,7 +61,12 @@ struct KParams {
     gulong* pooled_accepted;       // pooled mode: device-wide accepted counter
     guchar* accept;                           // [launch step][nchains] or null
     gulong* naccept;               // per chain
-    gdouble* sum; gdouble* sumsq;                // per chain x D or null
+    gdouble* sum; gdouble* sumsq;                // per chain x D or null: running sums in sojourn form (see `held`)
+    // Saved (post-burn-in, thinned) steps the chain has spent at its CURRENT state that are not in sum / sumsq yet.  The save
+    // rule only counts (held += 1); when a transition is accepted the state being left is folded in first:
+    // sum += held * x, sumsq += held * (x * x), held = 0.  Sums over the saved steps = sum + held * x (the read-back kernels
+    // form that view).  A chain that did not move during a launch therefore touches neither array.
+    glong* held;
     gdouble* hist; long long hist_cols;         // [col][nchains][D] or null
     gdouble* hist_lt; gdouble* hist_g;           // [col][nchains] / [col][nchains][D] or null
     gint* error_flag;                           // set to klara_status on device-detected errors
@@ -918,6 +923,9 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
     constexpr bool RSPL = TARGET == KLARA_TARGET_LOGISTIC;
     // single unmonitored transition: an accepted proposal goes from the proposal registers straight to HBM
     constexpr bool DIRECT = ONESTEP && NOMON && SAMPLER != KLARA_SAMPLER_SLICE;
+    // monitored jobs: the step functions hand the proposal back and the commit happens here, after the state being left has been
+    // folded into the running sums (KParams::held)
+    constexpr bool OUTER = !NOMON && SAMPLER != KLARA_SAMPLER_SLICE;
     const KParams& p = *pp;
     kd_tables_to_lds();
     guchar* const accept_out = (!NOMON && p.accept != nullptr) ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
@@ -964,9 +972,11 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
         const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
         // running sums are first needed at the end of a transition: not prefetched (saves 4E VGPRs)
         double sm[E], sq[E];
+        long long held = 0;
         if (do_sum) {
             load_win<E>(cx, group_window(p.sum, first_chain, here, p.D), p.D, sm);
             load_win<E>(cx, group_window(p.sumsq, first_chain, here, p.D), p.D, sq);
+            held = p.held[cx.chain_ok ? cx.chain : 0];
         }
         double z[E];
         AccDraw ad = { 0.5, 0.0 };
@@ -990,15 +1000,36 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             const unsigned long long t = kl.t0 + (unsigned long long)s;
             if (KCNT) tune_count_proposal(p, tn);
             bool acc;
-            if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E, !DIRECT>(p, tg, cx, gchain, t, z, ad, vp, cur.x, cur.lt, prop);
-            else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E, PLAIN, !DIRECT>(p, tg, cx, gchain, t, z, ad, tn.step, cur.x, cur.g, cur.lt, prop);
+            if (SAMPLER == KLARA_SAMPLER_MH) acc = step_mh<T, E, !(DIRECT || OUTER)>(p, tg, cx, gchain, t, z, ad, vp, cur.x, cur.lt, prop);
+            else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E, PLAIN, !(DIRECT || OUTER)>(p, tg, cx, gchain, t, z, ad, tn.step, cur.x, cur.g, cur.lt, prop);
             else if (SAMPLER == KLARA_SAMPLER_HMC) {
                 double a_prob = 0.0;
-                acc = step_hmc<T, E, PLAIN, !DIRECT>(p, tg, cx, gchain, t, z, ad, tn.step, da ? da_nleaps(p, tn.step) : p.nleaps, a_prob,
+                acc = step_hmc<T, E, PLAIN, !(DIRECT || OUTER)>(p, tg, cx, gchain, t, z, ad, tn.step, da ? da_nleaps(p, tn.step) : p.nleaps, a_prob,
                                      cur.x, cur.g, cur.lt, prop);
                 if (da) da_update(p, tn, (long long)t + 1, a_prob);                   // iterate/HMC.jl:225-249
             }
-            else acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, cur.x, cur.lt, stuck);
+            else {
+                if (do_sum && held > 0) {                                  // the slice sampler always moves: fold first
+                    const double hf = (double)held;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { sm[e] = sm[e] + hf * cur.x[e]; sq[e] = sq[e] + hf * (cur.x[e] * cur.x[e]); }
+                    held = 0;
+                }
+                acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, cur.x, cur.lt, stuck);
+            }
+            if (OUTER) {
+                if (do_sum && acc && held > 0) {                           // leaving a state after `held` saved steps
+                    const double hf = (double)held;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { sm[e] = sm[e] + hf * cur.x[e]; sq[e] = sq[e] + hf * (cur.x[e] * cur.x[e]); }
+                    held = 0;
+                }
+                if (acc) {                                                 // commit (MH.jl:98-100, MALA.jl:95-105, HMC.jl:166-176)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { cur.x[e] = prop.x[e]; if (NEEDG) cur.g[e] = prop.g[e]; }
+                    cur.lt = prop.lt;
+                }
+            }
             nacc += acc ? 1ull : 0ull;
             last_acc = acc;
             if (KCNT && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;   // the slice sampler never counts accepts
@@ -1012,10 +1043,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             const long long i1 = (long long)t + 1;
             if (!NOMON && i1 > p.burnin && i1 <= p.nsteps_total) {
                 if (sphase == 0) {
-                    if (do_sum) {
-#pragma unroll
-                        for (int e = 0; e < E; ++e) { sm[e] = sm[e] + cur.x[e]; sq[e] = sq[e] + cur.x[e] * cur.x[e]; }
-                    }
+                    if (do_sum) held += 1;
                     if (hist != nullptr && scol < p.hist_cols) {
                         gdouble* dst = hist + (scol * p.nchains + cx.chain) * p.D + cx.i0;
 #pragma unroll
@@ -1051,6 +1079,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             store_win<E>(cx, group_window(p.sumsq, first_chain, here, p.D), p.D, sq);
         }
         if (cx.chain_ok && cx.q == 0 && cx.rq == 0) {
+            if (do_sum) p.held[cx.chain] = held;
             if (nacc != 0) { p.LT[cx.chain] = cur.lt; p.naccept[cx.chain] += nacc; }
             if (da) { p.tune_step[cx.chain] = tn.step; p.da_epsbar[cx.chain] = tn.epsbar; p.da_hbar[cx.chain] = tn.hbar; }
             if (per_chain_tune) {

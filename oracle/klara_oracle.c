@@ -562,6 +562,17 @@ void ko_init_state_normal(const klara_desc* d, double* X)
         ko_normals(d->seed, (uint64_t)(d->chain_offset + n), KO_INIT_TRANSITION, d->ndims, X + n * d->ndims);
 }
 
+/* the chain leaves the state xold after *held saved steps: fold them into the running sums (see ko_run) */
+static void ko_fold(double* sum, double* sumsq, const double* xold, int D, int64_t* held)
+{
+    const double h = (double)*held;
+    for (int i = 0; i < D; ++i) {
+        sum[i] = sum[i] + h * xold[i];
+        sumsq[i] = sumsq[i] + h * (xold[i] * xold[i]);
+    }
+    *held = 0;
+}
+
 /* one transition of one chain; returns accept flag */
 static int ko_transition(const ko_target_ctx* c, uint64_t gchain, uint64_t t, double step, int64_t nleaps,
                          double* x, double* g, double* lt, int* stuck, double* a_out)
@@ -578,7 +589,14 @@ static int ko_transition(const ko_target_ctx* c, uint64_t gchain, uint64_t t, do
 /* run(job) — src/jobs/BasicMCJob.jl:212-244 for every chain.  t0 = number of transitions already
  * done (the global 0-based index of the first transition of this call).  Outputs may be NULL:
  *   accept_out[s * nchains + n]      diagnosticvalues[:accept] of transition t0+s
- *   sum/sumsq[n * D + i]             accumulated over postrange steps (BasicMCRange.jl:17-36)
+ *   sum/sumsq[n * D + i], held[n]    running sums over postrange steps (BasicMCRange.jl:17-36) in sojourn form: a saved step
+ *                                    only counts (held[n] += 1); when the chain leaves a state x after `held` saved steps,
+ *                                    sum += held * x and sumsq += held * (x * x) (one product, one sum each) and held = 0.
+ *                                    The sums over the saved steps are sum + held * x (ko users form this view); a chain that
+ *                                    moves at every saved step adds 1 * x each time — the plain running sum.  (Julia's
+ *                                    mean(chain) sums the stored values in its own pairwise order, stats/mean.jl:7-11; the order
+ *                                    here is build-defined like every other reduction, and it is what lets the device skip the
+ *                                    running-sum traffic of chains that did not move.)
  *   naccept[n]                       accepted transitions
  *   hist[(col * nchains + n) * D + i] value saved as column `col` (save rule BasicMCJob.jl:226-231)
  * Tuner arrays have nchains entries (per-chain mode) or 1 entry (pooled mode). */
@@ -586,7 +604,7 @@ int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double
            double* step, int64_t* accepted, int64_t* proposed, int64_t* totproposed,
            int64_t t0, int64_t nsteps, uint8_t* accept_out, double* sum, double* sumsq,
            uint64_t* naccept, double* hist, int64_t hist_cols, double* hist_lt, double* hist_g,
-           double* da_epsbar, double* da_hbar)
+           double* da_epsbar, double* da_hbar, int64_t* held)
 {
     ko_target_ctx c; ko_ctx_init(&c, d, L);
     const int D = d->ndims;
@@ -617,9 +635,13 @@ int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double
                     nl = (q == q && q < 65536.0) ? (int64_t)nearbyint(q) : 65536;   /* Int(round(.)), ties to even; capped */
                     if (nl < 1) nl = 1;
                 }
+                double xold[KO_MAXD];
+                const int want_fold = sum && held[n] > 0;
+                if (want_fold) memcpy(xold, x, sizeof(double) * (size_t)D);
                 const int acc = ko_transition(&c, (uint64_t)(d->chain_offset + n), (uint64_t)t,
                                               tn.step, nl, x, g, &LT[n], &stuck, &a_prob);
                 if (stuck) break;
+                if (want_fold && acc) ko_fold(sum + n * D, sumsq + n * D, xold, D, &held[n]);
                 if (da) {                                       /* iterate/HMC.jl:225-249 */
                     const int64_t count = t + 1;                /* job.sstate.count, incremented at :125-127 */
                     if (count <= d->da_nadapt) {                /* tune!(tune, tuner, count, a) DualAveragingMCTuner.jl:95-101 */
@@ -642,10 +664,7 @@ int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double
                 const int64_t i1 = t + 1;                       /* 1-based step index i of run() */
                 if (i1 > d->burnin && (i1 - d->burnin - 1) % d->thinning == 0 && i1 <= d->nsteps) {
                     const int64_t col = (i1 - d->burnin - 1) / d->thinning;
-                    if (sum) for (int i = 0; i < D; ++i) {
-                        sum[n * D + i] = sum[n * D + i] + x[i];
-                        sumsq[n * D + i] = sumsq[n * D + i] + x[i] * x[i];
-                    }
+                    if (sum) held[n] += 1;
                     if (hist && col < hist_cols)
                         memcpy(hist + ((size_t)col * (size_t)d->nchains + (size_t)n) * (size_t)D, x,
                                sizeof(double) * (size_t)D);
@@ -669,19 +688,20 @@ int ko_run(const klara_desc* d, const ko_layout* L, double* X, double* G, double
             for (int64_t n = 0; n < d->nchains; ++n) {
                 int stuck = 0;
                 double* x = X + n * D; double* g = G + n * D;
+                double xold[KO_MAXD];
+                const int want_fold = sum && held[n] > 0;
+                if (want_fold) memcpy(xold, x, sizeof(double) * (size_t)D);
                 const int acc = ko_transition(&c, (uint64_t)(d->chain_offset + n), (uint64_t)t,
                                               tn.step, d->nleaps, x, g, &LT[n], &stuck, NULL);
                 stuck_any |= stuck;
+                if (want_fold && acc && !stuck) ko_fold(sum + n * D, sumsq + n * D, xold, D, &held[n]);
                 nacc += acc;
                 if (accept_out) accept_out[s * d->nchains + n] = (uint8_t)acc;
                 if (naccept) naccept[n] += (uint64_t)acc;
                 const int64_t i1 = t + 1;
                 if (i1 > d->burnin && (i1 - d->burnin - 1) % d->thinning == 0 && i1 <= d->nsteps) {
                     const int64_t col = (i1 - d->burnin - 1) / d->thinning;
-                    if (sum) for (int i = 0; i < D; ++i) {
-                        sum[n * D + i] = sum[n * D + i] + x[i];
-                        sumsq[n * D + i] = sumsq[n * D + i] + x[i] * x[i];
-                    }
+                    if (sum) held[n] += 1;
                     if (hist && col < hist_cols)
                         memcpy(hist + ((size_t)col * (size_t)d->nchains + (size_t)n) * (size_t)D, x,
                                sizeof(double) * (size_t)D);

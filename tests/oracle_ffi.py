@@ -43,7 +43,7 @@ def load() -> C.CDLL:
     lib.ko_init.restype = C.c_int
     lib.ko_init_state_normal.argtypes = [C.POINTER(L.KlaraDesc), vp]
     lib.ko_init_state_normal.restype = None
-    lib.ko_run.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout)] + [vp] * 7 + [C.c_int64, C.c_int64] + [vp] * 5 + [C.c_int64, vp, vp, vp, vp]
+    lib.ko_run.argtypes = [C.POINTER(L.KlaraDesc), C.POINTER(KoLayout)] + [vp] * 7 + [C.c_int64, C.c_int64] + [vp] * 5 + [C.c_int64, vp, vp, vp, vp, vp]
     lib.ko_run.restype = C.c_int
     lib.ko_philox_block.argtypes = [vp, vp, vp]
     lib.ko_stream_block.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]
@@ -201,8 +201,10 @@ class OracleJob:
         self.da_epsbar = np.zeros(nt); self.da_hbar = np.zeros(nt)
         self.t = 0
         self.naccept = np.zeros(self.N, np.uint64)
-        self.sum = np.zeros((self.N, self.D)) if want_sums else None
-        self.sumsq = np.zeros((self.N, self.D)) if want_sums else None
+        # running sums in sojourn form (klara_oracle.c ko_run): folded parts + the saved steps held at the current state
+        self._sum = np.zeros((self.N, self.D)) if want_sums else None
+        self._sumsq = np.zeros((self.N, self.D)) if want_sums else None
+        self.held = np.zeros(self.N, np.int64)
         self.hist_cols = (int(nsteps) - int(burnin) - 1) // int(thinning) + 1
         self.hist = np.zeros((self.hist_cols, self.N, self.D)) if want_hist else None
         self.hist_lt = np.zeros((self.hist_cols, self.N)) if want_hist else None
@@ -212,6 +214,15 @@ class OracleJob:
 
     def _p(self, a):
         return None if a is None else a.ctypes.data
+
+    @property
+    def sum(self):
+        """sum of the saved values per (chain, dimension): folded part + held * x (the view klara_get_chain_sums returns)"""
+        return None if self._sum is None else self._sum + self.held[:, None].astype(np.float64) * self.X
+
+    @property
+    def sumsq(self):
+        return None if self._sumsq is None else self._sumsq + self.held[:, None].astype(np.float64) * (self.X * self.X)
 
     def _bind_user(self):
         if self._user is not None:             # (process-global in the oracle: bound before every call that evaluates the target)
@@ -229,8 +240,9 @@ class OracleJob:
         self.G[...] = 0.0
         self.t = 0
         self.naccept[...] = 0
-        if self.sum is not None:
-            self.sum[...] = 0.0; self.sumsq[...] = 0.0
+        if self._sum is not None:
+            self._sum[...] = 0.0; self._sumsq[...] = 0.0
+        self.held[...] = 0
         self.accept = np.zeros((0, self.N), np.uint8)
         self._bind_user()
         return self.lib.ko_init(C.byref(self.desc), C.byref(self.layout), self._p(self.X), self._p(self.G),
@@ -243,9 +255,10 @@ class OracleJob:
         self._bind_user()
         st = self.lib.ko_run(C.byref(self.desc), C.byref(self.layout), self._p(self.X), self._p(self.G),
                              self._p(self.LT), self._p(self.step), self._p(self.accepted), self._p(self.proposed),
-                             self._p(self.totproposed), self.t, int(nsteps), self._p(acc), self._p(self.sum),
-                             self._p(self.sumsq), self._p(self.naccept), self._p(self.hist), self.hist_cols,
-                             self._p(self.hist_lt), self._p(self.hist_g), self._p(self.da_epsbar), self._p(self.da_hbar))
+                             self._p(self.totproposed), self.t, int(nsteps), self._p(acc), self._p(self._sum),
+                             self._p(self._sumsq), self._p(self.naccept), self._p(self.hist), self.hist_cols,
+                             self._p(self.hist_lt), self._p(self.hist_g), self._p(self.da_epsbar), self._p(self.da_hbar),
+                             self._p(self.held))
         self.t += int(nsteps)
         if acc is not None:
             self.accept = np.concatenate([self.accept, acc], axis=0)
@@ -255,7 +268,7 @@ class OracleJob:
         """Steps to nsteps, closing a batch of saved samples every `batchlen` of them (klara_desc.bm_batchlen);
         returns (mcvar_bm (N x D), nbatches) — mcvar.jl:35-41."""
         d = self.desc
-        prev = np.zeros_like(self.sum); mean = np.zeros_like(self.sum); m2 = np.zeros_like(self.sum)
+        prev = np.zeros_like(self._sum); mean = np.zeros_like(self._sum); m2 = np.zeros_like(self._sum)
         nb = 0
         while self.t < nsteps:
             close_at = d.burnin + ((nb + 1) * batchlen - 1) * d.thinning + 1
@@ -264,7 +277,8 @@ class OracleJob:
                 k = min(k, close_at - self.t)
             assert self.run(k) == 0
             if self.t == close_at and close_at <= d.nsteps:
-                self.lib.ko_bm_close(self._p(self.sum), self._p(prev), self._p(mean), self._p(m2), self.sum.size, nb, int(batchlen))
+                view = np.ascontiguousarray(self.sum)
+                self.lib.ko_bm_close(self._p(view), self._p(prev), self._p(mean), self._p(m2), view.size, nb, int(batchlen))
                 nb += 1
         mcvar = batchlen * (m2 / (nb - 1)) / (nb * batchlen) if nb > 1 else np.full_like(m2, np.nan)
         return mcvar, nb
