@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--total-chains", type=int, default=NCHAINS_PER_GPU, help="--scaling strong: chains of the whole job, sharded over the ranks")
     ap.add_argument("--streams", type=int, default=0,
                     help="internal streams for independent chain partitions (0 = library default, 1 = every launch on the caller's stream)")
+    ap.add_argument("--clock-warmup", type=int, default=3200,
+                    help="transitions of an identical scratch job run straight before the timed repetitions so that the device clocks "
+                         "are at their steady state (0 = off); the measured job gets exactly --warmup steps")
     ap.add_argument("--no-save", action="store_true", help="drop the save rule (no running sums): the transition kernel alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -154,6 +157,17 @@ def main():
     if dist is not None:   # warm the communicator outside the timed region
         t = torch.zeros(4, device=cdev); dist.all_reduce(t)
     K.gather_engine_summaries(eng)
+    # Device warm-up.  An MI355X that has been idle for a few milliseconds (job creation is enough) runs the first ~20 ms of
+    # work at reduced clocks: the same 20-transition launches take 21.5 us per transition on a cold device and 17.5 us when
+    # it has just been busy (scripts/probe_short_region.py, profiles/r2_short_region_probe.txt).  A timed region of
+    # `--steps 20` lasts 0.4 ms and would measure the clock ramp, not the kernel, so the device is kept busy for ~50 ms on an
+    # identical SCRATCH job straight before the timed repetitions; the measured job itself gets exactly `--warmup` steps.
+    if args.clock_warmup > 0:
+        scratch = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=10 ** 7, burnin=0,
+                           driftstep=0.9, seed=1, chain_offset=offset, device=local_rank, monitor=monitor, steps_per_launch=spl,
+                           stream=stream, nstreams=args.streams)
+        scratch.init_state_normal()
+        scratch.run(args.clock_warmup)          # (closed after the timed repetitions: freeing memory would idle the device again)
     times, kernel_ms_per_step, summ = [], [], None
     for _ in range(args.reps):
         barrier()
@@ -171,6 +185,8 @@ def main():
         kms, nl = eng.last_run_ms()
         kernel_ms_per_step.append(kms / args.steps)
     elapsed = statistics.median(times)
+    if args.clock_warmup > 0:
+        scratch.close()
     # the job's one exchange, after its last transition: chain summaries pooled on the device (+ RCCL all-reduce for N > 1)
     barrier()
     t0 = time.perf_counter()
@@ -203,6 +219,7 @@ def main():
                        "timed_region": f"median of {args.reps} repetitions of {args.steps} transitions",
                        "repetition_ms_per_step": [t_ * 1e3 / args.steps for t_ in times],
                        "acceptance_rate": acc_rate, "rccl_ranks_seen": ranks_seen, "summary_gather_ms": gather_ms,
+                       "device_clock_warmup": f"{args.clock_warmup} transitions of an identical scratch job before the timed repetitions" if args.clock_warmup > 0 else "off",
                        "timed_region_kernel_ms_per_step": statistics.median(kernel_ms_per_step)},
         }
     eng.close()
