@@ -117,9 +117,12 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     // diagonal Gaussian and nothing tunes: the pair-transposed layout
     // (klara_diagt.h), Q = 8 lanes per chain, NP element pairs per lane
     if (diagt_eligible(d)) {
-        const int Q = D <= 128 ? 8 : (D <= 256 ? 16 : 32);                        // lanes per chain
-        const int np = (D + 2 * Q - 1) / (2 * Q);                                 // NP = ceil(D/2 / Q) exactly (see klara_diagt.h): 2..8
-        if (np >= 2 && np <= KLARA_DIAGT_NP_MAX) { *kind = 3; *G = Q; *E = 2 * np; return KLARA_OK; }
+        int Q = D <= 128 ? 8 : (D <= 256 ? 16 : 32);                              // lanes per chain
+        // untuned MH / MALA up to D = 104: 4 lanes per chain, 16 chains per wavefront, NP = ceil(D/8) in 3..13 (klara_launch.h)
+        const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
+        if (plain && (d.sampler == KLARA_SAMPLER_MH || d.sampler == KLARA_SAMPLER_MALA) && D <= 104 && !getenv("KLARA_DIAGT_NO_Q4")) Q = 4;
+        const int np = (D + 2 * Q - 1) / (2 * Q);                                 // NP = ceil(D/2 / Q) exactly (see klara_diagt.h)
+        if (np >= 2 && np <= (Q == 4 ? 13 : KLARA_DIAGT_NP_MAX)) { *kind = 3; *G = Q; *E = 2 * np; return KLARA_OK; }
     }
     // diagonal Gaussian: E elements per lane, G lanes; optional override for layout experiments
     // D <= 128: E = 2 or 4, whichever wastes fewer lanes; on a tie E = 4 (twice the chains per wavefront
@@ -515,7 +518,8 @@ static klara_status init_common(klara_handle* h)
     hipError_t e;
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, needgrad, grid_for(h), st);
     else if (h->kind == 3)
-        e = h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
+        e = h->G == 4 ? klara_launch_diagt_init_q4(p, h->E / 2, needgrad, grid_for(h), st)
+          : h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
           : h->G == 16 ? klara_launch_diagt_init_q16(p, h->E / 2, needgrad, grid_for(h), st)
                        : klara_launch_diagt_init_q32(p, h->E / 2, needgrad, grid_for(h), st);
     else if (h->kind == 4) e = klara_launch_hiert_init(p, h->E / 2, d.hier_ntimes, needgrad, grid_for(h), st);
@@ -602,7 +606,10 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
             case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala##SUFFIX(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break; \
             default: e = klara_launch_diagt_hmc##SUFFIX(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;                 \
             }
-            if (h->G == 8) { KLARA_DIAGT_LAUNCH() } else if (h->G == 16) { KLARA_DIAGT_LAUNCH(_q16) } else { KLARA_DIAGT_LAUNCH(_q32) }
+            if (h->G == 4) {
+                e = d.sampler == KLARA_SAMPLER_MH ? klara_launch_diagt_mh_q4(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st)
+                                                  : klara_launch_diagt_mala_q4(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st);
+            } else if (h->G == 8) { KLARA_DIAGT_LAUNCH() } else if (h->G == 16) { KLARA_DIAGT_LAUNCH(_q16) } else { KLARA_DIAGT_LAUNCH(_q32) }
 #undef KLARA_DIAGT_LAUNCH
             if (e != hipSuccess) return e;
         }

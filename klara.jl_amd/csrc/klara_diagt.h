@@ -146,6 +146,34 @@ __device__ __forceinline__ void diagt_fold(const PairCtx<NP, Q>& c, __amdgpu_buf
     held = fold ? 0 : held;
 }
 
+// The same fold without resident sums: sum[i] += held * x[i], sumsq[i] += held * (x[i] * x[i]) as no-return FP64 atomic adds
+// (global_atomic_add_f64: one IEEE addition performed at the L2, the same rounding as the host's) — no load to wait for and no
+// 4*NP registers for the sums.  Used where chains move rarely (Vanilla MH / MALA on the 4-lanes-per-chain layout); a chain's sums
+// are only ever touched by its own lanes, in program order.
+template <int NP, int Q>
+__device__ __forceinline__ void diagt_fold_atomic(const PairCtx<NP, Q>& c, gdouble* sum, gdouble* sumsq, long long first_elem, int D,
+                                                  bool fold, long long& held, const double (&x)[2 * NP])
+{
+    if (fold) {
+        const double hf = (double)held;
+        gdouble* const s0 = sum + first_elem + (c.off0 >> 3);
+        gdouble* const q0 = sumsq + first_elem + (c.off0 >> 3);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const bool ok0 = p < NP - 1 || c.last_ok, ok1 = p < NP - 1 || c.last_full;
+            if (ok0) {
+                (void)__builtin_amdgcn_global_atomic_fadd_f64(s0 + p * Q * 2, hf * x[2 * p]);
+                (void)__builtin_amdgcn_global_atomic_fadd_f64(q0 + p * Q * 2, hf * (x[2 * p] * x[2 * p]));
+            }
+            if (ok1) {
+                (void)__builtin_amdgcn_global_atomic_fadd_f64(s0 + p * Q * 2 + 1, hf * x[2 * p + 1]);
+                (void)__builtin_amdgcn_global_atomic_fadd_f64(q0 + p * Q * 2 + 1, hf * (x[2 * p + 1] * x[2 * p + 1]));
+            }
+        }
+        held = 0;
+    }
+}
+
 // per-element parameter vector (weights, means, proposal scales): element 2P+h of the lane's pair p
 template <int NP, int Q>
 __device__ __forceinline__ void load_pair_param(const PairCtx<NP, Q>& c, const gdouble* base, int D, double dflt, double (&v)[2 * NP])
@@ -190,7 +218,8 @@ __device__ __forceinline__ void diag_elem(double x, double w, double m2w, double
 // DA (HMC only): DualAveragingMCTuner — per-chain step and trajectory length (iterate/HMC.jl:142-144, 225-249); the
 // wavefront runs to the longest trajectory of its chains, a finished chain's lanes keep their state.
 template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false, bool DA = false>
-__global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? KLARA_DT_W1 : KLARA_DT_WF) : 1))
+__global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? KLARA_DT_W1 : KLARA_DT_WF)
+                                           : (Q == 4 && NP <= 13 && !TUNE ? (SAMPLER == KLARA_SAMPLER_MALA ? 3 : (SAMPLER == KLARA_SAMPLER_MH ? 2 : 1)) : 1)))
 void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 {
     static_assert(!(ONESTEP && (MON || TUNE)), "monitored / tuned jobs run the committing kernel");
@@ -200,6 +229,9 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
     constexpr bool NEEDG = SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_HMC;
     constexpr bool SLICE = SAMPLER == KLARA_SAMPLER_SLICE;
     static_assert(!(SLICE && ONESTEP), "the slice sampler moves every chain: it runs the committing kernel");
+    // running sums folded by atomic adds instead of being held in registers (diagt_fold_atomic): untuned MH / MALA on the
+    // 4-lanes-per-chain form of the layout
+    constexpr bool ATOMSUM = MON && !TUNE && Q == 4 && (SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_MALA);
     const KParams& p = *pp;
     // weights and means of a non-unit diagonal: one LDS copy per workgroup (element i at [i], padding = (1, 0)) instead
     // of 4*NP registers per lane; a pair's (w, mu) values are 16-byte LDS reads where they are used
@@ -270,13 +302,13 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
         // a chain that does not move (98-99.6 % of the transitions of the drift-0.9 job) costs no running-sum traffic at all:
         // 210 MB per launch of 65,536 x 100 otherwise, 40-90 us of every launch.
         const bool do_sum = MON && p.sum != nullptr;
-        double sm[E], sq[E];
+        double sm[ATOMSUM ? 2 : E], sq[ATOMSUM ? 2 : E];
         bool sums_loaded = false;                          // (per chain: uniform over the chain's Q lanes)
         long long held = 0;
         __amdgpu_buffer_rsrc_t wsum = wx, wsq = wx;
         if (do_sum) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) { sm[e] = 0.0; sq[e] = 0.0; }
+            for (int e = 0; e < (ATOMSUM ? 2 : E); ++e) { sm[e] = 0.0; sq[e] = 0.0; }
             wsum = group_window(p.sum, first_chain, here, D); wsq = group_window(p.sumsq, first_chain, here, D);
             held = p.held[chain_ok ? chain : 0];
         }
@@ -302,18 +334,22 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             bool acc;
             double ltp, a_da = 0.0;
 
-            // All proposal normals of the transition are drawn first: they do not depend on the chain state, so the
-            // Philox/Box-Muller work (~4000 issue cycles) runs while the state loads issued above are still in flight.
-            double z[E];
-            if (SAMPLER != KLARA_SAMPLER_HMC && !SLICE) {
+            // One transition per launch: all proposal normals are drawn first — they do not depend on the chain state, so the
+            // Philox/Box-Muller work (~4000 issue cycles) runs while the state loads issued above are still in flight.  Fused
+            // launches draw a pair where it is consumed instead (no array of 2*NP normals: 4*NP registers less).
+            constexpr bool ZFIRST = ONESTEP && SAMPLER != KLARA_SAMPLER_HMC && !SLICE;
+            double z[ZFIRST ? E : 2];
+            if (ZFIRST) {
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
                     pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z[2 * pi], z[2 * pi + 1], u_last, lg_last);
                     KLARA_DT_PAIR_FENCE(pi);
                 }
             }
-            if (SLICE && do_sum && __any(held > 0))                                // the slice sampler always moves: fold first
-                diagt_fold<NP, Q>(cx, wsum, wsq, held > 0, sums_loaded, held, x, sm, sq);
+            if constexpr (SLICE) {
+                if (do_sum && __any(held > 0))                                     // the slice sampler always moves: fold first
+                    diagt_fold<NP, Q>(cx, wsum, wsq, held > 0, sums_loaded, held, x, sm, sq);
+            }
             if (SLICE) {                                                           // iterate/SliceSampler.jl:60-109
                 // Coordinates are visited in turn.  Coordinate i lives on lane (i/2) % Q of its chain as register
                 // 2*((i/2)/Q) + (i&1); everything scalar (the slice level, the interval, the probes' log-targets) is computed
@@ -396,12 +432,18 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 #pragma unroll
                 for (int e = 0; e < E; ++e) xp[e] = x[e];          // (the commit below is then a no-op)
             } else if (SAMPLER == KLARA_SAMPLER_MH) {                              // iterate/MH.jl:72-124
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    xp[e] = x[e] + sig[e] * z[e];                                              // MH.jl:79
+                const auto mh_elem = [&](int e, double ze) {
+                    xp[e] = x[e] + sig[e] * ze;                                                // MH.jl:79
                     double term, gd;
                     diag_elem<UNITW>(xp[e], wv(e), m2wv(e), mv(e), term, gd);       // :81
                     red[0] = red[0] + term;
+                };
+#pragma unroll
+                for (int pi = 0; pi < NP; ++pi) {
+                    double z0 = ZFIRST ? z[(2 * pi) % (ZFIRST ? E : 2)] : 0.0, z1 = ZFIRST ? z[(2 * pi + 1) % (ZFIRST ? E : 2)] : 0.0;
+                    if (!ZFIRST) pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z0, z1, u_last, lg_last);
+                    mh_elem(2 * pi, z0); mh_elem(2 * pi + 1, z1);
+                    if (!ZFIRST) KLARA_DT_PAIR_FENCE(pi);
                 }
                 red1[0] = red[0];
                 group_allreduce<1>(red1, Q, cx.lane);
@@ -414,12 +456,11 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             } else if (SAMPLER == KLARA_SAMPLER_MALA) {                            // iterate/MALA.jl:78-128
                 const double h_ = tn.step, halfh = 0.5 * h_, sq = KCNT ? __builtin_sqrt(h_) : p.sqrt_step0;
                 const double half_inv_h = 0.5 * (KCNT ? 1.0 / h_ : p.inv_step0);
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
+                const auto mala_elem = [&](int e, double ze) {
                     double term, ge, gpe;
                     diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), term, ge);        // (the current gradient, re-formed)
                     const double m_ = x[e] + halfh * ge;                                       // :83
-                    xp[e] = m_ + sq * z[e];                                                    // :84
+                    xp[e] = m_ + sq * ze;                                                      // :84
                     diag_elem<UNITW>(xp[e], wv(e), m2wv(e), mv(e), term, gpe);      // :86
                     red[0] = red[0] + term;
                     const double q1 = m_ - xp[e];
@@ -427,6 +468,13 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                     const double mup = xp[e] + halfh * gpe;                                    // :91
                     const double q2 = mup - x[e];
                     red[2] = red[2] + (q2 * q2) * half_inv_h;                                  // :92
+                };
+#pragma unroll
+                for (int pi = 0; pi < NP; ++pi) {
+                    double z0 = ZFIRST ? z[(2 * pi) % (ZFIRST ? E : 2)] : 0.0, z1 = ZFIRST ? z[(2 * pi + 1) % (ZFIRST ? E : 2)] : 0.0;
+                    if (!ZFIRST) pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z0, z1, u_last, lg_last);
+                    mala_elem(2 * pi, z0); mala_elem(2 * pi + 1, z1);
+                    if (!ZFIRST) KLARA_DT_PAIR_FENCE(pi);
                 }
                 group_allreduce<3>(red, Q, cx.lane);
                 ltp = gconst - red[0];
@@ -500,9 +548,10 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                 }
             } else {
                 nacc += acc ? 1ull : 0ull;
-                if (!SLICE && do_sum && __any(acc && held > 0)) {          // a chain of this wavefront leaves its state
-                    const bool fold = acc && held > 0;
-                    diagt_fold<NP, Q>(cx, wsum, wsq, fold, sums_loaded, held, x, sm, sq);
+                if (!SLICE && do_sum && __any(chain_ok && acc && held > 0)) {          // a chain of this wavefront leaves its state
+                    const bool fold = chain_ok && acc && held > 0;
+                    if constexpr (ATOMSUM) diagt_fold_atomic<NP, Q>(cx, p.sum, p.sumsq, first_chain * D, D, fold, held, x);
+                    else diagt_fold<NP, Q>(cx, wsum, wsq, fold, sums_loaded, held, x, sm, sq);
                 }
                 if (acc) {
 #pragma unroll
@@ -528,9 +577,11 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             }
         }
         if (do_sum) {
-            if (__any(sums_loaded)) {                      // only the chains that left a state during the launch write their sums back
-                store_pairs_if<NP, Q>(cx, wsum, sums_loaded, sm);
-                store_pairs_if<NP, Q>(cx, wsq, sums_loaded, sq);
+            if constexpr (!ATOMSUM) {
+                if (__any(sums_loaded)) {                  // only the chains that left a state during the launch write their sums back
+                    store_pairs_if<NP, Q>(cx, wsum, sums_loaded, sm);
+                    store_pairs_if<NP, Q>(cx, wsq, sums_loaded, sq);
+                }
             }
             if (chain_ok && cx.q == 0) p.held[chain] = held;
         }

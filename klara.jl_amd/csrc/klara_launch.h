@@ -26,6 +26,8 @@ hipError_t klara_launch_mfma4_probe(const double* A, const double* B, const doub
 // (257 <= D <= 512), the latter two with NP in 5..8; the launchers of the wider variants carry a _q16 / _q32 suffix.
 #if KLARA_DIAGT_Q == 8
 #define KLARA_DIAGT_FN(name) name
+#elif KLARA_DIAGT_Q == 4
+#define KLARA_DIAGT_FN(name) name##_q4
 #elif KLARA_DIAGT_Q == 16
 #define KLARA_DIAGT_FN(name) name##_q16
 #elif KLARA_DIAGT_Q == 32
@@ -42,10 +44,17 @@ hipError_t klara_launch_mfma4_probe(const double* A, const double* B, const doub
 KLARA_DIAGT_DECLARE()
 KLARA_DIAGT_DECLARE(_q16)
 KLARA_DIAGT_DECLARE(_q32)
+// Q = 4 lanes per chain, 16 chains per wavefront, NP = ceil(D/8) in 3..13 (17 <= D <= 104): jobs in which nothing counts or tunes
+// (VanillaMCTuner, not verbose) with the MH or the MALA sampler — D = 100 occupies 50 of 52 pair slots instead of 50 of 56, the
+// per-wavefront work (reductions, accept test, addressing) is shared by 16 chains, and the running sums are folded with atomic
+// adds instead of living in registers (klara_diagt.h diagt_fold_atomic).  Only klara_diagt_{mh,mala,init}.hip are built for it.
+hipError_t klara_launch_diagt_mh_q4(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_mala_q4(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_init_q4(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
 // pairs per lane the kernels are instantiated for; a job takes NP = ceil(ceil(D/2) / Q) exactly (only the LAST pair of a lane
 // can be padding)
-#if KLARA_DIAGT_Q == 4     // experiment: 4 lanes per chain, 16 chains per wavefront (D = 100 -> 13 pairs per lane, no padding)
-#define KLARA_DIAGT_NP_MENU_DO(X) X(2) X(4) X(8) X(13) X(16)
+#if KLARA_DIAGT_Q == 4
+#define KLARA_DIAGT_NP_MENU_DO(X) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 #elif KLARA_DIAGT_Q == 8
 #define KLARA_DIAGT_NP_MENU_DO(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #else                      // Q = 16 / 32 start where the narrower variant ends: NP = 5..8
@@ -53,6 +62,18 @@ KLARA_DIAGT_DECLARE(_q32)
 #endif
 #define KLARA_DIAGT_NP_MAX 8
 
+#if KLARA_DIAGT_Q == 4     // (no tuned / dual-averaging instantiations: those jobs take the 8-lane form)
+#define KLARA_DIAGT_CASE(S, NP_)                                                                                   \
+    case NP_:                                                                                                      \
+        if (tune || da) return hipErrorInvalidValue;                                                               \
+        else if (mon && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true>), grid, blk, 0, st, p, kl); \
+        else if (mon) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, true>), grid, blk, 0, st, p, kl);        \
+        else if (onestep && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, true, true, false>), grid, blk, 0, st, p, kl);  \
+        else if (onestep) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, true, false, false>), grid, blk, 0, st, p, kl);    \
+        else if (unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, false>), grid, blk, 0, st, p, kl);      \
+        else hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, false>), grid, blk, 0, st, p, kl);                \
+        break;
+#else
 #define KLARA_DIAGT_CASE(S, NP_)                                                                                   \
     case NP_:                                                                                                      \
         if (da && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true, true, (S == KLARA_SAMPLER_HMC)>), grid, blk, 0, st, p, kl); \
@@ -66,6 +87,7 @@ KLARA_DIAGT_DECLARE(_q32)
         else if (unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, false>), grid, blk, 0, st, p, kl);      \
         else hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, false>), grid, blk, 0, st, p, kl);                \
         break;
+#endif
 #define KLARA_DIAGT_CASE_KLARA_SAMPLER_MH(NP_) KLARA_DIAGT_CASE(KLARA_SAMPLER_MH, NP_)
 #define KLARA_DIAGT_CASE_KLARA_SAMPLER_MALA(NP_) KLARA_DIAGT_CASE(KLARA_SAMPLER_MALA, NP_)
 #define KLARA_DIAGT_CASE_KLARA_SAMPLER_HMC(NP_) KLARA_DIAGT_CASE(KLARA_SAMPLER_HMC, NP_)

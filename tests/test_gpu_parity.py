@@ -950,8 +950,9 @@ def test_full_size_pair_transposed_on_sampled_chains(name, kw, nsteps, spl):
     mask = eng.accept_mask()
     na, _ = eng.accept_counts()
     assert np.array_equal(na, mask.sum(axis=0))
-    groups = (n + 7) // 8
-    boundary = ((groups + 1) // 2) * 8                    # first chain of the second partition
+    cpw = 64 // eng.layout()[1]                           # chains per wavefront: 16 on the 4-lane form (MALA), 8 on the 8-lane form
+    groups = (n + cpw - 1) // cpw
+    boundary = ((groups + 1) // 2) * cpw                  # first chain of the second partition
     case = dict(kw, target=target, nchains=16, nsteps=nsteps, name=name, x0=None, seed=20260927)
     for off in (0, boundary - 8, n - 16):
         job = O.OracleJob(**cases.oracle_kwargs(case, layout=eng.layout(), chain_offset=off))
