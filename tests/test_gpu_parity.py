@@ -170,7 +170,7 @@ def test_parity_pair_transposed_layout(name, mode):
     n = case["nsteps"]
     eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_ACCEPT, steps_per_launch={"one_launch": 0, "launch_per_transition": 1, "mixed": 7}[mode]))
     layout = eng.layout()
-    assert layout[0] == 3 and layout[1] == 8, layout
+    assert layout[0] == 3 and layout[1] == (4 if case["sampler"] in (L.SAMPLER_MH, L.SAMPLER_MALA) and case["target"].ndims <= 104 else 8), layout
     assert tuple(layout) == tuple(O.default_layout(case["target"].kind, case["target"].ndims, sampler=case["sampler"]))
     job = O.OracleJob(**cases.oracle_kwargs(case, layout=layout))
     eng.init_state_normal(); assert job.init_state_normal() == 0
@@ -213,7 +213,7 @@ def test_group_layout_dimension_sweep():
 @pytest.mark.parametrize("sampler,kw,step", [(L.SAMPLER_MALA, dict(driftstep=0.3), 1), (L.SAMPLER_HMC, dict(leapstep=0.2, nleaps=3), 3),
                                              (L.SAMPLER_MH, None, 3), (L.SAMPLER_SLICE, "slice", 7)])
 def test_pair_transposed_dimension_sweep(sampler, kw, step):
-    """Dimensions 17..128 (8 lanes per chain), odd ones included, on the pair-transposed layout (every one for MALA, every
+    """Dimensions 17..128 (4 lanes per chain for MH / MALA up to 104, 8 otherwise), odd ones included, on the pair-transposed layout (every one for MALA, every
     third for HMC and MH, every seventh for the slice sampler), then 129..512 (16 and 32 lanes per chain) in coarser steps:
     with and without padding pairs / a half pair, i.e. every way of obtaining the accept draw and of storing the last pair."""
     wide = {1: 3, 3: 13, 7: 61}[step]
@@ -222,7 +222,10 @@ def test_pair_transposed_dimension_sweep(sampler, kw, step):
         case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=11,
                     nsteps=6, burnin=0, x0=None, seed=d, name=f"sweep3_d{d}", **skw)
         eng, job = _run_pair(case, spl=2)
-        assert eng.layout()[:2] == (3, 8 if d <= 128 else 16 if d <= 256 else 32)
+        lanes = 8 if d <= 128 else 16 if d <= 256 else 32
+        if sampler in (L.SAMPLER_MH, L.SAMPLER_MALA) and d <= 104:
+            lanes = 4                              # untuned MH / MALA: 4 lanes per chain, 16 chains per wavefront
+        assert eng.layout()[:2] == (3, lanes)
         x, lt, g = eng.state()
         assert np.array_equal(x, job.X) and np.array_equal(lt, job.LT), d
         assert sampler == L.SAMPLER_MH or np.array_equal(g, job.G), d
@@ -263,7 +266,9 @@ def test_pair_transposed_every_pairs_per_lane(d, sampler):
     case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=13, nsteps=12,
                 burnin=2, x0=None, seed=5, name=f"np_d{d}", **kw)
     eng, job = _run_pair(case, splits=[5, 7], spl=3)
-    assert eng.layout()[0] == 3 and eng.layout()[2] == 2 * ((d + 15) // 16)      # NP = ceil(ceil(d/2)/8)
+    lanes = eng.layout()[1]                                                        # 4 (untuned MALA up to D = 104) or 8
+    assert eng.layout()[0] == 3 and lanes == (4 if sampler == L.SAMPLER_MALA and d <= 104 else 8)
+    assert eng.layout()[2] == 2 * (((d + 1) // 2 + lanes - 1) // lanes)           # NP = ceil(ceil(d/2) / lanes)
     _assert_same(eng, job, case)
     eng.close()
 
@@ -332,6 +337,20 @@ def test_c_abi_summary_allreduce_over_rccl_single_rank(klib):
     assert np.array_equal(s, ps) and np.array_equal(q, pq)
     assert (na.value, nt.value, ns.value, nc.value) == (pna, pnt, pns * case["nchains"], case["nchains"])
     L.check(klib.klara_comm_destroy(comm), "comm_destroy")
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["dt_mala_d100", "dt_mala_d18", "dt_mala_mvnormal_d30", "dt_mh_d100", "dt_mh_mvnormal_d20"])
+@pytest.mark.parametrize("spl", [0, 1])
+def test_pair_transposed_8_lane_form_of_untuned_mh_mala(name, spl, monkeypatch):
+    """Untuned MH / MALA jobs up to D = 104 take the 4-lane form of the layout; KLARA_DIAGT_NO_Q4 keeps them on the 8-lane kernels
+    (the ones their tuned siblings run), with resident running sums instead of atomic folds: same bits as the oracle told that
+    summation order."""
+    monkeypatch.setenv("KLARA_DIAGT_NO_Q4", "1")
+    case = cases.make_case(name)
+    eng, job = _run_pair(case, spl=spl)
+    assert eng.layout()[:2] == (3, 8)
+    _assert_same(eng, job, case)
     eng.close()
 
 
