@@ -278,10 +278,11 @@ def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
     # the byte side.  S = 2*D*8 + 8 (x, gradient, log-target); SURVEY 8(d): B_K = (2 S + 1) / K per transition and chain.
     s_state = 2 * NDIMS * 8 + 8
     contract = n * (2 * s_state + 1)                               # per launch of K fused transitions: state in, state out, accepts
-    # what this kernel has to move per launch: x and lt in (the gradient is re-formed from x); x, gradient, lt and the accept
-    # counter out for the chains that moved during the launch; running sums in and out when the save rule is on
+    # what this kernel has to move per launch: x, lt (and the held count) in — the gradient is re-formed from x; for the chains
+    # that moved during the launch: x, gradient, lt and the accept counter out and, with the save rule on, their running sums read
+    # and written once (sojourn form: a chain that did not move touches neither array)
     moved = min(1.0, 1.0 - (1.0 - nacc / max(ntr, 1)) ** spl)
-    minimal = n * ((NDIMS * 8 + 8) + moved * (s_state + 16) + (4 * NDIMS * 8 if monitor else 0))
+    minimal = n * ((NDIMS * 8 + 8 + (16 if monitor else 0)) + moved * (s_state + 16 + (4 * NDIMS * 8 if monitor else 0)))
     hbm = {"contract_2S_plus_1_bytes_per_launch": contract, "minimal_bytes_per_launch": minimal,
            "contract_frac_of_8TBs": contract / launch_s / 1e9 / HBM_PEAK_GBS, "minimal_frac_of_8TBs": minimal / launch_s / 1e9 / HBM_PEAK_GBS,
            "fraction_of_chains_that_moved": moved, "traffic_bytes_per_launch": None}

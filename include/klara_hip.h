@@ -206,8 +206,14 @@ klara_status klara_run_async(klara_handle* h, int64_t nsteps);
 klara_status klara_synchronize(klara_handle* h);
 
 /* reset(job[, x]) of BasicMCJob.jl:187-201: rewind sampler/tuner state and counters; x_host may be
- * NULL (keep the current values, re-evaluate the target). */
+ * NULL (keep the current values, re-evaluate the target).  In the reference the random generator keeps advancing across a
+ * reset, so run -> reset -> run gives an independent replicate; here the transition index restarts at 0 and the job moves to a
+ * fresh Philox key instead: after the k-th klara_reset the key is seed + k * KLARA_EPOCH_KEY_STRIDE (mod 2^64).
+ * klara_set_state does not change the key: it replays the job from the given values. */
+#define KLARA_EPOCH_KEY_STRIDE 0x9E3779B97F4A7C15ull
 klara_status klara_reset(klara_handle* h, const double* x_host);
+/* the Philox key the job currently draws from and the number of klara_reset calls so far (either pointer may be NULL) */
+klara_status klara_stream_key(klara_handle* h, uint64_t* key, uint64_t* epoch);
 
 /* Read-back.  Any pointer may be NULL. */
 klara_status klara_get_state(klara_handle* h, double* x, double* logtarget, double* gradlogtarget);

@@ -232,8 +232,12 @@ class MuvChains:
 def mean(chains: MuvChains, chain: Optional[int] = None) -> np.ndarray:
     """mean(s::VariableNState{Multivariate}) — stats/mean.jl:7-11: per-dimension mean over saved steps.
     chain=None returns (nchains x D) from the on-device running sums; chain=c reads that chain's history."""
-    if chain is not None and chains._sums is None:
-        return chains.value(chain).mean(axis=1)
+    if chains._sums is None:
+        if not (chains._job.engine.monitor & L.MON_HISTORY):
+            raise ValueError("mean needs the running sums (summaries=True) or the stored values (monitor value)")
+        if chain is not None:
+            return chains.value(chain).mean(axis=1)
+        return np.stack([chains.value(c).mean(axis=1) for c in range(chains.nchains)])
     s, _, n = chains._sums
     m = s / n
     return m if chain is None else m[chain]
@@ -241,6 +245,10 @@ def mean(chains: MuvChains, chain: Optional[int] = None) -> np.ndarray:
 
 def mcvar_iid(chains: MuvChains) -> np.ndarray:
     """mcvar(s, Val{:iid}) = var(v)/length(v) — stats/variance/mcvar.jl:5 (per chain, per dimension)."""
+    if chains._sums is None:
+        if not (chains._job.engine.monitor & L.MON_HISTORY):
+            raise ValueError("mcvar_iid needs the running sums (summaries=True) or the stored values (monitor value)")
+        return chain_mcvar(chains, "iid")
     s, q, n = chains._sums
     var = (q - s * s / n) / (n - 1)
     return var / n
@@ -252,19 +260,18 @@ def chain_mcvar(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, max
     job = chains._job
     if vtype == "bm" and job.bm_batchlen == batchlen and not (job.engine.monitor & L.MON_HISTORY):
         return job.engine.chain_bm()[0]            # streaming batch means: no history was stored
-    iid, bm, imse = job.engine.chain_mcvar(batchlen, maxlag)
-    return {"iid": iid, "bm": bm, "imse": imse}[vtype]
+    return job.engine.chain_mcvar(batchlen, maxlag, want=(vtype,))[{"iid": 0, "bm": 1, "imse": 2}[vtype]]
 
 
 def chain_ess(chains: MuvChains, vtype: str = "imse", batchlen: int = 100) -> np.ndarray:
     """ess(s, vtype) = n * mcvar_iid / mcvar_vtype (stats/convergence/ess.jl:3) for every chain and dimension."""
-    iid, bm, imse = chains._job.engine.chain_mcvar(batchlen, 0)
+    iid, bm, imse = chains._job.engine.chain_mcvar(batchlen, 0, want=("iid", vtype))
     return chains.n * iid / {"bm": bm, "imse": imse}[vtype]
 
 
 def chain_iact(chains: MuvChains, vtype: str = "imse", batchlen: int = 100) -> np.ndarray:
     """iact(s, vtype) = mcvar_vtype / mcvar_iid (stats/convergence/iact.jl:3) for every chain and dimension."""
-    iid, bm, imse = chains._job.engine.chain_mcvar(batchlen, 0)
+    iid, bm, imse = chains._job.engine.chain_mcvar(batchlen, 0, want=("iid", vtype))
     return {"bm": bm, "imse": imse}[vtype] / iid
 
 
@@ -276,21 +283,39 @@ def acceptance(chains: MuvChains, diagnostics: bool = True) -> np.ndarray:
     return chains._acc.mean(axis=0)
 
 
+# ------------------------------------------------------------------ random streams of jobs
+# Determinism contract.  A job's noise is a pure function of (seed, global chain id, transition index) — Philox4x32-10, key =
+# seed (csrc/detmath.h) — so an explicit `seed=` reproduces a job bit for bit on any number of GPUs.  Klara's own jobs draw from
+# Julia's global, unseeded generator: two jobs built the same way are independent (`run([job1, job2])`, jobs.jl:212).  To keep
+# that, a job built WITHOUT `seed=` takes a fresh key: a per-process random base (os.urandom) plus a counter, so chain c of one
+# job never shares its stream with chain c of another; `job.seed` reports the key that was used.
+_SEED_BASE = int.from_bytes(os.urandom(8), "little")
+_seed_counter = 0
+
+
+def _next_job_seed() -> int:
+    global _seed_counter
+    _seed_counter += 1
+    return (_SEED_BASE + 0x9E3779B97F4A7C15 * _seed_counter) & 0xFFFFFFFFFFFFFFFF
+
+
 # ------------------------------------------------------------------ job (src/jobs/BasicMCJob.jl)
 class BasicMCJob:
     """BasicMCJob(model, sampler, range, v0; tuner=VanillaMCTuner(), outopts=...) — BasicMCJob.jl:107-185.
 
     outopts keys follow jobs.jl:9-43: destination in {"nstate", "none"}, monitor (["value"]),
     diagnostics ([] or ["accept"]).  Extra keyword arguments pick the shard: `chain_offset` (global id of
-    the first chain), `device`, `seed`, `steps_per_launch`; `bm_batchlen` > 0 keeps streaming batch means so that
+    the first chain), `device`, `seed` (default: a fresh key per job, see "random streams of jobs" above), `steps_per_launch`; `bm_batchlen` > 0 keeps streaming batch means so that
     `chain_mcvar(chain, "bm", bm_batchlen)` needs no stored history (destination "none").
     """
 
     def __init__(self, model: GenericModel, sampler: MCSampler, mcrange: BasicMCRange, v0: Dict[str, Sequence],
-                 tuner: Optional[MCTuner] = None, outopts: Optional[dict] = None, *, seed: int = 20260927,
+                 tuner: Optional[MCTuner] = None, outopts: Optional[dict] = None, *, seed: Optional[int] = None,
                  chain_offset: int = 0, device: int = 0, steps_per_launch: int = 0, summaries: bool = True,
                  bm_batchlen: int = 0):
         self.model, self.sampler, self.range = model, sampler, mcrange
+        self.seed = _next_job_seed() if seed is None else int(seed)
+        seed = self.seed
         self.tuner = tuner if tuner is not None else VanillaMCTuner()
         self.outopts = dict(outopts) if outopts is not None else {}
         self.outopts.setdefault("destination", "nstate")              # jobs.jl:10

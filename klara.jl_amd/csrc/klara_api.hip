@@ -51,6 +51,7 @@ struct klara_handle {
     double lpconst = 0.0;
     // run state
     bool have_state = false;
+    unsigned long long epoch = 0;   // klara_reset calls so far: the Philox key of the job is seed + epoch * KLARA_EPOCH_KEY_STRIDE
     long long steps_done = 0;       // transitions since set_state/reset (= global transition index)
     long long nsaved = 0;           // postrange steps passed so far
     // host mirror of the pooled tuner counters (decides where launches must end)
@@ -187,7 +188,7 @@ static klara_status validate(const klara_desc* d)
     if (d->target == KLARA_TARGET_CUSTOM && (!d->custom_src || d->custom_ndata < 0 || (d->custom_ndata > 0 && !d->custom_data)))
         return KLARA_ERR_INVALID_ARG;
     if (d->bm_batchlen < 0 || (d->bm_batchlen > 0 && !(d->monitor & KLARA_MON_SUMMARIES))) return KLARA_ERR_INVALID_ARG;
-    if (d->steps_per_launch < 0 || d->tuner_score < 0 || d->tuner_score > 1) return KLARA_ERR_INVALID_ARG;
+    if (d->steps_per_launch < 0 || d->tuner_score < 0 || d->tuner_score > 1) return KLARA_ERR_INVALID_ARG;   // (int32: a launch length always fits KLaunch::nsteps)
     return KLARA_OK;
 }
 
@@ -365,6 +366,7 @@ extern "C" klara_status klara_destroy(klara_handle* h)
     if (!h) return KLARA_ERR_INVALID_ARG;
     hipSetDevice(h->d.device);
     hipStreamSynchronize(h->stream);
+    for (int j = 0; j < 3; ++j) if (h->side[j]) hipStreamSynchronize(h->side[j]);
     free_all(h);
     delete h;
     return KLARA_OK;
@@ -383,7 +385,7 @@ static KParams make_params(klara_handle* h)
     p.hist_lt = (decltype(p.hist_lt))h->hist_lt; p.hist_g = (decltype(p.hist_g))h->hist_g;
     p.nchains = d.nchains; p.chain_offset = d.chain_offset; p.D = d.ndims; p.G = h->G; p.rs = h->RS;
     p.pooled = d.tuner_mode == KLARA_TUNE_POOLED;
-    p.seed = d.seed;
+    p.seed = d.seed + h->epoch * KLARA_EPOCH_KEY_STRIDE;      // (mod 2^64)
     p.vecparam = (decltype(p.vecparam))h->vecparam; p.nleaps = d.nleaps; p.stepout = d.slice_stepout;
     p.tuner = d.tuner; p.cnt = cnt_predicate(d); p.targetrate = d.targetrate;
     p.tuner_score = d.tuner_score; p.score_k = d.score_k; p.period = d.period; p.is_mh = d.sampler == KLARA_SAMPLER_MH;
@@ -568,13 +570,31 @@ extern "C" klara_status klara_init_state_normal(klara_handle* h)
     return init_common(h);
 }
 
+// reset(job[, x]) rewinds the sampler / tuner state and the counters; the reference's random generator keeps advancing, so the
+// next run is an independent replicate (BasicMCJob.jl:187-201).  The counter-based stream restarts its transition index at 0, so
+// the job moves on to a fresh Philox key instead: seed + epoch * KLARA_EPOCH_KEY_STRIDE (klara_stream_key reports it).
+// klara_set_state alone keeps the key: it is the way to replay a job from chosen values.
 extern "C" klara_status klara_reset(klara_handle* h, const double* x_host)
 {
     if (!h) return KLARA_ERR_INVALID_ARG;
-    if (x_host) return klara_set_state(h, x_host);
-    if (!h->have_state) return KLARA_ERR_STATE;
+    if (!x_host && !h->have_state) return KLARA_ERR_STATE;
     HIPCHK(hipSetDevice(h->d.device));
+    h->epoch += 1;
+    {
+        const KParams hp = make_params(h);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->d_params, &hp, sizeof(KParams), hipMemcpyHostToDevice));
+    }
+    if (x_host) return klara_set_state(h, x_host);
     return init_common(h);
+}
+
+extern "C" klara_status klara_stream_key(klara_handle* h, uint64_t* key, uint64_t* epoch)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (key) *key = h->d.seed + h->epoch * KLARA_EPOCH_KEY_STRIDE;
+    if (epoch) *epoch = h->epoch;
+    return KLARA_OK;
 }
 
 static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
@@ -726,28 +746,34 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
     }
     long long remaining = nsteps, launches = 0;
     RunCursor cur = { h->steps_done, h->m_prop, h->m_tot, h->bm_count };
-    while (remaining > 0) {
+    hipError_t err = hipSuccess;
+    while (remaining > 0 && err == hipSuccess) {
         const PlannedLaunch pl = plan_launch(d, cur, remaining);
         KLaunch kl;
         kl.group0 = 0; kl.group_end = 0x7fffffffffffffffll;
         kl.t0 = (unsigned long long)cur.steps_done;
-        kl.nsteps = (int)pl.k;
+        kl.nsteps = (int)pl.k;                                             // (plan_launch keeps k <= steps_per_launch <= INT_MAX)
         kl.save_phase0 = pl.save_phase0;
         kl.save_col0 = pl.save_col0;
-        HIPCHK(launch_steps(h, kl));
-        if (pl.tune_after) {
+        err = launch_steps(h, kl);
+        if (err == hipSuccess && pl.tune_after) {
             hipLaunchKernelGGL(k_pooled_tune, dim3(1), dim3(64), 0, h->stream, p, (int)pl.k);
-            HIPCHK(hipGetLastError());
+            err = hipGetLastError();
         }
-        if (pl.bm_close_after) HIPCHK(launch_bm_close(h));                 // (reads h->bm_count: batches closed before this one)
+        if (err == hipSuccess && pl.bm_close_after) err = launch_bm_close(h);   // (reads h->bm_count: batches closed before this one)
+        if (err != hipSuccess) break;
         advance_cursor(d, cur, pl);
         h->steps_done = cur.steps_done; h->m_prop = cur.m_prop; h->m_tot = cur.m_tot; h->bm_count = cur.bm_count;
         remaining -= pl.k; ++launches;
     }
-    for (int j = 0; j + 1 < h->nparts; ++j) {              // join: the caller's stream continues when every partition is done
-        HIPCHK(hipEventRecord(h->join_ev[j], h->side[j]));
-        HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev[j], 0));
+    // join — also when a launch failed: the partition streams may still have work in flight on X / GR / LT, and every later
+    // call (get_state, reset, destroy) synchronises the caller's stream only
+    for (int j = 0; j + 1 < h->nparts; ++j) {
+        const hipError_t e1 = hipEventRecord(h->join_ev[j], h->side[j]);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(h->stream, h->join_ev[j], 0) : e1;
+        if (e2 != hipSuccess) { hipStreamSynchronize(h->side[j]); if (err == hipSuccess) err = e2; }
     }
+    HIPCHK(err);
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->last_launches = launches; h->timed = true;
     // saved-sample bookkeeping: count of i in postrange with i <= steps_done
@@ -899,16 +925,26 @@ __global__ __launch_bounds__(256) void k_pool_stage1(const double* __restrict__ 
 __global__ __launch_bounds__(256) void k_pool_stage2(const double* __restrict__ partial, const unsigned long long* __restrict__ partial_acc,
                                                      int D, int nb, bool with_sums, double* __restrict__ out)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (with_sums && j < 2 * D) {
+    // block j < 2 D: column j of the partials; block 2 D: the accept counters.  Thread t adds the partials b = t, t + 256, ...
+    // (ascending), then a fixed-shape tree over the 256 threads.
+    __shared__ double sd[256];
+    __shared__ unsigned long long su[256];
+    const int j = blockIdx.x, t = threadIdx.x;
+    if (j < 2 * D) {
+        if (!with_sums) return;
         double a = 0.0;
-        for (int b = 0; b < nb; ++b) a += partial[(long long)b * 2 * D + j];
-        out[j] = a;
-    }
-    if (j == 0) {
+        for (int b = t; b < nb; b += 256) a += partial[(long long)b * 2 * D + j];
+        sd[t] = a;
+        __syncthreads();
+        for (int m = 128; m > 0; m >>= 1) { if (t < m) sd[t] += sd[t + m]; __syncthreads(); }
+        if (t == 0) out[j] = sd[0];
+    } else {
         unsigned long long a = 0;
-        for (int b = 0; b < nb; ++b) a += partial_acc[b];
-        *reinterpret_cast<unsigned long long*>(out + 2 * D) = a;
+        for (int b = t; b < nb; b += 256) a += partial_acc[b];
+        su[t] = a;
+        __syncthreads();
+        for (int m = 128; m > 0; m >>= 1) { if (t < m) su[t] += su[t + m]; __syncthreads(); }
+        if (t == 0) *reinterpret_cast<unsigned long long*>(out + 2 * D) = su[0];
     }
 }
 // out: 2 D doubles (sum, sumsq; untouched unless with_sums) followed by the u64 accept total; on the handle's stream
@@ -921,7 +957,7 @@ static hipError_t pool_summaries_async(klara_handle* h, bool with_sums, double* 
                        h->pool_partial, reinterpret_cast<unsigned long long*>(h->pool_partial + (size_t)KLARA_POOL_BLOCKS * 2 * D));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_pool_stage2, dim3((2 * D + 255) / 256), dim3(256), 0, h->stream, h->pool_partial,
+    hipLaunchKernelGGL(k_pool_stage2, dim3(2 * D + 1), dim3(256), 0, h->stream, h->pool_partial,
                        reinterpret_cast<const unsigned long long*>(h->pool_partial + (size_t)KLARA_POOL_BLOCKS * 2 * D), D, nb, with_sums, out);
     return hipGetLastError();
 }

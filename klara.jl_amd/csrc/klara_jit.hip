@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <cstdint>
@@ -84,7 +85,12 @@ std::string cache_dir()
     else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/klara_hip";
     else if (const char* h = getenv("HOME")) { d = std::string(h) + "/.cache"; mkdir(d.c_str(), 0755); d += "/klara_hip"; }
     if (d.empty()) return d;
-    mkdir(d.c_str(), 0755);                          // (EEXIST is fine; an unusable directory just disables the cache)
+    mkdir(d.c_str(), 0700);                          // (EEXIST is fine; an unusable directory just disables the cache)
+    // Cached files are code objects that get loaded and executed: only a directory that belongs to this user and that nobody
+    // else can write to is trusted (a shared or world-writable KLARA_JIT_CACHE_DIR such as /tmp would let another user plant
+    // a .kjit file under a predictable name).  Anything else disables the disk cache, never the job.
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0) return "";
     return d;
 }
 
@@ -105,8 +111,12 @@ std::string cache_file(const std::string& key, const std::string& opts)
 // layout: "KJIT1\n", u32 count, count x (i32 mode (-1: init kernel), u32 length, name bytes), u64 code size, code, u64 FNV-1a of all before
 bool cache_read(const std::string& path, CodeObject& co)
 {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);       // (no symlinks; regular files of this user only)
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0) { close(fd); return false; }
+    FILE* f = fdopen(fd, "rb");
+    if (!f) { close(fd); return false; }
     std::vector<char> buf;
     char chunk[65536];
     size_t n;
@@ -147,8 +157,10 @@ void cache_write(const std::string& path, const CodeObject& co)
     const uint64_t sum = fnv1a(buf.data(), buf.size(), 0xcbf29ce484222325ull);
     put(&sum, 8);
     const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f) return;
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return;
+    FILE* f = fdopen(fd, "wb");
+    if (!f) { close(fd); remove(tmp.c_str()); return; }
     const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
     fclose(f);
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());     // (atomic publish; a concurrent writer produces the same bytes)

@@ -262,6 +262,12 @@ class Engine:
             x = _f64(x, (self.nchains, self.ndims))
             L.check(self._lib.klara_reset(self._h, x.ctypes.data), "klara_reset")
 
+    def stream_key(self):
+        """(Philox key the job currently draws from, klara_reset calls so far) — include/klara_hip.h klara_reset."""
+        k, e = C.c_uint64(0), C.c_uint64(0)
+        L.check(self._lib.klara_stream_key(self._h, C.byref(k), C.byref(e)), "klara_stream_key")
+        return int(k.value), int(e.value)
+
     def run(self, nsteps: int):
         L.check(self._lib.klara_run(self._h, int(nsteps)), "klara_run")
 
@@ -322,11 +328,12 @@ class Engine:
                 "klara_get_chain_fields")
         return lt, g
 
-    def chain_mcvar(self, batchlen: int = 100, maxlag: int = 0):
-        """(mcvar_iid, mcvar_bm, mcvar_imse), each (nchains, ndims), from the on-device history (mcvar.jl)."""
-        out = [np.empty((self.nchains, self.ndims)) for _ in range(3)]
-        L.check(self._lib.klara_get_chain_mcvar(self._h, int(batchlen), int(maxlag), out[0].ctypes.data,
-                                                out[1].ctypes.data, out[2].ctypes.data), "klara_get_chain_mcvar")
+    def chain_mcvar(self, batchlen: int = 100, maxlag: int = 0, want=("iid", "bm", "imse")):
+        """(mcvar_iid, mcvar_bm, mcvar_imse), each (nchains, ndims) or None when not in `want`, from the on-device history
+        (mcvar.jl); an estimator that is not asked for is not computed (the IMSE pass costs O(n x stopping lag) per series)."""
+        out = [np.empty((self.nchains, self.ndims)) if k in want else None for k in ("iid", "bm", "imse")]
+        L.check(self._lib.klara_get_chain_mcvar(self._h, int(batchlen), int(maxlag), *[None if a is None else a.ctypes.data for a in out]),
+                "klara_get_chain_mcvar")
         return tuple(out)
 
     def chain_bm(self):

@@ -35,7 +35,22 @@ try:
     bench_cfg = {k: line["config"][k] for k in ("steps_per_launch", "nchains_per_gpu", "ndims", "save_rule")}
 except Exception as exc:
     bench_cfg = {"error": repr(exc)}
-out = {"bench_config": bench_cfg, "source": "rocprofv3 --pmc passes of scripts/profile_round.sh (bench.py --steps 64 --warmup 16 --reps 1 --no-cpu-baseline), one counter "
+# durations of the headline kernel in its one-shape trace pass (pass 0a): what bench.py's roofline.launch_us has to agree with
+trace = {}
+for f in glob.glob(os.path.join(prof, "trace_headline", "**", "*kernel_trace.csv"), recursive=True):
+    durs = defaultdict(list)
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            if "k_diagt<" in r["Kernel_Name"]:
+                durs[(r["Kernel_Name"], int(r["Grid_Size"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for (name, grid), v in durs.items():
+        v.sort()
+        trace[f"{name} grid={grid}"] = {"n": len(v), "mean_ns": sum(v) / len(v), "median_ns": v[len(v) // 2], "min_ns": v[0], "max_ns": v[-1]}
+try:
+    trace["bench_line_launch_us_in_the_profiled_run"] = json.loads(open(os.path.join(prof, "bench_line_trace_headline.json")).read())["roofline"]["launch_us"]
+except Exception:
+    pass
+out = {"bench_config": bench_cfg, "headline_kernel_trace": trace, "source": "rocprofv3 --pmc passes of scripts/profile_round.sh (bench.py --steps 64 --warmup 16 --reps 1 --no-cpu-baseline), one counter "
                  "group per run, --kernel-trace only; means per dispatch, chip totals (GRBM_GUI_ACTIVE: sum over the 8 XCDs); "
                  "FETCH_SIZE / WRITE_SIZE in KiB as reported (FETCH_SIZE is doubled by the reader, see profiles/README.md)",
        "kernels": rows}

@@ -196,6 +196,7 @@ class OracleJob:
                 d.custom_data = ptr(custom_data); d.custom_ndata = int(np.size(custom_data))
         d.seed = int(seed)
         self.desc = d
+        self._seed0, self.epoch = int(seed), 0
         k, g, e = layout if layout is not None else default_layout(int(target_kind), self.D, int(d.logit_ndata), sampler=int(sampler),
                                                                    tuner=int(tuner), tuner_mode=int(tuner_mode), verbose=bool(verbose),
                                                                    hier_nunits=int(d.hier_nunits), hier_ntimes=int(d.hier_ntimes))
@@ -236,6 +237,16 @@ class OracleJob:
 
     def set_state(self, x) -> int:
         self.X[...] = _f64(x).reshape(self.N, self.D)
+        return self._init()
+
+    def reset(self, x=None) -> int:
+        """reset(job[, x]): the job moves on to the next Philox key (include/klara_hip.h klara_reset), everything else rewinds"""
+        self.epoch = getattr(self, "epoch", 0) + 1
+        if not hasattr(self, "_seed0"):
+            self._seed0 = int(self.desc.seed)
+        self.desc.seed = (self._seed0 + self.epoch * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        if x is not None:
+            self.X[...] = _f64(x).reshape(self.N, self.D)
         return self._init()
 
     def init_state_normal(self) -> int:

@@ -484,7 +484,7 @@ def test_reset_and_error_paths_on_pair_transposed_layout():
     eng.run(case["nsteps"]); x1 = eng.state()[0]; m1 = eng.accept_mask()
     with pytest.raises(K.KlaraError):
         eng.run(1)                                  # beyond nsteps: the accept-mask buffer is full (KLARA_ERR_STATE)
-    eng.reset(x0); eng.run(case["nsteps"])
+    eng.set_state(x0); eng.run(case["nsteps"])           # set_state keeps the stream: the job is replayed
     assert np.array_equal(eng.state()[0], x1) and np.array_equal(eng.accept_mask(), m1)
     bad = x0.copy(); bad[5, 7] = np.inf
     with pytest.raises(K.KlaraError) as ei:
@@ -494,12 +494,26 @@ def test_reset_and_error_paths_on_pair_transposed_layout():
 
 
 def test_reset_rewinds_the_job():
-    """reset(job) / reset(job, x) — BasicMCJob.jl:187-201."""
-    case = cases.make_case("hmc_d100")
+    """reset(job) / reset(job, x) — BasicMCJob.jl:187-201: sampler / tuner state, counters and monitors rewind; the random stream
+    does NOT (the reference's generator keeps advancing), so run -> reset(x0) -> run is an independent replicate from the same
+    start: a different trajectory, bit-identical to the oracle on the job's next Philox key (klara_hip.h klara_reset), while
+    set_state(x0) replays the first run."""
+    case = cases.make_case("hmc_d100_tuned")
     eng = K.Engine(**cases.engine_kwargs(case)); eng.init_state_normal()
+    job = O.OracleJob(**cases.oracle_kwargs(case, layout=eng.layout())); job.init_state_normal()
+    assert eng.stream_key() == (case["seed"], 0)
     x0 = eng.state()[0]
-    eng.run(case["nsteps"]); x1 = eng.state()[0]; m1 = eng.accept_mask()
-    eng.reset(x0); eng.run(case["nsteps"])
+    eng.run(case["nsteps"]); job.run(case["nsteps"]); x1 = eng.state()[0]; m1 = eng.accept_mask()
+    _assert_same(eng, job, case)
+    for k, x in ((1, x0), (2, None)):                     # reset(job, x0), then reset(job) from wherever it is
+        eng.reset(x); assert job.reset(x) == 0
+        assert eng.stream_key() == ((case["seed"] + k * 0x9E3779B97F4A7C15) % 2 ** 64, k)
+        assert eng.accept_counts()[1] == 0 and eng.tune()[3][0] == case["period"]          # counters and tuner state rewound
+        eng.run(case["nsteps"]); assert job.run(case["nsteps"]) == 0
+        _assert_same(eng, job, case)
+        assert not np.array_equal(eng.accept_mask(), m1)
+    eng.close()
+    eng = K.Engine(**cases.engine_kwargs(case)); eng.set_state(x0); eng.run(case["nsteps"])
     assert np.array_equal(eng.state()[0], x1) and np.array_equal(eng.accept_mask(), m1)
     eng.close()
 
@@ -611,7 +625,7 @@ def test_monitored_fields_and_iostream_sink(tmp_path):
     case = cases.make_case("mala_swiss")
     X, y = cases.swiss_data()
     p = K.BasicContMuvParameter("p", logtarget=K.LogisticTarget(X, y, 100.0))
-    job = K.BasicMCJob(K.likelihood_model(p, False), K.MALA(0.1), K.BasicMCRange(nsteps=40, burnin=10), {"p": case["x0"]},
+    job = K.BasicMCJob(K.likelihood_model(p, False), K.MALA(0.1), K.BasicMCRange(nsteps=40, burnin=10), {"p": case["x0"]}, seed=20260927,
                        outopts={"destination": "iostream", "filepath": str(tmp_path), "monitor": ["value", "logtarget", "gradlogtarget"],
                                 "diagnostics": ["accept"]})
     o = O.OracleJob(**cases.oracle_kwargs(case, layout=job.engine.layout()), want_hist=True)
@@ -638,7 +652,7 @@ def test_device_mcvar_matches_host_estimators():
     the NumPy restatement (klara_jl_amd.stats) on individual chains; tolerance 1e-9 relative (different summation)."""
     p = K.BasicContMuvParameter("p", logtarget=K.GaussDiagTarget.negdot(3))
     job = K.BasicMCJob(K.likelihood_model(p, False), K.MH(np.full(3, 0.6)), K.BasicMCRange(nsteps=2600, burnin=100),
-                       {"p": np.zeros((70, 3))})
+                       {"p": np.zeros((70, 3))}, seed=20260927)
     K.run(job)
     chain = K.output(job)
     iid, bm, imse = (K.chain_mcvar(chain, t, batchlen=50) for t in ("iid", "bm", "imse"))
@@ -660,7 +674,7 @@ def test_readme_flow_basic_mc_job():
     p = K.BasicContMuvParameter("p", logtarget=K.GaussDiagTarget.negdot(2))
     model = K.likelihood_model(p, False)
     job = K.BasicMCJob(model, K.MH(np.ones(2)), K.BasicMCRange(nsteps=10000, burnin=1000),
-                       {"p": np.tile([5.1, -0.9], (256, 1))}, outopts={"diagnostics": ["accept"]})
+                       {"p": np.tile([5.1, -0.9], (256, 1))}, outopts={"diagnostics": ["accept"]}, seed=20260927)
     K.run(job)
     chain = K.output(job)
     m = K.mean(chain)                         # (nchains x D)
@@ -818,7 +832,7 @@ def test_streaming_batch_means_through_the_job_api():
     chain means predicts the spread of those means across independent chains."""
     p = K.BasicContMuvParameter("p", logtarget=K.GaussDiagTarget.negdot(3))
     job = K.BasicMCJob(K.likelihood_model(p, False), K.MALA(0.9), K.BasicMCRange(nsteps=6000, burnin=1000),
-                       {"p": np.zeros((4096, 3))}, outopts={"destination": "none"}, bm_batchlen=100)
+                       {"p": np.zeros((4096, 3))}, outopts={"destination": "none"}, bm_batchlen=100, seed=20260927)
     K.run(job)
     chain = K.output(job)
     v = K.chain_mcvar(chain, "bm", 100)                    # (chains, D): variance of each chain's mean
@@ -903,7 +917,7 @@ def test_custom_target_through_the_job_api():
     tgt = K.CustomTarget(2, cases.SRC_BANANA)
     p = K.BasicContMuvParameter("p", logtarget=tgt)
     job = K.BasicMCJob(K.likelihood_model(p, False), K.HMC(0.15, 7), K.BasicMCRange(nsteps=300, burnin=50, thinning=2),
-                       {"p": np.tile([0.5, 0.2], (96, 1))}, outopts={"diagnostics": ["accept"]})
+                       {"p": np.tile([0.5, 0.2], (96, 1))}, outopts={"diagnostics": ["accept"]}, seed=20260927)
     K.run(job)
     chain = K.output(job)
     assert chain.value(3).shape == (2, 125)

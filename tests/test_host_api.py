@@ -157,6 +157,16 @@ def test_sampler_and_tuner_constructors():
     assert K.logistic_rate_score(0.25) == pytest.approx(1.7039056039366212, rel=1e-15)
 
 
+def test_jobs_built_without_a_seed_get_distinct_streams():
+    """two jobs built with default arguments must not share their random stream (the reference's jobs draw from one
+    global generator, so `run([job1, job2])` gives independent chains).  The default key is fresh per job; an explicit seed is kept."""
+    from klara_jl_amd import api
+    a, b, c = api._next_job_seed(), api._next_job_seed(), api._next_job_seed()
+    assert len({a, b, c}) == 3 and all(0 <= v < 2 ** 64 for v in (a, b, c))
+    import inspect
+    assert inspect.signature(api.BasicMCJob.__init__).parameters["seed"].default is None
+
+
 def test_target_families():
     t = K.GaussDiagTarget.mvnormal([6.11, -8.5], 1.0)
     assert t.ndims == 2 and np.allclose(t.w, 0.5) and t.const == pytest.approx(-np.log(2 * np.pi))
