@@ -85,7 +85,12 @@ typedef enum klara_target {
      * and is compiled for gfx950 at klara_create (hiprtc) into the group-layout transition kernels, one chain per lane
      * (D <= 64; the whole vector in one lane: registers up to D = 32, scratch-backed beyond; KLARA_D is predefined to D so that loops unroll).  kd_exp, kd_log,
      * kd_fma, kd_erf (klara.jl_amd/csrc/detmath.h) and IEEE + - * / sqrt give the same bits on host and device;
-     * `data` is custom_data (custom_ndata doubles, copied to the device at create). */
+     * `data` is custom_data (custom_ndata doubles, copied to the device at create).
+     * Likelihood + prior form (BasicContMuvParameter(:p, loglikelihood=..., logprior=..., gradloglikelihood=..., gradlogprior=...),
+     * BasicContMuvParameter.jl:174-201): a source that starts with `#define KLARA_USER_LIKELIHOOD_PRIOR 1` defines
+     * klara_user_loglikelihood, klara_user_logprior (and klara_user_gradloglikelihood, klara_user_gradlogprior for MALA / HMC)
+     * instead; the library composes logtarget = loglikelihood + logprior and the gradients' elementwise sum
+     * (klara.jl_amd/csrc/klara_custom_compose.h) and can keep both parts per saved step (KLARA_MON_HIST_LLLP). */
     KLARA_TARGET_CUSTOM = 4
 } klara_target;
 
@@ -110,6 +115,8 @@ typedef enum klara_tuner_mode {
 #define KLARA_MON_SUMMARIES 0x4u  /* accumulate sum x, sum x^2 over postrange steps on device      */
 #define KLARA_MON_HIST_LT   0x8u  /* :monitor=>[:logtarget]: keep logtarget at every postrange step */
 #define KLARA_MON_HIST_GRAD 0x10u /* :monitor=>[:gradlogtarget] (MALA/HMC only)                    */
+#define KLARA_MON_HIST_LLLP 0x20u /* :monitor=>[:loglikelihood, :logprior]: the two parts of a likelihood + prior user target
+                                     (KLARA_TARGET_CUSTOM whose source defines KLARA_USER_LIKELIHOOD_PRIOR) at every postrange step */
 
 typedef struct klara_desc {
     uint32_t struct_size;        /* = sizeof(klara_desc), ABI check                                  */
@@ -254,6 +261,9 @@ klara_status klara_get_chain(klara_handle* h, int64_t local_chain, double* value
  * KLARA_MON_HIST_LT) and gradlogtarget[d + D*i] (KLARA_MON_HIST_GRAD); either pointer may be NULL. */
 klara_status klara_get_chain_fields(klara_handle* h, int64_t local_chain, double* logtarget,
                                     double* gradlogtarget, int64_t capacity_cols, int64_t* ncols_out);
+/* loglikelihood[i] and logprior[i] of one chain over the saved steps (KLARA_MON_HIST_LLLP); either pointer may be NULL */
+klara_status klara_get_chain_likelihood_prior(klara_handle* h, int64_t local_chain, double* loglikelihood, double* logprior,
+                                              int64_t capacity_cols, int64_t* ncols_out);
 /* Monte Carlo variance of every (chain, dimension) series of the stored history, computed on device
  * (src/stats/variance/mcvar.jl): iid (:5), batch means with `batchlen` (:35-41), Geyer's initial monotone sequence
  * estimator up to `maxlag` (<= 0: n-1) (:75-105).  Each output is nchains x ndims or NULL; requires KLARA_MON_HISTORY.

@@ -25,7 +25,7 @@ TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET_HIER_NORMAL, TARG
 # klara_tuner / mode
 TUNER_VANILLA, TUNER_ACCEPT_RATE, TUNER_DUAL_AVERAGING = 0, 1, 2
 TUNE_PER_CHAIN, TUNE_POOLED = 0, 1
-MON_ACCEPT, MON_HISTORY, MON_SUMMARIES, MON_HIST_LT, MON_HIST_GRAD = 0x1, 0x2, 0x4, 0x8, 0x10
+MON_ACCEPT, MON_HISTORY, MON_SUMMARIES, MON_HIST_LT, MON_HIST_GRAD, MON_HIST_LLLP = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 
 _dp = C.POINTER(C.c_double)
 
@@ -72,7 +72,7 @@ EXPORTS = [
     "klara_create", "klara_destroy", "klara_set_state", "klara_init_state_normal", "klara_run",
     "klara_run_async", "klara_synchronize", "klara_reset", "klara_stream_key", "klara_get_state", "klara_get_accept_mask",
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
-    "klara_get_chain_fields", "klara_get_chain_mcvar", "klara_get_chain_bm", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
+    "klara_get_chain_fields", "klara_get_chain_likelihood_prior", "klara_get_chain_mcvar", "klara_get_chain_bm", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
     "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_normal_tail", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
     "klara_comm_unique_id", "klara_comm_init", "klara_comm_destroy", "klara_gather_summaries",
     "klara_check_custom_target", "klara_compile_log", "klara_selftest_plan", "klara_abi_version",
@@ -111,6 +111,7 @@ def load() -> C.CDLL:
         "klara_get_pooled_summaries": [H, C.c_void_p, C.c_void_p, u64p, u64p, i64p],
         "klara_get_chain": [H, C.c_int64, C.c_void_p, C.c_int64, i64p],
         "klara_get_chain_fields": [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, i64p],
+        "klara_get_chain_likelihood_prior": [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, i64p],
         "klara_get_chain_mcvar": [H, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_get_tune": [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_get_dual_averaging": [H, C.c_void_p, C.c_void_p],

@@ -169,11 +169,23 @@ class BasicContMuvParameter:
     loglikelihood+logprior+gradlogtarget of doc/examples/swiss/MALA/analytical.jl:20-26.
     """
 
-    def __init__(self, key: str, logtarget=None, **unsupported):
-        if logtarget is None:
-            raise ValueError("logtarget (a target family object) is required")
+    def __init__(self, key: str, logtarget=None, loglikelihood: Optional[str] = None, logprior: Optional[str] = None,
+                 gradloglikelihood: Optional[str] = None, gradlogprior: Optional[str] = None, ndims: Optional[int] = None, data=None,
+                 **unsupported):
         if unsupported:
             raise NotImplementedError(f"closure fields not available on device: {sorted(unsupported)}")
+        if logtarget is None:
+            # likelihood + prior closures (BasicContMuvParameter.jl:174-201): C text for each, composed on device as
+            # logtarget = loglikelihood + logprior, gradlogtarget = gradloglikelihood + gradlogprior
+            if loglikelihood is None or logprior is None:
+                raise ValueError("give logtarget (a target family object) or both loglikelihood and logprior (C source text)")
+            if ndims is None:
+                raise ValueError("ndims is required with loglikelihood / logprior closures")
+            if (gradloglikelihood is None) != (gradlogprior is None):
+                raise ValueError("gradloglikelihood and gradlogprior go together")
+            logtarget = CustomTarget.likelihood_prior(ndims, loglikelihood, logprior, gradloglikelihood or "", gradlogprior or "", data)
+        elif loglikelihood is not None or logprior is not None:
+            raise ValueError("logtarget and loglikelihood / logprior are alternatives")
         if not isinstance(logtarget, (GaussDiagTarget, GaussDenseTarget, LogisticTarget, HierNormalTarget, CustomTarget)):
             raise TypeError("logtarget must be GaussDiagTarget, GaussDenseTarget, LogisticTarget, HierNormalTarget or CustomTarget")
         self.key = str(key).lstrip(":")
@@ -223,6 +235,12 @@ class MuvChains:
 
     def gradlogtarget(self, chain: int = 0) -> np.ndarray:
         return self._job.engine.chain_fields(chain, False, True)[1]
+
+    def loglikelihood(self, chain: int = 0) -> np.ndarray:
+        return self._job.engine.chain_likelihood_prior(chain)[0]
+
+    def logprior(self, chain: int = 0) -> np.ndarray:
+        return self._job.engine.chain_likelihood_prior(chain)[1]
 
     @property
     def diagnosticvalues(self):
@@ -343,7 +361,7 @@ class BasicMCJob:
             monitor |= L.MON_ACCEPT
         if self.outopts["destination"] in ("nstate", "iostream"):
             mon = [str(m).lstrip(":") for m in self.outopts.get("monitor", [])]
-            known = {"value", "logtarget", "gradlogtarget"}
+            known = {"value", "logtarget", "gradlogtarget", "loglikelihood", "logprior"}
             if set(mon) - known:
                 raise NotImplementedError(f"monitor fields not kept on device: {sorted(set(mon) - known)}")
             if "value" in mon:
@@ -352,6 +370,10 @@ class BasicMCJob:
                 monitor |= L.MON_HIST_LT
             if "gradlogtarget" in mon:
                 monitor |= L.MON_HIST_GRAD
+            if "loglikelihood" in mon or "logprior" in mon:          # iterate/MALA.jl:104-109: kept when the parameter has the closures
+                if not getattr(self.parameter.target, "has_parts", False):
+                    raise ValueError("loglikelihood / logprior can only be monitored for a parameter built from those closures")
+                monitor |= L.MON_HIST_LLLP
         if summaries:
             monitor |= L.MON_SUMMARIES
         kw = dict(sampler=sampler.kind, target=self.parameter.target, nchains=nchains, nsteps=mcrange.nsteps,

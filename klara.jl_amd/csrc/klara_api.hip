@@ -38,7 +38,7 @@ struct klara_handle {
     double *sum = nullptr, *sumsq = nullptr;
     long long* held = nullptr;      // running sums in sojourn form: saved steps at the current state not yet in sum / sumsq (KParams::held)
     double* hist = nullptr; long long hist_cols = 0;
-    double *hist_lt = nullptr, *hist_g = nullptr;
+    double *hist_lt = nullptr, *hist_g = nullptr, *hist_ll = nullptr, *hist_lp = nullptr;
     int* err = nullptr;
     double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr,
            *hY = nullptr, *hxc = nullptr;
@@ -206,7 +206,7 @@ static void free_all(klara_handle* h)
 {
     hipFree(h->X); hipFree(h->GR); hipFree(h->LT); hipFree(h->tune_step); hipFree(h->tune_acc);
     hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->da_epsbar); hipFree(h->da_hbar); hipFree(h->pooled_acc); hipFree(h->accept);
-    hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->held); hipFree(h->hist); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->err);
+    hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->held); hipFree(h->hist); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->hist_ll); hipFree(h->hist_lp); hipFree(h->err);
     hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
     hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->pool_partial); hipFree(h->d_params); hipFree(h->cdata);
     hipFree(h->bm_prev); hipFree(h->bm_mean); hipFree(h->bm_m2);
@@ -302,11 +302,15 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         h->accept_cap = desc->nsteps;
         CKH(dalloc(&h->accept, (size_t)desc->nsteps * N));
     }
-    if (desc->monitor & (KLARA_MON_HISTORY | KLARA_MON_HIST_LT | KLARA_MON_HIST_GRAD)) {
+    if ((desc->monitor & KLARA_MON_HIST_LLLP) && (desc->target != KLARA_TARGET_CUSTOM || !strstr(desc->custom_src, "KLARA_USER_LIKELIHOOD_PRIOR"))) {
+        free_all(h); delete h; return KLARA_ERR_INVALID_ARG;           // only a likelihood + prior user target has the two parts
+    }
+    if (desc->monitor & (KLARA_MON_HISTORY | KLARA_MON_HIST_LT | KLARA_MON_HIST_GRAD | KLARA_MON_HIST_LLLP)) {
         // npoststeps = length((burnin+1):thinning:nsteps)  (BasicMCRange.jl:26)
         h->hist_cols = (desc->nsteps - desc->burnin - 1) / desc->thinning + 1;
         if (desc->monitor & KLARA_MON_HISTORY) CKH(dalloc(&h->hist, (size_t)h->hist_cols * N * D));
         if (desc->monitor & KLARA_MON_HIST_LT) CKH(dalloc(&h->hist_lt, (size_t)h->hist_cols * N));
+        if (desc->monitor & KLARA_MON_HIST_LLLP) { CKH(dalloc(&h->hist_ll, (size_t)h->hist_cols * N)); CKH(dalloc(&h->hist_lp, (size_t)h->hist_cols * N)); }
         if (desc->monitor & KLARA_MON_HIST_GRAD) {
             if (desc->sampler != KLARA_SAMPLER_MALA && desc->sampler != KLARA_SAMPLER_HMC) {
                 free_all(h); delete h; return KLARA_ERR_INVALID_ARG;   // no gradient is carried by MH / slice
@@ -383,6 +387,7 @@ static KParams make_params(klara_handle* h)
     p.accept = (decltype(p.accept))h->accept; p.naccept = (decltype(p.naccept))h->naccept; p.sum = (decltype(p.sum))h->sum; p.sumsq = (decltype(p.sumsq))h->sumsq; p.held = (decltype(p.held))h->held;
     p.hist = (decltype(p.hist))h->hist; p.hist_cols = h->hist_cols; p.error_flag = (decltype(p.error_flag))h->err;
     p.hist_lt = (decltype(p.hist_lt))h->hist_lt; p.hist_g = (decltype(p.hist_g))h->hist_g;
+    p.hist_ll = (decltype(p.hist_ll))h->hist_ll; p.hist_lp = (decltype(p.hist_lp))h->hist_lp;
     p.nchains = d.nchains; p.chain_offset = d.chain_offset; p.D = d.ndims; p.G = h->G; p.rs = h->RS;
     p.pooled = d.tuner_mode == KLARA_TUNE_POOLED;
     p.seed = d.seed + h->epoch * KLARA_EPOCH_KEY_STRIDE;      // (mod 2^64)
@@ -1110,6 +1115,23 @@ extern "C" klara_status klara_get_chain_fields(klara_handle* h, int64_t local_ch
     if (gradlogtarget && n > 0)
         HIPCHK(hipMemcpy2D(gradlogtarget, D * sizeof(double), h->hist_g + (size_t)local_chain * D,
                            N * D * sizeof(double), D * sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
+    if (ncols_out) *ncols_out = h->nsaved;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_chain_likelihood_prior(klara_handle* h, int64_t local_chain, double* loglikelihood, double* logprior,
+                                                         int64_t capacity_cols, int64_t* ncols_out)
+{
+    if (!h || local_chain < 0 || local_chain >= h->d.nchains) return KLARA_ERR_INVALID_ARG;
+    if (!h->hist_ll) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t N = (size_t)h->d.nchains;
+    const long long n = h->nsaved < capacity_cols ? h->nsaved : capacity_cols;
+    if (loglikelihood && n > 0)
+        HIPCHK(hipMemcpy2D(loglikelihood, sizeof(double), h->hist_ll + (size_t)local_chain, N * sizeof(double), sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
+    if (logprior && n > 0)
+        HIPCHK(hipMemcpy2D(logprior, sizeof(double), h->hist_lp + (size_t)local_chain, N * sizeof(double), sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
     if (ncols_out) *ncols_out = h->nsaved;
     return KLARA_OK;
 }

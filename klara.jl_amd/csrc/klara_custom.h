@@ -14,9 +14,20 @@
 //
 // This file is only ever compiled by the run-time compiler, after klara_kernels.h and the user's source.
 #pragma once
+#include "klara_custom_compose.h"       // likelihood + prior form (KLARA_USER_LIKELIHOOD_PRIOR): lt = ll + lp, grad = gll + glp
 
 template <int E>
 struct CustomTarget {
+    // :monitor => [:loglikelihood, :logprior] (iterate/MALA.jl:104-109): the two parts at the saved state
+    __device__ __forceinline__ void parts(const double (&x)[E], double& ll, double& lp) const
+    {
+#ifdef KLARA_USER_LIKELIHOOD_PRIOR
+        ll = klara_user_loglikelihood(x, D, data, ndata);
+        lp = klara_user_logprior(x, D, data, ndata);
+#else
+        ll = 0.0; lp = 0.0;
+#endif
+    }
     const double* data; long long ndata; int D;
     static __device__ __forceinline__ size_t lds_bytes(const KParams&) { return 0; }
     __device__ __forceinline__ void init(const KParams& p, const LaneCtx<E>&, double*)

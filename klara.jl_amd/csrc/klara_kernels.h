@@ -69,6 +69,7 @@ struct KParams {
     glong* held;
     gdouble* hist; long long hist_cols;         // [col][nchains][D] or null
     gdouble* hist_lt; gdouble* hist_g;           // [col][nchains] / [col][nchains][D] or null
+    gdouble* hist_ll; gdouble* hist_lp;          // [col][nchains] or null: loglikelihood / logprior of a likelihood + prior user target
     gint* error_flag;                           // set to klara_status on device-detected errors
     long long nchains; long long chain_offset;
     int D; int G; int pooled;
@@ -1051,6 +1052,13 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
                     }
                     if (hist_lt != nullptr && scol < p.hist_cols && cx.chain_ok && cx.q == 0 && cx.rq == 0)
                         hist_lt[scol * p.nchains + cx.chain] = cur.lt;
+                    if constexpr (TARGET == KLARA_TARGET_CUSTOM) {            // :monitor => [:loglikelihood, :logprior]
+                        if (p.hist_ll != nullptr && scol < p.hist_cols) {
+                            double ll_, lp_;
+                            tg.parts(cur.x, ll_, lp_);
+                            if (cx.chain_ok) { p.hist_ll[scol * p.nchains + cx.chain] = ll_; p.hist_lp[scol * p.nchains + cx.chain] = lp_; }
+                        }
+                    }
                     if (NEEDG && hist_g != nullptr && scol < p.hist_cols) {
                         gdouble* dst = hist_g + (scol * p.nchains + cx.chain) * p.D + cx.i0;
 #pragma unroll

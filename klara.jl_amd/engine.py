@@ -115,6 +115,20 @@ class CustomTarget:
         if self.data is not None:
             self.data = _f64(self.data).ravel()
 
+    @classmethod
+    def likelihood_prior(cls, ndims: int, loglikelihood: str, logprior: str, gradloglikelihood: str = "", gradlogprior: str = "",
+                         data=None) -> "CustomTarget":
+        """The likelihood + prior form of `BasicContMuvParameter(:p, loglikelihood=..., logprior=..., gradloglikelihood=...,
+        gradlogprior=...)` (BasicContMuvParameter.jl:174-201): each argument is C text defining klara_user_loglikelihood /
+        klara_user_logprior / klara_user_gradloglikelihood / klara_user_gradlogprior; the library composes
+        logtarget = loglikelihood + logprior and gradlogtarget = gradloglikelihood + gradlogprior (klara_custom_compose.h)."""
+        src = "#define KLARA_USER_LIKELIHOOD_PRIOR 1\n" + "\n".join(t for t in (loglikelihood, logprior, gradloglikelihood, gradlogprior) if t)
+        return cls(ndims, src, data)
+
+    @property
+    def has_parts(self) -> bool:
+        return "KLARA_USER_LIKELIHOOD_PRIOR" in self.source
+
     def check(self, sampler: int) -> None:
         """Compile only (no GPU needed); raises KlaraError with the compiler's log on failure."""
         L.check(L.load().klara_check_custom_target(self.source.encode(), int(sampler), self.ndims), "klara_check_custom_target")
@@ -327,6 +341,16 @@ class Engine:
                                                  g.ctypes.data if gradlogtarget else None, n.value, C.byref(n)),
                 "klara_get_chain_fields")
         return lt, g
+
+    def chain_likelihood_prior(self, local_chain: int):
+        """(loglikelihood (n,), logprior (n,)) of one chain over the saved steps — a likelihood + prior user target monitored with
+        MON_HIST_LLLP (:monitor => [:loglikelihood, :logprior])."""
+        n = C.c_int64(0)
+        L.check(self._lib.klara_get_chain_likelihood_prior(self._h, int(local_chain), None, None, 0, C.byref(n)), "klara_get_chain_likelihood_prior")
+        ll = np.empty(n.value); lp = np.empty(n.value)
+        L.check(self._lib.klara_get_chain_likelihood_prior(self._h, int(local_chain), ll.ctypes.data, lp.ctypes.data, n.value, C.byref(n)),
+                "klara_get_chain_likelihood_prior")
+        return ll, lp
 
     def chain_mcvar(self, batchlen: int = 100, maxlag: int = 0, want=("iid", "bm", "imse")):
         """(mcvar_iid, mcvar_bm, mcvar_imse), each (nchains, ndims) or None when not in `want`, from the on-device history

@@ -31,6 +31,50 @@ def compound_symmetric_precision(d, rho=0.5):
     return (np.eye(d) - (rho / (1.0 - rho + d * rho)) * np.ones((d, d))) / (1.0 - rho)
 
 
+# ---- likelihood + prior closures: the Normal-Normal model of the reference's parameter tests
+# (/root/reference/test/BasicContMuvParameter.jl:232-292, 326-453, 458-530): x | mu ~ N(mu, diag(s)), mu ~ N(mu0, diag(s0)); the
+# parameter is mu, the data block is (x[D], s[D], mu0[D], s0[D]).  Written with diagonal covariances (the reference's test values
+# are eye / diagm): logpdf = -1/2 (sum d_i^2 / s_i + D log 2 pi + sum log s_i).
+SRC_NN_LL = r"""
+KLARA_USER_FN double klara_user_loglikelihood(const double* mu, int D, const double* data, long long ndata)
+{
+    const double* x = data; const double* s = data + KLARA_D;
+    double q = 0.0, ld = 0.0;
+    for (int i = 0; i < KLARA_D; ++i) { const double d = x[i] - mu[i]; q = q + d * d / s[i]; ld = ld + kd_log(s[i]); }
+    return -0.5 * (q + (double)KLARA_D * 1.8378770664093453 + ld);
+}
+"""
+SRC_NN_LP = r"""
+KLARA_USER_FN double klara_user_logprior(const double* mu, int D, const double* data, long long ndata)
+{
+    const double* m0 = data + 2 * KLARA_D; const double* s0 = data + 3 * KLARA_D;
+    double q = 0.0, ld = 0.0;
+    for (int i = 0; i < KLARA_D; ++i) { const double d = mu[i] - m0[i]; q = q + d * d / s0[i]; ld = ld + kd_log(s0[i]); }
+    return -0.5 * (q + (double)KLARA_D * 1.8378770664093453 + ld);
+}
+"""
+SRC_NN_GLL = r"""
+KLARA_USER_FN void klara_user_gradloglikelihood(const double* mu, int D, const double* data, long long ndata, double* g)
+{
+    const double* x = data; const double* s = data + KLARA_D;
+    for (int i = 0; i < KLARA_D; ++i) g[i] = (x[i] - mu[i]) / s[i];
+}
+"""
+SRC_NN_GLP = r"""
+KLARA_USER_FN void klara_user_gradlogprior(const double* mu, int D, const double* data, long long ndata, double* g)
+{
+    const double* m0 = data + 2 * KLARA_D; const double* s0 = data + 3 * KLARA_D;
+    for (int i = 0; i < KLARA_D; ++i) g[i] = -(mu[i] - m0[i]) / s0[i];
+}
+"""
+
+
+def normal_normal_target(x, s, mu0, s0):
+    """CustomTarget in likelihood + prior form for the Normal-Normal model above."""
+    d = len(x)
+    return K.CustomTarget.likelihood_prior(d, SRC_NN_LL, SRC_NN_LP, SRC_NN_GLL, SRC_NN_GLP, np.concatenate([x, s, mu0, s0]).astype(np.float64))
+
+
 # ---- user-defined targets (KLARA_TARGET_CUSTOM): C text compiled by hiprtc for the device and by gcc for the oracle
 SRC_NEGDOT = r"""
 /* README.md:23,155: plogtarget(z) = -dot(z, z), pgradlogtarget(z) = -2*z */
@@ -337,6 +381,13 @@ def make_case(name):
     elif name == "custom_quartic_hmc_d50":
         c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(50, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=33, nsteps=12, burnin=2,
                  leapstep=0.08, nleaps=5)
+    elif name == "custom_normal_normal_mala":   # likelihood + prior closures (lt = ll + lp, grad = gll + glp composed by the library)
+        rng = np.random.default_rng(12)
+        t = normal_normal_target(rng.standard_normal(6) * 2, np.linspace(0.5, 2.0, 6), np.linspace(-1, 1, 6), np.linspace(1.0, 5.0, 6))
+        c = dict(sampler=L.SAMPLER_MALA, target=t, nchains=70, nsteps=60, burnin=10, driftstep=0.4, x0=np.zeros((70, 6)))
+    elif name == "custom_normal_normal_mh":     # no gradient closures needed
+        t = K.CustomTarget.likelihood_prior(2, SRC_NN_LL, SRC_NN_LP, data=np.array([-1.88, 2.23, 1.0, 1.0, 0.0, 0.0, 1.0, 1.0]))
+        c = dict(sampler=L.SAMPLER_MH, target=t, nchains=66, nsteps=50, burnin=10, mh_sigma=[0.8, 0.8], x0=np.tile([-2.637, -1.132], (66, 1)))
     elif name == "custom_quartic_slice_d7":
         c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget(7, SRC_QUARTIC_CHAIN, [0.1, 0.4]), nchains=66, nsteps=12, burnin=2,
                  slice_widths=np.full(7, 1.5))
@@ -361,7 +412,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "slice_d20_stepout", "mh_rats", "mala_rats_tuned"] + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
              "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
-             "custom_quartic_mala_d64", "custom_quartic_hmc_d50"]
+             "custom_quartic_mala_d64", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",

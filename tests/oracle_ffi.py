@@ -77,14 +77,15 @@ _user_libs = {}
 def compile_user_target(src: str, ndims: int):
     """Host form of a user-defined target (KLARA_TARGET_CUSTOM): the same C text the product hands to hiprtc, compiled by
     gcc with the same arithmetic contract (-ffp-contract=off, detmath.h for kd_*).  Returns (lib, lt_ptr, grad_ptr|None)."""
-    key = hashlib.sha1(f"{ndims}\n{src}".encode()).hexdigest()[:16]
+    key = hashlib.sha1(f"v2 {ndims}\n{src}".encode()).hexdigest()[:16]
     if key in _user_libs:
         return _user_libs[key]
     out = ROOT / "oracle" / "_user"
     out.mkdir(exist_ok=True)
     so, c = out / f"user_{key}.so", out / f"user_{key}.c"
     if not so.exists():
-        c.write_text(f'#include "detmath.h"\n#define KLARA_D {int(ndims)}\n#define KLARA_USER_FN\n#line 1 "klara_user_target"\n{src}\n')
+        c.write_text(f'#include "detmath.h"\n#define KLARA_D {int(ndims)}\n#define KLARA_USER_FN\n#line 1 "klara_user_target"\n{src}\n'
+                     '#line 1 "klara_custom_glue"\n#include "klara_custom_compose.h"\n')      # (likelihood + prior form: same composition as the device)
         r = subprocess.run(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-shared", "-I", str(ROOT / "klara.jl_amd" / "csrc"),
                             "-o", str(so), str(c), "-lm"], capture_output=True, text=True)
         if r.returncode != 0:

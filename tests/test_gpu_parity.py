@@ -935,6 +935,46 @@ def test_custom_target_through_the_job_api():
     job.close()
 
 
+def test_likelihood_prior_closures_through_the_job_api():
+    """BasicContMuvParameter(:p, loglikelihood=..., logprior=..., gradloglikelihood=..., gradlogprior=...) with
+    :monitor => [:value, :logtarget, :loglikelihood, :logprior] (BasicContMuvParameter.jl:174-201, iterate/MALA.jl:104-109): MALA on the
+    Normal-Normal model of the reference's parameter tests.  Trajectory against the oracle (same closures compiled for the host);
+    at every saved step logtarget == loglikelihood + logprior bit for bit, and the two parts equal the host closures at the saved values."""
+    import ctypes as C
+    case = cases.make_case("custom_normal_normal_mala")
+    t = case["target"]
+    p = K.BasicContMuvParameter("p", loglikelihood=cases.SRC_NN_LL, logprior=cases.SRC_NN_LP, gradloglikelihood=cases.SRC_NN_GLL,
+                                gradlogprior=cases.SRC_NN_GLP, ndims=6, data=t.data)
+    job = K.BasicMCJob(K.likelihood_model(p, False), K.MALA(0.4), K.BasicMCRange(nsteps=60, burnin=10), {"p": case["x0"]},
+                       outopts={"monitor": ["value", "logtarget", "loglikelihood", "logprior"], "diagnostics": ["accept"]}, seed=20260927)
+    K.run(job)
+    chain = K.output(job)
+    o = O.OracleJob(**cases.oracle_kwargs(case, layout=job.engine.layout()), want_hist=True)
+    o.set_state(case["x0"]); o.run(60)
+    assert np.array_equal(job.engine.accept_mask(), o.accept) and 0.2 < o.accept.mean() < 0.95
+    lib, _, _ = O.compile_user_target(t.source, 6)
+    dp = C.POINTER(C.c_double)
+    for f in (lib.klara_user_loglikelihood, lib.klara_user_logprior):
+        f.restype = C.c_double; f.argtypes = [dp, C.c_int, dp, C.c_longlong]
+    for c in (0, 33, 69):
+        v = chain.value(c); lt = chain.logtarget(c); ll = chain.loglikelihood(c); lp = chain.logprior(c)
+        assert np.array_equal(v, o.hist[:, c, :].T) and np.array_equal(lt, o.hist_lt[:, c])
+        assert np.array_equal(lt, ll + lp)
+        for i in range(v.shape[1]):
+            xi = np.ascontiguousarray(v[:, i])
+            assert ll[i] == lib.klara_user_loglikelihood(xi.ctypes.data_as(dp), 6, t.data.ctypes.data_as(dp), t.data.size)
+            assert lp[i] == lib.klara_user_logprior(xi.ctypes.data_as(dp), 6, t.data.ctypes.data_as(dp), t.data.size)
+    # posterior mean of the conjugate model: (x / s + mu0 / s0) / (1 / s + 1 / s0)
+    x, sv, m0, s0 = t.data[:6], t.data[6:12], t.data[12:18], t.data[18:24]
+    post_mean = (x / sv + m0 / s0) / (1 / sv + 1 / s0); post_sd = np.sqrt(1 / (1 / sv + 1 / s0))
+    m = K.mean(chain).mean(axis=0)
+    assert np.all(np.abs(m - post_mean) < 0.35 * post_sd), (m, post_mean)
+    with pytest.raises(ValueError):
+        K.BasicMCJob(K.likelihood_model(K.BasicContMuvParameter("p", logtarget=K.GaussDiagTarget.negdot(3)), False), K.MALA(0.4),
+                     K.BasicMCRange(nsteps=5), {"p": np.zeros((2, 3))}, outopts={"monitor": ["value", "loglikelihood"]})
+    job.close()
+
+
 # ------------------------------------------------------------------ full-size parity on sampled chains
 @pytest.mark.parametrize("name,kw,nsteps", [
     ("cfg2_mala", dict(sampler=L.SAMPLER_MALA, driftstep=0.9), 40),

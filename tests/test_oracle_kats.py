@@ -237,6 +237,45 @@ def test_hierarchical_rats_target_matches_numpy_and_finite_differences():
         assert g[i] == pytest.approx(fd, rel=2e-5, abs=1e-5), i
 
 
+@pytest.mark.parametrize("mu,x,s,mu0,s0", [
+    ([-2.637, -1.132], [-1.88, 2.23], [1.0, 1.0], [0.0, 0.0], [1.0, 1.0]),        # test/BasicContMuvParameter.jl:235-281
+    ([5.59, -7.25], [4.11, 8.17], [1.0, 1.0], [0.0, 0.0], [1.0, 1.0]),            # :328-396
+    ([4.21, 7.91], [-3.1, -2.52], [2.0, 1.0], [1.0, 2.5], [3.0, 5.0]),            # :402-449
+    ([6.69, -3.125], [5.43, 9.783], [1.0, 1.0], [0.0, 0.0], [1.0, 1.0]),          # :458-530
+])
+def test_likelihood_prior_closures_normal_normal_kats(mu, x, s, mu0, s0):
+    """The reference's own known answers for a parameter built from loglikelihood / logprior (and their gradient) closures:
+    ll = logpdf(MvNormal(mu, S), x), lp = logpdf(MvNormal(mu0, S0), mu), lt = ll + lp, gll = S^-1 (x - mu), glp = -S0^-1 (mu - mu0),
+    glt = gll + glp (`isapprox` in the reference).  Here: the closures as C text (tests/cases.py), compiled for the host exactly as
+    the device compiles them, the composition supplied by klara_custom_compose.h (BasicContMuvParameter.jl:184-189); reference
+    values from SciPy's multivariate normal."""
+    import ctypes as C
+    t = cases.normal_normal_target(x, s, mu0, s0)
+    assert t.has_parts
+    lib, lt_ptr, grad_ptr = O.compile_user_target(t.source, 2)
+    mu = np.array(mu, float); data = t.data
+    dp = C.POINTER(C.c_double)
+    for f in (lib.klara_user_loglikelihood, lib.klara_user_logprior, lib.klara_user_logtarget):
+        f.restype = C.c_double; f.argtypes = [dp, C.c_int, dp, C.c_longlong]
+    for f in (lib.klara_user_gradloglikelihood, lib.klara_user_gradlogprior, lib.klara_user_gradlogtarget):
+        f.restype = None; f.argtypes = [dp, C.c_int, dp, C.c_longlong, dp]
+    a = lambda v: v.ctypes.data_as(dp)
+    ll = lib.klara_user_loglikelihood(a(mu), 2, a(data), data.size); lp = lib.klara_user_logprior(a(mu), 2, a(data), data.size)
+    lt = lib.klara_user_logtarget(a(mu), 2, a(data), data.size)
+    gll, glp, glt = np.zeros(2), np.zeros(2), np.zeros(2)
+    lib.klara_user_gradloglikelihood(a(mu), 2, a(data), data.size, a(gll)); lib.klara_user_gradlogprior(a(mu), 2, a(data), data.size, a(glp))
+    lib.klara_user_gradlogtarget(a(mu), 2, a(data), data.size, a(glt))
+    ref_ll = stats.multivariate_normal(mu, np.diag(s)).logpdf(x); ref_lp = stats.multivariate_normal(mu0, np.diag(s0)).logpdf(mu)
+    assert math.isclose(ll, ref_ll, rel_tol=1e-13) and math.isclose(lp, ref_lp, rel_tol=1e-13)
+    assert lt == ll + lp                                                     # the composition is the sum of the two parts, bit for bit
+    assert np.allclose(gll, (np.array(x) - mu) / np.array(s), rtol=1e-15) and np.allclose(glp, -(mu - np.array(mu0)) / np.array(s0), rtol=1e-15)
+    assert np.array_equal(glt, gll + glp)
+    # and through the oracle's target evaluation (what the samplers call)
+    job = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=L.TARGET_CUSTOM, nchains=1, ndims=2, nsteps=1, custom_src=t.source, custom_data=t.data)
+    lt2, g2 = job.eval_target(mu)
+    assert lt2 == lt and np.array_equal(g2, glt)
+
+
 def test_tuner_cadence_and_counters():
     """samplers.jl:29-45: totproposed starts at period => exactly burnin/period tuning events
     (10 for 1000/100); after burn-in `proposed` keeps growing (iterate/MALA.jl:130-152)."""
