@@ -15,7 +15,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def test_library_exports_every_declared_symbol(klib):
     header = (ROOT / "include" / "klara_hip.h").read_text()
     # (klara_user_*: the two functions a user-defined target's source defines, named in a comment — not library symbols)
-    declared = set(re.findall(r"\b(klara_[a-z0-9_]+)\s*\(", header)) - {"klara_status", "klara_user_logtarget", "klara_user_gradlogtarget"}
+    declared = {n for n in re.findall(r"\b(klara_[a-z0-9_]+)\s*\(", header) if not n.startswith("klara_user_")} - {"klara_status"}
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(klib, name), name
