@@ -61,6 +61,54 @@ def test_desc_fields_agree_across_header_ctypes_and_julia_stub():
     assert all(f"{n}::{t}" in integ for n, t in jfields)
 
 
+def test_julia_job_constructor_maps_klara_structs_to_the_descriptor():
+    """julia/KlaraHIP.jl cannot run here (no Julia), so what can drift is checked mechanically:
+    (1) klara_desc(; ...) takes every field of the struct by keyword and passes them positionally in struct order;
+    (2) the HIPMCJob constructor reads Klara's own field names — the ones the reference's structs declare (citations in the
+        stub) — and sets only descriptor fields that exist;
+    (3) every ccall passes as many arguments as its signature tuple names, with the argument count of the C prototype;
+    (4) the constants mirror the header."""
+    import re
+    jl = (ROOT / "julia" / "KlaraHIP.jl").read_text()
+    fields = [n for n, _ in L.KlaraDesc._fields_]
+    # (1)
+    sig = jl[jl.index("function klara_desc(;") + len("function klara_desc(;"):]
+    body = sig[sig.index("KlaraDesc(UInt32(sizeof(KlaraDesc)), KLARA_ABI_VERSION,"):]
+    sig = sig[:sig.index(")\n    KlaraDesc(")]
+    kws = re.findall(r"([A-Za-z_0-9]+)=", re.sub(r"\([^()]*\)", "", sig))
+    assert kws == fields[2:], (kws, fields[2:])
+    pos = body[len("KlaraDesc(UInt32(sizeof(KlaraDesc)), KLARA_ABI_VERSION,"):body.index(")\nend")]
+    assert [a.strip() for a in pos.replace("\n", " ").split(",")] == fields[2:]
+    # (2) Klara field names (reference file:line as cited in the stub) and descriptor keys
+    ctor = jl[jl.index("function HIPMCJob(parameter::HIPParameter"):jl.index("# raw form for callers")]
+    for klara_field in ("sampler.driftstep", "sampler.leapstep", "sampler.nleaps", "sampler.widths", "sampler.stepout", "sampler.setproposal",
+                        "sampler.symmetric", "sampler.normalised", "tn.period", "tn.verbose", "tn.targetrate", "tn.score", "tn.nadapt",
+                        "tn.ε0bar", "tn.h0bar", "tn.γ", "tn.t0", "tn.κ", "mcrange.nsteps", "mcrange.burnin", "mcrange.thinning"):
+        assert klara_field in ctor, klara_field
+    assert "job.range.npoststeps" in jl and "job.range.postrange" in jl and "job.range.nsteps" in jl
+    keys = set(re.findall(r"kw\[:([A-Za-z_0-9]+)\]", ctor)) | set(re.findall(r":([A-Za-z_0-9]+) =>", ctor[:ctor.index("# --- sampler")]))
+    assert keys <= set(fields), keys - set(fields)
+    assert {"sampler", "target", "tuner", "nchains", "ndims", "nsteps", "burnin", "thinning", "monitor", "seed", "driftstep", "leapstep",
+            "nleaps", "mh_sigma", "slice_widths", "slice_stepout", "targetrate", "period", "verbose", "da_nadapt", "gauss_prec", "logit_X",
+            "hier_Y", "custom_src"} <= keys
+    # NState fields the output() fills (nstates/ParameterNStates/BasicContMuvParameterNState.jl:1-21)
+    for f in ("ns.value", "ns.logtarget", "ns.gradlogtarget", "ns.loglikelihood", "ns.logprior", "ns.diagnosticvalues"):
+        assert f in jl, f
+    # (3) ccall arity against the header's prototypes
+    hdr = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "klara_hip.h").read_text(), flags=re.S)
+    proto = {m.group(1): len([a for a in m.group(2).split(",") if a.strip() and a.strip() != "void"])
+             for m in re.finditer(r"\b(klara_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr)}
+    for m in re.finditer(r"ccall\(\(:(klara_[a-z_0-9]+), lib\), (\w+), \(([^()]*(?:\{[^()]*\}[^()]*)*)\),", jl):
+        name, argt = m.group(1), m.group(3)
+        n = len([a for a in re.split(r",\s*(?![^{}]*\})", argt) if a.strip()])
+        assert proto[name] == n, (name, proto[name], n)
+    # (4)
+    for name, val in (("SAMPLER_MH", L.SAMPLER_MH), ("SAMPLER_SLICE", L.SAMPLER_SLICE), ("TARGET_CUSTOM", L.TARGET_CUSTOM),
+                      ("TUNER_DUAL_AVERAGING", L.TUNER_DUAL_AVERAGING), ("TUNE_POOLED", L.TUNE_POOLED)):
+        assert re.search(name + r"[^\n]*Int32\(" + str(val) + r"\)", jl), name
+    assert "MON_ACCEPT, MON_HISTORY, MON_SUMMARIES, MON_HIST_LT, MON_HIST_GRAD, MON_HIST_LLLP = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20" in jl
+
+
 def test_julia_stub_binds_only_declared_symbols():
     import re
     jl = (ROOT / "julia" / "KlaraHIP.jl").read_text()
