@@ -84,7 +84,9 @@ def compile_user_target(src: str, ndims: int):
     out.mkdir(exist_ok=True)
     so, c = out / f"user_{key}.so", out / f"user_{key}.c"
     if not so.exists():
-        c.write_text(f'#include "detmath.h"\n#define KLARA_D {int(ndims)}\n#define KLARA_USER_FN\n#line 1 "klara_user_target"\n{src}\n'
+        # (a likelihood + prior source without gradient closures — an MH / slice job — gets no composed gradient, as on the device)
+        nograd = "#define KLARA_CUSTOM_NOGRAD 1\n" if ("KLARA_USER_LIKELIHOOD_PRIOR" in src and "klara_user_gradloglikelihood" not in src) else ""
+        c.write_text(f'#include "detmath.h"\n#define KLARA_D {int(ndims)}\n#define KLARA_USER_FN\n{nograd}#line 1 "klara_user_target"\n{src}\n'
                      '#line 1 "klara_custom_glue"\n#include "klara_custom_compose.h"\n')      # (likelihood + prior form: same composition as the device)
         r = subprocess.run(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-shared", "-I", str(ROOT / "klara.jl_amd" / "csrc"),
                             "-o", str(so), str(c), "-lm"], capture_output=True, text=True)

@@ -820,8 +820,8 @@ def test_streaming_batch_means(name, batchlen, streams):
     assert onb == nb and np.array_equal(bm, obm)
     posthoc = eng.chain_mcvar(batchlen, 0)[1]              # k_chain_stats over the history: first nb*batchlen samples, two-pass
     assert np.allclose(bm, posthoc, rtol=1e-8, atol=1e-24)   # (a chain that never moved: 0 against rounding noise of 1e-32)
-    # reset clears the accumulators; other launch boundaries, same batches
-    eng.reset(xstart); eng.run(c["nsteps"])
+    # set_state clears the accumulators and keeps the stream (a replay); other launch boundaries, same batches
+    eng.set_state(xstart); eng.run(c["nsteps"])
     bm2, nb2 = eng.chain_bm()
     assert nb2 == nb and np.array_equal(bm2, bm)
     eng.close()
