@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define KLARA_ABI_VERSION 2
+#define KLARA_ABI_VERSION 3
 /* klara_desc.steps_per_launch = 0 selects this many transitions per kernel launch (launches also end at the pooled tuner's
  * events and at batch boundaries of the streaming batch means, whichever comes first) */
 #define KLARA_DEFAULT_STEPS_PER_LAUNCH 32
@@ -184,6 +184,15 @@ typedef struct klara_desc {
                                     every bm_batchlen saved samples a batch of every (chain, dimension) series is closed on
                                     device; klara_get_chain_bm then gives mcvar(:bm) (mcvar.jl:35-41) with no stored history */
 
+    int64_t  hist_ring_cols;     /* > 0: the history monitors (value / logtarget / gradlogtarget / loglikelihood, logprior) keep only
+                                    the LAST hist_ring_cols saved steps (a ring): bounded memory for jobs that drain the samples as
+                                    they go (the :iostream destination with :flush, jobs.jl:17-29).  0: every saved step is kept. */
+    int32_t  acov_maxlag;        /* > 0: lagged cross-products of every (chain, dimension) series are accumulated while sampling
+                                    (lags 0..acov_maxlag, at most 31), so that Geyer's initial monotone / positive sequence estimators
+                                    (mcvar(:imse | :ipse, maxlag), mcvar.jl:75-105,137-158) need no stored history:
+                                    klara_get_chain_acov_mcvar.  Uses a value ring of its own when no history monitor is on. */
+    int32_t  reserved0;          /* 0 */
+
     uint64_t seed;               /* Philox key                                                       */
     uint32_t monitor;            /* KLARA_MON_* bits                                                 */
     int32_t  steps_per_launch;   /* transitions fused in one kernel launch (>=1; 0 = library default) */
@@ -254,7 +263,9 @@ klara_status klara_gather_summaries(klara_handle* h, klara_comm* comm, double* s
                                     uint64_t* ntransitions, uint64_t* nsamples, uint64_t* nchains);
 
 /* one chain of the stored history in Klara's NState layout: value[d + D*i], i = saved step
- * (BasicContMuvParameterNState.jl:89-119); requires KLARA_MON_HISTORY. */
+ * (BasicContMuvParameterNState.jl:89-119); requires KLARA_MON_HISTORY.  With klara_desc.hist_ring_cols > 0 the columns are the
+ * last min(saved, hist_ring_cols) saved steps, oldest first, and *ncols_out is that count (klara_get_chain_fields and
+ * klara_get_chain_likelihood_prior likewise); klara_saved_steps tells how many steps have been saved in all. */
 klara_status klara_get_chain(klara_handle* h, int64_t local_chain, double* value, int64_t capacity_cols,
                              int64_t* ncols_out);
 /* the other monitored NState fields of one chain (BasicContMuvParameterNState.jl:1-21): logtarget[i] (n values,
@@ -270,11 +281,21 @@ klara_status klara_get_chain_likelihood_prior(klara_handle* h, int64_t local_cha
  * ess = n * iid / imse and iact = imse / iid (src/stats/convergence/{ess,iact}.jl:3) follow on the host. */
 klara_status klara_get_chain_mcvar(klara_handle* h, int64_t batchlen, int64_t maxlag, double* mcvar_iid,
                                    double* mcvar_bm, double* mcvar_imse);
+/* Streaming form of mcvar(v, Val{:imse}, maxlag) / mcvar(v, Val{:ipse}, maxlag) (mcvar.jl:75-105, 137-158) for klara_desc.acov_maxlag > 0
+ * (maxlag = acov_maxlag): the empirical autocovariances autocov(v, 0:maxlag) (StatsBase, demean = true) of every series are
+ * formed exactly from the lagged cross-products, the first and the last maxlag samples and the total, all kept while sampling
+ * (3 (maxlag + 1) doubles per series), then Geyer's truncation.  Each output is nchains x ndims or NULL.  Also available post hoc
+ * from a stored history: klara_get_chain_mcvar (imse) and klara_get_chain_mcvar_ipse. */
+klara_status klara_get_chain_acov_mcvar(klara_handle* h, double* mcvar_imse, double* mcvar_ipse, int64_t* nsamples_out);
+/* Geyer's initial positive sequence estimator over the stored history (mcvar.jl:137-158), maxlag <= 0: n - 1 */
+klara_status klara_get_chain_mcvar_ipse(klara_handle* h, int64_t maxlag, double* mcvar_ipse);
 /* Streaming form of mcvar(v, Val{:bm}) (src/stats/variance/mcvar.jl:35-41: batchlen * var(batch means) / (nbatches *
  * batchlen)) for klara_desc.bm_batchlen > 0: batch means are formed from the running sums at every batch boundary and
  * their mean / sum of squared deviations are updated in place (Welford), so no history is stored — 3 x nchains x ndims
  * doubles however long the run.  mcvar_bm is nchains x ndims (NaN while fewer than two batches are closed). */
 klara_status klara_get_chain_bm(klara_handle* h, double* mcvar_bm, int64_t* nbatches_out);
+/* saved (post-burn-in, thinned) steps so far */
+klara_status klara_saved_steps(klara_handle* h, int64_t* nsaved_out);
 /* tuner state per chain (tuners.jl:5-10). In pooled mode every chain reports the shared state. */
 klara_status klara_get_tune(klara_handle* h, double* step, int64_t* accepted, int64_t* proposed,
                             int64_t* totproposed);

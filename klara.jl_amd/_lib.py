@@ -13,7 +13,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libklara_hip.so"
 
-KLARA_ABI_VERSION = 2
+KLARA_ABI_VERSION = 3
 DEFAULT_STEPS_PER_LAUNCH = 32     # KLARA_DEFAULT_STEPS_PER_LAUNCH
 
 # klara_status
@@ -49,6 +49,7 @@ class KlaraDesc(C.Structure):
         ("hier_Y", _dp), ("hier_xc", _dp), ("hier_nunits", C.c_int32), ("hier_ntimes", C.c_int32),
         ("hier_prior_prec", C.c_double), ("hier_gamma_a", C.c_double), ("hier_gamma_b", C.c_double),
         ("custom_src", C.c_char_p), ("custom_data", _dp), ("custom_ndata", C.c_int64), ("bm_batchlen", C.c_int64),
+        ("hist_ring_cols", C.c_int64), ("acov_maxlag", C.c_int32), ("reserved0", C.c_int32),
         ("seed", C.c_uint64), ("monitor", C.c_uint32), ("steps_per_launch", C.c_int32),
         ("stream", C.c_void_p),
     ]
@@ -72,7 +73,7 @@ EXPORTS = [
     "klara_create", "klara_destroy", "klara_set_state", "klara_init_state_normal", "klara_run",
     "klara_run_async", "klara_synchronize", "klara_reset", "klara_stream_key", "klara_get_state", "klara_get_accept_mask",
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
-    "klara_get_chain_fields", "klara_get_chain_likelihood_prior", "klara_get_chain_mcvar", "klara_get_chain_bm", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
+    "klara_get_chain_fields", "klara_get_chain_likelihood_prior", "klara_get_chain_mcvar", "klara_get_chain_mcvar_ipse", "klara_get_chain_acov_mcvar", "klara_saved_steps", "klara_get_chain_bm", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout",
     "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_normal_tail", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
     "klara_comm_unique_id", "klara_comm_init", "klara_comm_destroy", "klara_gather_summaries",
     "klara_check_custom_target", "klara_compile_log", "klara_selftest_plan", "klara_abi_version",
@@ -130,6 +131,9 @@ def load() -> C.CDLL:
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "klara_check_custom_target": [C.c_char_p, C.c_int32, C.c_int32],
         "klara_get_chain_bm": [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
+        "klara_get_chain_acov_mcvar": [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
+        "klara_get_chain_mcvar_ipse": [C.c_void_p, C.c_int64, C.c_void_p],
+        "klara_saved_steps": [C.c_void_p, C.POINTER(C.c_int64)],
         "klara_selftest_plan": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.POINTER(C.c_int64)],
     }

@@ -274,10 +274,16 @@ def mcvar_iid(chains: MuvChains) -> np.ndarray:
 
 def chain_mcvar(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, maxlag: int = 0) -> np.ndarray:
     """mcvar(s, Val{vtype}) for EVERY chain and dimension at once, computed on device over the stored history
-    (stats/variance/mcvar.jl:5,35-41,75-105).  Returns (nchains x D); vtype in {"iid", "bm", "imse"}."""
+    (stats/variance/mcvar.jl:5,35-41,75-105,137-158) — or, for "bm" / "imse" / "ipse", from what a job with bm_batchlen / acov_maxlag
+    accumulated while sampling.  Returns (nchains x D); vtype in {"iid", "bm", "imse", "ipse"}."""
     job = chains._job
     if vtype == "bm" and job.bm_batchlen == batchlen and not (job.engine.monitor & L.MON_HISTORY):
         return job.engine.chain_bm()[0]            # streaming batch means: no history was stored
+    if vtype in ("imse", "ipse") and job.acov_maxlag > 0 and maxlag in (0, job.acov_maxlag) and not (job.engine.monitor & L.MON_HISTORY):
+        imse, ipse, _ = job.engine.chain_acov_mcvar(want=(vtype,))   # autocovariances kept while sampling: no history either
+        return imse if vtype == "imse" else ipse
+    if vtype == "ipse":
+        return job.engine.chain_mcvar_ipse(maxlag)
     return job.engine.chain_mcvar(batchlen, maxlag, want=(vtype,))[{"iid": 0, "bm": 1, "imse": 2}[vtype]]
 
 
@@ -324,13 +330,14 @@ class BasicMCJob:
     outopts keys follow jobs.jl:9-43: destination in {"nstate", "none"}, monitor (["value"]),
     diagnostics ([] or ["accept"]).  Extra keyword arguments pick the shard: `chain_offset` (global id of
     the first chain), `device`, `seed` (default: a fresh key per job, see "random streams of jobs" above), `steps_per_launch`; `bm_batchlen` > 0 keeps streaming batch means so that
-    `chain_mcvar(chain, "bm", bm_batchlen)` needs no stored history (destination "none").
+    `chain_mcvar(chain, "bm", bm_batchlen)` needs no stored history (destination "none"); `acov_maxlag` > 0 does the same for
+    `chain_mcvar(chain, "imse" | "ipse", maxlag=acov_maxlag)` (autocovariances accumulated while sampling).
     """
 
     def __init__(self, model: GenericModel, sampler: MCSampler, mcrange: BasicMCRange, v0: Dict[str, Sequence],
                  tuner: Optional[MCTuner] = None, outopts: Optional[dict] = None, *, seed: Optional[int] = None,
                  chain_offset: int = 0, device: int = 0, steps_per_launch: int = 0, summaries: bool = True,
-                 bm_batchlen: int = 0):
+                 bm_batchlen: int = 0, acov_maxlag: int = 0):
         self.model, self.sampler, self.range = model, sampler, mcrange
         self.seed = _next_job_seed() if seed is None else int(seed)
         seed = self.seed
@@ -346,6 +353,9 @@ class BasicMCJob:
             self.outopts.setdefault("filepath", "")
             self.outopts.setdefault("filesuffix", "csv")
             self.outopts.setdefault("flush", False)
+            # saved steps held on the device between two writes (a ring of that many columns): the sink streams, as the
+            # reference's does (one write per saved step), instead of keeping the whole run in memory
+            self.outopts.setdefault("chunk", 256)
         params = [v for v in model.vertices if isinstance(v, BasicContMuvParameter)]
         if len(params) != 1:
             raise ValueError("model must hold exactly one BasicContMuvParameter")
@@ -379,8 +389,10 @@ class BasicMCJob:
         kw = dict(sampler=sampler.kind, target=self.parameter.target, nchains=nchains, nsteps=mcrange.nsteps,
                   burnin=mcrange.burnin, thinning=mcrange.thinning, tuner=self.tuner.kind,
                   period=self.tuner.period, verbose=self.tuner.verbose, seed=seed, chain_offset=chain_offset,
-                  device=device, monitor=monitor, steps_per_launch=steps_per_launch, bm_batchlen=int(bm_batchlen))
-        self.bm_batchlen = int(bm_batchlen)
+                  device=device, monitor=monitor, steps_per_launch=steps_per_launch, bm_batchlen=int(bm_batchlen),
+                  acov_maxlag=int(acov_maxlag),
+                  hist_ring_cols=int(self.outopts["chunk"]) if self.outopts["destination"] == "iostream" else 0)
+        self.bm_batchlen, self.acov_maxlag = int(bm_batchlen), int(acov_maxlag)
         if isinstance(sampler, MH):
             kw["mh_sigma"] = sampler.sigma
         elif isinstance(sampler, MALA):
@@ -416,32 +428,51 @@ def run(job):
     """run(job::BasicMCJob) — BasicMCJob.jl:212-244; run(jobs::Vector) = map(run, jobs) — jobs.jl:212."""
     if isinstance(job, (list, tuple)):
         return [run(j) for j in job]
-    job.engine.run(job.range.nsteps)
-    job._ran = True
     if job.outopts["destination"] == "iostream":
-        _write_iostream(job)
+        _run_to_iostream(job)
+    else:
+        job.engine.run(job.range.nsteps)
+    job._ran = True
     return job
 
 
-def _write_iostream(job: "BasicMCJob") -> None:
-    """:destination => :iostream — CSV files per monitored field (jobs.jl:193-202; BasicContParamIOStream.jl:152-159)."""
-    from .iostream import write_chain
+def _run_to_iostream(job: "BasicMCJob") -> None:
+    """:destination => :iostream — CSV files per monitored field (jobs.jl:193-202; BasicContParamIOStream.jl:152-159), written
+    WHILE the job runs: the device keeps a ring of outopts["chunk"] saved steps, the loop below runs until the ring is full (or
+    the job is done), appends those steps to every chain's files and, with :flush, flushes them (jobs.jl:17-29) — the memory a
+    long job needs does not grow with its length."""
+    from .iostream import ChainWriter
     eng = job.engine
     base = job.outopts.get("filepath", "") or "."
     suffix = job.outopts.get("filesuffix", "csv")
-    acc = None
-    if eng.monitor & L.MON_ACCEPT:
-        m = eng.accept_mask()
-        post = np.asarray(job.range.postrange) - 1
-        acc = m[post[post < m.shape[0]]]
+    chunk, thin = int(job.outopts["chunk"]), job.range.thinning
+    has_v, has_lt, has_g = bool(eng.monitor & L.MON_HISTORY), bool(eng.monitor & L.MON_HIST_LT), bool(eng.monitor & L.MON_HIST_GRAD)
+    has_acc = bool(eng.monitor & L.MON_ACCEPT)
     width = len(str(eng.nchains))
-    for c in range(eng.nchains):
-        d = base if eng.nchains == 1 else os.path.join(base, f"chain_{c + 1:0{width}d}")
-        value = eng.chain(c) if eng.monitor & L.MON_HISTORY else None
-        lt, g = (None, None)
-        if eng.monitor & (L.MON_HIST_LT | L.MON_HIST_GRAD):
-            lt, g = eng.chain_fields(c, bool(eng.monitor & L.MON_HIST_LT), bool(eng.monitor & L.MON_HIST_GRAD))
-        write_chain(d, suffix, value, lt, g, None if acc is None else acc[:, c])
+    writers = [ChainWriter(base if eng.nchains == 1 else os.path.join(base, f"chain_{c + 1:0{width}d}"), suffix, has_v, has_lt, has_g, has_acc)
+               for c in range(eng.nchains)]
+    post = np.asarray(job.range.postrange) - 1                    # 0-based transition index of every saved step
+    written, done = 0, 0
+    try:
+        while done < job.range.nsteps:
+            # transitions until `chunk` more steps have been saved (none are saved during burn-in)
+            k = min(job.range.nsteps - done, max(1, (job.range.burnin - done) if done < job.range.burnin else chunk * thin))
+            eng.run(k); done += k
+            new = eng.saved_steps() - written
+            if new <= 0:
+                continue
+            assert new <= chunk
+            acc = eng.accept_mask()[post[written:written + new]] if has_acc else None
+            for c, w in enumerate(writers):
+                value = eng.chain(c)[:, -new:] if has_v else None
+                lt, g = eng.chain_fields(c, has_lt, has_g) if (has_lt or has_g) else (None, None)
+                w.append(value, None if lt is None else lt[-new:], None if g is None else g[:, -new:], None if acc is None else acc[:, c])
+                if job.outopts.get("flush", False):
+                    w.flush()
+            written += new
+    finally:
+        for w in writers:
+            w.close()
 
 
 def output(job: BasicMCJob) -> MuvChains:

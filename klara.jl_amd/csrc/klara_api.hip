@@ -37,7 +37,10 @@ struct klara_handle {
     unsigned long long* naccept = nullptr;
     double *sum = nullptr, *sumsq = nullptr;
     long long* held = nullptr;      // running sums in sojourn form: saved steps at the current state not yet in sum / sumsq (KParams::held)
-    double* hist = nullptr; long long hist_cols = 0;
+    double* hist = nullptr; long long hist_cols = 0;     // hist_cols: columns of the history buffers (= ring when > 0 and ring is set)
+    bool ring = false;                                   // the history buffers hold the last hist_cols saved steps only
+    // streaming autocovariances (acov_maxlag > 0): W = maxlag + 1 lags; [k][series] layouts
+    int acov_W = 0; double *acov_S = nullptr, *acov_head = nullptr, *acov_tail = nullptr, *acov_total = nullptr; long long acov_n = 0;
     double *hist_lt = nullptr, *hist_g = nullptr, *hist_ll = nullptr, *hist_lp = nullptr;
     int* err = nullptr;
     double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr,
@@ -187,6 +190,7 @@ static klara_status validate(const klara_desc* d)
         return KLARA_ERR_INVALID_ARG;
     if (d->target == KLARA_TARGET_CUSTOM && (!d->custom_src || d->custom_ndata < 0 || (d->custom_ndata > 0 && !d->custom_data)))
         return KLARA_ERR_INVALID_ARG;
+    if (d->hist_ring_cols < 0 || d->acov_maxlag < 0 || d->acov_maxlag > 31 || d->reserved0 != 0) return KLARA_ERR_INVALID_ARG;
     if (d->bm_batchlen < 0 || (d->bm_batchlen > 0 && !(d->monitor & KLARA_MON_SUMMARIES))) return KLARA_ERR_INVALID_ARG;
     if (d->steps_per_launch < 0 || d->tuner_score < 0 || d->tuner_score > 1) return KLARA_ERR_INVALID_ARG;   // (int32: a launch length always fits KLaunch::nsteps)
     return KLARA_OK;
@@ -206,7 +210,7 @@ static void free_all(klara_handle* h)
 {
     hipFree(h->X); hipFree(h->GR); hipFree(h->LT); hipFree(h->tune_step); hipFree(h->tune_acc);
     hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->da_epsbar); hipFree(h->da_hbar); hipFree(h->pooled_acc); hipFree(h->accept);
-    hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->held); hipFree(h->hist); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->hist_ll); hipFree(h->hist_lp); hipFree(h->err);
+    hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->held); hipFree(h->hist); hipFree(h->acov_S); hipFree(h->acov_head); hipFree(h->acov_tail); hipFree(h->acov_total); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->hist_ll); hipFree(h->hist_lp); hipFree(h->err);
     hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
     hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->pool_partial); hipFree(h->d_params); hipFree(h->cdata);
     hipFree(h->bm_prev); hipFree(h->bm_mean); hipFree(h->bm_m2);
@@ -281,6 +285,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         if (desc->nstreams >= 1 && desc->nstreams <= 4) np = desc->nstreams;
         if (const char* s = getenv("KLARA_STREAMS")) { const int v = atoi(s); if (v >= 1 && v <= 4) np = v; }
         if (desc->tuner_mode == KLARA_TUNE_POOLED) np = 1;     // the pooled tuner update sits between launches, on one stream
+        if (desc->acov_maxlag > 0) np = 1;                     // ... and so does the consumer of the launch's saved samples
         if (np > groups) np = (int)groups;
         h->nparts = np;
         if (np > 1) CKH(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
@@ -305,10 +310,20 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     if ((desc->monitor & KLARA_MON_HIST_LLLP) && (desc->target != KLARA_TARGET_CUSTOM || !strstr(desc->custom_src, "KLARA_USER_LIKELIHOOD_PRIOR"))) {
         free_all(h); delete h; return KLARA_ERR_INVALID_ARG;           // only a likelihood + prior user target has the two parts
     }
-    if (desc->monitor & (KLARA_MON_HISTORY | KLARA_MON_HIST_LT | KLARA_MON_HIST_GRAD | KLARA_MON_HIST_LLLP)) {
+    const bool acov = desc->acov_maxlag > 0;
+    if ((desc->monitor & (KLARA_MON_HISTORY | KLARA_MON_HIST_LT | KLARA_MON_HIST_GRAD | KLARA_MON_HIST_LLLP)) || acov) {
         // npoststeps = length((burnin+1):thinning:nsteps)  (BasicMCRange.jl:26)
         h->hist_cols = (desc->nsteps - desc->burnin - 1) / desc->thinning + 1;
-        if (desc->monitor & KLARA_MON_HISTORY) CKH(dalloc(&h->hist, (size_t)h->hist_cols * N * D));
+        long long ringc = desc->hist_ring_cols;
+        if (acov && !(desc->monitor & KLARA_MON_HISTORY) && ringc == 0) ringc = 32;     // the estimator's own value ring
+        if (acov) { h->d.monitor |= KLARA_MON_HISTORY; h->d.hist_ring_cols = ringc; }   // (the kernels save values; ring_cols(h->d) == ringc)
+        if (ringc > 0 && ringc < h->hist_cols) { h->hist_cols = ringc; h->ring = true; }
+        if ((desc->monitor & KLARA_MON_HISTORY) || acov) CKH(dalloc(&h->hist, (size_t)h->hist_cols * N * D));
+        if (acov) {
+            h->acov_W = desc->acov_maxlag + 1;
+            const size_t ws = (size_t)h->acov_W * N * D;
+            CKH(dalloc(&h->acov_S, ws)); CKH(dalloc(&h->acov_head, ws)); CKH(dalloc(&h->acov_tail, ws)); CKH(dalloc(&h->acov_total, N * D));
+        }
         if (desc->monitor & KLARA_MON_HIST_LT) CKH(dalloc(&h->hist_lt, (size_t)h->hist_cols * N));
         if (desc->monitor & KLARA_MON_HIST_LLLP) { CKH(dalloc(&h->hist_ll, (size_t)h->hist_cols * N)); CKH(dalloc(&h->hist_lp, (size_t)h->hist_cols * N)); }
         if (desc->monitor & KLARA_MON_HIST_GRAD) {
@@ -329,7 +344,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     } else if (desc->target == KLARA_TARGET_CUSTOM) {
         if (desc->custom_ndata > 0) CK(upload(&h->cdata, desc->custom_data, (size_t)desc->custom_ndata));
         int modes[2];
-        const int nmodes = kernel_modes(*desc, modes);
+        const int nmodes = kernel_modes(h->d, modes);           // (h->d: the monitor word with what the library turned on itself)
         CK(klara_jit_create(desc->custom_src, desc->sampler, desc->ndims, E, modes, nmodes, true, &h->jit));
     } else if (desc->target == KLARA_TARGET_LOGISTIC) {
         CK(upload(&h->lX, desc->logit_X, (size_t)desc->logit_ndata * D));
@@ -508,6 +523,12 @@ static klara_status init_common(klara_handle* h)
         HIPCHK(hipMemsetAsync(h->bm_m2, 0, N * D * sizeof(double), st));
     }
     h->bm_count = 0;
+    if (h->acov_S) {
+        const size_t ws = (size_t)h->acov_W * N * D * sizeof(double);
+        HIPCHK(hipMemsetAsync(h->acov_S, 0, ws, st)); HIPCHK(hipMemsetAsync(h->acov_head, 0, ws, st)); HIPCHK(hipMemsetAsync(h->acov_tail, 0, ws, st));
+        HIPCHK(hipMemsetAsync(h->acov_total, 0, N * D * sizeof(double), st));
+    }
+    h->acov_n = 0;
     // tuner_state: samplers.jl:29-45 — step per sampler, accepted = proposed = 0, totproposed = period
     const double step0 = d.sampler == KLARA_SAMPLER_MH ? 1.0
                        : d.sampler == KLARA_SAMPLER_MALA ? d.driftstep
@@ -698,7 +719,23 @@ static hipError_t launch_bm_close(klara_handle* h)
 // closes (streaming batch means), whichever comes first; plus the save-rule bookkeeping the kernels take from the host
 // (BasicMCRange.jl:36 postrange = (burnin+1):thinning:nsteps), so that they carry no 64-bit division.
 struct RunCursor { long long steps_done, m_prop, m_tot, bm_count; };
-struct PlannedLaunch { long long k; int save_phase0; long long save_col0; bool tune_after, bm_close_after; };
+struct PlannedLaunch { long long k; int save_phase0; long long save_col0; bool tune_after, bm_close_after; long long saved; };
+
+// columns of the history ring of a job (0: every saved step is kept) — klara_desc.hist_ring_cols, or the 32-column value ring the
+// streaming autocovariances keep for themselves when no value history was asked for
+static long long ring_cols(const klara_desc& d)
+{
+    long long r = d.hist_ring_cols;
+    if (d.acov_maxlag > 0 && !(d.monitor & KLARA_MON_HISTORY) && r == 0) r = 32;
+    const long long npost = (d.nsteps - d.burnin - 1) / d.thinning + 1;
+    return (r > 0 && r < npost) ? r : 0;
+}
+// saved (post-burn-in, thinned) steps among the first `steps` transitions
+static long long saved_upto(const klara_desc& d, long long steps)
+{
+    const long long sd = steps < d.nsteps ? steps : d.nsteps;
+    return sd > d.burnin ? (sd - d.burnin - 1) / d.thinning + 1 : 0;
+}
 
 static PlannedLaunch plan_launch(const klara_desc& d, const RunCursor& c, long long remaining)
 {
@@ -717,10 +754,23 @@ static PlannedLaunch plan_launch(const klara_desc& d, const RunCursor& c, long l
         if (bm_close_at > d.nsteps) bm_close_at = -1;
         else if (bm_close_at > c.steps_done && k > bm_close_at - c.steps_done) k = bm_close_at - c.steps_done;
     }
-    pl.k = k;
     // phase of the first post-burn-in step of this launch and the number of columns already saved
     pl.save_phase0 = c.steps_done >= d.burnin ? (int)((c.steps_done - d.burnin) % d.thinning) : 0;
     pl.save_col0 = c.steps_done > d.burnin ? (c.steps_done - d.burnin - 1) / d.thinning + 1 : 0;
+    // history ring: a launch never wraps — it ends with the last column of the ring at the latest, the kernels get the ring
+    // column of their first saved step (saved sample number S is transition burnin + (S - 1) * thinning + 1)
+    const long long ring = ring_cols(d);
+    if (ring > 0) {
+        const long long room = ring - pl.save_col0 % ring;
+        const long long last_ok = d.burnin + (pl.save_col0 + room - 1) * d.thinning + 1;       // transition of the last sample that fits
+        const long long next = d.burnin + (pl.save_col0 + room) * d.thinning + 1;              // (the one after it would wrap)
+        (void)last_ok;
+        if (c.steps_done + k >= next) k = next - 1 - c.steps_done;
+        if (k < 1) k = 1;
+    }
+    pl.k = k;
+    pl.saved = saved_upto(d, c.steps_done + k) - saved_upto(d, c.steps_done);
+    if (ring > 0) pl.save_col0 %= ring;
     pl.tune_after = pooled_cnt;
     pl.bm_close_after = bm_close_at >= 0 && c.steps_done + k == bm_close_at;
     return pl;
@@ -734,6 +784,107 @@ static void advance_cursor(const klara_desc& d, RunCursor& c, const PlannedLaunc
     }
     c.steps_done += pl.k;
     if (pl.bm_close_after) ++c.bm_count;
+}
+
+// ---- streaming autocovariances (klara_desc.acov_maxlag): after every launch the samples it saved — columns [col0, col0 + m) of
+// the value ring — update, for every (chain, dimension) series, the lagged cross-products S_k = sum_t x_t x_(t-k), k < W, the total,
+// the first W samples and the last W samples (most recent first).  One thread per series, S and the window in registers.
+template <int WMAX>
+__global__ __launch_bounds__(256) void k_acov_update(const double* __restrict__ hist, long long col0, int m, long long n_before, int W,
+                                                     long long nd, double* __restrict__ S, double* __restrict__ head,
+                                                     double* __restrict__ tail, double* __restrict__ total)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nd) return;
+    double s[WMAX], win[WMAX];
+#pragma unroll
+    for (int k = 0; k < WMAX; ++k) { s[k] = k < W ? S[(long long)k * nd + i] : 0.0; win[k] = k < W ? tail[(long long)k * nd + i] : 0.0; }
+    double tot = total[i];
+    for (int j = 0; j < m; ++j) {
+        const double x = hist[(col0 + j) * nd + i];
+        s[0] = s[0] + x * x;
+#pragma unroll
+        for (int k = 1; k < WMAX; ++k) s[k] = s[k] + x * win[k - 1];        // (win holds zeros where no sample exists yet)
+        if (n_before + j < W) head[(n_before + j) * nd + i] = x;
+#pragma unroll
+        for (int k = WMAX - 1; k > 0; --k) win[k] = win[k - 1];
+        win[0] = x;
+        tot = tot + x;
+    }
+#pragma unroll
+    for (int k = 0; k < WMAX; ++k) if (k < W) { S[(long long)k * nd + i] = s[k]; tail[(long long)k * nd + i] = win[k]; }
+    total[i] = tot;
+}
+
+static hipError_t launch_acov_update(klara_handle* h, long long col0, long long m)
+{
+    const long long nd = (long long)h->d.nchains * h->d.ndims;
+    const dim3 grid((unsigned)((nd + 255) / 256)), blk(256);
+    const int W = h->acov_W;
+    if (W <= 8) hipLaunchKernelGGL((k_acov_update<8>), grid, blk, 0, h->stream, h->hist, col0, (int)m, h->acov_n, W, nd, h->acov_S, h->acov_head, h->acov_tail, h->acov_total);
+    else if (W <= 16) hipLaunchKernelGGL((k_acov_update<16>), grid, blk, 0, h->stream, h->hist, col0, (int)m, h->acov_n, W, nd, h->acov_S, h->acov_head, h->acov_tail, h->acov_total);
+    else hipLaunchKernelGGL((k_acov_update<32>), grid, blk, 0, h->stream, h->hist, col0, (int)m, h->acov_n, W, nd, h->acov_S, h->acov_head, h->acov_tail, h->acov_total);
+    return hipGetLastError();
+}
+
+// autocov(v, 0:maxlag) of StatsBase (demean = true) from the streamed sums: with m = total / n,
+//   n acv_k = sum_(t>k) (x_t - m)(x_(t-k) - m) = S_k - m [(total - first k) + (total - last k)] + (n - k) m^2,
+// then Geyer's truncation (mcvar.jl:75-105 imse, :137-158 ipse).
+__global__ __launch_bounds__(256) void k_acov_finalize(const double* __restrict__ S, const double* __restrict__ head, const double* __restrict__ tail,
+                                                       const double* __restrict__ total, long long n, int W, long long nd,
+                                                       double* __restrict__ imse, double* __restrict__ ipse)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nd) return;
+    const double tot = total[i], mean = tot / (double)n;
+    const long long maxlag = (W - 1) < (n - 1) ? (W - 1) : (n - 1);
+    const long long kk = (maxlag - 1) / 2;                       // floor((maxlag-1)/2), mcvar.jl:76
+    double hs = 0.0, ts = 0.0, acv0 = 0.0, gsum_m = 0.0, gsum_p = 0.0, gprev = 0.0;
+    bool stop = false;
+    for (long long j = 0; j <= kk && !stop; ++j) {
+        double pair = 0.0;
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const long long k = 2 * j + h2;
+            // hs / ts = sum of the first / last k samples
+            const double a = (S[k * nd + i] - mean * ((tot - ts) + (tot - hs)) + (double)(n - k) * mean * mean) / (double)n;
+            if (k == 0) acv0 = a;
+            pair += a;
+            hs += head[k * nd + i]; ts += tail[k * nd + i];
+        }
+        if (pair <= 0.0) { stop = true; break; }                 // m = j (mcvar.jl:87-90)
+        gsum_p += pair;
+        double gm = pair;
+        if (j > 0 && gm > gprev) gm = gprev;                     // monotone sequence (mcvar.jl:94-100)
+        gsum_m += gm; gprev = gm;
+    }
+    if (imse) imse[i] = (-acv0 + 2.0 * gsum_m) / (double)n;
+    if (ipse) ipse[i] = (-acv0 + 2.0 * gsum_p) / (double)n;
+}
+
+extern "C" klara_status klara_get_chain_acov_mcvar(klara_handle* h, double* mcvar_imse, double* mcvar_ipse, int64_t* nsamples_out)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->acov_S || !h->have_state || h->acov_n < 2) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    const long long nd = (long long)h->d.nchains * h->d.ndims;
+    double* buf = nullptr;
+    HIPCHK(dalloc(&buf, (size_t)2 * nd));
+    hipLaunchKernelGGL(k_acov_finalize, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, h->stream, h->acov_S, h->acov_head, h->acov_tail,
+                       h->acov_total, h->acov_n, h->acov_W, nd, mcvar_imse ? buf : nullptr, mcvar_ipse ? buf + nd : nullptr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && mcvar_imse) e = hipMemcpy(mcvar_imse, buf, nd * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && mcvar_ipse) e = hipMemcpy(mcvar_ipse, buf + nd, nd * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(buf);
+    if (nsamples_out) *nsamples_out = h->acov_n;
+    return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
+}
+
+extern "C" klara_status klara_saved_steps(klara_handle* h, int64_t* nsaved_out)
+{
+    if (!h || !nsaved_out) return KLARA_ERR_INVALID_ARG;
+    *nsaved_out = h->nsaved;
+    return KLARA_OK;
 }
 
 extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
@@ -766,6 +917,10 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
             err = hipGetLastError();
         }
         if (err == hipSuccess && pl.bm_close_after) err = launch_bm_close(h);   // (reads h->bm_count: batches closed before this one)
+        if (err == hipSuccess && h->acov_S && pl.saved > 0) {                   // streaming autocovariances consume the launch's samples
+            err = launch_acov_update(h, pl.save_col0, pl.saved);
+            h->acov_n += pl.saved;
+        }
         if (err != hipSuccess) break;
         advance_cursor(d, cur, pl);
         h->steps_done = cur.steps_done; h->m_prop = cur.m_prop; h->m_tot = cur.m_tot; h->bm_count = cur.bm_count;
@@ -1083,20 +1238,43 @@ extern "C" klara_status klara_gather_summaries(klara_handle* h, klara_comm* c, d
     return KLARA_OK;
 }
 
+// Columns [first, first + count) of the saved steps from a history buffer whose column c lives at slot c % hist_cols (ring) or c:
+// `width` bytes per column copied to consecutive rows of dst, `stride` bytes between the buffer's columns.
+static hipError_t copy_saved_columns(const klara_handle* h, void* dst, const char* src, size_t width, size_t stride, long long first, long long count)
+{
+    long long done = 0;
+    while (done < count) {
+        const long long slot = h->ring ? (first + done) % h->hist_cols : first + done;
+        long long run = count - done;
+        if (h->ring && slot + run > h->hist_cols) run = h->hist_cols - slot;
+        const hipError_t e = hipMemcpy2D((char*)dst + (size_t)done * width, width, src + (size_t)slot * stride, stride, width, (size_t)run, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        done += run;
+    }
+    return hipSuccess;
+}
+// the saved steps a history read returns: all of them, or the last hist_cols of a ring
+static void saved_window(const klara_handle* h, long long capacity, long long* first, long long* count)
+{
+    const long long avail = h->ring && h->nsaved > h->hist_cols ? h->hist_cols : h->nsaved;
+    *count = avail < capacity ? avail : capacity;
+    *first = h->nsaved - avail;
+}
+
 extern "C" klara_status klara_get_chain(klara_handle* h, int64_t local_chain, double* value,
                                         int64_t capacity_cols, int64_t* ncols_out)
 {
     if (!h || local_chain < 0 || local_chain >= h->d.nchains) return KLARA_ERR_INVALID_ARG;
-    if (!h->hist) return KLARA_ERR_STATE;
+    if (!h->hist || !(h->d.monitor & KLARA_MON_HISTORY)) return KLARA_ERR_STATE;
     HIPCHK(hipSetDevice(h->d.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t N = (size_t)h->d.nchains, D = (size_t)h->d.ndims;
-    const long long n = h->nsaved < capacity_cols ? h->nsaved : capacity_cols;
+    long long first, n;
+    saved_window(h, capacity_cols, &first, &n);
     // device layout [col][chain][D] -> Klara NState.value (D x n) column-major = n contiguous D-vectors
     if (value && n > 0)
-        HIPCHK(hipMemcpy2D(value, D * sizeof(double), h->hist + (size_t)local_chain * D, N * D * sizeof(double),
-                           D * sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
-    if (ncols_out) *ncols_out = h->nsaved;
+        HIPCHK(copy_saved_columns(h, value, (const char*)(h->hist + (size_t)local_chain * D), D * sizeof(double), N * D * sizeof(double), first, n));
+    if (ncols_out) { long long f2, all; saved_window(h, 0x7fffffffffffffffll, &f2, &all); *ncols_out = all; }
     return KLARA_OK;
 }
 
@@ -1108,14 +1286,13 @@ extern "C" klara_status klara_get_chain_fields(klara_handle* h, int64_t local_ch
     HIPCHK(hipSetDevice(h->d.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t N = (size_t)h->d.nchains, D = (size_t)h->d.ndims;
-    const long long n = h->nsaved < capacity_cols ? h->nsaved : capacity_cols;
+    long long first, n;
+    saved_window(h, capacity_cols, &first, &n);
     if (logtarget && n > 0)
-        HIPCHK(hipMemcpy2D(logtarget, sizeof(double), h->hist_lt + (size_t)local_chain, N * sizeof(double),
-                           sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
+        HIPCHK(copy_saved_columns(h, logtarget, (const char*)(h->hist_lt + (size_t)local_chain), sizeof(double), N * sizeof(double), first, n));
     if (gradlogtarget && n > 0)
-        HIPCHK(hipMemcpy2D(gradlogtarget, D * sizeof(double), h->hist_g + (size_t)local_chain * D,
-                           N * D * sizeof(double), D * sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
-    if (ncols_out) *ncols_out = h->nsaved;
+        HIPCHK(copy_saved_columns(h, gradlogtarget, (const char*)(h->hist_g + (size_t)local_chain * D), D * sizeof(double), N * D * sizeof(double), first, n));
+    if (ncols_out) { long long f2, all; saved_window(h, 0x7fffffffffffffffll, &f2, &all); *ncols_out = all; }
     return KLARA_OK;
 }
 
@@ -1127,12 +1304,13 @@ extern "C" klara_status klara_get_chain_likelihood_prior(klara_handle* h, int64_
     HIPCHK(hipSetDevice(h->d.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t N = (size_t)h->d.nchains;
-    const long long n = h->nsaved < capacity_cols ? h->nsaved : capacity_cols;
+    long long first, n;
+    saved_window(h, capacity_cols, &first, &n);
     if (loglikelihood && n > 0)
-        HIPCHK(hipMemcpy2D(loglikelihood, sizeof(double), h->hist_ll + (size_t)local_chain, N * sizeof(double), sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
+        HIPCHK(copy_saved_columns(h, loglikelihood, (const char*)(h->hist_ll + (size_t)local_chain), sizeof(double), N * sizeof(double), first, n));
     if (logprior && n > 0)
-        HIPCHK(hipMemcpy2D(logprior, sizeof(double), h->hist_lp + (size_t)local_chain, N * sizeof(double), sizeof(double), (size_t)n, hipMemcpyDeviceToHost));
-    if (ncols_out) *ncols_out = h->nsaved;
+        HIPCHK(copy_saved_columns(h, logprior, (const char*)(h->hist_lp + (size_t)local_chain), sizeof(double), N * sizeof(double), first, n));
+    if (ncols_out) { long long f2, all; saved_window(h, 0x7fffffffffffffffll, &f2, &all); *ncols_out = all; }
     return KLARA_OK;
 }
 
@@ -1145,7 +1323,7 @@ extern "C" klara_status klara_get_chain_likelihood_prior(klara_handle* h, int64_
 //          pair until the first non-positive pair sum, so the cost is O(n * stopping lag) instead of O(n^2).
 __global__ __launch_bounds__(256) void k_chain_stats(const double* __restrict__ hist, long long ncols, long long N, int D,
                                                      long long batchlen, long long maxlag, double* iid, double* bm,
-                                                     double* imse)
+                                                     double* imse, double* ipse)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * D) return;
@@ -1176,10 +1354,10 @@ __global__ __launch_bounds__(256) void k_chain_stats(const double* __restrict__ 
             bm[i] = (double)batchlen * (sb2 / (double)(nb - 1)) / (double)(nb * batchlen);
         } else bm[i] = NAN;                                   // "Choose batch size such that the number of batches is > 1"
     }
-    if (imse) {
+    if (imse || ipse) {
         const long long ml = maxlag < n - 1 ? maxlag : n - 1;
         const long long k = (ml - 1) / 2;                     // floor((maxlag-1)/2), mcvar.jl:76
-        double gsum = 0.0, gprev = 0.0;
+        double gsum = 0.0, gprev = 0.0, gsum_p = 0.0;
         for (long long j = 0; j <= k; ++j) {
             double a0 = 0.0, a1 = 0.0;
             const long long l0 = 2 * j, l1 = 2 * j + 1;
@@ -1188,10 +1366,12 @@ __global__ __launch_bounds__(256) void k_chain_stats(const double* __restrict__ 
             for (long long t = 0; t + l1 < n; ++t) a1 += (v[t * stride] - m) * (v[(t + l1) * stride] - m);
             double gj = (a0 + a1) / (double)n;
             if (gj <= 0.0) break;                             // m = j (mcvar.jl:87-90)
+            gsum_p += gj;                                     // initial positive sequence (mcvar.jl:137-158): no monotone step
             if (j > 0 && gj > gprev) gj = gprev;              // monotone sequence (mcvar.jl:94-100)
             gsum += gj; gprev = gj;
         }
-        imse[i] = (-acv0 / (double)n + 2.0 * gsum) / (double)n;
+        if (imse) imse[i] = (-acv0 / (double)n + 2.0 * gsum) / (double)n;
+        if (ipse) ipse[i] = (-acv0 / (double)n + 2.0 * gsum_p) / (double)n;
     }
 }
 
@@ -1199,19 +1379,36 @@ extern "C" klara_status klara_get_chain_mcvar(klara_handle* h, int64_t batchlen,
                                               double* mcvar_bm, double* mcvar_imse)
 {
     if (!h) return KLARA_ERR_INVALID_ARG;
-    if (!h->hist || !h->have_state || h->nsaved < 2) return KLARA_ERR_STATE;
+    if (!h->hist || h->ring || !(h->d.monitor & KLARA_MON_HISTORY) || !h->have_state || h->nsaved < 2) return KLARA_ERR_STATE;   // (needs every saved step)
     HIPCHK(hipSetDevice(h->d.device));
     const long long N = h->d.nchains, D = h->d.ndims, total = N * D;
     double* buf = nullptr;
     HIPCHK(dalloc(&buf, (size_t)3 * total));
     hipLaunchKernelGGL(k_chain_stats, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->hist,
                        (long long)h->nsaved, N, (int)D, (long long)batchlen, (long long)(maxlag > 0 ? maxlag : h->nsaved - 1),
-                       mcvar_iid ? buf : nullptr, mcvar_bm ? buf + total : nullptr, mcvar_imse ? buf + 2 * total : nullptr);
+                       mcvar_iid ? buf : nullptr, mcvar_bm ? buf + total : nullptr, mcvar_imse ? buf + 2 * total : nullptr, (double*)nullptr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && mcvar_iid) e = hipMemcpy(mcvar_iid, buf, total * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess && mcvar_bm) e = hipMemcpy(mcvar_bm, buf + total, total * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess && mcvar_imse) e = hipMemcpy(mcvar_imse, buf + 2 * total, total * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(buf);
+    return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
+}
+
+extern "C" klara_status klara_get_chain_mcvar_ipse(klara_handle* h, int64_t maxlag, double* mcvar_ipse)
+{
+    if (!h || !mcvar_ipse) return KLARA_ERR_INVALID_ARG;
+    if (!h->hist || h->ring || !(h->d.monitor & KLARA_MON_HISTORY) || !h->have_state || h->nsaved < 2) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    const long long N = h->d.nchains, D = h->d.ndims, total = N * D;
+    double* buf = nullptr;
+    HIPCHK(dalloc(&buf, (size_t)total));
+    hipLaunchKernelGGL(k_chain_stats, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->hist, (long long)h->nsaved, N, (int)D, 0ll,
+                       (long long)(maxlag > 0 ? maxlag : h->nsaved - 1), (double*)nullptr, (double*)nullptr, (double*)nullptr, buf);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(mcvar_ipse, buf, total * sizeof(double), hipMemcpyDeviceToHost);
     hipFree(buf);
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }

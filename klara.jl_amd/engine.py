@@ -187,7 +187,8 @@ class Engine:
                  da_nadapt: int = 0, da_eps0bar: float = 1.0, da_h0bar: float = 0.0, da_gamma: float = 0.05,
                  da_t0: int = 10, da_kappa: float = 0.75,
                  seed: int = 20260927, chain_offset: int = 0, device: int = 0, monitor: int = 0,
-                 steps_per_launch: int = 0, stream: int = 0, nstreams: int = 0, bm_batchlen: int = 0):
+                 steps_per_launch: int = 0, stream: int = 0, nstreams: int = 0, bm_batchlen: int = 0, hist_ring_cols: int = 0,
+                 acov_maxlag: int = 0):
         self._lib = L.load()
         self.target = target
         self.ndims = int(target.ndims)
@@ -238,6 +239,7 @@ class Engine:
         d.seed, d.monitor, d.steps_per_launch = int(seed), self.monitor, int(steps_per_launch)
         d.nstreams = int(nstreams)
         d.bm_batchlen = int(bm_batchlen)
+        d.hist_ring_cols, d.acov_maxlag = int(hist_ring_cols), int(acov_maxlag)
         d.stream = C.c_void_p(int(stream)) if stream else None
         self._h = C.c_void_p()
         L.check(self._lib.klara_create(C.byref(d), C.byref(self._h)), "klara_create")
@@ -359,6 +361,26 @@ class Engine:
         L.check(self._lib.klara_get_chain_mcvar(self._h, int(batchlen), int(maxlag), *[None if a is None else a.ctypes.data for a in out]),
                 "klara_get_chain_mcvar")
         return tuple(out)
+
+    def chain_acov_mcvar(self, want=("imse", "ipse")):
+        """(mcvar_imse, mcvar_ipse, nsamples), each (nchains, ndims) or None: Geyer's estimators with maxlag = acov_maxlag from the
+        autocovariances accumulated while sampling — no stored history (mcvar.jl:75-105, 137-158)."""
+        out = [np.empty((self.nchains, self.ndims)) if k in want else None for k in ("imse", "ipse")]
+        n = C.c_int64(0)
+        L.check(self._lib.klara_get_chain_acov_mcvar(self._h, *[None if a is None else a.ctypes.data for a in out], C.byref(n)),
+                "klara_get_chain_acov_mcvar")
+        return out[0], out[1], int(n.value)
+
+    def chain_mcvar_ipse(self, maxlag: int = 0) -> np.ndarray:
+        """mcvar(:ipse, maxlag) of every (chain, dimension) series over the stored history (mcvar.jl:137-158)."""
+        out = np.empty((self.nchains, self.ndims))
+        L.check(self._lib.klara_get_chain_mcvar_ipse(self._h, int(maxlag), out.ctypes.data), "klara_get_chain_mcvar_ipse")
+        return out
+
+    def saved_steps(self) -> int:
+        n = C.c_int64(0)
+        L.check(self._lib.klara_saved_steps(self._h, C.byref(n)), "klara_saved_steps")
+        return int(n.value)
 
     def chain_bm(self):
         """(mcvar_bm (nchains, ndims), nbatches): streaming batch means (bm_batchlen > 0), no stored history (mcvar.jl:35-41)."""

@@ -63,3 +63,36 @@ def write_chain(directory: str, suffix: str, value: Optional[np.ndarray], logtar
     if accept is not None:
         with open(os.path.join(directory, f"diagnosticvalues.{suffix}"), "w") as f:
             f.writelines(("true" if a else "false") + "\n" for a in accept)
+
+
+class ChainWriter:
+    """The open files of one chain's BasicContParamIOStream (BasicContParamIOStream.jl:64-82: one per monitored field, mode "w"):
+    `append` writes the lines of newly saved steps, `flush` is `flush(iostream)` (:141-149), so a long job streams to disk with
+    bounded memory instead of holding every saved step (jobs.jl:17-29 `:flush`)."""
+
+    def __init__(self, directory: str, suffix: str, value: bool, logtarget: bool, gradlogtarget: bool, accept: bool):
+        os.makedirs(directory, exist_ok=True)
+        mk = lambda name, on: open(os.path.join(directory, f"{name}.{suffix}"), "w") if on else None
+        self.files = {"value": mk("value", value), "logtarget": mk("logtarget", logtarget),
+                      "gradlogtarget": mk("gradlogtarget", gradlogtarget), "diagnosticvalues": mk("diagnosticvalues", accept)}
+
+    def append(self, value=None, logtarget=None, gradlogtarget=None, accept=None) -> None:
+        f = self.files
+        if f["value"] is not None and value is not None:
+            f["value"].writelines(_line(value[:, i]) for i in range(value.shape[1]))
+        if f["logtarget"] is not None and logtarget is not None:
+            f["logtarget"].writelines(julia_float_repr(float(v)) + "\n" for v in logtarget)
+        if f["gradlogtarget"] is not None and gradlogtarget is not None:
+            f["gradlogtarget"].writelines(_line(gradlogtarget[:, i]) for i in range(gradlogtarget.shape[1]))
+        if f["diagnosticvalues"] is not None and accept is not None:
+            f["diagnosticvalues"].writelines(("true" if a else "false") + "\n" for a in accept)
+
+    def flush(self) -> None:
+        for fh in self.files.values():
+            if fh is not None:
+                fh.flush()
+
+    def close(self) -> None:
+        for fh in self.files.values():
+            if fh is not None:
+                fh.close()

@@ -935,6 +935,91 @@ def test_custom_target_through_the_job_api():
     job.close()
 
 
+@pytest.mark.parametrize("name,ring,pieces", [("mala_swiss", 7, [13, 20, 7]), ("dt_hmc_d100", 4, [20]), ("hmc_dense_d37", 5, [3, 12]), ("hmc_rats", 6, [30])])
+def test_history_ring_keeps_the_last_saved_steps(name, ring, pieces):
+    """klara_desc.hist_ring_cols: the history monitors keep a ring of the last R saved steps — after any sequence of runs the
+    read-back equals the last R columns of the same job's full history, for value, logtarget and gradlogtarget."""
+    case = cases.make_case(name)
+    mon = L.MON_HISTORY | L.MON_HIST_LT | L.MON_HIST_GRAD
+    full = K.Engine(**cases.engine_kwargs(case, monitor=mon)); part = K.Engine(**cases.engine_kwargs(case, monitor=mon, hist_ring_cols=ring, steps_per_launch=5))
+    for e in (full, part):
+        e.set_state(case["x0"]) if case["x0"] is not None else e.init_state_normal()
+    done = 0
+    for k in pieces:
+        full.run(k); part.run(k); done += k
+        nsaved = full.saved_steps()
+        assert part.saved_steps() == nsaved
+        keep = min(ring, nsaved)
+        for c in (0, case["nchains"] - 1):
+            v = part.chain(c)
+            assert v.shape == (case["target"].ndims, keep)
+            if keep:
+                assert np.array_equal(v, full.chain(c)[:, nsaved - keep:])
+                lt, g = part.chain_fields(c, True, True); flt, fg = full.chain_fields(c, True, True)
+                assert np.array_equal(lt, flt[nsaved - keep:]) and np.array_equal(g, fg[:, nsaved - keep:])
+    with pytest.raises(K.KlaraError):
+        part.chain_mcvar(5, 0)                       # the post-hoc estimators need every saved step
+    full.close(); part.close()
+
+
+@pytest.mark.parametrize("name,maxlag", [("mala_d3_tuned", 9), ("hmc_d10_tuned_pooled", 6), ("dt_mala_d100_small_step", 15), ("mh_readme", 31)])
+def test_streaming_autocovariance_estimators(name, maxlag):
+    """klara_desc.acov_maxlag: mcvar(:imse, maxlag) and mcvar(:ipse, maxlag) (mcvar.jl:75-105, 137-158) of every (chain, dimension)
+    series from cross-products accumulated while sampling — no stored history — against (a) the NumPy restatement
+    (klara_jl_amd.stats, FFT autocovariance) on individual chains of a full-history twin of the job, (b) the device's post-hoc
+    estimators over that history.  Tolerance 1e-8 relative: three ways of summing the same products."""
+    case = cases.make_case(name)
+    n = {"mh_readme": 3000}.get(name, case["nsteps"])
+    case = dict(case, nsteps=n)
+    twin = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_HISTORY))
+    eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_SUMMARIES, acov_maxlag=maxlag, steps_per_launch=7))
+    for e in (twin, eng):
+        e.set_state(case["x0"]) if case["x0"] is not None else e.init_state_normal()
+    twin.run(n)
+    for k in (n // 3, n - n // 3):
+        eng.run(k)
+    imse, ipse, ns = eng.chain_acov_mcvar()
+    assert ns == twin.saved_steps() > 2 * maxlag
+    x1, _, _ = eng.state(); x2, _, _ = twin.state()
+    assert np.array_equal(x1, x2)                                   # same job
+    ph_imse = twin.chain_mcvar(5, maxlag, want=("imse",))[2]; ph_ipse = twin.chain_mcvar_ipse(maxlag)
+    assert np.allclose(imse, ph_imse, rtol=1e-8, atol=1e-300) and np.allclose(ipse, ph_ipse, rtol=1e-8, atol=1e-300)
+    for c in (0, case["nchains"] // 2, case["nchains"] - 1):
+        v = twin.chain(c)
+        for d in range(v.shape[0]):
+            if v[d].std() == 0:
+                continue
+            assert np.isclose(imse[c, d], K.stats.mcvar(v[d], "imse", maxlag), rtol=1e-8), (c, d)
+            assert np.isclose(ipse[c, d], K.stats.mcvar(v[d], "ipse", maxlag), rtol=1e-8), (c, d)
+    twin.close(); eng.close()
+
+
+def test_iostream_sink_streams_with_bounded_memory(tmp_path):
+    """:destination => :iostream with :flush (jobs.jl:17-29): the sink writes while the job runs — the device holds a ring of
+    outopts chunk = 7 saved steps — and the files equal the ones written in one go from a full history."""
+    from klara_jl_amd.iostream import write_chain
+    case = cases.make_case("mala_swiss")
+    X, y = cases.swiss_data()
+    p = K.BasicContMuvParameter("p", logtarget=K.LogisticTarget(X, y, 100.0))
+    job = K.BasicMCJob(K.likelihood_model(p, False), K.MALA(0.1), K.BasicMCRange(nsteps=40, burnin=10, thinning=2), {"p": case["x0"]},
+                       outopts={"destination": "iostream", "filepath": str(tmp_path / "s"), "monitor": ["value", "logtarget", "gradlogtarget"],
+                                "diagnostics": ["accept"], "flush": True, "chunk": 7}, seed=20260927)
+    assert job.engine.chain(0).shape == (4, 0)
+    K.run(job)
+    assert job.engine.chain(0).shape == (4, 7)                       # the device never held more than the ring
+    twin = K.Engine(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, 100.0), nchains=70, nsteps=39, burnin=10, thinning=2, driftstep=0.1,
+                    monitor=L.MON_HISTORY | L.MON_HIST_LT | L.MON_HIST_GRAD | L.MON_ACCEPT)
+    twin.set_state(case["x0"]); twin.run(39)
+    post = np.arange(11, 40, 2) - 1
+    for c in (0, 41, 69):
+        lt, g = twin.chain_fields(c, True, True)
+        write_chain(str(tmp_path / "r" / f"chain_{c + 1:02d}"), "csv", twin.chain(c), lt, g, twin.accept_mask()[post, c])
+        for f in ("value", "logtarget", "gradlogtarget", "diagnosticvalues"):
+            a = (tmp_path / "s" / f"chain_{c + 1:02d}" / f"{f}.csv").read_text(); b = (tmp_path / "r" / f"chain_{c + 1:02d}" / f"{f}.csv").read_text()
+            assert a == b and a.count("\n") == 15, (c, f)
+    job.close(); twin.close()
+
+
 def test_likelihood_prior_closures_through_the_job_api():
     """BasicContMuvParameter(:p, loglikelihood=..., logprior=..., gradloglikelihood=..., gradlogprior=...) with
     :monitor => [:value, :logtarget, :loglikelihood, :logprior] (BasicContMuvParameter.jl:174-201, iterate/MALA.jl:104-109): MALA on the

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(klib):
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(klib, name), name
-    assert klib.klara_abi_version() == L.KLARA_ABI_VERSION == 2
+    assert klib.klara_abi_version() == L.KLARA_ABI_VERSION == 3
 
 
 def test_desc_struct_matches_header_layout():
@@ -319,18 +319,19 @@ def _plan(klib, runs, **kw):
 @pytest.mark.parametrize("seed", range(40))
 def test_launch_planning_is_pure_host_logic(klib, seed):
     """klara_run's launch splitting, checked without a device against a step-by-step model: every launch stays within
-    steps_per_launch, never crosses an event of the pooled tuner (tuners.jl:27-32: every `period` proposals while
+    steps_per_launch, never wraps around the history ring, never crosses an event of the pooled tuner (tuners.jl:27-32: every `period` proposals while
     totproposed <= burnin, totproposed starting at period) or a batch boundary of the streaming batch means, and carries the
     save-rule bookkeeping of BasicMCRange.jl:36 ((burnin+1):thinning:nsteps)."""
     rng = np.random.default_rng(seed)
     burnin, thinning, period = int(rng.choice([0, 5, 30, 100])), int(rng.choice([1, 2, 7])), int(rng.choice([3, 10, 25]))
     spl = int(rng.choice([0, 1, 4, 16, 50]))
     pooled = bool(rng.integers(0, 2)); bm = int(rng.choice([0, 0, 3, 10]))
+    ring = int(rng.choice([0, 0, 4, 9, 32])); acov = int(rng.choice([0, 0, 5]))
     runs = [int(v) for v in rng.integers(1, 120, int(rng.integers(1, 5)))]
     total = sum(runs)
     if total <= burnin:
         runs.append(burnin + 1); total = sum(runs)
-    kw = dict(burnin=burnin, thinning=thinning, period=period, steps_per_launch=spl, bm_batchlen=bm)
+    kw = dict(burnin=burnin, thinning=thinning, period=period, steps_per_launch=spl, bm_batchlen=bm, hist_ring_cols=ring, acov_maxlag=acov)
     if pooled:
         kw.update(tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.5)
     if bm:
@@ -353,10 +354,19 @@ def test_launch_planning_is_pure_host_logic(klib, seed):
         assert not any(a < e < b for e in tune_events | batch_ends), (a, b)
     assert {int(e) for e, f in zip(ends, fl) if f & 2} == batch_ends
     assert ((fl & 1) != 0).all() == pooled and ((fl & 1) != 0).any() == pooled
-    # save rule: columns saved before the launch, and the thinning phase of its first post-burn-in transition
-    for a, c, p_ in zip(starts, col, ph):
-        assert c == len([t for t in saved if t <= a])
+    # save rule: columns saved before the launch, and the thinning phase of its first post-burn-in transition; with a history ring
+    # (klara_desc.hist_ring_cols, or the 32 columns the streaming autocovariances keep for themselves) the column is the ring slot
+    # and no launch wraps around the ring
+    rcols = ring if ring else (32 if acov else 0)
+    if rcols >= len(saved):
+        rcols = 0
+    for a, b, c, p_ in zip(starts, ends, col, ph):
+        before = len([t for t in saved if t <= a])
+        inside = len([t for t in saved if a < t <= b])
+        assert c == (before % rcols if rcols else before)
         assert p_ == ((a - burnin) % thinning if a >= burnin else 0)
+        if rcols:
+            assert c + inside <= rcols, (a, b, c, inside, rcols)
 
 
 def _build_c_example(tmp_path):
