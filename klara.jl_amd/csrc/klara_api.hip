@@ -263,7 +263,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     if (desc->target == KLARA_TARGET_LOGISTIC) {
         // D <= 8 parameters cannot fill a wavefront's lanes usefully, the ndata-row likelihood can: RS lanes share a chain
         // and each takes every RS-th row (fixed by ndata alone, so results do not depend on how chains are sharded)
-        int rs = desc->logit_ndata >= 64 ? 4 : 1;
+        int rs = desc->logit_ndata >= 128 ? 8 : (desc->logit_ndata >= 64 ? 4 : 1);     // (swiss, 200 rows: 8 — 8.07e8 vs 7.69e8 transitions/s at 4)
         if (const char* s = getenv("KLARA_LOGIT_ROWSPLIT")) { const int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) rs = v; }
         h->RS = rs;
         if (rs > 1) h->kind = 2;
@@ -623,7 +623,7 @@ extern "C" klara_status klara_stream_key(klara_handle* h, uint64_t* key, uint64_
     return KLARA_OK;
 }
 
-static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
+static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
 {
     const klara_desc& d = h->d;
     const KParams* p = h->d_params;
@@ -637,8 +637,8 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl)
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on
         const bool da = d.tuner == KLARA_TUNER_DUAL_AVERAGING;                                 // (HMC only: validate())
         const bool tune = !plain || da;                                                        // something counts proposals / tunes
-        const long long cpw = 64 / h->G, groups = (d.nchains + cpw - 1) / cpw, per = (groups + h->nparts - 1) / h->nparts;
-        for (int j = 0; j < h->nparts; ++j) {
+        const long long cpw = 64 / h->G, groups = (d.nchains + cpw - 1) / cpw, per = (groups + nparts - 1) / nparts;
+        for (int j = 0; j < nparts; ++j) {
             KLaunch kp = kl;
             kp.group0 = j * per; kp.group_end = (j + 1) * per < groups ? (j + 1) * per : groups;
             if (kp.group0 >= kp.group_end) break;
@@ -695,10 +695,10 @@ __global__ __launch_bounds__(256) void k_bm_close(const double* __restrict__ sum
 }
 
 // every partition closes its own chains on its own stream (layout kind 3 runs chain partitions on internal streams)
-static hipError_t launch_bm_close(klara_handle* h)
+static hipError_t launch_bm_close(klara_handle* h, int nparts)
 {
     const long long N = h->d.nchains, D = h->d.ndims;
-    const int np = h->kind == 3 ? h->nparts : 1;
+    const int np = h->kind == 3 ? nparts : 1;
     const long long cpw = h->kind == 3 ? 64 / h->G : 8, groups = (N + cpw - 1) / cpw, per = (groups + np - 1) / np;
     for (int j = 0; j < np; ++j) {
         long long c0 = 0, c1 = N;
@@ -896,9 +896,15 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
     if ((d.monitor & KLARA_MON_ACCEPT) && h->steps_done + nsteps > h->accept_cap) return KLARA_ERR_STATE;
     KParams p = make_params(h);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    if (h->nparts > 1) {                                   // fork: the partition streams start after everything queued so far
+    // Chain partitions on internal streams pay off when a run issues several launches per partition (the streams drift apart and
+    // one partition's kernel fills the SIMDs while the other's ramps up or drains: 12.9 vs 14.1 us per transition at 65,536 x 100).
+    // A run that is a single launch is issued whole on the caller's stream: two half-size kernels that start together only split
+    // the machine unevenly (16.7 vs 17.8 us per transition for 20-transition runs).
+    const long long spl_run = d.steps_per_launch > 0 ? d.steps_per_launch : KLARA_DEFAULT_STEPS_PER_LAUNCH;
+    const int nparts = nsteps > spl_run ? h->nparts : 1;
+    if (nparts > 1) {                                      // fork: the partition streams start after everything queued so far
         HIPCHK(hipEventRecord(h->fork_ev, h->stream));
-        for (int j = 0; j + 1 < h->nparts; ++j) HIPCHK(hipStreamWaitEvent(h->side[j], h->fork_ev, 0));
+        for (int j = 0; j + 1 < nparts; ++j) HIPCHK(hipStreamWaitEvent(h->side[j], h->fork_ev, 0));
     }
     long long remaining = nsteps, launches = 0;
     RunCursor cur = { h->steps_done, h->m_prop, h->m_tot, h->bm_count };
@@ -911,12 +917,12 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
         kl.nsteps = (int)pl.k;                                             // (plan_launch keeps k <= steps_per_launch <= INT_MAX)
         kl.save_phase0 = pl.save_phase0;
         kl.save_col0 = pl.save_col0;
-        err = launch_steps(h, kl);
+        err = launch_steps(h, kl, nparts);
         if (err == hipSuccess && pl.tune_after) {
             hipLaunchKernelGGL(k_pooled_tune, dim3(1), dim3(64), 0, h->stream, p, (int)pl.k);
             err = hipGetLastError();
         }
-        if (err == hipSuccess && pl.bm_close_after) err = launch_bm_close(h);   // (reads h->bm_count: batches closed before this one)
+        if (err == hipSuccess && pl.bm_close_after) err = launch_bm_close(h, nparts);   // (reads h->bm_count: batches closed before this one)
         if (err == hipSuccess && h->acov_S && pl.saved > 0) {                   // streaming autocovariances consume the launch's samples
             err = launch_acov_update(h, pl.save_col0, pl.saved);
             h->acov_n += pl.saved;
@@ -928,7 +934,7 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
     }
     // join — also when a launch failed: the partition streams may still have work in flight on X / GR / LT, and every later
     // call (get_state, reset, destroy) synchronises the caller's stream only
-    for (int j = 0; j + 1 < h->nparts; ++j) {
+    for (int j = 0; j + 1 < nparts; ++j) {
         const hipError_t e1 = hipEventRecord(h->join_ev[j], h->side[j]);
         const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(h->stream, h->join_ev[j], 0) : e1;
         if (e2 != hipSuccess) { hipStreamSynchronize(h->side[j]); if (err == hipSuccess) err = e2; }

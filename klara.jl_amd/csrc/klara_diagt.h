@@ -32,6 +32,9 @@
 #ifndef KLARA_DT_W1
 #define KLARA_DT_W1 4
 #endif
+#ifndef KLARA_Q4_MALA_WF
+#define KLARA_Q4_MALA_WF 3   // wavefronts per SIMD requested for the 4-lane MALA kernels with more than 8 pairs per lane
+#endif
 #ifndef KLARA_DT_WF
 #define KLARA_DT_WF 2     // wavefronts per SIMD requested for the fused / monitored / tuned instantiations
 #endif
@@ -219,7 +222,7 @@ __device__ __forceinline__ void diag_elem(double x, double w, double m2w, double
 // wavefront runs to the longest trajectory of its chains, a finished chain's lanes keep their state.
 template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false, bool DA = false>
 __global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? KLARA_DT_W1 : KLARA_DT_WF)
-                                           : (Q == 4 && NP <= 13 && !TUNE ? (SAMPLER == KLARA_SAMPLER_MALA ? 3 : (SAMPLER == KLARA_SAMPLER_MH ? 2 : 1)) : 1)))
+                                           : (Q == 4 && NP <= 13 && !TUNE ? (SAMPLER == KLARA_SAMPLER_MALA ? KLARA_Q4_MALA_WF : (SAMPLER == KLARA_SAMPLER_MH ? 2 : 1)) : 1)))
 void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 {
     static_assert(!(ONESTEP && (MON || TUNE)), "monitored / tuned jobs run the committing kernel");
