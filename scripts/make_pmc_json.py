@@ -42,7 +42,7 @@ for f in glob.glob(os.path.join(prof, "trace_headline", "**", "*kernel_trace.csv
     with open(f) as fh:
         for r in csv.DictReader(fh):
             if "k_diagt<" in r["Kernel_Name"]:
-                durs[(r["Kernel_Name"], int(r["Grid_Size"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                durs[(r["Kernel_Name"], int(r.get("Grid_Size") or r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for (name, grid), v in durs.items():
         v.sort()
         trace[f"{name} grid={grid}"] = {"n": len(v), "mean_ns": sum(v) / len(v), "median_ns": v[len(v) // 2], "min_ns": v[0], "max_ns": v[-1]}
