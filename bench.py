@@ -42,6 +42,10 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s a
 FP64_MFMA_PEAK_TF = 78.6    # FP64 matrix = FP64 vector peak on MI355X
 CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock; 256 CUs x 4 SIMDs
 NSIMD = 1024
+# The workload's chains move rarely: MALA with driftstep 0.9 in 100 dimensions accepts 0.4 % of its proposals at stationarity (1.8 % in the
+# first transitions from N(0, I)).  klara_desc.sparse_moves tells the library so (include/klara_hip.h): running sums are then folded
+# straight into memory when a chain moves instead of living in registers.  `extra` also reports the job without the hint.
+SPARSE = True
 PMC_JSON = ROOT / "profiles" / "r2_pmc_kernels.json"
 PMC_EXPECT = {}             # filled by main(): the launch length the committed counters must have been collected at
 
@@ -145,7 +149,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     eng = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=total_steps,
                    burnin=0, driftstep=0.9, seed=20260927, chain_offset=offset, device=local_rank,
-                   monitor=monitor, steps_per_launch=spl, stream=stream, nstreams=args.streams)
+                   monitor=monitor, steps_per_launch=spl, stream=stream, nstreams=args.streams, sparse_moves=SPARSE)
     eng.init_state_normal()
 
     def barrier():
@@ -165,7 +169,7 @@ def main():
     if args.clock_warmup > 0:
         scratch = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=10 ** 7, burnin=0,
                            driftstep=0.9, seed=1, chain_offset=offset, device=local_rank, monitor=monitor, steps_per_launch=spl,
-                           stream=stream, nstreams=args.streams)
+                           stream=stream, nstreams=args.streams, sparse_moves=SPARSE)
         scratch.init_state_normal()
         scratch.run(args.clock_warmup)          # (closed after the timed repetitions: freeing memory would idle the device again)
     times, kernel_ms_per_step, summ = [], [], None
@@ -213,6 +217,7 @@ def main():
                                    "BASELINE configs[1] without the save rule: MALA driftstep=0.9, lt=-|x|^2, D=100, VanillaMCTuner, x0~N(0,I)",
                        "nchains_per_gpu": n, "nchains_total": n_total, "ndims": NDIMS, "steps_per_launch": spl,
                        "save_rule": "running sums (KLARA_MON_SUMMARIES), burnin 0, thinning 1" if monitor else "off",
+                       "sparse_moves_hint": SPARSE,
                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective; summaries pooled on device"
                                       + (" and all-reduced over RCCL" if world > 1 else ""),
                        "streams": "library default (2 chain partitions on 2 HIP streams)" if args.streams == 0 else args.streams,
@@ -260,7 +265,7 @@ def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
     region overlaps two half-size launches on two streams, which says nothing about a single launch)."""
     e = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=10 ** 7, burnin=0,
                  driftstep=0.9, seed=20260927, chain_offset=offset, device=local_rank, monitor=monitor, steps_per_launch=spl,
-                 stream=stream, nstreams=1)
+                 stream=stream, nstreams=1, sparse_moves=SPARSE)
     e.init_state_normal()
     launch_s, nlaunch = launch_duration(e, spl, nlaunch=64 if spl > 1 else 256)
     lay_kind, lay_g, lay_e = e.layout()
@@ -315,7 +320,8 @@ def extra_measurements(K, L, n, stream):
     # -- the headline workload in its other modes
     for key, kw in (("mala_one_transition_per_launch_no_save", dict(steps_per_launch=1, monitor=0)),
                     ("mala_fused_no_save", dict(steps_per_launch=0, monitor=0)),
-                    ("mala_one_transition_per_launch_with_save", dict(steps_per_launch=1, monitor=L.MON_SUMMARIES))):
+                    ("mala_one_transition_per_launch_with_save", dict(steps_per_launch=1, monitor=L.MON_SUMMARIES, sparse_moves=SPARSE)),
+                    ("mala_fused_with_save_without_the_sparse_moves_hint", dict(steps_per_launch=0, monitor=L.MON_SUMMARIES))):
         e = K.Engine(sampler=L.SAMPLER_MALA, target=neg, nchains=n, nsteps=10 ** 7, driftstep=0.9, stream=stream, **kw)
         e.init_state_normal()
         rate, _, _ = timed_rate(e, n, 64, 1024)

@@ -191,7 +191,14 @@ typedef struct klara_desc {
                                     (lags 0..acov_maxlag, at most 31), so that Geyer's initial monotone / positive sequence estimators
                                     (mcvar(:imse | :ipse, maxlag), mcvar.jl:75-105,137-158) need no stored history:
                                     klara_get_chain_acov_mcvar.  Uses a value ring of its own when no history monitor is on. */
-    int32_t  reserved0;          /* 0 */
+    int32_t  sparse_moves;       /* hint, 0 or 1: the chains are expected to move rarely (acceptance of a per cent or so, like MALA with a drift
+                                    step far too large for the dimension).  Untuned MH / MALA jobs on the diagonal Gaussian (17 <= D <= 104) that
+                                    keep running sums then take the 4-lanes-per-chain layout, whose running sums are folded straight into
+                                    memory when a chain moves (no resident sums): 13 vs 15.4 us per transition at 65,536 x 100 and 0.9 %
+                                    acceptance, but 50 / 124 / 213 us at 21 / 56 / 99.7 % (profiles/r2_acceptance_cost_probe.txt).  Without
+                                    the hint such jobs keep their sums in registers (15.4 - 18.4 us whatever the acceptance).  Jobs that keep
+                                    no running sums take the 4-lane layout either way.  Results do not depend on the hint beyond the
+                                    summation order that klara_get_layout reports. */
 
     uint64_t seed;               /* Philox key                                                       */
     uint32_t monitor;            /* KLARA_MON_* bits                                                 */

@@ -39,7 +39,7 @@ struct KlaraDesc
     hier_Y::Ptr{Float64}; hier_xc::Ptr{Float64}; hier_nunits::Int32; hier_ntimes::Int32
     hier_prior_prec::Float64; hier_gamma_a::Float64; hier_gamma_b::Float64
     custom_src::Cstring; custom_data::Ptr{Float64}; custom_ndata::Int64; bm_batchlen::Int64
-    hist_ring_cols::Int64; acov_maxlag::Int32; reserved0::Int32
+    hist_ring_cols::Int64; acov_maxlag::Int32; sparse_moves::Int32
     seed::UInt64; monitor::UInt32; steps_per_launch::Int32; stream::Ptr{Cvoid}
 end
 
@@ -56,7 +56,7 @@ function klara_desc(; sampler=SAMPLER_MH, target=TARGET_GAUSS_DIAG, tuner=TUNER_
                     hier_Y=Ptr{Float64}(C_NULL), hier_xc=Ptr{Float64}(C_NULL), hier_nunits=0, hier_ntimes=0,
                     hier_prior_prec=1e-4, hier_gamma_a=1e-3, hier_gamma_b=1e-3,
                     custom_src=Cstring(C_NULL), custom_data=Ptr{Float64}(C_NULL), custom_ndata=0, bm_batchlen=0,
-                    hist_ring_cols=0, acov_maxlag=0, reserved0=0,
+                    hist_ring_cols=0, acov_maxlag=0, sparse_moves=0,
                     seed=UInt64(0), monitor=UInt32(0), steps_per_launch=0, stream=C_NULL)
     KlaraDesc(UInt32(sizeof(KlaraDesc)), KLARA_ABI_VERSION,
               sampler, target, tuner, tuner_mode,
@@ -72,7 +72,7 @@ function klara_desc(; sampler=SAMPLER_MH, target=TARGET_GAUSS_DIAG, tuner=TUNER_
               hier_Y, hier_xc, hier_nunits, hier_ntimes,
               hier_prior_prec, hier_gamma_a, hier_gamma_b,
               custom_src, custom_data, custom_ndata, bm_batchlen,
-              hist_ring_cols, acov_maxlag, reserved0,
+              hist_ring_cols, acov_maxlag, sparse_moves,
               seed, monitor, steps_per_launch, stream)
 end
 

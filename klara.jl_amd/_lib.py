@@ -49,7 +49,7 @@ class KlaraDesc(C.Structure):
         ("hier_Y", _dp), ("hier_xc", _dp), ("hier_nunits", C.c_int32), ("hier_ntimes", C.c_int32),
         ("hier_prior_prec", C.c_double), ("hier_gamma_a", C.c_double), ("hier_gamma_b", C.c_double),
         ("custom_src", C.c_char_p), ("custom_data", _dp), ("custom_ndata", C.c_int64), ("bm_batchlen", C.c_int64),
-        ("hist_ring_cols", C.c_int64), ("acov_maxlag", C.c_int32), ("reserved0", C.c_int32),
+        ("hist_ring_cols", C.c_int64), ("acov_maxlag", C.c_int32), ("sparse_moves", C.c_int32),
         ("seed", C.c_uint64), ("monitor", C.c_uint32), ("steps_per_launch", C.c_int32),
         ("stream", C.c_void_p),
     ]

@@ -124,7 +124,10 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
         int Q = D <= 128 ? 8 : (D <= 256 ? 16 : 32);                              // lanes per chain
         // untuned MH / MALA up to D = 104: 4 lanes per chain, 16 chains per wavefront, NP = ceil(D/8) in 3..13 (klara_launch.h)
         const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
-        if (plain && (d.sampler == KLARA_SAMPLER_MH || d.sampler == KLARA_SAMPLER_MALA) && D <= 104 && !getenv("KLARA_DIAGT_NO_Q4")) Q = 4;
+        // ... when they keep no running sums, or when the caller says the chains move rarely (klara_desc.sparse_moves): the 4-lane
+        // kernels fold the running sums into memory with atomic adds, which only pays at acceptance rates of a per cent or so
+        const bool sums4 = !(d.monitor & KLARA_MON_SUMMARIES) || d.sparse_moves != 0;
+        if (plain && sums4 && (d.sampler == KLARA_SAMPLER_MH || d.sampler == KLARA_SAMPLER_MALA) && D <= 104 && !getenv("KLARA_DIAGT_NO_Q4")) Q = 4;
         const int np = (D + 2 * Q - 1) / (2 * Q);                                 // NP = ceil(D/2 / Q) exactly (see klara_diagt.h)
         if (np >= 2 && np <= (Q == 4 ? 13 : KLARA_DIAGT_NP_MAX)) { *kind = 3; *G = Q; *E = 2 * np; return KLARA_OK; }
     }
@@ -190,7 +193,7 @@ static klara_status validate(const klara_desc* d)
         return KLARA_ERR_INVALID_ARG;
     if (d->target == KLARA_TARGET_CUSTOM && (!d->custom_src || d->custom_ndata < 0 || (d->custom_ndata > 0 && !d->custom_data)))
         return KLARA_ERR_INVALID_ARG;
-    if (d->hist_ring_cols < 0 || d->acov_maxlag < 0 || d->acov_maxlag > 31 || d->reserved0 != 0) return KLARA_ERR_INVALID_ARG;
+    if (d->hist_ring_cols < 0 || d->acov_maxlag < 0 || d->acov_maxlag > 31 || d->sparse_moves < 0 || d->sparse_moves > 1) return KLARA_ERR_INVALID_ARG;
     if (d->bm_batchlen < 0 || (d->bm_batchlen > 0 && !(d->monitor & KLARA_MON_SUMMARIES))) return KLARA_ERR_INVALID_ARG;
     if (d->steps_per_launch < 0 || d->tuner_score < 0 || d->tuner_score > 1) return KLARA_ERR_INVALID_ARG;   // (int32: a launch length always fits KLaunch::nsteps)
     return KLARA_OK;

@@ -188,7 +188,7 @@ class Engine:
                  da_t0: int = 10, da_kappa: float = 0.75,
                  seed: int = 20260927, chain_offset: int = 0, device: int = 0, monitor: int = 0,
                  steps_per_launch: int = 0, stream: int = 0, nstreams: int = 0, bm_batchlen: int = 0, hist_ring_cols: int = 0,
-                 acov_maxlag: int = 0):
+                 acov_maxlag: int = 0, sparse_moves: bool = False):
         self._lib = L.load()
         self.target = target
         self.ndims = int(target.ndims)
@@ -239,7 +239,7 @@ class Engine:
         d.seed, d.monitor, d.steps_per_launch = int(seed), self.monitor, int(steps_per_launch)
         d.nstreams = int(nstreams)
         d.bm_batchlen = int(bm_batchlen)
-        d.hist_ring_cols, d.acov_maxlag = int(hist_ring_cols), int(acov_maxlag)
+        d.hist_ring_cols, d.acov_maxlag, d.sparse_moves = int(hist_ring_cols), int(acov_maxlag), int(bool(sparse_moves))
         d.stream = C.c_void_p(int(stream)) if stream else None
         self._h = C.c_void_p()
         L.check(self._lib.klara_create(C.byref(d), C.byref(self._h)), "klara_create")

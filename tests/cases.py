@@ -325,6 +325,15 @@ def make_case(name):
     # ---- pair-transposed layout (kind 3): VanillaMCTuner jobs on diagonal Gaussians that monitor at most the accept mask
     elif name == "dt_mala_d100":       # BASELINE cfg 2 shape; 130 chains = 16 full wavefront groups + 2 chains
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=130, nsteps=40, burnin=0, driftstep=0.9)
+    elif name in ("sparse_mala_d100", "sparse_mala_d100_small_step", "sparse_mh_d100", "sparse_mala_mvnormal_d30"):
+        # klara_desc.sparse_moves: untuned MH / MALA that keep running sums on the 4-lane layout, sums folded by atomic adds —
+        # at a low acceptance (the layout's purpose), at a high one (a fold at almost every transition) and on a non-unit diagonal
+        base = {"sparse_mala_d100": dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=131, nsteps=60, burnin=10, driftstep=0.9),
+                "sparse_mala_d100_small_step": dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=67, nsteps=40, burnin=0, thinning=1, driftstep=0.05),
+                "sparse_mh_d100": dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(100), nchains=70, nsteps=60, burnin=7, thinning=3, mh_sigma=np.full(100, 0.1)),
+                "sparse_mala_mvnormal_d30": dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 2, 30), np.linspace(0.6, 1.7, 30)),
+                                                 nchains=45, nsteps=50, burnin=5, driftstep=0.3)}[name]
+        c = dict(base, sparse_moves=True)
     elif name == "dt_mala_d100_small_step":
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=67, nsteps=40, burnin=0, driftstep=0.05)
     elif name == "dt_mala_d112_full":  # D/2 = 7*8: no padding pair, the accept uniform takes the explicit path
@@ -412,7 +421,8 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "slice_d20_stepout", "mh_rats", "mala_rats_tuned"] + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
              "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
-             "custom_quartic_mala_d64", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh"]
+             "custom_quartic_mala_d64", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh",
+             "sparse_mala_d100", "sparse_mala_d100_small_step", "sparse_mh_d100", "sparse_mala_mvnormal_d30"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",

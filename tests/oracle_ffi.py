@@ -104,7 +104,7 @@ DIAGT_Q = 8
 
 
 def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, tuner=0, tuner_mode=0, verbose=False,
-                   hier_nunits: int = 0, hier_ntimes: int = 0):
+                   hier_nunits: int = 0, hier_ntimes: int = 0, summaries: bool = True, sparse_moves: bool = False):
     """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box).  `sampler`, `tuner`,
     `tuner_mode` and `verbose` are only needed to recognise the pair-transposed layout (kind 3): diagonal Gaussian,
     MH / MALA / HMC, even D <= 128, Vanilla or AcceptanceRate tuner (klara_api.hip diagt_eligible)."""
@@ -117,7 +117,8 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
         counts = bool(verbose) if sampler in (L.SAMPLER_MH, L.SAMPLER_SLICE) else (
             (tuner == L.TUNER_VANILLA and bool(verbose)) or tuner == L.TUNER_ACCEPT_RATE or (tuner == L.TUNER_DUAL_AVERAGING and bool(verbose)))
         plain_job = (not counts) and tuner_mode == L.TUNE_PER_CHAIN and tuner != L.TUNER_DUAL_AVERAGING
-        if plain_job and sampler in (L.SAMPLER_MH, L.SAMPLER_MALA) and d <= 104 and "KLARA_DIAGT_NO_Q4" not in os.environ:
+        if (plain_job and (not summaries or sparse_moves) and sampler in (L.SAMPLER_MH, L.SAMPLER_MALA) and d <= 104
+                and "KLARA_DIAGT_NO_Q4" not in os.environ):
             q = 4
         return (3, q, 2 * ((d + 2 * q - 1) // (2 * q)))
     if (target_kind == L.TARGET_HIER_NORMAL and sampler in (L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC)
@@ -159,7 +160,7 @@ class OracleJob:
                  seed=20260927, chain_offset=0, gauss_w=None, gauss_mu=None, gauss_const=0.0, gauss_prec=None,
                  logit_X=None, logit_y=None, logit_lambda=100.0, hier_Y=None, hier_xc=None, hier_prior_prec=1e-4,
                  hier_gamma_a=1e-3, hier_gamma_b=1e-3, custom_src=None, custom_data=None, layout=None,
-                 want_accept=True, want_sums=True, want_hist=False):
+                 want_accept=True, want_sums=True, want_hist=False, sparse_moves=False):
         self.lib = load()
         self.N, self.D = int(nchains), int(ndims)
         d = L.KlaraDesc()
@@ -202,7 +203,8 @@ class OracleJob:
         self._seed0, self.epoch = int(seed), 0
         k, g, e = layout if layout is not None else default_layout(int(target_kind), self.D, int(d.logit_ndata), sampler=int(sampler),
                                                                    tuner=int(tuner), tuner_mode=int(tuner_mode), verbose=bool(verbose),
-                                                                   hier_nunits=int(d.hier_nunits), hier_ntimes=int(d.hier_ntimes))
+                                                                   hier_nunits=int(d.hier_nunits), hier_ntimes=int(d.hier_ntimes),
+                                                                   summaries=bool(want_sums), sparse_moves=bool(sparse_moves))
         self.layout = KoLayout(k, g, e)
         nt = 1 if tuner_mode == L.TUNE_POOLED else self.N
         self.X = np.zeros((self.N, self.D)); self.G = np.zeros((self.N, self.D)); self.LT = np.zeros(self.N)

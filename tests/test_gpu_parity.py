@@ -213,18 +213,19 @@ def test_group_layout_dimension_sweep():
 @pytest.mark.parametrize("sampler,kw,step", [(L.SAMPLER_MALA, dict(driftstep=0.3), 1), (L.SAMPLER_HMC, dict(leapstep=0.2, nleaps=3), 3),
                                              (L.SAMPLER_MH, None, 3), (L.SAMPLER_SLICE, "slice", 7)])
 def test_pair_transposed_dimension_sweep(sampler, kw, step):
-    """Dimensions 17..128 (4 lanes per chain for MH / MALA up to 104, 8 otherwise), odd ones included, on the pair-transposed layout (every one for MALA, every
+    """Dimensions 17..128 (4 lanes per chain for MH / MALA up to 104 at the odd ones, where the job carries the sparse_moves hint;
+    8 otherwise), odd ones included, on the pair-transposed layout (every one for MALA, every
     third for HMC and MH, every seventh for the slice sampler), then 129..512 (16 and 32 lanes per chain) in coarser steps:
     with and without padding pairs / a half pair, i.e. every way of obtaining the accept draw and of storing the last pair."""
     wide = {1: 3, 3: 13, 7: 61}[step]
     for d in list(range(17, 129, step)) + list(range(129, 513, wide)) + [256, 257, 511, 512]:
         skw = dict(slice_widths=np.full(d, 1.5)) if kw == "slice" else (kw if kw is not None else dict(mh_sigma=np.full(d, 0.2)))
         case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=11,
-                    nsteps=6, burnin=0, x0=None, seed=d, name=f"sweep3_d{d}", **skw)
+                    nsteps=6, burnin=0, x0=None, seed=d, name=f"sweep3_d{d}", sparse_moves=(d % 2 == 1), **skw)
         eng, job = _run_pair(case, spl=2)
         lanes = 8 if d <= 128 else 16 if d <= 256 else 32
-        if sampler in (L.SAMPLER_MH, L.SAMPLER_MALA) and d <= 104:
-            lanes = 4                              # untuned MH / MALA: 4 lanes per chain, 16 chains per wavefront
+        if sampler in (L.SAMPLER_MH, L.SAMPLER_MALA) and d <= 104 and d % 2 == 1:
+            lanes = 4                              # untuned MH / MALA with the sparse_moves hint: 4 lanes per chain, sums folded by atomic adds
         assert eng.layout()[:2] == (3, lanes)
         x, lt, g = eng.state()
         assert np.array_equal(x, job.X) and np.array_equal(lt, job.LT), d
@@ -264,7 +265,7 @@ def test_pair_transposed_every_pairs_per_lane(d, sampler):
     the LAST pair of a lane can be padding, which holds because NP is exactly the ceiling)."""
     kw = dict(driftstep=0.25) if sampler == L.SAMPLER_MALA else dict(leapstep=0.2, nleaps=3)
     case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=13, nsteps=12,
-                burnin=2, x0=None, seed=5, name=f"np_d{d}", **kw)
+                burnin=2, x0=None, seed=5, name=f"np_d{d}", sparse_moves=True, **kw)
     eng, job = _run_pair(case, splits=[5, 7], spl=3)
     lanes = eng.layout()[1]                                                        # 4 (untuned MALA up to D = 104) or 8
     assert eng.layout()[0] == 3 and lanes == (4 if sampler == L.SAMPLER_MALA and d <= 104 else 8)
@@ -343,9 +344,9 @@ def test_c_abi_summary_allreduce_over_rccl_single_rank(klib):
 @pytest.mark.parametrize("name", ["dt_mala_d100", "dt_mala_d18", "dt_mala_mvnormal_d30", "dt_mh_d100", "dt_mh_mvnormal_d20"])
 @pytest.mark.parametrize("spl", [0, 1])
 def test_pair_transposed_8_lane_form_of_untuned_mh_mala(name, spl, monkeypatch):
-    """Untuned MH / MALA jobs up to D = 104 take the 4-lane form of the layout; KLARA_DIAGT_NO_Q4 keeps them on the 8-lane kernels
-    (the ones their tuned siblings run), with resident running sums instead of atomic folds: same bits as the oracle told that
-    summation order."""
+    """Untuned MH / MALA jobs up to D = 104 take the 4-lane form of the layout when they keep no running sums or carry the
+    sparse_moves hint; otherwise — and always under KLARA_DIAGT_NO_Q4 — the 8-lane kernels (the ones their tuned siblings run),
+    with resident running sums instead of atomic folds: same bits as the oracle told that summation order."""
     monkeypatch.setenv("KLARA_DIAGT_NO_Q4", "1")
     case = cases.make_case(name)
     eng, job = _run_pair(case, spl=spl)
@@ -361,9 +362,12 @@ def test_layout_choice_matches_its_mirror():
         for sampler, extra in ((L.SAMPLER_MALA, dict(driftstep=0.1)), (L.SAMPLER_MH, dict(mh_sigma=np.ones(d))),
                                (L.SAMPLER_SLICE, dict(slice_widths=np.ones(d)))):
             for tuner in (L.TUNER_VANILLA, L.TUNER_ACCEPT_RATE):
-                e = K.Engine(sampler=sampler, target=K.GaussDiagTarget.negdot(d), nchains=5, nsteps=2, tuner=tuner, targetrate=0.5, **extra)
-                assert tuple(e.layout()) == tuple(O.default_layout(L.TARGET_GAUSS_DIAG, d, sampler=sampler, tuner=tuner)), (d, sampler, tuner)
-                e.close()
+                for mon, sparse in ((0, False), (L.MON_SUMMARIES, False), (L.MON_SUMMARIES, True)):
+                    e = K.Engine(sampler=sampler, target=K.GaussDiagTarget.negdot(d), nchains=5, nsteps=2, tuner=tuner, targetrate=0.5, monitor=mon,
+                                 sparse_moves=sparse, **extra)
+                    mirror = O.default_layout(L.TARGET_GAUSS_DIAG, d, sampler=sampler, tuner=tuner, summaries=bool(mon), sparse_moves=sparse)
+                    assert tuple(e.layout()) == tuple(mirror), (d, sampler, tuner, mon, sparse)
+                    e.close()
 
 
 def test_pair_transposed_layout_is_optional():

@@ -91,7 +91,8 @@ def test_cfg2_mala_moments_within_1e3():
     eng.close()
 
     eng = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(d), nchains=n, nsteps=210000, burnin=10000,
-                   driftstep=0.9, monitor=L.MON_SUMMARIES, bm_batchlen=5000, steps_per_launch=50)
+                   driftstep=0.9, monitor=L.MON_SUMMARIES, bm_batchlen=5000, steps_per_launch=50, sparse_moves=True)   # (the bench job's mode)
+    assert eng.layout()[:2] == (3, 4)
     eng.init_state_normal()
     eng.run(210000)
     mean, var, acc, ns = _pooled_moments(eng)
