@@ -25,14 +25,15 @@ from klara_jl_amd import _lib as L  # noqa: E402
 def run_case(name):
     c = cases.make_case(name)
     layout = None                      # the oracle mirrors the product's layout choice (oracle_ffi.default_layout)
-    job = O.OracleJob(**cases.oracle_kwargs(c, layout=layout))
-    if name in cases.DIAGT_CASES:
+    dt = name in cases.DIAGT_CASES     # (these run with the accept mask as their only monitor: no running sums, 4 lanes per chain for MH / MALA)
+    job = O.OracleJob(**cases.oracle_kwargs(c, layout=layout), want_sums=not dt)
+    if dt:
         assert job.layout.kind == 3
     st = job.init_state_normal() if c["x0"] is None else job.set_state(c["x0"])
     assert st == 0, (name, st)
     x0 = job.X.copy()
     assert job.run(c["nsteps"]) == 0
-    return dict(x0=x0, x=job.X, lt=job.LT, g=job.G, accept=job.accept, sum=job.sum, sumsq=job.sumsq,
+    return dict(x0=x0, x=job.X, lt=job.LT, g=job.G, accept=job.accept, sum=job.sum if not dt else np.zeros(0), sumsq=job.sumsq if not dt else np.zeros(0),
                 naccept=job.naccept, step=job.step, accepted=job.accepted, proposed=job.proposed,
                 totproposed=job.totproposed, da_epsbar=job.da_epsbar, da_hbar=job.da_hbar, layout=np.array([job.layout.kind, job.layout.G, job.layout.E]))
 
