@@ -112,7 +112,16 @@ KD_FN double kd_u52(uint32_t whi, uint32_t wlo)
 
 /* ---------------------------------------------------------------- log */
 /* Algorithm: FreeBSD msun e_log.c reduction x = 2^k * (1+f), sqrt(1/2) <= 1+f < sqrt(2),
- * s = f/(2+f), log(1+f) = f - hfsq + s*(hfsq + R(s^2)); single code path for every f. */
+ * s = f/(2+f), log(1+f) = f - hfsq + s*(hfsq + R(s^2)); single code path for every f.
+ * The reduction, the polynomial coefficients Lg1..Lg7 and the ln2 split are those of e_log.c, whose notice reads:
+ * ====================================================
+ * Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+ *
+ * Developed at SunSoft, a Sun Microsystems, Inc. business.
+ * Permission to use, copy, modify, and distribute this
+ * software is freely granted, provided that this notice
+ * is preserved.
+ * ==================================================== */
 KD_FN double kd_log(double x)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;

@@ -1,8 +1,10 @@
 """Post-hoc chain statistics of the reference (src/stats/**) on the saved values of a chain.
 
 These consume the path's output.  `mean`, iid variance and `acceptance` for ALL chains come from
-the on-device running sums / accept masks (api.py); the autocovariance-based estimators below run on the host over
-one chain's history at a time (NumPy) — a device version is listed as next work in DESIGN.md.
+the on-device running sums / accept masks (api.py), and every estimator below also exists on the device for every (chain, dimension)
+series at once — post hoc over a stored history (klara_get_chain_mcvar / _ipse) and, for :bm / :imse / :ipse, accumulated while
+sampling (klara_get_chain_bm, klara_get_chain_acov_mcvar).  This module is the NumPy restatement of the reference's estimators on one
+chain's history: what the device versions are tested against.
 
   mcvar(v, "iid")            var(v)/length(v)                                  stats/variance/mcvar.jl:5
   mcvar(v, "bm", batchlen)   batch means, Flegal & Jones 2010                  mcvar.jl:35-41

@@ -109,6 +109,11 @@ def test_julia_job_constructor_maps_klara_structs_to_the_descriptor():
     assert "MON_ACCEPT, MON_HISTORY, MON_SUMMARIES, MON_HIST_LT, MON_HIST_GRAD, MON_HIST_LLLP = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20" in jl
 
 
+def test_integration_md_prints_the_julia_module_verbatim():
+    jl = (ROOT / "julia" / "KlaraHIP.jl").read_text()
+    assert "```julia\n" + jl + "```" in (ROOT / "INTEGRATION.md").read_text()
+
+
 def test_julia_stub_binds_only_declared_symbols():
     import re
     jl = (ROOT / "julia" / "KlaraHIP.jl").read_text()
