@@ -336,25 +336,24 @@ def extra_measurements(K, L, n, stream):
     ex["mala_one_transition_per_launch_roofline"] = valu_roofline(diagt_kernel_name(1, lay[1], lay[2], True, True, False), ls, grid=diagt_grid(n, lay[1]))
 
     # -- HMC L=10 eps=0.1 on the README target (VALU) and on the dense target (FP64 MFMA; cfg 3)
-    e = K.Engine(sampler=L.SAMPLER_HMC, target=neg, nchains=n, nsteps=10 ** 7, leapstep=0.1, nleaps=10, steps_per_launch=16,
-                 stream=stream, nstreams=1)
+    e = K.Engine(sampler=L.SAMPLER_HMC, target=neg, nchains=n, nsteps=10 ** 7, leapstep=0.1, nleaps=10, stream=stream, nstreams=1)
     e.init_state_normal()
-    rate, ls, _ = timed_rate(e, n, 16, 128)
+    rate, ls, _ = timed_rate(e, n, 32, 128)
     lay = e.layout(); e.close()
     ex["hmc_iso_leapfrog_chain_per_s"] = rate * 10
     ex["hmc_iso_roofline"] = valu_roofline(diagt_kernel_name(2, lay[1], lay[2], False, True, False), ls, grid=diagt_grid(n, lay[1]))
 
     e = K.Engine(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget.compound_symmetric(NDIMS, 0.5), nchains=n, nsteps=10 ** 7,
-                 leapstep=0.1, nleaps=10, steps_per_launch=16, stream=stream)
+                 leapstep=0.1, nleaps=10, stream=stream)
     e.init_state_normal()
-    rate, ls, _ = timed_rate(e, n, 16, 128)
+    rate, ls, _ = timed_rate(e, n, 32, 128)
     e.close()
-    flops_per_launch = n * 16 * 10 * (2 * NDIMS * NDIMS + 6 * NDIMS)         # 2 D^2 + 6 D per leapfrog and chain
+    flops_per_launch = n * L.DEFAULT_STEPS_PER_LAUNCH * 10 * (2 * NDIMS * NDIMS + 6 * NDIMS)         # 2 D^2 + 6 D per leapfrog and chain
     tf = flops_per_launch / ls / 1e12
     ex["cfg3_hmc_dense_leapfrog_chain_per_s"] = rate * 10
     ex["cfg3_hmc_dense_transitions_per_s"] = rate
     rf = {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF,
-          "kernel": "k_dense_transitions<HMC, NE=25> (v_mfma_f64_16x16x4 + v_mfma_f64_4x4x4_4b tail tile), 16 transitions per launch",
+          "kernel": f"k_dense_transitions<HMC, NE=25> (v_mfma_f64_16x16x4 + v_mfma_f64_4x4x4_4b tail tile), {L.DEFAULT_STEPS_PER_LAUNCH} transitions per launch",
           "launch_us": ls * 1e6,
           "source": "algorithmic flops (2 D^2 + 6 D per leapfrog and chain, SURVEY 8(d)) / launch duration from HIP events in this run"}
     row = pmc_lookup("k_dense_transitions<2")

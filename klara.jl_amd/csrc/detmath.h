@@ -258,6 +258,21 @@ KD_FN double kd_log_pos(double x)
     return r;
 }
 
+/* log(1 + exp(x)) and 1 / (1 + exp(-x)) from ONE exponential, t = exp(-|x|) in [0, 1]:
+ *   log(1 + exp(x)) = max(x, 0) + log(1 + t),    1 / (1 + exp(-x)) = x >= 0 ? 1 / (1 + t) : t / (1 + t).
+ * The logistic-regression targets need both per data row (doc/examples/swiss/MALA/analytical.jl:13,17 write exp(Xp) and exp(-Xp)
+ * separately): one kd_exp instead of two, and no overflow for large |x| (the literal form gives log(inf) beyond x = 709). */
+KD_FN void kd_softplus_logistic(double x, double* softplus, double* logistic)
+{
+    const double ax = x < 0.0 ? -x : x;
+    const double t = kd_exp(-ax);
+    const double onept = 1.0 + t;
+    const double l1p = kd_log_pos(onept);
+    *softplus = (x > 0.0 ? x : 0.0) + l1p;
+    *logistic = (x >= 0.0 ? 1.0 : t) / onept;
+    if (x != x) { *softplus = x; *logistic = x; }
+}
+
 /* ---------------------------------------------------------------- erf */
 /* erf for the tuner's erf_rate_score (src/tuners/AcceptanceRateMCTuner.jl:17).  Evaluated rarely (once per tuning
  * period), so a plain, fixed-trip-count formulation is used instead of the msun rational approximations:

@@ -384,12 +384,14 @@ struct LogisticTarget {
 #pragma unroll
             for (int e = 0; e < E; ++e) if (e < D) xp = kd_fma(row[e], x[e], xp);   // Xp = v[2]*p
             const double yr = sy[r];
+            double sp, lg;
+            kd_softplus_logistic(xp, &sp, &lg);                                   // log(1+exp(Xp)), 1/(1+exp(-Xp)): one exponential
             if (WANT_LT) {
                 dotxy = dotxy + xp * yr;                                          // dot(Xp, v[3])
-                slog = slog + kd_log_pos(1.0 + kd_exp(xp));                           // sum(log(1+exp(Xp)))
+                slog = slog + sp;                                                 // sum(log(1+exp(Xp)))
             }
             if (WANT_GRAD) {
-                const double res = yr - 1.0 / (1.0 + kd_exp(-xp));                // v[3]-1./(1+exp(-Xp))
+                const double res = yr - lg;                                       // v[3]-1./(1+exp(-Xp))
 #pragma unroll
                 for (int e = 0; e < E; ++e) if (e < D) gacc[e] = kd_fma(row[e], res, gacc[e]);
             }

@@ -162,12 +162,14 @@ static void ko_logit_eval(const ko_target_ctx* c, const double* p, double* lt, d
         const double* row = d->logit_X + (size_t)r * D;
         double xp = 0.0;
         for (int k = 0; k < D; ++k) xp = kd_fma(row[k], p[k], xp);            /* Xp = v[2]*p        */
+        double sp, lg;                                                          /* log(1+exp(Xp)), 1/(1+exp(-Xp)) from one */
+        kd_softplus_logistic(xp, &sp, &lg);                                     /* exponential (detmath.h): same value, no overflow */
         if (lt) {
             pdot[q] = pdot[q] + xp * d->logit_y[r];                             /* dot(Xp, v[3])      */
-            plog[q] = plog[q] + kd_log_pos(1.0 + kd_exp(xp));                       /* sum(log(1+exp(Xp)))*/
+            plog[q] = plog[q] + sp;                                             /* sum(log(1+exp(Xp)))*/
         }
         if (g) {
-            const double res = d->logit_y[r] - 1.0 / (1.0 + kd_exp(-xp));       /* v[3]-1./(1+exp(-Xp)) */
+            const double res = d->logit_y[r] - lg;                              /* v[3]-1./(1+exp(-Xp)) */
             for (int k = 0; k < D; ++k) pg[q][k] = kd_fma(row[k], res, pg[q][k]); /* v[2]'*(...)      */
         }
     }

@@ -118,7 +118,9 @@ KLARA_USER_FN double klara_user_logtarget(const double* p, int D, const double* 
         double xp = 0.0;
         for (int e = 0; e < KLARA_D; ++e) xp = kd_fma(X[r * KLARA_D + e], p[e], xp);
         dotxy = dotxy + xp * y[r];
-        slog = slog + kd_log_pos(1.0 + kd_exp(xp));
+        double sp, lg;
+        kd_softplus_logistic(xp, &sp, &lg);
+        slog = slog + sp;
     }
     double dotpp = 0.0;
     for (int e = 0; e < KLARA_D; ++e) dotpp = dotpp + p[e] * p[e];
@@ -132,7 +134,9 @@ KLARA_USER_FN void klara_user_gradlogtarget(const double* p, int D, const double
     for (int r = 0; r < n; ++r) {
         double xp = 0.0;
         for (int e = 0; e < KLARA_D; ++e) xp = kd_fma(X[r * KLARA_D + e], p[e], xp);
-        const double res = y[r] - 1.0 / (1.0 + kd_exp(-xp));
+        double sp, lg;
+        kd_softplus_logistic(xp, &sp, &lg);
+        const double res = y[r] - lg;
         for (int e = 0; e < KLARA_D; ++e) g[e] = kd_fma(X[r * KLARA_D + e], res, g[e]);
     }
     for (int e = 0; e < KLARA_D; ++e) g[e] = g[e] - p[e] / lambda;
