@@ -29,7 +29,8 @@ struct MfmaCtx {
     int lane, q, cl;
     long long chain;
     bool chain_ok;
-    bool valid[NE];
+    int nv;      // elements e < nv of this lane are real: 4 e + q < D on an existing chain (one register instead of NE lane masks)
+    __device__ __forceinline__ bool valid(int e) const { return e < nv; }
 };
 
 template <int NE>
@@ -42,8 +43,8 @@ __device__ __forceinline__ MfmaCtx<NE> make_mctx(const KParams& p)
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     c.chain = wave * 16 + c.cl;
     c.chain_ok = c.chain < p.nchains;
-#pragma unroll
-    for (int e = 0; e < NE; ++e) c.valid[e] = c.chain_ok && (4 * e + c.q < p.D);
+    c.nv = c.chain_ok ? (p.D - c.q + 3) / 4 : 0;
+    if (c.nv > NE) c.nv = NE;
     return c;
 }
 
@@ -52,14 +53,14 @@ __device__ __forceinline__ void mload(const MfmaCtx<NE>& c, const gdouble* base,
 {
     const gdouble* row = base + c.chain * D + c.q;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) v[e] = c.valid[e] ? row[4 * e] : 0.0;
+    for (int e = 0; e < NE; ++e) v[e] = c.valid(e) ? row[4 * e] : 0.0;
 }
 template <int NE>
 __device__ __forceinline__ void mstore(const MfmaCtx<NE>& c, gdouble* base, int D, const double (&v)[NE])
 {
     gdouble* row = base + c.chain * D + c.q;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) if (c.valid[e]) row[4 * e] = v[e];
+    for (int e = 0; e < NE; ++e) if (c.valid(e)) row[4 * e] = v[e];
 }
 
 // all-reduce over the 4 lanes (q = 0..3) of a chain: xor 16 then xor 32 — the canonical tree
@@ -199,7 +200,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             mnormals<NE>(cx, p.seed, gchain, t, mom);                  // HMC.jl:135
             double k0[1] = { 0.0 };
 #pragma unroll
-            for (int e = 0; e < NE; ++e) k0[0] = k0[0] + (cx.valid[e] ? mom[e] * mom[e] : 0.0);
+            for (int e = 0; e < NE; ++e) k0[0] = k0[0] + (cx.valid(e) ? mom[e] * mom[e] : 0.0);
             mreduce<1>(k0, cx.lane);
             const double H0 = lt - 0.5 * k0[0];                        // HMC.jl:137
             const double eps = tn.step, halfe = 0.5 * eps;
@@ -239,8 +240,8 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             double l1 = 0.0, k1 = 0.0;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                l1 = l1 + (cx.valid[e] ? xp[e] * gp[e] : 0.0);         // lt' = c + 1/2 x'.g'   (HMC.jl:157)
-                k1 = k1 + (cx.valid[e] ? mom[e] * mom[e] : 0.0);
+                l1 = l1 + (cx.valid(e) ? xp[e] * gp[e] : 0.0);         // lt' = c + 1/2 x'.g'   (HMC.jl:157)
+                k1 = k1 + (cx.valid(e) ? mom[e] * mom[e] : 0.0);
             }
             red[0] = l1; red[1] = k1;
             mreduce<2>(red, cx.lane);
@@ -267,17 +268,17 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                     const double mu = xc[e] + halfh * g0[e];           // MALA.jl:83
                     xp[e] = mu + sq * z[e];                            // MALA.jl:84
                     const double q1 = mu - xp[e];
-                    s1 = s1 + (cx.valid[e] ? (q1 * q1) * half_inv_h : 0.0);      // MALA.jl:90
+                    s1 = s1 + (cx.valid(e) ? (q1 * q1) * half_inv_h : 0.0);      // MALA.jl:90
                 }
             }
             dense_grad<NE>(ldsP, cx.lane, xp, gp);                     // MALA.jl:86
             double l1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                l1 = l1 + (cx.valid[e] ? xp[e] * gp[e] : 0.0);
+                l1 = l1 + (cx.valid(e) ? xp[e] * gp[e] : 0.0);
                 const double mup = xp[e] + halfh * gp[e];              // MALA.jl:91
                 const double q2 = mup - xc[e];
-                s2 = s2 + (cx.valid[e] ? (q2 * q2) * half_inv_h : 0.0);          // MALA.jl:92
+                s2 = s2 + (cx.valid(e) ? (q2 * q2) * half_inv_h : 0.0);          // MALA.jl:92
             }
             red[0] = l1; red[1] = s1; red[2] = s2;
             mreduce<3>(red, cx.lane);
@@ -302,7 +303,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             dense_grad<NE>(ldsP, cx.lane, xp, gp);                     // MH.jl:81
             double l1 = 0.0;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) l1 = l1 + (cx.valid[e] ? xp[e] * gp[e] : 0.0);
+            for (int e = 0; e < NE; ++e) l1 = l1 + (cx.valid(e) ? xp[e] * gp[e] : 0.0);
             red[0] = l1;
             mreduce<1>(red, cx.lane);
             ltp = p.gconst + 0.5 * red[0];
@@ -322,7 +323,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 gdouble* sr = p.sum + cx.chain * p.D + cx.q;
                 gdouble* qr = p.sumsq + cx.chain * p.D + cx.q;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) if (cx.valid[e]) {
+                for (int e = 0; e < NE; ++e) if (cx.valid(e)) {
                     sr[4 * e] = sr[4 * e] + hf * xo[e];
                     qr[4 * e] = qr[4 * e] + hf * (xo[e] * xo[e]);
                 }
@@ -366,7 +367,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                     if (col < p.hist_cols) {
                         gdouble* dst = p.hist + (col * p.nchains + cx.chain) * p.D + cx.q;
 #pragma unroll
-                        for (int e = 0; e < NE; ++e) if (cx.valid[e]) dst[4 * e] = xs[e];
+                        for (int e = 0; e < NE; ++e) if (cx.valid(e)) dst[4 * e] = xs[e];
                     }
                 }
             }
@@ -382,7 +383,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 }
                 gdouble* dst = p.hist_g + (col * p.nchains + cx.chain) * p.D + cx.q;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) if (cx.valid[e]) dst[4 * e] = gs[e];
+                for (int e = 0; e < NE; ++e) if (cx.valid(e)) dst[4 * e] = gs[e];
             }
         }
     }
@@ -420,8 +421,8 @@ __global__ __launch_bounds__(512) void k_dense_init(const KParams p, const doubl
     bool bad = false;
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-        l1 = l1 + (cx.valid[e] ? x[e] * g[e] : 0.0);
-        if (needgrad) bad = bad || (cx.valid[e] && !kfinite(g[e]));
+        l1 = l1 + (cx.valid(e) ? x[e] * g[e] : 0.0);
+        if (needgrad) bad = bad || (cx.valid(e) && !kfinite(g[e]));
     }
     red[0] = l1;
     mreduce<1>(red, cx.lane);
