@@ -12,7 +12,7 @@ from klara_jl_amd import _lib as L
 
 def job():
     e = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=65536, nsteps=10 ** 7, driftstep=0.9,
-                 monitor=L.MON_SUMMARIES)
+                 monitor=L.MON_SUMMARIES, sparse_moves=1)                 # the bench job
     e.init_state_normal()
     return e
 
