@@ -86,9 +86,10 @@ struct GaussDiagTarget <: HIPTarget          # lt = c - sum w_i (x_i - mu_i)^2 ;
     ndims::Int; w::Vector{Float64}; mu::Vector{Float64}; c::Float64
 end
 GaussDiagTarget(D::Integer) = GaussDiagTarget(D, Float64[], Float64[], 0.0)
-struct GaussDenseTarget <: HIPTarget         # lt = c - 1/2 x' P x, P row-major D x D
-    P::Matrix{Float64}; c::Float64
+struct GaussDenseTarget <: HIPTarget         # lt = c - 1/2 (x-mu)' P (x-mu), P row-major D x D; mu empty = 0
+    P::Matrix{Float64}; c::Float64; mu::Vector{Float64}
 end
+GaussDenseTarget(P::Matrix{Float64}, c::Float64=0.0) = GaussDenseTarget(P, c, Float64[])
 struct LogisticTarget <: HIPTarget           # doc/examples/swiss/MALA/analytical.jl:11-18; X is ndata x D
     X::Matrix{Float64}; y::Vector{Float64}; lambda::Float64
 end
@@ -192,6 +193,7 @@ function HIPMCJob(parameter::HIPParameter, sampler, mcrange, v0::Dict;
     elseif isa(t, GaussDenseTarget)
         P = rowmajor(t.P); push!(keep, P)
         kw[:target] = TARGET_GAUSS_DENSE; kw[:gauss_prec] = pointer(P); kw[:gauss_const] = t.c
+        if !isempty(t.mu); push!(keep, t.mu); kw[:gauss_mu] = pointer(t.mu); end
     elseif isa(t, LogisticTarget)
         X = rowmajor(t.X); push!(keep, X); push!(keep, t.y)
         kw[:target] = TARGET_LOGISTIC; kw[:logit_X] = pointer(X); kw[:logit_y] = pointer(t.y)

@@ -52,6 +52,7 @@ struct klara_handle {
     double *bm_prev = nullptr, *bm_mean = nullptr, *bm_m2 = nullptr; long long bm_count = 0;
     KParams* d_params = nullptr;    // device copy of the handle's static kernel parameters
     double lpconst = 0.0;
+    bool dense_mu = false;          // dense target with a mean: Pfrag carries mu behind the matrix fragments
     // run state
     bool have_state = false;
     unsigned long long epoch = 0;   // klara_reset calls so far: the Philox key of the job is seed + epoch * KLARA_EPOCH_KEY_STRIDE
@@ -246,9 +247,6 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     int kind, G, E;
     st = select_layout(*desc, &kind, &G, &E);
     if (st != KLARA_OK) return st;
-    if (desc->target == KLARA_TARGET_GAUSS_DENSE &&
-        (desc->sampler == KLARA_SAMPLER_SLICE || desc->gauss_mu != nullptr))
-        return KLARA_ERR_UNSUPPORTED;
     if (desc->tuner_mode == KLARA_TUNE_POOLED && desc->sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
     // the logistic kernels keep the data rows in LDS next to the 8 KB of math tables, inside the 64 KB a launch gets
     // without raising the per-kernel limit: ndata * (D + 1) doubles <= 56 KB (swiss: 200 x 5 doubles = 8 KB)
@@ -366,6 +364,11 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
                     const size_t row = 16 * (size_t)t + ((tail && t == MT - 1) ? (l & 3) : (l & 15)), col = 4 * (size_t)kk + (l >> 4);
                     if (row < D && col < D) frag[((size_t)t * NE + kk) * 64 + l] = desc->gauss_prec[row * D + col];
                 }
+        h->dense_mu = desc->gauss_mu != nullptr;
+        if (h->dense_mu) {                                       // the mean, [4 e + q] = mu[4 e + q], zero beyond D
+            frag.resize(frag.size() + 4 * (size_t)NE, 0.0);
+            for (int i = 0; i < D; ++i) frag[(size_t)MT * NE * 64 + i] = desc->gauss_mu[i];
+        }
         CK(upload(&h->Pfrag, frag.data(), frag.size()));
     }
     // the descriptor's host pointers are not retained
@@ -547,7 +550,7 @@ static klara_status init_common(klara_handle* h)
     const int needgrad = d.sampler == KLARA_SAMPLER_MALA || d.sampler == KLARA_SAMPLER_HMC;
     KParams p = make_params(h);
     hipError_t e;
-    if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, needgrad, grid_for(h), st);
+    if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, h->dense_mu, needgrad, grid_for(h), st);
     else if (h->kind == 3)
         e = h->G == 4 ? klara_launch_diagt_init_q4(p, h->E / 2, needgrad, grid_for(h), st)
           : h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
@@ -634,7 +637,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
     const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
     int mode = (plain ? 1 : 0) | ((plain && d.monitor == 0) ? 2 : 0);         // 3: no monitors either
     if (mode == 3 && kl.nsteps == 1) mode = 7;                                 // one iterate! per launch
-    if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, h->E, h->Pfrag, grid_for(h), h->stream);
+    if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, h->E, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on

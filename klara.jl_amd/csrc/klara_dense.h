@@ -1,7 +1,8 @@
 // klara_dense.h — dense-Gaussian target on the FP64 matrix cores (layout kind 1, "MFMA-transposed").
 //
 // Target (builder-defined; Klara ships no dense example — SURVEY F8, §8(d) cfg 3):
-//     lt(x) = c - 1/2 x' P x,   grad(x) = -P x,   P = D x D precision matrix (mu = 0).
+//     lt(x) = c - 1/2 (x-mu)' P (x-mu),   grad(x) = -P (x-mu),   P = D x D precision matrix; HASMU = false is the mu = 0 form
+//     (no subtraction anywhere), HASMU = true reads mu from LDS where the difference is formed.
 //
 // One wavefront carries 16 chains.  Lane l = (q = l >> 4, cl = l & 15) belongs to chain cl of the tile
 // and holds the NE = ceil(D/4) elements { 4e + q : e = 0..NE-1 } of every per-chain vector.  The
@@ -27,10 +28,19 @@ template <int NE>
 struct MfmaCtx {
     static constexpr int MT = (NE + 3) / 4;
     int lane, q, cl;
-    long long chain;
+    long long chain, first_chain;      // first_chain: chain 0 of the wavefront's tile (wave-uniform)
+    int here;                          // chains of the tile that exist
     bool chain_ok;
-    int nv;      // elements e < nv of this lane are real: 4 e + q < D on an existing chain (one register instead of NE lane masks)
+    int nv;          // elements e < nv of this lane are real: 4 e + q < D on an existing chain (one register instead of NE lane masks)
+    unsigned voff0;  // byte offset of element 0 of this lane inside the tile's window
     __device__ __forceinline__ bool valid(int e) const { return e < nv; }
+    // Padding is zeroed where it enters (loads return 0 outside the window, the normals of missing elements are set to 0, the padded
+    // rows of P are 0): every missing element of every per-chain vector then stays +-0 through the transition, its terms add +-0 to
+    // the sums, and no sum needs a validity select.  Only the byte offsets of loads and stores depend on nv.
+    __device__ __forceinline__ unsigned off(int e, int nv_) const { return e < nv_ ? voff0 + 32u * (unsigned)e : KLARA_BUF_OOB; }
+    // nv behind an empty asm: the NE offsets of an access group are formed where they are used (2 instructions each) instead of
+    // being hoisted out of the transition loop as NE loop-invariant registers that the MFMA loop then forces into scratch
+    __device__ __forceinline__ int nv_here() const { int n = nv; __asm__ volatile("" : "+v"(n)); return n; }
 };
 
 template <int NE>
@@ -40,27 +50,44 @@ __device__ __forceinline__ MfmaCtx<NE> make_mctx(const KParams& p)
     c.lane = threadIdx.x & 63;
     c.q = c.lane >> 4;
     c.cl = c.lane & 15;
-    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    c.chain = wave * 16 + c.cl;
-    c.chain_ok = c.chain < p.nchains;
+    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    c.first_chain = wave * 16;
+    const long long left = p.nchains - c.first_chain;
+    c.here = left < 16 ? (left > 0 ? (int)left : 0) : 16;
+    c.chain = c.first_chain + c.cl;
+    c.chain_ok = c.cl < c.here;
     c.nv = c.chain_ok ? (p.D - c.q + 3) / 4 : 0;
     if (c.nv > NE) c.nv = NE;
+    c.voff0 = (unsigned)((c.cl * p.D + c.q) * 8);
     return c;
 }
 
+// the tile's rows of a (chains x D) array as one buffer window (scalar descriptor; accesses outside it return 0 / are dropped)
 template <int NE>
-__device__ __forceinline__ void mload(const MfmaCtx<NE>& c, const gdouble* base, int D, double (&v)[NE])
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mwin(const MfmaCtx<NE>& c, const gdouble* base, long long row0, int D)
 {
-    const gdouble* row = base + c.chain * D + c.q;
-#pragma unroll
-    for (int e = 0; e < NE; ++e) v[e] = c.valid(e) ? row[4 * e] : 0.0;
+    // (every term is wave-uniform; the explicit readfirstlane keeps the descriptor in scalar registers where the compiler cannot
+    // prove it — a descriptor in vector registers costs a readfirstlane loop around every access)
+    const unsigned long long a = (unsigned long long)(base + (row0 + c.first_chain) * D);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(c.here * D * 8), 0x00020000);
 }
 template <int NE>
-__device__ __forceinline__ void mstore(const MfmaCtx<NE>& c, gdouble* base, int D, const double (&v)[NE])
+__device__ __forceinline__ void mload(const MfmaCtx<NE>& c, const gdouble* base, int D, double (&v)[NE], long long row0 = 0)
 {
-    gdouble* row = base + c.chain * D + c.q;
+    const __amdgpu_buffer_rsrc_t w = mwin<NE>(c, base, row0, D);
+    const int nv = c.nv_here();
 #pragma unroll
-    for (int e = 0; e < NE; ++e) if (c.valid(e)) row[4 * e] = v[e];
+    for (int e = 0; e < NE; ++e) v[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(w, c.off(e, nv), 0, 0));
+}
+template <int NE>
+__device__ __forceinline__ void mstore(const MfmaCtx<NE>& c, gdouble* base, int D, const double (&v)[NE], long long row0 = 0)
+{
+    const __amdgpu_buffer_rsrc_t w = mwin<NE>(c, base, row0, D);
+    const int nv = c.nv_here();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, v[e]), w, c.off(e, nv), 0, 0);
 }
 
 // all-reduce over the 4 lanes (q = 0..3) of a chain: xor 16 then xor 32 — the canonical tree
@@ -83,6 +110,7 @@ __device__ __forceinline__ void mnormals(const MfmaCtx<NE>& c, unsigned long lon
 {
     const uint32_t sh = (uint32_t)(c.q >> 1);
     const bool odd = (c.q & 1) != 0;
+    const int nv = c.nv_here();
     // Lanes q and q^1 (lane ^ 16) of a chain need the two halves of the SAME Box-Muller pairs (even dims take the
     // cos half, odd dims the sin half).  Instead of both lanes evaluating every pair, elements are taken two at a
     // time: the even-q lane evaluates the pair of element e, the odd-q lane the pair of element e+1, and they swap
@@ -93,14 +121,14 @@ __device__ __forceinline__ void mnormals(const MfmaCtx<NE>& c, unsigned long lon
         const uint32_t mine = 2u * (uint32_t)(odd ? e + 1 : e) + sh;
         kd_normal_pair(kd_stream_block(seed, gchain, t, mine), &z0, &z1);
         const double recv = bperm_xor(odd ? z0 : z1, c.lane, 16);
-        z[e] = odd ? recv : z0;          // even q: cos half of pair(e);   odd q: sin half of pair(e) from the partner
-        z[e + 1] = odd ? z1 : recv;      // even q: cos half of pair(e+1) from the partner; odd q: sin half of pair(e+1)
+        z[e] = e < nv ? (odd ? recv : z0) : 0.0;              // even q: cos half of pair(e);   odd q: sin half of pair(e) from the partner
+        z[e + 1] = e + 1 < nv ? (odd ? z1 : recv) : 0.0;  // even q: cos half of pair(e+1) from the partner; odd q: sin half of pair(e+1)
         __builtin_amdgcn_sched_barrier(0);   // keep the unrolled Philox/Box-Muller bodies from interleaving (VGPR pressure)
     }
     if (NE & 1) {
         double z0, z1;
         kd_normal_pair(kd_stream_block(seed, gchain, t, 2u * (uint32_t)(NE - 1) + sh), &z0, &z1);
-        z[NE - 1] = odd ? z1 : z0;
+        z[NE - 1] = NE - 1 < nv ? (odd ? z1 : z0) : 0.0;
     }
 }
 
@@ -114,9 +142,10 @@ __device__ __forceinline__ void mnormals(const MfmaCtx<NE>& c, unsigned long lon
 // lane that owns that element.  No shuffle, no extra registers (one f64 accumulator instead of four), the same LDS
 // footprint (the tail's A fragments take the place of the padded tile's), 10.7 % less matrix-pipe time at D = 100.
 // Its accumulation order is the same k-ascending fma chain (tests/test_gpu_parity.py::test_mfma_f64_4x4x4_order).
-template <int NE>
+// HASMU: the B operand is x - mu, mu read per k-step from LDS (ldsMu[4 kk + q], zero for missing elements).
+template <int NE, bool HASMU = false>
 __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int lane,
-                                           const double (&x)[NE], double (&g)[4 * ((NE + 3) / 4)])
+                                           const double (&x)[NE], double (&g)[4 * ((NE + 3) / 4)], const double* ldsMu = nullptr)
 {
     constexpr int MT = (NE + 3) / 4;
     constexpr bool TAIL = (NE % 4) == 1;
@@ -132,7 +161,7 @@ __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int 
     for (int t = 0; t < MT; ++t) a_cur[t] = ldsP[(t * NE) * 64 + lane];
 #pragma unroll
     for (int kk = 0; kk < NE; ++kk) {
-        const double b = x[kk];
+        const double b = HASMU ? x[kk] - ldsMu[4 * kk + (lane >> 4)] : x[kk];
         if (kk + 1 < NE) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) a_nxt[t] = ldsP[(t * NE + kk + 1) * 64 + lane];
@@ -153,7 +182,7 @@ __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int 
     if (TAIL) { g[4 * MTF + 0] = -acc_t; g[4 * MTF + 1] = 0.0; g[4 * MTF + 2] = 0.0; g[4 * MTF + 3] = 0.0; }
 }
 
-template <int SAMPLER, int NE, bool DA>
+template <int SAMPLER, int NE, bool DA, bool HASMU = false>
 __global__ __launch_bounds__(512)
 void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
 {
@@ -164,9 +193,13 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
     constexpr int NG = 4 * MT;
     double* ldsP = reinterpret_cast<double*>(smem);
     for (int i = threadIdx.x; i < MT * NE * 64; i += blockDim.x) ldsP[i] = Pfrag[i];
+    const double* const ldsMu = ldsP + MT * NE * 64;             // mu[4 e + q] at [4 e + q], zero-padded (HASMU only)
+    if (HASMU) { for (int i = threadIdx.x; i < 4 * NE; i += blockDim.x) ldsP[MT * NE * 64 + i] = Pfrag[MT * NE * 64 + i]; }
     kd_tables_to_lds();          // (also the barrier for ldsP)
 
     const MfmaCtx<NE> cx = make_mctx<NE>(p);
+    // x - mu of the lane's element e (lt = c + 1/2 (x-mu).g); missing elements: 0 - 0
+    const auto dx = [&](const double (&v)[NE], int e) { return HASMU ? v[e] - ldsMu[4 * e + cx.q] : v[e]; };
     const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
     const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
     constexpr bool da = DA;   // dual averaging is a separate instantiation: the masked leapfrog loop costs registers
@@ -177,6 +210,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
     long long scol = kl.save_col0;
     double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
     unsigned long long nacc = 0;
+    bool stuck = false;                                  // slice sampler: step-out / shrink ran out of attempts
     const bool do_sum = p.sum != nullptr;
     long long held = do_sum ? p.held[cx.chain_ok ? cx.chain : 0] : 0;        // running sums in sojourn form (KParams::held)
 
@@ -200,7 +234,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             mnormals<NE>(cx, p.seed, gchain, t, mom);                  // HMC.jl:135
             double k0[1] = { 0.0 };
 #pragma unroll
-            for (int e = 0; e < NE; ++e) k0[0] = k0[0] + (cx.valid(e) ? mom[e] * mom[e] : 0.0);
+            for (int e = 0; e < NE; ++e) k0[0] = k0[0] + mom[e] * mom[e];
             mreduce<1>(k0, cx.lane);
             const double H0 = lt - 0.5 * k0[0];                        // HMC.jl:137
             const double eps = tn.step, halfe = 0.5 * eps;
@@ -213,7 +247,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                     for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];   // samplers.jl:130
 #pragma unroll
                     for (int e = 0; e < NE; ++e) xp[e] = xp[e] + eps * mom[e];      // samplers.jl:131
-                    dense_grad<NE>(ldsP, cx.lane, xp, gp);                          // samplers.jl:132
+                    dense_grad<NE, HASMU>(ldsP, cx.lane, xp, gp, ldsMu);                          // samplers.jl:132
 #pragma unroll
                     for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];   // samplers.jl:133
                 }
@@ -228,7 +262,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                         for (int e = 0; e < NE; ++e) xp[e] = xp[e] + eps * mom[e];
                     }
                     double gn[NG];
-                    dense_grad<NE>(ldsP, cx.lane, xp, gn);
+                    dense_grad<NE, HASMU>(ldsP, cx.lane, xp, gn, ldsMu);
                     if (go) {
 #pragma unroll
                         for (int e = 0; e < NG; ++e) gp[e] = gn[e];
@@ -240,8 +274,8 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             double l1 = 0.0, k1 = 0.0;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                l1 = l1 + (cx.valid(e) ? xp[e] * gp[e] : 0.0);         // lt' = c + 1/2 x'.g'   (HMC.jl:157)
-                k1 = k1 + (cx.valid(e) ? mom[e] * mom[e] : 0.0);
+                l1 = l1 + dx(xp, e) * gp[e];                           // lt' = c + 1/2 (x'-mu).g'   (HMC.jl:157)
+                k1 = k1 + mom[e] * mom[e];
             }
             red[0] = l1; red[1] = k1;
             mreduce<2>(red, cx.lane);
@@ -268,17 +302,17 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                     const double mu = xc[e] + halfh * g0[e];           // MALA.jl:83
                     xp[e] = mu + sq * z[e];                            // MALA.jl:84
                     const double q1 = mu - xp[e];
-                    s1 = s1 + (cx.valid(e) ? (q1 * q1) * half_inv_h : 0.0);      // MALA.jl:90
+                    s1 = s1 + (q1 * q1) * half_inv_h;                            // MALA.jl:90
                 }
             }
-            dense_grad<NE>(ldsP, cx.lane, xp, gp);                     // MALA.jl:86
+            dense_grad<NE, HASMU>(ldsP, cx.lane, xp, gp, ldsMu);                     // MALA.jl:86
             double l1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                l1 = l1 + (cx.valid(e) ? xp[e] * gp[e] : 0.0);
+                l1 = l1 + dx(xp, e) * gp[e];
                 const double mup = xp[e] + halfh * gp[e];              // MALA.jl:91
                 const double q2 = mup - xc[e];
-                s2 = s2 + (cx.valid(e) ? (q2 * q2) * half_inv_h : 0.0);          // MALA.jl:92
+                s2 = s2 + (q2 * q2) * half_inv_h;                                // MALA.jl:92
             }
             red[0] = l1; red[1] = s1; red[2] = s2;
             mreduce<3>(red, cx.lane);
@@ -291,6 +325,84 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
                 acc = ratio > kd_log_u01(u);
             }
+        } else if (SAMPLER == KLARA_SAMPLER_SLICE) {
+            // iterate/SliceSampler.jl:60-109.  Coordinate i = 4 e + q lives on lane q = i & 3 of its chain as register e = i >> 2.
+            // A probe is a full evaluation of the log-target (the reference calls logtarget! on the whole vector, :77-94): the
+            // gradient GEMM of the 16 chains with coordinate i replaced, then lt = c + 1/2 (x-mu).g.  Loops run until every chain
+            // of the wavefront is done (__any); a finished chain's lanes re-evaluate their last probe.
+            double cur = lt;
+            for (int i = 0; i < p.D; ++i) {                                                    // :65
+                const int qo = i & 3, eo = i >> 2;
+                const bool owner = cx.q == qo;
+                double xi_l = 0.0;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) if (e == eo) xi_l = xp[e];
+                const double xi = lane_bcast(xi_l, cx.cl + 16 * qo);
+                const double wd = p.vecparam[i];
+                const uint32_t base = (uint32_t)i << KLARA_SLICE_ATT_BITS;
+                const kd_u32x4 b0 = kd_stream_block(p.seed, gchain, t, base);
+                const double logu = kd_log_u01(kd_uniform_xy(b0)) + cur;                       // :66
+                const double ru = kd_uniform_zw(b0);                                           // :71
+                double Li = xi - ru * wd;                                                      // :72
+                double Ri = xi + (1.0 - ru) * wd;                                              // :73
+                const auto lt_with = [&](double cand) -> double {
+                    double xt[NE], gt[NG], r1[1];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) xt[e] = (owner && e == eo) ? cand : xp[e];
+                    dense_grad<NE, HASMU>(ldsP, cx.lane, xt, gt, ldsMu);
+                    double l1 = 0.0;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) l1 = l1 + dx(xt, e) * gt[e];
+                    r1[0] = l1;
+                    mreduce<1>(r1, cx.lane);
+                    return p.gconst + 0.5 * r1[0];
+                };
+                if (p.stepout) {                                                               // :75-89
+                    double l = lt_with(Li);
+                    int guard = 0;
+                    while (true) {
+                        bool go = cx.chain_ok && !stuck && (l > logu);
+                        if (go && ++guard > KLARA_SLICE_MAX_ATT) { stuck = true; go = false; }
+                        if (!__any(go)) break;
+                        const double Ln = Li - wd;
+                        const double ln = lt_with(go ? Ln : Li);
+                        if (go) { Li = Ln; l = ln; }
+                    }
+                    double r = lt_with(Ri);
+                    guard = 0;
+                    while (true) {
+                        bool go = cx.chain_ok && !stuck && (r > logu);
+                        if (go && ++guard > KLARA_SLICE_MAX_ATT) { stuck = true; go = false; }
+                        if (!__any(go)) break;
+                        const double Rn = Ri + wd;
+                        const double rn = lt_with(go ? Rn : Ri);
+                        if (go) { Ri = Rn; r = rn; }
+                    }
+                }
+                double xprime = xi, ltnew = cur;
+                bool done = !cx.chain_ok || stuck;
+                for (uint32_t a = 1;; ++a) {                                                   // :91-106
+                    if (!done && a > KLARA_SLICE_MAX_ATT) { stuck = true; done = true; }
+                    if (!__any(!done)) break;
+                    const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, base | a));
+                    const double cand = u * (Ri - Li) + Li;                                    // :92-93
+                    const double lc = lt_with(done ? xprime : cand);                           // :94
+                    if (!done) {
+                        xprime = cand; ltnew = lc;
+                        if (lc > logu) done = true;                                            // :95
+                        else if (cand > xi) Ri = cand;                                         // :98
+                        else if (cand < xi) Li = cand;                                         // :100
+                        else { stuck = true; done = true; }                                    // :102
+                    }
+                }
+                if (!stuck) {
+                    cur = ltnew;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) if (owner && e == eo) xp[e] = xprime;         // :108
+                }
+            }
+            ltp = cur;
+            acc = true;                                                // the slice sampler always moves (SliceSampler.jl:108)
         } else {
             // iterate/MH.jl:72-124
             double z[NE], sg[NE], red[1];
@@ -300,10 +412,10 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 sg[e] = (4 * e + cx.q < p.D) ? p.vecparam[4 * e + cx.q] : 0.0;
                 xp[e] = xp[e] + sg[e] * z[e];                          // MH.jl:79
             }
-            dense_grad<NE>(ldsP, cx.lane, xp, gp);                     // MH.jl:81
+            dense_grad<NE, HASMU>(ldsP, cx.lane, xp, gp, ldsMu);                     // MH.jl:81
             double l1 = 0.0;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) l1 = l1 + (cx.valid(e) ? xp[e] * gp[e] : 0.0);
+            for (int e = 0; e < NE; ++e) l1 = l1 + dx(xp, e) * gp[e];
             red[0] = l1;
             mreduce<1>(red, cx.lane);
             ltp = p.gconst + 0.5 * red[0];
@@ -320,19 +432,22 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 const double hf = (double)held;
                 double xo[NE];
                 mload<NE>(cx, p.X, p.D, xo);
-                gdouble* sr = p.sum + cx.chain * p.D + cx.q;
-                gdouble* qr = p.sumsq + cx.chain * p.D + cx.q;
+                const __amdgpu_buffer_rsrc_t ws = mwin<NE>(cx, p.sum, 0, p.D), wq = mwin<NE>(cx, p.sumsq, 0, p.D);
+                const int nv = cx.nv_here();
 #pragma unroll
-                for (int e = 0; e < NE; ++e) if (cx.valid(e)) {
-                    sr[4 * e] = sr[4 * e] + hf * xo[e];
-                    qr[4 * e] = qr[4 * e] + hf * (xo[e] * xo[e]);
+                for (int e = 0; e < NE; ++e) {
+                    const unsigned o = cx.off(e, nv);
+                    const double sv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ws, o, 0, 0));
+                    const double qv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wq, o, 0, 0));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sv + hf * xo[e]), ws, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, qv + hf * (xo[e] * xo[e])), wq, o, 0, 0);
                 }
                 held = 0;
             }
         }
         if (acc) {
             mstore<NE>(cx, p.X, p.D, xp);
-            if (SAMPLER != KLARA_SAMPLER_MH) {
+            if (SAMPLER != KLARA_SAMPLER_MH && SAMPLER != KLARA_SAMPLER_SLICE) {
                 double gs[NE];
 #pragma unroll
                 for (int e = 0; e < NE; ++e) gs[e] = gp[e];
@@ -341,7 +456,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             lt = ltp;
         }
         nacc += acc ? 1ull : 0ull;
-        if (p.cnt && acc) tn.accepted += 1;
+        if (p.cnt && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;       // (the slice sampler never counts accepts)
         if (accept_out != nullptr && cx.chain_ok && cx.q == 0)
             accept_out[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
         if (!p.pooled && !da) tuning_block(p, tn);
@@ -363,17 +478,11 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 } else {
                     mload<NE>(cx, p.X, p.D, xs);
                 }
-                {
-                    if (col < p.hist_cols) {
-                        gdouble* dst = p.hist + (col * p.nchains + cx.chain) * p.D + cx.q;
-#pragma unroll
-                        for (int e = 0; e < NE; ++e) if (cx.valid(e)) dst[4 * e] = xs[e];
-                    }
-                }
+                if (col < p.hist_cols) mstore<NE>(cx, p.hist, p.D, xs, col * p.nchains);
             }
             if (p.hist_lt != nullptr && col < p.hist_cols && cx.chain_ok && cx.q == 0)
                 p.hist_lt[col * p.nchains + cx.chain] = lt;
-            if (SAMPLER != KLARA_SAMPLER_MH && p.hist_g != nullptr && col < p.hist_cols) {
+            if (SAMPLER != KLARA_SAMPLER_MH && SAMPLER != KLARA_SAMPLER_SLICE && p.hist_g != nullptr && col < p.hist_cols) {
                 double gs[NE];
                 if (acc) {
 #pragma unroll
@@ -381,13 +490,12 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 } else {
                     mload<NE>(cx, p.GR, p.D, gs);
                 }
-                gdouble* dst = p.hist_g + (col * p.nchains + cx.chain) * p.D + cx.q;
-#pragma unroll
-                for (int e = 0; e < NE; ++e) if (cx.valid(e)) dst[4 * e] = gs[e];
+                mstore<NE>(cx, p.hist_g, p.D, gs, col * p.nchains);
             }
         }
     }
 
+    if (SAMPLER == KLARA_SAMPLER_SLICE && stuck && cx.chain_ok && cx.q == 0) atomicMax((int*)p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
     if (cx.chain_ok && cx.q == 0) {
         p.LT[cx.chain] = lt;
         p.naccept[cx.chain] += nacc;
@@ -405,24 +513,25 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
 }
 
 // initialize! for the dense target: g = -P x, lt = c + 1/2 x.g, finiteness asserts
-template <int NE>
+template <int NE, bool HASMU = false>
 __global__ __launch_bounds__(512) void k_dense_init(const KParams p, const double* __restrict__ Pfrag, int needgrad)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = (NE + 3) / 4;
     double* ldsP = reinterpret_cast<double*>(smem);
-    for (int i = threadIdx.x; i < MT * NE * 64; i += blockDim.x) ldsP[i] = Pfrag[i];
+    for (int i = threadIdx.x; i < MT * NE * 64 + (HASMU ? 4 * NE : 0); i += blockDim.x) ldsP[i] = Pfrag[i];
+    const double* const ldsMu = ldsP + MT * NE * 64;
     __syncthreads();
     const MfmaCtx<NE> cx = make_mctx<NE>(p);
     double x[NE], g[4 * MT], red[1];
     mload<NE>(cx, p.X, p.D, x);
-    dense_grad<NE>(ldsP, cx.lane, x, g);
+    dense_grad<NE, HASMU>(ldsP, cx.lane, x, g, ldsMu);
     double l1 = 0.0;
     bool bad = false;
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-        l1 = l1 + (cx.valid(e) ? x[e] * g[e] : 0.0);
-        if (needgrad) bad = bad || (cx.valid(e) && !kfinite(g[e]));
+        l1 = l1 + (HASMU ? x[e] - ldsMu[4 * e + cx.q] : x[e]) * g[e];
+        if (needgrad) bad = bad || !kfinite(g[e]);
     }
     red[0] = l1;
     mreduce<1>(red, cx.lane);

@@ -2,17 +2,17 @@
 #include "klara_launch.h"
 #include "klara_dense.h"
 
-template <int SAMPLER, bool DA>
-static hipError_t launch_dense_s(const KParams* p, const KLaunch& kl, int NE, const double* Pfrag, dim3 grid, hipStream_t st)
+template <int SAMPLER, bool DA, bool HASMU>
+static hipError_t launch_dense_m(const KParams* p, const KLaunch& kl, int NE, const double* Pfrag, dim3 grid, hipStream_t st)
 {
     const dim3 blk(512);
 #define KLARA_DENSE_CASE(N)                                                                            \
     case N: {                                                                                          \
-        constexpr size_t lds = sizeof(double) * 64 * (size_t)N * (size_t)((N + 3) / 4);                \
-        hipError_t e = hipFuncSetAttribute((const void*)k_dense_transitions<SAMPLER, N, DA>,               \
+        constexpr size_t lds = sizeof(double) * (64 * (size_t)N * (size_t)((N + 3) / 4) + (HASMU ? 4 * N : 0)); \
+        hipError_t e = hipFuncSetAttribute((const void*)k_dense_transitions<SAMPLER, N, DA, HASMU>,        \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return e;                                                                 \
-        hipLaunchKernelGGL((k_dense_transitions<SAMPLER, N, DA>), grid, blk, lds, st, p, kl, Pfrag);       \
+        hipLaunchKernelGGL((k_dense_transitions<SAMPLER, N, DA, HASMU>), grid, blk, lds, st, p, kl, Pfrag); \
         break;                                                                                         \
     }
     switch (NE) {
@@ -26,30 +26,37 @@ static hipError_t launch_dense_s(const KParams* p, const KLaunch& kl, int NE, co
     return hipGetLastError();
 }
 
-hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, int NE, const double* Pfrag,
+template <int SAMPLER, bool DA>
+static hipError_t launch_dense_s(const KParams* p, const KLaunch& kl, int NE, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st)
+{
+    return hasmu ? launch_dense_m<SAMPLER, DA, true>(p, kl, NE, Pfrag, grid, st) : launch_dense_m<SAMPLER, DA, false>(p, kl, NE, Pfrag, grid, st);
+}
+
+hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, int NE, const double* Pfrag, bool hasmu,
                               dim3 grid, hipStream_t st)
 {
     switch (sampler) {
-    case KLARA_SAMPLER_MH: return launch_dense_s<KLARA_SAMPLER_MH, false>(p, kl, NE, Pfrag, grid, st);
-    case KLARA_SAMPLER_MALA: return launch_dense_s<KLARA_SAMPLER_MALA, false>(p, kl, NE, Pfrag, grid, st);
+    case KLARA_SAMPLER_MH: return launch_dense_s<KLARA_SAMPLER_MH, false>(p, kl, NE, Pfrag, hasmu, grid, st);
+    case KLARA_SAMPLER_MALA: return launch_dense_s<KLARA_SAMPLER_MALA, false>(p, kl, NE, Pfrag, hasmu, grid, st);
+    case KLARA_SAMPLER_SLICE: return launch_dense_s<KLARA_SAMPLER_SLICE, false>(p, kl, NE, Pfrag, hasmu, grid, st);
     case KLARA_SAMPLER_HMC:
-        if (tuner == KLARA_TUNER_DUAL_AVERAGING) return launch_dense_s<KLARA_SAMPLER_HMC, true>(p, kl, NE, Pfrag, grid, st);
-        return launch_dense_s<KLARA_SAMPLER_HMC, false>(p, kl, NE, Pfrag, grid, st);
+        if (tuner == KLARA_TUNER_DUAL_AVERAGING) return launch_dense_s<KLARA_SAMPLER_HMC, true>(p, kl, NE, Pfrag, hasmu, grid, st);
+        return launch_dense_s<KLARA_SAMPLER_HMC, false>(p, kl, NE, Pfrag, hasmu, grid, st);
     default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag, int needgrad, dim3 grid,
-                                   hipStream_t st)
+template <bool HASMU>
+static hipError_t launch_dense_init_m(const KParams& p, int NE, const double* Pfrag, int needgrad, dim3 grid, hipStream_t st)
 {
     const dim3 blk(512);
 #define KLARA_DENSE_CASE(N)                                                                            \
     case N: {                                                                                          \
-        constexpr size_t lds = sizeof(double) * 64 * (size_t)N * (size_t)((N + 3) / 4);                \
-        hipError_t e = hipFuncSetAttribute((const void*)k_dense_init<N>,                               \
+        constexpr size_t lds = sizeof(double) * (64 * (size_t)N * (size_t)((N + 3) / 4) + (HASMU ? 4 * N : 0)); \
+        hipError_t e = hipFuncSetAttribute((const void*)k_dense_init<N, HASMU>,                        \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return e;                                                                 \
-        hipLaunchKernelGGL((k_dense_init<N>), grid, blk, lds, st, p, Pfrag, needgrad);                 \
+        hipLaunchKernelGGL((k_dense_init<N, HASMU>), grid, blk, lds, st, p, Pfrag, needgrad);          \
         break;                                                                                         \
     }
     switch (NE) {
@@ -61,6 +68,11 @@ hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag
     }
 #undef KLARA_DENSE_CASE
     return hipGetLastError();
+}
+
+hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag, bool hasmu, int needgrad, dim3 grid, hipStream_t st)
+{
+    return hasmu ? launch_dense_init_m<true>(p, NE, Pfrag, needgrad, grid, st) : launch_dense_init_m<false>(p, NE, Pfrag, needgrad, grid, st);
 }
 
 hipError_t klara_launch_mfma_probe(const double* A, const double* B, const double* C, double* D, hipStream_t st)

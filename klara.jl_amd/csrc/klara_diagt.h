@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void k_diagt_init(const KParams p, int needgra
     constexpr int E = 2 * NP, CPW = 64 / Q;
     const int D = p.D;
     const PairCtx<NP, Q> cx = make_pctx<NP, Q>(D);
-    const long long grp = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long grp = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));   // wave-uniform: scalar windows
     const long long first_chain = grp * CPW;
     const long long left = p.nchains - first_chain;
     const int here = left < CPW ? (left > 0 ? (int)left : 0) : CPW;

@@ -203,7 +203,7 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
     const int D = p.D, R = p.hR;
     guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
 
-    const long long grp = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long grp = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));   // wave-uniform: scalar windows
     if (grp * CPW >= p.nchains) return;
     const long long first_chain = grp * CPW;
     const long long left = p.nchains - first_chain;
@@ -322,34 +322,36 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
         } else if (SAMPLER == KLARA_SAMPLER_MALA) {                                   // iterate/MALA.jl:78-128 (mom holds z)
             const double h_ = tn.step, halfh = 0.5 * h_, sqh = KCNT ? __builtin_sqrt(h_) : p.sqrt_step0;
             const double half_inv_h = 0.5 * (KCNT ? 1.0 / h_ : p.inv_step0);
-            HierVec<RPL> mu_, t1, t2;
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
-                mu_.a[k] = x.a[k] + halfh * g.a[k]; mu_.b[k] = x.b[k] + halfh * g.b[k];         // :83
-                xp.a[k] = mu_.a[k] + sqh * mom.a[k]; xp.b[k] = mu_.b[k] + sqh * mom.b[k];       // :84
+                xp.a[k] = (x.a[k] + halfh * g.a[k]) + sqh * mom.a[k];                          // :83-84
+                xp.b[k] = (x.b[k] + halfh * g.b[k]) + sqh * mom.b[k];
             }
 #pragma unroll
-            for (int k = 0; k < 5; ++k) { mu_.h[k] = x.h[k] + halfh * g.h[k]; xp.h[k] = mu_.h[k] + sqh * mom.h[k]; }
+            for (int k = 0; k < 5; ++k) xp.h[k] = (x.h[k] + halfh * g.h[k]) + sqh * mom.h[k];
             ltp = hier_eval<RPL, NT, true, true>(cx, xp, gp);                                  // :86
+            // the two proposal-density terms, summed in hier_sumvec's order (a_k, b_k ascending, then the hyper block on lane 0); the
+            // drift mean x + h/2 g is formed again instead of being kept across the evaluation (same operations, same bits)
+            const auto qterm = [&](double from_x, double from_g, double to) {
+                const double d = (from_x + halfh * from_g) - to;
+                return (d * d) * half_inv_h;
+            };
+            double s1[1] = { 0.0 }, s2[1] = { 0.0 };
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
-                const double qa = mu_.a[k] - xp.a[k], qb = mu_.b[k] - xp.b[k];
-                t1.a[k] = (qa * qa) * half_inv_h; t1.b[k] = (qb * qb) * half_inv_h;             // :90
-                const double ma = xp.a[k] + halfh * gp.a[k], mb = xp.b[k] + halfh * gp.b[k];    // :91
-                const double ra = ma - x.a[k], rb = mb - x.b[k];
-                t2.a[k] = (ra * ra) * half_inv_h; t2.b[k] = (rb * rb) * half_inv_h;             // :92
+                s1[0] = s1[0] + qterm(x.a[k], g.a[k], xp.a[k]); s1[0] = s1[0] + qterm(x.b[k], g.b[k], xp.b[k]);     // :90
+                s2[0] = s2[0] + qterm(xp.a[k], gp.a[k], x.a[k]); s2[0] = s2[0] + qterm(xp.b[k], gp.b[k], x.b[k]);   // :91-92
             }
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                const double qh = mu_.h[k] - xp.h[k];
-                t1.h[k] = (qh * qh) * half_inv_h;
-                const double mh = xp.h[k] + halfh * gp.h[k];
-                const double rh = mh - x.h[k];
-                t2.h[k] = (rh * rh) * half_inv_h;
+                const double q1 = qterm(x.h[k], g.h[k], xp.h[k]), q2 = qterm(xp.h[k], gp.h[k], x.h[k]);
+                s1[0] = s1[0] + (cx.q == 0 ? q1 : 0.0); s2[0] = s2[0] + (cx.q == 0 ? q2 : 0.0);
             }
+            group_allreduce<1>(s1, KLARA_HIERT_Q, cx.lane);
+            group_allreduce<1>(s2, KLARA_HIERT_Q, cx.lane);
             double ratio = ltp - lt;                                                           // :88
-            ratio += hier_sumvec<RPL, NT>(cx, t1);                                             // :90
-            ratio -= hier_sumvec<RPL, NT>(cx, t2);                                             // :92
+            ratio += s1[0];                                                                    // :90
+            ratio -= s2[0];                                                                    // :92
             acc = ratio > 0.0;                                                                 // :94
             if (!acc && ratio > KD_LOG_UMIN_GUARD)
                 acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((D + 1) >> 1))));
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256) void k_hiert_init(const KParams p, int needgra
     constexpr int CPW = 64 / KLARA_HIERT_Q;
     kd_tables_to_lds();
     const HierLane<RPL, NT> cx = make_hlane<RPL, NT>(p);
-    const long long grp = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long grp = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));   // wave-uniform: scalar windows
     const long long first_chain = grp * CPW;
     const long long left = p.nchains - first_chain;
     const int here = left < CPW ? (left > 0 ? (int)left : 0) : CPW;

@@ -13,9 +13,10 @@ hipError_t klara_launch_hmc(const KParams* p, const KLaunch& kl, int mode, int t
 hipError_t klara_launch_slice(const KParams* p, const KLaunch& kl, int mode, int target, int E, int G, dim3 grid, size_t lds,
                            hipStream_t st);
 // dense (MFMA) kernels; NE in {8,16,25,32}
-hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, int NE, const double* Pfrag,
+// (Pfrag: the fragment-ordered precision matrix, followed — hasmu — by the 4 NE zero-padded entries of the mean)
+hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, int NE, const double* Pfrag, bool hasmu,
                               dim3 grid, hipStream_t st);
-hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag, int needgrad, dim3 grid,
+hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag, bool hasmu, int needgrad, dim3 grid,
                                    hipStream_t st);
 hipError_t klara_launch_mfma_probe(const double* A, const double* B, const double* C, double* D,
                                    hipStream_t st);

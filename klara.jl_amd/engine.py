@@ -54,15 +54,20 @@ class GaussDiagTarget:
 
 @dataclass
 class GaussDenseTarget:
-    """lt = c - 1/2 x' P x with a dense D x D precision matrix (KLARA_TARGET_GAUSS_DENSE, FP64 MFMA)."""
+    """lt = c - 1/2 (x-mu)' P (x-mu) with a dense D x D precision matrix (KLARA_TARGET_GAUSS_DENSE, FP64 MFMA); mu = None is 0."""
     precision: np.ndarray
     const: float = 0.0
+    mu: Optional[np.ndarray] = None
     kind = L.TARGET_GAUSS_DENSE
 
     def __post_init__(self):
         self.precision = _f64(self.precision)
         if self.precision.ndim != 2 or self.precision.shape[0] != self.precision.shape[1]:
             raise ValueError("precision must be square")
+        if self.mu is not None:
+            self.mu = _f64(self.mu)
+            if self.mu.shape != (self.precision.shape[0],):
+                raise ValueError("mu must have one entry per dimension")
 
     @property
     def ndims(self) -> int:
@@ -220,6 +225,8 @@ class Engine:
             d.gauss_const = float(target.const)
         elif isinstance(target, GaussDenseTarget):
             a = _f64(target.precision); keep.append(a); d.gauss_prec = _ptr(a)
+            if target.mu is not None:
+                a = _f64(target.mu, (self.ndims,)); keep.append(a); d.gauss_mu = _ptr(a)
             d.gauss_const = float(target.const)
         elif isinstance(target, LogisticTarget):
             a = _f64(target.X); keep.append(a); d.logit_X = _ptr(a)

@@ -264,6 +264,22 @@ def make_case(name):
         rng = np.random.default_rng(d)
         a = rng.standard_normal((d, d)); p = a @ a.T / d + np.eye(d)
         c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(p), nchains=21, nsteps=10, burnin=0, leapstep=0.12, nleaps=3)
+    elif name in ("hmc_dense_d100_mean", "mala_dense_d37_mean", "mh_dense_d20_mean", "hmc_dense_d70_mean_dualavg"):   # (x - mu)' P (x - mu)
+        d = int(name.split("_")[2][1:])
+        rng = np.random.default_rng(100 + d)
+        a = rng.standard_normal((d, d)); p = a @ a.T / d + np.eye(d)
+        t = K.GaussDenseTarget(p, const=0.75, mu=rng.standard_normal(d) * 2.0)
+        x0 = t.mu[None, :] + rng.standard_normal((23, d))
+        if name.startswith("hmc") and not name.endswith("dualavg"):
+            c = dict(sampler=L.SAMPLER_HMC, target=t, nchains=23, nsteps=12, burnin=2, leapstep=0.1, nleaps=5, x0=x0)
+        elif name.startswith("hmc"):
+            c = dict(sampler=L.SAMPLER_HMC, target=t, nchains=23, nsteps=30, burnin=0, leapstep=0.2, nleaps=4, x0=x0,
+                     tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.8, da_nadapt=20)
+        elif name.startswith("mala"):
+            c = dict(sampler=L.SAMPLER_MALA, target=t, nchains=23, nsteps=25, burnin=5, driftstep=0.2, x0=x0,
+                     tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=5)
+        else:
+            c = dict(sampler=L.SAMPLER_MH, target=t, nchains=23, nsteps=40, burnin=0, mh_sigma=np.full(d, 0.25), x0=x0)
     elif name == "mala_dense_d100":
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDenseTarget(compound_symmetric_precision(100)), nchains=35,
                  nsteps=20, burnin=0, driftstep=0.3)
@@ -319,6 +335,14 @@ def make_case(name):
         x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(10).standard_normal((21, t.ndims))
         c = dict(sampler=L.SAMPLER_MALA, target=t, nchains=21, nsteps=60, burnin=40, driftstep=2e-3, tuner=L.TUNER_ACCEPT_RATE,
                  targetrate=0.574, period=10, x0=x0)
+    elif name in ("slice_dense_d20", "slice_dense_d37_mean"):   # slice sampler on the dense target: every probe is a full MFMA evaluation
+        d = int(name.split("_")[2][1:])
+        rng = np.random.default_rng(300 + d)
+        a = rng.standard_normal((d, d)); p = a @ a.T / d + np.eye(d)
+        mean = name.endswith("mean")
+        t = K.GaussDenseTarget(p, const=-1.25, mu=rng.standard_normal(d) if mean else None)
+        c = dict(sampler=L.SAMPLER_SLICE, target=t, nchains=21, nsteps=6, burnin=1, slice_widths=np.linspace(0.4, 2.5, d),
+                 slice_stepout=not mean, x0=rng.standard_normal((21, d)) + (t.mu if mean else 0.0))
     elif name == "slice_d20_stepout":  # pair-transposed layout: step-out and shrink loops with per-chain trip counts, non-unit diagonal
         c = dict(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 2, 20), np.linspace(0.5, 3.0, 20)), nchains=37,
                  nsteps=8, burnin=2, slice_widths=np.linspace(0.2, 4.0, 20))
@@ -421,7 +445,8 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_rats", "hmc_rats_pooled", "mala_rats", "slice_rats", "hmc_d10_dualavg", "hmc_dense_d37_dualavg",
              "hmc_rats_dualavg", "mala_d3_tuned_erf", "mala_d1", "hmc_d128_full", "mala_d129", "mh_d512",
              "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg",
-             "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
+             "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "hmc_dense_d100_mean", "mala_dense_d37_mean", "mh_dense_d20_mean",
+             "hmc_dense_d70_mean_dualavg", "slice_dense_d20", "slice_dense_d37_mean", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
              "slice_d20_stepout", "mh_rats", "mala_rats_tuned"] + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
              "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
@@ -443,7 +468,7 @@ def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):
     if isinstance(t, K.GaussDiagTarget):
         kw.update(gauss_w=t.w, gauss_mu=t.mu, gauss_const=t.const)
     elif isinstance(t, K.GaussDenseTarget):
-        kw.update(gauss_prec=t.precision, gauss_const=t.const)
+        kw.update(gauss_prec=t.precision, gauss_const=t.const, gauss_mu=t.mu)
     elif isinstance(t, K.CustomTarget):
         kw.update(custom_src=t.source, custom_data=t.data)
     elif isinstance(t, K.HierNormalTarget):

@@ -199,6 +199,20 @@ def test_unnormalised_target_closure():
     assert np.allclose(0.5 * g, -(x - mu))
 
 
+def test_dense_target_with_mean_matches_scipy():
+    # the builder-defined dense target with a mean: lt = c - 1/2 (x-mu)' P (x-mu), grad = -P (x-mu) — against scipy's MvNormal log-density
+    rng = np.random.default_rng(4)
+    d = 23
+    a = rng.standard_normal((d, d)); cov = a @ a.T / d + np.eye(d); prec = np.linalg.inv(cov)
+    mu, x = rng.standard_normal(d) * 3, rng.standard_normal(d) * 2
+    c = -0.5 * (d * math.log(2 * math.pi) + np.linalg.slogdet(cov)[1])
+    job = O.OracleJob(sampler=L.SAMPLER_HMC, target_kind=L.TARGET_GAUSS_DENSE, nchains=1, ndims=d, nsteps=1, gauss_prec=prec, gauss_mu=mu,
+                      gauss_const=c)
+    lt, g = job.eval_target(x)
+    assert lt == pytest.approx(stats.multivariate_normal(mu, cov).logpdf(x), rel=1e-11)
+    assert np.allclose(g, -prec @ (x - mu), rtol=1e-11, atol=1e-12)
+
+
 def test_logistic_target_matches_numpy():
     X, y = cases.swiss_data()
     p = np.array([5.1, -0.9, 8.2, -4.5])
