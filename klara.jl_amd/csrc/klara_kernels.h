@@ -31,6 +31,9 @@
 #ifndef KLARA_LOGIT_UNROLL
 #define KLARA_LOGIT_UNROLL 4
 #endif
+#ifndef KLARA_E4_WAVES_LOGISTIC
+#define KLARA_E4_WAVES_LOGISTIC 4
+#endif
 #ifndef KLARA_E4_WAVES_PLAIN
 #define KLARA_E4_WAVES_PLAIN 3   // the specialised (no tuner, no monitor) E=4 kernels fit 168 VGPRs
 #endif
@@ -917,7 +920,11 @@ __device__ __forceinline__ void set_chain(const KParams& p, LaneCtx<E>& c, long 
 // MODE bit 0 (PLAIN): nothing counts / tunes.  MODE bit 1 (NOMON): no monitor at all (no accept mask, running sums or
 // history) — the save-rule bookkeeping disappears from the generated code.
 template <int SAMPLER, int TARGET, int E, int GT, int MODE>
-__global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? ((MODE & 3) == 3 ? KLARA_E4_WAVES_PLAIN : KLARA_E4_WAVES) : 1)))
+// (MALA on the logistic target at E = 4 — cfg 4 — asks for 4 wavefronts per SIMD: its row loop is a chain of exp / log / division latencies that two
+//  wavefronts cannot cover; the 128-register budget spills 156-272 B outside the row loop and still measured 1.01e9 against 8.1e8
+//  transitions/s with running sums, 1.05e9 against 9.4e8 without, same box)
+__global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? (TARGET == KLARA_TARGET_LOGISTIC && SAMPLER == KLARA_SAMPLER_MALA ? KLARA_E4_WAVES_LOGISTIC
+                                                                  : ((MODE & 3) == 3 ? KLARA_E4_WAVES_PLAIN : KLARA_E4_WAVES)) : 1)))
 void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 {
     constexpr bool PLAIN = (MODE & 1) != 0, NOMON = (MODE & 2) != 0;
@@ -960,12 +967,16 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
     load_chain<E, NEEDG, PLAIN>(p, cx, cur, grp * cpw, here_of(grp));
 
     while (true) {
-        // prefetch the next group this wave owns
+        // One transition per launch: the next group this wave owns is prefetched (its load latency would otherwise be a visible part
+        // of the launch).  Fused launches amortise that latency over their transitions and load the next group when they get to it —
+        // the prefetched copy would hold 2 E + 8 registers through every transition (logistic MALA at 4 wavefronts per SIMD: the
+        // difference between fitting 128 registers and spilling).
+        constexpr bool PREFETCH = ONESTEP;
         const long long grp_next = grp + nwaves;
         const bool has_next = grp_next * cpw < p.nchains;
         LaneCtx<E> cxn = cx;
         ChainRegs<E> nxt;
-        if (has_next) {
+        if (PREFETCH && has_next) {
             set_chain<E, GT, RSPL>(p, cxn, grp_next);
             load_chain<E, NEEDG, PLAIN>(p, cxn, nxt, grp_next * cpw, here_of(grp_next));
         }
@@ -1103,7 +1114,12 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             if (stuck) atomicMax((int*)p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
         }
         if (!has_next) break;
-        cur = nxt; cx = cxn; grp = grp_next;
+        if (PREFETCH) { cur = nxt; cx = cxn; }
+        else {
+            set_chain<E, GT, RSPL>(p, cx, grp_next);
+            load_chain<E, NEEDG, PLAIN>(p, cx, cur, grp_next * cpw, here_of(grp_next));
+        }
+        grp = grp_next;
     }
 }
 
