@@ -274,37 +274,92 @@ KD_FN void kd_softplus_logistic(double x, double* softplus, double* logistic)
 }
 
 /* ---------------------------------------------------------------- erf */
-/* erf for the tuner's erf_rate_score (src/tuners/AcceptanceRateMCTuner.jl:17).  Evaluated rarely (once per tuning
- * period), so a plain, fixed-trip-count formulation is used instead of the msun rational approximations:
- *   |x| < 3 : erf(x) = 2/sqrt(pi) * exp(-x^2) * sum_{n>=0} x^(2n+1) 2^n / (2n+1)!!      (all terms positive)
- *   |x| >= 3: erfc(x) = exp(-x^2)/sqrt(pi) * 1/(x + (1/2)/(x + 1/(x + (3/2)/(x + ...))))  (60 levels, bottom-up)
- *   |x| >= 6: +-1.                       Accuracy: <= 20 ulp against libm (tests/test_oracle_kats.py) — ample for a step-size score. */
-KD_FN double kd_erf(double x)
+/* erf for the tuner's erf_rate_score (src/tuners/AcceptanceRateMCTuner.jl:17: erf(k x) + 1; Julia's erf is openlibm's = FreeBSD msun
+ * s_erf.c).  The evaluation below is that algorithm, operation for operation — the interval split, the rational approximations on
+ * |x| < 0.84375, [0.84375, 1.25), [1.25, 1/0.35), [1/0.35, 6), the two-factor exp(-z^2 - 0.5625) exp((z-x)(z+x) + R/S) with z = x
+ * truncated to 32 bits of mantissa — with kd_exp for the exponentials, so the reference's erf_rate_score vectors
+ * (test/AcceptanceRateMCTuner.jl:13-14) are reproduced bit for bit (tests/test_oracle_kats.py).  The coefficients are those of s_erf.c,
+ * whose notice reads:
+ * ====================================================
+ * Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+ *
+ * Developed at SunPro, a Sun Microsystems, Inc. business.
+ * Permission to use, copy, modify, and distribute this
+ * software is freely granted, provided that this notice
+ * is preserved.
+ * ==================================================== */
+/* The coefficients sit in one constant table and the polynomials are Horner loops that are NOT unrolled: erf is evaluated once per
+ * tuning period by the chains that use the erf score, but its code is part of every tuned kernel, and 60 double constants kept in
+ * registers across the transition loop cost the tuned kernels their zero-scratch budget (tests/test_host_api.py).  The loop performs the
+ * operations of the nested form c0 + z (c1 + z (c2 + ...)) in the same order.  For the same reason kd_erf is a real call on the device
+ * (noinline): its registers are not part of the calling kernel's allocation. */
+#if defined(__clang__)
+#define KD_NOUNROLL _Pragma("nounroll")
+#else
+#define KD_NOUNROLL _Pragma("GCC unroll 1")
+#endif
+KD_FN double kd_horner(const double* c, int n, double z)        /* c[0] + z (c[1] + z (... + z c[n-1])) */
 {
-    const double two_over_sqrtpi = 1.12837916709551257390e+00, one_over_sqrtpi = 5.64189583547756286948e-01;
-    const double ax = x < 0.0 ? -x : x;
-    double r;
-    /* exp(-x^2) with the rounding error of x*x folded back in: exp(-(x2 + lo)) = exp(-x2) * (1 - lo) */
-    const double x2 = ax * ax;
-    const double x2lo = kd_fma(ax, ax, -x2);
-    double ex = kd_exp(-x2);
-    ex = ex - ex * x2lo;
-    if (ax < 3.0) {
-        double term = ax, sum = ax;
-        for (int n = 0; n < 100; ++n) {
-            term = term * (2.0 * x2) / (double)(2 * n + 3);
-            sum = sum + term;
-        }
-        r = two_over_sqrtpi * ex * sum;
-    } else if (ax < 6.0) {
-        double f = ax;
-        for (int k = 60; k >= 1; --k) f = ax + (0.5 * (double)k) / f;
-        r = 1.0 - ex * one_over_sqrtpi / f;
-    } else {
-        r = 1.0;
-    }
+    double r = c[n - 1];
+    KD_NOUNROLL
+    for (int i = n - 2; i >= 0; --i) r = c[i] + z * r;
+    return r;
+}
+#if defined(__HIPCC__)
+#define KD_FN_COLD static __host__ __device__ __attribute__((noinline))
+#else
+#define KD_FN_COLD static __attribute__((noinline))
+#endif
+KD_FN_COLD double kd_erf(double x)
+{
+    static const double T[] = {
+        /* pp0..pp4  [0]  */ 1.28379167095512558561e-01, -3.25042107247001499370e-01, -2.84817495755985104766e-02,
+                             -5.77027029648944159157e-03, -2.37630166566501626084e-05,
+        /* 1,qq1..5  [5]  */ 1.0, 3.97917223959155352819e-01, 6.50222499887672944485e-02, 5.08130628187576562776e-03,
+                             1.32494738004321644526e-04, -3.96022827877536812320e-06,
+        /* pa0..pa6  [11] */ -2.36211856075265944077e-03, 4.14856118683748331666e-01, -3.72207876035701323847e-01,
+                             3.18346619901161753674e-01, -1.10894694282396677476e-01, 3.54783043256182359371e-02,
+                             -2.16637559486879084300e-03,
+        /* 1,qa1..6  [18] */ 1.0, 1.06420880400844228286e-01, 5.40397917702171048937e-01, 7.18286544141962662868e-02,
+                             1.26171219808761642112e-01, 1.36370839120290507362e-02, 1.19844998467991074170e-02,
+        /* ra0..ra7  [25] */ -9.86494403484714822705e-03, -6.93858572707181764372e-01, -1.05586262253232909814e+01,
+                             -6.23753324503260060396e+01, -1.62396669462573470355e+02, -1.84605092906711035994e+02,
+                             -8.12874355063065934246e+01, -9.81432934416914548592e+00,
+        /* 1,sa1..8  [33] */ 1.0, 1.96512716674392571292e+01, 1.37657754143519042600e+02, 4.34565877475229228821e+02,
+                             6.45387271733267880336e+02, 4.29008140027567833386e+02, 1.08635005541779435134e+02,
+                             6.57024977031928170135e+00, -6.04244152148580987438e-02,
+        /* rb0..rb6  [42] */ -9.86494292470009928597e-03, -7.99283237680523006574e-01, -1.77579549177547519889e+01,
+                             -1.60636384855821916062e+02, -6.37566443368389627722e+02, -1.02509513161107724954e+03,
+                             -4.83519191608651397019e+02,
+        /* 1,sb1..7  [49] */ 1.0, 3.03380607434824582924e+01, 3.25792512996573918826e+02, 1.53672958608443695994e+03,
+                             3.19985821950859553908e+03, 2.55305040643316442583e+03, 4.74528541206955367215e+02,
+                             -2.24409524465858183362e+01 };
+    const double erx = 8.45062911510467529297e-01, efx = 1.28379167095512586316e-01, efx8 = 1.02703333676410069053e+00;
+    const double tiny = 1e-300;
     if (x != x) return x;
-    return x < 0.0 ? -r : r;
+    const double ax = x < 0.0 ? -x : x;
+    const int neg = x < 0.0;
+    if (ax < 0.84375) {
+        if (ax < 0x1p-28) {
+            if (ax < 0x1p-1015) return 0.125 * (8.0 * x + efx8 * x);          /* avoid underflow */
+            return x + efx * x;
+        }
+        const double z = x * x;
+        const double y = kd_horner(T + 0, 5, z) / kd_horner(T + 5, 6, z);
+        return x + x * y;
+    }
+    if (ax < 1.25) {
+        const double sd = ax - 1.0;
+        const double PQ = kd_horner(T + 11, 7, sd) / kd_horner(T + 18, 7, sd);
+        return neg ? -erx - PQ : erx + PQ;
+    }
+    if (ax >= 6.0) return neg ? tiny - 1.0 : 1.0 - tiny;                    /* (also +-inf) */
+    const double sd = 1.0 / (ax * ax);
+    const int lo = ax < 1.0 / 0.35;
+    const double RS = kd_horner(lo ? T + 25 : T + 42, lo ? 8 : 7, sd) / kd_horner(lo ? T + 33 : T + 49, lo ? 9 : 8, sd);
+    const double z = kd_u2d(kd_d2u(ax) & 0xffffffff00000000ull);
+    const double r = kd_exp(-z * z - 0.5625) * kd_exp((z - ax) * (z + ax) + RS);
+    return neg ? r / ax - 1.0 : 1.0 - r / ax;
 }
 
 /* ---------------------------------------------------------------- sin/cos(2*pi*u) */

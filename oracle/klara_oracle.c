@@ -88,7 +88,8 @@ double ko_logistic(double x, double l, double k, double x0, double y0)
 }
 /* src/tuners/AcceptanceRateMCTuner.jl:9  logistic_rate_score(x, k=7.) = logistic(x, 2., k, 0., 0.) */
 double ko_logistic_rate_score(double x, double k) { return ko_logistic(x, 2.0, k, 0.0, 0.0); }
-/* src/tuners/AcceptanceRateMCTuner.jl:17 erf_rate_score(x, k=3.) = erf(k*x)+1  (detmath kd_erf, <= 4 ulp of libm) */
+/* src/tuners/AcceptanceRateMCTuner.jl:17 erf_rate_score(x, k=3.) = erf(k*x)+1  (detmath kd_erf: msun s_erf.c operation for operation; the
+ * reference vectors test/AcceptanceRateMCTuner.jl:13-14 bit for bit) */
 double ko_erf_rate_score(double x, double k) { return kd_erf(k * x) + 1.0; }
 
 /* ------------------------------------------------------------------ targets */
