@@ -9,7 +9,8 @@ in the post-burn-in range and is accumulated into the per-chain running sums (KL
 the headline (config.steps_per_launch), one transition per launch is reported in `extra`.
 
 Timed region: `--reps` (5) repetitions of exactly `--steps` transitions, each bracketed by a barrier + torch.cuda.synchronize()
-on both sides (max over ranks per repetition); `value` uses the MEDIAN repetition.  With --gpus N every rank owns its own shard
+on both sides; a rank's time runs from leaving the opening barrier to its own synchronize() after the K steps, the repetition's
+time is the MAX over ranks (the closing barrier's own latency is not part of any rank's K steps); `value` uses the MEDIAN repetition.  With --gpus N every rank owns its own shard
 (weak scaling: 65,536 chains per GPU, global chain ids = rank * 65,536 + local; `--scaling strong`: `--total-chains` sharded over
 the ranks), no data-path collective; the only exchange is the end-of-run reduction of the chain summaries — pooled on the device
 and, for N > 1, all-reduced over RCCL — once, after the job's last transition; it is timed on its own (config.summary_gather_ms:
@@ -178,10 +179,9 @@ def main():
         t0 = time.perf_counter()
         eng.run(args.steps)
         torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0          # this rank's K steps; the job's time is the MAX over ranks (below)
         if dist is not None:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
+            dist.barrier()                           # closing bracket: every rank is done before anyone goes on
             te = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
@@ -238,6 +238,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()             # rank 0's roofline pass is over: every rank leaves the job together
         dist.destroy_process_group()
 
 
