@@ -249,6 +249,27 @@ KD_FN double kd_exp(double x)
     return res;
 }
 
+/* exp(-a) for a >= 0, the form the logistic rows need (t = exp(-|Xp|) in [0, 1]): kd_exp's reduction, table and polynomial — the same
+ * bits for a <= 708 — without what that range does not need: no overflow side, the power of two is added to the exponent field
+ * (results are normal numbers, so this equals the two exact multiplications of kd_exp), and beyond 708, where the result would be
+ * subnormal, it is 0.  NaN gives 0; the caller passes NaN through itself. */
+KD_FN double kd_exp_neg(double a)
+{
+    const double C2 = 0.5, C3 = 0x1.5555555555555p-3, C4 = 0x1.5555555555555p-5, C5 = 0x1.1111111111111p-7;
+    double xc = -a;
+    if (!(xc > -709.0)) xc = -709.0;                                          /* (also NaN) keeps the conversion defined */
+    const int k = (int)(KD_INVLN2N * xc + (xc < 0.0 ? -0.5 : 0.5));
+    const double dk = (double)k;
+    const double r = kd_fma(dk, -KD_LN2N_LO, kd_fma(dk, -KD_LN2N_HI, xc));
+    const int idx = k & 127, e = k >> 7;
+    const double th = KD_EXPTAB(2 * idx), tl = KD_EXPTAB(2 * idx + 1);
+    const double r2 = r * r;
+    const double p = kd_fma(r2 * r2, kd_fma(r, C5, C4), kd_fma(r2, kd_fma(r, C3, C2), r));
+    const double y = th + kd_fma(th, p, tl);
+    const double res = kd_u2d(kd_d2u(y) + ((uint64_t)(int64_t)e << 52));
+    return a <= 708.0 ? res : 0.0;
+}
+
 /* log of a positive number that may be +inf or NaN (1 + exp(.) of the logistic target): the table log plus the two
  * pass-through cases */
 KD_FN double kd_log_pos(double x)
@@ -261,13 +282,14 @@ KD_FN double kd_log_pos(double x)
 /* log(1 + exp(x)) and 1 / (1 + exp(-x)) from ONE exponential, t = exp(-|x|) in [0, 1]:
  *   log(1 + exp(x)) = max(x, 0) + log(1 + t),    1 / (1 + exp(-x)) = x >= 0 ? 1 / (1 + t) : t / (1 + t).
  * The logistic-regression targets need both per data row (doc/examples/swiss/MALA/analytical.jl:13,17 write exp(Xp) and exp(-Xp)
- * separately): one kd_exp instead of two, and no overflow for large |x| (the literal form gives log(inf) beyond x = 709). */
+ * separately): one exponential instead of two, and no overflow for large |x| (the literal form gives log(inf) beyond x = 709).
+ * Beyond |x| = 708 the pair is (max(x, 0), x >= 0 ? 1 : 0) exactly. */
 KD_FN void kd_softplus_logistic(double x, double* softplus, double* logistic)
 {
     const double ax = x < 0.0 ? -x : x;
-    const double t = kd_exp(-ax);
-    const double onept = 1.0 + t;
-    const double l1p = kd_log_pos(onept);
+    const double t = kd_exp_neg(ax);                 /* [0, 1], never NaN */
+    const double onept = 1.0 + t;                    /* [1, 2] */
+    const double l1p = kd_log_u01(onept);
     *softplus = (x > 0.0 ? x : 0.0) + l1p;
     *logistic = (x >= 0.0 ? 1.0 : t) / onept;
     if (x != x) { *softplus = x; *logistic = x; }

@@ -250,7 +250,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     if (desc->tuner_mode == KLARA_TUNE_POOLED && desc->sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
     // the logistic kernels keep the data rows in LDS next to the 8 KB of math tables, inside the 64 KB a launch gets
     // without raising the per-kernel limit: ndata * (D + 1) doubles <= 56 KB (swiss: 200 x 5 doubles = 8 KB)
-    if (desc->target == KLARA_TARGET_LOGISTIC && (size_t)desc->logit_ndata * (size_t)(desc->ndims + 1) > 7168u)
+    if (desc->target == KLARA_TARGET_LOGISTIC && (size_t)desc->logit_ndata * (size_t)(E + 1) > 7168u)      // (rows are padded to E columns)
         return KLARA_ERR_UNSUPPORTED;
 
     int ndev = 0;
@@ -456,7 +456,7 @@ static dim3 grid_for_transitions(const klara_handle* h)
 static size_t lds_for(const klara_handle* h)
 {
     if (h->kind != 1 && h->d.target == KLARA_TARGET_LOGISTIC)
-        return sizeof(double) * (size_t)h->d.logit_ndata * (size_t)(h->d.ndims + 1);
+        return sizeof(double) * (size_t)h->d.logit_ndata * (size_t)(h->E + 1);
     return 0;
 }
 

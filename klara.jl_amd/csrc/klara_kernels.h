@@ -357,14 +357,17 @@ struct DiagTarget {
 template <int E>
 struct LogisticTarget {
     const double* sX; const double* sy; int ndata; int D; double lambda, lpconst;
+    // The design matrix sits in LDS with a row stride of E doubles, columns D..E-1 zero: a row is read with 16-byte loads at a
+    // compile-time stride and the dot product / gradient accumulations run over all E elements without a per-element `e < D` test
+    // (fma(0, x, acc) = acc exactly, so the padded terms leave the D-term chains of the oracle untouched).
     static __device__ __forceinline__ size_t lds_bytes(const KParams& p)
     {
-        return sizeof(double) * (size_t)p.ndata * (size_t)(p.D + 1);
+        return sizeof(double) * (size_t)p.ndata * (size_t)(E + 1);
     }
     __device__ __forceinline__ void init(const KParams& p, const LaneCtx<E>&, double* lds)
     {
-        double* X = lds; double* y = lds + (size_t)p.ndata * p.D;
-        for (int i = threadIdx.x; i < p.ndata * p.D; i += blockDim.x) X[i] = p.lX[i];
+        double* X = lds; double* y = lds + (size_t)p.ndata * E;
+        for (int i = threadIdx.x; i < p.ndata * E; i += blockDim.x) { const int r = i / E, e = i - r * E; X[i] = e < p.D ? p.lX[r * p.D + e] : 0.0; }
         for (int i = threadIdx.x; i < p.ndata; i += blockDim.x) y[i] = p.ly[i];
         __syncthreads();
         sX = X; sy = y; ndata = p.ndata; D = p.D; lambda = p.lambda; lpconst = p.lpconst;
@@ -382,10 +385,12 @@ struct LogisticTarget {
         // at 2 wavefronts per SIMD for cfg 4's per-GPU share, so dependent-issue latency is otherwise exposed)
 #pragma unroll KLARA_LOGIT_UNROLL
         for (int r = cx.rq; r < ndata; r += cx.RS) {
-            const double* row = sX + r * D;
+            double row[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) row[e] = sX[r * E + e];
             double xp = 0.0;
 #pragma unroll
-            for (int e = 0; e < E; ++e) if (e < D) xp = kd_fma(row[e], x[e], xp);   // Xp = v[2]*p
+            for (int e = 0; e < E; ++e) xp = kd_fma(row[e], x[e], xp);            // Xp = v[2]*p
             const double yr = sy[r];
             double sp, lg;
             kd_softplus_logistic(xp, &sp, &lg);                                   // log(1+exp(Xp)), 1/(1+exp(-Xp)): one exponential
@@ -396,7 +401,7 @@ struct LogisticTarget {
             if (WANT_GRAD) {
                 const double res = yr - lg;                                       // v[3]-1./(1+exp(-Xp))
 #pragma unroll
-                for (int e = 0; e < E; ++e) if (e < D) gacc[e] = kd_fma(row[e], res, gacc[e]);
+                for (int e = 0; e < E; ++e) gacc[e] = kd_fma(row[e], res, gacc[e]);
             }
         }
         if (cx.RS > 1) {

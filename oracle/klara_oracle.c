@@ -756,6 +756,9 @@ void ko_math(int op, int64_t n, const double* in, const double* in2, double* out
         case 4: out[i] = sqrt(in[i]); break;
         case 6: out[i] = kd_erf(in[i]); break;
     case 7: out[i] = kd_log_u01(in[i]); break;
+        case 9: out[i] = kd_exp_neg(in[i]); break;
+        case 10: kd_softplus_logistic(in[i], &s, &c); out[i] = s; break;
+        case 11: kd_softplus_logistic(in[i], &s, &c); out[i] = c; break;
     case 8: out[i] = kd_sqrt_radicand(in[i]); break;
         default: out[i] = in[i] / in2[i]; break;
         }

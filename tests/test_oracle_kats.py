@@ -63,6 +63,30 @@ def test_detmath_accuracy_vs_libm():
     assert se[0] == 1.0 and se[1] == 0.0 and se[2] == np.inf and se[3] == 5e-324
 
 
+def test_softplus_logistic_pair():
+    """kd_exp_neg(a) = kd_exp(-a) bit for bit up to 708 and 0 beyond; log(1 + exp(x)) and 1 / (1 + exp(-x)) from it against
+    160-bit arithmetic (the logistic rows, doc/examples/swiss/MALA/analytical.jl:13,17: 2 ulp of max(value, 1) for the first, 2 ulp for the second),
+    exact limits for large |x|, NaN passed through."""
+    import mpmath
+    rng = np.random.default_rng(7)
+    a = np.concatenate([rng.uniform(0, 708, 200000), rng.uniform(0, 40, 100000), [0.0, 708.0, 1e-300, 37.5]])
+    assert np.array_equal(O.math_op(9, a), O.math_op(1, -a))
+    assert np.all(O.math_op(9, np.array([708.0000001, 745.0, 1e9, np.inf])) == 0.0)
+    x = np.concatenate([rng.uniform(-40, 40, 4000), rng.uniform(-750, 750, 500), [0.0, -0.0, 1e-320, 800.0, -800.0]])
+    sp, lg = O.math_op(10, x), O.math_op(11, x)
+    mpmath.mp.prec = 160
+    for xi, s_, l_ in zip(x, sp, lg):
+        e = mpmath.exp(mpmath.mpf(float(xi)))
+        ts, tl = mpmath.log(1 + e), e / (1 + e)
+        # (log(1 + t) is formed from the rounded 1 + t, as the reference's log(1 + exp(Xp)) is: absolute error up to an ulp of 1)
+        assert abs(mpmath.mpf(float(s_)) - ts) <= 2 * mpmath.mpf(float(np.spacing(max(abs(float(s_)), 1.0)))), xi
+        if abs(xi) <= 708:
+            assert abs(mpmath.mpf(float(l_)) - tl) <= 2 * mpmath.mpf(float(np.spacing(abs(float(l_)) or 5e-324))), xi
+        else:
+            assert l_ == (1.0 if xi > 0 else 0.0)
+    assert np.isnan(O.math_op(10, [np.nan])[0]) and np.isnan(O.math_op(11, [np.nan])[0])
+
+
 def test_box_muller_moments():
     n = 200000
     blocks = O.stream_blocks(12345, 3, 0, range(n))
