@@ -36,6 +36,7 @@ extern "C" {
 /* klara_desc.steps_per_launch = 0 selects this many transitions per kernel launch (launches also end at the pooled tuner's
  * events and at batch boundaries of the streaming batch means, whichever comes first) */
 #define KLARA_DEFAULT_STEPS_PER_LAUNCH 32
+#define KLARA_LOGIT_MAX_LDS_DOUBLES 18432u   /* 144 KB of the 160 KB of LDS of a compute unit */
 
 typedef enum klara_status {
     KLARA_OK = 0,
@@ -166,7 +167,7 @@ typedef struct klara_desc {
     const double* gauss_prec;    /* DENSE: D*D row-major precision matrix                            */
     const double* logit_X;       /* LOGISTIC: ndata x D row-major design matrix                      */
     const double* logit_y;       /* LOGISTIC: ndata outcomes                                         */
-    int32_t  logit_ndata;        /* LOGISTIC: rows; D <= 8 and ndata * (E + 1) <= 7168, E = 2, 4 or 8 >= D (rows live in LDS) */
+    int32_t  logit_ndata;        /* LOGISTIC: rows; D <= 8 and ndata * (E + 1) <= KLARA_LOGIT_MAX_LDS_DOUBLES, E = 2, 4 or 8 >= D (rows live in LDS) */
     int32_t  nstreams;           /* internal HIP streams for independent chain partitions (pair-transposed layout only):
                                     0 = automatic (2 when a partition still fills the GPU), 1..4 = forced        */
     double   logit_lambda;       /* LOGISTIC: prior variance (v[1] of the example)                   */

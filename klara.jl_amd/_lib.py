@@ -15,6 +15,7 @@ LIB_PATH = _HERE / "lib" / "libklara_hip.so"
 
 KLARA_ABI_VERSION = 3
 DEFAULT_STEPS_PER_LAUNCH = 32     # KLARA_DEFAULT_STEPS_PER_LAUNCH
+LOGIT_MAX_LDS_DOUBLES = 18432     # KLARA_LOGIT_MAX_LDS_DOUBLES
 
 # klara_status
 OK, ERR_INVALID_ARG, ERR_NONFINITE_INIT, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_STATE, ERR_SLICE_STUCK, ERR_COMPILE = range(9)

@@ -248,9 +248,10 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     st = select_layout(*desc, &kind, &G, &E);
     if (st != KLARA_OK) return st;
     if (desc->tuner_mode == KLARA_TUNE_POOLED && desc->sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
-    // the logistic kernels keep the data rows in LDS next to the 8 KB of math tables, inside the 64 KB a launch gets
-    // without raising the per-kernel limit: ndata * (D + 1) doubles <= 56 KB (swiss: 200 x 5 doubles = 8 KB)
-    if (desc->target == KLARA_TARGET_LOGISTIC && (size_t)desc->logit_ndata * (size_t)(E + 1) > 7168u)      // (rows are padded to E columns)
+    // the logistic kernels keep the data rows (padded to E columns, + the responses) in LDS next to the 8 KB of math tables: up to
+    // 144 KB of the CU's 160 (swiss: 200 x 5 doubles = 8 KB); beyond the 56 KB a launch gets by default the launchers raise the
+    // kernel's limit, and fewer workgroups share a CU
+    if (desc->target == KLARA_TARGET_LOGISTIC && (size_t)desc->logit_ndata * (size_t)(E + 1) > KLARA_LOGIT_MAX_LDS_DOUBLES)
         return KLARA_ERR_UNSUPPORTED;
 
     int ndev = 0;
@@ -465,11 +466,20 @@ template <int TARGET>
 static hipError_t launch_init_t(const KParams& p, int E, int G, int needgrad, dim3 grid, size_t lds, hipStream_t st)
 {
     const dim3 blk(256);
-    if (E == 2 && G == 64 && TARGET == KLARA_TARGET_GAUSS_DIAG) hipLaunchKernelGGL((k_init<TARGET, 2, 64>), grid, blk, lds, st, p, needgrad);
-    else if (E == 2) hipLaunchKernelGGL((k_init<TARGET, 2, 0>), grid, blk, lds, st, p, needgrad);
-    else if (E == 4) hipLaunchKernelGGL((k_init<TARGET, 4, 0>), grid, blk, lds, st, p, needgrad);
-    else if (E == 8 && TARGET != KLARA_TARGET_HIER_NORMAL) hipLaunchKernelGGL((k_init<TARGET, (TARGET == KLARA_TARGET_HIER_NORMAL ? 4 : 8), 0>), grid, blk, lds, st, p, needgrad);
+#define KLARA_INIT_LAUNCH(E_, G_)                                                                                                  \
+    do {                                                                                                                          \
+        if (lds > KLARA_LDS_DEFAULT_DYNAMIC) {                                                                                    \
+            hipError_t e_ = hipFuncSetAttribute((const void*)k_init<TARGET, E_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e_ != hipSuccess) return e_;                                                                                      \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((k_init<TARGET, E_, G_>), grid, blk, lds, st, p, needgrad);                                             \
+    } while (0)
+    if (E == 2 && G == 64 && TARGET == KLARA_TARGET_GAUSS_DIAG) KLARA_INIT_LAUNCH(2, 64);
+    else if (E == 2) KLARA_INIT_LAUNCH(2, 0);
+    else if (E == 4) KLARA_INIT_LAUNCH(4, 0);
+    else if (E == 8 && TARGET != KLARA_TARGET_HIER_NORMAL) KLARA_INIT_LAUNCH((TARGET == KLARA_TARGET_HIER_NORMAL ? 4 : 8), 0);
     else return hipErrorInvalidValue;
+#undef KLARA_INIT_LAUNCH
     return hipGetLastError();
 }
 

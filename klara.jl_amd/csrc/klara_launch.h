@@ -118,12 +118,22 @@ const char* klara_jit_log();
 
 // mode 7: mode 3 with exactly one transition per launch; mode 3: nothing counts/tunes and nothing is monitored;
 // mode 1: nothing counts/tunes; mode 0: general
+// (a launch gets 64 KB of LDS — 8 KB of math tables + 56 KB of dynamic — without asking; the logistic target's data rows may need more)
+#define KLARA_LDS_DEFAULT_DYNAMIC 57344u
+#define KLARA_LAUNCH_TM(S, T, E_, G_, M_)                                                                                          \
+    do {                                                                                                                          \
+        if (lds > KLARA_LDS_DEFAULT_DYNAMIC) {                                                                                    \
+            hipError_t e_ = hipFuncSetAttribute((const void*)k_transitions<S, T, E_, G_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e_ != hipSuccess) return e_;                                                                                      \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((k_transitions<S, T, E_, G_, M_>), grid, blk, lds, st, p, kl);                                          \
+    } while (0)
 #define KLARA_LAUNCH_T(S, T, E_, G_)                                                                    \
     do {                                                                                               \
-        if (mode == 7) hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 7>), grid, blk, lds, st, p, kl);      \
-        else if ((mode & 3) == 3) hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 3>), grid, blk, lds, st, p, kl); \
-        else if (mode & 1) hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 1>), grid, blk, lds, st, p, kl);  \
-        else hipLaunchKernelGGL((k_transitions<S, T, E_, G_, 0>), grid, blk, lds, st, p, kl);                \
+        if (mode == 7) KLARA_LAUNCH_TM(S, T, E_, G_, 7);                                                \
+        else if ((mode & 3) == 3) KLARA_LAUNCH_TM(S, T, E_, G_, 3);                                     \
+        else if (mode & 1) KLARA_LAUNCH_TM(S, T, E_, G_, 1);                                            \
+        else KLARA_LAUNCH_TM(S, T, E_, G_, 0);                                                          \
     } while (0)
 
 // dispatch helper used by every group-layout launcher

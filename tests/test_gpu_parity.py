@@ -558,7 +558,7 @@ def test_error_paths():
             K.Engine(nchains=4, nsteps=5, **kw)
         assert ei.value.status == L.ERR_UNSUPPORTED
     rng = np.random.default_rng(3)
-    for ndata, ok in ((1433, True), (1434, False)):            # logistic data rows live in LDS: ndata * (D + 1) <= 7168 doubles
+    for ndata, ok in ((1434, True), (3686, True), (3687, False)):   # logistic data rows live in LDS: ndata * (E + 1) <= 18432 doubles (beyond 7168 the kernels' LDS limit is raised)
         tgt = K.LogisticTarget(rng.standard_normal((ndata, 4)), (rng.random(ndata) < 0.5).astype(float))
         if ok:
             with K.Engine(sampler=L.SAMPLER_MALA, target=tgt, nchains=8, nsteps=2, driftstep=0.01) as e:

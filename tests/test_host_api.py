@@ -160,7 +160,7 @@ def test_create_validates_like_the_reference_constructors(klib):
     assert status(target=K.CustomTarget(65, cases.SRC_NEGDOT)) == L.ERR_UNSUPPORTED                    # one lane holds the vector: D <= 64
     assert status(target=K.CustomTarget(2, cases.SRC_NEGDOT, data=np.zeros(0))) in (0, L.ERR_HIP)       # empty data block is fine
     rng = np.random.default_rng(0)
-    big = K.LogisticTarget(rng.standard_normal((1434, 4)), np.zeros(1434))
+    big = K.LogisticTarget(rng.standard_normal((3687, 4)), np.zeros(3687))
     assert status(target=big, driftstep=0.01) == L.ERR_UNSUPPORTED                                     # data rows must fit the LDS budget
     assert status(sampler=L.SAMPLER_SLICE, slice_widths=np.ones(8), target=K.GaussDenseTarget(np.eye(8))) in (0, L.ERR_HIP)   # (no device here)
     assert status(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(np.eye(129))) == L.ERR_UNSUPPORTED                         # D <= 128 on the matrix cores
