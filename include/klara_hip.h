@@ -84,7 +84,7 @@ typedef enum klara_target {
      *   KLARA_USER_FN void   klara_user_gradlogtarget(const double* x, int D, const double* data, long long ndata,
      *                                                 double* g);           (needed by MALA / HMC only)
      * and is compiled for gfx950 at klara_create (hiprtc) into the group-layout transition kernels, one chain per lane
-     * (D <= 64; the whole vector in one lane: registers up to D = 32, scratch-backed beyond; KLARA_D is predefined to D so that loops unroll).  kd_exp, kd_log,
+     * (D <= 256; the whole vector in one lane: registers up to D = 32, scratch-backed beyond; KLARA_D is predefined to D so that loops unroll).  kd_exp, kd_log,
      * kd_fma, kd_erf (klara.jl_amd/csrc/detmath.h) and IEEE + - * / sqrt give the same bits on host and device;
      * `data` is custom_data (custom_ndata doubles, copied to the device at create).
      * Likelihood + prior form (BasicContMuvParameter(:p, loglikelihood=..., logprior=..., gradloglikelihood=..., gradlogprior=...),

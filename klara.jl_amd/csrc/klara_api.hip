@@ -13,7 +13,7 @@
 
 // user-defined targets keep the whole vector in one lane (klara_custom.h): pow2ceil(D) elements per lane
 #ifndef KLARA_CUSTOM_MAXD
-#define KLARA_CUSTOM_MAXD 64
+#define KLARA_CUSTOM_MAXD 256
 #endif
 
 #define HIPCHK(expr)                                                                   \

@@ -8,7 +8,8 @@
 //
 // in the C subset both hipcc and a host C compiler accept (KLARA_D is predefined to the job's dimension so that loops
 // unroll and x / g stay in registers; kd_exp, kd_log, kd_fma, kd_erf and IEEE + - * / sqrt are bit-reproducible on host and
-// device, libm calls are not).  One chain per lane (G = 1, E = pow2ceil(D) <= 64 elements, in registers up to 32), so the user's
+// device, libm calls are not).  One chain per lane (G = 1, E = pow2ceil(D) <= 256 elements: in registers up to 32, in scratch beyond — a
+// D = 200 job compiles for half a minute per kernel mode and is cached on disk), so the user's
 // function sees the whole parameter vector and no cross-lane reduction exists; `data` is the job's read-only block
 // (klara_desc.custom_data) in device memory.
 //

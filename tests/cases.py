@@ -420,6 +420,9 @@ def make_case(name):
     elif name == "custom_quartic_mala_d64":   # the largest user-defined dimension: 64 elements per lane (scratch-backed)
         c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(64, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=70, nsteps=20, burnin=5,
                  driftstep=0.05)
+    elif name == "custom_quartic_mala_d100":  # a user-defined target at the BASELINE dimension: 128 elements per lane, scratch-backed
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(100, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=70, nsteps=12, burnin=2,
+                 driftstep=0.04)
     elif name == "custom_quartic_hmc_d50":
         c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(50, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=33, nsteps=12, burnin=2,
                  leapstep=0.08, nleaps=5)
@@ -455,7 +458,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "mala_logit_d6_bigdata", "slice_logit_d3", "slice_d20_stepout", "mh_rats", "mala_rats_tuned"] + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
              "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
-             "custom_quartic_mala_d64", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh",
+             "custom_quartic_mala_d64", "custom_quartic_mala_d100", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh",
              "sparse_mala_d100", "sparse_mala_d100_small_step", "sparse_mh_d100", "sparse_mala_mvnormal_d30"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",

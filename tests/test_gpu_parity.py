@@ -901,8 +901,8 @@ def test_custom_target_compile_error_and_limits():
     with pytest.raises(K.KlaraError) as ei:               # MALA needs the gradient closure
         K.Engine(sampler=L.SAMPLER_MALA, target=K.CustomTarget(2, cases.SRC_BANANA_LT_ONLY), nchains=4, nsteps=5, driftstep=0.1)
     assert ei.value.status == L.ERR_COMPILE and "klara_user_gradlogtarget" in ei.value.log
-    with pytest.raises(K.KlaraError) as ei:               # D <= 64: the whole vector lives in one lane
-        K.Engine(sampler=L.SAMPLER_MH, target=K.CustomTarget(65, cases.SRC_NEGDOT), nchains=4, nsteps=5, mh_sigma=np.ones(65))
+    with pytest.raises(K.KlaraError) as ei:               # D <= 256: the whole vector lives in one lane
+        K.Engine(sampler=L.SAMPLER_MH, target=K.CustomTarget(257, cases.SRC_NEGDOT), nchains=4, nsteps=5, mh_sigma=np.ones(257))
     assert ei.value.status == L.ERR_UNSUPPORTED
     # a closure that is not finite at the start: the reference's initialize! assert (MH.jl:83)
     src = "KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata) { return kd_log(x[0]); }"
