@@ -6,6 +6,8 @@
 * cfg 5 runs as stated (131,072 chains per GPU, HMC L = 32, per-GPU pooled AcceptanceRateMCTuner(0.65, period 100),
   2,000 steps, burn-in 1,000, running sums on) with blocks of 16 chains replayed by the CPU oracle bit for bit and every
   pooled tuner event recomputed on the host from the device's own accept counts;
+* cfg 4 runs as stated (32,768 chains per GPU, MALA driftstep 0.1 on the swiss logistic regression, 10,000 steps, burn-in 1,000)
+  with blocks of 8 chains replayed by the oracle bit for bit and the pooled posterior against the Laplace approximation;
 * the proposal normals' tail mass on 1.7e10 device draws.
 """
 import ctypes as C
@@ -217,6 +219,52 @@ def test_cfg5_rats_hmc_full_size_against_the_oracle():
     mean, var, acc, ns = _pooled_moments(eng)
     r = 30
     assert abs(mean[2 * r] - 242.6) < 1.2 and abs(mean[2 * r + 1] - 6.186) < 0.06 and abs(mean[2 * r + 2] - math.log(6.07)) < 0.06, mean[2 * r:]
+    eng.close()
+
+
+# ------------------------------------------------------------------ cfg 4: swiss logistic regression, MALA, one GPU's share as stated
+def test_cfg4_swiss_mala_full_size_against_the_oracle():
+    """BASELINE cfg 4, one GPU's share, as SURVEY 8(d) states it: Bayesian logistic regression on the swiss data (lambda = 100,
+    doc/examples/swiss/MALA/analytical.jl), MALA driftstep 0.1, VanillaMCTuner, 32,768 chains (= 262,144 / 8), 10,000 steps, burn-in
+    1,000, x0 = (5.1, -0.9, 8.2, -4.5) + 0.1 N(0, I) per chain, running sums on — the row-split kernel at 4 wavefronts per SIMD that
+    bench.py times.  Three blocks of 8 chains (first, middle, the ragged last wavefront group) are replayed by the oracle bit for bit:
+    accept masks of all 10,000 transitions, final x / logtarget / gradient, running sums; the pooled posterior matches the Laplace
+    approximation (MAP + inverse Hessian from SciPy on the same data)."""
+    from scipy import optimize
+    X, y = cases.swiss_data()
+    lam = 100.0
+    n, nsteps, burnin = 32768 - 3, 10000, 1000
+    rng = np.random.default_rng(4)
+    x0 = np.array([5.1, -0.9, 8.2, -4.5])[None, :] + 0.1 * rng.standard_normal((n, 4))
+    kw = dict(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, lam), nsteps=nsteps, burnin=burnin, driftstep=0.1)
+    eng = K.Engine(nchains=n, monitor=L.MON_SUMMARIES | L.MON_ACCEPT, **kw)
+    assert eng.layout() == (2, 8, 4)
+    eng.set_state(x0)
+    eng.run(nsteps)
+    mask = eng.accept_mask()
+    x, lt, g = eng.state()
+    s, q, nsaved = eng.chain_sums()
+    assert mask.shape == (nsteps, n) and nsaved == nsteps - burnin
+    for off in (0, 16384 + 3, n - 8):
+        job = O.OracleJob(**cases.oracle_kwargs(dict(kw, nchains=8, name="cfg4", x0=None, seed=20260927), layout=eng.layout(), chain_offset=off))
+        job.set_state(x0[off:off + 8])
+        assert job.run(nsteps) == 0
+        sl = slice(off, off + 8)
+        assert np.array_equal(mask[:, sl], job.accept), off
+        assert np.array_equal(x[sl], job.X) and np.array_equal(lt[sl], job.LT) and np.array_equal(g[sl], job.G), off
+        assert np.array_equal(s[sl], job.sum) and np.array_equal(q[sl], job.sumsq), off
+
+    def nlp(p):
+        xp = X @ p
+        return -(xp @ y - np.sum(np.logaddexp(0.0, xp)) - 0.5 * p @ p / lam)
+
+    pm = optimize.minimize(nlp, np.zeros(4), method="BFGS").x
+    sg = 1.0 / (1.0 + np.exp(-(X @ pm)))
+    sd = np.sqrt(np.diag(np.linalg.inv(X.T @ (X * (sg * (1 - sg))[:, None]) + np.eye(4) / lam)))
+    mean, var, acc, ns = _pooled_moments(eng)
+    assert 0.2 < acc < 0.98, acc
+    assert np.all(np.abs(mean - pm) < 0.15 * sd + 0.05 * np.abs(pm)), (mean, pm, sd)       # (the posterior is skewed: Laplace is approximate)
+    assert np.all(np.abs(np.sqrt(var) / sd - 1.0) < 0.3), (var, sd)
     eng.close()
 
 
