@@ -710,10 +710,11 @@ def _random_case(seed):
         d = int(rng.choice([2, 4, 7, 16, 18, 23, 48, 65, 96, 127, 140]))
         target = K.GaussDiagTarget.mvnormal(rng.uniform(-2, 2, d), rng.uniform(0.5, 2.0, d))
     elif fam == "dense":
-        d = int(rng.choice([3, 8, 20, 33, 50]))
-        target = K.GaussDenseTarget(cases.compound_symmetric_precision(d, float(rng.uniform(0.1, 0.7))))
+        d = int(rng.choice([3, 8, 20, 33, 50, 70]))
+        target = K.GaussDenseTarget(cases.compound_symmetric_precision(d, float(rng.uniform(0.1, 0.7))), const=float(rng.uniform(-2, 2)),
+                                    mu=(rng.uniform(-1.5, 1.5, d) if rng.integers(0, 2) else None))
     elif fam == "logit":
-        d = int(rng.choice([1, 2, 3, 4, 6, 8])); n = int(rng.choice([5, 30, 63, 64, 100]))
+        d = int(rng.choice([1, 2, 3, 4, 6, 8])); n = int(rng.choice([5, 30, 63, 64, 100, 300]))
         X, y = cases.synthetic_logit(n, d, seed=seed)
         target = K.LogisticTarget(X, y, float(rng.choice([1.0, 100.0])))
     elif fam == "hier":
@@ -725,7 +726,7 @@ def _random_case(seed):
     else:
         d = int(rng.choice([2, 5, 9, 16, 24]))
         target = K.CustomTarget(d, cases.SRC_QUARTIC_CHAIN, [float(rng.uniform(0.01, 0.2)), float(rng.uniform(0.1, 0.8))])
-    samplers = [L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC] + ([] if fam == "dense" else [L.SAMPLER_SLICE])
+    samplers = [L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC] + ([] if fam == "dense" and d > 33 else [L.SAMPLER_SLICE])   # (dense slice: D full evaluations per probe)
     sampler = int(rng.choice(samplers))
     scale = 0.02 if fam == "hier" else (0.05 if fam == "logit" else 0.3)
     c = dict(sampler=sampler, target=target, nchains=int(rng.choice([1, 2, 7, 8, 9, 33, 64, 100, 131])), x0=None, seed=int(rng.integers(1, 2 ** 40)),
