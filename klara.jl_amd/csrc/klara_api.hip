@@ -238,10 +238,77 @@ static int kernel_modes(const klara_desc& d, int (&modes)[2])
     return 1;
 }
 
+// The logistic-regression target beyond D = 8 (the row-split kernels hold the whole parameter vector of a chain in every lane's
+// registers and the data rows in LDS): the same closures — doc/examples/swiss/MALA/analytical.jl:11-18, operation for operation what
+// LogisticTarget::eval and the oracle's ko_logistic_eval compute with all rows on one lane — as source text for the run-time compiled
+// path (klara_custom.h): one chain per lane, E = pow2ceil(D) <= 256 elements, the data block [lambda, D log(2 pi lambda), X, y] read
+// from global memory, any number of rows.
+static const char* const KLARA_LOGIT_WIDE_SRC = R"SRC(
+KLARA_USER_FN double klara_user_logtarget(const double* p, int D, const double* data, long long ndata)
+{
+    const long long n = (ndata - 2) / (KLARA_D + 1);
+    const double lambda = data[0], lpconst = data[1];
+    const double* X = data + 2; const double* y = X + n * KLARA_D;
+    double dotxy = 0.0, slog = 0.0;
+    for (long long r = 0; r < n; ++r) {
+        double xp = 0.0;
+        for (int e = 0; e < KLARA_D; ++e) xp = kd_fma(X[r * KLARA_D + e], p[e], xp);
+        double sp, lg;
+        kd_softplus_logistic(xp, &sp, &lg);
+        dotxy = dotxy + xp * y[r];
+        slog = slog + sp;
+    }
+    double dotpp = 0.0;
+    for (int e = 0; e < KLARA_D; ++e) dotpp = dotpp + p[e] * p[e];
+    const double ll = dotxy - slog;
+    const double lp = -0.5 * (dotpp / lambda + lpconst);
+    return ll + lp;
+}
+KLARA_USER_FN void klara_user_gradlogtarget(const double* p, int D, const double* data, long long ndata, double* g)
+{
+    const long long n = (ndata - 2) / (KLARA_D + 1);
+    const double lambda = data[0];
+    const double* X = data + 2; const double* y = X + n * KLARA_D;
+    for (int e = 0; e < KLARA_D; ++e) g[e] = 0.0;
+    for (long long r = 0; r < n; ++r) {
+        double xp = 0.0;
+        for (int e = 0; e < KLARA_D; ++e) xp = kd_fma(X[r * KLARA_D + e], p[e], xp);
+        double sp, lg;
+        kd_softplus_logistic(xp, &sp, &lg);
+        const double res = y[r] - lg;
+        for (int e = 0; e < KLARA_D; ++e) g[e] = kd_fma(X[r * KLARA_D + e], res, g[e]);
+    }
+    for (int e = 0; e < KLARA_D; ++e) g[e] = g[e] - p[e] / lambda;
+}
+)SRC";
+
+static klara_status create_impl(const klara_desc* desc, klara_handle** out);
+
 extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
 {
     if (!out) return KLARA_ERR_INVALID_ARG;
     *out = nullptr;
+    klara_status st = validate(desc);
+    if (st != KLARA_OK) return st;
+    if (desc->target == KLARA_TARGET_LOGISTIC && desc->ndims > 8) {
+        if (desc->ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
+        if (desc->monitor & KLARA_MON_HIST_LLLP) return KLARA_ERR_UNSUPPORTED;
+        const size_t n = (size_t)desc->logit_ndata, D = (size_t)desc->ndims;
+        std::vector<double> blk(2 + n * (D + 1));
+        blk[0] = desc->logit_lambda;
+        blk[1] = (double)desc->ndims * kd_log(2.0 * 3.141592653589793 * desc->logit_lambda);
+        memcpy(blk.data() + 2, desc->logit_X, n * D * sizeof(double));
+        memcpy(blk.data() + 2 + n * D, desc->logit_y, n * sizeof(double));
+        klara_desc dd = *desc;
+        dd.target = KLARA_TARGET_CUSTOM; dd.custom_src = KLARA_LOGIT_WIDE_SRC; dd.custom_data = blk.data(); dd.custom_ndata = (int64_t)blk.size();
+        dd.logit_X = nullptr; dd.logit_y = nullptr; dd.logit_ndata = 0;
+        return create_impl(&dd, out);
+    }
+    return create_impl(desc, out);
+}
+
+static klara_status create_impl(const klara_desc* desc, klara_handle** out)
+{
     klara_status st = validate(desc);
     if (st != KLARA_OK) return st;
     int kind, G, E;

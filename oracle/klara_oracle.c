@@ -156,6 +156,26 @@ static void ko_logit_eval(const ko_target_ctx* c, const double* p, double* lt, d
     /* row split: row r belongs to lane r % RS; lane partials are then combined pairwise (xor tree) */
     const int RS = (c->L->kind == 2) ? c->L->G : 1;
     double pdot[64], plog[64], pg[64][16];
+    if (RS == 1 && D > 16) {                     /* beyond 16 parameters: all rows on one lane, no tree (the closure form of the library) */
+        double dotxy1 = 0.0, slog1 = 0.0, g1[KO_MAXD];
+        for (int k = 0; k < D; ++k) g1[k] = 0.0;
+        for (int r = 0; r < n; ++r) {
+            const double* row = d->logit_X + (size_t)r * D;
+            double xp = 0.0;
+            for (int k = 0; k < D; ++k) xp = kd_fma(row[k], p[k], xp);
+            double sp, lg;
+            kd_softplus_logistic(xp, &sp, &lg);
+            if (lt) { dotxy1 = dotxy1 + xp * d->logit_y[r]; slog1 = slog1 + sp; }
+            if (g) { const double res = d->logit_y[r] - lg; for (int k = 0; k < D; ++k) g1[k] = kd_fma(row[k], res, g1[k]); }
+        }
+        if (lt) {
+            double dotpp = 0.0;
+            for (int k = 0; k < D; ++k) dotpp = dotpp + p[k] * p[k];
+            *lt = (dotxy1 - slog1) + -0.5 * (dotpp / d->logit_lambda + c->logit_lpconst);
+        }
+        if (g) for (int k = 0; k < D; ++k) g[k] = g1[k] - p[k] / d->logit_lambda;
+        return;
+    }
     if (D > 16 || RS > 64) { if (lt) *lt = NAN; return; }
     for (int q = 0; q < RS; ++q) { pdot[q] = 0.0; plog[q] = 0.0; for (int k = 0; k < D; ++k) pg[q][k] = 0.0; }
     for (int r = 0; r < n; ++r) {

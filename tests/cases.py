@@ -291,18 +291,21 @@ def make_case(name):
         x0 = np.array([5.1, -0.9, 8.2, -4.5])
         c = dict(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, 100.0), nchains=70, nsteps=40, burnin=10,
                  driftstep=0.1, x0=x0[None, :] + 0.1 * np.random.default_rng(1).standard_normal((70, 4)))
-    elif name in ("mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small", "mala_logit_d6_bigdata", "slice_logit_d3"):
+    elif name in ("mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small", "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide",
+                  "hmc_logit_d20_wide"):
         # synthetic logistic data: E = 2 / 4 / 8 (D = 3, 6, 7: rows padded to E columns in LDS), with and without row split; 1,500 x 9
         # doubles = 108 KB of rows: beyond the 56 KB a launch gets by default
         d, nd = {"mala_logit_d2": (2, 90), "hmc_logit_d7": (7, 131), "mh_logit_d8_small": (8, 30), "mala_logit_d6_bigdata": (6, 1500),
-                 "slice_logit_d3": (3, 75)}[name]
+                 "slice_logit_d3": (3, 75), "mala_logit_d12_wide": (12, 150), "hmc_logit_d20_wide": (20, 400)}[name]   # D > 8: closure form
         rng = np.random.default_rng(d)
         X = rng.standard_normal((nd, d)); beta = rng.standard_normal(d)
         y = (rng.random(nd) < 1.0 / (1.0 + np.exp(-X @ beta))).astype(np.float64)
         kw = {"mala_logit_d2": dict(sampler=L.SAMPLER_MALA, driftstep=0.05), "hmc_logit_d7": dict(sampler=L.SAMPLER_HMC, leapstep=0.05, nleaps=4),
               "mh_logit_d8_small": dict(sampler=L.SAMPLER_MH, mh_sigma=np.full(8, 0.2)),
               "mala_logit_d6_bigdata": dict(sampler=L.SAMPLER_MALA, driftstep=0.002),
-              "slice_logit_d3": dict(sampler=L.SAMPLER_SLICE, slice_widths=np.full(3, 0.8))}[name]
+              "slice_logit_d3": dict(sampler=L.SAMPLER_SLICE, slice_widths=np.full(3, 0.8)),
+              "mala_logit_d12_wide": dict(sampler=L.SAMPLER_MALA, driftstep=0.01, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=5),
+              "hmc_logit_d20_wide": dict(sampler=L.SAMPLER_HMC, leapstep=0.07, nleaps=5)}[name]
         c = dict(target=K.LogisticTarget(X, y, 10.0), nchains=45, nsteps=25, burnin=5, x0=0.1 * rng.standard_normal((45, d)), **kw)
     elif name == "hmc_swiss":
         X, y = swiss_data()
@@ -455,7 +458,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg",
              "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "hmc_dense_d100_mean", "mala_dense_d37_mean", "mh_dense_d20_mean",
              "hmc_dense_d70_mean_dualavg", "slice_dense_d20", "slice_dense_d37_mean", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
-             "mala_logit_d6_bigdata", "slice_logit_d3", "slice_d20_stepout", "mh_rats", "mala_rats_tuned"] + [
+             "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide", "hmc_logit_d20_wide", "slice_d20_stepout", "mh_rats", "mala_rats_tuned"] + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
              "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
              "custom_quartic_mala_d64", "custom_quartic_mala_d100", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh",

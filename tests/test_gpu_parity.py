@@ -714,7 +714,7 @@ def _random_case(seed):
         target = K.GaussDenseTarget(cases.compound_symmetric_precision(d, float(rng.uniform(0.1, 0.7))), const=float(rng.uniform(-2, 2)),
                                     mu=(rng.uniform(-1.5, 1.5, d) if rng.integers(0, 2) else None))
     elif fam == "logit":
-        d = int(rng.choice([1, 2, 3, 4, 6, 8])); n = int(rng.choice([5, 30, 63, 64, 100, 300]))
+        d = int(rng.choice([1, 2, 3, 4, 6, 8, 11])); n = int(rng.choice([5, 30, 63, 64, 100, 300]))   # (11: the closure form beyond 8 parameters)
         X, y = cases.synthetic_logit(n, d, seed=seed)
         target = K.LogisticTarget(X, y, float(rng.choice([1.0, 100.0])))
     elif fam == "hier":

@@ -255,6 +255,18 @@ def test_logistic_target_matches_numpy():
     assert np.allclose(g, ref_g, rtol=1e-11)
 
 
+def test_logistic_target_with_20_parameters_matches_numpy():
+    # beyond 8 parameters the library evaluates the same closures from run-time compiled source (all rows on one lane)
+    X, y = cases.synthetic_logit(300, 20, seed=3)
+    p = 0.3 * np.random.default_rng(1).standard_normal(20)
+    job = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=L.TARGET_LOGISTIC, nchains=1, ndims=20, nsteps=1, logit_X=X, logit_y=y, logit_lambda=10.0)
+    assert (job.layout.kind, job.layout.G, job.layout.E) == (0, 1, 32)
+    lt, g = job.eval_target(p)
+    xp = X @ p
+    assert lt == pytest.approx(xp @ y - np.sum(np.log(1 + np.exp(xp))) - 0.5 * (p @ p / 10.0 + 20 * np.log(2 * np.pi * 10.0)), rel=1e-12)
+    assert np.allclose(g, X.T @ (y - 1 / (1 + np.exp(-xp))) - p / 10.0, rtol=1e-11, atol=1e-12)
+
+
 def test_hierarchical_rats_target_matches_numpy_and_finite_differences():
     """Builder-defined BUGS 'Rats' target on the reference's data files (data/rats/*.csv): closed form in
     NumPy for lt, central differences for the gradient."""
