@@ -282,6 +282,36 @@ KLARA_USER_FN void klara_user_gradlogtarget(const double* p, int D, const double
 }
 )SRC";
 
+// The dense Gaussian beyond D = 128 (the matrix-core layouts end there): the same closure form — g = -(P d) as a k-ascending fma chain
+// per row, lt = c + 1/2 sum_i d_i g_i, d = x - mu (the oracle's ko_dense_grad / ko_dense_lt_from_grad with all elements on one lane);
+// data block [c, P (D x D row-major), mu (D)].
+static const char* const KLARA_DENSE_WIDE_SRC = R"SRC(
+KLARA_USER_FN void klara_user_gradlogtarget(const double* x, int D, const double* data, long long ndata, double* g)
+{
+    const double* P = data + 1; const double* mu = P + (long long)KLARA_D * KLARA_D;
+    _Pragma("nounroll")
+    for (int i = 0; i < KLARA_D; ++i) {
+        double acc = 0.0;
+        _Pragma("unroll 4")
+        for (int k = 0; k < KLARA_D; ++k) acc = kd_fma(P[(long long)i * KLARA_D + k], x[k] - mu[k], acc);
+        g[i] = -acc;
+    }
+}
+KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata)
+{
+    const double* P = data + 1; const double* mu = P + (long long)KLARA_D * KLARA_D;
+    double s = 0.0;
+    _Pragma("nounroll")
+    for (int i = 0; i < KLARA_D; ++i) {
+        double acc = 0.0;
+        _Pragma("unroll 4")
+        for (int k = 0; k < KLARA_D; ++k) acc = kd_fma(P[(long long)i * KLARA_D + k], x[k] - mu[k], acc);
+        s = s + (x[i] - mu[i]) * (-acc);
+    }
+    return data[0] + 0.5 * s;
+}
+)SRC";
+
 static klara_status create_impl(const klara_desc* desc, klara_handle** out);
 
 extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
@@ -302,6 +332,19 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         klara_desc dd = *desc;
         dd.target = KLARA_TARGET_CUSTOM; dd.custom_src = KLARA_LOGIT_WIDE_SRC; dd.custom_data = blk.data(); dd.custom_ndata = (int64_t)blk.size();
         dd.logit_X = nullptr; dd.logit_y = nullptr; dd.logit_ndata = 0;
+        return create_impl(&dd, out);
+    }
+    if (desc->target == KLARA_TARGET_GAUSS_DENSE && desc->ndims > 128) {
+        if (desc->ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
+        if (desc->monitor & KLARA_MON_HIST_LLLP) return KLARA_ERR_UNSUPPORTED;
+        const size_t D = (size_t)desc->ndims;
+        std::vector<double> blk(1 + D * D + D, 0.0);
+        blk[0] = desc->gauss_const;
+        memcpy(blk.data() + 1, desc->gauss_prec, D * D * sizeof(double));
+        if (desc->gauss_mu) memcpy(blk.data() + 1 + D * D, desc->gauss_mu, D * sizeof(double));
+        klara_desc dd = *desc;
+        dd.target = KLARA_TARGET_CUSTOM; dd.custom_src = KLARA_DENSE_WIDE_SRC; dd.custom_data = blk.data(); dd.custom_ndata = (int64_t)blk.size();
+        dd.gauss_prec = nullptr; dd.gauss_mu = nullptr;
         return create_impl(&dd, out);
     }
     return create_impl(desc, out);

@@ -252,7 +252,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                     for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];   // samplers.jl:133
                 }
             } else {
-                const int nl = da_nleaps(p, eps);
+                const int nl = cx.chain_ok ? da_nleaps(p, eps) : 1;      // (a padding lane must not set the wavefront's trip count)
                 for (int l = 0; __any(l < nl); ++l) {
                     const bool go = l < nl;
                     if (go) {

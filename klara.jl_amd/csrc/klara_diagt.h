@@ -505,7 +505,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 #pragma unroll
                 for (int e = 0; e < E; ++e) xp[e] = x[e];                                      // :139
                 grad_of(x, gp);                                                                // :140 (re-formed)
-                const int nl = DA ? da_nleaps(p, eps) : p.nleaps;                              // :142-144
+                const int nl = DA ? (chain_ok ? da_nleaps(p, eps) : 1) : p.nleaps;             // :142-144 (padding lanes: 1)
                 for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {                          // :146-155, samplers.jl:122-134
                     const bool go = !DA || l < nl;
 #pragma unroll

@@ -279,7 +279,7 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
             const double H0 = lt - 0.5 * hier_sumsq<RPL, NT>(cx, mom);                     // :137
             xp = x; gp = g;                                                               // :139-140
             const double eps = tn.step, halfe = 0.5 * eps;
-            const int nl = DA ? da_nleaps(p, eps) : p.nleaps;                             // iterate/HMC.jl:142-144
+            const int nl = DA ? (chain_ok ? da_nleaps(p, eps) : 1) : p.nleaps;            // iterate/HMC.jl:142-144 (padding lanes: 1)
             for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {                         // :146-155, samplers.jl:122-134
                 const bool go = !DA || l < nl;                                            // (a finished chain keeps its state)
     #pragma unroll

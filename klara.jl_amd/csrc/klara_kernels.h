@@ -230,10 +230,17 @@ template <int E>
 __device__ __forceinline__ void load_param(const LaneCtx<E>& c, const gdouble* base, int D, double dflt,
                                            double (&v)[E])
 {
+    // (branch-free: E conditional loads are E basic blocks, and at E = 128 the compiler spent two minutes on them)
+    if (base == nullptr) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = dflt;
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        v[e] = dflt;
-        if (base != nullptr && c.i0 + e < D) v[e] = base[c.i0 + e];
+        const int i = c.i0 + e;
+        const double t = base[i < D ? i : D - 1];
+        v[e] = i < D ? t : dflt;
     }
 }
 
@@ -594,7 +601,9 @@ __device__ __forceinline__ void tuning_block(const KParams& p, TuneRegs& tn)
 }
 
 // nleaps of a transition under dual averaging: max(1, Int(round(lambda/step))) — iterate/HMC.jl:142-144
-// (round = ties to even; capped at 65536, non-finite quotient -> cap).
+// (round = ties to even; capped at 65536, non-finite quotient -> cap).  Callers pass 1 for the padding lanes of a ragged last wavefront:
+// their phantom state (x = 0, re-read every transition) can drive the dual-averaging step towards 0, and the wavefront runs to the
+// longest trajectory among its lanes — 65,536 leapfrogs per transition for nothing.
 __device__ __forceinline__ int da_nleaps(const KParams& p, double step)
 {
     const double q = p.da_lambda / step;
@@ -1023,7 +1032,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             else if (SAMPLER == KLARA_SAMPLER_MALA) acc = step_mala<T, E, PLAIN, !(DIRECT || OUTER)>(p, tg, cx, gchain, t, z, ad, tn.step, cur.x, cur.g, cur.lt, prop);
             else if (SAMPLER == KLARA_SAMPLER_HMC) {
                 double a_prob = 0.0;
-                acc = step_hmc<T, E, PLAIN, !(DIRECT || OUTER)>(p, tg, cx, gchain, t, z, ad, tn.step, da ? da_nleaps(p, tn.step) : p.nleaps, a_prob,
+                acc = step_hmc<T, E, PLAIN, !(DIRECT || OUTER)>(p, tg, cx, gchain, t, z, ad, tn.step, da ? (cx.chain_ok ? da_nleaps(p, tn.step) : 1) : p.nleaps, a_prob,
                                      cur.x, cur.g, cur.lt, prop);
                 if (da) da_update(p, tn, (long long)t + 1, a_prob);                   // iterate/HMC.jl:225-249
             }
@@ -1063,11 +1072,9 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             if (!NOMON && i1 > p.burnin && i1 <= p.nsteps_total) {
                 if (sphase == 0) {
                     if (do_sum) held += 1;
-                    if (hist != nullptr && scol < p.hist_cols) {
-                        gdouble* dst = hist + (scol * p.nchains + cx.chain) * p.D + cx.i0;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) if (cx.valid[e] && cx.rq == 0) dst[e] = cur.x[e];
-                    }
+                    // (window stores: invalid elements and the row-split's replica lanes carry out-of-range offsets — no per-element branch)
+                    if (hist != nullptr && scol < p.hist_cols)
+                        store_win<E>(cx, group_window(hist, scol * p.nchains + first_chain, here, p.D), p.D, cur.x);
                     if (hist_lt != nullptr && scol < p.hist_cols && cx.chain_ok && cx.q == 0 && cx.rq == 0)
                         hist_lt[scol * p.nchains + cx.chain] = cur.lt;
                     if constexpr (TARGET == KLARA_TARGET_CUSTOM) {            // :monitor => [:loglikelihood, :logprior]
@@ -1077,11 +1084,8 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
                             if (cx.chain_ok) { p.hist_ll[scol * p.nchains + cx.chain] = ll_; p.hist_lp[scol * p.nchains + cx.chain] = lp_; }
                         }
                     }
-                    if (NEEDG && hist_g != nullptr && scol < p.hist_cols) {
-                        gdouble* dst = hist_g + (scol * p.nchains + cx.chain) * p.D + cx.i0;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) if (cx.valid[e] && cx.rq == 0) dst[e] = cur.g[e];
-                    }
+                    if (NEEDG && hist_g != nullptr && scol < p.hist_cols)
+                        store_win<E>(cx, group_window(hist_g, scol * p.nchains + first_chain, here, p.D), p.D, cur.g);
                     ++scol;
                 }
                 sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;

@@ -129,6 +129,8 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
         while e < d:
             e *= 2
         return (0, 1, e)
+    if target_kind == L.TARGET_GAUSS_DENSE and d > 128:     # beyond the matrix-core layouts: the run-time compiled closure form
+        return (0, 1, 256)
     if target_kind == L.TARGET_GAUSS_DENSE:
         ne = 8 if d <= 32 else 16 if d <= 64 else 25 if d <= 100 else 32
         return (1, 4, ne)

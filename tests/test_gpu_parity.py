@@ -549,7 +549,7 @@ def test_error_paths():
         eng.chain(0)                                           # history not monitored
     assert ei.value.status == L.ERR_STATE
     eng.close()
-    for kw in (dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(np.eye(129))),                 # the matrix-core layouts end at D = 128
+    for kw in (dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(np.eye(257))),                 # the matrix-core layouts end at D = 128, the closure form at 256
                dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(4), tuner=L.TUNER_DUAL_AVERAGING,
                     targetrate=0.6, da_nadapt=10),
                dict(sampler=L.SAMPLER_SLICE, slice_widths=np.ones(4), target=K.GaussDiagTarget.negdot(4),
@@ -798,6 +798,23 @@ def test_random_configurations(seed):
     if mon & L.MON_HIST_GRAD:
         assert np.array_equal(g, job.hist_g[:, ch, :].T)
     eng.close()
+
+
+def test_dual_averaging_padding_lanes_do_not_set_the_trip_count():
+    """A ragged last wavefront carries padding lanes whose phantom chain (x = 0, re-read every transition) can drive the dual-averaging
+    step towards 0 when 0 is far out in the target's tail — nleaps = round(lambda / step) (iterate/HMC.jl:142-144) then reaches the cap
+    of 65,536 and the wavefront, which runs to its longest trajectory, spends seconds per transition (30 s for this 30-transition job
+    before padding lanes were pinned to one leapfrog)."""
+    for name in ("hmc_dense_d70_mean_dualavg", "hmc_d40_dualavg"):
+        c = dict(cases.make_case(name))
+        if name == "hmc_d40_dualavg":          # the same on the pair-transposed layout: a mean far from the padding lanes' x = 0
+            c["target"] = K.GaussDiagTarget.mvnormal(np.full(40, 30.0), np.linspace(0.6, 1.6, 40)); c["nchains"] = 27
+            c["x0"] = 30.0 + np.random.default_rng(2).standard_normal((27, 40))
+        eng = K.Engine(**cases.engine_kwargs(c))
+        eng.set_state(c["x0"])
+        eng.run(c["nsteps"])
+        assert eng.last_run_ms()[0] < 2000.0, (name, eng.last_run_ms())
+        eng.close()
 
 
 # ------------------------------------------------------------------ streaming batch means

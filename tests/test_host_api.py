@@ -163,7 +163,7 @@ def test_create_validates_like_the_reference_constructors(klib):
     big = K.LogisticTarget(rng.standard_normal((3687, 4)), np.zeros(3687))
     assert status(target=big, driftstep=0.01) == L.ERR_UNSUPPORTED                                     # data rows must fit the LDS budget
     assert status(sampler=L.SAMPLER_SLICE, slice_widths=np.ones(8), target=K.GaussDenseTarget(np.eye(8))) in (0, L.ERR_HIP)   # (no device here)
-    assert status(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(np.eye(129))) == L.ERR_UNSUPPORTED                         # D <= 128 on the matrix cores
+    assert status(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(np.eye(257))) == L.ERR_UNSUPPORTED                         # D <= 128 on the matrix cores, <= 256 as closures
 
 
 def test_no_cpu_fallback_without_gpu(klib):
