@@ -10,7 +10,8 @@
  * (test/common.jl:6, test/AcceptanceRateMCTuner.jl:8-14), the Gaussian target closures
  * (test/BasicContMuvParameter.jl:39-56,62-80,...), the NState column layout
  * (test/ParameterNStates.jl:139-146), Philox4x32-10 (Random123 known-answer vectors) — see
- * tests/test_oracle_kats.py.  Beyond that the oracle is checked against analytic posterior moments.
+ * tests/test_oracle_kats.py.  Beyond that the oracle is checked against analytic posterior moments and, transition by transition,
+ * against an independent Python restatement of the same Julia sources (tests/numpy_mirror.py, tests/test_numpy_mirror.py).
  *
  * Third-party pieces of the reference's arithmetic that are NOT in /root/reference (REQUIRE lists version floors only,
  * there is no lockfile): Julia Base `randn`/`rand` (dSFMT + ziggurat, unseeded — replaced by the build-defined stream

@@ -1,0 +1,222 @@
+"""A second, independent restatement of the reference's transition path — plain Python / numpy, written from the Julia sources
+and SURVEY.md Appendix A, sharing NO code with oracle/klara_oracle.c or klara.jl_amd/csrc/detmath.h ("C primary;
+Python/numpy mirror").  Test infrastructure only.
+
+What is restated here, and from where:
+  * the counter stream: Philox4x32-10 (Salmon et al., SC'11: multipliers 0xD2511F53 / 0xCD9E8D57, Weyl
+    constants 0x9E3779B9 / 0xBB67AE85), counter = ((transition << 24) | slot, global chain id), key = seed; 52-bit uniforms
+    (m + 1/2) 2^-52; Box-Muller sqrt(-2 ln u1) (cos, sin)(2 pi u2) with numpy's libm — NOT the library's table-driven functions, so
+    the normals agree with the library's to a few ulp only and trajectories to ~1e-12, while accept decisions must be identical;
+  * iterate!(job, MH | MALA | HMC | SliceSampler, Multivariate): src/samplers/iterate/{MH.jl:72-124, MALA.jl:78-128, HMC.jl:124-201,
+    SliceSampler.jl:60-109}, leapfrog! samplers.jl:122-134, hamiltonian samplers.jl:103;
+  * the tuning block iterate/MALA.jl:130-152 / HMC.jl:203-224 with tuners.jl:27-32 and AcceptanceRateMCTuner.jl:9,46;
+  * the save rule BasicMCJob.jl:219-238 with BasicMCRange.jl:17-36, mean(chain) stats/mean.jl:7-11;
+  * the targets: README.md:23,155 (-dot(z,z)), the MvNormal closures of test/BasicContMuvParameter.jl, the swiss logistic regression
+    doc/examples/swiss/MALA/analytical.jl:11-18, and the builder-defined dense Gaussian.
+"""
+import math
+
+import numpy as np
+
+M32 = 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------ counter stream
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    for _ in range(10):
+        p0 = 0xD2511F53 * c0
+        p1 = 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & M32, p1 & M32, ((p0 >> 32) ^ c3 ^ k1) & M32, p0 & M32
+        k0 = (k0 + 0x9E3779B9) & M32
+        k1 = (k1 + 0xBB67AE85) & M32
+    return c0, c1, c2, c3
+
+
+def stream_block(seed, chain, transition, slot):
+    blk = ((transition << 24) | slot) & 0xFFFFFFFFFFFFFFFF
+    return philox4x32_10(blk & M32, blk >> 32, chain & M32, (chain >> 32) & M32, seed & M32, (seed >> 32) & M32)
+
+
+def u52(hi, lo):
+    m = (hi << 20) | (lo >> 12)
+    return (m + 0.5) * 2.0 ** -52
+
+
+def normals(seed, chain, t, D):
+    """z[i], i < D: pair i >> 1 of the transition, cosine half for even i, sine half for odd i"""
+    z = np.empty(D)
+    for s in range((D + 1) // 2):
+        x, y, zz, w = stream_block(seed, chain, t, s)
+        r = math.sqrt(-2.0 * math.log(u52(x, y)))
+        a = 2.0 * math.pi * u52(zz, w)
+        z[2 * s] = r * math.cos(a)
+        if 2 * s + 1 < D:
+            z[2 * s + 1] = r * math.sin(a)
+    return z
+
+
+def accept_uniform(seed, chain, t, D):
+    x, y, _, _ = stream_block(seed, chain, t, (D + 1) // 2)
+    return u52(x, y)
+
+
+INIT_T = (1 << 40) - 1          # transition index "-1": the initial-state stream
+
+
+# ------------------------------------------------------------------ targets: (lt, grad) closures
+def diag_target(w, mu, c):
+    w, mu = np.asarray(w, float), np.asarray(mu, float)
+    return (lambda x: c - float(np.sum(w * (x - mu) ** 2))), (lambda x: -2.0 * w * (x - mu))
+
+
+def dense_target(P, mu, c):
+    P, mu = np.asarray(P, float), np.asarray(mu, float)
+    return (lambda x: c - 0.5 * float((x - mu) @ P @ (x - mu))), (lambda x: -(P @ (x - mu)))
+
+
+def logistic_target(X, y, lam):
+    X, y = np.asarray(X, float), np.asarray(y, float)
+    d = X.shape[1]
+
+    def lt(p):       # analytical.jl:11-16: ploglikelihood + plogprior
+        xp = X @ p
+        return float(xp @ y - np.sum(np.logaddexp(0.0, xp)) - 0.5 * (p @ p / lam + d * math.log(2.0 * math.pi * lam)))
+
+    def grad(p):     # :17-18
+        xp = X @ p
+        return X.T @ (y - 1.0 / (1.0 + np.exp(-xp))) - p / lam
+
+    return lt, grad
+
+
+# ------------------------------------------------------------------ one chain of one job
+class Chain:
+    def __init__(self, sampler, lt, grad, x0, seed, chain_id, *, sigma=None, driftstep=None, leapstep=None, nleaps=None,
+                 widths=None, stepout=True, tuner="vanilla", verbose=False, targetrate=None, period=100, score_k=7.0,
+                 nsteps=0, burnin=0, thinning=1):
+        self.sampler, self.ltf, self.gradf = sampler, lt, grad
+        self.x = np.array(x0, float)
+        self.D = self.x.size
+        self.seed, self.cid = seed, chain_id
+        self.sigma, self.widths, self.stepout = sigma, widths, stepout
+        self.nleaps = nleaps
+        self.tuner, self.verbose, self.targetrate, self.period, self.score_k = tuner, verbose, targetrate, period, score_k
+        self.nsteps, self.burnin, self.thinning = nsteps, burnin, thinning
+        # initialize!: MH.jl:72-85, MALA.jl:76-90, HMC.jl:106-120, SliceSampler.jl:40-48
+        self.lt = self.ltf(self.x)
+        assert math.isfinite(self.lt)
+        self.g = self.gradf(self.x) if sampler in ("mala", "hmc") else None
+        # tuner_state: samplers.jl:29-45 — MH's step is 1.0 and never read; totproposed starts at the period
+        # (the slice sampler falls to the generic tuner_state: BasicMCTune(NaN, 0, 0, period), samplers.jl:29)
+        self.step = {"mh": 1.0, "mala": driftstep, "hmc": leapstep, "slice": float("nan")}[sampler]
+        self.accepted, self.proposed, self.totproposed = 0, 0, period
+        self.t = 0
+        self.accepts, self.saved = [], []
+
+    def _cnt(self):
+        if self.sampler in ("mh", "slice"):
+            return self.verbose                                   # iterate/MH.jl:73-75, SliceSampler.jl:61-63
+        return (self.tuner == "vanilla" and self.verbose) or self.tuner == "rate"      # iterate/MALA.jl:79, HMC.jl:125-127
+
+    def _mh(self, t):                                             # iterate/MH.jl:72-124
+        xp = self.x + self.sigma * normals(self.seed, self.cid, t, self.D)          # :79
+        ltp = self.ltf(xp)                                                           # :81
+        ratio = ltp - self.lt                                                        # :83
+        acc = ratio > 0 or ratio > math.log(accept_uniform(self.seed, self.cid, t, self.D))     # :97
+        if acc:
+            self.x, self.lt = xp, ltp
+        return acc
+
+    def _mala(self, t):                                           # iterate/MALA.jl:78-128
+        h = self.step
+        mu = self.x + 0.5 * h * self.g                                               # :83
+        xp = mu + math.sqrt(h) * normals(self.seed, self.cid, t, self.D)             # :84
+        ltp, gp = self.ltf(xp), self.gradf(xp)                                       # :86
+        ratio = ltp - self.lt                                                        # :88
+        ratio += float(np.sum(0.5 * ((mu - xp) ** 2 / h)))                           # :90
+        mup = xp + 0.5 * h * gp                                                      # :91
+        ratio -= float(np.sum(0.5 * ((mup - self.x) ** 2 / h)))                      # :92
+        acc = ratio > 0 or ratio > math.log(accept_uniform(self.seed, self.cid, t, self.D))     # :94
+        if acc:
+            self.x, self.g, self.lt = xp, gp, ltp
+        return acc
+
+    def _hmc(self, t):                                            # iterate/HMC.jl:124-201
+        eps = self.step
+        p = normals(self.seed, self.cid, t, self.D)                                  # :135
+        h0 = self.lt - 0.5 * float(p @ p)                                            # :137, samplers.jl:103
+        xp, gp = self.x.copy(), self.g.copy()
+        for _ in range(self.nleaps):                                                 # :146-155, samplers.jl:122-134
+            p = p + 0.5 * eps * gp
+            xp = xp + eps * p
+            gp = self.gradf(xp)
+            p = p + 0.5 * eps * gp
+        ltp = self.ltf(xp)                                                           # :157
+        h1 = ltp - 0.5 * float(p @ p)                                                # :159
+        d = h1 - h0
+        a = 1.0 if d >= 0 else math.exp(d)                                           # :163  min(1, exp(ratio))
+        acc = accept_uniform(self.seed, self.cid, t, self.D) < a                     # :165  rand() always drawn
+        if acc:
+            self.x, self.g, self.lt = xp, gp, ltp
+        return acc
+
+    def _slice(self, t):                                          # iterate/SliceSampler.jl:60-109
+        for i in range(self.D):
+            b0 = stream_block(self.seed, self.cid, t, i << 14)
+            logu = math.log(u52(b0[0], b0[1])) + self.lt                             # :66
+            r = u52(b0[2], b0[3])                                                    # :71
+            w, xi = self.widths[i], self.x[i]
+            lo, hi = xi - r * w, xi + (1.0 - r) * w                                  # :72-73
+
+            def at(v):
+                y = self.x.copy(); y[i] = v
+                return self.ltf(y)
+
+            if self.stepout:                                                         # :75-89
+                while at(lo) > logu:
+                    lo -= w
+                while at(hi) > logu:
+                    hi += w
+            a = 1
+            while True:                                                              # :91-106
+                bb = stream_block(self.seed, self.cid, t, (i << 14) | a)
+                cand = u52(bb[0], bb[1]) * (hi - lo) + lo                            # :92-93
+                lc = at(cand)                                                        # :94
+                if lc > logu:
+                    break
+                if cand > xi:
+                    hi = cand
+                elif cand < xi:
+                    lo = cand
+                else:
+                    raise RuntimeError("slice shrunk to the current point")          # :102
+                a += 1
+            self.x[i], self.lt = cand, lc                                            # :108
+        return True
+
+    def run(self, n):
+        for _ in range(n):
+            t = self.t
+            cnt = self._cnt()
+            if cnt:
+                self.proposed += 1
+            acc = {"mh": self._mh, "mala": self._mala, "hmc": self._hmc, "slice": self._slice}[self.sampler](t)
+            if cnt and acc and self.sampler != "slice":
+                self.accepted += 1
+            # burn-in block: iterate/MALA.jl:130-152, HMC.jl:203-224 (rate!, tune!, reset_burnin!); MH.jl:126-140 and
+            # SliceSampler.jl:111-119 have the same block without tune! (their step is never adapted)
+            if cnt and self.totproposed <= self.burnin and self.proposed % self.period == 0:
+                if self.tuner == "rate" and self.sampler in ("mala", "hmc"):
+                    rate = self.accepted / self.proposed                                          # tuners.jl:27-29
+                    self.step *= 2.0 / (1.0 + math.exp(-self.score_k * (rate - self.targetrate)))  # AcceptanceRateMCTuner.jl:9,46
+                self.totproposed += self.proposed
+                self.accepted = self.proposed = 0
+            self.accepts.append(bool(acc))
+            i = t + 1                                                                # the 1-based step index of run(job)
+            if i > self.burnin and (i - self.burnin - 1) % self.thinning == 0 and i <= self.nsteps:    # BasicMCRange.jl:36
+                self.saved.append(self.x.copy())
+            self.t += 1
+
+
+def init_state_normal(seed, chain_id, D):
+    return normals(seed, chain_id, INIT_T, D)
