@@ -93,7 +93,7 @@ def logistic_target(X, y, lam):
 class Chain:
     def __init__(self, sampler, lt, grad, x0, seed, chain_id, *, sigma=None, driftstep=None, leapstep=None, nleaps=None,
                  widths=None, stepout=True, tuner="vanilla", verbose=False, targetrate=None, period=100, score_k=7.0,
-                 nsteps=0, burnin=0, thinning=1):
+                 nsteps=0, burnin=0, thinning=1, nadapt=0, eps0bar=1.0, h0bar=0.0, gamma=0.05, t0=10, kappa=0.75):
         self.sampler, self.ltf, self.gradf = sampler, lt, grad
         self.x = np.array(x0, float)
         self.D = self.x.size
@@ -110,13 +110,19 @@ class Chain:
         # (the slice sampler falls to the generic tuner_state: BasicMCTune(NaN, 0, 0, period), samplers.jl:29)
         self.step = {"mh": 1.0, "mala": driftstep, "hmc": leapstep, "slice": float("nan")}[sampler]
         self.accepted, self.proposed, self.totproposed = 0, 0, period
+        # DualAveragingMCTuner (HMC only): tuner_state HMC.jl:124-133 (lambda = nleaps * leapstep, eps_bar, h_bar), mu = log(10 step)
+        # HMC.jl:209.  (The reference first passes the step through initialize_step!, which cannot run for multivariate parameters —
+        # samplers.jl:195 reads an undefined variable; as in the library, the sampler's leapstep is the starting step.)
+        self.nadapt, self.gamma, self.t0, self.kappa = nadapt, gamma, t0, kappa
+        if tuner == "da":
+            self.lam, self.mu_da, self.epsbar, self.hbar = nleaps * leapstep, math.log(10.0 * leapstep), eps0bar, h0bar
         self.t = 0
         self.accepts, self.saved = [], []
 
     def _cnt(self):
         if self.sampler in ("mh", "slice"):
             return self.verbose                                   # iterate/MH.jl:73-75, SliceSampler.jl:61-63
-        return (self.tuner == "vanilla" and self.verbose) or self.tuner == "rate"      # iterate/MALA.jl:79, HMC.jl:125-127
+        return (self.tuner in ("vanilla", "da") and self.verbose) or self.tuner == "rate"      # iterate/MALA.jl:79, HMC.jl:128-132
 
     def _mh(self, t):                                             # iterate/MH.jl:72-124
         xp = self.x + self.sigma * normals(self.seed, self.cid, t, self.D)          # :79
@@ -146,7 +152,8 @@ class Chain:
         p = normals(self.seed, self.cid, t, self.D)                                  # :135
         h0 = self.lt - 0.5 * float(p @ p)                                            # :137, samplers.jl:103
         xp, gp = self.x.copy(), self.g.copy()
-        for _ in range(self.nleaps):                                                 # :146-155, samplers.jl:122-134
+        nleaps = max(1, int(round(self.lam / eps))) if self.tuner == "da" else self.nleaps     # :142-144 (round: ties to even, as Julia's)
+        for _ in range(nleaps):                                                      # :146-155, samplers.jl:122-134
             p = p + 0.5 * eps * gp
             xp = xp + eps * p
             gp = self.gradf(xp)
@@ -156,6 +163,7 @@ class Chain:
         d = h1 - h0
         a = 1.0 if d >= 0 else math.exp(d)                                           # :163  min(1, exp(ratio))
         acc = accept_uniform(self.seed, self.cid, t, self.D) < a                     # :165  rand() always drawn
+        self.a = a
         if acc:
             self.x, self.g, self.lt = xp, gp, ltp
         return acc
@@ -203,6 +211,25 @@ class Chain:
             acc = {"mh": self._mh, "mala": self._mala, "hmc": self._hmc, "slice": self._slice}[self.sampler](t)
             if cnt and acc and self.sampler != "slice":
                 self.accepted += 1
+            if self.tuner == "da":                                                   # iterate/HMC.jl:225-249
+                count = t + 1                                                        # job.sstate.count, incremented at :125-127
+                if count <= self.nadapt:                                             # tune!: DualAveragingMCTuner.jl:95-101
+                    hw = 1.0 / (count + self.t0)
+                    self.hbar = (1.0 - hw) * self.hbar + hw * (self.targetrate - self.a)
+                    self.step = math.exp(self.mu_da - math.sqrt(count) * self.hbar / self.gamma)
+                    ew = count ** (-self.kappa)
+                    self.epsbar = math.exp((1.0 - ew) * math.log(self.epsbar) + ew * math.log(self.step))
+                    if cnt and self.proposed % self.period == 0:                     # the verbose report: rate!, reset_burnin!
+                        self.totproposed += self.proposed
+                        self.accepted = self.proposed = 0
+                else:
+                    self.step = self.epsbar                                          # :247
+                self.accepts.append(bool(acc))
+                i = t + 1
+                if i > self.burnin and (i - self.burnin - 1) % self.thinning == 0 and i <= self.nsteps:
+                    self.saved.append(self.x.copy())
+                self.t += 1
+                continue
             # burn-in block: iterate/MALA.jl:130-152, HMC.jl:203-224 (rate!, tune!, reset_burnin!); MH.jl:126-140 and
             # SliceSampler.jl:111-119 have the same block without tune! (their step is never adapted)
             if cnt and self.totproposed <= self.burnin and self.proposed % self.period == 0:

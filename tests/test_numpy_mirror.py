@@ -90,6 +90,24 @@ def test_hmc_on_a_diagonal_mvnormal_vanilla():
     _compare(job, chains, 80, 0, 2, True)
 
 
+@pytest.mark.parametrize("verbose", [False, True])
+def test_hmc_with_the_dual_averaging_tuner(verbose):
+    d = 5
+    t = cases.K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.6, 1.6, d))
+    lt, grad = M.diag_target(t.w, t.mu, t.const)
+    kw = dict(nsteps=70, burnin=40, thinning=1)
+    job = O.OracleJob(sampler=L.SAMPLER_HMC, target_kind=L.TARGET_GAUSS_DIAG, nchains=NCHAINS, ndims=d, leapstep=0.25, nleaps=5, gauss_w=t.w, gauss_mu=t.mu,
+                      gauss_const=t.const, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=40, verbose=verbose, period=10,
+                      seed=SEED, chain_offset=OFFSET, **kw)
+    x0 = np.random.default_rng(9).standard_normal((NCHAINS, d))
+    assert job.set_state(x0) == 0
+    chains = [M.Chain("hmc", lt, grad, x0[k], SEED, OFFSET + k, leapstep=0.25, nleaps=5, tuner="da", targetrate=0.65, nadapt=40, verbose=verbose,
+                      period=10, **kw) for k in range(NCHAINS)]
+    _compare(job, chains, 70, 40, 1, True)
+    for k, c in enumerate(chains):
+        assert job.da_epsbar[k] == pytest.approx(c.epsbar, rel=1e-10) and job.da_hbar[k] == pytest.approx(c.hbar, rel=1e-9, abs=1e-12)
+
+
 @pytest.mark.parametrize("stepout", [True, False])
 def test_slice_sampler(stepout):
     d = 3
