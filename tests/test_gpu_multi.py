@@ -88,3 +88,30 @@ def test_sharded_job_and_rccl_summary_gather_through_the_c_abi():
         assert np.allclose(gs, s, rtol=1e-12, atol=1e-9) and np.allclose(gq, q, rtol=1e-12), rank                # gathered sums, every rank
         assert counts == (na, nt, nsaved * NCHAINS, NCHAINS), (rank, counts)
     ref.close()
+
+
+def test_bench_two_ranks_on_one_device_logic():
+    """`bench.py --gpus 2` the way the driver launches it (python -m torch.distributed.run, one process per rank), on ONE device with the
+    gloo backend (`--same-device`: RCCL refuses two ranks on one GPU) — the rank / shard / barrier / max-over-ranks / summary all-reduce
+    logic of the multi-GPU path, runnable on a one-GPU box: rank 0 prints one JSON line for both ranks' chains."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(root / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--reps", "3", "--backend", "gloo", "--same-device",
+           "--no-extra", "--no-cpu-baseline", "--clock-warmup", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["nchains_total"] == 2 * d["config"]["nchains_per_gpu"] and d["config"]["rccl_ranks_seen"] == 2
+    assert d["value"] == pytest.approx(d["config"]["nchains_total"] * 20 / (d["ms_per_step"] * 20e-3), rel=1e-9)
+    assert d["roofline"]["bound"] == "valu" and "cpu_baseline" not in d
