@@ -34,6 +34,9 @@
 #ifndef KLARA_E4_WAVES_LOGISTIC
 #define KLARA_E4_WAVES_LOGISTIC 4
 #endif
+#ifndef KLARA_E4_WAVES_LOGISTIC_HMC
+#define KLARA_E4_WAVES_LOGISTIC_HMC 4   /* swiss HMC L = 10: 1.97e9 against 1.83e9 leapfrog*chain/s with running sums, same box */
+#endif
 #ifndef KLARA_E4_WAVES_PLAIN
 #define KLARA_E4_WAVES_PLAIN 3   // the specialised (no tuner, no monitor) E=4 kernels fit 168 VGPRs
 #endif
@@ -934,10 +937,11 @@ __device__ __forceinline__ void set_chain(const KParams& p, LaneCtx<E>& c, long 
 // MODE bit 0 (PLAIN): nothing counts / tunes.  MODE bit 1 (NOMON): no monitor at all (no accept mask, running sums or
 // history) — the save-rule bookkeeping disappears from the generated code.
 template <int SAMPLER, int TARGET, int E, int GT, int MODE>
-// (MALA on the logistic target at E = 4 — cfg 4 — asks for 4 wavefronts per SIMD: its row loop is a chain of exp / log / division latencies that two
+// (MALA and HMC on the logistic target at E = 4 — cfg 4 — ask for 4 wavefronts per SIMD: its row loop is a chain of exp / log / division latencies that two
 //  wavefronts cannot cover; the 128-register budget spills 156-272 B outside the row loop and still measured 1.01e9 against 8.1e8
 //  transitions/s with running sums, 1.05e9 against 9.4e8 without, same box)
 __global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? (TARGET == KLARA_TARGET_LOGISTIC && SAMPLER == KLARA_SAMPLER_MALA ? KLARA_E4_WAVES_LOGISTIC
+                                                                  : TARGET == KLARA_TARGET_LOGISTIC && SAMPLER == KLARA_SAMPLER_HMC ? KLARA_E4_WAVES_LOGISTIC_HMC
                                                                   : ((MODE & 3) == 3 ? KLARA_E4_WAVES_PLAIN : KLARA_E4_WAVES)) : 1)))
 void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 {
