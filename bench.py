@@ -336,6 +336,17 @@ def extra_measurements(K, L, n, stream):
     lay = e.layout(); e.close()
     ex["mala_one_transition_per_launch_roofline"] = valu_roofline(diagt_kernel_name(1, lay[1], lay[2], True, True, False), ls, grid=diagt_grid(n, lay[1]))
 
+    # -- cfg 1: the README job (README.md:23-47: MH, sigma = (1, 1), lt = -dot(z, z), D = 2, burn-in 1000, x0 = (5.1, -0.9)) as 1,048,576
+    # replicas — one chain per lane — with the running sums of mean(chain) on
+    nr = 1 << 20
+    e = K.Engine(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(2), nchains=nr, nsteps=10 ** 7, burnin=1000, mh_sigma=[1.0, 1.0],
+                 monitor=L.MON_SUMMARIES, stream=stream, nstreams=1)
+    e.set_state(np.tile([5.1, -0.9], (nr, 1)))
+    rate, ls, _ = timed_rate(e, nr, 1024, 2048)
+    e.close()
+    ex["cfg1_readme_mh_1048576_replicas_transitions_per_s"] = rate
+    ex["cfg1_roofline"] = valu_roofline("k_transitions<0, 0, 2, 0, 1>", ls)
+
     # -- HMC L=10 eps=0.1 on the README target (VALU) and on the dense target (FP64 MFMA; cfg 3)
     e = K.Engine(sampler=L.SAMPLER_HMC, target=neg, nchains=n, nsteps=10 ** 7, leapstep=0.1, nleaps=10, stream=stream, nstreams=1)
     e.init_state_normal()
