@@ -186,6 +186,34 @@ def test_bench_and_smoke_refuse_to_run_without_a_gpu():
     assert r.returncode != 0 and "KlaraError" in r.stderr
 
 
+def test_committed_bench_lines_are_complete_and_recomputable():
+    """profiles/r2_bench_*.json are the JSON lines bench.py printed on the GPU box: the driver's keys, a roofline whose fraction can be
+    recomputed from the committed PMC summary (SQ_ACTIVE_INST_VALU x 4 / 1,024 SIMDs / (launch duration x 2.4 GHz)) and does not exceed 1,
+    the HBM side with traffic >= the minimum, a {bound, frac} object for every other configuration, and the CPU baseline."""
+    import json
+    pmc = json.loads((ROOT / "profiles" / "r2_pmc_kernels.json").read_text())
+    rows = {(r["kernel"], r.get("grid")): r["counters"] for r in pmc["kernels"]}
+    for name in ("r2_bench_default.json", "r2_bench_driver_flags.json"):
+        d = json.loads((ROOT / "profiles" / name).read_text())
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert k in d, (name, k)
+        assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and d["unit"] == "transitions/s"
+        assert d["value"] == pytest.approx(d["config"]["nchains_total"] * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3), rel=1e-9)
+        rf = d["roofline"]
+        assert rf["bound"] == "valu" and 0.5 < rf["frac"] <= 1.0
+        c = next(v for (kn, g), v in rows.items() if kn == rf["pmc_kernel"] and g == 262144)
+        assert rf["frac"] == pytest.approx(4.0 * c["SQ_ACTIVE_INST_VALU"]["mean"] / 1024 / (rf["launch_us"] * 1e-6 * 2.4e9), rel=1e-6)
+        h = rf["hbm"]
+        assert h["traffic_bytes_per_launch"] >= h["minimal_bytes_per_launch"] and h["traffic_over_minimal"] < 1.25 and h["traffic_frac_of_8TBs"] < 0.1
+        ex = d["extra"]
+        for key in ("cfg1_roofline", "cfg3_hmc_dense_roofline", "cfg4_roofline", "cfg5_roofline", "hmc_iso_roofline", "slice_d100_roofline",
+                    "mala_one_transition_per_launch_roofline"):
+            assert ex[key]["bound"] in ("valu", "mfma") and ex[key]["frac"] is not None and 0.3 < ex[key]["frac"] <= 1.0, (name, key, ex[key])
+        assert ex["cfg3_hmc_dense_leapfrog_chain_per_s"] >= 1e8                       # north_star's HMC target
+        cb = d["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and d["value"] / cb["value"] > 10
+
+
 def test_basic_mc_range():
     r = K.BasicMCRange(nsteps=10000, burnin=1000)
     assert (r.nsteps, r.burnin, r.thinning, r.npoststeps) == (10000, 1000, 1, 9000)
