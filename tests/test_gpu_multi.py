@@ -115,3 +115,24 @@ def test_bench_two_ranks_on_one_device_logic():
     assert d["config"]["nchains_total"] == 2 * d["config"]["nchains_per_gpu"] and d["config"]["rccl_ranks_seen"] == 2
     assert d["value"] == pytest.approx(d["config"]["nchains_total"] * 20 / (d["ms_per_step"] * 20e-3), rel=1e-9)
     assert d["roofline"]["bound"] == "valu" and "cpu_baseline" not in d
+
+
+def test_bench_single_gpu_line_at_the_drivers_flags():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` as the driver runs it (extras and CPU baseline off to keep the test short): one JSON
+    line, the contract's keys, value = chains x steps / time, a VALU roofline below 1 whose launch duration was measured in this run."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extra", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["higher_is_better"], d["vs_baseline"], d["dtype"]) == (1, 20, 5, True, None, "f64")
+    assert d["value"] == pytest.approx(65536 * 20 / (d["ms_per_step"] * 20e-3), rel=1e-9) and d["value"] > 1e9
+    assert d["config"]["steps_per_launch"] == 32 and d["config"]["save_rule"].startswith("running sums")
+    rf = d["roofline"]
+    assert rf["bound"] == "valu" and 0.5 < rf["frac"] <= 1.0 and 300 < rf["launch_us"] < 700
