@@ -760,9 +760,9 @@ def _random_case(seed):
     return c, rng
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("KLARA_RANDOM_CASES", "96"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KLARA_RANDOM_FIRST", "0")), int(os.environ.get("KLARA_RANDOM_FIRST", "0")) + int(os.environ.get("KLARA_RANDOM_CASES", "96"))))
 def test_random_configurations(seed):
-    """96 jobs (KLARA_RANDOM_CASES overrides the count) drawn at random from the accepted configuration space, run in randomly sized pieces with a random number of
+    """96 jobs (KLARA_RANDOM_CASES overrides the count, KLARA_RANDOM_FIRST the first seed) drawn at random from the accepted configuration space, run in randomly sized pieces with a random number of
     transitions per launch and every monitor on: accept mask, state, sums, tuner state and one chain's full history must
     equal the oracle's bit for bit."""
     c, rng = _random_case(seed)
