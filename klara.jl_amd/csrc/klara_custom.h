@@ -8,8 +8,8 @@
 //
 // in the C subset both hipcc and a host C compiler accept (KLARA_D is predefined to the job's dimension so that loops
 // unroll and x / g stay in registers; kd_exp, kd_log, kd_fma, kd_erf and IEEE + - * / sqrt are bit-reproducible on host and
-// device, libm calls are not).  One chain per lane (G = 1, E = pow2ceil(D) <= 256 elements: in registers up to 32, in scratch beyond — a
-// D = 200 job compiles for half a minute per kernel mode and is cached on disk), so the user's
+// device, libm calls are not).  One chain per lane (G = 1, E = pow2ceil(D) <= 256 elements: in registers up to 32, in scratch beyond; above 128 elements
+// the element loops are not unrolled, klara_jit.hip), so the user's
 // function sees the whole parameter vector and no cross-lane reduction exists; `data` is the job's read-only block
 // (klara_desc.custom_data) in device memory.
 //
@@ -41,11 +41,11 @@ struct CustomTarget {
         if (WANT_LT) ltpart = klara_user_logtarget(x, D, data, ndata);
         if (WANT_GRAD) {
 #ifdef KLARA_CUSTOM_NOGRAD                                           // MH / slice sampler: no gradient closure is required
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) g[e] = 0.0;
 #else
             klara_user_gradlogtarget(x, D, data, ndata, g);
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) if (e >= D) g[e] = 0.0;     // padding elements stay exactly zero
 #endif
         }

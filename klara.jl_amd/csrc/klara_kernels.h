@@ -31,6 +31,13 @@
 #ifndef KLARA_LOGIT_UNROLL
 #define KLARA_LOGIT_UNROLL 4
 #endif
+// Loops over a lane's E elements are fully unrolled (the element arrays are registers).  The run-time compiled closure kernels with
+// 256 elements per lane define this to "nounroll" (klara_jit.hip): unrolled, such a kernel takes half a minute to compile per mode
+// (tens of thousands of instructions, 512 registers, one wavefront per SIMD) for 12 % more throughput than the loop form over
+// scratch-resident arrays, which compiles in a second.
+#ifndef KLARA_PRAGMA_UNROLL_E
+#define KLARA_PRAGMA_UNROLL_E _Pragma("unroll")
+#endif
 #ifndef KLARA_E4_WAVES_LOGISTIC
 #define KLARA_E4_WAVES_LOGISTIC 4
 #endif
@@ -143,27 +150,27 @@ template <int N>
 __device__ __forceinline__ void group_allreduce(double (&v)[N], int G, int lane)
 {
     if (G > 1) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_mov<0xB1>(v[i]);    // quad_perm [1,0,3,2]
     }
     if (G > 2) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_mov<0x4E>(v[i]);    // quad_perm [2,3,0,1]
     }
     if (G > 4) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_mov<0x141>(v[i]);   // row_half_mirror
     }
     if (G > 8) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int i = 0; i < N; ++i) v[i] = v[i] + dpp_mov<0x140>(v[i]);   // row_mirror
     }
     if (G > 16) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int i = 0; i < N; ++i) v[i] = v[i] + bperm_xor(v[i], lane, 16);
     }
     if (G > 32) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int i = 0; i < N; ++i) v[i] = v[i] + bperm_xor(v[i], lane, 32);
     }
 }
@@ -201,7 +208,7 @@ __device__ __forceinline__ LaneCtx<E> make_ctx(const KParams& p)
     c.chain = wave * (64 / (G * c.RS)) + grp;
     c.chain_ok = c.chain < p.nchains;
     c.i0 = E * c.q;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) c.valid[e] = c.chain_ok && (c.i0 + e < p.D);
     c.voff0 = (unsigned)((grp * p.D + c.i0) * 8);
     c.aligned = (p.D % E) == 0;
@@ -216,7 +223,7 @@ __device__ __forceinline__ void load_vec(const LaneCtx<E>& c, const gdouble* bas
     // out-of-range lanes read element 0 of a valid row (always in bounds) and discard it: a select
     // instead of an exec-masked branch per element
     const gdouble* row = base + (c.chain_ok ? c.chain : 0) * D;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) {
         const double t = row[c.valid[e] ? c.i0 + e : 0];
         v[e] = c.valid[e] ? t : 0.0;
@@ -226,7 +233,7 @@ template <int E>
 __device__ __forceinline__ void store_vec(const LaneCtx<E>& c, gdouble* base, int D, const double (&v)[E])
 {
     gdouble* row = base + c.chain * D + c.i0;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) if (c.valid[e] && c.rq == 0) row[e] = v[e];
 }
 template <int E>
@@ -235,11 +242,11 @@ __device__ __forceinline__ void load_param(const LaneCtx<E>& c, const gdouble* b
 {
     // (branch-free: E conditional loads are E basic blocks, and at E = 128 the compiler spent two minutes on them)
     if (base == nullptr) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) v[e] = dflt;
         return;
     }
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) {
         const int i = c.i0 + e;
         const double t = base[i < D ? i : D - 1];
@@ -272,14 +279,14 @@ __device__ __forceinline__ void load_win(const LaneCtx<E>& c, __amdgpu_buffer_rs
 {
     if (c.aligned) {
         const unsigned o = c.i0 < D ? c.voff0 : KLARA_BUF_OOB;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; e += 2) {
             const kd_uint4 t = __builtin_amdgcn_raw_buffer_load_b128(w, o + 8u * (unsigned)e, 0, 0);
             v[e] = __builtin_bit_cast(double, kd_uint2{ t.x, t.y });
             v[e + 1] = __builtin_bit_cast(double, kd_uint2{ t.z, t.w });
         }
     } else {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e)
             v[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(w, elem_off<E>(c, D, e, false), 0, 0));
     }
@@ -289,13 +296,13 @@ __device__ __forceinline__ void store_win(const LaneCtx<E>& c, __amdgpu_buffer_r
 {
     if (c.aligned) {
         const unsigned o = (c.i0 < D && c.rq == 0) ? c.voff0 : KLARA_BUF_OOB;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; e += 2) {
             const kd_uint2 a = __builtin_bit_cast(kd_uint2, v[e]), b = __builtin_bit_cast(kd_uint2, v[e + 1]);
             __builtin_amdgcn_raw_buffer_store_b128(kd_uint4{ a.x, a.y, b.x, b.y }, w, o + 8u * (unsigned)e, 0, 0);
         }
     } else {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e)
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, v[e]), w, elem_off<E>(c, D, e, true), 0, 0);
     }
@@ -315,7 +322,7 @@ __device__ __forceinline__ void lane_normals(const LaneCtx<E>& c, unsigned long 
                                              double (&z)[E], AccDraw& ad, int acc_slot)
 {
     static_assert(E % 2 == 0, "E must be even");
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int j = 0; j < E / 2; ++j) {
         const kd_u32x4 b = kd_stream_block(seed, gchain, t, (uint32_t)((c.i0 >> 1) + j));
         double z0, z1, u1, lg1;
@@ -350,7 +357,7 @@ struct DiagTarget {
                                          double (&g)[E]) const
     {
         double acc = 0.0;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) {
             const double dd = x[e] - mu[e];
             if (WANT_LT) acc = acc + w[e] * (dd * dd);   // padding lanes hold x = mu = 0: the term is exactly 0
@@ -389,17 +396,17 @@ struct LogisticTarget {
         // rows r = rq, rq + RS, ... of the design matrix belong to this lane (RS = 1: all of them); the RS lane
         // partials are combined by one xor butterfly below (the oracle sums in the same order, layout kind 2)
         double dotxy = 0.0, slog = 0.0, gacc[E];
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) gacc[e] = 0.0;
         // rows are independent until the accumulations: unrolling lets two rows' exp/log chains interleave (the kernel runs
         // at 2 wavefronts per SIMD for cfg 4's per-GPU share, so dependent-issue latency is otherwise exposed)
 #pragma unroll KLARA_LOGIT_UNROLL
         for (int r = cx.rq; r < ndata; r += cx.RS) {
             double row[E];
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) row[e] = sX[r * E + e];
             double xp = 0.0;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) xp = kd_fma(row[e], x[e], xp);            // Xp = v[2]*p
             const double yr = sy[r];
             double sp, lg;
@@ -410,30 +417,30 @@ struct LogisticTarget {
             }
             if (WANT_GRAD) {
                 const double res = yr - lg;                                       // v[3]-1./(1+exp(-Xp))
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
                 for (int e = 0; e < E; ++e) gacc[e] = kd_fma(row[e], res, gacc[e]);
             }
         }
         if (cx.RS > 1) {
             double red[E + 2];
             red[0] = dotxy; red[1] = slog;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) red[2 + e] = gacc[e];
             group_allreduce<E + 2>(red, cx.RS, cx.lane);
             dotxy = red[0]; slog = red[1];
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) gacc[e] = red[2 + e];
         }
         if (WANT_LT) {
             double dotpp = 0.0;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) dotpp = dotpp + x[e] * x[e];
             const double ll = dotxy - slog;
             const double lp = -0.5 * (dotpp / lambda + lpconst);                  // plogprior
             ltpart = ll + lp;
         }
         if (WANT_GRAD) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) g[e] = gacc[e] - x[e] / lambda;           // -p/v[1]
         }
     }
@@ -456,11 +463,11 @@ struct HierTarget {
     __device__ __forceinline__ void init(const KParams& p, const LaneCtx<E>& cx, double*)
     {
         R = p.hR; T = p.hT; p0 = p.hp0; a0 = p.ha0; b0 = p.hb0; i0 = cx.i0;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int k = 0; k < 5; ++k) { hl[k] = (2 * R + k) / E; he[k] = (2 * R + k) % E; }
         X1 = 0.0; X2 = 0.0; Td = (double)T;
         for (int j = 0; j < T; ++j) { const double xj = p.hxc[j]; X1 = X1 + xj; X2 = kd_fma(xj, xj, X2); }
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int pr = 0; pr < E / 2; ++pr) {
             const int ia = i0 + 2 * pr;
             const int rat = ia < 2 * R ? (ia >> 1) : 0;
@@ -479,10 +486,10 @@ struct HierTarget {
         const int gb = cx.lane - cx.q;
         // hyper-parameters: a_c, b_c, s_c, s_a, s_b
         double hv[5];
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int k = 0; k < 5; ++k) {
             double v = 0.0;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) if (e == he[k]) v = x[e];
             hv[k] = (cx.G > 1) ? lane_bcast(v, gb + hl[k]) : v;
         }
@@ -496,7 +503,7 @@ struct HierTarget {
             wc = kd_exp(-2.0 * sc); wa = kd_exp(-2.0 * sa); wb = kd_exp(-2.0 * sb);
         }
         double red[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };     // A1, B1, A2, B2, C2 lane partials
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int pr = 0; pr < E / 2; ++pr) {
             const int ia = i0 + 2 * pr;                  // element index of a_i; the rat is ia >> 1
             const bool israt = ia < 2 * R;
@@ -522,7 +529,7 @@ struct HierTarget {
         const double A1 = red[0], B1 = red[1], A2 = red[2], B2 = red[3], C2 = red[4];
         const double RT = (double)R * (double)T, Rd = (double)R;
         if (WANT_GRAD) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) {
                 const int i = i0 + e;
                 if (i == 2 * R) g[e] = wa * A1 - p0 * ac;
@@ -661,7 +668,7 @@ __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const Lan
                                         double (&x)[E], double& lt, Proposal<E>& prop)
 {
     double xp[E], gd[E], red[1];
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) xp[e] = x[e] + sigma[e] * z[e];                       // MH.jl:79
     tg.template eval<true, false>(cx, xp, red[0], gd);                                // :81
     group_allreduce<1>(red, cx.G, cx.lane);
@@ -670,11 +677,11 @@ __device__ __forceinline__ bool step_mh(const KParams& p, const T& tg, const Lan
     bool acc = ratio > 0.0;                                                           // :97
     acc = accept_log_test<E>(p, cx, gchain, t, ad, acc, ratio);
     if (!COMMIT) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) prop.x[e] = xp[e];
         prop.lt = ltp;
     } else if (acc) {                                                                 // :98-100
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) x[e] = xp[e];
         lt = ltp;
     }
@@ -695,13 +702,13 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
     // of 2 per element (a division is ~70 issue cycles per wave on gfx950); the oracle does the same.
     const double inv_h = KCNT ? 1.0 / h : p.inv_step0;
     const double half_inv_h = 0.5 * inv_h;                           // 0.5*(abs2(.)*inv_h) == abs2(.)*(0.5*inv_h): halving is exact
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) mu[e] = x[e] + halfh * g[e];                          // :83
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) xp[e] = mu[e] + sq * z[e];                            // :84
     tg.template eval<true, true>(cx, xp, red[0], gp);                                 // :86
     double s1 = 0.0, s2 = 0.0;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) {
         const double q1 = mu[e] - xp[e];
         s1 = s1 + (q1 * q1) * half_inv_h;                        // :90
@@ -718,11 +725,11 @@ __device__ __forceinline__ bool step_mala(const KParams& p, const T& tg, const L
     bool acc = ratio > 0.0;                                                           // :94
     acc = accept_log_test<E>(p, cx, gchain, t, ad, acc, ratio);
     if (!COMMIT) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) { prop.x[e] = xp[e]; prop.g[e] = gp[e]; }
         prop.lt = ltp;
     } else if (acc) {                                                                 // :95-105
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) { x[e] = xp[e]; g[e] = gp[e]; }
         lt = ltp;
     }
@@ -738,24 +745,24 @@ __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const La
                                          double (&x)[E], double (&g)[E], double& lt, Proposal<E>& prop)
 {
     double mom[E], xp[E], gp[E], red[2], dummy;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) mom[e] = z[e];                                        // :135
     double k0[1] = { 0.0 };
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) k0[0] = k0[0] + mom[e] * mom[e];
     group_allreduce<1>(k0, cx.G, cx.lane);
     const double H0 = lt - 0.5 * k0[0];                                               // :137
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) { xp[e] = x[e]; gp[e] = g[e]; }                       // :139-140
     const double halfe = 0.5 * eps;
     if (!KDA) {
         for (int l = 0; l < p.nleaps; ++l) {                                          // :146-155
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];              // samplers.jl:130
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) xp[e] = xp[e] + eps * mom[e];                 // samplers.jl:131
             tg.template eval<false, true>(cx, xp, dummy, gp);                         // samplers.jl:132
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];              // samplers.jl:133
         }
     } else {
@@ -765,17 +772,17 @@ __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const La
         for (int l = 0; __any(l < nleaps); ++l) {
             const bool go = l < nleaps;
             double mo[E], xo[E], go_[E];
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) { mo[e] = mom[e]; xo[e] = xp[e]; go_[e] = gp[e]; }
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) xp[e] = xp[e] + eps * mom[e];
             tg.template eval<false, true>(cx, xp, dummy, gp);
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];
             if (!go) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
                 for (int e = 0; e < E; ++e) { mom[e] = mo[e]; xp[e] = xo[e]; gp[e] = go_[e]; }
             }
         }
@@ -783,7 +790,7 @@ __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const La
     double gd[E];
     tg.template eval<true, false>(cx, xp, red[0], gd);                                // :157
     double k1 = 0.0;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) k1 = k1 + mom[e] * mom[e];
     red[1] = k1;
     group_allreduce<2>(red, cx.G, cx.lane);
@@ -799,11 +806,11 @@ __device__ __forceinline__ bool step_hmc(const KParams& p, const T& tg, const La
         : kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
     const bool acc = u < a;                                                           // :165
     if (!COMMIT) {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) { prop.x[e] = xp[e]; prop.g[e] = gp[e]; }
         prop.lt = ltp;
     } else if (acc) {                                                                 // :166-176
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) { x[e] = xp[e]; g[e] = gp[e]; }
         lt = ltp;
     }
@@ -826,7 +833,7 @@ __device__ __forceinline__ bool step_slice(const KParams& p, const T& tg, const 
         const bool owner = (cx.q == qo);
         // coordinate value and width, broadcast from the owner lane
         double xi_l = 0.0, w_l = 0.0;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) if (e == eo) { xi_l = x[e]; w_l = widths[e]; }
         const double xi = (cx.G > 1) ? lane_bcast(xi_l, group_base + qo) : xi_l;
         const double w = (cx.G > 1) ? lane_bcast(w_l, group_base + qo) : w_l;
@@ -838,7 +845,7 @@ __device__ __forceinline__ bool step_slice(const KParams& p, const T& tg, const 
         double Ri = xi + (1.0 - ru) * w;                                              // :73
         double tmp[E];
         auto lt_with = [&](double cand) -> double {
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) tmp[e] = (owner && e == eo) ? cand : x[e];
             return eval_lt<T, E>(tg, cx, tmp);
         };
@@ -882,7 +889,7 @@ __device__ __forceinline__ bool step_slice(const KParams& p, const T& tg, const 
         }
         if (!stuck) {
             lt = ltnew;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) if (owner && e == eo) x[e] = xprime;          // :108
         }
     }
@@ -923,7 +930,7 @@ __device__ __forceinline__ void set_chain(const KParams& p, LaneCtx<E>& c, long 
     const int W = RSPL ? c.G * c.RS : c.G;
     c.chain = group_index * (64 / W) + (c.lane / W);
     c.chain_ok = c.chain < p.nchains;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) c.valid[e] = c.chain_ok && (c.i0 + e < p.D);
 }
 
@@ -1043,7 +1050,7 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             else {
                 if (do_sum && held > 0) {                                  // the slice sampler always moves: fold first
                     const double hf = (double)held;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
                     for (int e = 0; e < E; ++e) { sm[e] = sm[e] + hf * cur.x[e]; sq[e] = sq[e] + hf * (cur.x[e] * cur.x[e]); }
                     held = 0;
                 }
@@ -1052,12 +1059,12 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
             if (OUTER) {
                 if (do_sum && acc && held > 0) {                           // leaving a state after `held` saved steps
                     const double hf = (double)held;
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
                     for (int e = 0; e < E; ++e) { sm[e] = sm[e] + hf * cur.x[e]; sq[e] = sq[e] + hf * (cur.x[e] * cur.x[e]); }
                     held = 0;
                 }
                 if (acc) {                                                 // commit (MH.jl:98-100, MALA.jl:95-105, HMC.jl:166-176)
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
                     for (int e = 0; e < E; ++e) { cur.x[e] = prop.x[e]; if (NEEDG) cur.g[e] = prop.g[e]; }
                     cur.lt = prop.lt;
                 }
@@ -1155,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_init(const KParams p, int needgrad)
     bool bad = cx.chain_ok && !kfinite(lt);
     if (needgrad) {
         store_vec<E>(cx, p.GR, p.D, g);
-#pragma unroll
+KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) bad = bad || (cx.valid[e] && !kfinite(g[e]));
     }
     if (cx.chain_ok && cx.q == 0 && cx.rq == 0) p.LT[cx.chain] = lt;

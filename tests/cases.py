@@ -280,8 +280,8 @@ def make_case(name):
                      tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=5)
         else:
             c = dict(sampler=L.SAMPLER_MH, target=t, nchains=23, nsteps=40, burnin=0, mh_sigma=np.full(d, 0.25), x0=x0)
-    elif name == "mh_dense_d130_wide":     # beyond D = 128: the closure form (one chain per lane), with a mean.  (MH: the 256-element
-        rng = np.random.default_rng(130)   #  kernels of the gradient samplers take half a minute each to compile)
+    elif name == "mh_dense_d130_wide":     # beyond D = 128: the closure form (one chain per lane, 256 elements, loops), with a mean
+        rng = np.random.default_rng(130)
         a = rng.standard_normal((130, 130)); p = a @ a.T / 130 + np.eye(130)
         t = K.GaussDenseTarget(p, const=0.5, mu=rng.standard_normal(130))
         c = dict(sampler=L.SAMPLER_MH, target=t, nchains=9, nsteps=12, burnin=2, mh_sigma=np.full(130, 0.08), x0=t.mu[None, :] + rng.standard_normal((9, 130)))
