@@ -280,6 +280,11 @@ def make_case(name):
                      tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=5)
         else:
             c = dict(sampler=L.SAMPLER_MH, target=t, nchains=23, nsteps=40, burnin=0, mh_sigma=np.full(d, 0.25), x0=x0)
+    elif name == "hmc_dense_d130_wide":    # the gradient closure of the wide dense form, no mean
+        rng = np.random.default_rng(131)
+        a = rng.standard_normal((130, 130)); p = a @ a.T / 130 + np.eye(130)
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(p, const=-0.5), nchains=9, nsteps=8, burnin=1, leapstep=0.1, nleaps=3,
+                 x0=rng.standard_normal((9, 130)))
     elif name == "mh_dense_d130_wide":     # beyond D = 128: the closure form (one chain per lane, 256 elements, loops), with a mean
         rng = np.random.default_rng(130)
         a = rng.standard_normal((130, 130)); p = a @ a.T / 130 + np.eye(130)
@@ -462,7 +467,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_rats_dualavg", "mala_d3_tuned_erf", "mala_d1", "hmc_d128_full", "mala_d129", "mh_d512",
              "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg",
              "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "hmc_dense_d100_mean", "mala_dense_d37_mean", "mh_dense_d20_mean",
-             "hmc_dense_d70_mean_dualavg", "slice_dense_d20", "slice_dense_d37_mean", "mh_dense_d130_wide", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
+             "hmc_dense_d70_mean_dualavg", "slice_dense_d20", "slice_dense_d37_mean", "mh_dense_d130_wide", "hmc_dense_d130_wide", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
              "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide", "hmc_logit_d20_wide", "slice_d20_stepout", "mh_rats", "mala_rats_tuned"] + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
              "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
