@@ -63,6 +63,19 @@ def test_mala_with_the_acceptance_rate_tuner_and_thinning():
     _compare(job, chains, 120, 40, 3, True)
 
 
+def test_mala_vanilla_verbose_counts_without_tuning():
+    d = 4
+    lt, grad = M.diag_target(np.ones(d), np.zeros(d), 0.0)
+    kw = dict(nsteps=100, burnin=60, thinning=1)
+    job = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=L.TARGET_GAUSS_DIAG, nchains=NCHAINS, ndims=d, driftstep=0.6, verbose=True, period=8,
+                      seed=SEED, chain_offset=OFFSET, **kw)
+    x0 = np.random.default_rng(12).standard_normal((NCHAINS, d))
+    assert job.set_state(x0) == 0
+    chains = [M.Chain("mala", lt, grad, x0[k], SEED, OFFSET + k, driftstep=0.6, verbose=True, period=8, **kw) for k in range(NCHAINS)]
+    _compare(job, chains, 100, 60, 1, True)
+    assert all(c.step == 0.6 for c in chains)                     # VanillaMCTuner: counters and burn-in reports only
+
+
 def test_hmc_on_the_dense_target_with_a_mean_tuned():
     d = 6
     rng = np.random.default_rng(3)
