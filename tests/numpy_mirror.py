@@ -89,6 +89,40 @@ def logistic_target(X, y, lam):
     return lt, grad
 
 
+def hier_normal_target(Y, xc, prior_prec, ga, gb):
+    """The builder-defined BUGS "Rats" target of BASELINE cfg 5 (include/klara_hip.h KLARA_TARGET_HIER_NORMAL): Y_ij ~ N(a_i + b_i xc_j, s_c^2),
+    a_i ~ N(a_c, s_a^2), b_i ~ N(b_c, s_b^2), a_c, b_c ~ N(0, 1 / prior_prec), 1 / s_k^2 ~ Gamma(ga, gb), in
+    theta = (a_1, b_1, ..., a_R, b_R, a_c, b_c, log s_c, log s_a, log s_b); gradient by hand from the log-density."""
+    Y, xc = np.asarray(Y, float), np.asarray(xc, float)
+    R, T = Y.shape
+
+    def split(v):
+        return v[0:2 * R:2], v[1:2 * R:2], v[2 * R], v[2 * R + 1], v[2 * R + 2], v[2 * R + 3], v[2 * R + 4]
+
+    def lt(v):
+        a, b, ac, bc, sc, sa, sb = split(v)
+        r = Y - a[:, None] - b[:, None] * xc[None, :]
+        wc, wa, wb = math.exp(-2 * sc), math.exp(-2 * sa), math.exp(-2 * sb)
+        return float(-R * T * sc - 0.5 * wc * np.sum(r * r) - R * sa - 0.5 * wa * np.sum((a - ac) ** 2) - R * sb - 0.5 * wb * np.sum((b - bc) ** 2)
+                     - 0.5 * prior_prec * (ac * ac + bc * bc) + sum(-2 * ga * s_ - gb * math.exp(-2 * s_) for s_ in (sc, sa, sb)))
+
+    def grad(v):
+        a, b, ac, bc, sc, sa, sb = split(v)
+        r = Y - a[:, None] - b[:, None] * xc[None, :]
+        wc, wa, wb = math.exp(-2 * sc), math.exp(-2 * sa), math.exp(-2 * sb)
+        g = np.empty_like(v)
+        g[0:2 * R:2] = wc * r.sum(axis=1) - wa * (a - ac)
+        g[1:2 * R:2] = wc * (r * xc[None, :]).sum(axis=1) - wb * (b - bc)
+        g[2 * R] = wa * np.sum(a - ac) - prior_prec * ac
+        g[2 * R + 1] = wb * np.sum(b - bc) - prior_prec * bc
+        g[2 * R + 2] = -R * T + wc * np.sum(r * r) - 2 * ga + 2 * gb * wc
+        g[2 * R + 3] = -R + wa * np.sum((a - ac) ** 2) - 2 * ga + 2 * gb * wa
+        g[2 * R + 4] = -R + wb * np.sum((b - bc) ** 2) - 2 * ga + 2 * gb * wb
+        return g
+
+    return lt, grad
+
+
 # ------------------------------------------------------------------ one chain of one job
 class Chain:
     def __init__(self, sampler, lt, grad, x0, seed, chain_id, *, sigma=None, driftstep=None, leapstep=None, nleaps=None,

@@ -135,6 +135,19 @@ def test_slice_sampler(stepout):
     _compare(job, chains, 40, 5, 1, False)
 
 
+def test_hmc_on_the_rats_hierarchical_model():
+    t = cases.rats_target()
+    lt, grad = M.hier_normal_target(t.Y, t.xc, t.prior_prec, t.gamma_a, t.gamma_b)
+    kw = dict(nsteps=60, burnin=10, thinning=1)
+    job = O.OracleJob(sampler=L.SAMPLER_HMC, target_kind=L.TARGET_HIER_NORMAL, nchains=NCHAINS, ndims=t.ndims, leapstep=0.02, nleaps=8, hier_Y=t.Y, hier_xc=t.xc,
+                      hier_prior_prec=t.prior_prec, hier_gamma_a=t.gamma_a, hier_gamma_b=t.gamma_b, seed=SEED, chain_offset=OFFSET, **kw)
+    x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(13).standard_normal((NCHAINS, t.ndims))
+    assert job.set_state(x0) == 0
+    chains = [M.Chain("hmc", lt, grad, x0[k], SEED, OFFSET + k, leapstep=0.02, nleaps=8, **kw) for k in range(NCHAINS)]
+    _compare(job, chains, 60, 10, 1, True)
+    assert 0.3 < np.mean([np.mean(c.accepts) for c in chains]) < 1.0
+
+
 def test_mala_on_the_swiss_logistic_regression():
     X, y = cases.swiss_data()
     lt, grad = M.logistic_target(X, y, 100.0)
