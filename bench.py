@@ -43,10 +43,8 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s a
 FP64_MFMA_PEAK_TF = 78.6    # FP64 matrix = FP64 vector peak on MI355X
 CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock; 256 CUs x 4 SIMDs
 NSIMD = 1024
-# The workload's chains move rarely: MALA with driftstep 0.9 in 100 dimensions accepts 0.4 % of its proposals at stationarity (1.8 % in the
-# first transitions from N(0, I)).  klara_desc.sparse_moves tells the library so (include/klara_hip.h): running sums are then folded
-# straight into memory when a chain moves instead of living in registers.  `extra` also reports the job without the hint.
-SPARSE = True
+# How the running sums of a moving chain are kept (4-lane kernels + atomic folds, or 8-lane kernels + resident sums) is decided by the
+# library itself, on the device, launch by launch (klara_desc.sparse_moves = 0): no caller hint.
 PMC_JSON = ROOT / "profiles" / "r2_pmc_kernels.json"
 PMC_EXPECT = {}             # filled by main(): the launch length the committed counters must have been collected at
 
@@ -150,7 +148,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     eng = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=total_steps,
                    burnin=0, driftstep=0.9, seed=20260927, chain_offset=offset, device=local_rank,
-                   monitor=monitor, steps_per_launch=spl, stream=stream, nstreams=args.streams, sparse_moves=SPARSE)
+                   monitor=monitor, steps_per_launch=spl, stream=stream, nstreams=args.streams)
     eng.init_state_normal()
 
     def barrier():
@@ -170,7 +168,7 @@ def main():
     if args.clock_warmup > 0:
         scratch = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=10 ** 7, burnin=0,
                            driftstep=0.9, seed=1, chain_offset=offset, device=local_rank, monitor=monitor, steps_per_launch=spl,
-                           stream=stream, nstreams=args.streams, sparse_moves=SPARSE)
+                           stream=stream, nstreams=args.streams)
         scratch.init_state_normal()
         scratch.run(args.clock_warmup)          # (closed after the timed repetitions: freeing memory would idle the device again)
     times, kernel_ms_per_step, summ = [], [], None
@@ -200,6 +198,7 @@ def main():
         dist.barrier()
     gather_ms = (time.perf_counter() - t0) * 1e3
     lay_kind, lay_g, lay_e = eng.layout()
+    launch_counts = eng.launch_modes()[0] if hasattr(L.load(), 'klara_get_launch_modes') else [0, 0, 0]
     acc_rate = float(summ["acceptance"]) if summ is not None and "acceptance" in summ else None
     ranks_seen = int(round(float(summ["nsamples"]) / max(1, (args.warmup + args.reps * args.steps) * n))) if (summ is not None and monitor) else world
 
@@ -217,7 +216,8 @@ def main():
                                    "BASELINE configs[1] without the save rule: MALA driftstep=0.9, lt=-|x|^2, D=100, VanillaMCTuner, x0~N(0,I)",
                        "nchains_per_gpu": n, "nchains_total": n_total, "ndims": NDIMS, "steps_per_launch": spl,
                        "save_rule": "running sums (KLARA_MON_SUMMARIES), burnin 0, thinning 1" if monitor else "off",
-                       "sparse_moves_hint": SPARSE,
+                       "running_sums_mode": "decided by the library on the device, launch by launch (no caller hint)",
+                       "launches_4lane_8lane_device_decided": [int(v) for v in launch_counts],
                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective; summaries pooled on device"
                                       + (" and all-reduced over RCCL" if world > 1 else ""),
                        "streams": "library default (2 chain partitions on 2 HIP streams)" if args.streams == 0 else args.streams,
@@ -225,7 +225,8 @@ def main():
                        "repetition_ms_per_step": [t_ * 1e3 / args.steps for t_ in times],
                        "acceptance_rate": acc_rate, "rccl_ranks_seen": ranks_seen, "summary_gather_ms": gather_ms,
                        "device_clock_warmup": f"{args.clock_warmup} transitions of an identical scratch job before the timed repetitions" if args.clock_warmup > 0 else "off",
-                       "timed_region_kernel_ms_per_step": statistics.median(kernel_ms_per_step)},
+                       "timed_region_kernel_ms_per_step": statistics.median(kernel_ms_per_step),
+                       "repetition_kernel_ms_per_step": kernel_ms_per_step},
         }
     eng.close()
 
@@ -266,12 +267,15 @@ def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
     region overlaps two half-size launches on two streams, which says nothing about a single launch)."""
     e = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(NDIMS), nchains=n, nsteps=10 ** 7, burnin=0,
                  driftstep=0.9, seed=20260927, chain_offset=offset, device=local_rank, monitor=monitor, steps_per_launch=spl,
-                 stream=stream, nstreams=1, sparse_moves=SPARSE)
+                 stream=stream, nstreams=1)
     e.init_state_normal()
     launch_s, nlaunch = launch_duration(e, spl, nlaunch=64 if spl > 1 else 256)
     lay_kind, lay_g, lay_e = e.layout()
     _, _, nacc, ntr, _ = e.pooled_summaries(with_sums=False)
+    cnt, last_mode, _ = e.launch_modes() if hasattr(L.load(), 'klara_get_launch_modes') else (None, [0], None)
     e.close()
+    if lay_kind == 3 and (not monitor or last_mode[0] == 0):        # the 4-lane kernels ran (they sum in the layout's 8-lane order)
+        lay_g, lay_e = 4, 2 * ((NDIMS + 7) // 8)
     if lay_kind == 3:
         kname = diagt_kernel_name(1, lay_g, lay_e, spl == 1 and not monitor, True, bool(monitor))
         label = (f"{kname} (pair-transposed layout: {lay_g} lanes x {lay_e // 2} element pairs per chain, {64 // lay_g} chains per "
@@ -321,8 +325,9 @@ def extra_measurements(K, L, n, stream):
     # -- the headline workload in its other modes
     for key, kw in (("mala_one_transition_per_launch_no_save", dict(steps_per_launch=1, monitor=0)),
                     ("mala_fused_no_save", dict(steps_per_launch=0, monitor=0)),
-                    ("mala_one_transition_per_launch_with_save", dict(steps_per_launch=1, monitor=L.MON_SUMMARIES, sparse_moves=SPARSE)),
-                    ("mala_fused_with_save_without_the_sparse_moves_hint", dict(steps_per_launch=0, monitor=L.MON_SUMMARIES))):
+                    ("mala_one_transition_per_launch_with_save", dict(steps_per_launch=1, monitor=L.MON_SUMMARIES)),
+                    ("mala_fused_with_save_4lane_kernels_forced", dict(steps_per_launch=0, monitor=L.MON_SUMMARIES, sparse_moves=1)),
+                    ("mala_fused_with_save_8lane_kernels_forced", dict(steps_per_launch=0, monitor=L.MON_SUMMARIES, sparse_moves=2))):
         e = K.Engine(sampler=L.SAMPLER_MALA, target=neg, nchains=n, nsteps=10 ** 7, driftstep=0.9, stream=stream, **kw)
         e.init_state_normal()
         rate, _, _ = timed_rate(e, n, 64, 1024)

@@ -194,14 +194,13 @@ typedef struct klara_desc {
                                     (lags 0..acov_maxlag, at most 31), so that Geyer's initial monotone / positive sequence estimators
                                     (mcvar(:imse | :ipse, maxlag), mcvar.jl:75-105,137-158) need no stored history:
                                     klara_get_chain_acov_mcvar.  Uses a value ring of its own when no history monitor is on. */
-    int32_t  sparse_moves;       /* hint, 0 or 1: the chains are expected to move rarely (acceptance of a per cent or so, like MALA with a drift
-                                    step far too large for the dimension).  Untuned MH / MALA jobs on the diagonal Gaussian (17 <= D <= 104) that
-                                    keep running sums then take the 4-lanes-per-chain layout, whose running sums are folded straight into
-                                    memory when a chain moves (no resident sums): 13 vs 15.4 us per transition at 65,536 x 100 and 0.9 %
-                                    acceptance, but 50 / 124 / 213 us at 21 / 56 / 99.7 % (profiles/r2_acceptance_cost_probe.txt).  Without
-                                    the hint such jobs keep their sums in registers (15.4 - 18.4 us whatever the acceptance).  Jobs that keep
-                                    no running sums take the 4-lane layout either way.  Results do not depend on the hint beyond the
-                                    summation order that klara_get_layout reports. */
+    int32_t  sparse_moves;       /* how untuned MH / MALA jobs on the diagonal Gaussian (17 <= D <= 104) keep their running sums.  Two kernel
+                                    families run such a job and produce the same bits (both sum in the 8-lane order klara_get_layout reports):
+                                    4 lanes per chain, a moving chain's sums folded straight into memory (cheapest while chains move rarely:
+                                    acceptance of a few per cent), and 8 lanes per chain with the sums of the chains that moved resident in
+                                    registers (flat cost at any acceptance).  0 (default): the library decides launch by launch, on the device,
+                                    from the accepted proposals of the previous launch (klara_get_launch_modes reports what ran); 1: always the
+                                    4-lane kernels; 2: always the 8-lane kernels.  Results never depend on this field. */
 
     uint64_t seed;               /* Philox key                                                       */
     uint32_t monitor;            /* KLARA_MON_* bits                                                 */
@@ -328,6 +327,13 @@ klara_status klara_device_ptrs(klara_handle* h, void** x, void** logtarget, void
  * with few lanes per chain (unit r on lane r / (elements_per_lane/2), hyper block replicated).  See DESIGN.md section 3. */
 klara_status klara_get_layout(klara_handle* h, int32_t* kind, int32_t* lanes_per_chain,
                               int32_t* elems_per_lane);
+
+/* How the launches of this handle were issued so far (layout kind 3 jobs that both kernel families can run, see
+ * klara_desc.sparse_moves; zeros otherwise): counts[0] = launches issued as the 4-lane kernel alone, counts[1] = as the 8-lane
+ * kernel alone, counts[2] = as a device-decided pair; last_mode[j] / last_accepted[j] = decision (0: 4 lanes, 1: 8 lanes) and
+ * accepted proposals the most recent completed launch of chain partition j < 4 left behind (-1 when not available).  Never
+ * synchronises: the per-partition values are read from host-visible memory and may lag the device. */
+klara_status klara_get_launch_modes(klara_handle* h, int64_t counts[3], int32_t last_mode[4], int64_t last_accepted[4]);
 
 /* Self-test hook: writes nblocks Philox4x32-10 blocks produced by rocRAND's device engine
  * (rocrand_device::philox4x32_10_engine, seed/subsequence/offset = 4*first_block) into out[4*nblocks];

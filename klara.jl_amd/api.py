@@ -337,7 +337,7 @@ class BasicMCJob:
     def __init__(self, model: GenericModel, sampler: MCSampler, mcrange: BasicMCRange, v0: Dict[str, Sequence],
                  tuner: Optional[MCTuner] = None, outopts: Optional[dict] = None, *, seed: Optional[int] = None,
                  chain_offset: int = 0, device: int = 0, steps_per_launch: int = 0, summaries: bool = True,
-                 bm_batchlen: int = 0, acov_maxlag: int = 0, sparse_moves: bool = False):
+                 bm_batchlen: int = 0, acov_maxlag: int = 0, sparse_moves: int = 0):
         self.model, self.sampler, self.range = model, sampler, mcrange
         self.seed = _next_job_seed() if seed is None else int(seed)
         seed = self.seed
@@ -390,7 +390,7 @@ class BasicMCJob:
                   burnin=mcrange.burnin, thinning=mcrange.thinning, tuner=self.tuner.kind,
                   period=self.tuner.period, verbose=self.tuner.verbose, seed=seed, chain_offset=chain_offset,
                   device=device, monitor=monitor, steps_per_launch=steps_per_launch, bm_batchlen=int(bm_batchlen),
-                  acov_maxlag=int(acov_maxlag), sparse_moves=bool(sparse_moves),
+                  acov_maxlag=int(acov_maxlag), sparse_moves=int(sparse_moves),
                   hist_ring_cols=int(self.outopts["chunk"]) if self.outopts["destination"] == "iostream" else 0)
         self.bm_batchlen, self.acov_maxlag = int(bm_batchlen), int(acov_maxlag)
         if isinstance(sampler, MH):

@@ -16,6 +16,11 @@
 #define KLARA_CUSTOM_MAXD 256
 #endif
 
+// device-decided kernel choice (KAuto): launches shorter than this are issued as one kernel chosen on the host
+#ifndef KLARA_AUTO_PAIR_MIN_STEPS
+#define KLARA_AUTO_PAIR_MIN_STEPS 4
+#endif
+
 #define HIPCHK(expr)                                                                   \
     do {                                                                               \
         hipError_t e__ = (expr);                                                       \
@@ -66,6 +71,15 @@ struct klara_handle {
     // internal stream.  Chains are independent, so partition j's transition t+1 only follows its own transition t; the
     // streams drift apart and one partition's kernel fills the SIMDs while the other's drains / ramps up.
     int nparts = 1; hipStream_t side[3] = { nullptr, nullptr, nullptr }; hipEvent_t fork_ev = nullptr, join_ev[3] = { nullptr, nullptr, nullptr };
+    // layout kind 3, untuned MH / MALA with 17 <= D <= 104: the 4-lanes-per-chain kernels are available as well (np4 pairs per lane).
+    // They sum in the 8-lane order, so which of the two kernel families runs a launch changes no bit; with running sums on, the
+    // choice is taken on the device launch by launch (KAuto, klara_diagt.h): auto_cells = [partition][launch parity] decision,
+    // auto_ctr = [partition] launch counter, auto_mirror = host-visible {mode, accepted} per partition (may be null).
+    bool q4_ok = false; int np4 = 0;
+    int* auto_cells = nullptr; unsigned long long* auto_ctr = nullptr; int* auto_mirror = nullptr; int* auto_mirror_dev = nullptr;
+    long long launch_idx = 0;
+    double auto_threshold = 0.12;   // acceptance above which a launch keeps resident sums (8 lanes) — the measured crossover, profiles/r3_acceptance_cost_probe.txt
+    long long n_launch_mode[3] = { 0, 0, 0 };   // launches issued as: forced / single 4-lane, forced / single 8-lane, device-decided pair
 };
 
 static int cnt_predicate(const klara_desc& d)
@@ -87,6 +101,15 @@ static bool diagt_eligible(const klara_desc& d)
     if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
     if (getenv("KLARA_LAYOUT_E")) return false;
     return true;
+}
+
+// untuned MH / MALA on the pair-transposed layout up to D = 104: 4 lanes per chain, 16 chains per wavefront, NP = ceil(D/8) in 3..13
+// (klara_launch.h) — kernels that keep no resident running sums (a moving chain's sums are folded into memory by atomic adds)
+static bool q4_eligible(const klara_desc& d)
+{
+    const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
+    return diagt_eligible(d) && plain && (d.sampler == KLARA_SAMPLER_MH || d.sampler == KLARA_SAMPLER_MALA) && d.ndims <= 104 &&
+           !getenv("KLARA_DIAGT_NO_Q4");
 }
 
 // layout kind 4 (klara_hiert.h): MH / MALA / HMC on the hierarchical target, 8 lanes per chain, 4 units per lane
@@ -122,15 +145,11 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     // diagonal Gaussian and nothing tunes: the pair-transposed layout
     // (klara_diagt.h), Q = 8 lanes per chain, NP element pairs per lane
     if (diagt_eligible(d)) {
-        int Q = D <= 128 ? 8 : (D <= 256 ? 16 : 32);                              // lanes per chain
-        // untuned MH / MALA up to D = 104: 4 lanes per chain, 16 chains per wavefront, NP = ceil(D/8) in 3..13 (klara_launch.h)
-        const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
-        // ... when they keep no running sums, or when the caller says the chains move rarely (klara_desc.sparse_moves): the 4-lane
-        // kernels fold the running sums into memory with atomic adds, which only pays at acceptance rates of a per cent or so
-        const bool sums4 = !(d.monitor & KLARA_MON_SUMMARIES) || d.sparse_moves != 0;
-        if (plain && sums4 && (d.sampler == KLARA_SAMPLER_MH || d.sampler == KLARA_SAMPLER_MALA) && D <= 104 && !getenv("KLARA_DIAGT_NO_Q4")) Q = 4;
+        // lanes per chain of the layout, i.e. of the summation order klara_get_layout reports.  (Untuned MH / MALA up to D = 104 also
+        // run on 4-lane kernels that reproduce the 8-lane order: q4_eligible.)
+        const int Q = D <= 128 ? 8 : (D <= 256 ? 16 : 32);
         const int np = (D + 2 * Q - 1) / (2 * Q);                                 // NP = ceil(D/2 / Q) exactly (see klara_diagt.h)
-        if (np >= 2 && np <= (Q == 4 ? 13 : KLARA_DIAGT_NP_MAX)) { *kind = 3; *G = Q; *E = 2 * np; return KLARA_OK; }
+        if (np >= 2 && np <= KLARA_DIAGT_NP_MAX) { *kind = 3; *G = Q; *E = 2 * np; return KLARA_OK; }
     }
     // diagonal Gaussian: E elements per lane, G lanes; optional override for layout experiments
     // D <= 128: E = 2 or 4, whichever wastes fewer lanes; on a tie E = 4 (twice the chains per wavefront
@@ -194,7 +213,7 @@ static klara_status validate(const klara_desc* d)
         return KLARA_ERR_INVALID_ARG;
     if (d->target == KLARA_TARGET_CUSTOM && (!d->custom_src || d->custom_ndata < 0 || (d->custom_ndata > 0 && !d->custom_data)))
         return KLARA_ERR_INVALID_ARG;
-    if (d->hist_ring_cols < 0 || d->acov_maxlag < 0 || d->acov_maxlag > 31 || d->sparse_moves < 0 || d->sparse_moves > 1) return KLARA_ERR_INVALID_ARG;
+    if (d->hist_ring_cols < 0 || d->acov_maxlag < 0 || d->acov_maxlag > 31 || d->sparse_moves < 0 || d->sparse_moves > 2) return KLARA_ERR_INVALID_ARG;
     if (d->bm_batchlen < 0 || (d->bm_batchlen > 0 && !(d->monitor & KLARA_MON_SUMMARIES))) return KLARA_ERR_INVALID_ARG;
     if (d->steps_per_launch < 0 || d->tuner_score < 0 || d->tuner_score > 1) return KLARA_ERR_INVALID_ARG;   // (int32: a launch length always fits KLaunch::nsteps)
     return KLARA_OK;
@@ -217,7 +236,8 @@ static void free_all(klara_handle* h)
     hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->held); hipFree(h->hist); hipFree(h->acov_S); hipFree(h->acov_head); hipFree(h->acov_tail); hipFree(h->acov_total); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->hist_ll); hipFree(h->hist_lp); hipFree(h->err);
     hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
     hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->pool_partial); hipFree(h->d_params); hipFree(h->cdata);
-    hipFree(h->bm_prev); hipFree(h->bm_mean); hipFree(h->bm_m2);
+    hipFree(h->bm_prev); hipFree(h->bm_mean); hipFree(h->bm_m2); hipFree(h->auto_cells); hipFree(h->auto_ctr);
+    if (h->auto_mirror) hipHostFree(h->auto_mirror);
     klara_jit_destroy(h->jit);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -392,7 +412,9 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out)
     else { CKH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     CKH(hipEventCreate(&h->ev0)); CKH(hipEventCreate(&h->ev1));
     if (h->kind == 3) {
-        const long long cpw = 64 / G, groups = (desc->nchains + cpw - 1) / cpw;
+        h->q4_ok = q4_eligible(*desc);
+        h->np4 = (desc->ndims + 7) / 8;
+        const long long cpw = h->q4_ok ? 16 : 64 / G, groups = (desc->nchains + cpw - 1) / cpw;
         int np = groups >= 4096 ? 2 : 1;                       // >= one full round of wavefronts (4 per SIMD) per partition
         if (desc->nstreams >= 1 && desc->nstreams <= 4) np = desc->nstreams;
         if (const char* s = getenv("KLARA_STREAMS")) { const int v = atoi(s); if (v >= 1 && v <= 4) np = v; }
@@ -404,6 +426,14 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out)
         for (int j = 0; j + 1 < np; ++j) {
             CKH(hipStreamCreateWithFlags(&h->side[j], hipStreamNonBlocking));
             CKH(hipEventCreateWithFlags(&h->join_ev[j], hipEventDisableTiming));
+        }
+        if (h->q4_ok && (desc->monitor & KLARA_MON_SUMMARIES)) {
+            CKH(dalloc(&h->auto_cells, 8)); CKH(dalloc(&h->auto_ctr, 4));
+            if (hipHostMalloc((void**)&h->auto_mirror, 16 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
+                for (int i = 0; i < 16; ++i) h->auto_mirror[i] = (i & 3) == 0 ? 1 : ((i & 3) == 2 ? -1 : 0);
+                if (hipHostGetDevicePointer((void**)&h->auto_mirror_dev, h->auto_mirror, 0) != hipSuccess) { hipHostFree(h->auto_mirror); h->auto_mirror = nullptr; h->auto_mirror_dev = nullptr; }
+            } else { h->auto_mirror = nullptr; (void)hipGetLastError(); }
+            if (const char* s = getenv("KLARA_AUTO_THRESHOLD")) { const double v = atof(s); if (v >= 0.0 && v <= 1.0) h->auto_threshold = v; }
         }
     }
 
@@ -649,6 +679,11 @@ static klara_status init_common(klara_handle* h)
         HIPCHK(hipMemsetAsync(h->bm_m2, 0, N * D * sizeof(double), st));
     }
     h->bm_count = 0;
+    if (h->auto_cells) {             // first launch of a job: resident sums (flat cost whatever the acceptance turns out to be)
+        const int ones[8] = { 1, 1, 1, 1, 1, 1, 1, 1 };
+        HIPCHK(hipMemcpyAsync(h->auto_cells, ones, sizeof(ones), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(h->auto_ctr, 0, 4 * sizeof(unsigned long long), st));
+    }
     if (h->acov_S) {
         const size_t ws = (size_t)h->acov_W * N * D * sizeof(double);
         HIPCHK(hipMemsetAsync(h->acov_S, 0, ws, st)); HIPCHK(hipMemsetAsync(h->acov_head, 0, ws, st)); HIPCHK(hipMemsetAsync(h->acov_tail, 0, ws, st));
@@ -672,8 +707,7 @@ static klara_status init_common(klara_handle* h)
     hipError_t e;
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, h->dense_mu, needgrad, grid_for(h), st);
     else if (h->kind == 3)
-        e = h->G == 4 ? klara_launch_diagt_init_q4(p, h->E / 2, needgrad, grid_for(h), st)
-          : h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
+        e = h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
           : h->G == 16 ? klara_launch_diagt_init_q16(p, h->E / 2, needgrad, grid_for(h), st)
                        : klara_launch_diagt_init_q32(p, h->E / 2, needgrad, grid_for(h), st);
     else if (h->kind == 4) e = klara_launch_hiert_init(p, h->E / 2, d.hier_ntimes, needgrad, grid_for(h), st);
@@ -687,6 +721,8 @@ static klara_status init_common(klara_handle* h)
     int flag = 0;
     HIPCHK(hipMemcpyAsync(&flag, h->err, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    // (host mirror of the decision cells, written once nothing is in flight)
+    if (h->auto_mirror) for (int i = 0; i < 16; ++i) h->auto_mirror[i] = (i & 3) == 0 ? 1 : ((i & 3) == 2 ? (int)(h->launch_idx - 1) : 0);
     h->steps_done = 0; h->nsaved = 0; h->m_prop = 0; h->m_tot = d.period; h->timed = false;
     if (flag != 0) { h->have_state = false; return (klara_status)flag; }
     h->have_state = true;
@@ -749,6 +785,17 @@ extern "C" klara_status klara_stream_key(klara_handle* h, uint64_t* key, uint64_
     return KLARA_OK;
 }
 
+// layout kind 3: the chains [c0, c1) of partition j of nparts — cut in blocks of 16 chains (64 / G for the wider layouts), i.e. whole
+// chain groups of every kernel that may run the job
+static void part_range(const klara_handle* h, int nparts, int j, long long* c0, long long* c1)
+{
+    const long long N = h->d.nchains, blk = 16;
+    const long long blocks = (N + blk - 1) / blk, per = (blocks + nparts - 1) / nparts;
+    *c0 = j * per * blk; *c1 = (j + 1) * per * blk;
+    if (*c0 > N) *c0 = N;
+    if (*c1 > N) *c1 = N;
+}
+
 static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
 {
     const klara_desc& d = h->d;
@@ -763,26 +810,71 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on
         const bool da = d.tuner == KLARA_TUNER_DUAL_AVERAGING;                                 // (HMC only: validate())
         const bool tune = !plain || da;                                                        // something counts proposals / tunes
-        const long long cpw = 64 / h->G, groups = (d.nchains + cpw - 1) / cpw, per = (groups + nparts - 1) / nparts;
+        // which kernel family runs the launch (q4_ok jobs: same bits either way)
+        const bool sums = (d.monitor & KLARA_MON_SUMMARIES) != 0;
+        int force = -1;                                      // 0: 4 lanes per chain; 1: 8 lanes; -1: decided on the device
+        if (!h->q4_ok) force = 1;
+        else if (!sums) force = 0;                           // nothing to fold: the 4-lane kernels
+        else if (d.sparse_moves == 1) force = 0;
+        else if (d.sparse_moves == 2) force = 1;
+        if (h->q4_ok && sums) if (const char* sm = getenv("KLARA_SUM_MODE")) { const int v = atoi(sm); if (v == 0 || v == 1) force = v; }
+        const long long idx = h->launch_idx++;
         for (int j = 0; j < nparts; ++j) {
-            KLaunch kp = kl;
-            kp.group0 = j * per; kp.group_end = (j + 1) * per < groups ? (j + 1) * per : groups;
-            if (kp.group0 >= kp.group_end) break;
-            const dim3 grid((unsigned)((kp.group_end - kp.group0 + 3) / 4));      // one wavefront per group of 8 chains
+            long long c0, c1;
+            part_range(h, nparts, j, &c0, &c1);
+            if (c0 >= c1) break;
             hipStream_t st = j == 0 ? h->stream : h->side[j - 1];
-            hipError_t e;
+            hipError_t e = hipSuccess;
+            const auto go = [&](int lanes, const KAuto& ka) -> hipError_t {
+                KLaunch kp = kl;
+                const long long cpw = 64 / lanes;
+                kp.group0 = c0 / cpw; kp.group_end = (c1 + cpw - 1) / cpw;
+                const long long nw = kp.group_end - kp.group0;               // one wavefront per group of cpw chains
+                const int np = lanes == 4 ? h->np4 : h->E / 2;
+                if (lanes == 4)
+                    return d.sampler == KLARA_SAMPLER_MH ? klara_launch_diagt_mh_q4(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st)
+                                                         : klara_launch_diagt_mala_q4(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);
 #define KLARA_DIAGT_LAUNCH(SUFFIX)                                                                                                          \
-            switch (d.sampler) {                                                                                                              \
-            case KLARA_SAMPLER_MH: e = klara_launch_diagt_mh##SUFFIX(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;    \
-            case KLARA_SAMPLER_SLICE: e = klara_launch_diagt_slice##SUFFIX(p, kp, h->E / 2, unitw, mon, tune, grid, st); break;                    \
-            case KLARA_SAMPLER_MALA: e = klara_launch_diagt_mala##SUFFIX(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break; \
-            default: e = klara_launch_diagt_hmc##SUFFIX(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st); break;                 \
-            }
-            if (h->G == 4) {
-                e = d.sampler == KLARA_SAMPLER_MH ? klara_launch_diagt_mh_q4(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st)
-                                                  : klara_launch_diagt_mala_q4(p, kp, h->E / 2, onestep && !tune, unitw, mon, tune, da, grid, st);
-            } else if (h->G == 8) { KLARA_DIAGT_LAUNCH() } else if (h->G == 16) { KLARA_DIAGT_LAUNCH(_q16) } else { KLARA_DIAGT_LAUNCH(_q32) }
+                switch (d.sampler) {                                                                                                          \
+                case KLARA_SAMPLER_MH: return klara_launch_diagt_mh##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);        \
+                case KLARA_SAMPLER_SLICE: return klara_launch_diagt_slice##SUFFIX(p, kp, np, unitw, mon, tune, ka, nw, st);                        \
+                case KLARA_SAMPLER_MALA: return klara_launch_diagt_mala##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);    \
+                default: return klara_launch_diagt_hmc##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);                     \
+                }
+                if (lanes == 8) { KLARA_DIAGT_LAUNCH() } else if (lanes == 16) { KLARA_DIAGT_LAUNCH(_q16) } else { KLARA_DIAGT_LAUNCH(_q32) }
 #undef KLARA_DIAGT_LAUNCH
+            };
+            if (force >= 0 && !(h->q4_ok && sums)) {
+                e = go(force == 0 ? 4 : h->G, KLARA_AUTO_NONE);
+            } else {
+                // running sums on a job both kernel families can run: every launch counts its accepted proposals and leaves the
+                // decision for the next one in the partition's cell of the other parity (KAuto)
+                KAuto ka;
+                ka.cell_in = nullptr;
+                ka.cell_out = h->auto_cells + 2 * j + (int)((idx + 1) & 1);
+                ka.acc_ctr = h->auto_ctr + j;
+                ka.mirror = h->auto_mirror_dev ? h->auto_mirror_dev + 4 * j : nullptr;
+                ka.thr_work = (unsigned long long)(h->auto_threshold * 65536.0 * (double)(c1 - c0) * (double)kl.nsteps);
+                ka.fanout = nparts == 1 ? 4 : 1;             // a whole-job launch decides for every partition
+                ka.launch_idx = (int)idx;
+                if (force >= 0) {
+                    ka.my_mode = force;
+                    e = go(force == 0 ? 4 : 8, ka);
+                    h->n_launch_mode[force] += j == 0;
+                } else if (kl.nsteps < KLARA_AUTO_PAIR_MIN_STEPS) {
+                    // a short launch is not worth an idle sibling: the host picks from the last decision it has seen (stale at worst)
+                    ka.my_mode = h->auto_mirror ? (__atomic_load_n(h->auto_mirror + 4 * j, __ATOMIC_RELAXED) != 0) : 1;
+                    e = go(ka.my_mode == 0 ? 4 : 8, ka);
+                    h->n_launch_mode[ka.my_mode] += j == 0;
+                } else {
+                    // both kernels, each subject to the decision the previous launch left (an idle sibling costs ~3 us of a launch that
+                    // takes hundreds: 17.9 against 17.7 us per transition for 20-transition launches, nothing measurable on two streams)
+                    ka.cell_in = h->auto_cells + 2 * j + (int)(idx & 1);
+                    ka.my_mode = 0; e = go(4, ka);
+                    if (e == hipSuccess) { ka.my_mode = 1; e = go(8, ka); }
+                    h->n_launch_mode[2] += j == 0;
+                }
+            }
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
@@ -825,10 +917,9 @@ static hipError_t launch_bm_close(klara_handle* h, int nparts)
 {
     const long long N = h->d.nchains, D = h->d.ndims;
     const int np = h->kind == 3 ? nparts : 1;
-    const long long cpw = h->kind == 3 ? 64 / h->G : 8, groups = (N + cpw - 1) / cpw, per = (groups + np - 1) / np;
     for (int j = 0; j < np; ++j) {
         long long c0 = 0, c1 = N;
-        if (np > 1) { c0 = j * per * cpw; c1 = (j + 1) * per * cpw; if (c1 > N) c1 = N; }
+        if (np > 1) part_range(h, np, j, &c0, &c1);          // (the chains the partition's transition kernels cover)
         if (c0 >= c1) break;
         const long long n = (c1 - c0) * D;
         hipLaunchKernelGGL(k_bm_close, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, j == 0 ? h->stream : h->side[j - 1], h->sum, h->X, h->held, (int)D,
@@ -1620,6 +1711,18 @@ extern "C" klara_status klara_get_layout(klara_handle* h, int32_t* kind, int32_t
     if (kind) *kind = h->kind;
     if (lanes_per_chain) *lanes_per_chain = h->kind == 2 ? h->RS : h->G;
     if (elems_per_lane) *elems_per_lane = h->E;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_launch_modes(klara_handle* h, int64_t counts[3], int32_t last_mode[4], int64_t last_accepted[4])
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (counts) for (int i = 0; i < 3; ++i) counts[i] = h->n_launch_mode[i];
+    for (int j = 0; j < 4; ++j) {
+        const bool have = h->auto_mirror != nullptr;
+        if (last_mode) last_mode[j] = have ? __atomic_load_n(h->auto_mirror + 4 * j, __ATOMIC_ACQUIRE) : -1;
+        if (last_accepted) last_accepted[j] = have ? __atomic_load_n(h->auto_mirror + 4 * j + 1, __ATOMIC_RELAXED) : -1;
+    }
     return KLARA_OK;
 }
 

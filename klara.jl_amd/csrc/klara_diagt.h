@@ -45,6 +45,65 @@
 #endif
 #define KLARA_DT_PAIR_FENCE(pi) do { if (KLARA_DT_FENCE_EVERY > 0 && ((pi) + 1) % KLARA_DT_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
 
+// Per-launch "which kernel runs" protocol for jobs whose running sums can be kept two ways (untuned MH / MALA, 17 <= D <= 104):
+// the 4-lane kernels fold the sums of a chain that moves straight into memory (atomic adds: nothing resident, cheapest while chains
+// move rarely), the 8-lane kernels keep the sums of the chains that moved in registers (flat cost at any acceptance).  Both produce
+// the same bits (the 4-lane kernels sum in the 8-lane order, see below), so the choice is a pure performance decision and is taken
+// ON THE DEVICE, launch by launch: the host enqueues both kernels of a launch, each reads the decision cell of this launch
+// (cell_in) and returns at once unless it names its own mode; the one that runs counts the accepted proposals of the launch and
+// its last wavefront writes the decision for the NEXT launch (cell_out — the cells alternate, so the sibling of a launch still sees
+// the value the launch was decided with).  No host round trip, no synchronisation, any number of launches in flight.
+struct KAuto {
+    const int* cell_in;             // decision this launch is subject to (nullptr: run unconditionally)
+    int* cell_out;                  // decision for the next launch of this chain partition (nullptr: none kept)
+    unsigned long long* acc_ctr;    // launch-wide (waves done << 40 | accepted proposals) counter, zero between launches
+    int* mirror;                    // host-visible {mode, accepted of the launch (saturated), launch index, 0} per partition, or nullptr
+    unsigned long long thr_work;    // accepted * 65536 > thr_work  ->  next launch keeps resident sums (mode 1)
+    int my_mode;                    // 0: sums folded into memory (4 lanes per chain); 1: resident sums (8 lanes per chain)
+    int fanout;                     // cells (stride 2 ints) / mirrors (stride 4) the decision is written to: 1, or 4 when the launch covers every partition
+    int launch_idx;                 // index of this launch in the job (mirror[2]: tells the host how fresh the decision is)
+};
+#define KLARA_AUTO_NONE KAuto{ nullptr, nullptr, nullptr, nullptr, 0ull, 0, 1, 0 }
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += (unsigned)__builtin_amdgcn_ds_bpermute((int)((((unsigned)threadIdx.x & 63u) ^ (unsigned)m) << 2), (int)v);
+    return v;
+}
+// end of a launch: every wavefront adds its accepted proposals to its workgroup's LDS counter, the last wavefront of a workgroup
+// adds the workgroup's total to the launch counter (one returning atomic per workgroup: thousands of wavefronts finishing together
+// on ONE address cost ~25 us per launch), and the last workgroup to arrive decides the next launch
+__shared__ unsigned klara_auto_wg[2];      // {accepted, wavefronts done} of this workgroup; zeroed by auto_begin
+__device__ __forceinline__ void auto_begin()           // before the kernel's first workgroup barrier
+{
+    if (threadIdx.x < 2) klara_auto_wg[threadIdx.x] = 0u;
+}
+__device__ __forceinline__ void auto_finish(const KAuto& ka, unsigned wave_acc)
+{
+    if (ka.acc_ctr == nullptr) return;
+    const unsigned tot = wave_sum_u32(wave_acc);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&klara_auto_wg[0], tot);                                        // (LDS; in order with the next one)
+        if (atomicAdd(&klara_auto_wg[1], 1u) != (blockDim.x >> 6) - 1) return;    // not the workgroup's last wavefront
+        const unsigned long long wg_tot = atomicAdd(&klara_auto_wg[0], 0u);
+        const unsigned long long old = atomicAdd(ka.acc_ctr, (1ull << 40) | wg_tot);
+        if ((old >> 40) == (unsigned long long)gridDim.x - 1) {
+            const unsigned long long total = (old & ((1ull << 40) - 1)) + wg_tot;
+            *ka.acc_ctr = 0ull;
+            const int mode = (total << 16) > ka.thr_work ? 1 : 0;
+            if (ka.cell_out != nullptr) for (int k = 0; k < ka.fanout; ++k) ka.cell_out[2 * k] = mode;
+            if (ka.mirror != nullptr) {
+                for (int k = 0; k < ka.fanout; ++k) {
+                    __hip_atomic_store(ka.mirror + 4 * k + 1, (int)(total > 0x7fffffffull ? 0x7fffffffull : total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(ka.mirror + 4 * k, mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(ka.mirror + 4 * k + 2, ka.launch_idx, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (last: the host reads it first)
+                }
+            }
+        }
+    }
+}
+
 template <int NP, int Q>
 struct PairCtx {
     int lane, q, cw;        // lane in the wavefront, lane within the chain, chain within the wavefront
@@ -149,32 +208,56 @@ __device__ __forceinline__ void diagt_fold(const PairCtx<NP, Q>& c, __amdgpu_buf
     held = fold ? 0 : held;
 }
 
-// The same fold without resident sums: sum[i] += held * x[i], sumsq[i] += held * (x[i] * x[i]) as no-return FP64 atomic adds
-// (global_atomic_add_f64: one IEEE addition performed at the L2, the same rounding as the host's) — no load to wait for and no
-// 4*NP registers for the sums.  Used where chains move rarely (Vanilla MH / MALA on the 4-lanes-per-chain layout); a chain's sums
-// are only ever touched by its own lanes, in program order.
+// The same fold without resident sums, as a plain read-modify-write of the chain's sums in memory (a chain's sums are only ever
+// touched by its own lanes, in program order, and a launch never overlaps another launch of the same chains): 16-byte loads and
+// stores of the moving chains' pairs, KLARA_DT_RMW_CHUNK pairs of sum and sumsq in flight at a time (8 transient registers per
+// pair; the Philox / Box-Muller temporaries are dead here).  Used by the 4-lanes-per-chain kernels (untuned MH / MALA), which have
+// no registers for resident sums.  (Round 2 folded with no-return FP64 atomic adds: nothing to wait for, but one 8-byte atomic
+// per lane at the L2's atomic rate — 65 G/s — against 16 bytes per lane at the L2 / HBM rate: same-box, us per transition of
+// 65,536 x 100 at 0.9 / 4 / 10 / 21 / 56 % acceptance: atomics 15.8 / 16.9 / 27 / 50 / 124, read-modify-write 15.3 / 16.6 / 17.5 / 19.1 / 22.3.)
+#ifndef KLARA_DT_RMW_CHUNK
+#define KLARA_DT_RMW_CHUNK 3
+#endif
 template <int NP, int Q>
-__device__ __forceinline__ void diagt_fold_atomic(const PairCtx<NP, Q>& c, gdouble* sum, gdouble* sumsq, long long first_elem, int D,
-                                                  bool fold, long long& held, const double (&x)[2 * NP])
+__device__ __forceinline__ void diagt_fold_rmw(const PairCtx<NP, Q>& c, __amdgpu_buffer_rsrc_t wsum, __amdgpu_buffer_rsrc_t wsq, bool fold,
+                                               long long& held, const double (&x)[2 * NP])
 {
-    if (fold) {
-        const double hf = (double)held;
-        gdouble* const s0 = sum + first_elem + (c.off0 >> 3);
-        gdouble* const q0 = sumsq + first_elem + (c.off0 >> 3);
+    const double hf = fold ? (double)held : 0.0;
+    constexpr int CH = KLARA_DT_RMW_CHUNK;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const bool ok0 = p < NP - 1 || c.last_ok, ok1 = p < NP - 1 || c.last_full;
-            if (ok0) {
-                (void)__builtin_amdgcn_global_atomic_fadd_f64(s0 + p * Q * 2, hf * x[2 * p]);
-                (void)__builtin_amdgcn_global_atomic_fadd_f64(q0 + p * Q * 2, hf * (x[2 * p] * x[2 * p]));
-            }
-            if (ok1) {
-                (void)__builtin_amdgcn_global_atomic_fadd_f64(s0 + p * Q * 2 + 1, hf * x[2 * p + 1]);
-                (void)__builtin_amdgcn_global_atomic_fadd_f64(q0 + p * Q * 2 + 1, hf * (x[2 * p + 1] * x[2 * p + 1]));
+    for (int p0 = 0; p0 < NP; p0 += CH) {
+        kd_uint4 ts[CH], tq[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (p0 + k < NP) {
+                const unsigned o = fold ? pair_off<NP, Q>(c, p0 + k) : KLARA_BUF_OOB;
+                ts[k] = __builtin_amdgcn_raw_buffer_load_b128(wsum, o, 0, 0);
+                tq[k] = __builtin_amdgcn_raw_buffer_load_b128(wsq, o, 0, 0);
             }
         }
-        held = 0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (p0 + k < NP) {
+                const int p = p0 + k;
+                const unsigned o = fold ? pair_off<NP, Q>(c, p) : KLARA_BUF_OOB;
+                const double s0 = __builtin_bit_cast(double, kd_uint2{ ts[k].x, ts[k].y }) + hf * x[2 * p];
+                const double s1 = __builtin_bit_cast(double, kd_uint2{ ts[k].z, ts[k].w }) + hf * x[2 * p + 1];
+                const double q0 = __builtin_bit_cast(double, kd_uint2{ tq[k].x, tq[k].y }) + hf * (x[2 * p] * x[2 * p]);
+                const double q1 = __builtin_bit_cast(double, kd_uint2{ tq[k].z, tq[k].w }) + hf * (x[2 * p + 1] * x[2 * p + 1]);
+                const kd_uint2 a = __builtin_bit_cast(kd_uint2, s0), b = __builtin_bit_cast(kd_uint2, s1);
+                const kd_uint2 e = __builtin_bit_cast(kd_uint2, q0), f = __builtin_bit_cast(kd_uint2, q1);
+                if (p < NP - 1) {
+                    __builtin_amdgcn_raw_buffer_store_b128(kd_uint4{ a.x, a.y, b.x, b.y }, wsum, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(kd_uint4{ e.x, e.y, f.x, f.y }, wsq, o, 0, 0);
+                } else {                                 // the last pair may be half a pair (odd D): 8-byte stores, the second only if it exists
+                    const unsigned o1 = (fold && c.last_full) ? o + 8u : KLARA_BUF_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b64(a, wsum, o, 0, 0); __builtin_amdgcn_raw_buffer_store_b64(b, wsum, o1, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(e, wsq, o, 0, 0); __builtin_amdgcn_raw_buffer_store_b64(f, wsq, o1, 0, 0);
+                }
+            }
+        }
     }
+    held = fold ? 0 : held;
 }
 
 // per-element parameter vector (weights, means, proposal scales): element 2P+h of the lane's pair p
@@ -220,11 +303,18 @@ __device__ __forceinline__ void diag_elem(double x, double w, double m2w, double
 // pooled per GPU, verbose counting) — the same device functions, per-chain state in registers over the launch.
 // DA (HMC only): DualAveragingMCTuner — per-chain step and trajectory length (iterate/HMC.jl:142-144, 225-249); the
 // wavefront runs to the longest trajectory of its chains, a finished chain's lanes keep their state.
-template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false, bool DA = false>
-__global__ __launch_bounds__(256, (NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? KLARA_DT_W1 : KLARA_DT_WF)
-                                           : (Q == 4 && NP <= 13 && !TUNE ? (SAMPLER == KLARA_SAMPLER_MALA ? KLARA_Q4_MALA_WF : (SAMPLER == KLARA_SAMPLER_MH ? 2 : 1)) : 1)))
-void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
+template <int SAMPLER, int NP, int Q, bool ONESTEP, bool TUNE>
+__host__ __device__ constexpr int diagt_min_waves()       // wavefronts per SIMD the register allocator is asked to leave room for
 {
+    return NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? KLARA_DT_W1 : KLARA_DT_WF)
+                   : (Q == 4 && NP <= 13 && !TUNE ? (SAMPLER == KLARA_SAMPLER_MALA ? KLARA_Q4_MALA_WF : (SAMPLER == KLARA_SAMPLER_MH ? 2 : 1)) : 1);
+}
+
+template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false, bool DA = false>
+__global__ __launch_bounds__(256, (diagt_min_waves<SAMPLER, NP, Q, ONESTEP, TUNE>()))
+void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
+{
+    if (ka.cell_in != nullptr && *ka.cell_in != ka.my_mode) return;       // (launch-uniform: the sibling kernel runs this launch)
     static_assert(!(ONESTEP && (MON || TUNE)), "monitored / tuned jobs run the committing kernel");
     static_assert(!DA || (TUNE && SAMPLER == KLARA_SAMPLER_HMC), "dual averaging: tuned HMC");
     constexpr bool PLAIN = !TUNE;              // KCNT / KPOOLED (klara_kernels.h) fold to 0 when nothing counts
@@ -232,9 +322,9 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
     constexpr bool NEEDG = SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_HMC;
     constexpr bool SLICE = SAMPLER == KLARA_SAMPLER_SLICE;
     static_assert(!(SLICE && ONESTEP), "the slice sampler moves every chain: it runs the committing kernel");
-    // running sums folded by atomic adds instead of being held in registers (diagt_fold_atomic): untuned MH / MALA on the
+    // running sums folded into memory instead of being held in registers (diagt_fold_rmw): untuned MH / MALA on the
     // 4-lanes-per-chain form of the layout
-    constexpr bool ATOMSUM = MON && !TUNE && Q == 4 && (SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_MALA);
+    constexpr bool MEMSUM = MON && !TUNE && Q == 4 && (SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_MALA);
     const KParams& p = *pp;
     // weights and means of a non-unit diagonal: one LDS copy per workgroup (element i at [i], padding = (1, 0)) instead
     // of 4*NP registers per lane; a pair's (w, mu) values are 16-byte LDS reads where they are used
@@ -248,6 +338,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             lds_m2w[i] = -2.0 * lds_w[i];
         }
     }
+    auto_begin();
     kd_tables_to_lds();          // (ends with the workgroup barrier)
     const int D = p.D;
     const PairCtx<NP, Q> cx = make_pctx<NP, Q>(D);
@@ -275,6 +366,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
     const long long wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     // one chain group per wavefront (the launcher sizes the grid for it); a persistent loop here makes the compiler
     // park the polynomial constants in VGPRs for the whole kernel
+    unsigned wave_acc = 0;                                  // accepted proposals of this wavefront's chains (KAuto)
     KLARA_DT_GROUP_LOOP {
         const long long first_chain = grp * CPW;
         const long long left = p.nchains - first_chain;
@@ -305,13 +397,13 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
         // a chain that does not move (98-99.6 % of the transitions of the drift-0.9 job) costs no running-sum traffic at all:
         // 210 MB per launch of 65,536 x 100 otherwise, 40-90 us of every launch.
         const bool do_sum = MON && p.sum != nullptr;
-        double sm[ATOMSUM ? 2 : E], sq[ATOMSUM ? 2 : E];
+        double sm[MEMSUM ? 2 : E], sq[MEMSUM ? 2 : E];
         bool sums_loaded = false;                          // (per chain: uniform over the chain's Q lanes)
         long long held = 0;
         __amdgpu_buffer_rsrc_t wsum = wx, wsq = wx;
         if (do_sum) {
 #pragma unroll
-            for (int e = 0; e < (ATOMSUM ? 2 : E); ++e) { sm[e] = 0.0; sq[e] = 0.0; }
+            for (int e = 0; e < (MEMSUM ? 2 : E); ++e) { sm[e] = 0.0; sq[e] = 0.0; }
             wsum = group_window(p.sum, first_chain, here, D); wsq = group_window(p.sumsq, first_chain, here, D);
             held = p.held[chain_ok ? chain : 0];
         }
@@ -332,7 +424,12 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             const unsigned long long t = kl.t0 + (unsigned long long)s;
             if (KCNT) tune_count_proposal(p, tn);
             double xp[E];
-            double red[3] = { 0.0, 0.0, 0.0 }, red1[1], red2[2];
+            const auto put_xp = [&](int pi, double a, double b) { xp[2 * pi] = a; xp[2 * pi + 1] = b; };
+            // Q = 4 sums in the order of the 8-lane layout (the order klara_get_layout reports): lane q of 4 holds the pairs of the
+            // 8-lane layout's lanes q (its even pairs p) and q + 4 (odd p), each in ascending order; two partial sums per lane, the
+            // strides 1 and 2 of the butterfly on both, stride 4 is their sum — bit for bit what 8 lanes per chain produce.
+            constexpr int NR = Q == 4 ? 2 : 1;
+            double red[3 * NR] = {}, red1[1], red2[2];
             double u_last = 0.5, lg_last = 0.0;
             bool acc;
             double ltp, a_da = 0.0;
@@ -437,21 +534,30 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
 #pragma unroll
                 for (int e = 0; e < E; ++e) xp[e] = x[e];          // (the commit below is then a no-op)
             } else if (SAMPLER == KLARA_SAMPLER_MH) {                              // iterate/MH.jl:72-124
-                const auto mh_elem = [&](int e, double ze) {
-                    xp[e] = x[e] + sig[e] * ze;                                                // MH.jl:79
+                const auto mh_elem = [&](int e, double ze, int r) -> double {
+                    const double xe = x[e] + sig[e] * ze;                                      // MH.jl:79
                     double term, gd;
-                    diag_elem<UNITW>(xp[e], wv(e), m2wv(e), mv(e), term, gd);       // :81
-                    red[0] = red[0] + term;
+                    diag_elem<UNITW>(xe, wv(e), m2wv(e), mv(e), term, gd);          // :81
+                    red[r] = red[r] + term;
+                    return xe;
                 };
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
                     double z0 = ZFIRST ? z[(2 * pi) % (ZFIRST ? E : 2)] : 0.0, z1 = ZFIRST ? z[(2 * pi + 1) % (ZFIRST ? E : 2)] : 0.0;
                     if (!ZFIRST) pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z0, z1, u_last, lg_last);
-                    mh_elem(2 * pi, z0); mh_elem(2 * pi + 1, z1);
+                    const int r = (NR == 2 && (pi & 1)) ? 3 : 0;
+                    const double a = mh_elem(2 * pi, z0, r), b = mh_elem(2 * pi + 1, z1, r);
+                    put_xp(pi, a, b);
                     if (!ZFIRST) KLARA_DT_PAIR_FENCE(pi);
                 }
-                red1[0] = red[0];
-                group_allreduce<1>(red1, Q, cx.lane);
+                if (NR == 2) {
+                    red2[0] = red[0]; red2[1] = red[3];
+                    group_allreduce<2>(red2, Q, cx.lane);
+                    red1[0] = red2[0] + red2[1];
+                } else {
+                    red1[0] = red[0];
+                    group_allreduce<1>(red1, Q, cx.lane);
+                }
                 ltp = gconst - red1[0];
                 const double ratio = ltp - lt;                                                 // :83
                 acc = ratio > 0.0;                                                             // :97
@@ -461,27 +567,31 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             } else if (SAMPLER == KLARA_SAMPLER_MALA) {                            // iterate/MALA.jl:78-128
                 const double h_ = tn.step, halfh = 0.5 * h_, sq = KCNT ? __builtin_sqrt(h_) : p.sqrt_step0;
                 const double half_inv_h = 0.5 * (KCNT ? 1.0 / h_ : p.inv_step0);
-                const auto mala_elem = [&](int e, double ze) {
+                const auto mala_elem = [&](int e, double ze, int r) -> double {
                     double term, ge, gpe;
                     diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), term, ge);        // (the current gradient, re-formed)
                     const double m_ = x[e] + halfh * ge;                                       // :83
-                    xp[e] = m_ + sq * ze;                                                      // :84
-                    diag_elem<UNITW>(xp[e], wv(e), m2wv(e), mv(e), term, gpe);      // :86
-                    red[0] = red[0] + term;
-                    const double q1 = m_ - xp[e];
-                    red[1] = red[1] + (q1 * q1) * half_inv_h;                                  // :90
-                    const double mup = xp[e] + halfh * gpe;                                    // :91
+                    const double xe = m_ + sq * ze;                                            // :84
+                    diag_elem<UNITW>(xe, wv(e), m2wv(e), mv(e), term, gpe);         // :86
+                    red[r] = red[r] + term;
+                    const double q1 = m_ - xe;
+                    red[r + 1] = red[r + 1] + (q1 * q1) * half_inv_h;                          // :90
+                    const double mup = xe + halfh * gpe;                                       // :91
                     const double q2 = mup - x[e];
-                    red[2] = red[2] + (q2 * q2) * half_inv_h;                                  // :92
+                    red[r + 2] = red[r + 2] + (q2 * q2) * half_inv_h;                          // :92
+                    return xe;
                 };
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
                     double z0 = ZFIRST ? z[(2 * pi) % (ZFIRST ? E : 2)] : 0.0, z1 = ZFIRST ? z[(2 * pi + 1) % (ZFIRST ? E : 2)] : 0.0;
                     if (!ZFIRST) pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z0, z1, u_last, lg_last);
-                    mala_elem(2 * pi, z0); mala_elem(2 * pi + 1, z1);
+                    const int r = (NR == 2 && (pi & 1)) ? 3 : 0;
+                    const double a = mala_elem(2 * pi, z0, r), b = mala_elem(2 * pi + 1, z1, r);
+                    put_xp(pi, a, b);
                     if (!ZFIRST) KLARA_DT_PAIR_FENCE(pi);
                 }
-                group_allreduce<3>(red, Q, cx.lane);
+                group_allreduce<3 * NR>(red, Q, cx.lane);
+                if (NR == 2) { red[0] = red[0] + red[3]; red[1] = red[1] + red[4]; red[2] = red[2] + red[5]; }
                 ltp = gconst - red[0];
                 double ratio = ltp - lt;                                                       // :88
                 ratio += red[1];                                                               // :90
@@ -545,7 +655,8 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             else if (DA && per_chain_tune && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {   // verbose report block
                 tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
             }
-            if (ONESTEP) {
+            if constexpr (ONESTEP) {
+                wave_acc += (acc && chain_ok && cx.q == 0) ? 1u : 0u;
                 if (acc) {                               // accepted proposal: registers -> HBM, nothing else moves
                     store_pairs<NP, Q>(cx, wx, xp);
                     if (NEEDG) { double gq[E]; grad_of(xp, gq); store_pairs<NP, Q>(cx, wg, gq); }
@@ -555,7 +666,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
                 nacc += acc ? 1ull : 0ull;
                 if (!SLICE && do_sum && __any(chain_ok && acc && held > 0)) {          // a chain of this wavefront leaves its state
                     const bool fold = chain_ok && acc && held > 0;
-                    if constexpr (ATOMSUM) diagt_fold_atomic<NP, Q>(cx, p.sum, p.sumsq, first_chain * D, D, fold, held, x);
+                    if constexpr (MEMSUM) diagt_fold_rmw<NP, Q>(cx, wsum, wsq, fold, held, x);
                     else diagt_fold<NP, Q>(cx, wsum, wsq, fold, sums_loaded, held, x, sm, sq);
                 }
                 if (acc) {
@@ -582,7 +693,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             }
         }
         if (do_sum) {
-            if constexpr (!ATOMSUM) {
+            if constexpr (!MEMSUM) {
                 if (__any(sums_loaded)) {                  // only the chains that left a state during the launch write their sums back
                     store_pairs_if<NP, Q>(cx, wsum, sums_loaded, sm);
                     store_pairs_if<NP, Q>(cx, wsq, sums_loaded, sq);
@@ -591,6 +702,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             if (chain_ok && cx.q == 0) p.held[chain] = held;
         }
         if (SLICE && stuck && chain_ok && cx.q == 0) atomicMax((int*)p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
+        if (!ONESTEP) wave_acc += (chain_ok && cx.q == 0) ? (unsigned)nacc : 0u;     // (per-lane partial; summed in auto_finish)
         if (!ONESTEP && nacc != 0) {
             store_pairs<NP, Q>(cx, wx, x);
             if (NEEDG) { double gq[E]; grad_of(x, gq); store_pairs<NP, Q>(cx, wg, gq); }
@@ -606,6 +718,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl)
             }
         }
     }
+    auto_finish(ka, wave_acc);
 }
 
 // initialize!(pstate, parameter, sampler) for layout kind 3: lt (and the gradient) at X, finiteness check

@@ -1,7 +1,7 @@
 // klara_diagt_hmc.hip — instantiates the pair-transposed HMC kernels (layout kind 3) for gfx950.
 #include "klara_launch.h"
 
-hipError_t KLARA_DIAGT_FN(klara_launch_diagt_hmc)(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st)
+hipError_t KLARA_DIAGT_FN(klara_launch_diagt_hmc)(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, const KAuto& ka, long long nwaves, hipStream_t st)
 {
     KLARA_DISPATCH_DIAGT(KLARA_SAMPLER_HMC);
 }

@@ -3,20 +3,20 @@
 
 #define KLARA_DIAGT_SLICE_CASE(NP_)                                                                                       \
     case NP_:                                                                                                              \
-        if (tune && unitw) hipLaunchKernelGGL((k_diagt<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, true, true, true>), grid, blk, 0, st, p, kl);        \
-        else if (tune) hipLaunchKernelGGL((k_diagt<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, false, true, true>), grid, blk, 0, st, p, kl);       \
-        else if (mon && unitw) hipLaunchKernelGGL((k_diagt<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, true, true>), grid, blk, 0, st, p, kl);      \
-        else if (mon) hipLaunchKernelGGL((k_diagt<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, false, true>), grid, blk, 0, st, p, kl);              \
-        else if (unitw) hipLaunchKernelGGL((k_diagt<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, true, false>), grid, blk, 0, st, p, kl);            \
-        else hipLaunchKernelGGL((k_diagt<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, false, false>), grid, blk, 0, st, p, kl);                      \
+        if (tune && unitw) e_ = diagt_go<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, true, true, true>(p, kl, ka, nwaves, st);        \
+        else if (tune) e_ = diagt_go<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, false, true, true>(p, kl, ka, nwaves, st);       \
+        else if (mon && unitw) e_ = diagt_go<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, true, true>(p, kl, ka, nwaves, st);      \
+        else if (mon) e_ = diagt_go<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, false, true>(p, kl, ka, nwaves, st);              \
+        else if (unitw) e_ = diagt_go<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, true, false>(p, kl, ka, nwaves, st);            \
+        else e_ = diagt_go<KLARA_SAMPLER_SLICE, NP_, KLARA_DIAGT_Q, false, false, false>(p, kl, ka, nwaves, st);                      \
         break;
 
-hipError_t KLARA_DIAGT_FN(klara_launch_diagt_slice)(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st)
+hipError_t KLARA_DIAGT_FN(klara_launch_diagt_slice)(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, bool tune, const KAuto& ka, long long nwaves, hipStream_t st)
 {
-    const dim3 blk(256);
+    hipError_t e_ = hipSuccess;
     switch (NP) {
         KLARA_DIAGT_NP_MENU_DO(KLARA_DIAGT_SLICE_CASE)
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+    return e_;
 }

@@ -37,10 +37,10 @@ hipError_t klara_launch_mfma4_probe(const double* A, const double* B, const doub
 #define KLARA_DIAGT_FN(name) name          // (experimental lane counts replace the Q = 8 set)
 #endif
 #define KLARA_DIAGT_DECLARE(SUFFIX)                                                                                                                       \
-    hipError_t klara_launch_diagt_mh##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);   \
-    hipError_t klara_launch_diagt_mala##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st); \
-    hipError_t klara_launch_diagt_hmc##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);  \
-    hipError_t klara_launch_diagt_slice##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, bool tune, dim3 grid, hipStream_t st);                      \
+    hipError_t klara_launch_diagt_mh##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, const KAuto& ka, long long nwaves, hipStream_t st);   \
+    hipError_t klara_launch_diagt_mala##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, const KAuto& ka, long long nwaves, hipStream_t st); \
+    hipError_t klara_launch_diagt_hmc##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, const KAuto& ka, long long nwaves, hipStream_t st);  \
+    hipError_t klara_launch_diagt_slice##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, bool tune, const KAuto& ka, long long nwaves, hipStream_t st);                      \
     hipError_t klara_launch_diagt_init##SUFFIX(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
 KLARA_DIAGT_DECLARE()
 KLARA_DIAGT_DECLARE(_q16)
@@ -49,8 +49,8 @@ KLARA_DIAGT_DECLARE(_q32)
 // (VanillaMCTuner, not verbose) with the MH or the MALA sampler — D = 100 occupies 50 of 52 pair slots instead of 50 of 56, the
 // per-wavefront work (reductions, accept test, addressing) is shared by 16 chains, and the running sums are folded with atomic
 // adds instead of living in registers (klara_diagt.h diagt_fold_atomic).  Only klara_diagt_{mh,mala,init}.hip are built for it.
-hipError_t klara_launch_diagt_mh_q4(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
-hipError_t klara_launch_diagt_mala_q4(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, dim3 grid, hipStream_t st);
+hipError_t klara_launch_diagt_mh_q4(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, const KAuto& ka, long long nwaves, hipStream_t st);
+hipError_t klara_launch_diagt_mala_q4(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, const KAuto& ka, long long nwaves, hipStream_t st);
 hipError_t klara_launch_diagt_init_q4(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
 // pairs per lane the kernels are instantiated for; a job takes NP = ceil(ceil(D/2) / Q) exactly (only the LAST pair of a lane
 // can be padding)
@@ -63,30 +63,38 @@ hipError_t klara_launch_diagt_init_q4(const KParams& p, int NP, int needgrad, di
 #endif
 #define KLARA_DIAGT_NP_MAX 8
 
+// one launch of a pair-transposed kernel over `nwaves` chain groups: one wavefront each, four per workgroup
+template <int S, int NP_, int Q_, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false, bool DA = false>
+static hipError_t diagt_go(const KParams* p, const KLaunch& kl, const KAuto& ka, long long nwaves, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_diagt<S, NP_, Q_, ONESTEP, UNITW, MON, TUNE, DA>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, p, kl, ka);
+    return hipGetLastError();
+}
+
 #if KLARA_DIAGT_Q == 4     // (no tuned / dual-averaging instantiations: those jobs take the 8-lane form)
 #define KLARA_DIAGT_CASE(S, NP_)                                                                                   \
     case NP_:                                                                                                      \
         if (tune || da) return hipErrorInvalidValue;                                                               \
-        else if (mon && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true>), grid, blk, 0, st, p, kl); \
-        else if (mon) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, true>), grid, blk, 0, st, p, kl);        \
-        else if (onestep && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, true, true, false>), grid, blk, 0, st, p, kl);  \
-        else if (onestep) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, true, false, false>), grid, blk, 0, st, p, kl);    \
-        else if (unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, false>), grid, blk, 0, st, p, kl);      \
-        else hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, false>), grid, blk, 0, st, p, kl);                \
+        else if (mon && unitw) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, true, true>(p, kl, ka, nwaves, st); \
+        else if (mon) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, false, true>(p, kl, ka, nwaves, st);        \
+        else if (onestep && unitw) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, true, true, false>(p, kl, ka, nwaves, st);  \
+        else if (onestep) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, true, false, false>(p, kl, ka, nwaves, st);    \
+        else if (unitw) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, true, false>(p, kl, ka, nwaves, st);      \
+        else e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, false, false>(p, kl, ka, nwaves, st);                \
         break;
 #else
 #define KLARA_DIAGT_CASE(S, NP_)                                                                                   \
     case NP_:                                                                                                      \
-        if (da && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true, true, (S == KLARA_SAMPLER_HMC)>), grid, blk, 0, st, p, kl); \
-        else if (da) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, true, true, (S == KLARA_SAMPLER_HMC)>), grid, blk, 0, st, p, kl); \
-        else if (tune && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true, true>), grid, blk, 0, st, p, kl);  \
-        else if (tune) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, true, true>), grid, blk, 0, st, p, kl);  \
-        else if (mon && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, true>), grid, blk, 0, st, p, kl); \
-        else if (mon) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, true>), grid, blk, 0, st, p, kl);        \
-        else if (onestep && unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, true, true, false>), grid, blk, 0, st, p, kl);  \
-        else if (onestep) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, true, false, false>), grid, blk, 0, st, p, kl);    \
-        else if (unitw) hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, true, false>), grid, blk, 0, st, p, kl);      \
-        else hipLaunchKernelGGL((k_diagt<S, NP_, KLARA_DIAGT_Q, false, false, false>), grid, blk, 0, st, p, kl);                \
+        if (da && unitw) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, true, true, true, (S == KLARA_SAMPLER_HMC)>(p, kl, ka, nwaves, st); \
+        else if (da) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, false, true, true, (S == KLARA_SAMPLER_HMC)>(p, kl, ka, nwaves, st); \
+        else if (tune && unitw) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, true, true, true>(p, kl, ka, nwaves, st);  \
+        else if (tune) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, false, true, true>(p, kl, ka, nwaves, st);  \
+        else if (mon && unitw) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, true, true>(p, kl, ka, nwaves, st); \
+        else if (mon) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, false, true>(p, kl, ka, nwaves, st);        \
+        else if (onestep && unitw) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, true, true, false>(p, kl, ka, nwaves, st);  \
+        else if (onestep) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, true, false, false>(p, kl, ka, nwaves, st);    \
+        else if (unitw) e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, true, false>(p, kl, ka, nwaves, st);      \
+        else e_ = diagt_go<S, NP_, KLARA_DIAGT_Q, false, false, false>(p, kl, ka, nwaves, st);                \
         break;
 #endif
 #define KLARA_DIAGT_CASE_KLARA_SAMPLER_MH(NP_) KLARA_DIAGT_CASE(KLARA_SAMPLER_MH, NP_)
@@ -94,12 +102,12 @@ hipError_t klara_launch_diagt_init_q4(const KParams& p, int NP, int needgrad, di
 #define KLARA_DIAGT_CASE_KLARA_SAMPLER_HMC(NP_) KLARA_DIAGT_CASE(KLARA_SAMPLER_HMC, NP_)
 #define KLARA_DISPATCH_DIAGT(S)                                                                                    \
     do {                                                                                                           \
-        const dim3 blk(256);                                                                                       \
+        hipError_t e_ = hipSuccess;                                                                                \
         switch (NP) {                                                                                              \
             KLARA_DIAGT_NP_MENU_DO(KLARA_DIAGT_CASE_##S)                                                           \
             default: return hipErrorInvalidValue;                                                                  \
         }                                                                                                          \
-        return hipGetLastError();                                                                                  \
+        return e_;                                                                                                 \
     } while (0)
 
 // MH / MALA / HMC on the hierarchical target, 8 lanes per chain (layout kind 4, klara_hiert.h); RPL = 4 units per lane, NT = 5
@@ -119,7 +127,9 @@ const char* klara_jit_log();
 // mode 7: mode 3 with exactly one transition per launch; mode 3: nothing counts/tunes and nothing is monitored;
 // mode 1: nothing counts/tunes; mode 0: general
 // (a launch gets 64 KB of LDS — 8 KB of math tables + 56 KB of dynamic — without asking; the logistic target's data rows may need more)
+#ifndef KLARA_LDS_DEFAULT_DYNAMIC
 #define KLARA_LDS_DEFAULT_DYNAMIC 57344u
+#endif
 #define KLARA_LAUNCH_TM(S, T, E_, G_, M_)                                                                                          \
     do {                                                                                                                          \
         if (lds > KLARA_LDS_DEFAULT_DYNAMIC) {                                                                                    \

@@ -193,7 +193,7 @@ class Engine:
                  da_t0: int = 10, da_kappa: float = 0.75,
                  seed: int = 20260927, chain_offset: int = 0, device: int = 0, monitor: int = 0,
                  steps_per_launch: int = 0, stream: int = 0, nstreams: int = 0, bm_batchlen: int = 0, hist_ring_cols: int = 0,
-                 acov_maxlag: int = 0, sparse_moves: bool = False):
+                 acov_maxlag: int = 0, sparse_moves: int = 0):
         self._lib = L.load()
         self.target = target
         self.ndims = int(target.ndims)
@@ -246,7 +246,7 @@ class Engine:
         d.seed, d.monitor, d.steps_per_launch = int(seed), self.monitor, int(steps_per_launch)
         d.nstreams = int(nstreams)
         d.bm_batchlen = int(bm_batchlen)
-        d.hist_ring_cols, d.acov_maxlag, d.sparse_moves = int(hist_ring_cols), int(acov_maxlag), int(bool(sparse_moves))
+        d.hist_ring_cols, d.acov_maxlag, d.sparse_moves = int(hist_ring_cols), int(acov_maxlag), int(sparse_moves)
         d.stream = C.c_void_p(int(stream)) if stream else None
         self._h = C.c_void_p()
         L.check(self._lib.klara_create(C.byref(d), C.byref(self._h)), "klara_create")
@@ -415,6 +415,13 @@ class Engine:
         k, g, e = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         L.check(self._lib.klara_get_layout(self._h, C.byref(k), C.byref(g), C.byref(e)), "klara_get_layout")
         return int(k.value), int(g.value), int(e.value)
+
+    def launch_modes(self):
+        """(counts[3], last_mode[4], last_accepted[4]) — how the launches were issued (klara_get_launch_modes): 4-lane kernel alone,
+        8-lane kernel alone, device-decided pair; the per-partition values may lag the device (never synchronises)."""
+        cnt = np.zeros(3, dtype=np.int64); lm = np.zeros(4, dtype=np.int32); la = np.zeros(4, dtype=np.int64)
+        L.check(self._lib.klara_get_launch_modes(self._h, cnt.ctypes.data, lm.ctypes.data, la.ctypes.data), "klara_get_launch_modes")
+        return cnt, lm, la
 
     def device_ptrs(self):
         x, lt, g = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -13,7 +13,7 @@ OBJCOPY = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
 FILT = "c++filt"
 subs = sys.argv[1:]
 rows = []
-for obj in sorted((ROOT / "build" / "csrc").glob("*.o")):
+for obj in sorted((ROOT / "build" / (__import__("os").environ.get("KR_OBJDIR", "csrc"))).glob("*.o")):
     co, fb = Path("/tmp") / (obj.stem + ".co"), Path("/tmp") / (obj.stem + ".fatbin")
     subprocess.run([OBJCOPY, f"--dump-section=.hip_fatbin={fb}", str(obj)], capture_output=True, text=True)
     if not fb.exists():

@@ -372,14 +372,14 @@ def make_case(name):
     elif name == "dt_mala_d100":       # BASELINE cfg 2 shape; 130 chains = 16 full wavefront groups + 2 chains
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=130, nsteps=40, burnin=0, driftstep=0.9)
     elif name in ("sparse_mala_d100", "sparse_mala_d100_small_step", "sparse_mh_d100", "sparse_mala_mvnormal_d30"):
-        # klara_desc.sparse_moves: untuned MH / MALA that keep running sums on the 4-lane layout, sums folded by atomic adds —
+        # klara_desc.sparse_moves = 1: untuned MH / MALA that keep running sums always on the 4-lane kernels, sums folded by atomic adds —
         # at a low acceptance (the layout's purpose), at a high one (a fold at almost every transition) and on a non-unit diagonal
         base = {"sparse_mala_d100": dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=131, nsteps=60, burnin=10, driftstep=0.9),
                 "sparse_mala_d100_small_step": dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=67, nsteps=40, burnin=0, thinning=1, driftstep=0.05),
                 "sparse_mh_d100": dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(100), nchains=70, nsteps=60, burnin=7, thinning=3, mh_sigma=np.full(100, 0.1)),
                 "sparse_mala_mvnormal_d30": dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 2, 30), np.linspace(0.6, 1.7, 30)),
                                                  nchains=45, nsteps=50, burnin=5, driftstep=0.3)}[name]
-        c = dict(base, sparse_moves=True)
+        c = dict(base, sparse_moves=1)
     elif name == "dt_mala_d100_small_step":
         c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=67, nsteps=40, burnin=0, driftstep=0.05)
     elif name == "dt_mala_d112_full":  # D/2 = 7*8: no padding pair, the accept uniform takes the explicit path

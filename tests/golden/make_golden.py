@@ -25,7 +25,7 @@ from klara_jl_amd import _lib as L  # noqa: E402
 def run_case(name):
     c = cases.make_case(name)
     layout = None                      # the oracle mirrors the product's layout choice (oracle_ffi.default_layout)
-    dt = name in cases.DIAGT_CASES     # (these run with the accept mask as their only monitor: no running sums, 4 lanes per chain for MH / MALA)
+    dt = name in cases.DIAGT_CASES     # (these run with the accept mask as their only monitor: no running sums)
     job = O.OracleJob(**cases.oracle_kwargs(c, layout=layout), want_sums=not dt)
     if dt:
         assert job.layout.kind == 3

@@ -113,13 +113,7 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     if (target_kind == L.TARGET_GAUSS_DIAG and sampler is not None and plain
             and 17 <= d <= 512 and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0" and "KLARA_LAYOUT_E" not in os.environ):
         q = 8 if d <= 128 else (16 if d <= 256 else 32)          # lanes per chain (klara_api.hip select_layout)
-        # jobs in which nothing counts or tunes, MH / MALA, D <= 104: 4 lanes per chain (klara_api.hip cnt_predicate / select_layout)
-        counts = bool(verbose) if sampler in (L.SAMPLER_MH, L.SAMPLER_SLICE) else (
-            (tuner == L.TUNER_VANILLA and bool(verbose)) or tuner == L.TUNER_ACCEPT_RATE or (tuner == L.TUNER_DUAL_AVERAGING and bool(verbose)))
-        plain_job = (not counts) and tuner_mode == L.TUNE_PER_CHAIN and tuner != L.TUNER_DUAL_AVERAGING
-        if (plain_job and (not summaries or sparse_moves) and sampler in (L.SAMPLER_MH, L.SAMPLER_MALA) and d <= 104
-                and "KLARA_DIAGT_NO_Q4" not in os.environ):
-            q = 4
+        # (untuned MH / MALA up to D = 104 also run on 4-lane kernels: they sum in this 8-lane order, klara_diagt.h)
         return (3, q, 2 * ((d + 2 * q - 1) // (2 * q)))
     if (target_kind == L.TARGET_HIER_NORMAL and sampler in (L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC)
             and 9 <= hier_nunits <= 32 and os.environ.get("KLARA_LAYOUT_KIND", "4") != "0"):

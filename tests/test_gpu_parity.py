@@ -170,7 +170,7 @@ def test_parity_pair_transposed_layout(name, mode):
     n = case["nsteps"]
     eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_ACCEPT, steps_per_launch={"one_launch": 0, "launch_per_transition": 1, "mixed": 7}[mode]))
     layout = eng.layout()
-    assert layout[0] == 3 and layout[1] == (4 if case["sampler"] in (L.SAMPLER_MH, L.SAMPLER_MALA) and case["target"].ndims <= 104 else 8), layout
+    assert layout[0] == 3 and layout[1] == 8, layout       # (MH / MALA up to D = 104 run on 4-lane kernels that sum in this 8-lane order)
     assert tuple(layout) == tuple(O.default_layout(case["target"].kind, case["target"].ndims, sampler=case["sampler"], summaries=False))
     job = O.OracleJob(**cases.oracle_kwargs(case, layout=layout))
     eng.init_state_normal(); assert job.init_state_normal() == 0
@@ -213,20 +213,20 @@ def test_group_layout_dimension_sweep():
 @pytest.mark.parametrize("sampler,kw,step", [(L.SAMPLER_MALA, dict(driftstep=0.3), 1), (L.SAMPLER_HMC, dict(leapstep=0.2, nleaps=3), 3),
                                              (L.SAMPLER_MH, None, 3), (L.SAMPLER_SLICE, "slice", 7)])
 def test_pair_transposed_dimension_sweep(sampler, kw, step):
-    """Dimensions 17..128 (4 lanes per chain for MH / MALA up to 104 at the odd ones, where the job carries the sparse_moves hint;
-    8 otherwise), odd ones included, on the pair-transposed layout (every one for MALA, every
+    """Dimensions 17..128 (the 4-lane kernels for MH / MALA up to 104 at the odd ones — sparse_moves = 1 —, the 8-lane kernels
+    otherwise), odd ones included, on the pair-transposed layout (every one for MALA, every
     third for HMC and MH, every seventh for the slice sampler), then 129..512 (16 and 32 lanes per chain) in coarser steps:
     with and without padding pairs / a half pair, i.e. every way of obtaining the accept draw and of storing the last pair."""
     wide = {1: 3, 3: 13, 7: 61}[step]
     for d in list(range(17, 129, step)) + list(range(129, 513, wide)) + [256, 257, 511, 512]:
         skw = dict(slice_widths=np.full(d, 1.5)) if kw == "slice" else (kw if kw is not None else dict(mh_sigma=np.full(d, 0.2)))
         case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=11,
-                    nsteps=6, burnin=0, x0=None, seed=d, name=f"sweep3_d{d}", sparse_moves=(d % 2 == 1), **skw)
+                    nsteps=6, burnin=0, x0=None, seed=d, name=f"sweep3_d{d}", sparse_moves=(1 if d % 2 == 1 else 2), **skw)
         eng, job = _run_pair(case, spl=2)
-        lanes = 8 if d <= 128 else 16 if d <= 256 else 32
-        if sampler in (L.SAMPLER_MH, L.SAMPLER_MALA) and d <= 104 and d % 2 == 1:
-            lanes = 4                              # untuned MH / MALA with the sparse_moves hint: 4 lanes per chain, sums folded by atomic adds
-        assert eng.layout()[:2] == (3, lanes)
+        lanes = 8 if d <= 128 else 16 if d <= 256 else 32       # (the summation order; MH / MALA up to 104 at the odd dimensions run the
+        assert eng.layout()[:2] == (3, lanes)                    # 4-lane kernels — sparse_moves = 1 —, which reproduce the 8-lane order)
+        if sampler in (L.SAMPLER_MH, L.SAMPLER_MALA) and d <= 104:
+            assert tuple(eng.launch_modes()[0]) == ((3, 0, 0) if d % 2 == 1 else (0, 3, 0)), d
         x, lt, g = eng.state()
         assert np.array_equal(x, job.X) and np.array_equal(lt, job.LT), d
         assert sampler == L.SAMPLER_MH or np.array_equal(g, job.G), d
@@ -265,10 +265,11 @@ def test_pair_transposed_every_pairs_per_lane(d, sampler):
     the LAST pair of a lane can be padding, which holds because NP is exactly the ceiling)."""
     kw = dict(driftstep=0.25) if sampler == L.SAMPLER_MALA else dict(leapstep=0.2, nleaps=3)
     case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=13, nsteps=12,
-                burnin=2, x0=None, seed=5, name=f"np_d{d}", sparse_moves=True, **kw)
+                burnin=2, x0=None, seed=5, name=f"np_d{d}", sparse_moves=1, **kw)
     eng, job = _run_pair(case, splits=[5, 7], spl=3)
-    lanes = eng.layout()[1]                                                        # 4 (untuned MALA up to D = 104) or 8
-    assert eng.layout()[0] == 3 and lanes == (4 if sampler == L.SAMPLER_MALA and d <= 104 else 8)
+    lanes = eng.layout()[1]                                                        # (untuned MALA up to D = 104 runs the 4-lane kernels here)
+    assert eng.layout()[0] == 3 and lanes == 8
+    assert (eng.launch_modes()[0][0] > 0) == (sampler == L.SAMPLER_MALA and d <= 104)
     assert eng.layout()[2] == 2 * (((d + 1) // 2 + lanes - 1) // lanes)           # NP = ceil(ceil(d/2) / lanes)
     _assert_same(eng, job, case)
     eng.close()
@@ -344,9 +345,9 @@ def test_c_abi_summary_allreduce_over_rccl_single_rank(klib):
 @pytest.mark.parametrize("name", ["dt_mala_d100", "dt_mala_d18", "dt_mala_mvnormal_d30", "dt_mh_d100", "dt_mh_mvnormal_d20"])
 @pytest.mark.parametrize("spl", [0, 1])
 def test_pair_transposed_8_lane_form_of_untuned_mh_mala(name, spl, monkeypatch):
-    """Untuned MH / MALA jobs up to D = 104 take the 4-lane form of the layout when they keep no running sums or carry the
-    sparse_moves hint; otherwise — and always under KLARA_DIAGT_NO_Q4 — the 8-lane kernels (the ones their tuned siblings run),
-    with resident running sums instead of atomic folds: same bits as the oracle told that summation order."""
+    """Untuned MH / MALA jobs up to D = 104 can run on the 4-lane kernels (always when they keep no running sums); under
+    KLARA_DIAGT_NO_Q4 they only ever run the 8-lane kernels (the ones their tuned siblings run), with resident running sums instead
+    of atomic folds: same bits — both families sum in the 8-lane order."""
     monkeypatch.setenv("KLARA_DIAGT_NO_Q4", "1")
     case = cases.make_case(name)
     eng, job = _run_pair(case, spl=spl)
@@ -362,7 +363,7 @@ def test_layout_choice_matches_its_mirror():
         for sampler, extra in ((L.SAMPLER_MALA, dict(driftstep=0.1)), (L.SAMPLER_MH, dict(mh_sigma=np.ones(d))),
                                (L.SAMPLER_SLICE, dict(slice_widths=np.ones(d)))):
             for tuner in (L.TUNER_VANILLA, L.TUNER_ACCEPT_RATE):
-                for mon, sparse in ((0, False), (L.MON_SUMMARIES, False), (L.MON_SUMMARIES, True)):
+                for mon, sparse in ((0, 0), (L.MON_SUMMARIES, 0), (L.MON_SUMMARIES, 1), (L.MON_SUMMARIES, 2)):
                     e = K.Engine(sampler=sampler, target=K.GaussDiagTarget.negdot(d), nchains=5, nsteps=2, tuner=tuner, targetrate=0.5, monitor=mon,
                                  sparse_moves=sparse, **extra)
                     mirror = O.default_layout(L.TARGET_GAUSS_DIAG, d, sampler=sampler, tuner=tuner, summaries=bool(mon), sparse_moves=sparse)
@@ -1130,9 +1131,8 @@ def test_full_size_pair_transposed_on_sampled_chains(name, kw, nsteps, spl):
     mask = eng.accept_mask()
     na, _ = eng.accept_counts()
     assert np.array_equal(na, mask.sum(axis=0))
-    cpw = 64 // eng.layout()[1]                           # chains per wavefront: 16 on the 4-lane form (MALA), 8 on the 8-lane form
-    groups = (n + cpw - 1) // cpw
-    boundary = ((groups + 1) // 2) * cpw                  # first chain of the second partition
+    blocks = (n + 15) // 16                               # partitions are cut in blocks of 16 chains (klara_api.hip part_range)
+    boundary = ((blocks + 1) // 2) * 16                   # first chain of the second partition
     case = dict(kw, target=target, nchains=16, nsteps=nsteps, name=name, x0=None, seed=20260927)
     for off in (0, boundary - 8, n - 16):
         job = O.OracleJob(**cases.oracle_kwargs(case, layout=eng.layout(), chain_offset=off))
@@ -1140,6 +1140,56 @@ def test_full_size_pair_transposed_on_sampled_chains(name, kw, nsteps, spl):
         sl = slice(off, off + 16)
         assert np.array_equal(mask[:, sl], job.accept), (name, off)
         assert np.array_equal(x[sl], job.X) and np.array_equal(lt[sl], job.LT) and np.array_equal(g[sl], job.G), (name, off)
+    eng.close()
+
+
+@pytest.mark.parametrize("sparse", [0, 1, 2])
+def test_full_size_bench_job_replayed_by_the_oracle(sparse):
+    """The job bench.py times, as the driver runs it: MALA driftstep 0.9 on lt = -|x|^2, D = 100, 65,531 chains (ragged last group),
+    running sums on, the library's 32 transitions per launch, seed 20260927; `run(5)` (the driver's warm-up) and `run(20)` (its timed
+    region: ONE launch, whole job on the caller's stream), then 96 more transitions (three launches on two chain partitions / streams).
+    sparse = 0 is what bench.py runs — the kernel of every launch chosen on the device from the previous launch's accepted proposals:
+    resident sums (8 lanes) while the fresh job still accepts tens of per cent, atomic folds (4 lanes) once it has settled —, 1 and 2
+    pin the two kernel families.  Blocks of 16 chains at the start, across the partition boundary and in the ragged tail are replayed
+    by the oracle: accept masks of all 121 transitions, x / logtarget / gradient, running sums — bit for bit in all three modes."""
+    n, d, runs = 65536 - 5, 100, (5, 20, 96)
+    nsteps = sum(runs)
+    target = K.GaussDiagTarget.negdot(d)
+    kw = dict(sampler=L.SAMPLER_MALA, driftstep=0.9)
+    eng = K.Engine(target=target, nchains=n, nsteps=nsteps, burnin=0, seed=20260927, monitor=L.MON_ACCEPT | L.MON_SUMMARIES,
+                   sparse_moves=sparse, **kw)
+    assert eng.layout() == (3, 8, 14)
+    eng.init_state_normal()
+    for r in runs:
+        eng.run(r)
+    cnt, last_mode, last_acc = eng.launch_modes()
+    assert int(cnt.sum()) == 5                                      # 1 + 1 + 3 launches
+    if sparse == 0:
+        assert cnt[2] == 5, cnt                                     # every launch a device-decided pair (5, 20, 32, 32, 32 transitions)
+        assert last_mode[0] in (0, 1) and last_acc[0] >= 0
+    else:
+        assert cnt[sparse - 1] == 5, cnt
+    x, lt, g = eng.state()
+    mask = eng.accept_mask()
+    s, q, nsaved = eng.chain_sums()
+    assert nsaved == nsteps
+    na, _ = eng.accept_counts()
+    assert np.array_equal(na, mask.sum(axis=0))
+    if sparse == 0:
+        # the fresh job (x0 ~ N(0, I)) accepts tens of per cent of its first proposals and about 1 % after a hundred transitions:
+        # the device-side decision must have left the 8-lane kernels behind by the last launch
+        assert mask[:5].mean() > 0.2 and mask[-32:].mean() < 0.04, (mask[:5].mean(), mask[-32:].mean())
+        assert last_mode[0] == 0 and last_mode[1] == 0, last_mode
+    blocks = (n + 15) // 16
+    boundary = ((blocks + 1) // 2) * 16
+    case = dict(kw, target=target, nchains=16, nsteps=nsteps, burnin=0, name="bench_job", x0=None, seed=20260927)
+    for off in (0, boundary - 8, n - 16):
+        job = O.OracleJob(**cases.oracle_kwargs(case, layout=eng.layout(), chain_offset=off))
+        job.init_state_normal(); job.run(nsteps)
+        sl = slice(off, off + 16)
+        assert np.array_equal(mask[:, sl], job.accept), off
+        assert np.array_equal(x[sl], job.X) and np.array_equal(lt[sl], job.LT) and np.array_equal(g[sl], job.G), off
+        assert np.array_equal(s[sl], job.sum) and np.array_equal(q[sl], job.sumsq), off
     eng.close()
 
 
