@@ -171,7 +171,7 @@ def main():
                            stream=stream, nstreams=args.streams)
         scratch.init_state_normal()
         scratch.run(args.clock_warmup)          # (closed after the timed repetitions: freeing memory would idle the device again)
-    times, kernel_ms_per_step, summ = [], [], None
+    times, kernel_ms_per_step, summ, rank_times = [], [], None, []
     for _ in range(args.reps):
         barrier()
         t0 = time.perf_counter()
@@ -181,8 +181,12 @@ def main():
         if dist is not None:
             dist.barrier()                           # closing bracket: every rank is done before anyone goes on
             te = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            elapsed = float(te.item())
+            every = [torch.zeros_like(te) for _ in range(world)]
+            dist.all_gather(every, te)               # every rank's own K steps: the job's time is their MAX; the spread shows imbalance
+            rank_times.append([float(t.item()) for t in every])
+            elapsed = max(rank_times[-1])
+        else:
+            rank_times.append([elapsed])
         times.append(elapsed)
         kms, nl = eng.last_run_ms()
         kernel_ms_per_step.append(kms / args.steps)
@@ -223,6 +227,9 @@ def main():
                        "streams": "library default (2 chain partitions on 2 HIP streams)" if args.streams == 0 else args.streams,
                        "timed_region": f"median of {args.reps} repetitions of {args.steps} transitions",
                        "repetition_ms_per_step": [t_ * 1e3 / args.steps for t_ in times],
+                       "per_rank_ms_per_step": [statistics.median(rt[r] for rt in rank_times) * 1e3 / args.steps for r in range(world)],
+                       "rank_time_max_over_min": max(statistics.median(rt[r] for rt in rank_times) for r in range(world))
+                                                 / min(statistics.median(rt[r] for rt in rank_times) for r in range(world)),
                        "acceptance_rate": acc_rate, "rccl_ranks_seen": ranks_seen, "summary_gather_ms": gather_ms,
                        "device_clock_warmup": f"{args.clock_warmup} transitions of an identical scratch job before the timed repetitions" if args.clock_warmup > 0 else "off",
                        "timed_region_kernel_ms_per_step": statistics.median(kernel_ms_per_step),

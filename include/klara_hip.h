@@ -246,6 +246,10 @@ klara_status klara_get_state(klara_handle* h, double* x, double* logtarget, doub
  * step-major (requires KLARA_MON_ACCEPT).  *nsteps_out receives the number of recorded steps. */
 klara_status klara_get_accept_mask(klara_handle* h, uint8_t* mask, int64_t capacity_steps,
                                    int64_t* nsteps_out);
+/* the same for the transitions [first_step, first_step + nsteps) only (0-based, within the steps run so far): nsteps x nchains
+ * bytes — what a sink that drains a long job chunk by chunk reads (diagnosticvalues of the newly saved steps,
+ * BasicContParamIOStream.jl:152-159) instead of every row since the start. */
+klara_status klara_get_accept_rows(klara_handle* h, int64_t first_step, int64_t nsteps, uint8_t* mask);
 /* per-chain accepted-transition counts over all steps since set_state/reset */
 klara_status klara_get_accept_counts(klara_handle* h, uint64_t* naccept, uint64_t* nsteps_out);
 /* per-chain sums over saved (postrange) steps: sum[c*D+d], sumsq[c*D+d]; *nsaved_out = count */

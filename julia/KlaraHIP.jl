@@ -9,11 +9,22 @@
 #
 # UNTESTED in the build image (no Julia there); tests/test_host_api.py checks mechanically what can be checked without it: the
 # struct layout against the C header, the descriptor builder's argument order, the Klara field names each mapping reads
-# (cited below) and that only declared symbols are bound.  Written for Julia >= 0.7 (`Cvoid`, `undef`); on Klara's own 0.6 read
-# `Void` / `Array{T}(dims)`.
+# (cited below), that only declared symbols are bound, and that blocks / brackets balance.  One file for Klara's own Julia 0.6
+# (REQUIRE:1 — `Void`, `Array{T}(dims)`, `finalizer(obj, f)`) and for Julia >= 0.7 (`Cvoid`, `Array{T}(undef, dims)`,
+# `finalizer(f, obj)`): the three differences are confined to the compatibility block below, everything else is common syntax.
 module KlaraHIP
 import Base: run
 const lib = "libklara_hip"            # klara.jl_amd/lib/libklara_hip.so on LD_LIBRARY_PATH
+
+# ---------------------------------------------------------------- Julia 0.6 / >= 0.7 compatibility (the only version-dependent code)
+@static if VERSION < v"0.7.0-"
+    const Cvoid = Void
+    newarray(::Type{T}, dims::Integer...) where {T} = Array{T}(dims...)
+    on_finalize(obj, f) = finalizer(obj, f)
+else
+    newarray(::Type{T}, dims::Integer...) where {T} = Array{T}(undef, dims...)
+    on_finalize(obj, f) = finalizer(f, obj)
+end
 
 # ---------------------------------------------------------------- constants of include/klara_hip.h
 const KLARA_ABI_VERSION = UInt32(3)
@@ -227,7 +238,7 @@ function HIPMCJob(parameter::HIPParameter, sampler, mcrange, v0::Dict;
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:klara_create, lib), Cint, (Ref{KlaraDesc}, Ref{Ptr{Cvoid}}), desc, h), "klara_create")
     job = HIPMCJob(h[], N, D, parameter, sampler, tn, mcrange, oo, mon, keep)
-    finalizer(j -> ccall((:klara_destroy, lib), Cint, (Ptr{Cvoid},), j.handle), job)
+    on_finalize(job, j -> ccall((:klara_destroy, lib), Cint, (Ptr{Cvoid},), j.handle))
     # initialize!(pstate, parameter, sampler, outopts): BasicMCJob.jl:73 (finiteness asserts on device)
     check(ccall((:klara_set_state, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), job.handle, X0), "klara_set_state")
     job
@@ -239,7 +250,7 @@ function HIPMCJob(desc::KlaraDesc, X0::Matrix{Float64}, range)
     check(ccall((:klara_create, lib), Cint, (Ref{KlaraDesc}, Ref{Ptr{Cvoid}}), desc, h), "klara_create")
     job = HIPMCJob(h[], size(X0, 2), size(X0, 1), HIPParameter(:p, GaussDiagTarget(size(X0, 1))), nothing, nothing, range,
                    Dict{Symbol, Any}(), desc.monitor, Any[X0])
-    finalizer(j -> ccall((:klara_destroy, lib), Cint, (Ptr{Cvoid},), j.handle), job)
+    on_finalize(job, j -> ccall((:klara_destroy, lib), Cint, (Ptr{Cvoid},), j.handle))
     check(ccall((:klara_set_state, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), job.handle, X0), "klara_set_state")
     job
 end
@@ -256,7 +267,7 @@ function chainvalue(job::HIPMCJob, c::Integer)
     n = Ref{Clonglong}(0)
     ccall((:klara_get_chain, lib), Cint, (Ptr{Cvoid}, Clonglong, Ptr{Float64}, Clonglong, Ref{Clonglong}),
           job.handle, c - 1, C_NULL, 0, n)
-    v = Matrix{Float64}(undef, job.ndims, n[])
+    v = newarray(Float64, job.ndims, n[])
     check(ccall((:klara_get_chain, lib), Cint, (Ptr{Cvoid}, Clonglong, Ptr{Float64}, Clonglong, Ref{Clonglong}),
                 job.handle, c - 1, v, n[], n), "klara_get_chain")
     v
@@ -287,7 +298,7 @@ function output(job::HIPMCJob, c::Integer=1)
     if !isempty(dkeys)                                      # diagnosticvalues[1, i] = accept flag of saved step i (iterate/MALA.jl:112-117)
         nst = Ref{Clonglong}(0)
         ccall((:klara_get_accept_mask, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Clonglong, Ref{Clonglong}), job.handle, C_NULL, 0, nst)
-        mask = Matrix{UInt8}(undef, job.nchains, nst[])     # step-major rows of nchains bytes == column = step
+        mask = newarray(UInt8, job.nchains, nst[])     # step-major rows of nchains bytes == column = step
         check(ccall((:klara_get_accept_mask, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Clonglong, Ref{Clonglong}), job.handle, mask, nst[], nst), "klara_get_accept_mask")
         for (i, step) in enumerate(job.range.postrange)
             step <= nst[] && (ns.diagnosticvalues[1, i] = mask[c, step] != 0)
@@ -298,20 +309,20 @@ end
 
 # mean(chain) for every chain from the on-device running sums (stats/mean.jl:7-11): D x N
 function chainmeans(job::HIPMCJob)
-    s = Matrix{Float64}(undef, job.ndims, job.nchains); q = similar(s); n = Ref{Clonglong}(0)
+    s = newarray(Float64, job.ndims, job.nchains); q = similar(s); n = Ref{Clonglong}(0)
     check(ccall((:klara_get_chain_sums, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{Clonglong}),
                 job.handle, s, q, n), "klara_get_chain_sums")
     s ./ n[]
 end
 # acceptance rate of every chain over all transitions (stats/acceptance.jl:28-34 counts the saved steps' diagnostics)
 function chainacceptance(job::HIPMCJob)
-    a = Vector{UInt64}(undef, job.nchains); nst = Ref{UInt64}(0)
+    a = newarray(UInt64, job.nchains); nst = Ref{UInt64}(0)
     check(ccall((:klara_get_accept_counts, lib), Cint, (Ptr{Cvoid}, Ptr{UInt64}, Ref{UInt64}), job.handle, a, nst), "klara_get_accept_counts")
     a ./ Float64(nst[])
 end
 # mcvar(chain, Val{:bm}) for every chain and dimension from the streaming batch means (bm_batchlen > 0): D x N, nbatches
 function chainmcvar_bm(job::HIPMCJob)
-    v = Matrix{Float64}(undef, job.ndims, job.nchains); nb = Ref{Clonglong}(0)
+    v = newarray(Float64, job.ndims, job.nchains); nb = Ref{Clonglong}(0)
     check(ccall((:klara_get_chain_bm, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Clonglong}), job.handle, v, nb), "klara_get_chain_bm")
     (v, nb[])
 end
@@ -320,6 +331,15 @@ function streamkey(job::HIPMCJob)
     k = Ref{UInt64}(0); e = Ref{UInt64}(0)
     check(ccall((:klara_stream_key, lib), Cint, (Ptr{Cvoid}, Ref{UInt64}, Ref{UInt64}), job.handle, k, e), "klara_stream_key")
     (k[], e[])
+end
+
+# how the launches were issued so far (klara_get_launch_modes): (4-lane kernel alone, 8-lane kernel alone, device-decided pair), and per
+# chain partition the last decision (0: 4 lanes, 1: 8 lanes) and the accepted proposals of the launch that took it
+function launchmodes(job::HIPMCJob)
+    counts = newarray(Int64, 3); lastmode = newarray(Int32, 4); lastaccepted = newarray(Int64, 4)
+    check(ccall((:klara_get_launch_modes, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Ptr{Int64}), job.handle, counts, lastmode, lastaccepted),
+          "klara_get_launch_modes")
+    (counts, lastmode, lastaccepted)
 end
 
 # user-defined target: compile the closures' C text without a GPU; the compiler's message on failure
@@ -332,7 +352,7 @@ end
 # ---- multi-GPU: one process per GPU; the only exchange is the all-reduce of the pooled summaries (RCCL over xGMI)
 mutable struct HIPComm; handle::Ptr{Cvoid}; end
 function comm_unique_id()
-    id = Vector{UInt8}(undef, 128)
+    id = newarray(UInt8, 128)
     check(ccall((:klara_comm_unique_id, lib), Cint, (Ptr{UInt8},), id), "klara_comm_unique_id")
     id
 end
@@ -340,12 +360,12 @@ function HIPComm(nranks::Integer, rank::Integer, id::Vector{UInt8}, device::Inte
     c = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:klara_comm_init, lib), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Ptr{UInt8}, Cint), c, nranks, rank, id, device), "klara_comm_init")
     comm = HIPComm(c[])
-    finalizer(x -> ccall((:klara_comm_destroy, lib), Cint, (Ptr{Cvoid},), x.handle), comm)
+    on_finalize(comm, x -> ccall((:klara_comm_destroy, lib), Cint, (Ptr{Cvoid},), x.handle))
     comm
 end
 # (sum x, sum x^2 per dimension over every chain of every GPU, accepted, transitions, saved samples, chains)
 function gather_summaries(job::HIPMCJob, comm::HIPComm)
-    s = Vector{Float64}(undef, job.ndims); q = similar(s)
+    s = newarray(Float64, job.ndims); q = similar(s)
     na = Ref{UInt64}(0); nt = Ref{UInt64}(0); ns = Ref{UInt64}(0); nc = Ref{UInt64}(0)
     check(ccall((:klara_gather_summaries, lib), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}),

@@ -72,7 +72,7 @@ class KlaraError(RuntimeError):
 # every symbol include/klara_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "klara_create", "klara_destroy", "klara_set_state", "klara_init_state_normal", "klara_run",
-    "klara_run_async", "klara_synchronize", "klara_reset", "klara_stream_key", "klara_get_state", "klara_get_accept_mask",
+    "klara_run_async", "klara_synchronize", "klara_reset", "klara_stream_key", "klara_get_state", "klara_get_accept_mask", "klara_get_accept_rows",
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
     "klara_get_chain_fields", "klara_get_chain_likelihood_prior", "klara_get_chain_mcvar", "klara_get_chain_mcvar_ipse", "klara_get_chain_acov_mcvar", "klara_saved_steps", "klara_get_chain_bm", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout", "klara_get_launch_modes",
     "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_normal_tail", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
@@ -108,6 +108,7 @@ def load() -> C.CDLL:
         "klara_stream_key": [H, u64p, u64p],
         "klara_get_state": [H, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_get_accept_mask": [H, C.c_void_p, C.c_int64, i64p],
+        "klara_get_accept_rows": [H, C.c_int64, C.c_int64, C.c_void_p],
         "klara_get_accept_counts": [H, C.c_void_p, u64p],
         "klara_get_chain_sums": [H, C.c_void_p, C.c_void_p, i64p],
         "klara_get_pooled_summaries": [H, C.c_void_p, C.c_void_p, u64p, u64p, i64p],

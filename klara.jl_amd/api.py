@@ -279,24 +279,40 @@ def chain_mcvar(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, max
     job = chains._job
     if vtype == "bm" and job.bm_batchlen == batchlen and not (job.engine.monitor & L.MON_HISTORY):
         return job.engine.chain_bm()[0]            # streaming batch means: no history was stored
-    if vtype in ("imse", "ipse") and job.acov_maxlag > 0 and maxlag in (0, job.acov_maxlag) and not (job.engine.monitor & L.MON_HISTORY):
-        imse, ipse, _ = job.engine.chain_acov_mcvar(want=(vtype,))   # autocovariances kept while sampling: no history either
+    streamed = job.acov_maxlag > 0 and not (job.engine.monitor & L.MON_HISTORY)
+    if vtype in ("imse", "ipse") and streamed:
+        # The autocovariances kept while sampling stop at lag acov_maxlag (<= 31); the reference's maxlag = 0 means n - 1
+        # (mcvar.jl:75).  The streamed estimator is therefore only returned for the lag window it was built for — asked for
+        # explicitly, maxlag == acov_maxlag — and anything else needs the stored values (a slowly mixing chain whose
+        # Geyer sequence has not turned non-positive by lag 31 would be silently underestimated).
+        if maxlag != job.acov_maxlag:
+            raise ValueError(f"this job keeps streaming autocovariances up to lag {job.acov_maxlag} and no value history: "
+                             f"mcvar(:{vtype}) is available for maxlag={job.acov_maxlag} only (asked for maxlag={maxlag}, where 0 means n - 1)")
+        imse, ipse, _ = job.engine.chain_acov_mcvar(want=(vtype,))
         return imse if vtype == "imse" else ipse
     if vtype == "ipse":
         return job.engine.chain_mcvar_ipse(maxlag)
     return job.engine.chain_mcvar(batchlen, maxlag, want=(vtype,))[{"iid": 0, "bm": 1, "imse": 2}[vtype]]
 
 
-def chain_ess(chains: MuvChains, vtype: str = "imse", batchlen: int = 100) -> np.ndarray:
+def _mcvar_pair(chains: MuvChains, vtype: str, batchlen: int, maxlag: int):
+    """(mcvar_iid, mcvar_vtype) of every chain and dimension; vtype in {"bm", "imse", "ipse"}."""
+    if vtype not in ("bm", "imse", "ipse"):
+        raise ValueError(f"vtype must be 'bm', 'imse' or 'ipse', not {vtype!r}")
+    has_history = bool(chains._job.engine.monitor & L.MON_HISTORY)      # (two-pass variance over the stored values when they exist)
+    return (chain_mcvar(chains, "iid") if has_history else mcvar_iid(chains)), chain_mcvar(chains, vtype, batchlen, maxlag)
+
+
+def chain_ess(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, maxlag: int = 0) -> np.ndarray:
     """ess(s, vtype) = n * mcvar_iid / mcvar_vtype (stats/convergence/ess.jl:3) for every chain and dimension."""
-    iid, bm, imse = chains._job.engine.chain_mcvar(batchlen, 0, want=("iid", vtype))
-    return chains.n * iid / {"bm": bm, "imse": imse}[vtype]
+    iid, v = _mcvar_pair(chains, vtype, batchlen, maxlag)
+    return chains.n * iid / v
 
 
-def chain_iact(chains: MuvChains, vtype: str = "imse", batchlen: int = 100) -> np.ndarray:
+def chain_iact(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, maxlag: int = 0) -> np.ndarray:
     """iact(s, vtype) = mcvar_vtype / mcvar_iid (stats/convergence/iact.jl:3) for every chain and dimension."""
-    iid, bm, imse = chains._job.engine.chain_mcvar(batchlen, 0, want=("iid", vtype))
-    return {"bm": bm, "imse": imse}[vtype] / iid
+    iid, v = _mcvar_pair(chains, vtype, batchlen, maxlag)
+    return v / iid
 
 
 def acceptance(chains: MuvChains, diagnostics: bool = True) -> np.ndarray:
@@ -311,16 +327,26 @@ def acceptance(chains: MuvChains, diagnostics: bool = True) -> np.ndarray:
 # Determinism contract.  A job's noise is a pure function of (seed, global chain id, transition index) — Philox4x32-10, key =
 # seed (csrc/detmath.h) — so an explicit `seed=` reproduces a job bit for bit on any number of GPUs.  Klara's own jobs draw from
 # Julia's global, unseeded generator: two jobs built the same way are independent (`run([job1, job2])`, jobs.jl:212).  To keep
-# that, a job built WITHOUT `seed=` takes a fresh key: a per-process random base (os.urandom) plus a counter, so chain c of one
-# job never shares its stream with chain c of another; `job.seed` reports the key that was used.
+# that, a job built WITHOUT `seed=` takes a fresh key: splitmix64 of (a per-process random base from os.urandom + a counter), so
+# chain c of one job never shares its stream with chain c of another; `job.seed` reports the key that was used.  The keys are
+# HASHED, not an arithmetic progression: `reset(job)` moves a job to seed + k * KLARA_EPOCH_KEY_STRIDE (include/klara_hip.h), and a
+# progression of default keys with that same stride would make job i after k resets replay job i + k.
 _SEED_BASE = int.from_bytes(os.urandom(8), "little")
 _seed_counter = 0
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+
+def _splitmix64(z: int) -> int:
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
 
 
 def _next_job_seed() -> int:
     global _seed_counter
     _seed_counter += 1
-    return (_SEED_BASE + 0x9E3779B97F4A7C15 * _seed_counter) & 0xFFFFFFFFFFFFFFFF
+    return _splitmix64((_SEED_BASE + _seed_counter) & _M64)
 
 
 # ------------------------------------------------------------------ job (src/jobs/BasicMCJob.jl)
@@ -439,17 +465,18 @@ def run(job):
 def _run_to_iostream(job: "BasicMCJob") -> None:
     """:destination => :iostream — CSV files per monitored field (jobs.jl:193-202; BasicContParamIOStream.jl:152-159), written
     WHILE the job runs: the device keeps a ring of outopts["chunk"] saved steps, the loop below runs until the ring is full (or
-    the job is done), appends those steps to every chain's files and, with :flush, flushes them (jobs.jl:17-29) — the memory a
-    long job needs does not grow with its length."""
+    the job is done), appends those steps to every chain's files and, with :flush, flushes them (jobs.jl:17-29) — the host
+    memory a long job needs does not grow with its length (only the rows of the newly saved steps of the accept diagnostics are read
+    back, klara_get_accept_rows; the device keeps one byte per transition and chain of them)."""
     from .iostream import ChainWriter
     eng = job.engine
     base = job.outopts.get("filepath", "") or "."
     suffix = job.outopts.get("filesuffix", "csv")
     chunk, thin = int(job.outopts["chunk"]), job.range.thinning
     has_v, has_lt, has_g = bool(eng.monitor & L.MON_HISTORY), bool(eng.monitor & L.MON_HIST_LT), bool(eng.monitor & L.MON_HIST_GRAD)
-    has_acc = bool(eng.monitor & L.MON_ACCEPT)
+    has_acc, has_lllp = bool(eng.monitor & L.MON_ACCEPT), bool(eng.monitor & L.MON_HIST_LLLP)
     width = len(str(eng.nchains))
-    writers = [ChainWriter(base if eng.nchains == 1 else os.path.join(base, f"chain_{c + 1:0{width}d}"), suffix, has_v, has_lt, has_g, has_acc)
+    writers = [ChainWriter(base if eng.nchains == 1 else os.path.join(base, f"chain_{c + 1:0{width}d}"), suffix, has_v, has_lt, has_g, has_acc, has_lllp)
                for c in range(eng.nchains)]
     post = np.asarray(job.range.postrange) - 1                    # 0-based transition index of every saved step
     written, done = 0, 0
@@ -462,11 +489,16 @@ def _run_to_iostream(job: "BasicMCJob") -> None:
             if new <= 0:
                 continue
             assert new <= chunk
-            acc = eng.accept_mask()[post[written:written + new]] if has_acc else None
+            acc = None
+            if has_acc:      # only the rows of the newly saved steps come back (not every transition since the start)
+                first, last = int(post[written]), int(post[written + new - 1])
+                acc = eng.accept_rows(first, last - first + 1)[::thin]
             for c, w in enumerate(writers):
                 value = eng.chain(c)[:, -new:] if has_v else None
                 lt, g = eng.chain_fields(c, has_lt, has_g) if (has_lt or has_g) else (None, None)
-                w.append(value, None if lt is None else lt[-new:], None if g is None else g[:, -new:], None if acc is None else acc[:, c])
+                ll, lp = eng.chain_likelihood_prior(c) if has_lllp else (None, None)
+                w.append(value, None if lt is None else lt[-new:], None if g is None else g[:, -new:], None if acc is None else acc[:, c],
+                         None if ll is None else ll[-new:], None if lp is None else lp[-new:])
                 if job.outopts.get("flush", False):
                     w.flush()
             written += new

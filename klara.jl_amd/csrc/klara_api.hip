@@ -767,14 +767,19 @@ extern "C" klara_status klara_reset(klara_handle* h, const double* x_host)
     if (!h) return KLARA_ERR_INVALID_ARG;
     if (!x_host && !h->have_state) return KLARA_ERR_STATE;
     HIPCHK(hipSetDevice(h->d.device));
-    h->epoch += 1;
-    {
+    // the job moves to its next key only if the reset succeeds: a failed one — non-finite initial values, a device
+    // error — leaves the epoch, the key and the device copy of the parameters as they were
+    const auto put_params = [&]() -> klara_status {
         const KParams hp = make_params(h);
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemcpy(h->d_params, &hp, sizeof(KParams), hipMemcpyHostToDevice));
-    }
-    if (x_host) return klara_set_state(h, x_host);
-    return init_common(h);
+        return KLARA_OK;
+    };
+    h->epoch += 1;
+    klara_status st = put_params();
+    if (st == KLARA_OK) st = x_host ? klara_set_state(h, x_host) : init_common(h);
+    if (st != KLARA_OK) { h->epoch -= 1; (void)put_params(); }
+    return st;
 }
 
 extern "C" klara_status klara_stream_key(klara_handle* h, uint64_t* key, uint64_t* epoch)
@@ -1219,6 +1224,18 @@ extern "C" klara_status klara_get_accept_mask(klara_handle* h, uint8_t* mask, in
     const long long n = h->steps_done < capacity_steps ? h->steps_done : capacity_steps;
     if (mask && n > 0) HIPCHK(hipMemcpy(mask, h->accept, (size_t)n * (size_t)h->d.nchains, hipMemcpyDeviceToHost));
     if (nsteps_out) *nsteps_out = h->steps_done;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_accept_rows(klara_handle* h, int64_t first_step, int64_t nsteps, uint8_t* mask)
+{
+    if (!h || first_step < 0 || nsteps < 0 || (nsteps > 0 && !mask)) return KLARA_ERR_INVALID_ARG;
+    if (!h->accept || !h->have_state) return KLARA_ERR_STATE;
+    if (first_step + nsteps > h->steps_done) return KLARA_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (nsteps > 0)
+        HIPCHK(hipMemcpy(mask, h->accept + (size_t)first_step * (size_t)h->d.nchains, (size_t)nsteps * (size_t)h->d.nchains, hipMemcpyDeviceToHost));
     return KLARA_OK;
 }
 

@@ -3,8 +3,8 @@
 Chains are independent (`run(job::Vector) = map(run, job)`, src/jobs/jobs.jl:212), so rank r of R owns the
 block [r*N/R, (r+1)*N/R) and seeds its Philox subsequences with the GLOBAL chain id: results do not depend
 on R.  The only exchange is one end-of-run all-reduce of the pooled chain summaries
-(sum x[D], sum x^2[D], n_accept, n_transitions, n_saved*chains): (2D+3) doubles ~ 1.6 kB at D = 100,
-latency-bound over RCCL/xGMI.  Backend "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests.
+(sum x[D], sum x^2[D], n_accept, n_transitions, n_saved*chains): (2D+3) doubles ~ 1.6 kB at D = 100 (+ D doubles for the
+between-rank term of the pooled variance), latency-bound over RCCL/xGMI.  Backend "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests.
 """
 from __future__ import annotations
 
@@ -21,32 +21,55 @@ def shard_chains(nchains_total: int, rank: int, world: int) -> Tuple[int, int]:
     return offset, count
 
 
-def allreduce_summaries(local: Dict[str, np.ndarray], group=None, device=None) -> Dict[str, np.ndarray]:
-    """SUM-all-reduce of pooled summaries; `local` holds sum[D], sumsq[D], naccept, ntransitions, nsamples.
+def _local_moments(s: np.ndarray, q: np.ndarray, n: float):
+    """(mean, M2 = sum (x - mean)^2) per dimension from raw sums, with the subtraction done in exact rational arithmetic: q - s^2/n
+    loses mean^2/var digits to cancellation when it is evaluated in doubles (rats alpha_c: mean 242, sd 2.7 -> 4 digits); evaluated
+    exactly, the only error left is the rounding already inside the raw sums themselves."""
+    from fractions import Fraction
+    if n <= 0:
+        return np.zeros_like(s), np.zeros_like(s)
+    nn = Fraction(int(n))
+    mean = np.array([float(Fraction(float(v)) / nn) for v in s])
+    m2 = np.array([float(Fraction(float(b)) - Fraction(float(a)) ** 2 / nn) for a, b in zip(s, q)])
+    return mean, np.maximum(m2, 0.0)
 
-    Returns the global sums plus derived posterior moments (mean, var) and the acceptance rate.
-    Works without torch.distributed initialised (single process) — then it only derives the moments.
+
+def allreduce_summaries(local: Dict[str, np.ndarray], group=None, device=None) -> Dict[str, np.ndarray]:
+    """All-reduce of pooled summaries; `local` holds sum[D], sumsq[D], naccept, ntransitions, nsamples of this rank's chains.
+
+    Returns the global sums plus derived posterior moments (mean, var) and the acceptance rate.  The variance is NOT formed as
+    sumsq/n - mean^2 from the reduced raw sums: every rank turns its sums into (n_r, mean_r, M2_r) exactly (_local_moments) and
+    the ranks are combined by Chan's formula, M2 = sum_r M2_r + sum_r n_r (mean_r - mean)^2 — two SUM all-reduces of (2D + 3) and
+    D doubles.  Works without torch.distributed initialised (single process) — then it only derives the moments.
     """
     import torch
     import torch.distributed as dist
 
     d = int(np.asarray(local["sum"]).size)
-    buf = np.concatenate([np.asarray(local["sum"], dtype=np.float64).ravel(),
-                          np.asarray(local["sumsq"], dtype=np.float64).ravel(),
-                          np.array([local["naccept"], local["ntransitions"], local["nsamples"]], dtype=np.float64)])
-    if dist.is_available() and dist.is_initialized():
-        if device is None:
-            device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    s_l = np.asarray(local["sum"], dtype=np.float64).ravel(); q_l = np.asarray(local["sumsq"], dtype=np.float64).ravel()
+    n_l = float(local["nsamples"])
+    live = dist.is_available() and dist.is_initialized()
+    if live and device is None:
+        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+    def reduce_sum(buf: np.ndarray) -> np.ndarray:
+        if not live:
+            return buf
         t = torch.from_numpy(buf).to(device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        buf = t.cpu().numpy()
+        return t.cpu().numpy()
+
+    buf = reduce_sum(np.concatenate([s_l, q_l, np.array([local["naccept"], local["ntransitions"], n_l], dtype=np.float64)]))
     s, q = buf[:d], buf[d:2 * d]
     nacc, ntr, ns = buf[2 * d], buf[2 * d + 1], buf[2 * d + 2]
     out = {"sum": s, "sumsq": q, "naccept": nacc, "ntransitions": ntr, "nsamples": ns}
     if ns > 0:
-        m = s / ns
-        out["mean"] = m
-        out["var"] = q / ns - m * m
+        from fractions import Fraction
+        mean = np.array([float(Fraction(float(v)) / Fraction(int(ns))) for v in s])
+        mean_l, m2_l = _local_moments(s_l, q_l, n_l)
+        m2 = reduce_sum(m2_l + n_l * (mean_l - mean) ** 2)          # Chan: within-rank + between-rank sums of squares
+        out["mean"] = mean
+        out["var"] = m2 / ns
     if ntr > 0:
         out["acceptance"] = nacc / ntr
     return out

@@ -313,6 +313,12 @@ class Engine:
         L.check(self._lib.klara_get_accept_mask(self._h, m.ctypes.data, n.value, C.byref(n)), "klara_get_accept_mask")
         return m
 
+    def accept_rows(self, first_step: int, nsteps: int) -> np.ndarray:
+        """accept diagnostics of the transitions [first_step, first_step + nsteps) only: (nsteps, nchains) bytes"""
+        m = np.empty((int(nsteps), self.nchains), dtype=np.uint8)
+        L.check(self._lib.klara_get_accept_rows(self._h, int(first_step), int(nsteps), m.ctypes.data), "klara_get_accept_rows")
+        return m
+
     def accept_counts(self):
         a = np.empty(self.nchains, dtype=np.uint64); n = C.c_uint64(0)
         L.check(self._lib.klara_get_accept_counts(self._h, a.ctypes.data, C.byref(n)), "klara_get_accept_counts")

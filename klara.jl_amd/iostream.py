@@ -70,14 +70,20 @@ class ChainWriter:
     `append` writes the lines of newly saved steps, `flush` is `flush(iostream)` (:141-149), so a long job streams to disk with
     bounded memory instead of holding every saved step (jobs.jl:17-29 `:flush`)."""
 
-    def __init__(self, directory: str, suffix: str, value: bool, logtarget: bool, gradlogtarget: bool, accept: bool):
+    def __init__(self, directory: str, suffix: str, value: bool, logtarget: bool, gradlogtarget: bool, accept: bool,
+                 likelihood_prior: bool = False):
         os.makedirs(directory, exist_ok=True)
         mk = lambda name, on: open(os.path.join(directory, f"{name}.{suffix}"), "w") if on else None
-        self.files = {"value": mk("value", value), "logtarget": mk("logtarget", logtarget),
+        # one file per monitored field, named after the field (BasicContParamIOStream.jl:64-82)
+        self.files = {"value": mk("value", value), "loglikelihood": mk("loglikelihood", likelihood_prior), "logprior": mk("logprior", likelihood_prior),
+                      "logtarget": mk("logtarget", logtarget),
                       "gradlogtarget": mk("gradlogtarget", gradlogtarget), "diagnosticvalues": mk("diagnosticvalues", accept)}
 
-    def append(self, value=None, logtarget=None, gradlogtarget=None, accept=None) -> None:
+    def append(self, value=None, logtarget=None, gradlogtarget=None, accept=None, loglikelihood=None, logprior=None) -> None:
         f = self.files
+        for name, series in (("loglikelihood", loglikelihood), ("logprior", logprior)):
+            if f[name] is not None and series is not None:
+                f[name].writelines(julia_float_repr(float(v)) + "\n" for v in series)
         if f["value"] is not None and value is not None:
             f["value"].writelines(_line(value[:, i]) for i in range(value.shape[1]))
         if f["logtarget"] is not None and logtarget is not None:

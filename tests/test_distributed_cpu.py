@@ -51,6 +51,48 @@ def test_summary_allreduce_world2():
         assert a == 7 / 60
 
 
+def _worker_offset(rank, world, port, q):
+    """the same exchange on data with |mean| >> sd (the rats model's alpha_c: mean 242, sd 2.7): raw sums formed exactly (math.fsum)"""
+    import math, sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import torch.distributed as dist
+    import klara_jl_amd as K
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = 242.0 + 2.7 * np.random.default_rng(5).standard_normal((4000, 2)); x[:, 1] *= 1e-3
+    off, cnt = K.shard_chains(4000, rank, world)
+    mine = x[off:off + cnt]
+    local = {"sum": np.array([math.fsum(mine[:, j]) for j in range(2)]), "sumsq": np.array([math.fsum(mine[:, j] ** 2) for j in range(2)]),
+             "naccept": 1, "ntransitions": 2, "nsamples": cnt}
+    out = K.allreduce_summaries(local)
+    q.put((rank, out["mean"], out["var"]))
+    dist.destroy_process_group()
+
+
+def test_pooled_variance_of_offset_data_over_two_ranks():
+    """the pooled variance of the all-reduced summaries on data whose mean is ~90 standard deviations from zero.
+    Per-rank (n, mean, M2) from exact rational arithmetic, Chan's combination across the ranks: within 1e-12 (relative) of the
+    variance computed in exact arithmetic from the samples — what is left is the rounding of the squares and of the raw sums."""
+    from fractions import Fraction
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker_offset, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    x = 242.0 + 2.7 * np.random.default_rng(5).standard_normal((4000, 2)); x[:, 1] *= 1e-3
+    for j in range(2):
+        fx = [Fraction(float(v)) for v in x[:, j]]
+        m = sum(fx) / len(fx)
+        var = float(sum((v - m) ** 2 for v in fx) / len(fx))
+        for _, mean, v in res:
+            assert abs(mean[j] - float(m)) <= 1e-15 * abs(float(m))
+            assert abs(v[j] - var) <= 1e-12 * var, (j, v[j], var)
+
+
 def test_allreduce_single_process_derives_moments():
     import klara_jl_amd as K
     x = np.random.default_rng(1).standard_normal((40, 2))

@@ -90,6 +90,61 @@ def test_sharded_job_and_rccl_summary_gather_through_the_c_abi():
     ref.close()
 
 
+def _gloo_rank_main(rank, world, port, out_q):
+    """one rank of a 2-rank job: a real Engine shard on cuda:0, the summaries all-reduced by torch.distributed (gloo)"""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    try:
+        import torch.distributed as dist
+        import klara_jl_amd as K
+        from klara_jl_amd import _lib as L
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        offset, n = K.shard_chains(NCHAINS, rank, world)
+        eng = _engine(K, L, n, offset, 0)
+        eng.init_state_normal(); eng.run(NSTEPS)
+        out = K.gather_engine_summaries(eng)                # the path's one exchange (distributed.py), here over gloo
+        x, lt, g = eng.state()
+        out_q.put((rank, offset, n, out, x, lt, g, None))
+        eng.close(); dist.destroy_process_group()
+    except Exception as exc:
+        out_q.put((rank, 0, 0, None, None, None, None, repr(exc)))
+
+
+def test_two_engine_shards_on_one_device_over_gloo():
+    """the N > 1 path with REAL engines on a one-GPU box — two processes, each a shard of the job (global chain ids
+    through chain_offset) on cuda:0, summaries all-reduced over gloo: per-chain states bit-identical to the unsharded job, all-reduced
+    sums and moments equal to the unsharded job's to 1e-12."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_rank_main, args=(r, 2, port, out_q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [out_q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    errs = [r[-1] for r in results if r[-1] is not None]
+    assert not errs, errs
+    import klara_jl_amd as K
+    from klara_jl_amd import _lib as L
+    ref = _engine(K, L, NCHAINS, 0, 0)
+    ref.init_state_normal(); ref.run(NSTEPS)
+    x, lt, g = ref.state()
+    whole = K.gather_engine_summaries(ref)                  # (no process group in this process: the unsharded job's own moments)
+    assert sum(r[2] for r in results) == NCHAINS
+    for rank, offset, n, out, rx, rlt, rg, _ in results:
+        sl = slice(offset, offset + n)
+        assert np.array_equal(rx, x[sl]) and np.array_equal(rlt, lt[sl]) and np.array_equal(rg, g[sl]), rank
+        assert out["nsamples"] == whole["nsamples"] == (NSTEPS - BURNIN) * NCHAINS and out["naccept"] == whole["naccept"]
+        assert np.allclose(out["sum"], whole["sum"], rtol=1e-12, atol=1e-9) and np.allclose(out["sumsq"], whole["sumsq"], rtol=1e-12)
+        assert np.allclose(out["mean"], whole["mean"], rtol=1e-12, atol=1e-13) and np.allclose(out["var"], whole["var"], rtol=1e-12)
+    ref.close()
+
+
 def test_bench_two_ranks_on_one_device_logic():
     """`bench.py --gpus 2` the way the driver launches it (python -m torch.distributed.run, one process per rank), on ONE device with the
     gloo backend (`--same-device`: RCCL refuses two ranks on one GPU) — the rank / shard / barrier / max-over-ranks / summary all-reduce
@@ -115,6 +170,8 @@ def test_bench_two_ranks_on_one_device_logic():
     assert d["config"]["nchains_total"] == 2 * d["config"]["nchains_per_gpu"] and d["config"]["rccl_ranks_seen"] == 2
     assert d["value"] == pytest.approx(d["config"]["nchains_total"] * 20 / (d["ms_per_step"] * 20e-3), rel=1e-9)
     assert d["roofline"]["bound"] == "valu" and "cpu_baseline" not in d
+    assert len(d["config"]["per_rank_ms_per_step"]) == 2 and d["config"]["rank_time_max_over_min"] >= 1.0
+    assert max(d["config"]["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"], rel=0.2)
 
 
 def test_bench_single_gpu_line_at_the_drivers_flags():

@@ -517,6 +517,16 @@ def test_reset_rewinds_the_job():
         eng.run(case["nsteps"]); assert job.run(case["nsteps"]) == 0
         _assert_same(eng, job, case)
         assert not np.array_equal(eng.accept_mask(), m1)
+    # a reset that fails (non-finite values) leaves the job on its key: no epoch for a reset that did not happen
+    bad = x0.copy(); bad[1, 2] = np.inf
+    with pytest.raises(K.KlaraError) as ei:
+        eng.reset(bad)
+    assert ei.value.status == L.ERR_NONFINITE_INIT
+    assert eng.stream_key() == ((case["seed"] + 2 * 0x9E3779B97F4A7C15) % 2 ** 64, 2)
+    eng.reset(x0); assert job.reset(x0) == 0                                               # ... and the next good one is reset number 3
+    assert eng.stream_key() == ((case["seed"] + 3 * 0x9E3779B97F4A7C15) % 2 ** 64, 3)
+    eng.run(case["nsteps"]); assert job.run(case["nsteps"]) == 0
+    _assert_same(eng, job, case)
     eng.close()
     eng = K.Engine(**cases.engine_kwargs(case)); eng.set_state(x0); eng.run(case["nsteps"])
     assert np.array_equal(eng.state()[0], x1) and np.array_equal(eng.accept_mask(), m1)
@@ -1081,6 +1091,35 @@ def test_likelihood_prior_closures_through_the_job_api():
         K.BasicMCJob(K.likelihood_model(K.BasicContMuvParameter("p", logtarget=K.GaussDiagTarget.negdot(3)), False), K.MALA(0.4),
                      K.BasicMCRange(nsteps=5), {"p": np.zeros((2, 3))}, outopts={"monitor": ["value", "loglikelihood"]})
     job.close()
+
+
+def test_iostream_sink_writes_the_likelihood_and_prior_files(tmp_path):
+    """:destination => :iostream with :monitor => [:value, :loglikelihood, :logprior] (BasicContParamIOStream.jl:64-82: one file per
+    monitored field): loglikelihood.csv / logprior.csv are written chunk by chunk next to value.csv, their lines are the in-memory
+    job's values, and the accept diagnostics come back through the windowed read (klara_get_accept_rows) — ADVICE r2."""
+    from klara_jl_amd.iostream import julia_float_repr as j
+    case = cases.make_case("custom_normal_normal_mala")
+    t = case["target"]
+    mk = lambda: K.BasicContMuvParameter("p", loglikelihood=cases.SRC_NN_LL, logprior=cases.SRC_NN_LP, gradloglikelihood=cases.SRC_NN_GLL,
+                                         gradlogprior=cases.SRC_NN_GLP, ndims=6, data=t.data)
+    rng_ = K.BasicMCRange(nsteps=47, burnin=10, thinning=3)
+    mem = K.BasicMCJob(K.likelihood_model(mk(), False), K.MALA(0.4), rng_, {"p": case["x0"]},
+                       outopts={"monitor": ["value", "loglikelihood", "logprior"], "diagnostics": ["accept"]}, seed=20260927)
+    K.run(mem); chain = K.output(mem)
+    job = K.BasicMCJob(K.likelihood_model(mk(), False), K.MALA(0.4), rng_, {"p": case["x0"]},
+                       outopts={"destination": "iostream", "filepath": str(tmp_path / "s"), "monitor": ["value", "loglikelihood", "logprior"],
+                                "diagnostics": ["accept"], "chunk": 5}, seed=20260927)
+    K.run(job)
+    post = np.arange(11, 48, 3) - 1
+    rows = mem.engine.accept_rows(int(post[2]), int(post[6] - post[2] + 1))
+    assert np.array_equal(rows, mem.engine.accept_mask()[post[2]:post[6] + 1])
+    for c in (0, 41, 69):
+        d = tmp_path / "s" / f"chain_{c + 1:02d}"
+        assert (d / "loglikelihood.csv").read_text().splitlines() == [j(v) for v in chain.loglikelihood(c)]
+        assert (d / "logprior.csv").read_text().splitlines() == [j(v) for v in chain.logprior(c)]
+        assert (d / "value.csv").read_text().splitlines() == [",".join(j(v) for v in chain.value(c)[:, i]) for i in range(len(post))]
+        assert (d / "diagnosticvalues.csv").read_text().splitlines() == ["true" if a else "false" for a in mem.engine.accept_mask()[post, c]]
+    job.close(); mem.close()
 
 
 # ------------------------------------------------------------------ full-size parity on sampled chains

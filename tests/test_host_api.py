@@ -114,6 +114,74 @@ def test_integration_md_prints_the_julia_module_verbatim():
     assert "```julia\n" + jl + "```" in (ROOT / "INTEGRATION.md").read_text()
 
 
+def _julia_code_tokens(src):
+    """Julia source with comments, strings and character / symbol literals blanked (what is left is code structure)."""
+    import re
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c == "#":                                   # (no #= =# block comments in the file: asserted by the caller)
+            while i < n and src[i] != "\n":
+                i += 1
+        elif c == '"':
+            i += 1
+            while i < n and src[i] != '"':
+                i += 2 if src[i] == "\\" else 1
+            i += 1; out.append(' "" ')
+        elif c == "'" and i + 2 < n and src[i + 2] == "'":          # a character literal (the file uses ' for transposes nowhere)
+            i += 3; out.append(" 'c' ")
+        else:
+            out.append(c); i += 1
+    return "".join(out)
+
+
+def test_julia_module_is_structurally_valid_for_0_6_and_later():
+    """julia/KlaraHIP.jl must load next to Klara itself, i.e. on Julia 0.6 (/root/reference/REQUIRE:1) as well as on
+    >= 0.7.  No Julia here, so: (1) block openers and `end`s balance, brackets balance and never cross a block boundary; (2) the
+    version-dependent constructs (`Void` / `Cvoid` alias, uninitialised arrays, the argument order of `finalizer`) occur ONLY inside
+    the `@static if VERSION < v"0.7.0-"` compatibility block; (3) nothing that only one of the two syntaxes accepts is used."""
+    import re
+    src = (ROOT / "julia" / "KlaraHIP.jl").read_text()
+    assert "#=" not in src and "=#" not in src
+    code = _julia_code_tokens(src)
+    # (1) blocks: every opener keyword at statement level needs an `end`
+    toks = re.findall(r"@static|[A-Za-z_][A-Za-z_0-9!]*|[()\[\]{}]|:+", code)
+    depth, stack, brackets = 0, [], []
+    openers = {"function", "if", "for", "while", "struct", "module", "let", "begin", "try", "do", "quote", "macro"}
+    prev = ""
+    for tk in toks:
+        if tk in "([{":
+            brackets.append((tk, len(stack)))
+        elif tk in ")]}":
+            assert brackets, "unbalanced closing bracket"
+            op, d = brackets.pop()
+            assert {"(": ")", "[": "]", "{": "}"}[op] == tk and d == len(stack), "a bracket pair crosses a block boundary"
+        elif prev.endswith(":") and prev != "::" and tk in openers | {"end", "type"}:
+            pass                                        # a symbol literal such as :function (none expected, but not a block)
+        elif tk in openers or (tk == "type" and prev == "abstract"):
+            assert not brackets or tk in ("if", "for"), f"block opener {tk} inside brackets"
+            if not brackets:
+                stack.append(tk)
+        elif tk == "end":
+            assert not brackets, "`end` inside brackets (indexing with end is not used in this file)"
+            assert stack, "`end` without an opener"
+            stack.pop()
+        prev = tk
+    assert not stack and not brackets, (stack, brackets)
+    assert toks.count("module") == 1 and code.rstrip().endswith("end")
+    # (2) version-dependent constructs are confined to the compatibility block
+    a = src.index('@static if VERSION < v"0.7.0-"'); b = src.index("\nend\n", a) + 5
+    compat, rest = src[a:b], _julia_code_tokens(src[:a] + src[b:])
+    assert "const Cvoid = Void" in compat and "Array{T}(dims...)" in compat and "Array{T}(undef, dims...)" in compat
+    assert "finalizer(obj, f)" in compat and "finalizer(f, obj)" in compat
+    for banned in (r"\bundef\b", r"\bVoid\b", r"\bfinalizer\(", r"\bNothing\b", r"\bcodeunits\b", r"\bfindfirst\b", r"\bimmutable\b",
+                   r"(?<!abstract )\btype\b", r"\bisnothing\b", r"\bcontains\(", r"\bsomething\("):
+        assert not re.search(banned, rest), banned
+    # (3) 0.6 has no `Array{T}(undef, ...)`, >= 0.7 has no `Array{T}(dims)`: outside the block arrays come from newarray / literals / similar
+    assert not re.search(r"\b(Array|Vector|Matrix)\{[^}]*\}\(", rest)
+    assert rest.count("newarray(") >= 8 and rest.count("on_finalize(") == 3
+
+
 def test_julia_stub_binds_only_declared_symbols():
     import re
     jl = (ROOT / "julia" / "KlaraHIP.jl").read_text()
@@ -245,6 +313,13 @@ def test_jobs_built_without_a_seed_get_distinct_streams():
     from klara_jl_amd import api
     a, b, c = api._next_job_seed(), api._next_job_seed(), api._next_job_seed()
     assert len({a, b, c}) == 3 and all(0 <= v < 2 ** 64 for v in (a, b, c))
+    # reset(job) moves a job to seed + k * KLARA_EPOCH_KEY_STRIDE; no default key of a later job may sit on that
+    # progression (job i after k resets must not replay job i + k): the default keys are hashed, not equally spaced
+    stride = 0x9E3779B97F4A7C15
+    keys = [api._next_job_seed() for _ in range(64)]
+    reset_keys = {(keys[i] + k * stride) % 2 ** 64 for i in range(64) for k in range(1, 65)}
+    assert not (reset_keys & set(keys))
+    assert api._splitmix64(0) == 0xE220A8397B1DCDAF and api._splitmix64(1) == 0x910A2DEC89025CC1      # Vigna's reference values
     import inspect
     assert inspect.signature(api.BasicMCJob.__init__).parameters["seed"].default is None
 
