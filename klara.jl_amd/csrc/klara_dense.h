@@ -143,7 +143,8 @@ __device__ __forceinline__ void mnormals(const MfmaCtx<NE>& c, unsigned long lon
 // footprint (the tail's A fragments take the place of the padded tile's), 10.7 % less matrix-pipe time at D = 100.
 // Its accumulation order is the same k-ascending fma chain (tests/test_gpu_parity.py::test_mfma_f64_4x4x4_order).
 // HASMU: the B operand is x - mu, mu read per k-step from LDS (ldsMu[4 kk + q], zero for missing elements).
-template <int NE, bool HASMU = false>
+// NEG = false returns +P (x - mu) (the leapfrog folds the sign into its fma: p = fma(-k, P x, p)).
+template <int NE, bool HASMU = false, bool NEG = true>
 __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int lane,
                                            const double (&x)[NE], double (&g)[4 * ((NE + 3) / 4)], const double* ldsMu = nullptr)
 {
@@ -176,10 +177,10 @@ __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int 
     }
 #pragma unroll
     for (int t = 0; t < MTF; ++t) {
-        g[4 * t + 0] = -acc[t][0]; g[4 * t + 1] = -acc[t][1];
-        g[4 * t + 2] = -acc[t][2]; g[4 * t + 3] = -acc[t][3];
+        g[4 * t + 0] = NEG ? -acc[t][0] : acc[t][0]; g[4 * t + 1] = NEG ? -acc[t][1] : acc[t][1];
+        g[4 * t + 2] = NEG ? -acc[t][2] : acc[t][2]; g[4 * t + 3] = NEG ? -acc[t][3] : acc[t][3];
     }
-    if (TAIL) { g[4 * MTF + 0] = -acc_t; g[4 * MTF + 1] = 0.0; g[4 * MTF + 2] = 0.0; g[4 * MTF + 3] = 0.0; }
+    if (TAIL) { g[4 * MTF + 0] = NEG ? -acc_t : acc_t; g[4 * MTF + 1] = 0.0; g[4 * MTF + 2] = 0.0; g[4 * MTF + 3] = 0.0; }
 }
 
 template <int SAMPLER, int NE, bool DA, bool HASMU = false>
@@ -241,33 +242,41 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             // dual averaging: per-chain trip count (iterate/HMC.jl:142-144); the 16 chains of the tile run to the
             // longest trajectory, a finished chain's lanes re-use their frozen state (its MFMA columns are
             // recomputed but discarded)
+            // leapfrog! L times (HMC.jl:146-155, samplers.jl:122-134) in its merged form — DESIGN.md section 2, deliberate deviation (7),
+            // mirrored by the oracle for this layout: adjacent half-kicks are one update and every update is one fma, with the
+            // gradient's sign folded in (the matrix cores return +P (x - mu)):
+            //   p = fma(eps/2, g, p);  L x { x = fma(eps, p, x);  a = P (x - mu);  p = fma(-(l < L-1 ? eps : eps/2), a, p) };  g = -a
+            // 2 NE instead of 6 NE + 4 MT vector instructions per gradient beside the MFMAs, which run on the same FP64 units.
+#pragma unroll
+            for (int e = 0; e < NE; ++e) mom[e] = kd_fma(halfe, gp[e], mom[e]);
             if (!da) {
-                for (int l = 0; l < p.nleaps; ++l) {                   // HMC.jl:146-155
+                const int nl = p.nleaps;
+                for (int l = 0; l < nl; ++l) {
 #pragma unroll
-                    for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];   // samplers.jl:130
+                    for (int e = 0; e < NE; ++e) xp[e] = kd_fma(eps, mom[e], xp[e]);
+                    dense_grad<NE, HASMU, false>(ldsP, cx.lane, xp, gp, ldsMu);
+                    const double nkf = l + 1 < nl ? -eps : -halfe;
 #pragma unroll
-                    for (int e = 0; e < NE; ++e) xp[e] = xp[e] + eps * mom[e];      // samplers.jl:131
-                    dense_grad<NE, HASMU>(ldsP, cx.lane, xp, gp, ldsMu);                          // samplers.jl:132
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];   // samplers.jl:133
+                    for (int e = 0; e < NE; ++e) mom[e] = kd_fma(nkf, gp[e], mom[e]);
                 }
+#pragma unroll
+                for (int e = 0; e < NG; ++e) gp[e] = -gp[e];
             } else {
                 const int nl = cx.chain_ok ? da_nleaps(p, eps) : 1;      // (a padding lane must not set the wavefront's trip count)
                 for (int l = 0; __any(l < nl); ++l) {
                     const bool go = l < nl;
                     if (go) {
 #pragma unroll
-                        for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];
-#pragma unroll
-                        for (int e = 0; e < NE; ++e) xp[e] = xp[e] + eps * mom[e];
+                        for (int e = 0; e < NE; ++e) xp[e] = kd_fma(eps, mom[e], xp[e]);
                     }
                     double gn[NG];
-                    dense_grad<NE, HASMU>(ldsP, cx.lane, xp, gn, ldsMu);
+                    dense_grad<NE, HASMU, false>(ldsP, cx.lane, xp, gn, ldsMu);
                     if (go) {
+                        const double nkf = l + 1 < nl ? -eps : -halfe;
 #pragma unroll
-                        for (int e = 0; e < NG; ++e) gp[e] = gn[e];
+                        for (int e = 0; e < NG; ++e) gp[e] = -gn[e];
 #pragma unroll
-                        for (int e = 0; e < NE; ++e) mom[e] = mom[e] + halfe * gp[e];
+                        for (int e = 0; e < NE; ++e) mom[e] = kd_fma(nkf, gn[e], mom[e]);
                     }
                 }
             }

@@ -516,7 +516,7 @@ KLARA_PRAGMA_UNROLL_E
             const double u = kd_fma(Td, ai, -2.0 * Sy[pr]);
             const double v = kd_fma(bi, X2, kd_fma(2.0 * ai, X1, -2.0 * Sxy[pr]));
             const double S2 = kd_fma(bi, v, kd_fma(ai, u, Syy[pr]));
-            if (WANT_GRAD) { g[2 * pr] = wc * S1 - wa * da; g[2 * pr + 1] = wc * Sx - wb * db; }
+            if (WANT_GRAD) { g[2 * pr] = kd_fma(wc, S1, -(wa * da)); g[2 * pr + 1] = kd_fma(wc, Sx, -(wb * db)); }
             // element order within the lane: a-slot terms then b-slot terms, exactly the oracle's term arrays
             red[0] = red[0] + (israt ? da : 0.0);        red[1] = red[1] + 0.0;
             red[2] = red[2] + (israt ? da * da : 0.0);   red[3] = red[3] + 0.0;
@@ -532,11 +532,11 @@ KLARA_PRAGMA_UNROLL_E
 KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) {
                 const int i = i0 + e;
-                if (i == 2 * R) g[e] = wa * A1 - p0 * ac;
-                else if (i == 2 * R + 1) g[e] = wb * B1 - p0 * bc;
-                else if (i == 2 * R + 2) g[e] = ((wc * C2 - RT) - 2.0 * a0) + (2.0 * b0) * wc;
-                else if (i == 2 * R + 3) g[e] = ((wa * A2 - Rd) - 2.0 * a0) + (2.0 * b0) * wa;
-                else if (i == 2 * R + 4) g[e] = ((wb * B2 - Rd) - 2.0 * a0) + (2.0 * b0) * wb;
+                if (i == 2 * R) g[e] = kd_fma(wa, A1, -(p0 * ac));
+                else if (i == 2 * R + 1) g[e] = kd_fma(wb, B1, -(p0 * bc));
+                else if (i == 2 * R + 2) g[e] = kd_fma(2.0 * b0, wc, kd_fma(wc, C2, -RT) - 2.0 * a0);
+                else if (i == 2 * R + 3) g[e] = kd_fma(2.0 * b0, wa, kd_fma(wa, A2, -Rd) - 2.0 * a0);
+                else if (i == 2 * R + 4) g[e] = kd_fma(2.0 * b0, wb, kd_fma(wb, B2, -Rd) - 2.0 * a0);
                 else if (i > 2 * R + 4) g[e] = 0.0;
             }
         }

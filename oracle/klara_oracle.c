@@ -81,6 +81,20 @@ static double ko_reduce(const ko_layout* L, const double* terms, int D)
     return part[0];
 }
 
+/* the same reduction of the products a[i] * b[i], every lane partial accumulated as fma(a, b, partial) */
+static double ko_reduce_prod(const ko_layout* L, const double* a, const double* b, int D)
+{
+    double part[64], nw[64];
+    const int G = L->G;
+    for (int l = 0; l < G; ++l) part[l] = 0.0;
+    for (int i = 0; i < D; ++i) { const int lane = i / L->E; part[lane] = kd_fma(a[i], b[i], part[lane]); }     /* (contiguous rule only) */
+    for (int m = 1; m < G; m <<= 1) {
+        for (int l = 0; l < G; ++l) nw[l] = part[l] + part[l ^ m];
+        memcpy(part, nw, sizeof(double) * (size_t)G);
+    }
+    return part[0];
+}
+
 /* ------------------------------------------------------------------ tuner scores */
 /* src/stats/logistic.jl:11  logistic(x, l, k, x0, y0) = l/(1+exp(-k*(x-x0)))+y0 */
 double ko_logistic(double x, double l, double k, double x0, double y0)
@@ -255,7 +269,7 @@ static double ko_hier_eval(const ko_target_ctx* c, const double* th, double* g, 
         const double u = kd_fma(Td, ai, -2.0 * Sy);
         const double v = kd_fma(bi, X2, kd_fma(2.0 * ai, X1, -2.0 * Sxy));
         const double S2 = kd_fma(bi, v, kd_fma(ai, u, Syy));
-        if (g) { g[2 * i] = wc * S1 - wa * da; g[2 * i + 1] = wc * Sx - wb * db; }
+        if (g) { g[2 * i] = kd_fma(wc, S1, -(wa * da)); g[2 * i + 1] = kd_fma(wc, Sx, -(wb * db)); }
         tA1[2 * i] = da; tA2[2 * i] = da * da; tC2[2 * i] = S2;
         tB1[2 * i + 1] = db; tB2[2 * i + 1] = db * db;
     }
@@ -266,18 +280,20 @@ static double ko_hier_eval(const ko_target_ctx* c, const double* th, double* g, 
         for (int i = 0; i < R; ++i) { uA1[i] = tA1[2 * i]; uA2[i] = tA2[2 * i]; uC2[i] = tC2[2 * i]; uB1[i] = tB1[2 * i + 1]; uB2[i] = tB2[2 * i + 1]; }
         const ko_layout U = { 0, c->L->G, c->L->E / 2 };      /* unit r on lane r / (E/2): the contiguous rule */
         A1 = ko_reduce(&U, uA1, R); B1 = ko_reduce(&U, uB1, R);
-        A2 = ko_reduce(&U, uA2, R); B2 = ko_reduce(&U, uB2, R); C2 = ko_reduce(&U, uC2, R);
+        /* the sums of squares accumulate the products themselves: partial = fma(d, d, partial) (klara_hiert.h hier_eval) */
+        A2 = ko_reduce_prod(&U, uA1, uA1, R); B2 = ko_reduce_prod(&U, uB1, uB1, R); C2 = ko_reduce(&U, uC2, R);
+        (void)uA2; (void)uB2;
     } else {
         A1 = ko_reduce(c->L, tA1, D); B1 = ko_reduce(c->L, tB1, D);
         A2 = ko_reduce(c->L, tA2, D); B2 = ko_reduce(c->L, tB2, D); C2 = ko_reduce(c->L, tC2, D);
     }
     const double RT = (double)R * (double)T, Rd = (double)R;
     if (g) {
-        g[2 * R] = wa * A1 - p0 * ac;
-        g[2 * R + 1] = wb * B1 - p0 * bc;
-        g[2 * R + 2] = ((wc * C2 - RT) - 2.0 * a0) + (2.0 * b0) * wc;
-        g[2 * R + 3] = ((wa * A2 - Rd) - 2.0 * a0) + (2.0 * b0) * wa;
-        g[2 * R + 4] = ((wb * B2 - Rd) - 2.0 * a0) + (2.0 * b0) * wb;
+        g[2 * R] = kd_fma(wa, A1, -(p0 * ac));
+        g[2 * R + 1] = kd_fma(wb, B1, -(p0 * bc));
+        g[2 * R + 2] = kd_fma(2.0 * b0, wc, kd_fma(wc, C2, -RT) - 2.0 * a0);
+        g[2 * R + 3] = kd_fma(2.0 * b0, wa, kd_fma(wa, A2, -Rd) - 2.0 * a0);
+        g[2 * R + 4] = kd_fma(2.0 * b0, wb, kd_fma(wb, B2, -Rd) - 2.0 * a0);
     }
     const double l_c = (-RT * sc - 0.5 * (wc * C2)) + (-2.0 * a0 * sc - b0 * wc);
     const double l_a = (-Rd * sa - 0.5 * (wa * A2)) + (-2.0 * a0 * sa - b0 * wa);
@@ -431,6 +447,10 @@ static int ko_mala(const ko_target_ctx* c, uint64_t chain, uint64_t t, double h,
     return acc;
 }
 
+/* which jobs take the merged leapfrog (see ko_hmc): the ones the device runs on its few-lanes hierarchical kernels (layout kind 4)
+ * and on the matrix-core kernels of the dense target (kind 1) */
+static int ko_merged_leapfrog(const ko_target_ctx* c) { return c->L->kind == 4 || c->L->kind == 1; }
+
 /* iterate!(job, HMC, Multivariate) — src/samplers/iterate/HMC.jl:124-201;
  * leapfrog! — src/samplers/samplers.jl:122-134; hamiltonian — samplers.jl:103 */
 static int ko_hmc(const ko_target_ctx* c, uint64_t chain, uint64_t t, double eps, int64_t nleaps,
@@ -445,6 +465,19 @@ static int ko_hmc(const ko_target_ctx* c, uint64_t chain, uint64_t t, double eps
     memcpy(xp, x, sizeof(double) * (size_t)D);                           /* :139 */
     memcpy(gp, g, sizeof(double) * (size_t)D);                           /* :140 */
     const double halfe = 0.5 * eps;
+    if (ko_merged_leapfrog(c)) {
+        /* DELIBERATE DEVIATION for the kernels that run the merged leapfrog (klara_hiert.h, layout
+         * kind 4; klara_dense.h, kind 1): the closing half-kick of step l and the opening half-kick of step l + 1 use the same gradient and are one
+         * update p += eps g, and every update is one fma.  Same trajectory in exact arithmetic; <= 1 ulp per update from the
+         * literal form below (samplers.jl:130-133 evaluates p + (eps/2) g twice, unfused). */
+        for (int i = 0; i < D; ++i) p[i] = kd_fma(halfe, gp[i], p[i]);
+        for (int64_t l = 0; l < nleaps; ++l) {
+            for (int i = 0; i < D; ++i) xp[i] = kd_fma(eps, p[i], xp[i]);
+            ko_gradlogtarget(c, xp, gp);
+            const double kf = l + 1 < nleaps ? eps : halfe;
+            for (int i = 0; i < D; ++i) p[i] = kd_fma(kf, gp[i], p[i]);
+        }
+    } else
     for (int64_t l = 0; l < nleaps; ++l) {                               /* :146-155 */
         for (int i = 0; i < D; ++i) p[i] = p[i] + halfe * gp[i];         /* samplers.jl:130 */
         for (int i = 0; i < D; ++i) xp[i] = xp[i] + eps * p[i];          /* samplers.jl:131 */
