@@ -332,6 +332,14 @@ klara_status klara_device_ptrs(klara_handle* h, void** x, void** logtarget, void
 klara_status klara_get_layout(klara_handle* h, int32_t* kind, int32_t* lanes_per_chain,
                               int32_t* elems_per_lane);
 
+/* Registers, scratch and static LDS of the transition kernel this handle launches for a launch of `nsteps` transitions (1 selects the
+ * one-transition-per-launch instantiation where one exists), read from the loaded code object — no launch happens.  which = 0: the
+ * kernel a launch runs (for jobs that two kernel families can run, see klara_desc.sparse_moves: the 4-lane one), 1: the 8-lane
+ * sibling of such jobs (the same kernel as 0 otherwise).  bench.py checks the committed PMC summaries against these values, so that
+ * counters collected on an older build of a kernel are not silently combined with timings of the current one. */
+klara_status klara_get_kernel_attributes(klara_handle* h, int32_t which, int32_t nsteps, int32_t* vgprs, int32_t* scratch_bytes,
+                                         int32_t* static_lds_bytes);
+
 /* How the launches of this handle were issued so far (layout kind 3 jobs that both kernel families can run, see
  * klara_desc.sparse_moves; zeros otherwise): counts[0] = launches issued as the 4-lane kernel alone, counts[1] = as the 8-lane
  * kernel alone, counts[2] = as a device-decided pair; last_mode[j] / last_accepted[j] = decision (0: 4 lanes, 1: 8 lanes) and

@@ -256,9 +256,11 @@ KD_FN double kd_exp(double x)
 KD_FN double kd_exp_neg(double a)
 {
     const double C2 = 0.5, C3 = 0x1.5555555555555p-3, C4 = 0x1.5555555555555p-5, C5 = 0x1.1111111111111p-7;
-    double xc = -a;
-    if (!(xc > -709.0)) xc = -709.0;                                          /* (also NaN) keeps the conversion defined */
-    const int k = (int)(KD_INVLN2N * xc + (xc < 0.0 ? -0.5 : 0.5));
+    /* max(-a, -709): one instruction; a NaN argument gives -709 as well (fmax returns the other operand), which keeps the
+     * conversion defined.  -a <= 0 here, so the rounding offset of kd_exp is the constant -1/2 (at -a = +-0 both offsets
+     * truncate to k = 0). */
+    const double xc = __builtin_fmax(-a, -709.0);
+    const int k = (int)(KD_INVLN2N * xc + -0.5);
     const double dk = (double)k;
     const double r = kd_fma(dk, -KD_LN2N_LO, kd_fma(dk, -KD_LN2N_HI, xc));
     const int idx = k & 127, e = k >> 7;
@@ -284,14 +286,22 @@ KD_FN double kd_log_pos(double x)
  * The logistic-regression targets need both per data row (doc/examples/swiss/MALA/analytical.jl:13,17 write exp(Xp) and exp(-Xp)
  * separately): one exponential instead of two, and no overflow for large |x| (the literal form gives log(inf) beyond x = 709).
  * Beyond |x| = 708 the pair is (max(x, 0), x >= 0 ? 1 : 0) exactly. */
-KD_FN void kd_softplus_logistic(double x, double* softplus, double* logistic)
+KD_FN void kd_softplus_logistic_rows(double x, double* softplus, double* logistic)
 {
-    const double ax = x < 0.0 ? -x : x;
+    const double ax = __builtin_fabs(x);             /* (a source modifier on the device) */
     const double t = kd_exp_neg(ax);                 /* [0, 1], never NaN */
     const double onept = 1.0 + t;                    /* [1, 2] */
     const double l1p = kd_log_u01(onept);
     *softplus = (x > 0.0 ? x : 0.0) + l1p;
     *logistic = (x >= 0.0 ? 1.0 : t) / onept;
+}
+/* The pair as a function of any double: NaN is passed through.  (The data rows of the logistic targets call the form above, which
+ * returns finite values for a NaN argument: a NaN there can only come from a non-finite parameter vector, the row's term Xp * y of
+ * the same evaluation is then NaN whatever y is, and so is the log-target — which is what initialize! tests (MALA.jl:83-84) — so
+ * the per-row pass-through, a compare and four selects on each of ndata rows, bought nothing.) */
+KD_FN void kd_softplus_logistic(double x, double* softplus, double* logistic)
+{
+    kd_softplus_logistic_rows(x, softplus, logistic);
     if (x != x) { *softplus = x; *logistic = x; }
 }
 

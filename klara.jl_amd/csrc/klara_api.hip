@@ -21,6 +21,8 @@
 #define KLARA_AUTO_PAIR_MIN_STEPS 4
 #endif
 
+thread_local hipFuncAttributes* klara_attr_query = nullptr;     // see klara_launch.h klara_go
+
 #define HIPCHK(expr)                                                                   \
     do {                                                                               \
         hipError_t e__ = (expr);                                                       \
@@ -79,6 +81,7 @@ struct klara_handle {
     int* auto_cells = nullptr; unsigned long long* auto_ctr = nullptr; int* auto_mirror = nullptr; int* auto_mirror_dev = nullptr;
     long long launch_idx = 0;
     double auto_threshold = 0.12;   // acceptance above which a launch keeps resident sums (8 lanes) — the measured crossover, profiles/r3_acceptance_cost_probe.txt
+    int query_lanes = 4;            // klara_get_kernel_attributes: which of the two kernel families to report
     long long n_launch_mode[3] = { 0, 0, 0 };   // launches issued as: forced / single 4-lane, forced / single 8-lane, device-decided pair
 };
 
@@ -274,7 +277,7 @@ KLARA_USER_FN double klara_user_logtarget(const double* p, int D, const double* 
         double xp = 0.0;
         for (int e = 0; e < KLARA_D; ++e) xp = kd_fma(X[r * KLARA_D + e], p[e], xp);
         double sp, lg;
-        kd_softplus_logistic(xp, &sp, &lg);
+        kd_softplus_logistic_rows(xp, &sp, &lg);
         dotxy = dotxy + xp * y[r];
         slog = slog + sp;
     }
@@ -294,7 +297,7 @@ KLARA_USER_FN void klara_user_gradlogtarget(const double* p, int D, const double
         double xp = 0.0;
         for (int e = 0; e < KLARA_D; ++e) xp = kd_fma(X[r * KLARA_D + e], p[e], xp);
         double sp, lg;
-        kd_softplus_logistic(xp, &sp, &lg);
+        kd_softplus_logistic_rows(xp, &sp, &lg);
         const double res = y[r] - lg;
         for (int e = 0; e < KLARA_D; ++e) g[e] = kd_fma(X[r * KLARA_D + e], res, g[e]);
     }
@@ -823,7 +826,9 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
         else if (d.sparse_moves == 1) force = 0;
         else if (d.sparse_moves == 2) force = 1;
         if (h->q4_ok && sums) if (const char* sm = getenv("KLARA_SUM_MODE")) { const int v = atoi(sm); if (v == 0 || v == 1) force = v; }
-        const long long idx = h->launch_idx++;
+        const bool query = klara_attr_query != nullptr;       // klara_get_kernel_attributes: which kernel, not a launch
+        if (query && h->q4_ok) force = h->query_lanes == 8 ? 1 : 0;
+        const long long idx = query ? h->launch_idx : h->launch_idx++;
         for (int j = 0; j < nparts; ++j) {
             long long c0, c1;
             part_range(h, nparts, j, &c0, &c1);
@@ -865,19 +870,21 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
                 if (force >= 0) {
                     ka.my_mode = force;
                     e = go(force == 0 ? 4 : 8, ka);
-                    h->n_launch_mode[force] += j == 0;
+                    h->n_launch_mode[force] += (j == 0 && !query);
                 } else if (kl.nsteps < KLARA_AUTO_PAIR_MIN_STEPS) {
-                    // a short launch is not worth an idle sibling: the host picks from the last decision it has seen (stale at worst)
+                    // a short launch is not worth an idle sibling: the host picks from the last decision it has seen (stale at worst),
+                    // and only every 16th such launch counts its accepted proposals and renews the decision (the workgroups of a
+                    // one-transition launch all finish together: their counter updates on one address are ~20 % of such a launch)
                     ka.my_mode = h->auto_mirror ? (__atomic_load_n(h->auto_mirror + 4 * j, __ATOMIC_RELAXED) != 0) : 1;
-                    e = go(ka.my_mode == 0 ? 4 : 8, ka);
-                    h->n_launch_mode[ka.my_mode] += j == 0;
+                    e = go(ka.my_mode == 0 ? 4 : 8, (idx & 15) == 0 ? ka : KLARA_AUTO_NONE);
+                    h->n_launch_mode[ka.my_mode] += (j == 0 && !query);
                 } else {
                     // both kernels, each subject to the decision the previous launch left (an idle sibling costs ~3 us of a launch that
                     // takes hundreds: 17.9 against 17.7 us per transition for 20-transition launches, nothing measurable on two streams)
                     ka.cell_in = h->auto_cells + 2 * j + (int)(idx & 1);
                     ka.my_mode = 0; e = go(4, ka);
                     if (e == hipSuccess) { ka.my_mode = 1; e = go(8, ka); }
-                    h->n_launch_mode[2] += j == 0;
+                    h->n_launch_mode[2] += (j == 0 && !query);
                 }
             }
             if (e != hipSuccess) return e;
@@ -1728,6 +1735,26 @@ extern "C" klara_status klara_get_layout(klara_handle* h, int32_t* kind, int32_t
     if (kind) *kind = h->kind;
     if (lanes_per_chain) *lanes_per_chain = h->kind == 2 ? h->RS : h->G;
     if (elems_per_lane) *elems_per_lane = h->E;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_kernel_attributes(klara_handle* h, int32_t which, int32_t nsteps, int32_t* vgprs, int32_t* scratch_bytes,
+                                                    int32_t* static_lds_bytes)
+{
+    if (!h || nsteps < 1 || which < 0 || which > 1) return KLARA_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->d.device));
+    hipFuncAttributes a;
+    memset(&a, 0, sizeof(a));
+    KLaunch kl;
+    kl.group0 = 0; kl.group_end = 0x7fffffffffffffffll; kl.t0 = 0; kl.nsteps = nsteps; kl.save_phase0 = 0; kl.save_col0 = 0;
+    h->query_lanes = which == 1 ? 8 : 4;
+    klara_attr_query = &a;
+    const hipError_t e = launch_steps(h, kl, 1);
+    klara_attr_query = nullptr;
+    HIPCHK(e);
+    if (vgprs) *vgprs = a.numRegs;
+    if (scratch_bytes) *scratch_bytes = (int32_t)a.localSizeBytes;
+    if (static_lds_bytes) *static_lds_bytes = (int32_t)a.sharedSizeBytes;
     return KLARA_OK;
 }
 

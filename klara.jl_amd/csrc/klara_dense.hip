@@ -12,7 +12,8 @@ static hipError_t launch_dense_m(const KParams* p, const KLaunch& kl, int NE, co
         hipError_t e = hipFuncSetAttribute((const void*)k_dense_transitions<SAMPLER, N, DA, HASMU>,        \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return e;                                                                 \
-        hipLaunchKernelGGL((k_dense_transitions<SAMPLER, N, DA, HASMU>), grid, blk, lds, st, p, kl, Pfrag); \
+        e = klara_go(k_dense_transitions<SAMPLER, N, DA, HASMU>, grid, blk, lds, st, p, kl, Pfrag);         \
+        if (e != hipSuccess) return e;                                                                 \
         break;                                                                                         \
     }
     switch (NE) {

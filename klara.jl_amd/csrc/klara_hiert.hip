@@ -6,10 +6,9 @@ template <int SAMPLER>
 static hipError_t launch_hiert(const KParams* p, const KLaunch& kl, bool mon, bool tune, dim3 grid, hipStream_t st)
 {
     const dim3 blk(256);
-    if (tune) hipLaunchKernelGGL((k_hiert<SAMPLER, 4, 5, true, true>), grid, blk, 0, st, p, kl);
-    else if (mon) hipLaunchKernelGGL((k_hiert<SAMPLER, 4, 5, true, false>), grid, blk, 0, st, p, kl);
-    else hipLaunchKernelGGL((k_hiert<SAMPLER, 4, 5, false, false>), grid, blk, 0, st, p, kl);
-    return hipGetLastError();
+    if (tune) return klara_go(k_hiert<SAMPLER, 4, 5, true, true>, grid, blk, 0, st, p, kl);
+    if (mon) return klara_go(k_hiert<SAMPLER, 4, 5, true, false>, grid, blk, 0, st, p, kl);
+    return klara_go(k_hiert<SAMPLER, 4, 5, false, false>, grid, blk, 0, st, p, kl);
 }
 
 hipError_t klara_launch_hiert(const KParams* p, const KLaunch& kl, int sampler, int RPL, int NT, bool mon, bool tune, bool da, dim3 grid,
@@ -21,8 +20,7 @@ hipError_t klara_launch_hiert(const KParams* p, const KLaunch& kl, int sampler, 
     case KLARA_SAMPLER_MALA: return launch_hiert<KLARA_SAMPLER_MALA>(p, kl, mon, tune, grid, st);
     case KLARA_SAMPLER_HMC:
         if (da) {
-            hipLaunchKernelGGL((k_hiert<KLARA_SAMPLER_HMC, 4, 5, true, true, true>), grid, dim3(256), 0, st, p, kl);
-            return hipGetLastError();
+            return klara_go(k_hiert<KLARA_SAMPLER_HMC, 4, 5, true, true, true>, grid, dim3(256), 0, st, p, kl);
         }
         return launch_hiert<KLARA_SAMPLER_HMC>(p, kl, mon, tune, grid, st);
     default: return hipErrorInvalidValue;

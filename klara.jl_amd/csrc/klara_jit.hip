@@ -311,6 +311,14 @@ hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaun
 {
     auto it = j->trans.find(mode == 7 ? 7 : (mode & 3) == 3 ? 3 : (mode & 1) ? 1 : 0);
     if (it == j->trans.end()) return hipErrorInvalidValue;
+    if (klara_attr_query != nullptr) {               // klara_get_kernel_attributes: report instead of launching
+        int regs = 0, scratch = 0, lds = 0;
+        hipError_t e = hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, it->second);
+        if (e == hipSuccess) e = hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, it->second);
+        if (e == hipSuccess) e = hipFuncGetAttribute(&lds, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, it->second);
+        klara_attr_query->numRegs = regs; klara_attr_query->localSizeBytes = (size_t)scratch; klara_attr_query->sharedSizeBytes = (size_t)lds;
+        return e;
+    }
     KLaunch klv = kl;
     void* args[] = { &p, &klv };
     return hipModuleLaunchKernel(it->second, grid.x, 1, 1, 256, 1, 1, 0, st, args, nullptr);

@@ -398,10 +398,11 @@ struct LogisticTarget {
         double dotxy = 0.0, slog = 0.0, gacc[E];
 KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) gacc[e] = 0.0;
-        // rows are independent until the accumulations: unrolling lets two rows' exp/log chains interleave (the kernel runs
-        // at 2 wavefronts per SIMD for cfg 4's per-GPU share, so dependent-issue latency is otherwise exposed)
-#pragma unroll KLARA_LOGIT_UNROLL
-        for (int r = cx.rq; r < ndata; r += cx.RS) {
+        // One data row: everything a row contributes, in the oracle's order.  The rows of a lane are r = rq, rq + RS, ...: every
+        // lane takes ndata / RS of them (a wave-uniform count: a scalar loop the compiler can unroll — the lane-dependent bound
+        // `r < ndata` made it a divergent loop with exec-mask bookkeeping and register copies in every iteration) and the lanes
+        // with rq < ndata % RS one more.
+        const auto row_of = [&](int r) {
             double row[E];
 KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) row[e] = sX[r * E + e];
@@ -410,7 +411,7 @@ KLARA_PRAGMA_UNROLL_E
             for (int e = 0; e < E; ++e) xp = kd_fma(row[e], x[e], xp);            // Xp = v[2]*p
             const double yr = sy[r];
             double sp, lg;
-            kd_softplus_logistic(xp, &sp, &lg);                                   // log(1+exp(Xp)), 1/(1+exp(-Xp)): one exponential
+            kd_softplus_logistic_rows(xp, &sp, &lg);                                   // log(1+exp(Xp)), 1/(1+exp(-Xp)): one exponential
             if (WANT_LT) {
                 dotxy = dotxy + xp * yr;                                          // dot(Xp, v[3])
                 slog = slog + sp;                                                 // sum(log(1+exp(Xp)))
@@ -420,7 +421,12 @@ KLARA_PRAGMA_UNROLL_E
 KLARA_PRAGMA_UNROLL_E
                 for (int e = 0; e < E; ++e) gacc[e] = kd_fma(row[e], res, gacc[e]);
             }
-        }
+        };
+        const int nfull = ndata / cx.RS, tail = ndata - nfull * cx.RS;
+        // (rows are independent until the accumulations: unrolling lets two rows' exp / log / division chains interleave)
+#pragma unroll KLARA_LOGIT_UNROLL
+        for (int it = 0; it < nfull; ++it) row_of(cx.rq + it * cx.RS);
+        if (cx.rq < tail) row_of(cx.rq + nfull * cx.RS);
         if (cx.RS > 1) {
             double red[E + 2];
             red[0] = dotxy; red[1] = slog;
@@ -706,12 +712,16 @@ KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) mu[e] = x[e] + halfh * g[e];                          // :83
 KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) xp[e] = mu[e] + sq * z[e];                            // :84
-    tg.template eval<true, true>(cx, xp, red[0], gp);                                 // :86
+    // (:90 does not depend on the evaluation: formed first, so that the drift mean is not live across it)
     double s1 = 0.0, s2 = 0.0;
 KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) {
         const double q1 = mu[e] - xp[e];
         s1 = s1 + (q1 * q1) * half_inv_h;                        // :90
+    }
+    tg.template eval<true, true>(cx, xp, red[0], gp);                                 // :86
+KLARA_PRAGMA_UNROLL_E
+    for (int e = 0; e < E; ++e) {
         const double mup = xp[e] + halfh * gp[e];                                     // :91
         const double q2 = mup - x[e];
         s2 = s2 + (q2 * q2) * half_inv_h;                        // :92
@@ -961,6 +971,11 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
     // monitored jobs: the step functions hand the proposal back and the commit happens here, after the state being left has been
     // folded into the running sums (KParams::held)
     constexpr bool OUTER = !NOMON && SAMPLER != KLARA_SAMPLER_SLICE;
+    // The logistic targets fold the running sums of a chain that moves straight into memory (a read-modify-write of 2 D values per
+    // accepted transition, against ~3,000 vector instructions of a transition) instead of keeping 4 E registers of sums resident:
+    // with them the 128-register kernels of cfg 4 (4 wavefronts per SIMD) spilled.  Everything else keeps resident sums (the README
+    // job runs a transition in ~60 instructions: a memory round trip per accepted move would dominate it).
+    constexpr bool MEMSUMS = TARGET == KLARA_TARGET_LOGISTIC;
     const KParams& p = *pp;
     kd_tables_to_lds();
     guchar* const accept_out = (!NOMON && p.accept != nullptr) ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
@@ -1010,13 +1025,31 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 
         const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
         // running sums are first needed at the end of a transition: not prefetched (saves 4E VGPRs)
-        double sm[E], sq[E];
+        double sm[MEMSUMS ? 1 : E], sq[MEMSUMS ? 1 : E];
         long long held = 0;
         if (do_sum) {
-            load_win<E>(cx, group_window(p.sum, first_chain, here, p.D), p.D, sm);
-            load_win<E>(cx, group_window(p.sumsq, first_chain, here, p.D), p.D, sq);
+            if constexpr (!MEMSUMS) {
+                load_win<E>(cx, group_window(p.sum, first_chain, here, p.D), p.D, sm);
+                load_win<E>(cx, group_window(p.sumsq, first_chain, here, p.D), p.D, sq);
+            }
             held = p.held[cx.chain_ok ? cx.chain : 0];
         }
+        // the fold of the state being left (KParams::held) — into the resident sums, or (MEMSUMS) straight into memory
+        const auto fold_state = [&]() {
+            const double hf = (double)held;
+            if constexpr (MEMSUMS) {
+                double ts[E], tq[E];
+                const __amdgpu_buffer_rsrc_t ws = group_window(p.sum, first_chain, here, p.D), wq = group_window(p.sumsq, first_chain, here, p.D);
+                load_win<E>(cx, ws, p.D, ts); load_win<E>(cx, wq, p.D, tq);
+KLARA_PRAGMA_UNROLL_E
+                for (int e = 0; e < E; ++e) { ts[e] = ts[e] + hf * cur.x[e]; tq[e] = tq[e] + hf * (cur.x[e] * cur.x[e]); }
+                store_win<E>(cx, ws, p.D, ts); store_win<E>(cx, wq, p.D, tq);
+            } else {
+KLARA_PRAGMA_UNROLL_E
+                for (int e = 0; e < E; ++e) { sm[e] = sm[e] + hf * cur.x[e]; sq[e] = sq[e] + hf * (cur.x[e] * cur.x[e]); }
+            }
+            held = 0;
+        };
         double z[E];
         AccDraw ad = { 0.5, 0.0 };
         const int acc_slot = (p.D + 1) >> 1;
@@ -1048,21 +1081,11 @@ void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
                 if (da) da_update(p, tn, (long long)t + 1, a_prob);                   // iterate/HMC.jl:225-249
             }
             else {
-                if (do_sum && held > 0) {                                  // the slice sampler always moves: fold first
-                    const double hf = (double)held;
-KLARA_PRAGMA_UNROLL_E
-                    for (int e = 0; e < E; ++e) { sm[e] = sm[e] + hf * cur.x[e]; sq[e] = sq[e] + hf * (cur.x[e] * cur.x[e]); }
-                    held = 0;
-                }
+                if (do_sum && held > 0) fold_state();                      // the slice sampler always moves: fold first
                 acc = step_slice<T, E>(p, tg, cx, gchain, t, vp, cur.x, cur.lt, stuck);
             }
             if (OUTER) {
-                if (do_sum && acc && held > 0) {                           // leaving a state after `held` saved steps
-                    const double hf = (double)held;
-KLARA_PRAGMA_UNROLL_E
-                    for (int e = 0; e < E; ++e) { sm[e] = sm[e] + hf * cur.x[e]; sq[e] = sq[e] + hf * (cur.x[e] * cur.x[e]); }
-                    held = 0;
-                }
+                if (do_sum && acc && held > 0) fold_state();               // leaving a state after `held` saved steps
                 if (acc) {                                                 // commit (MH.jl:98-100, MALA.jl:95-105, HMC.jl:166-176)
 KLARA_PRAGMA_UNROLL_E
                     for (int e = 0; e < E; ++e) { cur.x[e] = prop.x[e]; if (NEEDG) cur.g[e] = prop.g[e]; }
@@ -1115,9 +1138,11 @@ KLARA_PRAGMA_UNROLL_E
             store_win<E>(cx, group_window(p.X, first_chain, here, p.D), p.D, cur.x);
             if (NEEDG) store_win<E>(cx, group_window(p.GR, first_chain, here, p.D), p.D, cur.g);
         }
-        if (do_sum) {
-            store_win<E>(cx, group_window(p.sum, first_chain, here, p.D), p.D, sm);
-            store_win<E>(cx, group_window(p.sumsq, first_chain, here, p.D), p.D, sq);
+        if constexpr (!MEMSUMS) {
+            if (do_sum) {
+                store_win<E>(cx, group_window(p.sum, first_chain, here, p.D), p.D, sm);
+                store_win<E>(cx, group_window(p.sumsq, first_chain, here, p.D), p.D, sq);
+            }
         }
         if (cx.chain_ok && cx.q == 0 && cx.rq == 0) {
             if (do_sum) p.held[cx.chain] = held;

@@ -3,6 +3,18 @@
 #include "klara_kernels.h"
 #include "klara_diagt.h"
 
+// Every transition kernel is launched through klara_go: when klara_attr_query points at a hipFuncAttributes (klara_get_kernel_attributes,
+// klara_api.hip) the launcher reports the kernel's registers / scratch / LDS instead of launching it — the dispatch code that
+// picks an instantiation for a job is then the one source of truth for "which kernel does this handle run".
+extern thread_local hipFuncAttributes* klara_attr_query;
+template <class... KArgs, class... Args>
+static inline hipError_t klara_go(void (*kern)(KArgs...), dim3 grid, dim3 blk, size_t lds, hipStream_t st, Args... args)
+{
+    if (klara_attr_query != nullptr) return hipFuncGetAttributes(klara_attr_query, (const void*)kern);
+    hipLaunchKernelGGL(kern, grid, blk, lds, st, args...);
+    return hipGetLastError();
+}
+
 // group-layout transition kernels; target in {GAUSS_DIAG, LOGISTIC}; E in {2,4,8}; G = lanes per chain
 hipError_t klara_launch_mh(const KParams* p, const KLaunch& kl, int mode, int target, int E, int G, dim3 grid, size_t lds,
                            hipStream_t st);
@@ -67,8 +79,7 @@ hipError_t klara_launch_diagt_init_q4(const KParams& p, int NP, int needgrad, di
 template <int S, int NP_, int Q_, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false, bool DA = false>
 static hipError_t diagt_go(const KParams* p, const KLaunch& kl, const KAuto& ka, long long nwaves, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_diagt<S, NP_, Q_, ONESTEP, UNITW, MON, TUNE, DA>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, p, kl, ka);
-    return hipGetLastError();
+    return klara_go(k_diagt<S, NP_, Q_, ONESTEP, UNITW, MON, TUNE, DA>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, p, kl, ka);
 }
 
 #if KLARA_DIAGT_Q == 4     // (no tuned / dual-averaging instantiations: those jobs take the 8-lane form)
@@ -136,7 +147,7 @@ const char* klara_jit_log();
             hipError_t e_ = hipFuncSetAttribute((const void*)k_transitions<S, T, E_, G_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e_ != hipSuccess) return e_;                                                                                      \
         }                                                                                                                         \
-        hipLaunchKernelGGL((k_transitions<S, T, E_, G_, M_>), grid, blk, lds, st, p, kl);                                          \
+        { const hipError_t e_ = klara_go(k_transitions<S, T, E_, G_, M_>, grid, blk, lds, st, p, kl); if (e_ != hipSuccess) return e_; }  \
     } while (0)
 #define KLARA_LAUNCH_T(S, T, E_, G_)                                                                    \
     do {                                                                                               \

@@ -429,6 +429,13 @@ class Engine:
         L.check(self._lib.klara_get_launch_modes(self._h, cnt.ctypes.data, lm.ctypes.data, la.ctypes.data), "klara_get_launch_modes")
         return cnt, lm, la
 
+    def kernel_attributes(self, which: int = 0, nsteps: int = 32):
+        """(vgprs, scratch bytes, static LDS bytes) of the transition kernel a launch of `nsteps` transitions runs, from the loaded
+        code object (klara_get_kernel_attributes); which = 1: the 8-lane sibling of jobs two kernel families can run."""
+        v, s_, l = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        L.check(self._lib.klara_get_kernel_attributes(self._h, int(which), int(nsteps), C.byref(v), C.byref(s_), C.byref(l)), "klara_get_kernel_attributes")
+        return int(v.value), int(s_.value), int(l.value)
+
     def device_ptrs(self):
         x, lt, g = C.c_void_p(), C.c_void_p(), C.c_void_p()
         L.check(self._lib.klara_device_ptrs(self._h, C.byref(x), C.byref(lt), C.byref(g)), "klara_device_ptrs")

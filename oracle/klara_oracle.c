@@ -179,7 +179,7 @@ static void ko_logit_eval(const ko_target_ctx* c, const double* p, double* lt, d
             double xp = 0.0;
             for (int k = 0; k < D; ++k) xp = kd_fma(row[k], p[k], xp);
             double sp, lg;
-            kd_softplus_logistic(xp, &sp, &lg);
+            kd_softplus_logistic_rows(xp, &sp, &lg);
             if (lt) { dotxy1 = dotxy1 + xp * d->logit_y[r]; slog1 = slog1 + sp; }
             if (g) { const double res = d->logit_y[r] - lg; for (int k = 0; k < D; ++k) g1[k] = kd_fma(row[k], res, g1[k]); }
         }
@@ -199,7 +199,7 @@ static void ko_logit_eval(const ko_target_ctx* c, const double* p, double* lt, d
         double xp = 0.0;
         for (int k = 0; k < D; ++k) xp = kd_fma(row[k], p[k], xp);            /* Xp = v[2]*p        */
         double sp, lg;                                                          /* log(1+exp(Xp)), 1/(1+exp(-Xp)) from one */
-        kd_softplus_logistic(xp, &sp, &lg);                                     /* exponential (detmath.h): same value, no overflow */
+        kd_softplus_logistic_rows(xp, &sp, &lg);                                     /* exponential (detmath.h): same value, no overflow */
         if (lt) {
             pdot[q] = pdot[q] + xp * d->logit_y[r];                             /* dot(Xp, v[3])      */
             plog[q] = plog[q] + sp;                                             /* sum(log(1+exp(Xp)))*/

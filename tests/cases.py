@@ -119,7 +119,7 @@ KLARA_USER_FN double klara_user_logtarget(const double* p, int D, const double* 
         for (int e = 0; e < KLARA_D; ++e) xp = kd_fma(X[r * KLARA_D + e], p[e], xp);
         dotxy = dotxy + xp * y[r];
         double sp, lg;
-        kd_softplus_logistic(xp, &sp, &lg);
+        kd_softplus_logistic_rows(xp, &sp, &lg);
         slog = slog + sp;
     }
     double dotpp = 0.0;
@@ -135,7 +135,7 @@ KLARA_USER_FN void klara_user_gradlogtarget(const double* p, int D, const double
         double xp = 0.0;
         for (int e = 0; e < KLARA_D; ++e) xp = kd_fma(X[r * KLARA_D + e], p[e], xp);
         double sp, lg;
-        kd_softplus_logistic(xp, &sp, &lg);
+        kd_softplus_logistic_rows(xp, &sp, &lg);
         const double res = y[r] - lg;
         for (int e = 0; e < KLARA_D; ++e) g[e] = kd_fma(X[r * KLARA_D + e], res, g[e]);
     }

@@ -533,6 +533,24 @@ def test_reset_rewinds_the_job():
     eng.close()
 
 
+def test_nonfinite_initial_values_are_rejected_by_the_logistic_target():
+    """A NaN parameter makes every row's Xp NaN; the rows' softplus / logistic pair stays finite (kd_softplus_logistic_rows) but the
+    term Xp * y — and with it the log-target — is NaN, which is what initialize! tests (MALA.jl:83-84, MH.jl:72-85)."""
+    X, y = cases.swiss_data()
+    for sampler, kw in ((L.SAMPLER_MALA, dict(driftstep=0.1)), (L.SAMPLER_MH, dict(mh_sigma=np.full(4, 0.1)))):
+        eng = K.Engine(sampler=sampler, target=K.LogisticTarget(X, y, 100.0), nchains=20, nsteps=10, **kw)
+        x = np.zeros((20, 4)); x[7, 2] = np.nan
+        with pytest.raises(K.KlaraError) as ei:
+            eng.set_state(x)
+        assert ei.value.status == L.ERR_NONFINITE_INIT
+        x[7, 2] = np.inf
+        with pytest.raises(K.KlaraError) as ei:
+            eng.set_state(x)
+        assert ei.value.status == L.ERR_NONFINITE_INIT
+        eng.set_state(np.zeros((20, 4))); eng.run(3)
+        eng.close()
+
+
 def test_nonfinite_initial_values_are_rejected():
     eng = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(3), nchains=5, nsteps=10, driftstep=0.1)
     x = np.zeros((5, 3)); x[3, 1] = np.nan
