@@ -18,11 +18,15 @@ an end-of-run cost of ~0.1 ms does not belong inside a timed region that the dri
 
 Prints ONE JSON line (rank 0).  Keys beyond the driver's contract:
   roofline      the dominant transition kernel.  `bound` = "valu": the kernel is bound by vector-ALU issue (in-kernel Philox +
-                Box-Muller), so `achieved` = VALU-busy SIMD-cycles per second = SQ_ACTIVE_INST_VALU (quad-cycles, x 4) per launch,
-                taken from the committed PMC summary profiles/r2_pmc_kernels.json of this command, / the mean launch duration
-                measured HERE with HIP events on the launch stream (one launch at a time, nstreams = 1); `peak` = 1024 SIMDs x
-                2.4 GHz.  `hbm` gives the byte side: SURVEY section 8(d)'s contract bytes, the bytes this kernel has to move,
-                the PMC traffic and the fraction of 8 TB/s each amounts to.
+                Box-Muller), HBM moves a few per cent of its peak (`hbm`).  `frac` is ALGORITHMIC: `achieved` = the vector
+                instructions the algorithm needs per launch (scripts/instruction_budget.py: one count per operation of the stream
+                functions and of the sampler arithmetic, derivation in profiles/README.md) x 4 issue cycles / the mean launch
+                duration measured HERE with HIP events on the launch stream (one launch at a time, nstreams = 1); `peak` = 1024
+                SIMDs x 2.4 GHz.  `utilisation` is the VALU-busy fraction (SQ_ACTIVE_INST_VALU of the committed PMC summary
+                profiles/r3_pmc_kernels.json / the same duration) and `issued_over_necessary` the instructions the kernel really
+                issues (SQ_INSTS_VALU) over the budget; `pmc.stale` is true when the loaded kernel's registers / scratch differ
+                from the ones the counters were collected on.  `hbm` gives the byte side: SURVEY section 8(d)'s contract bytes,
+                the bytes this kernel has to move, the PMC traffic and the fraction of 8 TB/s each amounts to.
   cpu_baseline  the CPU oracle ("port" of the reference path, OpenMP over chains) on a bounded sample of the same workload
   extra         the other configurations, each with its own {bound, frac, kernel, source} object
 """
@@ -45,8 +49,16 @@ CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock; 256 CUs x 4 SIMDs
 NSIMD = 1024
 # How the running sums of a moving chain are kept (4-lane kernels + atomic folds, or 8-lane kernels + resident sums) is decided by the
 # library itself, on the device, launch by launch (klara_desc.sparse_moves = 0): no caller hint.
-PMC_JSON = ROOT / "profiles" / "r2_pmc_kernels.json"
+PMC_JSON = ROOT / "profiles" / "r3_pmc_kernels.json"
 PMC_EXPECT = {}             # filled by main(): the launch length the committed counters must have been collected at
+
+
+def budgets():
+    """scripts/instruction_budget.py: necessary vector instructions per wavefront and transition of the kernels priced here"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("instruction_budget", ROOT / "scripts" / "instruction_budget.py")
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod.BUDGETS
 
 
 def pmc_lookup(kernel_sub, grid=None):
@@ -69,21 +81,53 @@ def pmc_lookup(kernel_sub, grid=None):
     return best
 
 
-def valu_roofline(kernel_sub, launch_s, grid=None, label=None):
-    """{bound: valu, achieved, peak, frac}: VALU-busy SIMD-cycles per launch (PMC) / launch duration (live)."""
-    rf = {"bound": "valu", "achieved": None, "peak": NSIMD * CLOCK_HZ, "unit": "VALU-busy SIMD-cycle/s", "frac": None,
+def pmc_recorded_attributes():
+    """{lookup key: [vgprs, scratch bytes]} of the kernels as they were loaded when the committed counters were collected"""
+    try:
+        return json.loads(PMC_JSON.read_text()).get("loaded_kernel_attributes", {})
+    except Exception:
+        return {}
+
+
+def valu_roofline(kernel_sub, launch_s, grid=None, label=None, necessary_per_launch=None, attrs=None, budget=None):
+    """{bound: valu, achieved, peak, frac, utilisation, ...}.  frac = necessary VALU issue-cycles per launch (instruction budget x 4)
+    / (launch duration x 1024 SIMDs x 2.4 GHz) — None for a kernel without a budget; utilisation = VALU-busy SIMD-cycles per launch
+    (PMC) / the same denominator.  attrs = (vgprs, scratch bytes, static LDS) of the kernel as loaded (klara_get_kernel_attributes):
+    a PMC row collected on a kernel with other registers / scratch is marked stale and not used."""
+    peak = NSIMD * CLOCK_HZ
+    rf = {"bound": "valu", "achieved": None, "peak": peak, "unit": "necessary VALU issue-cycle/s", "frac": None, "utilisation": None,
           "kernel": label or kernel_sub, "launch_us": launch_s * 1e6,
-          "source": "SQ_ACTIVE_INST_VALU (quad-cycles x 4, summed over the chip) per launch from profiles/r2_pmc_kernels.json / "
-                    "launch duration from HIP events in this run; peak = 1024 SIMDs x 2.4 GHz"}
+          "source": "frac: necessary vector instructions per launch (scripts/instruction_budget.py, profiles/README.md) x 4 issue cycles / launch "
+                    "duration from HIP events in this run / (1024 SIMDs x 2.4 GHz); utilisation: SQ_ACTIVE_INST_VALU (quad-cycles x 4, chip "
+                    f"total) per launch from profiles/{PMC_JSON.name} / the same denominator"}
+    if necessary_per_launch is not None:
+        rf.update(achieved=4.0 * necessary_per_launch / launch_s, frac=4.0 * necessary_per_launch / launch_s / peak,
+                  necessary_valu_insts_per_launch=necessary_per_launch)
+    if budget is not None:
+        rf["budget"] = {k: v for k, v in budget.items()}
     row = pmc_lookup(kernel_sub, grid)
+    pmc = {"file": f"profiles/{PMC_JSON.name}", "key": kernel_sub, "kernel": None, "stale": None}
+    rf["pmc"] = pmc
+    if attrs is not None:       # (vgprs rounded up to the allocation granule of 8, scratch bytes: what scripts/make_pmc_json.py records per key)
+        pmc.update(loaded_vgpr=8 * ((attrs[0] + 7) // 8), loaded_scratch=attrs[1])
     if row is None or "SQ_ACTIVE_INST_VALU" not in row["counters"]:
-        rf["source"] += " — NO PMC ROW for this kernel in the committed summary: frac not available"
+        pmc["why"] = "no row for this kernel / grid in the committed summary"
         return rf
+    pmc["kernel"] = row["kernel"]
+    rec = pmc_recorded_attributes().get(kernel_sub)
+    if attrs is not None and rec is not None:
+        pmc.update(recorded_vgpr=rec[0], recorded_scratch=rec[1], stale=bool([pmc["loaded_vgpr"], pmc["loaded_scratch"]] != list(rec)))
+        if pmc["stale"]:
+            pmc["why"] = "the loaded kernel's registers / scratch differ from the build the counters were collected on: counters not used"
+            return rf
     c = row["counters"]
     busy = 4.0 * c["SQ_ACTIVE_INST_VALU"]["mean"]
-    rf.update(achieved=busy / launch_s, frac=busy / launch_s / (NSIMD * CLOCK_HZ), pmc_kernel=row["kernel"],
-              valu_busy_cycles_per_simd=busy / NSIMD, valu_insts_per_launch=c.get("SQ_INSTS_VALU", {}).get("mean"),
-              waves_per_launch=c.get("SQ_WAVES", {}).get("mean"))
+    rf.update(utilisation=busy / launch_s / peak, valu_busy_cycles_per_simd=busy / NSIMD,
+              issued_valu_insts_per_launch=c.get("SQ_INSTS_VALU", {}).get("mean"), waves_per_launch=c.get("SQ_WAVES", {}).get("mean"))
+    if necessary_per_launch is not None and rf["issued_valu_insts_per_launch"]:
+        rf["issued_over_necessary"] = rf["issued_valu_insts_per_launch"] / necessary_per_launch
+    if "GRBM_GUI_ACTIVE" in c:      # (chip clock during the PMC pass: the sum over the 8 XCDs / 8 / the launch duration of that pass is not known here)
+        rf["pmc_gui_active_cycles_per_xcd"] = c["GRBM_GUI_ACTIVE"]["mean"] / 8.0
     return rf
 
 
@@ -280,8 +324,10 @@ def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
     lay_kind, lay_g, lay_e = e.layout()
     _, _, nacc, ntr, _ = e.pooled_summaries(with_sums=False)
     cnt, last_mode, _ = e.launch_modes() if hasattr(L.load(), 'klara_get_launch_modes') else (None, [0], None)
+    four = lay_kind == 3 and (not monitor or last_mode[0] == 0)     # the 4-lane kernels ran (they sum in the layout's 8-lane order)
+    attrs = e.kernel_attributes(0 if four else 1, spl) if hasattr(L.load(), 'klara_get_kernel_attributes') else None
     e.close()
-    if lay_kind == 3 and (not monitor or last_mode[0] == 0):        # the 4-lane kernels ran (they sum in the layout's 8-lane order)
+    if four:
         lay_g, lay_e = 4, 2 * ((NDIMS + 7) // 8)
     if lay_kind == 3:
         kname = diagt_kernel_name(1, lay_g, lay_e, spl == 1 and not monitor, True, bool(monitor))
@@ -290,7 +336,10 @@ def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
     else:
         kname, label = "k_transitions<1, 0,", f"k_transitions<MALA, GAUSS_DIAG, E={lay_e}>"
     grid = diagt_grid(n, lay_g) if lay_kind == 3 else None
-    rf = valu_roofline(kname, launch_s, grid=grid, label=label)
+    bud = budgets()["headline_4lane" if lay_g == 4 else "headline_8lane"] if lay_kind == 3 else None
+    nwaves = (n + (64 // lay_g) - 1) // (64 // lay_g) if lay_kind == 3 else None
+    rf = valu_roofline(kname, launch_s, grid=grid, label=label, attrs=attrs, budget=bud,
+                       necessary_per_launch=bud["per_wave_transition"] * nwaves * spl if bud else None)
     rf.update(launches=nlaunch, chains_per_launch=n, transitions_per_launch=spl)
     # the byte side.  S = 2*D*8 + 8 (x, gradient, log-target); SURVEY 8(d): B_K = (2 S + 1) / K per transition and chain.
     s_state = 2 * NDIMS * 8 + 8
@@ -311,8 +360,10 @@ def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
                                   "the init kernel (profiles/README.md)")
     rf["traffic"] = hbm["traffic_bytes_per_launch"]
     rf["hbm"] = hbm
-    rf["note"] = ("VALU-issue bound: ~1,070 VALU instructions per wavefront and transition, 70 % of them the in-kernel Philox4x32-10 + "
-                  "Box-Muller of the proposal normals (DESIGN.md section 5); HBM moves a fraction of its peak (hbm.*)")
+    if bud:
+        rf["note"] = (f"VALU-issue bound: {bud['per_wave_transition']:.0f} necessary vector instructions per wavefront ({64 // lay_g} chains) and transition = "
+                      f"{bud['per_wave_transition'] / (64 // lay_g):.1f} per chain and transition, {100.0 * bud['pair_evaluations_per_lane'] * 102 / bud['per_wave_transition']:.0f} % of them "
+                      "the in-kernel Philox4x32-10 + Box-Muller of the proposal normals; HBM moves a few per cent of its peak (hbm.*)")
     return rf
 
 
@@ -328,6 +379,8 @@ def extra_measurements(K, L, n, stream):
     the roofline that bounds its kernel."""
     import numpy as np
     ex = {}
+    bud = budgets()
+    attrs_of = lambda e, nsteps, which=0: e.kernel_attributes(which, nsteps) if hasattr(L.load(), "klara_get_kernel_attributes") else None
     neg = K.GaussDiagTarget.negdot(NDIMS)
     # -- the headline workload in its other modes
     for key, kw in (("mala_one_transition_per_launch_no_save", dict(steps_per_launch=1, monitor=0)),
@@ -345,8 +398,10 @@ def extra_measurements(K, L, n, stream):
                  monitor=0, nstreams=1)
     e.init_state_normal()
     ls, _ = launch_duration(e, 1, nlaunch=256)
-    lay = e.layout(); e.close()
-    ex["mala_one_transition_per_launch_roofline"] = valu_roofline(diagt_kernel_name(1, lay[1], lay[2], True, True, False), ls, grid=diagt_grid(n, lay[1]))
+    at = attrs_of(e, 1); e.close()
+    b4 = bud["headline_4lane"]                          # (the 4-lane kernels run every job that keeps no running sums)
+    ex["mala_one_transition_per_launch_roofline"] = valu_roofline(diagt_kernel_name(1, 4, 2 * ((NDIMS + 7) // 8), True, True, False), ls, grid=diagt_grid(n, 4),
+                                                                  attrs=at, necessary_per_launch=(b4["per_wave_transition"] - b4["bookkeeping"]) * ((n + 15) // 16))
 
     # -- cfg 1: the README job (README.md:23-47: MH, sigma = (1, 1), lt = -dot(z, z), D = 2, burn-in 1000, x0 = (5.1, -0.9)) as 1,048,576
     # replicas — one chain per lane — with the running sums of mean(chain) on
@@ -355,23 +410,23 @@ def extra_measurements(K, L, n, stream):
                  monitor=L.MON_SUMMARIES, stream=stream, nstreams=1)
     e.set_state(np.tile([5.1, -0.9], (nr, 1)))
     rate, ls, _ = timed_rate(e, nr, 1024, 2048)
-    e.close()
+    at = attrs_of(e, 32); e.close()
     ex["cfg1_readme_mh_1048576_replicas_transitions_per_s"] = rate
-    ex["cfg1_roofline"] = valu_roofline("k_transitions<0, 0, 2, 0, 1>", ls)
+    ex["cfg1_roofline"] = valu_roofline("k_transitions<0, 0, 2, 0, 1>", ls, attrs=at)
 
     # -- HMC L=10 eps=0.1 on the README target (VALU) and on the dense target (FP64 MFMA; cfg 3)
     e = K.Engine(sampler=L.SAMPLER_HMC, target=neg, nchains=n, nsteps=10 ** 7, leapstep=0.1, nleaps=10, stream=stream, nstreams=1)
     e.init_state_normal()
     rate, ls, _ = timed_rate(e, n, 32, 128)
-    lay = e.layout(); e.close()
+    lay = e.layout(); at = attrs_of(e, 32); e.close()
     ex["hmc_iso_leapfrog_chain_per_s"] = rate * 10
-    ex["hmc_iso_roofline"] = valu_roofline(diagt_kernel_name(2, lay[1], lay[2], False, True, False), ls, grid=diagt_grid(n, lay[1]))
+    ex["hmc_iso_roofline"] = valu_roofline(diagt_kernel_name(2, lay[1], lay[2], False, True, False), ls, grid=diagt_grid(n, lay[1]), attrs=at)
 
     e = K.Engine(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget.compound_symmetric(NDIMS, 0.5), nchains=n, nsteps=10 ** 7,
                  leapstep=0.1, nleaps=10, stream=stream)
     e.init_state_normal()
     rate, ls, _ = timed_rate(e, n, 32, 128)
-    e.close()
+    at = attrs_of(e, L.DEFAULT_STEPS_PER_LAUNCH); e.close()
     flops_per_launch = n * L.DEFAULT_STEPS_PER_LAUNCH * 10 * (2 * NDIMS * NDIMS + 6 * NDIMS)         # 2 D^2 + 6 D per leapfrog and chain
     tf = flops_per_launch / ls / 1e12
     ex["cfg3_hmc_dense_leapfrog_chain_per_s"] = rate * 10
@@ -381,7 +436,11 @@ def extra_measurements(K, L, n, stream):
           "launch_us": ls * 1e6,
           "source": "algorithmic flops (2 D^2 + 6 D per leapfrog and chain, SURVEY 8(d)) / launch duration from HIP events in this run"}
     row = pmc_lookup("k_dense_transitions<2")
-    if row is not None and "SQ_VALU_MFMA_BUSY_CYCLES" in row["counters"]:
+    rec = pmc_recorded_attributes().get("k_dense_transitions<2")
+    rf["pmc"] = {"file": f"profiles/{PMC_JSON.name}", "key": "k_dense_transitions<2", "kernel": row["kernel"] if row else None,
+                 "loaded_vgpr": 8 * ((at[0] + 7) // 8) if at else None, "loaded_scratch": at[1] if at else None,
+                 "stale": bool(at is not None and rec is not None and [8 * ((at[0] + 7) // 8), at[1]] != list(rec)) if (at and rec) else None}
+    if row is not None and "SQ_VALU_MFMA_BUSY_CYCLES" in row["counters"] and not rf["pmc"]["stale"]:
         busy = row["counters"]["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"]
         rf["mfma_pipe_busy_frac"] = busy / NSIMD / (ls * CLOCK_HZ)
         rf["mfma_pipe_source"] = "SQ_VALU_MFMA_BUSY_CYCLES per launch (profiles/r2_pmc_kernels.json) / 1024 SIMDs / (launch duration x 2.4 GHz)"
@@ -392,10 +451,10 @@ def extra_measurements(K, L, n, stream):
                  stream=stream, nstreams=1)
     e.init_state_normal()
     rate, ls, _ = timed_rate(e, n, 4, 16)
-    lay = e.layout(); e.close()
+    lay = e.layout(); at = attrs_of(e, 4); e.close()
     ex["slice_d100_transitions_per_s"] = rate
     ex["slice_d100_coordinate_updates_per_s"] = rate * NDIMS
-    ex["slice_d100_roofline"] = valu_roofline(f"k_diagt<3, {lay[2] // 2}, {lay[1]},", ls)
+    ex["slice_d100_roofline"] = valu_roofline(f"k_diagt<3, {lay[2] // 2}, {lay[1]},", ls, attrs=at)
 
     # -- the two data-model configurations of BASELINE.json at their per-GPU share (cfg 4: 262,144 / 8 chains of the swiss
     # logistic regression, MALA h = 0.1; cfg 5: 1,048,576 / 8 chains of the rats hierarchical model, HMC L = 32 with the
@@ -411,9 +470,10 @@ def extra_measurements(K, L, n, stream):
                      steps_per_launch=50, monitor=L.MON_SUMMARIES, stream=stream)
         e.set_state(x0)
         rate, ls, _ = timed_rate(e, nc, 100, 500)
-        e.close()
+        at = attrs_of(e, 50); e.close()
         ex["cfg4_swiss_logistic_mala_transitions_per_s_per_gpu"] = rate
-        ex["cfg4_roofline"] = valu_roofline("k_transitions<1, 2,", ls)
+        ex["cfg4_roofline"] = valu_roofline("k_transitions<1, 2,", ls, attrs=at, budget=bud["cfg4"],
+                                            necessary_per_launch=bud["cfg4"]["per_wave_transition"] * (nc // bud["cfg4"]["chains_per_wave"]) * 50)
         rats = np.load(gold / "rats.npz")
         t = K.HierNormalTarget(rats["weight"], rats["age"] - 22.0)
         nc = 131072
@@ -423,10 +483,11 @@ def extra_measurements(K, L, n, stream):
                      monitor=L.MON_SUMMARIES, stream=stream)
         e.set_state(x0)
         rate, ls, _ = timed_rate(e, nc, 100, 200)
-        e.close()
+        at = attrs_of(e, 10); e.close()
         ex["cfg5_rats_hmc_L32_leapfrog_chain_per_s_per_gpu"] = rate * 32
         ex["cfg5_rats_hmc_L32_transitions_per_s_per_gpu"] = rate
-        ex["cfg5_roofline"] = valu_roofline("k_hiert<2,", ls)
+        ex["cfg5_roofline"] = valu_roofline("k_hiert<2,", ls, attrs=at, budget=bud["cfg5"],
+                                            necessary_per_launch=bud["cfg5"]["per_wave_transition"] * (nc // bud["cfg5"]["chains_per_wave"]) * 10)
     except Exception as exc:      # the fixtures are part of the repository; a failure here must not lose the headline line
         ex["model_configs_error"] = repr(exc)
     return ex

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""NECESSARY vector-instruction budgets of the transition kernels bench.py prices.
+
+`roofline.frac` in the bench line is  necessary VALU issue-cycles / elapsed SIMD-cycles:  the instructions the algorithm AS SPECIFIED
+needs (this file: one count per source-level operation of detmath.h and of the sampler / target arithmetic, at its cheapest gfx950
+encoding), 4 issue cycles each (one FP64 / integer vector instruction of a 64-lane wavefront on a 16-lane SIMD; the quarter-rate
+v_rsq_f64 / v_rcp_f64 are counted as one instruction like everything else, which makes the budget slightly too small, i.e. the
+fraction conservative), divided by launch duration x 1,024 SIMDs x 2.4 GHz.  The instructions a kernel actually ISSUES come from the
+PMC summaries (SQ_INSTS_VALU per launch, profiles/r3_pmc_kernels.json) and from the compiler's assembly (scripts/asm_loops.py); the
+bench line carries both and their ratio.  VALU-busy time / elapsed time is reported as `utilisation`: it says the pipe is full,
+not that the kernel is tight.
+
+What is NOT in a budget: address arithmetic, loop control, register moves, exec-mask handling, range guards the inputs of the
+workload cannot trigger, instructions executed for padding lanes / padding element slots, work of rarely taken branches (the commit
+of an accepted proposal, the fold of the running sums).  What IS in it although one could argue: the cross-lane data movement of the
+reductions (2 v_mov_dpp per double and butterfly step), the replicated per-lane evaluation of per-chain scalars (every lane of a
+chain executes them anyway: SIMD), the divisions and unfused multiply-adds the reference's formulas state.
+
+usage: instruction_budget.py            prints the tables
+"""
+
+# ---- building blocks: operations of one evaluation on one lane (klara.jl_amd/csrc/detmath.h) -------------------------------------
+PHILOX = 10 * (2 + 2) + 1        # 10 rounds x (2 v_mad_u64_u32: hi and lo of both products; 2 v_bitop3 xor3) + the per-lane counter word;
+                                 # the key schedule is wave-uniform (scalar unit)
+UNIT_BITS = 3                    # v_lshrrev + v_or (exponent | top 20 bits), v_alignbit (low word)
+U52 = UNIT_BITS + 1              # ... and the exact subtraction
+LOG_U01 = 23                     # tmp, index (bfe), k (ashr), hz (and, sub), table offset, r (fma), dk (cvt), w (fma), hi (add), lo (sub, add, fma),
+                                 # r2 (mul), 5 fma of the degree-7 polynomial, r*r2, 2 fma, final add  [the two table words: one ds_read_b128]
+SQRT_RAD = 1 + 10                # -2 log u; v_rsq_f64 + 9 mul / fma (kd_sqrt_radicand)
+SINCOS = 18                      # j (bfe), centre word (v_and_or), t (sub), y (2 fma), z (mul), sin y (mul + 3 fma), cos y - 1 (2 fma + mul), table offset,
+                                 # rotation (4 fma)
+NORMAL_PAIR = PHILOX + U52 + UNIT_BITS + LOG_U01 + SQRT_RAD + SINCOS + 2       # ... + the two products radius x (cos, sin)  = 102
+EXP = 39                         # kd_exp: 2 clamps, rounding offset (bfi) + mul + add, 2 cvt, r (2 fma), index / exponent (and, ashr), table offset, r2, r4,
+                                 # 4 fma, y (fma, add), e/2 and e - e/2 (3), two scale words (2 x (add, shl)), 2 mul, three special-case selects (3 x 3)
+EXP_NEG = 24                     # kd_exp_neg: max, mul + add, 2 cvt, r (2 fma), and / ashr, table offset, r2, r4, 4 fma, y (fma, add), exponent (shl, and, add),
+                                 # the a <= 708 select (cmp + 2 cndmask)
+DIV = 10                         # IEEE f64 division as hipcc emits it: 2 v_div_scale, v_rcp, 5 fma, v_div_fmas, v_div_fixup
+BFLY = 3                         # one butterfly step of one double: 2 v_mov_dpp (or ds_bpermute) + v_add_f64
+
+
+def mala_diag_unitw_element():
+    """iterate/MALA.jl:83-92 on one element of lt = -|x|^2 (no contraction: Julia evaluates a*b + c in two roundings):
+    grad (1), drift mean (mul, add), proposal (mul, add), its square (1), its gradient (1), sum (1), q1 (sub, mul, mul, add), backward mean
+    (mul, add), q2 (sub, mul, mul, add)"""
+    return 1 + 2 + 2 + 1 + 1 + 1 + 4 + 2 + 4          # 19
+
+
+def headline(lanes_per_chain: int = 4, ndims: int = 100):
+    """k_diagt<MALA, ..., UNITW, MON>: necessary instructions per WAVEFRONT and transition.  A chain's ceil(D/2) element pairs are one
+    Philox block + one Box-Muller evaluation + two elements of sampler arithmetic each; a wavefront carries 64 / lanes chains."""
+    chains = 64 // lanes_per_chain
+    pair = NORMAL_PAIR + 2 * mala_diag_unitw_element()                 # 102 + 38 = 140
+    pairs = (ndims + 1) // 2 * chains / 64.0                           # pair evaluations per lane: 12.5 (4 lanes), 6.25 (8 lanes)
+    # the three sums of the Metropolis ratio in the 8-lane order: 8 lanes: 3 butterfly steps; 4 lanes: two partial sums per lane, 2 steps
+    # on both, then their sum
+    red = 3 * 3 * BFLY if lanes_per_chain == 8 else 3 * (2 * 2 * BFLY + 1)
+    accept = 1 + 3 + 2 + 2 + 1                                          # lt', ratio (3 adds), two compares, broadcast of log u, or
+    book = 3                                                            # accept count, held += 1, save-rule phase
+    return {"per_pair": pair, "pair_evaluations_per_lane": pairs, "reductions": red, "accept_test": accept, "bookkeeping": book,
+            "per_wave_transition": pairs * pair + red + accept + book, "chains_per_wave": chains}
+
+
+def cfg5_hier(nleaps: int = 32, units_per_lane: int = 4):
+    """k_hiert<HMC>: per wavefront (8 chains x 8 lanes), merged leapfrog (klara_hiert.h)."""
+    vals = 2 * units_per_lane + 5                                      # a lane's values: (a, b) of its units + its copy of the 5 hyper-parameters
+    unit = 2 + 2 + 2 + 1 + 3 + 2 + 2 + 2 + 5                           # da, db; S1; Sx; u; v (mul + 2 fma); S2; g_a (mul, fma); g_b; 5 accumulations
+    exp3 = 4 + 1 + EXP + 6                                             # pick s_c / s_a / s_b by lane (2 selects), -2 s, exp, three broadcasts
+    hyper = 2 + 2 + 3 * 3                                              # gradient of a_c, b_c (mul, fma) and of the three log-sigmas (fma, sub, fma)
+    leap = 2 * vals + units_per_lane * unit + 5 * 3 * BFLY + exp3 + hyper      # drift + kick (one fma per value each), units, 5-value butterfly
+    normals = (units_per_lane + 3) * NORMAL_PAIR                        # momentum: one pair per unit, three for the hyper block
+    lt_eval = units_per_lane * (unit - 4) + 5 * 3 * BFLY + exp3 + 25    # log-target of the proposal (no gradient terms), its closing arithmetic
+    energy = 2 * (2 * vals + 3 * BFLY)                                  # sum p^2 before and after
+    accept = EXP + PHILOX + U52 + 8
+    per_tr = nleaps * leap + normals + lt_eval + energy + accept + vals  # + the opening half-kick
+    return {"per_leapfrog": leap, "per_unit": unit, "exp_and_broadcasts": exp3, "butterfly": 5 * 3 * BFLY, "hyper_gradient": hyper,
+            "kick_and_drift": 2 * vals, "normals": normals, "per_wave_transition": per_tr, "chains_per_wave": 8, "nleaps": nleaps}
+
+
+def cfg4_logistic(ndata: int = 200, ndims: int = 4, rowsplit: int = 8):
+    """k_transitions<MALA, LOGISTIC, E=4> with the 8-lane row split: per wavefront (8 chains) and transition."""
+    row = ndims + EXP_NEG + 1 + LOG_U01 + 2 + 3 + DIV + 2 + 1 + 1 + ndims + 1     # Xp; exp(-|Xp|); 1 + t; log; softplus (max, add); numerator select;
+    # division; Xp*y (mul, add); sum of softplus; residual; gradient accumulations; row offset
+    rows = ndata // rowsplit
+    bfly = (ndims + 2) * 3 * BFLY                                       # (D + 2)-value butterfly over the 8 lanes
+    prior = 2 * ndims + (DIV + 2) + ndims * (DIV + 1)                   # p.p; -(p.p / lambda + const)/2; -p / lambda per component (the example's divisions)
+    normals = ((ndims + 1) // 2) * NORMAL_PAIR                          # every lane of a chain holds the whole vector
+    sampler = ndims * mala_diag_unitw_element() - ndims * 3             # MALA arithmetic per element (the target's own terms are above)
+    accept = 12
+    return {"per_row": row, "rows_per_lane": rows, "butterfly": bfly, "prior": prior, "normals": normals, "sampler": sampler,
+            "per_wave_transition": rows * row + bfly + prior + normals + sampler + accept, "chains_per_wave": 64 // rowsplit}
+
+
+BUDGETS = {"headline_4lane": headline(4), "headline_8lane": headline(8), "cfg5": cfg5_hier(), "cfg4": cfg4_logistic()}
+
+if __name__ == "__main__":
+    print(f"building blocks: Philox4x32-10 {PHILOX}, u52 {U52}, log(u) {LOG_U01}, radius {SQRT_RAD}, sin/cos {SINCOS}, normal pair {NORMAL_PAIR}, "
+          f"exp {EXP}, exp(-a) {EXP_NEG}, division {DIV}, butterfly step {BFLY}")
+    for name, b in BUDGETS.items():
+        print(name, {k: (round(v, 1) if isinstance(v, float) else v) for k, v in b.items()},
+              f"-> {b['per_wave_transition'] / b['chains_per_wave']:.1f} per chain and transition")

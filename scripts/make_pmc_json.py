@@ -50,7 +50,18 @@ try:
     trace["bench_line_launch_us_in_the_profiled_run"] = json.loads(open(os.path.join(prof, "bench_line_trace_headline.json")).read())["roofline"]["launch_us"]
 except Exception:
     pass
-out = {"bench_config": bench_cfg, "headline_kernel_trace": trace, "source": "rocprofv3 --pmc passes of scripts/profile_round.sh (bench.py --steps 64 --warmup 16 --reps 1 --no-cpu-baseline), one counter "
+# registers / scratch of the kernels as loaded in the counter run (bench.py asks the library: klara_get_kernel_attributes) — bench.py compares
+# them with what is loaded when it prices a kernel with these counters
+loaded = {}
+try:
+    line = json.loads(open(os.path.join(prof, "bench_line_sq.json")).read())
+    for rf in [line.get("roofline", {})] + [v for v in line.get("extra", {}).values() if isinstance(v, dict)]:
+        pm = rf.get("pmc") or {}
+        if pm.get("key") and pm.get("loaded_vgpr") is not None:      # (every roofline object of the bench line carries one)
+            loaded[pm["key"]] = [pm["loaded_vgpr"], pm["loaded_scratch"]]
+except Exception as exc:
+    loaded = {"error": repr(exc)}
+out = {"bench_config": bench_cfg, "loaded_kernel_attributes": loaded, "headline_kernel_trace": trace, "source": "rocprofv3 --pmc passes of scripts/profile_round.sh (bench.py --steps 64 --warmup 16 --reps 1 --no-cpu-baseline), one counter "
                  "group per run, --kernel-trace only; means per dispatch, chip totals (GRBM_GUI_ACTIVE: sum over the 8 XCDs); "
                  "FETCH_SIZE / WRITE_SIZE in KiB as reported (FETCH_SIZE is doubled by the reader, see profiles/README.md)",
        "kernels": rows}

@@ -8,7 +8,7 @@
 #   mem   SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM
 #   fetch FETCH_SIZE        write WRITE_SIZE
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"

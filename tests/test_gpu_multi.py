@@ -193,3 +193,6 @@ def test_bench_single_gpu_line_at_the_drivers_flags():
     assert d["config"]["steps_per_launch"] == 32 and d["config"]["save_rule"].startswith("running sums")
     rf = d["roofline"]
     assert rf["bound"] == "valu" and 0.5 < rf["frac"] <= 1.0 and 300 < rf["launch_us"] < 700
+    # frac is algorithmic: the instruction budget of the kernel that ran x 4 issue cycles / (launch duration x 1024 SIMDs x 2.4 GHz)
+    assert rf["frac"] == pytest.approx(4.0 * rf["necessary_valu_insts_per_launch"] / (rf["launch_us"] * 1e-6) / (1024 * 2.4e9), rel=1e-9)
+    assert rf["pmc"]["stale"] in (None, False, True) and (rf["utilisation"] is None or rf["frac"] <= rf["utilisation"] <= 1.0)
