@@ -55,6 +55,7 @@ struct klara_handle {
     double* pooled_out = nullptr;   // 2*D doubles + 1 u64 scratch for pooled summaries
     double* pool_partial = nullptr; // KLARA_POOL_BLOCKS x (2 D doubles + 1 u64): stage-1 partials of the pooled summaries
     double* cdata = nullptr; KlaraJit* jit = nullptr;   // user-defined target: data block, run-time compiled kernels
+    bool jit_pair = false;          // ... given as a pair closure: run-time compiled k_diagt instantiations (layout kind 3)
     // streaming batch means (bm_batchlen > 0): running sum at the last batch boundary, Welford mean / M2 of the batch means
     double *bm_prev = nullptr, *bm_mean = nullptr, *bm_m2 = nullptr; long long bm_count = 0;
     KParams* d_params = nullptr;    // device copy of the handle's static kernel parameters
@@ -125,6 +126,12 @@ static bool hiert_eligible(const klara_desc& d)
     return true;
 }
 
+// a user target given as a pair closure (`#define KLARA_USER_PAIR_TARGET 1` + klara_user_pair, include/klara_hip.h)
+static bool pair_form(const klara_desc& d)
+{
+    return d.target == KLARA_TARGET_CUSTOM && d.custom_src != nullptr && strstr(d.custom_src, "KLARA_USER_PAIR_TARGET") != nullptr;
+}
+
 static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E)
 {
     if (hiert_eligible(d)) { *kind = 4; *G = 8; *E = 8; return KLARA_OK; }
@@ -136,6 +143,14 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
         return KLARA_OK;
     }
     *kind = 0;
+    if (d.target == KLARA_TARGET_CUSTOM && pair_form(d)) {
+        // pair closure (klara_diagt.h USERPAIR): the pair-transposed layout, Q = 8 / 16 / 32 lanes per chain
+        if (D < 17 || D > 2 * 32 * KLARA_DIAGT_NP_MAX) return KLARA_ERR_UNSUPPORTED;       // (fewer than 9 pairs: use the whole-vector form)
+        if (d.sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
+        const int Q = D <= 128 ? 8 : (D <= 256 ? 16 : 32);
+        *kind = 3; *G = Q; *E = 2 * ((D + 2 * Q - 1) / (2 * Q));
+        return KLARA_OK;
+    }
     if (d.target == KLARA_TARGET_CUSTOM) {       // one chain per lane, the whole vector in registers (klara_custom.h)
         *G = 1; *E = pow2ceil(D < 2 ? 2 : D);
         return D <= KLARA_CUSTOM_MAXD ? KLARA_OK : KLARA_ERR_UNSUPPORTED;
@@ -488,9 +503,20 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out)
         CK(upload(&h->hxc, desc->hier_xc, (size_t)desc->hier_ntimes));
     } else if (desc->target == KLARA_TARGET_CUSTOM) {
         if (desc->custom_ndata > 0) CK(upload(&h->cdata, desc->custom_data, (size_t)desc->custom_ndata));
+        if (pair_form(*desc)) {
+            // k_diagt instantiations for this job: fused launches always; one transition per launch where that kernel exists
+            const bool plain_ = !cnt_predicate(h->d) && desc->tuner_mode == KLARA_TUNE_PER_CHAIN && desc->tuner != KLARA_TUNER_DUAL_AVERAGING;
+            const bool mon_ = (h->d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0, da_ = desc->tuner == KLARA_TUNER_DUAL_AVERAGING;
+            const bool tune_ = !plain_ || da_;
+            if (desc->monitor & KLARA_MON_HIST_LLLP) { free_all(h); delete h; return KLARA_ERR_INVALID_ARG; }
+            const int modes[2] = { 0, 1 };
+            h->jit_pair = true;
+            CK(klara_jit_create_pair(desc->custom_src, desc->sampler, desc->ndims, E / 2, G, mon_, tune_, da_, modes, (!mon_ && !tune_) ? 2 : 1, true, &h->jit));
+        } else {
         int modes[2];
         const int nmodes = kernel_modes(h->d, modes);           // (h->d: the monitor word with what the library turned on itself)
         CK(klara_jit_create(desc->custom_src, desc->sampler, desc->ndims, E, modes, nmodes, true, &h->jit));
+        }
     } else if (desc->target == KLARA_TARGET_LOGISTIC) {
         CK(upload(&h->lX, desc->logit_X, (size_t)desc->logit_ndata * D));
         CK(upload(&h->ly, desc->logit_y, (size_t)desc->logit_ndata));
@@ -709,6 +735,7 @@ static klara_status init_common(klara_handle* h)
     KParams p = make_params(h);
     hipError_t e;
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, h->dense_mu, needgrad, grid_for(h), st);
+    else if (h->kind == 3 && h->jit_pair) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), st);
     else if (h->kind == 3)
         e = h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
           : h->G == 16 ? klara_launch_diagt_init_q16(p, h->E / 2, needgrad, grid_for(h), st)
@@ -841,6 +868,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
                 kp.group0 = c0 / cpw; kp.group_end = (c1 + cpw - 1) / cpw;
                 const long long nw = kp.group_end - kp.group0;               // one wavefront per group of cpw chains
                 const int np = lanes == 4 ? h->np4 : h->E / 2;
+                if (h->jit_pair) return klara_jit_launch_pair(h->jit, (onestep && !tune && !mon) ? 1 : 0, p, kp, nw, st);
                 if (lanes == 4)
                     return d.sampler == KLARA_SAMPLER_MH ? klara_launch_diagt_mh_q4(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st)
                                                          : klara_launch_diagt_mala_q4(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);
@@ -1923,8 +1951,13 @@ extern "C" klara_status klara_selftest_mfma_f64_4x4x4(int32_t device, const doub
 extern "C" klara_status klara_check_custom_target(const char* src, int32_t sampler, int32_t ndims)
 {
     if (!src || sampler < KLARA_SAMPLER_MH || sampler > KLARA_SAMPLER_SLICE || ndims <= 0) return KLARA_ERR_INVALID_ARG;
-    if (ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
     const int modes[1] = { 0 };
+    if (strstr(src, "KLARA_USER_PAIR_TARGET")) {            // pair closure: the plain fused instantiation of its layout
+        if (ndims < 17 || ndims > 2 * 32 * KLARA_DIAGT_NP_MAX || sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
+        const int Q = ndims <= 128 ? 8 : (ndims <= 256 ? 16 : 32);
+        return klara_jit_create_pair(src, sampler, ndims, (ndims + 2 * Q - 1) / (2 * Q), Q, false, false, false, modes, 1, false, nullptr);
+    }
+    if (ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
     return klara_jit_create(src, sampler, ndims, pow2ceil(ndims < 2 ? 2 : ndims), modes, 1, false, nullptr);
 }
 

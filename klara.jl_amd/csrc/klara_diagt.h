@@ -310,10 +310,25 @@ __host__ __device__ constexpr int diagt_min_waves()       // wavefronts per SIMD
                    : (Q == 4 && NP <= 13 && !TUNE ? (SAMPLER == KLARA_SAMPLER_MALA ? KLARA_Q4_MALA_WF : (SAMPLER == KLARA_SAMPLER_MH ? 2 : 1)) : 1);
 }
 
-template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false, bool DA = false>
+// USERPAIR (run-time compiled instantiations only, klara_custom_pair.h): the target is the user's pair closure
+//     lt(x) = sum over element pairs P of klara_user_pair(x[2P], x[2P+1], P, ...)      (it also returns the pair's two partial derivatives)
+// instead of the diagonal Gaussian — the device form of BasicContMuvParameter(:p, logtarget=f, gradlogtarget=g)
+// (BasicContMuvParameter.jl:174-201) for targets that are sums of terms of one or two neighbouring coordinates, on the same few
+// lanes per chain, the same stream, samplers, tuners, monitors and save rule.  The kernel's sums run over -term (lt = 0 - sum(-term):
+// the same bits as the sum itself) and a pair contributes ONE term to them.
+#ifdef KLARA_USER_PAIR_TARGET
+#define KLARA_PAIR_CALL(a, b, P, g0, g1) klara_user_pair((a), (b), (P), D, (const double*)p.cdata, (long long)p.cndata, (g0), (g1))
+#else
+#define KLARA_PAIR_CALL(a, b, P, g0, g1) 0.0
+#endif
+template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false, bool DA = false, bool USERPAIR = false>
 __global__ __launch_bounds__(256, (diagt_min_waves<SAMPLER, NP, Q, ONESTEP, TUNE>()))
 void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
 {
+#ifndef KLARA_USER_PAIR_TARGET
+    static_assert(!USERPAIR, "pair closures exist in run-time compiled translation units only");
+#endif
+    static_assert(!USERPAIR || (UNITW && SAMPLER != KLARA_SAMPLER_SLICE && Q >= 8), "pair closures: MH / MALA / HMC on 8 or more lanes per chain");
     if (ka.cell_in != nullptr && *ka.cell_in != ka.my_mode) return;       // (launch-uniform: the sibling kernel runs this launch)
     static_assert(!(ONESTEP && (MON || TUNE)), "monitored / tuned jobs run the committing kernel");
     static_assert(!DA || (TUNE && SAMPLER == KLARA_SAMPLER_HMC), "dual averaging: tuned HMC");
@@ -354,7 +369,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
     const auto mvl = [&](int e) { return UNITW ? 0.0 : *(volatile const double*)&lds_mu[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
     const auto m2wvl = [&](int e) { return UNITW ? -2.0 : *(volatile const double*)&lds_m2w[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
     if (SAMPLER == KLARA_SAMPLER_MH || SLICE) load_pair_param<NP, Q>(cx, p.vecparam, D, 1.0, sig);   // proposal scales / slice widths
-    const double gconst = p.gconst;
+    const double gconst = USERPAIR ? 0.0 : p.gconst;
 
     // accept draw: slot S = ceil(D/2) = D/2.  (NP-1)*Q < D/2 <= NP*Q, so when the layout has padding (D/2 < NP*Q) the
     // slot is the last pair of lane S % Q and its Box-Muller already formed u and log(u).
@@ -384,9 +399,22 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
         // the current gradient it is re-formed from x — the same operations that produced the stored bits — and the
         // proposal's gradient is formed from the proposal when it is written out.  Half the state read, and 8*NP fewer
         // registers over the launch (x, proposal, normals and running sums are what a lane holds).
+        // user pair closure at the lane's pair pi: -term and the two partial derivatives; padding pairs / the missing half of an odd
+        // D's last pair contribute exact zeros (their values, normals and derivatives stay 0 through every update)
+        const auto user_pair = [&](int pi, double a, double b, double& nt, double& g0, double& g1) {
+            double u0 = 0.0, u1 = 0.0;
+            const double u = KLARA_PAIR_CALL(a, b, pi * Q + cx.q, &u0, &u1);
+            const bool ok0 = pi < NP - 1 || cx.last_ok, ok1 = pi < NP - 1 || cx.last_full;
+            nt = ok0 ? -u : 0.0; g0 = ok0 ? u0 : 0.0; g1 = ok1 ? u1 : 0.0;
+        };
         const auto grad_of = [&](const double (&v)[E], double (&out)[E]) {
+            if constexpr (USERPAIR) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) { double term_; diag_elem<UNITW>(v[e], wv(e), m2wv(e), mv(e), term_, out[e]); }
+                for (int pi = 0; pi < NP; ++pi) { double nt; user_pair(pi, v[2 * pi], v[2 * pi + 1], nt, out[2 * pi], out[2 * pi + 1]); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) { double term_; diag_elem<UNITW>(v[e], wv(e), m2wv(e), mv(e), term_, out[e]); }
+            }
         };
         double lt = p.LT[chain_ok ? chain : 0];
         unsigned long long nacc = 0;
@@ -546,8 +574,16 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                     double z0 = ZFIRST ? z[(2 * pi) % (ZFIRST ? E : 2)] : 0.0, z1 = ZFIRST ? z[(2 * pi + 1) % (ZFIRST ? E : 2)] : 0.0;
                     if (!ZFIRST) pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z0, z1, u_last, lg_last);
                     const int r = (NR == 2 && (pi & 1)) ? 3 : 0;
-                    const double a = mh_elem(2 * pi, z0, r), b = mh_elem(2 * pi + 1, z1, r);
-                    put_xp(pi, a, b);
+                    if constexpr (USERPAIR) {
+                        const double a = x[2 * pi] + sig[2 * pi] * z0, b = x[2 * pi + 1] + sig[2 * pi + 1] * z1;      // MH.jl:79
+                        double nt, g0, g1;
+                        user_pair(pi, a, b, nt, g0, g1);                                                           // :81
+                        red[r] = red[r] + nt;
+                        put_xp(pi, a, b);
+                    } else {
+                        const double a = mh_elem(2 * pi, z0, r), b = mh_elem(2 * pi + 1, z1, r);
+                        put_xp(pi, a, b);
+                    }
                     if (!ZFIRST) KLARA_DT_PAIR_FENCE(pi);
                 }
                 if (NR == 2) {
@@ -586,8 +622,24 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                     double z0 = ZFIRST ? z[(2 * pi) % (ZFIRST ? E : 2)] : 0.0, z1 = ZFIRST ? z[(2 * pi + 1) % (ZFIRST ? E : 2)] : 0.0;
                     if (!ZFIRST) pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z0, z1, u_last, lg_last);
                     const int r = (NR == 2 && (pi & 1)) ? 3 : 0;
-                    const double a = mala_elem(2 * pi, z0, r), b = mala_elem(2 * pi + 1, z1, r);
-                    put_xp(pi, a, b);
+                    if constexpr (USERPAIR) {
+                        double nt, ge0, ge1, gp0, gp1;
+                        user_pair(pi, x[2 * pi], x[2 * pi + 1], nt, ge0, ge1);                    // (the current gradient, re-formed)
+                        const double m0 = x[2 * pi] + halfh * ge0, m1 = x[2 * pi + 1] + halfh * ge1;               // :83
+                        const double a = m0 + sq * z0, b = m1 + sq * z1;                                           // :84
+                        user_pair(pi, a, b, nt, gp0, gp1);                                                         // :86
+                        red[r] = red[r] + nt;
+                        const double q10 = m0 - a, q11 = m1 - b;
+                        red[r + 1] = red[r + 1] + (q10 * q10) * half_inv_h;                                        // :90
+                        red[r + 1] = red[r + 1] + (q11 * q11) * half_inv_h;
+                        const double q20 = (a + halfh * gp0) - x[2 * pi], q21 = (b + halfh * gp1) - x[2 * pi + 1]; // :91
+                        red[r + 2] = red[r + 2] + (q20 * q20) * half_inv_h;                                        // :92
+                        red[r + 2] = red[r + 2] + (q21 * q21) * half_inv_h;
+                        put_xp(pi, a, b);
+                    } else {
+                        const double a = mala_elem(2 * pi, z0, r), b = mala_elem(2 * pi + 1, z1, r);
+                        put_xp(pi, a, b);
+                    }
                     if (!ZFIRST) KLARA_DT_PAIR_FENCE(pi);
                 }
                 group_allreduce<3 * NR>(red, Q, cx.lane);
@@ -618,6 +670,19 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                 const int nl = DA ? (chain_ok ? da_nleaps(p, eps) : 1) : p.nleaps;             // :142-144 (padding lanes: 1)
                 for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {                          // :146-155, samplers.jl:122-134
                     const bool go = !DA || l < nl;
+                    if constexpr (USERPAIR) {
+#pragma unroll
+                        for (int pi = 0; pi < NP; ++pi) {
+                            const double ma = mom[2 * pi] + halfe * gp[2 * pi], mb = mom[2 * pi + 1] + halfe * gp[2 * pi + 1];
+                            const double xa = xp[2 * pi] + eps * ma, xb = xp[2 * pi + 1] + eps * mb;
+                            double nt, ga, gb;
+                            user_pair(pi, xa, xb, nt, ga, gb);
+                            const double na = ma + halfe * ga, nb = mb + halfe * gb;
+                            mom[2 * pi] = go ? na : mom[2 * pi]; mom[2 * pi + 1] = go ? nb : mom[2 * pi + 1];
+                            xp[2 * pi] = go ? xa : xp[2 * pi]; xp[2 * pi + 1] = go ? xb : xp[2 * pi + 1];
+                            gp[2 * pi] = go ? ga : gp[2 * pi]; gp[2 * pi + 1] = go ? gb : gp[2 * pi + 1];
+                        }
+                    } else {
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
                         const double m1 = mom[e] + halfe * gp[e];
@@ -627,13 +692,25 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                         const double m2 = m1 + halfe * g1;
                         mom[e] = go ? m2 : mom[e]; xp[e] = go ? x1 : xp[e]; gp[e] = go ? g1 : gp[e];
                     }
+                    }
                 }
+                if constexpr (USERPAIR) {
+#pragma unroll
+                    for (int pi = 0; pi < NP; ++pi) {
+                        double nt, ga, gb;
+                        user_pair(pi, xp[2 * pi], xp[2 * pi + 1], nt, ga, gb);                     // :157
+                        red[0] = red[0] + nt;
+                        red[1] = red[1] + mom[2 * pi] * mom[2 * pi];
+                        red[1] = red[1] + mom[2 * pi + 1] * mom[2 * pi + 1];
+                    }
+                } else {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     double term, gd;
                     diag_elem<UNITW>(xp[e], wv(e), m2wv(e), mv(e), term, gd);   // :157
                     red[0] = red[0] + term;
                     red[1] = red[1] + mom[e] * mom[e];
+                }
                 }
                 red2[0] = red[0]; red2[1] = red[1];
                 group_allreduce<2>(red2, Q, cx.lane);
@@ -722,9 +799,12 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
 }
 
 // initialize!(pstate, parameter, sampler) for layout kind 3: lt (and the gradient) at X, finiteness check
-template <int NP, int Q>
+template <int NP, int Q, bool USERPAIR = false>
 __global__ __launch_bounds__(256) void k_diagt_init(const KParams p, int needgrad)
 {
+#ifndef KLARA_USER_PAIR_TARGET
+    static_assert(!USERPAIR, "pair closures exist in run-time compiled translation units only");
+#endif
     constexpr int E = 2 * NP, CPW = 64 / Q;
     const int D = p.D;
     const PairCtx<NP, Q> cx = make_pctx<NP, Q>(D);
@@ -739,6 +819,17 @@ __global__ __launch_bounds__(256) void k_diagt_init(const KParams p, int needgra
     load_pair_param<NP, Q>(cx, p.gmu, D, 0.0, mu);
     load_pairs<NP, Q>(cx, group_window(p.X, first_chain, here, D), x);
     bool bad = false;
+    if constexpr (USERPAIR) {
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi) {
+            double u0 = 0.0, u1 = 0.0;
+            const double u = KLARA_PAIR_CALL(x[2 * pi], x[2 * pi + 1], pi * Q + cx.q, &u0, &u1);
+            const bool ok0 = pi < NP - 1 || cx.last_ok, ok1 = pi < NP - 1 || cx.last_full;
+            red[0] = red[0] + (ok0 ? -u : 0.0);
+            g[2 * pi] = ok0 ? u0 : 0.0; g[2 * pi + 1] = ok1 ? u1 : 0.0;
+            bad = bad || !kfinite(g[2 * pi]) || !kfinite(g[2 * pi + 1]);
+        }
+    } else {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         double term;
@@ -746,8 +837,9 @@ __global__ __launch_bounds__(256) void k_diagt_init(const KParams p, int needgra
         red[0] = red[0] + term;
         bad = bad || !kfinite(g[e]);
     }
+    }
     group_allreduce<1>(red, Q, cx.lane);
-    const double lt = p.gconst - red[0];
+    const double lt = (USERPAIR ? 0.0 : p.gconst) - red[0];
     bad = chain_ok && ((needgrad && bad) || !kfinite(lt));
     if (needgrad) store_pairs<NP, Q>(cx, group_window(p.GR, first_chain, here, D), g);
     if (chain_ok && cx.q == 0) p.LT[chain] = lt;

@@ -169,6 +169,23 @@ void cache_write(const std::string& path, const CodeObject& co)
 #ifndef KLARA_JIT_UNROLL_MAX_E
 #define KLARA_JIT_UNROLL_MAX_E 128   /* measured, MALA on 65,536 chains: E = 128 unrolled 2.3e8 transitions/s (11 s to compile) against 1.7e8 as loops (0.4 s); E = 256 unrolled 9.1e7 (32 s) against 8.1e7 (0.3 s); KLARA_JIT_UNROLL_MAX_E in the environment overrides */
 #endif
+// pair closures (klara_diagt.h USERPAIR) on the pair-transposed layout: NP pairs per lane, Q lanes per chain; `mode` here is
+// bit 0 = one transition per launch (ONESTEP), the job's monitor / tuner flags are fixed per handle
+struct PairForm { int NP = 0, Q = 0; bool mon = false, tune = false, da = false; };
+std::string pair_trans_expr(int sampler, const PairForm& f, int mode)
+{
+    char b[160];
+    const bool onestep = (mode & 1) != 0;
+    snprintf(b, sizeof b, "k_diagt<%d, %d, %d, %s, true, %s, %s, %s, true>", sampler, f.NP, f.Q, onestep ? "true" : "false",
+             f.mon ? "true" : "false", f.tune ? "true" : "false", f.da ? "true" : "false");
+    return b;
+}
+std::string pair_init_expr(const PairForm& f)
+{
+    char b[96];
+    snprintf(b, sizeof b, "k_diagt_init<%d, %d, true>", f.NP, f.Q);
+    return b;
+}
 std::string trans_expr(int sampler, int E, int mode)
 {
     char b[128];
@@ -183,12 +200,13 @@ std::string init_expr(int E)
 }
 
 // compile (or fetch) the code object of one (source, sampler, D, modes) combination
-klara_status compile(const char* src, int sampler, int D, int E, const int* modes, int nmodes, const CodeObject** out)
+klara_status compile(const char* src, int sampler, int D, int E, const int* modes, int nmodes, const CodeObject** out, const PairForm* pf = nullptr)
 {
     g_log.clear();
     Rtc* r = rtc();
     if (!r->ok) { g_log = "libhiprtc.so could not be loaded"; return KLARA_ERR_UNSUPPORTED; }
     std::string key = std::to_string(sampler) + "/" + std::to_string(D) + "/";
+    if (pf) key += "pair/" + std::to_string(pf->NP) + "/" + std::to_string(pf->Q) + "/" + std::to_string((int)pf->mon) + std::to_string((int)pf->tune) + std::to_string((int)pf->da) + "/";
     for (int i = 0; i < nmodes; ++i) key += std::to_string(modes[i]) + ",";
     key += (getenv("KLARA_JIT_UNROLL_MAX_E") ? getenv("KLARA_JIT_UNROLL_MAX_E") : ""); key += "\n"; key += src;
     {
@@ -226,11 +244,14 @@ klara_status compile(const char* src, int sampler, int D, int E, const int* mode
     // (the run-time compiler has no <stdint.h>; its own fixed-width types live in a private namespace)
     tu += "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
           "typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;\n";
+    if (pf) tu += "#ifndef KLARA_USER_PAIR_TARGET\n#define KLARA_USER_PAIR_TARGET 1\n#endif\n";
     tu += "#include \"klara_kernels.h\"\n"
           "#define KLARA_USER_FN static __device__ __forceinline__\n"
           "#line 1 \"klara_user_target\"\n";
     tu += src;
-    tu += "\n#line 1 \"klara_custom_glue\"\n#include \"klara_custom.h\"\n";
+    // the glue: whole-vector closures instantiate the group-layout kernels on CustomTarget (klara_custom.h); a pair closure is
+    // declared by now, so klara_diagt.h's USERPAIR branches can call it
+    tu += pf ? "\n#line 1 \"klara_custom_pair_glue\"\n#include \"klara_diagt.h\"\n" : "\n#line 1 \"klara_custom_glue\"\n#include \"klara_custom.h\"\n";
 
     hiprtcProgram prog;
     if (r->CreateProgram(&prog, tu.c_str(), "klara_custom_target.hip", klara_jit_nheaders, klara_jit_header_sources,
@@ -238,10 +259,10 @@ klara_status compile(const char* src, int sampler, int D, int E, const int* mode
         g_log = "hiprtcCreateProgram failed";
         return KLARA_ERR_COMPILE;
     }
-    const std::string ie = init_expr(E);
+    const std::string ie = pf ? pair_init_expr(*pf) : init_expr(E);
     r->AddNameExpression(prog, ie.c_str());
     std::vector<std::string> te;
-    for (int i = 0; i < nmodes; ++i) { te.push_back(trans_expr(sampler, E, modes[i])); r->AddNameExpression(prog, te.back().c_str()); }
+    for (int i = 0; i < nmodes; ++i) { te.push_back(pf ? pair_trans_expr(sampler, *pf, modes[i]) : trans_expr(sampler, E, modes[i])); r->AddNameExpression(prog, te.back().c_str()); }
     const hiprtcResult cr = r->CompileProgram(prog, (int)(sizeof opts / sizeof *opts), opts);
     size_t ls = 0;
     if (r->GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) { g_log.resize(ls); r->GetProgramLog(prog, &g_log[0]); }
@@ -273,6 +294,27 @@ struct KlaraJit {
     hipFunction_t init = nullptr;
     std::map<int, hipFunction_t> trans;
 };
+
+klara_status klara_jit_create_pair(const char* src, int sampler, int D, int NP, int Q, bool mon, bool tune, bool da, const int* modes, int nmodes,
+                                   bool load, KlaraJit** out)
+{
+    PairForm pf; pf.NP = NP; pf.Q = Q; pf.mon = mon; pf.tune = tune; pf.da = da;
+    const CodeObject* co = nullptr;
+    klara_status st = compile(src, sampler, D, 2 * NP, modes, nmodes, &co, &pf);
+    if (st != KLARA_OK || !load) return st;
+    KlaraJit* j = new (std::nothrow) KlaraJit();
+    if (!j) return KLARA_ERR_NOMEM;
+    bool ok = hipModuleLoadData(&j->mod, co->code.data()) == hipSuccess;
+    ok = ok && hipModuleGetFunction(&j->init, j->mod, co->init_name.c_str()) == hipSuccess;
+    for (auto it = co->trans_names.begin(); ok && it != co->trans_names.end(); ++it) {
+        hipFunction_t f = nullptr;
+        ok = hipModuleGetFunction(&f, j->mod, it->second.c_str()) == hipSuccess;
+        j->trans[it->first] = f;
+    }
+    if (!ok) { klara_jit_destroy(j); return KLARA_ERR_HIP; }
+    *out = j;
+    return KLARA_OK;
+}
 
 klara_status klara_jit_create(const char* src, int sampler, int D, int E, const int* modes, int nmodes, bool load, KlaraJit** out)
 {
@@ -322,6 +364,25 @@ hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaun
     KLaunch klv = kl;
     void* args[] = { &p, &klv };
     return hipModuleLaunchKernel(it->second, grid.x, 1, 1, 256, 1, 1, 0, st, args, nullptr);
+}
+
+// the pair-closure kernels take (KParams*, KLaunch, KAuto) like every k_diagt instantiation; one wavefront per chain group
+hipError_t klara_jit_launch_pair(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, long long nwaves, hipStream_t st)
+{
+    auto it = j->trans.find(mode);
+    if (it == j->trans.end()) return hipErrorInvalidValue;
+    if (klara_attr_query != nullptr) {
+        int regs = 0, scratch = 0, lds = 0;
+        hipError_t e = hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, it->second);
+        if (e == hipSuccess) e = hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, it->second);
+        if (e == hipSuccess) e = hipFuncGetAttribute(&lds, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, it->second);
+        klara_attr_query->numRegs = regs; klara_attr_query->localSizeBytes = (size_t)scratch; klara_attr_query->sharedSizeBytes = (size_t)lds;
+        return e;
+    }
+    KLaunch klv = kl;
+    KAuto ka = KLARA_AUTO_NONE;
+    void* args[] = { &p, &klv, &ka };
+    return hipModuleLaunchKernel(it->second, (unsigned)((nwaves + 3) / 4), 1, 1, 256, 1, 1, 0, st, args, nullptr);
 }
 
 const char* klara_jit_log() { return g_log.c_str(); }

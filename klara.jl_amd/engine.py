@@ -130,9 +130,27 @@ class CustomTarget:
         src = "#define KLARA_USER_LIKELIHOOD_PRIOR 1\n" + "\n".join(t for t in (loglikelihood, logprior, gradloglikelihood, gradlogprior) if t)
         return cls(ndims, src, data)
 
+    @classmethod
+    def pairwise(cls, ndims: int, pair_source: str, data=None) -> "CustomTarget":
+        """Closures of a target that is a SUM OF TERMS OF ONE OR TWO NEIGHBOURING COORDINATES, one element pair at a time:
+        `pair_source` is C text defining
+
+            KLARA_USER_FN double klara_user_pair(double x0, double x1, int pair, int D, const double* data, long long ndata,
+                                                 double* g0, double* g1);
+
+        with logtarget(x) = sum over pairs P of klara_user_pair(x[2P], x[2P+1], P, ...) and (*g0, *g1) the pair's two partial
+        derivatives (for the half pair of an odd D, x1 is 0 and *g1 is ignored).  Such a job runs on the few-lanes-per-chain
+        kernels of the diagonal Gaussian (layout kind 3: 8 / 16 / 32 lanes per chain, 17 <= D <= 512; MH, MALA, HMC with every tuner
+        and monitor) instead of one chain per lane — the form for large D (include/klara_hip.h, KLARA_USER_PAIR_TARGET)."""
+        return cls(ndims, "#define KLARA_USER_PAIR_TARGET 1\n" + pair_source, data)
+
     @property
     def has_parts(self) -> bool:
         return "KLARA_USER_LIKELIHOOD_PRIOR" in self.source
+
+    @property
+    def is_pairwise(self) -> bool:
+        return "KLARA_USER_PAIR_TARGET" in self.source
 
     def check(self, sampler: int) -> None:
         """Compile only (no GPU needed); raises KlaraError with the compiler's log on failure."""

@@ -310,6 +310,41 @@ static ko_user_lt_fn ko_user_lt = NULL;
 static ko_user_grad_fn ko_user_grad = NULL;
 void ko_set_custom_target(ko_user_lt_fn lt, ko_user_grad_fn grad) { ko_user_lt = lt; ko_user_grad = grad; }
 
+/* The same closures given one element pair at a time (`#define KLARA_USER_PAIR_TARGET 1`, include/klara_hip.h):
+ *     lt(x) = sum over pairs P of klara_user_pair(x[2P], x[2P+1], P, ...),   which also returns the pair's two partial derivatives.
+ * The device evaluates it on the pair-transposed layout (klara_diagt.h USERPAIR): pair P on lane P % G, a lane adds ITS pairs' terms in
+ * ascending order, then the xor butterfly — ko_reduce_pairs; the sums run over -term and lt = 0 - sum, the same bits as the sum of
+ * the terms.  The missing half of an odd D's last pair is passed as 0 and its derivative is dropped. */
+typedef double (*ko_user_pair_fn)(double x0, double x1, int pair, int D, const double* data, long long ndata, double* g0, double* g1);
+static ko_user_pair_fn ko_user_pair = NULL;
+void ko_set_custom_pair_target(ko_user_pair_fn f) { ko_user_pair = f; }
+static double ko_reduce_pairs(const ko_layout* L, const double* pt, int npairs)
+{
+    double part[64], nw[64];
+    const int G = L->G;
+    for (int l = 0; l < G; ++l) part[l] = 0.0;
+    for (int P = 0; P < npairs; ++P) part[P % G] = part[P % G] + pt[P];
+    for (int m = 1; m < G; m <<= 1) {
+        for (int l = 0; l < G; ++l) nw[l] = part[l] + part[l ^ m];
+        memcpy(part, nw, sizeof(double) * (size_t)G);
+    }
+    return part[0];
+}
+static double ko_pair_eval(const ko_target_ctx* c, const double* x, double* g)
+{
+    const klara_desc* d = c->d;
+    const int D = d->ndims, np = (D + 1) / 2;
+    double nt[KO_MAXD];
+    for (int P = 0; P < np; ++P) {
+        const int full = 2 * P + 1 < D;
+        double g0 = 0.0, g1 = 0.0;
+        const double u = ko_user_pair(x[2 * P], full ? x[2 * P + 1] : 0.0, P, D, d->custom_data, (long long)d->custom_ndata, &g0, &g1);
+        nt[P] = -u;
+        if (g) { g[2 * P] = g0; if (full) g[2 * P + 1] = g1; }
+    }
+    return 0.0 - ko_reduce_pairs(c->L, nt, np);
+}
+
 /* logtarget!(state) — BasicContMuvParameter.jl:174-201 */
 static double ko_logtarget(const ko_target_ctx* c, const double* x, double* scratch)
 {
@@ -321,7 +356,9 @@ static double ko_logtarget(const ko_target_ctx* c, const double* x, double* scra
         return ko_dense_lt_from_grad(c, x, g, scratch);
     }
     case KLARA_TARGET_HIER_NORMAL: return ko_hier_eval(c, x, NULL, scratch);
-    case KLARA_TARGET_CUSTOM: return ko_user_lt(x, c->d->ndims, c->d->custom_data, (long long)c->d->custom_ndata);
+    case KLARA_TARGET_CUSTOM:
+        if (ko_user_pair) return ko_pair_eval(c, x, NULL);
+        return ko_user_lt(x, c->d->ndims, c->d->custom_data, (long long)c->d->custom_ndata);
     default: { double lt; ko_logit_eval(c, x, &lt, NULL); return lt; }
     }
 }
@@ -333,6 +370,7 @@ static void ko_gradlogtarget(const ko_target_ctx* c, const double* x, double* g)
     case KLARA_TARGET_GAUSS_DENSE: ko_dense_grad(c, x, g); break;
     case KLARA_TARGET_HIER_NORMAL: { double sc[1]; (void)ko_hier_eval(c, x, g, sc); break; }
     case KLARA_TARGET_CUSTOM:      /* (MH / slice jobs need no gradient closure; their init evaluates none) */
+        if (ko_user_pair) { (void)ko_pair_eval(c, x, g); break; }
         if (ko_user_grad) ko_user_grad(x, c->d->ndims, c->d->custom_data, (long long)c->d->custom_ndata, g);
         else for (int i = 0; i < c->d->ndims; ++i) g[i] = 0.0;
         break;

@@ -168,6 +168,42 @@ KLARA_USER_FN void klara_user_gradlogtarget(const double* x, int D, const double
 """
 
 
+# ---- pair closures (K.CustomTarget.pairwise, include/klara_hip.h KLARA_USER_PAIR_TARGET): lt = sum over element pairs
+SRC_PAIR_NEGDOT = r"""
+/* README.md:23 logtarget = -dot(z, z), :155 gradlogtarget = -2 z, one element pair at a time */
+KLARA_USER_FN double klara_user_pair(double x0, double x1, int pair, int D, const double* data, long long ndata, double* g0, double* g1)
+{
+    *g0 = -2.0 * x0; *g1 = -2.0 * x1;
+    return -(x0 * x0 + x1 * x1);
+}
+"""
+SRC_PAIR_QUARTIC = r"""
+/* non-Gaussian, coupled within the pair: -(x0^2/2 + c x0^4) - (x1^2/2 + c x1^4) - k/2 (x1 - x0)^2, data = [c, k]; the half pair of
+ * an odd D (2 pair + 1 == D) has no second coordinate */
+KLARA_USER_FN double klara_user_pair(double x0, double x1, int pair, int D, const double* data, long long ndata, double* g0, double* g1)
+{
+    const double c = data[0], k = data[1];
+    const double q0 = x0 * x0, q1 = x1 * x1;
+    if (2 * pair + 1 >= D) { *g0 = -(x0 + (4.0 * c) * (q0 * x0)); *g1 = 0.0; return -(0.5 * q0 + c * (q0 * q0)); }
+    const double d = x1 - x0;
+    *g0 = -(x0 + (4.0 * c) * (q0 * x0)) + k * d;
+    *g1 = -(x1 + (4.0 * c) * (q1 * x1)) - k * d;
+    return -((0.5 * q0 + c * (q0 * q0)) + (0.5 * q1 + c * (q1 * q1))) - (0.5 * k) * (d * d);
+}
+"""
+SRC_PAIR_BANANA = r"""
+/* the twisted ("banana") Gaussian on every pair: -x0^2 / (2 s) - (x1 + b x0^2 - s b)^2 / 2, data = [b, s] */
+KLARA_USER_FN double klara_user_pair(double x0, double x1, int pair, int D, const double* data, long long ndata, double* g0, double* g1)
+{
+    const double b = data[0], s = data[1];
+    const double w = kd_fma(b, x0 * x0, x1) - s * b;
+    *g0 = -x0 / s - (w * (2.0 * b)) * x0;
+    *g1 = -w;
+    return -(x0 * x0) / (2.0 * s) - 0.5 * (w * w);
+}
+"""
+
+
 def synthetic_logit(n, d, seed=5):
     rng = np.random.default_rng(seed)
     X = rng.standard_normal((n, d))
@@ -446,6 +482,25 @@ def make_case(name):
     elif name == "custom_normal_normal_mh":     # no gradient closures needed
         t = K.CustomTarget.likelihood_prior(2, SRC_NN_LL, SRC_NN_LP, data=np.array([-1.88, 2.23, 1.0, 1.0, 0.0, 0.0, 1.0, 1.0]))
         c = dict(sampler=L.SAMPLER_MH, target=t, nchains=66, nsteps=50, burnin=10, mh_sigma=[0.8, 0.8], x0=np.tile([-2.637, -1.132], (66, 1)))
+    # ---- pair closures on the pair-transposed layout
+    elif name == "pair_negdot_mala_d100":      # the README closure, BASELINE cfg 2's shape, ragged chain count
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget.pairwise(100, SRC_PAIR_NEGDOT), nchains=67, nsteps=40, burnin=5, driftstep=0.05)
+    elif name == "pair_negdot_mala_d100_big_step":     # ... at the drift step of cfg 2 (rare accepts), one transition per launch exercised by the modes
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget.pairwise(100, SRC_PAIR_NEGDOT), nchains=130, nsteps=60, burnin=0, driftstep=0.9)
+    elif name == "pair_quartic_hmc_d50_tuned":
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget.pairwise(50, SRC_PAIR_QUARTIC, [0.02, 0.5]), nchains=33, nsteps=130, burnin=100,
+                 leapstep=0.15, nleaps=4, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.7, period=25, x0=0.5 * np.random.default_rng(4).standard_normal((33, 50)))
+    elif name == "pair_banana_mh_d33":         # odd D: the last pair is half a pair
+        c = dict(sampler=L.SAMPLER_MH, target=K.CustomTarget.pairwise(33, SRC_PAIR_QUARTIC, [0.1, 0.4]), nchains=45, nsteps=50, burnin=4, thinning=2,
+                 mh_sigma=np.linspace(0.05, 0.4, 33), x0=0.3 * np.random.default_rng(5).standard_normal((45, 33)))
+    elif name == "pair_banana_hmc_d100_dualavg":
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget.pairwise(100, SRC_PAIR_BANANA, [0.05, 9.0]), nchains=21, nsteps=60, burnin=0,
+                 leapstep=0.05, nleaps=6, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=40,
+                 x0=np.random.default_rng(6).standard_normal((21, 100)) * np.tile([2.0, 1.0], 50))
+    elif name == "pair_quartic_mala_d300_pooled":      # 32 lanes per chain, pooled tuner
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget.pairwise(300, SRC_PAIR_QUARTIC, [0.05, 0.3]), nchains=19, nsteps=120, burnin=100,
+                 driftstep=0.02, tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.574, period=20,
+                 x0=0.4 * np.random.default_rng(7).standard_normal((19, 300)))
     elif name == "custom_quartic_slice_d7":
         c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget(7, SRC_QUARTIC_CHAIN, [0.1, 0.4]), nchains=66, nsteps=12, burnin=2,
                  slice_widths=np.full(7, 1.5))
@@ -472,12 +527,14 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
              "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
              "custom_quartic_mala_d64", "custom_quartic_mala_d100", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh",
-             "sparse_mala_d100", "sparse_mala_d100_small_step", "sparse_mh_d100", "sparse_mala_mvnormal_d30"]
+             "sparse_mala_d100", "sparse_mala_d100_small_step", "sparse_mh_d100", "sparse_mala_mvnormal_d30",
+             "pair_negdot_mala_d100", "pair_negdot_mala_d100_big_step", "pair_quartic_hmc_d50_tuned", "pair_banana_mh_d33",
+             "pair_banana_hmc_d100_dualavg", "pair_quartic_mala_d300_pooled"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",
                 "dt_mala_d100_small_step", "dt_hmc_d100", "dt_mh_mvnormal_d20", "custom_banana_hmc",
-                "custom_quartic_mala_d20_pooled"]
+                "custom_quartic_mala_d20_pooled", "pair_quartic_hmc_d50_tuned"]
 
 
 def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):

@@ -61,6 +61,8 @@ def load() -> C.CDLL:
     lib.ko_bm_close.restype = None
     lib.ko_set_custom_target.argtypes = [vp, vp]
     lib.ko_set_custom_target.restype = None
+    lib.ko_set_custom_pair_target.argtypes = [vp]
+    lib.ko_set_custom_pair_target.restype = None
     for name in ("ko_logistic",):
         getattr(lib, name).argtypes = [C.c_double] * 5
         getattr(lib, name).restype = C.c_double
@@ -93,9 +95,12 @@ def compile_user_target(src: str, ndims: int):
         if r.returncode != 0:
             raise RuntimeError("user target did not compile on the host:\n" + r.stderr)
     lib = C.CDLL(str(so))
+    if "KLARA_USER_PAIR_TARGET" in src:        # pair closure (klara_user_pair): third entry; no whole-vector closures
+        _user_libs[key] = (lib, None, None, C.cast(lib.klara_user_pair, C.c_void_p))
+        return _user_libs[key]
     lt = C.cast(lib.klara_user_logtarget, C.c_void_p)
     grad = C.cast(lib.klara_user_gradlogtarget, C.c_void_p) if hasattr(lib, "klara_user_gradlogtarget") else None
-    _user_libs[key] = (lib, lt, grad)
+    _user_libs[key] = (lib, lt, grad, None)
     return _user_libs[key]
 
 
@@ -104,7 +109,7 @@ DIAGT_Q = 8
 
 
 def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, tuner=0, tuner_mode=0, verbose=False,
-                   hier_nunits: int = 0, hier_ntimes: int = 0, summaries: bool = True, sparse_moves: bool = False):
+                   hier_nunits: int = 0, hier_ntimes: int = 0, summaries: bool = True, sparse_moves: bool = False, pair_form: bool = False):
     """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box).  `sampler`, `tuner`,
     `tuner_mode` and `verbose` are only needed to recognise the pair-transposed layout (kind 3): diagonal Gaussian,
     MH / MALA / HMC, even D <= 128, Vanilla or AcceptanceRate tuner (klara_api.hip diagt_eligible)."""
@@ -118,6 +123,9 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     if (target_kind == L.TARGET_HIER_NORMAL and sampler in (L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC)
             and 9 <= hier_nunits <= 32 and os.environ.get("KLARA_LAYOUT_KIND", "4") != "0"):
         return (4, 8, 8)              # klara_hiert.h: 8 lanes per chain, 4 units per lane
+    if target_kind == L.TARGET_CUSTOM and pair_form:     # pair closure: the pair-transposed layout (klara_api.hip select_layout)
+        q = 8 if d <= 128 else (16 if d <= 256 else 32)
+        return (3, q, 2 * ((d + 2 * q - 1) // (2 * q)))
     if target_kind == L.TARGET_CUSTOM:        # one chain per lane, pow2ceil(D) elements in registers (klara_custom.h)
         e = 2
         while e < d:
@@ -205,7 +213,8 @@ class OracleJob:
         k, g, e = layout if layout is not None else default_layout(int(target_kind), self.D, int(d.logit_ndata), sampler=int(sampler),
                                                                    tuner=int(tuner), tuner_mode=int(tuner_mode), verbose=bool(verbose),
                                                                    hier_nunits=int(d.hier_nunits), hier_ntimes=int(d.hier_ntimes),
-                                                                   summaries=bool(want_sums), sparse_moves=bool(sparse_moves))
+                                                                   summaries=bool(want_sums), sparse_moves=bool(sparse_moves),
+                                                                   pair_form=bool(custom_src is not None and "KLARA_USER_PAIR_TARGET" in custom_src))
         self.layout = KoLayout(k, g, e)
         nt = 1 if tuner_mode == L.TUNE_POOLED else self.N
         self.X = np.zeros((self.N, self.D)); self.G = np.zeros((self.N, self.D)); self.LT = np.zeros(self.N)
@@ -240,6 +249,7 @@ class OracleJob:
     def _bind_user(self):
         if self._user is not None:             # (process-global in the oracle: bound before every call that evaluates the target)
             self.lib.ko_set_custom_target(self._user[1], self._user[2])
+            self.lib.ko_set_custom_pair_target(self._user[3])
 
     def set_state(self, x) -> int:
         self.X[...] = _f64(x).reshape(self.N, self.D)

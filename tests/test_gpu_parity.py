@@ -1088,7 +1088,7 @@ def test_likelihood_prior_closures_through_the_job_api():
     o = O.OracleJob(**cases.oracle_kwargs(case, layout=job.engine.layout()), want_hist=True)
     o.set_state(case["x0"]); o.run(60)
     assert np.array_equal(job.engine.accept_mask(), o.accept) and 0.2 < o.accept.mean() < 0.95
-    lib, _, _ = O.compile_user_target(t.source, 6)
+    lib = O.compile_user_target(t.source, 6)[0]
     dp = C.POINTER(C.c_double)
     for f in (lib.klara_user_loglikelihood, lib.klara_user_logprior):
         f.restype = C.c_double; f.argtypes = [dp, C.c_int, dp, C.c_longlong]

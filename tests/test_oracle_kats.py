@@ -307,7 +307,7 @@ def test_likelihood_prior_closures_normal_normal_kats(mu, x, s, mu0, s0):
     import ctypes as C
     t = cases.normal_normal_target(x, s, mu0, s0)
     assert t.has_parts
-    lib, lt_ptr, grad_ptr = O.compile_user_target(t.source, 2)
+    lib, lt_ptr, grad_ptr = O.compile_user_target(t.source, 2)[:3]
     mu = np.array(mu, float); data = t.data
     dp = C.POINTER(C.c_double)
     for f in (lib.klara_user_loglikelihood, lib.klara_user_logprior, lib.klara_user_logtarget):
