@@ -105,6 +105,11 @@ def valu_roofline(kernel_sub, launch_s, grid=None, label=None, necessary_per_lau
                   necessary_valu_insts_per_launch=necessary_per_launch)
     if budget is not None:
         rf["budget"] = {k: v for k, v in budget.items()}
+        if necessary_per_launch is not None and budget.get("extra_issue_units_per_wave_transition") is not None:
+            # the same fraction with v_mad_u64_u32 (x 1.6) and v_rsq_f64 / v_rcp_f64 (x 3.2) at their measured issue cost
+            # (profiles/r3_ubench_instruction_costs.txt) instead of one plain instruction each
+            w = 1.0 + budget["extra_issue_units_per_wave_transition"] / budget["per_wave_transition"]
+            rf["frac_at_measured_instruction_costs"] = rf["frac"] * w
     row = pmc_lookup(kernel_sub, grid)
     pmc = {"file": f"profiles/{PMC_JSON.name}", "key": kernel_sub, "kernel": None, "stale": None}
     rf["pmc"] = pmc

@@ -49,7 +49,7 @@ struct klara_handle {
     // streaming autocovariances (acov_maxlag > 0): W = maxlag + 1 lags; [k][series] layouts
     int acov_W = 0; double *acov_S = nullptr, *acov_head = nullptr, *acov_tail = nullptr, *acov_total = nullptr; long long acov_n = 0;
     double *hist_lt = nullptr, *hist_g = nullptr, *hist_ll = nullptr, *hist_lp = nullptr;
-    int* err = nullptr;
+    int* err = nullptr; int* flag_host = nullptr;     // device error flag; pinned host word it is read back into
     double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr,
            *hY = nullptr, *hxc = nullptr;
     double* pooled_out = nullptr;   // 2*D doubles + 1 u64 scratch for pooled summaries
@@ -256,6 +256,7 @@ static void free_all(klara_handle* h)
     hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->pool_partial); hipFree(h->d_params); hipFree(h->cdata);
     hipFree(h->bm_prev); hipFree(h->bm_mean); hipFree(h->bm_m2); hipFree(h->auto_cells); hipFree(h->auto_ctr);
     if (h->auto_mirror) hipHostFree(h->auto_mirror);
+    if (h->flag_host) hipHostFree(h->flag_host);
     klara_jit_destroy(h->jit);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -461,6 +462,7 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out)
     if (desc->tuner == KLARA_TUNER_DUAL_AVERAGING) { CKH(dalloc(&h->da_epsbar, NT)); CKH(dalloc(&h->da_hbar, NT)); } CKH(dalloc(&h->pooled_acc, 1)); CKH(dalloc(&h->naccept, N));
     CKH(dalloc(&h->err, 1)); CKH(dalloc(&h->pooled_out, 2 * D + 2)); CKH(dalloc(&h->pool_partial, (size_t)1024 * (2 * D + 1)));
     CKH(hipMemset(h->err, 0, sizeof(int)));
+    if (hipHostMalloc((void**)&h->flag_host, sizeof(int), hipHostMallocDefault) != hipSuccess) { h->flag_host = nullptr; (void)hipGetLastError(); }
     if (desc->monitor & KLARA_MON_SUMMARIES) { CKH(dalloc(&h->sum, N * D)); CKH(dalloc(&h->sumsq, N * D)); CKH(dalloc(&h->held, N)); }
     if (desc->bm_batchlen > 0) { CKH(dalloc(&h->bm_prev, N * D)); CKH(dalloc(&h->bm_mean, N * D)); CKH(dalloc(&h->bm_m2, N * D)); }
     if (desc->monitor & KLARA_MON_ACCEPT) {
@@ -1209,9 +1211,17 @@ extern "C" klara_status klara_synchronize(klara_handle* h)
 {
     if (!h) return KLARA_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(h->d.device));
+    // (the error flag comes back into PINNED host memory: a 4-byte copy into pageable memory is staged by the runtime and costs a
+    // 20-transition run of the headline job ~2 % of its time)
     int flag = 0;
-    HIPCHK(hipMemcpyAsync(&flag, h->err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->flag_host) {
+        HIPCHK(hipMemcpyAsync(h->flag_host, h->err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        flag = *h->flag_host;
+    } else {
+        HIPCHK(hipMemcpyAsync(&flag, h->err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     if (flag != 0) return (klara_status)flag;
     return KLARA_OK;
 }

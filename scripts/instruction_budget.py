@@ -3,9 +3,9 @@
 
 `roofline.frac` in the bench line is  necessary VALU issue-cycles / elapsed SIMD-cycles:  the instructions the algorithm AS SPECIFIED
 needs (this file: one count per source-level operation of detmath.h and of the sampler / target arithmetic, at its cheapest gfx950
-encoding), 4 issue cycles each (one FP64 / integer vector instruction of a 64-lane wavefront on a 16-lane SIMD; the quarter-rate
-v_rsq_f64 / v_rcp_f64 are counted as one instruction like everything else, which makes the budget slightly too small, i.e. the
-fraction conservative), divided by launch duration x 1,024 SIMDs x 2.4 GHz.  The instructions a kernel actually ISSUES come from the
+encoding), 4 issue cycles each (one FP64 / integer vector instruction of a 64-lane wavefront on a 16-lane SIMD; v_mad_u64_u32 and the
+quarter-rate v_rsq_f64 / v_rcp_f64 are counted as ONE instruction like everything else, which makes the budget too small, i.e. the
+fraction conservative — `extra_issue_units` below carries what they really cost), divided by launch duration x 1,024 SIMDs x 2.4 GHz.  The instructions a kernel actually ISSUES come from the
 PMC summaries (SQ_INSTS_VALU per launch, profiles/r3_pmc_kernels.json) and from the compiler's assembly (scripts/asm_loops.py); the
 bench line carries both and their ratio.  VALU-busy time / elapsed time is reported as `utilisation`: it says the pipe is full,
 not that the kernel is tight.
@@ -42,14 +42,14 @@ def mala_diag_unitw_element():
     """iterate/MALA.jl:83-92 on one element of lt = -|x|^2 (no contraction: Julia evaluates a*b + c in two roundings):
     grad (1), drift mean (mul, add), proposal (mul, add), its square (1), its gradient (1), sum (1), q1 (sub, mul, mul, add), backward mean
     (mul, add), q2 (sub, mul, mul, add)"""
-    return 1 + 2 + 2 + 1 + 1 + 1 + 4 + 2 + 4          # 19
+    return 1 + 2 + 2 + 1 + 1 + 1 + 4 + 2 + 4          # 18
 
 
 def headline(lanes_per_chain: int = 4, ndims: int = 100):
     """k_diagt<MALA, ..., UNITW, MON>: necessary instructions per WAVEFRONT and transition.  A chain's ceil(D/2) element pairs are one
     Philox block + one Box-Muller evaluation + two elements of sampler arithmetic each; a wavefront carries 64 / lanes chains."""
     chains = 64 // lanes_per_chain
-    pair = NORMAL_PAIR + 2 * mala_diag_unitw_element()                 # 102 + 38 = 140
+    pair = NORMAL_PAIR + 2 * mala_diag_unitw_element()                 # 102 + 36 = 138
     pairs = (ndims + 1) // 2 * chains / 64.0                           # pair evaluations per lane: 12.5 (4 lanes), 6.25 (8 lanes)
     # the three sums of the Metropolis ratio in the 8-lane order: 8 lanes: 3 butterfly steps; 4 lanes: two partial sums per lane, 2 steps
     # on both, then their sum
@@ -90,7 +90,25 @@ def cfg4_logistic(ndata: int = 200, ndims: int = 4, rowsplit: int = 8):
             "per_wave_transition": rows * row + bfly + prior + normals + sampler + accept, "chains_per_wave": 64 // rowsplit}
 
 
-BUDGETS = {"headline_4lane": headline(4), "headline_8lane": headline(8), "cfg5": cfg5_hier(), "cfg4": cfg4_logistic()}
+# ---- the same budgets weighted by what an instruction costs the issue port -----------------------------------------------------------
+# scripts/ubench.hip (profiles/r3_ubench_instruction_costs.txt, 8 independent chains x 4 wavefronts per SIMD): against a plain vector
+# instruction (v_add_f64 / v_mul_f64 / v_fma_f64 / v_bitop3: 5.0-5.4 "cycles at 2.4 GHz" on a chip that clocks ~1.9 GHz in that loop = 4
+# real cycles), v_mad_u64_u32 takes 8.27 (x 1.6) and v_rsq_f64 / v_rcp_f64 ~16 (x 3.2).  `extra_issue_units` are the instruction-equivalents
+# those three add to a budget; bench.py reports the fraction with and without them.
+MAD_EXTRA, QUARTER_EXTRA = 0.6, 2.2
+PAIR_EXTRA = 20 * MAD_EXTRA + QUARTER_EXTRA                # 20 v_mad_u64_u32 of a Philox block, the radius' v_rsq_f64
+
+
+def _with_extra(b, extra):
+    b = dict(b); b["extra_issue_units_per_wave_transition"] = extra
+    return b
+
+
+_h4, _h8, _c5, _c4 = headline(4), headline(8), cfg5_hier(), cfg4_logistic()
+BUDGETS = {"headline_4lane": _with_extra(_h4, _h4["pair_evaluations_per_lane"] * PAIR_EXTRA),
+           "headline_8lane": _with_extra(_h8, _h8["pair_evaluations_per_lane"] * PAIR_EXTRA),
+           "cfg5": _with_extra(_c5, 7 * PAIR_EXTRA + 20 * MAD_EXTRA),                       # momentum pairs + the accept draw's Philox block
+           "cfg4": _with_extra(_c4, 2 * PAIR_EXTRA + _c4["rows_per_lane"] * QUARTER_EXTRA + 5 * QUARTER_EXTRA)}   # + one v_rcp_f64 per row and per prior division
 
 if __name__ == "__main__":
     print(f"building blocks: Philox4x32-10 {PHILOX}, u52 {U52}, log(u) {LOG_U01}, radius {SQRT_RAD}, sin/cos {SINCOS}, normal pair {NORMAL_PAIR}, "

@@ -31,6 +31,52 @@ __global__ __launch_bounds__(256) void k_op(double* out, double seedv, int G)
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = a + b + acc + c0 + c1;
 }
 
+// issue cost of single instructions: 8 independent chains per wavefront (throughput, not latency), 4 wavefronts per SIMD
+template <int OP>
+__global__ __launch_bounds__(256) void k_tp(double* out, double seedv)
+{
+    const int lane = threadIdx.x & 63;
+    double a[8]; uint32_t u[8]; uint64_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] = seedv + 1e-3 * lane + k; u[k] = threadIdx.x * 7u + k; w[k] = (uint64_t)threadIdx.x * 0x9E3779B97F4A7C15ull + k; }
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (OP == 0) a[k] = kd_fma(a[k], 0.999, 0.001);
+            else if (OP == 1) a[k] = a[k] + 1.25;
+            else if (OP == 2) a[k] = a[k] * 1.0000001;
+            else if (OP == 3) { const uint64_t p = (uint64_t)u[k] * 0xD2511F53u + w[k]; w[k] = p; u[k] = (uint32_t)(p >> 32); }     // v_mad_u64_u32
+            else if (OP == 4) u[k] = u[k] * 0x9E3779B9u;                                                                        // v_mul_lo_u32
+            else if (OP == 5) u[k] = __umulhi(u[k], 0xD2511F53u) + 1u;                                                          // v_mul_hi_u32 (+ add)
+            else if (OP == 6) u[k] = KD_XOR3(u[k], 0x12345u, (uint32_t)i);                                                      // v_bitop3
+            else if (OP == 7) a[k] = __builtin_amdgcn_rsq(a[k]) + 2.0;                                                          // v_rsq_f64 (+ add)
+            else if (OP == 8) a[k] = __builtin_amdgcn_rcp(a[k]) + 2.0;                                                          // v_rcp_f64 (+ add)
+            else if (OP == 9) a[k] = (double)(int)(a[k]) + 1.5;                                                                 // cvt_i32_f64 + cvt_f64_i32 (+ add)
+            else if (OP == 10) a[k] = dpp_mov<0xB1>(a[k]) + 1.0;                                                                // 2 v_mov_dpp (+ add)
+            else if (OP == 11) a[k] = a[k] > 3.0 ? a[k] - 1.0 : a[k] + 0.5;                                                      // cmp + 2 cndmask + 2 add
+        }
+    }
+    double s = 0.0; uint32_t t = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s += a[k]; t += u[k] + (uint32_t)w[k]; }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s + t;
+}
+template <int OP>
+static void run_tp(const char* name)
+{
+    double* d; hipMalloc(&d, sizeof(double) * 256 * 1024 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int blocks = 256 * 4;
+    hipLaunchKernelGGL(k_tp<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.5);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_tp<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.5);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-44s %6.2f cycles per wave-instruction group at 2.4 GHz (8 independent chains x 4 waves/SIMD, %.3f ms)\n", name,
+           ms * 1e-3 * 2.4e9 / (4.0 * ITERS * 8.0), ms);
+    hipFree(d);
+}
+
 template <int OP>
 static void run(const char* name, int G = 64)
 {
@@ -81,6 +127,18 @@ static void mfma_peak()
 
 int main()
 {
+    run_tp<0>("v_fma_f64");
+    run_tp<1>("v_add_f64");
+    run_tp<2>("v_mul_f64");
+    run_tp<3>("v_mad_u64_u32");
+    run_tp<4>("v_mul_lo_u32");
+    run_tp<5>("v_mul_hi_u32 + v_add_u32");
+    run_tp<6>("v_bitop3_b32");
+    run_tp<7>("v_rsq_f64 + v_add_f64");
+    run_tp<8>("v_rcp_f64 + v_add_f64");
+    run_tp<9>("v_cvt_i32_f64 + v_cvt_f64_i32 + v_add_f64");
+    run_tp<10>("2 v_mov_dpp + v_add_f64");
+    run_tp<11>("v_cmp_f64 + 2 v_cndmask + 2 v_add_f64");
     mfma_peak();
     run<8>("fma_f64 (dependent)");
     run<9>("mul_lo_u32 chain");
