@@ -301,7 +301,7 @@ def main():
 
 def diagt_kernel_name(sampler_id, lay_g, lay_e, onestep, unitw, mon, tune=False, da=False):
     b = lambda v: "true" if v else "false"
-    return f"k_diagt<{sampler_id}, {lay_e // 2}, {lay_g}, {b(onestep)}, {b(unitw)}, {b(mon)}, {b(tune)}, {b(da)}>"
+    return f"k_diagt<{sampler_id}, {lay_e // 2}, {lay_g}, {b(onestep)}, {b(unitw)}, {b(mon)}, {b(tune)}, {b(da)},"      # (prefix: further template flags follow)
 
 
 def diagt_grid(n, lay_g):

@@ -668,30 +668,35 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                 for (int e = 0; e < E; ++e) xp[e] = x[e];                                      // :139
                 grad_of(x, gp);                                                                // :140 (re-formed)
                 const int nl = DA ? (chain_ok ? da_nleaps(p, eps) : 1) : p.nleaps;             // :142-144 (padding lanes: 1)
-                for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {                          // :146-155, samplers.jl:122-134
+                // leapfrog! nl times (:146-155, samplers.jl:122-134) in its merged form (deliberate deviation (7),
+                // mirrored by the oracle): adjacent half-kicks are one update, every update is one fma
+#pragma unroll
+                for (int e = 0; e < E; ++e) mom[e] = kd_fma(halfe, gp[e], mom[e]);
+                for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {
                     const bool go = !DA || l < nl;
+                    const double kf = l + 1 < nl ? eps : halfe;
                     if constexpr (USERPAIR) {
 #pragma unroll
                         for (int pi = 0; pi < NP; ++pi) {
-                            const double ma = mom[2 * pi] + halfe * gp[2 * pi], mb = mom[2 * pi + 1] + halfe * gp[2 * pi + 1];
-                            const double xa = xp[2 * pi] + eps * ma, xb = xp[2 * pi + 1] + eps * mb;
-                            double nt, ga, gb;
-                            user_pair(pi, xa, xb, nt, ga, gb);
-                            const double na = ma + halfe * ga, nb = mb + halfe * gb;
-                            mom[2 * pi] = go ? na : mom[2 * pi]; mom[2 * pi + 1] = go ? nb : mom[2 * pi + 1];
+                            const double xa = kd_fma(eps, mom[2 * pi], xp[2 * pi]), xb = kd_fma(eps, mom[2 * pi + 1], xp[2 * pi + 1]);
                             xp[2 * pi] = go ? xa : xp[2 * pi]; xp[2 * pi + 1] = go ? xb : xp[2 * pi + 1];
+                            double nt, ga, gb;
+                            user_pair(pi, xp[2 * pi], xp[2 * pi + 1], nt, ga, gb);
                             gp[2 * pi] = go ? ga : gp[2 * pi]; gp[2 * pi + 1] = go ? gb : gp[2 * pi + 1];
+                            const double na = kd_fma(kf, gp[2 * pi], mom[2 * pi]), nb = kd_fma(kf, gp[2 * pi + 1], mom[2 * pi + 1]);
+                            mom[2 * pi] = go ? na : mom[2 * pi]; mom[2 * pi + 1] = go ? nb : mom[2 * pi + 1];
                         }
                     } else {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const double m1 = mom[e] + halfe * gp[e];
-                        const double x1 = xp[e] + eps * m1;
-                        double term, g1;
-                        diag_elem<UNITW>(x1, 1.0, m2wvl(e), mvl(e), term, g1);           // (term unused in the leapfrog)
-                        const double m2 = m1 + halfe * g1;
-                        mom[e] = go ? m2 : mom[e]; xp[e] = go ? x1 : xp[e]; gp[e] = go ? g1 : gp[e];
-                    }
+                        for (int e = 0; e < E; ++e) {
+                            const double x1 = kd_fma(eps, mom[e], xp[e]);
+                            xp[e] = go ? x1 : xp[e];
+                            double term, g1;
+                            diag_elem<UNITW>(xp[e], 1.0, m2wvl(e), mvl(e), term, g1);       // (term unused in the leapfrog)
+                            gp[e] = go ? g1 : gp[e];
+                            const double m2 = kd_fma(kf, gp[e], mom[e]);
+                            mom[e] = go ? m2 : mom[e];
+                        }
                     }
                 }
                 if constexpr (USERPAIR) {

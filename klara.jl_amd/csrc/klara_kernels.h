@@ -765,35 +765,38 @@ KLARA_PRAGMA_UNROLL_E
 KLARA_PRAGMA_UNROLL_E
     for (int e = 0; e < E; ++e) { xp[e] = x[e]; gp[e] = g[e]; }                       // :139-140
     const double halfe = 0.5 * eps;
+    // leapfrog! `nleaps` times (:146-155, samplers.jl:122-134) in its merged form (deliberate deviation (7); the
+    // oracle takes the same steps): the closing half-kick of step l and the opening half-kick of step l + 1 use the same gradient and
+    // are ONE update p += eps g, and every update is one fma:
+    //   p = fma(eps/2, g, p);  L x { x = fma(eps, p, x);  g = grad(x);  p = fma(l < L-1 ? eps : eps/2, g, p) }
+KLARA_PRAGMA_UNROLL_E
+    for (int e = 0; e < E; ++e) mom[e] = kd_fma(halfe, gp[e], mom[e]);
     if (!KDA) {
-        for (int l = 0; l < p.nleaps; ++l) {                                          // :146-155
+        const int nl = p.nleaps;
+        for (int l = 0; l < nl; ++l) {
 KLARA_PRAGMA_UNROLL_E
-            for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];              // samplers.jl:130
+            for (int e = 0; e < E; ++e) xp[e] = kd_fma(eps, mom[e], xp[e]);
+            tg.template eval<false, true>(cx, xp, dummy, gp);
+            const double kf = l + 1 < nl ? eps : halfe;
 KLARA_PRAGMA_UNROLL_E
-            for (int e = 0; e < E; ++e) xp[e] = xp[e] + eps * mom[e];                 // samplers.jl:131
-            tg.template eval<false, true>(cx, xp, dummy, gp);                         // samplers.jl:132
-KLARA_PRAGMA_UNROLL_E
-            for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];              // samplers.jl:133
+            for (int e = 0; e < E; ++e) mom[e] = kd_fma(kf, gp[e], mom[e]);
         }
     } else {
         // dual averaging: the trip count differs per chain (iterate/HMC.jl:142-144); the wavefront runs to the
-        // longest trajectory it carries and finished chains are masked (the target evaluation may use
+        // longest trajectory it carries and finished chains keep their state (the target evaluation may use
         // cross-lane collectives, so control flow stays wave-uniform)
         for (int l = 0; __any(l < nleaps); ++l) {
             const bool go = l < nleaps;
-            double mo[E], xo[E], go_[E];
+            double gn[E];
 KLARA_PRAGMA_UNROLL_E
-            for (int e = 0; e < E; ++e) { mo[e] = mom[e]; xo[e] = xp[e]; go_[e] = gp[e]; }
+            for (int e = 0; e < E; ++e) { const double xn = kd_fma(eps, mom[e], xp[e]); xp[e] = go ? xn : xp[e]; }
+            tg.template eval<false, true>(cx, xp, dummy, gn);
+            const double kf = l + 1 < nleaps ? eps : halfe;          // the chain's own last step closes with a half-kick
 KLARA_PRAGMA_UNROLL_E
-            for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];
-KLARA_PRAGMA_UNROLL_E
-            for (int e = 0; e < E; ++e) xp[e] = xp[e] + eps * mom[e];
-            tg.template eval<false, true>(cx, xp, dummy, gp);
-KLARA_PRAGMA_UNROLL_E
-            for (int e = 0; e < E; ++e) mom[e] = mom[e] + halfe * gp[e];
-            if (!go) {
-KLARA_PRAGMA_UNROLL_E
-                for (int e = 0; e < E; ++e) { mom[e] = mo[e]; xp[e] = xo[e]; gp[e] = go_[e]; }
+            for (int e = 0; e < E; ++e) {
+                gp[e] = go ? gn[e] : gp[e];
+                const double mn = kd_fma(kf, gp[e], mom[e]);
+                mom[e] = go ? mn : mom[e];
             }
         }
     }

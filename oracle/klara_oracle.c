@@ -485,10 +485,6 @@ static int ko_mala(const ko_target_ctx* c, uint64_t chain, uint64_t t, double h,
     return acc;
 }
 
-/* which jobs take the merged leapfrog (see ko_hmc): the ones the device runs on its few-lanes hierarchical kernels (layout kind 4)
- * and on the matrix-core kernels of the dense target (kind 1) */
-static int ko_merged_leapfrog(const ko_target_ctx* c) { return c->L->kind == 4 || c->L->kind == 1; }
-
 /* iterate!(job, HMC, Multivariate) — src/samplers/iterate/HMC.jl:124-201;
  * leapfrog! — src/samplers/samplers.jl:122-134; hamiltonian — samplers.jl:103 */
 static int ko_hmc(const ko_target_ctx* c, uint64_t chain, uint64_t t, double eps, int64_t nleaps,
@@ -503,24 +499,16 @@ static int ko_hmc(const ko_target_ctx* c, uint64_t chain, uint64_t t, double eps
     memcpy(xp, x, sizeof(double) * (size_t)D);                           /* :139 */
     memcpy(gp, g, sizeof(double) * (size_t)D);                           /* :140 */
     const double halfe = 0.5 * eps;
-    if (ko_merged_leapfrog(c)) {
-        /* DELIBERATE DEVIATION for the kernels that run the merged leapfrog (klara_hiert.h, layout
-         * kind 4; klara_dense.h, kind 1): the closing half-kick of step l and the opening half-kick of step l + 1 use the same gradient and are one
-         * update p += eps g, and every update is one fma.  Same trajectory in exact arithmetic; <= 1 ulp per update from the
-         * literal form below (samplers.jl:130-133 evaluates p + (eps/2) g twice, unfused). */
-        for (int i = 0; i < D; ++i) p[i] = kd_fma(halfe, gp[i], p[i]);
-        for (int64_t l = 0; l < nleaps; ++l) {
-            for (int i = 0; i < D; ++i) xp[i] = kd_fma(eps, p[i], xp[i]);
-            ko_gradlogtarget(c, xp, gp);
-            const double kf = l + 1 < nleaps ? eps : halfe;
-            for (int i = 0; i < D; ++i) p[i] = kd_fma(kf, gp[i], p[i]);
-        }
-    } else
+    /* DELIBERATE DEVIATION, as every HMC kernel of the library runs it: leapfrog! L times
+     * (samplers.jl:122-134: p = p + eps/2 g; x = x + eps p; g = grad(x); p = p + eps/2 g, each an unfused a + b*c) in its merged
+     * form — the closing half-kick of step l and the opening half-kick of step l + 1 use the same gradient and are ONE update
+     * p += eps g, and every update is one fma.  The same trajectory in exact arithmetic; <= 1 ulp per update from the literal form. */
+    for (int i = 0; i < D; ++i) p[i] = kd_fma(halfe, gp[i], p[i]);       /* samplers.jl:130 of the first step */
     for (int64_t l = 0; l < nleaps; ++l) {                               /* :146-155 */
-        for (int i = 0; i < D; ++i) p[i] = p[i] + halfe * gp[i];         /* samplers.jl:130 */
-        for (int i = 0; i < D; ++i) xp[i] = xp[i] + eps * p[i];          /* samplers.jl:131 */
+        for (int i = 0; i < D; ++i) xp[i] = kd_fma(eps, p[i], xp[i]);    /* samplers.jl:131 */
         ko_gradlogtarget(c, xp, gp);                                     /* samplers.jl:132 */
-        for (int i = 0; i < D; ++i) p[i] = p[i] + halfe * gp[i];         /* samplers.jl:133 */
+        const double kf = l + 1 < nleaps ? eps : halfe;                  /* :133 of this step (+ :130 of the next) */
+        for (int i = 0; i < D; ++i) p[i] = kd_fma(kf, gp[i], p[i]);
     }
     double ltp;                                                          /* :157 logtarget!(x') */
     if (d->target == KLARA_TARGET_GAUSS_DENSE) ltp = ko_dense_lt_from_grad(c, xp, gp, scratch);
