@@ -361,7 +361,7 @@ def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
     if row is not None and "FETCH_SIZE" in row["counters"] and "WRITE_SIZE" in row["counters"]:
         tb = (2.0 * row["counters"]["FETCH_SIZE"]["mean"] + row["counters"]["WRITE_SIZE"]["mean"]) * 1024.0
         hbm.update(traffic_bytes_per_launch=tb, traffic_frac_of_8TBs=tb / launch_s / 1e9 / HBM_PEAK_GBS, traffic_over_minimal=tb / minimal,
-                   traffic_source="profiles/r2_pmc_kernels.json: FETCH_SIZE x 2 + WRITE_SIZE (KiB), separate --pmc passes; calibrated on "
+                   traffic_source=f"{PMC_JSON.relative_to(ROOT)}: FETCH_SIZE x 2 + WRITE_SIZE (KiB), separate --pmc passes; calibrated on "
                                   "the init kernel (profiles/README.md)")
     rf["traffic"] = hbm["traffic_bytes_per_launch"]
     rf["hbm"] = hbm
@@ -448,7 +448,7 @@ def extra_measurements(K, L, n, stream):
     if row is not None and "SQ_VALU_MFMA_BUSY_CYCLES" in row["counters"] and not rf["pmc"]["stale"]:
         busy = row["counters"]["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"]
         rf["mfma_pipe_busy_frac"] = busy / NSIMD / (ls * CLOCK_HZ)
-        rf["mfma_pipe_source"] = "SQ_VALU_MFMA_BUSY_CYCLES per launch (profiles/r2_pmc_kernels.json) / 1024 SIMDs / (launch duration x 2.4 GHz)"
+        rf["mfma_pipe_source"] = f"SQ_VALU_MFMA_BUSY_CYCLES per launch ({PMC_JSON.relative_to(ROOT)}) / 1024 SIMDs / (launch duration x 2.4 GHz)"
     ex["cfg3_hmc_dense_roofline"] = rf
 
     # -- slice sampler on the README target, D = 100

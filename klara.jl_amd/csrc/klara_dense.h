@@ -504,7 +504,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
         }
     }
 
-    if (SAMPLER == KLARA_SAMPLER_SLICE && stuck && cx.chain_ok && cx.q == 0) atomicMax((int*)p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
+    if (SAMPLER == KLARA_SAMPLER_SLICE && stuck && cx.chain_ok && cx.q == 0) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);
     if (cx.chain_ok && cx.q == 0) {
         p.LT[cx.chain] = lt;
         p.naccept[cx.chain] += nacc;
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(512) void k_dense_init(const KParams p, const doubl
         mstore<NE>(cx, p.GR, p.D, gs);
     }
     if (cx.chain_ok && cx.q == 0) p.LT[cx.chain] = lt;
-    if (bad) atomicMax((int*)p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
+    if (bad) klara_raise(p.error_flag, KLARA_ERR_NONFINITE_INIT);
 }
 
 // test hook: one v_mfma_f64_4x4x4_4b with per-lane operands (lane layout and accumulation order are pinned by tests)

@@ -783,7 +783,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
             }
             if (chain_ok && cx.q == 0) p.held[chain] = held;
         }
-        if (SLICE && stuck && chain_ok && cx.q == 0) atomicMax((int*)p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
+        if (SLICE && stuck && chain_ok && cx.q == 0) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);
         if (!ONESTEP) wave_acc += (chain_ok && cx.q == 0) ? (unsigned)nacc : 0u;     // (per-lane partial; summed in auto_finish)
         if (!ONESTEP && nacc != 0) {
             store_pairs<NP, Q>(cx, wx, x);
@@ -848,5 +848,5 @@ __global__ __launch_bounds__(256) void k_diagt_init(const KParams p, int needgra
     bad = chain_ok && ((needgrad && bad) || !kfinite(lt));
     if (needgrad) store_pairs<NP, Q>(cx, group_window(p.GR, first_chain, here, D), g);
     if (chain_ok && cx.q == 0) p.LT[chain] = lt;
-    if (bad) atomicMax((int*)p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
+    if (bad) klara_raise(p.error_flag, KLARA_ERR_NONFINITE_INIT);
 }

@@ -468,5 +468,5 @@ __global__ __launch_bounds__(256) void k_hiert_init(const KParams p, int needgra
         for (int k = 0; k < 5; ++k) bad = bad || !kfinite(g.h[k]);
     }
     if (chain_ok && cx.q == 0) p.LT[chain] = lt;
-    if (chain_ok && bad) atomicMax((int*)p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
+    if (chain_ok && bad) klara_raise(p.error_flag, KLARA_ERR_NONFINITE_INIT);
 }

@@ -66,6 +66,11 @@ typedef KGLOBAL unsigned long long gulong;
 typedef KGLOBAL uint8_t guchar;
 typedef KGLOBAL int gint;
 
+// A device-detected error (non-finite start, slice sampler stuck).  The flag is a word of host memory mapped into the device's address
+// space (klara_api.hip), so that klara_synchronize reads it without a copy command; a plain store is all a PCIe write offers (no fetch-max), and
+// the two conditions cannot meet in one launch (the first is raised by the initialisation kernels, the second by transitions).
+__device__ __forceinline__ void klara_raise(gint* flag, int code) { __hip_atomic_store((int*)flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // Kernel parameter block.  All pointers are device pointers.
 struct KParams {
     gdouble* X; gdouble* GR; gdouble* LT;         // state: value nchains x D, gradlogtarget nchains x D, logtarget nchains
@@ -1159,7 +1164,7 @@ KLARA_PRAGMA_UNROLL_E
             } else if (KPOOLED && KCNT) {
                 atomicAdd((unsigned long long*)p.pooled_accepted, (unsigned long long)(tn.accepted - acc0));
             }
-            if (stuck) atomicMax((int*)p.error_flag, (int)KLARA_ERR_SLICE_STUCK);
+            if (stuck) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);
         }
         if (!has_next) break;
         if (PREFETCH) { cur = nxt; cx = cxn; }
@@ -1194,7 +1199,7 @@ KLARA_PRAGMA_UNROLL_E
         for (int e = 0; e < E; ++e) bad = bad || (cx.valid[e] && !kfinite(g[e]));
     }
     if (cx.chain_ok && cx.q == 0 && cx.rq == 0) p.LT[cx.chain] = lt;
-    if (bad) atomicMax((int*)p.error_flag, (int)KLARA_ERR_NONFINITE_INIT);
+    if (bad) klara_raise(p.error_flag, KLARA_ERR_NONFINITE_INIT);
 }
 
 // x0 ~ N(0, I) from the init stream (transition index 2^40-1)

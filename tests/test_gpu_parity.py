@@ -1250,6 +1250,32 @@ def test_full_size_bench_job_replayed_by_the_oracle(sparse):
     eng.close()
 
 
+def test_kernel_attributes_and_launch_modes_queries():
+    """klara_get_kernel_attributes reports registers / scratch / static LDS of the kernel a handle launches, from the loaded code
+    object and without launching anything (bench.py checks its committed PMC summaries against it); klara_get_launch_modes counts how the
+    launches were issued."""
+    neg = K.GaussDiagTarget.negdot(100)
+    e = K.Engine(sampler=L.SAMPLER_MALA, target=neg, nchains=4099, nsteps=10 ** 6, driftstep=0.9, monitor=L.MON_SUMMARIES)
+    e.init_state_normal()
+    before = e.state()[0].copy()
+    four, eight, one = e.kernel_attributes(0, 32), e.kernel_attributes(1, 32), e.kernel_attributes(0, 1)
+    assert np.array_equal(e.state()[0], before) and tuple(e.launch_modes()[0]) == (0, 0, 0)        # nothing ran, nothing was counted
+    assert 128 < four[0] <= 168 and 168 < eight[0] <= 256 and four[2] >= 8192 and eight[2] >= 8192   # 3 / 2 wavefronts per SIMD; math tables in LDS
+    assert one[0] > 0
+    e.run(64)
+    assert tuple(e.launch_modes()[0]) == (0, 0, 2)                                                 # two device-decided launches
+    e.close()
+    for kw, lo, hi in ((dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget.compound_symmetric(100, 0.5), leapstep=0.1, nleaps=10), 200, 256),
+                       (dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(2), mh_sigma=[1.0, 1.0]), 16, 128),
+                       (dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget.pairwise(100, cases.SRC_PAIR_NEGDOT), driftstep=0.5), 64, 256)):
+        e = K.Engine(nchains=300, nsteps=100, **kw)
+        v, sc, lds = e.kernel_attributes(0, 32)
+        assert lo <= v <= hi and sc >= 0 and lds >= 0, (kw["sampler"], v, sc, lds)
+        assert e.kernel_attributes(1, 32) == (v, sc, lds)                                          # one kernel family: the same kernel
+        assert tuple(e.launch_modes()[0]) == (0, 0, 0)
+        e.close()
+
+
 def test_pair_transposed_slice_sampler_moments():
     """Slice sampler on layout kind 3, MvNormal(mu, sigma) with D = 20, 16,384 chains x 60 transitions from x0 ~ N(0, I): the
     ensemble of final states has the target's mean and standard deviation (tolerance 5 standard errors, max over coordinates)."""

@@ -182,6 +182,27 @@ def test_julia_module_is_structurally_valid_for_0_6_and_later():
     assert rest.count("newarray(") >= 8 and rest.count("on_finalize(") == 3
 
 
+def test_instruction_budgets_follow_from_their_parts():
+    """scripts/instruction_budget.py (what bench.py's algorithmic roofline fractions divide by): the totals are the sums of the parts
+    profiles/README.md derives, and the building blocks are the operation counts of detmath.h's functions."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("instruction_budget", ROOT / "scripts" / "instruction_budget.py")
+    B = importlib.util.module_from_spec(spec); spec.loader.exec_module(B)
+    assert (B.PHILOX, B.U52, B.LOG_U01, B.SQRT_RAD, B.SINCOS, B.NORMAL_PAIR) == (41, 4, 23, 11, 18, 102)
+    assert B.mala_diag_unitw_element() == 18
+    h4, h8 = B.BUDGETS["headline_4lane"], B.BUDGETS["headline_8lane"]
+    assert h4["per_pair"] == 102 + 2 * 18 and h4["pair_evaluations_per_lane"] == 12.5 and h4["chains_per_wave"] == 16
+    assert h4["per_wave_transition"] == 12.5 * 138 + 39 + 9 + 3 == 1776.0
+    assert h8["per_wave_transition"] == 6.25 * 138 + 27 + 9 + 3
+    c5, c4 = B.BUDGETS["cfg5"], B.BUDGETS["cfg4"]
+    assert c5["per_leapfrog"] == 26 + 4 * 21 + 45 + 50 + 13 == 218 and c5["per_wave_transition"] > 32 * 218
+    assert c4["per_row"] == 76 and c4["per_wave_transition"] == 25 * 76 + 54 + 64 + 204 + 60 + 12
+    # the README of profiles/ quotes these totals
+    txt = (ROOT / "profiles" / "README.md").read_text()
+    for v in ("1,776", "8,053", "2,294"):
+        assert v in txt, v
+
+
 def test_julia_stub_binds_only_declared_symbols():
     import re
     jl = (ROOT / "julia" / "KlaraHIP.jl").read_text()
