@@ -266,12 +266,17 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
             if (!cx.rv[k]) { mom.a[k] = 0.0; mom.b[k] = 0.0; }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // The hyper block's three blocks and the block of the accept draw (slot R + 3 = ceil(D/2)) are the same for the 8 lanes of a chain:
+        // lane q evaluates ONE of them — slot R + (q & 3) — and the four lanes of a quad exchange the results (2 v_mov_dpp per double)
+        // instead of every lane evaluating all four: 102 + 14 vector instructions per transition instead of 3 x 102 + 45.
+        double acc_u, acc_logu;
         {
-            double z0, z1;
-            kd_normal_pair(kd_stream_block(p.seed, gchain, t, (uint32_t)R), &mom.h[0], &mom.h[1]);
-            kd_normal_pair(kd_stream_block(p.seed, gchain, t, (uint32_t)(R + 1)), &mom.h[2], &mom.h[3]);
-            kd_normal_pair(kd_stream_block(p.seed, gchain, t, (uint32_t)(R + 2)), &z0, &z1);
-            mom.h[4] = z0;
+            double z0, z1, u1, lg1;
+            kd_normal_pair_ex(kd_stream_block(p.seed, gchain, t, (uint32_t)(R + (cx.q & 3))), &z0, &z1, &u1, &lg1);
+            mom.h[0] = quad_bcast(z0, 0); mom.h[1] = quad_bcast(z1, 0);
+            mom.h[2] = quad_bcast(z0, 1); mom.h[3] = quad_bcast(z1, 1);
+            mom.h[4] = quad_bcast(z0, 2);
+            acc_u = quad_bcast(u1, 3); acc_logu = quad_bcast(lg1, 3);
         }
         HierVec<RPL> xp, gp;
         double ltp, a = 0.0;
@@ -321,8 +326,7 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
             const double ratio = H1 - H0;                                                 // :161
             const double ex = kd_exp(ratio);
             a = 1.0 < ex ? 1.0 : ex;                                                      // :163
-            const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((D + 1) >> 1)));
-            acc = u < a;                                                                  // :165
+            acc = acc_u < a;                                                              // :165
         } else if (SAMPLER == KLARA_SAMPLER_MALA) {                                   // iterate/MALA.jl:78-128 (mom holds z)
             const double h_ = tn.step, halfh = 0.5 * h_, sqh = KCNT ? __builtin_sqrt(h_) : p.sqrt_step0;
             const double half_inv_h = 0.5 * (KCNT ? 1.0 / h_ : p.inv_step0);
@@ -357,8 +361,7 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
             ratio += s1[0];                                                                    // :90
             ratio -= s2[0];                                                                    // :92
             acc = ratio > 0.0;                                                                 // :94
-            if (!acc && ratio > KD_LOG_UMIN_GUARD)
-                acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((D + 1) >> 1))));
+            acc = acc || ratio > acc_logu;
         } else {                                                                       // iterate/MH.jl:72-124 (mom holds z)
 #pragma unroll
             for (int k = 0; k < RPL; ++k) { xp.a[k] = x.a[k] + sig.a[k] * mom.a[k]; xp.b[k] = x.b[k] + sig.b[k] * mom.b[k]; }   // :79
@@ -367,8 +370,7 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
             ltp = hier_eval<RPL, NT, true, false>(cx, xp, gp);                                 // :81
             const double ratio = ltp - lt;                                                     // :83
             acc = ratio > 0.0;                                                                 // :97
-            if (!acc && ratio > KD_LOG_UMIN_GUARD)
-                acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((D + 1) >> 1))));
+            acc = acc || ratio > acc_logu;
         }
         if (do_sum && __any(acc && held > 0)) {                                       // leaving a state after `held` saved steps
             const bool fold = acc && held > 0;

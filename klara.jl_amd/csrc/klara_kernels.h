@@ -319,7 +319,13 @@ KLARA_PRAGMA_UNROLL_E
 // normals.  Whenever the layout has padding (G*E > D, e.g. D = 100 on 32 lanes x 4) some lane evaluates that very
 // block as one of its (unused) normal pairs, and Box-Muller has already formed u = u52(x,y) and log(u) for it: the
 // accept test then costs one ds_bpermute instead of a Philox block plus a log.  Same words, same kd_log -> same bits.
-struct AccDraw { double u, logu; };
+struct AccDraw { double u, logu; bool have; /* u, logu are this chain's accept draw in every lane already (row-split layout) */ };
+
+// lane k of every quad to the quad's four lanes
+__device__ __forceinline__ double quad_bcast(double v, int k)
+{
+    return k == 0 ? dpp_mov<0x00>(v) : k == 1 ? dpp_mov<0x55>(v) : k == 2 ? dpp_mov<0xAA>(v) : dpp_mov<0xFF>(v);
+}
 
 template <int E>
 __device__ __forceinline__ void lane_normals(const LaneCtx<E>& c, unsigned long long seed,
@@ -327,6 +333,27 @@ __device__ __forceinline__ void lane_normals(const LaneCtx<E>& c, unsigned long 
                                              double (&z)[E], AccDraw& ad, int acc_slot)
 {
     static_assert(E % 2 == 0, "E must be even");
+    // Row-split layout (logistic target): RS >= 4 lanes hold the SAME chain and would each evaluate the same E/2 blocks, plus the block
+    // of the accept draw.  Lane rq evaluates ONE block instead — slot rq & 3 — and the four lanes of a quad exchange the results: one
+    // Philox + Box-Muller evaluation per lane and transition instead of E/2 + 1 (cfg 4, E = 4: 102 + 12 instead of 204 + ~70 vector
+    // instructions of a ~2,650-instruction transition).  The same blocks, the same functions: no bit changes.
+    if constexpr (E <= 8) {
+        if (c.RS >= 4) {
+            double z0, z1, u1, lg1;
+            kd_normal_pair_ex(kd_stream_block(seed, gchain, t, (uint32_t)(c.rq & 3)), &z0, &z1, &u1, &lg1);
+KLARA_PRAGMA_UNROLL_E
+            for (int j = 0; j < E / 2; ++j) {
+                const double a = quad_bcast(z0, j), b = quad_bcast(z1, j);
+                z[2 * j] = c.valid[2 * j] ? a : 0.0;
+                z[2 * j + 1] = c.valid[2 * j + 1] ? b : 0.0;
+            }
+            if (acc_slot >= 0 && acc_slot < 4) {
+                const int src = (c.lane & ~3) | acc_slot;
+                ad.u = lane_bcast(u1, src); ad.logu = lane_bcast(lg1, src); ad.have = true;
+            }
+            return;
+        }
+    }
 KLARA_PRAGMA_UNROLL_E
     for (int j = 0; j < E / 2; ++j) {
         const kd_u32x4 b = kd_stream_block(seed, gchain, t, (uint32_t)((c.i0 >> 1) + j));
@@ -653,6 +680,7 @@ template <int E>
 __device__ __forceinline__ bool accept_log_test(const KParams& p, const LaneCtx<E>& cx, unsigned long long gchain,
                                                 unsigned long long t, const AccDraw& ad, bool acc, double ratio)
 {
+    if (ad.have) return acc || ratio > ad.logu;
     const int acc_owner = ((p.D + 1) >> 1) / (E / 2);          // lane (within the group) whose normals used slot ceil(D/2)
     if (acc_owner < cx.G) {                                    // free: log(u) was formed by that lane's Box-Muller
         const double logu = cx.G > 1 ? lane_bcast(ad.logu, (cx.lane - cx.q) + acc_owner) : ad.logu;
@@ -819,7 +847,7 @@ KLARA_PRAGMA_UNROLL_E
     const double a = 1.0 < ex ? 1.0 : ex;                                             // :163
     a_out = a;
     const int acc_owner = ((p.D + 1) >> 1) / (E / 2);
-    const double u = (acc_owner < cx.G)
+    const double u = ad.have ? ad.u : (acc_owner < cx.G)
         ? (cx.G > 1 ? lane_bcast(ad.u, (cx.lane - cx.q) + acc_owner) : ad.u)
         : kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
     const bool acc = u < a;                                                           // :165
@@ -1059,7 +1087,7 @@ KLARA_PRAGMA_UNROLL_E
             held = 0;
         };
         double z[E];
-        AccDraw ad = { 0.5, 0.0 };
+        AccDraw ad = { 0.5, 0.0, false };
         const int acc_slot = (p.D + 1) >> 1;
         if (NEEDZ) lane_normals<E>(cx, p.seed, gchain, kl.t0, z, ad, acc_slot);   // before the loaded state is touched
 

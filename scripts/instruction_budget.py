@@ -67,10 +67,11 @@ def cfg5_hier(nleaps: int = 32, units_per_lane: int = 4):
     exp3 = 4 + 1 + EXP + 6                                             # pick s_c / s_a / s_b by lane (2 selects), -2 s, exp, three broadcasts
     hyper = 2 + 2 + 3 * 3                                              # gradient of a_c, b_c (mul, fma) and of the three log-sigmas (fma, sub, fma)
     leap = 2 * vals + units_per_lane * unit + 5 * 3 * BFLY + exp3 + hyper      # drift + kick (one fma per value each), units, 5-value butterfly
-    normals = (units_per_lane + 3) * NORMAL_PAIR                        # momentum: one pair per unit, three for the hyper block
+    normals = (units_per_lane + 1) * NORMAL_PAIR + 7 * 2                # momentum: one block per unit; the hyper block's three blocks and the accept
+    # draw's block are spread over the four lanes of a quad (one each) and exchanged: 7 doubles x 2 v_mov_dpp
     lt_eval = units_per_lane * (unit - 4) + 5 * 3 * BFLY + exp3 + 25    # log-target of the proposal (no gradient terms), its closing arithmetic
     energy = 2 * (2 * vals + 3 * BFLY)                                  # sum p^2 before and after
-    accept = EXP + PHILOX + U52 + 8
+    accept = EXP + 8
     per_tr = nleaps * leap + normals + lt_eval + energy + accept + vals  # + the opening half-kick
     return {"per_leapfrog": leap, "per_unit": unit, "exp_and_broadcasts": exp3, "butterfly": 5 * 3 * BFLY, "hyper_gradient": hyper,
             "kick_and_drift": 2 * vals, "normals": normals, "per_wave_transition": per_tr, "chains_per_wave": 8, "nleaps": nleaps}
@@ -83,7 +84,9 @@ def cfg4_logistic(ndata: int = 200, ndims: int = 4, rowsplit: int = 8):
     rows = ndata // rowsplit
     bfly = (ndims + 2) * 3 * BFLY                                       # (D + 2)-value butterfly over the 8 lanes
     prior = 2 * ndims + (DIV + 2) + ndims * (DIV + 1)                   # p.p; -(p.p / lambda + const)/2; -p / lambda per component (the example's divisions)
-    normals = ((ndims + 1) // 2) * NORMAL_PAIR                          # every lane of a chain holds the whole vector
+    normals = NORMAL_PAIR + 2 * ndims + 4                               # every lane of a chain holds the whole vector; the (D + 1) / 2 blocks of the normals
+    # and the accept draw's block are spread over the four lanes of a quad (one each) and exchanged (2 v_mov_dpp per normal, 2 + 2 ds_bpermute
+    # for the draw)
     sampler = ndims * mala_diag_unitw_element() - ndims * 3             # MALA arithmetic per element (the target's own terms are above)
     accept = 12
     return {"per_row": row, "rows_per_lane": rows, "butterfly": bfly, "prior": prior, "normals": normals, "sampler": sampler,
@@ -107,8 +110,8 @@ def _with_extra(b, extra):
 _h4, _h8, _c5, _c4 = headline(4), headline(8), cfg5_hier(), cfg4_logistic()
 BUDGETS = {"headline_4lane": _with_extra(_h4, _h4["pair_evaluations_per_lane"] * PAIR_EXTRA),
            "headline_8lane": _with_extra(_h8, _h8["pair_evaluations_per_lane"] * PAIR_EXTRA),
-           "cfg5": _with_extra(_c5, 7 * PAIR_EXTRA + 20 * MAD_EXTRA),                       # momentum pairs + the accept draw's Philox block
-           "cfg4": _with_extra(_c4, 2 * PAIR_EXTRA + _c4["rows_per_lane"] * QUARTER_EXTRA + 5 * QUARTER_EXTRA)}   # + one v_rcp_f64 per row and per prior division
+           "cfg5": _with_extra(_c5, 5 * PAIR_EXTRA),                                        # a lane's Philox / Box-Muller evaluations
+           "cfg4": _with_extra(_c4, 1 * PAIR_EXTRA + _c4["rows_per_lane"] * QUARTER_EXTRA + 5 * QUARTER_EXTRA)}   # + one v_rcp_f64 per row and per prior division
 
 if __name__ == "__main__":
     print(f"building blocks: Philox4x32-10 {PHILOX}, u52 {U52}, log(u) {LOG_U01}, radius {SQRT_RAD}, sin/cos {SINCOS}, normal pair {NORMAL_PAIR}, "
