@@ -285,6 +285,14 @@ __device__ __forceinline__ void pair_normals(const PairCtx<NP, Q>& c, unsigned l
     if (p == NP - 1 && !c.last_full) z1 = 0.0;
 }
 
+// compile-time loop: f(kd_int<I>{}) for I = FROM .. TO-1 (a register-array index that must stay a constant through nested run-time loops)
+template <int V> struct kd_int { static constexpr int value = V; };
+template <int FROM, int TO, class F>
+__device__ __forceinline__ void kd_static_for(F&& f)
+{
+    if constexpr (FROM < TO) { f(kd_int<FROM>{}); kd_static_for<FROM + 1, TO>(f); }
+}
+
 // The diagonal target on one element (klara_kernels.h DiagTarget, same operations in the same order).  UNITW: w = 1 and
 // mu = 0 (README.md:23 -dot(z,z)): x - 0, 1*(.) and (-2*1)*(.) are exact, so dropping them changes no bit.
 // m2w = -2.0 * w, formed once per workgroup (the same product DiagTarget forms per evaluation).
@@ -488,17 +496,31 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                 // re-forms the moving term and re-adds the lane's terms in ascending order (the order of a full evaluation).
                 acc = true; ltp = lt;
                 const int gb = cx.lane - cx.q;
-                for (int i = 0; i < D; ++i) {                                                  // :65
-                    const int P = i >> 1, qo = P & (Q - 1), eo = 2 * (P / Q) + (i & 1);
-                    const bool owner = cx.q == qo;
-                    double xi_l = 0.0, w_l = 0.0, term[E];
+                // the lane's terms w (x - mu)^2, kept up to date over the coordinates of the transition (a coordinate update changes one)
+                double term[E];
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        if (e == eo) { xi_l = x[e]; w_l = sig[e]; }
-                        double gd;
-                        diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), term[e], gd);
-                    }
-                    const double xi = lane_bcast(xi_l, gb + qo), wd = lane_bcast(w_l, gb + qo);
+                for (int e = 0; e < E; ++e) { double gd; diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), term[e], gd); }
+                // i = 2 (ph Q + qo) + half ascending = ph, then qo, then half ascending: the register slot eo = 2 ph + half of the moving
+                // coordinate is a compile-time constant of the (unrolled) outer and inner loops, the owner lane qo is a wave-uniform loop counter
+                kd_static_for<0, NP>([&](auto PH) __attribute__((always_inline)) {
+                for (int qo = 0; qo < Q; ++qo) {
+                kd_static_for<0, 2>([&](auto HALF) __attribute__((always_inline)) {               // :65
+                    constexpr int ph = decltype(PH)::value, half = decltype(HALF)::value;
+                    const int i = 2 * (ph * Q + qo) + half;
+                    if (i >= D) return;
+                    constexpr int eo = 2 * ph + half;
+                    const bool owner = cx.q == qo;
+                    // A lane's part of a probe's log-target is its terms added in ascending order with the candidate's term in place of
+                    // the moving one (the order of a full evaluation).  Formed once per coordinate: the sum of the terms before the moving
+                    // one, and the whole sum of a lane that does not own the coordinate; a probe then adds the candidate's term and the
+                    // E - 1 - eo terms behind it on the owner lane.
+                    double prefix = 0.0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) if (e < eo) prefix = prefix + term[e];
+                    double whole = prefix;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) if (e >= eo) whole = whole + term[e];
+                    const double xi = lane_bcast(x[eo], gb + qo), wd = lane_bcast(sig[eo], gb + qo);
                     const double wi_t = lane_bcast(UNITW ? 1.0 : wv(eo), gb + qo), mi_t = lane_bcast(UNITW ? 0.0 : mv(eo), gb + qo);
                     const uint32_t base = (uint32_t)i << KLARA_SLICE_ATT_BITS;
                     const kd_u32x4 b0 = kd_stream_block(p.seed, gchain, t, base);
@@ -506,11 +528,16 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                     const double ru = kd_uniform_zw(b0);                                       // :71
                     double Li = xi - ru * wd;                                                  // :72
                     double Ri = xi + (1.0 - ru) * wd;                                          // :73
-                    const auto lt_with = [&](double cand) -> double {
-                        double tc, gd, part[1] = { 0.0 };
+                    const auto term_of = [&](double cand) -> double {
+                        double tc, gd;
                         diag_elem<UNITW>(cand, wi_t, -2.0 * wi_t, mi_t, tc, gd);
+                        return tc;
+                    };
+                    const auto lt_with = [&](double cand) -> double {
+                        double own = prefix + term_of(cand), part[1];
 #pragma unroll
-                        for (int e = 0; e < E; ++e) part[0] = part[0] + ((owner && e == eo) ? tc : term[e]);
+                        for (int e = 0; e < E; ++e) if (e > eo) own = own + term[e];
+                        part[0] = owner ? own : whole;
                         group_allreduce<1>(part, Q, cx.lane);
                         return gconst - part[0];
                     };
@@ -554,10 +581,12 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                     }
                     if (!stuck) {
                         lt = ltnew;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) if (owner && e == eo) x[e] = xprime;       // :108
+                        const double tnew = term_of(xprime);
+                        if (owner) { x[eo] = xprime; term[eo] = tnew; }                        // :108
                     }
+                });
                 }
+                });
                 ltp = lt;
 #pragma unroll
                 for (int e = 0; e < E; ++e) xp[e] = x[e];          // (the commit below is then a no-op)

@@ -46,3 +46,17 @@ if "5" in which:
     r = rate_of(e, nc, 100, 200)
     print(f"[{tag}] cfg5 rats HMC L=32: {r * 32:.4g} leapfrog chain/s", flush=True)
     e.close()
+if "slice" in which:
+    for D, w in ((100, 1.0), (40, 1.0), (200, 1.0)):
+        n = 65536
+        e = K.Engine(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.negdot(D), nchains=n, nsteps=10 ** 7, slice_widths=np.full(D, w), steps_per_launch=4, nstreams=1)
+        e.init_state_normal()
+        r = rate_of(e, n, 16, 4)
+        print(f"[{tag}] slice sampler, lt = -|x|^2, D = {D}: {r:.4g} transitions/s = {r * D:.4g} coordinate updates/s", flush=True)
+        e.close()
+    e = K.Engine(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget(100, w=np.linspace(0.5, 2.0, 100), mu=np.linspace(-1.0, 1.0, 100)), nchains=65536, nsteps=10 ** 7,
+                 slice_widths=np.full(100, 1.0), steps_per_launch=4, nstreams=1, monitor=L.MON_SUMMARIES)
+    e.init_state_normal()
+    r = rate_of(e, 65536, 16, 4)
+    print(f"[{tag}] slice sampler, weighted diagonal with means, running sums, D = 100: {r:.4g} transitions/s", flush=True)
+    e.close()
