@@ -35,6 +35,7 @@ EXP = 39                         # kd_exp: 2 clamps, rounding offset (bfi) + mul
 EXP_NEG = 24                     # kd_exp_neg: max, mul + add, 2 cvt, r (2 fma), and / ashr, table offset, r2, r4, 4 fma, y (fma, add), exponent (shl, and, add),
                                  # the a <= 708 select (cmp + 2 cndmask)
 DIV = 10                         # IEEE f64 division as hipcc emits it: 2 v_div_scale, v_rcp, 5 fma, v_div_fmas, v_div_fixup
+DIV_UNIT = 8                     # kd_div_unit_range (numerator in [2^-1021, 1] or 0, denominator in [1, 2]): v_rcp, 2 x 2 fma, mul, 2 fma
 BFLY = 3                         # one butterfly step of one double: 2 v_mov_dpp (or ds_bpermute) + v_add_f64
 
 
@@ -79,7 +80,7 @@ def cfg5_hier(nleaps: int = 32, units_per_lane: int = 4):
 
 def cfg4_logistic(ndata: int = 200, ndims: int = 4, rowsplit: int = 8):
     """k_transitions<MALA, LOGISTIC, E=4> with the 8-lane row split: per wavefront (8 chains) and transition."""
-    row = ndims + EXP_NEG + 1 + LOG_U01 + 2 + 3 + DIV + 2 + 1 + 1 + ndims + 1     # Xp; exp(-|Xp|); 1 + t; log; softplus (max, add); numerator select;
+    row = ndims + EXP_NEG + 1 + LOG_U01 + 2 + 3 + DIV_UNIT + 2 + 1 + 1 + ndims + 1     # Xp; exp(-|Xp|); 1 + t; log; softplus (max, add); numerator select;
     # division; Xp*y (mul, add); sum of softplus; residual; gradient accumulations; row offset
     rows = ndata // rowsplit
     bfly = (ndims + 2) * 3 * BFLY                                       # (D + 2)-value butterfly over the 8 lanes
