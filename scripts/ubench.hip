@@ -125,8 +125,69 @@ static void mfma_peak()
     hipFree(d);
 }
 
-int main()
+// Do vector instructions of one wavefront issue while another wavefront of the same SIMD keeps the FP64 matrix pipe busy?  One workgroup
+// of 8 wavefronts per CU (2 per SIMD): wavefronts 0-3 run a chain-free MFMA loop, wavefronts 4-7 a vector loop (KIND 0: v_fma_f64,
+// 1: v_mad_u64_u32 + v_bitop3, 2: Philox + Box-Muller pairs); each half alone, then both together.
+template <int KIND>
+__global__ __launch_bounds__(512) void k_overlap(double* out, int mfma_iters, int valu_iters)
 {
+    kd_tables_to_lds();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0;
+    if (wave < 4) {
+        double a = 1.0 + lane * 1e-3, b = 0.5 - lane * 1e-3;
+        d4 acc[7];
+        for (int t = 0; t < 7; ++t) acc[t] = (d4){ 0.0, 0.0, 0.0, 0.0 };
+        for (int i = 0; i < mfma_iters; ++i) {
+#pragma unroll
+            for (int t = 0; t < 7; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+        for (int t = 0; t < 7; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    } else {
+        double a[8]; uint32_t u[8]; uint64_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a[k] = 1.0 + 1e-3 * lane + k; u[k] = threadIdx.x * 7u + k; w[k] = (uint64_t)threadIdx.x * 0x9E3779B97F4A7C15ull + k; }
+        for (int i = 0; i < valu_iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (KIND == 0) a[k] = kd_fma(a[k], 0.999, 0.001);
+                else if (KIND == 1) { const uint64_t p = (uint64_t)u[k] * 0xD2511F53u + w[k]; w[k] = p; u[k] = KD_XOR3((uint32_t)(p >> 32), (uint32_t)p, (uint32_t)i); }
+                else { double z0, z1; kd_normal_pair(kd_stream_block(7u, (uint64_t)u[k], (uint64_t)i, (uint32_t)k), &z0, &z1); a[k] += z0 * z1; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += a[k] + (double)u[k] + (double)w[k];
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int KIND>
+static void overlap(const char* name, int valu_iters)
+{
+    double* d; hipMalloc(&d, sizeof(double) * 512 * 256);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int mi = 20000;
+    float t[3];
+    for (int c = 0; c < 3; ++c) {
+        const int m = c == 1 ? 0 : mi, v = c == 0 ? 0 : valu_iters;
+        hipLaunchKernelGGL(k_overlap<KIND>, dim3(256), dim3(512), 0, 0, d, m / 20, v / 20);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_overlap<KIND>, dim3(256), dim3(512), 0, 0, d, m, v);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&t[c], e0, e1);
+    }
+    printf("overlap MFMA f64 | %-28s: MFMA alone %.2f ms, vector alone %.2f ms, together %.2f ms (sum %.2f, max %.2f)\n", name, t[0], t[1], t[2], t[0] + t[1],
+           t[0] > t[1] ? t[0] : t[1]);
+    hipFree(d);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc > 1 && argv[1][0] == 'o') {
+        overlap<0>("v_fma_f64", 400000);
+        overlap<1>("v_mad_u64_u32 + v_bitop3", 160000);
+        overlap<2>("Philox + Box-Muller pair", 7000);
+        return 0;
+    }
     run_tp<0>("v_fma_f64");
     run_tp<1>("v_add_f64");
     run_tp<2>("v_mul_f64");
