@@ -84,8 +84,11 @@ typedef enum klara_target {
      *   KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata);
      *   KLARA_USER_FN void   klara_user_gradlogtarget(const double* x, int D, const double* data, long long ndata,
      *                                                 double* g);           (needed by MALA / HMC only)
-     * and is compiled for gfx950 at klara_create (hiprtc) into the group-layout transition kernels, one chain per lane
-     * (D <= 256; the whole vector in one lane: registers up to D = 32, scratch-backed beyond; KLARA_D is predefined to D so that loops unroll).  kd_exp, kd_log,
+     * and is compiled for gfx950 at klara_create (hiprtc) into the group-layout transition kernels (D <= 256; KLARA_D is predefined
+     * to D so that loops unroll): up to D = 32 one chain per lane, the whole vector in the lane's registers; beyond, 4 .. 32 lanes per
+     * chain — normals, sampler arithmetic and sums spread over them — and for an evaluation the closure reads the vector from the chain's
+     * row of LDS, every lane of the chain evaluating it identically (KLARA_CUSTOM_LANES=1 in the environment keeps one chain per lane
+     * at any D: the vector then lives in scratch, which only a closure far costlier than the sampler's own work repays).  kd_exp, kd_log,
      * kd_fma, kd_erf (klara.jl_amd/csrc/detmath.h) and IEEE + - * / sqrt give the same bits on host and device;
      * `data` is custom_data (custom_ndata doubles, copied to the device at create).
      * Likelihood + prior form (BasicContMuvParameter(:p, loglikelihood=..., logprior=..., gradloglikelihood=..., gradlogprior=...),

@@ -49,6 +49,7 @@ struct klara_handle {
     // streaming autocovariances (acov_maxlag > 0): W = maxlag + 1 lags; [k][series] layouts
     int acov_W = 0; double *acov_S = nullptr, *acov_head = nullptr, *acov_tail = nullptr, *acov_total = nullptr; long long acov_n = 0;
     double *hist_lt = nullptr, *hist_g = nullptr, *hist_ll = nullptr, *hist_lp = nullptr;
+    int custom_rows = 2;                              // staged closures: vectors per chain in LDS (3 for the likelihood + prior form)
     int* err = nullptr; int* flag_host = nullptr;     // error flag as the kernels address it; the same word as the host reads it (null: err is device memory)
     double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr,
            *hY = nullptr, *hxc = nullptr;
@@ -132,7 +133,29 @@ static bool pair_form(const klara_desc& d)
     return d.target == KLARA_TARGET_CUSTOM && d.custom_src != nullptr && strstr(d.custom_src, "KLARA_USER_PAIR_TARGET") != nullptr;
 }
 
-static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E)
+// Whole-vector closures (klara_custom.h).  Up to 32 dimensions a lane keeps the whole vector in registers (one chain per lane); beyond,
+// the chain is spread over G lanes with E = 2 ceil(D / 2G) <= 16 elements each and evaluations read the vector from the chain's row of
+// LDS (STAGED).  G: enough lanes for 16 elements per lane, and a workgroup's rows (4 wavefronts x 64 / G chains) within the 56 KB of
+// dynamic LDS a launch gets without asking.  `lanes` = 1 keeps one chain per lane at any D (the library's own heavy closures — the
+// logistic regression beyond 8 parameters, the dense Gaussian beyond 128 dimensions — cost O(n D) / O(D^2) per evaluation, and the
+// G identical evaluations of the staged form would multiply exactly that part; KLARA_CUSTOM_LANES=1 in the environment for a user's).
+static size_t custom_stage_bytes(int D, int G, int nrows)        // (klara_custom.h klara_custom_stage_stride)
+{
+    int s = nrows * ((D + 1) & ~1) + 2;
+    if ((2 * s) % 64 == 0) s += 2;
+    return (size_t)4 * (size_t)(64 / G) * (size_t)s * sizeof(double);
+}
+static void custom_layout(int D, int lanes, bool lik_prior, int* G, int* E)
+{
+    if (const char* s = getenv("KLARA_CUSTOM_LANES")) { const int v = atoi(s); if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) lanes = v; }
+    if (lanes == 1 || (lanes == 0 && D <= 32)) { *G = 1; *E = pow2ceil(D < 2 ? 2 : D); return; }
+    int g = lanes > 1 ? lanes : 4;
+    while (g < 32 && ((D + 2 * g - 1) / (2 * g) > 8 || custom_stage_bytes(D, g, lik_prior ? 3 : 2) > KLARA_LDS_DEFAULT_DYNAMIC)) g *= 2;
+    *G = g; *E = 2 * ((D + 2 * g - 1) / (2 * g));
+}
+static bool custom_lik_prior(const char* src) { return src != nullptr && strstr(src, "KLARA_USER_LIKELIHOOD_PRIOR") != nullptr; }
+
+static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E, int custom_lanes = 0)
 {
     if (hiert_eligible(d)) { *kind = 4; *G = 8; *E = 8; return KLARA_OK; }
     const int D = d.ndims;
@@ -151,9 +174,11 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
         *kind = 3; *G = Q; *E = 2 * ((D + 2 * Q - 1) / (2 * Q));
         return KLARA_OK;
     }
-    if (d.target == KLARA_TARGET_CUSTOM) {       // one chain per lane, the whole vector in registers (klara_custom.h)
-        *G = 1; *E = pow2ceil(D < 2 ? 2 : D);
-        return D <= KLARA_CUSTOM_MAXD ? KLARA_OK : KLARA_ERR_UNSUPPORTED;
+    if (d.target == KLARA_TARGET_CUSTOM) {       // whole-vector closure: one chain per lane, or staged through LDS on G lanes (klara_custom.h)
+        if (D > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
+        custom_layout(D, custom_lanes, custom_lik_prior(d.custom_src), G, E);
+        if (*G > 1 && (*E > 16 || custom_stage_bytes(D, *G, custom_lik_prior(d.custom_src) ? 3 : 2) > KLARA_LDS_DEFAULT_DYNAMIC)) { *G = 1; *E = pow2ceil(D); }
+        return KLARA_OK;
     }
     if (d.target == KLARA_TARGET_LOGISTIC) {
         *G = 1;   // every lane holds the whole parameter vector; klara_create may turn on the row split (kind 2)
@@ -351,7 +376,7 @@ KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* 
 }
 )SRC";
 
-static klara_status create_impl(const klara_desc* desc, klara_handle** out);
+static klara_status create_impl(const klara_desc* desc, klara_handle** out, int custom_lanes = 0);
 
 extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
 {
@@ -371,7 +396,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         klara_desc dd = *desc;
         dd.target = KLARA_TARGET_CUSTOM; dd.custom_src = KLARA_LOGIT_WIDE_SRC; dd.custom_data = blk.data(); dd.custom_ndata = (int64_t)blk.size();
         dd.logit_X = nullptr; dd.logit_y = nullptr; dd.logit_ndata = 0;
-        return create_impl(&dd, out);
+        return create_impl(&dd, out, 1);
     }
     if (desc->target == KLARA_TARGET_GAUSS_DENSE && desc->ndims > 128) {
         if (desc->ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
@@ -384,17 +409,17 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         klara_desc dd = *desc;
         dd.target = KLARA_TARGET_CUSTOM; dd.custom_src = KLARA_DENSE_WIDE_SRC; dd.custom_data = blk.data(); dd.custom_ndata = (int64_t)blk.size();
         dd.gauss_prec = nullptr; dd.gauss_mu = nullptr;
-        return create_impl(&dd, out);
+        return create_impl(&dd, out, 1);
     }
     return create_impl(desc, out);
 }
 
-static klara_status create_impl(const klara_desc* desc, klara_handle** out)
+static klara_status create_impl(const klara_desc* desc, klara_handle** out, int custom_lanes)
 {
     klara_status st = validate(desc);
     if (st != KLARA_OK) return st;
     int kind, G, E;
-    st = select_layout(*desc, &kind, &G, &E);
+    st = select_layout(*desc, &kind, &G, &E, custom_lanes);
     if (st != KLARA_OK) return st;
     if (desc->tuner_mode == KLARA_TUNE_POOLED && desc->sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
     // the logistic kernels keep the data rows (padded to E columns, + the responses) in LDS next to the 8 KB of math tables: up to
@@ -411,6 +436,7 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out)
     klara_handle* h = new (std::nothrow) klara_handle();
     if (!h) return KLARA_ERR_NOMEM;
     h->d = *desc; h->kind = kind; h->G = G; h->E = E;
+    h->custom_rows = (desc->target == KLARA_TARGET_CUSTOM && custom_lik_prior(desc->custom_src)) ? 3 : 2;
     if (desc->target == KLARA_TARGET_LOGISTIC) {
         // D <= 8 parameters cannot fill a wavefront's lanes usefully, the ndata-row likelihood can: RS lanes share a chain
         // and each takes every RS-th row (fixed by ndata alone, so results do not depend on how chains are sharded)
@@ -520,7 +546,7 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out)
         } else {
         int modes[2];
         const int nmodes = kernel_modes(h->d, modes);           // (h->d: the monitor word with what the library turned on itself)
-        CK(klara_jit_create(desc->custom_src, desc->sampler, desc->ndims, E, modes, nmodes, true, &h->jit));
+        CK(klara_jit_create(desc->custom_src, desc->sampler, desc->ndims, E, G, modes, nmodes, true, &h->jit));
         }
     } else if (desc->target == KLARA_TARGET_LOGISTIC) {
         CK(upload(&h->lX, desc->logit_X, (size_t)desc->logit_ndata * D));
@@ -632,6 +658,8 @@ static size_t lds_for(const klara_handle* h)
 {
     if (h->kind != 1 && h->d.target == KLARA_TARGET_LOGISTIC)
         return sizeof(double) * (size_t)h->d.logit_ndata * (size_t)(h->E + 1);
+    if (h->kind == 0 && h->d.target == KLARA_TARGET_CUSTOM && h->G > 1)              // staged closure: the rows of a workgroup's chains
+        return custom_stage_bytes(h->d.ndims, h->G, h->custom_rows);
     return 0;
 }
 
@@ -740,13 +768,13 @@ static klara_status init_common(klara_handle* h)
     KParams p = make_params(h);
     hipError_t e;
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, h->dense_mu, needgrad, grid_for(h), st);
-    else if (h->kind == 3 && h->jit_pair) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), st);
+    else if (h->kind == 3 && h->jit_pair) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), 0, st);
     else if (h->kind == 3)
         e = h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
           : h->G == 16 ? klara_launch_diagt_init_q16(p, h->E / 2, needgrad, grid_for(h), st)
                        : klara_launch_diagt_init_q32(p, h->E / 2, needgrad, grid_for(h), st);
     else if (h->kind == 4) e = klara_launch_hiert_init(p, h->E / 2, d.hier_ntimes, needgrad, grid_for(h), st);
-    else if (d.target == KLARA_TARGET_CUSTOM) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), st);
+    else if (d.target == KLARA_TARGET_CUSTOM) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), lds_for(h), st);
     else if (d.target == KLARA_TARGET_GAUSS_DIAG)
         e = launch_init_t<KLARA_TARGET_GAUSS_DIAG>(p, h->E, h->G, needgrad, grid_for(h), lds_for(h), st);
     else if (d.target == KLARA_TARGET_HIER_NORMAL)
@@ -929,7 +957,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
         const bool da = d.tuner == KLARA_TUNER_DUAL_AVERAGING;
         return klara_launch_hiert(p, kl, d.sampler, h->E / 2, d.hier_ntimes, mon, !plain || da, da, grid_for(h), h->stream);
     }
-    if (d.target == KLARA_TARGET_CUSTOM) return klara_jit_launch(h->jit, mode, p, kl, grid_for_transitions(h), h->stream);
+    if (d.target == KLARA_TARGET_CUSTOM) return klara_jit_launch(h->jit, mode, p, kl, grid_for_transitions(h), lds_for(h), h->stream);
     switch (d.sampler) {
     case KLARA_SAMPLER_MH: return klara_launch_mh(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
     case KLARA_SAMPLER_MALA: return klara_launch_mala(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
@@ -1968,7 +1996,9 @@ extern "C" klara_status klara_check_custom_target(const char* src, int32_t sampl
         return klara_jit_create_pair(src, sampler, ndims, (ndims + 2 * Q - 1) / (2 * Q), Q, false, false, false, modes, 1, false, nullptr);
     }
     if (ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
-    return klara_jit_create(src, sampler, ndims, pow2ceil(ndims < 2 ? 2 : ndims), modes, 1, false, nullptr);
+    int G = 1, E = 2;
+    custom_layout(ndims, 0, custom_lik_prior(src), &G, &E);
+    return klara_jit_create(src, sampler, ndims, E, G, modes, 1, false, nullptr);
 }
 
 extern "C" const char* klara_compile_log(void) { return klara_jit_log(); }

@@ -186,26 +186,26 @@ std::string pair_init_expr(const PairForm& f)
     snprintf(b, sizeof b, "k_diagt_init<%d, %d, true>", f.NP, f.Q);
     return b;
 }
-std::string trans_expr(int sampler, int E, int mode)
+std::string trans_expr(int sampler, int E, int G, int mode)
 {
     char b[128];
-    snprintf(b, sizeof b, "k_transitions<%d, KLARA_TARGET_CUSTOM, %d, 1, %d>", sampler, E, mode);
+    snprintf(b, sizeof b, "k_transitions<%d, KLARA_TARGET_CUSTOM, %d, %d, %d>", sampler, E, G, mode);
     return b;
 }
-std::string init_expr(int E)
+std::string init_expr(int E, int G)
 {
     char b[96];
-    snprintf(b, sizeof b, "k_init<KLARA_TARGET_CUSTOM, %d, 1>", E);
+    snprintf(b, sizeof b, "k_init<KLARA_TARGET_CUSTOM, %d, %d>", E, G);
     return b;
 }
 
 // compile (or fetch) the code object of one (source, sampler, D, modes) combination
-klara_status compile(const char* src, int sampler, int D, int E, const int* modes, int nmodes, const CodeObject** out, const PairForm* pf = nullptr)
+klara_status compile(const char* src, int sampler, int D, int E, int G, const int* modes, int nmodes, const CodeObject** out, const PairForm* pf = nullptr)
 {
     g_log.clear();
     Rtc* r = rtc();
     if (!r->ok) { g_log = "libhiprtc.so could not be loaded"; return KLARA_ERR_UNSUPPORTED; }
-    std::string key = std::to_string(sampler) + "/" + std::to_string(D) + "/";
+    std::string key = std::to_string(sampler) + "/" + std::to_string(D) + "/" + std::to_string(E) + "x" + std::to_string(G) + "/";
     if (pf) key += "pair/" + std::to_string(pf->NP) + "/" + std::to_string(pf->Q) + "/" + std::to_string((int)pf->mon) + std::to_string((int)pf->tune) + std::to_string((int)pf->da) + "/";
     for (int i = 0; i < nmodes; ++i) key += std::to_string(modes[i]) + ",";
     key += (getenv("KLARA_JIT_UNROLL_MAX_E") ? getenv("KLARA_JIT_UNROLL_MAX_E") : ""); key += "\n"; key += src;
@@ -259,10 +259,10 @@ klara_status compile(const char* src, int sampler, int D, int E, const int* mode
         g_log = "hiprtcCreateProgram failed";
         return KLARA_ERR_COMPILE;
     }
-    const std::string ie = pf ? pair_init_expr(*pf) : init_expr(E);
+    const std::string ie = pf ? pair_init_expr(*pf) : init_expr(E, G);
     r->AddNameExpression(prog, ie.c_str());
     std::vector<std::string> te;
-    for (int i = 0; i < nmodes; ++i) { te.push_back(pf ? pair_trans_expr(sampler, *pf, modes[i]) : trans_expr(sampler, E, modes[i])); r->AddNameExpression(prog, te.back().c_str()); }
+    for (int i = 0; i < nmodes; ++i) { te.push_back(pf ? pair_trans_expr(sampler, *pf, modes[i]) : trans_expr(sampler, E, G, modes[i])); r->AddNameExpression(prog, te.back().c_str()); }
     const hiprtcResult cr = r->CompileProgram(prog, (int)(sizeof opts / sizeof *opts), opts);
     size_t ls = 0;
     if (r->GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) { g_log.resize(ls); r->GetProgramLog(prog, &g_log[0]); }
@@ -300,7 +300,7 @@ klara_status klara_jit_create_pair(const char* src, int sampler, int D, int NP, 
 {
     PairForm pf; pf.NP = NP; pf.Q = Q; pf.mon = mon; pf.tune = tune; pf.da = da;
     const CodeObject* co = nullptr;
-    klara_status st = compile(src, sampler, D, 2 * NP, modes, nmodes, &co, &pf);
+    klara_status st = compile(src, sampler, D, 2 * NP, Q, modes, nmodes, &co, &pf);
     if (st != KLARA_OK || !load) return st;
     KlaraJit* j = new (std::nothrow) KlaraJit();
     if (!j) return KLARA_ERR_NOMEM;
@@ -316,10 +316,10 @@ klara_status klara_jit_create_pair(const char* src, int sampler, int D, int NP, 
     return KLARA_OK;
 }
 
-klara_status klara_jit_create(const char* src, int sampler, int D, int E, const int* modes, int nmodes, bool load, KlaraJit** out)
+klara_status klara_jit_create(const char* src, int sampler, int D, int E, int G, const int* modes, int nmodes, bool load, KlaraJit** out)
 {
     const CodeObject* co = nullptr;
-    klara_status st = compile(src, sampler, D, E, modes, nmodes, &co);
+    klara_status st = compile(src, sampler, D, E, G, modes, nmodes, &co);
     if (st != KLARA_OK || !load) return st;
     KlaraJit* j = new (std::nothrow) KlaraJit();
     if (!j) return KLARA_ERR_NOMEM;
@@ -342,14 +342,14 @@ void klara_jit_destroy(KlaraJit* j)
     delete j;
 }
 
-hipError_t klara_jit_launch_init(KlaraJit* j, const KParams& p, int needgrad, dim3 grid, hipStream_t st)
+hipError_t klara_jit_launch_init(KlaraJit* j, const KParams& p, int needgrad, dim3 grid, size_t lds, hipStream_t st)
 {
     KParams pv = p;
     void* args[] = { &pv, &needgrad };
-    return hipModuleLaunchKernel(j->init, grid.x, 1, 1, 256, 1, 1, 0, st, args, nullptr);
+    return hipModuleLaunchKernel(j->init, grid.x, 1, 1, 256, 1, 1, (unsigned)lds, st, args, nullptr);
 }
 
-hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, dim3 grid, hipStream_t st)
+hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, dim3 grid, size_t lds, hipStream_t st)
 {
     auto it = j->trans.find(mode == 7 ? 7 : (mode & 3) == 3 ? 3 : (mode & 1) ? 1 : 0);
     if (it == j->trans.end()) return hipErrorInvalidValue;
@@ -363,7 +363,7 @@ hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaun
     }
     KLaunch klv = kl;
     void* args[] = { &p, &klv };
-    return hipModuleLaunchKernel(it->second, grid.x, 1, 1, 256, 1, 1, 0, st, args, nullptr);
+    return hipModuleLaunchKernel(it->second, grid.x, 1, 1, 256, 1, 1, (unsigned)lds, st, args, nullptr);
 }
 
 // the pair-closure kernels take (KParams*, KLaunch, KAuto) like every k_diagt instantiation; one wavefront per chain group

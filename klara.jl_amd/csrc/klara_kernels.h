@@ -993,7 +993,8 @@ template <int SAMPLER, int TARGET, int E, int GT, int MODE>
 // (MALA and HMC on the logistic target at E = 4 — cfg 4 — ask for 4 wavefronts per SIMD: its row loop is a chain of exp / log / division latencies that two
 //  wavefronts cannot cover; the 128-register budget spills 156-272 B outside the row loop and still measured 1.01e9 against 8.1e8
 //  transitions/s with running sums, 1.05e9 against 9.4e8 without, same box)
-__global__ __launch_bounds__(256, (E == 2 ? 3 : (E == 4 ? (TARGET == KLARA_TARGET_LOGISTIC && SAMPLER == KLARA_SAMPLER_MALA ? KLARA_E4_WAVES_LOGISTIC
+__global__ __launch_bounds__(256, (TARGET == KLARA_TARGET_CUSTOM && GT > 1 ? 2 /* staged closures: two workgroups' rows fit a CU's LDS */ :
+                                   E == 2 ? 3 : (E == 4 ? (TARGET == KLARA_TARGET_LOGISTIC && SAMPLER == KLARA_SAMPLER_MALA ? KLARA_E4_WAVES_LOGISTIC
                                                                   : TARGET == KLARA_TARGET_LOGISTIC && SAMPLER == KLARA_SAMPLER_HMC ? KLARA_E4_WAVES_LOGISTIC_HMC
                                                                   : ((MODE & 3) == 3 ? KLARA_E4_WAVES_PLAIN : KLARA_E4_WAVES)) : 1)))
 void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
@@ -1150,7 +1151,7 @@ KLARA_PRAGMA_UNROLL_E
                     if constexpr (TARGET == KLARA_TARGET_CUSTOM) {            // :monitor => [:loglikelihood, :logprior]
                         if (p.hist_ll != nullptr && scol < p.hist_cols) {
                             double ll_, lp_;
-                            tg.parts(cur.x, ll_, lp_);
+                            tg.parts(cx, cur.x, ll_, lp_);
                             if (cx.chain_ok) { p.hist_ll[scol * p.nchains + cx.chain] = ll_; p.hist_lp[scol * p.nchains + cx.chain] = lp_; }
                         }
                     }

@@ -129,15 +129,15 @@ hipError_t klara_launch_hiert_init(const KParams& p, int RPL, int NT, int needgr
 // user-defined targets (KLARA_TARGET_CUSTOM): run-time compiled instantiations of k_init / k_transitions (klara_jit.hip);
 // `modes` are the k_transitions MODE values the job can launch; load = false only compiles (no GPU needed)
 struct KlaraJit;
-klara_status klara_jit_create(const char* src, int sampler, int D, int E, const int* modes, int nmodes, bool load, KlaraJit** out);
+klara_status klara_jit_create(const char* src, int sampler, int D, int E, int G, const int* modes, int nmodes, bool load, KlaraJit** out);
 // pair closures (`#define KLARA_USER_PAIR_TARGET 1` + klara_user_pair, klara_diagt.h USERPAIR): k_diagt_init / k_diagt instantiated
 // for the job's NP pairs per lane, Q lanes per chain and monitor / tuner flags; modes: 0 = fused launches, 1 = one transition per launch
 klara_status klara_jit_create_pair(const char* src, int sampler, int D, int NP, int Q, bool mon, bool tune, bool da, const int* modes, int nmodes,
                                    bool load, KlaraJit** out);
 hipError_t klara_jit_launch_pair(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, long long nwaves, hipStream_t st);
 void klara_jit_destroy(KlaraJit* j);
-hipError_t klara_jit_launch_init(KlaraJit* j, const KParams& p, int needgrad, dim3 grid, hipStream_t st);
-hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, dim3 grid, hipStream_t st);
+hipError_t klara_jit_launch_init(KlaraJit* j, const KParams& p, int needgrad, dim3 grid, size_t lds, hipStream_t st);
+hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, dim3 grid, size_t lds, hipStream_t st);
 const char* klara_jit_log();
 
 // mode 7: mode 3 with exactly one transition per launch; mode 3: nothing counts/tunes and nothing is monitored;

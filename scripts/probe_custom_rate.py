@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of user-defined targets (run-time compiled closures, one chain per lane): the README target written as a closure and the
+"""Throughput of user-defined targets (run-time compiled closures: whole-vector closures, one chain per lane up to 32 dimensions and staged through LDS on 4-32 lanes beyond; pair closures): the README target written as a closure and the
 quartic chain of tests/cases.py, MALA, 65,536 chains."""
 import sys
 from pathlib import Path
@@ -10,14 +10,19 @@ import cases
 import klara_jl_amd as K
 from klara_jl_amd import _lib as L
 
+import os
 n = 65536
-for d, src, data, h in ((16, cases.SRC_NEGDOT, None, 0.1), (32, cases.SRC_NEGDOT, None, 0.1), (100, cases.SRC_NEGDOT, None, 0.05),
-                        (100, cases.SRC_QUARTIC_CHAIN, [0.02, 0.5], 0.02)):
-    e = K.Engine(sampler=L.SAMPLER_MALA, target=K.CustomTarget(d, src, data), nchains=n, nsteps=10 ** 6, driftstep=h)
-    e.init_state_normal(); e.run(64)
-    e.run(256); ms, nl = e.last_run_ms()
-    print(f"custom closure D = {d:3d} ({'quartic chain' if data else 'negdot'}): {n * 256 / (ms * 1e-3):.4g} transitions/s")
-    e.close()
+for d, src, data, h in ((16, cases.SRC_NEGDOT, None, 0.1), (32, cases.SRC_NEGDOT, None, 0.1), (40, cases.SRC_NEGDOT, None, 0.1), (100, cases.SRC_NEGDOT, None, 0.05),
+                        (100, cases.SRC_QUARTIC_CHAIN, [0.02, 0.5], 0.02), (256, cases.SRC_QUARTIC_CHAIN, [0.02, 0.5], 0.01)):
+    for lanes in (("0", "1") if d > 32 else ("0",)):          # beyond 32 dimensions: staged through LDS (default) against one chain per lane (scratch)
+        os.environ["KLARA_CUSTOM_LANES"] = lanes
+        e = K.Engine(sampler=L.SAMPLER_MALA, target=K.CustomTarget(d, src, data), nchains=n, nsteps=10 ** 6, driftstep=h, monitor=L.MON_SUMMARIES)
+        e.init_state_normal(); e.run(32)
+        e.run(128); ms, nl = e.last_run_ms()
+        print(f"whole-vector closure D = {d:3d} ({'quartic chain' if data else 'negdot'}), layout {e.layout()}: {n * 128 / (ms * 1e-3):.4g} transitions/s "
+              f"(kernel registers / scratch / LDS {e.kernel_attributes(0, 32)})", flush=True)
+        e.close()
+os.environ.pop("KLARA_CUSTOM_LANES", None)
 
 # pair closures (K.CustomTarget.pairwise): the same README closure, a quartic with within-pair coupling and the banana, on the few-lanes-per-chain
 # kernels (layout kind 3), next to the built-in diagonal family on the same lanes

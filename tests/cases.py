@@ -466,10 +466,10 @@ def make_case(name):
     elif name == "custom_quartic_hmc_d32":    # 32 elements per lane: still register-resident
         c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(32, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=70, nsteps=25, burnin=5,
                  leapstep=0.1, nleaps=4)
-    elif name == "custom_quartic_mala_d64":   # the largest user-defined dimension: 64 elements per lane (scratch-backed)
+    elif name == "custom_quartic_mala_d64":   # beyond 32 dimensions: 4 lanes per chain, staged through LDS
         c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(64, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=70, nsteps=20, burnin=5,
                  driftstep=0.05)
-    elif name == "custom_quartic_mala_d100":  # a user-defined target at the BASELINE dimension: 128 elements per lane, scratch-backed
+    elif name == "custom_quartic_mala_d100":  # a user-defined target at the BASELINE dimension: 8 lanes per chain, staged through LDS
         c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(100, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=70, nsteps=12, burnin=2,
                  driftstep=0.04)
     elif name == "custom_quartic_hmc_d50":
@@ -482,6 +482,28 @@ def make_case(name):
     elif name == "custom_normal_normal_mh":     # no gradient closures needed
         t = K.CustomTarget.likelihood_prior(2, SRC_NN_LL, SRC_NN_LP, data=np.array([-1.88, 2.23, 1.0, 1.0, 0.0, 0.0, 1.0, 1.0]))
         c = dict(sampler=L.SAMPLER_MH, target=t, nchains=66, nsteps=50, burnin=10, mh_sigma=[0.8, 0.8], x0=np.tile([-2.637, -1.132], (66, 1)))
+    # ---- whole-vector closures beyond 32 dimensions: G lanes per chain, evaluations staged through LDS (klara_custom.h STAGED)
+    elif name == "staged_negdot_mala_d100_big_step":   # the README closure at BASELINE cfg 2's shape and drift step (rare accepts)
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(100, SRC_NEGDOT), nchains=131, nsteps=60, burnin=0, driftstep=0.9)
+    elif name == "staged_quartic_mh_d33_thinned":      # odd D (the last lane's elements end early), MH needs no gradient closure
+        c = dict(sampler=L.SAMPLER_MH, target=K.CustomTarget(33, SRC_QUARTIC_CHAIN[:SRC_QUARTIC_CHAIN.index("KLARA_USER_FN void")], [0.1, 0.4]), nchains=45, nsteps=50,
+                 burnin=4, thinning=2, mh_sigma=np.linspace(0.05, 0.4, 33), x0=0.3 * np.random.default_rng(5).standard_normal((45, 33)))
+    elif name == "staged_quartic_slice_d40":
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget(40, SRC_QUARTIC_CHAIN[:SRC_QUARTIC_CHAIN.index("KLARA_USER_FN void")], [0.05, 0.3]), nchains=19, nsteps=6,
+                 burnin=1, slice_widths=np.linspace(0.6, 1.4, 40))
+    elif name == "staged_quartic_hmc_d200_dualavg":    # 16 lanes per chain
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(200, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=21, nsteps=50, burnin=0,
+                 leapstep=0.05, nleaps=5, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=30)
+    elif name == "staged_quartic_mala_d70_pooled":
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(70, SRC_QUARTIC_CHAIN, [0.05, 0.3]), nchains=48, nsteps=130, burnin=100,
+                 driftstep=0.1, tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.574, period=20)
+    elif name == "staged_normal_normal_mala_d48":      # likelihood + prior closures: three rows of LDS per chain
+        rng = np.random.default_rng(13)
+        t = normal_normal_target(rng.standard_normal(48) * 2, np.linspace(0.5, 2.0, 48), np.linspace(-1, 1, 48), np.linspace(1.0, 5.0, 48))
+        c = dict(sampler=L.SAMPLER_MALA, target=t, nchains=70, nsteps=40, burnin=10, driftstep=0.1, x0=np.zeros((70, 48)))
+    elif name == "staged_quartic_hmc_d256_tuned":      # the largest user-defined dimension: 32 lanes per chain
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(256, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=9, nsteps=60, burnin=40,
+                 leapstep=0.05, nleaps=3, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.7, period=10)
     # ---- pair closures on the pair-transposed layout
     elif name == "pair_negdot_mala_d100":      # the README closure, BASELINE cfg 2's shape, ragged chain count
         c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget.pairwise(100, SRC_PAIR_NEGDOT), nchains=67, nsteps=40, burnin=5, driftstep=0.05)
@@ -529,7 +551,9 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "custom_quartic_mala_d64", "custom_quartic_mala_d100", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh",
              "sparse_mala_d100", "sparse_mala_d100_small_step", "sparse_mh_d100", "sparse_mala_mvnormal_d30",
              "pair_negdot_mala_d100", "pair_negdot_mala_d100_big_step", "pair_quartic_hmc_d50_tuned", "pair_banana_mh_d33",
-             "pair_banana_hmc_d100_dualavg", "pair_quartic_mala_d300_pooled"]
+             "pair_banana_hmc_d100_dualavg", "pair_quartic_mala_d300_pooled",
+             "staged_negdot_mala_d100_big_step", "staged_quartic_mh_d33_thinned", "staged_quartic_slice_d40", "staged_quartic_hmc_d200_dualavg",
+             "staged_quartic_mala_d70_pooled", "staged_normal_normal_mala_d48", "staged_quartic_hmc_d256_tuned"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",

@@ -109,7 +109,7 @@ DIAGT_Q = 8
 
 
 def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, tuner=0, tuner_mode=0, verbose=False,
-                   hier_nunits: int = 0, hier_ntimes: int = 0, summaries: bool = True, sparse_moves: bool = False, pair_form: bool = False):
+                   hier_nunits: int = 0, hier_ntimes: int = 0, summaries: bool = True, sparse_moves: bool = False, pair_form: bool = False, custom_rows: int = 2):
     """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box).  `sampler`, `tuner`,
     `tuner_mode` and `verbose` are only needed to recognise the pair-transposed layout (kind 3): diagonal Gaussian,
     MH / MALA / HMC, even D <= 128, Vanilla or AcceptanceRate tuner (klara_api.hip diagt_eligible)."""
@@ -126,6 +126,16 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     if target_kind == L.TARGET_CUSTOM and pair_form:     # pair closure: the pair-transposed layout (klara_api.hip select_layout)
         q = 8 if d <= 128 else (16 if d <= 256 else 32)
         return (3, q, 2 * ((d + 2 * q - 1) // (2 * q)))
+    if target_kind == L.TARGET_CUSTOM and d > 32 and os.environ.get("KLARA_CUSTOM_LANES", "0") != "1":
+        # whole-vector closure staged through LDS (klara_api.hip custom_layout): G lanes x E = 2 ceil(D / 2G) <= 16 elements, a workgroup's
+        # rows (4 wavefronts x 64 / G chains, `custom_rows` vectors each) within 56 KB
+        g = int(os.environ.get("KLARA_CUSTOM_LANES", "0")) or 4
+        rows = custom_rows
+        stride = rows * ((d + 1) & ~1) + 2
+        stride += 2 if (2 * stride) % 64 == 0 else 0
+        while g < 32 and ((d + 2 * g - 1) // (2 * g) > 8 or 4 * (64 // g) * stride * 8 > 57344):
+            g *= 2
+        return (0, g, 2 * ((d + 2 * g - 1) // (2 * g)))
     if target_kind == L.TARGET_CUSTOM:        # one chain per lane, pow2ceil(D) elements in registers (klara_custom.h)
         e = 2
         while e < d:
@@ -214,7 +224,8 @@ class OracleJob:
                                                                    tuner=int(tuner), tuner_mode=int(tuner_mode), verbose=bool(verbose),
                                                                    hier_nunits=int(d.hier_nunits), hier_ntimes=int(d.hier_ntimes),
                                                                    summaries=bool(want_sums), sparse_moves=bool(sparse_moves),
-                                                                   pair_form=bool(custom_src is not None and "KLARA_USER_PAIR_TARGET" in custom_src))
+                                                                   pair_form=bool(custom_src is not None and "KLARA_USER_PAIR_TARGET" in custom_src),
+                                                                   custom_rows=3 if (custom_src is not None and "KLARA_USER_LIKELIHOOD_PRIOR" in custom_src) else 2)
         self.layout = KoLayout(k, g, e)
         nt = 1 if tuner_mode == L.TUNE_POOLED else self.N
         self.X = np.zeros((self.N, self.D)); self.G = np.zeros((self.N, self.D)); self.LT = np.zeros(self.N)
