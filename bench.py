@@ -331,6 +331,7 @@ def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
     cnt, last_mode, _ = e.launch_modes() if hasattr(L.load(), 'klara_get_launch_modes') else (None, [0], None)
     four = lay_kind == 3 and (not monitor or last_mode[0] == 0)     # the 4-lane kernels ran (they sum in the layout's 8-lane order)
     attrs = e.kernel_attributes(0 if four else 1, spl) if hasattr(L.load(), 'klara_get_kernel_attributes') else None
+    clock_mhz = e.shader_clock_mhz() if hasattr(e, "shader_clock_mhz") else 0.0      # during the last of those launches (in-kernel probe)
     e.close()
     if four:
         lay_g, lay_e = 4, 2 * ((NDIMS + 7) // 8)
@@ -346,6 +347,13 @@ def roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream):
     rf = valu_roofline(kname, launch_s, grid=grid, label=label, attrs=attrs, budget=bud,
                        necessary_per_launch=bud["per_wave_transition"] * nwaves * spl if bud else None)
     rf.update(launches=nlaunch, chains_per_launch=n, transitions_per_launch=spl)
+    if clock_mhz > 0.0 and rf.get("frac") is not None:
+        # the peak above is priced at the 2.4 GHz the data sheet names; under this instruction mix the chip clocks lower (power), and
+        # issue cycles that did not exist cannot be used: the same fraction against the cycles the SIMDs actually had
+        rf["shader_clock_mhz"] = clock_mhz
+        rf["frac_at_measured_clock"] = rf["frac"] * (CLOCK_HZ / (clock_mhz * 1e6))
+        if rf.get("frac_at_measured_instruction_costs") is not None:
+            rf["frac_at_measured_clock_and_instruction_costs"] = rf["frac_at_measured_instruction_costs"] * (CLOCK_HZ / (clock_mhz * 1e6))
     # the byte side.  S = 2*D*8 + 8 (x, gradient, log-target); SURVEY 8(d): B_K = (2 S + 1) / K per transition and chain.
     s_state = 2 * NDIMS * 8 + 8
     contract = n * (2 * s_state + 1)                               # per launch of K fused transitions: state in, state out, accepts

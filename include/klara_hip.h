@@ -350,6 +350,12 @@ klara_status klara_get_layout(klara_handle* h, int32_t* kind, int32_t* lanes_per
  * kernel a launch runs (for jobs that two kernel families can run, see klara_desc.sparse_moves: the 4-lane one), 1: the 8-lane
  * sibling of such jobs (the same kernel as 0 otherwise).  bench.py checks the committed PMC summaries against these values, so that
  * counters collected on an older build of a kernel are not silently combined with timings of the current one. */
+/* Shader clock (MHz) the device ran at during the handle's last launch of a pair-transposed kernel (layout kind 3): one workgroup in
+ * the middle of the grid stores the shader-cycle counter and the constant-rate wall clock when it starts and when it ends; 0 when the
+ * handle runs other kernels or has not launched yet.  An MI355X clocks between ~1.9 and 2.4 GHz depending on the power the instruction
+ * mix draws: a kernel's issue-cycle budget (bench.py roofline) is only comparable with elapsed time at the clock that was actually
+ * running.  Synchronises the handle's streams. */
+klara_status klara_get_shader_clock(klara_handle* h, double* mhz);
 klara_status klara_get_kernel_attributes(klara_handle* h, int32_t which, int32_t nsteps, int32_t* vgprs, int32_t* scratch_bytes,
                                          int32_t* static_lds_bytes);
 

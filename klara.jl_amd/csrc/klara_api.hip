@@ -49,6 +49,7 @@ struct klara_handle {
     // streaming autocovariances (acov_maxlag > 0): W = maxlag + 1 lags; [k][series] layouts
     int acov_W = 0; double *acov_S = nullptr, *acov_head = nullptr, *acov_tail = nullptr, *acov_total = nullptr; long long acov_n = 0;
     double *hist_lt = nullptr, *hist_g = nullptr, *hist_ll = nullptr, *hist_lp = nullptr;
+    unsigned long long* clock_probe = nullptr;        // pair-transposed kernels: (s_memtime, s_memrealtime) at the end / start of one workgroup of the last launch
     int custom_rows = 2;                              // staged closures: vectors per chain in LDS (3 for the likelihood + prior form)
     int* err = nullptr; int* flag_host = nullptr;     // error flag as the kernels address it; the same word as the host reads it (null: err is device memory)
     double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr,
@@ -279,7 +280,7 @@ static void free_all(klara_handle* h)
     hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->held); hipFree(h->hist); hipFree(h->acov_S); hipFree(h->acov_head); hipFree(h->acov_tail); hipFree(h->acov_total); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->hist_ll); hipFree(h->hist_lp); if (!h->flag_host) hipFree(h->err);
     hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
     hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->pool_partial); hipFree(h->d_params); hipFree(h->cdata);
-    hipFree(h->bm_prev); hipFree(h->bm_mean); hipFree(h->bm_m2); hipFree(h->auto_cells); hipFree(h->auto_ctr);
+    hipFree(h->bm_prev); hipFree(h->bm_mean); hipFree(h->bm_m2); hipFree(h->auto_cells); hipFree(h->auto_ctr); hipFree(h->clock_probe);
     if (h->auto_mirror) hipHostFree(h->auto_mirror);
     if (h->flag_host) hipHostFree(h->flag_host);
     klara_jit_destroy(h->jit);
@@ -472,6 +473,7 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
             CKH(hipStreamCreateWithFlags(&h->side[j], hipStreamNonBlocking));
             CKH(hipEventCreateWithFlags(&h->join_ev[j], hipEventDisableTiming));
         }
+        CKH(dalloc(&h->clock_probe, 4)); CKH(hipMemset(h->clock_probe, 0, 4 * sizeof(unsigned long long)));
         if (h->q4_ok && (desc->monitor & KLARA_MON_SUMMARIES)) {
             CKH(dalloc(&h->auto_cells, 8)); CKH(dalloc(&h->auto_ctr, 4));
             if (hipHostMalloc((void**)&h->auto_mirror, 16 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
@@ -629,6 +631,7 @@ static KParams make_params(klara_handle* h)
     p.hY = (decltype(p.hY))h->hY; p.hxc = (decltype(p.hxc))h->hxc; p.hR = d.hier_nunits; p.hT = d.hier_ntimes; p.hp0 = d.hier_prior_prec;
     p.ha0 = d.hier_gamma_a; p.hb0 = d.hier_gamma_b;
     p.cdata = (decltype(p.cdata))h->cdata; p.cndata = d.custom_ndata;
+    p.clock_probe = (decltype(p.clock_probe))h->clock_probe;
     return p;
 }
 
@@ -1821,6 +1824,22 @@ extern "C" klara_status klara_get_kernel_attributes(klara_handle* h, int32_t whi
     if (vgprs) *vgprs = a.numRegs;
     if (scratch_bytes) *scratch_bytes = (int32_t)a.localSizeBytes;
     if (static_lds_bytes) *static_lds_bytes = (int32_t)a.sharedSizeBytes;
+    return KLARA_OK;
+}
+
+extern "C" klara_status klara_get_shader_clock(klara_handle* h, double* mhz)
+{
+    if (!h || !mhz) return KLARA_ERR_INVALID_ARG;
+    *mhz = 0.0;
+    if (!h->clock_probe) return KLARA_OK;
+    HIPCHK(hipSetDevice(h->d.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int j = 0; j < 3; ++j) if (h->side[j]) HIPCHK(hipStreamSynchronize(h->side[j]));
+    unsigned long long v[4] = { 0, 0, 0, 0 };
+    HIPCHK(hipMemcpy(v, h->clock_probe, sizeof(v), hipMemcpyDeviceToHost));
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->d.device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+    if (v[1] > v[3] && v[0] > v[2]) *mhz = (double)(v[0] - v[2]) / (double)(v[1] - v[3]) * (double)khz * 1e-3;
     return KLARA_OK;
 }
 

@@ -363,6 +363,9 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
     }
     auto_begin();
     kd_tables_to_lds();          // (ends with the workgroup barrier)
+    if (p.clock_probe != nullptr && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) {
+        p.clock_probe[2] = __builtin_amdgcn_s_memtime(); p.clock_probe[3] = __builtin_amdgcn_s_memrealtime();
+    }
     const int D = p.D;
     const PairCtx<NP, Q> cx = make_pctx<NP, Q>(D);
     const int nsteps = ONESTEP ? 1 : kl.nsteps;
@@ -828,6 +831,9 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                 atomicAdd((unsigned long long*)p.pooled_accepted, (unsigned long long)(tn.accepted - acc0));
             }
         }
+    }
+    if (p.clock_probe != nullptr && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) {
+        p.clock_probe[0] = __builtin_amdgcn_s_memtime(); p.clock_probe[1] = __builtin_amdgcn_s_memrealtime();
     }
     auto_finish(ka, wave_acc);
 }

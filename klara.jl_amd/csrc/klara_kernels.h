@@ -109,6 +109,9 @@ struct KParams {
     const gdouble* lX; const gdouble* ly; int ndata; double lambda; double lpconst;   // logistic
     const gdouble* hY; const gdouble* hxc; int hR; int hT; double hp0; double ha0; double hb0;   // hierarchical normal
     const gdouble* cdata; long long cndata;                      // user-defined target (klara_custom.h): read-only data block
+    // shader-clock probe of the pair-transposed kernels (klara_get_shader_clock): one workgroup in the middle of the grid writes
+    // (s_memtime, s_memrealtime) when it starts [2], [3] and when it ends [0], [1] — stores only, nothing kept in registers
+    gulong* clock_probe;
 };
 
 // Per-launch values, passed by value.  Everything else (KParams) is static for a handle and lives in device memory:

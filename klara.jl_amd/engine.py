@@ -454,6 +454,14 @@ class Engine:
         L.check(self._lib.klara_get_kernel_attributes(self._h, int(which), int(nsteps), C.byref(v), C.byref(s_), C.byref(l)), "klara_get_kernel_attributes")
         return int(v.value), int(s_.value), int(l.value)
 
+    def shader_clock_mhz(self) -> float:
+        """Shader clock during the last launch of a pair-transposed kernel (klara_get_shader_clock); 0.0 when unknown."""
+        if not hasattr(self._lib, "klara_get_shader_clock"):
+            return 0.0
+        v = C.c_double(0.0)
+        L.check(self._lib.klara_get_shader_clock(self._h, C.byref(v)), "klara_get_shader_clock")
+        return float(v.value)
+
     def device_ptrs(self):
         x, lt, g = C.c_void_p(), C.c_void_p(), C.c_void_p()
         L.check(self._lib.klara_device_ptrs(self._h, C.byref(x), C.byref(lt), C.byref(g)), "klara_device_ptrs")

@@ -180,8 +180,55 @@ static void overlap(const char* name, int valu_iters)
     hipFree(d);
 }
 
+// Shader clock under load: s_memtime counts shader-engine cycles, s_memrealtime a constant 100 MHz reference.  KIND 0: Philox + Box-Muller pairs
+// (the proposal normals of every kernel), 1: v_fma_f64 only, 2: integer only (v_mad_u64_u32 + v_bitop3); WAVES wavefronts per SIMD on every CU.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_clock(unsigned long long* out, int iters)
+{
+    kd_tables_to_lds();
+    const int lane = threadIdx.x & 63;
+    double a[8]; uint32_t u[8]; uint64_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] = 1.0 + 1e-3 * lane + k; u[k] = threadIdx.x * 7u + k; w[k] = (uint64_t)threadIdx.x * 0x9E3779B97F4A7C15ull + k; }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (KIND == 1) a[k] = kd_fma(a[k], 0.999, 0.001);
+            else if (KIND == 2) { const uint64_t p = (uint64_t)u[k] * 0xD2511F53u + w[k]; w[k] = p; u[k] = KD_XOR3((uint32_t)(p >> 32), (uint32_t)p, (uint32_t)i); }
+            else { double z0, z1; kd_normal_pair(kd_stream_block(7u, (uint64_t)u[k], (uint64_t)i, (uint32_t)k), &z0, &z1); a[k] += z0 * z1; }
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += a[k] + (double)u[k] + (double)w[k];
+    if (s == 12345.678) out[3] = 1;
+    if (blockIdx.x == 17 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+template <int KIND>
+static void clock_probe(const char* name, int waves_per_simd, int iters)
+{
+    unsigned long long* d; hipMalloc(&d, 64); hipMemset(d, 0, 64);
+    hipLaunchKernelGGL(k_clock<KIND>, dim3(256 * waves_per_simd), dim3(256), 0, 0, d, iters / 10);
+    hipLaunchKernelGGL(k_clock<KIND>, dim3(256 * waves_per_simd), dim3(256), 0, 0, d, iters);
+    hipDeviceSynchronize();
+    unsigned long long h[2]; hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    printf("shader clock under %-34s (%d wavefronts per SIMD, %.1f ms): %.0f MHz\n", name, waves_per_simd, h[1] / 1e5, 100.0 * (double)h[0] / (double)h[1]);
+    hipFree(d);
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 1 && argv[1][0] == 'c') {
+        for (int rep = 0; rep < 2; ++rep) {
+            clock_probe<0>("Philox + Box-Muller pairs", 3, 4000);
+            clock_probe<1>("v_fma_f64", 3, 60000);
+            clock_probe<2>("v_mad_u64_u32 + v_bitop3", 3, 40000);
+            clock_probe<0>("Philox + Box-Muller pairs", 1, 4000);
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'o') {
         overlap<0>("v_fma_f64", 400000);
         overlap<1>("v_mad_u64_u32 + v_bitop3", 160000);

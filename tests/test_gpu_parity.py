@@ -1262,8 +1262,10 @@ def test_kernel_attributes_and_launch_modes_queries():
     assert np.array_equal(e.state()[0], before) and tuple(e.launch_modes()[0]) == (0, 0, 0)        # nothing ran, nothing was counted
     assert 128 < four[0] <= 168 and 168 < eight[0] <= 256 and four[2] >= 8192 and eight[2] >= 8192   # 3 / 2 wavefronts per SIMD; math tables in LDS
     assert one[0] > 0
+    assert e.shader_clock_mhz() == 0.0                                                             # nothing launched yet
     e.run(64)
     assert tuple(e.launch_modes()[0]) == (0, 0, 2)                                                 # two device-decided launches
+    assert 1200.0 < e.shader_clock_mhz() < 2700.0                                                  # the in-kernel clock probe of the last launch
     e.close()
     for kw, lo, hi in ((dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget.compound_symmetric(100, 0.5), leapstep=0.1, nleaps=10), 200, 256),
                        (dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(2), mh_sigma=[1.0, 1.0]), 16, 128),
