@@ -218,8 +218,64 @@ static void clock_probe(const char* name, int waves_per_simd, int iters)
     hipFree(d);
 }
 
+// Issue cadence in real shader cycles (s_memtime inside the kernel): NCH independent chains per wavefront, W wavefronts per SIMD.
+template <int OP, int NCH>
+__global__ __launch_bounds__(256) void k_issue(unsigned long long* out, int iters)
+{
+    const int lane = threadIdx.x & 63;
+    double a[NCH]; uint32_t u[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) { a[k] = 1.0 + 1e-3 * lane + k; u[k] = threadIdx.x * 7u + k; }
+    __syncthreads();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                if (OP == 0) a[k] = kd_fma(a[k], 0.999, 0.001);
+                else if (OP == 1) u[k] = KD_XOR3(u[k], 0x12345u, (uint32_t)i);
+                else a[k] = a[k] * a[k];
+            }
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) s += a[k] + (double)u[k];
+    if (s == 12345.678) out[3] = 1;
+    if (blockIdx.x == 5 && threadIdx.x == 0) out[0] = c1 - c0;
+}
+template <int OP, int NCH>
+static void issue(const char* name)
+{
+    unsigned long long* d; hipMalloc(&d, 64);
+    const int iters = 4000;
+    printf("%-14s %d chains:", name, NCH);
+    for (int w : { 1, 2, 3, 4, 8 }) {
+        hipMemset(d, 0, 64);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL((k_issue<OP, NCH>), dim3(256 * w), dim3(256), 0, 0, d, iters / 8);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_issue<OP, NCH>), dim3(256 * w), dim3(256), 0, 0, d, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h; hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+        printf("  W=%d: wave %.2f, kernel %.2f", w, (double)h / ((double)iters * 8 * NCH), ms * 1e-3 * 2.3e9 / ((double)iters * 8 * NCH * w));
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+    printf("   (wave: shader cycles per instruction of one wavefront; kernel: elapsed x 2.3 GHz per wave-instruction of a SIMD)\n");
+    hipFree(d);
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 1 && argv[1][0] == 'i') {
+        issue<0, 1>("v_fma_f64"); issue<0, 2>("v_fma_f64"); issue<0, 4>("v_fma_f64"); issue<0, 8>("v_fma_f64");
+        issue<2, 1>("v_mul_f64"); issue<2, 4>("v_mul_f64");
+        issue<1, 1>("v_bitop3_b32"); issue<1, 2>("v_bitop3_b32"); issue<1, 8>("v_bitop3_b32");
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'c') {
         for (int rep = 0; rep < 2; ++rep) {
             clock_probe<0>("Philox + Box-Muller pairs", 3, 4000);
