@@ -1145,6 +1145,8 @@ def test_iostream_sink_writes_the_likelihood_and_prior_files(tmp_path):
     ("cfg2_mala", dict(sampler=L.SAMPLER_MALA, driftstep=0.9), 40),
     ("cfg3_hmc_dense", dict(sampler=L.SAMPLER_HMC, leapstep=0.1, nleaps=10), 6),
     ("hmc_iso", dict(sampler=L.SAMPLER_HMC, leapstep=0.1, nleaps=10), 12),
+    ("staged_closure_mala", dict(sampler=L.SAMPLER_MALA, driftstep=0.3), 12),       # the README closure as a whole-vector user closure: 8 lanes per chain, staged through LDS
+    ("pair_closure_hmc", dict(sampler=L.SAMPLER_HMC, leapstep=0.1, nleaps=5), 8),   # ... and as a pair closure on the pair-transposed layout
 ])
 def test_full_size_bit_exact_on_sampled_chains(name, kw, nsteps):
     """BASELINE.json sizes (65,536 chains x 100 dims): chains are independent and the stream is keyed by the global
@@ -1152,7 +1154,13 @@ def test_full_size_bit_exact_on_sampled_chains(name, kw, nsteps):
     (first, middle, last — the last one exercises the partially filled final wavefront) are compared bit for bit."""
     n, d = 65536 - 5, 100                               # not a multiple of the chains-per-wavefront: ragged tail
     target = K.GaussDenseTarget.compound_symmetric(d, 0.5) if name == "cfg3_hmc_dense" else K.GaussDiagTarget.negdot(d)
+    if name == "staged_closure_mala":
+        target = K.CustomTarget(d, cases.SRC_NEGDOT)
+    elif name == "pair_closure_hmc":
+        target = K.CustomTarget.pairwise(d, cases.SRC_PAIR_NEGDOT)
     eng = K.Engine(target=target, nchains=n, nsteps=nsteps, monitor=L.MON_ACCEPT | L.MON_SUMMARIES, steps_per_launch=3, **kw)
+    if name == "staged_closure_mala":
+        assert tuple(eng.layout()) == (0, 8, 14)
     eng.init_state_normal()
     eng.run(nsteps)
     x, lt, g = eng.state()
