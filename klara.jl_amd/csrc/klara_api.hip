@@ -50,6 +50,7 @@ struct klara_handle {
     int acov_W = 0; double *acov_S = nullptr, *acov_head = nullptr, *acov_tail = nullptr, *acov_total = nullptr; long long acov_n = 0;
     double *hist_lt = nullptr, *hist_g = nullptr, *hist_ll = nullptr, *hist_lp = nullptr;
     unsigned long long* clock_probe = nullptr;        // pair-transposed kernels: (s_memtime, s_memrealtime) at the end / start of one workgroup of the last launch
+    int custom_wpb = 4;                               // staged closures: wavefronts per workgroup (2 where four wavefronts' rows do not fit the LDS)
     int custom_rows = 2;                              // staged closures: vectors per chain in LDS (3 for the likelihood + prior form)
     int* err = nullptr; int* flag_host = nullptr;     // error flag as the kernels address it; the same word as the host reads it (null: err is device memory)
     double *vecparam = nullptr, *gw = nullptr, *gmu = nullptr, *lX = nullptr, *ly = nullptr, *Pfrag = nullptr,
@@ -140,23 +141,30 @@ static bool pair_form(const klara_desc& d)
 // dynamic LDS a launch gets without asking.  `lanes` = 1 keeps one chain per lane at any D (the library's own heavy closures — the
 // logistic regression beyond 8 parameters, the dense Gaussian beyond 128 dimensions — cost O(n D) / O(D^2) per evaluation, and the
 // G identical evaluations of the staged form would multiply exactly that part; KLARA_CUSTOM_LANES=1 in the environment for a user's).
-static size_t custom_stage_bytes(int D, int G, int nrows)        // (klara_custom.h klara_custom_stage_stride)
+static size_t custom_stage_bytes(int D, int G, int nrows, int wpb)        // (klara_custom.h klara_custom_stage_stride)
 {
     int s = nrows * ((D + 1) & ~1) + 2;
     if ((2 * s) % 64 == 0) s += 2;
-    return (size_t)4 * (size_t)(64 / G) * (size_t)s * sizeof(double);
+    return (size_t)wpb * (size_t)(64 / G) * (size_t)s * sizeof(double);
 }
-static void custom_layout(int D, int lanes, bool lik_prior, int* G, int* E)
+// wpb: wavefronts per workgroup of the staged kernels — 4, or 2 where four wavefronts' rows would not fit and force more lanes per chain
+static void custom_layout(int D, int lanes, bool lik_prior, int* G, int* E, int* wpb)
 {
+    *wpb = 4;
     if (const char* s = getenv("KLARA_CUSTOM_LANES")) { const int v = atoi(s); if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) lanes = v; }
     if (lanes == 1 || (lanes == 0 && D <= 32)) { *G = 1; *E = pow2ceil(D < 2 ? 2 : D); return; }
     int g = lanes > 1 ? lanes : 4;
-    while (g < 32 && ((D + 2 * g - 1) / (2 * g) > 8 || custom_stage_bytes(D, g, lik_prior ? 3 : 2) > KLARA_LDS_DEFAULT_DYNAMIC)) g *= 2;
-    *G = g; *E = 2 * ((D + 2 * g - 1) / (2 * g));
+    while (g < 32 && (D + 2 * g - 1) / (2 * g) > 8) g *= 2;                      // at most 16 elements per lane
+    const int nrows = lik_prior ? 3 : 2;
+    int w = 4;
+    if (const char* s = getenv("KLARA_CUSTOM_WPB")) { const int v = atoi(s); if (v == 2 || v == 4) w = v; }
+    else if (g >= 8 && custom_stage_bytes(D, g, nrows, 4) > KLARA_LDS_DEFAULT_DYNAMIC) w = 2;     // (measured: D = 128 +20 %, D = 256 +21 %; at 4 lanes x 16 elements the kernels spill and 8 x 8 on four wavefronts is faster)
+    while (g < 32 && custom_stage_bytes(D, g, nrows, w) > KLARA_LDS_DEFAULT_DYNAMIC) g *= 2;
+    *G = g; *E = 2 * ((D + 2 * g - 1) / (2 * g)); *wpb = w;
 }
 static bool custom_lik_prior(const char* src) { return src != nullptr && strstr(src, "KLARA_USER_LIKELIHOOD_PRIOR") != nullptr; }
 
-static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E, int custom_lanes = 0)
+static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E, int custom_lanes = 0, int* custom_wpb = nullptr)
 {
     if (hiert_eligible(d)) { *kind = 4; *G = 8; *E = 8; return KLARA_OK; }
     const int D = d.ndims;
@@ -177,8 +185,10 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     }
     if (d.target == KLARA_TARGET_CUSTOM) {       // whole-vector closure: one chain per lane, or staged through LDS on G lanes (klara_custom.h)
         if (D > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
-        custom_layout(D, custom_lanes, custom_lik_prior(d.custom_src), G, E);
-        if (*G > 1 && (*E > 16 || custom_stage_bytes(D, *G, custom_lik_prior(d.custom_src) ? 3 : 2) > KLARA_LDS_DEFAULT_DYNAMIC)) { *G = 1; *E = pow2ceil(D); }
+        int wpb = 4;
+        custom_layout(D, custom_lanes, custom_lik_prior(d.custom_src), G, E, &wpb);
+        if (*G > 1 && (*E > 16 || custom_stage_bytes(D, *G, custom_lik_prior(d.custom_src) ? 3 : 2, wpb) > KLARA_LDS_DEFAULT_DYNAMIC)) { *G = 1; *E = pow2ceil(D); wpb = 4; }
+        if (custom_wpb) *custom_wpb = wpb;
         return KLARA_OK;
     }
     if (d.target == KLARA_TARGET_LOGISTIC) {
@@ -420,7 +430,8 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
     klara_status st = validate(desc);
     if (st != KLARA_OK) return st;
     int kind, G, E;
-    st = select_layout(*desc, &kind, &G, &E, custom_lanes);
+    int custom_wpb = 4;
+    st = select_layout(*desc, &kind, &G, &E, custom_lanes, &custom_wpb);
     if (st != KLARA_OK) return st;
     if (desc->tuner_mode == KLARA_TUNE_POOLED && desc->sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
     // the logistic kernels keep the data rows (padded to E columns, + the responses) in LDS next to the 8 KB of math tables: up to
@@ -438,6 +449,7 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
     if (!h) return KLARA_ERR_NOMEM;
     h->d = *desc; h->kind = kind; h->G = G; h->E = E;
     h->custom_rows = (desc->target == KLARA_TARGET_CUSTOM && custom_lik_prior(desc->custom_src)) ? 3 : 2;
+    h->custom_wpb = custom_wpb;
     if (desc->target == KLARA_TARGET_LOGISTIC) {
         // D <= 8 parameters cannot fill a wavefront's lanes usefully, the ndata-row likelihood can: RS lanes share a chain
         // and each takes every RS-th row (fixed by ndata alone, so results do not depend on how chains are sharded)
@@ -640,7 +652,7 @@ static dim3 grid_for(const klara_handle* h)
 {
     const long long cpw = h->kind == 1 ? 16 : 64 / (h->G * h->RS);
     const long long waves = (h->d.nchains + cpw - 1) / cpw;
-    const long long wpb = h->kind == 1 ? 8 : 4;
+    const long long wpb = h->kind == 1 ? 8 : h->custom_wpb;
     return dim3((unsigned)((waves + wpb - 1) / wpb));
 }
 
@@ -654,7 +666,7 @@ static dim3 grid_for_transitions(const klara_handle* h)
     while (gpw > 1 && groups / gpw < 8192) gpw >>= 1;
     if (const char* s = getenv("KLARA_GROUPS_PER_WAVE")) { const long long v = atoll(s); if (v >= 1 && v <= 1024) gpw = v; }
     const long long waves = (groups + gpw - 1) / gpw;
-    return dim3((unsigned)((waves + 3) / 4));
+    return dim3((unsigned)((waves + h->custom_wpb - 1) / h->custom_wpb));
 }
 
 static size_t lds_for(const klara_handle* h)
@@ -662,7 +674,7 @@ static size_t lds_for(const klara_handle* h)
     if (h->kind != 1 && h->d.target == KLARA_TARGET_LOGISTIC)
         return sizeof(double) * (size_t)h->d.logit_ndata * (size_t)(h->E + 1);
     if (h->kind == 0 && h->d.target == KLARA_TARGET_CUSTOM && h->G > 1)              // staged closure: the rows of a workgroup's chains
-        return custom_stage_bytes(h->d.ndims, h->G, h->custom_rows);
+        return custom_stage_bytes(h->d.ndims, h->G, h->custom_rows, h->custom_wpb);
     return 0;
 }
 
@@ -777,7 +789,7 @@ static klara_status init_common(klara_handle* h)
           : h->G == 16 ? klara_launch_diagt_init_q16(p, h->E / 2, needgrad, grid_for(h), st)
                        : klara_launch_diagt_init_q32(p, h->E / 2, needgrad, grid_for(h), st);
     else if (h->kind == 4) e = klara_launch_hiert_init(p, h->E / 2, d.hier_ntimes, needgrad, grid_for(h), st);
-    else if (d.target == KLARA_TARGET_CUSTOM) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), lds_for(h), st);
+    else if (d.target == KLARA_TARGET_CUSTOM) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), lds_for(h), st, 64 * h->custom_wpb);
     else if (d.target == KLARA_TARGET_GAUSS_DIAG)
         e = launch_init_t<KLARA_TARGET_GAUSS_DIAG>(p, h->E, h->G, needgrad, grid_for(h), lds_for(h), st);
     else if (d.target == KLARA_TARGET_HIER_NORMAL)
@@ -960,7 +972,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
         const bool da = d.tuner == KLARA_TUNER_DUAL_AVERAGING;
         return klara_launch_hiert(p, kl, d.sampler, h->E / 2, d.hier_ntimes, mon, !plain || da, da, grid_for(h), h->stream);
     }
-    if (d.target == KLARA_TARGET_CUSTOM) return klara_jit_launch(h->jit, mode, p, kl, grid_for_transitions(h), lds_for(h), h->stream);
+    if (d.target == KLARA_TARGET_CUSTOM) return klara_jit_launch(h->jit, mode, p, kl, grid_for_transitions(h), lds_for(h), h->stream, 64 * h->custom_wpb);
     switch (d.sampler) {
     case KLARA_SAMPLER_MH: return klara_launch_mh(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
     case KLARA_SAMPLER_MALA: return klara_launch_mala(p, kl, mode, d.target, h->E, h->G, grid_for_transitions(h), lds_for(h), h->stream);
@@ -2015,8 +2027,8 @@ extern "C" klara_status klara_check_custom_target(const char* src, int32_t sampl
         return klara_jit_create_pair(src, sampler, ndims, (ndims + 2 * Q - 1) / (2 * Q), Q, false, false, false, modes, 1, false, nullptr);
     }
     if (ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
-    int G = 1, E = 2;
-    custom_layout(ndims, 0, custom_lik_prior(src), &G, &E);
+    int G = 1, E = 2, wpb = 4;
+    custom_layout(ndims, 0, custom_lik_prior(src), &G, &E, &wpb);
     return klara_jit_create(src, sampler, ndims, E, G, modes, 1, false, nullptr);
 }
 

@@ -342,14 +342,14 @@ void klara_jit_destroy(KlaraJit* j)
     delete j;
 }
 
-hipError_t klara_jit_launch_init(KlaraJit* j, const KParams& p, int needgrad, dim3 grid, size_t lds, hipStream_t st)
+hipError_t klara_jit_launch_init(KlaraJit* j, const KParams& p, int needgrad, dim3 grid, size_t lds, hipStream_t st, int block)
 {
     KParams pv = p;
     void* args[] = { &pv, &needgrad };
-    return hipModuleLaunchKernel(j->init, grid.x, 1, 1, 256, 1, 1, (unsigned)lds, st, args, nullptr);
+    return hipModuleLaunchKernel(j->init, grid.x, 1, 1, (unsigned)block, 1, 1, (unsigned)lds, st, args, nullptr);
 }
 
-hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, dim3 grid, size_t lds, hipStream_t st)
+hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, dim3 grid, size_t lds, hipStream_t st, int block)
 {
     auto it = j->trans.find(mode == 7 ? 7 : (mode & 3) == 3 ? 3 : (mode & 1) ? 1 : 0);
     if (it == j->trans.end()) return hipErrorInvalidValue;
@@ -363,7 +363,7 @@ hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaun
     }
     KLaunch klv = kl;
     void* args[] = { &p, &klv };
-    return hipModuleLaunchKernel(it->second, grid.x, 1, 1, 256, 1, 1, (unsigned)lds, st, args, nullptr);
+    return hipModuleLaunchKernel(it->second, grid.x, 1, 1, (unsigned)block, 1, 1, (unsigned)lds, st, args, nullptr);
 }
 
 // the pair-closure kernels take (KParams*, KLaunch, KAuto) like every k_diagt instantiation; one wavefront per chain group

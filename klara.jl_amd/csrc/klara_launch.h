@@ -136,8 +136,8 @@ klara_status klara_jit_create_pair(const char* src, int sampler, int D, int NP, 
                                    bool load, KlaraJit** out);
 hipError_t klara_jit_launch_pair(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, long long nwaves, hipStream_t st);
 void klara_jit_destroy(KlaraJit* j);
-hipError_t klara_jit_launch_init(KlaraJit* j, const KParams& p, int needgrad, dim3 grid, size_t lds, hipStream_t st);
-hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, dim3 grid, size_t lds, hipStream_t st);
+hipError_t klara_jit_launch_init(KlaraJit* j, const KParams& p, int needgrad, dim3 grid, size_t lds, hipStream_t st, int block = 256);
+hipError_t klara_jit_launch(KlaraJit* j, int mode, const KParams* p, const KLaunch& kl, dim3 grid, size_t lds, hipStream_t st, int block = 256);
 const char* klara_jit_log();
 
 // mode 7: mode 3 with exactly one transition per launch; mode 3: nothing counts/tunes and nothing is monitored;
