@@ -50,6 +50,7 @@ struct klara_handle {
     int acov_W = 0; double *acov_S = nullptr, *acov_head = nullptr, *acov_tail = nullptr, *acov_total = nullptr; long long acov_n = 0;
     double *hist_lt = nullptr, *hist_g = nullptr, *hist_ll = nullptr, *hist_lp = nullptr;
     unsigned long long* clock_probe = nullptr;        // pair-transposed kernels: (s_memtime, s_memrealtime) at the end / start of one workgroup of the last launch
+    bool pair_enqueued = false;                       // a launch of this handle has enqueued both kernel families (their one-time scratch set-up is behind us)
     int custom_wpb = 4;                               // staged closures: wavefronts per workgroup (2 where four wavefronts' rows do not fit the LDS)
     int custom_rows = 2;                              // staged closures: vectors per chain in LDS (3 for the likelihood + prior form)
     int* err = nullptr; int* flag_host = nullptr;     // error flag as the kernels address it; the same word as the host reads it (null: err is device memory)
@@ -954,9 +955,18 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
                     ka.my_mode = h->auto_mirror ? (__atomic_load_n(h->auto_mirror + 4 * j, __ATOMIC_RELAXED) != 0) : 1;
                     e = go(ka.my_mode == 0 ? 4 : 8, (idx & 15) == 0 ? ka : KLARA_AUTO_NONE);
                     h->n_launch_mode[ka.my_mode] += (j == 0 && !query);
+                } else if (nparts == 1 && h->pair_enqueued && h->auto_mirror && !query
+                           && __atomic_load_n(h->auto_mirror + 4 * j + 2, __ATOMIC_ACQUIRE) == (int)(idx - 1)) {
+                    // a synchronous caller (one launch per run, the previous one complete): the decision for this launch is already on the
+                    // host — one kernel, unconditional, no idle sibling (~5 us of a 20-transition launch).  Only after a launch has enqueued both
+                    // families: a kernel family's first dispatch on a queue sets up its scratch (~120 us, once).
+                    ka.my_mode = __atomic_load_n(h->auto_mirror + 4 * j, __ATOMIC_RELAXED) != 0;
+                    e = go(ka.my_mode == 0 ? 4 : 8, ka);
+                    h->n_launch_mode[2] += (j == 0);
                 } else {
                     // both kernels, each subject to the decision the previous launch left (an idle sibling costs ~3 us of a launch that
                     // takes hundreds: 17.9 against 17.7 us per transition for 20-transition launches, nothing measurable on two streams)
+                    h->pair_enqueued = true;
                     ka.cell_in = h->auto_cells + 2 * j + (int)(idx & 1);
                     ka.my_mode = 0; e = go(4, ka);
                     if (e == hipSuccess) { ka.my_mode = 1; e = go(8, ka); }
