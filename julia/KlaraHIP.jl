@@ -342,6 +342,13 @@ function launchmodes(job::HIPMCJob)
     (counts, lastmode, lastaccepted)
 end
 
+# shader clock (MHz) during the job's last launch of a pair-transposed kernel (an in-kernel probe, klara_get_shader_clock); 0.0 when unknown
+function shaderclock(job::HIPMCJob)
+    mhz = newarray(Float64, 1)
+    check(ccall((:klara_get_shader_clock, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), job.handle, mhz), "klara_get_shader_clock")
+    mhz[1]
+end
+
 # user-defined target: compile the closures' C text without a GPU; the compiler's message on failure
 function check_custom_target(src::String, sampler::Integer, ndims::Integer)
     st = ccall((:klara_check_custom_target, lib), Cint, (Cstring, Cint, Cint), src, sampler, ndims)
