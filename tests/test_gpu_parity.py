@@ -1111,6 +1111,39 @@ def test_likelihood_prior_closures_through_the_job_api():
     job.close()
 
 
+def test_likelihood_prior_monitors_of_a_staged_closure():
+    """The same monitors beyond 32 dimensions, where the closures are evaluated from the chain's rows of LDS by every lane of the chain
+    (klara_custom.h STAGED, three rows for the likelihood + prior form): logtarget == loglikelihood + logprior bit for bit at every saved
+    step, both parts equal the host closures at the saved values, accept masks and histories equal the oracle's."""
+    import ctypes as C
+    case = cases.make_case("staged_normal_normal_mala_d48")
+    t = case["target"]
+    d = t.ndims
+    p = K.BasicContMuvParameter("p", loglikelihood=cases.SRC_NN_LL, logprior=cases.SRC_NN_LP, gradloglikelihood=cases.SRC_NN_GLL,
+                                gradlogprior=cases.SRC_NN_GLP, ndims=d, data=t.data)
+    job = K.BasicMCJob(K.likelihood_model(p, False), K.MALA(0.1), K.BasicMCRange(nsteps=40, burnin=10), {"p": case["x0"]},
+                       outopts={"monitor": ["value", "logtarget", "loglikelihood", "logprior"], "diagnostics": ["accept"]}, seed=20260927)
+    assert job.engine.layout()[1] > 1                                   # several lanes per chain: the staged form
+    K.run(job)
+    chain = K.output(job)
+    o = O.OracleJob(**cases.oracle_kwargs(case, layout=job.engine.layout()), want_hist=True)
+    o.set_state(case["x0"]); o.run(40)
+    assert np.array_equal(job.engine.accept_mask(), o.accept) and 0.1 < o.accept.mean() < 0.99
+    lib = O.compile_user_target(t.source, d)[0]
+    dp = C.POINTER(C.c_double)
+    for f in (lib.klara_user_loglikelihood, lib.klara_user_logprior):
+        f.restype = C.c_double; f.argtypes = [dp, C.c_int, dp, C.c_longlong]
+    for c in (0, 33, 69):
+        v = chain.value(c); lt = chain.logtarget(c); ll = chain.loglikelihood(c); lp = chain.logprior(c)
+        assert np.array_equal(v, o.hist[:, c, :].T) and np.array_equal(lt, o.hist_lt[:, c])
+        assert np.array_equal(lt, ll + lp)
+        for i in range(v.shape[1]):
+            xi = np.ascontiguousarray(v[:, i])
+            assert ll[i] == lib.klara_user_loglikelihood(xi.ctypes.data_as(dp), d, t.data.ctypes.data_as(dp), t.data.size)
+            assert lp[i] == lib.klara_user_logprior(xi.ctypes.data_as(dp), d, t.data.ctypes.data_as(dp), t.data.size)
+    job.close()
+
+
 def test_iostream_sink_writes_the_likelihood_and_prior_files(tmp_path):
     """:destination => :iostream with :monitor => [:value, :loglikelihood, :logprior] (BasicContParamIOStream.jl:64-82: one file per
     monitored field): loglikelihood.csv / logprior.csv are written chunk by chunk next to value.csv, their lines are the in-memory
