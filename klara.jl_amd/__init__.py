@@ -15,5 +15,6 @@ from .distributed import allreduce_summaries, gather_engine_summaries, shard_cha
 from .build import build_library, build_oracle  # noqa: F401
 from . import stats  # noqa: F401
 from .stats import ess, iact, mcse, mcvar  # noqa: F401
+from .iostream import ContMuvMarkovChain, read_chain  # noqa: F401
 
 __all__ = [n for n in dir() if not n.startswith("_")]

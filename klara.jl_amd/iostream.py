@@ -102,3 +102,56 @@ class ChainWriter:
         for fh in self.files.values():
             if fh is not None:
                 fh.close()
+
+
+class ContMuvMarkovChain:
+    """What `read(iostream, T)` hands back (BasicContParamIOStream.jl:254-281 -> read!, :215-252): the monitored fields of one chain,
+    `value` / `gradlogtarget` as (size x n) matrices — one CSV line per saved step, transposed on reading (:224) —, `loglikelihood` /
+    `logprior` / `logtarget` as vectors of length n (:219), `diagnosticvalues` as a (keys x n) matrix of the parsed `true` / `false`
+    fields (:249-251); fields that were not monitored (no file) are empty, as in the reference."""
+
+    def __init__(self, size: int, n: int):
+        self.size, self.n = int(size), int(n)
+        self.value = np.zeros((0, 0)); self.gradlogtarget = np.zeros((0, 0))
+        self.loglikelihood = np.zeros(0); self.logprior = np.zeros(0); self.logtarget = np.zeros(0)
+        self.diagnosticvalues = np.zeros((0, 0), dtype=bool)
+        self.diagnostickeys = []
+
+
+def read_chain(directory: str, suffix: str = "csv", diagnostickeys=("accept",)) -> ContMuvMarkovChain:
+    """`read(BasicContParamIOStream(size, n, ...; filepath=directory, mode="r"), Float64)` for the fields this build writes: parses
+    whichever of value / loglikelihood / logprior / logtarget / gradlogtarget / diagnosticvalues files exist in `directory`.  Julia's
+    float printing round-trips (`julia_float_repr`), so a job written by the :iostream sink reads back bit for bit."""
+    def rows(name):
+        path = os.path.join(directory, f"{name}.{suffix}")
+        if not os.path.exists(path):
+            return None
+        with open(path) as f:
+            return [ln.rstrip("\n").split(",") for ln in f if ln.strip() != ""]
+
+    def num(tok: str) -> float:
+        return {"Inf": math.inf, "-Inf": -math.inf, "NaN": math.nan}.get(tok, None) if tok in ("Inf", "-Inf", "NaN") else float(tok)
+
+    mats, vecs = {}, {}
+    for name in ("value", "gradlogtarget"):
+        r = rows(name)
+        if r is not None:
+            mats[name] = np.array([[num(t) for t in ln] for ln in r], dtype=np.float64).T.copy() if r else np.zeros((0, 0))
+    for name in ("loglikelihood", "logprior", "logtarget"):
+        r = rows(name)
+        if r is not None:
+            vecs[name] = np.array([num(ln[0]) for ln in r], dtype=np.float64)
+    n = next((m.shape[1] for m in mats.values()), next((v.size for v in vecs.values()), 0))
+    size = next((m.shape[0] for m in mats.values()), 0)
+    chain = ContMuvMarkovChain(size, n)
+    for name, m in mats.items():
+        setattr(chain, name, m)
+    for name, v in vecs.items():
+        setattr(chain, name, v)
+    d = rows("diagnosticvalues")
+    if d is not None:
+        chain.diagnosticvalues = np.array([[t.strip() == "true" for t in ln] for ln in d], dtype=bool).T.copy() if d else np.zeros((0, 0), dtype=bool)
+        chain.diagnostickeys = list(diagnostickeys)[:chain.diagnosticvalues.shape[0]]
+        if n == 0:
+            chain.n = chain.diagnosticvalues.shape[1]
+    return chain

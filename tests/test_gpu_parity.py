@@ -676,6 +676,10 @@ def test_monitored_fields_and_iostream_sink(tmp_path):
     assert (d / "logtarget.csv").read_text().splitlines()[29] == j(o.hist_lt[29, 41])
     assert (d / "gradlogtarget.csv").read_text().splitlines()[3] == ",".join(j(v) for v in o.hist_g[3, 41])
     assert (d / "diagnosticvalues.csv").read_text().splitlines() == ["true" if a else "false" for a in o.accept[10:, 41]]
+    # read(iostream, Float64) (BasicContParamIOStream.jl:254-281): the files read back as the chain, bit for bit
+    back = K.read_chain(str(d))
+    assert back.size == 4 and back.n == 30 and np.array_equal(back.value, o.hist[:, 41, :].T) and np.array_equal(back.logtarget, o.hist_lt[:, 41])
+    assert np.array_equal(back.gradlogtarget, o.hist_g[:, 41, :].T) and np.array_equal(back.diagnosticvalues[0], o.accept[10:, 41].astype(bool))
     assert np.allclose(K.acceptance(chain), o.accept[10:].mean(axis=0))
     job.close()
 

@@ -546,3 +546,39 @@ def test_bench_kernel_register_budget(tmp_path):
     assert fused["vgpr_count"] <= 168 and fused["private_segment_fixed_size"] == 0, fused                      # 3 wavefronts per SIMD
     assert saving["vgpr_count"] <= 256 and saving["private_segment_fixed_size"] == 0, saving
     assert tuned["vgpr_count"] <= 256 and tuned["private_segment_fixed_size"] == 0, tuned
+
+
+def test_iostream_files_round_trip_the_reference_tests_vectors(tmp_path):
+    """The :iostream sink's on-disk format against the values the reference's own IO-stream tests write and read back
+    (test/ParameterIOStreams.jl:159-193 BasicContMuvParameterState, :195-238 ContMuvMarkovChain; write = one comma-joined line per saved
+    state, BasicContParamIOStream.jl:152-159; read = readdlm + transpose, :215-252): the files hold Julia's shortest float printing, and
+    `read_chain` returns the matrices / vectors / accept diagnostics exactly."""
+    from klara_jl_amd.iostream import ChainWriter, read_chain, julia_float_repr
+    # test/ParameterIOStreams.jl:161-163: value and a gradient field of 4 saved states of a 2-vector, their accept diagnostics
+    nstatev = np.array([[1.33, 2.44, 3.14, -0.82], [7.21, -9.75, -5.26, -0.63]])
+    nstateg = np.array([[3.13, -12.10, 13.11, -0.99], [9.91, -5.25, -8.15, -9.69]])
+    nstated = np.array([False, True, True, False])
+    w = ChainWriter(str(tmp_path / "a"), "csv", value=True, logtarget=False, gradlogtarget=True, accept=True)
+    for i in range(4):                                                   # one write per saved state, as the job loop does (:152-159)
+        w.append(value=nstatev[:, i:i + 1], gradlogtarget=nstateg[:, i:i + 1], accept=nstated[i:i + 1])
+    w.flush(); w.close()
+    assert (tmp_path / "a" / "value.csv").read_text() == "1.33,7.21\n2.44,-9.75\n3.14,-5.26\n-0.82,-0.63\n"          # join(state.value, ',')
+    assert (tmp_path / "a" / "gradlogtarget.csv").read_text() == "3.13,9.91\n-12.1,-5.25\n13.11,-8.15\n-0.99,-9.69\n"
+    assert (tmp_path / "a" / "diagnosticvalues.csv").read_text() == "false\ntrue\ntrue\nfalse\n"
+    assert not (tmp_path / "a" / "logtarget.csv").exists()               # only monitored fields get a file (:64-82)
+    c = read_chain(str(tmp_path / "a"))
+    assert c.size == 2 and c.n == 4 and np.array_equal(c.value, nstatev) and np.array_equal(c.gradlogtarget, nstateg)
+    assert c.diagnostickeys == ["accept"] and np.array_equal(c.diagnosticvalues, nstated[None, :])
+    assert c.logtarget.size == 0 and c.loglikelihood.size == 0 and c.logprior.size == 0          # (:for i in [2:4; 6:13] ... length == 0)
+    # test/ParameterIOStreams.jl:197-200: value, loglikelihood, logtarget of 3 saved states (the reference uses Float32 there; the values
+    # are the decimal literals)
+    v2 = np.array([[-1.85, -0.09, 0.36], [-0.45, -0.85, 1.91]]); ll = np.array([-1.30, -1.65, -0.18]); lt = np.array([-0.44, 0.72, -0.21])
+    w = ChainWriter(str(tmp_path / "b"), "csv", value=True, logtarget=True, gradlogtarget=False, accept=False, likelihood_prior=True)
+    w.append(value=v2, logtarget=lt, loglikelihood=ll, logprior=np.zeros(3)); w.close()
+    assert (tmp_path / "b" / "loglikelihood.csv").read_text() == "-1.3\n-1.65\n-0.18\n" and (tmp_path / "b" / "logtarget.csv").read_text() == "-0.44\n0.72\n-0.21\n"
+    c = read_chain(str(tmp_path / "b"))
+    assert np.array_equal(c.value, v2) and np.array_equal(c.loglikelihood, ll) and np.array_equal(c.logtarget, lt) and c.diagnosticvalues.size == 0
+    # the printing round-trips every double (what makes write -> read exact for a real job's values)
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.standard_normal(2000) * 10.0 ** rng.integers(-12, 12, 2000), [0.0, -0.0, 1e-5, 1e-4, 999999.0, 1e6, 123456.7, 5e-324, 1.7976931348623157e308]])
+    assert all(float(julia_float_repr(x)) == x and np.signbit(float(julia_float_repr(x))) == np.signbit(x) for x in xs)
