@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define KLARA_ABI_VERSION 3
+#define KLARA_ABI_VERSION 4   /* 4: klara_gather_moments; klara_desc.sparse_moves 0 = device-decided (round 3's additions, renumbered late) */
 /* klara_desc.steps_per_launch = 0 selects this many transitions per kernel launch (launches also end at the pooled tuner's
  * events and at batch boundaries of the streaming batch means, whichever comes first) */
 #define KLARA_DEFAULT_STEPS_PER_LAUNCH 32
@@ -287,6 +287,17 @@ klara_status klara_comm_destroy(klara_comm* comm);
  * transitions, transitions, saved samples (= saved steps x chains), chains.  Collective: every rank calls it. */
 klara_status klara_gather_summaries(klara_handle* h, klara_comm* comm, double* sum, double* sumsq, uint64_t* naccept,
                                     uint64_t* ntransitions, uint64_t* nsamples, uint64_t* nchains);
+
+/* The pooled posterior moments over every chain of every rank WITHOUT the cancellation of sumsq/n - mean^2 (which loses
+ * mean^2/var digits: 4 at the rats model's alpha_c): mean[D], m2[D] = sum (x - mean)^2 per dimension over all saved samples
+ * (variance = m2 / nsamples, Klara's var(chain) over the pooled chains), the counters as klara_gather_summaries.  Every chain's
+ * running sums become (n, mean, M2) on the device with the one cancelling subtraction carried in double-double, then chains,
+ * blocks and ranks are merged by Chan's update; across ranks that is three all-reduces (4 counters, D weighted means, D sums of
+ * squares).  comm = NULL: this handle's chains only, no RCCL involved (what a host with its own transport — torch.distributed,
+ * MPI.jl, Julia's Distributed — merges itself, klara.jl_amd/distributed.py allreduce_moments).  Requires KLARA_MON_SUMMARIES.
+ * Collective when comm != NULL: every rank calls it. */
+klara_status klara_gather_moments(klara_handle* h, klara_comm* comm, double* mean, double* m2, uint64_t* nsamples,
+                                  uint64_t* naccept, uint64_t* ntransitions, uint64_t* nchains);
 
 /* one chain of the stored history in Klara's NState layout: value[d + D*i], i = saved step
  * (BasicContMuvParameterNState.jl:89-119); requires KLARA_MON_HISTORY.  With klara_desc.hist_ring_cols > 0 the columns are the

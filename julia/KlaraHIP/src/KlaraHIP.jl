@@ -1,19 +1,35 @@
-# KlaraHIP.jl — Julia host side of libklara_hip.so: Klara's own job / sampler / tuner / range structs in, Klara's own
+# KlaraHIP.jl — Julia host side of libklara_hip.so: Klara's own sampler / tuner / range structs in, Klara's own
 # BasicContMuvParameterNState out, the transition loop on an MI355X in between (include/klara_hip.h, INTEGRATION.md).
+# Package layout: julia/KlaraHIP/{REQUIRE, src/KlaraHIP.jl, test/runtests.jl}; put julia/ on LOAD_PATH (or Pkg.clone the directory).
 #
 #     using Klara, KlaraHIP
 #     p      = HIPParameter(:p, GaussDiagTarget(100))                     # device form of BasicContMuvParameter(:p, logtarget=...)
 #     job    = HIPMCJob(p, MALA(0.9), BasicMCRange(nsteps=10000, burnin=1000), Dict(:p => randn(100, 65536));
 #                       tuner=VanillaMCTuner(), outopts=Dict(:monitor => [:value], :diagnostics => [:accept]))
 #     run(job); chain = output(job, 1); mean(chain); acceptance(chain)
+#     reset(job); run(job)                                                # an independent replicate (BasicMCJob.jl:187-201)
+#
+# `run`, `reset` (Base generics Klara extends: src/Klara.jl:26-27) and `output` (Klara's own, exported at src/Klara.jl:232) are
+# IMPORTED before the methods below are defined, so `run(job)`, `reset(job[, x])`, `output(job[, c])` on an HIPMCJob are methods
+# of the same functions a Klara user already calls on a BasicMCJob (src/jobs/BasicMCJob.jl:187-201,212,279); HIPMCJob <: Klara.MCJob,
+# so `run(jobs::Vector)` (src/jobs/jobs.jl:212) maps over HIP jobs too.  Everything else the example names is exported below.
 #
 # UNTESTED in the build image (no Julia there); tests/test_host_api.py checks mechanically what can be checked without it: the
 # struct layout against the C header, the descriptor builder's argument order, the Klara field names each mapping reads
-# (cited below), that only declared symbols are bound, and that blocks / brackets balance.  One file for Klara's own Julia 0.6
+# (cited below), that only declared symbols are bound, that blocks / brackets balance, that every unqualified name of the example
+# above and of INTEGRATION.md is exported here or by Klara, that every generic of Klara / Base this file adds methods to is imported
+# first, and that nothing reaches through the caller's top-level module.  One file for Klara's own Julia 0.6
 # (REQUIRE:1 — `Void`, `Array{T}(dims)`, `finalizer(obj, f)`) and for Julia >= 0.7 (`Cvoid`, `Array{T}(undef, dims)`,
 # `finalizer(f, obj)`): the three differences are confined to the compatibility block below, everything else is common syntax.
 module KlaraHIP
-import Base: run
+import Klara
+import Klara: output, MCJob, MH, MALA, HMC, SliceSampler, VanillaMCTuner, AcceptanceRateMCTuner, DualAveragingMCTuner,
+              BasicContMuvParameterState, BasicContMuvParameterNState, erf_rate_score, logistic_rate_score
+import Distributions
+import Base: run, reset, show
+export HIPMCJob, HIPParameter, HIPTarget, GaussDiagTarget, GaussDenseTarget, LogisticTarget, HierNormalTarget, CustomTarget,
+       chainvalue, chainmeans, chainacceptance, chainmcvar_bm, streamkey, launchmodes, shaderclock, check_custom_target,
+       HIPComm, comm_unique_id, gather_summaries, gather_moments, pooledmoments, KlaraDesc, klara_desc
 const lib = "libklara_hip"            # klara.jl_amd/lib/libklara_hip.so on LD_LIBRARY_PATH
 
 # ---------------------------------------------------------------- Julia 0.6 / >= 0.7 compatibility (the only version-dependent code)
@@ -27,7 +43,7 @@ else
 end
 
 # ---------------------------------------------------------------- constants of include/klara_hip.h
-const KLARA_ABI_VERSION = UInt32(3)
+const KLARA_ABI_VERSION = UInt32(4)
 const SAMPLER_MH, SAMPLER_MALA, SAMPLER_HMC, SAMPLER_SLICE = Int32(0), Int32(1), Int32(2), Int32(3)
 const TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET_HIER_NORMAL, TARGET_CUSTOM = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
 const TUNER_VANILLA, TUNER_ACCEPT_RATE, TUNER_DUAL_AVERAGING = Int32(0), Int32(1), Int32(2)
@@ -123,7 +139,7 @@ struct HIPParameter
 end
 
 # ---------------------------------------------------------------- the job
-mutable struct HIPMCJob            # stands for N BasicMCJobs of one model (run(jobs::Vector) = map(run, jobs), jobs.jl:212)
+mutable struct HIPMCJob <: MCJob   # stands for N BasicMCJobs of one model (run(jobs::Vector) = map(run, jobs), jobs.jl:212)
     handle::Ptr{Cvoid}; nchains::Int; ndims::Int
     parameter::HIPParameter; sampler; tuner; range        # Klara's own MCSampler / MCTuner / BasicMCRange
     outopts::Dict{Symbol, Any}; monitor::UInt32
@@ -154,47 +170,45 @@ function HIPMCJob(parameter::HIPParameter, sampler, mcrange, v0::Dict;
                            :steps_per_launch => steps_per_launch, :bm_batchlen => bm_batchlen,
                            :nsteps => mcrange.nsteps, :burnin => mcrange.burnin, :thinning => mcrange.thinning)
     # --- sampler
-    sname = string(typeof(sampler).name.name)
-    if sname == "MALA"
+    if isa(sampler, MALA)
         kw[:sampler] = SAMPLER_MALA; kw[:driftstep] = Float64(sampler.driftstep)
-    elseif sname == "HMC"
+    elseif isa(sampler, HMC)
         kw[:sampler] = SAMPLER_HMC; kw[:leapstep] = Float64(sampler.leapstep); kw[:nleaps] = Int32(sampler.nleaps)
-    elseif sname == "SliceSampler"
+    elseif isa(sampler, SliceSampler)
         w = convert(Vector{Float64}, sampler.widths); push!(keep, w)
         length(w) == D || error("SliceSampler widths must have one entry per dimension")
         kw[:sampler] = SAMPLER_SLICE; kw[:slice_widths] = pointer(w); kw[:slice_stepout] = Int32(sampler.stepout)
-    elseif sname == "MH"
+    elseif isa(sampler, MH)
         (sampler.symmetric && sampler.normalised) || error("only the symmetric normalised random-walk MH(sigma) runs on the device (iterate/MH.jl:72-124)")
-        prop = sampler.setproposal(Main.Klara.BasicContMuvParameterState(zeros(D)))    # MvNormal(x, sigma): its variances give sigma
-        sig = sqrt.(Main.Klara.Distributions.var(prop)); push!(keep, sig)
+        prop = sampler.setproposal(BasicContMuvParameterState(zeros(D)))    # MvNormal(x, sigma): its variances give sigma
+        sig = sqrt.(Distributions.var(prop)); push!(keep, sig)
         kw[:sampler] = SAMPLER_MH; kw[:mh_sigma] = pointer(sig)
     else
-        error("sampler $(sname) is not on the device path (MH, MALA, HMC, SliceSampler are)")
+        error("sampler $(typeof(sampler)) is not on the device path (MH, MALA, HMC, SliceSampler are)")
     end
     # --- tuner
-    tn = tuner === nothing ? Main.Klara.VanillaMCTuner() : tuner
-    tname = string(typeof(tn).name.name)
+    tn = tuner === nothing ? VanillaMCTuner() : tuner
     kw[:period] = Int32(tn.period); kw[:verbose] = Int32(tn.verbose)
-    if tname == "VanillaMCTuner"
+    if isa(tn, VanillaMCTuner)
         kw[:tuner] = TUNER_VANILLA
-    elseif tname == "AcceptanceRateMCTuner"
+    elseif isa(tn, AcceptanceRateMCTuner)
         kw[:tuner] = TUNER_ACCEPT_RATE; kw[:targetrate] = Float64(tn.targetrate)
         kw[:tuner_mode] = pooled ? TUNE_POOLED : TUNE_PER_CHAIN
         # tuner.score is a function: logistic_rate_score (k = 7) and erf_rate_score (k = 3) are the two Klara ships
-        if tn.score === Main.Klara.erf_rate_score
+        if tn.score === erf_rate_score
             kw[:tuner_score] = Int32(1); kw[:score_k] = 3.0
-        elseif tn.score === Main.Klara.logistic_rate_score
+        elseif tn.score === logistic_rate_score
             kw[:tuner_score] = Int32(0); kw[:score_k] = 7.0
         else
             error("AcceptanceRateMCTuner score must be logistic_rate_score or erf_rate_score on the device")
         end
-    elseif tname == "DualAveragingMCTuner"
-        sname == "HMC" || error("DualAveragingMCTuner is wired into HMC only (HMC.jl:124-133)")
+    elseif isa(tn, DualAveragingMCTuner)
+        isa(sampler, HMC) || error("DualAveragingMCTuner is wired into HMC only (HMC.jl:124-133)")
         kw[:tuner] = TUNER_DUAL_AVERAGING; kw[:targetrate] = Float64(tn.targetrate); kw[:da_nadapt] = Int64(tn.nadapt)
         kw[:da_eps0bar] = Float64(tn.ε0bar); kw[:da_h0bar] = Float64(tn.h0bar); kw[:da_gamma] = Float64(tn.γ)
         kw[:da_t0] = Int32(tn.t0); kw[:da_kappa] = Float64(tn.κ)
     else
-        error("tuner $(tname) is not on the device path")
+        error("tuner $(typeof(tn)) is not on the device path")
     end
     # --- target
     if isa(t, GaussDiagTarget)
@@ -255,12 +269,22 @@ function HIPMCJob(desc::KlaraDesc, X0::Matrix{Float64}, range)
     job
 end
 
+# run / reset: methods of Base.run / Base.reset — the generics Klara itself extends (src/Klara.jl:26-27; imported above)
 run(job::HIPMCJob) =                                     # BasicMCJob.jl:212-244 for all chains
     check(ccall((:klara_run, lib), Cint, (Ptr{Cvoid}, Clonglong), job.handle, job.range.nsteps), "klara_run")
 
-reset(job::HIPMCJob) = check(ccall((:klara_reset, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), job.handle, C_NULL), "klara_reset")
+reset(job::HIPMCJob) =                                   # BasicMCJob.jl:187-195; the job moves to its next Philox key (klara_hip.h)
+    check(ccall((:klara_reset, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), job.handle, C_NULL), "klara_reset")
 reset(job::HIPMCJob, X::Matrix{Float64}) =
     check(ccall((:klara_reset, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), job.handle, X), "klara_reset")
+
+function show(io::IO, job::HIPMCJob)                     # BasicMCJob.jl:281-295 prints parameter, model, sampler, tuner, range
+    println(io, "HIPMCJob: ", job.nchains, " chains of ", job.ndims, " dimensions on libklara_hip")
+    print(io, "  "); show(io, job.parameter.target)
+    print(io, "\n  "); show(io, job.sampler)
+    print(io, "\n  "); show(io, job.tuner)
+    print(io, "\n  "); show(io, job.range)
+end
 
 # value matrix of chain c exactly as BasicContMuvParameterNState.value (D x npoststeps)
 function chainvalue(job::HIPMCJob, c::Integer)
@@ -273,7 +297,7 @@ function chainvalue(job::HIPMCJob, c::Integer)
     v
 end
 
-# output(job, c): the BasicContMuvParameterNState of chain c (BasicMCJob.jl:279; nstates/ParameterNStates/
+# output(job, c): a method of Klara.output (imported above) — the BasicContMuvParameterNState of chain c (BasicMCJob.jl:279; nstates/ParameterNStates/
 # BasicContMuvParameterNState.jl:23-61: fields value, loglikelihood, logprior, logtarget, gradloglikelihood, gradlogprior,
 # gradlogtarget, ..., diagnosticvalues, size, monitor, n, diagnostickeys) filled from the device history
 function output(job::HIPMCJob, c::Integer=1)
@@ -284,7 +308,7 @@ function output(job::HIPMCJob, c::Integer=1)
     monitor[4] = (job.monitor & MON_HIST_LT) != 0           # logtarget
     monitor[7] = (job.monitor & MON_HIST_GRAD) != 0         # gradlogtarget
     dkeys = (job.monitor & MON_ACCEPT) != 0 ? [:accept] : Symbol[]
-    ns = Main.Klara.BasicContMuvParameterNState(job.ndims, n, monitor, dkeys)
+    ns = BasicContMuvParameterNState(job.ndims, n, monitor, dkeys)
     if monitor[1]; ns.value = chainvalue(job, c); end
     nc = Ref{Clonglong}(0)
     if monitor[4] || monitor[7]
@@ -378,5 +402,24 @@ function gather_summaries(job::HIPMCJob, comm::HIPComm)
                 (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}),
                 job.handle, comm.handle, s, q, na, nt, ns, nc), "klara_gather_summaries")
     (s, q, na[], nt[], ns[], nc[])
+end
+# The pooled posterior moments over every chain of every GPU without the cancellation of sumsq/n - mean^2 (klara_gather_moments:
+# per-chain (n, mean, M2) on the device, Chan's merge over chains, blocks and ranks): (mean, var, nsamples, accepted, transitions, chains)
+function gather_moments(job::HIPMCJob, comm::HIPComm)
+    m = newarray(Float64, job.ndims); m2 = similar(m)
+    ns = Ref{UInt64}(0); na = Ref{UInt64}(0); nt = Ref{UInt64}(0); nc = Ref{UInt64}(0)
+    check(ccall((:klara_gather_moments, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}),
+                job.handle, comm.handle, m, m2, ns, na, nt, nc), "klara_gather_moments")
+    (m, m2 ./ Float64(ns[]), ns[], na[], nt[], nc[])
+end
+# ... and of this job's chains alone (no communicator, no RCCL)
+function pooledmoments(job::HIPMCJob)
+    m = newarray(Float64, job.ndims); m2 = similar(m)
+    ns = Ref{UInt64}(0); na = Ref{UInt64}(0); nt = Ref{UInt64}(0); nc = Ref{UInt64}(0)
+    check(ccall((:klara_gather_moments, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}),
+                job.handle, C_NULL, m, m2, ns, na, nt, nc), "klara_gather_moments")
+    (m, m2 ./ Float64(ns[]), ns[], na[], nt[], nc[])
 end
 end # module

@@ -13,7 +13,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libklara_hip.so"
 
-KLARA_ABI_VERSION = 3
+KLARA_ABI_VERSION = 4
 DEFAULT_STEPS_PER_LAUNCH = 32     # KLARA_DEFAULT_STEPS_PER_LAUNCH
 LOGIT_MAX_LDS_DOUBLES = 18432     # KLARA_LOGIT_MAX_LDS_DOUBLES
 
@@ -76,7 +76,7 @@ EXPORTS = [
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
     "klara_get_chain_fields", "klara_get_chain_likelihood_prior", "klara_get_chain_mcvar", "klara_get_chain_mcvar_ipse", "klara_get_chain_acov_mcvar", "klara_saved_steps", "klara_get_chain_bm", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout", "klara_get_launch_modes", "klara_get_kernel_attributes", "klara_get_shader_clock",
     "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_normal_tail", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
-    "klara_comm_unique_id", "klara_comm_init", "klara_comm_destroy", "klara_gather_summaries",
+    "klara_comm_unique_id", "klara_comm_init", "klara_comm_destroy", "klara_gather_summaries", "klara_gather_moments",
     "klara_check_custom_target", "klara_compile_log", "klara_selftest_plan", "klara_abi_version",
 ]
 
@@ -134,6 +134,8 @@ def load() -> C.CDLL:
         "klara_comm_destroy": [C.c_void_p],
         "klara_gather_summaries": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+        "klara_gather_moments": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "klara_check_custom_target": [C.c_char_p, C.c_int32, C.c_int32],
         "klara_get_chain_bm": [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
         "klara_get_chain_acov_mcvar": [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
@@ -155,7 +157,10 @@ def load() -> C.CDLL:
     lib.klara_abi_version.argtypes = []
     lib.klara_abi_version.restype = C.c_int32
     if lib.klara_abi_version() != KLARA_ABI_VERSION:
-        raise RuntimeError("libklara_hip.so ABI version mismatch")
+        if "KLARA_HIP_LIB" not in os.environ or lib.klara_abi_version() < 3:
+            raise RuntimeError("libklara_hip.so ABI version mismatch")
+        # same-box A/B against an older build: klara_desc has not changed since version 3, the older library only lacks entry points
+        globals()["KLARA_ABI_VERSION"] = int(lib.klara_abi_version())
     _lib = lib
     return lib
 

@@ -1576,6 +1576,143 @@ extern "C" klara_status klara_gather_summaries(klara_handle* h, klara_comm* c, d
     return KLARA_OK;
 }
 
+// ---- pooled moments without cancellation (the consumer is mean(chain) / var over every chain,
+// src/stats/mean.jl:7-11).  sumsq/n - mean^2 from pooled raw sums loses mean^2/var digits (rats alpha_c: mean 242, sd 2.7 -> 4
+// digits).  Here every chain's raw sums become (n_c, mean_c, M2_c) with the one cancelling subtraction, q - s^2/n, carried in
+// double-double (s^2 = p + pe exactly by fma, the quotient's remainder by fma), and chains, blocks and ranks are merged by
+// Chan's update — sums of non-negative terms only.  Fixed shapes => deterministic for a given chain count.
+__global__ void k_scale(double* __restrict__ dst, const double* __restrict__ src, double f, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) dst[j] = f * src[j];
+}
+__device__ inline void chan_merge(double& n, double& mean, double& m2, double nb, double meanb, double m2b)
+{
+    const double nt = n + nb;
+    if (!(nt > 0.0)) return;
+    const double delta = meanb - mean, w = nb / nt;
+    mean = mean + delta * w;
+    m2 = (m2 + m2b) + (delta * delta) * (n * w);
+    n = nt;
+}
+__global__ __launch_bounds__(256) void k_moments_stage1(const double* __restrict__ sum, const double* __restrict__ sumsq,
+                                                        const double* __restrict__ X, const long long* __restrict__ held,
+                                                        long long N, int D, int nb, double nsaved, double* __restrict__ partial)
+{
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j < D; j += 256) {
+        double n = 0.0, mean = 0.0, m2 = 0.0;
+        for (long long c = b; c < N; c += nb) {                             // (a chain's sums over its saved steps: part + held * x)
+            const long long hd = held[c];
+            const double x = X[c * D + j];
+            const double s = hd > 0 ? sum[c * D + j] + (double)hd * x : sum[c * D + j];
+            const double q = hd > 0 ? sumsq[c * D + j] + (double)hd * (x * x) : sumsq[c * D + j];
+            const double p = s * s, pe = fma(s, s, -p);                    // s^2 = p + pe
+            const double qh = p / nsaved, r = fma(-qh, nsaved, p);         // p = qh * nsaved + r
+            const double ql = (r + pe) / nsaved;                           // s^2 / nsaved = qh + ql (+ O(2^-105))
+            double m2c = (q - qh) - ql;
+            if (m2c < 0.0) m2c = 0.0;
+            chan_merge(n, mean, m2, nsaved, s / nsaved, m2c);
+        }
+        partial[(long long)b * 2 * D + j] = mean;
+        partial[(long long)b * 2 * D + D + j] = m2;
+    }
+}
+// block j: dimension j.  Thread t merges the blocks' partials b = t, t + 256, ... (ascending), then a fixed tree over the threads.
+// out[j] = mean, out[D + j] = M2 over the handle's chains; the count is nsaved * N.
+__global__ __launch_bounds__(256) void k_moments_stage2(const double* __restrict__ partial, long long N, int D, int nb, double nsaved,
+                                                        double* __restrict__ out)
+{
+    __shared__ double sn[256], sm[256], sq[256];
+    const int j = blockIdx.x, t = threadIdx.x;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int b = t; b < nb; b += 256) {
+        const long long chains = (N - b + nb - 1) / nb;                     // chains c = b, b + nb, ... < N
+        chan_merge(n, mean, m2, nsaved * (double)chains, partial[(long long)b * 2 * D + j], partial[(long long)b * 2 * D + D + j]);
+    }
+    sn[t] = n; sm[t] = mean; sq[t] = m2;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if (t < m) chan_merge(sn[t], sm[t], sq[t], sn[t + m], sm[t + m], sq[t + m]);
+        __syncthreads();
+    }
+    if (t == 0) { out[j] = sm[0]; out[D + j] = sq[0]; }
+}
+// rank-local part of the between-rank merge: buf[j] = mean_r -> M2_r + n_r (mean_r - mean)^2 with mean = wsum[j] / ntot
+__global__ void k_moments_between(double* __restrict__ m2, const double* mean_r, const double* __restrict__ wsum,
+                                  const unsigned long long* __restrict__ ntot, double n_r, int D, double* mean_out)   // (mean_out may be mean_r)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D) return;
+    const double mean = wsum[j] / (double)*ntot, d = mean_r[j] - mean;
+    mean_out[j] = mean;
+    m2[j] = m2[j] + n_r * (d * d);
+}
+// out: mean[D], M2[D], then the u64 accept total; on the handle's stream
+static hipError_t pool_moments_async(klara_handle* h, double* out)
+{
+    const int D = h->d.ndims;
+    const long long N = h->d.nchains;
+    const int nb = (int)(N < KLARA_POOL_BLOCKS ? N : KLARA_POOL_BLOCKS);
+    hipError_t e = pool_summaries_async(h, false, out);                     // the accept total -> out[2 D]
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_moments_stage1, dim3(nb), dim3(256), 0, h->stream, h->sum, h->sumsq, h->X, h->held, N, D, nb, (double)h->nsaved, h->pool_partial);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_moments_stage2, dim3(D), dim3(256), 0, h->stream, h->pool_partial, N, D, nb, (double)h->nsaved, out);
+    return hipGetLastError();
+}
+
+extern "C" klara_status klara_gather_moments(klara_handle* h, klara_comm* c, double* mean, double* m2, uint64_t* nsamples,
+                                             uint64_t* naccept, uint64_t* ntransitions, uint64_t* nchains)
+{
+    if (!h) return KLARA_ERR_INVALID_ARG;
+    if (!h->have_state || !h->sum) return KLARA_ERR_STATE;
+    HIPCHK(hipSetDevice(h->d.device));
+    const size_t D = (size_t)h->d.ndims;
+    unsigned long long cnt[4] = { 0, (unsigned long long)h->steps_done * (unsigned long long)h->d.nchains,
+                                  (unsigned long long)h->nsaved * (unsigned long long)h->d.nchains, (unsigned long long)h->d.nchains };
+    std::vector<double> host(2 * D + 1);
+    if (!c) {                                                               // this handle's chains only
+        HIPCHK(pool_moments_async(h, h->pooled_out));
+        HIPCHK(hipMemcpyAsync(host.data(), h->pooled_out, (2 * D + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(&cnt[0], host.data() + 2 * D, sizeof(cnt[0]));
+    } else {
+        // device staging: [0, D) mean_r -> mean, [D, 2D) M2_r -> M2, [2D] accept total, then [2D+1, 2D+4) counters, [2D+4, 3D+4) n_r mean_r
+        if (c->cap < 3 * D + 4) {
+            if (c->buf) hipFree(c->buf);
+            c->buf = nullptr; c->cap = 0;
+            HIPCHK(dalloc(&c->buf, 3 * D + 4));
+            c->cap = 3 * D + 4;
+        }
+        HIPCHK(pool_moments_async(h, c->buf));
+        unsigned long long* dcnt = reinterpret_cast<unsigned long long*>(c->buf + 2 * D);
+        HIPCHK(hipMemcpyAsync(dcnt + 1, cnt + 1, 3 * sizeof(cnt[0]), hipMemcpyHostToDevice, h->stream));
+        double* wsum = c->buf + 2 * D + 4;
+        const double n_r = (double)cnt[2];
+        hipLaunchKernelGGL(k_scale, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, h->stream, wsum, c->buf, n_r, (int)D);
+        HIPCHK(hipGetLastError());
+        // three in-place all-reduces on the job's stream: 4 counters, D weighted means, D sums of squares — latency-bound
+        if (c->AllReduce(dcnt, dcnt, 4, ncclUint64, ncclSum, c->comm, h->stream) != ncclSuccess) return KLARA_ERR_HIP;
+        if (c->AllReduce(wsum, wsum, D, ncclDouble, ncclSum, c->comm, h->stream) != ncclSuccess) return KLARA_ERR_HIP;
+        hipLaunchKernelGGL(k_moments_between, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, h->stream, c->buf + D, c->buf, wsum, dcnt + 2, n_r, (int)D, c->buf);
+        HIPCHK(hipGetLastError());
+        if (c->AllReduce(c->buf + D, c->buf + D, D, ncclDouble, ncclSum, c->comm, h->stream) != ncclSuccess) return KLARA_ERR_HIP;
+        std::vector<double> hostc(2 * D + 4);
+        HIPCHK(hipMemcpyAsync(hostc.data(), c->buf, (2 * D + 4) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(host.data(), hostc.data(), 2 * D * sizeof(double));
+        memcpy(cnt, hostc.data() + 2 * D, sizeof(cnt));
+    }
+    if (mean) memcpy(mean, host.data(), D * sizeof(double));
+    if (m2) memcpy(m2, host.data() + D, D * sizeof(double));
+    if (naccept) *naccept = cnt[0];
+    if (ntransitions) *ntransitions = cnt[1];
+    if (nsamples) *nsamples = cnt[2];
+    if (nchains) *nchains = cnt[3];
+    return KLARA_OK;
+}
+
 // Columns [first, first + count) of the saved steps from a history buffer whose column c lives at slot c % hist_cols (ring) or c:
 // `width` bytes per column copied to consecutive rows of dst, `stride` bytes between the buffer's columns.
 static hipError_t copy_saved_columns(const klara_handle* h, void* dst, const char* src, size_t width, size_t stride, long long first, long long count)

@@ -2,9 +2,11 @@
 
 Chains are independent (`run(job::Vector) = map(run, job)`, src/jobs/jobs.jl:212), so rank r of R owns the
 block [r*N/R, (r+1)*N/R) and seeds its Philox subsequences with the GLOBAL chain id: results do not depend
-on R.  The only exchange is one end-of-run all-reduce of the pooled chain summaries
-(sum x[D], sum x^2[D], n_accept, n_transitions, n_saved*chains): (2D+3) doubles ~ 1.6 kB at D = 100 (+ D doubles for the
-between-rank term of the pooled variance), latency-bound over RCCL/xGMI.  Backend "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests.
+on R.  The only exchange is the end-of-run merge of the pooled chain summaries: every rank holds (n_r, mean_r[D], M2_r[D]) of its
+chains — formed on the device without the cancellation of sumsq/n - mean^2 (klara_gather_moments, include/klara_hip.h) — and the
+ranks are merged by Chan's update in three SUM all-reduces (3 counters, D weighted means, D sums of squares): ~1.6 kB at D = 100,
+latency-bound over RCCL/xGMI.  Backend "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests.  No rational arithmetic, no exceptions on
+non-finite sums (they propagate as NaN moments on every rank alike, so no rank can leave the collectives early).
 """
 from __future__ import annotations
 
@@ -21,32 +23,43 @@ def shard_chains(nchains_total: int, rank: int, world: int) -> Tuple[int, int]:
     return offset, count
 
 
+def _two_prod(a: np.ndarray, b: np.ndarray):
+    """a * b = p + e exactly (Dekker / Veltkamp splitting; numpy has no fma)."""
+    p = a * b
+    def split(v):
+        c = 134217729.0 * v                    # 2^27 + 1
+        hi = c - (c - v)
+        return hi, v - hi
+    ah, al = split(a); bh, bl = split(b)
+    e = ((ah * bh - p) + ah * bl + al * bh) + al * bl
+    return p, e
+
+
 def _local_moments(s: np.ndarray, q: np.ndarray, n: float):
-    """(mean, M2 = sum (x - mean)^2) per dimension from raw sums, with the subtraction done in exact rational arithmetic: q - s^2/n
-    loses mean^2/var digits to cancellation when it is evaluated in doubles (rats alpha_c: mean 242, sd 2.7 -> 4 digits); evaluated
-    exactly, the only error left is the rounding already inside the raw sums themselves."""
-    from fractions import Fraction
+    """(mean, M2 = sum (x - mean)^2) per dimension from raw sums with the one cancelling subtraction, q - s^2/n, carried in
+    double-double: evaluated in plain doubles it loses mean^2/var digits (rats alpha_c: mean 242, sd 2.7 -> 4 digits); this way the
+    only error left is the rounding already inside the raw sums themselves.  Non-finite sums give NaN / inf moments (no exception)."""
     if n <= 0:
         return np.zeros_like(s), np.zeros_like(s)
-    nn = Fraction(int(n))
-    mean = np.array([float(Fraction(float(v)) / nn) for v in s])
-    m2 = np.array([float(Fraction(float(b)) - Fraction(float(a)) ** 2 / nn) for a, b in zip(s, q)])
-    return mean, np.maximum(m2, 0.0)
+    with np.errstate(all="ignore"):
+        p, pe = _two_prod(s, s)                 # s^2 = p + pe
+        qh = p / n
+        t, te = _two_prod(qh, np.full_like(qh, n))
+        r = (p - t) - te                        # p = qh * n + r  (p - t is exact: qh * n is within an ulp of p)
+        ql = (r + pe) / n
+        m2 = (q - qh) - ql
+        m2 = np.where(m2 < 0.0, 0.0, m2)
+        return s / n, m2
 
 
-def allreduce_summaries(local: Dict[str, np.ndarray], group=None, device=None) -> Dict[str, np.ndarray]:
-    """All-reduce of pooled summaries; `local` holds sum[D], sumsq[D], naccept, ntransitions, nsamples of this rank's chains.
-
-    Returns the global sums plus derived posterior moments (mean, var) and the acceptance rate.  The variance is NOT formed as
-    sumsq/n - mean^2 from the reduced raw sums: every rank turns its sums into (n_r, mean_r, M2_r) exactly (_local_moments) and
-    the ranks are combined by Chan's formula, M2 = sum_r M2_r + sum_r n_r (mean_r - mean)^2 — two SUM all-reduces of (2D + 3) and
-    D doubles.  Works without torch.distributed initialised (single process) — then it only derives the moments.
-    """
+def allreduce_moments(local: Dict[str, np.ndarray], group=None, device=None) -> Dict[str, np.ndarray]:
+    """Chan's merge of per-rank moments: `local` holds mean[D], m2[D], nsamples, naccept, ntransitions of this rank's chains.
+    Three SUM all-reduces — (nsamples, naccept, ntransitions), n_r mean_r, M2_r + n_r (mean_r - mean)^2 — every rank takes part in
+    all three whatever its values are.  Works without torch.distributed initialised (single process)."""
     import torch
     import torch.distributed as dist
 
-    d = int(np.asarray(local["sum"]).size)
-    s_l = np.asarray(local["sum"], dtype=np.float64).ravel(); q_l = np.asarray(local["sumsq"], dtype=np.float64).ravel()
+    mean_l = np.asarray(local["mean"], dtype=np.float64).ravel(); m2_l = np.asarray(local["m2"], dtype=np.float64).ravel()
     n_l = float(local["nsamples"])
     live = dist.is_available() and dist.is_initialized()
     if live and device is None:
@@ -55,31 +68,63 @@ def allreduce_summaries(local: Dict[str, np.ndarray], group=None, device=None) -
     def reduce_sum(buf: np.ndarray) -> np.ndarray:
         if not live:
             return buf
-        t = torch.from_numpy(buf).to(device)
+        t = torch.from_numpy(np.ascontiguousarray(buf)).to(device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return t.cpu().numpy()
 
-    buf = reduce_sum(np.concatenate([s_l, q_l, np.array([local["naccept"], local["ntransitions"], n_l], dtype=np.float64)]))
-    s, q = buf[:d], buf[d:2 * d]
-    nacc, ntr, ns = buf[2 * d], buf[2 * d + 1], buf[2 * d + 2]
-    out = {"sum": s, "sumsq": q, "naccept": nacc, "ntransitions": ntr, "nsamples": ns}
-    if ns > 0:
-        from fractions import Fraction
-        mean = np.array([float(Fraction(float(v)) / Fraction(int(ns))) for v in s])
-        mean_l, m2_l = _local_moments(s_l, q_l, n_l)
+    cnt = reduce_sum(np.array([n_l, float(local["naccept"]), float(local["ntransitions"])], dtype=np.float64))   # (exact below 2^53)
+    ns, nacc, ntr = cnt
+    with np.errstate(all="ignore"):
+        wsum = reduce_sum(n_l * mean_l)
+        mean = wsum / ns if ns > 0 else np.zeros_like(wsum)
         m2 = reduce_sum(m2_l + n_l * (mean_l - mean) ** 2)          # Chan: within-rank + between-rank sums of squares
+    out = {"naccept": nacc, "ntransitions": ntr, "nsamples": ns}
+    if ns > 0:
         out["mean"] = mean
+        out["m2"] = m2
         out["var"] = m2 / ns
     if ntr > 0:
         out["acceptance"] = nacc / ntr
     return out
 
 
+def allreduce_summaries(local: Dict[str, np.ndarray], group=None, device=None) -> Dict[str, np.ndarray]:
+    """The same exchange for a caller that holds pooled RAW sums: `local` = sum[D], sumsq[D], naccept, ntransitions, nsamples of this
+    rank's chains.  Returns the global sums plus the posterior moments (mean, var) and the acceptance rate; the variance comes from
+    per-rank (n, mean, M2) (_local_moments) merged by allreduce_moments, never from sumsq/n - mean^2 of the reduced sums."""
+    import torch
+    import torch.distributed as dist
+
+    s_l = np.asarray(local["sum"], dtype=np.float64).ravel(); q_l = np.asarray(local["sumsq"], dtype=np.float64).ravel()
+    n_l = float(local["nsamples"])
+    mean_l, m2_l = _local_moments(s_l, q_l, n_l)
+    out = allreduce_moments({"mean": mean_l, "m2": m2_l, "nsamples": n_l, "naccept": local["naccept"],
+                             "ntransitions": local["ntransitions"]}, group=group, device=device)
+    live = dist.is_available() and dist.is_initialized()
+    if live:
+        if device is None:
+            device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.from_numpy(np.concatenate([s_l, q_l])).to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        sq = t.cpu().numpy()
+    else:
+        sq = np.concatenate([s_l, q_l])
+    d = s_l.size
+    out["sum"], out["sumsq"] = sq[:d], sq[d:]
+    return out
+
+
 def gather_engine_summaries(engine, group=None) -> Dict[str, np.ndarray]:
-    """Pooled summaries of this rank's Engine, all-reduced over the job's ranks."""
+    """Pooled summaries of this rank's Engine merged over the job's ranks: the rank's moments come from the device
+    (Engine.pooled_moments -> klara_gather_moments with no communicator), the merge is allreduce_moments."""
     with_sums = bool(engine.monitor & 0x4)
-    s, q, nacc, ntr, nsaved = engine.pooled_summaries(with_sums=with_sums)
-    d = engine.ndims
-    local = {"sum": s if s is not None else np.zeros(d), "sumsq": q if q is not None else np.zeros(d),
-             "naccept": nacc, "ntransitions": ntr, "nsamples": nsaved * engine.nchains if with_sums else 0}
-    return allreduce_summaries(local, group=group)
+    if with_sums:
+        mean, m2, ns, nacc, ntr, _ = engine.pooled_moments()
+    else:
+        _, _, nacc, ntr, _ = engine.pooled_summaries(with_sums=False)
+        mean = m2 = np.zeros(engine.ndims); ns = 0
+    out = allreduce_moments({"mean": mean, "m2": m2, "nsamples": ns, "naccept": nacc, "ntransitions": ntr}, group=group)
+    if "mean" in out:                       # the raw sums a caller of the previous form reads, derived (the moments are the product)
+        out["sum"] = out["mean"] * out["nsamples"]
+        out["sumsq"] = out["m2"] + out["nsamples"] * out["mean"] ** 2
+    return out

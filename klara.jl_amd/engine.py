@@ -356,6 +356,15 @@ class Engine:
             C.byref(na), C.byref(nt), C.byref(ns)), "klara_get_pooled_summaries")
         return s, q, int(na.value), int(nt.value), int(ns.value)
 
+    def pooled_moments(self, comm=None):
+        """(mean[D], M2[D], nsamples, naccept, ntransitions, nchains) over this handle's chains — or, with a klara_comm handle,
+        over every rank's — formed on the device without the cancellation of sumsq/n - mean^2 (klara_gather_moments)."""
+        mean = np.empty(self.ndims); m2 = np.empty(self.ndims)
+        ns, na, nt, nc = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        L.check(self._lib.klara_gather_moments(self._h, comm, mean.ctypes.data, m2.ctypes.data, C.byref(ns), C.byref(na), C.byref(nt),
+                                               C.byref(nc)), "klara_gather_moments")
+        return mean, m2, int(ns.value), int(na.value), int(nt.value), int(nc.value)
+
     def chain(self, local_chain: int) -> np.ndarray:
         """One chain's saved values in Klara's NState layout: (ndims, nsaved), column-major."""
         n = C.c_int64(0)
