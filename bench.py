@@ -159,17 +159,28 @@ def main():
                     help="logic test only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver would
+        # (one process per GPU, rendezvous on 127.0.0.1), hand their output through and leave with their exit code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch it with --nproc-per-node {args.gpus} "
+                         "(or without a launcher: it starts its own ranks)")
+
     import numpy as np
     import torch
     import klara_jl_amd as K
     from klara_jl_amd import _lib as L
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the transition path has no CPU fallback)")
     if args.same_device:

@@ -145,6 +145,110 @@ def test_two_engine_shards_on_one_device_over_gloo():
     ref.close()
 
 
+RATS_CHAINS, RATS_STEPS, RATS_BURNIN = 2051, 300, 100
+
+
+def _rats_engine(K, L, nchains, offset):
+    """HMC on the hierarchical rats model (cfg 5's shape): alpha_c has mean ~242 and sd ~2.7 — the dimension on which q/n - mean^2 loses 4 digits"""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import cases
+    t = cases.rats_target()
+    x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(12).standard_normal((RATS_CHAINS, t.ndims))
+    eng = K.Engine(sampler=L.SAMPLER_HMC, target=t, nchains=nchains, nsteps=RATS_STEPS, burnin=RATS_BURNIN, leapstep=0.02, nleaps=8,
+                   chain_offset=offset, monitor=L.MON_SUMMARIES, seed=5)
+    eng.set_state(x0[offset:offset + nchains])
+    return eng
+
+
+def _exact_pooled_moments(s, q, nsaved):
+    """pooled mean and variance from per-chain raw sums in exact rational arithmetic (the yardstick: what the sums hold)"""
+    from fractions import Fraction
+    n = Fraction(int(nsaved) * s.shape[0])
+    mean, var = [], []
+    for j in range(s.shape[1]):
+        S = sum(Fraction(float(v)) for v in s[:, j]); Q = sum(Fraction(float(v)) for v in q[:, j])
+        m = S / n
+        mean.append(float(m)); var.append(float(Q / n - m * m))
+    return np.array(mean), np.array(var)
+
+
+def _gloo_rats_rank_main(rank, world, port, out_q):
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    try:
+        import torch.distributed as dist
+        import klara_jl_amd as K
+        from klara_jl_amd import _lib as L
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        offset, n = K.shard_chains(RATS_CHAINS, rank, world)
+        eng = _rats_engine(K, L, n, offset)
+        eng.run(RATS_STEPS)
+        out = K.gather_engine_summaries(eng)                # device-formed (n, mean, M2) of the shard, Chan's merge over gloo
+        s, q, nsaved = eng.chain_sums()
+        out_q.put((rank, offset, n, out, s, q, nsaved, None))
+        eng.close(); dist.destroy_process_group()
+    except Exception as exc:
+        out_q.put((rank, 0, 0, None, None, None, 0, repr(exc)))
+
+
+def test_pooled_moments_without_cancellation_one_handle_rccl_single_rank_and_two_shards(klib):
+    """the pooled variance of the rats model's alpha_c (mean 242, sd 2.7) from the C path — klara_gather_moments:
+    per-chain (n, mean, M2) on the device with q - s^2/n in double-double, Chan's merge over chains and blocks, and over ranks either by three
+    RCCL all-reduces (comm) or by the caller's transport (comm = NULL + distributed.allreduce_moments) — within 1e-12 of the variance computed
+    in exact rational arithmetic from the per-chain sums, for one handle, through a one-rank RCCL communicator, and for two real engine shards
+    on one device merged over gloo."""
+    import socket
+    import klara_jl_amd as K
+    from klara_jl_amd import _lib as L
+    ref = _rats_engine(K, L, RATS_CHAINS, 0)
+    ref.run(RATS_STEPS)
+    s, q, nsaved = ref.chain_sums()
+    assert nsaved == RATS_STEPS - RATS_BURNIN
+    emean, evar = _exact_pooled_moments(s, q, nsaved)
+    D = ref.ndims
+    ac = D - 5                                              # alpha_c (theta = alpha_1, beta_1, ..., alpha_c, beta_c, log sigma_c, ...)
+    assert 230 < emean[ac] < 255 and evar[ac] < 100
+    mean, m2, ns, na, nt, nc = ref.pooled_moments()
+    assert (ns, nc, nt) == (nsaved * RATS_CHAINS, RATS_CHAINS, RATS_STEPS * RATS_CHAINS)
+    assert np.allclose(mean, emean, rtol=1e-14, atol=1e-16)
+    assert np.all(np.abs(m2 / ns - evar) <= 1e-12 * evar), np.max(np.abs(m2 / ns - evar) / evar)
+    ps, pq, pna, _, _ = ref.pooled_summaries()
+    assert na == pna
+    # through RCCL (one rank: the call sequence, the packing and the between-rank kernel), twice: a repeatable collective
+    uid = (C.c_uint8 * 128)()
+    L.check(klib.klara_comm_unique_id(uid), "comm_unique_id")
+    comm = C.c_void_p()
+    L.check(klib.klara_comm_init(C.byref(comm), 1, 0, uid, 0), "comm_init")
+    for _ in range(2):
+        cmean, cm2, cns, cna, cnt, cnc = ref.pooled_moments(comm)
+        assert (cns, cna, cnt, cnc) == (ns, na, nt, nc)
+        assert np.allclose(cmean, mean, rtol=1e-15, atol=0) and np.allclose(cm2, m2, rtol=1e-15, atol=0)
+    L.check(klib.klara_comm_destroy(comm), "comm_destroy")
+    ref.close()
+    # two shards of the same job on this device, merged over gloo
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_rats_rank_main, args=(r, 2, port, out_q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [out_q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    errs = [r[-1] for r in results if r[-1] is not None]
+    assert not errs, errs
+    for rank, offset, n, out, rs, rq, rnsaved, _ in results:
+        assert np.array_equal(rs, s[offset:offset + n]) and np.array_equal(rq, q[offset:offset + n]) and rnsaved == nsaved     # sharding changes no bit
+        assert out["nsamples"] == ns and out["naccept"] == na
+        assert np.allclose(out["mean"], emean, rtol=1e-14, atol=1e-16)
+        assert np.all(np.abs(out["var"] - evar) <= 1e-12 * evar), (rank, np.max(np.abs(out["var"] - evar) / evar))
+
+
 def test_bench_two_ranks_on_one_device_logic():
     """`bench.py --gpus 2` the way the driver launches it (python -m torch.distributed.run, one process per rank), on ONE device with the
     gloo backend (`--same-device`: RCCL refuses two ranks on one GPU) — the rank / shard / barrier / max-over-ranks / summary all-reduce
@@ -172,6 +276,26 @@ def test_bench_two_ranks_on_one_device_logic():
     assert d["roofline"]["bound"] == "valu" and "cpu_baseline" not in d
     assert len(d["config"]["per_rank_ms_per_step"]) == 2 and d["config"]["rank_time_max_over_min"] >= 1.0
     assert max(d["config"]["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"], rel=0.2)
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset — the form the driver uses for N = 1 — must not exit with a usage
+    message: it starts its ranks itself (torch.distributed.run, 127.0.0.1) and rank 0's JSON line comes back through it."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--reps", "2", "--backend", "gloo",
+                        "--same-device", "--no-extra", "--no-cpu-baseline", "--clock-warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and d["value"] > 0
 
 
 def test_bench_single_gpu_line_at_the_drivers_flags():
