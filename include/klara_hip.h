@@ -101,7 +101,8 @@ typedef enum klara_target {
      *   KLARA_USER_FN double klara_user_pair(double x0, double x1, int pair, int D, const double* data, long long ndata,
      *                                        double* g0, double* g1);
      * with logtarget(x) = sum over pairs P of klara_user_pair(x[2P], x[2P+1], P, ...) and (*g0, *g1) the pair's two partial derivatives
-     * (for the half pair of an odd D, x1 is 0 and *g1 is ignored).  Such a job runs on the few-lanes-per-chain kernels of the diagonal
+     * (for the half pair of an odd D, x1 is 0 and *g1 is ignored; the function is called for the real pairs only, 0 <= pair < ceil(D/2), so it may
+     * index `data` by pair or by coordinate).  Such a job runs on the few-lanes-per-chain kernels of the diagonal
      * Gaussian (layout kind 3: 8 / 16 / 32 lanes per chain, 17 <= D <= 512; MH, MALA, HMC with every tuner, the running sums and the
      * value / logtarget / gradlogtarget histories; klara_get_layout reports the summation order: a lane adds its pairs' terms in
      * ascending order, then the butterfly over the chain's lanes) instead of holding the whole vector in one lane: at D = 100 the

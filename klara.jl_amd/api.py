@@ -272,10 +272,13 @@ def mcvar_iid(chains: MuvChains) -> np.ndarray:
     return var / n
 
 
-def chain_mcvar(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, maxlag: int = 0) -> np.ndarray:
+def chain_mcvar(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, maxlag: Optional[int] = None) -> np.ndarray:
     """mcvar(s, Val{vtype}) for EVERY chain and dimension at once, computed on device over the stored history
     (stats/variance/mcvar.jl:5,35-41,75-105,137-158) — or, for "bm" / "imse" / "ipse", from what a job with bm_batchlen / acov_maxlag
-    accumulated while sampling.  Returns (nchains x D); vtype in {"iid", "bm", "imse", "ipse"}."""
+    accumulated while sampling.  Returns (nchains x D); vtype in {"iid", "bm", "imse", "ipse"}.
+    `maxlag` left at its default means the reference's default (0 = n - 1 lags, mcvar.jl:75) when the values are stored, and the job's own
+    window `acov_maxlag` when the job streams its autocovariances without a value history — the estimate is then TRUNCATED at that lag
+    (<= 31); an explicit maxlag other than the window is refused for such a job."""
     job = chains._job
     if vtype == "bm" and job.bm_batchlen == batchlen and not (job.engine.monitor & L.MON_HISTORY):
         return job.engine.chain_bm()[0]            # streaming batch means: no history was stored
@@ -285,17 +288,18 @@ def chain_mcvar(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, max
         # (mcvar.jl:75).  The streamed estimator is therefore only returned for the lag window it was built for — asked for
         # explicitly, maxlag == acov_maxlag — and anything else needs the stored values (a slowly mixing chain whose
         # Geyer sequence has not turned non-positive by lag 31 would be silently underestimated).
-        if maxlag != job.acov_maxlag:
+        if maxlag is not None and maxlag != job.acov_maxlag:
             raise ValueError(f"this job keeps streaming autocovariances up to lag {job.acov_maxlag} and no value history: "
                              f"mcvar(:{vtype}) is available for maxlag={job.acov_maxlag} only (asked for maxlag={maxlag}, where 0 means n - 1)")
         imse, ipse, _ = job.engine.chain_acov_mcvar(want=(vtype,))
         return imse if vtype == "imse" else ipse
+    maxlag = 0 if maxlag is None else maxlag
     if vtype == "ipse":
         return job.engine.chain_mcvar_ipse(maxlag)
     return job.engine.chain_mcvar(batchlen, maxlag, want=(vtype,))[{"iid": 0, "bm": 1, "imse": 2}[vtype]]
 
 
-def _mcvar_pair(chains: MuvChains, vtype: str, batchlen: int, maxlag: int):
+def _mcvar_pair(chains: MuvChains, vtype: str, batchlen: int, maxlag: Optional[int]):
     """(mcvar_iid, mcvar_vtype) of every chain and dimension; vtype in {"bm", "imse", "ipse"}."""
     if vtype not in ("bm", "imse", "ipse"):
         raise ValueError(f"vtype must be 'bm', 'imse' or 'ipse', not {vtype!r}")
@@ -303,13 +307,13 @@ def _mcvar_pair(chains: MuvChains, vtype: str, batchlen: int, maxlag: int):
     return (chain_mcvar(chains, "iid") if has_history else mcvar_iid(chains)), chain_mcvar(chains, vtype, batchlen, maxlag)
 
 
-def chain_ess(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, maxlag: int = 0) -> np.ndarray:
+def chain_ess(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, maxlag: Optional[int] = None) -> np.ndarray:
     """ess(s, vtype) = n * mcvar_iid / mcvar_vtype (stats/convergence/ess.jl:3) for every chain and dimension."""
     iid, v = _mcvar_pair(chains, vtype, batchlen, maxlag)
     return chains.n * iid / v
 
 
-def chain_iact(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, maxlag: int = 0) -> np.ndarray:
+def chain_iact(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, maxlag: Optional[int] = None) -> np.ndarray:
     """iact(s, vtype) = mcvar_vtype / mcvar_iid (stats/convergence/iact.jl:3) for every chain and dimension."""
     iid, v = _mcvar_pair(chains, vtype, batchlen, maxlag)
     return v / iid

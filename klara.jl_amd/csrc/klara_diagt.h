@@ -413,9 +413,11 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
         // user pair closure at the lane's pair pi: -term and the two partial derivatives; padding pairs / the missing half of an odd
         // D's last pair contribute exact zeros (their values, normals and derivatives stay 0 through every update)
         const auto user_pair = [&](int pi, double a, double b, double& nt, double& g0, double& g1) {
-            double u0 = 0.0, u1 = 0.0;
-            const double u = KLARA_PAIR_CALL(a, b, pi * Q + cx.q, &u0, &u1);
+            // (the closure is CALLED for real pairs only, pair < ceil(D/2): it may index its data block by pair or by coordinate —
+            // the oracle's ko_pair_eval makes exactly these calls.  Only a lane's last pair can be padding.)
+            double u0 = 0.0, u1 = 0.0, u = 0.0;
             const bool ok0 = pi < NP - 1 || cx.last_ok, ok1 = pi < NP - 1 || cx.last_full;
+            if (ok0) u = KLARA_PAIR_CALL(a, b, pi * Q + cx.q, &u0, &u1);
             nt = ok0 ? -u : 0.0; g0 = ok0 ? u0 : 0.0; g1 = ok1 ? u1 : 0.0;
         };
         const auto grad_of = [&](const double (&v)[E], double (&out)[E]) {
@@ -862,9 +864,9 @@ __global__ __launch_bounds__(256) void k_diagt_init(const KParams p, int needgra
     if constexpr (USERPAIR) {
 #pragma unroll
         for (int pi = 0; pi < NP; ++pi) {
-            double u0 = 0.0, u1 = 0.0;
-            const double u = KLARA_PAIR_CALL(x[2 * pi], x[2 * pi + 1], pi * Q + cx.q, &u0, &u1);
+            double u0 = 0.0, u1 = 0.0, u = 0.0;
             const bool ok0 = pi < NP - 1 || cx.last_ok, ok1 = pi < NP - 1 || cx.last_full;
+            if (ok0) u = KLARA_PAIR_CALL(x[2 * pi], x[2 * pi + 1], pi * Q + cx.q, &u0, &u1);       // real pairs only (see k_diagt)
             red[0] = red[0] + (ok0 ? -u : 0.0);
             g[2 * pi] = ok0 ? u0 : 0.0; g[2 * pi + 1] = ok1 ? u1 : 0.0;
             bad = bad || !kfinite(g[2 * pi]) || !kfinite(g[2 * pi + 1]);

@@ -177,6 +177,18 @@ KLARA_USER_FN double klara_user_pair(double x0, double x1, int pair, int D, cons
     return -(x0 * x0 + x1 * x1);
 }
 """
+SRC_PAIR_INDEXED = r"""
+/* lt = -sum_i w_i x_i^2 with w = data[0 .. D): the closure indexes its data block BY COORDINATE (ndata = D exactly), which is only safe
+ * because it is called for real pairs alone, pair < ceil(D/2) (ADVICE r3: the kernels used to call it for the padding pairs of a lane too,
+ * pair up to NP*Q - 1, and mask the result).  A call outside that range stops the kernel (and the host build) at once. */
+KLARA_USER_FN double klara_user_pair(double x0, double x1, int pair, int D, const double* data, long long ndata, double* g0, double* g1)
+{
+    if (pair < 0 || 2 * pair >= D || 2 * pair >= ndata) __builtin_trap();
+    const double w0 = data[2 * pair], w1 = 2 * pair + 1 < D ? data[2 * pair + 1] : 0.0;
+    *g0 = -2.0 * (w0 * x0); *g1 = -2.0 * (w1 * x1);
+    return -(w0 * (x0 * x0)) - w1 * (x1 * x1);
+}
+"""
 SRC_PAIR_QUARTIC = r"""
 /* non-Gaussian, coupled within the pair: -(x0^2/2 + c x0^4) - (x1^2/2 + c x1^4) - k/2 (x1 - x0)^2, data = [c, k]; the half pair of
  * an odd D (2 pair + 1 == D) has no second coordinate */
@@ -523,6 +535,12 @@ def make_case(name):
         c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget.pairwise(300, SRC_PAIR_QUARTIC, [0.05, 0.3]), nchains=19, nsteps=120, burnin=100,
                  driftstep=0.02, tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.574, period=20,
                  x0=0.4 * np.random.default_rng(7).standard_normal((19, 300)))
+    elif name == "pair_indexed_mala_d100":     # data indexed by coordinate: D = 100 on 8 lanes has padding pairs 50..55
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget.pairwise(100, SRC_PAIR_INDEXED, np.linspace(0.5, 2.0, 100)), nchains=67, nsteps=40, burnin=5,
+                 driftstep=0.05)
+    elif name == "pair_indexed_hmc_d37":       # odd D: a half pair, and padding pairs 19..23
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget.pairwise(37, SRC_PAIR_INDEXED, np.linspace(0.5, 2.0, 37)), nchains=35, nsteps=30, burnin=5,
+                 leapstep=0.1, nleaps=5)
     elif name == "custom_quartic_slice_d7":
         c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget(7, SRC_QUARTIC_CHAIN, [0.1, 0.4]), nchains=66, nsteps=12, burnin=2,
                  slice_widths=np.full(7, 1.5))
@@ -551,7 +569,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "custom_quartic_mala_d64", "custom_quartic_mala_d100", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh",
              "sparse_mala_d100", "sparse_mala_d100_small_step", "sparse_mh_d100", "sparse_mala_mvnormal_d30",
              "pair_negdot_mala_d100", "pair_negdot_mala_d100_big_step", "pair_quartic_hmc_d50_tuned", "pair_banana_mh_d33",
-             "pair_banana_hmc_d100_dualavg", "pair_quartic_mala_d300_pooled",
+             "pair_banana_hmc_d100_dualavg", "pair_quartic_mala_d300_pooled", "pair_indexed_mala_d100", "pair_indexed_hmc_d37",
              "staged_negdot_mala_d100_big_step", "staged_quartic_mh_d33_thinned", "staged_quartic_slice_d40", "staged_quartic_hmc_d200_dualavg",
              "staged_quartic_mala_d70_pooled", "staged_normal_normal_mala_d48", "staged_quartic_hmc_d256_tuned"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)

@@ -1049,6 +1049,23 @@ def test_streaming_autocovariance_estimators(name, maxlag):
     twin.close(); eng.close()
 
 
+def test_streamed_job_ess_default_uses_the_jobs_own_lag_window():
+    """chain_ess / chain_iact / chain_mcvar(:imse | :ipse) with maxlag left at its default on a job that streams its autocovariances and
+    stores no values use the job's own window (acov_maxlag, a documented truncation) instead of raising; an explicit other maxlag is refused."""
+    p = K.BasicContMuvParameter("p", logtarget=K.GaussDiagTarget.negdot(3))
+    job = K.BasicMCJob(K.likelihood_model(p, False), K.MH(np.full(3, 0.6)), K.BasicMCRange(nsteps=1100, burnin=100), {"p": np.zeros((70, 3))},
+                       outopts={"destination": "none"}, seed=20260927, acov_maxlag=12)
+    K.run(job)
+    chain = K.output(job)
+    ess, iact, imse = K.chain_ess(chain), K.chain_iact(chain, "ipse"), K.chain_mcvar(chain, "imse")
+    assert np.array_equal(ess, K.chain_ess(chain, maxlag=12)) and np.array_equal(iact, K.chain_iact(chain, "ipse", maxlag=12))
+    assert np.array_equal(imse, K.chain_mcvar(chain, "imse", maxlag=12)) and np.all(np.isfinite(ess)) and np.all(ess < 1000) and np.all(iact > 1.0)
+    for bad in (0, 5, 31):
+        with pytest.raises(ValueError, match="maxlag=12 only"):
+            K.chain_ess(chain, maxlag=bad)
+    job.close()
+
+
 def test_iostream_sink_streams_with_bounded_memory(tmp_path):
     """:destination => :iostream with :flush (jobs.jl:17-29): the sink writes while the job runs — the device holds a ring of
     outopts chunk = 7 saved steps — and the files equal the ones written in one go from a full history."""
