@@ -44,6 +44,31 @@
 #include "../klara.jl_amd/csrc/detmath.h"
 
 #define KO_MAXD 1024
+
+/* LITERAL MODE (VERDICT r3 item 5 / ADVICE r3): ko_set_literal(1) — or KO_LITERAL=1 in the environment when the library is loaded —
+ * takes back the deliberate deviations from the literal Julia arithmetic that the shipped oracle shares with the kernels (DESIGN.md
+ * section 2 (2), (6), (7)): the leapfrog runs as samplers.jl:130-133 writes it (four unmerged, unfused updates per step), MALA's
+ * correction terms are 0.5*(abs2(.)/step) (MALA.jl:90,92), and the logistic rows take log(1+exp(Xp)) and 1/(1+exp(-Xp)) from two
+ * exponentials (swiss/MALA/analytical.jl:13,17).  Used by tests/test_literal_arithmetic.py alone, to MEASURE how far the shipped
+ * arithmetic is from the literal one; the kernels are compared with the shipped mode. */
+static int ko_literal = -1;
+static int ko_is_literal(void)
+{
+    if (ko_literal < 0) { const char* e = getenv("KO_LITERAL"); ko_literal = (e && e[0] == '1') ? 1 : 0; }
+    return ko_literal;
+}
+void ko_set_literal(int on) { ko_literal = on ? 1 : 0; }
+int ko_get_literal(void) { return ko_is_literal(); }
+/* the data row's pair (log(1+exp(xp)), 1/(1+exp(-xp))): shipped = one exponential (detmath.h), literal = the example's two */
+static void ko_row_softplus_logistic(double xp, double* sp, double* lg)
+{
+    if (ko_is_literal()) {
+        *sp = kd_log(1.0 + kd_exp(xp));                                  /* analytical.jl:13 log.(1+exp.(Xp)) */
+        *lg = 1.0 / (1.0 + kd_exp(-xp));                                 /* analytical.jl:17 1./(1+exp.(-Xp)) */
+    } else {
+        kd_softplus_logistic_rows(xp, sp, lg);
+    }
+}
 #define KO_SLICE_ATT_BITS 14
 #define KO_SLICE_MAX_ATT ((1 << KO_SLICE_ATT_BITS) - 1)
 #define KO_INIT_TRANSITION ((((uint64_t)1) << 40) - 1)
@@ -179,7 +204,7 @@ static void ko_logit_eval(const ko_target_ctx* c, const double* p, double* lt, d
             double xp = 0.0;
             for (int k = 0; k < D; ++k) xp = kd_fma(row[k], p[k], xp);
             double sp, lg;
-            kd_softplus_logistic_rows(xp, &sp, &lg);
+            ko_row_softplus_logistic(xp, &sp, &lg);
             if (lt) { dotxy1 = dotxy1 + xp * d->logit_y[r]; slog1 = slog1 + sp; }
             if (g) { const double res = d->logit_y[r] - lg; for (int k = 0; k < D; ++k) g1[k] = kd_fma(row[k], res, g1[k]); }
         }
@@ -199,7 +224,7 @@ static void ko_logit_eval(const ko_target_ctx* c, const double* p, double* lt, d
         double xp = 0.0;
         for (int k = 0; k < D; ++k) xp = kd_fma(row[k], p[k], xp);            /* Xp = v[2]*p        */
         double sp, lg;                                                          /* log(1+exp(Xp)), 1/(1+exp(-Xp)) from one */
-        kd_softplus_logistic_rows(xp, &sp, &lg);                                     /* exponential (detmath.h): same value, no overflow */
+        ko_row_softplus_logistic(xp, &sp, &lg);                                     /* exponential (detmath.h): same value, no overflow */
         if (lt) {
             pdot[q] = pdot[q] + xp * d->logit_y[r];                             /* dot(Xp, v[3])      */
             plog[q] = plog[q] + sp;                                             /* sum(log(1+exp(Xp)))*/
@@ -467,12 +492,13 @@ static int ko_mala(const ko_target_ctx* c, uint64_t chain, uint64_t t, double h,
     for (int i = 0; i < D; ++i) xp[i] = mu[i] + sq * z[i];              /* :84 */
     const double ltp = ko_uptograd(c, xp, gp, scratch);                  /* :86 */
     double ratio = ltp - *lt;                                            /* :88 */
-    for (int i = 0; i < D; ++i) { const double q = mu[i] - xp[i]; s1[i] = (q * q) * half_inv_h; }
+    const int literal = ko_is_literal();
+    for (int i = 0; i < D; ++i) { const double q = mu[i] - xp[i]; s1[i] = literal ? 0.5 * ((q * q) / h) : (q * q) * half_inv_h; }
     ratio += ko_reduce(c->L, s1, D);                                     /* :90 */
     for (int i = 0; i < D; ++i) {
         const double mup = xp[i] + halfh * gp[i];                        /* :91 */
         const double q = mup - x[i];
-        s2[i] = (q * q) * half_inv_h;
+        s2[i] = literal ? 0.5 * ((q * q) / h) : (q * q) * half_inv_h;
     }
     ratio -= ko_reduce(c->L, s2, D);                                     /* :92 */
     int acc = ratio > 0.0;                                               /* :94 */
@@ -503,12 +529,21 @@ static int ko_hmc(const ko_target_ctx* c, uint64_t chain, uint64_t t, double eps
      * (samplers.jl:122-134: p = p + eps/2 g; x = x + eps p; g = grad(x); p = p + eps/2 g, each an unfused a + b*c) in its merged
      * form — the closing half-kick of step l and the opening half-kick of step l + 1 use the same gradient and are ONE update
      * p += eps g, and every update is one fma.  The same trajectory in exact arithmetic; <= 1 ulp per update from the literal form. */
+    if (ko_is_literal()) {
+        for (int64_t l = 0; l < nleaps; ++l) {                           /* :146-155, leapfrog! as written */
+            for (int i = 0; i < D; ++i) p[i] = p[i] + halfe * gp[i];     /* samplers.jl:130 */
+            for (int i = 0; i < D; ++i) xp[i] = xp[i] + eps * p[i];      /* samplers.jl:131 */
+            ko_gradlogtarget(c, xp, gp);                                 /* samplers.jl:132 */
+            for (int i = 0; i < D; ++i) p[i] = p[i] + halfe * gp[i];     /* samplers.jl:133 */
+        }
+    } else {
     for (int i = 0; i < D; ++i) p[i] = kd_fma(halfe, gp[i], p[i]);       /* samplers.jl:130 of the first step */
     for (int64_t l = 0; l < nleaps; ++l) {                               /* :146-155 */
         for (int i = 0; i < D; ++i) xp[i] = kd_fma(eps, p[i], xp[i]);    /* samplers.jl:131 */
         ko_gradlogtarget(c, xp, gp);                                     /* samplers.jl:132 */
         const double kf = l + 1 < nleaps ? eps : halfe;                  /* :133 of this step (+ :130 of the next) */
         for (int i = 0; i < D; ++i) p[i] = kd_fma(kf, gp[i], p[i]);
+    }
     }
     double ltp;                                                          /* :157 logtarget!(x') */
     if (d->target == KLARA_TARGET_GAUSS_DENSE) ltp = ko_dense_lt_from_grad(c, xp, gp, scratch);

@@ -63,6 +63,10 @@ def load() -> C.CDLL:
     lib.ko_set_custom_target.restype = None
     lib.ko_set_custom_pair_target.argtypes = [vp]
     lib.ko_set_custom_pair_target.restype = None
+    lib.ko_set_literal.argtypes = [C.c_int]        # literal Julia arithmetic (tests/test_literal_arithmetic.py only)
+    lib.ko_set_literal.restype = None
+    lib.ko_get_literal.argtypes = []
+    lib.ko_get_literal.restype = C.c_int
     for name in ("ko_logistic",):
         getattr(lib, name).argtypes = [C.c_double] * 5
         getattr(lib, name).restype = C.c_double
