@@ -194,19 +194,24 @@ __device__ __forceinline__ void kd_tables_to_lds()
 #define KD_EXPTAB(i) kd_exptab_host[i]
 #endif
 
-KD_FN double kd_log_u01(double x)
+/* The evaluation is split at its table read — reduce (bits -> bin, exponent, reduced argument), the gather, finish — so that a caller
+ * with several independent arguments (the data rows of the logistic targets, klara_kernels.h) can issue all the gathers of a batch before the
+ * first finish; kd_log_u01 itself is the three in sequence, so every caller computes the same bits. */
+KD_FN void kd_log_u01_reduce(double x, uint32_t* i, int* k, double* z)
+{
+    const uint64_t ux = kd_d2u(x);
+    const uint32_t hx = (uint32_t)(ux >> 32);
+    const uint32_t tmp = hx - 0x3fe60000u;
+    *i = (tmp >> 13) & 127u;
+    *k = (int32_t)tmp >> 20;                              /* arithmetic shift: floor */
+    const uint32_t hz = hx - (tmp & 0xfff00000u);
+    *z = kd_u2d(((uint64_t)hz << 32) | (ux & 0xffffffffull));
+}
+KD_FN double kd_log_u01_finish(double z, int k, double invc, double logc)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;  /* ln2_hi: 32 trailing zero bits */
     const double B0 = 0x1.5555555555555p-2, B1 = -0.25, B2 = 0x1.999999999999ap-3, B3 = -0x1.5555555555555p-3,
                  B4 = 0x1.2492492492492p-3, B5 = -0.125;
-    const uint64_t ux = kd_d2u(x);
-    const uint32_t hx = (uint32_t)(ux >> 32);
-    const uint32_t tmp = hx - 0x3fe60000u;
-    const uint32_t i = (tmp >> 13) & 127u;
-    const int k = (int32_t)tmp >> 20;                     /* arithmetic shift: floor */
-    const uint32_t hz = hx - (tmp & 0xfff00000u);
-    const double z = kd_u2d(((uint64_t)hz << 32) | (ux & 0xffffffffull));
-    const double invc = KD_LOGTAB(2 * i), logc = KD_LOGTAB(2 * i + 1);
     const double r = kd_fma(z, invc, -1.0);
     const double dk = (double)k;
     const double w = kd_fma(dk, ln2_hi, logc);            /* dk*ln2_hi exact */
@@ -215,6 +220,12 @@ KD_FN double kd_log_u01(double x)
     const double r2 = r * r;
     const double q = kd_fma(r2, kd_fma(r2, kd_fma(r, B5, B4), kd_fma(r, B3, B2)), kd_fma(r, B1, B0));
     return hi + kd_fma(r * r2, q, kd_fma(r2, -0.5, lo));
+}
+KD_FN double kd_log_u01(double x)
+{
+    uint32_t i; int k; double z;
+    kd_log_u01_reduce(x, &i, &k, &z);
+    return kd_log_u01_finish(z, k, KD_LOGTAB(2 * i), KD_LOGTAB(2 * i + 1));
 }
 
 /* ---------------------------------------------------------------- exp */
@@ -253,23 +264,40 @@ KD_FN double kd_exp(double x)
  * bits for a <= 708 — without what that range does not need: no overflow side, the power of two is added to the exponent field
  * (results are normal numbers, so this equals the two exact multiplications of kd_exp), and beyond 708, where the result would be
  * subnormal, it is 0.  NaN gives 0; the caller passes NaN through itself. */
-KD_FN double kd_exp_neg(double a)
+/* (split at the table read like kd_log_u01: reduce, gather, finish) */
+KD_FN void kd_exp_neg_reduce(double a, int* k, double* r)
 {
-    const double C2 = 0.5, C3 = 0x1.5555555555555p-3, C4 = 0x1.5555555555555p-5, C5 = 0x1.1111111111111p-7;
     /* max(-a, -709): one instruction; a NaN argument gives -709 as well (fmax returns the other operand), which keeps the
      * conversion defined.  -a <= 0 here, so the rounding offset of kd_exp is the constant -1/2 (at -a = +-0 both offsets
      * truncate to k = 0). */
     const double xc = __builtin_fmax(-a, -709.0);
-    const int k = (int)(KD_INVLN2N * xc + -0.5);
-    const double dk = (double)k;
-    const double r = kd_fma(dk, -KD_LN2N_LO, kd_fma(dk, -KD_LN2N_HI, xc));
-    const int idx = k & 127, e = k >> 7;
-    const double th = KD_EXPTAB(2 * idx), tl = KD_EXPTAB(2 * idx + 1);
+    *k = (int)(KD_INVLN2N * xc + -0.5);
+    const double dk = (double)*k;
+    *r = kd_fma(dk, -KD_LN2N_LO, kd_fma(dk, -KD_LN2N_HI, xc));
+}
+KD_FN double kd_exp_neg_poly(double r)                 /* p(r) = r + r^2/2 + ... + r^5/120: needs no table value */
+{
+    const double C2 = 0.5, C3 = 0x1.5555555555555p-3, C4 = 0x1.5555555555555p-5, C5 = 0x1.1111111111111p-7;
     const double r2 = r * r;
-    const double p = kd_fma(r2 * r2, kd_fma(r, C5, C4), kd_fma(r2, kd_fma(r, C3, C2), r));
+    return kd_fma(r2 * r2, kd_fma(r, C5, C4), kd_fma(r2, kd_fma(r, C3, C2), r));
+}
+KD_FN double kd_exp_neg_combine(double a, int k, double p, double th, double tl)
+{
+    const int e = k >> 7;
     const double y = th + kd_fma(th, p, tl);
     const double res = kd_u2d(kd_d2u(y) + ((uint64_t)(int64_t)e << 52));
     return a <= 708.0 ? res : 0.0;
+}
+KD_FN double kd_exp_neg_finish(double a, int k, double r, double th, double tl)
+{
+    return kd_exp_neg_combine(a, k, kd_exp_neg_poly(r), th, tl);
+}
+KD_FN double kd_exp_neg(double a)
+{
+    int k; double r;
+    kd_exp_neg_reduce(a, &k, &r);
+    const int idx = k & 127;
+    return kd_exp_neg_finish(a, k, r, KD_EXPTAB(2 * idx), KD_EXPTAB(2 * idx + 1));
 }
 
 /* log of a positive number that may be +inf or NaN (1 + exp(.) of the logistic target): the table log plus the two

@@ -28,8 +28,20 @@
 #ifndef KLARA_E4_WAVES
 #define KLARA_E4_WAVES 2   // min waves per SIMD requested for the E=4 kernels (register budget 256)
 #endif
-#ifndef KLARA_LOGIT_UNROLL
-#define KLARA_LOGIT_UNROLL 4
+// data rows of the logistic target that go through the stages of an evaluation together (LogisticTarget::eval)
+#ifndef KLARA_LOGIT_BATCH
+#define KLARA_LOGIT_BATCH 5
+#endif
+#define KLARA_LOGIT_BATCH_OF(E) ((E) <= 4 ? KLARA_LOGIT_BATCH : ((KLARA_LOGIT_BATCH) > 3 ? 3 : KLARA_LOGIT_BATCH))
+template <int N> struct KInt { static constexpr int value = N; };
+// nothing is scheduled across a stage boundary of the batched row evaluation
+// (KLARA_PIN(v): the value is "produced" here as far as the compiler knows, so arithmetic on it cannot be hoisted above this point)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KLARA_SCHED_STAGE() __builtin_amdgcn_sched_barrier(0)
+#define KLARA_PIN(v) asm volatile("" : "+v"(v))
+#else
+#define KLARA_SCHED_STAGE() ((void)0)
+#define KLARA_PIN(v) ((void)0)
 #endif
 // Loops over a lane's E elements are fully unrolled (the element arrays are registers).  The run-time compiled closure kernels with
 // 256 elements per lane define this to "nounroll" (klara_jit.hip): unrolled, such a kernel takes half a minute to compile per mode
@@ -437,31 +449,78 @@ KLARA_PRAGMA_UNROLL_E
         // lane takes ndata / RS of them (a wave-uniform count: a scalar loop the compiler can unroll — the lane-dependent bound
         // `r < ndata` made it a divergent loop with exec-mask bookkeeping and register copies in every iteration) and the lanes
         // with rq < ndata % RS one more.
-        const auto row_of = [&](int r) {
-            double row[E];
+        // A BATCH of R rows, staged: every row is a chain row -> Xp -> exp (table gather) -> 1 + t -> log (table gather) -> division, i.e.
+        // three LDS round trips in a row, and written one row after the other the compiler emits exactly that — a wavefront then issues
+        // ~80 vector instructions per row between three exposed waits and relies on its SIMD's other wavefronts alone (VALU busy 0.76 at
+        // 4 wavefronts per SIMD, profiles/r3_pmc_kernels.json).  Here the R rows of a batch go through each stage together — all R row reads,
+        // all R exp gathers, all R log gathers are in flight before the first is consumed — and the accumulations run last, row by row in
+        // ascending order: the operations and the summation order of the one-row form, bit for bit (the oracle's ko_logit_eval).
+        const auto rows_of = [&](auto rtag, int r0, int stride) {
+            constexpr int R = decltype(rtag)::value;
+            double row[R][E], yr[R], xp[R], rr[R], th[R], tl[R], t[R], onept[R], z[R], invc[R], logc[R], sp[R], lg[R];
+            int kk[R], lk[R]; uint32_t li[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int r = r0 + j * stride;
 KLARA_PRAGMA_UNROLL_E
-            for (int e = 0; e < E; ++e) row[e] = sX[r * E + e];
-            double xp = 0.0;
-KLARA_PRAGMA_UNROLL_E
-            for (int e = 0; e < E; ++e) xp = kd_fma(row[e], x[e], xp);            // Xp = v[2]*p
-            const double yr = sy[r];
-            double sp, lg;
-            kd_softplus_logistic_rows(xp, &sp, &lg);                                   // log(1+exp(Xp)), 1/(1+exp(-Xp)): one exponential
-            if (WANT_LT) {
-                dotxy = dotxy + xp * yr;                                          // dot(Xp, v[3])
-                slog = slog + sp;                                                 // sum(log(1+exp(Xp)))
+                for (int e = 0; e < E; ++e) row[j][e] = sX[r * E + e];
+                yr[j] = sy[r];
             }
-            if (WANT_GRAD) {
-                const double res = yr - lg;                                       // v[3]-1./(1+exp(-Xp))
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                double a = 0.0;
 KLARA_PRAGMA_UNROLL_E
-                for (int e = 0; e < E; ++e) gacc[e] = kd_fma(row[e], res, gacc[e]);
+                for (int e = 0; e < E; ++e) a = kd_fma(row[j][e], x[e], a);       // Xp = v[2]*p
+                xp[j] = a;
+                kd_exp_neg_reduce(__builtin_fabs(a), &kk[j], &rr[j]);             // t = exp(-|Xp|): one exponential for both functions
+            }
+            KLARA_SCHED_STAGE();
+#pragma unroll
+            for (int j = 0; j < R; ++j) { const int idx = kk[j] & 127; th[j] = KD_EXPTAB(2 * idx); tl[j] = KD_EXPTAB(2 * idx + 1); }
+            KLARA_SCHED_STAGE();
+#pragma unroll
+            for (int j = 0; j < R; ++j) { KLARA_PIN(rr[j]); rr[j] = kd_exp_neg_poly(rr[j]); }   // (needs no table value: issued under the gathers)
+            KLARA_SCHED_STAGE();
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                t[j] = kd_exp_neg_combine(__builtin_fabs(xp[j]), kk[j], rr[j], th[j], tl[j]);
+                onept[j] = 1.0 + t[j];
+                kd_log_u01_reduce(onept[j], &li[j], &lk[j], &z[j]);
+            }
+            KLARA_SCHED_STAGE();
+#pragma unroll
+            for (int j = 0; j < R; ++j) { invc[j] = KD_LOGTAB(2 * li[j]); logc[j] = KD_LOGTAB(2 * li[j] + 1); }
+            KLARA_SCHED_STAGE();
+#pragma unroll
+            for (int j = 0; j < R; ++j) lg[j] = kd_div_unit_range(xp[j] >= 0.0 ? 1.0 : t[j], onept[j]);   // 1/(1+exp(-Xp)) (no table value either)
+            KLARA_SCHED_STAGE();
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const double l1p = kd_log_u01_finish(z[j], lk[j], invc[j], logc[j]);
+                sp[j] = (xp[j] > 0.0 ? xp[j] : 0.0) + l1p;                        // log(1+exp(Xp))
+            }
+            KLARA_SCHED_STAGE();
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (WANT_LT) {
+                    dotxy = dotxy + xp[j] * yr[j];                                // dot(Xp, v[3])
+                    slog = slog + sp[j];                                          // sum(log(1+exp(Xp)))
+                }
+                if (WANT_GRAD) {
+                    const double res = yr[j] - lg[j];                             // v[3]-1./(1+exp(-Xp))
+KLARA_PRAGMA_UNROLL_E
+                    for (int e = 0; e < E; ++e) gacc[e] = kd_fma(row[j][e], res, gacc[e]);
+                }
             }
         };
+        // The rows of a lane are r = rq, rq + RS, ...: every lane takes ndata / RS of them (a wave-uniform count: scalar loops) and the
+        // lanes with rq < ndata % RS one more.
+        constexpr int RB = KLARA_LOGIT_BATCH_OF(E);
         const int nfull = ndata / cx.RS, tail = ndata - nfull * cx.RS;
-        // (rows are independent until the accumulations: unrolling lets two rows' exp / log / division chains interleave)
-#pragma unroll KLARA_LOGIT_UNROLL
-        for (int it = 0; it < nfull; ++it) row_of(cx.rq + it * cx.RS);
-        if (cx.rq < tail) row_of(cx.rq + nfull * cx.RS);
+        const int nbat = nfull / RB;
+        for (int b = 0; b < nbat; ++b) rows_of(KInt<RB>(), cx.rq + b * RB * cx.RS, cx.RS);
+        for (int it = nbat * RB; it < nfull; ++it) rows_of(KInt<1>(), cx.rq + it * cx.RS, cx.RS);
+        if (cx.rq < tail) rows_of(KInt<1>(), cx.rq + nfull * cx.RS, cx.RS);
         if (cx.RS > 1) {
             double red[E + 2];
             red[0] = dotxy; red[1] = slog;
