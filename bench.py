@@ -436,7 +436,9 @@ def extra_measurements(K, L, n, stream):
     rate, ls, _ = timed_rate(e, nr, 1024, 2048)
     at = attrs_of(e, 32); e.close()
     ex["cfg1_readme_mh_1048576_replicas_transitions_per_s"] = rate
-    ex["cfg1_roofline"] = valu_roofline("k_transitions<0, 0, 2, 0, 1>", ls, attrs=at)
+    b1 = bud["cfg1"]           # (launch = the library's 32 transitions of the 1,048,576 chains: 16,384 wavefronts of 64 chains)
+    ex["cfg1_roofline"] = valu_roofline("k_transitions<0, 0, 2, 0, 1>", ls, attrs=at, budget=b1,
+                                        necessary_per_launch=b1["per_wave_transition"] * (nr // b1["chains_per_wave"]) * L.DEFAULT_STEPS_PER_LAUNCH)
 
     # -- HMC L=10 eps=0.1 on the README target (VALU) and on the dense target (FP64 MFMA; cfg 3)
     e = K.Engine(sampler=L.SAMPLER_HMC, target=neg, nchains=n, nsteps=10 ** 7, leapstep=0.1, nleaps=10, stream=stream, nstreams=1)
@@ -444,7 +446,9 @@ def extra_measurements(K, L, n, stream):
     rate, ls, _ = timed_rate(e, n, 32, 128)
     lay = e.layout(); at = attrs_of(e, 32); e.close()
     ex["hmc_iso_leapfrog_chain_per_s"] = rate * 10
-    ex["hmc_iso_roofline"] = valu_roofline(diagt_kernel_name(2, lay[1], lay[2], False, True, False), ls, grid=diagt_grid(n, lay[1]), attrs=at)
+    bh = bud["hmc_iso"]
+    ex["hmc_iso_roofline"] = valu_roofline(diagt_kernel_name(2, lay[1], lay[2], False, True, False), ls, grid=diagt_grid(n, lay[1]), attrs=at, budget=bh,
+                                           necessary_per_launch=bh["per_wave_transition"] * (n // bh["chains_per_wave"]) * L.DEFAULT_STEPS_PER_LAUNCH)
 
     e = K.Engine(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget.compound_symmetric(NDIMS, 0.5), nchains=n, nsteps=10 ** 7,
                  leapstep=0.1, nleaps=10, stream=stream)
@@ -478,7 +482,13 @@ def extra_measurements(K, L, n, stream):
     lay = e.layout(); at = attrs_of(e, 4); e.close()
     ex["slice_d100_transitions_per_s"] = rate
     ex["slice_d100_coordinate_updates_per_s"] = rate * NDIMS
-    ex["slice_d100_roofline"] = valu_roofline(f"k_diagt<3, {lay[2] // 2}, {lay[1]},", ls, attrs=at)
+    # the slice sampler's trip counts are data dependent: the algorithmic budget takes a chain's own mean probe counts on this target in
+    # stationarity (a seeded simulation of the procedure, scripts/instruction_budget.py slice_probe_counts); `frac_lockstep` prices what the 8
+    # chains of a wavefront, which share the loops, have to execute — the mean of the maximum over 8 chains
+    bs, bsl = bud["slice_d100"], bud["slice_d100_lockstep"]
+    ex["slice_d100_roofline"] = valu_roofline(f"k_diagt<3, {lay[2] // 2}, {lay[1]},", ls, attrs=at, budget=bs,
+                                              necessary_per_launch=bs["per_wave_transition"] * (n // bs["chains_per_wave"]) * 4)
+    ex["slice_d100_roofline"]["frac_lockstep"] = 4.0 * bsl["per_wave_transition"] * (n // bsl["chains_per_wave"]) * 4 / ls / (NSIMD * CLOCK_HZ)
 
     # -- the two data-model configurations of BASELINE.json at their per-GPU share (cfg 4: 262,144 / 8 chains of the swiss
     # logistic regression, MALA h = 0.1; cfg 5: 1,048,576 / 8 chains of the rats hierarchical model, HMC L = 32 with the
@@ -494,8 +504,9 @@ def extra_measurements(K, L, n, stream):
                      steps_per_launch=50, monitor=L.MON_SUMMARIES, stream=stream)
         e.set_state(x0)
         rate, ls, _ = timed_rate(e, nc, 100, 500)
-        at = attrs_of(e, 50); e.close()
+        at = attrs_of(e, 50); lay4 = e.layout(); e.close()
         ex["cfg4_swiss_logistic_mala_transitions_per_s_per_gpu"] = rate
+        assert lay4[:2] == (2, 64 // bud["cfg4"]["chains_per_wave"]), lay4      # (the budget's lanes per chain are the job's row split)
         ex["cfg4_roofline"] = valu_roofline("k_transitions<1, 2,", ls, attrs=at, budget=bud["cfg4"],
                                             necessary_per_launch=bud["cfg4"]["per_wave_transition"] * (nc // bud["cfg4"]["chains_per_wave"]) * 50)
         rats = np.load(gold / "rats.npz")

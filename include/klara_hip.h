@@ -300,6 +300,13 @@ klara_status klara_gather_summaries(klara_handle* h, klara_comm* comm, double* s
 klara_status klara_gather_moments(klara_handle* h, klara_comm* comm, double* mean, double* m2, uint64_t* nsamples,
                                   uint64_t* naccept, uint64_t* ntransitions, uint64_t* nchains);
 
+/* Memory-safety aid (tests only).  With KLARA_DEBUG_CANARY=1 in the environment every device array the library allocates lies between
+ * two 4 KiB canaries of a signalling-NaN pattern; klara_destroy returns KLARA_ERR_STATE when a kernel of the job wrote into one, and this
+ * call checks the canaries of everything alive: *nalloc = arrays checked, *ncorrupt = arrays whose canaries were damaged (they are
+ * repaired, so a damage is reported once).  poke != 0 first stores 8 bytes right behind the largest live array — the proof that the
+ * check fires.  KLARA_ERR_STATE when the canaries are not enabled. */
+klara_status klara_selftest_canary(int32_t poke, int64_t* nalloc, int64_t* ncorrupt);
+
 /* one chain of the stored history in Klara's NState layout: value[d + D*i], i = saved step
  * (BasicContMuvParameterNState.jl:89-119); requires KLARA_MON_HISTORY.  With klara_desc.hist_ring_cols > 0 the columns are the
  * last min(saved, hist_ring_cols) saved steps, oldest first, and *ncols_out is that count (klara_get_chain_fields and

@@ -77,7 +77,7 @@ EXPORTS = [
     "klara_get_chain_fields", "klara_get_chain_likelihood_prior", "klara_get_chain_mcvar", "klara_get_chain_mcvar_ipse", "klara_get_chain_acov_mcvar", "klara_saved_steps", "klara_get_chain_bm", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout", "klara_get_launch_modes", "klara_get_kernel_attributes", "klara_get_shader_clock",
     "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_normal_tail", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
     "klara_comm_unique_id", "klara_comm_init", "klara_comm_destroy", "klara_gather_summaries", "klara_gather_moments",
-    "klara_check_custom_target", "klara_compile_log", "klara_selftest_plan", "klara_abi_version",
+    "klara_check_custom_target", "klara_compile_log", "klara_selftest_plan", "klara_selftest_canary", "klara_abi_version",
 ]
 
 _lib = None
@@ -136,6 +136,7 @@ def load() -> C.CDLL:
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "klara_gather_moments": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+        "klara_selftest_canary": [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "klara_check_custom_target": [C.c_char_p, C.c_int32, C.c_int32],
         "klara_get_chain_bm": [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],
         "klara_get_chain_acov_mcvar": [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],

@@ -169,6 +169,7 @@ KD_FN double kd_log(double x)
 static const double kd_logtab_host[256] __attribute__((aligned(16))) = KD_LOGTAB_INIT;
 static const double kd_sctab_host[512] __attribute__((aligned(16))) = KD_SCTAB_INIT;
 static const double kd_exptab_host[256] __attribute__((aligned(16))) = KD_EXPTAB_INIT;
+static const double kd_l12tab_host[256] __attribute__((aligned(16))) = KD_L12TAB_INIT;
 #if defined(__HIPCC__)
 /* On the GPU the tables live in LDS (8 KB per workgroup): the lookups are per-lane gathers, and as DS reads they are
  * tracked by lgkmcnt, so waiting for one never drains the HBM prefetch that is in flight on vmcnt.  Every kernel that
@@ -176,6 +177,10 @@ static const double kd_exptab_host[256] __attribute__((aligned(16))) = KD_EXPTAB
 static __device__ const double kd_logtab_dev[256] __attribute__((aligned(16))) = KD_LOGTAB_INIT;
 static __device__ const double kd_sctab_dev[512] __attribute__((aligned(16))) = KD_SCTAB_INIT;
 static __device__ const double kd_exptab_dev[256] __attribute__((aligned(16))) = KD_EXPTAB_INIT;
+/* kd_log12's table is NOT part of the 8 KB block every kernel stages (a launch gets 64 KB of LDS without asking, and the staged-closure
+ * layouts are sized against what the block leaves): the generic function reads it from memory (2 KB, cache resident), the logistic
+ * kernels keep their own copy in LDS behind the data rows and gather from there (klara_kernels.h LogisticTarget). */
+static __device__ const double kd_l12tab_dev[256] __attribute__((aligned(16))) = KD_L12TAB_INIT;
 __shared__ double kd_tab_lds[1024] __attribute__((aligned(16)));
 __device__ __forceinline__ void kd_tables_to_lds()
 {
@@ -188,10 +193,12 @@ __device__ __forceinline__ void kd_tables_to_lds()
 #define KD_LOGTAB(i) kd_tab_lds[i]
 #define KD_SCTAB(i) kd_tab_lds[256 + (i)]
 #define KD_EXPTAB(i) kd_tab_lds[768 + (i)]
+#define KD_L12TAB(i) kd_l12tab_dev[i]
 #else
 #define KD_LOGTAB(i) kd_logtab_host[i]
 #define KD_SCTAB(i) kd_sctab_host[i]
 #define KD_EXPTAB(i) kd_exptab_host[i]
+#define KD_L12TAB(i) kd_l12tab_host[i]
 #endif
 
 /* The evaluation is split at its table read — reduce (bits -> bin, exponent, reduced argument), the gather, finish — so that a caller
@@ -260,19 +267,26 @@ KD_FN double kd_exp(double x)
     return res;
 }
 
-/* exp(-a) for a >= 0, the form the logistic rows need (t = exp(-|Xp|) in [0, 1]): kd_exp's reduction, table and polynomial — the same
- * bits for a <= 708 — without what that range does not need: no overflow side, the power of two is added to the exponent field
- * (results are normal numbers, so this equals the two exact multiplications of kd_exp), and beyond 708, where the result would be
- * subnormal, it is 0.  NaN gives 0; the caller passes NaN through itself. */
-/* (split at the table read like kd_log_u01: reduce, gather, finish) */
+/* exp(-a) for a >= 0, the form the logistic rows need (t = exp(-|Xp|) in (0, 1]): kd_exp's table and polynomial with the reduction of
+ * Arm's optimized-routines exp — k = round-to-nearest(x 128/ln2) read from the low mantissa bits of fma(x, 128/ln2, 1.5 * 2^52), and
+ * k as a double by one exact subtraction: one fma, one sub and no int <-> double conversion where kd_exp takes a mul, an add and two
+ * conversions — without what the range does not need: no overflow side, no NaN or subnormal handling, and the power of two is added to
+ * the exponent field (results are normal numbers, so this equals kd_exp's two exact multiplications).  Beyond a = 708, where the value
+ * would be subnormal, the argument is clamped: the result is exp(-708) = 3.3e-308 instead of a number below 2.3e-308 — an absolute error
+ * below 3.3e-308 (the only callers form 1 + t, where it vanishes, and t / (1 + t)).  A NaN argument gives exp(-708) as well (fmax
+ * returns the other operand); the caller passes NaN through itself.  < 1 ulp up to 708 (tests/test_oracle_kats.py); NOT bit-identical
+ * with kd_exp(-a): k is rounded to nearest-even here and towards zero-after-offset there, so a few arguments near the ties between two
+ * table entries are reduced to the other neighbour.
+ * Split at its table read — reduce, the gather (KD_EXPTAB(2 (k & 127)), (2 (k & 127) + 1)), polynomial, combine — so that a caller with
+ * several independent arguments (the data rows of the logistic targets, klara_kernels.h) can have all the gathers of a batch in flight
+ * before the first is consumed; kd_exp_neg itself is the four in sequence. */
+#define KD_EXP_SHIFT 0x1.8p52
 KD_FN void kd_exp_neg_reduce(double a, int* k, double* r)
 {
-    /* max(-a, -709): one instruction; a NaN argument gives -709 as well (fmax returns the other operand), which keeps the
-     * conversion defined.  -a <= 0 here, so the rounding offset of kd_exp is the constant -1/2 (at -a = +-0 both offsets
-     * truncate to k = 0). */
-    const double xc = __builtin_fmax(-a, -709.0);
-    *k = (int)(KD_INVLN2N * xc + -0.5);
-    const double dk = (double)*k;
+    const double xc = __builtin_fmax(-a, -708.0);
+    const double kd = kd_fma(xc, KD_INVLN2N, KD_EXP_SHIFT);            /* in [2^52, 2^53): ulp 1, so the sum is rounded to an integer */
+    *k = (int)(uint32_t)kd_d2u(kd);                                     /* ... whose two's complement sits in the low mantissa bits */
+    const double dk = kd - KD_EXP_SHIFT;                                /* exact */
     *r = kd_fma(dk, -KD_LN2N_LO, kd_fma(dk, -KD_LN2N_HI, xc));
 }
 KD_FN double kd_exp_neg_poly(double r)                 /* p(r) = r + r^2/2 + ... + r^5/120: needs no table value */
@@ -281,23 +295,44 @@ KD_FN double kd_exp_neg_poly(double r)                 /* p(r) = r + r^2/2 + ...
     const double r2 = r * r;
     return kd_fma(r2 * r2, kd_fma(r, C5, C4), kd_fma(r2, kd_fma(r, C3, C2), r));
 }
-KD_FN double kd_exp_neg_combine(double a, int k, double p, double th, double tl)
+KD_FN double kd_exp_neg_combine(int k, double p, double th, double tl)
 {
-    const int e = k >> 7;
     const double y = th + kd_fma(th, p, tl);
-    const double res = kd_u2d(kd_d2u(y) + ((uint64_t)(int64_t)e << 52));
-    return a <= 708.0 ? res : 0.0;
-}
-KD_FN double kd_exp_neg_finish(double a, int k, double r, double th, double tl)
-{
-    return kd_exp_neg_combine(a, k, kd_exp_neg_poly(r), th, tl);
+    /* 2^(k >> 7) into the exponent field: only the high word changes ((k >> 7) << 20 = (k << 13) & 0xfff00000) */
+    const uint64_t hi = (uint64_t)(((uint32_t)k << 13) & 0xfff00000u) << 32;
+    return kd_u2d(kd_d2u(y) + hi);
 }
 KD_FN double kd_exp_neg(double a)
 {
     int k; double r;
     kd_exp_neg_reduce(a, &k, &r);
     const int idx = k & 127;
-    return kd_exp_neg_finish(a, k, r, KD_EXPTAB(2 * idx), KD_EXPTAB(2 * idx + 1));
+    return kd_exp_neg_combine(k, kd_exp_neg_poly(r), KD_EXPTAB(2 * idx), KD_EXPTAB(2 * idx + 1));
+}
+
+/* log(x) for x in [1, 2] — log(1 + t), t = exp(-|Xp|) in (0, 1], of the logistic rows.  Table method like kd_log_u01 on the one binade
+ * the argument can lie in: bin i = the 7 leading mantissa bits (x = 2 joins the last bin), r = x invc_i - 1 exactly rounded, |r| <= 2^-8
+ * (bin 0 has c = 1: r = x - 1 exactly, < 2^-7, so log12(1) = 0 and the result keeps its relative accuracy as x -> 1),
+ * log x = (logc_i + r) + r^2 (-1/2 + r/3 - r^2/4 + r^3/5 - r^4/6 + r^5/7): no exponent handling, a shorter polynomial (the dropped term
+ * r^8/8 < 2^-59), two roundings at the scale of the result: absolute error below 1.5 * 2^-53 on the whole interval
+ * (tests/test_oracle_kats.py).  Split at its gather like the others. */
+KD_FN uint32_t kd_log12_bin(double x)
+{
+    const uint32_t i = ((uint32_t)(kd_d2u(x) >> 32) - 0x3ff00000u) >> 13;
+    return i < 127u ? i : 127u;
+}
+KD_FN double kd_log12_finish(double x, double invc, double logc)
+{
+    const double A2 = -0.5, A3 = 0x1.5555555555555p-2, A4 = -0.25, A5 = 0x1.999999999999ap-3, A6 = -0x1.5555555555555p-3,
+                 A7 = 0x1.2492492492492p-3;
+    const double r = kd_fma(x, invc, -1.0);
+    const double p = kd_fma(r, kd_fma(r, kd_fma(r, kd_fma(r, kd_fma(r, A7, A6), A5), A4), A3), A2);
+    return kd_fma(r * r, p, logc + r);
+}
+KD_FN double kd_log12(double x)
+{
+    const uint32_t i = kd_log12_bin(x);
+    return kd_log12_finish(x, KD_L12TAB(2 * i), KD_L12TAB(2 * i + 1));
 }
 
 /* log of a positive number that may be +inf or NaN (1 + exp(.) of the logistic target): the table log plus the two
@@ -313,7 +348,7 @@ KD_FN double kd_log_pos(double x)
  *   log(1 + exp(x)) = max(x, 0) + log(1 + t),    1 / (1 + exp(-x)) = x >= 0 ? 1 / (1 + t) : t / (1 + t).
  * The logistic-regression targets need both per data row (doc/examples/swiss/MALA/analytical.jl:13,17 write exp(Xp) and exp(-Xp)
  * separately): one exponential instead of two, and no overflow for large |x| (the literal form gives log(inf) beyond x = 709).
- * Beyond |x| = 708 the pair is (max(x, 0), x >= 0 ? 1 : 0) exactly. */
+ * Beyond |x| = 708 the pair is (max(x, 0), x >= 0 ? 1 : exp(-708) = 3.3e-308). */
 /* n / d for d in [1, 2] and n zero or a normal number in [2^-1021, 1]: the quotient is zero or a normal number and no intermediate
  * can overflow or lose bits to underflow, so the range scaling of the general division (v_div_scale x 2, v_div_fmas, v_div_fixup) has
  * nothing to do — what remains of the compiler's expansion is the reciprocal estimate, two Newton steps, the quotient and one
@@ -333,9 +368,9 @@ KD_FN double kd_div_unit_range(double n, double d)
 KD_FN void kd_softplus_logistic_rows(double x, double* softplus, double* logistic)
 {
     const double ax = __builtin_fabs(x);             /* (a source modifier on the device) */
-    const double t = kd_exp_neg(ax);                 /* 0 or [exp(-708), 1], never NaN */
+    const double t = kd_exp_neg(ax);                 /* (0, 1], never NaN; exp(-708) beyond |x| = 708 */
     const double onept = 1.0 + t;                    /* [1, 2] */
-    const double l1p = kd_log_u01(onept);
+    const double l1p = kd_log12(onept);
     *softplus = (x > 0.0 ? x : 0.0) + l1p;
     *logistic = kd_div_unit_range(x >= 0.0 ? 1.0 : t, onept);
 }

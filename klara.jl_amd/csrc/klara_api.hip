@@ -7,7 +7,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <vector>
 #include "klara_launch.h"
 
@@ -274,8 +276,80 @@ static klara_status validate(const klara_desc* d)
     return KLARA_OK;
 }
 
+// ---- device allocations, optionally between canaries.  Every kernel addresses the chains' vectors through buffer
+// resources whose num_records clamps ragged tails and whose KLARA_BUF_OOB offsets mask padding lanes: a window sized one element too
+// large, or an offset that is not out of range when it should be, reads or writes a neighbour's memory silently.  KLARA_DEBUG_CANARY=1 in the
+// environment puts 4 KiB of a signalling-NaN pattern (0x7FF4DEAD7FF4DEAD at every 8-byte aligned address) directly before and after
+// every device array: a stray WRITE changes the pattern (checked when the handle is destroyed: klara_destroy returns KLARA_ERR_STATE; and
+// by klara_selftest_canary for everything alive), a stray READ brings a NaN into a result that the parity tests compare bit for bit.
+static const size_t KCANARY = 4096;
+static const unsigned long long KCANARY_WORD = 0x7FF4DEAD7FF4DEADull;
+static bool canary_on()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("KLARA_DEBUG_CANARY"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+struct CanaryRec { char* base; size_t bytes; };
+static std::mutex canary_mu;
+static std::unordered_map<void*, CanaryRec> canary_map;
+static void canary_pattern(std::vector<unsigned char>& buf, size_t addr0)          // the pattern as it lies at device addresses addr0, addr0 + 1, ...
+{
+    for (size_t i = 0; i < buf.size(); ++i) buf[i] = (unsigned char)(KCANARY_WORD >> (8 * ((addr0 + i) & 7)));
+}
+static hipError_t canary_fill(const CanaryRec& r)
+{
+    std::vector<unsigned char> pat(KCANARY);
+    canary_pattern(pat, (size_t)r.base);
+    hipError_t e = hipMemcpy(r.base, pat.data(), KCANARY, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    canary_pattern(pat, (size_t)r.base + KCANARY + r.bytes);
+    return hipMemcpy(r.base + KCANARY + r.bytes, pat.data(), KCANARY, hipMemcpyHostToDevice);
+}
+static bool canary_intact(const CanaryRec& r)
+{
+    std::vector<unsigned char> got(KCANARY), pat(KCANARY);
+    for (int side = 0; side < 2; ++side) {
+        const char* at = side == 0 ? r.base : r.base + KCANARY + r.bytes;
+        if (hipMemcpy(got.data(), at, KCANARY, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        canary_pattern(pat, (size_t)at);
+        if (memcmp(got.data(), pat.data(), KCANARY) != 0) return false;
+    }
+    return true;
+}
+static hipError_t dalloc_bytes(void** p, size_t bytes)
+{
+    if (!canary_on()) return hipMalloc(p, bytes);
+    char* base = nullptr;
+    hipError_t e = hipMalloc((void**)&base, bytes + 2 * KCANARY);
+    if (e != hipSuccess) return e;
+    const CanaryRec r = { base, bytes };
+    if ((e = canary_fill(r)) != hipSuccess) { hipFree(base); return e; }
+    std::lock_guard<std::mutex> g(canary_mu);
+    canary_map[base + KCANARY] = r;
+    *p = base + KCANARY;
+    return hipSuccess;
+}
+// frees a device array; false when its canaries were found damaged (always true without KLARA_DEBUG_CANARY)
+static bool dfree(void* p)
+{
+    if (!p) return true;
+    if (!canary_on()) { hipFree(p); return true; }
+    CanaryRec r;
+    {
+        std::lock_guard<std::mutex> g(canary_mu);
+        auto it = canary_map.find(p);
+        if (it == canary_map.end()) { hipFree(p); return true; }
+        r = it->second;
+        canary_map.erase(it);
+    }
+    hipDeviceSynchronize();
+    const bool ok = canary_intact(r);
+    hipFree(r.base);
+    return ok;
+}
 template <class T>
-static hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
+static hipError_t dalloc(T** p, size_t n) { return dalloc_bytes((void**)p, n * sizeof(T)); }
 
 static klara_status upload(double** dst, const double* src, size_t n)
 {
@@ -284,14 +358,15 @@ static klara_status upload(double** dst, const double* src, size_t n)
     return KLARA_OK;
 }
 
-static void free_all(klara_handle* h)
+static bool free_all(klara_handle* h)
 {
-    hipFree(h->X); hipFree(h->GR); hipFree(h->LT); hipFree(h->tune_step); hipFree(h->tune_acc);
-    hipFree(h->tune_prop); hipFree(h->tune_tot); hipFree(h->da_epsbar); hipFree(h->da_hbar); hipFree(h->pooled_acc); hipFree(h->accept);
-    hipFree(h->naccept); hipFree(h->sum); hipFree(h->sumsq); hipFree(h->held); hipFree(h->hist); hipFree(h->acov_S); hipFree(h->acov_head); hipFree(h->acov_tail); hipFree(h->acov_total); hipFree(h->hist_lt); hipFree(h->hist_g); hipFree(h->hist_ll); hipFree(h->hist_lp); if (!h->flag_host) hipFree(h->err);
-    hipFree(h->vecparam); hipFree(h->gw); hipFree(h->gmu); hipFree(h->lX); hipFree(h->ly); hipFree(h->hY); hipFree(h->hxc);
-    hipFree(h->Pfrag); hipFree(h->pooled_out); hipFree(h->pool_partial); hipFree(h->d_params); hipFree(h->cdata);
-    hipFree(h->bm_prev); hipFree(h->bm_mean); hipFree(h->bm_m2); hipFree(h->auto_cells); hipFree(h->auto_ctr); hipFree(h->clock_probe);
+    bool ok = true;
+    ok &= dfree(h->X); ok &= dfree(h->GR); ok &= dfree(h->LT); ok &= dfree(h->tune_step); ok &= dfree(h->tune_acc);
+    ok &= dfree(h->tune_prop); ok &= dfree(h->tune_tot); ok &= dfree(h->da_epsbar); ok &= dfree(h->da_hbar); ok &= dfree(h->pooled_acc); ok &= dfree(h->accept);
+    ok &= dfree(h->naccept); ok &= dfree(h->sum); ok &= dfree(h->sumsq); ok &= dfree(h->held); ok &= dfree(h->hist); ok &= dfree(h->acov_S); ok &= dfree(h->acov_head); ok &= dfree(h->acov_tail); ok &= dfree(h->acov_total); ok &= dfree(h->hist_lt); ok &= dfree(h->hist_g); ok &= dfree(h->hist_ll); ok &= dfree(h->hist_lp); if (!h->flag_host) ok &= dfree(h->err);
+    ok &= dfree(h->vecparam); ok &= dfree(h->gw); ok &= dfree(h->gmu); ok &= dfree(h->lX); ok &= dfree(h->ly); ok &= dfree(h->hY); ok &= dfree(h->hxc);
+    ok &= dfree(h->Pfrag); ok &= dfree(h->pooled_out); ok &= dfree(h->pool_partial); ok &= dfree(h->d_params); ok &= dfree(h->cdata);
+    ok &= dfree(h->bm_prev); ok &= dfree(h->bm_mean); ok &= dfree(h->bm_m2); ok &= dfree(h->auto_cells); ok &= dfree(h->auto_ctr); ok &= dfree(h->clock_probe);
     if (h->auto_mirror) hipHostFree(h->auto_mirror);
     if (h->flag_host) hipHostFree(h->flag_host);
     klara_jit_destroy(h->jit);
@@ -300,6 +375,7 @@ static void free_all(klara_handle* h)
     for (int j = 0; j < 3; ++j) { if (h->side[j]) hipStreamDestroy(h->side[j]); if (h->join_ev[j]) hipEventDestroy(h->join_ev[j]); }
     if (h->fork_ev) hipEventDestroy(h->fork_ev);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    return ok;
 }
 
 static KParams make_params(klara_handle* h);
@@ -454,7 +530,11 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
     if (desc->target == KLARA_TARGET_LOGISTIC) {
         // D <= 8 parameters cannot fill a wavefront's lanes usefully, the ndata-row likelihood can: RS lanes share a chain
         // and each takes every RS-th row (fixed by ndata alone, so results do not depend on how chains are sharded)
-        int rs = desc->logit_ndata >= 128 ? 8 : (desc->logit_ndata >= 64 ? 4 : 1);     // (swiss, 200 rows: 8 — 8.07e8 vs 7.69e8 transitions/s at 4)
+        // 4 lanes from 64 rows on (round 4; rounds 1-3: 8 from 128 rows).  With the rows of an evaluation going through their stages in batches
+        // a wavefront no longer needs partners to cover its LDS round trips, so the kernels run at 2 wavefronts per SIMD with the registers
+        // of a 4-row batch, and 16 chains per wavefront share the sampler's per-wavefront work instead of 8: swiss (200 rows), 32,768 chains,
+        // same box, running sums on: 2.10e9 transitions/s at 4 lanes against 1.88e9 at 8 (gpurun_out/r4_gpu3/ab_logit.txt; profiles/README.md)
+        int rs = desc->logit_ndata >= 64 ? 4 : 1;
         if (const char* s = getenv("KLARA_LOGIT_ROWSPLIT")) { const int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) rs = v; }
         h->RS = rs;
         if (rs > 1) h->kind = 2;
@@ -608,9 +688,9 @@ extern "C" klara_status klara_destroy(klara_handle* h)
     hipSetDevice(h->d.device);
     hipStreamSynchronize(h->stream);
     for (int j = 0; j < 3; ++j) if (h->side[j]) hipStreamSynchronize(h->side[j]);
-    free_all(h);
+    const bool intact = free_all(h);
     delete h;
-    return KLARA_OK;
+    return intact ? KLARA_OK : KLARA_ERR_STATE;        // (KLARA_DEBUG_CANARY=1: a kernel of this job wrote outside one of its arrays)
 }
 
 static KParams make_params(klara_handle* h)
@@ -672,8 +752,8 @@ static dim3 grid_for_transitions(const klara_handle* h)
 
 static size_t lds_for(const klara_handle* h)
 {
-    if (h->kind != 1 && h->d.target == KLARA_TARGET_LOGISTIC)
-        return sizeof(double) * (size_t)h->d.logit_ndata * (size_t)(h->E + 1);
+    if (h->kind != 1 && h->d.target == KLARA_TARGET_LOGISTIC)        // data rows + responses + the kernel's copy of kd_log12's table (LogisticTarget::lds_bytes)
+        return sizeof(double) * (((size_t)h->d.logit_ndata * (size_t)(h->E + 1) + 1) / 2 * 2 + 256);
     if (h->kind == 0 && h->d.target == KLARA_TARGET_CUSTOM && h->G > 1)              // staged closure: the rows of a workgroup's chains
         return custom_stage_bytes(h->d.ndims, h->G, h->custom_rows, h->custom_wpb);
     return 0;
@@ -1190,7 +1270,7 @@ extern "C" klara_status klara_get_chain_acov_mcvar(klara_handle* h, double* mcva
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && mcvar_imse) e = hipMemcpy(mcvar_imse, buf, nd * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess && mcvar_ipse) e = hipMemcpy(mcvar_ipse, buf + nd, nd * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(buf);
+    (void)dfree(buf);
     if (nsamples_out) *nsamples_out = h->acov_n;
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }
@@ -1378,7 +1458,7 @@ extern "C" klara_status klara_get_chain_sums(klara_handle* h, double* sum, doubl
             if (e == hipSuccess) e = hipMemcpyAsync(dst, view, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         }
-        hipFree(view);
+        (void)dfree(view);
         if (e != hipSuccess) return KLARA_ERR_HIP;
     } else {
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1534,7 +1614,7 @@ extern "C" klara_status klara_comm_destroy(klara_comm* c)
     if (!c) return KLARA_ERR_INVALID_ARG;
     hipSetDevice(c->device);
     if (c->comm) c->CommDestroy(c->comm);
-    if (c->buf) hipFree(c->buf);
+    if (c->buf) (void)dfree(c->buf);
     delete c;
     return KLARA_OK;
 }
@@ -1547,7 +1627,7 @@ extern "C" klara_status klara_gather_summaries(klara_handle* h, klara_comm* c, d
     HIPCHK(hipSetDevice(h->d.device));
     const size_t D = (size_t)h->d.ndims;
     if (c->cap < 2 * D + 4) {
-        if (c->buf) hipFree(c->buf);
+        if (c->buf) (void)dfree(c->buf);
         c->buf = nullptr; c->cap = 0;
         HIPCHK(dalloc(&c->buf, 2 * D + 4));
         c->cap = 2 * D + 4;
@@ -1680,7 +1760,7 @@ extern "C" klara_status klara_gather_moments(klara_handle* h, klara_comm* c, dou
     } else {
         // device staging: [0, D) mean_r -> mean, [D, 2D) M2_r -> M2, [2D] accept total, then [2D+1, 2D+4) counters, [2D+4, 3D+4) n_r mean_r
         if (c->cap < 3 * D + 4) {
-            if (c->buf) hipFree(c->buf);
+            if (c->buf) (void)dfree(c->buf);
             c->buf = nullptr; c->cap = 0;
             HIPCHK(dalloc(&c->buf, 3 * D + 4));
             c->cap = 3 * D + 4;
@@ -1867,7 +1947,7 @@ extern "C" klara_status klara_get_chain_mcvar(klara_handle* h, int64_t batchlen,
     if (e == hipSuccess && mcvar_iid) e = hipMemcpy(mcvar_iid, buf, total * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess && mcvar_bm) e = hipMemcpy(mcvar_bm, buf + total, total * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess && mcvar_imse) e = hipMemcpy(mcvar_imse, buf + 2 * total, total * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(buf);
+    (void)dfree(buf);
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }
 
@@ -1884,7 +1964,7 @@ extern "C" klara_status klara_get_chain_mcvar_ipse(klara_handle* h, int64_t maxl
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMemcpy(mcvar_ipse, buf, total * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(buf);
+    (void)dfree(buf);
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }
 
@@ -2037,7 +2117,7 @@ extern "C" klara_status klara_selftest_rocrand_blocks(int32_t device, uint64_t s
                        (unsigned long long)subsequence, (unsigned long long)first_block, nblocks, d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(out, d, sizeof(uint32_t) * 4 * (size_t)nblocks, hipMemcpyDeviceToHost);
-    hipFree(d);
+    (void)dfree(d);
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }
 
@@ -2056,6 +2136,10 @@ __global__ void k_math(int op, long long n, const double* in, const double* in2,
     case 6: out[i] = kd_erf(in[i]); break;
     case 7: out[i] = kd_log_u01(in[i]); break;
     case 8: out[i] = kd_sqrt_radicand(in[i]); break;
+    case 9: out[i] = kd_exp_neg(in[i]); break;
+    case 10: kd_softplus_logistic(in[i], &s, &c); out[i] = s; break;
+    case 11: kd_softplus_logistic(in[i], &s, &c); out[i] = c; break;
+    case 12: out[i] = kd_log12(in[i]); break;
     default: out[i] = in[i] / in2[i]; break;
     }
 }
@@ -2076,7 +2160,7 @@ extern "C" klara_status klara_selftest_math(int32_t device, int32_t op, int64_t 
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
-    hipFree(di); hipFree(di2); hipFree(dout);
+    (void)dfree(di); (void)dfree(di2); (void)dfree(dout);
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }
 
@@ -2128,7 +2212,7 @@ extern "C" klara_status klara_selftest_normal_tail(int32_t device, uint64_t seed
     }
     if (e == hipSuccess) e = hipMemcpy(counts, dc, sizeof(uint64_t) * (size_t)nthr, hipMemcpyDeviceToHost);
     if (e == hipSuccess && moments) e = hipMemcpy(moments, dm, 4 * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(dthr); hipFree(dc); hipFree(dm);
+    (void)dfree(dthr); (void)dfree(dc); (void)dfree(dm);
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }
 
@@ -2144,7 +2228,7 @@ extern "C" klara_status klara_selftest_mfma_f64(int32_t device, const double* A,
     if (e == hipSuccess) e = hipMemcpy(buf + 128, C, 256 * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = klara_launch_mfma_probe(buf, buf + 64, buf + 128, buf + 384, 0);
     if (e == hipSuccess) e = hipMemcpy(D, buf + 384, 256 * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(buf);
+    (void)dfree(buf);
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }
 
@@ -2160,7 +2244,7 @@ extern "C" klara_status klara_selftest_mfma_f64_4x4x4(int32_t device, const doub
     if (e == hipSuccess) e = hipMemcpy(buf + 128, C, 64 * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = klara_launch_mfma4_probe(buf, buf + 64, buf + 128, buf + 192, 0);
     if (e == hipSuccess) e = hipMemcpy(D, buf + 192, 64 * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(buf);
+    (void)dfree(buf);
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }
 
@@ -2222,6 +2306,26 @@ extern "C" const char* klara_strerror(klara_status s)
     case KLARA_ERR_COMPILE: return "user-defined target did not compile (see klara_compile_log)";
     default: return "unknown status";
     }
+}
+
+extern "C" klara_status klara_selftest_canary(int32_t poke, int64_t* nalloc, int64_t* ncorrupt)
+{
+    if (!canary_on()) return KLARA_ERR_STATE;
+    hipDeviceSynchronize();
+    std::lock_guard<std::mutex> g(canary_mu);
+    if (poke && !canary_map.empty()) {                  // an off-by-one store right behind the largest live array: the check below must see it
+        const CanaryRec* big = nullptr;
+        for (auto& kv : canary_map) if (!big || kv.second.bytes > big->bytes) big = &kv.second;
+        const double zero = 0.0;
+        if (hipMemcpy(big->base + KCANARY + big->bytes, &zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return KLARA_ERR_HIP;
+    }
+    long long bad = 0;
+    for (auto& kv : canary_map) {
+        if (!canary_intact(kv.second)) { ++bad; if (canary_fill(kv.second) != hipSuccess) return KLARA_ERR_HIP; }    // (repaired: reported once)
+    }
+    if (nalloc) *nalloc = (int64_t)canary_map.size();
+    if (ncorrupt) *ncorrupt = bad;
+    return KLARA_OK;
 }
 
 extern "C" int32_t klara_abi_version(void) { return KLARA_ABI_VERSION; }

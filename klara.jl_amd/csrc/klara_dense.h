@@ -215,18 +215,23 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
     const bool do_sum = p.sum != nullptr;
     long long held = do_sum ? p.held[cx.chain_ok ? cx.chain : 0] : 0;        // running sums in sojourn form (KParams::held)
 
+    // An accepted proposal IS the next transition's current state: after an accept the lane's registers xp (value) and gp (gradient)
+    // hold exactly what was just stored to X / GR, so the next transition starts from them and only a chain whose last proposal was
+    // rejected (2 % of the transitions at cfg 3) re-reads its state — VERDICT r3 item 9 step 1: the kernel used to re-load x and g every
+    // transition (2 x 800 B per chain and transition, 2.7 GB of the 6.3 GB a 32-transition launch of cfg 3 moved).
+    double xp[NE], gp[NG];
+    bool have = false;
     for (int s = 0; s < kl.nsteps; ++s) {
         const unsigned long long t = kl.t0 + (unsigned long long)s;
         if (p.cnt) tune_count_proposal(p, tn);
         bool acc = false;
-        double xp[NE], gp[NG];
         double ltp = lt;
-        mload<NE>(cx, p.X, p.D, xp);                                   // current value
+        if (!have) mload<NE>(cx, p.X, p.D, xp);                        // current value
 
         if (SAMPLER == KLARA_SAMPLER_HMC) {
             // iterate/HMC.jl:124-201, leapfrog! samplers.jl:122-134
             double mom[NE], red[2];
-            {
+            if (!have) {
                 double g0[NE];
                 mload<NE>(cx, p.GR, p.D, g0);                           // HMC.jl:140
 #pragma unroll
@@ -304,7 +309,12 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             double s1 = 0.0;
             {
                 double g0[NE];
-                mload<NE>(cx, p.GR, p.D, g0);
+                if (have) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) g0[e] = gp[e];
+                } else {
+                    mload<NE>(cx, p.GR, p.D, g0);
+                }
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
                     xc[e] = xp[e];
@@ -464,6 +474,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             }
             lt = ltp;
         }
+        have = acc;                                      // (a rejected proposal leaves the registers holding the proposal: re-read next time)
         nacc += acc ? 1ull : 0ull;
         if (p.cnt && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;       // (the slice sampler never counts accepts)
         if (accept_out != nullptr && cx.chain_ok && cx.q == 0)

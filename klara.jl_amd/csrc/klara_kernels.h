@@ -30,7 +30,7 @@
 #endif
 // data rows of the logistic target that go through the stages of an evaluation together (LogisticTarget::eval)
 #ifndef KLARA_LOGIT_BATCH
-#define KLARA_LOGIT_BATCH 5
+#define KLARA_LOGIT_BATCH 4
 #endif
 #define KLARA_LOGIT_BATCH_OF(E) ((E) <= 4 ? KLARA_LOGIT_BATCH : ((KLARA_LOGIT_BATCH) > 3 ? 3 : KLARA_LOGIT_BATCH))
 template <int N> struct KInt { static constexpr int value = N; };
@@ -51,10 +51,10 @@ template <int N> struct KInt { static constexpr int value = N; };
 #define KLARA_PRAGMA_UNROLL_E _Pragma("unroll")
 #endif
 #ifndef KLARA_E4_WAVES_LOGISTIC
-#define KLARA_E4_WAVES_LOGISTIC 4
+#define KLARA_E4_WAVES_LOGISTIC 2
 #endif
 #ifndef KLARA_E4_WAVES_LOGISTIC_HMC
-#define KLARA_E4_WAVES_LOGISTIC_HMC 4   /* swiss HMC L = 10: 1.97e9 against 1.83e9 leapfrog*chain/s with running sums, same box */
+#define KLARA_E4_WAVES_LOGISTIC_HMC 2
 #endif
 #ifndef KLARA_E4_WAVES_PLAIN
 #define KLARA_E4_WAVES_PLAIN 3   // the specialised (no tuner, no monitor) E=4 kernels fit 168 VGPRs
@@ -420,21 +420,23 @@ KLARA_PRAGMA_UNROLL_E
 // (same-address LDS reads broadcast), so no cross-lane reduction exists.
 template <int E>
 struct LogisticTarget {
-    const double* sX; const double* sy; int ndata; int D; double lambda, lpconst;
+    const double* sX; const double* sy; const double* sL12; int ndata; int D; double lambda, lpconst;
     // The design matrix sits in LDS with a row stride of E doubles, columns D..E-1 zero: a row is read with 16-byte loads at a
     // compile-time stride and the dot product / gradient accumulations run over all E elements without a per-element `e < D` test
     // (fma(0, x, acc) = acc exactly, so the padded terms leave the D-term chains of the oracle untouched).
     static __device__ __forceinline__ size_t lds_bytes(const KParams& p)
     {
-        return sizeof(double) * (size_t)p.ndata * (size_t)(E + 1);
+        return sizeof(double) * (((size_t)p.ndata * (size_t)(E + 1) + 1) / 2 * 2 + 256);      // rows, responses, (16-byte aligned) kd_log12's table
     }
     __device__ __forceinline__ void init(const KParams& p, const LaneCtx<E>&, double* lds)
     {
         double* X = lds; double* y = lds + (size_t)p.ndata * E;
         for (int i = threadIdx.x; i < p.ndata * E; i += blockDim.x) { const int r = i / E, e = i - r * E; X[i] = e < p.D ? p.lX[r * p.D + e] : 0.0; }
         for (int i = threadIdx.x; i < p.ndata; i += blockDim.x) y[i] = p.ly[i];
+        double* l12 = lds + ((size_t)p.ndata * (E + 1) + 1) / 2 * 2;       // the rows' log(1 + t) table: gathered from LDS like the other tables
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) l12[i] = kd_l12tab_dev[i];
         __syncthreads();
-        sX = X; sy = y; ndata = p.ndata; D = p.D; lambda = p.lambda; lpconst = p.lpconst;
+        sX = X; sy = y; sL12 = l12; ndata = p.ndata; D = p.D; lambda = p.lambda; lpconst = p.lpconst;
     }
     template <bool WANT_LT, bool WANT_GRAD>
     __device__ __forceinline__ void eval(const LaneCtx<E>& cx, const double (&x)[E], double& ltpart,
@@ -457,8 +459,8 @@ KLARA_PRAGMA_UNROLL_E
         // ascending order: the operations and the summation order of the one-row form, bit for bit (the oracle's ko_logit_eval).
         const auto rows_of = [&](auto rtag, int r0, int stride) {
             constexpr int R = decltype(rtag)::value;
-            double row[R][E], yr[R], xp[R], rr[R], th[R], tl[R], t[R], onept[R], z[R], invc[R], logc[R], sp[R], lg[R];
-            int kk[R], lk[R]; uint32_t li[R];
+            double row[R][E], yr[R], xp[R], rr[R], th[R], tl[R], t[R], onept[R], invc[R], logc[R], sp[R], lg[R];
+            int kk[R]; uint32_t li[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 const int r = r0 + j * stride;
@@ -483,20 +485,20 @@ KLARA_PRAGMA_UNROLL_E
             KLARA_SCHED_STAGE();
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                t[j] = kd_exp_neg_combine(__builtin_fabs(xp[j]), kk[j], rr[j], th[j], tl[j]);
+                t[j] = kd_exp_neg_combine(kk[j], rr[j], th[j], tl[j]);
                 onept[j] = 1.0 + t[j];
-                kd_log_u01_reduce(onept[j], &li[j], &lk[j], &z[j]);
+                li[j] = kd_log12_bin(onept[j]);
             }
             KLARA_SCHED_STAGE();
 #pragma unroll
-            for (int j = 0; j < R; ++j) { invc[j] = KD_LOGTAB(2 * li[j]); logc[j] = KD_LOGTAB(2 * li[j] + 1); }
+            for (int j = 0; j < R; ++j) { invc[j] = sL12[2 * li[j]]; logc[j] = sL12[2 * li[j] + 1]; }
             KLARA_SCHED_STAGE();
 #pragma unroll
             for (int j = 0; j < R; ++j) lg[j] = kd_div_unit_range(xp[j] >= 0.0 ? 1.0 : t[j], onept[j]);   // 1/(1+exp(-Xp)) (no table value either)
             KLARA_SCHED_STAGE();
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const double l1p = kd_log_u01_finish(z[j], lk[j], invc[j], logc[j]);
+                const double l1p = kd_log12_finish(onept[j], invc[j], logc[j]);
                 sp[j] = (xp[j] > 0.0 ? xp[j] : 0.0) + l1p;                        // log(1+exp(Xp))
             }
             KLARA_SCHED_STAGE();

@@ -273,8 +273,8 @@ class Engine:
     # -- lifetime
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            self._lib.klara_destroy(self._h)
-            self._h = C.c_void_p()
+            h, self._h = self._h, C.c_void_p()
+            L.check(self._lib.klara_destroy(h), "klara_destroy")     # (KLARA_DEBUG_CANARY=1: fails when a kernel wrote outside an array)
 
     def __del__(self):
         try:

@@ -875,6 +875,7 @@ void ko_math(int op, int64_t n, const double* in, const double* in2, double* out
         case 10: kd_softplus_logistic(in[i], &s, &c); out[i] = s; break;
         case 11: kd_softplus_logistic(in[i], &s, &c); out[i] = c; break;
     case 8: out[i] = kd_sqrt_radicand(in[i]); break;
+        case 12: out[i] = kd_log12(in[i]); break;
         default: out[i] = in[i] / in2[i]; break;
         }
     }

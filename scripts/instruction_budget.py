@@ -32,8 +32,9 @@ SINCOS = 18                      # j (bfe), centre word (v_and_or), t (sub), y (
 NORMAL_PAIR = PHILOX + U52 + UNIT_BITS + LOG_U01 + SQRT_RAD + SINCOS + 2       # ... + the two products radius x (cos, sin)  = 102
 EXP = 39                         # kd_exp: 2 clamps, rounding offset (bfi) + mul + add, 2 cvt, r (2 fma), index / exponent (and, ashr), table offset, r2, r4,
                                  # 4 fma, y (fma, add), e/2 and e - e/2 (3), two scale words (2 x (add, shl)), 2 mul, three special-case selects (3 x 3)
-EXP_NEG = 24                     # kd_exp_neg: max, mul + add, 2 cvt, r (2 fma), and / ashr, table offset, r2, r4, 4 fma, y (fma, add), exponent (shl, and, add),
-                                 # the a <= 708 select (cmp + 2 cndmask)
+EXP_NEG = 18                     # kd_exp_neg (round 4: k from the low mantissa bits of one fma): max, fma, sub, r (2 fma), table offset (and, shl), r2, r4, 4 fma,
+                                 # y (fma, add), exponent word (shl, and, add)
+LOG12 = 12                       # kd_log12 on [1, 2]: bin (sub, shr, min), table offset, r (fma), 5 fma of the polynomial, r2, logc + r, final fma  [one ds_read_b128]
 DIV = 10                         # IEEE f64 division as hipcc emits it: 2 v_div_scale, v_rcp, 5 fma, v_div_fmas, v_div_fixup
 DIV_UNIT = 8                     # kd_div_unit_range (numerator in [2^-1021, 1] or 0, denominator in [1, 2]): v_rcp, 2 x 2 fma, mul, 2 fma
 BFLY = 3                         # one butterfly step of one double: 2 v_mov_dpp (or ds_bpermute) + v_add_f64
@@ -78,12 +79,12 @@ def cfg5_hier(nleaps: int = 32, units_per_lane: int = 4):
             "kick_and_drift": 2 * vals, "normals": normals, "per_wave_transition": per_tr, "chains_per_wave": 8, "nleaps": nleaps}
 
 
-def cfg4_logistic(ndata: int = 200, ndims: int = 4, rowsplit: int = 8):
-    """k_transitions<MALA, LOGISTIC, E=4> with the 8-lane row split: per wavefront (8 chains) and transition."""
-    row = ndims + EXP_NEG + 1 + LOG_U01 + 2 + 3 + DIV_UNIT + 2 + 1 + 1 + ndims + 1     # Xp; exp(-|Xp|); 1 + t; log; softplus (max, add); numerator select;
+def cfg4_logistic(ndata: int = 200, ndims: int = 4, rowsplit: int = 4):
+    """k_transitions<MALA, LOGISTIC, E=4> with the 4-lane row split: per wavefront (16 chains) and transition."""
+    row = ndims + EXP_NEG + 1 + LOG12 + 2 + 3 + DIV_UNIT + 2 + 1 + 1 + ndims + 1     # Xp; exp(-|Xp|); 1 + t; log; softplus (max, add); numerator select;
     # division; Xp*y (mul, add); sum of softplus; residual; gradient accumulations; row offset
     rows = ndata // rowsplit
-    bfly = (ndims + 2) * 3 * BFLY                                       # (D + 2)-value butterfly over the 8 lanes
+    bfly = (ndims + 2) * {4: 2, 8: 3}[rowsplit] * BFLY                  # (D + 2)-value butterfly over the chain's lanes
     prior = 2 * ndims + (DIV + 2) + ndims * (DIV + 1)                   # p.p; -(p.p / lambda + const)/2; -p / lambda per component (the example's divisions)
     normals = NORMAL_PAIR + 2 * ndims + 4                               # every lane of a chain holds the whole vector; the (D + 1) / 2 blocks of the normals
     # and the accept draw's block are spread over the four lanes of a quad (one each) and exchanged (2 v_mov_dpp per normal, 2 + 2 ds_bpermute
@@ -92,6 +93,92 @@ def cfg4_logistic(ndata: int = 200, ndims: int = 4, rowsplit: int = 8):
     accept = 12
     return {"per_row": row, "rows_per_lane": rows, "butterfly": bfly, "prior": prior, "normals": normals, "sampler": sampler,
             "per_wave_transition": rows * row + bfly + prior + normals + sampler + accept, "chains_per_wave": 64 // rowsplit}
+
+
+def cfg1_replicas():
+    """k_transitions<MH, DIAG, E=2, one chain per lane> — the README job (README.md:23-47: MH, sigma = (1, 1), lt = -dot(z, z), D = 2) as
+    replicas with running sums: per wavefront (64 chains) and transition."""
+    normals = NORMAL_PAIR                                               # one block = the chain's two normals
+    proposal = 2 * 2                                                    # x + sigma z (mul, add) per element, iterate/MH.jl:79
+    target = 2 * 2 + 1                                                  # -dot(z, z): mul, add per element; the sign
+    ratio = 1
+    # accept iff ratio > 0 or ratio > log(rand()) (MH.jl:97): the draw is made by the lanes with ratio <= 0 — about half of them, so a
+    # wavefront of 64 chains always makes it
+    accept = 1 + (PHILOX + U52 + LOG_U01) + 1 + 1
+    commit = 2 * 2 + 2                                                  # v_cndmask per dword of x (2 doubles) and lt
+    sums = 1 + (1 + 2 * (2 + 3)) + 1                                    # held += 1; fold of the state being left: cvt, sum += h x, sumsq += h (x x); held = 0
+    book = 2                                                            # accept counter, save-rule phase
+    return {"normals": normals, "proposal": proposal, "target": target, "accept_test": ratio + accept, "commit": commit, "running_sums": sums,
+            "bookkeeping": book, "per_wave_transition": normals + proposal + target + ratio + accept + commit + sums + book, "chains_per_wave": 64}
+
+
+def hmc_iso(nleaps: int = 10, ndims: int = 100, lanes_per_chain: int = 8):
+    """k_diagt<HMC, NP, Q=8, fused, UNITW> on the README target (north_star's "100-dim Gaussian HMC"), no monitor: per wavefront (8 chains)
+    and transition, merged fma leapfrog."""
+    chains = 64 // lanes_per_chain
+    pairs = (ndims + 1) // 2 * chains / 64.0                            # 6.25 pair evaluations per lane
+    per_pair = (NORMAL_PAIR                                             # the two momenta
+                + 2 * (2 + 2)                                           # p.p before and after (mul, add per element each)
+                + 2 * 1                                                 # opening half kick (fma per element)
+                + nleaps * 2 * 3                                        # per leapfrog and element: drift (fma), gradient -2x (mul), kick (fma)
+                + 2 * 2)                                                # log-target of the proposal: mul, add per element
+    red = 3 * 3 * BFLY                                                  # K0, lt', K1: three sums over 8 lanes
+    accept = 2 + 2 + EXP + 1 + 1 + 1                                    # H0, H1, ratio; exp; min; the uniform comes with the padding pair's block; compare
+    commit = 2 * 2 + 2                                                  # per pair slot: selects of the value pair; lt
+    return {"per_pair": per_pair, "pair_evaluations_per_lane": pairs, "reductions": red, "accept_test": accept,
+            "per_wave_transition": pairs * (per_pair + 4) + red + accept + 2 + 1, "chains_per_wave": chains, "nleaps": nleaps}
+
+
+def slice_probe_counts(width: float = 1.0, nsamples: int = 400000, seed: int = 7):
+    """Mean log-target probes of one coordinate update of the slice sampler (iterate/SliceSampler.jl:60-109, stepping out) on lt = -|x|^2 in
+    stationarity: (left probes, right probes, shrink attempts) per chain, and the means of the MAXIMUM over the 8 chains of a wavefront —
+    the lockstep loops of the kernel run until the slowest of its 8 chains is done.  A simulation of the procedure itself (NumPy), seeded."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    n = nsamples
+    x = rng.standard_normal(n) * np.sqrt(0.5); u = rng.random(n); s = np.sqrt(x * x - np.log(u))     # the slice on this coordinate: |c| < s
+    r = rng.random(n)
+    L = x - r * width; R = x + (1 - r) * width
+    nl = np.ones(n, int); nr = np.ones(n, int)
+    while True:
+        go = L > -s
+        if not go.any(): break
+        L = np.where(go, L - width, L); nl += go
+    while True:
+        go = R < s
+        if not go.any(): break
+        R = np.where(go, R + width, R); nr += go
+    ns = np.zeros(n, int); done = np.zeros(n, bool)
+    while not done.all():
+        c = rng.random(n) * (R - L) + L
+        act = ~done; ns += act
+        ok = np.abs(c) < s
+        done |= act & ok
+        R = np.where(act & ~ok & (c > x), c, R); L = np.where(act & ~ok & (c < x), c, L)
+    m8 = lambda a: float(a[:n // 8 * 8].reshape(-1, 8).max(1).mean())
+    return {"per_chain": (float(nl.mean()), float(nr.mean()), float(ns.mean())), "max_over_8_chains": (m8(nl), m8(nr), m8(ns))}
+
+
+SLICE_PROBES = {"per_chain": (2.128745, 2.1275425, 1.46118), "max_over_8_chains": (3.57358, 3.57234, 2.81954)}     # slice_probe_counts()
+
+
+def slice_diag(ndims: int = 100, counts=None):
+    """k_diagt<SLICE, NP=7, Q=8, UNITW>: per wavefront (8 chains) and COORDINATE update.  `counts` = (left probes, right probes, shrink
+    attempts); the algorithmic budget takes a chain's own mean counts, the lockstep variant the mean of the maximum over the wavefront's 8
+    chains (what 8 chains sharing the loops have to execute)."""
+    nl, nr, ns = counts if counts is not None else SLICE_PROBES["per_chain"]
+    E = 14
+    probe = 1 + 1 + (E - 1) / 2.0 + 2 + 3 * BFLY + 1                    # candidate's term; prefix + term; the terms behind the slot; owner select; butterfly; c - sum
+    fixed = (E                                                          # prefix and whole sums of the lane's cached terms
+             + 2 * 2                                                    # x_i and its width to the chain's lanes
+             + PHILOX + U52 + LOG_U01 + 1 + U52                         # log(rand()) + lt, runiform: one block
+             + 2 + 3                                                    # l_i = x_i - r w; r_i = x_i + (1 - r) w
+             + 2 + 4 + 2)                                               # the new term; x_i, term, lt selects
+    expand = 3 + 1 + 2 + probe + 4                                      # test, step, candidate select, probe, interval / value selects
+    shrink = PHILOX + U52 + 3 + 2 + probe + 13                          # attempt's block, candidate, select, probe, compares and interval updates
+    per = fixed + 2 * probe + (nl - 1 + nr - 1) * expand + ns * shrink + 4
+    return {"per_probe": probe, "fixed_per_coordinate": fixed, "per_expansion": expand, "per_shrink_attempt": shrink,
+            "probes": {"left": nl, "right": nr, "shrink": ns}, "per_wave_coordinate": per, "per_wave_transition": per * ndims, "chains_per_wave": 8}
 
 
 # ---- the same budgets weighted by what an instruction costs the issue port -----------------------------------------------------------
@@ -112,7 +199,11 @@ _h4, _h8, _c5, _c4 = headline(4), headline(8), cfg5_hier(), cfg4_logistic()
 BUDGETS = {"headline_4lane": _with_extra(_h4, _h4["pair_evaluations_per_lane"] * PAIR_EXTRA),
            "headline_8lane": _with_extra(_h8, _h8["pair_evaluations_per_lane"] * PAIR_EXTRA),
            "cfg5": _with_extra(_c5, 5 * PAIR_EXTRA),                                        # a lane's Philox / Box-Muller evaluations
-           "cfg4": _with_extra(_c4, 1 * PAIR_EXTRA + _c4["rows_per_lane"] * QUARTER_EXTRA + 5 * QUARTER_EXTRA)}   # + one v_rcp_f64 per row and per prior division
+           "cfg4": _with_extra(_c4, 1 * PAIR_EXTRA + _c4["rows_per_lane"] * QUARTER_EXTRA + 5 * QUARTER_EXTRA),   # + one v_rcp_f64 per row and per prior division
+           "cfg1": _with_extra(cfg1_replicas(), 2 * 20 * MAD_EXTRA + QUARTER_EXTRA),
+           "hmc_iso": _with_extra(hmc_iso(), hmc_iso()["pair_evaluations_per_lane"] * PAIR_EXTRA),
+           "slice_d100": _with_extra(slice_diag(), 100 * (1 + SLICE_PROBES["per_chain"][2]) * 20 * MAD_EXTRA),
+           "slice_d100_lockstep": _with_extra(slice_diag(counts=SLICE_PROBES["max_over_8_chains"]), 100 * (1 + SLICE_PROBES["max_over_8_chains"][2]) * 20 * MAD_EXTRA)}
 
 if __name__ == "__main__":
     print(f"building blocks: Philox4x32-10 {PHILOX}, u52 {U52}, log(u) {LOG_U01}, radius {SQRT_RAD}, sin/cos {SINCOS}, normal pair {NORMAL_PAIR}, "

@@ -57,3 +57,18 @@ def klib():
 def gpu_required():
     if not _gpu_available():
         pytest.fail("-m gpu tests need a GPU: torch.cuda.is_available() is False")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """KLARA_DEBUG_CANARY=1 (tests/test_gpu_canary.py runs the sweeps that way): whatever is still alive at the end of the session must have
+    intact canaries too — a damaged one fails the run."""
+    if os.environ.get("KLARA_DEBUG_CANARY") != "1" or not _gpu_available():
+        return
+    import ctypes as C
+    import klara_jl_amd
+    lib = klara_jl_amd._lib.load()
+    na, nc = C.c_int64(0), C.c_int64(0)
+    st = lib.klara_selftest_canary(0, C.byref(na), C.byref(nc))
+    print(f"\n[klara canary] {na.value} live device arrays checked at session end, {nc.value} with damaged canaries (status {st})")
+    if st != 0 or nc.value != 0:
+        session.exitstatus = 1

@@ -160,7 +160,7 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
         return (0, 1, e)
     if target_kind == L.TARGET_LOGISTIC:
         e = 2 if d <= 2 else 4 if d <= 4 else 8
-        return (2, 8 if ndata >= 128 else 4, e) if ndata >= 64 else (0, 1, e)
+        return (2, 4, e) if ndata >= 64 else (0, 1, e)
     def p2(v):
         g = 1
         while g < v:

@@ -38,6 +38,11 @@ def test_device_math_bit_exact(klib):
                            np.nextafter(np.arange(1, 2000, dtype=np.float64) ** 2 / 64.0, 0.0),
                            np.nextafter(np.arange(1, 2000, dtype=np.float64) ** 2 / 64.0, 100.0),
                            np.arange(1, 2000, dtype=np.float64) ** 2 / 64.0, [2.2e-16, 73.47]]),
+        # the logistic rows' functions: exp(-a), the softplus / logistic pair, log on [1, 2]
+        9: np.concatenate([rng.uniform(0, 750, n), rng.uniform(0, 40, n), [0.0, 708.0, 708.5, 1e9, np.inf]]),
+        10: np.concatenate([rng.uniform(-750, 750, n), rng.uniform(-40, 40, n), [0.0, -0.0, np.nan, 800.0, -800.0]]),
+        11: np.concatenate([rng.uniform(-750, 750, n), rng.uniform(-40, 40, n), [0.0, -0.0, np.nan, 800.0, -800.0]]),
+        12: np.concatenate([1.0 + rng.random(n), 1.0 + rng.random(n) * 2.0 ** -7, [1.0, 2.0, 1.0078125, 2.0 - 2.0 ** -52]]),
     }
     for op, x in sets.items():
         x = np.ascontiguousarray(x)

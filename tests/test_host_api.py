@@ -318,10 +318,22 @@ def test_instruction_budgets_follow_from_their_parts():
     assert h8["per_wave_transition"] == 6.25 * 138 + 27 + 9 + 3
     c5, c4 = B.BUDGETS["cfg5"], B.BUDGETS["cfg4"]
     assert c5["per_leapfrog"] == 26 + 4 * 21 + 45 + 50 + 13 == 218 and c5["per_wave_transition"] == 7818 and c5["normals"] == 5 * 102 + 14
-    assert c4["per_row"] == 74 and c4["per_wave_transition"] == 25 * 74 + 54 + 64 + 114 + 60 + 12 == 2154
+    # cfg 4 (round 4): 4 lanes per chain, 50 rows per lane; a row = Xp (4) + exp(-|Xp|) (18) + 1 + t (1) + log on [1, 2] (12) + softplus (2) + numerator select (3)
+    # + division (8) + Xp y (2) + sum (1) + residual (1) + gradient (4) + row offset (1)
+    assert (B.EXP_NEG, B.LOG12, B.DIV_UNIT) == (18, 12, 8)
+    assert c4["per_row"] == 4 + 18 + 1 + 12 + 2 + 3 + 8 + 2 + 1 + 1 + 4 + 1 == 57 and c4["rows_per_lane"] == 50 and c4["chains_per_wave"] == 16
+    assert c4["per_wave_transition"] == 50 * 57 + 36 + 64 + 114 + 60 + 12 == 3136
+    # round 4: budgets for the kernels whose fraction used to be null
+    c1, hi, sl, sll = B.BUDGETS["cfg1"], B.BUDGETS["hmc_iso"], B.BUDGETS["slice_d100"], B.BUDGETS["slice_d100_lockstep"]
+    assert c1["per_wave_transition"] == 102 + 4 + 5 + 72 + 6 + 13 + 2 == 204 and c1["chains_per_wave"] == 64
+    assert hi["per_pair"] == 102 + 8 + 2 + 60 + 4 == 176 and hi["per_wave_transition"] == 6.25 * 180 + 27 + 46 + 3
+    assert sl["per_probe"] == 20.5 and sl["fixed_per_coordinate"] == 104 and sl["per_shrink_attempt"] == 83.5 and sl["per_expansion"] == 30.5
+    pc = B.slice_probe_counts()                                   # the seeded simulation of the stepping-out procedure reproduces the constants
+    assert np.allclose(pc["per_chain"], B.SLICE_PROBES["per_chain"], rtol=1e-12) and np.allclose(pc["max_over_8_chains"], B.SLICE_PROBES["max_over_8_chains"], rtol=1e-12)
+    assert 2.0 < pc["per_chain"][0] < 2.3 and 1.3 < pc["per_chain"][2] < 1.6 and sll["per_wave_coordinate"] > 1.5 * sl["per_wave_coordinate"]
     # the README of profiles/ quotes these totals
     txt = (ROOT / "profiles" / "README.md").read_text()
-    for v in ("1,776", "7,818", "2,154"):
+    for v in ("1,776", "7,818", "3,136"):
         assert v in txt, v
 
 

@@ -64,17 +64,41 @@ def test_detmath_accuracy_vs_libm():
 
 
 def test_softplus_logistic_pair():
-    """kd_exp_neg(a) = kd_exp(-a) bit for bit up to 708 and 0 beyond; log(1 + exp(x)) and 1 / (1 + exp(-x)) from it against
-    160-bit arithmetic (the logistic rows, doc/examples/swiss/MALA/analytical.jl:13,17: 2 ulp of max(value, 1) for the first, 2 ulp for the second),
+    """The functions of the logistic targets' data rows (doc/examples/swiss/MALA/analytical.jl:13,17) against 160-bit arithmetic:
+    kd_exp_neg(a) = exp(-a) within 0.51 ulp up to a = 708 (Arm-style reduction: round-to-nearest k from the low mantissa bits of one fma),
+    clamped to exp(-708) beyond; kd_log12 on [1, 2]: absolute error below 1.5 * 2^-53, log12(1) = 0 exactly, full relative accuracy towards 1;
+    log(1 + exp(x)) and 1 / (1 + exp(-x)) from ONE exponential: 2 ulp of max(value, 1) for the first, 2 ulp for the second; never negative,
     exact limits for large |x|, NaN passed through."""
     import mpmath
-    rng = np.random.default_rng(7)
-    a = np.concatenate([rng.uniform(0, 708, 200000), rng.uniform(0, 40, 100000), [0.0, 708.0, 1e-300, 37.5]])
-    assert np.array_equal(O.math_op(9, a), O.math_op(1, -a))
-    assert np.all(O.math_op(9, np.array([708.0000001, 745.0, 1e9, np.inf])) == 0.0)
-    x = np.concatenate([rng.uniform(-40, 40, 4000), rng.uniform(-750, 750, 500), [0.0, -0.0, 1e-320, 800.0, -800.0]])
-    sp, lg = O.math_op(10, x), O.math_op(11, x)
     mpmath.mp.prec = 160
+    rng = np.random.default_rng(7)
+    a = np.concatenate([rng.uniform(0, 708, 200000), rng.uniform(0, 40, 100000), rng.uniform(0, 1, 50000), [0.0, 708.0, 1e-300, 37.5]])
+    got = O.math_op(9, a)
+    assert np.all(np.abs(got - np.exp(-a)) <= np.spacing(np.exp(-a)))                  # within 1 ulp of libm everywhere
+    worst = 0.0
+    for ai, gi in zip(a[::53], got[::53]):
+        e = mpmath.exp(-mpmath.mpf(float(ai)))
+        worst = max(worst, float(abs(mpmath.mpf(float(gi)) - e) / mpmath.mpf(float(np.spacing(float(e))))))
+    assert worst <= 0.51, worst
+    assert O.math_op(9, np.array([0.0]))[0] == 1.0
+    assert np.all(O.math_op(9, np.array([708.0000001, 745.0, 1e9, np.inf])) == O.math_op(9, np.array([708.0]))[0])     # clamped, a normal number
+    assert 3.3e-308 < O.math_op(9, np.array([708.0]))[0] < 3.4e-308
+    # kd_log12
+    x12 = np.concatenate([1.0 + rng.random(200000), 1.0 + rng.random(50000) * 2.0 ** -7, 1.0 + 2.0 ** -rng.uniform(8, 52, 20000),
+                          [1.0, 2.0, 1.0 + 2.0 ** -52, 2.0 - 2.0 ** -52, 1.0078125, 1.0078125 - 2.0 ** -52, 1.375]])
+    l12 = O.math_op(12, x12)
+    assert l12[np.flatnonzero(x12 == 1.0)[0]] == 0.0 and np.all(l12 >= 0.0)
+    worst_abs = worst_rel_near_one = 0.0
+    for xi, li in zip(x12[::41].tolist() + x12[-7:].tolist(), l12[::41].tolist() + l12[-7:].tolist()):
+        t = mpmath.log(mpmath.mpf(xi))
+        worst_abs = max(worst_abs, float(abs(mpmath.mpf(li) - t) * mpmath.mpf(2) ** 53))
+        if 1.0 < xi < 1.0078125:
+            worst_rel_near_one = max(worst_rel_near_one, float(abs(mpmath.mpf(li) - t) / t * mpmath.mpf(2) ** 53))
+    assert worst_abs <= 1.5, worst_abs
+    assert worst_rel_near_one <= 3.0, worst_rel_near_one       # (bin 0: r = x - 1 exactly; the dropped r^8/8 is 2^-52 of the value at its far end)
+    x = np.concatenate([rng.uniform(-40, 40, 4000), rng.uniform(-750, 750, 500), [0.0, -0.0, 1e-320, 800.0, -800.0, 36.0, -36.5, 37.0, 1e-9, -1e-9]])
+    sp, lg = O.math_op(10, x), O.math_op(11, x)
+    assert np.all(sp >= 0.0) and np.all(lg >= 0.0) and np.all(lg <= 1.0)
     for xi, s_, l_ in zip(x, sp, lg):
         e = mpmath.exp(mpmath.mpf(float(xi)))
         ts, tl = mpmath.log(1 + e), e / (1 + e)
@@ -83,7 +107,7 @@ def test_softplus_logistic_pair():
         if abs(xi) <= 708:
             assert abs(mpmath.mpf(float(l_)) - tl) <= 2 * mpmath.mpf(float(np.spacing(abs(float(l_)) or 5e-324))), xi
         else:
-            assert l_ == (1.0 if xi > 0 else 0.0)
+            assert l_ == (1.0 if xi > 0 else O.math_op(9, np.array([708.0]))[0])
     assert np.isnan(O.math_op(10, [np.nan])[0]) and np.isnan(O.math_op(11, [np.nan])[0])
 
 
