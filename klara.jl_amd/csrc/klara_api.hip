@@ -196,7 +196,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     }
     if (d.target == KLARA_TARGET_LOGISTIC) {
         *G = 1;   // every lane holds the whole parameter vector; klara_create may turn on the row split (kind 2)
-        if (D <= 2) *E = 2; else if (D <= 4) *E = 4; else if (D <= 8) *E = 8; else return KLARA_ERR_UNSUPPORTED;
+        if (D <= 2) *E = 2; else if (D <= 4) *E = 4; else if (D <= 8) *E = 8; else if (D <= 16) *E = 16; else return KLARA_ERR_UNSUPPORTED;
         return KLARA_OK;
     }
     // diagonal Gaussian and nothing tunes: the pair-transposed layout
@@ -472,7 +472,9 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     *out = nullptr;
     klara_status st = validate(desc);
     if (st != KLARA_OK) return st;
-    if (desc->target == KLARA_TARGET_LOGISTIC && desc->ndims > 8) {
+    // the logistic regression beyond 16 parameters — or beyond 8 when its rows, padded to 16 columns, do not fit the LDS — runs as a closure
+    if (desc->target == KLARA_TARGET_LOGISTIC &&
+        (desc->ndims > 16 || (desc->ndims > 8 && (size_t)desc->logit_ndata * 17 > KLARA_LOGIT_MAX_LDS_DOUBLES))) {
         if (desc->ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
         if (desc->monitor & KLARA_MON_HIST_LLLP) return KLARA_ERR_UNSUPPORTED;
         const size_t n = (size_t)desc->logit_ndata, D = (size_t)desc->ndims;
@@ -776,6 +778,7 @@ static hipError_t launch_init_t(const KParams& p, int E, int G, int needgrad, di
     else if (E == 2) KLARA_INIT_LAUNCH(2, 0);
     else if (E == 4) KLARA_INIT_LAUNCH(4, 0);
     else if (E == 8 && TARGET != KLARA_TARGET_HIER_NORMAL) KLARA_INIT_LAUNCH((TARGET == KLARA_TARGET_HIER_NORMAL ? 4 : 8), 0);
+    else if (E == 16 && TARGET == KLARA_TARGET_LOGISTIC) KLARA_INIT_LAUNCH((TARGET == KLARA_TARGET_LOGISTIC ? 16 : 2), 0);
     else return hipErrorInvalidValue;
 #undef KLARA_INIT_LAUNCH
     return hipGetLastError();

@@ -56,6 +56,9 @@ template <int N> struct KInt { static constexpr int value = N; };
 #ifndef KLARA_E4_WAVES_LOGISTIC_HMC
 #define KLARA_E4_WAVES_LOGISTIC_HMC 2
 #endif
+#ifndef KLARA_E8_WAVES_LOGISTIC
+#define KLARA_E8_WAVES_LOGISTIC 1   /* 5 .. 8 parameters: 294 registers at one wavefront per SIMD */
+#endif
 #ifndef KLARA_E4_WAVES_PLAIN
 #define KLARA_E4_WAVES_PLAIN 3   // the specialised (no tuner, no monitor) E=4 kernels fit 168 VGPRs
 #endif
@@ -352,19 +355,25 @@ __device__ __forceinline__ void lane_normals(const LaneCtx<E>& c, unsigned long 
     // of the accept draw.  Lane rq evaluates ONE block instead — slot rq & 3 — and the four lanes of a quad exchange the results: one
     // Philox + Box-Muller evaluation per lane and transition instead of E/2 + 1 (cfg 4, E = 4: 102 + 12 instead of 204 + ~70 vector
     // instructions of a ~2,650-instruction transition).  The same blocks, the same functions: no bit changes.
-    if constexpr (E <= 8) {
+    if constexpr (E <= 16) {
         if (c.RS >= 4) {
-            double z0, z1, u1, lg1;
-            kd_normal_pair_ex(kd_stream_block(seed, gchain, t, (uint32_t)(c.rq & 3)), &z0, &z1, &u1, &lg1);
+            constexpr int NB = (E / 2 + 3) / 4;        // blocks per lane: 1 up to E = 8, 2 at E = 16 (slots rq & 3 and 4 + (rq & 3))
+            double z0[NB], z1[NB], u1[NB], lg1[NB];
+#pragma unroll
+            for (int m = 0; m < NB; ++m)
+                kd_normal_pair_ex(kd_stream_block(seed, gchain, t, (uint32_t)((c.rq & 3) + 4 * m)), &z0[m], &z1[m], &u1[m], &lg1[m]);
 KLARA_PRAGMA_UNROLL_E
             for (int j = 0; j < E / 2; ++j) {
-                const double a = quad_bcast(z0, j), b = quad_bcast(z1, j);
+                const double a = quad_bcast(z0[j >> 2], j & 3), b = quad_bcast(z1[j >> 2], j & 3);
                 z[2 * j] = c.valid[2 * j] ? a : 0.0;
                 z[2 * j + 1] = c.valid[2 * j + 1] ? b : 0.0;
             }
-            if (acc_slot >= 0 && acc_slot < 4) {
-                const int src = (c.lane & ~3) | acc_slot;
-                ad.u = lane_bcast(u1, src); ad.logu = lane_bcast(lg1, src); ad.have = true;
+            if (acc_slot >= 0 && acc_slot < 4 * NB) {
+                const int src = (c.lane & ~3) | (acc_slot & 3);
+                double us = u1[0], ls = lg1[0];
+#pragma unroll
+                for (int m = 1; m < NB; ++m) if ((acc_slot >> 2) == m) { us = u1[m]; ls = lg1[m]; }
+                ad.u = lane_bcast(us, src); ad.logu = lane_bcast(ls, src); ad.have = true;
             }
             return;
         }
@@ -1060,7 +1069,8 @@ template <int SAMPLER, int TARGET, int E, int GT, int MODE>
 __global__ __launch_bounds__(256, (TARGET == KLARA_TARGET_CUSTOM && GT > 1 ? 2 /* staged closures: two workgroups' rows fit a CU's LDS */ :
                                    E == 2 ? 3 : (E == 4 ? (TARGET == KLARA_TARGET_LOGISTIC && SAMPLER == KLARA_SAMPLER_MALA ? KLARA_E4_WAVES_LOGISTIC
                                                                   : TARGET == KLARA_TARGET_LOGISTIC && SAMPLER == KLARA_SAMPLER_HMC ? KLARA_E4_WAVES_LOGISTIC_HMC
-                                                                  : ((MODE & 3) == 3 ? KLARA_E4_WAVES_PLAIN : KLARA_E4_WAVES)) : 1)))
+                                                                  : ((MODE & 3) == 3 ? KLARA_E4_WAVES_PLAIN : KLARA_E4_WAVES))
+                                                  : (E == 8 && TARGET == KLARA_TARGET_LOGISTIC ? KLARA_E8_WAVES_LOGISTIC : 1))))
 void k_transitions(const KParams* __restrict__ pp, const KLaunch kl)
 {
     constexpr bool PLAIN = (MODE & 1) != 0, NOMON = (MODE & 2) != 0;

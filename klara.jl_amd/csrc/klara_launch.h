@@ -177,6 +177,7 @@ const char* klara_jit_log();
             if (E == 2) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_LOGISTIC, 2, 0);              \
             else if (E == 4) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_LOGISTIC, 4, 0);         \
             else if (E == 8) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_LOGISTIC, 8, 0);         \
+            else if (E == 16) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_LOGISTIC, 16, 0);       \
             else return hipErrorInvalidValue;                                                          \
         } else if (target == KLARA_TARGET_HIER_NORMAL) {                                               \
             if (E == 2) KLARA_LAUNCH_T(SAMPLER, KLARA_TARGET_HIER_NORMAL, 2, 0);           \

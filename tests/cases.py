@@ -350,11 +350,15 @@ def make_case(name):
         c = dict(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, 100.0), nchains=70, nsteps=40, burnin=10,
                  driftstep=0.1, x0=x0[None, :] + 0.1 * np.random.default_rng(1).standard_normal((70, 4)))
     elif name in ("mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small", "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide",
-                  "hmc_logit_d20_wide"):
+                  "hmc_logit_d20_wide", "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"):
         # synthetic logistic data: E = 2 / 4 / 8 (D = 3, 6, 7: rows padded to E columns in LDS), with and without row split; 1,500 x 9
         # doubles = 108 KB of rows: beyond the 56 KB a launch gets by default
         d, nd = {"mala_logit_d2": (2, 90), "hmc_logit_d7": (7, 131), "mh_logit_d8_small": (8, 30), "mala_logit_d6_bigdata": (6, 1500),
-                 "slice_logit_d3": (3, 75), "mala_logit_d12_wide": (12, 150), "hmc_logit_d20_wide": (20, 400)}[name]   # D > 8: closure form
+                 "slice_logit_d3": (3, 75), "mala_logit_d12_wide": (12, 150), "hmc_logit_d20_wide": (20, 400),   # D > 16: closure form
+                 # round 4: 9 .. 16 parameters on the row-split kernels (E = 16: two Philox blocks per lane, accept slots 5 .. 8), unsplit below 64
+                 # rows, and back on the closure form when the rows do not fit the LDS
+                 "hmc_logit_d16_rows": (16, 150), "mh_logit_d9_rows": (9, 131), "slice_logit_d13_rows": (13, 70), "mala_logit_d11_unsplit": (11, 40),
+                 "mala_logit_d12_manyrows": (12, 1100)}[name]
         rng = np.random.default_rng(d)
         X = rng.standard_normal((nd, d)); beta = rng.standard_normal(d)
         y = (rng.random(nd) < 1.0 / (1.0 + np.exp(-X @ beta))).astype(np.float64)
@@ -363,7 +367,12 @@ def make_case(name):
               "mala_logit_d6_bigdata": dict(sampler=L.SAMPLER_MALA, driftstep=0.002),
               "slice_logit_d3": dict(sampler=L.SAMPLER_SLICE, slice_widths=np.full(3, 0.8)),
               "mala_logit_d12_wide": dict(sampler=L.SAMPLER_MALA, driftstep=0.01, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=5),
-              "hmc_logit_d20_wide": dict(sampler=L.SAMPLER_HMC, leapstep=0.07, nleaps=5)}[name]
+              "hmc_logit_d20_wide": dict(sampler=L.SAMPLER_HMC, leapstep=0.07, nleaps=5),
+              "hmc_logit_d16_rows": dict(sampler=L.SAMPLER_HMC, leapstep=0.05, nleaps=4, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=15),
+              "mh_logit_d9_rows": dict(sampler=L.SAMPLER_MH, mh_sigma=np.full(9, 0.15)),
+              "slice_logit_d13_rows": dict(sampler=L.SAMPLER_SLICE, slice_widths=np.full(13, 0.7)),
+              "mala_logit_d11_unsplit": dict(sampler=L.SAMPLER_MALA, driftstep=0.02),
+              "mala_logit_d12_manyrows": dict(sampler=L.SAMPLER_MALA, driftstep=0.002)}[name]
         c = dict(target=K.LogisticTarget(X, y, 10.0), nchains=45, nsteps=25, burnin=5, x0=0.1 * rng.standard_normal((45, d)), **kw)
     elif name == "hmc_swiss":
         X, y = swiss_data()
@@ -563,7 +572,8 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg",
              "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "hmc_dense_d100_mean", "mala_dense_d37_mean", "mh_dense_d20_mean",
              "hmc_dense_d70_mean_dualavg", "slice_dense_d20", "slice_dense_d37_mean", "mh_dense_d130_wide", "hmc_dense_d130_wide", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
-             "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide", "hmc_logit_d20_wide", "slice_d20_stepout", "mh_rats", "mala_rats_tuned"] + [
+             "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide", "hmc_logit_d20_wide", "slice_d20_stepout", "mh_rats", "mala_rats_tuned",
+             "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"] + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
              "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
              "custom_quartic_mala_d64", "custom_quartic_mala_d100", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh",

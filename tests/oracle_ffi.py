@@ -153,13 +153,13 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     if target_kind == L.TARGET_GAUSS_DENSE:
         ne = 8 if d <= 32 else 16 if d <= 64 else 25 if d <= 100 else 32
         return (1, 4, ne)
-    if target_kind == L.TARGET_LOGISTIC and d > 8:     # beyond 8 parameters: the run-time compiled closure form, one chain per lane
+    if target_kind == L.TARGET_LOGISTIC and (d > 16 or (d > 8 and ndata * 17 > 18432)):     # beyond 16 parameters (or rows that do not fit the LDS): the run-time compiled closure form, one chain per lane
         e = 16
         while e < d:
             e *= 2
         return (0, 1, e)
     if target_kind == L.TARGET_LOGISTIC:
-        e = 2 if d <= 2 else 4 if d <= 4 else 8
+        e = 2 if d <= 2 else 4 if d <= 4 else 8 if d <= 8 else 16
         return (2, 4, e) if ndata >= 64 else (0, 1, e)
     def p2(v):
         g = 1

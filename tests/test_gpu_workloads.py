@@ -228,7 +228,7 @@ def test_cfg5_rats_hmc_full_size_against_the_oracle():
 def test_cfg4_swiss_mala_full_size_against_the_oracle():
     """BASELINE cfg 4, one GPU's share, as SURVEY 8(d) states it: Bayesian logistic regression on the swiss data (lambda = 100,
     doc/examples/swiss/MALA/analytical.jl), MALA driftstep 0.1, VanillaMCTuner, 32,768 chains (= 262,144 / 8), 10,000 steps, burn-in
-    1,000, x0 = (5.1, -0.9, 8.2, -4.5) + 0.1 N(0, I) per chain, running sums on — the row-split kernel at 4 wavefronts per SIMD that
+    1,000, x0 = (5.1, -0.9, 8.2, -4.5) + 0.1 N(0, I) per chain, running sums on — the row-split kernel (4 lanes per chain, rows in batches, 2 wavefronts per SIMD) that
     bench.py times.  Three blocks of 8 chains (first, middle, the ragged last wavefront group) are replayed by the oracle bit for bit:
     accept masks of all 10,000 transitions, final x / logtarget / gradient, running sums; the pooled posterior matches the Laplace
     approximation (MAP + inverse Hessian from SciPy on the same data)."""
@@ -240,7 +240,7 @@ def test_cfg4_swiss_mala_full_size_against_the_oracle():
     x0 = np.array([5.1, -0.9, 8.2, -4.5])[None, :] + 0.1 * rng.standard_normal((n, 4))
     kw = dict(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, lam), nsteps=nsteps, burnin=burnin, driftstep=0.1)
     eng = K.Engine(nchains=n, monitor=L.MON_SUMMARIES | L.MON_ACCEPT, **kw)
-    assert eng.layout() == (2, 8, 4)
+    assert eng.layout() == (2, 4, 4)
     eng.set_state(x0)
     eng.run(nsteps)
     mask = eng.accept_mask()
