@@ -23,7 +23,7 @@ Prints ONE JSON line (rank 0).  Keys beyond the driver's contract:
                 functions and of the sampler arithmetic, derivation in profiles/README.md) x 4 issue cycles / the mean launch
                 duration measured HERE with HIP events on the launch stream (one launch at a time, nstreams = 1); `peak` = 1024
                 SIMDs x 2.4 GHz.  `utilisation` is the VALU-busy fraction (SQ_ACTIVE_INST_VALU of the committed PMC summary
-                profiles/r3_pmc_kernels.json / the same duration) and `issued_over_necessary` the instructions the kernel really
+                profiles/r4_pmc_kernels.json / the same duration) and `issued_over_necessary` the instructions the kernel really
                 issues (SQ_INSTS_VALU) over the budget; `pmc.stale` is true when the loaded kernel's registers / scratch differ
                 from the ones the counters were collected on.  `hbm` gives the byte side: SURVEY section 8(d)'s contract bytes,
                 the bytes this kernel has to move, the PMC traffic and the fraction of 8 TB/s each amounts to.
@@ -49,7 +49,7 @@ CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock; 256 CUs x 4 SIMDs
 NSIMD = 1024
 # How the running sums of a moving chain are kept (4-lane kernels + atomic folds, or 8-lane kernels + resident sums) is decided by the
 # library itself, on the device, launch by launch (klara_desc.sparse_moves = 0): no caller hint.
-PMC_JSON = ROOT / "profiles" / "r3_pmc_kernels.json"
+PMC_JSON = ROOT / "profiles" / "r4_pmc_kernels.json"
 PMC_EXPECT = {}             # filled by main(): the launch length the committed counters must have been collected at
 
 
