@@ -443,7 +443,7 @@ def extra_measurements(K, L, n, stream):
     # -- HMC L=10 eps=0.1 on the README target (VALU) and on the dense target (FP64 MFMA; cfg 3)
     e = K.Engine(sampler=L.SAMPLER_HMC, target=neg, nchains=n, nsteps=10 ** 7, leapstep=0.1, nleaps=10, stream=stream, nstreams=1)
     e.init_state_normal()
-    rate, ls, _ = timed_rate(e, n, 32, 128)
+    rate, ls, _ = timed_rate(e, n, 512, 512)      # (~13 ms of warm-up: a device that idled while the job was created ramps its clocks for ~20 ms)
     lay = e.layout(); at = attrs_of(e, 32); e.close()
     ex["hmc_iso_leapfrog_chain_per_s"] = rate * 10
     bh = bud["hmc_iso"]
@@ -474,6 +474,24 @@ def extra_measurements(K, L, n, stream):
         rf["mfma_pipe_source"] = f"SQ_VALU_MFMA_BUSY_CYCLES per launch ({PMC_JSON.relative_to(ROOT)}) / 1024 SIMDs / (launch duration x 2.4 GHz)"
     ex["cfg3_hmc_dense_roofline"] = rf
 
+    # -- the same sampler on a dense 256 x 256 precision: beyond what fits the LDS, P streamed from L2 through a register ring, the momentum in
+    # LDS, one wavefront per SIMD (klara_dense_big.h; round 4)
+    try:
+        D2 = 256
+        e = K.Engine(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget.compound_symmetric(D2, 0.5), nchains=n, nsteps=10 ** 7,
+                     leapstep=0.05, nleaps=10, steps_per_launch=16, stream=stream)
+        e.init_state_normal()
+        rate, ls, _ = timed_rate(e, n, 16, 32)
+        lay2 = e.layout(); e.close()
+        tf2 = n * 16 * 10 * (2 * D2 * D2 + 6 * D2) / ls / 1e12
+        ex["hmc_dense_d256_leapfrog_chain_per_s"] = rate * 10
+        ex["hmc_dense_d256_roofline"] = {"bound": "mfma", "achieved": tf2, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf2 / FP64_MFMA_PEAK_TF,
+                                         "kernel": f"k_dense_hmc_big<NE={lay2[2]}> (v_mfma_f64_16x16x4, A fragments streamed from memory), 16 transitions per launch",
+                                         "launch_us": ls * 1e6,
+                                         "source": "algorithmic flops (2 D^2 + 6 D per leapfrog and chain) / launch duration from HIP events in this run"}
+    except Exception as exc:
+        ex["hmc_dense_d256_error"] = repr(exc)
+
     # -- slice sampler on the README target, D = 100
     e = K.Engine(sampler=L.SAMPLER_SLICE, target=neg, nchains=n, nsteps=10 ** 7, slice_widths=np.full(NDIMS, 1.0), steps_per_launch=4,
                  stream=stream, nstreams=1)
@@ -503,7 +521,7 @@ def extra_measurements(K, L, n, stream):
         e = K.Engine(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, 100.0), nchains=nc, nsteps=10 ** 6, burnin=1000, driftstep=0.1,
                      steps_per_launch=50, monitor=L.MON_SUMMARIES, stream=stream)
         e.set_state(x0)
-        rate, ls, _ = timed_rate(e, nc, 100, 500)
+        rate, ls, _ = timed_rate(e, nc, 1000, 1000)      # (~16 ms of warm-up, see above: the first 500 transitions of this job run 10 % below its steady rate)
         at = attrs_of(e, 50); lay4 = e.layout(); e.close()
         ex["cfg4_swiss_logistic_mala_transitions_per_s_per_gpu"] = rate
         assert lay4[:2] == (2, 64 // bud["cfg4"]["chains_per_wave"]), lay4      # (the budget's lanes per chain are the job's row split)

@@ -167,6 +167,14 @@ static void custom_layout(int D, int lanes, bool lik_prior, int* G, int* E, int*
 }
 static bool custom_lik_prior(const char* src) { return src != nullptr && strstr(src, "KLARA_USER_LIKELIHOOD_PRIOR") != nullptr; }
 
+// the dense Gaussian beyond the LDS-resident layouts (D = 129 .. 256) stays on the matrix cores for HMC with the Vanilla / AcceptanceRate
+// tuners (klara_dense_big.h); every other sampler / tuner there takes the closure form (klara_create)
+static bool dense_streamed(const klara_desc& d)
+{
+    return d.target == KLARA_TARGET_GAUSS_DENSE && d.ndims > 128 && d.ndims <= 256 && d.sampler == KLARA_SAMPLER_HMC &&
+           d.tuner != KLARA_TUNER_DUAL_AVERAGING && getenv("KLARA_DENSE_NO_STREAM") == nullptr;
+}
+
 static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E, int custom_lanes = 0, int* custom_wpb = nullptr)
 {
     if (hiert_eligible(d)) { *kind = 4; *G = 8; *E = 8; return KLARA_OK; }
@@ -174,6 +182,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     if (d.target == KLARA_TARGET_GAUSS_DENSE) {
         *kind = 1; *G = 4;
         if (D <= 32) *E = 8; else if (D <= 64) *E = 16; else if (D <= 100) *E = 25; else if (D <= 128) *E = 32;
+        else if (dense_streamed(d)) *E = 8 * ((D + 31) / 32);       // HMC to D = 256 (NE = 40, 48, 56, 64): P streamed from memory, momentum in LDS (klara_dense_big.h)
         else return KLARA_ERR_UNSUPPORTED;
         return KLARA_OK;
     }
@@ -488,7 +497,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         dd.logit_X = nullptr; dd.logit_y = nullptr; dd.logit_ndata = 0;
         return create_impl(&dd, out, 1);
     }
-    if (desc->target == KLARA_TARGET_GAUSS_DENSE && desc->ndims > 128) {
+    if (desc->target == KLARA_TARGET_GAUSS_DENSE && desc->ndims > 128 && !dense_streamed(*desc)) {
         if (desc->ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
         if (desc->monitor & KLARA_MON_HIST_LLLP) return KLARA_ERR_UNSUPPORTED;
         const size_t D = (size_t)desc->ndims;
@@ -656,11 +665,14 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
         std::vector<double> frag((size_t)MT * NE * 64, 0.0);
         // (NE % 4 == 1: the last tile is the 4-row tail for v_mfma_f64_4x4x4_4b, A_b[i][k] on lane 16k + 4b + i)
         const bool tail = (NE % 4) == 1;
+        // tile-major (t, kk) for the LDS-resident layouts; k-major (kk, t) — the order of consumption — for the streamed ones (NE > 32)
+        const bool kmajor = NE > 32;
         for (int t = 0; t < MT; ++t)
             for (int kk = 0; kk < NE; ++kk)
                 for (int l = 0; l < 64; ++l) {
                     const size_t row = 16 * (size_t)t + ((tail && t == MT - 1) ? (l & 3) : (l & 15)), col = 4 * (size_t)kk + (l >> 4);
-                    if (row < D && col < D) frag[((size_t)t * NE + kk) * 64 + l] = desc->gauss_prec[row * D + col];
+                    const size_t f = kmajor ? (size_t)kk * MT + t : (size_t)t * NE + kk;
+                    if (row < D && col < D) frag[f * 64 + l] = desc->gauss_prec[row * D + col];
                 }
         h->dense_mu = desc->gauss_mu != nullptr;
         if (h->dense_mu) {                                       // the mean, [4 e + q] = mu[4 e + q], zero beyond D
@@ -735,7 +747,7 @@ static dim3 grid_for(const klara_handle* h)
 {
     const long long cpw = h->kind == 1 ? 16 : 64 / (h->G * h->RS);
     const long long waves = (h->d.nchains + cpw - 1) / cpw;
-    const long long wpb = h->kind == 1 ? 8 : h->custom_wpb;
+    const long long wpb = h->kind == 1 ? (h->E > 32 ? 4 : 8) : h->custom_wpb;      // (streamed dense layouts: one wavefront per SIMD, workgroups of 4)
     return dim3((unsigned)((waves + wpb - 1) / wpb));
 }
 

@@ -567,6 +567,7 @@ __global__ __launch_bounds__(512) void k_dense_init(const KParams p, const doubl
     if (bad) klara_raise(p.error_flag, KLARA_ERR_NONFINITE_INIT);
 }
 
+#ifndef KLARA_DENSE_NO_PROBES     // (non-template kernels: one translation unit only)
 // test hook: one v_mfma_f64_4x4x4_4b with per-lane operands (lane layout and accumulation order are pinned by tests)
 __global__ void k_mfma_f64_4x4x4_probe(const double* A, const double* B, const double* C, double* Dout)
 {
@@ -588,3 +589,4 @@ __global__ void k_mfma_f64_probe(const double* A, const double* B, const double*
 #pragma unroll
     for (int r = 0; r < 4; ++r) Dout[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = c[r];
 }
+#endif

@@ -1,0 +1,296 @@
+// klara_dense_big.h — HMC on the dense-Gaussian target beyond D = 128 on the FP64 matrix cores (NE = 8 ceil(D / 32) = 40, 48, 56, 64 elements per lane).
+//
+// What changes against klara_dense.h (D <= 128: P in LDS, three NE-element vectors per lane in 256 registers, 2 wavefronts per SIMD):
+//   * P no longer fits the LDS (D = 256: 512 KB).  The A fragments are STREAMED from memory in the order of consumption — fragment array in
+//     k-major order, ((kk * MT + t) * 64 + lane): consecutive 512-byte lines — through a ring of KLARA_DENSE_RING fragments per lane: the load
+//     of step s + RING is issued when step s is consumed, ~RING x 64 MFMA cycles ahead of its use.  Every wavefront of every CU reads P in the
+//     same order, so it lives in the L2s and the wavefronts of a CU share its lines in the L1.  No LDS staging, no barriers.
+//   * A lane's vectors no longer fit 256 registers, and a 512-register wavefront has 256 ARCHITECTURAL + 256 ACCUMULATOR registers, of which
+//     only MFMA operands / results can use the second half.  So: ONE wavefront per SIMD (workgroups of 4); the value x in architectural
+//     registers (it is the MFMA's B operand and the target of the drift), the gradient P x in the accumulators (it IS the MFMA result), and the
+//     MOMENTUM IN LDS — one private column per lane, momw[e * 64] —, touched twice per leapfrog (64 ds_read + 64 ds_write per lane against
+//     1,024 MFMAs).
+//   * HMC only (Vanilla / AcceptanceRate tuners, per chain or pooled; every monitor): it is the configuration the matrix cores are for
+//     (north_star: "MFMA used only where the logtarget is a dense contraction"; BASELINE cfg 3).  MALA / MH / slice / dual averaging beyond
+//     D = 128 stay on the closure form (klara_api.hip KLARA_DENSE_WIDE_SRC).
+// Same MFMA instruction, same k-ascending fma chain per output (zero-padded rows / columns add exact zeros), same merged fma leapfrog, same
+// 4-lane reduction tree: the oracle's ko_hmc / ko_dense_grad in layout kind 1, bit for bit.
+#pragma once
+#include "klara_dense.h"
+
+#ifndef KLARA_DENSE_RING
+#define KLARA_DENSE_RING 8
+#endif
+
+// acc[t] (tile t: elements 4t .. 4t+3 of the lane) = +P (x - mu), from zero
+template <int NE, bool HASMU>
+__device__ __forceinline__ void dense_stream(const double* __restrict__ gP, int lane, const double (&x)[NE], kd_double4 (&acc)[NE / 4],
+                                             const double* ldsMu)
+{
+    constexpr int MT = NE / 4, S = NE * MT, RING = KLARA_DENSE_RING;
+    static_assert(NE % 4 == 0 && S > RING, "whole 16-row tiles");
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };
+    // (P does not change during a launch, so the compiler would hoist all S fragment loads out of the leapfrog loop — 1,024 doubles per lane,
+    // i.e. into scratch; behind the empty asm the address is "new" in every call and the loads stay where they are written)
+    // (kept in the global address space: global loads return in order, so the ring is waited for one fragment at a time — vmcnt(RING - 1))
+    const gdouble* src = (const gdouble*)gP + lane;
+    __asm__ volatile("" : "+v"(src));
+    double ring[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) ring[i] = src[(size_t)i * 64];
+#pragma unroll
+    for (int kk = 0; kk < NE; ++kk) {
+        const double b = HASMU ? x[kk] - ldsMu[4 * kk + (lane >> 4)] : x[kk];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int s = kk * MT + t;
+            const double a = ring[s % RING];
+            if (s + RING < S) ring[s % RING] = src[(size_t)(s + RING) * 64];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the momentum draw of mnormals (klara_dense.h: the even / odd lanes of a chain evaluate alternate Box-Muller pairs and swap halves),
+// written to the lane's LDS column
+template <int NE>
+__device__ __forceinline__ void mnormals_lds(const MfmaCtx<NE>& c, unsigned long long seed, unsigned long long gchain, unsigned long long t,
+                                             double* momw)
+{
+    static_assert(NE % 2 == 0, "pairs of elements");
+    const uint32_t sh = (uint32_t)(c.q >> 1);
+    const bool odd = (c.q & 1) != 0;
+    const int nv = c.nv_here();
+#pragma unroll
+    for (int e = 0; e + 1 < NE; e += 2) {
+        double z0, z1;
+        const uint32_t mine = 2u * (uint32_t)(odd ? e + 1 : e) + sh;
+        kd_normal_pair(kd_stream_block(seed, gchain, t, mine), &z0, &z1);
+        const double recv = bperm_xor(odd ? z0 : z1, c.lane, 16);
+        momw[e * 64] = e < nv ? (odd ? recv : z0) : 0.0;
+        momw[(e + 1) * 64] = e + 1 < nv ? (odd ? z1 : recv) : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the lane's momentum column in LDS, touched in chunks of 8 elements: 8 reads in flight, then the 8 updates (one ds_read per element and a
+// wait after each costs the LDS latency 64 times per pass)
+#define KLARA_MOM_CHUNK 8
+template <int NE, class F>
+__device__ __forceinline__ void mom_read(const double* momw, F f)
+{
+    static_assert(NE % KLARA_MOM_CHUNK == 0, "whole chunks");
+#pragma unroll
+    for (int e0 = 0; e0 < NE; e0 += KLARA_MOM_CHUNK) {
+        double m[KLARA_MOM_CHUNK];
+#pragma unroll
+        for (int j = 0; j < KLARA_MOM_CHUNK; ++j) m[j] = momw[(e0 + j) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KLARA_MOM_CHUNK; ++j) f(e0 + j, m[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int NE, class F>
+__device__ __forceinline__ void mom_update(double* momw, F f)       // m = f(e, m)
+{
+#pragma unroll
+    for (int e0 = 0; e0 < NE; e0 += KLARA_MOM_CHUNK) {
+        double m[KLARA_MOM_CHUNK];
+#pragma unroll
+        for (int j = 0; j < KLARA_MOM_CHUNK; ++j) m[j] = momw[(e0 + j) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KLARA_MOM_CHUNK; ++j) momw[(e0 + j) * 64] = f(e0 + j, m[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NE, bool HASMU = false>
+__global__ __launch_bounds__(256)
+void k_dense_hmc_big(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
+{
+    const KParams& p = *pp;
+    guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = NE / 4;
+    double* const ldsMuW = reinterpret_cast<double*>(smem);                     // mu[4 e + q] at [4 e + q], zero-padded (HASMU only)
+    if (HASMU) { for (int i = threadIdx.x; i < 4 * NE; i += blockDim.x) ldsMuW[i] = Pfrag[(size_t)MT * NE * 64 + i]; }
+    const double* const ldsMu = ldsMuW;
+    kd_tables_to_lds();          // (also the barrier for mu)
+    const MfmaCtx<NE> cx = make_mctx<NE>(p);
+    double* const momw = ldsMuW + (HASMU ? 4 * NE : 0) + (size_t)(threadIdx.x >> 6) * NE * 64 + cx.lane;     // this lane's momentum column
+    const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
+    const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
+    TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0, 0.0, 0.0 };
+    tn.phase = p.cnt ? (int)(tn.proposed % p.period) : 0;
+    int sphase = kl.save_phase0;
+    long long scol = kl.save_col0;
+    double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
+    unsigned long long nacc = 0;
+    const bool do_sum = p.sum != nullptr;
+    long long held = do_sum ? p.held[cx.chain_ok ? cx.chain : 0] : 0;
+    const __amdgpu_buffer_rsrc_t wX = mwin<NE>(cx, p.X, 0, p.D), wG = mwin<NE>(cx, p.GR, 0, p.D);
+
+    // the committed state of the lane's chain: value in registers, gradient in the accumulator tiles (element e = ga[e >> 2][e & 3]).  They are
+    // (re)read from memory at the start of the launch and after a rejected proposal; an accepted proposal simply stays where it is.
+    double xp[NE];
+    kd_double4 ga[MT];
+    const auto reload = [&]() {
+        const int nv = cx.nv_here();
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const unsigned o = cx.off(e, nv);
+            xp[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
+            ga[e >> 2][e & 3] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, o, 0, 0));
+        }
+    };
+    reload();
+
+    for (int s = 0; s < kl.nsteps; ++s) {
+        const unsigned long long t = kl.t0 + (unsigned long long)s;
+        if (p.cnt) tune_count_proposal(p, tn);
+        // iterate/HMC.jl:124-201, leapfrog! samplers.jl:122-134 (merged fma form: DESIGN.md section 2 (7))
+        mnormals_lds<NE>(cx, p.seed, gchain, t, momw);                           // HMC.jl:135
+        double k0[1] = { 0.0 };
+        mom_read<NE>(momw, [&](int, double m) { k0[0] = k0[0] + m * m; });
+        mreduce<1>(k0, cx.lane);
+        const double H0 = lt - 0.5 * k0[0];                                      // HMC.jl:137
+        const double eps = tn.step, halfe = 0.5 * eps;
+        mom_update<NE>(momw, [&](int e, double m) { return kd_fma(halfe, (double)ga[e >> 2][e & 3], m); });
+        const int nl = p.nleaps;
+        for (int l = 0; l < nl; ++l) {
+            mom_read<NE>(momw, [&](int e, double m) { xp[e] = kd_fma(eps, m, xp[e]); });
+            dense_stream<NE, HASMU>(Pfrag, cx.lane, xp, ga, ldsMu);              // ga = +P (x - mu)
+            const double nkf = l + 1 < nl ? -eps : -halfe;
+            mom_update<NE>(momw, [&](int e, double m) { return kd_fma(nkf, (double)ga[e >> 2][e & 3], m); });
+        }
+#pragma unroll
+        for (int tt = 0; tt < MT; ++tt) ga[tt] = -ga[tt];                        // the proposal's gradient, -P (x' - mu)
+        double red[2], l1 = 0.0, k1 = 0.0;
+        mom_read<NE>(momw, [&](int e, double m) {
+            const double d = HASMU ? xp[e] - ldsMu[4 * e + cx.q] : xp[e];
+            l1 = l1 + d * (double)ga[e >> 2][e & 3];                             // lt' = c + 1/2 (x'-mu).g'   (HMC.jl:157)
+            k1 = k1 + m * m;
+        });
+        red[0] = l1; red[1] = k1;
+        mreduce<2>(red, cx.lane);
+        const double ltp = p.gconst + 0.5 * red[0];
+        const double H1 = ltp - 0.5 * red[1];                                    // HMC.jl:159
+        const double ratio = H1 - H0;                                            // HMC.jl:161
+        const double ex = kd_exp(ratio);
+        const double a = 1.0 < ex ? 1.0 : ex;                                    // HMC.jl:163
+        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+        const bool acc = u < a;                                                  // HMC.jl:165
+
+        if (do_sum && __any(acc && held > 0)) {          // leaving a state after `held` saved steps: fold it into the sums (the OLD value is in X)
+            if (acc && held > 0) {
+                const double hf = (double)held;
+                const __amdgpu_buffer_rsrc_t ws = mwin<NE>(cx, p.sum, 0, p.D), wq = mwin<NE>(cx, p.sumsq, 0, p.D);
+                const int nv = cx.nv_here();
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const unsigned o = cx.off(e, nv);
+                    const double xo = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
+                    const double sv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ws, o, 0, 0));
+                    const double qv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wq, o, 0, 0));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sv + hf * xo), ws, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, qv + hf * (xo * xo)), wq, o, 0, 0);
+                }
+                held = 0;
+            }
+        }
+        if (acc) {                                       // commit (HMC.jl:166-176)
+            const int nv = cx.nv_here();
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const unsigned o = cx.off(e, nv);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, xp[e]), wX, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, (double)ga[e >> 2][e & 3]), wG, o, 0, 0);
+            }
+            lt = ltp;
+        } else {
+            reload();                                    // the registers hold the rejected proposal: back to the committed state
+        }
+        nacc += acc ? 1ull : 0ull;
+        if (p.cnt && acc) tn.accepted += 1;
+        if (accept_out != nullptr && cx.chain_ok && cx.q == 0)
+            accept_out[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
+        if (!p.pooled) tuning_block(p, tn);
+        const long long i1 = (long long)t + 1;
+        const bool in_post = i1 > p.burnin && i1 <= p.nsteps_total;
+        const bool save_now = in_post && sphase == 0;
+        if (in_post) sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
+        if (save_now) {                                  // save rule (BasicMCJob.jl:226-231): the registers hold the committed state
+            const long long col = scol++;
+            if (do_sum) held += 1;
+            if (col < p.hist_cols) {
+                const int nv = cx.nv_here();
+                if (p.hist != nullptr) {
+                    const __amdgpu_buffer_rsrc_t wh = mwin<NE>(cx, p.hist, col * p.nchains, p.D);
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, xp[e]), wh, cx.off(e, nv), 0, 0);
+                }
+                if (p.hist_g != nullptr) {
+                    const __amdgpu_buffer_rsrc_t wh = mwin<NE>(cx, p.hist_g, col * p.nchains, p.D);
+#pragma unroll
+                    for (int e = 0; e < NE; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, (double)ga[e >> 2][e & 3]), wh, cx.off(e, nv), 0, 0);
+                }
+                if (p.hist_lt != nullptr && cx.chain_ok && cx.q == 0) p.hist_lt[col * p.nchains + cx.chain] = lt;
+            }
+        }
+    }
+
+    if (cx.chain_ok && cx.q == 0) {
+        p.LT[cx.chain] = lt;
+        p.naccept[cx.chain] += nacc;
+        if (do_sum) p.held[cx.chain] = held;
+        if (!p.pooled) {
+            p.tune_step[cx.chain] = tn.step;
+            p.tune_accepted[cx.chain] = tn.accepted;
+            p.tune_proposed[cx.chain] = tn.proposed;
+            p.tune_totproposed[cx.chain] = tn.totproposed;
+        } else if (p.cnt) {
+            atomicAdd((unsigned long long*)p.pooled_accepted, (unsigned long long)tn.accepted - (unsigned long long)p.tune_accepted[0]);
+        }
+    }
+}
+
+// initialize! for the streamed layouts: g = -P (x - mu), lt = c + 1/2 (x - mu).g, finiteness asserts
+template <int NE, bool HASMU = false>
+__global__ __launch_bounds__(256) void k_dense_init_big(const KParams p, const double* __restrict__ Pfrag, int needgrad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = NE / 4;
+    double* const ldsMuW = reinterpret_cast<double*>(smem);
+    if (HASMU) { for (int i = threadIdx.x; i < 4 * NE; i += blockDim.x) ldsMuW[i] = Pfrag[(size_t)MT * NE * 64 + i]; }
+    const double* const ldsMu = ldsMuW;
+    __syncthreads();
+    const MfmaCtx<NE> cx = make_mctx<NE>(p);
+    double x[NE], red[1];
+    kd_double4 ga[MT];
+    mload<NE>(cx, p.X, p.D, x);
+    dense_stream<NE, HASMU>(Pfrag, cx.lane, x, ga, ldsMu);
+    double l1 = 0.0;
+    bool bad = false;
+    const __amdgpu_buffer_rsrc_t wG = mwin<NE>(cx, p.GR, 0, p.D);
+    const int nv = cx.nv_here();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const double g = -ga[e >> 2][e & 3];
+        l1 = l1 + (HASMU ? x[e] - ldsMu[4 * e + cx.q] : x[e]) * g;
+        if (needgrad) {
+            bad = bad || !kfinite(g);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, g), wG, cx.off(e, nv), 0, 0);
+        }
+    }
+    red[0] = l1;
+    mreduce<1>(red, cx.lane);
+    const double lt = p.gconst + 0.5 * red[0];
+    bad = bad || (cx.chain_ok && !kfinite(lt));
+    if (cx.chain_ok && cx.q == 0) p.LT[cx.chain] = lt;
+    if (bad) klara_raise(p.error_flag, KLARA_ERR_NONFINITE_INIT);
+}

@@ -1,0 +1,38 @@
+// klara_dense_big.hip — instantiates the streamed dense-Gaussian HMC kernels (D = 129 .. 256: NE = 40, 48, 56, 64 elements per lane) for gfx950.
+#include "klara_launch.h"
+#define KLARA_DENSE_NO_PROBES 1
+#include "klara_dense_big.h"
+
+template <int N, bool HASMU>
+static hipError_t go_big(const KParams* p, const KLaunch& kl, const double* Pfrag, dim3 grid, hipStream_t st)
+{
+    constexpr size_t lds = sizeof(double) * ((HASMU ? 4 * N : 0) + 4 * (size_t)N * 64);        // mu + the four wavefronts' momentum columns
+    hipError_t e = hipFuncSetAttribute((const void*)k_dense_hmc_big<N, HASMU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return klara_go(k_dense_hmc_big<N, HASMU>, grid, dim3(256), lds, st, p, kl, Pfrag);
+}
+
+hipError_t klara_launch_dense_big(const KParams* p, const KLaunch& kl, int NE, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st)
+{
+    if (NE == 40) return hasmu ? go_big<40, true>(p, kl, Pfrag, grid, st) : go_big<40, false>(p, kl, Pfrag, grid, st);
+    if (NE == 48) return hasmu ? go_big<48, true>(p, kl, Pfrag, grid, st) : go_big<48, false>(p, kl, Pfrag, grid, st);
+    if (NE == 56) return hasmu ? go_big<56, true>(p, kl, Pfrag, grid, st) : go_big<56, false>(p, kl, Pfrag, grid, st);
+    if (NE == 64) return hasmu ? go_big<64, true>(p, kl, Pfrag, grid, st) : go_big<64, false>(p, kl, Pfrag, grid, st);
+    return hipErrorInvalidValue;
+}
+
+template <int N, bool HASMU>
+static hipError_t go_init_big(const KParams& p, const double* Pfrag, int needgrad, dim3 grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_dense_init_big<N, HASMU>), grid, dim3(256), sizeof(double) * (HASMU ? 4 * N : 0), st, p, Pfrag, needgrad);
+    return hipGetLastError();
+}
+
+hipError_t klara_launch_dense_init_big(const KParams& p, int NE, const double* Pfrag, bool hasmu, int needgrad, dim3 grid, hipStream_t st)
+{
+    if (NE == 40) return hasmu ? go_init_big<40, true>(p, Pfrag, needgrad, grid, st) : go_init_big<40, false>(p, Pfrag, needgrad, grid, st);
+    if (NE == 48) return hasmu ? go_init_big<48, true>(p, Pfrag, needgrad, grid, st) : go_init_big<48, false>(p, Pfrag, needgrad, grid, st);
+    if (NE == 56) return hasmu ? go_init_big<56, true>(p, Pfrag, needgrad, grid, st) : go_init_big<56, false>(p, Pfrag, needgrad, grid, st);
+    if (NE == 64) return hasmu ? go_init_big<64, true>(p, Pfrag, needgrad, grid, st) : go_init_big<64, false>(p, Pfrag, needgrad, grid, st);
+    return hipErrorInvalidValue;
+}

@@ -328,11 +328,27 @@ def make_case(name):
                      tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=5)
         else:
             c = dict(sampler=L.SAMPLER_MH, target=t, nchains=23, nsteps=40, burnin=0, mh_sigma=np.full(d, 0.25), x0=x0)
-    elif name == "hmc_dense_d130_wide":    # the gradient closure of the wide dense form, no mean
+    elif name == "hmc_dense_d130_wide":    # (round 4: HMC at D = 130 runs on the streamed matrix-core layout; the closure form of the dense target is mh_dense_d130_wide's)
         rng = np.random.default_rng(131)
         a = rng.standard_normal((130, 130)); p = a @ a.T / 130 + np.eye(130)
         c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(p, const=-0.5), nchains=9, nsteps=8, burnin=1, leapstep=0.1, nleaps=3,
                  x0=rng.standard_normal((9, 130)))
+    elif name in ("hmc_dense_d256_stream_tuned", "hmc_dense_d192_stream_mean", "hmc_dense_d160_stream_pooled", "hmc_dense_d129_stream", "hmc_dense_d201_stream"):
+        # HMC beyond D = 128 on the matrix cores: P streamed from memory, momentum in LDS (klara_dense_big.h; NE = 40 / 48 / 56 / 64 elements per lane)
+        d = {"hmc_dense_d256_stream_tuned": 256, "hmc_dense_d192_stream_mean": 192, "hmc_dense_d160_stream_pooled": 160, "hmc_dense_d129_stream": 129,
+             "hmc_dense_d201_stream": 201}[name]
+        rng = np.random.default_rng(d)
+        a = rng.standard_normal((d, d)); pm = a @ a.T / d + np.eye(d)
+        mu = rng.standard_normal(d) if name in ("hmc_dense_d192_stream_mean", "hmc_dense_d256_stream_tuned") else None
+        t = K.GaussDenseTarget(pm, const=0.25, mu=mu)
+        x0 = rng.standard_normal((37, d)) + (0.0 if mu is None else mu[None, :])
+        kw = {"hmc_dense_d256_stream_tuned": dict(nsteps=40, burnin=20, leapstep=0.12, nleaps=4, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.7, period=5),
+              "hmc_dense_d192_stream_mean": dict(nsteps=14, burnin=3, thinning=2, leapstep=0.1, nleaps=5),
+              "hmc_dense_d160_stream_pooled": dict(nsteps=40, burnin=30, leapstep=0.15, nleaps=3, tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED,
+                                                   targetrate=0.65, period=10),
+              "hmc_dense_d129_stream": dict(nsteps=10, burnin=0, leapstep=0.1, nleaps=2),
+              "hmc_dense_d201_stream": dict(nsteps=12, burnin=2, leapstep=0.08, nleaps=3)}[name]
+        c = dict(sampler=L.SAMPLER_HMC, target=t, nchains=37, x0=x0, **kw)
     elif name == "mh_dense_d130_wide":     # beyond D = 128: the closure form (one chain per lane, 256 elements, loops), with a mean
         rng = np.random.default_rng(130)
         a = rng.standard_normal((130, 130)); p = a @ a.T / 130 + np.eye(130)
@@ -571,7 +587,8 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_rats_dualavg", "mala_d3_tuned_erf", "mala_d1", "hmc_d128_full", "mala_d129", "mh_d512",
              "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg",
              "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "hmc_dense_d100_mean", "mala_dense_d37_mean", "mh_dense_d20_mean",
-             "hmc_dense_d70_mean_dualavg", "slice_dense_d20", "slice_dense_d37_mean", "mh_dense_d130_wide", "hmc_dense_d130_wide", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
+             "hmc_dense_d70_mean_dualavg", "slice_dense_d20", "slice_dense_d37_mean", "mh_dense_d130_wide", "hmc_dense_d130_wide",
+             "hmc_dense_d256_stream_tuned", "hmc_dense_d192_stream_mean", "hmc_dense_d160_stream_pooled", "hmc_dense_d129_stream", "hmc_dense_d201_stream", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
              "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide", "hmc_logit_d20_wide", "slice_d20_stepout", "mh_rats", "mala_rats_tuned",
              "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"] + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",

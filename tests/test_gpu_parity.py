@@ -458,7 +458,7 @@ def test_parity_with_golden_vectors(name):
 @pytest.mark.parametrize("name,splits,spl", [
     ("mala_d100", [1, 7, 42], 1), ("mala_d100", [50], 5), ("hmc_d100", [13, 17], 4),
     ("hmc_dense_d100", [5, 7], 3), ("mala_d3_tuned", [100, 60, 100], 7), ("hmc_d10_tuned_pooled", [33, 87], 16),
-    ("slice_d5", [11, 19], 2), ("mala_swiss", [40], 1),
+    ("slice_d5", [11, 19], 2), ("mala_swiss", [40], 1), ("hmc_dense_d192_stream_mean", [3, 11], 2), ("hmc_dense_d256_stream_tuned", [17, 23], 6),
 ])
 def test_launch_splitting_does_not_change_results(name, splits, spl):
     """K transitions per launch / multiple klara_run calls are invisible in the results."""
@@ -638,7 +638,7 @@ def test_history_layout_matches_nstate():
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["hmc_dense_d37", "mala_dense_d100", "hmc_d100", "hmc_rats"])
+@pytest.mark.parametrize("name", ["hmc_dense_d37", "mala_dense_d100", "hmc_d100", "hmc_rats", "hmc_dense_d192_stream_mean"])
 def test_history_of_all_monitored_fields(name):
     case = cases.make_case(name)
     mon = L.MON_HISTORY | L.MON_HIST_LT | L.MON_HIST_GRAD | L.MON_SUMMARIES | L.MON_ACCEPT
