@@ -1,6 +1,6 @@
 /* readme_job.c — the reference's README job (README.md:23-66: MH on lt = -dot(z, z), 10,000 steps, burn-in 1,000) for N chains
  * through the C ABI of libklara_hip.so, in plain C99.  Shows the call sequence a binding follows:
- *   klara_create -> klara_set_state -> klara_run -> klara_get_chain_sums / klara_get_accept_counts -> klara_destroy.
+ *   klara_create -> klara_set_state -> klara_run -> klara_get_chain_sums / klara_get_accept_counts / klara_gather_moments -> klara_destroy.
  *
  *   gcc -std=c99 -O2 -Iinclude examples/readme_job.c -Lklara.jl_amd/lib -lklara_hip -Wl,-rpath,$PWD/klara.jl_amd/lib -o readme_job
  */
@@ -30,6 +30,8 @@ int main(int argc, char** argv)
     int64_t nsaved = 0;
     long long c;
     double mean0 = 0.0, mean1 = 0.0, var0 = 0.0, acc = 0.0;
+    double pmean[2], pm2[2];
+    uint64_t psamples = 0, paccept = 0, ptrans = 0, pchains = 0;
 
     memset(&d, 0, sizeof d);
     d.struct_size = (uint32_t)sizeof d;
@@ -67,6 +69,11 @@ int main(int argc, char** argv)
     }
     printf("%lld chains x %lld saved samples: mean = (%.4f, %.4f) (truth 0), E[z1^2] = %.4f (truth 0.5), acceptance = %.3f\n",
            nchains, (long long)nsaved, mean0 / (double)nchains, mean1 / (double)nchains, var0 / (double)nchains, acc / (double)nchains);
+    /* the pooled posterior moments formed on the device (per-chain (n, mean, M2), Chan's merge): mean(chain) / var over all chains at once;
+     * with a klara_comm instead of NULL the same call merges the chains of every GPU of the job */
+    CHECK(klara_gather_moments(job, NULL, pmean, pm2, &psamples, &paccept, &ptrans, &pchains));
+    printf("pooled over %llu samples: mean = (%.5f, %.5f), var = (%.5f, %.5f) (truth 0.5), acceptance = %.4f\n", (unsigned long long)psamples,
+           pmean[0], pmean[1], pm2[0] / (double)psamples, pm2[1] / (double)psamples, (double)paccept / (double)ptrans);
     CHECK(klara_destroy(job));
     free(x0); free(sum); free(sumsq); free(naccept);
     return 0;

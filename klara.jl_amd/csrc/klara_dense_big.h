@@ -55,6 +55,26 @@ __device__ __forceinline__ void dense_stream(const double* __restrict__ gP, int 
 
 // the momentum draw of mnormals (klara_dense.h: the even / odd lanes of a chain evaluate alternate Box-Muller pairs and swap halves),
 // written to the lane's LDS column
+// ... and the same draw handed to a callback, element by element (f(e, z_e)): MALA / MH form their proposal from it where it is drawn
+template <int NE, class F>
+__device__ __forceinline__ void mnormals_each(const MfmaCtx<NE>& c, unsigned long long seed, unsigned long long gchain, unsigned long long t, F f)
+{
+    static_assert(NE % 2 == 0, "pairs of elements");
+    const uint32_t sh = (uint32_t)(c.q >> 1);
+    const bool odd = (c.q & 1) != 0;
+    const int nv = c.nv_here();
+#pragma unroll
+    for (int e = 0; e + 1 < NE; e += 2) {
+        double z0, z1;
+        const uint32_t mine = 2u * (uint32_t)(odd ? e + 1 : e) + sh;
+        kd_normal_pair(kd_stream_block(seed, gchain, t, mine), &z0, &z1);
+        const double recv = bperm_xor(odd ? z0 : z1, c.lane, 16);
+        f(e, e < nv ? (odd ? recv : z0) : 0.0);
+        f(e + 1, e + 1 < nv ? (odd ? z1 : recv) : 0.0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int NE>
 __device__ __forceinline__ void mnormals_lds(const MfmaCtx<NE>& c, unsigned long long seed, unsigned long long gchain, unsigned long long t,
                                              double* momw)
@@ -108,10 +128,12 @@ __device__ __forceinline__ void mom_update(double* momw, F f)       // m = f(e, 
     }
 }
 
-template <int NE, bool HASMU = false>
+template <int SAMPLER, int NE, bool HASMU = false>
 __global__ __launch_bounds__(256)
-void k_dense_hmc_big(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
+void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
 {
+    static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH, "HMC, MALA, MH");
+    constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;          // MH carries no gradient (GR is not written)
     const KParams& p = *pp;
     guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -144,7 +166,7 @@ void k_dense_hmc_big(const KParams* __restrict__ pp, const KLaunch kl, const dou
         for (int e = 0; e < NE; ++e) {
             const unsigned o = cx.off(e, nv);
             xp[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
-            ga[e >> 2][e & 3] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, o, 0, 0));
+            if (NEEDG) ga[e >> 2][e & 3] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, o, 0, 0));
         }
     };
     reload();
@@ -152,38 +174,101 @@ void k_dense_hmc_big(const KParams* __restrict__ pp, const KLaunch kl, const dou
     for (int s = 0; s < kl.nsteps; ++s) {
         const unsigned long long t = kl.t0 + (unsigned long long)s;
         if (p.cnt) tune_count_proposal(p, tn);
-        // iterate/HMC.jl:124-201, leapfrog! samplers.jl:122-134 (merged fma form: DESIGN.md section 2 (7))
-        mnormals_lds<NE>(cx, p.seed, gchain, t, momw);                           // HMC.jl:135
-        double k0[1] = { 0.0 };
-        mom_read<NE>(momw, [&](int, double m) { k0[0] = k0[0] + m * m; });
-        mreduce<1>(k0, cx.lane);
-        const double H0 = lt - 0.5 * k0[0];                                      // HMC.jl:137
-        const double eps = tn.step, halfe = 0.5 * eps;
-        mom_update<NE>(momw, [&](int e, double m) { return kd_fma(halfe, (double)ga[e >> 2][e & 3], m); });
-        const int nl = p.nleaps;
-        for (int l = 0; l < nl; ++l) {
-            mom_read<NE>(momw, [&](int e, double m) { xp[e] = kd_fma(eps, m, xp[e]); });
-            dense_stream<NE, HASMU>(Pfrag, cx.lane, xp, ga, ldsMu);              // ga = +P (x - mu)
-            const double nkf = l + 1 < nl ? -eps : -halfe;
-            mom_update<NE>(momw, [&](int e, double m) { return kd_fma(nkf, (double)ga[e >> 2][e & 3], m); });
-        }
+        bool acc = false;
+        double ltp = lt;
+        if constexpr (SAMPLER == KLARA_SAMPLER_HMC) {
+            // iterate/HMC.jl:124-201, leapfrog! samplers.jl:122-134 (merged fma form: DESIGN.md section 2 (7))
+            mnormals_lds<NE>(cx, p.seed, gchain, t, momw);                           // HMC.jl:135
+            double k0[1] = { 0.0 };
+            mom_read<NE>(momw, [&](int, double m) { k0[0] = k0[0] + m * m; });
+            mreduce<1>(k0, cx.lane);
+            const double H0 = lt - 0.5 * k0[0];                                      // HMC.jl:137
+            const double eps = tn.step, halfe = 0.5 * eps;
+            mom_update<NE>(momw, [&](int e, double m) { return kd_fma(halfe, (double)ga[e >> 2][e & 3], m); });
+            const int nl = p.nleaps;
+            for (int l = 0; l < nl; ++l) {
+                mom_read<NE>(momw, [&](int e, double m) { xp[e] = kd_fma(eps, m, xp[e]); });
+                dense_stream<NE, HASMU>(Pfrag, cx.lane, xp, ga, ldsMu);              // ga = +P (x - mu)
+                const double nkf = l + 1 < nl ? -eps : -halfe;
+                mom_update<NE>(momw, [&](int e, double m) { return kd_fma(nkf, (double)ga[e >> 2][e & 3], m); });
+            }
+    #pragma unroll
+            for (int tt = 0; tt < MT; ++tt) ga[tt] = -ga[tt];                        // the proposal's gradient, -P (x' - mu)
+            double red[2], l1 = 0.0, k1 = 0.0;
+            mom_read<NE>(momw, [&](int e, double m) {
+                const double d = HASMU ? xp[e] - ldsMu[4 * e + cx.q] : xp[e];
+                l1 = l1 + d * (double)ga[e >> 2][e & 3];                             // lt' = c + 1/2 (x'-mu).g'   (HMC.jl:157)
+                k1 = k1 + m * m;
+            });
+            red[0] = l1; red[1] = k1;
+            mreduce<2>(red, cx.lane);
+            ltp = p.gconst + 0.5 * red[0];
+            const double H1 = ltp - 0.5 * red[1];                                    // HMC.jl:159
+            const double ratio = H1 - H0;                                            // HMC.jl:161
+            const double ex = kd_exp(ratio);
+            const double a = 1.0 < ex ? 1.0 : ex;                                    // HMC.jl:163
+            const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+            acc = u < a;                                                             // HMC.jl:165
+
+        } else if constexpr (SAMPLER == KLARA_SAMPLER_MALA) {
+            // iterate/MALA.jl:78-128.  The proposal overwrites the value registers as its normals are drawn; the current gradient (accumulators) is
+            // consumed by the same pass; the current value is re-read from X for the backward term: no vector beyond x and P x is ever held.
+            const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h), half_inv_h = 0.5 * (1.0 / h);
+            double s1 = 0.0;
+            mnormals_each<NE>(cx, p.seed, gchain, t, [&](int e, double z) {
+                const double mu = xp[e] + halfh * (double)ga[e >> 2][e & 3];         // MALA.jl:83
+                xp[e] = mu + sq * z;                                                  // MALA.jl:84
+                const double q1 = mu - xp[e];
+                s1 = s1 + (q1 * q1) * half_inv_h;                                     // MALA.jl:90
+            });
+            dense_stream<NE, HASMU>(Pfrag, cx.lane, xp, ga, ldsMu);                  // MALA.jl:86
 #pragma unroll
-        for (int tt = 0; tt < MT; ++tt) ga[tt] = -ga[tt];                        // the proposal's gradient, -P (x' - mu)
-        double red[2], l1 = 0.0, k1 = 0.0;
-        mom_read<NE>(momw, [&](int e, double m) {
-            const double d = HASMU ? xp[e] - ldsMu[4 * e + cx.q] : xp[e];
-            l1 = l1 + d * (double)ga[e >> 2][e & 3];                             // lt' = c + 1/2 (x'-mu).g'   (HMC.jl:157)
-            k1 = k1 + m * m;
-        });
-        red[0] = l1; red[1] = k1;
-        mreduce<2>(red, cx.lane);
-        const double ltp = p.gconst + 0.5 * red[0];
-        const double H1 = ltp - 0.5 * red[1];                                    // HMC.jl:159
-        const double ratio = H1 - H0;                                            // HMC.jl:161
-        const double ex = kd_exp(ratio);
-        const double a = 1.0 < ex ? 1.0 : ex;                                    // HMC.jl:163
-        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
-        const bool acc = u < a;                                                  // HMC.jl:165
+            for (int tt = 0; tt < MT; ++tt) ga[tt] = -ga[tt];
+            double l1 = 0.0, s2 = 0.0, red[3];
+            {
+                const int nv = cx.nv_here();
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const double d = HASMU ? xp[e] - ldsMu[4 * e + cx.q] : xp[e];
+                    const double gpe = (double)ga[e >> 2][e & 3];
+                    l1 = l1 + d * gpe;
+                    const double xc = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, cx.off(e, nv), 0, 0));
+                    const double mup = xp[e] + halfh * gpe;                           // MALA.jl:91
+                    const double q2 = mup - xc;
+                    s2 = s2 + (q2 * q2) * half_inv_h;                                 // MALA.jl:92
+                }
+            }
+            red[0] = l1; red[1] = s1; red[2] = s2;
+            mreduce<3>(red, cx.lane);
+            ltp = p.gconst + 0.5 * red[0];
+            double ratio = ltp - lt;                                                  // MALA.jl:88
+            ratio += red[1];
+            ratio -= red[2];
+            acc = ratio > 0.0;                                                        // MALA.jl:94
+            if (!acc && ratio > KD_LOG_UMIN_GUARD) {
+                const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+                acc = ratio > kd_log_u01(u);
+            }
+        } else {
+            // iterate/MH.jl:72-124
+            mnormals_each<NE>(cx, p.seed, gchain, t, [&](int e, double z) {
+                const double sg = (4 * e + cx.q < p.D) ? p.vecparam[4 * e + cx.q] : 0.0;
+                xp[e] = xp[e] + sg * z;                                               // MH.jl:79
+            });
+            dense_stream<NE, HASMU>(Pfrag, cx.lane, xp, ga, ldsMu);                  // MH.jl:81
+            double l1 = 0.0, red[1];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) l1 = l1 + (HASMU ? xp[e] - ldsMu[4 * e + cx.q] : xp[e]) * (-(double)ga[e >> 2][e & 3]);
+            red[0] = l1;
+            mreduce<1>(red, cx.lane);
+            ltp = p.gconst + 0.5 * red[0];
+            const double ratio = ltp - lt;                                            // MH.jl:83
+            acc = ratio > 0.0;                                                        // MH.jl:97
+            if (!acc && ratio > KD_LOG_UMIN_GUARD) {
+                const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+                acc = ratio > kd_log_u01(u);
+            }
+        }
 
         if (do_sum && __any(acc && held > 0)) {          // leaving a state after `held` saved steps: fold it into the sums (the OLD value is in X)
             if (acc && held > 0) {
@@ -208,7 +293,7 @@ void k_dense_hmc_big(const KParams* __restrict__ pp, const KLaunch kl, const dou
             for (int e = 0; e < NE; ++e) {
                 const unsigned o = cx.off(e, nv);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, xp[e]), wX, o, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, (double)ga[e >> 2][e & 3]), wG, o, 0, 0);
+                if (NEEDG) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, (double)ga[e >> 2][e & 3]), wG, o, 0, 0);
             }
             lt = ltp;
         } else {
@@ -233,7 +318,7 @@ void k_dense_hmc_big(const KParams* __restrict__ pp, const KLaunch kl, const dou
 #pragma unroll
                     for (int e = 0; e < NE; ++e) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, xp[e]), wh, cx.off(e, nv), 0, 0);
                 }
-                if (p.hist_g != nullptr) {
+                if (NEEDG && p.hist_g != nullptr) {
                     const __amdgpu_buffer_rsrc_t wh = mwin<NE>(cx, p.hist_g, col * p.nchains, p.D);
 #pragma unroll
                     for (int e = 0; e < NE; ++e)

@@ -1,24 +1,38 @@
-// klara_dense_big.hip — instantiates the streamed dense-Gaussian HMC kernels (D = 129 .. 256: NE = 40, 48, 56, 64 elements per lane) for gfx950.
+// klara_dense_big.hip — instantiates the streamed dense-Gaussian kernels (D = 129 .. 256: NE = 40, 48, 56, 64 elements per lane; HMC, MALA, MH) for gfx950.
 #include "klara_launch.h"
 #define KLARA_DENSE_NO_PROBES 1
 #include "klara_dense_big.h"
 
-template <int N, bool HASMU>
+template <int S, int N, bool HASMU>
 static hipError_t go_big(const KParams* p, const KLaunch& kl, const double* Pfrag, dim3 grid, hipStream_t st)
 {
-    constexpr size_t lds = sizeof(double) * ((HASMU ? 4 * N : 0) + 4 * (size_t)N * 64);        // mu + the four wavefronts' momentum columns
-    hipError_t e = hipFuncSetAttribute((const void*)k_dense_hmc_big<N, HASMU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    return klara_go(k_dense_hmc_big<N, HASMU>, grid, dim3(256), lds, st, p, kl, Pfrag);
+    // mu + (HMC) the four wavefronts' momentum columns
+    constexpr size_t lds = sizeof(double) * ((HASMU ? 4 * N : 0) + (S == KLARA_SAMPLER_HMC ? 4 * (size_t)N * 64 : 0));
+    if (lds > KLARA_LDS_DEFAULT_DYNAMIC) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_dense_big<S, N, HASMU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return klara_go(k_dense_big<S, N, HASMU>, grid, dim3(256), lds, st, p, kl, Pfrag);
 }
 
-hipError_t klara_launch_dense_big(const KParams* p, const KLaunch& kl, int NE, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st)
+template <int S>
+static hipError_t go_big_s(const KParams* p, const KLaunch& kl, int NE, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st)
 {
-    if (NE == 40) return hasmu ? go_big<40, true>(p, kl, Pfrag, grid, st) : go_big<40, false>(p, kl, Pfrag, grid, st);
-    if (NE == 48) return hasmu ? go_big<48, true>(p, kl, Pfrag, grid, st) : go_big<48, false>(p, kl, Pfrag, grid, st);
-    if (NE == 56) return hasmu ? go_big<56, true>(p, kl, Pfrag, grid, st) : go_big<56, false>(p, kl, Pfrag, grid, st);
-    if (NE == 64) return hasmu ? go_big<64, true>(p, kl, Pfrag, grid, st) : go_big<64, false>(p, kl, Pfrag, grid, st);
+    if (NE == 40) return hasmu ? go_big<S, 40, true>(p, kl, Pfrag, grid, st) : go_big<S, 40, false>(p, kl, Pfrag, grid, st);
+    if (NE == 48) return hasmu ? go_big<S, 48, true>(p, kl, Pfrag, grid, st) : go_big<S, 48, false>(p, kl, Pfrag, grid, st);
+    if (NE == 56) return hasmu ? go_big<S, 56, true>(p, kl, Pfrag, grid, st) : go_big<S, 56, false>(p, kl, Pfrag, grid, st);
+    if (NE == 64) return hasmu ? go_big<S, 64, true>(p, kl, Pfrag, grid, st) : go_big<S, 64, false>(p, kl, Pfrag, grid, st);
     return hipErrorInvalidValue;
+}
+
+hipError_t klara_launch_dense_big(const KParams* p, const KLaunch& kl, int sampler, int NE, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st)
+{
+    switch (sampler) {
+    case KLARA_SAMPLER_HMC: return go_big_s<KLARA_SAMPLER_HMC>(p, kl, NE, Pfrag, hasmu, grid, st);
+    case KLARA_SAMPLER_MALA: return go_big_s<KLARA_SAMPLER_MALA>(p, kl, NE, Pfrag, hasmu, grid, st);
+    case KLARA_SAMPLER_MH: return go_big_s<KLARA_SAMPLER_MH>(p, kl, NE, Pfrag, hasmu, grid, st);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 template <int N, bool HASMU>

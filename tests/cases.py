@@ -349,7 +349,24 @@ def make_case(name):
               "hmc_dense_d129_stream": dict(nsteps=10, burnin=0, leapstep=0.1, nleaps=2),
               "hmc_dense_d201_stream": dict(nsteps=12, burnin=2, leapstep=0.08, nleaps=3)}[name]
         c = dict(sampler=L.SAMPLER_HMC, target=t, nchains=37, x0=x0, **kw)
-    elif name == "mh_dense_d130_wide":     # beyond D = 128: the closure form (one chain per lane, 256 elements, loops), with a mean
+    elif name in ("mala_dense_d200_stream_tuned", "mh_dense_d256_stream_mean", "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide"):
+        # MALA / MH beyond D = 128 on the streamed matrix-core layout (no vector beyond x and P x is held: the current value is re-read from X for the
+        # backward term); dual averaging there still takes the closure form
+        d = {"mala_dense_d200_stream_tuned": 200, "mh_dense_d256_stream_mean": 256, "mala_dense_d130_stream_pooled": 130, "hmc_dense_d130_dualavg_wide": 130}[name]
+        rng = np.random.default_rng(1000 + d)
+        a = rng.standard_normal((d, d)); pm = a @ a.T / d + np.eye(d)
+        mu = rng.standard_normal(d) if name in ("mh_dense_d256_stream_mean", "mala_dense_d200_stream_tuned") else None
+        t = K.GaussDenseTarget(pm, const=-1.5, mu=mu)
+        n = 9 if name == "hmc_dense_d130_dualavg_wide" else 35
+        x0 = rng.standard_normal((n, d)) + (0.0 if mu is None else mu[None, :])
+        kw = {"mala_dense_d200_stream_tuned": dict(sampler=L.SAMPLER_MALA, nsteps=40, burnin=20, driftstep=0.05, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=5),
+              "mh_dense_d256_stream_mean": dict(sampler=L.SAMPLER_MH, nsteps=30, burnin=4, thinning=2, mh_sigma=np.linspace(0.02, 0.08, 256)),
+              "mala_dense_d130_stream_pooled": dict(sampler=L.SAMPLER_MALA, nsteps=45, burnin=30, driftstep=0.2, tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED,
+                                                    targetrate=0.574, period=10),
+              "hmc_dense_d130_dualavg_wide": dict(sampler=L.SAMPLER_HMC, nsteps=14, burnin=0, leapstep=0.1, nleaps=3, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.8,
+                                                  da_nadapt=8)}[name]
+        c = dict(target=t, nchains=n, x0=x0, **kw)
+    elif name == "mh_dense_d130_wide":     # (round 4: MH at D = 130 runs on the streamed matrix-core layout too; the closure form: hmc_dense_d130_dualavg_wide)
         rng = np.random.default_rng(130)
         a = rng.standard_normal((130, 130)); p = a @ a.T / 130 + np.eye(130)
         t = K.GaussDenseTarget(p, const=0.5, mu=rng.standard_normal(130))
@@ -588,7 +605,8 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg",
              "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "hmc_dense_d100_mean", "mala_dense_d37_mean", "mh_dense_d20_mean",
              "hmc_dense_d70_mean_dualavg", "slice_dense_d20", "slice_dense_d37_mean", "mh_dense_d130_wide", "hmc_dense_d130_wide",
-             "hmc_dense_d256_stream_tuned", "hmc_dense_d192_stream_mean", "hmc_dense_d160_stream_pooled", "hmc_dense_d129_stream", "hmc_dense_d201_stream", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
+             "hmc_dense_d256_stream_tuned", "hmc_dense_d192_stream_mean", "hmc_dense_d160_stream_pooled", "hmc_dense_d129_stream", "hmc_dense_d201_stream",
+             "mala_dense_d200_stream_tuned", "mh_dense_d256_stream_mean", "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
              "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide", "hmc_logit_d20_wide", "slice_d20_stepout", "mh_rats", "mala_rats_tuned",
              "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"] + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",

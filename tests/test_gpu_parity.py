@@ -1435,3 +1435,7 @@ def test_c_example_runs_the_readme_job(tmp_path):
     assert m, r.stdout
     m0, m1, v0, acc = map(float, m.groups())
     assert abs(m0) < 0.01 and abs(m1) < 0.01 and abs(v0 - 0.5) < 0.01 and 0.35 < acc < 0.5
+    p = re.search(r"pooled over (\d+) samples: mean = \(([-0-9.]+), ([-0-9.]+)\), var = \(([0-9.]+), ([0-9.]+)\).*acceptance = ([0-9.]+)", r.stdout)
+    assert p, r.stdout                                         # klara_gather_moments from plain C
+    ns, pm0, pm1, pv0, pv1, pacc = int(p.group(1)), *map(float, p.groups()[1:])
+    assert ns == 4096 * 9000 and abs(pm0 - m0) < 1e-4 and abs(pm1 - m1) < 1e-4 and abs(pv0 - 0.5) < 0.01 and abs(pv1 - 0.5) < 0.01 and abs(pacc - acc) < 1e-3
