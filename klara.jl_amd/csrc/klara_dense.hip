@@ -3,7 +3,7 @@
 #include "klara_dense.h"
 
 // streamed layouts (NE = 40 .. 64; D = 129 .. 256; HMC, MALA, MH): klara_dense_big.hip
-hipError_t klara_launch_dense_big(const KParams* p, const KLaunch& kl, int sampler, int NE, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st);
+hipError_t klara_launch_dense_big(const KParams* p, const KLaunch& kl, int sampler, bool da, int NE, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st);
 hipError_t klara_launch_dense_init_big(const KParams& p, int NE, const double* Pfrag, bool hasmu, int needgrad, dim3 grid, hipStream_t st);
 
 template <int SAMPLER, bool DA, bool HASMU>
@@ -40,8 +40,8 @@ static hipError_t launch_dense_s(const KParams* p, const KLaunch& kl, int NE, co
 hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, int NE, const double* Pfrag, bool hasmu,
                               dim3 grid, hipStream_t st)
 {
-    if (NE > 32) return (sampler != KLARA_SAMPLER_SLICE && tuner != KLARA_TUNER_DUAL_AVERAGING) ? klara_launch_dense_big(p, kl, sampler, NE, Pfrag, hasmu, grid, st)
-                                                                                                 : hipErrorInvalidValue;
+    if (NE > 32) return sampler != KLARA_SAMPLER_SLICE ? klara_launch_dense_big(p, kl, sampler, tuner == KLARA_TUNER_DUAL_AVERAGING, NE, Pfrag, hasmu, grid, st)
+                                                       : hipErrorInvalidValue;
     switch (sampler) {
     case KLARA_SAMPLER_MH: return launch_dense_s<KLARA_SAMPLER_MH, false>(p, kl, NE, Pfrag, hasmu, grid, st);
     case KLARA_SAMPLER_MALA: return launch_dense_s<KLARA_SAMPLER_MALA, false>(p, kl, NE, Pfrag, hasmu, grid, st);

@@ -10,9 +10,10 @@
 //     registers (it is the MFMA's B operand and the target of the drift), the gradient P x in the accumulators (it IS the MFMA result), and the
 //     MOMENTUM IN LDS — one private column per lane, momw[e * 64] —, touched twice per leapfrog (64 ds_read + 64 ds_write per lane against
 //     1,024 MFMAs).
-//   * HMC only (Vanilla / AcceptanceRate tuners, per chain or pooled; every monitor): it is the configuration the matrix cores are for
-//     (north_star: "MFMA used only where the logtarget is a dense contraction"; BASELINE cfg 3).  MALA / MH / slice / dual averaging beyond
-//     D = 128 stay on the closure form (klara_api.hip KLARA_DENSE_WIDE_SRC).
+//   * HMC (Vanilla / AcceptanceRate tuners per chain or pooled, and dual averaging with its per-chain trip counts; every monitor), and — with no
+//     LDS at all — MALA and MH: their proposal overwrites the value registers as its normals are drawn, the current gradient (accumulators) is
+//     consumed by the same pass, and the current value is re-read from X for MALA's backward term, so nothing beyond x and P x is ever held.
+//     Only the slice sampler beyond D = 128 stays on the closure form (klara_api.hip KLARA_DENSE_WIDE_SRC): a probe is a full evaluation.
 // Same MFMA instruction, same k-ascending fma chain per output (zero-padded rows / columns add exact zeros), same merged fma leapfrog, same
 // 4-lane reduction tree: the oracle's ko_hmc / ko_dense_grad in layout kind 1, bit for bit.
 #pragma once
@@ -128,12 +129,14 @@ __device__ __forceinline__ void mom_update(double* momw, F f)       // m = f(e, 
     }
 }
 
-template <int SAMPLER, int NE, bool HASMU = false>
+template <int SAMPLER, int NE, bool HASMU = false, bool DA = false>
 __global__ __launch_bounds__(256)
 void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
 {
     static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH, "HMC, MALA, MH");
     constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;          // MH carries no gradient (GR is not written)
+    static_assert(!DA || SAMPLER == KLARA_SAMPLER_HMC, "dual averaging is wired into HMC only (HMC.jl:124-133)");
+    constexpr bool da = DA;
     const KParams& p = *pp;
     guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -147,6 +150,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
     const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
     const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
     TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0, 0.0, 0.0 };
+    if (da) { tn.epsbar = p.da_epsbar[tix]; tn.hbar = p.da_hbar[tix]; }
     tn.phase = p.cnt ? (int)(tn.proposed % p.period) : 0;
     int sphase = kl.save_phase0;
     long long scol = kl.save_col0;
@@ -185,14 +189,18 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             const double H0 = lt - 0.5 * k0[0];                                      // HMC.jl:137
             const double eps = tn.step, halfe = 0.5 * eps;
             mom_update<NE>(momw, [&](int e, double m) { return kd_fma(halfe, (double)ga[e >> 2][e & 3], m); });
-            const int nl = p.nleaps;
-            for (int l = 0; l < nl; ++l) {
-                mom_read<NE>(momw, [&](int e, double m) { xp[e] = kd_fma(eps, m, xp[e]); });
+            // dual averaging: per-chain trip count (iterate/HMC.jl:142-144); the 16 chains of the tile run to the longest trajectory.  A finished
+            // chain's value and momentum stop changing, so the gradient the later passes recompute for it is the one it already has, bit for bit:
+            // only the two updates are masked, the accumulators need no second copy.
+            const int nl = da ? (cx.chain_ok ? da_nleaps(p, eps) : 1) : p.nleaps;        // (a padding lane must not set the wavefront's trip count)
+            for (int l = 0; da ? __any(l < nl) : (l < nl); ++l) {
+                const bool go = !da || l < nl;
+                mom_read<NE>(momw, [&](int e, double m) { const double v = kd_fma(eps, m, xp[e]); xp[e] = go ? v : xp[e]; });
                 dense_stream<NE, HASMU>(Pfrag, cx.lane, xp, ga, ldsMu);              // ga = +P (x - mu)
                 const double nkf = l + 1 < nl ? -eps : -halfe;
-                mom_update<NE>(momw, [&](int e, double m) { return kd_fma(nkf, (double)ga[e >> 2][e & 3], m); });
+                mom_update<NE>(momw, [&](int e, double m) { const double v = kd_fma(nkf, (double)ga[e >> 2][e & 3], m); return go ? v : m; });
             }
-    #pragma unroll
+#pragma unroll
             for (int tt = 0; tt < MT; ++tt) ga[tt] = -ga[tt];                        // the proposal's gradient, -P (x' - mu)
             double red[2], l1 = 0.0, k1 = 0.0;
             mom_read<NE>(momw, [&](int e, double m) {
@@ -209,6 +217,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             const double a = 1.0 < ex ? 1.0 : ex;                                    // HMC.jl:163
             const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
             acc = u < a;                                                             // HMC.jl:165
+            if (da) da_update(p, tn, (long long)t + 1, a);                           // HMC.jl:225-249
 
         } else if constexpr (SAMPLER == KLARA_SAMPLER_MALA) {
             // iterate/MALA.jl:78-128.  The proposal overwrites the value registers as its normals are drawn; the current gradient (accumulators) is
@@ -303,7 +312,10 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
         if (p.cnt && acc) tn.accepted += 1;
         if (accept_out != nullptr && cx.chain_ok && cx.q == 0)
             accept_out[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
-        if (!p.pooled) tuning_block(p, tn);
+        if (!p.pooled && !da) tuning_block(p, tn);
+        else if (da && p.cnt && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {     // verbose report block, iterate/HMC.jl:229-243
+            tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
+        }
         const long long i1 = (long long)t + 1;
         const bool in_post = i1 > p.burnin && i1 <= p.nsteps_total;
         const bool save_now = in_post && sphase == 0;
@@ -333,6 +345,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
         p.LT[cx.chain] = lt;
         p.naccept[cx.chain] += nacc;
         if (do_sum) p.held[cx.chain] = held;
+        if (da) { p.da_epsbar[cx.chain] = tn.epsbar; p.da_hbar[cx.chain] = tn.hbar; }
         if (!p.pooled) {
             p.tune_step[cx.chain] = tn.step;
             p.tune_accepted[cx.chain] = tn.accepted;

@@ -351,13 +351,13 @@ def make_case(name):
         c = dict(sampler=L.SAMPLER_HMC, target=t, nchains=37, x0=x0, **kw)
     elif name in ("mala_dense_d200_stream_tuned", "mh_dense_d256_stream_mean", "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide"):
         # MALA / MH beyond D = 128 on the streamed matrix-core layout (no vector beyond x and P x is held: the current value is re-read from X for the
-        # backward term); dual averaging there still takes the closure form
+        # backward term); HMC with dual averaging streams too (per-chain trip counts: the wavefront runs to the longest trajectory of its 16 chains)
         d = {"mala_dense_d200_stream_tuned": 200, "mh_dense_d256_stream_mean": 256, "mala_dense_d130_stream_pooled": 130, "hmc_dense_d130_dualavg_wide": 130}[name]
         rng = np.random.default_rng(1000 + d)
         a = rng.standard_normal((d, d)); pm = a @ a.T / d + np.eye(d)
         mu = rng.standard_normal(d) if name in ("mh_dense_d256_stream_mean", "mala_dense_d200_stream_tuned") else None
         t = K.GaussDenseTarget(pm, const=-1.5, mu=mu)
-        n = 9 if name == "hmc_dense_d130_dualavg_wide" else 35
+        n = 35
         x0 = rng.standard_normal((n, d)) + (0.0 if mu is None else mu[None, :])
         kw = {"mala_dense_d200_stream_tuned": dict(sampler=L.SAMPLER_MALA, nsteps=40, burnin=20, driftstep=0.05, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=5),
               "mh_dense_d256_stream_mean": dict(sampler=L.SAMPLER_MH, nsteps=30, burnin=4, thinning=2, mh_sigma=np.linspace(0.02, 0.08, 256)),

@@ -398,6 +398,23 @@ def test_pair_transposed_layout_is_optional():
         del os.environ["KLARA_LAYOUT_KIND"]
 
 
+@pytest.mark.parametrize("name", ["hmc_dense_d130_wide", "mh_dense_d130_wide", "hmc_dense_d130_dualavg_wide"])
+def test_dense_target_beyond_128_closure_form_still_matches(name, monkeypatch):
+    """Round 4 moved HMC / MALA / MH on dense targets of 129..256 dimensions onto the matrix cores (streamed P); the run-time compiled closure form
+    they used to take (one chain per lane) remains what the slice sampler and D > 256 run, and KLARA_DENSE_NO_STREAM=1 selects it for every sampler:
+    both forms against the oracle in their own summation orders (layout kind 1 on 4 lanes; kind 0 on one lane), bit for bit."""
+    case = cases.make_case(name)
+    eng, job = _run_pair(case)
+    assert eng.layout()[0] == 1 and eng.layout()[2] in (40, 48, 56, 64)
+    _assert_same(eng, job, case)
+    eng.close()
+    monkeypatch.setenv("KLARA_DENSE_NO_STREAM", "1")
+    eng, job = _run_pair(case)
+    assert eng.layout() == (0, 1, 256)
+    _assert_same(eng, job, case)
+    eng.close()
+
+
 # Vanilla / AcceptanceRate jobs on even-D diagonal Gaussians run on the pair-transposed layout by default (HMC on the
 # hierarchical target: layout kind 4); the same cases forced
 # onto the group layout keep that path covered (both compared with the oracle told the respective summation order)
