@@ -753,11 +753,12 @@ def test_readme_flow_basic_mc_job():
 
 
 # ------------------------------------------------------------------ randomized configurations
-def _random_case(seed):
+def _random_case(seed, wide=False):
     """One job drawn from the whole configuration space the library accepts: target family and size, sampler, tuner,
-    range, chain count (valid combinations only — the refused ones are in test_error_paths)."""
-    rng = np.random.default_rng(1000 + seed)
-    fam = rng.choice(["diag_unit", "diag", "dense", "logit", "hier", "custom"], p=[0.2, 0.25, 0.15, 0.13, 0.14, 0.13])
+    range, chain count (valid combinations only — the refused ones are in test_error_paths).  wide: the sizes round 4 moved onto hand-written
+    kernels — dense targets of 129..256 dimensions (streamed matrix-core layouts) and logistic regressions with 9..16 parameters (row split)."""
+    rng = np.random.default_rng((5000 if wide else 1000) + seed)
+    fam = rng.choice(["dense", "logit"]) if wide else rng.choice(["diag_unit", "diag", "dense", "logit", "hier", "custom"], p=[0.2, 0.25, 0.15, 0.13, 0.14, 0.13])
     if fam == "diag_unit":
         d = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 19, 31, 40, 63, 77, 100, 128, 129, 200, 300]))
         target = K.GaussDiagTarget.negdot(d)
@@ -765,11 +766,12 @@ def _random_case(seed):
         d = int(rng.choice([2, 4, 7, 16, 18, 23, 48, 65, 96, 127, 140]))
         target = K.GaussDiagTarget.mvnormal(rng.uniform(-2, 2, d), rng.uniform(0.5, 2.0, d))
     elif fam == "dense":
-        d = int(rng.choice([3, 8, 20, 33, 50, 70]))
+        d = int(rng.choice([129, 144, 160, 161, 177, 192, 193, 224, 225, 256])) if wide else int(rng.choice([3, 8, 20, 33, 50, 70]))
         target = K.GaussDenseTarget(cases.compound_symmetric_precision(d, float(rng.uniform(0.1, 0.7))), const=float(rng.uniform(-2, 2)),
                                     mu=(rng.uniform(-1.5, 1.5, d) if rng.integers(0, 2) else None))
     elif fam == "logit":
-        d = int(rng.choice([1, 2, 3, 4, 6, 8, 11])); n = int(rng.choice([5, 30, 63, 64, 100, 300]))   # (11: the closure form beyond 8 parameters)
+        d = int(rng.choice([9, 10, 12, 13, 15, 16])) if wide else int(rng.choice([1, 2, 3, 4, 6, 8, 11]))
+        n = int(rng.choice([5, 30, 63, 64, 100, 300, 1100 if wide else 300]))   # (11: 9..16 parameters run on the row-split kernels since round 4; 1,100 rows x 17 columns do not fit the LDS: closure form)
         X, y = cases.synthetic_logit(n, d, seed=seed)
         target = K.LogisticTarget(X, y, float(rng.choice([1.0, 100.0])))
     elif fam == "hier":
@@ -783,7 +785,7 @@ def _random_case(seed):
         target = K.CustomTarget(d, cases.SRC_QUARTIC_CHAIN, [float(rng.uniform(0.01, 0.2)), float(rng.uniform(0.1, 0.8))])
     samplers = [L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC] + ([] if fam == "dense" and d > 33 else [L.SAMPLER_SLICE])   # (dense slice: D full evaluations per probe)
     sampler = int(rng.choice(samplers))
-    scale = 0.02 if fam == "hier" else (0.05 if fam == "logit" else 0.3)
+    scale = 0.02 if fam == "hier" else (0.05 if fam == "logit" else (0.1 if wide else 0.3))
     c = dict(sampler=sampler, target=target, nchains=int(rng.choice([1, 2, 7, 8, 9, 33, 64, 100, 131])), x0=None, seed=int(rng.integers(1, 2 ** 40)),
              name=f"random_{seed}_{fam}")
     if sampler == L.SAMPLER_MH:
@@ -815,12 +817,22 @@ def _random_case(seed):
     return c, rng
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configurations_wide(seed):
+    """48 more jobs from the sizes that moved onto hand-written kernels in round 4 (dense 129..256 dimensions on the streamed matrix-core layouts — HMC with
+    every tuner, MALA, MH —, the slice sampler there on the closure form at a few chains; logistic regression with 9..16 parameters), run like the others."""
+    _run_random(*_random_case(seed, wide=True))
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("KLARA_RANDOM_FIRST", "0")), int(os.environ.get("KLARA_RANDOM_FIRST", "0")) + int(os.environ.get("KLARA_RANDOM_CASES", "96"))))
 def test_random_configurations(seed):
     """96 jobs (KLARA_RANDOM_CASES overrides the count, KLARA_RANDOM_FIRST the first seed) drawn at random from the accepted configuration space, run in randomly sized pieces with a random number of
     transitions per launch and every monitor on: accept mask, state, sums, tuner state and one chain's full history must
     equal the oracle's bit for bit."""
-    c, rng = _random_case(seed)
+    _run_random(*_random_case(seed))
+
+
+def _run_random(c, rng):
     mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT
     if c["sampler"] in (L.SAMPLER_MALA, L.SAMPLER_HMC):
         mon |= L.MON_HIST_GRAD
