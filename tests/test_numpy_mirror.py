@@ -158,3 +158,48 @@ def test_mala_on_the_swiss_logistic_regression():
     assert job.set_state(x0) == 0
     chains = [M.Chain("mala", lt, grad, x0[k], SEED, OFFSET + k, driftstep=0.1, **kw) for k in range(NCHAINS)]
     _compare(job, chains, 150, 20, 1, True)
+
+
+@pytest.mark.parametrize("literal", [False, True])
+def test_long_runs_against_the_mirror(literal):
+    """the mirror used to be compared on 3 chains x <= 150 transitions.  Here: 16 chains x 2,000 transitions of HMC (L = 10, eps = 0.1 —
+    cfg 3's sampler) on a dense 12 x 12 precision with a mean, and 16 chains x 2,000 of MALA on the swiss logistic regression (cfg 4), against the C
+    oracle in its shipped arithmetic AND in its literal-Julia mode (unmerged unfused leapfrog, abs2/step, two exponentials — the arithmetic the
+    mirror itself uses): every one of the 64,000 accept decisions identical, final states equal to 1e-9 (shipped) / 1e-10 (literal; what is left
+    are the mirror's libm transcendentals and NumPy's summation order)."""
+    lib = O.load()
+    n = 16
+    lib.ko_set_literal(1 if literal else 0)
+    try:
+        d = 12
+        rng = np.random.default_rng(31)
+        a = rng.standard_normal((d, d)); P = a @ a.T / d + np.eye(d); mu = rng.standard_normal(d)
+        lt, grad = M.dense_target(P, mu, -0.5)
+        kw = dict(nsteps=2000, burnin=400, thinning=1)
+        job = O.OracleJob(sampler=L.SAMPLER_HMC, target_kind=L.TARGET_GAUSS_DENSE, nchains=n, ndims=d, leapstep=0.1, nleaps=10, gauss_prec=P, gauss_mu=mu,
+                          gauss_const=-0.5, seed=SEED, chain_offset=OFFSET, **kw)
+        x0 = mu[None, :] + rng.standard_normal((n, d))
+        assert job.set_state(x0) == 0
+        chains = [M.Chain("hmc", lt, grad, x0[k], SEED, OFFSET + k, leapstep=0.1, nleaps=10, **kw) for k in range(n)]
+        assert job.run(2000) == 0
+        for k, c in enumerate(chains):
+            c.run(2000)
+            assert np.array_equal(np.asarray(job.accept[:, k], bool), np.array(c.accepts)), ("HMC accept decisions differ", k)
+            assert np.allclose(job.X[k], c.x, rtol=1e-10 if literal else 1e-9, atol=1e-11), k
+            assert np.allclose(job.sum[k] / 1600, np.mean(c.saved, axis=0), rtol=1e-9, atol=1e-11)
+        assert 0.8 < job.accept.mean() <= 1.0
+        X, y = cases.swiss_data()
+        lt, grad = M.logistic_target(X, y, 100.0)
+        kw = dict(nsteps=2000, burnin=100, thinning=1)
+        job = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=L.TARGET_LOGISTIC, nchains=n, ndims=4, driftstep=0.1, logit_X=X, logit_y=y, logit_lambda=100.0,
+                          seed=SEED, chain_offset=OFFSET, **kw)
+        x0 = np.array([5.1, -0.9, 8.2, -4.5])[None, :] + 0.1 * np.random.default_rng(8).standard_normal((n, 4))
+        assert job.set_state(x0) == 0
+        chains = [M.Chain("mala", lt, grad, x0[k], SEED, OFFSET + k, driftstep=0.1, **kw) for k in range(n)]
+        assert job.run(2000) == 0
+        for k, c in enumerate(chains):
+            c.run(2000)
+            assert np.array_equal(np.asarray(job.accept[:, k], bool), np.array(c.accepts)), ("MALA accept decisions differ", k)
+            assert np.allclose(job.X[k], c.x, rtol=1e-9, atol=1e-11), k
+    finally:
+        lib.ko_set_literal(0)
