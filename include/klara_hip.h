@@ -184,7 +184,8 @@ typedef struct klara_desc {
     const double* logit_X;       /* LOGISTIC: ndata x D row-major design matrix                      */
     const double* logit_y;       /* LOGISTIC: ndata outcomes                                         */
     int32_t  logit_ndata;        /* LOGISTIC: rows.  D <= 8: ndata * (E + 1) <= KLARA_LOGIT_MAX_LDS_DOUBLES, E = 2, 4 or 8 >= D (rows live in LDS);
-                                    D = 9..256: any number of rows (run-time compiled closure form, rows read from memory) */
+                                    D = 9..16: the same kernels (E = 16) while the rows fit, the closure form beyond; D = 17..256: any number of
+                                    rows (run-time compiled closure form, rows read from memory) */
     int32_t  nstreams;           /* internal HIP streams for independent chain partitions (pair-transposed layout only):
                                     0 = automatic (2 when a partition still fills the GPU), 1..4 = forced        */
     double   logit_lambda;       /* LOGISTIC: prior variance (v[1] of the example)                   */
