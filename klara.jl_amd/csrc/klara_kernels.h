@@ -34,6 +34,8 @@
 #endif
 #define KLARA_LOGIT_BATCH_OF(E) ((E) <= 4 ? KLARA_LOGIT_BATCH : ((KLARA_LOGIT_BATCH) > 3 ? 3 : KLARA_LOGIT_BATCH))
 template <int N> struct KInt { static constexpr int value = N; };
+template <int N> __device__ __forceinline__ constexpr int kstride(KInt<N>) { return N; }
+__device__ __forceinline__ constexpr int kstride(int v) { return v; }
 // nothing is scheduled across a stage boundary of the batched row evaluation
 // (KLARA_PIN(v): the value is "produced" here as far as the compiler knows, so arithmetic on it cannot be hoisted above this point)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -466,7 +468,8 @@ KLARA_PRAGMA_UNROLL_E
         // 4 wavefronts per SIMD, profiles/r3_pmc_kernels.json).  Here the R rows of a batch go through each stage together — all R row reads,
         // all R exp gathers, all R log gathers are in flight before the first is consumed — and the accumulations run last, row by row in
         // ascending order: the operations and the summation order of the one-row form, bit for bit (the oracle's ko_logit_eval).
-        const auto rows_of = [&](auto rtag, int r0, int stride) {
+        const auto rows_of = [&](auto rtag, int r0, auto stride_) {
+            const int stride = kstride(stride_);        // (a KInt: compile-time, the batch's rows are reached by immediate offsets)
             constexpr int R = decltype(rtag)::value;
             double row[R][E], yr[R], xp[R], rr[R], th[R], tl[R], t[R], onept[R], invc[R], logc[R], sp[R], lg[R];
             int kk[R]; uint32_t li[R];
@@ -529,7 +532,8 @@ KLARA_PRAGMA_UNROLL_E
         constexpr int RB = KLARA_LOGIT_BATCH_OF(E);
         const int nfull = ndata / cx.RS, tail = ndata - nfull * cx.RS;
         const int nbat = nfull / RB;
-        for (int b = 0; b < nbat; ++b) rows_of(KInt<RB>(), cx.rq + b * RB * cx.RS, cx.RS);
+        if (cx.RS == 4) { for (int b = 0; b < nbat; ++b) rows_of(KInt<RB>(), cx.rq + b * RB * 4, KInt<4>()); }      // (the default split)
+        else { for (int b = 0; b < nbat; ++b) rows_of(KInt<RB>(), cx.rq + b * RB * cx.RS, cx.RS); }
         for (int it = nbat * RB; it < nfull; ++it) rows_of(KInt<1>(), cx.rq + it * cx.RS, cx.RS);
         if (cx.rq < tail) rows_of(KInt<1>(), cx.rq + nfull * cx.RS, cx.RS);
         if (cx.RS > 1) {
