@@ -19,7 +19,8 @@
  *   kd_log             FreeBSD-msun-style log (<1 ulp), every special case; kd_exp: 128-entry table, division-free (<1 ulp).
  *   kd_log_u01         table-driven, division-free log for the uniforms (radius and Metropolis tests).
  *   kd_sincos2pi       sin(2*pi*u), cos(2*pi*u) for u in [0,1): 256-entry table + rotation.
- *   kd_normal_pair     Box-Muller: one Philox block -> two N(0,1) doubles.
+ *   kd_normal_pair_w   Box-Muller on 64 bits: half a Philox block -> two N(0,1) doubles (44-bit radius uniform, 20-bit angle);
+ *                      kd_normal_pair_at: the proposal normals of element pair p — one block serves pairs p and p + 8.
  *
  * This header is NOT a restatement of any reference file; the samplers' arithmetic is written
  * separately in oracle/ (following the Julia sources) and in the .hip kernels.
@@ -106,9 +107,27 @@ KD_FN double kd_u52(uint32_t whi, uint32_t wlo)
     return kd_u2d(kd_unit_bits(whi, wlo)) - 0x1.fffffffffffffp-1;
 }
 
-/* kd_log_u01(u) >= kd_log_u01(2^-53) = -36.7368005696771 for every uniform kd_u52 can return, so a Metropolis ratio at
- * or below this guard is rejected whatever the uniform is (lets the kernels skip the draw; same result). */
-#define KD_LOG_UMIN_GUARD (-36.74)
+/* 44 random bits m = wa:wb[11:0] -> (m + 0.5) * 2^-44, built the same way (uu - (1 - 2^-45) = (2m + 1) 2^-45: exact).  The radius
+ * uniform of the proposal normals and the accept uniform of the Metropolis tests: half a Philox block each (kd_normal_pair_w). */
+KD_FN uint64_t kd_unit_bits44(uint32_t wa, uint32_t wb)      /* bits of 1 + m 2^-44 */
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t uh = __builtin_amdgcn_alignbit(0x3ffu, wa, 12);          /* 0x3ff00000 | wa >> 12 */
+    const uint32_t ul = __builtin_amdgcn_alignbit(wa, wb << 20, 12);        /* wa << 20 | (wb & 0xfff) << 8 */
+#else
+    const uint32_t uh = 0x3ff00000u | (wa >> 12);
+    const uint32_t ul = (wa << 20) | ((wb << 20) >> 12);
+#endif
+    return ((uint64_t)uh << 32) | (uint64_t)ul;
+}
+KD_FN double kd_u44(uint32_t wa, uint32_t wb)
+{
+    return kd_u2d(kd_unit_bits44(wa, wb)) - 0x1.fffffffffffp-1;
+}
+
+/* kd_log_u01(u) >= kd_log_u01(2^-45) = -31.1916... for every uniform kd_u44 can return, so a Metropolis ratio at
+ * or below this guard is rejected whatever the accept uniform is (lets the kernels skip the draw; same result). */
+#define KD_LOG_UMIN_GUARD (-31.2)
 
 /* ---------------------------------------------------------------- log */
 /* Algorithm: FreeBSD msun e_log.c reduction x = 2^k * (1+f), sqrt(1/2) <= 1+f < sqrt(2),
@@ -525,28 +544,54 @@ KD_FN double kd_sqrt_radicand(double y)
 }
 
 /* ---------------------------------------------------------------- Box-Muller */
-/* One Philox block (4 x 32 bit) -> two independent N(0,1):
- *   u1 = u52(x, y), u2 = u52(z, w); rad = sqrt(-2 log u1); z0 = rad cos(2 pi u2); z1 = rad sin(2 pi u2).
- * Element i of a D-vector uses block (i >> 1) of its transition and takes z0 if i is even, z1 if odd. */
-KD_FN void kd_normal_pair_ex(kd_u32x4 b, double* z0, double* z1, double* u1_out, double* logu1_out)
+/* The normals of the samplers (proposals, momenta, initial states): 64 bits -> two N(0,1),
+ *   rad = sqrt(-2 log u1); z0 = rad cos(2 pi u2); z1 = rad sin(2 pi u2).
+ * A Philox block carries two such pairs, so the 41 vector instructions of a block are paid once per FOUR normals (rounds 1-3 spent a
+ * whole block on a pair: 52-bit u1 and u2).  The lattice underneath:
+ *   radius  u1 = kd_u44(wa, wb)            44 bits: u1 >= 2^-45, |z| <= 7.9 (the mass beyond is 3e-15 per draw)
+ *   angle   u2 = (wb >> 12) 2^-20 + 2^-53  20 bits: 2^20 equally spaced directions; the marginal of rad cos / rad sin over an equally
+ *                                          spaced set of directions is the rectangle rule on a periodic analytic integrand — exact to
+ *                                          rounding; jointly (z0, z1) lie on 2^20 rays with a 44-bit radius along each
+ * (u1, log u1) are handed back: a layout's padding pair at index ceil(D/2) is the accept draw (kd_accept_uniform) for free. */
+KD_FN uint64_t kd_angle_bits20(uint32_t wb)
 {
-    const double u1 = kd_u52(b.x, b.y);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint64_t)__builtin_amdgcn_alignbit(0x3ffu, wb, 12) << 32;
+#else
+    return (uint64_t)(0x3ff00000u | (wb >> 12)) << 32;
+#endif
+}
+KD_FN void kd_normal_pair_w(uint32_t wa, uint32_t wb, double* z0, double* z1, double* u1_out, double* logu1_out)
+{
+    const double u1 = kd_u44(wa, wb);
     const double lg = kd_log_u01(u1);
     const double rad = kd_sqrt_radicand(-2.0 * lg);
     double sn, cs;
-    kd_sincos2pi_bits(kd_unit_bits(b.z, b.w), &sn, &cs);          /* angle 2 pi u2, u2 = kd_u52(z, w) */
+    kd_sincos2pi_bits(kd_angle_bits20(wb), &sn, &cs);
     *z0 = rad * cs;
     *z1 = rad * sn;
-    *u1_out = u1;            /* = kd_uniform_xy(b): the same words feed the accept uniform of slot ceil(D/2) */
+    *u1_out = u1;
     *logu1_out = lg;
 }
-KD_FN void kd_normal_pair(kd_u32x4 b, double* z0, double* z1)
-{
-    double u1, lg;
-    kd_normal_pair_ex(b, z0, z1, &u1, &lg);
-}
 
-/* uniform for accept tests / slice sampler: words (x,y) of a block (or (z,w) for the second) */
+/* Which 64 bits: element pair p (elements 2p, 2p + 1 of a D-vector, p < ceil(D/2)) takes half (p >> 3) & 1 — words (x, y) or (z, w) —
+ * of block slot (p & 7) + 8 (p >> 4): pairs p and p + 8 share a block.  Both sit in the same lane in every pair-transposed layout
+ * (lane q of Q <= 8 holds pairs q + Q j), so the sharing costs no cross-lane traffic.  Slots used: < ceil(D/2).
+ * Pair indices at or beyond ceil(D/2) exist as layout padding only; they take words (x, y) of block slot p (their normals are
+ * discarded), and index ceil(D/2) itself is the accept draw of the transition: kd_accept_uniform of block slot ceil(D/2). */
+KD_FN uint32_t kd_pair_block(uint32_t p) { return (p & 7u) | ((p >> 4) << 3); }
+KD_FN uint32_t kd_pair_half(uint32_t p) { return (p >> 3) & 1u; }
+KD_FN void kd_normal_pair_at(uint64_t seed, uint64_t chain, uint64_t transition, uint32_t p, uint32_t nreal,
+                             double* z0, double* z1, double* u1_out, double* logu1_out)
+{
+    const int real = p < nreal;
+    const int half = real && kd_pair_half(p) != 0u;
+    const kd_u32x4 b = kd_stream_block(seed, chain, transition, real ? kd_pair_block(p) : p);
+    kd_normal_pair_w(half ? b.z : b.x, half ? b.w : b.y, z0, z1, u1_out, logu1_out);
+}
+KD_FN double kd_accept_uniform(kd_u32x4 b) { return kd_u44(b.x, b.y); }
+
+/* uniforms of the slice sampler: words (x,y) of a block (or (z,w) for the second), 52 bits */
 KD_FN double kd_uniform_xy(kd_u32x4 b) { return kd_u52(b.x, b.y); }
 KD_FN double kd_uniform_zw(kd_u32x4 b) { return kd_u52(b.z, b.w); }
 

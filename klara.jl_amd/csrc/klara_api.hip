@@ -2180,8 +2180,8 @@ extern "C" klara_status klara_selftest_math(int32_t device, int32_t op, int64_t 
 }
 
 // |z| exceedance counts and raw power sums of the proposal normals, drawn exactly as the transition kernels draw them
-// (kd_normal_pair of kd_stream_block(seed, chain, transition, slot 0)); one thread per chain, wave-level ballots feed one
-// atomic per wavefront and threshold.  counts[k] = #{|z| > thr[k]} over 2 * nchains * ntransitions normals.
+// (kd_normal_pair_w on both halves of kd_stream_block(seed, chain, transition, slot 0)); one thread per chain, one atomic per thread
+// and threshold.  counts[k] = #{|z| > thr[k]} over 4 * nchains * ntransitions normals.
 __global__ __launch_bounds__(256) void k_normal_tail(unsigned long long seed, unsigned long long first_chain, long long nchains,
                                                      long long ntransitions, int nthr, const double* __restrict__ thr,
                                                      unsigned long long* __restrict__ counts, double* __restrict__ moments)
@@ -2192,13 +2192,16 @@ __global__ __launch_bounds__(256) void k_normal_tail(unsigned long long seed, un
     unsigned long long c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     double s1 = 0.0, s2 = 0.0, s4 = 0.0, mx = 0.0;
     for (long long t = 0; t < ntransitions; ++t) {
-        double z0, z1;
-        kd_normal_pair(kd_stream_block(seed, first_chain + (unsigned long long)(ok ? i : 0), (unsigned long long)t, 0u), &z0, &z1);
-        if (!ok) continue;
-        const double a0 = z0 < 0.0 ? -z0 : z0, a1 = z1 < 0.0 ? -z1 : z1;
-        for (int k = 0; k < 8; ++k) if (k < nthr) c[k] += (a0 > thr[k] ? 1ull : 0ull) + (a1 > thr[k] ? 1ull : 0ull);
-        s1 += z0 + z1; s2 += z0 * z0 + z1 * z1; s4 += (z0 * z0) * (z0 * z0) + (z1 * z1) * (z1 * z1);
-        mx = a0 > mx ? a0 : mx; mx = a1 > mx ? a1 : mx;
+        const kd_u32x4 b = kd_stream_block(seed, first_chain + (unsigned long long)(ok ? i : 0), (unsigned long long)t, 0u);
+        for (int h = 0; h < 2; ++h) {                           // the block's two pairs: pair indices 0 and 8 of a transition
+            double z0, z1, u1, lg;
+            kd_normal_pair_w(h ? b.z : b.x, h ? b.w : b.y, &z0, &z1, &u1, &lg);
+            if (!ok) continue;
+            const double a0 = z0 < 0.0 ? -z0 : z0, a1 = z1 < 0.0 ? -z1 : z1;
+            for (int k = 0; k < 8; ++k) if (k < nthr) c[k] += (a0 > thr[k] ? 1ull : 0ull) + (a1 > thr[k] ? 1ull : 0ull);
+            s1 += z0 + z1; s2 += z0 * z0 + z1 * z1; s4 += (z0 * z0) * (z0 * z0) + (z1 * z1) * (z1 * z1);
+            mx = a0 > mx ? a0 : mx; mx = a1 > mx ? a1 : mx;
+        }
     }
     for (int k = 0; k < 8; ++k) if (k < nthr && c[k] != 0) atomicAdd(&counts[k], c[k]);
     if (ok) {

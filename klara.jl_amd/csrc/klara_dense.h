@@ -101,8 +101,29 @@ __device__ __forceinline__ void mreduce(double (&v)[N], int lane)
     for (int i = 0; i < N; ++i) v[i] = v[i] + bperm_xor(v[i], lane, 32);
 }
 
-// normals for the lane's elements: element e <-> dim i = 4e+q <-> slot i>>1 = 2e + (q>>1),
-// branch q&1 (cos for even dims, sin for odd dims)
+// normals for the lane's elements: element e <-> dim i = 4e+q <-> pair index i>>1 = 2e + (q>>1), branch q&1 (cos for even dims, sin for odd
+// dims); the 64 bits of pair index p are half (p >> 3) & 1 of block slot (p & 7) + 8 (p >> 4) (detmath.h kd_normal_pair_at).
+// Lanes q and q^1 (lane ^ 16) of a chain need the two halves of the SAME Box-Muller pairs.  Instead of both lanes evaluating every pair,
+// elements are taken two at a time: the even-q lane evaluates the pair of element e, the odd-q lane the pair of element e+1, and they swap the
+// halves the partner needs with one ds_bpermute — half the transforms, identical values.  In loop slot e (even) the lane's pair index is
+// 2 (e + odd) + sh: its block slot is a compile-time number + (2 odd + sh) and its half is (e >> 2) & 1 for both lanes, so the pair 8 further on
+// (loop slot e + 4, same lane) takes the words (z, w) the block of slot e left behind: one Philox block per two slots.  (Pairs past ceil(D/2)
+// are layout padding: whatever they draw is discarded; the accept draw is taken explicitly by these kernels.)
+struct MPairStash { uint32_t w[4]; };
+__device__ __forceinline__ void mpair_normals(unsigned long long seed, unsigned long long gchain, unsigned long long t, int e, uint32_t lane_slot,
+                                              MPairStash& st, double& z0, double& z1)
+{
+    const int si = (e >> 1) & 1;
+    uint32_t wa, wb;
+    if ((e >> 2) & 1) { wa = st.w[2 * si]; wb = st.w[2 * si + 1]; }
+    else {
+        const uint32_t base = ((2u * (uint32_t)e) & 7u) | (((2u * (uint32_t)e) >> 4) << 3);
+        const kd_u32x4 b = kd_stream_block(seed, gchain, t, base + lane_slot);
+        wa = b.x; wb = b.y; st.w[2 * si] = b.z; st.w[2 * si + 1] = b.w;
+    }
+    double u1, lg;
+    kd_normal_pair_w(wa, wb, &z0, &z1, &u1, &lg);
+}
 template <int NE>
 __device__ __forceinline__ void mnormals(const MfmaCtx<NE>& c, unsigned long long seed,
                                          unsigned long long gchain, unsigned long long t,
@@ -111,23 +132,22 @@ __device__ __forceinline__ void mnormals(const MfmaCtx<NE>& c, unsigned long lon
     const uint32_t sh = (uint32_t)(c.q >> 1);
     const bool odd = (c.q & 1) != 0;
     const int nv = c.nv_here();
-    // Lanes q and q^1 (lane ^ 16) of a chain need the two halves of the SAME Box-Muller pairs (even dims take the
-    // cos half, odd dims the sin half).  Instead of both lanes evaluating every pair, elements are taken two at a
-    // time: the even-q lane evaluates the pair of element e, the odd-q lane the pair of element e+1, and they swap
-    // the halves the partner needs with one ds_bpermute — half the Philox/log/sincos work, identical values.
+    MPairStash st = { { 0u, 0u, 0u, 0u } };
 #pragma unroll
     for (int e = 0; e + 1 < NE; e += 2) {
         double z0, z1;
-        const uint32_t mine = 2u * (uint32_t)(odd ? e + 1 : e) + sh;
-        kd_normal_pair(kd_stream_block(seed, gchain, t, mine), &z0, &z1);
+        mpair_normals(seed, gchain, t, e, (odd ? 2u : 0u) + sh, st, z0, z1);
         const double recv = bperm_xor(odd ? z0 : z1, c.lane, 16);
         z[e] = e < nv ? (odd ? recv : z0) : 0.0;              // even q: cos half of pair(e);   odd q: sin half of pair(e) from the partner
         z[e + 1] = e + 1 < nv ? (odd ? z1 : recv) : 0.0;  // even q: cos half of pair(e+1) from the partner; odd q: sin half of pair(e+1)
         __builtin_amdgcn_sched_barrier(0);   // keep the unrolled Philox/Box-Muller bodies from interleaving (VGPR pressure)
     }
-    if (NE & 1) {
-        double z0, z1;
-        kd_normal_pair(kd_stream_block(seed, gchain, t, 2u * (uint32_t)(NE - 1) + sh), &z0, &z1);
+    if (NE & 1) {                            // the last element alone: both lanes of a pair evaluate pair index 2 (NE - 1) + sh
+        constexpr uint32_t p0 = 2u * (uint32_t)(NE - 1);
+        const kd_u32x4 b = kd_stream_block(seed, gchain, t, ((p0 & 7u) | ((p0 >> 4) << 3)) + sh);
+        constexpr bool hb = ((p0 >> 3) & 1u) != 0u;
+        double z0, z1, u1, lg;
+        kd_normal_pair_w(hb ? b.z : b.x, hb ? b.w : b.y, &z0, &z1, &u1, &lg);
         z[NE - 1] = NE - 1 < nv ? (odd ? z1 : z0) : 0.0;
     }
 }
@@ -298,7 +318,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             const double ratio = H1 - H0;                              // HMC.jl:161
             const double ex = kd_exp(ratio);
             const double a = 1.0 < ex ? 1.0 : ex;                      // HMC.jl:163
-            const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+            const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
             acc = u < a;                                               // HMC.jl:165
             if (da) da_update(p, tn, (long long)t + 1, a);             // HMC.jl:225-249
         } else if (SAMPLER == KLARA_SAMPLER_MALA) {
@@ -341,7 +361,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             ratio -= red[2];
             acc = ratio > 0.0;                                         // MALA.jl:94
             if (!acc && ratio > KD_LOG_UMIN_GUARD) {
-                const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+                const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
                 acc = ratio > kd_log_u01(u);
             }
         } else if (SAMPLER == KLARA_SAMPLER_SLICE) {
@@ -441,7 +461,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             const double ratio = ltp - lt;                             // MH.jl:83
             acc = ratio > 0.0;                                         // MH.jl:97
             if (!acc && ratio > KD_LOG_UMIN_GUARD) {
-                const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+                const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
                 acc = ratio > kd_log_u01(u);
             }
         }

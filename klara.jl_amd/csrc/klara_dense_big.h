@@ -60,15 +60,15 @@ __device__ __forceinline__ void dense_stream(const double* __restrict__ gP, int 
 template <int NE, class F>
 __device__ __forceinline__ void mnormals_each(const MfmaCtx<NE>& c, unsigned long long seed, unsigned long long gchain, unsigned long long t, F f)
 {
-    static_assert(NE % 2 == 0, "pairs of elements");
+    static_assert(NE % 8 == 0, "pairs of elements, and every block's second pair in the same lane");
     const uint32_t sh = (uint32_t)(c.q >> 1);
     const bool odd = (c.q & 1) != 0;
     const int nv = c.nv_here();
+    MPairStash st = { { 0u, 0u, 0u, 0u } };
 #pragma unroll
     for (int e = 0; e + 1 < NE; e += 2) {
         double z0, z1;
-        const uint32_t mine = 2u * (uint32_t)(odd ? e + 1 : e) + sh;
-        kd_normal_pair(kd_stream_block(seed, gchain, t, mine), &z0, &z1);
+        mpair_normals(seed, gchain, t, e, (odd ? 2u : 0u) + sh, st, z0, z1);
         const double recv = bperm_xor(odd ? z0 : z1, c.lane, 16);
         f(e, e < nv ? (odd ? recv : z0) : 0.0);
         f(e + 1, e + 1 < nv ? (odd ? z1 : recv) : 0.0);
@@ -80,20 +80,7 @@ template <int NE>
 __device__ __forceinline__ void mnormals_lds(const MfmaCtx<NE>& c, unsigned long long seed, unsigned long long gchain, unsigned long long t,
                                              double* momw)
 {
-    static_assert(NE % 2 == 0, "pairs of elements");
-    const uint32_t sh = (uint32_t)(c.q >> 1);
-    const bool odd = (c.q & 1) != 0;
-    const int nv = c.nv_here();
-#pragma unroll
-    for (int e = 0; e + 1 < NE; e += 2) {
-        double z0, z1;
-        const uint32_t mine = 2u * (uint32_t)(odd ? e + 1 : e) + sh;
-        kd_normal_pair(kd_stream_block(seed, gchain, t, mine), &z0, &z1);
-        const double recv = bperm_xor(odd ? z0 : z1, c.lane, 16);
-        momw[e * 64] = e < nv ? (odd ? recv : z0) : 0.0;
-        momw[(e + 1) * 64] = e + 1 < nv ? (odd ? z1 : recv) : 0.0;
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    mnormals_each<NE>(c, seed, gchain, t, [&](int e, double z) { momw[e * 64] = z; });
 }
 
 // the lane's momentum column in LDS, touched in chunks of 8 elements: 8 reads in flight, then the 8 updates (one ds_read per element and a
@@ -159,6 +146,8 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
     const bool do_sum = p.sum != nullptr;
     long long held = do_sum ? p.held[cx.chain_ok ? cx.chain : 0] : 0;
     const __amdgpu_buffer_rsrc_t wX = mwin<NE>(cx, p.X, 0, p.D), wG = mwin<NE>(cx, p.GR, 0, p.D);
+    const __amdgpu_buffer_rsrc_t wSig = __builtin_amdgcn_make_buffer_rsrc((void*)(SAMPLER == KLARA_SAMPLER_MH ? p.vecparam : nullptr), 0,
+                                                                          SAMPLER == KLARA_SAMPLER_MH ? p.D * 8 : 0, 0x00020000);   // MH's proposal scales
 
     // the committed state of the lane's chain: value in registers, gradient in the accumulator tiles (element e = ga[e >> 2][e & 3]).  They are
     // (re)read from memory at the start of the launch and after a rejected proposal; an accepted proposal simply stays where it is.
@@ -215,7 +204,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             const double ratio = H1 - H0;                                            // HMC.jl:161
             const double ex = kd_exp(ratio);
             const double a = 1.0 < ex ? 1.0 : ex;                                    // HMC.jl:163
-            const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+            const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
             acc = u < a;                                                             // HMC.jl:165
             if (da) da_update(p, tn, (long long)t + 1, a);                           // HMC.jl:225-249
 
@@ -254,14 +243,14 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             ratio += red[1];
             ratio -= red[2];
             acc = ratio > 0.0;                                                        // MALA.jl:94
-            if (!acc && ratio > KD_LOG_UMIN_GUARD) {
-                const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
-                acc = ratio > kd_log_u01(u);
+            if (__any(!acc && ratio > KD_LOG_UMIN_GUARD)) {      // (wave-uniform: see the note at the commit below; at or below the guard no uniform accepts)
+                const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+                acc = acc || ratio > kd_log_u01(u);
             }
         } else {
             // iterate/MH.jl:72-124
             mnormals_each<NE>(cx, p.seed, gchain, t, [&](int e, double z) {
-                const double sg = (4 * e + cx.q < p.D) ? p.vecparam[4 * e + cx.q] : 0.0;
+                const double sg = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wSig, (unsigned)(4 * e + cx.q) * 8u, 0, 0));   // (0 past D)
                 xp[e] = xp[e] + sg * z;                                               // MH.jl:79
             });
             dense_stream<NE, HASMU>(Pfrag, cx.lane, xp, ga, ldsMu);                  // MH.jl:81
@@ -273,46 +262,72 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             ltp = p.gconst + 0.5 * red[0];
             const double ratio = ltp - lt;                                            // MH.jl:83
             acc = ratio > 0.0;                                                        // MH.jl:97
-            if (!acc && ratio > KD_LOG_UMIN_GUARD) {
-                const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
-                acc = ratio > kd_log_u01(u);
+            if (__any(!acc && ratio > KD_LOG_UMIN_GUARD)) {      // (wave-uniform: see the note at the commit below; at or below the guard no uniform accepts)
+                const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+                acc = acc || ratio > kd_log_u01(u);
             }
         }
 
+        // Fold, commit, reload: NO divergent branch around the value / gradient arrays.  With ~500 live registers the allocator parks part of them in
+        // accumulator registers, and a copy it places at the head of a join block runs under the branch's execution mask, before the mask is restored:
+        // k_dense_big<MH, 48, mean> lost element 15 of every chain that had just rejected that way (ROCm 7.2; found by the randomised parity jobs when the
+        // normals changed the allocation).  So every lane takes every step under a wave-uniform condition; a lane with nothing to do addresses out of
+        // bounds (loads return 0, stores are dropped) and keeps its registers through selects.
         if (do_sum && __any(acc && held > 0)) {          // leaving a state after `held` saved steps: fold it into the sums (the OLD value is in X)
-            if (acc && held > 0) {
-                const double hf = (double)held;
-                const __amdgpu_buffer_rsrc_t ws = mwin<NE>(cx, p.sum, 0, p.D), wq = mwin<NE>(cx, p.sumsq, 0, p.D);
-                const int nv = cx.nv_here();
-#pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    const unsigned o = cx.off(e, nv);
-                    const double xo = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
-                    const double sv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ws, o, 0, 0));
-                    const double qv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wq, o, 0, 0));
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sv + hf * xo), ws, o, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, qv + hf * (xo * xo)), wq, o, 0, 0);
-                }
-                held = 0;
-            }
-        }
-        if (acc) {                                       // commit (HMC.jl:166-176)
+            const bool fold = acc && held > 0;
+            const double hf = (double)held;
+            const __amdgpu_buffer_rsrc_t ws = mwin<NE>(cx, p.sum, 0, p.D), wq = mwin<NE>(cx, p.sumsq, 0, p.D);
             const int nv = cx.nv_here();
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                const unsigned o = cx.off(e, nv);
+                const unsigned o = fold ? cx.off(e, nv) : KLARA_BUF_OOB;
+                const double xo = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
+                const double sv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ws, o, 0, 0));
+                const double qv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wq, o, 0, 0));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sv + hf * xo), ws, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, qv + hf * (xo * xo)), wq, o, 0, 0);
+            }
+            held = fold ? 0 : held;
+        }
+        if (__any(acc)) {                                // commit (HMC.jl:166-176)
+            const int nv = cx.nv_here();
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const unsigned o = acc ? cx.off(e, nv) : KLARA_BUF_OOB;
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, xp[e]), wX, o, 0, 0);
                 if (NEEDG) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, (double)ga[e >> 2][e & 3]), wG, o, 0, 0);
             }
-            lt = ltp;
-        } else {
-            reload();                                    // the registers hold the rejected proposal: back to the committed state
+        }
+        lt = acc ? ltp : lt;
+        if (__any(!acc)) {                               // the registers of a lane that rejected hold the proposal: back to the committed state
+            const int nv = cx.nv_here();
+#pragma unroll
+            for (int e0 = 0; e0 < NE; e0 += 8) {         // 8 elements at a time: the loads of a group in flight, then its selects (not 2 NE loaded values live at once)
+                double xc[8], gc[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned o = acc ? KLARA_BUF_OOB : cx.off(e0 + j, nv);
+                    xc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
+                    if (NEEDG) gc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, o, 0, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + j;
+                    xp[e] = acc ? xp[e] : xc[j];
+                    if (NEEDG) ga[e >> 2][e & 3] = acc ? ga[e >> 2][e & 3] : gc[j];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         nacc += acc ? 1ull : 0ull;
-        if (p.cnt && acc) tn.accepted += 1;
-        if (accept_out != nullptr && cx.chain_ok && cx.q == 0)
-            accept_out[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
-        if (!p.pooled && !da) tuning_block(p, tn);
+        tn.accepted += (p.cnt && acc) ? 1 : 0;
+        if (accept_out != nullptr) {                     // (one byte per chain from its q = 0 lane; the other lanes address out of bounds)
+            const __amdgpu_buffer_rsrc_t wa = __builtin_amdgcn_make_buffer_rsrc((void*)(accept_out + (long long)s * p.nchains + cx.first_chain), 0,
+                                                                                __builtin_amdgcn_readfirstlane(cx.here), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(acc ? 1 : 0), wa, (cx.chain_ok && cx.q == 0) ? (unsigned)cx.cl : KLARA_BUF_OOB, 0, 0);
+        }
+        if (!p.pooled && !da) tuning_block_uniform(p, tn);
         else if (da && p.cnt && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {     // verbose report block, iterate/HMC.jl:229-243
             tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
         }
@@ -336,7 +351,11 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
                     for (int e = 0; e < NE; ++e)
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, (double)ga[e >> 2][e & 3]), wh, cx.off(e, nv), 0, 0);
                 }
-                if (p.hist_lt != nullptr && cx.chain_ok && cx.q == 0) p.hist_lt[col * p.nchains + cx.chain] = lt;
+                if (p.hist_lt != nullptr) {
+                    const __amdgpu_buffer_rsrc_t wl = mwin<NE>(cx, p.hist_lt, col * p.nchains, 1);                // (row `col`, the tile's chains)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, lt), wl,
+                                                          (cx.chain_ok && cx.q == 0) ? (unsigned)cx.cl * 8u : KLARA_BUF_OOB, 0, 0);
+                }
             }
         }
     }

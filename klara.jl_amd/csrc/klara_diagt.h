@@ -273,14 +273,39 @@ __device__ __forceinline__ void load_pair_param(const PairCtx<NP, Q>& c, const g
     }
 }
 
-// proposal normals of pair p for transition t; padding pairs get z = 0 (their x, g, parameters are 0 / defaults, so
-// every term they contribute is exactly 0).  (u1, log u1) of the block are handed back: the last pair's are the accept
-// draw when the slot ceil(D/2) falls on it (see AccDraw in klara_kernels.h).
+// proposal normals of pair slot p of the lane (pair index p*Q + q) for transition t; padding pairs get z = 0 (their x, g, parameters are
+// 0 / defaults, so every term they contribute is exactly 0).  One Philox block serves pair indices i and i + 8 (detmath.h
+// kd_normal_pair_at); with Q <= 8 lanes per chain both sit in the same lane, STEP = 8/Q slots apart: the block is formed at the first
+// of the two and its words (z, w) wait in two registers (`stash`) for the second — 7 blocks per lane and transition instead of 13 in
+// the 4-lane headline kernel.  With 16 / 32 lanes per chain the partner sits in another lane: every lane forms its block and takes
+// its half.  (u1, log u1) are handed back: the last slot's are the accept draw when pair index ceil(D/2) falls on it (padding pairs
+// take words (x, y) of block slot = pair index; see AccDraw in klara_kernels.h) — which needs the last slot to form a block of its own.
+template <int Q> struct PairShare {
+    static constexpr int STEP = Q <= 8 ? 8 / Q : 0;
+    static constexpr bool second(int p) { return STEP != 0 && ((p / (STEP ? STEP : 1)) & 1) != 0; }
+};
 template <int NP, int Q>
 __device__ __forceinline__ void pair_normals(const PairCtx<NP, Q>& c, unsigned long long seed, unsigned long long gchain,
-                                             unsigned long long t, int p, double& z0, double& z1, double& u1, double& lg1)
+                                             unsigned long long t, int p, uint32_t (&stash)[4], double& z0, double& z1, double& u1, double& lg1)
 {
-    kd_normal_pair_ex(kd_stream_block(seed, gchain, t, (uint32_t)(p * Q + c.q)), &z0, &z1, &u1, &lg1);
+    constexpr int STEP = PairShare<Q>::STEP, S1 = STEP ? STEP : 1;
+    uint32_t wa, wb;
+    if (PairShare<Q>::second(p)) {
+        wa = stash[2 * (p % S1)]; wb = stash[2 * (p % S1) + 1];
+    } else {
+        const uint32_t idx = (uint32_t)(p * Q + c.q);
+        const bool pad = p == NP - 1 && !c.last_ok;
+        const kd_u32x4 b = kd_stream_block(seed, gchain, t, pad ? idx : kd_pair_block(idx));
+        if constexpr (STEP != 0) {                         // first of the two: half 0 by construction
+            wa = b.x; wb = b.y;
+            stash[2 * (p % S1)] = b.z; stash[2 * (p % S1) + 1] = b.w;
+        } else {
+            const bool hb = !pad && kd_pair_half(idx) != 0u;
+            wa = hb ? b.z : b.x; wb = hb ? b.w : b.y;
+        }
+    }
+    kd_normal_pair_w(wa, wb, &z0, &z1, &u1, &lg1);
+    KLARA_PIN(z0); KLARA_PIN(z1);        // formed HERE: left to itself the compiler sinks the transforms of the stashed halves towards their uses (+60 registers)
     if (p == NP - 1 && !c.last_ok) z0 = 0.0;
     if (p == NP - 1 && !c.last_full) z1 = 0.0;
 }
@@ -385,7 +410,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
     // accept draw: slot S = ceil(D/2) = D/2.  (NP-1)*Q < D/2 <= NP*Q, so when the layout has padding (D/2 < NP*Q) the
     // slot is the last pair of lane S % Q and its Box-Muller already formed u and log(u).
     const int acc_slot = (D + 1) >> 1;
-    const bool acc_free = acc_slot < NP * Q;
+    const bool acc_free = acc_slot < NP * Q && !PairShare<Q>::second(NP - 1);
     const int acc_lane = (cx.lane - cx.q) + (acc_slot & (Q - 1));
 
     const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
@@ -472,6 +497,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
             constexpr int NR = Q == 4 ? 2 : 1;
             double red[3 * NR] = {}, red1[1], red2[2];
             double u_last = 0.5, lg_last = 0.0;
+            uint32_t nstash[4] = { 0u, 0u, 0u, 0u };             // words (z, w) of the blocks whose second pair is still to come (pair_normals)
             bool acc;
             double ltp, a_da = 0.0;
 
@@ -485,7 +511,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
             if (ZFIRST) {
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
-                    pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z[2 * pi], z[2 * pi + 1], u_last, lg_last);
+                    pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, nstash, z[2 * pi], z[2 * pi + 1], u_last, lg_last);
                     KLARA_DT_PAIR_FENCE(pi);
                 }
             }
@@ -606,7 +632,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
                     double z0 = ZFIRST ? z[(2 * pi) % (ZFIRST ? E : 2)] : 0.0, z1 = ZFIRST ? z[(2 * pi + 1) % (ZFIRST ? E : 2)] : 0.0;
-                    if (!ZFIRST) pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z0, z1, u_last, lg_last);
+                    if (!ZFIRST) pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, nstash, z0, z1, u_last, lg_last);
                     const int r = (NR == 2 && (pi & 1)) ? 3 : 0;
                     if constexpr (USERPAIR) {
                         const double a = x[2 * pi] + sig[2 * pi] * z0, b = x[2 * pi + 1] + sig[2 * pi + 1] * z1;      // MH.jl:79
@@ -633,7 +659,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                 acc = ratio > 0.0;                                                             // :97
                 if (acc_free) acc = acc || ratio > lane_bcast(lg_last, acc_lane);
                 else if (!acc && ratio > KD_LOG_UMIN_GUARD)
-                    acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot)));
+                    acc = ratio > kd_log_u01(kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot)));
             } else if (SAMPLER == KLARA_SAMPLER_MALA) {                            // iterate/MALA.jl:78-128
                 const double h_ = tn.step, halfh = 0.5 * h_, sq = KCNT ? __builtin_sqrt(h_) : p.sqrt_step0;
                 const double half_inv_h = 0.5 * (KCNT ? 1.0 / h_ : p.inv_step0);
@@ -654,7 +680,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
                     double z0 = ZFIRST ? z[(2 * pi) % (ZFIRST ? E : 2)] : 0.0, z1 = ZFIRST ? z[(2 * pi + 1) % (ZFIRST ? E : 2)] : 0.0;
-                    if (!ZFIRST) pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, z0, z1, u_last, lg_last);
+                    if (!ZFIRST) pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, nstash, z0, z1, u_last, lg_last);
                     const int r = (NR == 2 && (pi & 1)) ? 3 : 0;
                     if constexpr (USERPAIR) {
                         double nt, ge0, ge1, gp0, gp1;
@@ -685,14 +711,14 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                 acc = ratio > 0.0;                                                             // :94
                 if (acc_free) acc = acc || ratio > lane_bcast(lg_last, acc_lane);
                 else if (!acc && ratio > KD_LOG_UMIN_GUARD)
-                    acc = ratio > kd_log_u01(kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot)));
+                    acc = ratio > kd_log_u01(kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot)));
             } else {                                                               // iterate/HMC.jl:124-201
                 const double eps = tn.step, halfe = 0.5 * eps;
                 double mom[E], gp[E];
                 double k0[1] = { 0.0 };
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
-                    pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, mom[2 * pi], mom[2 * pi + 1], u_last, lg_last);   // :135
+                    pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, nstash, mom[2 * pi], mom[2 * pi + 1], u_last, lg_last);   // :135
                     k0[0] = k0[0] + mom[2 * pi] * mom[2 * pi];
                     k0[0] = k0[0] + mom[2 * pi + 1] * mom[2 * pi + 1];
                 }
@@ -760,7 +786,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                 const double a = 1.0 < ex ? 1.0 : ex;                                          // :163
                 a_da = a;
                 const double u = acc_free ? lane_bcast(u_last, acc_lane)
-                                          : kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot));
+                                          : kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)acc_slot));
                 acc = u < a;                                                                   // :165
             }
 

@@ -257,12 +257,12 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
     for (int s = 0; s < kl.nsteps; ++s) {
         const unsigned long long t = kl.t0 + (unsigned long long)s;
         if (KCNT) tune_count_proposal(p, tn);
-        // momentum ~ N(0, I) (iterate/HMC.jl:135): unit i = elements 2i, 2i+1 = one Philox block (slot i); the hyper block
-        // (elements 2R..2R+4) takes slots R, R+1, R+2; the accept uniform is slot ceil(D/2) = R + 3
+        // momentum ~ N(0, I) (iterate/HMC.jl:135): unit i = elements 2i, 2i+1 = pair index i; the hyper block (elements 2R..2R+4) is pair
+        // indices R, R+1, R+2 (64 bits of a Philox block each: kd_normal_pair_at); the accept uniform is pair index ceil(D/2) = R + 3
         HierVec<RPL> mom;
 #pragma unroll
         for (int k = 0; k < RPL; ++k) {
-            kd_normal_pair(kd_stream_block(p.seed, gchain, t, (uint32_t)(RPL * cx.q + k)), &mom.a[k], &mom.b[k]);
+            { double u1_, lg_; kd_normal_pair_at(p.seed, gchain, t, (uint32_t)(RPL * cx.q + k), (uint32_t)(R + 3), &mom.a[k], &mom.b[k], &u1_, &lg_); }
             if (!cx.rv[k]) { mom.a[k] = 0.0; mom.b[k] = 0.0; }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -272,7 +272,7 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
         double acc_u, acc_logu;
         {
             double z0, z1, u1, lg1;
-            kd_normal_pair_ex(kd_stream_block(p.seed, gchain, t, (uint32_t)(R + (cx.q & 3))), &z0, &z1, &u1, &lg1);
+            kd_normal_pair_at(p.seed, gchain, t, (uint32_t)(R + (cx.q & 3)), (uint32_t)(R + 3), &z0, &z1, &u1, &lg1);
             mom.h[0] = quad_bcast(z0, 0); mom.h[1] = quad_bcast(z1, 0);
             mom.h[2] = quad_bcast(z0, 1); mom.h[3] = quad_bcast(z1, 1);
             mom.h[4] = quad_bcast(z0, 2);

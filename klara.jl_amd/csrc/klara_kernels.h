@@ -333,11 +333,11 @@ KLARA_PRAGMA_UNROLL_E
     }
 }
 
-// proposal normals of this lane's E elements for transition t: element i <- block slot i>>1,
+// proposal normals of this lane's E elements for transition t: element pair i>>1 <- 64 bits of a block (kd_normal_pair_at),
 // cos branch for even i, sin branch for odd i (E is even, i0 is even).
 // The accept uniform of a transition is words (x,y) of block slot S = ceil(D/2), the first block past the proposal
 // normals.  Whenever the layout has padding (G*E > D, e.g. D = 100 on 32 lanes x 4) some lane evaluates that very
-// block as one of its (unused) normal pairs, and Box-Muller has already formed u = u52(x,y) and log(u) for it: the
+// block as one of its (unused) normal pairs, and Box-Muller has already formed u = kd_u44(x,y) and log(u) for it: the
 // accept test then costs one ds_bpermute instead of a Philox block plus a log.  Same words, same kd_log -> same bits.
 struct AccDraw { double u, logu; bool have; /* u, logu are this chain's accept draw in every lane already (row-split layout) */ };
 
@@ -350,7 +350,7 @@ __device__ __forceinline__ double quad_bcast(double v, int k)
 template <int E>
 __device__ __forceinline__ void lane_normals(const LaneCtx<E>& c, unsigned long long seed,
                                              unsigned long long gchain, unsigned long long t,
-                                             double (&z)[E], AccDraw& ad, int acc_slot)
+                                             double (&z)[E], AccDraw& ad, int acc_slot, int npairs)
 {
     static_assert(E % 2 == 0, "E must be even");
     // Row-split layout (logistic target): RS >= 4 lanes hold the SAME chain and would each evaluate the same E/2 blocks, plus the block
@@ -362,8 +362,10 @@ __device__ __forceinline__ void lane_normals(const LaneCtx<E>& c, unsigned long 
             constexpr int NB = (E / 2 + 3) / 4;        // blocks per lane: 1 up to E = 8, 2 at E = 16 (slots rq & 3 and 4 + (rq & 3))
             double z0[NB], z1[NB], u1[NB], lg1[NB];
 #pragma unroll
-            for (int m = 0; m < NB; ++m)
-                kd_normal_pair_ex(kd_stream_block(seed, gchain, t, (uint32_t)((c.rq & 3) + 4 * m)), &z0[m], &z1[m], &u1[m], &lg1[m]);
+            for (int m = 0; m < NB; ++m) {      // pair indices < 8: block slot = pair index, words (x, y) (kd_normal_pair_at), real or padding
+                const kd_u32x4 b = kd_stream_block(seed, gchain, t, (uint32_t)((c.rq & 3) + 4 * m));
+                kd_normal_pair_w(b.x, b.y, &z0[m], &z1[m], &u1[m], &lg1[m]);
+            }
 KLARA_PRAGMA_UNROLL_E
             for (int j = 0; j < E / 2; ++j) {
                 const double a = quad_bcast(z0[j >> 2], j & 3), b = quad_bcast(z1[j >> 2], j & 3);
@@ -382,9 +384,8 @@ KLARA_PRAGMA_UNROLL_E
     }
 KLARA_PRAGMA_UNROLL_E
     for (int j = 0; j < E / 2; ++j) {
-        const kd_u32x4 b = kd_stream_block(seed, gchain, t, (uint32_t)((c.i0 >> 1) + j));
         double z0, z1, u1, lg1;
-        kd_normal_pair_ex(b, &z0, &z1, &u1, &lg1);
+        kd_normal_pair_at(seed, gchain, t, (uint32_t)((c.i0 >> 1) + j), (uint32_t)npairs, &z0, &z1, &u1, &lg1);
         if ((c.i0 >> 1) + j == acc_slot) { ad.u = u1; ad.logu = lg1; }
         // padding elements (index >= D, or lanes of a group past the last chain) get z = 0.  With x = g = 0
         // loaded there too, every per-element term downstream (proposal, gradient, kinetic/Metropolis sums)
@@ -725,6 +726,21 @@ __device__ __forceinline__ void tuning_block(const KParams& p, TuneRegs& tn)
     }
 }
 
+// The same block for kernels that must not branch divergently (klara_dense_big.h): entered when any lane's chain is due, every lane evaluates it, the lanes
+// that are not due keep their values through selects — the same operations on the same operands for the lanes that are.
+__device__ __forceinline__ void tuning_block_uniform(const KParams& p, TuneRegs& tn)
+{
+    if (!p.cnt) return;
+    const bool due = tn.totproposed <= p.burnin && tn.phase == 0;
+    if (!__any(due)) return;
+    const double rate = (double)tn.accepted / (double)tn.proposed;
+    double step = tn.step;
+    if (p.tuner == KLARA_TUNER_ACCEPT_RATE && !p.is_mh) step *= rate_score(p, rate - p.targetrate);
+    tn.step = due ? step : tn.step;
+    tn.totproposed = due ? tn.totproposed + tn.proposed : tn.totproposed;
+    tn.accepted = due ? 0 : tn.accepted; tn.proposed = due ? 0 : tn.proposed;
+}
+
 // nleaps of a transition under dual averaging: max(1, Int(round(lambda/step))) — iterate/HMC.jl:142-144
 // (round = ties to even; capped at 65536, non-finite quotient -> cap).  Callers pass 1 for the padding lanes of a ragged last wavefront:
 // their phantom state (x = 0, re-read every transition) can drive the dual-averaging step towards 0, and the wavefront runs to the
@@ -764,7 +780,7 @@ __device__ __forceinline__ bool accept_log_test(const KParams& p, const LaneCtx<
         return acc || ratio > logu;
     }
     if (!acc && ratio > KD_LOG_UMIN_GUARD) {   // below the guard no uniform of the stream can accept
-        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+        const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
         acc = ratio > kd_log_u01(u);
     }
     return acc;
@@ -926,7 +942,7 @@ KLARA_PRAGMA_UNROLL_E
     const int acc_owner = ((p.D + 1) >> 1) / (E / 2);
     const double u = ad.have ? ad.u : (acc_owner < cx.G)
         ? (cx.G > 1 ? lane_bcast(ad.u, (cx.lane - cx.q) + acc_owner) : ad.u)
-        : kd_uniform_xy(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+        : kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
     const bool acc = u < a;                                                           // :165
     if (!COMMIT) {
 KLARA_PRAGMA_UNROLL_E
@@ -1168,7 +1184,7 @@ KLARA_PRAGMA_UNROLL_E
         double z[E];
         AccDraw ad = { 0.5, 0.0, false };
         const int acc_slot = (p.D + 1) >> 1;
-        if (NEEDZ) lane_normals<E>(cx, p.seed, gchain, kl.t0, z, ad, acc_slot);   // before the loaded state is touched
+        if (NEEDZ) lane_normals<E>(cx, p.seed, gchain, kl.t0, z, ad, acc_slot, (p.D + 1) >> 1);   // before the loaded state is touched
 
         TuneRegs tn;
         if (per_chain_tune) tn = { cur.step, cur.accepted, cur.proposed, cur.totproposed, 0, 0.0, 0.0 };
@@ -1239,7 +1255,7 @@ KLARA_PRAGMA_UNROLL_E
                 }
                 sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
             }
-            if (!ONESTEP && NEEDZ && s + 1 < nsteps) lane_normals<E>(cx, p.seed, gchain, t + 1, z, ad, acc_slot);
+            if (!ONESTEP && NEEDZ && s + 1 < nsteps) lane_normals<E>(cx, p.seed, gchain, t + 1, z, ad, acc_slot, (p.D + 1) >> 1);
         }
 
         if (DIRECT) {
@@ -1317,6 +1333,6 @@ __global__ __launch_bounds__(256) void k_init_normal(const KParams p)
     const LaneCtx<E> cx = make_ctx<E, GT>(p);
     double z[E];
     AccDraw ad;
-    lane_normals<E>(cx, p.seed, (unsigned long long)(p.chain_offset + cx.chain), KLARA_INIT_TRANSITION, z, ad, -1);
+    lane_normals<E>(cx, p.seed, (unsigned long long)(p.chain_offset + cx.chain), KLARA_INIT_TRANSITION, z, ad, -1, (p.D + 1) >> 1);
     store_vec<E>(cx, p.X, p.D, z);
 }

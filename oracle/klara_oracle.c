@@ -28,9 +28,9 @@
  *
  * Random stream (build-defined; the reference's is unseeded MT19937): Philox4x32-10, key = seed,
  * counter = (transition << 24 | slot, global chain id) — detmath.h kd_stream_block.
- *   normals of a transition: element i <- block slot (i >> 1), Box-Muller cos branch for even i,
- *     sin branch for odd i;
- *   accept uniform (MH, MALA, HMC): slot ceil(D/2), words (x,y);
+ *   normals of a transition: element pair p = i >> 1 <- 64 bits: half (p >> 3) & 1 of block slot (p & 7) + 8 (p >> 4) (one block
+ *     serves pairs p and p + 8), Box-Muller on a 44-bit radius uniform and a 20-bit angle, cos branch for even i, sin branch for odd i;
+ *   accept uniform (MH, MALA, HMC): slot ceil(D/2), words (x,y), 44 bits;
  *   slice sampler, coordinate i: slot (i << 14): words (x,y) -> log-uniform, (z,w) -> runiform;
  *     shrink attempt a >= 1: slot (i << 14) | a, words (x,y).
  *   initial state x0 ~ N(0,I): transition index 2^40 - 1 ("-1"), same element -> slot mapping.
@@ -417,16 +417,17 @@ static double ko_uptograd(const ko_target_ctx* c, const double* x, double* g, do
 /* ------------------------------------------------------------------ random draws */
 static void ko_normals(uint64_t seed, uint64_t chain, uint64_t t, int D, double* z)
 {
+    /* element pair j <- half (j >> 3) & 1 of block slot (j & 7) + 8 (j >> 4): detmath.h kd_normal_pair_at */
     for (int j = 0; 2 * j < D; ++j) {
-        double z0, z1;
-        kd_normal_pair(kd_stream_block(seed, chain, t, (uint32_t)j), &z0, &z1);
+        double z0, z1, u1, lg1;
+        kd_normal_pair_at(seed, chain, t, (uint32_t)j, (uint32_t)((D + 1) / 2), &z0, &z1, &u1, &lg1);
         z[2 * j] = z0;
         if (2 * j + 1 < D) z[2 * j + 1] = z1;
     }
 }
 static double ko_accept_uniform(uint64_t seed, uint64_t chain, uint64_t t, int D)
 {
-    return kd_uniform_xy(kd_stream_block(seed, chain, t, (uint32_t)((D + 1) / 2)));
+    return kd_accept_uniform(kd_stream_block(seed, chain, t, (uint32_t)((D + 1) / 2)));
 }
 
 /* ------------------------------------------------------------------ per-chain state bundle */
@@ -880,20 +881,23 @@ void ko_math(int op, int64_t n, const double* in, const double* in2, double* out
         }
     }
 }
-void ko_normal_pair(const uint32_t blk[4], double out[2])
-{
-    kd_u32x4 b = { blk[0], blk[1], blk[2], blk[3] };
-    kd_normal_pair(b, &out[0], &out[1]);
-}
 double ko_u52(uint32_t hi, uint32_t lo) { return kd_u52(hi, lo); }
-/* batch form (n blocks -> 2n normals) and the CPU mirror of klara_selftest_normal_tail (same blocks, same counts) */
-void ko_normal_pairs(int64_t n, const uint32_t* blk, double* out)
+double ko_u44(uint32_t wa, uint32_t wb) { return kd_u44(wa, wb); }
+/* the samplers' form: n word pairs (wa, wb) -> 2n normals */
+void ko_normal_pairs_w(int64_t n, const uint32_t* w, double* out)
 {
     for (int64_t i = 0; i < n; ++i) {
-        kd_u32x4 b = { blk[4 * i], blk[4 * i + 1], blk[4 * i + 2], blk[4 * i + 3] };
-        kd_normal_pair(b, &out[2 * i], &out[2 * i + 1]);
+        double u1, lg;
+        kd_normal_pair_w(w[2 * i], w[2 * i + 1], &out[2 * i], &out[2 * i + 1], &u1, &lg);
     }
 }
+/* proposal normals of one transition of one chain as the samplers draw them (D values) and its accept uniform */
+void ko_transition_normals(uint64_t seed, uint64_t chain, uint64_t t, int32_t D, double* z, double* accept_u)
+{
+    ko_normals(seed, chain, t, D, z);
+    *accept_u = ko_accept_uniform(seed, chain, t, D);
+}
+/* the CPU mirror of klara_selftest_normal_tail (same blocks, same counts) */
 void ko_normal_tail(uint64_t seed, uint64_t first_chain, int64_t nchains, int64_t ntransitions, int32_t nthr, const double* thr,
                     uint64_t* counts, double* moments)
 {
@@ -902,9 +906,11 @@ void ko_normal_tail(uint64_t seed, uint64_t first_chain, int64_t nchains, int64_
 #pragma omp parallel for schedule(static) reduction(+ : c[:8], s1, s2, s4) reduction(max : mx)
     for (int64_t i = 0; i < nchains; ++i)
         for (int64_t t = 0; t < ntransitions; ++t) {
-            double z[2];
-            kd_normal_pair(kd_stream_block(seed, first_chain + (uint64_t)i, (uint64_t)t, 0u), &z[0], &z[1]);
-            for (int h = 0; h < 2; ++h) {
+            double z[4], u1, lg;
+            const kd_u32x4 b = kd_stream_block(seed, first_chain + (uint64_t)i, (uint64_t)t, 0u);
+            kd_normal_pair_w(b.x, b.y, &z[0], &z[1], &u1, &lg);
+            kd_normal_pair_w(b.z, b.w, &z[2], &z[3], &u1, &lg);
+            for (int h = 0; h < 4; ++h) {
                 const double a = fabs(z[h]);
                 for (int k = 0; k < nthr && k < 8; ++k) c[k] += a > thr[k];
                 s1 += z[h]; s2 += z[h] * z[h]; s4 += (z[h] * z[h]) * (z[h] * z[h]);

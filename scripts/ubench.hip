@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k_op(double* out, double seedv, int G)
         else if (OP == 3) { double s, c; kd_sincos2pi(b, &s, &c); b = 0.5 + 0.25 * s * c; }
         else if (OP == 4) { a = __builtin_sqrt(a) + 2.0; }
         else if (OP == 5) { a = 3.0 / a + 1.0; }
-        else if (OP == 6) { kd_u32x4 r = kd_philox4x32_10(c0, c1, 7u, i, 1u, 2u); double z0, z1; kd_normal_pair(r, &z0, &z1); acc += z0 * z1; c0 = r.x; c1 = r.y; }
+        else if (OP == 6) { kd_u32x4 r = kd_philox4x32_10(c0, c1, 7u, i, 1u, 2u); double z0, z1, u1_, lg_; kd_normal_pair_w(r.x, r.y, &z0, &z1, &u1_, &lg_); acc += z0 * z1; c0 = r.x; c1 = r.y; }
         else if (OP == 7) { double v[3] = { a, b, acc }; group_allreduce<3>(v, G, lane); a = v[0] * 1e-2 + 1.0; b = v[1] * 1e-3 + 0.5; acc = v[2] * 1e-3; }
         else if (OP == 8) { a = kd_fma(a, 0.999, 0.001); }
         else if (OP == 9) { c0 = c0 * 0x9E3779B9u + c1; }   // v_mul_lo_u32 chain
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512) void k_overlap(double* out, int mfma_iters, in
             for (int k = 0; k < 8; ++k) {
                 if (KIND == 0) a[k] = kd_fma(a[k], 0.999, 0.001);
                 else if (KIND == 1) { const uint64_t p = (uint64_t)u[k] * 0xD2511F53u + w[k]; w[k] = p; u[k] = KD_XOR3((uint32_t)(p >> 32), (uint32_t)p, (uint32_t)i); }
-                else { double z0, z1; kd_normal_pair(kd_stream_block(7u, (uint64_t)u[k], (uint64_t)i, (uint32_t)k), &z0, &z1); a[k] += z0 * z1; }
+                else { double z0, z1, u1_, lg_; const kd_u32x4 b_ = kd_stream_block(7u, (uint64_t)u[k], (uint64_t)i, (uint32_t)k); kd_normal_pair_w(b_.x, b_.y, &z0, &z1, &u1_, &lg_); a[k] += z0 * z1; }
             }
         }
 #pragma unroll
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_clock(unsigned long long* out, int iter
         for (int k = 0; k < 8; ++k) {
             if (KIND == 1) a[k] = kd_fma(a[k], 0.999, 0.001);
             else if (KIND == 2) { const uint64_t p = (uint64_t)u[k] * 0xD2511F53u + w[k]; w[k] = p; u[k] = KD_XOR3((uint32_t)(p >> 32), (uint32_t)p, (uint32_t)i); }
-            else { double z0, z1; kd_normal_pair(kd_stream_block(7u, (uint64_t)u[k], (uint64_t)i, (uint32_t)k), &z0, &z1); a[k] += z0 * z1; }
+            else { double z0, z1, u1_, lg_; const kd_u32x4 b_ = kd_stream_block(7u, (uint64_t)u[k], (uint64_t)i, (uint32_t)k); kd_normal_pair_w(b_.x, b_.y, &z0, &z1, &u1_, &lg_); a[k] += z0 * z1; }
         }
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();

@@ -42,22 +42,31 @@ def u52(hi, lo):
     return (m + 0.5) * 2.0 ** -52
 
 
+def u44(wa, wb):
+    """44 bits: word wa and the low 12 bits of wb"""
+    m = (wa << 12) | (wb & 0xFFF)
+    return (m + 0.5) * 2.0 ** -44
+
+
 def normals(seed, chain, t, D):
-    """z[i], i < D: pair i >> 1 of the transition, cosine half for even i, sine half for odd i"""
+    """z[i], i < D: element pair p = i >> 1 takes 64 bits of the transition's stream — half (p >> 3) & 1 of block slot
+    (p & 7) + 8 (p >> 4), so pairs p and p + 8 share a Philox block — and Box-Muller on a 44-bit radius uniform and a 20-bit
+    angle ((wb >> 12) 2^-20 + 2^-53 turns); cosine half for even i, sine half for odd i"""
     z = np.empty(D)
-    for s in range((D + 1) // 2):
-        x, y, zz, w = stream_block(seed, chain, t, s)
-        r = math.sqrt(-2.0 * math.log(u52(x, y)))
-        a = 2.0 * math.pi * u52(zz, w)
-        z[2 * s] = r * math.cos(a)
-        if 2 * s + 1 < D:
-            z[2 * s + 1] = r * math.sin(a)
+    for p in range((D + 1) // 2):
+        blk = stream_block(seed, chain, t, (p & 7) + 8 * (p >> 4))
+        wa, wb = (blk[2], blk[3]) if (p >> 3) & 1 else (blk[0], blk[1])
+        r = math.sqrt(-2.0 * math.log(u44(wa, wb)))
+        a = 2.0 * math.pi * ((wb >> 12) * 2.0 ** -20 + 2.0 ** -53)
+        z[2 * p] = r * math.cos(a)
+        if 2 * p + 1 < D:
+            z[2 * p + 1] = r * math.sin(a)
     return z
 
 
 def accept_uniform(seed, chain, t, D):
     x, y, _, _ = stream_block(seed, chain, t, (D + 1) // 2)
-    return u52(x, y)
+    return u44(x, y)
 
 
 INIT_T = (1 << 40) - 1          # transition index "-1": the initial-state stream

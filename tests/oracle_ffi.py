@@ -48,10 +48,10 @@ def load() -> C.CDLL:
     lib.ko_philox_block.argtypes = [vp, vp, vp]
     lib.ko_stream_block.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]
     lib.ko_math.argtypes = [C.c_int, C.c_int64, vp, vp, vp]
-    lib.ko_normal_pair.argtypes = [vp, vp]
     lib.ko_u52.argtypes = [C.c_uint32, C.c_uint32]
-    lib.ko_normal_pairs.argtypes = [C.c_int64, vp, vp]
-    lib.ko_normal_pairs.restype = None
+    lib.ko_u44.argtypes = [C.c_uint32, C.c_uint32]; lib.ko_u44.restype = C.c_double
+    lib.ko_normal_pairs_w.argtypes = [C.c_int64, vp, vp]; lib.ko_normal_pairs_w.restype = None
+    lib.ko_transition_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, vp, vp]; lib.ko_transition_normals.restype = None
     lib.ko_normal_tail.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, vp, vp, vp]
     lib.ko_normal_tail.restype = None
     lib.ko_u52.restype = C.c_double

@@ -817,6 +817,47 @@ def _random_case(seed, wide=False):
     return c, rng
 
 
+_BIG = [(smp, d, mu) for smp in ("mh", "mala", "hmc", "hmc_rate", "hmc_da") for d in (130, 161, 193, 256) for mu in (False, True)]
+
+
+@pytest.mark.parametrize("smp,d,mu", _BIG, ids=[f"{a}-d{b}-{'mean' if m else 'nomean'}" for a, b, m in _BIG])
+def test_every_streamed_dense_instantiation_in_one_launch(smp, d, mu):
+    """Every k_dense_big<sampler, NE, mean, dual averaging> instantiation (NE = 40 / 48 / 56 / 64) with ALL transitions of the job in ONE launch, a ragged
+    second tile, running sums and histories on, at step sizes where a good share of the proposals is rejected and a good share accepted: the state a
+    lane carries from one transition to the next — kept after an accept, re-read after a reject — is what this pins.  (k_dense_big<MH, 48, mean> once lost
+    an element of every chain that had just rejected: a register copy the compiler placed under a divergent branch's execution mask; a launch of one
+    transition cannot see that, and the randomised jobs only run into it by the luck of their launch sizes.)"""
+    rng = np.random.default_rng(d + 7 * len(smp) + int(mu))
+    target = K.GaussDenseTarget(cases.compound_symmetric_precision(d, 0.4), const=0.3, mu=(rng.uniform(-1.5, 1.5, d) if mu else None))
+    c = dict(target=target, nchains=21, x0=None, seed=4242 + d, name=f"big_{smp}_{d}_{int(mu)}", burnin=2, thinning=2, nsteps=14)
+    if smp == "mh":
+        c.update(sampler=L.SAMPLER_MH, mh_sigma=np.full(d, 0.07) * rng.uniform(0.7, 1.3, d))
+    elif smp == "mala":
+        c.update(sampler=L.SAMPLER_MALA, driftstep=0.3)
+    else:
+        c.update(sampler=L.SAMPLER_HMC, leapstep=0.45, nleaps=3)
+        if smp == "hmc_rate":
+            c.update(tuner=L.TUNER_ACCEPT_RATE, targetrate=0.6, period=4)
+        if smp == "hmc_da":
+            c.update(tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=9)
+    mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT | (L.MON_HIST_GRAD if smp != "mh" else 0)
+    eng = K.Engine(**cases.engine_kwargs(c, monitor=mon, steps_per_launch=0, nstreams=1))
+    assert eng.layout()[0] == 1 and eng.layout()[2] == 8 * ((d + 31) // 32), eng.layout()
+    job = O.OracleJob(**cases.oracle_kwargs(c, layout=eng.layout()), want_hist=True)
+    eng.init_state_normal(); assert job.init_state_normal() == 0
+    eng.run(c["nsteps"]); assert job.run(c["nsteps"]) == 0
+    rate = job.accept.mean()
+    assert 0.1 < rate < 0.9, rate                      # both the commit and the re-read are exercised
+    _assert_same(eng, job, c)
+    for ch in (0, 17, 20):
+        assert np.array_equal(eng.chain(ch), job.hist[:, ch, :].T), "history differs"
+        lt, g = eng.chain_fields(ch, logtarget=True, gradlogtarget=smp != "mh")
+        assert np.array_equal(lt, job.hist_lt[:, ch])
+        if smp != "mh":
+            assert np.array_equal(g, job.hist_g[:, ch, :].T)
+    eng.close()
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_random_configurations_wide(seed):
     """48 more jobs from the sizes that moved onto hand-written kernels in round 4 (dense 129..256 dimensions on the streamed matrix-core layouts — HMC with

@@ -272,10 +272,10 @@ def test_cfg4_swiss_mala_full_size_against_the_oracle():
 
 # ------------------------------------------------------------------ the proposal normals' tails
 def test_device_normal_tail_mass(klib):
-    """(1) The device generator and its CPU build count the same exceedances on the same 3.4e7 draws (exactly).
-    (2) 1.7e10 device draws (2^17 x 2^16 blocks): counts of |z| > 3, 4, 5, 6 within 4.5 binomial standard deviations of
-    the normal law (expected 4.6e7, 1.09e6, 9,849 and 34), E z^2 = 1 and E z^4 = 3, and no value beyond the generator's
-    largest possible normal sqrt(106 ln 2) = 8.572."""
+    """(1) The device generator and its CPU build count the same exceedances on the same 6.7e7 draws (exactly).
+    (2) 3.4e10 device draws (2^17 x 2^16 blocks, both pairs of every block — the samplers' kd_normal_pair_w): counts of |z| > 3, 4, 5, 6 within
+    4.5 binomial standard deviations of the normal law (expected 9.3e7, 2.18e6, 19,699 and 68), E z^2 = 1 and E z^4 = 3, and no value beyond the
+    generator's largest possible normal sqrt(90 ln 2) = 7.898 (44-bit radius uniform)."""
     thr = np.array([3.0, 4.0, 5.0, 6.0]); cnt = np.zeros(4, np.uint64); mom = np.zeros(4)
     ref = np.zeros(4, np.uint64); refm = np.zeros(4)
     nch, nt = 1 << 20, 16
@@ -285,10 +285,10 @@ def test_device_normal_tail_mass(klib):
     assert mom[3] == refm[3] and abs(mom[1] - refm[1]) < 1e-6 * refm[1]
     nch, nt = 1 << 17, 1 << 16
     L.check(klib.klara_selftest_normal_tail(0, 20260927, 1 << 33, nch, nt, 4, thr.ctypes.data, cnt.ctypes.data, mom.ctypes.data), "tail")
-    ndraw = 2.0 * nch * nt
+    ndraw = 4.0 * nch * nt
     p = 2 * stats.norm.sf(thr)
     dev = (cnt.astype(float) - ndraw * p) / np.sqrt(ndraw * p * (1 - p))
     assert np.all(np.abs(dev) < 4.5), (cnt, ndraw * p, dev)
     assert abs(mom[0] / ndraw) < 4.5 / math.sqrt(ndraw)
     assert abs(mom[1] / ndraw - 1.0) < 4.5 * math.sqrt(2.0 / ndraw) and abs(mom[2] / ndraw - 3.0) < 4.5 * math.sqrt(96.0 / ndraw)
-    assert 6.0 < mom[3] <= math.sqrt(106 * math.log(2)) + 1e-12
+    assert 6.0 < mom[3] <= math.sqrt(90 * math.log(2)) + 1e-12

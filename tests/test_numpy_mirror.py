@@ -24,7 +24,7 @@ def _compare(job, chains, nsteps, burnin, thinning, check_grad):
         assert job.LT[k] == pytest.approx(c.lt, rel=1e-9, abs=1e-9)
         if check_grad:
             assert np.allclose(job.G[k], c.g, rtol=1e-8, atol=1e-9)
-        assert job.step[k] == pytest.approx(c.step, rel=1e-12, nan_ok=True)
+        assert job.step[k] == pytest.approx(c.step, rel=1e-9, nan_ok=True)      # (dual averaging feeds a = min(1, exp(dH)) back into the step)
         assert (int(job.accepted[k]), int(job.proposed[k]), int(job.totproposed[k])) == (c.accepted, c.proposed, c.totproposed)
         assert len(c.saved) == nsaved
         if nsaved:
@@ -36,6 +36,7 @@ def test_philox_and_uniforms_agree_with_the_library():
         blk = O.stream_blocks(seed, chain, t, [slot])[0]
         assert tuple(int(v) for v in blk) == M.stream_block(seed, chain, t, slot)
         assert O.load().ko_u52(int(blk[0]), int(blk[1])) == M.u52(int(blk[0]), int(blk[1]))
+        assert O.load().ko_u44(int(blk[2]), int(blk[3])) == M.u44(int(blk[2]), int(blk[3]))
 
 
 def test_mh_readme_job_with_verbose_counters():

@@ -113,54 +113,54 @@ def test_softplus_logistic_pair():
 
 def test_box_muller_moments():
     n = 200000
-    blocks = O.stream_blocks(12345, 3, 0, range(n))
-    lib = O.load()
+    blocks = O.stream_blocks(12345, 3, 0, range(n // 2))        # both halves of every block: n word pairs
     out = np.zeros((n, 2))
-    import ctypes as C
-    for i in range(0, n, 1):
-        lib.ko_normal_pair(blocks[i].ctypes.data, out[i].ctypes.data)
+    words = np.ascontiguousarray(blocks.reshape(n, 2))
+    O.load().ko_normal_pairs_w(n, words.ctypes.data, out.ctypes.data)
     z = out.ravel()
     assert abs(z.mean()) < 4 / math.sqrt(z.size)
     assert abs(z.var() - 1) < 0.01
     assert abs(np.corrcoef(out[:, 0], out[:, 1])[0, 1]) < 0.01
+    assert abs(np.corrcoef(out[0::2, 0], out[1::2, 0])[0, 1]) < 0.01          # the two pairs of one block
     assert stats.kstest(z[:50000], "norm").pvalue > 1e-3
 
 
-def _blocks_from_mantissas(m1, m2):
-    """Philox words (x, y, z, w) whose kd_u52 uniforms have the 52-bit mantissas m1 (radius) and m2 (angle)."""
-    m1 = np.asarray(m1, dtype=np.uint64); m2 = np.asarray(m2, dtype=np.uint64)
-    b = np.empty((m1.size, 4), np.uint32)
-    b[:, 0] = (m1 >> np.uint64(20)).astype(np.uint32); b[:, 1] = ((m1 & np.uint64(0xfffff)) << np.uint64(12)).astype(np.uint32)
-    b[:, 2] = (m2 >> np.uint64(20)).astype(np.uint32); b[:, 3] = ((m2 & np.uint64(0xfffff)) << np.uint64(12)).astype(np.uint32)
-    return b
+def _words_from_mantissas(m44, j20):
+    """Word pairs (wa, wb) whose radius uniform has the 44-bit mantissa m44 and whose angle is direction j20 of 2^20 (bits 19..12 of wb,
+    which neither uses, are left zero / set: they must not matter)."""
+    m44 = np.asarray(m44, dtype=np.uint64); j20 = np.asarray(j20, dtype=np.uint64)
+    w = np.empty((m44.size, 2), np.uint32)
+    w[:, 0] = (m44 >> np.uint64(12)).astype(np.uint32)
+    w[:, 1] = ((j20 << np.uint64(12)) | (m44 & np.uint64(0xfff))).astype(np.uint32)
+    return w
 
 
 def test_normal_pair_against_independent_high_precision_box_muller():
-    """kd_normal_pair (detmath.h: the one source of proposal normals on the device AND in the oracle) against an independent
-    evaluation of the same definition from the same Philox words: u = (2m + 1) 2^-53, z0 = sqrt(-2 ln u1) cos(2 pi u2),
-    z1 = sqrt(-2 ln u1) sin(2 pi u2) in mpmath at 160 bits — 100,000 random blocks plus the extreme points of the 52-bit
-    lattice (smallest / largest radius uniform, angles at and next to every multiple of pi/2).
+    """kd_normal_pair_w (detmath.h: the one source of normals on the device AND in the oracle) against an independent evaluation of the
+    same definition from the same words: u1 = (2 m + 1) 2^-45 (m: 44 bits), u2 = j 2^-20 + 2^-53 (j: 20 bits),
+    z0 = sqrt(-2 ln u1) cos(2 pi u2), z1 = sqrt(-2 ln u1) sin(2 pi u2) in mpmath at 160 bits — 100,000 random word pairs plus the
+    extreme points of the lattice (smallest / largest radius uniform, directions at and next to every multiple of pi/2).
 
-    Bound: |z - exact| <= 2.5 ulp(radius).  (Measured: 2.02.)  ulp(z) is the wrong yardstick next to the zeros of sin / cos:
-    kd_sincos2pi is accurate to 2^-52 ABSOLUTE, so where |cos| ~ 1e-15 the product is off by a few 1e-16 — 30 % of a value
-    that is itself 1e-15 of a standard deviation.  Where the trigonometric factor is >= 1/2 in magnitude the error is also
-    asserted in ulps of z itself (<= 4.5: two binades of radius ulps)."""
+    Bound: |z - exact| <= 2.5 ulp(radius).  ulp(z) is the wrong yardstick next to the zeros of sin / cos: kd_sincos2pi is accurate to
+    2^-52 ABSOLUTE, so where |cos| ~ 1e-15 the product is off by a few 1e-16 — 30 % of a value that is itself 1e-15 of a standard
+    deviation.  Where the trigonometric factor is >= 1/2 in magnitude the error is also asserted in ulps of z itself (<= 4.5: two
+    binades of radius ulps)."""
     import mpmath as mp
     rng = np.random.default_rng(20260927)
     n = 100000
-    top = (1 << 52) - 1
-    edge1 = [0, 1, 2, top, top - 1, 1 << 51, (1 << 51) - 1, 1 << 40, 12345]
-    edge2 = [0, 1, top, top - 1] + [q * (1 << 50) + d for q in (1, 2, 3) for d in (-2, -1, 0, 1)] + [(j << 44) + d for j in (1, 77, 128, 255) for d in (-1, 0)]
-    m1 = np.concatenate([rng.integers(0, 1 << 52, n, dtype=np.uint64), np.repeat(np.array(edge1, np.uint64), len(edge2))])
-    m2 = np.concatenate([rng.integers(0, 1 << 52, n, dtype=np.uint64), np.tile(np.array(edge2, np.uint64), len(edge1))])
-    blk = _blocks_from_mantissas(m1, m2)
-    out = np.zeros((blk.shape[0], 2))
-    O.load().ko_normal_pairs(blk.shape[0], blk.ctypes.data, out.ctypes.data)
+    top, jtop = (1 << 44) - 1, (1 << 20) - 1
+    edge1 = [0, 1, 2, top, top - 1, 1 << 43, (1 << 43) - 1, 1 << 32, 12345]
+    edge2 = [0, 1, jtop, jtop - 1] + [q * (1 << 18) + d for q in (1, 2, 3) for d in (-2, -1, 0, 1)] + [(j << 12) + d for j in (1, 77, 128, 255) for d in (-1, 0)]
+    m1 = np.concatenate([rng.integers(0, 1 << 44, n, dtype=np.uint64), np.repeat(np.array(edge1, np.uint64), len(edge2))])
+    j2 = np.concatenate([rng.integers(0, 1 << 20, n, dtype=np.uint64), np.tile(np.array(edge2, np.uint64), len(edge1))])
+    w = _words_from_mantissas(m1, j2)
+    out = np.zeros((w.shape[0], 2))
+    O.load().ko_normal_pairs_w(w.shape[0], w.ctypes.data, out.ctypes.data)
     worst_rad = worst_z = 0.0
     with mp.workprec(160):
-        two53, twopi = mp.mpf(2) ** -53, 2 * mp.pi
-        for i in range(blk.shape[0]):
-            u1 = (2 * int(m1[i]) + 1) * two53; u2 = (2 * int(m2[i]) + 1) * two53
+        two45, two20, two53, twopi = mp.mpf(2) ** -45, mp.mpf(2) ** -20, mp.mpf(2) ** -53, 2 * mp.pi
+        for i in range(w.shape[0]):
+            u1 = (2 * int(m1[i]) + 1) * two45; u2 = int(j2[i]) * two20 + two53
             rad = mp.sqrt(-2 * mp.log(u1)); a = twopi * u2
             ulp_rad = mp.mpf(float(np.spacing(float(rad))))
             for h, trig in ((0, mp.cos(a)), (1, mp.sin(a))):
@@ -170,23 +170,26 @@ def test_normal_pair_against_independent_high_precision_box_muller():
                     worst_z = max(worst_z, float(err / mp.mpf(float(np.spacing(abs(float(rad * trig)))))))
     assert worst_rad <= 2.5, worst_rad
     assert worst_z <= 4.5, worst_z
-    # the largest normal the generator can produce: u1 = 2^-53 -> sqrt(2 * 53 ln 2) = 8.5718...
-    assert abs(np.abs(out[n:]).max() - math.sqrt(106 * math.log(2))) < 1e-13
+    # the largest normal the generator can produce: u1 = 2^-45 -> sqrt(2 * 45 ln 2) = 7.898...
+    assert abs(np.abs(out[n:]).max() - math.sqrt(90 * math.log(2))) < 1e-13
+    # the accept uniform is the radius uniform of words (x, y): never 0, never 1, log above the kernels' skip guard (-31.2)
+    assert O.load().ko_u44(0, 0) == 2.0 ** -45 and O.load().ko_u44(0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -45
+    assert O.math_op(7, np.array([2.0 ** -45]))[0] > -31.2
 
 
 def test_normal_tail_mass_on_the_host():
-    """Tail mass of the generator as the kernels call it (stream blocks of consecutive chains / transitions): 2 x 10^7 draws,
+    """Tail mass of the generator as the kernels call it (stream blocks of consecutive chains / transitions): 4 x 10^7 draws,
     counts of |z| > 1, 2, 3, 4 within 4.5 binomial standard deviations of the normal law, second and fourth moments 1 and 3."""
     lib = O.load()
     thr = np.array([1.0, 2.0, 3.0, 4.0]); cnt = np.zeros(4, np.uint64); mom = np.zeros(4)
     nch, nt = 10000, 1000
     lib.ko_normal_tail(987654321, 5, nch, nt, 4, thr.ctypes.data, cnt.ctypes.data, mom.ctypes.data)
-    ndraw = 2 * nch * nt
+    ndraw = 4 * nch * nt                                      # both pairs of every block
     p = 2 * stats.norm.sf(thr)
     assert np.all(np.abs(cnt.astype(float) - ndraw * p) < 4.5 * np.sqrt(ndraw * p * (1 - p))), (cnt, ndraw * p)
     assert abs(mom[0] / ndraw) < 4.5 / math.sqrt(ndraw)
     assert abs(mom[1] / ndraw - 1.0) < 4.5 * math.sqrt(2.0 / ndraw) and abs(mom[2] / ndraw - 3.0) < 4.5 * math.sqrt(96.0 / ndraw)
-    assert mom[3] < 8.58
+    assert mom[3] < 7.9
 
 
 def test_tuner_score_kats(oracle):
