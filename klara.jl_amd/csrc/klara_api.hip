@@ -87,7 +87,9 @@ struct klara_handle {
     bool q4_ok = false; int np4 = 0;
     int* auto_cells = nullptr; unsigned long long* auto_ctr = nullptr; int* auto_mirror = nullptr; int* auto_mirror_dev = nullptr;
     long long launch_idx = 0;
-    double auto_threshold = 0.12;   // acceptance above which a launch keeps resident sums (8 lanes) — the measured crossover, profiles/r3_acceptance_cost_probe.txt
+    double auto_threshold = 0.06;   // acceptance above which a launch keeps resident sums (8 lanes) — the measured crossover: the 4-lane kernels' folds are atomic adds
+                                    // since round 4 (flat to ~4.5 % acceptance, saturating the atomic units beyond: profiles/r4_acceptance_cost_atomic.txt; round 3's
+                                    // read-modify-write folds crossed at 0.12, profiles/r3_acceptance_cost_probe.txt)
     int query_lanes = 4;            // klara_get_kernel_attributes: which of the two kernel families to report
     long long n_launch_mode[3] = { 0, 0, 0 };   // launches issued as: forced / single 4-lane, forced / single 8-lane, device-decided pair
 };

@@ -218,6 +218,33 @@ __device__ __forceinline__ void diagt_fold(const PairCtx<NP, Q>& c, __amdgpu_buf
 #ifndef KLARA_DT_RMW_CHUNK
 #define KLARA_DT_RMW_CHUNK 3
 #endif
+// The same fold as fire-and-forget atomic adds (global_atomic_add_f64 without return): sum += held x, sumsq += held x^2 element by element.
+// Each element of a chain's sums is only ever touched by its own lane, one fold after the other, so the memory sees exactly the additions the
+// read-modify-write form makes (one IEEE add of the rounded product per fold: the same bits) — but the wavefront does not wait for 2 NP loads
+// before it can go on: at the 7 % acceptance of a fresh drift-0.9 job the load round trips of the folds were 1.5-2 of the 16.6 us per transition
+// of all chains (h = 0.6, ~10 % acceptance: 15.9 -> see profiles/r4_ab_fold_atomic.txt).
+template <int NP, int Q>
+__device__ __forceinline__ void diagt_fold_atomic(const PairCtx<NP, Q>& c, gdouble* sum0, gdouble* sq0, bool fold, long long& held, const double (&x)[2 * NP])
+{
+    typedef __attribute__((address_space(1))) double* gptr;
+    if (fold) {
+        const double hf = (double)held;
+        const gptr ps = (gptr)((__attribute__((address_space(1))) char*)sum0 + c.off0), pq = (gptr)((__attribute__((address_space(1))) char*)sq0 + c.off0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const bool ok0 = p < NP - 1 || c.last_ok, ok1 = p < NP - 1 || c.last_full;
+            if (ok0) {
+                (void)__builtin_amdgcn_global_atomic_fadd_f64(ps + p * Q * 2, hf * x[2 * p]);
+                (void)__builtin_amdgcn_global_atomic_fadd_f64(pq + p * Q * 2, hf * (x[2 * p] * x[2 * p]));
+            }
+            if (ok1) {
+                (void)__builtin_amdgcn_global_atomic_fadd_f64(ps + p * Q * 2 + 1, hf * x[2 * p + 1]);
+                (void)__builtin_amdgcn_global_atomic_fadd_f64(pq + p * Q * 2 + 1, hf * (x[2 * p + 1] * x[2 * p + 1]));
+            }
+        }
+    }
+    held = fold ? 0 : held;
+}
 template <int NP, int Q>
 __device__ __forceinline__ void diagt_fold_rmw(const PairCtx<NP, Q>& c, __amdgpu_buffer_rsrc_t wsum, __amdgpu_buffer_rsrc_t wsq, bool fold,
                                                long long& held, const double (&x)[2 * NP])
@@ -808,7 +835,13 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                 nacc += acc ? 1ull : 0ull;
                 if (!SLICE && do_sum && __any(chain_ok && acc && held > 0)) {          // a chain of this wavefront leaves its state
                     const bool fold = chain_ok && acc && held > 0;
+#ifdef KLARA_DT_FOLD_RMW
                     if constexpr (MEMSUM) diagt_fold_rmw<NP, Q>(cx, wsum, wsq, fold, held, x);
+#else
+                    // (both forms in one kernel, chosen by how many chains of the wavefront move, cost more than they save: 84 B of scratch and
+                    // 14.2 against 13.7 / 13.55 us per transition — profiles/r4_ab_fold_atomic.txt)
+                    if constexpr (MEMSUM) diagt_fold_atomic<NP, Q>(cx, p.sum + first_chain * D, p.sumsq + first_chain * D, fold, held, x);
+#endif
                     else diagt_fold<NP, Q>(cx, wsum, wsq, fold, sums_loaded, held, x, sm, sq);
                 }
                 if (acc) {

@@ -23,13 +23,24 @@ usage: instruction_budget.py            prints the tables
 PHILOX = 10 * (2 + 2) + 1        # 10 rounds x (2 v_mad_u64_u32: hi and lo of both products; 2 v_bitop3 xor3) + the per-lane counter word;
                                  # the key schedule is wave-uniform (scalar unit)
 UNIT_BITS = 3                    # v_lshrrev + v_or (exponent | top 20 bits), v_alignbit (low word)
-U52 = UNIT_BITS + 1              # ... and the exact subtraction
+U52 = UNIT_BITS + 1              # ... and the exact subtraction (the slice sampler's 52-bit uniforms)
+U44 = 3 + 1                      # the normals' radius uniform / the accept uniform: v_alignbit (exponent | top 20 bits), v_lshlrev + v_alignbit (low word), subtraction
+ANGLE_BITS = 1                   # the 20-bit angle: one v_alignbit (the low word is 0)
 LOG_U01 = 23                     # tmp, index (bfe), k (ashr), hz (and, sub), table offset, r (fma), dk (cvt), w (fma), hi (add), lo (sub, add, fma),
                                  # r2 (mul), 5 fma of the degree-7 polynomial, r*r2, 2 fma, final add  [the two table words: one ds_read_b128]
 SQRT_RAD = 1 + 10                # -2 log u; v_rsq_f64 + 9 mul / fma (kd_sqrt_radicand)
 SINCOS = 18                      # j (bfe), centre word (v_and_or), t (sub), y (2 fma), z (mul), sin y (mul + 3 fma), cos y - 1 (2 fma + mul), table offset,
                                  # rotation (4 fma)
-NORMAL_PAIR = PHILOX + U52 + UNIT_BITS + LOG_U01 + SQRT_RAD + SINCOS + 2       # ... + the two products radius x (cos, sin)  = 102
+BOX_MULLER = U44 + ANGLE_BITS + LOG_U01 + SQRT_RAD + SINCOS + 2        # 64 bits -> two normals (kd_normal_pair_w): ... + the two products radius x (cos, sin)  = 59
+NORMAL_PAIR = PHILOX / 2 + BOX_MULLER                                   # a pair whose block also serves the pair 8 further on (round 4): 79.5  (rounds 1-3: a block per pair, 102)
+NORMAL_PAIR_OWN = PHILOX + BOX_MULLER                                   # a pair with a block of its own (fewer than 9 pairs, or the partner pair sits in another lane): 100
+
+
+def philox_blocks(npairs: int) -> int:
+    """blocks of one transition's normals of one chain: pairs p and p + 8 share block (p & 7) + 8 (p >> 4)"""
+    return 8 * (npairs // 16) + min(npairs % 16, 8)
+
+
 EXP = 39                         # kd_exp: 2 clamps, rounding offset (bfi) + mul + add, 2 cvt, r (2 fma), index / exponent (and, ashr), table offset, r2, r4,
                                  # 4 fma, y (fma, add), e/2 and e - e/2 (3), two scale words (2 x (add, shl)), 2 mul, three special-case selects (3 x 3)
 EXP_NEG = 18                     # kd_exp_neg (round 4: k from the low mantissa bits of one fma): max, fma, sub, r (2 fma), table offset (and, shl), r2, r4, 4 fma,
@@ -51,15 +62,17 @@ def headline(lanes_per_chain: int = 4, ndims: int = 100):
     """k_diagt<MALA, ..., UNITW, MON>: necessary instructions per WAVEFRONT and transition.  A chain's ceil(D/2) element pairs are one
     Philox block + one Box-Muller evaluation + two elements of sampler arithmetic each; a wavefront carries 64 / lanes chains."""
     chains = 64 // lanes_per_chain
-    pair = NORMAL_PAIR + 2 * mala_diag_unitw_element()                 # 102 + 36 = 138
-    pairs = (ndims + 1) // 2 * chains / 64.0                           # pair evaluations per lane: 12.5 (4 lanes), 6.25 (8 lanes)
+    npairs = (ndims + 1) // 2
+    pair = BOX_MULLER + 2 * mala_diag_unitw_element()                  # 59 + 36 = 95
+    pairs = npairs * chains / 64.0                                     # pair evaluations per lane: 12.5 (4 lanes), 6.25 (8 lanes)
+    blocks = philox_blocks(npairs) * chains / 64.0                     # Philox blocks per lane: 6.5 (4 lanes), 3.25 (8 lanes) — 26 per chain at D = 100
     # the three sums of the Metropolis ratio in the 8-lane order: 8 lanes: 3 butterfly steps; 4 lanes: two partial sums per lane, 2 steps
     # on both, then their sum
     red = 3 * 3 * BFLY if lanes_per_chain == 8 else 3 * (2 * 2 * BFLY + 1)
     accept = 1 + 3 + 2 + 2 + 1                                          # lt', ratio (3 adds), two compares, broadcast of log u, or
     book = 3                                                            # accept count, held += 1, save-rule phase
-    return {"per_pair": pair, "pair_evaluations_per_lane": pairs, "reductions": red, "accept_test": accept, "bookkeeping": book,
-            "per_wave_transition": pairs * pair + red + accept + book, "chains_per_wave": chains}
+    return {"per_pair": pair, "pair_evaluations_per_lane": pairs, "philox_blocks_per_lane": blocks, "reductions": red, "accept_test": accept, "bookkeeping": book,
+            "per_wave_transition": pairs * pair + blocks * PHILOX + red + accept + book, "chains_per_wave": chains}
 
 
 def cfg5_hier(nleaps: int = 32, units_per_lane: int = 4):
@@ -69,7 +82,7 @@ def cfg5_hier(nleaps: int = 32, units_per_lane: int = 4):
     exp3 = 4 + 1 + EXP + 6                                             # pick s_c / s_a / s_b by lane (2 selects), -2 s, exp, three broadcasts
     hyper = 2 + 2 + 3 * 3                                              # gradient of a_c, b_c (mul, fma) and of the three log-sigmas (fma, sub, fma)
     leap = 2 * vals + units_per_lane * unit + 5 * 3 * BFLY + exp3 + hyper      # drift + kick (one fma per value each), units, 5-value butterfly
-    normals = (units_per_lane + 1) * NORMAL_PAIR + 7 * 2                # momentum: one block per unit; the hyper block's three blocks and the accept
+    normals = (units_per_lane + 1) * NORMAL_PAIR_OWN + 7 * 2            # momentum: one block per unit (a lane's units are consecutive pairs: no partner 8 further on); the hyper block's three blocks and the accept
     # draw's block are spread over the four lanes of a quad (one each) and exchanged: 7 doubles x 2 v_mov_dpp
     lt_eval = units_per_lane * (unit - 4) + 5 * 3 * BFLY + exp3 + 25    # log-target of the proposal (no gradient terms), its closing arithmetic
     energy = 2 * (2 * vals + 3 * BFLY)                                  # sum p^2 before and after
@@ -86,7 +99,7 @@ def cfg4_logistic(ndata: int = 200, ndims: int = 4, rowsplit: int = 4):
     rows = ndata // rowsplit
     bfly = (ndims + 2) * {4: 2, 8: 3}[rowsplit] * BFLY                  # (D + 2)-value butterfly over the chain's lanes
     prior = 2 * ndims + (DIV + 2) + ndims * (DIV + 1)                   # p.p; -(p.p / lambda + const)/2; -p / lambda per component (the example's divisions)
-    normals = NORMAL_PAIR + 2 * ndims + 4                               # every lane of a chain holds the whole vector; the (D + 1) / 2 blocks of the normals
+    normals = NORMAL_PAIR_OWN + 2 * ndims + 4                           # every lane of a chain holds the whole vector; the (D + 1) / 2 blocks of the normals
     # and the accept draw's block are spread over the four lanes of a quad (one each) and exchanged (2 v_mov_dpp per normal, 2 + 2 ds_bpermute
     # for the draw)
     sampler = ndims * mala_diag_unitw_element() - ndims * 3             # MALA arithmetic per element (the target's own terms are above)
@@ -98,13 +111,13 @@ def cfg4_logistic(ndata: int = 200, ndims: int = 4, rowsplit: int = 4):
 def cfg1_replicas():
     """k_transitions<MH, DIAG, E=2, one chain per lane> — the README job (README.md:23-47: MH, sigma = (1, 1), lt = -dot(z, z), D = 2) as
     replicas with running sums: per wavefront (64 chains) and transition."""
-    normals = NORMAL_PAIR                                               # one block = the chain's two normals
+    normals = NORMAL_PAIR_OWN                                           # one block = the chain's two normals (its second half has no taker at D = 2)
     proposal = 2 * 2                                                    # x + sigma z (mul, add) per element, iterate/MH.jl:79
     target = 2 * 2 + 1                                                  # -dot(z, z): mul, add per element; the sign
     ratio = 1
     # accept iff ratio > 0 or ratio > log(rand()) (MH.jl:97): the draw is made by the lanes with ratio <= 0 — about half of them, so a
     # wavefront of 64 chains always makes it
-    accept = 1 + (PHILOX + U52 + LOG_U01) + 1 + 1
+    accept = 1 + (PHILOX + U44 + LOG_U01) + 1 + 1
     commit = 2 * 2 + 2                                                  # v_cndmask per dword of x (2 doubles) and lt
     sums = 1 + (1 + 2 * (2 + 3)) + 1                                    # held += 1; fold of the state being left: cvt, sum += h x, sumsq += h (x x); held = 0
     book = 2                                                            # accept counter, save-rule phase
@@ -117,7 +130,9 @@ def hmc_iso(nleaps: int = 10, ndims: int = 100, lanes_per_chain: int = 8):
     and transition, merged fma leapfrog."""
     chains = 64 // lanes_per_chain
     pairs = (ndims + 1) // 2 * chains / 64.0                            # 6.25 pair evaluations per lane
-    per_pair = (NORMAL_PAIR                                             # the two momenta
+    npairs = (ndims + 1) // 2
+    blocks = philox_blocks(npairs) * chains / 64.0                      # 3.25 Philox blocks per lane
+    per_pair = (BOX_MULLER                                              # the two momenta (their block: `blocks` below)
                 + 2 * (2 + 2)                                           # p.p before and after (mul, add per element each)
                 + 2 * 1                                                 # opening half kick (fma per element)
                 + nleaps * 2 * 3                                        # per leapfrog and element: drift (fma), gradient -2x (mul), kick (fma)
@@ -125,8 +140,8 @@ def hmc_iso(nleaps: int = 10, ndims: int = 100, lanes_per_chain: int = 8):
     red = 3 * 3 * BFLY                                                  # K0, lt', K1: three sums over 8 lanes
     accept = 2 + 2 + EXP + 1 + 1 + 1                                    # H0, H1, ratio; exp; min; the uniform comes with the padding pair's block; compare
     commit = 2 * 2 + 2                                                  # per pair slot: selects of the value pair; lt
-    return {"per_pair": per_pair, "pair_evaluations_per_lane": pairs, "reductions": red, "accept_test": accept,
-            "per_wave_transition": pairs * (per_pair + 4) + red + accept + 2 + 1, "chains_per_wave": chains, "nleaps": nleaps}
+    return {"per_pair": per_pair, "pair_evaluations_per_lane": pairs, "philox_blocks_per_lane": blocks, "reductions": red, "accept_test": accept,
+            "per_wave_transition": pairs * (per_pair + 4) + blocks * PHILOX + red + accept + 2 + 1, "chains_per_wave": chains, "nleaps": nleaps}
 
 
 def slice_probe_counts(width: float = 1.0, nsamples: int = 400000, seed: int = 7):
@@ -196,17 +211,21 @@ def _with_extra(b, extra):
 
 
 _h4, _h8, _c5, _c4 = headline(4), headline(8), cfg5_hier(), cfg4_logistic()
-BUDGETS = {"headline_4lane": _with_extra(_h4, _h4["pair_evaluations_per_lane"] * PAIR_EXTRA),
-           "headline_8lane": _with_extra(_h8, _h8["pair_evaluations_per_lane"] * PAIR_EXTRA),
+def _normals_extra(b):        # 20 v_mad_u64_u32 per Philox block, one v_rsq_f64 per Box-Muller evaluation
+    return b["philox_blocks_per_lane"] * 20 * MAD_EXTRA + b["pair_evaluations_per_lane"] * QUARTER_EXTRA
+
+
+BUDGETS = {"headline_4lane": _with_extra(_h4, _normals_extra(_h4)),
+           "headline_8lane": _with_extra(_h8, _normals_extra(_h8)),
            "cfg5": _with_extra(_c5, 5 * PAIR_EXTRA),                                        # a lane's Philox / Box-Muller evaluations
            "cfg4": _with_extra(_c4, 1 * PAIR_EXTRA + _c4["rows_per_lane"] * QUARTER_EXTRA + 5 * QUARTER_EXTRA),   # + one v_rcp_f64 per row and per prior division
            "cfg1": _with_extra(cfg1_replicas(), 2 * 20 * MAD_EXTRA + QUARTER_EXTRA),
-           "hmc_iso": _with_extra(hmc_iso(), hmc_iso()["pair_evaluations_per_lane"] * PAIR_EXTRA),
+           "hmc_iso": _with_extra(hmc_iso(), _normals_extra(hmc_iso())),
            "slice_d100": _with_extra(slice_diag(), 100 * (1 + SLICE_PROBES["per_chain"][2]) * 20 * MAD_EXTRA),
            "slice_d100_lockstep": _with_extra(slice_diag(counts=SLICE_PROBES["max_over_8_chains"]), 100 * (1 + SLICE_PROBES["max_over_8_chains"][2]) * 20 * MAD_EXTRA)}
 
 if __name__ == "__main__":
-    print(f"building blocks: Philox4x32-10 {PHILOX}, u52 {U52}, log(u) {LOG_U01}, radius {SQRT_RAD}, sin/cos {SINCOS}, normal pair {NORMAL_PAIR}, "
+    print(f"building blocks: Philox4x32-10 {PHILOX}, u52 {U52}, log(u) {LOG_U01}, radius {SQRT_RAD}, sin/cos {SINCOS}, Box-Muller on 64 bits {BOX_MULLER}, normal pair {NORMAL_PAIR} (own block: {NORMAL_PAIR_OWN}), "
           f"exp {EXP}, exp(-a) {EXP_NEG}, division {DIV}, butterfly step {BFLY}")
     for name, b in BUDGETS.items():
         print(name, {k: (round(v, 1) if isinstance(v, float) else v) for k, v in b.items()},

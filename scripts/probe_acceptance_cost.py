@@ -11,10 +11,12 @@ import klara_jl_amd as K
 from klara_jl_amd import _lib as L
 
 quick = "--quick" in sys.argv
-drifts = (0.9, 0.8, 0.7, 0.65, 0.6, 0.55, 0.5, 0.3, 0.1, 0.01)
+import os
+drifts = tuple(float(v) for v in os.environ.get("PROBE_DRIFTS", "0.9,0.8,0.7,0.65,0.6,0.55,0.5,0.3,0.1,0.01").split(","))
+modes = os.environ.get("PROBE_MODES", "00,10,11,12").split(",")
 NAMES = {(0, 0): "off", (1, 0): "on, library decides (sparse_moves = 0)", (1, 1): "on, 4 lanes, sums folded in memory (sparse_moves = 1)",
          (1, 2): "on, 8 lanes + resident sums (sparse_moves = 2)"}
-for mon, sparse in ((0, 0), (L.MON_SUMMARIES, 0), (L.MON_SUMMARIES, 1), (L.MON_SUMMARIES, 2)):
+for mon, sparse in [(L.MON_SUMMARIES if m[0] == "1" else 0, int(m[1])) for m in modes]:
     for h in drifts:
         for spl in ((32,) if quick else (32, 1)):
             e = K.Engine(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(100), nchains=65536, nsteps=10 ** 7, driftstep=h,

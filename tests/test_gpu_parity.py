@@ -817,12 +817,14 @@ def _random_case(seed, wide=False):
     return c, rng
 
 
-_BIG = [(smp, d, mu) for smp in ("mh", "mala", "hmc", "hmc_rate", "hmc_da") for d in (130, 161, 193, 256) for mu in (False, True)]
+_BIG = [(smp, d, mu) for smp in ("mh", "mala", "hmc", "hmc_rate", "hmc_da") for d in (130, 161, 193, 256) for mu in (False, True)] + \
+       [(smp, d, mu) for smp in ("mh", "mala", "hmc", "hmc_da") for d in (21, 37, 70, 128) for mu in (False, True)]      # (P in LDS, klara_dense.h: NE = 8, 16, 25, 32)
 
 
 @pytest.mark.parametrize("smp,d,mu", _BIG, ids=[f"{a}-d{b}-{'mean' if m else 'nomean'}" for a, b, m in _BIG])
 def test_every_streamed_dense_instantiation_in_one_launch(smp, d, mu):
-    """Every k_dense_big<sampler, NE, mean, dual averaging> instantiation (NE = 40 / 48 / 56 / 64) with ALL transitions of the job in ONE launch, a ragged
+    """Every k_dense_big<sampler, NE, mean, dual averaging> instantiation (NE = 40 / 48 / 56 / 64), and the LDS-resident kernels below 129 dimensions at four
+    sizes, with ALL transitions of the job in ONE launch, a ragged
     second tile, running sums and histories on, at step sizes where a good share of the proposals is rejected and a good share accepted: the state a
     lane carries from one transition to the next — kept after an accept, re-read after a reject — is what this pins.  (k_dense_big<MH, 48, mean> once lost
     an element of every chain that had just rejected: a register copy the compiler placed under a divergent branch's execution mask; a launch of one
@@ -842,12 +844,12 @@ def test_every_streamed_dense_instantiation_in_one_launch(smp, d, mu):
             c.update(tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=9)
     mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT | (L.MON_HIST_GRAD if smp != "mh" else 0)
     eng = K.Engine(**cases.engine_kwargs(c, monitor=mon, steps_per_launch=0, nstreams=1))
-    assert eng.layout()[0] == 1 and eng.layout()[2] == 8 * ((d + 31) // 32), eng.layout()
+    assert eng.layout() == (1, 4, 8 * ((d + 31) // 32) if d > 128 else {21: 8, 37: 16, 70: 25, 128: 32}[d]), eng.layout()
     job = O.OracleJob(**cases.oracle_kwargs(c, layout=eng.layout()), want_hist=True)
     eng.init_state_normal(); assert job.init_state_normal() == 0
     eng.run(c["nsteps"]); assert job.run(c["nsteps"]) == 0
     rate = job.accept.mean()
-    assert 0.1 < rate < 0.9, rate                      # both the commit and the re-read are exercised
+    assert 0.05 < rate < 0.95, rate                    # both the commit and the re-read are exercised
     _assert_same(eng, job, c)
     for ch in (0, 17, 20):
         assert np.array_equal(eng.chain(ch), job.hist[:, ch, :].T), "history differs"

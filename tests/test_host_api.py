@@ -310,30 +310,31 @@ def test_instruction_budgets_follow_from_their_parts():
     import importlib.util
     spec = importlib.util.spec_from_file_location("instruction_budget", ROOT / "scripts" / "instruction_budget.py")
     B = importlib.util.module_from_spec(spec); spec.loader.exec_module(B)
-    assert (B.PHILOX, B.U52, B.LOG_U01, B.SQRT_RAD, B.SINCOS, B.NORMAL_PAIR) == (41, 4, 23, 11, 18, 102)
+    assert (B.PHILOX, B.U52, B.U44, B.LOG_U01, B.SQRT_RAD, B.SINCOS, B.BOX_MULLER, B.NORMAL_PAIR, B.NORMAL_PAIR_OWN) == (41, 4, 4, 23, 11, 18, 59, 79.5, 100)
+    assert [B.philox_blocks(n) for n in (1, 8, 9, 16, 17, 50, 64)] == [1, 8, 8, 8, 9, 26, 32]       # pairs p and p + 8 share a block
     assert B.mala_diag_unitw_element() == 18
     h4, h8 = B.BUDGETS["headline_4lane"], B.BUDGETS["headline_8lane"]
-    assert h4["per_pair"] == 102 + 2 * 18 and h4["pair_evaluations_per_lane"] == 12.5 and h4["chains_per_wave"] == 16
-    assert h4["per_wave_transition"] == 12.5 * 138 + 39 + 9 + 3 == 1776.0
-    assert h8["per_wave_transition"] == 6.25 * 138 + 27 + 9 + 3
+    assert h4["per_pair"] == 59 + 2 * 18 and h4["pair_evaluations_per_lane"] == 12.5 and h4["philox_blocks_per_lane"] == 6.5 and h4["chains_per_wave"] == 16
+    assert h4["per_wave_transition"] == 12.5 * 95 + 6.5 * 41 + 39 + 9 + 3 == 1505.0                    # (rounds 2-3, a block per pair: 1,776)
+    assert h8["per_wave_transition"] == 6.25 * 95 + 3.25 * 41 + 27 + 9 + 3
     c5, c4 = B.BUDGETS["cfg5"], B.BUDGETS["cfg4"]
-    assert c5["per_leapfrog"] == 26 + 4 * 21 + 45 + 50 + 13 == 218 and c5["per_wave_transition"] == 7818 and c5["normals"] == 5 * 102 + 14
+    assert c5["per_leapfrog"] == 26 + 4 * 21 + 45 + 50 + 13 == 218 and c5["per_wave_transition"] == 7808 and c5["normals"] == 5 * 100 + 14
     # cfg 4 (round 4): 4 lanes per chain, 50 rows per lane; a row = Xp (4) + exp(-|Xp|) (18) + 1 + t (1) + log on [1, 2] (12) + softplus (2) + numerator select (3)
     # + division (8) + Xp y (2) + sum (1) + residual (1) + gradient (4) + row offset (1)
     assert (B.EXP_NEG, B.LOG12, B.DIV_UNIT) == (18, 12, 8)
     assert c4["per_row"] == 4 + 18 + 1 + 12 + 2 + 3 + 8 + 2 + 1 + 1 + 4 + 1 == 57 and c4["rows_per_lane"] == 50 and c4["chains_per_wave"] == 16
-    assert c4["per_wave_transition"] == 50 * 57 + 36 + 64 + 114 + 60 + 12 == 3136
+    assert c4["per_wave_transition"] == 50 * 57 + 36 + 64 + 112 + 60 + 12 == 3134
     # round 4: budgets for the kernels whose fraction used to be null
     c1, hi, sl, sll = B.BUDGETS["cfg1"], B.BUDGETS["hmc_iso"], B.BUDGETS["slice_d100"], B.BUDGETS["slice_d100_lockstep"]
-    assert c1["per_wave_transition"] == 102 + 4 + 5 + 72 + 6 + 13 + 2 == 204 and c1["chains_per_wave"] == 64
-    assert hi["per_pair"] == 102 + 8 + 2 + 60 + 4 == 176 and hi["per_wave_transition"] == 6.25 * 180 + 27 + 46 + 3
+    assert c1["per_wave_transition"] == 100 + 4 + 5 + 72 + 6 + 13 + 2 == 202 and c1["chains_per_wave"] == 64
+    assert hi["per_pair"] == 59 + 8 + 2 + 60 + 4 == 133 and hi["per_wave_transition"] == 6.25 * 137 + 3.25 * 41 + 27 + 46 + 3
     assert sl["per_probe"] == 20.5 and sl["fixed_per_coordinate"] == 104 and sl["per_shrink_attempt"] == 83.5 and sl["per_expansion"] == 30.5
     pc = B.slice_probe_counts()                                   # the seeded simulation of the stepping-out procedure reproduces the constants
     assert np.allclose(pc["per_chain"], B.SLICE_PROBES["per_chain"], rtol=1e-12) and np.allclose(pc["max_over_8_chains"], B.SLICE_PROBES["max_over_8_chains"], rtol=1e-12)
     assert 2.0 < pc["per_chain"][0] < 2.3 and 1.3 < pc["per_chain"][2] < 1.6 and sll["per_wave_coordinate"] > 1.5 * sl["per_wave_coordinate"]
     # the README of profiles/ quotes these totals
     txt = (ROOT / "profiles" / "README.md").read_text()
-    for v in ("1,776", "7,818", "3,136"):
+    for v in ("1,505", "7,808", "3,134"):
         assert v in txt, v
 
 
