@@ -683,6 +683,42 @@ def test_bench_kernel_register_budget(tmp_path):
     assert tuned["vgpr_count"] <= 256 and tuned["private_segment_fixed_size"] == 0, tuned
 
 
+def test_streamed_dense_kernels_have_no_register_saves_under_a_partial_mask():
+    """scripts/scan_exec_joins.py over klara_dense_big.hip (the 338-512 register kernels: the allocator parks part of their arrays in accumulator
+    registers): no block of any kernel saves a register (v_accvgpr_write / scratch_store) between its label and the `s_or_b64 exec` that re-enables
+    the other side of a divergent branch — the placement that lost element 15 of every rejecting chain in k_dense_big<MH, 48, mean> before the
+    transition loop was made branch-free.  The scanner itself is proven on that pattern."""
+    import importlib.util, shutil, subprocess
+    spec = importlib.util.spec_from_file_location("scan_exec_joins", ROOT / "scripts" / "scan_exec_joins.py")
+    S = importlib.util.module_from_spec(spec); spec.loader.exec_module(S)
+    bad = """_Z1kv:
+\ts_and_saveexec_b64 s[0:1], s[2:3]
+\ts_cbranch_execz .LBB0_2
+\tbuffer_load_dwordx2 v[32:33], v4, s[72:75], 0 offen
+.LBB0_2:
+\ts_waitcnt vmcnt(32)
+\tv_accvgpr_write_b32 a53, v33
+\tv_accvgpr_write_b32 a52, v32
+\ts_or_b64 exec, exec, s[0:1]
+\ts_endpgm
+"""
+    good = bad.replace("\tv_accvgpr_write_b32 a53, v33\n\tv_accvgpr_write_b32 a52, v32\n\ts_or_b64 exec, exec, s[0:1]\n",
+                       "\ts_or_b64 exec, exec, s[0:1]\n\tv_accvgpr_write_b32 a53, v33\n\tv_accvgpr_write_b32 a52, v32\n")
+    assert [len(v) for v in S.scan(bad).values()] == [1] and [len(v) for v in S.scan(good).values()] == [0]
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        out = Path(d) / "k.s"
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", str(ROOT / "klara.jl_amd" / "csrc"),
+                            "-S", "--cuda-device-only", "-o", str(out), str(ROOT / "klara.jl_amd" / "csrc" / "klara_dense_big.hip")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hits = S.scan(out.read_text())
+    assert len(hits) >= 40                                            # 32 transition kernels + the initialisers
+    assert not {k: v for k, v in hits.items() if v}, {k: v[:2] for k, v in hits.items() if v}
+
+
 def test_iostream_files_round_trip_the_reference_tests_vectors(tmp_path):
     """The :iostream sink's on-disk format against the values the reference's own IO-stream tests write and read back
     (test/ParameterIOStreams.jl:159-193 BasicContMuvParameterState, :195-238 ContMuvMarkovChain; write = one comma-joined line per saved
