@@ -22,6 +22,18 @@
 #ifndef KLARA_DENSE_RING
 #define KLARA_DENSE_RING 8
 #endif
+// phase boundary of a transition: the scheduler may not move instructions across it (live ranges of one phase stay out of the next)
+#ifndef KLARA_BIG_NO_PHASES
+#define KLARA_BIG_PHASE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define KLARA_BIG_PHASE() ((void)0)
+#endif
+#ifndef KLARA_BIG_RELOAD_CHUNK
+#define KLARA_BIG_RELOAD_CHUNK 8      // elements re-read per group after a rejected proposal
+#endif
+#ifndef KLARA_BIG_XC_CHUNK
+#define KLARA_BIG_XC_CHUNK 8          // MALA's backward term: elements of the current value re-read per group (a power of two <= 8)
+#endif
 
 // acc[t] (tile t: elements 4t .. 4t+3 of the lane) = +P (x - mu), from zero
 template <int NE, bool HASMU>
@@ -122,6 +134,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
 {
     static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH, "HMC, MALA, MH");
     constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;          // MH carries no gradient (GR is not written)
+    constexpr bool KEEPG = SAMPLER == KLARA_SAMPLER_HMC;         // the committed gradient stays in the accumulators between transitions (MALA reads it from GR where it needs it)
     static_assert(!DA || SAMPLER == KLARA_SAMPLER_HMC, "dual averaging is wired into HMC only (HMC.jl:124-133)");
     constexpr bool da = DA;
     const KParams& p = *pp;
@@ -159,7 +172,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
         for (int e = 0; e < NE; ++e) {
             const unsigned o = cx.off(e, nv);
             xp[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
-            if (NEEDG) ga[e >> 2][e & 3] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, o, 0, 0));
+            if (KEEPG) ga[e >> 2][e & 3] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, o, 0, 0));
         }
     };
     reload();
@@ -213,30 +226,62 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             // consumed by the same pass; the current value is re-read from X for the backward term: no vector beyond x and P x is ever held.
             const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h), half_inv_h = 0.5 * (1.0 / h);
             double s1 = 0.0;
-            mnormals_each<NE>(cx, p.seed, gchain, t, [&](int e, double z) {
-                const double mu = xp[e] + halfh * (double)ga[e >> 2][e & 3];         // MALA.jl:83
-                xp[e] = mu + sq * z;                                                  // MALA.jl:84
-                const double q1 = mu - xp[e];
-                s1 = s1 + (q1 * q1) * half_inv_h;                                     // MALA.jl:90
-            });
+            // the normals go through the lane's LDS column like HMC's momentum: drawn first, consumed in groups of 8 — the transform's ~40 live
+            // registers and the pass over value + gradient do not overlap (drawn straight into the pass, NE = 64 came out with 560 B of scratch)
+            mnormals_lds<NE>(cx, p.seed, gchain, t, momw);
+            // the CURRENT gradient is read from GR where it is consumed (8 elements in flight), not kept in the accumulators between transitions: the
+            // accumulators are free while the normals are drawn, and a rejected proposal leaves nothing of the gradient to restore
+            {
+                const int nv = cx.nv_here();
+#pragma unroll
+                for (int e0 = 0; e0 < NE; e0 += 8) {
+                    double gc[8], zz[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        gc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, cx.off(e0 + j, nv), 0, 0));
+                        zz[j] = momw[(e0 + j) * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int e = e0 + j;
+                        const double mu = xp[e] + halfh * gc[j];                      // MALA.jl:83
+                        xp[e] = mu + sq * zz[j];                                      // MALA.jl:84
+                        const double q1 = mu - xp[e];
+                        s1 = s1 + (q1 * q1) * half_inv_h;                             // MALA.jl:90
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            KLARA_BIG_PHASE();
             dense_stream<NE, HASMU>(Pfrag, cx.lane, xp, ga, ldsMu);                  // MALA.jl:86
+            KLARA_BIG_PHASE();
 #pragma unroll
             for (int tt = 0; tt < MT; ++tt) ga[tt] = -ga[tt];
             double l1 = 0.0, s2 = 0.0, red[3];
             {
                 const int nv = cx.nv_here();
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    const double d = HASMU ? xp[e] - ldsMu[4 * e + cx.q] : xp[e];
-                    const double gpe = (double)ga[e >> 2][e & 3];
-                    l1 = l1 + d * gpe;
-                    const double xc = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, cx.off(e, nv), 0, 0));
-                    const double mup = xp[e] + halfh * gpe;                           // MALA.jl:91
-                    const double q2 = mup - xc;
-                    s2 = s2 + (q2 * q2) * half_inv_h;                                 // MALA.jl:92
+                for (int e0 = 0; e0 < NE; e0 += KLARA_BIG_XC_CHUNK) {      // the current value, 8 elements at a time: 8 loads in flight, then their terms (one load and a wait per element
+                    double xc[KLARA_BIG_XC_CHUNK];        // costs the memory latency NE times per transition at one wavefront per SIMD)
+#pragma unroll
+                    for (int j = 0; j < KLARA_BIG_XC_CHUNK; ++j) xc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, cx.off(e0 + j, nv), 0, 0));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < KLARA_BIG_XC_CHUNK; ++j) {
+                        const int e = e0 + j;
+                        const double d = HASMU ? xp[e] - ldsMu[4 * e + cx.q] : xp[e];
+                        const double gpe = (double)ga[e >> 2][e & 3];
+                        l1 = l1 + d * gpe;
+                        const double mup = xp[e] + halfh * gpe;                       // MALA.jl:91
+                        const double q2 = mup - xc[j];
+                        s2 = s2 + (q2 * q2) * half_inv_h;                             // MALA.jl:92
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             red[0] = l1; red[1] = s1; red[2] = s2;
+            KLARA_BIG_PHASE();
             mreduce<3>(red, cx.lane);
             ltp = p.gconst + 0.5 * red[0];
             double ratio = ltp - lt;                                                  // MALA.jl:88
@@ -289,6 +334,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             }
             held = fold ? 0 : held;
         }
+        KLARA_BIG_PHASE();
         if (__any(acc)) {                                // commit (HMC.jl:166-176)
             const int nv = cx.nv_here();
 #pragma unroll
@@ -299,23 +345,25 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             }
         }
         lt = acc ? ltp : lt;
+        KLARA_BIG_PHASE();
         if (__any(!acc)) {                               // the registers of a lane that rejected hold the proposal: back to the committed state
             const int nv = cx.nv_here();
+            constexpr int RC = KLARA_BIG_RELOAD_CHUNK;
 #pragma unroll
-            for (int e0 = 0; e0 < NE; e0 += 8) {         // 8 elements at a time: the loads of a group in flight, then its selects (not 2 NE loaded values live at once)
-                double xc[8], gc[8];
+            for (int e0 = 0; e0 < NE; e0 += RC) {        // RC elements at a time: the loads of a group in flight, then its selects (not 2 NE loaded values live at once)
+                double xc[RC], gc[RC];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < RC; ++j) {
                     const unsigned o = acc ? KLARA_BUF_OOB : cx.off(e0 + j, nv);
                     xc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
-                    if (NEEDG) gc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, o, 0, 0));
+                    if (KEEPG) gc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, o, 0, 0));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < RC; ++j) {
                     const int e = e0 + j;
                     xp[e] = acc ? xp[e] : xc[j];
-                    if (NEEDG) ga[e >> 2][e & 3] = acc ? ga[e >> 2][e & 3] : gc[j];
+                    if (KEEPG) ga[e >> 2][e & 3] = acc ? ga[e >> 2][e & 3] : gc[j];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -347,9 +395,20 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
                 }
                 if (NEEDG && p.hist_g != nullptr) {
                     const __amdgpu_buffer_rsrc_t wh = mwin<NE>(cx, p.hist_g, col * p.nchains, p.D);
+                    if constexpr (KEEPG) {
 #pragma unroll
-                    for (int e = 0; e < NE; ++e)
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, (double)ga[e >> 2][e & 3]), wh, cx.off(e, nv), 0, 0);
+                        for (int e = 0; e < NE; ++e)
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, (double)ga[e >> 2][e & 3]), wh, cx.off(e, nv), 0, 0);
+                    } else {                             // (MALA: the committed gradient is in GR — the accumulators may hold a rejected proposal's)
+#pragma unroll
+                        for (int e0 = 0; e0 < NE; e0 += 8) {
+                            double gc[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) gc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, cx.off(e0 + j, nv), 0, 0));
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, gc[j]), wh, cx.off(e0 + j, nv), 0, 0);
+                        }
+                    }
                 }
                 if (p.hist_lt != nullptr) {
                     const __amdgpu_buffer_rsrc_t wl = mwin<NE>(cx, p.hist_lt, col * p.nchains, 1);                // (row `col`, the tile's chains)
