@@ -177,6 +177,29 @@ def test_normal_pair_against_independent_high_precision_box_muller():
     assert O.math_op(7, np.array([2.0 ** -45]))[0] > -31.2
 
 
+def test_draw_schedule_of_a_transition():
+    """Which bits make which normal (detmath.h kd_normal_pair_at): element pair p takes half (p >> 3) & 1 of block slot
+    (p & 7) + 8 (p >> 4) of its transition — restated here in Python and compared BIT FOR BIT with what the oracle's samplers draw
+    (ko_transition_normals), for vector lengths on both sides of every boundary of the mapping.  Every (block, half) is used by one pair only, every
+    block slot is below ceil(D/2), and the accept uniform is the 44-bit uniform of words (x, y) of block slot ceil(D/2), which no pair touches."""
+    import ctypes as C
+    lib = O.load()
+    seed, chain, t = 20260927, (1 << 33) + 5, 123456
+    for D in (1, 2, 3, 15, 16, 17, 18, 31, 32, 33, 34, 100, 255, 256):
+        P = (D + 1) // 2
+        z = np.zeros(D); u = np.zeros(1)
+        lib.ko_transition_normals(C.c_uint64(seed), C.c_uint64(chain), C.c_uint64(t), D, z.ctypes.data, u.ctypes.data)
+        slots = [((p & 7) + 8 * (p >> 4), (p >> 3) & 1) for p in range(P)]
+        assert len(set(slots)) == P and max(b for b, _ in slots) < P
+        blocks = O.stream_blocks(seed, chain, t, sorted({b for b, _ in slots} | {P}))
+        byslot = dict(zip(sorted({b for b, _ in slots} | {P}), blocks))
+        words = np.array([[byslot[b][2 * h], byslot[b][2 * h + 1]] for b, h in slots], dtype=np.uint32)
+        ref = np.zeros((P, 2))
+        lib.ko_normal_pairs_w(P, words.ctypes.data, ref.ctypes.data)
+        assert np.array_equal(z, ref.ravel()[:D]), D
+        assert u[0] == lib.ko_u44(int(byslot[P][0]), int(byslot[P][1]))
+
+
 def test_normal_tail_mass_on_the_host():
     """Tail mass of the generator as the kernels call it (stream blocks of consecutive chains / transitions): 4 x 10^7 draws,
     counts of |z| > 1, 2, 3, 4 within 4.5 binomial standard deviations of the normal law, second and fourth moments 1 and 3."""
