@@ -399,9 +399,9 @@ klara_status klara_selftest_rocrand_blocks(int32_t device, uint64_t seed, uint64
 klara_status klara_selftest_math(int32_t device, int32_t op, int64_t n, const double* in,
                                  const double* in2, double* out);
 
-/* Self-test hook: the proposal normals exactly as the transition kernels draw them — kd_normal_pair of the stream block
- * (seed, chain = first_chain + i, transition = 0 .. ntransitions-1, slot 0) — for i < nchains: counts[k] = number of the
- * 2 * nchains * ntransitions normals with |z| > thr[k] (nthr <= 8); moments (may be NULL) = sum z, sum z^2, sum z^4, max |z|.
+/* Self-test hook: the proposal normals exactly as the transition kernels draw them — kd_normal_pair_w on both halves of the stream block
+ * (seed, chain first_chain + i, transition t, slot 0), i.e. the pair indices 0 and 8 of a transition — counted on the device: counts[k] = number of the
+ * 4 * nchains * ntransitions normals with |z| > thr[k] (nthr <= 8); moments (may be NULL) = sum z, sum z^2, sum z^4, max |z|.
  * Tests compare the counts with the CPU build of the same generator (exactly) and with the normal tail mass (statistically). */
 klara_status klara_selftest_normal_tail(int32_t device, uint64_t seed, uint64_t first_chain, int64_t nchains,
                                         int64_t ntransitions, int32_t nthr, const double* thr, uint64_t* counts,
