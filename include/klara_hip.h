@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define KLARA_ABI_VERSION 4   /* 4: klara_gather_moments; klara_desc.sparse_moves 0 = device-decided (round 3's additions, renumbered late) */
+#define KLARA_ABI_VERSION 5   /* 5: the random stream changed — one Philox block makes four normals, 44-bit accept uniform (same symbols and structs as 4,
+                                 but a given seed draws different chains than a version-4 library); 4: klara_gather_moments, klara_desc.sparse_moves 0 = device-decided */
 /* klara_desc.steps_per_launch = 0 selects this many transitions per kernel launch (launches also end at the pooled tuner's
  * events and at batch boundaries of the streaming batch means, whichever comes first) */
 #define KLARA_DEFAULT_STEPS_PER_LAUNCH 32
