@@ -493,20 +493,21 @@ def extra_measurements(K, L, n, stream):
         ex["hmc_dense_d256_error"] = repr(exc)
 
     # -- slice sampler on the README target, D = 100
-    e = K.Engine(sampler=L.SAMPLER_SLICE, target=neg, nchains=n, nsteps=10 ** 7, slice_widths=np.full(NDIMS, 1.0), steps_per_launch=4,
+    SLICE_SPL = 32
+    e = K.Engine(sampler=L.SAMPLER_SLICE, target=neg, nchains=n, nsteps=10 ** 7, slice_widths=np.full(NDIMS, 1.0), steps_per_launch=SLICE_SPL,
                  stream=stream, nstreams=1)
     e.init_state_normal()
-    rate, ls, _ = timed_rate(e, n, 4, 16)
-    lay = e.layout(); at = attrs_of(e, 4); e.close()
+    rate, ls, _ = timed_rate(e, n, SLICE_SPL, 4 * SLICE_SPL)
+    lay = e.layout(); at = attrs_of(e, SLICE_SPL); e.close()
     ex["slice_d100_transitions_per_s"] = rate
     ex["slice_d100_coordinate_updates_per_s"] = rate * NDIMS
-    # the slice sampler's trip counts are data dependent: the algorithmic budget takes a chain's own mean probe counts on this target in
-    # stationarity (a seeded simulation of the procedure, scripts/instruction_budget.py slice_probe_counts); `frac_lockstep` prices what the 8
-    # chains of a wavefront, which share the loops, have to execute — the mean of the maximum over 8 chains
+    # the slice sampler's trip counts are data dependent: the algorithmic budget takes an update's own mean probe counts on this target in
+    # stationarity (a seeded simulation of the procedure, scripts/instruction_budget.py slice_probe_counts); `frac_lockstep` prices what the 64
+    # coordinate updates a wavefront makes at a time (every lane its own: round 4), which share the loops, have to execute — the mean of the maximum over 64
     bs, bsl = bud["slice_d100"], bud["slice_d100_lockstep"]
     ex["slice_d100_roofline"] = valu_roofline(f"k_diagt<3, {lay[2] // 2}, {lay[1]},", ls, attrs=at, budget=bs,
-                                              necessary_per_launch=bs["per_wave_transition"] * (n // bs["chains_per_wave"]) * 4)
-    ex["slice_d100_roofline"]["frac_lockstep"] = 4.0 * bsl["per_wave_transition"] * (n // bsl["chains_per_wave"]) * 4 / ls / (NSIMD * CLOCK_HZ)
+                                              necessary_per_launch=bs["per_wave_transition"] * (n // bs["chains_per_wave"]) * SLICE_SPL)
+    ex["slice_d100_roofline"]["frac_lockstep"] = 4.0 * bsl["per_wave_transition"] * (n // bsl["chains_per_wave"]) * SLICE_SPL / ls / (NSIMD * CLOCK_HZ)
 
     # -- the two data-model configurations of BASELINE.json at their per-GPU share (cfg 4: 262,144 / 8 chains of the swiss
     # logistic regression, MALA h = 0.1; cfg 5: 1,048,576 / 8 chains of the rats hierarchical model, HMC L = 32 with the

@@ -547,43 +547,29 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                     diagt_fold<NP, Q>(cx, wsum, wsq, held > 0, sums_loaded, held, x, sm, sq);
             }
             if (SLICE) {                                                           // iterate/SliceSampler.jl:60-109
-                // Coordinates are visited in turn.  Coordinate i lives on lane (i/2) % Q of its chain as register
-                // 2*((i/2)/Q) + (i&1); everything scalar (the slice level, the interval, the probes' log-targets) is computed
-                // redundantly by the chain's Q lanes, and loops run until every chain of the wavefront is done (__any).
-                // Per coordinate the per-element terms w (x - mu)^2 of the other coordinates are formed once; a probe only
-                // re-forms the moving term and re-adds the lane's terms in ascending order (the order of a full evaluation).
-                acc = true; ltp = lt;
-                const int gb = cx.lane - cx.q;
-                // the lane's terms w (x - mu)^2, kept up to date over the coordinates of the transition (a coordinate update changes one)
+                // The target is a sum of per-coordinate terms, lt = c - sum_i w_i (x_i - mu_i)^2, and a coordinate update only ever compares the
+                // log-target of a candidate with the slice level log(rand()) + lt (:66, :76, :84, :95): with t_i the moving coordinate's term,
+                //     lt(candidate) > log(rand()) + lt   <=>   t_i(current) - t_i(candidate) > log(rand())
+                // — the other coordinates cancel.  So the updates of a transition do not depend on each other, and instead of the chain's Q lanes
+                // walking through the D coordinates together (every probe a full evaluation: the lane's terms re-added and a Q-lane reduction,
+                // 7 of 8 lanes repeating the scalar work), every lane updates ITS OWN coordinates, all 64 lanes of the wavefront at once: no
+                // cross-lane traffic until the new state's log-target is formed at the end (one full evaluation in the layout's order).  The
+                // comparison in this difference form is a deliberate deviation from the literal arithmetic, shared with the
+                // oracle for this layout; loops run until every lane of the wavefront is done (__any).
+                acc = true;
                 double term[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e) { double gd; diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), term[e], gd); }
-                // i = 2 (ph Q + qo) + half ascending = ph, then qo, then half ascending: the register slot eo = 2 ph + half of the moving
-                // coordinate is a compile-time constant of the (unrolled) outer and inner loops, the owner lane qo is a wave-uniform loop counter
-                kd_static_for<0, NP>([&](auto PH) __attribute__((always_inline)) {
-                for (int qo = 0; qo < Q; ++qo) {
-                kd_static_for<0, 2>([&](auto HALF) __attribute__((always_inline)) {               // :65
-                    constexpr int ph = decltype(PH)::value, half = decltype(HALF)::value;
-                    const int i = 2 * (ph * Q + qo) + half;
-                    if (i >= D) return;
-                    constexpr int eo = 2 * ph + half;
-                    const bool owner = cx.q == qo;
-                    // A lane's part of a probe's log-target is its terms added in ascending order with the candidate's term in place of
-                    // the moving one (the order of a full evaluation).  Formed once per coordinate: the sum of the terms before the moving
-                    // one, and the whole sum of a lane that does not own the coordinate; a probe then adds the candidate's term and the
-                    // E - 1 - eo terms behind it on the owner lane.
-                    double prefix = 0.0;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) if (e < eo) prefix = prefix + term[e];
-                    double whole = prefix;
-#pragma unroll
-                    for (int e = 0; e < E; ++e) if (e >= eo) whole = whole + term[e];
-                    const double xi = lane_bcast(x[eo], gb + qo), wd = lane_bcast(sig[eo], gb + qo);
-                    const double wi_t = lane_bcast(UNITW ? 1.0 : wv(eo), gb + qo), mi_t = lane_bcast(UNITW ? 0.0 : mv(eo), gb + qo);
-                    const uint32_t base = (uint32_t)i << KLARA_SLICE_ATT_BITS;
+                for (int e = 0; e < E; ++e) {                                                  // :65 (the lane's coordinates in ascending order)
+                    const int i = 2 * ((e >> 1) * Q + cx.q) + (e & 1);
+                    const bool live = chain_ok && i < D;
+                    const uint32_t base = (uint32_t)(live ? i : 0) << KLARA_SLICE_ATT_BITS;
                     const kd_u32x4 b0 = kd_stream_block(p.seed, gchain, t, base);
-                    const double logu = kd_log_u01(kd_uniform_xy(b0)) + lt;                    // :66
+                    const double lgu = kd_log_u01(kd_uniform_xy(b0));                          // :66 log(rand()); the slice level is lgu + lt
                     const double ru = kd_uniform_zw(b0);                                       // :71
+                    const double xi = x[e], wd = sig[e], tcur = term[e];
+                    const double wi_t = UNITW ? 1.0 : wv(e), mi_t = UNITW ? 0.0 : mv(e);
                     double Li = xi - ru * wd;                                                  // :72
                     double Ri = xi + (1.0 - ru) * wd;                                          // :73
                     const auto term_of = [&](double cand) -> double {
@@ -591,60 +577,51 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                         diag_elem<UNITW>(cand, wi_t, -2.0 * wi_t, mi_t, tc, gd);
                         return tc;
                     };
-                    const auto lt_with = [&](double cand) -> double {
-                        double own = prefix + term_of(cand), part[1];
-#pragma unroll
-                        for (int e = 0; e < E; ++e) if (e > eo) own = own + term[e];
-                        part[0] = owner ? own : whole;
-                        group_allreduce<1>(part, Q, cx.lane);
-                        return gconst - part[0];
-                    };
                     if (p.stepout) {                                                           // :75-89
-                        double l = lt_with(Li);
+                        double dl = tcur - term_of(Li);
                         int guard = 0;
                         while (true) {
-                            bool go = chain_ok && !stuck && (l > logu);
+                            bool go = live && !stuck && (dl > lgu);
                             if (go && ++guard > KLARA_SLICE_MAX_ATT) { stuck = true; go = false; }
                             if (!__any(go)) break;
                             const double Ln = Li - wd;
-                            const double ln = lt_with(go ? Ln : Li);
-                            if (go) { Li = Ln; l = ln; }
+                            const double dn = tcur - term_of(go ? Ln : Li);
+                            if (go) { Li = Ln; dl = dn; }
                         }
-                        double r = lt_with(Ri);
+                        double dr = tcur - term_of(Ri);
                         guard = 0;
                         while (true) {
-                            bool go = chain_ok && !stuck && (r > logu);
+                            bool go = live && !stuck && (dr > lgu);
                             if (go && ++guard > KLARA_SLICE_MAX_ATT) { stuck = true; go = false; }
                             if (!__any(go)) break;
                             const double Rn = Ri + wd;
-                            const double rn = lt_with(go ? Rn : Ri);
-                            if (go) { Ri = Rn; r = rn; }
+                            const double dn = tcur - term_of(go ? Rn : Ri);
+                            if (go) { Ri = Rn; dr = dn; }
                         }
                     }
-                    double xprime = xi, ltnew = lt;
-                    bool done = !chain_ok || stuck;
+                    double xprime = xi, tnew = tcur;
+                    bool done = !live || stuck;
                     for (uint32_t a = 1;; ++a) {                                               // :91-106
                         if (!done && a > KLARA_SLICE_MAX_ATT) { stuck = true; done = true; }
                         if (!__any(!done)) break;
                         const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, base | a));
                         const double cand = u * (Ri - Li) + Li;                                // :92-93
-                        const double lc = lt_with(done ? xprime : cand);                       // :94
+                        const double tc = term_of(done ? xprime : cand);                       // :94
                         if (!done) {
-                            xprime = cand; ltnew = lc;
-                            if (lc > logu) done = true;                                        // :95
+                            xprime = cand; tnew = tc;
+                            if (tcur - tc > lgu) done = true;                                  // :95
                             else if (cand > xi) Ri = cand;                                     // :98
                             else if (cand < xi) Li = cand;                                     // :100
                             else { stuck = true; done = true; }                                // :102
                         }
                     }
-                    if (!stuck) {
-                        lt = ltnew;
-                        const double tnew = term_of(xprime);
-                        if (owner) { x[eo] = xprime; term[eo] = tnew; }                        // :108
-                    }
-                });
+                    if (live && !stuck) { x[e] = xprime; term[e] = tnew; }                     // :108
                 }
-                });
+                red1[0] = 0.0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) red1[0] = red1[0] + term[e];
+                group_allreduce<1>(red1, Q, cx.lane);
+                lt = gconst - red1[0];                                                         // the new state's log-target: one full evaluation
                 ltp = lt;
 #pragma unroll
                 for (int e = 0; e < E; ++e) xp[e] = x[e];          // (the commit below is then a no-op)
@@ -876,7 +853,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
             }
             if (chain_ok && cx.q == 0) p.held[chain] = held;
         }
-        if (SLICE && stuck && chain_ok && cx.q == 0) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);
+        if (SLICE && stuck && chain_ok) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);      // (a per-lane flag: the lane whose coordinate ran out of attempts)
         if (!ONESTEP) wave_acc += (chain_ok && cx.q == 0) ? (unsigned)nacc : 0u;     // (per-lane partial; summed in auto_finish)
         if (!ONESTEP && nacc != 0) {
             store_pairs<NP, Q>(cx, wx, x);

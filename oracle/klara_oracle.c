@@ -613,6 +613,56 @@ static int ko_slice(const ko_target_ctx* c, uint64_t chain, uint64_t t, double* 
     return 1;
 }
 
+/* The same update on the diagonal Gaussian in the pair-transposed layout (kind 3), where the kernels compare in DIFFERENCE form (deliberate
+ * deviation (8)): the target is a sum of per-coordinate terms t_i = w_i (x_i - mu_i)^2, so
+ *     lt(candidate) > log(rand()) + lt   <=>   t_i(current) - t_i(candidate) > log(rand())
+ * and the coordinates of a transition do not depend on each other (every lane of the kernel updates its own).  The new state's log-target is one full
+ * evaluation in the layout's order at the end.  ko_set_literal(1) takes this back (ko_slice above: a full evaluation per probe). */
+static int ko_slice_diag_delta(const ko_target_ctx* c, uint64_t chain, uint64_t t, double* x, double* lt, int* stuck)
+{
+    const klara_desc* d = c->d;
+    const int D = d->ndims;
+    double scratch[KO_MAXD];
+    for (int i = 0; i < D; ++i) {                                        /* :65 */
+        const uint32_t base = (uint32_t)i << KO_SLICE_ATT_BITS;
+        const kd_u32x4 b0 = kd_stream_block(d->seed, chain, t, base);
+        const double lgu = kd_log_u01(kd_uniform_xy(b0));                /* :66 log(rand()) */
+        const double ru = kd_uniform_zw(b0);                             /* :71 */
+        const double w = d->slice_widths[i], xi = x[i];
+        const double mu = d->gauss_mu ? d->gauss_mu[i] : 0.0, wt = d->gauss_w ? d->gauss_w[i] : 1.0;
+#define KO_TERM(v) (wt * (((v) - mu) * ((v) - mu)))
+        const double tcur = KO_TERM(xi);
+        double Li = xi - ru * w;                                         /* :72 */
+        double Ri = xi + (1.0 - ru) * w;                                 /* :73 */
+        if (d->slice_stepout) {                                          /* :75-89 */
+            int guard = 0;
+            while (tcur - KO_TERM(Li) > lgu) {
+                Li -= w;
+                if (++guard > KO_SLICE_MAX_ATT) { *stuck = 1; return 0; }
+            }
+            guard = 0;
+            while (tcur - KO_TERM(Ri) > lgu) {
+                Ri += w;
+                if (++guard > KO_SLICE_MAX_ATT) { *stuck = 1; return 0; }
+            }
+        }
+        double xprime = xi;
+        for (uint32_t a = 1;; ++a) {                                     /* :91-106 */
+            if (a > KO_SLICE_MAX_ATT) { *stuck = 1; return 0; }
+            const double u = kd_uniform_xy(kd_stream_block(d->seed, chain, t, base | a));
+            xprime = u * (Ri - Li) + Li;                                 /* :92-93 */
+            if (tcur - KO_TERM(xprime) > lgu) break;                     /* :94-95 */
+            if (xprime > xi) Ri = xprime;                                /* :98 */
+            else if (xprime < xi) Li = xprime;                           /* :100 */
+            else { *stuck = 1; return 0; }                               /* :102 */
+        }
+#undef KO_TERM
+        x[i] = xprime;                                                   /* :108 */
+    }
+    *lt = ko_logtarget(c, x, scratch);
+    return 1;
+}
+
 /* Streaming batch means (klara_desc.bm_batchlen): mcvar(v, Val{:bm}) of src/stats/variance/mcvar.jl:35-41 takes
  * var(batch means); the history-free form closes a batch from the running sums at its two boundaries and updates the mean
  * and the sum of squared deviations of the batch means in place (Welford).  n = nchains * D series, count = batches closed
@@ -701,7 +751,9 @@ static int ko_transition(const ko_target_ctx* c, uint64_t gchain, uint64_t t, do
     case KLARA_SAMPLER_MH: return ko_mh(c, gchain, t, x, lt);
     case KLARA_SAMPLER_MALA: return ko_mala(c, gchain, t, step, x, g, lt);
     case KLARA_SAMPLER_HMC: return ko_hmc(c, gchain, t, step, nleaps, x, g, lt, a_out);
-    default: return ko_slice(c, gchain, t, x, lt, stuck);
+    default:
+        if (c->L->kind == 3 && d->target == KLARA_TARGET_GAUSS_DIAG && !ko_is_literal()) return ko_slice_diag_delta(c, gchain, t, x, lt, stuck);
+        return ko_slice(c, gchain, t, x, lt, stuck);
     }
 }
 

@@ -146,8 +146,9 @@ def hmc_iso(nleaps: int = 10, ndims: int = 100, lanes_per_chain: int = 8):
 
 def slice_probe_counts(width: float = 1.0, nsamples: int = 400000, seed: int = 7):
     """Mean log-target probes of one coordinate update of the slice sampler (iterate/SliceSampler.jl:60-109, stepping out) on lt = -|x|^2 in
-    stationarity: (left probes, right probes, shrink attempts) per chain, and the means of the MAXIMUM over the 8 chains of a wavefront —
-    the lockstep loops of the kernel run until the slowest of its 8 chains is done.  A simulation of the procedure itself (NumPy), seeded."""
+    stationarity: (left probes, right probes, shrink attempts) per chain, and the means of the MAXIMUM over the 8 chains of a wavefront
+    (round 3's kernel: the 8 chains of a wavefront shared the loops) and over 64 coordinate updates (round 4: every lane of the wavefront updates a
+    coordinate of its own; the loops run until the slowest of the 64 is done).  A simulation of the procedure itself (NumPy), seeded."""
     import numpy as np
     rng = np.random.default_rng(seed)
     n = nsamples
@@ -171,29 +172,32 @@ def slice_probe_counts(width: float = 1.0, nsamples: int = 400000, seed: int = 7
         done |= act & ok
         R = np.where(act & ~ok & (c > x), c, R); L = np.where(act & ~ok & (c < x), c, L)
     m8 = lambda a: float(a[:n // 8 * 8].reshape(-1, 8).max(1).mean())
-    return {"per_chain": (float(nl.mean()), float(nr.mean()), float(ns.mean())), "max_over_8_chains": (m8(nl), m8(nr), m8(ns))}
+    m64 = lambda a: float(a[:n // 64 * 64].reshape(-1, 64).max(1).mean())
+    return {"per_chain": (float(nl.mean()), float(nr.mean()), float(ns.mean())), "max_over_8_chains": (m8(nl), m8(nr), m8(ns)),
+            "max_over_64_lanes": (m64(nl), m64(nr), m64(ns))}
 
 
-SLICE_PROBES = {"per_chain": (2.128745, 2.1275425, 1.46118), "max_over_8_chains": (3.57358, 3.57234, 2.81954)}     # slice_probe_counts()
+SLICE_PROBES = {"per_chain": (2.128745, 2.1275425, 1.46118), "max_over_8_chains": (3.57358, 3.57234, 2.81954),
+                "max_over_64_lanes": (4.73024, 4.74288, 4.47424)}     # slice_probe_counts()
 
 
 def slice_diag(ndims: int = 100, counts=None):
-    """k_diagt<SLICE, NP=7, Q=8, UNITW>: per wavefront (8 chains) and COORDINATE update.  `counts` = (left probes, right probes, shrink
-    attempts); the algorithmic budget takes a chain's own mean counts, the lockstep variant the mean of the maximum over the wavefront's 8
-    chains (what 8 chains sharing the loops have to execute)."""
+    """k_diagt<SLICE, NP=7, Q=8, UNITW> (round 4: every lane updates its own coordinates, comparisons in difference form): per wavefront (8 chains =
+    64 coordinate updates at a time) and coordinate SLOT of a lane.  `counts` = (left probes, right probes, shrink attempts); the algorithmic budget
+    takes an update's own mean counts, the lockstep variant the mean of the maximum over the 64 updates that share the loops."""
     nl, nr, ns = counts if counts is not None else SLICE_PROBES["per_chain"]
-    E = 14
-    probe = 1 + 1 + (E - 1) / 2.0 + 2 + 3 * BFLY + 1                    # candidate's term; prefix + term; the terms behind the slot; owner select; butterfly; c - sum
-    fixed = (E                                                          # prefix and whole sums of the lane's cached terms
-             + 2 * 2                                                    # x_i and its width to the chain's lanes
-             + PHILOX + U52 + LOG_U01 + 1 + U52                         # log(rand()) + lt, runiform: one block
+    probe = 1 + 1 + 1                                                   # the candidate's term (x x), its difference to the current term, the compare
+    fixed = (PHILOX + U52 + LOG_U01 + U52                               # log(rand()), runiform: one block
              + 2 + 3                                                    # l_i = x_i - r w; r_i = x_i + (1 - r) w
-             + 2 + 4 + 2)                                               # the new term; x_i, term, lt selects
-    expand = 3 + 1 + 2 + probe + 4                                      # test, step, candidate select, probe, interval / value selects
-    shrink = PHILOX + U52 + 3 + 2 + probe + 13                          # attempt's block, candidate, select, probe, compares and interval updates
-    per = fixed + 2 * probe + (nl - 1 + nr - 1) * expand + ns * shrink + 4
+             + 1                                                        # the current term
+             + 4)                                                       # x_i and its term: selects of the two doubles
+    expand = 1 + probe + 4                                              # step, probe, interval / difference selects
+    shrink = PHILOX + U52 + 3 + probe + 2 + 8                           # attempt's block, candidate (sub, mul, add), probe, two more compares, selects of x', t', l_i, r_i
+    per = fixed + 2 * probe + (nl - 1 + nr - 1) * expand + ns * shrink
+    slots = ndims * 8 / 64.0                                            # coordinate slots per lane: 12.5
     return {"per_probe": probe, "fixed_per_coordinate": fixed, "per_expansion": expand, "per_shrink_attempt": shrink,
-            "probes": {"left": nl, "right": nr, "shrink": ns}, "per_wave_coordinate": per, "per_wave_transition": per * ndims, "chains_per_wave": 8}
+            "probes": {"left": nl, "right": nr, "shrink": ns}, "per_wave_slot": per, "coordinate_slots_per_lane": slots,
+            "per_wave_transition": per * slots + 14 + 3 * BFLY, "chains_per_wave": 8}         # + the new state's log-target: 14 adds, one butterfly
 
 
 # ---- the same budgets weighted by what an instruction costs the issue port -----------------------------------------------------------
@@ -221,8 +225,8 @@ BUDGETS = {"headline_4lane": _with_extra(_h4, _normals_extra(_h4)),
            "cfg4": _with_extra(_c4, 1 * PAIR_EXTRA + _c4["rows_per_lane"] * QUARTER_EXTRA + 5 * QUARTER_EXTRA),   # + one v_rcp_f64 per row and per prior division
            "cfg1": _with_extra(cfg1_replicas(), 2 * 20 * MAD_EXTRA + QUARTER_EXTRA),
            "hmc_iso": _with_extra(hmc_iso(), _normals_extra(hmc_iso())),
-           "slice_d100": _with_extra(slice_diag(), 100 * (1 + SLICE_PROBES["per_chain"][2]) * 20 * MAD_EXTRA),
-           "slice_d100_lockstep": _with_extra(slice_diag(counts=SLICE_PROBES["max_over_8_chains"]), 100 * (1 + SLICE_PROBES["max_over_8_chains"][2]) * 20 * MAD_EXTRA)}
+           "slice_d100": _with_extra(slice_diag(), 12.5 * (1 + SLICE_PROBES["per_chain"][2]) * 20 * MAD_EXTRA),
+           "slice_d100_lockstep": _with_extra(slice_diag(counts=SLICE_PROBES["max_over_64_lanes"]), 12.5 * (1 + SLICE_PROBES["max_over_64_lanes"][2]) * 20 * MAD_EXTRA)}
 
 if __name__ == "__main__":
     print(f"building blocks: Philox4x32-10 {PHILOX}, u52 {U52}, log(u) {LOG_U01}, radius {SQRT_RAD}, sin/cos {SINCOS}, Box-Muller on 64 bits {BOX_MULLER}, normal pair {NORMAL_PAIR} (own block: {NORMAL_PAIR_OWN}), "

@@ -1,9 +1,10 @@
 """How far is the shipped arithmetic from the literal Julia arithmetic?  
 
 The oracle the kernels are compared with shares three deliberate deviations with them: (7) the merged fma
-leapfrog (/root/reference/src/samplers/samplers.jl:122-134 writes four unmerged, unfused updates per step), (2) MALA's
+leapfrog (/root/reference/src/samplers/samplers.jl:122-134 writes four unmerged, unfused updates per step), (8) the slice sampler's
+comparisons on a diagonal Gaussian in difference form (src/samplers/iterate/SliceSampler.jl:66-95 evaluates the whole log-target per probe), (2) MALA's
 `0.5*(abs2.(...)/step)` evaluated as `abs2(.)*(0.5/step)` (src/samplers/iterate/MALA.jl:88-92), (6) the logistic rows' two exponentials
-taken from one (doc/examples/swiss/MALA/analytical.jl:13,17).  `ko_set_literal(1)` takes all three back.  These tests run the SAME jobs
+taken from one (doc/examples/swiss/MALA/analytical.jl:13,17).  `ko_set_literal(1)` takes all four back.  These tests run the SAME jobs
 on the SAME stream in both modes at the BASELINE configurations' trajectory lengths — 64 chains x 2,000 transitions — and measure
   * the first transition at which any state bit differs, and the first at which an accept decision differs,
   * the Hamming fraction of the accept masks (differing decisions / all decisions),
@@ -51,6 +52,10 @@ def _jobs():
         # BASELINE cfg 4: MALA h = 0.1 on the swiss logistic regression: two exponentials per row against one, and the quotient
         "cfg4_mala_swiss": dict(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, 100.0), driftstep=0.1,
                                 x0=np.array([5.1, -0.9, 8.2, -4.5]) * 0.0 + 0.1 * rng.standard_normal((NCHAINS, 4))),
+        # the slice sampler on a diagonal Gaussian in the pair-transposed layout (deviation (8)): comparisons in difference form,
+        # t_i(current) - t_i(candidate) > log(rand()), against a full evaluation of every probe compared with log(rand()) + lt (SliceSampler.jl:66-95)
+        "slice_mvnormal_d40": dict(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.mvnormal(np.linspace(-2.0, 3.0, 40), np.linspace(0.5, 2.0, 40)),
+                                   slice_widths=np.linspace(0.6, 1.8, 40), slice_stepout=True, x0=rng.standard_normal((NCHAINS, 40))),
     }
 
 
@@ -156,3 +161,9 @@ def test_literal_mode_is_off_by_default_and_changes_bits():
 
 if __name__ == "__main__":
     print(json.dumps([compare(n, c) for n, c in _jobs().items()], indent=1))
+
+
+def test_slice_difference_form_against_full_evaluations():
+    r = compare("slice_mvnormal_d40", _jobs()["slice_mvnormal_d40"])
+    assert r["first_saved_transition_with_a_different_state_bit"] is None, r        # 64 x 2,000 x 40 coordinate updates: the same points, bit for bit
+    _check(r)
