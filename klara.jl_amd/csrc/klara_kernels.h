@@ -25,6 +25,9 @@
 #include "../../include/klara_hip.h"
 #endif
 
+#ifndef KLARA_E2_DIAG_WAVES
+#define KLARA_E2_DIAG_WAVES 3   // min waves per SIMD requested for the 2-elements-per-lane kernels on the diagonal Gaussian (cfg 1 as replicas)
+#endif
 #ifndef KLARA_E4_WAVES
 #define KLARA_E4_WAVES 2   // min waves per SIMD requested for the E=4 kernels (register budget 256)
 #endif
@@ -1087,7 +1090,7 @@ template <int SAMPLER, int TARGET, int E, int GT, int MODE>
 //  wavefronts cannot cover; the 128-register budget spills 156-272 B outside the row loop and still measured 1.01e9 against 8.1e8
 //  transitions/s with running sums, 1.05e9 against 9.4e8 without, same box)
 __global__ __launch_bounds__(256, (TARGET == KLARA_TARGET_CUSTOM && GT > 1 ? 2 /* staged closures: two workgroups' rows fit a CU's LDS */ :
-                                   E == 2 ? 3 : (E == 4 ? (TARGET == KLARA_TARGET_LOGISTIC && SAMPLER == KLARA_SAMPLER_MALA ? KLARA_E4_WAVES_LOGISTIC
+                                   E == 2 ? (TARGET == KLARA_TARGET_GAUSS_DIAG ? KLARA_E2_DIAG_WAVES : 3) : (E == 4 ? (TARGET == KLARA_TARGET_LOGISTIC && SAMPLER == KLARA_SAMPLER_MALA ? KLARA_E4_WAVES_LOGISTIC
                                                                   : TARGET == KLARA_TARGET_LOGISTIC && SAMPLER == KLARA_SAMPLER_HMC ? KLARA_E4_WAVES_LOGISTIC_HMC
                                                                   : ((MODE & 3) == 3 ? KLARA_E4_WAVES_PLAIN : KLARA_E4_WAVES))
                                                   : (E == 8 && TARGET == KLARA_TARGET_LOGISTIC ? KLARA_E8_WAVES_LOGISTIC : 1))))
