@@ -594,5 +594,13 @@ KD_FN double kd_accept_uniform(kd_u32x4 b) { return kd_u44(b.x, b.y); }
 /* uniforms of the slice sampler: words (x,y) of a block (or (z,w) for the second), 52 bits */
 KD_FN double kd_uniform_xy(kd_u32x4 b) { return kd_u52(b.x, b.y); }
 KD_FN double kd_uniform_zw(kd_u32x4 b) { return kd_u52(b.z, b.w); }
+/* the uniform of shrink attempt a >= 1 of a coordinate whose draws start at block slot `base`: attempts 2k - 1 and 2k share block base | k
+ * (words (x, y), then (z, w)) — a kernel that loops over the attempts forms a block at every odd attempt only */
+KD_FN uint32_t kd_slice_attempt_slot(uint32_t base, uint32_t a) { return base | ((a + 1u) >> 1); }
+KD_FN double kd_slice_attempt_uniform(uint64_t seed, uint64_t chain, uint64_t transition, uint32_t base, uint32_t a)
+{
+    const kd_u32x4 b = kd_stream_block(seed, chain, transition, kd_slice_attempt_slot(base, a));
+    return (a & 1u) ? kd_uniform_xy(b) : kd_uniform_zw(b);
+}
 
 #endif /* KLARA_DETMATH_H */

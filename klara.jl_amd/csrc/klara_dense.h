@@ -423,7 +423,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 for (uint32_t a = 1;; ++a) {                                                   // :91-106
                     if (!done && a > KLARA_SLICE_MAX_ATT) { stuck = true; done = true; }
                     if (!__any(!done)) break;
-                    const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, base | a));
+                    const double u = kd_slice_attempt_uniform(p.seed, gchain, t, base, a);
                     const double cand = u * (Ri - Li) + Li;                                    // :92-93
                     const double lc = lt_with(done ? xprime : cand);                           // :94
                     if (!done) {

@@ -601,10 +601,12 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                     }
                     double xprime = xi, tnew = tcur;
                     bool done = !live || stuck;
+                    kd_u32x4 ab = b0;                                                          // the block of the current pair of attempts
                     for (uint32_t a = 1;; ++a) {                                               // :91-106
                         if (!done && a > KLARA_SLICE_MAX_ATT) { stuck = true; done = true; }
                         if (!__any(!done)) break;
-                        const double u = kd_uniform_xy(kd_stream_block(p.seed, gchain, t, base | a));
+                        if (a & 1u) ab = kd_stream_block(p.seed, gchain, t, kd_slice_attempt_slot(base, a));   // (a is wave-uniform: attempts 2k - 1 and 2k share a block)
+                        const double u = (a & 1u) ? kd_uniform_xy(ab) : kd_uniform_zw(ab);
                         const double cand = u * (Ri - Li) + Li;                                // :92-93
                         const double tc = term_of(done ? xprime : cand);                       // :94
                         if (!done) {

@@ -32,7 +32,7 @@
  *     serves pairs p and p + 8), Box-Muller on a 44-bit radius uniform and a 20-bit angle, cos branch for even i, sin branch for odd i;
  *   accept uniform (MH, MALA, HMC): slot ceil(D/2), words (x,y), 44 bits;
  *   slice sampler, coordinate i: slot (i << 14): words (x,y) -> log-uniform, (z,w) -> runiform;
- *     shrink attempt a >= 1: slot (i << 14) | a, words (x,y).
+ *     shrink attempt a >= 1: slot (i << 14) | ((a + 1) >> 1), words (x,y) for odd a, (z,w) for even a (two attempts per block).
  *   initial state x0 ~ N(0,I): transition index 2^40 - 1 ("-1"), same element -> slot mapping.
  */
 #include <stdint.h>
@@ -599,7 +599,7 @@ static int ko_slice(const ko_target_ctx* c, uint64_t chain, uint64_t t, double* 
         double xprime = xi;
         for (uint32_t a = 1;; ++a) {                                     /* :91-106 */
             if (a > KO_SLICE_MAX_ATT) { *stuck = 1; return 0; }
-            const double u = kd_uniform_xy(kd_stream_block(d->seed, chain, t, base | a));
+            const double u = kd_slice_attempt_uniform(d->seed, chain, t, base, a);
             xprime = u * (Ri - Li) + Li;                                 /* :92-93 */
             tmp[i] = xprime;
             *lt = ko_logtarget(c, tmp, scratch);                         /* :94 */
@@ -649,7 +649,7 @@ static int ko_slice_diag_delta(const ko_target_ctx* c, uint64_t chain, uint64_t 
         double xprime = xi;
         for (uint32_t a = 1;; ++a) {                                     /* :91-106 */
             if (a > KO_SLICE_MAX_ATT) { *stuck = 1; return 0; }
-            const double u = kd_uniform_xy(kd_stream_block(d->seed, chain, t, base | a));
+            const double u = kd_slice_attempt_uniform(d->seed, chain, t, base, a);
             xprime = u * (Ri - Li) + Li;                                 /* :92-93 */
             if (tcur - KO_TERM(xprime) > lgu) break;                     /* :94-95 */
             if (xprime > xi) Ri = xprime;                                /* :98 */

@@ -173,29 +173,32 @@ def slice_probe_counts(width: float = 1.0, nsamples: int = 400000, seed: int = 7
         R = np.where(act & ~ok & (c > x), c, R); L = np.where(act & ~ok & (c < x), c, L)
     m8 = lambda a: float(a[:n // 8 * 8].reshape(-1, 8).max(1).mean())
     m64 = lambda a: float(a[:n // 64 * 64].reshape(-1, 64).max(1).mean())
+    blocks64 = float(np.ceil(ns[:n // 64 * 64].reshape(-1, 64).max(1) / 2.0).mean())      # Philox blocks of the attempts: two attempts share one
     return {"per_chain": (float(nl.mean()), float(nr.mean()), float(ns.mean())), "max_over_8_chains": (m8(nl), m8(nr), m8(ns)),
-            "max_over_64_lanes": (m64(nl), m64(nr), m64(ns))}
+            "max_over_64_lanes": (m64(nl), m64(nr), m64(ns)), "shrink_blocks": (float(np.ceil(ns / 2.0).mean()), blocks64)}
 
 
 SLICE_PROBES = {"per_chain": (2.128745, 2.1275425, 1.46118), "max_over_8_chains": (3.57358, 3.57234, 2.81954),
-                "max_over_64_lanes": (4.73024, 4.74288, 4.47424)}     # slice_probe_counts()
+                "max_over_64_lanes": (4.73024, 4.74288, 4.47424), "shrink_blocks": (1.107035, 2.46368)}     # slice_probe_counts()
 
 
-def slice_diag(ndims: int = 100, counts=None):
+def slice_diag(ndims: int = 100, counts=None, blocks=None):
     """k_diagt<SLICE, NP=7, Q=8, UNITW> (round 4: every lane updates its own coordinates, comparisons in difference form): per wavefront (8 chains =
-    64 coordinate updates at a time) and coordinate SLOT of a lane.  `counts` = (left probes, right probes, shrink attempts); the algorithmic budget
-    takes an update's own mean counts, the lockstep variant the mean of the maximum over the 64 updates that share the loops."""
+    64 coordinate updates at a time) and coordinate SLOT of a lane.  `counts` = (left probes, right probes, shrink attempts), `blocks` = Philox blocks of
+    the attempts (two attempts share one); the algorithmic budget takes an update's own mean counts, the lockstep variant the means of the maxima over the
+    64 updates that share the loops."""
     nl, nr, ns = counts if counts is not None else SLICE_PROBES["per_chain"]
+    nb = blocks if blocks is not None else SLICE_PROBES["shrink_blocks"][0]
     probe = 1 + 1 + 1                                                   # the candidate's term (x x), its difference to the current term, the compare
     fixed = (PHILOX + U52 + LOG_U01 + U52                               # log(rand()), runiform: one block
              + 2 + 3                                                    # l_i = x_i - r w; r_i = x_i + (1 - r) w
              + 1                                                        # the current term
              + 4)                                                       # x_i and its term: selects of the two doubles
     expand = 1 + probe + 4                                              # step, probe, interval / difference selects
-    shrink = PHILOX + U52 + 3 + probe + 2 + 8                           # attempt's block, candidate (sub, mul, add), probe, two more compares, selects of x', t', l_i, r_i
-    per = fixed + 2 * probe + (nl - 1 + nr - 1) * expand + ns * shrink
+    shrink = U52 + 3 + probe + 2 + 8                                    # the attempt's uniform, candidate (sub, mul, add), probe, two more compares, selects of x', t', l_i, r_i
+    per = fixed + 2 * probe + (nl - 1 + nr - 1) * expand + ns * shrink + nb * PHILOX
     slots = ndims * 8 / 64.0                                            # coordinate slots per lane: 12.5
-    return {"per_probe": probe, "fixed_per_coordinate": fixed, "per_expansion": expand, "per_shrink_attempt": shrink,
+    return {"per_probe": probe, "fixed_per_coordinate": fixed, "per_expansion": expand, "per_shrink_attempt": shrink, "philox_blocks_of_the_attempts": nb,
             "probes": {"left": nl, "right": nr, "shrink": ns}, "per_wave_slot": per, "coordinate_slots_per_lane": slots,
             "per_wave_transition": per * slots + 14 + 3 * BFLY, "chains_per_wave": 8}         # + the new state's log-target: 14 adds, one butterfly
 
@@ -225,8 +228,9 @@ BUDGETS = {"headline_4lane": _with_extra(_h4, _normals_extra(_h4)),
            "cfg4": _with_extra(_c4, 1 * PAIR_EXTRA + _c4["rows_per_lane"] * QUARTER_EXTRA + 5 * QUARTER_EXTRA),   # + one v_rcp_f64 per row and per prior division
            "cfg1": _with_extra(cfg1_replicas(), 2 * 20 * MAD_EXTRA + QUARTER_EXTRA),
            "hmc_iso": _with_extra(hmc_iso(), _normals_extra(hmc_iso())),
-           "slice_d100": _with_extra(slice_diag(), 12.5 * (1 + SLICE_PROBES["per_chain"][2]) * 20 * MAD_EXTRA),
-           "slice_d100_lockstep": _with_extra(slice_diag(counts=SLICE_PROBES["max_over_64_lanes"]), 12.5 * (1 + SLICE_PROBES["max_over_64_lanes"][2]) * 20 * MAD_EXTRA)}
+           "slice_d100": _with_extra(slice_diag(), 12.5 * (1 + SLICE_PROBES["shrink_blocks"][0]) * 20 * MAD_EXTRA),
+           "slice_d100_lockstep": _with_extra(slice_diag(counts=SLICE_PROBES["max_over_64_lanes"], blocks=SLICE_PROBES["shrink_blocks"][1]),
+                                              12.5 * (1 + SLICE_PROBES["shrink_blocks"][1]) * 20 * MAD_EXTRA)}
 
 if __name__ == "__main__":
     print(f"building blocks: Philox4x32-10 {PHILOX}, u52 {U52}, log(u) {LOG_U01}, radius {SQRT_RAD}, sin/cos {SINCOS}, Box-Muller on 64 bits {BOX_MULLER}, normal pair {NORMAL_PAIR} (own block: {NORMAL_PAIR_OWN}), "

@@ -230,8 +230,8 @@ class Chain:
                     hi += w
             a = 1
             while True:                                                              # :91-106
-                bb = stream_block(self.seed, self.cid, t, (i << 14) | a)
-                cand = u52(bb[0], bb[1]) * (hi - lo) + lo                            # :92-93
+                bb = stream_block(self.seed, self.cid, t, (i << 14) | ((a + 1) >> 1))       # attempts 2k - 1 and 2k share block k: words (x, y), then (z, w)
+                cand = (u52(bb[0], bb[1]) if a & 1 else u52(bb[2], bb[3])) * (hi - lo) + lo      # :92-93
                 lc = at(cand)                                                        # :94
                 if lc > logu:
                     break

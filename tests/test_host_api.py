@@ -328,9 +328,9 @@ def test_instruction_budgets_follow_from_their_parts():
     c1, hi, sl, sll = B.BUDGETS["cfg1"], B.BUDGETS["hmc_iso"], B.BUDGETS["slice_d100"], B.BUDGETS["slice_d100_lockstep"]
     assert c1["per_wave_transition"] == 100 + 4 + 5 + 72 + 6 + 13 + 2 == 202 and c1["chains_per_wave"] == 64
     assert hi["per_pair"] == 59 + 8 + 2 + 60 + 4 == 133 and hi["per_wave_transition"] == 6.25 * 137 + 3.25 * 41 + 27 + 46 + 3
-    assert sl["per_probe"] == 3 and sl["fixed_per_coordinate"] == 82 and sl["per_shrink_attempt"] == 61 and sl["per_expansion"] == 8 and sl["coordinate_slots_per_lane"] == 12.5
+    assert sl["per_probe"] == 3 and sl["fixed_per_coordinate"] == 82 and sl["per_shrink_attempt"] == 20 and sl["per_expansion"] == 8 and sl["coordinate_slots_per_lane"] == 12.5
     pc = B.slice_probe_counts()                                   # the seeded simulation of the stepping-out procedure reproduces the constants
-    assert np.allclose(pc["per_chain"], B.SLICE_PROBES["per_chain"], rtol=1e-12) and np.allclose(pc["max_over_64_lanes"], B.SLICE_PROBES["max_over_64_lanes"], rtol=1e-12)
+    assert np.allclose(pc["per_chain"], B.SLICE_PROBES["per_chain"], rtol=1e-12) and np.allclose(pc["max_over_64_lanes"], B.SLICE_PROBES["max_over_64_lanes"], rtol=1e-12) and np.allclose(pc["shrink_blocks"], B.SLICE_PROBES["shrink_blocks"], rtol=1e-12)
     assert 2.0 < pc["per_chain"][0] < 2.3 and 1.3 < pc["per_chain"][2] < 1.6 and sll["per_wave_slot"] > 1.5 * sl["per_wave_slot"]
     # the README of profiles/ quotes these totals
     txt = (ROOT / "profiles" / "README.md").read_text()
