@@ -29,6 +29,9 @@
 #ifndef KLARA_DT_FENCE_EVERY
 #define KLARA_DT_FENCE_EVERY 2
 #endif
+#ifndef KLARA_DT_SLICE_WF
+#define KLARA_DT_SLICE_WF 4   // wavefronts per SIMD requested for the slice sampler's unmonitored kernels with up to 8 pairs per lane (running sums in registers: 2)
+#endif
 #ifndef KLARA_DT_W1
 #define KLARA_DT_W1 4
 #endif
@@ -382,7 +385,7 @@ __host__ __device__ constexpr int diagt_min_waves()       // wavefronts per SIMD
 #define KLARA_PAIR_CALL(a, b, P, g0, g1) 0.0
 #endif
 template <int SAMPLER, int NP, int Q, bool ONESTEP, bool UNITW, bool MON, bool TUNE = false, bool DA = false, bool USERPAIR = false>
-__global__ __launch_bounds__(256, (diagt_min_waves<SAMPLER, NP, Q, ONESTEP, TUNE>()))
+__global__ __launch_bounds__(256, (SAMPLER == KLARA_SAMPLER_SLICE && NP <= 8 && !MON && !TUNE ? KLARA_DT_SLICE_WF : diagt_min_waves<SAMPLER, NP, Q, ONESTEP, TUNE>()))
 void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
 {
 #ifndef KLARA_USER_PAIR_TARGET
@@ -431,7 +434,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
     const auto wvl = [&](int e) { return UNITW ? 1.0 : *(volatile const double*)&lds_w[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
     const auto mvl = [&](int e) { return UNITW ? 0.0 : *(volatile const double*)&lds_mu[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
     const auto m2wvl = [&](int e) { return UNITW ? -2.0 : *(volatile const double*)&lds_m2w[2 * ((e >> 1) * Q + cx.q) + (e & 1)]; };
-    if (SAMPLER == KLARA_SAMPLER_MH || SLICE) load_pair_param<NP, Q>(cx, p.vecparam, D, 1.0, sig);   // proposal scales / slice widths
+    if (SAMPLER == KLARA_SAMPLER_MH) load_pair_param<NP, Q>(cx, p.vecparam, D, 1.0, sig);   // proposal scales (the slice sampler reads its widths where it uses them)
     const double gconst = USERPAIR ? 0.0 : p.gconst;
 
     // accept draw: slot S = ceil(D/2) = D/2.  (NP-1)*Q < D/2 <= NP*Q, so when the layout has padding (D/2 < NP*Q) the
@@ -556,10 +559,10 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                 // cross-lane traffic until the new state's log-target is formed at the end (one full evaluation in the layout's order).  The
                 // comparison in this difference form is a deliberate deviation from the literal arithmetic, shared with the
                 // oracle for this layout; loops run until every lane of the wavefront is done (__any).
+                // (the loops are short dependent chains between wave-wide votes: the kernel lives on wavefronts per SIMD, so nothing but the value is kept
+                // in registers over the transition — a coordinate's current term is re-formed where its update starts, its width read where it is used)
                 acc = true;
-                double term[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e) { double gd; diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), term[e], gd); }
+                const __amdgpu_buffer_rsrc_t wwid = __builtin_amdgcn_make_buffer_rsrc((void*)p.vecparam, 0, D * 8, 0x00020000);
 #pragma unroll
                 for (int e = 0; e < E; ++e) {                                                  // :65 (the lane's coordinates in ascending order)
                     const int i = 2 * ((e >> 1) * Q + cx.q) + (e & 1);
@@ -568,8 +571,10 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                     const kd_u32x4 b0 = kd_stream_block(p.seed, gchain, t, base);
                     const double lgu = kd_log_u01(kd_uniform_xy(b0));                          // :66 log(rand()); the slice level is lgu + lt
                     const double ru = kd_uniform_zw(b0);                                       // :71
-                    const double xi = x[e], wd = sig[e], tcur = term[e];
                     const double wi_t = UNITW ? 1.0 : wv(e), mi_t = UNITW ? 0.0 : mv(e);
+                    const double xi = x[e], wd = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wwid, (unsigned)(live ? i : 0) * 8u, 0, 0));
+                    double tcur, gd_;
+                    diag_elem<UNITW>(xi, wi_t, -2.0 * wi_t, mi_t, tcur, gd_);
                     double Li = xi - ru * wd;                                                  // :72
                     double Ri = xi + (1.0 - ru) * wd;                                          // :73
                     const auto term_of = [&](double cand) -> double {
@@ -599,7 +604,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                             if (go) { Ri = Rn; dr = dn; }
                         }
                     }
-                    double xprime = xi, tnew = tcur;
+                    double xprime = xi;
                     bool done = !live || stuck;
                     kd_u32x4 ab = b0;                                                          // the block of the current pair of attempts
                     for (uint32_t a = 1;; ++a) {                                               // :91-106
@@ -610,18 +615,18 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                         const double cand = u * (Ri - Li) + Li;                                // :92-93
                         const double tc = term_of(done ? xprime : cand);                       // :94
                         if (!done) {
-                            xprime = cand; tnew = tc;
+                            xprime = cand;
                             if (tcur - tc > lgu) done = true;                                  // :95
                             else if (cand > xi) Ri = cand;                                     // :98
                             else if (cand < xi) Li = cand;                                     // :100
                             else { stuck = true; done = true; }                                // :102
                         }
                     }
-                    if (live && !stuck) { x[e] = xprime; term[e] = tnew; }                     // :108
+                    if (live && !stuck) x[e] = xprime;                                         // :108
                 }
                 red1[0] = 0.0;
 #pragma unroll
-                for (int e = 0; e < E; ++e) red1[0] = red1[0] + term[e];
+                for (int e = 0; e < E; ++e) { double te, gd; diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), te, gd); red1[0] = red1[0] + te; }
                 group_allreduce<1>(red1, Q, cx.lane);
                 lt = gconst - red1[0];                                                         // the new state's log-target: one full evaluation
                 ltp = lt;
