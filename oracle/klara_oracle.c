@@ -935,6 +935,14 @@ void ko_math(int op, int64_t n, const double* in, const double* in2, double* out
 }
 double ko_u52(uint32_t hi, uint32_t lo) { return kd_u52(hi, lo); }
 double ko_u44(uint32_t wa, uint32_t wb) { return kd_u44(wa, wb); }
+/* the slice sampler's draws of coordinate i in transition t: out[0] = log-uniform's uniform, out[1] = runiform, out[2 ..] = the uniforms of shrink attempts 1 .. nattempts */
+void ko_slice_draws(uint64_t seed, uint64_t chain, uint64_t t, uint32_t i, int32_t nattempts, double* out)
+{
+    const uint32_t base = i << KO_SLICE_ATT_BITS;
+    const kd_u32x4 b0 = kd_stream_block(seed, chain, t, base);
+    out[0] = kd_uniform_xy(b0); out[1] = kd_uniform_zw(b0);
+    for (int32_t a = 1; a <= nattempts; ++a) out[1 + a] = kd_slice_attempt_uniform(seed, chain, t, base, (uint32_t)a);
+}
 /* the samplers' form: n word pairs (wa, wb) -> 2n normals */
 void ko_normal_pairs_w(int64_t n, const uint32_t* w, double* out)
 {

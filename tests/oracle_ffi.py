@@ -50,6 +50,7 @@ def load() -> C.CDLL:
     lib.ko_math.argtypes = [C.c_int, C.c_int64, vp, vp, vp]
     lib.ko_u52.argtypes = [C.c_uint32, C.c_uint32]
     lib.ko_u44.argtypes = [C.c_uint32, C.c_uint32]; lib.ko_u44.restype = C.c_double
+    lib.ko_slice_draws.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32, vp]; lib.ko_slice_draws.restype = None
     lib.ko_normal_pairs_w.argtypes = [C.c_int64, vp, vp]; lib.ko_normal_pairs_w.restype = None
     lib.ko_transition_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, vp, vp]; lib.ko_transition_normals.restype = None
     lib.ko_normal_tail.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, vp, vp, vp]

@@ -200,6 +200,28 @@ def test_draw_schedule_of_a_transition():
         assert u[0] == lib.ko_u44(int(byslot[P][0]), int(byslot[P][1]))
 
 
+def test_draw_schedule_of_the_slice_sampler():
+    """Coordinate i of a transition: block slot i << 14 -> (the log-uniform's uniform from words (x, y), runiform from (z, w)); shrink attempt a >= 1: block slot
+    (i << 14) | ((a + 1) >> 1), words (x, y) for odd a and (z, w) for even a — two attempts per block.  Restated in Python against the oracle's draws; no
+    block serves two purposes, and the slots stay inside the 24-bit field for every coordinate the layouts allow (i < 1,024) and every attempt (a < 2^14)."""
+    import ctypes as C
+    lib = O.load()
+    seed, chain, t = 20260927, 77, 4242
+    u52 = lambda hi, lo: ((int(hi) << 20 | int(lo) >> 12) + 0.5) * 2.0 ** -52
+    for i in (0, 1, 99, 511, 1023):
+        n = 9
+        out = np.zeros(2 + n)
+        lib.ko_slice_draws(C.c_uint64(seed), C.c_uint64(chain), C.c_uint64(t), i, n, out.ctypes.data)
+        slots = [i << 14] + [(i << 14) | ((a + 1) >> 1) for a in range(1, n + 1)]
+        assert max(slots) < 1 << 24 and ((i << 14) | ((16383 + 1) >> 1)) < ((i + 1) << 14)
+        blocks = dict(zip(sorted(set(slots)), O.stream_blocks(seed, chain, t, sorted(set(slots)))))
+        b0 = blocks[i << 14]
+        assert out[0] == u52(b0[0], b0[1]) and out[1] == u52(b0[2], b0[3])
+        for a in range(1, n + 1):
+            b = blocks[(i << 14) | ((a + 1) >> 1)]
+            assert out[1 + a] == (u52(b[0], b[1]) if a & 1 else u52(b[2], b[3])), (i, a)
+
+
 def test_normal_tail_mass_on_the_host():
     """Tail mass of the generator as the kernels call it (stream blocks of consecutive chains / transitions): 4 x 10^7 draws,
     counts of |z| > 1, 2, 3, 4 within 4.5 binomial standard deviations of the normal law, second and fourth moments 1 and 3."""
