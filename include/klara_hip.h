@@ -408,6 +408,14 @@ klara_status klara_selftest_normal_tail(int32_t device, uint64_t seed, uint64_t 
                                         int64_t ntransitions, int32_t nthr, const double* thr, uint64_t* counts,
                                         double* moments);
 
+/* Self-test hook: the D proposal normals of transition `transition` of chains first_chain .. first_chain + nchains - 1 exactly as the samplers draw
+ * them (kd_normal_pair_at: element pair p <- half (p >> 3) & 1 of block slot (p & 7) + 8 (p >> 4)), z[nchains x ndims] row-major, and the
+ * transition's accept uniform (block slot ceil(ndims / 2)), accept_u[nchains] (may be NULL).  The joint-law tests of the stream — chi-square of
+ * a transition's sum z^2, independence of the two pairs that share a block and of a pair's radius and angle bits — run on this output, and
+ * the CPU build of the same generator (oracle ko_transition_normals) must return the same bits. */
+klara_status klara_selftest_transition_normals(int32_t device, uint64_t seed, uint64_t first_chain, int64_t nchains,
+                                               uint64_t transition, int32_t ndims, double* z, double* accept_u);
+
 /* Self-test hook: D(16x16) = A(16x4) * B(4x16) + C(16x16), all row-major, through ONE
  * v_mfma_f64_16x16x4_f64 — pins the instruction's accumulation order for the dense-target parity. */
 klara_status klara_selftest_mfma_f64(int32_t device, const double* A, const double* B, const double* C,

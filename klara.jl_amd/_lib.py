@@ -75,7 +75,7 @@ EXPORTS = [
     "klara_run_async", "klara_synchronize", "klara_reset", "klara_stream_key", "klara_get_state", "klara_get_accept_mask", "klara_get_accept_rows",
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
     "klara_get_chain_fields", "klara_get_chain_likelihood_prior", "klara_get_chain_mcvar", "klara_get_chain_mcvar_ipse", "klara_get_chain_acov_mcvar", "klara_saved_steps", "klara_get_chain_bm", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout", "klara_get_launch_modes", "klara_get_kernel_attributes", "klara_get_shader_clock",
-    "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_normal_tail", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
+    "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_normal_tail", "klara_selftest_transition_normals", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
     "klara_comm_unique_id", "klara_comm_init", "klara_comm_destroy", "klara_gather_summaries", "klara_gather_moments",
     "klara_check_custom_target", "klara_compile_log", "klara_selftest_plan", "klara_selftest_canary", "klara_abi_version",
 ]
@@ -127,6 +127,7 @@ def load() -> C.CDLL:
         "klara_selftest_rocrand_blocks": [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p],
         "klara_selftest_math": [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_selftest_normal_tail": [C.c_int32, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+        "klara_selftest_transition_normals": [C.c_int32, C.c_uint64, C.c_uint64, C.c_int64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p],
         "klara_selftest_mfma_f64": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_selftest_mfma_f64_4x4x4": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_comm_unique_id": [C.c_void_p],
@@ -157,11 +158,17 @@ def load() -> C.CDLL:
     lib.klara_compile_log.restype = C.c_char_p
     lib.klara_abi_version.argtypes = []
     lib.klara_abi_version.restype = C.c_int32
-    if lib.klara_abi_version() != KLARA_ABI_VERSION:
-        if "KLARA_HIP_LIB" not in os.environ or lib.klara_abi_version() < 3:
-            raise RuntimeError("libklara_hip.so ABI version mismatch")
-        # same-box A/B against an older build: klara_desc has not changed since version 3, the older library only lacks entry points
-        globals()["KLARA_ABI_VERSION"] = int(lib.klara_abi_version())
+    got = int(lib.klara_abi_version())
+    if got != KLARA_ABI_VERSION:
+        # An older build differs in its random stream (and, before version 4, in what klara_desc.sparse_moves = 0 means), so it is never
+        # accepted silently: only the same-box A/B scripts ask for it (KLARA_HIP_LIB=<older build> KLARA_ALLOW_ABI_MISMATCH=1), and only
+        # for versions whose klara_desc layout this binding can fill (3 .. current).
+        if os.environ.get("KLARA_ALLOW_ABI_MISMATCH") != "1" or "KLARA_HIP_LIB" not in os.environ or not (3 <= got <= KLARA_ABI_VERSION):
+            raise RuntimeError(f"libklara_hip.so ABI version mismatch: library {got}, binding {KLARA_ABI_VERSION}")
+        import warnings
+        warnings.warn(f"{path}: ABI version {got} (binding {KLARA_ABI_VERSION}) accepted because KLARA_ALLOW_ABI_MISMATCH=1 — "
+                      "its random stream and launch defaults differ from this version's", RuntimeWarning)
+        lib._klara_abi_override = got          # descriptors for THIS library carry its own version (klara_create checks it)
     _lib = lib
     return lib
 

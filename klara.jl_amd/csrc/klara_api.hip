@@ -2236,6 +2236,49 @@ extern "C" klara_status klara_selftest_normal_tail(int32_t device, uint64_t seed
     return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
 }
 
+// the normals of one transition as the samplers draw them: one thread per (chain, element pair)
+__global__ __launch_bounds__(256) void k_transition_normals(unsigned long long seed, unsigned long long first_chain, long long nchains,
+                                                            unsigned long long t, int D, double* __restrict__ z, double* __restrict__ accept_u)
+{
+    kd_tables_to_lds();
+    const int npairs = (D + 1) / 2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < nchains * (long long)(npairs + 1);
+    const long long c = ok ? i / (npairs + 1) : 0;
+    const int p = ok ? (int)(i % (npairs + 1)) : 0;
+    const unsigned long long chain = first_chain + (unsigned long long)c;
+    if (p < npairs) {
+        double z0, z1, u1, lg;
+        kd_normal_pair_at(seed, chain, t, (uint32_t)p, (uint32_t)npairs, &z0, &z1, &u1, &lg);
+        if (ok) {
+            z[c * D + 2 * p] = z0;
+            if (2 * p + 1 < D) z[c * D + 2 * p + 1] = z1;
+        }
+    } else if (ok && accept_u != nullptr) {
+        accept_u[c] = kd_accept_uniform(kd_stream_block(seed, chain, t, (uint32_t)npairs));
+    }
+}
+
+extern "C" klara_status klara_selftest_transition_normals(int32_t device, uint64_t seed, uint64_t first_chain, int64_t nchains,
+                                                          uint64_t transition, int32_t ndims, double* z, double* accept_u)
+{
+    if (!z || nchains <= 0 || ndims <= 0 || ndims > 4096) return KLARA_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(device));
+    double* dz = nullptr; double* du = nullptr;
+    hipError_t e = dalloc(&dz, (size_t)nchains * (size_t)ndims);
+    if (e == hipSuccess) e = dalloc(&du, (size_t)nchains);
+    if (e == hipSuccess) {
+        const long long nthreads = (long long)nchains * ((ndims + 1) / 2 + 1);
+        hipLaunchKernelGGL(k_transition_normals, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, 0, (unsigned long long)seed,
+                           (unsigned long long)first_chain, (long long)nchains, (unsigned long long)transition, (int)ndims, dz, du);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(z, dz, sizeof(double) * (size_t)nchains * (size_t)ndims, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && accept_u) e = hipMemcpy(accept_u, du, sizeof(double) * (size_t)nchains, hipMemcpyDeviceToHost);
+    (void)dfree(dz); (void)dfree(du);
+    return e == hipSuccess ? KLARA_OK : KLARA_ERR_HIP;
+}
+
 extern "C" klara_status klara_selftest_mfma_f64(int32_t device, const double* A, const double* B,
                                                 const double* C, double* D)
 {

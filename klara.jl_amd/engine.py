@@ -221,7 +221,7 @@ class Engine:
         self.monitor = int(monitor)
         d = L.KlaraDesc()
         d.struct_size = C.sizeof(L.KlaraDesc)
-        d.abi_version = L.KLARA_ABI_VERSION
+        d.abi_version = getattr(L.load(), "_klara_abi_override", L.KLARA_ABI_VERSION)   # (an older build under KLARA_ALLOW_ABI_MISMATCH=1: its own version)
         d.sampler, d.target, d.tuner, d.tuner_mode = int(sampler), int(target.kind), int(tuner), int(tuner_mode)
         d.nchains, d.chain_offset, d.ndims, d.device = self.nchains, int(chain_offset), self.ndims, int(device)
         keep = []  # keep host arrays alive until klara_create returns
