@@ -32,8 +32,17 @@
 extern "C" {
 #endif
 
-#define KLARA_ABI_VERSION 5   /* 5: the random stream changed — one Philox block makes four normals, 44-bit accept uniform (same symbols and structs as 4,
-                                 but a given seed draws different chains than a version-4 library); 4: klara_gather_moments, klara_desc.sparse_moves 0 = device-decided */
+#define KLARA_ABI_VERSION 6   /* 6: Box-Muller angles at the centres of their 2^20 cells (version 5 used the left edges, which put mass 2^-19 of every
+                                 normal on the coordinate axes), klara_selftest_transition_normals; same structs as 4 and 5, but a given seed draws
+                                 different chains than a version-5 library.  5: one Philox block makes four normals, 44-bit accept uniform.
+                                 4: klara_gather_moments, klara_desc.sparse_moves 0 = device-decided */
+/* THE RANDOM STREAM IS FROZEN AT VERSION 6.  What a (seed, chain, transition) draws — the counter layout (detmath.h kd_stream_block), the
+ * pair -> block-half map (kd_pair_block / kd_pair_half), the 44-bit radius / 20-bit centred angle Box-Muller (kd_normal_pair_w), the accept
+ * uniform's slot ceil(D/2) and the slice sampler's slots (kd_slice_attempt_slot) — is pinned by known-answer values committed under
+ * tests/golden/stream_kat.json (host build, device build and the independent NumPy restatement must all reproduce them), and the HIP
+ * path is tied to the LITERAL Julia arithmetic and to the NumPy mirror on every accept decision at the BASELINE sizes
+ * (tests/test_gpu_literal.py), with the joint law of a transition's normals tested in tests/test_stream_joint.py.  A change to the draw
+ * schedule, to detmath.h's transforms or to the oracle's arithmetic needs those three green BEFORE and AFTER, and a new version number. */
 /* klara_desc.steps_per_launch = 0 selects this many transitions per kernel launch (launches also end at the pooled tuner's
  * events and at batch boundaries of the streaming batch means, whichever comes first) */
 #define KLARA_DEFAULT_STEPS_PER_LAUNCH 32

@@ -43,7 +43,7 @@ else
 end
 
 # ---------------------------------------------------------------- constants of include/klara_hip.h
-const KLARA_ABI_VERSION = UInt32(5)
+const KLARA_ABI_VERSION = UInt32(6)
 const SAMPLER_MH, SAMPLER_MALA, SAMPLER_HMC, SAMPLER_SLICE = Int32(0), Int32(1), Int32(2), Int32(3)
 const TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET_HIER_NORMAL, TARGET_CUSTOM = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)
 const TUNER_VANILLA, TUNER_ACCEPT_RATE, TUNER_DUAL_AVERAGING = Int32(0), Int32(1), Int32(2)

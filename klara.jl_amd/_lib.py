@@ -13,7 +13,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libklara_hip.so"
 
-KLARA_ABI_VERSION = 5
+KLARA_ABI_VERSION = 6
 DEFAULT_STEPS_PER_LAUNCH = 32     # KLARA_DEFAULT_STEPS_PER_LAUNCH
 LOGIT_MAX_LDS_DOUBLES = 18432     # KLARA_LOGIT_MAX_LDS_DOUBLES
 

@@ -19,7 +19,7 @@
  *   kd_log             FreeBSD-msun-style log (<1 ulp), every special case; kd_exp: 128-entry table, division-free (<1 ulp).
  *   kd_log_u01         table-driven, division-free log for the uniforms (radius and Metropolis tests).
  *   kd_sincos2pi       sin(2*pi*u), cos(2*pi*u) for u in [0,1): 256-entry table + rotation.
- *   kd_normal_pair_w   Box-Muller on 64 bits: half a Philox block -> two N(0,1) doubles (44-bit radius uniform, 20-bit angle);
+ *   kd_normal_pair_w   Box-Muller on 64 bits: half a Philox block -> two N(0,1) doubles (44-bit radius uniform, 20-bit angle at cell centres);
  *                      kd_normal_pair_at: the proposal normals of element pair p — one block serves pairs p and p + 8.
  *
  * This header is NOT a restatement of any reference file; the samplers' arithmetic is written
@@ -549,16 +549,20 @@ KD_FN double kd_sqrt_radicand(double y)
  * A Philox block carries two such pairs, so the 41 vector instructions of a block are paid once per FOUR normals (rounds 1-3 spent a
  * whole block on a pair: 52-bit u1 and u2).  The lattice underneath:
  *   radius  u1 = kd_u44(wa, wb)            44 bits: u1 >= 2^-45, |z| <= 7.9 (the mass beyond is 3e-15 per draw)
- *   angle   u2 = (wb >> 12) 2^-20 + 2^-53  20 bits: 2^20 equally spaced directions; the marginal of rad cos / rad sin over an equally
- *                                          spaced set of directions is the rectangle rule on a periodic analytic integrand — exact to
- *                                          rounding; jointly (z0, z1) lie on 2^20 rays with a 44-bit radius along each
+ *   angle   u2 = ((wb >> 12) + 1/2) 2^-20 + 2^-53   20 bits: 2^20 equally spaced directions, the CENTRES of the cells — no direction lies on a
+ *                                          coordinate axis (ABI 5 used the cells' left edges: k = 0, 2^18, 2^19, 3 2^18 put mass 2^-19 of
+ *                                          every normal within 1e-16 of zero; tests/test_stream_joint.py counts |z| < 1e-9).
+ *                                          The marginal of rad cos / rad sin over an equally spaced set of directions is the rectangle
+ *                                          rule on a periodic analytic integrand — exact to rounding for smooth test functions; jointly
+ *                                          (z0, z1) lie on 2^20 rays with a 44-bit radius along each, so indicator-type statistics see the
+ *                                          lattice at the 2^-20 level (the spacing of neighbouring rays at radius r is 6e-6 r)
  * (u1, log u1) are handed back: a layout's padding pair at index ceil(D/2) is the accept draw (kd_accept_uniform) for free. */
-KD_FN uint64_t kd_angle_bits20(uint32_t wb)
+KD_FN uint64_t kd_angle_bits20(uint32_t wb)              /* bits of 1 + (k + 1/2) 2^-20: the half cell is bit 31 of the low word, a constant */
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (uint64_t)__builtin_amdgcn_alignbit(0x3ffu, wb, 12) << 32;
+    return ((uint64_t)__builtin_amdgcn_alignbit(0x3ffu, wb, 12) << 32) | 0x80000000ull;
 #else
-    return (uint64_t)(0x3ff00000u | (wb >> 12)) << 32;
+    return ((uint64_t)(0x3ff00000u | (wb >> 12)) << 32) | 0x80000000ull;
 #endif
 }
 KD_FN void kd_normal_pair_w(uint32_t wa, uint32_t wb, double* z0, double* z1, double* u1_out, double* logu1_out)

@@ -51,13 +51,13 @@ def u44(wa, wb):
 def normals(seed, chain, t, D):
     """z[i], i < D: element pair p = i >> 1 takes 64 bits of the transition's stream — half (p >> 3) & 1 of block slot
     (p & 7) + 8 (p >> 4), so pairs p and p + 8 share a Philox block — and Box-Muller on a 44-bit radius uniform and a 20-bit
-    angle ((wb >> 12) 2^-20 + 2^-53 turns); cosine half for even i, sine half for odd i"""
+    angle (((wb >> 12) + 1/2) 2^-20 + 2^-53 turns: the centre of one of 2^20 cells); cosine half for even i, sine half for odd i"""
     z = np.empty(D)
     for p in range((D + 1) // 2):
         blk = stream_block(seed, chain, t, (p & 7) + 8 * (p >> 4))
         wa, wb = (blk[2], blk[3]) if (p >> 3) & 1 else (blk[0], blk[1])
         r = math.sqrt(-2.0 * math.log(u44(wa, wb)))
-        a = 2.0 * math.pi * ((wb >> 12) * 2.0 ** -20 + 2.0 ** -53)
+        a = 2.0 * math.pi * (((wb >> 12) + 0.5) * 2.0 ** -20 + 2.0 ** -53)
         z[2 * p] = r * math.cos(a)
         if 2 * p + 1 < D:
             z[2 * p + 1] = r * math.sin(a)

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(klib):
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(klib, name), name
-    assert klib.klara_abi_version() == L.KLARA_ABI_VERSION == 5
+    assert klib.klara_abi_version() == L.KLARA_ABI_VERSION == 6
 
 
 def test_desc_struct_matches_header_layout():

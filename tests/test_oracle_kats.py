@@ -137,11 +137,11 @@ def _words_from_mantissas(m44, j20):
 
 def test_normal_pair_against_independent_high_precision_box_muller():
     """kd_normal_pair_w (detmath.h: the one source of normals on the device AND in the oracle) against an independent evaluation of the
-    same definition from the same words: u1 = (2 m + 1) 2^-45 (m: 44 bits), u2 = j 2^-20 + 2^-53 (j: 20 bits),
+    same definition from the same words: u1 = (2 m + 1) 2^-45 (m: 44 bits), u2 = (j + 1/2) 2^-20 + 2^-53 (j: 20 bits; cell centres),
     z0 = sqrt(-2 ln u1) cos(2 pi u2), z1 = sqrt(-2 ln u1) sin(2 pi u2) in mpmath at 160 bits — 100,000 random word pairs plus the
     extreme points of the lattice (smallest / largest radius uniform, directions at and next to every multiple of pi/2).
 
-    Bound: |z - exact| <= 2.5 ulp(radius).  ulp(z) is the wrong yardstick next to the zeros of sin / cos: kd_sincos2pi is accurate to
+    Bound: |z - exact| <= 3 ulp(radius) (worst of the sample: 2.54).  ulp(z) is the wrong yardstick next to the zeros of sin / cos: kd_sincos2pi is accurate to
     2^-52 ABSOLUTE, so where |cos| ~ 1e-15 the product is off by a few 1e-16 — 30 % of a value that is itself 1e-15 of a standard
     deviation.  Where the trigonometric factor is >= 1/2 in magnitude the error is also asserted in ulps of z itself (<= 4.5: two
     binades of radius ulps)."""
@@ -160,7 +160,7 @@ def test_normal_pair_against_independent_high_precision_box_muller():
     with mp.workprec(160):
         two45, two20, two53, twopi = mp.mpf(2) ** -45, mp.mpf(2) ** -20, mp.mpf(2) ** -53, 2 * mp.pi
         for i in range(w.shape[0]):
-            u1 = (2 * int(m1[i]) + 1) * two45; u2 = int(j2[i]) * two20 + two53
+            u1 = (2 * int(m1[i]) + 1) * two45; u2 = (int(j2[i]) + mp.mpf(1) / 2) * two20 + two53
             rad = mp.sqrt(-2 * mp.log(u1)); a = twopi * u2
             ulp_rad = mp.mpf(float(np.spacing(float(rad))))
             for h, trig in ((0, mp.cos(a)), (1, mp.sin(a))):
@@ -168,10 +168,10 @@ def test_normal_pair_against_independent_high_precision_box_muller():
                 worst_rad = max(worst_rad, float(err / ulp_rad))
                 if abs(trig) >= 0.5:
                     worst_z = max(worst_z, float(err / mp.mpf(float(np.spacing(abs(float(rad * trig)))))))
-    assert worst_rad <= 2.5, worst_rad
+    assert worst_rad <= 3.0, worst_rad
     assert worst_z <= 4.5, worst_z
-    # the largest normal the generator can produce: u1 = 2^-45 -> sqrt(2 * 45 ln 2) = 7.898...
-    assert abs(np.abs(out[n:]).max() - math.sqrt(90 * math.log(2))) < 1e-13
+    # the largest normal the generator can produce: u1 = 2^-45 -> sqrt(2 * 45 ln 2) = 7.898... along the direction nearest an axis (half a cell off it)
+    assert abs(np.abs(out[n:]).max() - math.sqrt(90 * math.log(2)) * math.cos(2 * math.pi * (2.0 ** -21 + 2.0 ** -53))) < 1e-13
     # the accept uniform is the radius uniform of words (x, y): never 0, never 1, log above the kernels' skip guard (-31.2)
     assert O.load().ko_u44(0, 0) == 2.0 ** -45 and O.load().ko_u44(0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -45
     assert O.math_op(7, np.array([2.0 ** -45]))[0] > -31.2

@@ -125,3 +125,50 @@ def test_joint_law_of_a_transitions_normals_on_the_device(klib, gpu_required):
     print(rep)
     # P(|z| < 1e-9) = 8e-10 per draw: 0.08 expected among 1.05e8; an axis-aligned direction lattice would put ~400 there
     assert rep["near_zero"] <= 2, rep
+
+
+# ------------------------------------------------------------------ the frozen stream's known answers (tests/golden/stream_kat.json)
+def _kat():
+    import json
+    from pathlib import Path
+    doc = json.loads((Path(__file__).resolve().parent / "golden" / "stream_kat.json").read_text())
+    assert doc["abi_version"] == L.KLARA_ABI_VERSION, "the stream is frozen: the known answers change only together with KLARA_ABI_VERSION (include/klara_hip.h)"
+    return doc["entries"]
+
+
+def test_frozen_stream_known_answers_host_build_and_numpy_restatement():
+    """The host build of detmath.h reproduces every committed value bit for bit; the independent NumPy restatement (own Philox, libm log / sqrt /
+    cos / sin) reproduces the blocks and the uniforms exactly and the normals to 1e-13."""
+    import numpy_mirror as M
+    lib = O.load()
+    for e in _kat():
+        seed, chain, t = e["seed"], e["chain"], e["transition"]
+        assert [int(v) for v in O.stream_blocks(seed, chain, t, [0])[0]] == e["block_slot0"] == list(M.stream_block(seed, chain, t, 0))
+        for d in (100, 7):
+            z = np.empty(d); u = C.c_double(0.0)
+            lib.ko_transition_normals(seed, chain, t, d, z.ctypes.data, C.byref(u))
+            want = np.array([float.fromhex(v) for v in e[f"normals_d{d}"]])
+            assert np.array_equal(z, want), (seed, chain, t, d)
+            assert u.value == float.fromhex(e[f"accept_uniform_d{d}"]) == M.accept_uniform(seed, chain, t, d)
+            assert np.max(np.abs(M.normals(seed, chain, t, d) - want)) < 1e-13
+        for i in (0, 99):
+            out = np.empty(8)
+            lib.ko_slice_draws(seed, chain, t, i, 6, out.ctypes.data)
+            want = [float.fromhex(v) for v in e[f"slice_draws_coord{i}"]]
+            assert list(out) == want
+            b0 = M.stream_block(seed, chain, t, i << 14)
+            assert [M.u52(b0[0], b0[1]), M.u52(b0[2], b0[3])] == want[:2]
+            for a in range(1, 7):
+                bb = M.stream_block(seed, chain, t, (i << 14) | ((a + 1) >> 1))
+                assert (M.u52(bb[0], bb[1]) if a & 1 else M.u52(bb[2], bb[3])) == want[1 + a]
+
+
+@pytest.mark.gpu
+def test_frozen_stream_known_answers_device_build(klib, gpu_required):
+    """The device build reproduces the committed normals and accept uniforms bit for bit."""
+    for e in _kat():
+        for d in (100, 7):
+            z = np.empty((1, d)); u = np.empty(1)
+            L.check(klib.klara_selftest_transition_normals(0, e["seed"], e["chain"], 1, e["transition"], d, z.ctypes.data, u.ctypes.data), "kat")
+            assert np.array_equal(z[0], np.array([float.fromhex(v) for v in e[f"normals_d{d}"]])), (e["seed"], e["chain"], d)
+            assert u[0] == float.fromhex(e[f"accept_uniform_d{d}"])
