@@ -46,6 +46,9 @@ extern "C" {
 /* klara_desc.steps_per_launch = 0 selects this many transitions per kernel launch (launches also end at the pooled tuner's
  * events and at batch boundaries of the streaming batch means, whichever comes first) */
 #define KLARA_DEFAULT_STEPS_PER_LAUNCH 32
+/* ... and for slice-sampler jobs on a diagonal Gaussian whose monitors are the accept diagnostics and / or the running sums (the kernel whose lanes
+ * run out of lockstep, klara.jl_amd/csrc/klara_diagt_slice.h: a wavefront waits for its slowest lane once per element slot and launch) */
+#define KLARA_DEFAULT_STEPS_PER_LAUNCH_SLICE 128
 #define KLARA_LOGIT_MAX_LDS_DOUBLES 18432u   /* 144 KB of the 160 KB of LDS of a compute unit */
 
 typedef enum klara_status {

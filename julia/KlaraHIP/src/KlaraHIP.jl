@@ -3,11 +3,17 @@
 # Package layout: julia/KlaraHIP/{REQUIRE, src/KlaraHIP.jl, test/runtests.jl}; put julia/ on LOAD_PATH (or Pkg.clone the directory).
 #
 #     using Klara, KlaraHIP
-#     p      = HIPParameter(:p, GaussDiagTarget(100))                     # device form of BasicContMuvParameter(:p, logtarget=...)
-#     job    = HIPMCJob(p, MALA(0.9), BasicMCRange(nsteps=10000, burnin=1000), Dict(:p => randn(100, 65536));
+#     plogtarget = GaussDiagTarget(2)                                     # README.md:23 `plogtarget(z) = -dot(z, z)` as a device target family
+#     p      = HIPParameter(:p, logtarget=plogtarget)                     # README.md:30  BasicContMuvParameter(:p, logtarget=plogtarget)
+#     model  = likelihood_model(p, false)                                 # README.md:35  unchanged: HIPParameter <: Klara.Parameter{Continuous, Multivariate}
+#     job    = HIPMCJob(model, MH(ones(2)), BasicMCRange(nsteps=10000, burnin=1000), Dict(:p => [5.1, -0.9]))     # README.md:39-51 BasicMCJob(model, sampler, mcrange, v0)
+#     run(job); chain = output(job); mean(chain); acceptance(chain)      # README.md:55-59 unchanged
+#     reset(job); run(job)                                                # an independent replicate (BasicMCJob.jl:187-201)
+#
+# Many chains of one model — what the device is for — are the same call with `nchains` (v0's vector is every chain's start) or a D x N matrix of starts:
+#     job    = HIPMCJob(model, MALA(0.9), BasicMCRange(nsteps=10000, burnin=1000), Dict(:p => randn(100, 65536));
 #                       tuner=VanillaMCTuner(), outopts=Dict(:monitor => [:value], :diagnostics => [:accept]))
 #     run(job); chain = output(job, 1); mean(chain); acceptance(chain)
-#     reset(job); run(job)                                                # an independent replicate (BasicMCJob.jl:187-201)
 #
 # `run`, `reset` (Base generics Klara extends: src/Klara.jl:26-27) and `output` (Klara's own, exported at src/Klara.jl:232) are
 # IMPORTED before the methods below are defined, so `run(job)`, `reset(job[, x])`, `output(job[, c])` on an HIPMCJob are methods
@@ -24,8 +30,10 @@
 module KlaraHIP
 import Klara
 import Klara: output, MCJob, MH, MALA, HMC, SliceSampler, VanillaMCTuner, AcceptanceRateMCTuner, DualAveragingMCTuner,
-              BasicContMuvParameterState, BasicContMuvParameterNState, erf_rate_score, logistic_rate_score
+              BasicContMuvParameterState, BasicContMuvParameterNState, erf_rate_score, logistic_rate_score,
+              Parameter, GenericModel, VariableState, VariableStateVector
 import Distributions
+import Distributions: Continuous, Multivariate
 import Base: run, reset, show
 export HIPMCJob, HIPParameter, HIPTarget, GaussDiagTarget, GaussDenseTarget, LogisticTarget, HierNormalTarget, CustomTarget,
        chainvalue, chainmeans, chainacceptance, chainmcvar_bm, streamkey, launchmodes, shaderclock, check_custom_target,
@@ -132,11 +140,20 @@ ndims_of(t::LogisticTarget) = size(t.X, 2)
 ndims_of(t::HierNormalTarget) = 2 * size(t.Y, 1) + 5
 ndims_of(t::CustomTarget) = t.ndims
 
-# BasicContMuvParameter(:p, ...) stand-in: the key routes v0[key] as in BasicMCJob.jl:156-185
-struct HIPParameter
+# The device form of BasicContMuvParameter (variables/parameters/BasicContMuvParameter.jl:3-28): a Klara.Parameter{Continuous, Multivariate}
+# with the fields a GenericModel reads and writes — `key` (GenericModel.jl:44 `m.ofkey[v.key] = n`), `index` (assigned by
+# likelihood_model(p, false): GenericModel.jl:110-113 `m.vertices[i].index = i`, hence mutable) and `states` (BasicContMuvParameter.jl:27) — and, in place
+# of the closure fields, the device target family.  `likelihood_model(p, false)` (models/generators.jl:20) therefore works on it unchanged.
+mutable struct HIPParameter <: Parameter{Continuous, Multivariate}
     key::Symbol
+    index::Integer
     target::HIPTarget
+    states::VariableStateVector
 end
+HIPParameter(key::Symbol, target::HIPTarget; index::Integer=0, states::VariableStateVector=VariableState[]) = HIPParameter(key, index, target, states)
+# keyword form, mirroring BasicContMuvParameter(key; logtarget=...) (BasicContMuvParameter.jl:383-411): the "closure" is a device target
+HIPParameter(key::Symbol; logtarget::HIPTarget=error("HIPParameter: logtarget=<a device target family, e.g. GaussDiagTarget(D)> is required"),
+             index::Integer=0, states::VariableStateVector=VariableState[]) = HIPParameter(key, index, logtarget, states)
 
 # ---------------------------------------------------------------- the job
 mutable struct HIPMCJob <: MCJob   # stands for N BasicMCJobs of one model (run(jobs::Vector) = map(run, jobs), jobs.jl:212)
@@ -157,11 +174,38 @@ rowmajor(A::Matrix{Float64}) = collect(transpose(A))       # Julia is column-maj
 #   AcceptanceRateMCTuner.targetrate, .score, .period, .verbose          tuners/AcceptanceRateMCTuner.jl:25-44
 #   DualAveragingMCTuner.targetrate, .nadapt, .ε0bar, .h0bar, .γ, .t0, .κ, .period, .verbose   tuners/DualAveragingMCTuner.jl:54-93
 #   BasicMCRange.burnin, .thinning, .nsteps, .postrange, .npoststeps     ranges/BasicMCRange.jl:7-36
+# v0[key]: a D x N matrix of starts (column = chain), or one vector — BasicMCJob's form (README.md:47 `Dict(:p=>[5.1, -0.9])`) — that every one of
+# `nchains` chains starts from
+startmatrix(x::Matrix{Float64}, nchains::Integer) = x
+function startmatrix(x::AbstractVector, nchains::Integer)
+    X = newarray(Float64, length(x), Int(nchains))
+    for j in 1:Int(nchains), i in 1:length(x)
+        X[i, j] = x[i]
+    end
+    X
+end
+startmatrix(x, nchains::Integer) = convert(Matrix{Float64}, x)
+
+# BasicMCJob(model, sampler, range, v0; tuner, outopts) (jobs/BasicMCJob.jl:140-185): the parameter is the model's first Parameter vertex
+# (`pindex`, :144) and v0 is keyed by the variables' keys (:156-158)
+function firstparameter(vs)               # BasicMCJob.jl:144 `findfirst(v -> isa(v, Parameter), model.vertices)` (findfirst's "none" differs between 0.6 and 0.7)
+    for i in 1:length(vs)
+        isa(vs[i], Parameter) && return i
+    end
+    error("the model has no Parameter vertex")
+end
+function HIPMCJob(model::GenericModel, sampler, mcrange, v0::Dict;
+                  pindex::Integer=firstparameter(model.vertices), kwargs...)
+    parameter = model.vertices[pindex]
+    isa(parameter, HIPParameter) || error("the model's parameter must be a HIPParameter (a device target family), got $(typeof(parameter))")
+    HIPMCJob(parameter, sampler, mcrange, v0; kwargs...)
+end
+
 function HIPMCJob(parameter::HIPParameter, sampler, mcrange, v0::Dict;
-                  tuner=nothing, outopts::Dict=Dict{Symbol, Any}(), pooled::Bool=false,
+                  tuner=nothing, outopts::Dict=Dict{Symbol, Any}(), pooled::Bool=false, nchains::Integer=1,
                   seed::Integer=rand(UInt64), chain_offset::Integer=0, device::Integer=0, steps_per_launch::Integer=0,
                   summaries::Bool=true, bm_batchlen::Integer=0)
-    X0 = convert(Matrix{Float64}, v0[parameter.key])                      # D x N: column = chain == N x D row-major
+    X0 = startmatrix(v0[parameter.key], nchains)                          # D x N: column = chain == N x D row-major
     D, N = size(X0)
     t = parameter.target
     D == ndims_of(t) || error("v0 has the wrong number of dimensions for the target")
@@ -275,8 +319,10 @@ run(job::HIPMCJob) =                                     # BasicMCJob.jl:212-244
 
 reset(job::HIPMCJob) =                                   # BasicMCJob.jl:187-195; the job moves to its next Philox key (klara_hip.h)
     check(ccall((:klara_reset, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), job.handle, C_NULL), "klara_reset")
-reset(job::HIPMCJob, X::Matrix{Float64}) =
+reset(job::HIPMCJob, X::Matrix{Float64}) =               # BasicMCJob.jl:197-201 reset(job, x): new initial values (D x N, one column per chain)
     check(ccall((:klara_reset, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), job.handle, X), "klara_reset")
+reset(job::HIPMCJob, x::AbstractVector) =                # README.md:68 `reset(job, [3.2, 9.4])`: every chain restarts from x
+    reset(job, startmatrix(x, job.nchains))
 
 function show(io::IO, job::HIPMCJob)                     # BasicMCJob.jl:281-295 prints parameter, model, sampler, tuner, range
     println(io, "HIPMCJob: ", job.nchains, " chains of ", job.ndims, " dimensions on libklara_hip")

@@ -6,6 +6,29 @@
 using Klara, KlaraHIP
 using Base.Test
 
+# --- the reference's README script (README.md:17-59) with its constructors swapped: BasicContMuvParameter -> HIPParameter, BasicMCJob -> HIPMCJob;
+# the log-target closure becomes the device target family that states the same function
+plogtarget = GaussDiagTarget(2)                       # README.md:23  plogtarget(z::Vector{Float64}) = -dot(z, z)
+p = HIPParameter(:p, logtarget=plogtarget)            # README.md:30
+@test isa(p, Klara.Parameter) && isa(p, Klara.ContinuousParameter) && isa(p, Klara.MultivariateParameter)
+model = likelihood_model(p, false)                    # README.md:35 (Klara's own generator: assigns p.index)
+@test p.index == 1 && model[:p] === p
+sampler = MH(ones(2))                                 # README.md:39
+mcrange = BasicMCRange(nsteps=10000, burnin=1000)     # README.md:43
+v0 = Dict(:p=>[5.1, -0.9])                            # README.md:47
+job = HIPMCJob(model, sampler, mcrange, v0)           # README.md:51
+run(job)                                              # README.md:55
+chain = output(job)                                   # README.md:59
+@test isa(chain, BasicContMuvParameterNState) && size(chain.value) == (2, 9000)
+@test maximum(abs.(mean(chain))) < 0.15
+reset(job, [3.2, 9.4])                                # README.md:71
+run(job)
+@test output(job).value != chain.value
+many = HIPMCJob(model, sampler, mcrange, v0; nchains=4096, seed=7)      # the same job as 4,096 replicas from the same start
+run(many)
+m, v, ns, na, nt, nc = pooledmoments(many)
+@test nc == 4096 && maximum(abs.(m)) < 5e-3 && maximum(abs.(v .- 0.5)) < 5e-3
+
 D, N = 100, 4096
 p   = HIPParameter(:p, GaussDiagTarget(D))
 job = HIPMCJob(p, MALA(0.1), BasicMCRange(nsteps=2000, burnin=1000), Dict(:p => randn(D, N));

@@ -115,6 +115,17 @@ static bool diagt_eligible(const klara_desc& d)
     return true;
 }
 
+// the slice sampler on the pair-transposed layout with nothing counting and no history kept: every lane takes its elements through a whole launch on
+// its own (klara_diagt_slice.h); a wavefront only waits for its slowest lane once per element slot and launch, so longer launches waste less
+static bool slice_free_eligible(const klara_desc& d)
+{
+    static const bool lockstep = getenv("KLARA_SLICE_LOCKSTEP") != nullptr;
+    return diagt_eligible(d) && d.sampler == KLARA_SAMPLER_SLICE && !cnt_predicate(d) && d.acov_maxlag == 0 && !lockstep &&
+           (d.monitor & ~(uint32_t)(KLARA_MON_ACCEPT | KLARA_MON_SUMMARIES)) == 0;
+}
+// transitions per launch when klara_desc.steps_per_launch = 0
+static long long default_steps_per_launch(const klara_desc& d) { return slice_free_eligible(d) ? KLARA_DEFAULT_STEPS_PER_LAUNCH_SLICE : KLARA_DEFAULT_STEPS_PER_LAUNCH; }
+
 // untuned MH / MALA on the pair-transposed layout up to D = 104: 4 lanes per chain, 16 chains per wavefront, NP = ceil(D/8) in 3..13
 // (klara_launch.h) — kernels that keep no resident running sums (a moving chain's sums are folded into memory by atomic adds)
 static bool q4_eligible(const klara_desc& d)
@@ -993,6 +1004,8 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
         const bool tune = !plain || da;                                                        // something counts proposals / tunes
         // which kernel family runs the launch (q4_ok jobs: same bits either way)
         const bool sums = (d.monitor & KLARA_MON_SUMMARIES) != 0;
+        // slice sampler: nothing counts and no history is kept -> the lanes run out of lockstep (klara_diagt_slice.h); same draws, same bits
+        const bool slice_free = !tune && slice_free_eligible(d);
         int force = -1;                                      // 0: 4 lanes per chain; 1: 8 lanes; -1: decided on the device
         if (!h->q4_ok) force = 1;
         else if (!sums) force = 0;                           // nothing to fold: the 4-lane kernels
@@ -1021,7 +1034,9 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
 #define KLARA_DIAGT_LAUNCH(SUFFIX)                                                                                                          \
                 switch (d.sampler) {                                                                                                          \
                 case KLARA_SAMPLER_MH: return klara_launch_diagt_mh##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);        \
-                case KLARA_SAMPLER_SLICE: return klara_launch_diagt_slice##SUFFIX(p, kp, np, unitw, mon, tune, ka, nw, st);                        \
+                case KLARA_SAMPLER_SLICE:                                                                                                     \
+                    if (slice_free) return klara_launch_diagt_slice_free##SUFFIX(p, kp, np, unitw, sums, ka, nw, st);                          \
+                    return klara_launch_diagt_slice##SUFFIX(p, kp, np, unitw, mon, tune, ka, nw, st);                                          \
                 case KLARA_SAMPLER_MALA: return klara_launch_diagt_mala##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);    \
                 default: return klara_launch_diagt_hmc##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);                     \
                 }
@@ -1153,7 +1168,7 @@ static PlannedLaunch plan_launch(const klara_desc& d, const RunCursor& c, long l
 {
     PlannedLaunch pl;
     const bool pooled_cnt = d.tuner_mode == KLARA_TUNE_POOLED && cnt_predicate(d);
-    const long long spl = d.steps_per_launch > 0 ? d.steps_per_launch : KLARA_DEFAULT_STEPS_PER_LAUNCH;
+    const long long spl = d.steps_per_launch > 0 ? d.steps_per_launch : default_steps_per_launch(d);
     long long k = remaining < spl ? remaining : spl;
     if (pooled_cnt && c.m_tot <= d.burnin) {
         const long long to_boundary = d.period - (c.m_prop % d.period);
@@ -1312,7 +1327,7 @@ extern "C" klara_status klara_run_async(klara_handle* h, int64_t nsteps)
     // one partition's kernel fills the SIMDs while the other's ramps up or drains: 12.9 vs 14.1 us per transition at 65,536 x 100).
     // A run that is a single launch is issued whole on the caller's stream: two half-size kernels that start together only split
     // the machine unevenly (16.7 vs 17.8 us per transition for 20-transition runs).
-    const long long spl_run = d.steps_per_launch > 0 ? d.steps_per_launch : KLARA_DEFAULT_STEPS_PER_LAUNCH;
+    const long long spl_run = d.steps_per_launch > 0 ? d.steps_per_launch : default_steps_per_launch(d);
     const int nparts = nsteps > spl_run ? h->nparts : 1;
     if (nparts > 1) {                                      // fork: the partition streams start after everything queued so far
         HIPCHK(hipEventRecord(h->fork_ev, h->stream));

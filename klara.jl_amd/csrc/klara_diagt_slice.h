@@ -1,0 +1,261 @@
+// klara_diagt_slice.h — the slice sampler on the diagonal Gaussian target, pair-transposed layout (kind 3), lanes out of lockstep.
+//
+// iterate!(job, SliceSampler, Multivariate) (src/samplers/iterate/SliceSampler.jl:60-109) updates the D coordinates of a chain one after the
+// other; on lt = c - sum_i w_i (x_i - mu_i)^2 every comparison of an update, lt(candidate) > log(rand()) + lt, reduces to
+//     t_i(current) - t_i(candidate) > log(rand())                                     (difference form: DESIGN.md section 2 (8), oracle ko_slice_diag_delta)
+// so coordinate i of transition t depends on NOTHING but coordinate i after transition t - 1 and its own draws (block slots (i << 14) | k of
+// transition t): not on the chain's other coordinates, not on the chain's log-target.  Round 4's kernel (k_diagt<SLICE>, klara_diagt.h) used
+// that to give every lane its own coordinates, but kept the 64 lanes of a wavefront in lockstep: step-out and shrink loops ran until the
+// slowest of 64 updates was done (4.5 shrink attempts where an update makes 1.46; issued / necessary instructions 2.55, 0.71 scalar instructions
+// per vector instruction for the votes, profiles/r4_pmc_summary.txt).
+//
+// Here the loops are turned inside out.  A lane takes ONE element pair of its chain (elements 2P, 2P + 1: two independent update machines,
+// interleaved for instruction-level parallelism) through ALL transitions of the launch before it moves to its next pair:
+//
+//     for pair slot p of the lane:                 (x, running sums, width, weight, mean of the pair: registers for the whole launch)
+//         until both machines have made nsteps transitions:      one iteration = at most one transition of each machine
+//             block A = start of a transition ? slot base (log(rand()), runiform)  :  the next block of shrink attempts, base | (k + 1)
+//             block B = base | 1, shrink attempts 1 and 2 of a starting transition
+//             starting machines: slice level, interval, step-out (SliceSampler.jl:66-89)
+//             two shrink attempts from B (starting) or A (continuing)               (SliceSampler.jl:91-106)
+//             accepted -> commit, next transition; else continue with the next attempt block in the next iteration
+//
+// A machine whose update needs more than two attempts (11 % of the updates on the README target) simply takes another iteration while its
+// neighbours start their next transition: nobody waits for the slowest of 64, and the only wave-wide vote left per iteration is the loop's
+// own.  What a wavefront still waits for is the slowest of its 128 machines over a whole pair slot (nsteps transitions each): a few per cent at 32
+// transitions per launch.  The new state's log-target is formed once, after the launch's last transition, in the layout's order (lane partials
+// over ascending elements, butterfly over the chain's Q lanes) — the same bits round 4's kernel and the oracle produce.
+//
+// Scope: untuned jobs whose monitors are the accept diagnostics and / or the running sums (any thinning / burn-in; the sums are lane-local too).
+// A job that counts proposals (verbose) or keeps a history (values, logtarget per saved step) runs k_diagt<SLICE>: the same draws, the same bits.
+#pragma once
+#include "klara_diagt.h"
+
+#ifndef KLARA_DT_SLICEF_WF
+#define KLARA_DT_SLICEF_WF 4      // wavefronts per SIMD the register allocator is asked to leave room for
+#endif
+#ifndef KLARA_DT_SLICEF_WF1
+#define KLARA_DT_SLICEF_WF1 8     // ... of the one-machine form
+#endif
+#ifndef KLARA_DT_SLICEF_WF1S
+#define KLARA_DT_SLICEF_WF1S 6    // ... with running sums or a non-unit diagonal (8 would spill the sums / weights)
+#endif
+#define KLARA_SLICEF_MAXNP 8
+
+template <bool UNITW>
+__device__ __forceinline__ double slicef_term(double v, double w, double m)
+{
+    const double dd = UNITW ? v : v - m;
+    return UNITW ? dd * dd : w * (dd * dd);          // klara_diagt.h diag_elem: the same operations in the same order
+}
+
+// NM: update machines per lane (1: one element at a time, more wavefronts per SIMD; 2: an element pair, two interleaved dependency chains)
+template <int Q, bool UNITW, bool SUMS, int NM>
+__global__ __launch_bounds__(256, (NM == 1 ? (SUMS || !UNITW ? KLARA_DT_SLICEF_WF1S : KLARA_DT_SLICEF_WF1) : KLARA_DT_SLICEF_WF))
+void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka, const int NP)
+{
+    static_assert(NM == 1 || NM == 2, "one or two machines per lane");
+    constexpr int CPW = 64 / Q;
+    const KParams& p = *pp;
+    __shared__ __attribute__((aligned(16))) double lds_w[UNITW ? 2 : 2 * KLARA_SLICEF_MAXNP * Q];
+    __shared__ __attribute__((aligned(16))) double lds_mu[UNITW ? 2 : 2 * KLARA_SLICEF_MAXNP * Q];
+    __shared__ __attribute__((aligned(16))) double lds_wd[2 * KLARA_SLICEF_MAXNP * Q];
+    const int D = p.D;
+    for (int i = (int)threadIdx.x; i < 2 * KLARA_SLICEF_MAXNP * Q; i += (int)blockDim.x) {
+        if (!UNITW) {
+            lds_w[i] = (p.gw != nullptr && i < D) ? p.gw[i] : 1.0;
+            lds_mu[i] = (p.gmu != nullptr && i < D) ? p.gmu[i] : 0.0;
+        }
+        lds_wd[i] = i < D ? p.vecparam[i] : 1.0;
+    }
+    auto_begin();
+    kd_tables_to_lds();          // (ends with the workgroup barrier)
+    const int lane = threadIdx.x & 63, q = lane & (Q - 1), cw = lane / Q;
+    const long long wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const long long grp = kl.group0 + wave0;
+    unsigned wave_acc = 0;
+    if (grp < kl.group_end && grp * CPW < p.nchains) {
+        const long long first_chain = grp * CPW;
+        const long long left = p.nchains - first_chain;
+        const int here = left < CPW ? (int)left : CPW;
+        const bool chain_ok = cw < here;
+        const long long chain = first_chain + cw;
+        const unsigned long long gchain = (unsigned long long)(p.chain_offset + chain);
+        const __amdgpu_buffer_rsrc_t wx = group_window(p.X, first_chain, here, D);
+        const bool do_sum = SUMS && p.sum != nullptr;
+        __amdgpu_buffer_rsrc_t wsum = wx, wsq = wx;
+        int held0 = 0;                                 // (saved steps held at the current state: 0 or 1 between this sampler's launches)
+        if (do_sum) {
+            wsum = group_window(p.sum, first_chain, here, D); wsq = group_window(p.sumsq, first_chain, here, D);
+            held0 = (int)p.held[chain_ok ? chain : 0];
+        }
+        const int nsteps = kl.nsteps;
+        const unsigned long long seed = p.seed;
+        const bool stepout = p.stepout != 0;
+        const long long burnin = p.burnin, nsteps_total = p.nsteps_total;
+        const int thinning = (int)p.thinning;
+        double red = 0.0;
+        int held_out = held0;
+        bool stuck_any = false;
+
+        for (int ps = 0; ps < (2 / NM) * NP; ++ps) {
+            // the lane's element(s) of this slot: NM = 2: the pair P = ps Q + q (elements 2P, 2P + 1); NM = 1: element (ps & 1) of pair (ps >> 1) Q + q
+            int ei[NM]; bool eok[NM]; unsigned eoff[NM];
+            double x[NM], sm[NM], sq[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                ei[m] = NM == 2 ? 2 * (ps * Q + q) + m : 2 * ((ps >> 1) * Q + q) + (ps & 1);
+                eok[m] = chain_ok && ei[m] < D;
+                eoff[m] = eok[m] ? (unsigned)((cw * D + ei[m]) * 8) : KLARA_BUF_OOB;
+                x[m] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wx, eoff[m], 0, 0));      // (0 outside the window)
+                sm[m] = 0.0; sq[m] = 0.0;
+                if (do_sum) {
+                    sm[m] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wsum, eoff[m], 0, 0));
+                    sq[m] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wsq, eoff[m], 0, 0));
+                }
+            }
+            double wt[NM], mu[NM], wd[NM], tcur[NM], L[NM], R[NM], lgu[NM];
+            uint32_t base[NM];
+            int tl[NM], k[NM], sphase[NM];
+            int held[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int i = ei[m];
+                const bool live = eok[m];
+                wt[m] = UNITW ? 1.0 : lds_w[i]; mu[m] = UNITW ? 0.0 : lds_mu[i]; wd[m] = lds_wd[i];
+                tcur[m] = slicef_term<UNITW>(x[m], wt[m], mu[m]);
+                base[m] = (uint32_t)(live ? i : 0) << KLARA_SLICE_ATT_BITS;
+                tl[m] = live ? 0 : nsteps; k[m] = 0; sphase[m] = kl.save_phase0; held[m] = held0;     // (tl = nsteps + 1: the machine is stuck)
+                L[m] = x[m]; R[m] = x[m]; lgu[m] = 0.0;
+            }
+
+            const uint32_t t0lo = (uint32_t)kl.t0, t0hi = (uint32_t)(kl.t0 >> 32);
+            while (true) {
+                bool act[NM], st[NM];
+                kd_u32x4 A[NM], B[NM];
+#pragma unroll
+                for (int m = 0; m < NM; ++m) { act[m] = tl[m] < nsteps; st[m] = act[m] && k[m] == 0; }
+                if (!__any(act[0] || act[NM - 1])) break;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    // counter words of (transition << 24 | slot) for transition t0 + tl (detmath.h kd_stream_block), formed in 32-bit pieces
+                    const uint32_t tlo = t0lo + (uint32_t)tl[m], thi = t0hi + (tlo < t0lo ? 1u : 0u);
+                    const uint32_t c0 = tlo << 24, c1 = (tlo >> 8) | (thi << 24);
+                    const uint32_t slotA = st[m] ? base[m] : (base[m] | (uint32_t)(k[m] + 1));
+                    A[m] = kd_philox4x32_10(c0 | slotA, c1, (uint32_t)gchain, (uint32_t)(gchain >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+                    B[m] = kd_philox4x32_10(c0 | base[m] | 1u, c1, (uint32_t)gchain, (uint32_t)(gchain >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+                }
+                // starting machines: slice level, interval, step-out.  Executed by every lane, kept by the starting ones (selects: a branch here
+                // is taken in all but a few per cent of the iterations and costs the merge copies of everything it defines)
+                {
+                    double Ln[NM], Rn[NM], lg[NM];
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        if (do_sum) {                                                          // the state being left is folded in first (KParams::held)
+                            const bool fold = st[m] && held[m] > 0;
+                            const double hf = (double)held[m];
+                            const double a = sm[m] + hf * x[m], b = sq[m] + hf * (x[m] * x[m]);
+                            sm[m] = fold ? a : sm[m]; sq[m] = fold ? b : sq[m];
+                            held[m] = fold ? 0 : held[m];
+                        }
+                        lg[m] = kd_log_u01(kd_uniform_xy(A[m]));                               // :66 log(rand()); the slice level is lg + lt
+                        const double ru = kd_uniform_zw(A[m]);                                 // :71
+                        Ln[m] = x[m] - ru * wd[m];                                             // :72
+                        Rn[m] = x[m] + (1.0 - ru) * wd[m];                                     // :73
+                    }
+                    if (stepout) {                                                             // :75-89
+                        // Nothing but doubles is carried from trip to trip: a machine steps on a side while t(current) - t(end point) > log(rand()),
+                        // re-formed from the end point at the top of every trip (a machine that is not starting compares against +inf: never).
+                        double lgx[NM], dl[NM], dr[NM];
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+                            lgx[m] = st[m] ? lg[m] : __builtin_inf();
+                            dl[m] = tcur[m] - slicef_term<UNITW>(Ln[m], wt[m], mu[m]);
+                            dr[m] = tcur[m] - slicef_term<UNITW>(Rn[m], wt[m], mu[m]);
+                        }
+                        for (int trip = 1;; trip = __builtin_amdgcn_readfirstlane(trip + 1)) {
+                            bool gl[NM], gr[NM];
+#pragma unroll
+                            for (int m = 0; m < NM; ++m) { gl[m] = dl[m] > lgx[m]; gr[m] = dr[m] > lgx[m]; }
+                            if (!__any(gl[0] || gr[0] || gl[NM - 1] || gr[NM - 1])) break;
+                            if (trip > KLARA_SLICE_MAX_ATT) {                                  // (a machine still stepping in trip n has made n - 1 steps: the guard is a scalar)
+#pragma unroll
+                                for (int m = 0; m < NM; ++m) tl[m] = (gl[m] || gr[m]) ? nsteps + 1 : tl[m];
+                                break;
+                            }
+#pragma unroll
+                            for (int m = 0; m < NM; ++m) {
+                                Ln[m] = gl[m] ? Ln[m] - wd[m] : Ln[m]; Rn[m] = gr[m] ? Rn[m] + wd[m] : Rn[m];
+                                dl[m] = tcur[m] - slicef_term<UNITW>(Ln[m], wt[m], mu[m]);
+                                dr[m] = tcur[m] - slicef_term<UNITW>(Rn[m], wt[m], mu[m]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) { L[m] = st[m] ? Ln[m] : L[m]; R[m] = st[m] ? Rn[m] : R[m]; lgu[m] = st[m] ? lg[m] : lgu[m]; }
+                }
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {                                                 // :91-106, two attempts
+                    const uint32_t w0 = st[m] ? B[m].x : A[m].x, w1 = st[m] ? B[m].y : A[m].y, w2 = st[m] ? B[m].z : A[m].z, w3 = st[m] ? B[m].w : A[m].w;
+                    const double c1 = kd_u52(w0, w1) * (R[m] - L[m]) + L[m];                   // :92-93
+                    const double t1 = slicef_term<UNITW>(c1, wt[m], mu[m]);                    // :94
+                    const bool in1 = tcur[m] - t1 > lgu[m];                                    // :95
+                    const bool up1 = c1 > x[m], dn1 = c1 < x[m];
+                    // (the interval only matters while the update goes on: it is narrowed as if attempt 1 had failed — when it succeeded nothing reads it
+                    // again before the next transition's :72-73 replace it)
+                    const double R1 = up1 ? c1 : R[m];                                         // :98
+                    const double L1 = dn1 ? c1 : L[m];                                         // :100 (c1 < x excludes c1 > x)
+                    const bool bad1 = !in1 && !up1 && !dn1;                                    // :102
+                    const double c2 = kd_u52(w2, w3) * (R1 - L1) + L1;
+                    const double t2 = slicef_term<UNITW>(c2, wt[m], mu[m]);
+                    const bool in2 = tcur[m] - t2 > lgu[m];
+                    const bool up2 = c2 > x[m], dn2 = c2 < x[m];
+                    const bool done = act[m] && (in1 || (!bad1 && in2));
+                    const bool bad = act[m] && (bad1 || (!in1 && !in2 && !up2 && !dn2));
+                    const bool more = act[m] && !done && !bad;
+                    const int knext = st[m] ? 1 : k[m] + 1;
+                    const bool full = more && 2 * (knext + 1) > KLARA_SLICE_MAX_ATT;           // (the next attempt block would pass the slot field)
+                    const double xn = in1 ? c1 : c2, tn = in1 ? t1 : t2;                       // :108 (the new value's term: what the next update starts from)
+                    x[m] = done ? xn : x[m]; tcur[m] = done ? tn : tcur[m];
+                    R[m] = up2 ? c2 : R1;
+                    L[m] = dn2 ? c2 : L1;
+                    if (SUMS) {                                                                // save rule: BasicMCJob.jl:226-231, BasicMCRange.jl:36
+                        const uint32_t tlo = t0lo + (uint32_t)tl[m], thi = t0hi + (tlo < t0lo ? 1u : 0u);
+                        const long long i1 = (long long)(((unsigned long long)thi << 32) | tlo) + 1;
+                        const bool post = done && i1 > burnin && i1 <= nsteps_total;
+                        held[m] += (post && sphase[m] == 0) ? 1 : 0;
+                        sphase[m] = post ? ((sphase[m] + 1 == thinning) ? 0 : sphase[m] + 1) : sphase[m];
+                    }
+                    k[m] = more ? knext : 0;
+                    tl[m] = (bad || full) ? nsteps + 1 : tl[m] + (done ? 1 : 0);               // stuck: the machine stops where it is (error raised below)
+                }
+            }
+            // the slot is done for this launch: value and sums back to memory, its terms into the lane's partial of the new log-target
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, x[m]), wx, eoff[m], 0, 0);
+                if (do_sum) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sm[m]), wsum, eoff[m], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sq[m]), wsq, eoff[m], 0, 0);
+                }
+                red = red + (ei[m] < D ? tcur[m] : 0.0);          // (ascending elements: the layout's order)
+            }
+            if (ps == 0) held_out = held[0];
+            stuck_any = stuck_any || tl[0] > nsteps || tl[NM - 1] > nsteps;
+        }
+        double r1[1] = { red };
+        group_allreduce<1>(r1, Q, lane);
+        if (chain_ok && q == 0) {
+            p.LT[chain] = p.gconst - r1[0];
+            p.naccept[chain] += (unsigned long long)nsteps;                                    // (every slice transition "accepts": diagnostics are all true)
+            if (do_sum) p.held[chain] = (long long)held_out;
+            if (p.accept != nullptr) {
+                guchar* const out = p.accept + kl.t0 * (unsigned long long)p.nchains + chain;
+                for (int s = 0; s < nsteps; ++s) out[(long long)s * p.nchains] = 1;
+            }
+            wave_acc = (unsigned)nsteps;
+        }
+        if (stuck_any && chain_ok) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);
+    }
+    auto_finish(ka, wave_acc);
+}

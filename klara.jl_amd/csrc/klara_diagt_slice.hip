@@ -1,5 +1,10 @@
 // klara_diagt_slice.hip — instantiates the pair-transposed slice-sampler kernels (layout kind 3) for gfx950.
 #include "klara_launch.h"
+#include "klara_diagt_slice.h"
+#include <cstdlib>
+#ifndef KLARA_SLICEF_DEFAULT_NM
+#define KLARA_SLICEF_DEFAULT_NM 1     // (same box, 65,536 x 100: 9.7e10 coordinate updates/s with one machine per lane, 9.5e10 with two: profiles/r5_ab_slice.txt)
+#endif
 
 #define KLARA_DIAGT_SLICE_CASE(NP_)                                                                                       \
     case NP_:                                                                                                              \
@@ -19,4 +24,20 @@ hipError_t KLARA_DIAGT_FN(klara_launch_diagt_slice)(const KParams* p, const KLau
     default: return hipErrorInvalidValue;
     }
     return e_;
+}
+
+// untuned jobs without a history monitor: every lane takes its element pairs through the whole launch on its own (klara_diagt_slice.h)
+hipError_t KLARA_DIAGT_FN(klara_launch_diagt_slice_free)(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool sums, const KAuto& ka, long long nwaves, hipStream_t st)
+{
+    if (NP < 1 || NP > KLARA_SLICEF_MAXNP) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((nwaves + 3) / 4)), blk(256);
+    static const int nm = getenv("KLARA_SLICE_MACHINES") ? atoi(getenv("KLARA_SLICE_MACHINES")) : KLARA_SLICEF_DEFAULT_NM;
+#define KLARA_SLICEF_GO(U, S)                                                                                          \
+    (nm == 1 ? klara_go(k_diagt_slice_free<KLARA_DIAGT_Q, U, S, 1>, grid, blk, 0, st, p, kl, ka, NP)                    \
+             : klara_go(k_diagt_slice_free<KLARA_DIAGT_Q, U, S, 2>, grid, blk, 0, st, p, kl, ka, NP))
+    if (unitw && sums) return KLARA_SLICEF_GO(true, true);
+    if (unitw) return KLARA_SLICEF_GO(true, false);
+    if (sums) return KLARA_SLICEF_GO(false, true);
+    return KLARA_SLICEF_GO(false, false);
+#undef KLARA_SLICEF_GO
 }
