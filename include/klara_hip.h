@@ -59,7 +59,8 @@ typedef enum klara_status {
     KLARA_ERR_NOMEM = 4,
     KLARA_ERR_UNSUPPORTED = 5,     /* valid Klara option that this build does not cover (see DESIGN)  */
     KLARA_ERR_STATE = 6,           /* call order (e.g. run before set_state)                          */
-    KLARA_ERR_SLICE_STUCK = 7,     /* iterate/SliceSampler.jl:102 "Shrunk to current position ..."   */
+    KLARA_ERR_SLICE_STUCK = 7,     /* iterate/SliceSampler.jl:102 "Shrunk to current position ..." (or 16,383 step-out / shrink attempts): the state of
+                                      the chains that raised it is unspecified afterwards (the reference throws out of run(job)); reset the job */
     KLARA_ERR_COMPILE = 8          /* CUSTOM target: the user's source did not compile (klara_compile_log) */
 } klara_status;
 

@@ -148,7 +148,7 @@ def load() -> C.CDLL:
     }
     for name, argtypes in sig.items():
         if "KLARA_HIP_LIB" in os.environ and not hasattr(lib, name):
-            continue            # (same-box A/B against an older build of the library, scripts/r3_ab.py: it may lack the newest entry points)
+            continue            # (same-box A/B against an older build of the library, scripts/ab_builds.py: it may lack the newest entry points)
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int

@@ -293,7 +293,8 @@ KD_FN double kd_exp(double x)
  * the exponent field (results are normal numbers, so this equals kd_exp's two exact multiplications).  Beyond a = 708, where the value
  * would be subnormal, the argument is clamped: the result is exp(-708) = 3.3e-308 instead of a number below 2.3e-308 — an absolute error
  * below 3.3e-308 (the only callers form 1 + t, where it vanishes, and t / (1 + t)).  A NaN argument gives exp(-708) as well (fmax
- * returns the other operand); the caller passes NaN through itself.  < 1 ulp up to 708 (tests/test_oracle_kats.py); NOT bit-identical
+ * returns the other operand): kd_softplus_logistic adds the pass-through; the batched data rows of the logistic kernels do NOT (see
+ * kd_softplus_logistic_rows below for why that changes no result).  < 1 ulp up to 708 (tests/test_oracle_kats.py); NOT bit-identical
  * with kd_exp(-a): k is rounded to nearest-even here and towards zero-after-offset there, so a few arguments near the ties between two
  * table entries are reduced to the other neighbour.
  * Split at its table read — reduce, the gather (KD_EXPTAB(2 (k & 127)), (2 (k & 127) + 1)), polynomial, combine — so that a caller with
@@ -394,9 +395,14 @@ KD_FN void kd_softplus_logistic_rows(double x, double* softplus, double* logisti
     *logistic = kd_div_unit_range(x >= 0.0 ? 1.0 : t, onept);
 }
 /* The pair as a function of any double: NaN is passed through.  (The data rows of the logistic targets call the form above, which
- * returns finite values for a NaN argument: a NaN there can only come from a non-finite parameter vector, the row's term Xp * y of
- * the same evaluation is then NaN whatever y is, and so is the log-target — which is what initialize! tests (MALA.jl:83-84) — so
- * the per-row pass-through, a compare and four selects on each of ndata rows, bought nothing.) */
+ * returns finite values for a NaN argument.  A NaN Xp can only come from a non-finite parameter vector.  Every evaluation that forms the
+ * log-target also forms the row's term Xp * y, which is then NaN whatever y is, and so is the log-target — what initialize! tests
+ * (MALA.jl:83-84) and what every Metropolis test of a proposal reads: the proposal is rejected exactly as the literal arithmetic
+ * rejects it.  The one evaluation WITHOUT a log-target is the gradient inside an HMC trajectory: there the rows' part of the gradient
+ * comes out finite where the literal X'(y - 1/(1+exp(-Xp))) is NaN in every component, but the component that made Xp non-finite is
+ * NaN in the gradient anyway through -p/lambda, stays NaN through the remaining leapfrogs, and the trajectory's closing log-target is
+ * NaN: the same rejection.  So the per-row pass-through — a compare and four selects on each of ndata rows — buys nothing observable
+ * and is left out) */
 KD_FN void kd_softplus_logistic(double x, double* softplus, double* logistic)
 {
     kd_softplus_logistic_rows(x, softplus, logistic);

@@ -1664,19 +1664,24 @@ extern "C" klara_status klara_gather_summaries(klara_handle* h, klara_comm* c, d
         HIPCHK(dalloc(&c->buf, 2 * D + 4));
         c->cap = 2 * D + 4;
     }
-    HIPCHK(hipMemsetAsync(c->buf, 0, (2 * D + 4) * sizeof(double), h->stream));
-    HIPCHK(pool_summaries_async(h, h->sum != nullptr, c->buf));
+    // From here on every rank is inside a fixed sequence of collectives: a rank that returned at its first local failure would leave the others
+    // waiting in theirs.  Local errors are remembered, every collective is still entered, the status is reported after the last one.
+    bool bad = false;
+    const auto H = [&](hipError_t e) { if (e != hipSuccess) bad = true; };
+    H(hipMemsetAsync(c->buf, 0, (2 * D + 4) * sizeof(double), h->stream));
+    H(pool_summaries_async(h, h->sum != nullptr, c->buf));
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(c->buf + 2 * D);
     const unsigned long long local[3] = { (unsigned long long)h->steps_done * (unsigned long long)h->d.nchains,
                                           (unsigned long long)h->nsaved * (unsigned long long)h->d.nchains,
                                           (unsigned long long)h->d.nchains };
-    HIPCHK(hipMemcpyAsync(cnt + 1, local, sizeof(local), hipMemcpyHostToDevice, h->stream));
+    H(hipMemcpyAsync(cnt + 1, local, sizeof(local), hipMemcpyHostToDevice, h->stream));
     // two in-place all-reduces on the job's stream: 2D doubles, 4 counters — (2D + 4) x 8 B per rank, latency-bound
-    if (c->AllReduce(c->buf, c->buf, 2 * D, ncclDouble, ncclSum, c->comm, h->stream) != ncclSuccess) return KLARA_ERR_HIP;
-    if (c->AllReduce(cnt, cnt, 4, ncclUint64, ncclSum, c->comm, h->stream) != ncclSuccess) return KLARA_ERR_HIP;
+    if (c->AllReduce(c->buf, c->buf, 2 * D, ncclDouble, ncclSum, c->comm, h->stream) != ncclSuccess) bad = true;
+    if (c->AllReduce(cnt, cnt, 4, ncclUint64, ncclSum, c->comm, h->stream) != ncclSuccess) bad = true;
     std::vector<double> host(2 * D + 4);
-    HIPCHK(hipMemcpyAsync(host.data(), c->buf, (2 * D + 4) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    H(hipMemcpyAsync(host.data(), c->buf, (2 * D + 4) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    H(hipStreamSynchronize(h->stream));
+    if (bad) return KLARA_ERR_HIP;
     if (sum) memcpy(sum, host.data(), D * sizeof(double));
     if (sumsq) memcpy(sumsq, host.data() + D, D * sizeof(double));
     unsigned long long out[4];
@@ -1756,7 +1761,8 @@ __global__ void k_moments_between(double* __restrict__ m2, const double* mean_r,
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D) return;
-    const double mean = wsum[j] / (double)*ntot, d = mean_r[j] - mean;
+    const double nt = (double)*ntot;
+    const double mean = nt > 0.0 ? wsum[j] / nt : 0.0, d = mean_r[j] - mean;       // (no saved sample on any rank: zeros, as chan_merge leaves them without a communicator)
     mean_out[j] = mean;
     m2[j] = m2[j] + n_r * (d * d);
 }
@@ -1797,22 +1803,26 @@ extern "C" klara_status klara_gather_moments(klara_handle* h, klara_comm* c, dou
             HIPCHK(dalloc(&c->buf, 3 * D + 4));
             c->cap = 3 * D + 4;
         }
-        HIPCHK(pool_moments_async(h, c->buf));
+        // (as in klara_gather_summaries: once the sequence of collectives starts, every rank goes through all of it; errors are reported after the last)
+        bool bad = false;
+        const auto H = [&](hipError_t e) { if (e != hipSuccess) bad = true; };
+        H(pool_moments_async(h, c->buf));
         unsigned long long* dcnt = reinterpret_cast<unsigned long long*>(c->buf + 2 * D);
-        HIPCHK(hipMemcpyAsync(dcnt + 1, cnt + 1, 3 * sizeof(cnt[0]), hipMemcpyHostToDevice, h->stream));
+        H(hipMemcpyAsync(dcnt + 1, cnt + 1, 3 * sizeof(cnt[0]), hipMemcpyHostToDevice, h->stream));
         double* wsum = c->buf + 2 * D + 4;
         const double n_r = (double)cnt[2];
         hipLaunchKernelGGL(k_scale, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, h->stream, wsum, c->buf, n_r, (int)D);
-        HIPCHK(hipGetLastError());
+        H(hipGetLastError());
         // three in-place all-reduces on the job's stream: 4 counters, D weighted means, D sums of squares — latency-bound
-        if (c->AllReduce(dcnt, dcnt, 4, ncclUint64, ncclSum, c->comm, h->stream) != ncclSuccess) return KLARA_ERR_HIP;
-        if (c->AllReduce(wsum, wsum, D, ncclDouble, ncclSum, c->comm, h->stream) != ncclSuccess) return KLARA_ERR_HIP;
+        if (c->AllReduce(dcnt, dcnt, 4, ncclUint64, ncclSum, c->comm, h->stream) != ncclSuccess) bad = true;
+        if (c->AllReduce(wsum, wsum, D, ncclDouble, ncclSum, c->comm, h->stream) != ncclSuccess) bad = true;
         hipLaunchKernelGGL(k_moments_between, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, h->stream, c->buf + D, c->buf, wsum, dcnt + 2, n_r, (int)D, c->buf);
-        HIPCHK(hipGetLastError());
-        if (c->AllReduce(c->buf + D, c->buf + D, D, ncclDouble, ncclSum, c->comm, h->stream) != ncclSuccess) return KLARA_ERR_HIP;
+        H(hipGetLastError());
+        if (c->AllReduce(c->buf + D, c->buf + D, D, ncclDouble, ncclSum, c->comm, h->stream) != ncclSuccess) bad = true;
         std::vector<double> hostc(2 * D + 4);
-        HIPCHK(hipMemcpyAsync(hostc.data(), c->buf, (2 * D + 4) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        H(hipMemcpyAsync(hostc.data(), c->buf, (2 * D + 4) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        H(hipStreamSynchronize(h->stream));
+        if (bad) return KLARA_ERR_HIP;
         memcpy(host.data(), hostc.data(), 2 * D * sizeof(double));
         memcpy(cnt, hostc.data() + 2 * D, sizeof(cnt));
     }

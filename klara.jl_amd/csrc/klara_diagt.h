@@ -860,7 +860,9 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
             }
             if (chain_ok && cx.q == 0) p.held[chain] = held;
         }
-        if (SLICE && stuck && chain_ok) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);      // (a per-lane flag: the lane whose coordinate ran out of attempts)
+        // (a per-lane flag: the lane whose coordinate ran out of attempts stops, the chain's other lanes finish the transition — the oracle returns at the
+        // first stuck coordinate, so after KLARA_ERR_SLICE_STUCK the device state is NOT the oracle's: unspecified, include/klara_hip.h)
+        if (SLICE && stuck && chain_ok) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);
         if (!ONESTEP) wave_acc += (chain_ok && cx.q == 0) ? (unsigned)nacc : 0u;     // (per-lane partial; summed in auto_finish)
         if (!ONESTEP && nacc != 0) {
             store_pairs<NP, Q>(cx, wx, x);
