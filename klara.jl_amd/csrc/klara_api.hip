@@ -996,7 +996,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
     const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
     int mode = (plain ? 1 : 0) | ((plain && d.monitor == 0) ? 2 : 0);         // 3: no monitors either
     if (mode == 3 && kl.nsteps == 1) mode = 7;                                 // one iterate! per launch
-    if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, h->E, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
+    if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, plain, h->E, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on

@@ -37,10 +37,19 @@ struct MfmaCtx {
     // Padding is zeroed where it enters (loads return 0 outside the window, the normals of missing elements are set to 0, the padded
     // rows of P are 0): every missing element of every per-chain vector then stays +-0 through the transition, its terms add +-0 to
     // the sums, and no sum needs a validity select.  Only the byte offsets of loads and stores depend on nv.
-    __device__ __forceinline__ unsigned off(int e, int nv_) const { return e < nv_ ? voff0 + 32u * (unsigned)e : KLARA_BUF_OOB; }
+    // (nv_ comes from nv_here() at the access group's site; the base offset is hidden from the optimiser the same way — otherwise voff0 + 32 e
+    // is hoisted out of the transition loop for every e: NE registers that the MFMA loop then pushes into scratch)
+    __device__ __forceinline__ unsigned off(int e, int nv_) const
+    {
+        unsigned vb = voff0;
+        __asm__ volatile("" : "+v"(vb));
+        return e < nv_ ? vb + 32u * (unsigned)e : KLARA_BUF_OOB;
+    }
     // nv behind an empty asm: the NE offsets of an access group are formed where they are used (2 instructions each) instead of
     // being hoisted out of the transition loop as NE loop-invariant registers that the MFMA loop then forces into scratch
     __device__ __forceinline__ int nv_here() const { int n = nv; __asm__ volatile("" : "+v"(n)); return n; }
+    // the lane's chain index, re-formed where it is used (a scalar base + the lane's column) instead of living in two registers through the MFMA loops
+    __device__ __forceinline__ long long chain_here() const { int c = cl; __asm__ volatile("" : "+v"(c)); return first_chain + c; }
 };
 
 template <int NE>
@@ -203,7 +212,9 @@ __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int 
     if (TAIL) { g[4 * MTF + 0] = NEG ? -acc_t : acc_t; g[4 * MTF + 1] = 0.0; g[4 * MTF + 2] = 0.0; g[4 * MTF + 3] = 0.0; }
 }
 
-template <int SAMPLER, int NE, bool DA, bool HASMU = false>
+// PLAIN: nothing counts proposals or tunes (VanillaMCTuner, not verbose — BASELINE cfg 3): the step is the job's scalar step0, no tuner
+// state is loaded, carried through the launch or written back (13 registers per lane that the generic instantiation spills: 80 B of scratch)
+template <int SAMPLER, int NE, bool DA, bool HASMU = false, bool PLAIN = false>
 __global__ __launch_bounds__(512)
 void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
 {
@@ -221,12 +232,15 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
     const MfmaCtx<NE> cx = make_mctx<NE>(p);
     // x - mu of the lane's element e (lt = c + 1/2 (x-mu).g); missing elements: 0 - 0
     const auto dx = [&](const double (&v)[NE], int e) { return HASMU ? v[e] - ldsMu[4 * e + cx.q] : v[e]; };
-    const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
+    const auto gch = [&]() { return (unsigned long long)(p.chain_offset + cx.chain_here()); };       // global chain id: the Philox subsequence
     const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
     constexpr bool da = DA;   // dual averaging is a separate instantiation: the masked leapfrog loop costs registers
-    TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0, 0.0, 0.0 };
+    static_assert(!(PLAIN && DA), "dual averaging tunes");
+    const bool cnt = !PLAIN && p.cnt != 0;
+    TuneRegs tn = { p.step0, 0, 0, 0, 0, 0.0, 0.0 };
+    if (!PLAIN) tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0, 0.0, 0.0 };
     if (da) { tn.epsbar = p.da_epsbar[tix]; tn.hbar = p.da_hbar[tix]; }
-    tn.phase = p.cnt ? (int)(tn.proposed % p.period) : 0;
+    tn.phase = cnt ? (int)(tn.proposed % p.period) : 0;
     int sphase = kl.save_phase0;
     long long scol = kl.save_col0;
     double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
@@ -243,7 +257,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
     bool have = false;
     for (int s = 0; s < kl.nsteps; ++s) {
         const unsigned long long t = kl.t0 + (unsigned long long)s;
-        if (p.cnt) tune_count_proposal(p, tn);
+        if (cnt) tune_count_proposal(p, tn);
         bool acc = false;
         double ltp = lt;
         if (!have) mload<NE>(cx, p.X, p.D, xp);                        // current value
@@ -257,7 +271,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
 #pragma unroll
                 for (int e = 0; e < NE; ++e) gp[e] = g0[e];
             }
-            mnormals<NE>(cx, p.seed, gchain, t, mom);                  // HMC.jl:135
+            mnormals<NE>(cx, p.seed, gch(), t, mom);                  // HMC.jl:135
             double k0[1] = { 0.0 };
 #pragma unroll
             for (int e = 0; e < NE; ++e) k0[0] = k0[0] + mom[e] * mom[e];
@@ -318,14 +332,14 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             const double ratio = H1 - H0;                              // HMC.jl:161
             const double ex = kd_exp(ratio);
             const double a = 1.0 < ex ? 1.0 : ex;                      // HMC.jl:163
-            const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+            const double u = kd_accept_uniform(kd_stream_block(p.seed, gch(), t, (uint32_t)((p.D + 1) >> 1)));
             acc = u < a;                                               // HMC.jl:165
             if (da) da_update(p, tn, (long long)t + 1, a);             // HMC.jl:225-249
         } else if (SAMPLER == KLARA_SAMPLER_MALA) {
             // iterate/MALA.jl:78-128
             double z[NE], xc[NE], red[3];
             const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h), inv_h = 1.0 / h, half_inv_h = 0.5 * inv_h;
-            mnormals<NE>(cx, p.seed, gchain, t, z);
+            mnormals<NE>(cx, p.seed, gch(), t, z);
             double s1 = 0.0;
             {
                 double g0[NE];
@@ -361,7 +375,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             ratio -= red[2];
             acc = ratio > 0.0;                                         // MALA.jl:94
             if (!acc && ratio > KD_LOG_UMIN_GUARD) {
-                const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+                const double u = kd_accept_uniform(kd_stream_block(p.seed, gch(), t, (uint32_t)((p.D + 1) >> 1)));
                 acc = ratio > kd_log_u01(u);
             }
         } else if (SAMPLER == KLARA_SAMPLER_SLICE) {
@@ -379,7 +393,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 const double xi = lane_bcast(xi_l, cx.cl + 16 * qo);
                 const double wd = p.vecparam[i];
                 const uint32_t base = (uint32_t)i << KLARA_SLICE_ATT_BITS;
-                const kd_u32x4 b0 = kd_stream_block(p.seed, gchain, t, base);
+                const kd_u32x4 b0 = kd_stream_block(p.seed, gch(), t, base);
                 const double logu = kd_log_u01(kd_uniform_xy(b0)) + cur;                       // :66
                 const double ru = kd_uniform_zw(b0);                                           // :71
                 double Li = xi - ru * wd;                                                      // :72
@@ -423,7 +437,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 for (uint32_t a = 1;; ++a) {                                                   // :91-106
                     if (!done && a > KLARA_SLICE_MAX_ATT) { stuck = true; done = true; }
                     if (!__any(!done)) break;
-                    const double u = kd_slice_attempt_uniform(p.seed, gchain, t, base, a);
+                    const double u = kd_slice_attempt_uniform(p.seed, gch(), t, base, a);
                     const double cand = u * (Ri - Li) + Li;                                    // :92-93
                     const double lc = lt_with(done ? xprime : cand);                           // :94
                     if (!done) {
@@ -445,7 +459,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
         } else {
             // iterate/MH.jl:72-124
             double z[NE], sg[NE], red[1];
-            mnormals<NE>(cx, p.seed, gchain, t, z);
+            mnormals<NE>(cx, p.seed, gch(), t, z);
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 sg[e] = (4 * e + cx.q < p.D) ? p.vecparam[4 * e + cx.q] : 0.0;
@@ -461,7 +475,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             const double ratio = ltp - lt;                             // MH.jl:83
             acc = ratio > 0.0;                                         // MH.jl:97
             if (!acc && ratio > KD_LOG_UMIN_GUARD) {
-                const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
+                const double u = kd_accept_uniform(kd_stream_block(p.seed, gch(), t, (uint32_t)((p.D + 1) >> 1)));
                 acc = ratio > kd_log_u01(u);
             }
         }
@@ -496,11 +510,11 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
         }
         have = acc;                                      // (a rejected proposal leaves the registers holding the proposal: re-read next time)
         nacc += acc ? 1ull : 0ull;
-        if (p.cnt && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;       // (the slice sampler never counts accepts)
+        if (cnt && acc && SAMPLER != KLARA_SAMPLER_SLICE) tn.accepted += 1;       // (the slice sampler never counts accepts)
         if (accept_out != nullptr && cx.chain_ok && cx.q == 0)
-            accept_out[(long long)s * p.nchains + cx.chain] = acc ? 1 : 0;
-        if (!p.pooled && !da) tuning_block(p, tn);
-        else if (da && p.cnt && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {
+            accept_out[(long long)s * p.nchains + cx.chain_here()] = acc ? 1 : 0;
+        if (!PLAIN && !p.pooled && !da) tuning_block(p, tn);
+        else if (da && cnt && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {
             tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
         }
         const long long i1 = (long long)t + 1;
@@ -521,7 +535,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 if (col < p.hist_cols) mstore<NE>(cx, p.hist, p.D, xs, col * p.nchains);
             }
             if (p.hist_lt != nullptr && col < p.hist_cols && cx.chain_ok && cx.q == 0)
-                p.hist_lt[col * p.nchains + cx.chain] = lt;
+                p.hist_lt[col * p.nchains + cx.chain_here()] = lt;
             if (SAMPLER != KLARA_SAMPLER_MH && SAMPLER != KLARA_SAMPLER_SLICE && p.hist_g != nullptr && col < p.hist_cols) {
                 double gs[NE];
                 if (acc) {
@@ -536,17 +550,23 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
     }
 
     if (SAMPLER == KLARA_SAMPLER_SLICE && stuck && cx.chain_ok && cx.q == 0) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);
-    if (cx.chain_ok && cx.q == 0) {
-        p.LT[cx.chain] = lt;
-        p.naccept[cx.chain] += nacc;
-        if (do_sum) p.held[cx.chain] = held;
-        if (da) { p.da_epsbar[cx.chain] = tn.epsbar; p.da_hbar[cx.chain] = tn.hbar; }
-        if (!p.pooled) {
-            p.tune_step[cx.chain] = tn.step;
-            p.tune_accepted[cx.chain] = tn.accepted;
-            p.tune_proposed[cx.chain] = tn.proposed;
-            p.tune_totproposed[cx.chain] = tn.totproposed;
-        } else if (p.cnt) {
+    // (the lane index is re-read here — v_mbcnt — instead of keeping threadIdx.x & 63 alive through the launch for this one test: the register it
+    // would occupy is the one the MFMA loop spills)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (lane_e < cx.here) {                                              // q == 0 (lanes 0..15) on an existing chain
+        const long long chain_e = cx.first_chain + lane_e;
+        p.LT[chain_e] = lt;
+        p.naccept[chain_e] += nacc;
+        if (do_sum) p.held[chain_e] = held;
+        if (da) { p.da_epsbar[chain_e] = tn.epsbar; p.da_hbar[chain_e] = tn.hbar; }
+        if (PLAIN) {
+            // (nothing changed: tune_step[] still holds step0, the counters their zeros)
+        } else if (!p.pooled) {
+            p.tune_step[chain_e] = tn.step;
+            p.tune_accepted[chain_e] = tn.accepted;
+            p.tune_proposed[chain_e] = tn.proposed;
+            p.tune_totproposed[chain_e] = tn.totproposed;
+        } else if (cnt) {
             atomicAdd((unsigned long long*)p.pooled_accepted, (unsigned long long)tn.accepted - (unsigned long long)p.tune_accepted[0]);
         }
     }

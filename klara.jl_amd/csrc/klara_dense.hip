@@ -6,17 +6,17 @@
 hipError_t klara_launch_dense_big(const KParams* p, const KLaunch& kl, int sampler, bool da, int NE, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st);
 hipError_t klara_launch_dense_init_big(const KParams& p, int NE, const double* Pfrag, bool hasmu, int needgrad, dim3 grid, hipStream_t st);
 
-template <int SAMPLER, bool DA, bool HASMU>
+template <int SAMPLER, bool DA, bool HASMU, bool PLAIN = false>
 static hipError_t launch_dense_m(const KParams* p, const KLaunch& kl, int NE, const double* Pfrag, dim3 grid, hipStream_t st)
 {
     const dim3 blk(512);
 #define KLARA_DENSE_CASE(N)                                                                            \
     case N: {                                                                                          \
         constexpr size_t lds = sizeof(double) * (64 * (size_t)N * (size_t)((N + 3) / 4) + (HASMU ? 4 * N : 0)); \
-        hipError_t e = hipFuncSetAttribute((const void*)k_dense_transitions<SAMPLER, N, DA, HASMU>,        \
+        hipError_t e = hipFuncSetAttribute((const void*)k_dense_transitions<SAMPLER, N, DA, HASMU, PLAIN>,        \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return e;                                                                 \
-        e = klara_go(k_dense_transitions<SAMPLER, N, DA, HASMU>, grid, blk, lds, st, p, kl, Pfrag);         \
+        e = klara_go(k_dense_transitions<SAMPLER, N, DA, HASMU, PLAIN>, grid, blk, lds, st, p, kl, Pfrag);  \
         if (e != hipSuccess) return e;                                                                 \
         break;                                                                                         \
     }
@@ -31,13 +31,14 @@ static hipError_t launch_dense_m(const KParams* p, const KLaunch& kl, int NE, co
     return hipGetLastError();
 }
 
-template <int SAMPLER, bool DA>
+template <int SAMPLER, bool DA, bool PLAIN = false>
 static hipError_t launch_dense_s(const KParams* p, const KLaunch& kl, int NE, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st)
 {
+    if (PLAIN) return hasmu ? launch_dense_m<SAMPLER, DA, true, PLAIN>(p, kl, NE, Pfrag, grid, st) : launch_dense_m<SAMPLER, DA, false, PLAIN>(p, kl, NE, Pfrag, grid, st);
     return hasmu ? launch_dense_m<SAMPLER, DA, true>(p, kl, NE, Pfrag, grid, st) : launch_dense_m<SAMPLER, DA, false>(p, kl, NE, Pfrag, grid, st);
 }
 
-hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, int NE, const double* Pfrag, bool hasmu,
+hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, bool plain, int NE, const double* Pfrag, bool hasmu,
                               dim3 grid, hipStream_t st)
 {
     if (NE > 32) return sampler != KLARA_SAMPLER_SLICE ? klara_launch_dense_big(p, kl, sampler, tuner == KLARA_TUNER_DUAL_AVERAGING, NE, Pfrag, hasmu, grid, st)
@@ -48,6 +49,7 @@ hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, 
     case KLARA_SAMPLER_SLICE: return launch_dense_s<KLARA_SAMPLER_SLICE, false>(p, kl, NE, Pfrag, hasmu, grid, st);
     case KLARA_SAMPLER_HMC:
         if (tuner == KLARA_TUNER_DUAL_AVERAGING) return launch_dense_s<KLARA_SAMPLER_HMC, true>(p, kl, NE, Pfrag, hasmu, grid, st);
+        if (plain) return launch_dense_s<KLARA_SAMPLER_HMC, false, true>(p, kl, NE, Pfrag, hasmu, grid, st);      // nothing counts or tunes: the step is a scalar, no tuner state
         return launch_dense_s<KLARA_SAMPLER_HMC, false>(p, kl, NE, Pfrag, hasmu, grid, st);
     default: return hipErrorInvalidValue;
     }

@@ -26,7 +26,7 @@ hipError_t klara_launch_slice(const KParams* p, const KLaunch& kl, int mode, int
                            hipStream_t st);
 // dense (MFMA) kernels; NE in {8,16,25,32}
 // (Pfrag: the fragment-ordered precision matrix, followed — hasmu — by the 4 NE zero-padded entries of the mean)
-hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, int NE, const double* Pfrag, bool hasmu,
+hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, bool plain, int NE, const double* Pfrag, bool hasmu,
                               dim3 grid, hipStream_t st);
 hipError_t klara_launch_dense_init(const KParams& p, int NE, const double* Pfrag, bool hasmu, int needgrad, dim3 grid,
                                    hipStream_t st);
