@@ -492,9 +492,10 @@ def extra_measurements(K, L, n, stream):
     except Exception as exc:
         ex["hmc_dense_d256_error"] = repr(exc)
 
-    # -- slice sampler on the README target, D = 100
-    SLICE_SPL = 32
-    e = K.Engine(sampler=L.SAMPLER_SLICE, target=neg, nchains=n, nsteps=10 ** 7, slice_widths=np.full(NDIMS, 1.0), steps_per_launch=SLICE_SPL,
+    # -- slice sampler on the README target, D = 100: the library's own launch length for this job (KLARA_DEFAULT_STEPS_PER_LAUNCH_SLICE; the lanes run out of
+    # lockstep and a wavefront waits for its slowest lane once per element slot and launch, klara_diagt_slice.h)
+    SLICE_SPL = 128
+    e = K.Engine(sampler=L.SAMPLER_SLICE, target=neg, nchains=n, nsteps=10 ** 7, slice_widths=np.full(NDIMS, 1.0), steps_per_launch=0,
                  stream=stream, nstreams=1)
     e.init_state_normal()
     rate, ls, _ = timed_rate(e, n, SLICE_SPL, 4 * SLICE_SPL)
@@ -502,11 +503,12 @@ def extra_measurements(K, L, n, stream):
     ex["slice_d100_transitions_per_s"] = rate
     ex["slice_d100_coordinate_updates_per_s"] = rate * NDIMS
     # the slice sampler's trip counts are data dependent: the algorithmic budget takes an update's own mean probe counts on this target in
-    # stationarity (a seeded simulation of the procedure, scripts/instruction_budget.py slice_probe_counts); `frac_lockstep` prices what the 64
-    # coordinate updates a wavefront makes at a time (every lane its own: round 4), which share the loops, have to execute — the mean of the maximum over 64
+    # stationarity (a seeded simulation of the procedure, scripts/instruction_budget.py slice_probe_counts); `frac_lockstep` prices what 64 coordinate
+    # updates that share their loops have to execute — the mean of the maximum over 64 (round 4's kernel, still the one for jobs that keep a history)
     bs, bsl = bud["slice_d100"], bud["slice_d100_lockstep"]
-    ex["slice_d100_roofline"] = valu_roofline(f"k_diagt<3, {lay[2] // 2}, {lay[1]},", ls, attrs=at, budget=bs,
+    ex["slice_d100_roofline"] = valu_roofline(f"k_diagt_slice_free<{lay[1]},", ls, attrs=at, budget=bs,
                                               necessary_per_launch=bs["per_wave_transition"] * (n // bs["chains_per_wave"]) * SLICE_SPL)
+    ex["slice_d100_roofline"]["transitions_per_launch"] = SLICE_SPL
     ex["slice_d100_roofline"]["frac_lockstep"] = 4.0 * bsl["per_wave_transition"] * (n // bsl["chains_per_wave"]) * SLICE_SPL / ls / (NSIMD * CLOCK_HZ)
 
     # -- the two data-model configurations of BASELINE.json at their per-GPU share (cfg 4: 262,144 / 8 chains of the swiss

@@ -115,13 +115,15 @@ static bool diagt_eligible(const klara_desc& d)
     return true;
 }
 
-// the slice sampler on the pair-transposed layout with nothing counting and no history kept: every lane takes its elements through a whole launch on
+// the slice sampler on the pair-transposed layout with nothing counting: every lane takes its elements through a whole launch on
 // its own (klara_diagt_slice.h); a wavefront only waits for its slowest lane once per element slot and launch, so longer launches waste less
 static bool slice_free_eligible(const klara_desc& d)
 {
     static const bool lockstep = getenv("KLARA_SLICE_LOCKSTEP") != nullptr;
-    return diagt_eligible(d) && d.sampler == KLARA_SAMPLER_SLICE && !cnt_predicate(d) && d.acov_maxlag == 0 && !lockstep &&
-           (d.monitor & ~(uint32_t)(KLARA_MON_ACCEPT | KLARA_MON_SUMMARIES)) == 0;
+    const uint32_t lane_local = KLARA_MON_ACCEPT | KLARA_MON_SUMMARIES | KLARA_MON_HISTORY | KLARA_MON_HIST_LT;
+    const bool values_kept = (d.monitor & KLARA_MON_HISTORY) != 0 || d.acov_maxlag > 0;       // (the log-target history is formed from the saved values)
+    return diagt_eligible(d) && d.sampler == KLARA_SAMPLER_SLICE && !cnt_predicate(d) && !lockstep &&
+           (d.monitor & ~lane_local) == 0 && (!(d.monitor & KLARA_MON_HIST_LT) || values_kept);
 }
 // transitions per launch when klara_desc.steps_per_launch = 0
 static long long default_steps_per_launch(const klara_desc& d) { return slice_free_eligible(d) ? KLARA_DEFAULT_STEPS_PER_LAUNCH_SLICE : KLARA_DEFAULT_STEPS_PER_LAUNCH; }
@@ -988,6 +990,7 @@ static void part_range(const klara_handle* h, int nparts, int j, long long* c0, 
     if (*c1 > N) *c1 = N;
 }
 
+static long long saved_upto(const klara_desc& d, long long steps);       // (launch planning, below)
 static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
 {
     const klara_desc& d = h->d;
@@ -1035,7 +1038,13 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
                 switch (d.sampler) {                                                                                                          \
                 case KLARA_SAMPLER_MH: return klara_launch_diagt_mh##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);        \
                 case KLARA_SAMPLER_SLICE:                                                                                                     \
-                    if (slice_free) return klara_launch_diagt_slice_free##SUFFIX(p, kp, np, unitw, sums, ka, nw, st);                          \
+                    if (slice_free) {                                                                                                         \
+                        const hipError_t e_ = klara_launch_diagt_slice_free##SUFFIX(p, kp, np, unitw, mon, ka, nw, st);                        \
+                        if (e_ != hipSuccess || h->hist_lt == nullptr || query) return e_;                                                    \
+                        /* the saved states' log-targets, from their saved values (klara_diagt_slice.h) */                                   \
+                        const long long nsaved_ = saved_upto(d, (long long)kl.t0 + kl.nsteps) - saved_upto(d, (long long)kl.t0);              \
+                        return klara_launch_diagt_hist_lt##SUFFIX(p, kp, np, unitw, kl.save_col0, (int)nsaved_, nw, st);                       \
+                    }                                                                                                                         \
                     return klara_launch_diagt_slice##SUFFIX(p, kp, np, unitw, mon, tune, ka, nw, st);                                          \
                 case KLARA_SAMPLER_MALA: return klara_launch_diagt_mala##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);    \
                 default: return klara_launch_diagt_hmc##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);                     \

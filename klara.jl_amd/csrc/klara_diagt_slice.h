@@ -26,8 +26,10 @@
 // transitions per launch.  The new state's log-target is formed once, after the launch's last transition, in the layout's order (lane partials
 // over ascending elements, butterfly over the chain's Q lanes) — the same bits round 4's kernel and the oracle produce.
 //
-// Scope: untuned jobs whose monitors are the accept diagnostics and / or the running sums (any thinning / burn-in; the sums are lane-local too).
-// A job that counts proposals (verbose) or keeps a history (values, logtarget per saved step) runs k_diagt<SLICE>: the same draws, the same bits.
+// Scope: untuned jobs; monitors: the accept diagnostics, the running sums and the value history (any thinning / burn-in, ring or not) are lane-local
+// like the updates themselves — a machine stores its element of a saved state when ITS transition ends; the log-target history of the saved states
+// is formed afterwards from the saved values by k_diagt_hist_lt, in the layout's order.  A job that counts proposals (verbose tuner) runs
+// k_diagt<SLICE>: the same draws, the same bits.
 #pragma once
 #include "klara_diagt.h"
 
@@ -83,6 +85,7 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
         const unsigned long long gchain = (unsigned long long)(p.chain_offset + chain);
         const __amdgpu_buffer_rsrc_t wx = group_window(p.X, first_chain, here, D);
         const bool do_sum = SUMS && p.sum != nullptr;
+        const bool do_hist = SUMS && p.hist != nullptr;                  // (SUMS: a saved-sample monitor is on — running sums and / or value history)
         __amdgpu_buffer_rsrc_t wsum = wx, wsq = wx;
         int held0 = 0;                                 // (saved steps held at the current state: 0 or 1 between this sampler's launches)
         if (do_sum) {
@@ -94,6 +97,8 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
         const bool stepout = p.stepout != 0;
         const long long burnin = p.burnin, nsteps_total = p.nsteps_total;
         const int thinning = (int)p.thinning;
+        gdouble* const hist0 = p.hist;
+        const int hist_cols = (int)p.hist_cols;
         double red = 0.0;
         int held_out = held0;
         bool stuck_any = false;
@@ -116,7 +121,7 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
             }
             double wt[NM], mu[NM], wd[NM], tcur[NM], L[NM], R[NM], lgu[NM];
             uint32_t base[NM];
-            int tl[NM], k[NM], sphase[NM];
+            int tl[NM], k[NM], sphase[NM], scol[NM];
             int held[NM];
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
@@ -125,7 +130,7 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
                 wt[m] = UNITW ? 1.0 : lds_w[i]; mu[m] = UNITW ? 0.0 : lds_mu[i]; wd[m] = lds_wd[i];
                 tcur[m] = slicef_term<UNITW>(x[m], wt[m], mu[m]);
                 base[m] = (uint32_t)(live ? i : 0) << KLARA_SLICE_ATT_BITS;
-                tl[m] = live ? 0 : nsteps; k[m] = 0; sphase[m] = kl.save_phase0; held[m] = held0;     // (tl = nsteps + 1: the machine is stuck)
+                tl[m] = live ? 0 : nsteps; k[m] = 0; sphase[m] = kl.save_phase0; scol[m] = (int)kl.save_col0; held[m] = held0;     // (tl = nsteps + 1: the machine is stuck)
                 L[m] = x[m]; R[m] = x[m]; lgu[m] = 0.0;
             }
 
@@ -223,7 +228,11 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
                         const uint32_t tlo = t0lo + (uint32_t)tl[m], thi = t0hi + (tlo < t0lo ? 1u : 0u);
                         const long long i1 = (long long)(((unsigned long long)thi << 32) | tlo) + 1;
                         const bool post = done && i1 > burnin && i1 <= nsteps_total;
-                        held[m] += (post && sphase[m] == 0) ? 1 : 0;
+                        const bool savenow = post && sphase[m] == 0;
+                        held[m] += savenow ? 1 : 0;
+                        if (do_hist && savenow && scol[m] < hist_cols)                         // copy!(nstate, state, i): this element of column scol
+                            hist0[((long long)scol[m] * p.nchains + chain) * D + ei[m]] = xn;
+                        scol[m] += savenow ? 1 : 0;
                         sphase[m] = post ? ((sphase[m] + 1 == thinning) ? 0 : sphase[m] + 1) : sphase[m];
                     }
                     k[m] = more ? knext : 0;
@@ -258,4 +267,39 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
         if (stuck_any && chain_ok) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);
     }
     auto_finish(ka, wave_acc);
+}
+
+// The log-target of the saved states of a launch, formed from the saved VALUES (hist columns [col0, col0 + ncols)): lt = c - sum_i w_i (x_i - mu_i)^2 in
+// the layout's order — lane partials over the lane's elements ascending, butterfly over the chain's Q lanes — i.e. the bits k_diagt<SLICE> keeps per
+// saved step (its log-target after a transition is that full evaluation).  One wavefront per (column, chain group).
+template <int Q, bool UNITW>
+__global__ __launch_bounds__(256) void k_diagt_hist_lt(const KParams* __restrict__ pp, const KLaunch kl, const int NP, const long long col0, const int ncols)
+{
+    constexpr int CPW = 64 / Q;
+    const KParams& p = *pp;
+    const int D = p.D;
+    const int lane = threadIdx.x & 63, q = lane & (Q - 1), cw = lane / Q;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long ngroups = kl.group_end - kl.group0;
+    if (wave >= ngroups * ncols) return;
+    const long long grp = kl.group0 + wave % ngroups, col = col0 + wave / ngroups;
+    const long long first_chain = grp * CPW;
+    if (first_chain >= p.nchains || col >= p.hist_cols) return;
+    const long long left = p.nchains - first_chain;
+    const int here = left < CPW ? (int)left : CPW;
+    const __amdgpu_buffer_rsrc_t wh = group_window(p.hist, col * p.nchains + first_chain, here, D);
+    double red[1] = { 0.0 };
+    for (int ps = 0; ps < NP; ++ps) {
+        const int P = ps * Q + q;
+        const unsigned off = 2 * P < D ? (unsigned)((cw * D + 2 * P) * 8) : KLARA_BUF_OOB;
+        const kd_uint4 t = __builtin_amdgcn_raw_buffer_load_b128(wh, off, 0, 0);
+        const double x0 = __builtin_bit_cast(double, kd_uint2{ t.x, t.y }), x1 = 2 * P + 1 < D ? __builtin_bit_cast(double, kd_uint2{ t.z, t.w }) : 0.0;
+        const bool in0 = 2 * P < D, in1 = 2 * P + 1 < D;
+        const double w0 = (!UNITW && p.gw != nullptr && in0) ? p.gw[2 * P] : 1.0, w1 = (!UNITW && p.gw != nullptr && in1) ? p.gw[2 * P + 1] : 1.0;
+        const double m0 = (!UNITW && p.gmu != nullptr && in0) ? p.gmu[2 * P] : 0.0, m1 = (!UNITW && p.gmu != nullptr && in1) ? p.gmu[2 * P + 1] : 0.0;
+        red[0] = red[0] + slicef_term<UNITW>(x0, w0, m0);
+        red[0] = red[0] + slicef_term<UNITW>(x1, w1, m1);
+    }
+    group_allreduce<1>(red, Q, lane);
+    if (cw < here && q == 0) p.hist_lt[col * p.nchains + first_chain + cw] = p.gconst - red[0];
 }

@@ -27,8 +27,9 @@ hipError_t KLARA_DIAGT_FN(klara_launch_diagt_slice)(const KParams* p, const KLau
 }
 
 // untuned jobs without a history monitor: every lane takes its element pairs through the whole launch on its own (klara_diagt_slice.h)
-hipError_t KLARA_DIAGT_FN(klara_launch_diagt_slice_free)(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool sums, const KAuto& ka, long long nwaves, hipStream_t st)
+hipError_t KLARA_DIAGT_FN(klara_launch_diagt_slice_free)(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, const KAuto& ka, long long nwaves, hipStream_t st)
 {
+    const bool sums = mon;      // (template flag SUMS: a saved-sample monitor — running sums and / or value history — is on)
     if (NP < 1 || NP > KLARA_SLICEF_MAXNP) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((nwaves + 3) / 4)), blk(256);
     static const int nm = getenv("KLARA_SLICE_MACHINES") ? atoi(getenv("KLARA_SLICE_MACHINES")) : KLARA_SLICEF_DEFAULT_NM;
@@ -40,4 +41,14 @@ hipError_t KLARA_DIAGT_FN(klara_launch_diagt_slice_free)(const KParams* p, const
     if (sums) return KLARA_SLICEF_GO(false, true);
     return KLARA_SLICEF_GO(false, false);
 #undef KLARA_SLICEF_GO
+}
+
+// log-target history of the `ncols` states a launch of the kernel above saved (columns col0 ...), from their saved values
+hipError_t KLARA_DIAGT_FN(klara_launch_diagt_hist_lt)(const KParams* p, const KLaunch& kl, int NP, bool unitw, long long col0, int ncols, long long ngroups, hipStream_t st)
+{
+    if (ncols <= 0 || ngroups <= 0) return hipSuccess;
+    const long long nwaves = ngroups * ncols;
+    const dim3 grid((unsigned)((nwaves + 3) / 4)), blk(256);
+    return unitw ? klara_go(k_diagt_hist_lt<KLARA_DIAGT_Q, true>, grid, blk, 0, st, p, kl, NP, col0, ncols)
+                 : klara_go(k_diagt_hist_lt<KLARA_DIAGT_Q, false>, grid, blk, 0, st, p, kl, NP, col0, ncols);
 }

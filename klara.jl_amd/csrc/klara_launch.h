@@ -53,7 +53,8 @@ hipError_t klara_launch_mfma4_probe(const double* A, const double* B, const doub
     hipError_t klara_launch_diagt_mala##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, const KAuto& ka, long long nwaves, hipStream_t st); \
     hipError_t klara_launch_diagt_hmc##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, const KAuto& ka, long long nwaves, hipStream_t st);  \
     hipError_t klara_launch_diagt_slice##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, bool tune, const KAuto& ka, long long nwaves, hipStream_t st);                      \
-    hipError_t klara_launch_diagt_slice_free##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool sums, const KAuto& ka, long long nwaves, hipStream_t st);                          \
+    hipError_t klara_launch_diagt_slice_free##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool unitw, bool mon, const KAuto& ka, long long nwaves, hipStream_t st);                           \
+    hipError_t klara_launch_diagt_hist_lt##SUFFIX(const KParams* p, const KLaunch& kl, int NP, bool unitw, long long col0, int ncols, long long ngroups, hipStream_t st);                              \
     hipError_t klara_launch_diagt_init##SUFFIX(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
 KLARA_DIAGT_DECLARE()
 KLARA_DIAGT_DECLARE(_q16)

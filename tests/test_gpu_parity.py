@@ -673,6 +673,32 @@ def test_history_of_all_monitored_fields(name):
     eng.close()
 
 
+@pytest.mark.parametrize("spl,ring", [(7, 0), (0, 0), (5, 4)])
+def test_slice_sampler_out_of_lockstep_keeps_history_sums_and_logtargets(spl, ring):
+    """The free-running slice kernel (klara_diagt_slice.h: every lane takes its elements through a launch on its own) with every monitor it serves:
+    value history (a machine stores its element of a saved state when ITS transition ends), log-target history (formed afterwards from the saved
+    values, k_diagt_hist_lt), running sums, accept diagnostics — burn-in 4, thinning 3, several launches, a history ring — against the oracle
+    bit for bit: final state, sums, every saved column of three chains (the ragged last wavefront group among them)."""
+    case = dict(cases.make_case("slice_d20_stepout"), nchains=45, nsteps=31, burnin=4, thinning=3)
+    case["x0"] = np.random.default_rng(12).standard_normal((45, 20))
+    mon = L.MON_HISTORY | L.MON_HIST_LT | L.MON_SUMMARIES | L.MON_ACCEPT
+    eng = K.Engine(**cases.engine_kwargs(case, monitor=mon, steps_per_launch=spl, hist_ring_cols=ring))
+    assert eng.layout()[0] == 3
+    job = O.OracleJob(**cases.oracle_kwargs(case, layout=eng.layout()), want_hist=True)
+    eng.set_state(case["x0"]); job.set_state(case["x0"])
+    for k in (13, 18):
+        eng.run(k); assert job.run(k) == 0
+    _assert_same(eng, job, case)
+    nsaved = eng.saved_steps()
+    assert nsaved == 9
+    keep = min(ring, nsaved) if ring else nsaved
+    for c in (0, 22, 44):
+        lt, _ = eng.chain_fields(c, True, False)
+        assert np.array_equal(eng.chain(c), job.hist[nsaved - keep:, c, :].T), c
+        assert np.array_equal(lt, job.hist_lt[nsaved - keep:, c]), c
+    eng.close()
+
+
 def test_monitored_fields_and_iostream_sink(tmp_path):
     """doc/examples/swiss/MALA/analytical.jl:36-44: monitor [:value, :logtarget, :gradlogtarget], diagnostics
     [:accept] — kept per saved step on device, bit-equal to the oracle, and written by the :iostream destination
