@@ -221,7 +221,7 @@ typedef struct klara_desc {
                                     the LAST hist_ring_cols saved steps (a ring): bounded memory for jobs that drain the samples as
                                     they go (the :iostream destination with :flush, jobs.jl:17-29).  0: every saved step is kept. */
     int32_t  acov_maxlag;        /* > 0: lagged cross-products of every (chain, dimension) series are accumulated while sampling
-                                    (lags 0..acov_maxlag, at most 31), so that Geyer's initial monotone / positive sequence estimators
+                                    (lags 0..acov_maxlag, at most 127: 3 (maxlag + 1) doubles per series), so that Geyer's initial monotone / positive sequence estimators
                                     (mcvar(:imse | :ipse, maxlag), mcvar.jl:75-105,137-158) need no stored history:
                                     klara_get_chain_acov_mcvar.  Uses a value ring of its own when no history monitor is on. */
     int32_t  sparse_moves;       /* how untuned MH / MALA jobs on the diagonal Gaussian (17 <= D <= 104) keep their running sums.  Two kernel

@@ -284,7 +284,7 @@ def chain_mcvar(chains: MuvChains, vtype: str = "imse", batchlen: int = 100, max
         return job.engine.chain_bm()[0]            # streaming batch means: no history was stored
     streamed = job.acov_maxlag > 0 and not (job.engine.monitor & L.MON_HISTORY)
     if vtype in ("imse", "ipse") and streamed:
-        # The autocovariances kept while sampling stop at lag acov_maxlag (<= 31); the reference's maxlag = 0 means n - 1
+        # The autocovariances kept while sampling stop at lag acov_maxlag (<= 127); the reference's maxlag = 0 means n - 1
         # (mcvar.jl:75).  The streamed estimator is therefore only returned for the lag window it was built for — asked for
         # explicitly, maxlag == acov_maxlag — and anything else needs the stored values (a slowly mixing chain whose
         # Geyer sequence has not turned non-positive by lag 31 would be silently underestimated).

@@ -49,7 +49,7 @@ struct klara_handle {
     double* hist = nullptr; long long hist_cols = 0;     // hist_cols: columns of the history buffers (= ring when > 0 and ring is set)
     bool ring = false;                                   // the history buffers hold the last hist_cols saved steps only
     // streaming autocovariances (acov_maxlag > 0): W = maxlag + 1 lags; [k][series] layouts
-    int acov_W = 0; double *acov_S = nullptr, *acov_head = nullptr, *acov_tail = nullptr, *acov_total = nullptr; long long acov_n = 0;
+    int acov_W = 0; double *acov_S = nullptr, *acov_head = nullptr, *acov_tail = nullptr, *acov_total = nullptr, *acov_near = nullptr; long long acov_n = 0;
     double *hist_lt = nullptr, *hist_g = nullptr, *hist_ll = nullptr, *hist_lp = nullptr;
     unsigned long long* clock_probe = nullptr;        // pair-transposed kernels: (s_memtime, s_memrealtime) at the end / start of one workgroup of the last launch
     bool pair_enqueued = false;                       // a launch of this handle has enqueued both kernel families (their one-time scratch set-up is behind us)
@@ -294,7 +294,7 @@ static klara_status validate(const klara_desc* d)
         return KLARA_ERR_INVALID_ARG;
     if (d->target == KLARA_TARGET_CUSTOM && (!d->custom_src || d->custom_ndata < 0 || (d->custom_ndata > 0 && !d->custom_data)))
         return KLARA_ERR_INVALID_ARG;
-    if (d->hist_ring_cols < 0 || d->acov_maxlag < 0 || d->acov_maxlag > 31 || d->sparse_moves < 0 || d->sparse_moves > 2) return KLARA_ERR_INVALID_ARG;
+    if (d->hist_ring_cols < 0 || d->acov_maxlag < 0 || d->acov_maxlag > 127 || d->sparse_moves < 0 || d->sparse_moves > 2) return KLARA_ERR_INVALID_ARG;
     if (d->bm_batchlen < 0 || (d->bm_batchlen > 0 && !(d->monitor & KLARA_MON_SUMMARIES))) return KLARA_ERR_INVALID_ARG;
     if (d->steps_per_launch < 0 || d->tuner_score < 0 || d->tuner_score > 1) return KLARA_ERR_INVALID_ARG;   // (int32: a launch length always fits KLaunch::nsteps)
     return KLARA_OK;
@@ -387,7 +387,7 @@ static bool free_all(klara_handle* h)
     bool ok = true;
     ok &= dfree(h->X); ok &= dfree(h->GR); ok &= dfree(h->LT); ok &= dfree(h->tune_step); ok &= dfree(h->tune_acc);
     ok &= dfree(h->tune_prop); ok &= dfree(h->tune_tot); ok &= dfree(h->da_epsbar); ok &= dfree(h->da_hbar); ok &= dfree(h->pooled_acc); ok &= dfree(h->accept);
-    ok &= dfree(h->naccept); ok &= dfree(h->sum); ok &= dfree(h->sumsq); ok &= dfree(h->held); ok &= dfree(h->hist); ok &= dfree(h->acov_S); ok &= dfree(h->acov_head); ok &= dfree(h->acov_tail); ok &= dfree(h->acov_total); ok &= dfree(h->hist_lt); ok &= dfree(h->hist_g); ok &= dfree(h->hist_ll); ok &= dfree(h->hist_lp); if (!h->flag_host) ok &= dfree(h->err);
+    ok &= dfree(h->naccept); ok &= dfree(h->sum); ok &= dfree(h->sumsq); ok &= dfree(h->held); ok &= dfree(h->hist); ok &= dfree(h->acov_S); ok &= dfree(h->acov_head); ok &= dfree(h->acov_tail); ok &= dfree(h->acov_total); ok &= dfree(h->acov_near); ok &= dfree(h->hist_lt); ok &= dfree(h->hist_g); ok &= dfree(h->hist_ll); ok &= dfree(h->hist_lp); if (!h->flag_host) ok &= dfree(h->err);
     ok &= dfree(h->vecparam); ok &= dfree(h->gw); ok &= dfree(h->gmu); ok &= dfree(h->lX); ok &= dfree(h->ly); ok &= dfree(h->hY); ok &= dfree(h->hxc);
     ok &= dfree(h->Pfrag); ok &= dfree(h->pooled_out); ok &= dfree(h->pool_partial); ok &= dfree(h->d_params); ok &= dfree(h->cdata);
     ok &= dfree(h->bm_prev); ok &= dfree(h->bm_mean); ok &= dfree(h->bm_m2); ok &= dfree(h->auto_cells); ok &= dfree(h->auto_ctr); ok &= dfree(h->clock_probe);
@@ -635,6 +635,7 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
             h->acov_W = desc->acov_maxlag + 1;
             const size_t ws = (size_t)h->acov_W * N * D;
             CKH(dalloc(&h->acov_S, ws)); CKH(dalloc(&h->acov_head, ws)); CKH(dalloc(&h->acov_tail, ws)); CKH(dalloc(&h->acov_total, N * D));
+            if (h->acov_W > 32) CKH(dalloc(&h->acov_near, (size_t)32 * N * D));      // (scratch of the far-tail update, launch_acov_update)
         }
         if (desc->monitor & KLARA_MON_HIST_LT) CKH(dalloc(&h->hist_lt, (size_t)h->hist_cols * N));
         if (desc->monitor & KLARA_MON_HIST_LLLP) { CKH(dalloc(&h->hist_ll, (size_t)h->hist_cols * N)); CKH(dalloc(&h->hist_lp, (size_t)h->hist_cols * N)); }
@@ -1252,14 +1253,69 @@ __global__ __launch_bounds__(256) void k_acov_update(const double* __restrict__ 
     total[i] = tot;
 }
 
+// Lags 32 b .. 32 b + 31 (b >= 1; windows beyond 32 lags, klara_desc.acov_maxlag up to 127): the cross-products of x with its own history delayed by
+// 32 b samples, y_j = x_(j - 32 b) — the same 32-lag update on the pair (x, y): S_(32b + r) += x_j y_(j - r).  y comes from the launch's own
+// columns where j >= 32 b and from the tail kept by the earlier launches (tail[k] = the (k + 1)-th most recent sample before this launch)
+// otherwise; the passes of the higher blocks run BEFORE the lag-0 pass rewrites the tail.
+__global__ __launch_bounds__(256) void k_acov_update_block(const double* __restrict__ hist, long long col0, int m, int b, int W, long long nd,
+                                                           double* __restrict__ S, const double* __restrict__ tail)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nd) return;
+    const int k0 = 32 * b;
+    double s[32], win[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        s[r] = k0 + r < W ? S[(long long)(k0 + r) * nd + i] : 0.0;
+        win[r] = k0 + r < W ? tail[(long long)(k0 + r) * nd + i] : 0.0;            // y_(-1-r) = x_(-1-r-k0)   (zeros where no sample exists yet)
+    }
+    for (int j = 0; j < m; ++j) {
+        const double x = hist[(col0 + j) * nd + i];
+        const double y = j >= k0 ? hist[(col0 + j - k0) * nd + i] : tail[(long long)(k0 - j - 1) * nd + i];
+        s[0] = s[0] + x * y;
+#pragma unroll
+        for (int r = 1; r < 32; ++r) s[r] = s[r] + x * win[r - 1];
+#pragma unroll
+        for (int r = 31; r > 0; --r) win[r] = win[r - 1];
+        win[0] = y;
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) if (k0 + r < W) S[(long long)(k0 + r) * nd + i] = s[r];
+}
+// ... and the tail of a window beyond 32 lags, after the lag-0 pass (which has moved entries 0..31): entries 32 .. W-1 take the samples that are now
+// 33 .. W back — from this launch's columns or from the old tail, moved from the far end so that nothing is overwritten before it is read
+__global__ __launch_bounds__(256) void k_acov_tail_far(const double* __restrict__ hist, long long col0, int m, int W, long long nd,
+                                                       double* __restrict__ tail, const double* __restrict__ old_near)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nd) return;
+    for (int k = W - 1; k >= 32; --k) {                     // new tail[k] = x_(m-1-k): a column of this launch, or the old tail[k - m]
+        double v;
+        if (k < m) v = hist[(col0 + m - 1 - k) * nd + i];
+        else if (k - m >= 32) v = tail[(long long)(k - m) * nd + i];            // (an entry further down: not yet overwritten — k descends)
+        else v = old_near[(long long)(k - m) * nd + i];                          // (one of the first 32 entries as they were BEFORE the lag-0 pass)
+        tail[(long long)k * nd + i] = v;
+    }
+}
+
 static hipError_t launch_acov_update(klara_handle* h, long long col0, long long m)
 {
     const long long nd = (long long)h->d.nchains * h->d.ndims;
     const dim3 grid((unsigned)((nd + 255) / 256)), blk(256);
     const int W = h->acov_W;
+    if (W > 32) {       // windows beyond 32 lags: the higher lag blocks first (they read the tail as the earlier launches left it)
+        for (int b = (W - 1) / 32; b >= 1; --b)
+            hipLaunchKernelGGL(k_acov_update_block, grid, blk, 0, h->stream, h->hist, col0, (int)m, b, W, nd, h->acov_S, h->acov_tail);
+        // (the lag-0 pass below rewrites tail[0..31]; the far tail needs their old values when fewer than 32 samples arrive: keep a copy)
+        hipError_t e = hipMemcpyAsync(h->acov_near, h->acov_tail, (size_t)32 * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+        if (e != hipSuccess) return e;
+    }
+    const int W0 = W < 32 ? W : 32;
     if (W <= 8) hipLaunchKernelGGL((k_acov_update<8>), grid, blk, 0, h->stream, h->hist, col0, (int)m, h->acov_n, W, nd, h->acov_S, h->acov_head, h->acov_tail, h->acov_total);
     else if (W <= 16) hipLaunchKernelGGL((k_acov_update<16>), grid, blk, 0, h->stream, h->hist, col0, (int)m, h->acov_n, W, nd, h->acov_S, h->acov_head, h->acov_tail, h->acov_total);
     else hipLaunchKernelGGL((k_acov_update<32>), grid, blk, 0, h->stream, h->hist, col0, (int)m, h->acov_n, W, nd, h->acov_S, h->acov_head, h->acov_tail, h->acov_total);
+    (void)W0;
+    if (W > 32) hipLaunchKernelGGL(k_acov_tail_far, grid, blk, 0, h->stream, h->hist, col0, (int)m, W, nd, h->acov_tail, h->acov_near);
     return hipGetLastError();
 }
 

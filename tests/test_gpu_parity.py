@@ -1120,17 +1120,20 @@ def test_history_ring_keeps_the_last_saved_steps(name, ring, pieces):
     full.close(); part.close()
 
 
-@pytest.mark.parametrize("name,maxlag", [("mala_d3_tuned", 9), ("hmc_d10_tuned_pooled", 6), ("dt_mala_d100_small_step", 15), ("mh_readme", 31)])
-def test_streaming_autocovariance_estimators(name, maxlag):
+@pytest.mark.parametrize("name,maxlag,spl,mon", [("mala_d3_tuned", 9, 7, 0), ("hmc_d10_tuned_pooled", 6, 7, 0), ("dt_mala_d100_small_step", 15, 7, 0), ("mh_readme", 31, 7, 0),
+                                                 # windows beyond 32 lags (lag blocks of 32; round 5): the estimator's own 32-column ring (launches of <= 32 saved samples: the delayed
+                                                 # sequence comes from the kept tail), and with a value history and 50-transition launches (it comes from the launch's own columns too)
+                                                 ("mh_readme", 100, 7, 0), ("mh_readme", 127, 50, L.MON_HISTORY), ("mala_d3_tuned", 40, 50, L.MON_HISTORY)])
+def test_streaming_autocovariance_estimators(name, maxlag, spl, mon):
     """klara_desc.acov_maxlag: mcvar(:imse, maxlag) and mcvar(:ipse, maxlag) (mcvar.jl:75-105, 137-158) of every (chain, dimension)
     series from cross-products accumulated while sampling — no stored history — against (a) the NumPy restatement
     (klara_jl_amd.stats, FFT autocovariance) on individual chains of a full-history twin of the job, (b) the device's post-hoc
     estimators over that history.  Tolerance 1e-8 relative: three ways of summing the same products."""
     case = cases.make_case(name)
-    n = {"mh_readme": 3000}.get(name, case["nsteps"])
+    n = {"mh_readme": 3000}.get(name, max(case["nsteps"], 6 * maxlag + case.get("burnin", 0)))
     case = dict(case, nsteps=n)
     twin = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_HISTORY))
-    eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_SUMMARIES, acov_maxlag=maxlag, steps_per_launch=7))
+    eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_SUMMARIES | mon, acov_maxlag=maxlag, steps_per_launch=spl))
     for e in (twin, eng):
         e.set_state(case["x0"]) if case["x0"] is not None else e.init_state_normal()
     twin.run(n)
