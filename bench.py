@@ -49,7 +49,7 @@ CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock; 256 CUs x 4 SIMDs
 NSIMD = 1024
 # How the running sums of a moving chain are kept (4-lane kernels + atomic folds, or 8-lane kernels + resident sums) is decided by the
 # library itself, on the device, launch by launch (klara_desc.sparse_moves = 0): no caller hint.
-PMC_JSON = ROOT / "profiles" / "r4_pmc_kernels.json"
+PMC_JSON = ROOT / "profiles" / "r5_pmc_kernels.json"
 PMC_EXPECT = {}             # filled by main(): the launch length the committed counters must have been collected at
 
 

@@ -108,6 +108,28 @@ def test_cfg2_mala_moments_within_1e3():
     eng.close()
 
 
+# ------------------------------------------------------------------ the slice sampler at the headline shape
+def test_slice_sampler_d100_moments_within_1e3():
+    """north_star names the slice sampler among the four samplers of the path: SliceSampler(widths 1, stepping out) on lt = -|x|^2, D = 100, 65,536 chains,
+    x0 ~ N(0, I), 1,200 transitions after a burn-in of 200 — the kernel whose lanes run out of lockstep (klara_diagt_slice.h), running sums on, the
+    library's own launch length.  Truth: mean 0, variance 1/2; five measured standard errors of the pooled mean below 1e-3."""
+    n, d = 65536, 100
+    eng = K.Engine(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.negdot(d), nchains=n, nsteps=1400, burnin=200, slice_widths=np.ones(d),
+                   monitor=L.MON_SUMMARIES, bm_batchlen=50)
+    assert eng.layout()[0] == 3
+    eng.init_state_normal()
+    eng.run(1400)
+    mean, var, acc, ns = _pooled_moments(eng)
+    se = _pooled_mean_se(eng)
+    x, lt, _ = eng.state()
+    assert np.allclose(lt, -(x * x).sum(axis=1), rtol=1e-12)
+    print("slice d100: se", se.max(), "mean err", np.max(np.abs(mean)), "var err", np.max(np.abs(var - 0.5)))
+    assert ns == 1200 and acc == 1.0
+    assert 5 * se.max() < TOL, se.max()
+    assert np.max(np.abs(mean)) < TOL and np.max(np.abs(var - 0.5)) < TOL, (np.max(np.abs(mean)), var.min(), var.max())
+    eng.close()
+
+
 # ------------------------------------------------------------------ cfg 3: HMC on the dense 100-dim Gaussian (FP64 MFMA)
 def _device_copy(dst_tensor, src_ptr):
     """device-to-device copy of the engine's state matrix into a torch tensor (plumbing for the checker only)."""
