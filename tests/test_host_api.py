@@ -497,6 +497,74 @@ def test_committed_bench_lines_are_complete_and_recomputable():
         assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and d["value"] / cb["value"] > 10
 
 
+def test_round5_bench_lines_are_complete_and_recomputable():
+    """profiles/r5_bench_{default,driver_flags}.json, the JSON lines bench.py printed on the closing box: the driver's keys; the headline fraction recomputed from
+    the committed budget and the line's own launch duration, its VALU-busy figure from the committed counters (profiles/r5_pmc_kernels.json), rocprofv3's average of
+    the same kernel (profiles/r5_bench_headline_kernel_stats.csv) within 3 % of the HIP-event duration; every other configuration's roofline object; the slice
+    sampler's counters (frac >= 0.45, SALU / VALU <= 0.3, >= 9e10 coordinate updates/s); cfg 3 at >= 0.88 of the MFMA peak with 0 B scratch."""
+    import csv, json
+    pmc = json.loads((ROOT / "profiles" / "r5_pmc_kernels.json").read_text())
+    stats = {r["Name"]: r for r in csv.DictReader((ROOT / "profiles" / "r5_bench_headline_kernel_stats.csv").open())}
+    head_avg_us = float(next(v for k, v in stats.items() if k.startswith("void k_diagt<1, 13, 4, false, true, true,"))["AverageNs"]) * 1e-3
+    for name in ("r5_bench_default.json", "r5_bench_driver_flags.json"):
+        d = json.loads((ROOT / "profiles" / name).read_text())
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in d, (name, k)
+        assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and d["unit"] == "transitions/s"
+        assert "configs[1]" in d["config"]["workload"] and d["config"]["save_rule"].startswith("running sums")
+        assert d["value"] == pytest.approx(d["config"]["nchains_total"] / (d["ms_per_step"] * 1e-3), rel=1e-9)
+        rf = d["roofline"]
+        assert rf["bound"] == "valu" and rf["budget"]["per_wave_transition"] == 1505.0
+        nec = 1505.0 * 4096 * 32
+        assert rf["necessary_valu_insts_per_launch"] == nec
+        assert rf["frac"] == pytest.approx(4.0 * nec / (rf["launch_us"] * 1e-6) / (1024 * 2.4e9), rel=1e-9) and 0.65 < rf["frac"] < 1.0
+        assert abs(rf["launch_us"] / head_avg_us - 1.0) < 0.03, (rf["launch_us"], head_avg_us)
+        row = next(r for r in pmc["kernels"] if r["kernel"] == rf["pmc"]["kernel"] and r.get("grid") == 262144)
+        assert rf["pmc"]["stale"] is False
+        assert rf["utilisation"] == pytest.approx(4.0 * row["counters"]["SQ_ACTIVE_INST_VALU"]["mean"] / (rf["launch_us"] * 1e-6) / (1024 * 2.4e9), rel=1e-6)
+        assert rf["issued_over_necessary"] == pytest.approx(row["counters"]["SQ_INSTS_VALU"]["mean"] / nec, rel=1e-9) and rf["issued_over_necessary"] < 1.12
+        h = rf["hbm"]
+        assert h["contract_2S_plus_1_bytes_per_launch"] == 65536 * 3217 and h["traffic_over_minimal"] < 1.25 and h["traffic_frac_of_8TBs"] < 0.1
+        ex = d["extra"]
+        for key in ("cfg1_roofline", "cfg3_hmc_dense_roofline", "cfg4_roofline", "cfg5_roofline", "hmc_iso_roofline", "slice_d100_roofline", "mala_one_transition_per_launch_roofline"):
+            assert ex[key]["bound"] in ("valu", "mfma") and ex[key]["frac"] is not None and 0.3 < ex[key]["frac"] <= 1.0, (name, key, ex[key])
+        sl = ex["slice_d100_roofline"]
+        assert "k_diagt_slice_free<8, true, false, 1>" in sl["pmc"]["kernel"] and sl["pmc"]["stale"] is False and sl["pmc"]["loaded_scratch"] == 0
+        srow = next(r for r in pmc["kernels"] if r["kernel"] == sl["pmc"]["kernel"])
+        assert sl["frac"] >= 0.45 and sl["utilisation"] > 0.9 and sl["issued_over_necessary"] < 2.0
+        assert srow["counters"]["SQ_INSTS_SALU"]["mean"] / srow["counters"]["SQ_INSTS_VALU"]["mean"] < 0.3
+        assert ex["slice_d100_coordinate_updates_per_s"] >= 9e10
+        c3 = ex["cfg3_hmc_dense_roofline"]
+        assert c3["frac"] >= 0.88 and c3["pmc"]["loaded_scratch"] == 0 and "k_dense_transitions<2, 25, false, false, true>" in c3["pmc"]["kernel"]
+        assert ex["cfg3_hmc_dense_leapfrog_chain_per_s"] >= 1e8 and ex["hmc_iso_leapfrog_chain_per_s"] >= 1e8          # north_star's HMC target
+        cb = d["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_slice_and_dense_kernel_resources(tmp_path):
+    """No GPU needed: the free-running slice kernels (one machine per lane) fit 8 / 6 wavefronts per SIMD without scratch, and the cfg 3 kernel
+    (k_dense_transitions<HMC, NE = 25, PLAIN>) has no scratch (round 4: 64-80 B)."""
+    import re, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    meta = {}
+    for tu in ("klara_diagt_slice", "klara_dense"):
+        out = tmp_path / f"{tu}.s"
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", str(ROOT / "klara.jl_amd" / "csrc"),
+                            "-S", "--cuda-device-only", "-o", str(out), str(ROOT / "klara.jl_amd" / "csrc" / f"{tu}.hip")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for blk in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", out.read_text(), re.S):
+            t = blk.group(0)
+            meta[re.search(r"\.name:\s+(\S+)", t).group(1)] = {k: int(re.search(r"\." + k + r":\s+(\d+)", t).group(1)) for k in ("vgpr_count", "private_segment_fixed_size")}
+    free = {k: v for k, v in meta.items() if k.startswith("_Z18k_diagt_slice_freeILi8E") and k.split("EEv")[0].endswith("ELi1")}
+    assert len(free) == 4, sorted(free)
+    for k, v in free.items():
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_count"] <= (64 if "ILi8ELb1ELb0ELi1" in k else 80), (k, v)
+    plain = [v for k, v in meta.items() if k.startswith("_Z19k_dense_transitionsILi2ELi25ELb0E") and k.split("EEv")[0].endswith("Lb1")]
+    assert len(plain) == 2 and all(v["private_segment_fixed_size"] == 0 for v in plain), plain
+
+
 def test_basic_mc_range():
     r = K.BasicMCRange(nsteps=10000, burnin=1000)
     assert (r.nsteps, r.burnin, r.thinning, r.npoststeps) == (10000, 1000, 1, 9000)
