@@ -39,12 +39,15 @@ struct MfmaCtx {
     // the sums, and no sum needs a validity select.  Only the byte offsets of loads and stores depend on nv.
     // (nv_ comes from nv_here() at the access group's site; the base offset is hidden from the optimiser the same way — otherwise voff0 + 32 e
     // is hoisted out of the transition loop for every e: NE registers that the MFMA loop then pushes into scratch)
-    __device__ __forceinline__ unsigned off(int e, int nv_) const
+    __device__ __forceinline__ unsigned off_fresh(int e, int nv_) const
     {
         unsigned vb = voff0;
         __asm__ volatile("" : "+v"(vb));
         return e < nv_ ? vb + 32u * (unsigned)e : KLARA_BUF_OOB;
     }
+    // (the streamed kernels of klara_dense_big.h — one wavefront per SIMD, 512 registers — keep the plain form: the extra instruction per access
+    // cost their MH instantiation 3 %)
+    __device__ __forceinline__ unsigned off(int e, int nv_) const { return e < nv_ ? voff0 + 32u * (unsigned)e : KLARA_BUF_OOB; }
     // nv behind an empty asm: the NE offsets of an access group are formed where they are used (2 instructions each) instead of
     // being hoisted out of the transition loop as NE loop-invariant registers that the MFMA loop then forces into scratch
     __device__ __forceinline__ int nv_here() const { int n = nv; __asm__ volatile("" : "+v"(n)); return n; }
@@ -88,7 +91,7 @@ __device__ __forceinline__ void mload(const MfmaCtx<NE>& c, const gdouble* base,
     const __amdgpu_buffer_rsrc_t w = mwin<NE>(c, base, row0, D);
     const int nv = c.nv_here();
 #pragma unroll
-    for (int e = 0; e < NE; ++e) v[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(w, c.off(e, nv), 0, 0));
+    for (int e = 0; e < NE; ++e) v[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(w, c.off_fresh(e, nv), 0, 0));
 }
 template <int NE>
 __device__ __forceinline__ void mstore(const MfmaCtx<NE>& c, gdouble* base, int D, const double (&v)[NE], long long row0 = 0)
@@ -96,7 +99,7 @@ __device__ __forceinline__ void mstore(const MfmaCtx<NE>& c, gdouble* base, int 
     const __amdgpu_buffer_rsrc_t w = mwin<NE>(c, base, row0, D);
     const int nv = c.nv_here();
 #pragma unroll
-    for (int e = 0; e < NE; ++e) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, v[e]), w, c.off(e, nv), 0, 0);
+    for (int e = 0; e < NE; ++e) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, v[e]), w, c.off_fresh(e, nv), 0, 0);
 }
 
 // all-reduce over the 4 lanes (q = 0..3) of a chain: xor 16 then xor 32 — the canonical tree
@@ -489,7 +492,7 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 const int nv = cx.nv_here();
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
-                    const unsigned o = cx.off(e, nv);
+                    const unsigned o = cx.off_fresh(e, nv);
                     const double sv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ws, o, 0, 0));
                     const double qv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wq, o, 0, 0));
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sv + hf * xo[e]), ws, o, 0, 0);

@@ -28,6 +28,9 @@
 #else
 #define KLARA_BIG_PHASE() ((void)0)
 #endif
+#ifndef KLARA_BIG_NORMALS_GROUP
+#define KLARA_BIG_NORMALS_GROUP 1     // Box-Muller pairs the scheduler may interleave (one wavefront per SIMD: nothing else hides a pair's dependent chains)
+#endif
 #ifndef KLARA_BIG_RELOAD_CHUNK
 #define KLARA_BIG_RELOAD_CHUNK 8      // elements re-read per group after a rejected proposal
 #endif
@@ -84,7 +87,7 @@ __device__ __forceinline__ void mnormals_each(const MfmaCtx<NE>& c, unsigned lon
         const double recv = bperm_xor(odd ? z0 : z1, c.lane, 16);
         f(e, e < nv ? (odd ? recv : z0) : 0.0);
         f(e + 1, e + 1 < nv ? (odd ? z1 : recv) : 0.0);
-        __builtin_amdgcn_sched_barrier(0);
+        if ((e / 2 + 1) % KLARA_BIG_NORMALS_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -134,7 +137,8 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
 {
     static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH, "HMC, MALA, MH");
     constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;          // MH carries no gradient (GR is not written)
-    constexpr bool KEEPG = SAMPLER == KLARA_SAMPLER_HMC;         // the committed gradient stays in the accumulators between transitions (MALA reads it from GR where it needs it)
+    constexpr bool KEEPG = NEEDG;                               // the committed gradient stays in the accumulators between transitions (re-read from GR only after a reject)
+    constexpr bool XLDS = SAMPLER != KLARA_SAMPLER_HMC;          // MALA / MH: the current value waits in the lane's LDS column (MALA: where its normals were, for the backward term) — a rejected proposal is undone from there
     static_assert(!DA || SAMPLER == KLARA_SAMPLER_HMC, "dual averaging is wired into HMC only (HMC.jl:124-133)");
     constexpr bool da = DA;
     const KParams& p = *pp;
@@ -144,9 +148,14 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
     double* const ldsMuW = reinterpret_cast<double*>(smem);                     // mu[4 e + q] at [4 e + q], zero-padded (HASMU only)
     if (HASMU) { for (int i = threadIdx.x; i < 4 * NE; i += blockDim.x) ldsMuW[i] = Pfrag[(size_t)MT * NE * 64 + i]; }
     const double* const ldsMu = ldsMuW;
-    kd_tables_to_lds();          // (also the barrier for mu)
+    // MH's proposal scales, sigma[4 e + q] at [4 e + q], 0 past D (round 5: a buffer load per element inside the normals' loop was an exposed memory
+    // round trip per Box-Muller pair at one wavefront per SIMD)
+    constexpr bool SIGLDS = SAMPLER == KLARA_SAMPLER_MH;
+    double* const ldsSig = ldsMuW + (HASMU ? 4 * NE : 0);
+    if (SIGLDS) { for (int i = threadIdx.x; i < 4 * NE; i += blockDim.x) ldsSig[i] = (p.vecparam != nullptr && i < p.D) ? p.vecparam[i] : 0.0; }
+    kd_tables_to_lds();          // (also the barrier for mu / sigma)
     const MfmaCtx<NE> cx = make_mctx<NE>(p);
-    double* const momw = ldsMuW + (HASMU ? 4 * NE : 0) + (size_t)(threadIdx.x >> 6) * NE * 64 + cx.lane;     // this lane's momentum column
+    double* const momw = ldsSig + (SIGLDS ? 4 * NE : 0) + (size_t)(threadIdx.x >> 6) * NE * 64 + cx.lane;     // this lane's column: momentum (HMC), normals then the current value (MALA), the current value (MH)
     const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
     const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
     TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0, 0.0, 0.0 };
@@ -159,8 +168,6 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
     const bool do_sum = p.sum != nullptr;
     long long held = do_sum ? p.held[cx.chain_ok ? cx.chain : 0] : 0;
     const __amdgpu_buffer_rsrc_t wX = mwin<NE>(cx, p.X, 0, p.D), wG = mwin<NE>(cx, p.GR, 0, p.D);
-    const __amdgpu_buffer_rsrc_t wSig = __builtin_amdgcn_make_buffer_rsrc((void*)(SAMPLER == KLARA_SAMPLER_MH ? p.vecparam : nullptr), 0,
-                                                                          SAMPLER == KLARA_SAMPLER_MH ? p.D * 8 : 0, 0x00020000);   // MH's proposal scales
 
     // the committed state of the lane's chain: value in registers, gradient in the accumulator tiles (element e = ga[e >> 2][e & 3]).  They are
     // (re)read from memory at the start of the launch and after a rejected proposal; an accepted proposal simply stays where it is.
@@ -227,25 +234,25 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h), half_inv_h = 0.5 * (1.0 / h);
             double s1 = 0.0;
             // the normals go through the lane's LDS column like HMC's momentum: drawn first, consumed in groups of 8 — the transform's ~40 live
-            // registers and the pass over value + gradient do not overlap (drawn straight into the pass, NE = 64 came out with 560 B of scratch)
+            // registers and the pass over value + gradient do not overlap (drawn straight into the pass, NE = 64 comes out with 530 B of scratch and
+            // 18 % slower: measured again in round 5)
             mnormals_lds<NE>(cx, p.seed, gchain, t, momw);
-            // the CURRENT gradient is read from GR where it is consumed (8 elements in flight), not kept in the accumulators between transitions: the
-            // accumulators are free while the normals are drawn, and a rejected proposal leaves nothing of the gradient to restore
+            // Round 5: nothing of this pass comes from memory any more.  The CURRENT gradient is in the accumulators (it stays there between transitions
+            // like HMC's; round 4 re-read it from GR here, 8 loads in flight per group: eight exposed memory round trips per transition at one wavefront per
+            // SIMD), and the current value takes the place of each normal in the lane's LDS column as it is consumed — the backward term below reads it
+            // from there instead of re-reading X (another eight round trips), and so does a lane whose proposal is rejected.
             {
-                const int nv = cx.nv_here();
 #pragma unroll
                 for (int e0 = 0; e0 < NE; e0 += 8) {
-                    double gc[8], zz[8];
+                    double zz[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        gc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, cx.off(e0 + j, nv), 0, 0));
-                        zz[j] = momw[(e0 + j) * 64];
-                    }
+                    for (int j = 0; j < 8; ++j) zz[j] = momw[(e0 + j) * 64];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int e = e0 + j;
-                        const double mu = xp[e] + halfh * gc[j];                      // MALA.jl:83
+                        momw[e * 64] = xp[e];                                         // (the lane's own column: DS operations of a lane stay in order)
+                        const double mu = xp[e] + halfh * (double)ga[e >> 2][e & 3];  // MALA.jl:83
                         xp[e] = mu + sq * zz[j];                                      // MALA.jl:84
                         const double q1 = mu - xp[e];
                         s1 = s1 + (q1 * q1) * half_inv_h;                             // MALA.jl:90
@@ -260,12 +267,11 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             for (int tt = 0; tt < MT; ++tt) ga[tt] = -ga[tt];
             double l1 = 0.0, s2 = 0.0, red[3];
             {
-                const int nv = cx.nv_here();
 #pragma unroll
-                for (int e0 = 0; e0 < NE; e0 += KLARA_BIG_XC_CHUNK) {      // the current value, 8 elements at a time: 8 loads in flight, then their terms (one load and a wait per element
-                    double xc[KLARA_BIG_XC_CHUNK];        // costs the memory latency NE times per transition at one wavefront per SIMD)
+                for (int e0 = 0; e0 < NE; e0 += KLARA_BIG_XC_CHUNK) {      // the current value from the lane's LDS column, 8 elements at a time
+                    double xc[KLARA_BIG_XC_CHUNK];
 #pragma unroll
-                    for (int j = 0; j < KLARA_BIG_XC_CHUNK; ++j) xc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, cx.off(e0 + j, nv), 0, 0));
+                    for (int j = 0; j < KLARA_BIG_XC_CHUNK; ++j) xc[j] = momw[(e0 + j) * 64];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < KLARA_BIG_XC_CHUNK; ++j) {
@@ -295,7 +301,8 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
         } else {
             // iterate/MH.jl:72-124
             mnormals_each<NE>(cx, p.seed, gchain, t, [&](int e, double z) {
-                const double sg = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wSig, (unsigned)(4 * e + cx.q) * 8u, 0, 0));   // (0 past D)
+                const double sg = ldsSig[4 * e + cx.q];                               // (0 past D)
+                momw[e * 64] = xp[e];                                                 // the current value: what a rejecting lane goes back to
                 xp[e] = xp[e] + sg * z;                                               // MH.jl:79
             });
             dense_stream<NE, HASMU>(Pfrag, cx.lane, xp, ga, ldsMu);                  // MH.jl:81
@@ -355,7 +362,8 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
 #pragma unroll
                 for (int j = 0; j < RC; ++j) {
                     const unsigned o = acc ? KLARA_BUF_OOB : cx.off(e0 + j, nv);
-                    xc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
+                    if (XLDS) xc[j] = momw[(e0 + j) * 64];                            // (MALA: the current value is still in the lane's LDS column)
+                    else xc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
                     if (KEEPG) gc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, o, 0, 0));
                 }
                 __builtin_amdgcn_sched_barrier(0);

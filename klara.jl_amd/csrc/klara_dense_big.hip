@@ -7,7 +7,7 @@ template <int S, int N, bool HASMU, bool DA = false>
 static hipError_t go_big(const KParams* p, const KLaunch& kl, const double* Pfrag, dim3 grid, hipStream_t st)
 {
     // mu + (HMC: momentum, MALA: the proposal's normals) the four wavefronts' columns
-    constexpr size_t lds = sizeof(double) * ((HASMU ? 4 * N : 0) + (S != KLARA_SAMPLER_MH ? 4 * (size_t)N * 64 : 0));
+    constexpr size_t lds = sizeof(double) * ((HASMU ? 4 * N : 0) + (S == KLARA_SAMPLER_MH ? 4 * N : 0) + 4 * (size_t)N * 64);      // mu, MH's sigma, one column per lane of the 4 wavefronts
     if (lds > KLARA_LDS_DEFAULT_DYNAMIC) {
         hipError_t e = hipFuncSetAttribute((const void*)k_dense_big<S, N, HASMU, DA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

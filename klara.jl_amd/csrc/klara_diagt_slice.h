@@ -14,10 +14,10 @@
 //
 //     for pair slot p of the lane:                 (x, running sums, width, weight, mean of the pair: registers for the whole launch)
 //         until both machines have made nsteps transitions:      one iteration = at most one transition of each machine
-//             block A = start of a transition ? slot base (log(rand()), runiform)  :  the next block of shrink attempts, base | (k + 1)
-//             block B = base | 1, shrink attempts 1 and 2 of a starting transition
-//             starting machines: slice level, interval, step-out (SliceSampler.jl:66-89)
-//             two shrink attempts from B (starting) or A (continuing)               (SliceSampler.jl:91-106)
+//             block A = slot base (log(rand()), runiform): what a starting machine needs
+//             block B = base | (k + 1): the next two shrink attempts (k = 0 for a starting machine)
+//             starting machines: slice level, interval, step-out (SliceSampler.jl:66-89)      (executed by all, kept by the starting ones)
+//             two shrink attempts from B                                             (SliceSampler.jl:91-106)
 //             accepted -> commit, next transition; else continue with the next attempt block in the next iteration
 //
 // A machine whose update needs more than two attempts (11 % of the updates on the README target) simply takes another iteration while its
@@ -146,9 +146,10 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
                     // counter words of (transition << 24 | slot) for transition t0 + tl (detmath.h kd_stream_block), formed in 32-bit pieces
                     const uint32_t tlo = t0lo + (uint32_t)tl[m], thi = t0hi + (tlo < t0lo ? 1u : 0u);
                     const uint32_t c0 = tlo << 24, c1 = (tlo >> 8) | (thi << 24);
-                    const uint32_t slotA = st[m] ? base[m] : (base[m] | (uint32_t)(k[m] + 1));
-                    A[m] = kd_philox4x32_10(c0 | slotA, c1, (uint32_t)gchain, (uint32_t)(gchain >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
-                    B[m] = kd_philox4x32_10(c0 | base[m] | 1u, c1, (uint32_t)gchain, (uint32_t)(gchain >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+                    // A: the coordinate's block (log(rand()), runiform) — used by starting machines only; B: the block of the next two shrink attempts,
+                    // slot base | (k + 1): attempts 1, 2 of a starting machine (k = 0), attempts 2k + 1, 2k + 2 of a continuing one
+                    A[m] = kd_philox4x32_10(c0 | base[m], c1, (uint32_t)gchain, (uint32_t)(gchain >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+                    B[m] = kd_philox4x32_10(c0 | base[m] | (uint32_t)(k[m] + 1), c1, (uint32_t)gchain, (uint32_t)(gchain >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
                 }
                 // starting machines: slice level, interval, step-out.  Executed by every lane, kept by the starting ones (selects: a branch here
                 // is taken in all but a few per cent of the iterations and costs the merge copies of everything it defines)
@@ -178,30 +179,32 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
                             dl[m] = tcur[m] - slicef_term<UNITW>(Ln[m], wt[m], mu[m]);
                             dr[m] = tcur[m] - slicef_term<UNITW>(Rn[m], wt[m], mu[m]);
                         }
-                        for (int trip = 1;; trip = __builtin_amdgcn_readfirstlane(trip + 1)) {
-                            bool gl[NM], gr[NM];
-#pragma unroll
-                            for (int m = 0; m < NM; ++m) { gl[m] = dl[m] > lgx[m]; gr[m] = dr[m] > lgx[m]; }
-                            if (!__any(gl[0] || gr[0] || gl[NM - 1] || gr[NM - 1])) break;
-                            if (trip > KLARA_SLICE_MAX_ATT) {                                  // (a machine still stepping in trip n has made n - 1 steps: the guard is a scalar)
-#pragma unroll
-                                for (int m = 0; m < NM; ++m) tl[m] = (gl[m] || gr[m]) ? nsteps + 1 : tl[m];
-                                break;
-                            }
+                        // one loop exit (a second one — the guard — costs merge copies of the four end points in every trip): the trip counter is a
+                        // scalar, a machine still stepping in trip n has made n - 1 steps, and whoever is still stepping when the loop ends on the
+                        // guard is stuck
+                        int trip = 1;
+                        while (__any(dl[0] > lgx[0] || dr[0] > lgx[0] || dl[NM - 1] > lgx[NM - 1] || dr[NM - 1] > lgx[NM - 1]) && trip <= KLARA_SLICE_MAX_ATT) {
 #pragma unroll
                             for (int m = 0; m < NM; ++m) {
-                                Ln[m] = gl[m] ? Ln[m] - wd[m] : Ln[m]; Rn[m] = gr[m] ? Rn[m] + wd[m] : Rn[m];
+                                // (one masked fma per side: fma(-1, wd, L) rounds like L - wd, fma(-0.0, wd, L) = L; a one-word select of the factor instead
+                                // of a two-word select of the result)
+                                const double fl = kd_u2d((uint64_t)(dl[m] > lgx[m] ? 0xbff00000u : 0x80000000u) << 32);
+                                const double fr = kd_u2d((uint64_t)(dr[m] > lgx[m] ? 0x3ff00000u : 0x80000000u) << 32);     // (-0.0, not +0.0: x + -0.0 = x for every x, -0.0 included)
+                                Ln[m] = kd_fma(fl, wd[m], Ln[m]); Rn[m] = kd_fma(fr, wd[m], Rn[m]);
                                 dl[m] = tcur[m] - slicef_term<UNITW>(Ln[m], wt[m], mu[m]);
                                 dr[m] = tcur[m] - slicef_term<UNITW>(Rn[m], wt[m], mu[m]);
                             }
+                            trip = __builtin_amdgcn_readfirstlane(trip + 1);
                         }
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) tl[m] = (dl[m] > lgx[m] || dr[m] > lgx[m]) ? nsteps + 1 : tl[m];      // (only possible after the guard)
                     }
 #pragma unroll
                     for (int m = 0; m < NM; ++m) { L[m] = st[m] ? Ln[m] : L[m]; R[m] = st[m] ? Rn[m] : R[m]; lgu[m] = st[m] ? lg[m] : lgu[m]; }
                 }
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {                                                 // :91-106, two attempts
-                    const uint32_t w0 = st[m] ? B[m].x : A[m].x, w1 = st[m] ? B[m].y : A[m].y, w2 = st[m] ? B[m].z : A[m].z, w3 = st[m] ? B[m].w : A[m].w;
+                    const uint32_t w0 = B[m].x, w1 = B[m].y, w2 = B[m].z, w3 = B[m].w;
                     const double c1 = kd_u52(w0, w1) * (R[m] - L[m]) + L[m];                   // :92-93
                     const double t1 = slicef_term<UNITW>(c1, wt[m], mu[m]);                    // :94
                     const bool in1 = tcur[m] - t1 > lgu[m];                                    // :95
