@@ -491,6 +491,23 @@ def extra_measurements(K, L, n, stream):
                                          "source": "algorithmic flops (2 D^2 + 6 D per leapfrog and chain) / launch duration from HIP events in this run"}
     except Exception as exc:
         ex["hmc_dense_d256_error"] = repr(exc)
+    # ... and MALA / MH on the same target (one gradient per transition: 2 D^2 flop per transition and chain; round 5: the current gradient stays in the
+    # accumulators, the current value and MH's proposal scales in LDS)
+    try:
+        D2 = 256
+        for key, kw in (("mala", dict(sampler=L.SAMPLER_MALA, driftstep=0.002)), ("mh", dict(sampler=L.SAMPLER_MH, mh_sigma=np.full(D2, 0.02)))):
+            e = K.Engine(target=K.GaussDenseTarget.compound_symmetric(D2, 0.5), nchains=n, nsteps=10 ** 7, steps_per_launch=32, stream=stream, **kw)
+            e.init_state_normal()
+            rate, ls, _ = timed_rate(e, n, 64, 128)
+            lay2 = e.layout(); e.close()
+            tf2 = n * 32 * 2 * D2 * D2 / ls / 1e12
+            ex[f"{key}_dense_d256_transitions_per_s"] = rate
+            ex[f"{key}_dense_d256_roofline"] = {"bound": "mfma", "achieved": tf2, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf2 / FP64_MFMA_PEAK_TF,
+                                                "kernel": f"k_dense_big<{key.upper()}, NE={lay2[2]}> (v_mfma_f64_16x16x4, A fragments streamed from memory), 32 transitions per launch",
+                                                "launch_us": ls * 1e6,
+                                                "source": "algorithmic flops (2 D^2 per transition and chain: one gradient) / launch duration from HIP events in this run"}
+    except Exception as exc:
+        ex["mala_mh_dense_d256_error"] = repr(exc)
 
     # -- slice sampler on the README target, D = 100: the library's own launch length for this job (KLARA_DEFAULT_STEPS_PER_LAUNCH_SLICE; the lanes run out of
     # lockstep and a wavefront waits for its slowest lane once per element slot and launch, klara_diagt_slice.h)
