@@ -446,8 +446,11 @@ def extra_measurements(K, L, n, stream):
     rate, ls, _ = timed_rate(e, n, 512, 512)      # (~13 ms of warm-up: a device that idled while the job was created ramps its clocks for ~20 ms)
     lay = e.layout(); at = attrs_of(e, 32); e.close()
     ex["hmc_iso_leapfrog_chain_per_s"] = rate * 10
-    bh = bud["hmc_iso"]
-    ex["hmc_iso_roofline"] = valu_roofline(diagt_kernel_name(2, lay[1], lay[2], False, True, False), ls, grid=diagt_grid(n, lay[1]), attrs=at, budget=bh,
+    # (round 5: an unmonitored HMC job on this target runs the 4-lanes-per-chain kernels, NP = ceil(D / 8) pairs per lane, which sum in the layout's 8-lane order)
+    four = NDIMS <= 104 and "hmc_iso_4lane" in bud
+    bh = bud["hmc_iso_4lane"] if four else bud["hmc_iso"]
+    hg, he = (4, 2 * ((NDIMS + 7) // 8)) if four else (lay[1], lay[2])
+    ex["hmc_iso_roofline"] = valu_roofline(diagt_kernel_name(2, hg, he, False, True, False), ls, grid=diagt_grid(n, hg), attrs=at, budget=bh,
                                            necessary_per_launch=bh["per_wave_transition"] * (n // bh["chains_per_wave"]) * L.DEFAULT_STEPS_PER_LAUNCH)
 
     e = K.Engine(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget.compound_symmetric(NDIMS, 0.5), nchains=n, nsteps=10 ** 7,

@@ -133,7 +133,12 @@ static long long default_steps_per_launch(const klara_desc& d) { return slice_fr
 static bool q4_eligible(const klara_desc& d)
 {
     const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
-    return diagt_eligible(d) && plain && (d.sampler == KLARA_SAMPLER_MH || d.sampler == KLARA_SAMPLER_MALA) && d.ndims <= 104 &&
+    // (round 5: HMC too while no saved-sample monitor is on — 12.5 of 13 pair slots real at D = 100 instead of 6.25 of 7, the reductions in the 8-lane order as
+    // for MH / MALA; with running sums or a history the 8-lane kernels keep it: at HMC's acceptance every transition would fold)
+    // (a non-unit diagonal beyond 9 pairs per lane spills: those stay on 8 lanes)
+    const bool hmc_ok = d.sampler == KLARA_SAMPLER_HMC && (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) == 0 && d.acov_maxlag == 0 &&
+                        ((d.gauss_w == nullptr && d.gauss_mu == nullptr) || d.ndims <= 72) && !getenv("KLARA_DIAGT_NO_Q4_HMC");
+    return diagt_eligible(d) && plain && (d.sampler == KLARA_SAMPLER_MH || d.sampler == KLARA_SAMPLER_MALA || hmc_ok) && d.ndims <= 104 &&
            !getenv("KLARA_DIAGT_NO_Q4");
 }
 
@@ -1012,6 +1017,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
         const bool slice_free = !tune && slice_free_eligible(d);
         int force = -1;                                      // 0: 4 lanes per chain; 1: 8 lanes; -1: decided on the device
         if (!h->q4_ok) force = 1;
+        else if (d.sampler == KLARA_SAMPLER_HMC && onestep) force = 1;   // (one transition per launch: the 8-lane single-transition kernel measured 5 % faster)
         else if (!sums) force = 0;                           // nothing to fold: the 4-lane kernels
         else if (d.sparse_moves == 1) force = 0;
         else if (d.sparse_moves == 2) force = 1;
@@ -1034,7 +1040,8 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
                 if (h->jit_pair) return klara_jit_launch_pair(h->jit, (onestep && !tune && !mon) ? 1 : 0, p, kp, nw, st);
                 if (lanes == 4)
                     return d.sampler == KLARA_SAMPLER_MH ? klara_launch_diagt_mh_q4(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st)
-                                                         : klara_launch_diagt_mala_q4(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);
+                         : d.sampler == KLARA_SAMPLER_HMC ? klara_launch_diagt_hmc_q4(p, kp, np, false, unitw, mon, tune, da, ka, nw, st)
+                                                          : klara_launch_diagt_mala_q4(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);
 #define KLARA_DIAGT_LAUNCH(SUFFIX)                                                                                                          \
                 switch (d.sampler) {                                                                                                          \
                 case KLARA_SAMPLER_MH: return klara_launch_diagt_mh##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);        \
@@ -1055,6 +1062,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
             };
             if (force >= 0 && !(h->q4_ok && sums)) {
                 e = go(force == 0 ? 4 : h->G, KLARA_AUTO_NONE);
+                if (h->q4_ok) h->n_launch_mode[force == 0 ? 0 : 1] += (j == 0 && !query);      // (klara_get_launch_modes: which family ran)
             } else {
                 // running sums on a job both kernel families can run: every launch counts its accepted proposals and leaves the
                 // decision for the next one in the partition's cell of the other parity (KAuto)

@@ -370,7 +370,7 @@ template <int SAMPLER, int NP, int Q, bool ONESTEP, bool TUNE>
 __host__ __device__ constexpr int diagt_min_waves()       // wavefronts per SIMD the register allocator is asked to leave room for
 {
     return NP <= 8 ? (ONESTEP && SAMPLER != KLARA_SAMPLER_HMC ? KLARA_DT_W1 : KLARA_DT_WF)
-                   : (Q == 4 && NP <= 13 && !TUNE ? (SAMPLER == KLARA_SAMPLER_MALA ? KLARA_Q4_MALA_WF : (SAMPLER == KLARA_SAMPLER_MH ? 2 : 1)) : 1);
+                   : (Q == 4 && NP <= 13 && !TUNE ? (SAMPLER == KLARA_SAMPLER_MALA ? KLARA_Q4_MALA_WF : 2) : 1);
 }
 
 // USERPAIR (run-time compiled instantiations only, klara_custom_pair.h): the target is the user's pair closure
@@ -726,14 +726,18 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
             } else {                                                               // iterate/HMC.jl:124-201
                 const double eps = tn.step, halfe = 0.5 * eps;
                 double mom[E], gp[E];
-                double k0[1] = { 0.0 };
+                // (Q = 4: two partial sums per reduction — the pairs of the 8-lane layout's lanes q (even pi) and q + 4 (odd pi) — as in the MH / MALA branches:
+                // strides 1 and 2 of the butterfly on both, stride 4 is their sum: the bits 8 lanes per chain produce)
+                double k0[NR] = {};
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
                     pair_normals<NP, Q>(cx, p.seed, gchain, t, pi, nstash, mom[2 * pi], mom[2 * pi + 1], u_last, lg_last);   // :135
-                    k0[0] = k0[0] + mom[2 * pi] * mom[2 * pi];
-                    k0[0] = k0[0] + mom[2 * pi + 1] * mom[2 * pi + 1];
+                    const int r = (NR == 2 && (pi & 1)) ? 1 : 0;
+                    k0[r] = k0[r] + mom[2 * pi] * mom[2 * pi];
+                    k0[r] = k0[r] + mom[2 * pi + 1] * mom[2 * pi + 1];
                 }
-                group_allreduce<1>(k0, Q, cx.lane);
+                group_allreduce<NR>(k0, Q, cx.lane);
+                if (NR == 2) k0[0] = k0[0] + k0[1];
                 const double H0 = lt - 0.5 * k0[0];                                            // :137
 #pragma unroll
                 for (int e = 0; e < E; ++e) xp[e] = x[e];                                      // :139
@@ -784,12 +788,19 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                 for (int e = 0; e < E; ++e) {
                     double term, gd;
                     diag_elem<UNITW>(xp[e], wv(e), m2wv(e), mv(e), term, gd);   // :157
-                    red[0] = red[0] + term;
-                    red[1] = red[1] + mom[e] * mom[e];
+                    const int r = (NR == 2 && ((e >> 1) & 1)) ? 3 : 0;          // (Q = 4: the odd pairs' partials, see the opening sum)
+                    red[r] = red[r] + term;
+                    red[r + 1] = red[r + 1] + mom[e] * mom[e];
                 }
                 }
-                red2[0] = red[0]; red2[1] = red[1];
-                group_allreduce<2>(red2, Q, cx.lane);
+                if (NR == 2) {
+                    double red4[4] = { red[0], red[1], red[3], red[4] };
+                    group_allreduce<4>(red4, Q, cx.lane);
+                    red2[0] = red4[0] + red4[2]; red2[1] = red4[1] + red4[3];
+                } else {
+                    red2[0] = red[0]; red2[1] = red[1];
+                    group_allreduce<2>(red2, Q, cx.lane);
+                }
                 ltp = gconst - red2[0];
                 const double H1 = ltp - 0.5 * red2[1];                                         // :159
                 const double ratio = H1 - H0;                                                  // :161

@@ -65,6 +65,7 @@ KLARA_DIAGT_DECLARE(_q32)
 // adds instead of living in registers (klara_diagt.h diagt_fold_atomic).  Only klara_diagt_{mh,mala,init}.hip are built for it.
 hipError_t klara_launch_diagt_mh_q4(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, const KAuto& ka, long long nwaves, hipStream_t st);
 hipError_t klara_launch_diagt_mala_q4(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, const KAuto& ka, long long nwaves, hipStream_t st);
+hipError_t klara_launch_diagt_hmc_q4(const KParams* p, const KLaunch& kl, int NP, bool onestep, bool unitw, bool mon, bool tune, bool da, const KAuto& ka, long long nwaves, hipStream_t st);
 hipError_t klara_launch_diagt_init_q4(const KParams& p, int NP, int needgrad, dim3 grid, hipStream_t st);
 // pairs per lane the kernels are instantiated for; a job takes NP = ceil(ceil(D/2) / Q) exactly (only the LAST pair of a lane
 // can be padding)

@@ -137,7 +137,8 @@ def hmc_iso(nleaps: int = 10, ndims: int = 100, lanes_per_chain: int = 8):
                 + 2 * 1                                                 # opening half kick (fma per element)
                 + nleaps * 2 * 3                                        # per leapfrog and element: drift (fma), gradient -2x (mul), kick (fma)
                 + 2 * 2)                                                # log-target of the proposal: mul, add per element
-    red = 3 * 3 * BFLY                                                  # K0, lt', K1: three sums over 8 lanes
+    # K0, lt', K1: three sums over 8 lanes; 4 lanes (round 5): two partial sums per lane, 2 butterfly steps on both, then their sum (the 8-lane order)
+    red = 3 * 3 * BFLY if lanes_per_chain == 8 else 3 * (2 * 2 * BFLY + 1)
     accept = 2 + 2 + EXP + 1 + 1 + 1                                    # H0, H1, ratio; exp; min; the uniform comes with the padding pair's block; compare
     commit = 2 * 2 + 2                                                  # per pair slot: selects of the value pair; lt
     return {"per_pair": per_pair, "pair_evaluations_per_lane": pairs, "philox_blocks_per_lane": blocks, "reductions": red, "accept_test": accept,
@@ -228,6 +229,7 @@ BUDGETS = {"headline_4lane": _with_extra(_h4, _normals_extra(_h4)),
            "cfg4": _with_extra(_c4, 1 * PAIR_EXTRA + _c4["rows_per_lane"] * QUARTER_EXTRA + 5 * QUARTER_EXTRA),   # + one v_rcp_f64 per row and per prior division
            "cfg1": _with_extra(cfg1_replicas(), 2 * 20 * MAD_EXTRA + QUARTER_EXTRA),
            "hmc_iso": _with_extra(hmc_iso(), _normals_extra(hmc_iso())),
+           "hmc_iso_4lane": _with_extra(hmc_iso(lanes_per_chain=4), _normals_extra(hmc_iso(lanes_per_chain=4))),
            "slice_d100": _with_extra(slice_diag(), 12.5 * (1 + SLICE_PROBES["shrink_blocks"][0]) * 20 * MAD_EXTRA),
            "slice_d100_lockstep": _with_extra(slice_diag(counts=SLICE_PROBES["max_over_64_lanes"], blocks=SLICE_PROBES["shrink_blocks"][1]),
                                               12.5 * (1 + SLICE_PROBES["shrink_blocks"][1]) * 20 * MAD_EXTRA)}

@@ -239,6 +239,39 @@ def test_pair_transposed_dimension_sweep(sampler, kw, step):
         eng.close()
 
 
+def test_hmc_on_the_4_lane_kernels_sums_in_the_8_lane_order(monkeypatch):
+    """Round 5: unmonitored HMC jobs on the diagonal Gaussian (17 <= D <= 104; non-unit diagonals to D = 72) run on the 4-lanes-per-chain kernels — 12.5 of 13
+    pair slots real at D = 100 instead of 6.25 of 7 — whose reductions (the two kinetic energies and the log-target) reproduce the 8-lane order like
+    MH / MALA's.  Every third dimension, odd ones included, ragged chain counts, fused and one-transition launches: accept mask, state, log-target and
+    gradient bit for bit against the oracle told the 8-lane layout; and the same job pinned to the 8-lane kernels gives the same bits."""
+    for d in list(range(17, 105, 3)) + [100, 104]:
+        unit = d % 2 == 0 or d > 72
+        t = K.GaussDiagTarget.negdot(d) if unit else K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d))
+        case = dict(sampler=L.SAMPLER_HMC, target=t, nchains=37, nsteps=9, burnin=0, leapstep=0.15, nleaps=4, x0=None, seed=1000 + d, name=f"hmc4_d{d}")
+        outs = []
+        for pin8 in (False, True):
+            if pin8:
+                monkeypatch.setenv("KLARA_DIAGT_NO_Q4_HMC", "1")
+            else:
+                monkeypatch.delenv("KLARA_DIAGT_NO_Q4_HMC", raising=False)
+            eng = K.Engine(**cases.engine_kwargs(case, monitor=L.MON_ACCEPT, steps_per_launch=(1 if d % 5 == 0 else 4)))
+            assert eng.layout()[:2] == (3, 8)
+            job = O.OracleJob(**cases.oracle_kwargs(case, layout=eng.layout()))
+            eng.init_state_normal(); job.init_state_normal()
+            eng.run(9); job.run(9)
+            n4, n8, _ = eng.launch_modes()[0]
+            one = d % 5 == 0                              # (one transition per launch: the 8-lane single-transition kernel runs these)
+            assert ((n4 > 0 and n8 == 0) if not (pin8 or one) else n4 == 0), (d, pin8, n4, n8)
+            x, lt, g = eng.state()
+            mask = eng.accept_mask()
+            assert np.array_equal(mask, job.accept), (d, pin8)
+            assert np.array_equal(x, job.X) and np.array_equal(lt, job.LT) and np.array_equal(g, job.G), (d, pin8)
+            outs.append((x, mask))
+            eng.close()
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), d
+    monkeypatch.delenv("KLARA_DIAGT_NO_Q4_HMC", raising=False)
+
+
 @pytest.mark.parametrize("nstreams", [0, 3])
 def test_few_lanes_layouts_chain_count_sweep(nstreams):
     """1..20 chains (every fill level of the last 8-chain wavefront group) on layout kinds 3 and 4; with three chain
