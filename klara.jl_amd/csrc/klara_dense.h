@@ -93,13 +93,16 @@ __device__ __forceinline__ void mload(const MfmaCtx<NE>& c, const gdouble* base,
 #pragma unroll
     for (int e = 0; e < NE; ++e) v[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(w, c.off_fresh(e, nv), 0, 0));
 }
-template <int NE>
+#ifndef KLARA_DENSE_COMMIT_AUX
+#define KLARA_DENSE_COMMIT_AUX 0      // cache-policy bits of the X / GR stores of an accepted transition (2 = nt)
+#endif
+template <int NE, int AUX = 0>
 __device__ __forceinline__ void mstore(const MfmaCtx<NE>& c, gdouble* base, int D, const double (&v)[NE], long long row0 = 0)
 {
     const __amdgpu_buffer_rsrc_t w = mwin<NE>(c, base, row0, D);
     const int nv = c.nv_here();
 #pragma unroll
-    for (int e = 0; e < NE; ++e) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, v[e]), w, c.off_fresh(e, nv), 0, 0);
+    for (int e = 0; e < NE; ++e) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, v[e]), w, c.off_fresh(e, nv), 0, AUX);
 }
 
 // all-reduce over the 4 lanes (q = 0..3) of a chain: xor 16 then xor 32 — the canonical tree
@@ -502,12 +505,12 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
             }
         }
         if (acc) {
-            mstore<NE>(cx, p.X, p.D, xp);
+            mstore<NE, KLARA_DENSE_COMMIT_AUX>(cx, p.X, p.D, xp);
             if (SAMPLER != KLARA_SAMPLER_MH && SAMPLER != KLARA_SAMPLER_SLICE) {
                 double gs[NE];
 #pragma unroll
                 for (int e = 0; e < NE; ++e) gs[e] = gp[e];
-                mstore<NE>(cx, p.GR, p.D, gs);
+                mstore<NE, KLARA_DENSE_COMMIT_AUX>(cx, p.GR, p.D, gs);
             }
             lt = ltp;
         }

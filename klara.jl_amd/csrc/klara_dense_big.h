@@ -34,6 +34,15 @@
 #ifndef KLARA_BIG_RELOAD_CHUNK
 #define KLARA_BIG_RELOAD_CHUNK 8      // elements re-read per group after a rejected proposal
 #endif
+#ifndef KLARA_BIG_X_EVERY
+#define KLARA_BIG_X_EVERY 0           // 1: MALA / MH store an accepted value to X at once (round 4); 0: X is written once, when the launch ends
+#endif
+#ifndef KLARA_BIG_G_AUX
+#define KLARA_BIG_G_AUX 2             // cache-policy bits of MALA's per-transition GR store: 2 = nt (measured: 0 -> 37.4, nt 41.4, sc1 nt 33.3 TFLOP/s at D = 256)
+#endif
+#ifndef KLARA_BIG_HMC_AUX
+#define KLARA_BIG_HMC_AUX 0           // ... of HMC's X / GR stores
+#endif
 #ifndef KLARA_BIG_XC_CHUNK
 #define KLARA_BIG_XC_CHUNK 8          // MALA's backward term: elements of the current value re-read per group (a power of two <= 8)
 #endif
@@ -139,6 +148,9 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
     constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;          // MH carries no gradient (GR is not written)
     constexpr bool KEEPG = NEEDG;                               // the committed gradient stays in the accumulators between transitions (re-read from GR only after a reject)
     constexpr bool XLDS = SAMPLER != KLARA_SAMPLER_HMC;          // MALA / MH: the current value waits in the lane's LDS column (MALA: where its normals were, for the backward term) — a rejected proposal is undone from there
+    // ... so nothing inside a launch reads X: the value is written ONCE, after the last transition (it was 2 KB per chain and accepted transition at D = 256:
+    // half of MALA's and all of MH's write stream, 4.3 GB per 32-transition launch, through the L2 that also holds P)
+    constexpr bool XONCE = XLDS && !KLARA_BIG_X_EVERY;
     static_assert(!DA || SAMPLER == KLARA_SAMPLER_HMC, "dual averaging is wired into HMC only (HMC.jl:124-133)");
     constexpr bool da = DA;
     const KParams& p = *pp;
@@ -325,7 +337,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
         // k_dense_big<MH, 48, mean> lost element 15 of every chain that had just rejected that way (ROCm 7.2; found by the randomised parity jobs when the
         // normals changed the allocation).  So every lane takes every step under a wave-uniform condition; a lane with nothing to do addresses out of
         // bounds (loads return 0, stores are dropped) and keeps its registers through selects.
-        if (do_sum && __any(acc && held > 0)) {          // leaving a state after `held` saved steps: fold it into the sums (the OLD value is in X)
+        if (do_sum && __any(acc && held > 0)) {          // leaving a state after `held` saved steps: fold it into the sums (the OLD value is in X, or in the LDS column)
             const bool fold = acc && held > 0;
             const double hf = (double)held;
             const __amdgpu_buffer_rsrc_t ws = mwin<NE>(cx, p.sum, 0, p.D), wq = mwin<NE>(cx, p.sumsq, 0, p.D);
@@ -333,7 +345,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const unsigned o = fold ? cx.off(e, nv) : KLARA_BUF_OOB;
-                const double xo = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
+                const double xo = XONCE ? momw[e * 64] : __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));     // (the lane's LDS column still holds the value the chain is leaving)
                 const double sv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ws, o, 0, 0));
                 const double qv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wq, o, 0, 0));
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sv + hf * xo), ws, o, 0, 0);
@@ -342,13 +354,14 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             held = fold ? 0 : held;
         }
         KLARA_BIG_PHASE();
-        if (__any(acc)) {                                // commit (HMC.jl:166-176)
+        if ((!XONCE || NEEDG) && __any(acc)) {           // commit (HMC.jl:166-176): what a later reject re-reads
             const int nv = cx.nv_here();
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const unsigned o = acc ? cx.off(e, nv) : KLARA_BUF_OOB;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, xp[e]), wX, o, 0, 0);
-                if (NEEDG) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, (double)ga[e >> 2][e & 3]), wG, o, 0, 0);
+                constexpr int AUX = SAMPLER == KLARA_SAMPLER_HMC ? KLARA_BIG_HMC_AUX : KLARA_BIG_G_AUX;
+                if (!XONCE) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, xp[e]), wX, o, 0, AUX);
+                if (NEEDG) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, (double)ga[e >> 2][e & 3]), wG, o, 0, AUX);
             }
         }
         lt = acc ? ltp : lt;
@@ -427,6 +440,11 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
         }
     }
 
+    if (XONCE) {                                         // the committed value, once per launch
+        const int nv = cx.nv_here();
+#pragma unroll
+        for (int e = 0; e < NE; ++e) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, xp[e]), wX, cx.off(e, nv), 0, 0);
+    }
     if (cx.chain_ok && cx.q == 0) {
         p.LT[cx.chain] = lt;
         p.naccept[cx.chain] += nacc;

@@ -13,7 +13,8 @@ from klara_jl_amd import _lib as L
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 n, d = 65536, 256
 slow = "KLARA_DENSE_NO_STREAM" in os.environ
-for name, kw in (("MALA", dict(sampler=L.SAMPLER_MALA, driftstep=0.002)), ("MH", dict(sampler=L.SAMPLER_MH, mh_sigma=np.full(d, 0.02)))):
+drift = float(os.environ.get("AB_DRIFT", "0.002"))      # (0.002: every proposal accepted; AB_DRIFT=0.012 rejects about every third)
+for name, kw in (("MALA", dict(sampler=L.SAMPLER_MALA, driftstep=drift)), ("MH", dict(sampler=L.SAMPLER_MH, mh_sigma=np.full(d, 0.02)))):
     e = K.Engine(target=K.GaussDenseTarget.compound_symmetric(d, 0.5), nchains=n, nsteps=10 ** 6, steps_per_launch=8 if slow else 32, **kw)
     e.init_state_normal(); e.run(8 if slow else 64)
     r = []
