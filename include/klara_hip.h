@@ -80,8 +80,8 @@ typedef enum klara_target {
      * is w = 1/(2 sigma^2), c = -D/2 log(2 pi) - D log sigma. */
     KLARA_TARGET_GAUSS_DIAG = 0,
     /* lt = c - 1/2 (x-mu)' P (x-mu) ; grad = -P (x-mu).  P = dense precision matrix (D x D).  D <= 128: FP64 matrix cores (all four
-     * samplers; P in LDS); D = 129..256: HMC (every tuner), MALA and MH stay on the matrix cores (P streamed from memory; HMC's
-     * momentum in LDS: 64 TFLOP/s at D = 256), the slice sampler takes the same closures through the run-time compiled path, one chain per lane. */
+     * samplers; P in LDS); D = 129..256: all four stay on the matrix cores (P streamed from memory; HMC's momentum in LDS: 64 TFLOP/s
+     * at D = 256); beyond 256 the same closures through the run-time compiled path, one chain per lane. */
     KLARA_TARGET_GAUSS_DENSE = 1,
     /* Bayesian logistic regression of doc/examples/swiss/MALA/analytical.jl:11-18:
      * lt = dot(Xp, y) - sum(log(1+exp(Xp))) - 0.5 (p.p/lambda + D log(2 pi lambda)). */

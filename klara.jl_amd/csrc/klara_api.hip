@@ -187,12 +187,12 @@ static void custom_layout(int D, int lanes, bool lik_prior, int* G, int* E, int*
 }
 static bool custom_lik_prior(const char* src) { return src != nullptr && strstr(src, "KLARA_USER_LIKELIHOOD_PRIOR") != nullptr; }
 
-// the dense Gaussian beyond the LDS-resident layouts (D = 129 .. 256) stays on the matrix cores for HMC (every tuner), MALA and MH
-// (klara_dense_big.h); the slice sampler there takes the closure form (klara_create)
+// the dense Gaussian beyond the LDS-resident layouts (D = 129 .. 256) stays on the matrix cores for every sampler — HMC (every tuner), MALA, MH
+// and (round 5) the slice sampler (klara_dense_big.h); beyond D = 256 the closure form (klara_create)
 static bool dense_streamed(const klara_desc& d)
 {
-    return d.target == KLARA_TARGET_GAUSS_DENSE && d.ndims > 128 && d.ndims <= 256 && d.sampler != KLARA_SAMPLER_SLICE &&
-           getenv("KLARA_DENSE_NO_STREAM") == nullptr;
+    return d.target == KLARA_TARGET_GAUSS_DENSE && d.ndims > 128 && d.ndims <= 256 && getenv("KLARA_DENSE_NO_STREAM") == nullptr &&
+           (d.sampler != KLARA_SAMPLER_SLICE || getenv("KLARA_DENSE_SLICE_NO_STREAM") == nullptr);
 }
 
 static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E, int custom_lanes = 0, int* custom_wpb = nullptr)

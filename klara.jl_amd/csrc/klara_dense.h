@@ -218,6 +218,75 @@ __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int 
     if (TAIL) { g[4 * MTF + 0] = NEG ? -acc_t : acc_t; g[4 * MTF + 1] = 0.0; g[4 * MTF + 2] = 0.0; g[4 * MTF + 3] = 0.0; }
 }
 
+// The slice sampler on a dense target, THE CHAINS OF A TILE OUT OF LOCKSTEP (iterate/SliceSampler.jl:60-109).  A probe is a full evaluation of the
+// log-target (the reference calls logtarget! on the whole vector, :77-94): one matrix pass over the 16 chains of the tile, lt = c + 1/2 (x - mu).g.
+// The columns of that pass are independent — a chain's result depends on its own vector only — and every draw is addressed by (transition,
+// coordinate, attempt), so nothing obliges the 16 chains to probe the same coordinate or the same stage of its update: each chain is a little
+// machine (start of a coordinate -> step-out to the left -> to the right -> shrink attempts -> next coordinate) that takes ONE probe per pass,
+// whichever its stage asks for, and the transition ends when the slowest of the 16 has updated its D coordinates (their probe counts add up over D
+// coordinates, so the spread is a few per cent — in lockstep per loop every pass waited for the slowest of 16 at every stage).  One call site of
+// the matrix pass instead of five.  The candidate is written into the owner lane's register in place; an accepted candidate simply stays.
+// probe(x) returns the log-target of the lane's chain at x, the same in the chain's 4 lanes.  Returns the new log-target in `cur`; `stuck` is sticky.
+template <int NE, class Probe>
+__device__ __forceinline__ void slice_dense_free(const KParams& p, const MfmaCtx<NE>& cx, unsigned long long gchain, unsigned long long t,
+                                                 double (&xp)[NE], double& cur, bool& stuck, Probe probe)
+{
+    int i = 0, ph = 0;                                   // coordinate; stage: 0 start, 1 step-out left, 2 step-out right, 3 shrink
+    bool active = cx.chain_ok && !stuck && p.D > 0;
+    double Li = 0.0, Ri = 0.0, logu = 0.0, xi = 0.0, wd = 0.0;
+    uint32_t a = 1, guard = 0;
+    while (__any(active)) {
+        const int ic = i < p.D ? i : p.D - 1;
+        const int qo = ic & 3, eo = ic >> 2;
+        const uint32_t base = (uint32_t)ic << KLARA_SLICE_ATT_BITS;
+        {   // a chain at the start of coordinate i (:65-73; executed by all, kept by the starting ones)
+            const bool starting = active && ph == 0;
+            double xi_l = 0.0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) xi_l = (e == eo) ? xp[e] : xi_l;
+            const double xs = lane_bcast(xi_l, cx.cl + 16 * qo);
+            const double ws = p.vecparam[ic];
+            const kd_u32x4 b0 = kd_stream_block(p.seed, gchain, t, base);
+            const double lus = kd_log_u01(kd_uniform_xy(b0)) + cur;                            // :66
+            const double ru = kd_uniform_zw(b0);                                               // :71
+            xi = starting ? xs : xi; wd = starting ? ws : wd; logu = starting ? lus : logu;
+            Li = starting ? xs - ru * ws : Li;                                                 // :72
+            Ri = starting ? xs + (1.0 - ru) * ws : Ri;                                         // :73
+            a = starting ? 1u : a; guard = starting ? 0u : guard;
+            ph = starting ? (p.stepout ? 1 : 3) : ph;
+        }
+        const double u = kd_slice_attempt_uniform(p.seed, gchain, t, base, a);
+        const double cand = ph == 1 ? Li : (ph == 2 ? Ri : u * (Ri - Li) + Li);                // :76 / :83 / :92-93
+        const bool owner = active && cx.q == qo;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) xp[e] = (owner && e == eo) ? cand : xp[e];
+        const double lc = probe(xp);                                                           // :77 / :84 / :94
+        const bool above = lc > logu;
+        // step-out (:75-89): while the end is inside the slice, move it out by one width and probe again
+        const bool out = active && ph != 3 && above;
+        guard += out ? 1u : 0u;
+        const bool over = out && guard > (uint32_t)KLARA_SLICE_MAX_ATT;
+        Li = (out && !over && ph == 1) ? Li - wd : Li;
+        Ri = (out && !over && ph == 2) ? Ri + wd : Ri;
+        const bool next_stage = active && ph != 3 && !above;
+        // shrink (:91-106)
+        const bool shr = active && ph == 3;
+        const bool acc = shr && above;                                                         // :95
+        const bool rej = shr && !above;
+        Ri = (rej && cand > xi) ? cand : Ri;                                                   // :98
+        Li = (rej && cand < xi) ? cand : Li;                                                   // :100
+        const bool nowhere = rej && !(cand > xi) && !(cand < xi);                              // :102
+        a += rej ? 1u : 0u;
+        const bool spent = rej && a > (uint32_t)KLARA_SLICE_MAX_ATT;
+        stuck = stuck || over || nowhere || spent;
+        cur = acc ? lc : cur;                                                                  // :108 (the candidate is already in its register)
+        guard = next_stage ? 0u : guard;
+        ph = next_stage ? ph + 1 : (acc ? 0 : ph);
+        i += acc ? 1 : 0;
+        active = active && !stuck && i < p.D;
+    }
+}
+
 // PLAIN: nothing counts proposals or tunes (VanillaMCTuner, not verbose — BASELINE cfg 3): the step is the job's scalar step0, no tuner
 // state is loaded, carried through the launch or written back (13 registers per lane that the generic instantiation spills: 80 B of scratch)
 template <int SAMPLER, int NE, bool DA, bool HASMU = false, bool PLAIN = false>
@@ -385,81 +454,21 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 acc = ratio > kd_log_u01(u);
             }
         } else if (SAMPLER == KLARA_SAMPLER_SLICE) {
-            // iterate/SliceSampler.jl:60-109.  Coordinate i = 4 e + q lives on lane q = i & 3 of its chain as register e = i >> 2.
-            // A probe is a full evaluation of the log-target (the reference calls logtarget! on the whole vector, :77-94): the
-            // gradient GEMM of the 16 chains with coordinate i replaced, then lt = c + 1/2 (x-mu).g.  Loops run until every chain
-            // of the wavefront is done (__any); a finished chain's lanes re-evaluate their last probe.
+            // iterate/SliceSampler.jl:60-109.  Coordinate i = 4 e + q lives on lane q = i & 3 of its chain as register e = i >> 2.  A probe is a full
+            // evaluation of the log-target: the gradient GEMM of the tile's 16 chains, then lt = c + 1/2 (x-mu).g.  Round 5: the chains of the tile
+            // out of lockstep (slice_dense_free above) — every pass serves each chain's own next probe; it used to serve one stage of one
+            // coordinate and wait for the slowest of the 16 at each of five call sites.
             double cur = lt;
-            for (int i = 0; i < p.D; ++i) {                                                    // :65
-                const int qo = i & 3, eo = i >> 2;
-                const bool owner = cx.q == qo;
-                double xi_l = 0.0;
+            slice_dense_free<NE>(p, cx, gch(), t, xp, cur, stuck, [&](const double (&xt)[NE]) {
+                double gt[NG], r1[1];
+                dense_grad<NE, HASMU>(ldsP, cx.lane, xt, gt, ldsMu);
+                double l1 = 0.0;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) if (e == eo) xi_l = xp[e];
-                const double xi = lane_bcast(xi_l, cx.cl + 16 * qo);
-                const double wd = p.vecparam[i];
-                const uint32_t base = (uint32_t)i << KLARA_SLICE_ATT_BITS;
-                const kd_u32x4 b0 = kd_stream_block(p.seed, gch(), t, base);
-                const double logu = kd_log_u01(kd_uniform_xy(b0)) + cur;                       // :66
-                const double ru = kd_uniform_zw(b0);                                           // :71
-                double Li = xi - ru * wd;                                                      // :72
-                double Ri = xi + (1.0 - ru) * wd;                                              // :73
-                const auto lt_with = [&](double cand) -> double {
-                    double xt[NE], gt[NG], r1[1];
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) xt[e] = (owner && e == eo) ? cand : xp[e];
-                    dense_grad<NE, HASMU>(ldsP, cx.lane, xt, gt, ldsMu);
-                    double l1 = 0.0;
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) l1 = l1 + dx(xt, e) * gt[e];
-                    r1[0] = l1;
-                    mreduce<1>(r1, cx.lane);
-                    return p.gconst + 0.5 * r1[0];
-                };
-                if (p.stepout) {                                                               // :75-89
-                    double l = lt_with(Li);
-                    int guard = 0;
-                    while (true) {
-                        bool go = cx.chain_ok && !stuck && (l > logu);
-                        if (go && ++guard > KLARA_SLICE_MAX_ATT) { stuck = true; go = false; }
-                        if (!__any(go)) break;
-                        const double Ln = Li - wd;
-                        const double ln = lt_with(go ? Ln : Li);
-                        if (go) { Li = Ln; l = ln; }
-                    }
-                    double r = lt_with(Ri);
-                    guard = 0;
-                    while (true) {
-                        bool go = cx.chain_ok && !stuck && (r > logu);
-                        if (go && ++guard > KLARA_SLICE_MAX_ATT) { stuck = true; go = false; }
-                        if (!__any(go)) break;
-                        const double Rn = Ri + wd;
-                        const double rn = lt_with(go ? Rn : Ri);
-                        if (go) { Ri = Rn; r = rn; }
-                    }
-                }
-                double xprime = xi, ltnew = cur;
-                bool done = !cx.chain_ok || stuck;
-                for (uint32_t a = 1;; ++a) {                                                   // :91-106
-                    if (!done && a > KLARA_SLICE_MAX_ATT) { stuck = true; done = true; }
-                    if (!__any(!done)) break;
-                    const double u = kd_slice_attempt_uniform(p.seed, gch(), t, base, a);
-                    const double cand = u * (Ri - Li) + Li;                                    // :92-93
-                    const double lc = lt_with(done ? xprime : cand);                           // :94
-                    if (!done) {
-                        xprime = cand; ltnew = lc;
-                        if (lc > logu) done = true;                                            // :95
-                        else if (cand > xi) Ri = cand;                                         // :98
-                        else if (cand < xi) Li = cand;                                         // :100
-                        else { stuck = true; done = true; }                                    // :102
-                    }
-                }
-                if (!stuck) {
-                    cur = ltnew;
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) if (owner && e == eo) xp[e] = xprime;         // :108
-                }
-            }
+                for (int e = 0; e < NE; ++e) l1 = l1 + dx(xt, e) * gt[e];
+                r1[0] = l1;
+                mreduce<1>(r1, cx.lane);
+                return p.gconst + 0.5 * r1[0];
+            });
             ltp = cur;
             acc = true;                                                // the slice sampler always moves (SliceSampler.jl:108)
         } else {

@@ -41,8 +41,7 @@ static hipError_t launch_dense_s(const KParams* p, const KLaunch& kl, int NE, co
 hipError_t klara_launch_dense(const KParams* p, const KLaunch& kl, int sampler, int tuner, bool plain, int NE, const double* Pfrag, bool hasmu,
                               dim3 grid, hipStream_t st)
 {
-    if (NE > 32) return sampler != KLARA_SAMPLER_SLICE ? klara_launch_dense_big(p, kl, sampler, tuner == KLARA_TUNER_DUAL_AVERAGING, NE, Pfrag, hasmu, grid, st)
-                                                       : hipErrorInvalidValue;
+    if (NE > 32) return klara_launch_dense_big(p, kl, sampler, tuner == KLARA_TUNER_DUAL_AVERAGING, NE, Pfrag, hasmu, grid, st);
     switch (sampler) {
     case KLARA_SAMPLER_MH: return launch_dense_s<KLARA_SAMPLER_MH, false>(p, kl, NE, Pfrag, hasmu, grid, st);
     case KLARA_SAMPLER_MALA: return launch_dense_s<KLARA_SAMPLER_MALA, false>(p, kl, NE, Pfrag, hasmu, grid, st);

@@ -13,7 +13,8 @@
 //   * HMC (Vanilla / AcceptanceRate tuners per chain or pooled, and dual averaging with its per-chain trip counts; every monitor), and — with no
 //     LDS at all — MALA and MH: their proposal overwrites the value registers as its normals are drawn, the current gradient (accumulators) is
 //     consumed by the same pass, and the current value is re-read from X for MALA's backward term, so nothing beyond x and P x is ever held.
-//     Only the slice sampler beyond D = 128 stays on the closure form (klara_api.hip KLARA_DENSE_WIDE_SRC): a probe is a full evaluation.
+//   * The slice sampler (round 5): a probe is a full evaluation = one pass over P for the tile's 16 chains, each chain at its own coordinate and
+//     stage (slice_dense_free, klara_dense.h); no LDS column.
 // Same MFMA instruction, same k-ascending fma chain per output (zero-padded rows / columns add exact zeros), same merged fma leapfrog, same
 // 4-lane reduction tree: the oracle's ko_hmc / ko_dense_grad in layout kind 1, bit for bit.
 #pragma once
@@ -144,10 +145,11 @@ template <int SAMPLER, int NE, bool HASMU = false, bool DA = false>
 __global__ __launch_bounds__(256)
 void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
 {
-    static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH, "HMC, MALA, MH");
-    constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;          // MH carries no gradient (GR is not written)
+    static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_SLICE, "HMC, MALA, MH, slice");
+    constexpr bool SLICE = SAMPLER == KLARA_SAMPLER_SLICE;
+    constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH && !SLICE;    // MH and the slice sampler carry no gradient (GR is not written)
     constexpr bool KEEPG = NEEDG;                               // the committed gradient stays in the accumulators between transitions (re-read from GR only after a reject)
-    constexpr bool XLDS = SAMPLER != KLARA_SAMPLER_HMC;          // MALA / MH: the current value waits in the lane's LDS column (MALA: where its normals were, for the backward term) — a rejected proposal is undone from there
+    constexpr bool XLDS = SAMPLER != KLARA_SAMPLER_HMC && !SLICE;   // MALA / MH: the current value waits in the lane's LDS column (MALA: where its normals were, for the backward term) — a rejected proposal is undone from there
     // ... so nothing inside a launch reads X: the value is written ONCE, after the last transition (it was 2 KB per chain and accepted transition at D = 256:
     // half of MALA's and all of MH's write stream, 4.3 GB per 32-transition launch, through the L2 that also holds P)
     constexpr bool XONCE = XLDS && !KLARA_BIG_X_EVERY;
@@ -167,7 +169,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
     if (SIGLDS) { for (int i = threadIdx.x; i < 4 * NE; i += blockDim.x) ldsSig[i] = (p.vecparam != nullptr && i < p.D) ? p.vecparam[i] : 0.0; }
     kd_tables_to_lds();          // (also the barrier for mu / sigma)
     const MfmaCtx<NE> cx = make_mctx<NE>(p);
-    double* const momw = ldsSig + (SIGLDS ? 4 * NE : 0) + (size_t)(threadIdx.x >> 6) * NE * 64 + cx.lane;     // this lane's column: momentum (HMC), normals then the current value (MALA), the current value (MH)
+    double* const momw = ldsSig + (SIGLDS ? 4 * NE : 0) + (SLICE ? 0 : (size_t)(threadIdx.x >> 6) * NE * 64 + cx.lane);     // (the slice sampler has none) this lane's column: momentum (HMC), normals then the current value (MALA), the current value (MH)
     const unsigned long long gchain = (unsigned long long)(p.chain_offset + cx.chain);
     const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
     TuneRegs tn = { p.tune_step[tix], p.tune_accepted[tix], p.tune_proposed[tix], p.tune_totproposed[tix], 0, 0.0, 0.0 };
@@ -177,6 +179,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
     long long scol = kl.save_col0;
     double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
     unsigned long long nacc = 0;
+    bool stuck = false;                                  // slice sampler: step-out / shrink ran out of attempts
     const bool do_sum = p.sum != nullptr;
     long long held = do_sum ? p.held[cx.chain_ok ? cx.chain : 0] : 0;
     const __amdgpu_buffer_rsrc_t wX = mwin<NE>(cx, p.X, 0, p.D), wG = mwin<NE>(cx, p.GR, 0, p.D);
@@ -310,6 +313,18 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
                 const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
                 acc = acc || ratio > kd_log_u01(u);
             }
+        } else if constexpr (SLICE) {
+            // iterate/SliceSampler.jl:60-109 — the 16 chains of the tile out of lockstep, one pass over P per probe (slice_dense_free, klara_dense.h)
+            slice_dense_free<NE>(p, cx, gchain, t, xp, ltp, stuck, [&](const double (&x)[NE]) {
+                dense_stream<NE, HASMU>(Pfrag, cx.lane, x, ga, ldsMu);
+                double l1 = 0.0, r1[1];
+#pragma unroll
+                for (int e = 0; e < NE; ++e) l1 = l1 + (HASMU ? x[e] - ldsMu[4 * e + cx.q] : x[e]) * (-(double)ga[e >> 2][e & 3]);
+                r1[0] = l1;
+                mreduce<1>(r1, cx.lane);
+                return p.gconst + 0.5 * r1[0];
+            });
+            acc = true;                                  // the slice sampler always moves (SliceSampler.jl:108)
         } else {
             // iterate/MH.jl:72-124
             mnormals_each<NE>(cx, p.seed, gchain, t, [&](int e, double z) {
@@ -359,7 +374,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const unsigned o = acc ? cx.off(e, nv) : KLARA_BUF_OOB;
-                constexpr int AUX = SAMPLER == KLARA_SAMPLER_HMC ? KLARA_BIG_HMC_AUX : KLARA_BIG_G_AUX;
+                constexpr int AUX = SAMPLER == KLARA_SAMPLER_HMC ? KLARA_BIG_HMC_AUX : (SAMPLER == KLARA_SAMPLER_MALA ? KLARA_BIG_G_AUX : 0);
                 if (!XONCE) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, xp[e]), wX, o, 0, AUX);
                 if (NEEDG) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, (double)ga[e >> 2][e & 3]), wG, o, 0, AUX);
             }
@@ -390,7 +405,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             }
         }
         nacc += acc ? 1ull : 0ull;
-        tn.accepted += (p.cnt && acc) ? 1 : 0;
+        tn.accepted += (p.cnt && acc && !SLICE) ? 1 : 0;          // (the slice sampler never counts accepts)
         if (accept_out != nullptr) {                     // (one byte per chain from its q = 0 lane; the other lanes address out of bounds)
             const __amdgpu_buffer_rsrc_t wa = __builtin_amdgcn_make_buffer_rsrc((void*)(accept_out + (long long)s * p.nchains + cx.first_chain), 0,
                                                                                 __builtin_amdgcn_readfirstlane(cx.here), 0x00020000);
@@ -440,6 +455,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
         }
     }
 
+    if (SLICE && stuck && cx.chain_ok && cx.q == 0) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);
     if (XONCE) {                                         // the committed value, once per launch
         const int nv = cx.nv_here();
 #pragma unroll

@@ -1,4 +1,4 @@
-// klara_dense_big.hip — instantiates the streamed dense-Gaussian kernels (D = 129 .. 256: NE = 40, 48, 56, 64 elements per lane; HMC — also with dual averaging —, MALA, MH) for gfx950.
+// klara_dense_big.hip — instantiates the streamed dense-Gaussian kernels (D = 129 .. 256: NE = 40, 48, 56, 64 elements per lane; HMC — also with dual averaging —, MALA, MH, slice) for gfx950.
 #include "klara_launch.h"
 #define KLARA_DENSE_NO_PROBES 1
 #include "klara_dense_big.h"
@@ -7,7 +7,7 @@ template <int S, int N, bool HASMU, bool DA = false>
 static hipError_t go_big(const KParams* p, const KLaunch& kl, const double* Pfrag, dim3 grid, hipStream_t st)
 {
     // mu + (HMC: momentum, MALA: the proposal's normals) the four wavefronts' columns
-    constexpr size_t lds = sizeof(double) * ((HASMU ? 4 * N : 0) + (S == KLARA_SAMPLER_MH ? 4 * N : 0) + 4 * (size_t)N * 64);      // mu, MH's sigma, one column per lane of the 4 wavefronts
+    constexpr size_t lds = sizeof(double) * ((HASMU ? 4 * N : 0) + (S == KLARA_SAMPLER_MH ? 4 * N : 0) + (S == KLARA_SAMPLER_SLICE ? 0 : 4 * (size_t)N * 64));      // mu, MH's sigma, one column per lane of the 4 wavefronts (none for the slice sampler)
     if (lds > KLARA_LDS_DEFAULT_DYNAMIC) {
         hipError_t e = hipFuncSetAttribute((const void*)k_dense_big<S, N, HASMU, DA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -31,6 +31,7 @@ hipError_t klara_launch_dense_big(const KParams* p, const KLaunch& kl, int sampl
     case KLARA_SAMPLER_HMC: return da ? go_big_s<KLARA_SAMPLER_HMC, true>(p, kl, NE, Pfrag, hasmu, grid, st) : go_big_s<KLARA_SAMPLER_HMC>(p, kl, NE, Pfrag, hasmu, grid, st);
     case KLARA_SAMPLER_MALA: return go_big_s<KLARA_SAMPLER_MALA>(p, kl, NE, Pfrag, hasmu, grid, st);
     case KLARA_SAMPLER_MH: return go_big_s<KLARA_SAMPLER_MH>(p, kl, NE, Pfrag, hasmu, grid, st);
+    case KLARA_SAMPLER_SLICE: return go_big_s<KLARA_SAMPLER_SLICE>(p, kl, NE, Pfrag, hasmu, grid, st);
     default: return hipErrorInvalidValue;
     }
 }

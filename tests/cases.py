@@ -443,13 +443,14 @@ def make_case(name):
         x0 = t.least_squares_start()[None, :] + 0.05 * np.random.default_rng(10).standard_normal((21, t.ndims))
         c = dict(sampler=L.SAMPLER_MALA, target=t, nchains=21, nsteps=60, burnin=40, driftstep=2e-3, tuner=L.TUNER_ACCEPT_RATE,
                  targetrate=0.574, period=10, x0=x0)
-    elif name in ("slice_dense_d20", "slice_dense_d37_mean"):   # slice sampler on the dense target: every probe is a full MFMA evaluation
+    elif name in ("slice_dense_d20", "slice_dense_d37_mean", "slice_dense_d192_stream", "slice_dense_d130_stream_mean", "slice_dense_d256_stream"):
+        # slice sampler on the dense target: every probe is a full MFMA evaluation (round 5: beyond D = 128 on the streamed layouts, the chains of a tile out of lockstep)
         d = int(name.split("_")[2][1:])
         rng = np.random.default_rng(300 + d)
         a = rng.standard_normal((d, d)); p = a @ a.T / d + np.eye(d)
         mean = name.endswith("mean")
         t = K.GaussDenseTarget(p, const=-1.25, mu=rng.standard_normal(d) if mean else None)
-        c = dict(sampler=L.SAMPLER_SLICE, target=t, nchains=21, nsteps=6, burnin=1, slice_widths=np.linspace(0.4, 2.5, d),
+        c = dict(sampler=L.SAMPLER_SLICE, target=t, nchains=21, nsteps=6 if d <= 128 else 3, burnin=1, slice_widths=np.linspace(0.4, 2.5, d),
                  slice_stepout=not mean, x0=rng.standard_normal((21, d)) + (t.mu if mean else 0.0))
     elif name == "slice_d20_stepout":  # pair-transposed layout: step-out and shrink loops with per-chain trip counts, non-unit diagonal
         c = dict(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 2, 20), np.linspace(0.5, 3.0, 20)), nchains=37,
@@ -606,7 +607,8 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "hmc_dense_d100_mean", "mala_dense_d37_mean", "mh_dense_d20_mean",
              "hmc_dense_d70_mean_dualavg", "slice_dense_d20", "slice_dense_d37_mean", "mh_dense_d130_wide", "hmc_dense_d130_wide",
              "hmc_dense_d256_stream_tuned", "hmc_dense_d192_stream_mean", "hmc_dense_d160_stream_pooled", "hmc_dense_d129_stream", "hmc_dense_d201_stream",
-             "mala_dense_d200_stream_tuned", "mh_dense_d256_stream_mean", "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
+             "mala_dense_d200_stream_tuned", "mh_dense_d256_stream_mean", "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide",
+             "slice_dense_d192_stream", "slice_dense_d130_stream_mean", "slice_dense_d256_stream", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
              "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide", "hmc_logit_d20_wide", "slice_d20_stepout", "mh_rats", "mala_rats_tuned",
              "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"] + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",

@@ -435,7 +435,7 @@ def test_pair_transposed_layout_is_optional():
 @pytest.mark.parametrize("name", ["hmc_dense_d130_wide", "mh_dense_d130_wide", "hmc_dense_d130_dualavg_wide"])
 def test_dense_target_beyond_128_closure_form_still_matches(name, monkeypatch):
     """Round 4 moved HMC / MALA / MH on dense targets of 129..256 dimensions onto the matrix cores (streamed P); the run-time compiled closure form
-    they used to take (one chain per lane) remains what the slice sampler and D > 256 run, and KLARA_DENSE_NO_STREAM=1 selects it for every sampler:
+    they used to take (one chain per lane) remains what D > 256 runs (round 5 moved the slice sampler over too), and KLARA_DENSE_NO_STREAM=1 selects it for every sampler:
     both forms against the oracle in their own summation orders (layout kind 1 on 4 lanes; kind 0 on one lane), bit for bit."""
     case = cases.make_case(name)
     eng, job = _run_pair(case)
@@ -879,6 +879,7 @@ def _random_case(seed, wide=False):
 
 _BIG = [(smp, d, mu) for smp in ("mh", "mala", "hmc", "hmc_rate", "hmc_da") for d in (130, 161, 193, 256) for mu in (False, True)] + \
        [(smp, d, mu) for smp in ("mh", "mala", "hmc", "hmc_da") for d in (21, 37, 70, 128) for mu in (False, True)]      # (P in LDS, klara_dense.h: NE = 8, 16, 25, 32)
+_BIG += [("slice", d, mu) for d in (130, 161, 193, 256) for mu in (False, True)]       # (round 5: the slice sampler on the streamed layouts; step-out on without a mean, off with one)
 
 
 @pytest.mark.parametrize("smp,d,mu", _BIG, ids=[f"{a}-d{b}-{'mean' if m else 'nomean'}" for a, b, m in _BIG])
@@ -892,7 +893,9 @@ def test_every_streamed_dense_instantiation_in_one_launch(smp, d, mu):
     rng = np.random.default_rng(d + 7 * len(smp) + int(mu))
     target = K.GaussDenseTarget(cases.compound_symmetric_precision(d, 0.4), const=0.3, mu=(rng.uniform(-1.5, 1.5, d) if mu else None))
     c = dict(target=target, nchains=21, x0=None, seed=4242 + d, name=f"big_{smp}_{d}_{int(mu)}", burnin=2, thinning=2, nsteps=14)
-    if smp == "mh":
+    if smp == "slice":               # (a probe is a full evaluation: D x ~6 of them per transition and chain on the oracle's side)
+        c.update(sampler=L.SAMPLER_SLICE, slice_widths=np.linspace(0.5, 2.0, d), slice_stepout=not mu, nsteps=5, burnin=1)
+    elif smp == "mh":
         c.update(sampler=L.SAMPLER_MH, mh_sigma=np.full(d, 0.07) * rng.uniform(0.7, 1.3, d))
     elif smp == "mala":
         c.update(sampler=L.SAMPLER_MALA, driftstep=0.3)
@@ -902,20 +905,21 @@ def test_every_streamed_dense_instantiation_in_one_launch(smp, d, mu):
             c.update(tuner=L.TUNER_ACCEPT_RATE, targetrate=0.6, period=4)
         if smp == "hmc_da":
             c.update(tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=9)
-    mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT | (L.MON_HIST_GRAD if smp != "mh" else 0)
+    nograd = smp in ("mh", "slice")
+    mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT | (0 if nograd else L.MON_HIST_GRAD)
     eng = K.Engine(**cases.engine_kwargs(c, monitor=mon, steps_per_launch=0, nstreams=1))
     assert eng.layout() == (1, 4, 8 * ((d + 31) // 32) if d > 128 else {21: 8, 37: 16, 70: 25, 128: 32}[d]), eng.layout()
     job = O.OracleJob(**cases.oracle_kwargs(c, layout=eng.layout()), want_hist=True)
     eng.init_state_normal(); assert job.init_state_normal() == 0
     eng.run(c["nsteps"]); assert job.run(c["nsteps"]) == 0
     rate = job.accept.mean()
-    assert 0.05 < rate < 0.95, rate                    # both the commit and the re-read are exercised
+    assert rate == 1.0 if smp == "slice" else 0.05 < rate < 0.95, rate                    # both the commit and the re-read are exercised
     _assert_same(eng, job, c)
     for ch in (0, 17, 20):
         assert np.array_equal(eng.chain(ch), job.hist[:, ch, :].T), "history differs"
-        lt, g = eng.chain_fields(ch, logtarget=True, gradlogtarget=smp != "mh")
+        lt, g = eng.chain_fields(ch, logtarget=True, gradlogtarget=not nograd)
         assert np.array_equal(lt, job.hist_lt[:, ch])
-        if smp != "mh":
+        if not nograd:
             assert np.array_equal(g, job.hist_g[:, ch, :].T)
     eng.close()
 
@@ -923,7 +927,7 @@ def test_every_streamed_dense_instantiation_in_one_launch(smp, d, mu):
 @pytest.mark.parametrize("seed", range(48))
 def test_random_configurations_wide(seed):
     """48 more jobs from the sizes that moved onto hand-written kernels in round 4 (dense 129..256 dimensions on the streamed matrix-core layouts — HMC with
-    every tuner, MALA, MH —, the slice sampler there on the closure form at a few chains; logistic regression with 9..16 parameters), run like the others."""
+    every tuner, MALA, MH; logistic regression with 9..16 parameters), run like the others."""
     _run_random(*_random_case(seed, wide=True))
 
 
