@@ -218,73 +218,30 @@ __device__ __forceinline__ void dense_grad(const double* __restrict__ ldsP, int 
     if (TAIL) { g[4 * MTF + 0] = NEG ? -acc_t : acc_t; g[4 * MTF + 1] = 0.0; g[4 * MTF + 2] = 0.0; g[4 * MTF + 3] = 0.0; }
 }
 
-// The slice sampler on a dense target, THE CHAINS OF A TILE OUT OF LOCKSTEP (iterate/SliceSampler.jl:60-109).  A probe is a full evaluation of the
-// log-target (the reference calls logtarget! on the whole vector, :77-94): one matrix pass over the 16 chains of the tile, lt = c + 1/2 (x - mu).g.
-// The columns of that pass are independent — a chain's result depends on its own vector only — and every draw is addressed by (transition,
-// coordinate, attempt), so nothing obliges the 16 chains to probe the same coordinate or the same stage of its update: each chain is a little
-// machine (start of a coordinate -> step-out to the left -> to the right -> shrink attempts -> next coordinate) that takes ONE probe per pass,
-// whichever its stage asks for, and the transition ends when the slowest of the 16 has updated its D coordinates (their probe counts add up over D
-// coordinates, so the spread is a few per cent — in lockstep per loop every pass waited for the slowest of 16 at every stage).  One call site of
-// the matrix pass instead of five.  The candidate is written into the owner lane's register in place; an accepted candidate simply stays.
-// probe(x) returns the log-target of the lane's chain at x, the same in the chain's 4 lanes.  Returns the new log-target in `cur`; `stuck` is sticky.
+// The slice sampler on a dense target, the chains of a tile out of lockstep (slice_free_machine, klara_kernels.h): a probe is one matrix pass over the
+// 16 chains of the tile, lt = c + 1/2 (x - mu).g, and each chain takes from it the probe its own coordinate and stage ask for (round 4: one stage of one
+// coordinate per pass, waiting for the slowest of the 16, at five call sites of the pass).  Coordinate i = 4 e + q lives on lane q = i & 3 of its chain as
+// register e = i >> 2.  probe(x) returns the log-target of the lane's chain at x, the same in the chain's 4 lanes.
 template <int NE, class Probe>
 __device__ __forceinline__ void slice_dense_free(const KParams& p, const MfmaCtx<NE>& cx, unsigned long long gchain, unsigned long long t,
                                                  double (&xp)[NE], double& cur, bool& stuck, Probe probe)
 {
-    int i = 0, ph = 0;                                   // coordinate; stage: 0 start, 1 step-out left, 2 step-out right, 3 shrink
-    bool active = cx.chain_ok && !stuck && p.D > 0;
-    double Li = 0.0, Ri = 0.0, logu = 0.0, xi = 0.0, wd = 0.0;
-    uint32_t a = 1, guard = 0;
-    while (__any(active)) {
-        const int ic = i < p.D ? i : p.D - 1;
-        const int qo = ic & 3, eo = ic >> 2;
-        const uint32_t base = (uint32_t)ic << KLARA_SLICE_ATT_BITS;
-        {   // a chain at the start of coordinate i (:65-73; executed by all, kept by the starting ones)
-            const bool starting = active && ph == 0;
+    slice_free_machine(p, cx.chain_ok, gchain, t, cur, stuck,
+        [&](int i, double& xs, double& ws) {
+            const int qo = i & 3, eo = i >> 2;
             double xi_l = 0.0;
 #pragma unroll
             for (int e = 0; e < NE; ++e) xi_l = (e == eo) ? xp[e] : xi_l;
-            const double xs = lane_bcast(xi_l, cx.cl + 16 * qo);
-            const double ws = p.vecparam[ic];
-            const kd_u32x4 b0 = kd_stream_block(p.seed, gchain, t, base);
-            const double lus = kd_log_u01(kd_uniform_xy(b0)) + cur;                            // :66
-            const double ru = kd_uniform_zw(b0);                                               // :71
-            xi = starting ? xs : xi; wd = starting ? ws : wd; logu = starting ? lus : logu;
-            Li = starting ? xs - ru * ws : Li;                                                 // :72
-            Ri = starting ? xs + (1.0 - ru) * ws : Ri;                                         // :73
-            a = starting ? 1u : a; guard = starting ? 0u : guard;
-            ph = starting ? (p.stepout ? 1 : 3) : ph;
-        }
-        const double u = kd_slice_attempt_uniform(p.seed, gchain, t, base, a);
-        const double cand = ph == 1 ? Li : (ph == 2 ? Ri : u * (Ri - Li) + Li);                // :76 / :83 / :92-93
-        const bool owner = active && cx.q == qo;
+            xs = lane_bcast(xi_l, cx.cl + 16 * qo);
+            ws = p.vecparam[i];
+        },
+        [&](int i, bool on, double cand) {
+            const int qo = i & 3, eo = i >> 2;
+            const bool owner = on && cx.q == qo;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) xp[e] = (owner && e == eo) ? cand : xp[e];
-        const double lc = probe(xp);                                                           // :77 / :84 / :94
-        const bool above = lc > logu;
-        // step-out (:75-89): while the end is inside the slice, move it out by one width and probe again
-        const bool out = active && ph != 3 && above;
-        guard += out ? 1u : 0u;
-        const bool over = out && guard > (uint32_t)KLARA_SLICE_MAX_ATT;
-        Li = (out && !over && ph == 1) ? Li - wd : Li;
-        Ri = (out && !over && ph == 2) ? Ri + wd : Ri;
-        const bool next_stage = active && ph != 3 && !above;
-        // shrink (:91-106)
-        const bool shr = active && ph == 3;
-        const bool acc = shr && above;                                                         // :95
-        const bool rej = shr && !above;
-        Ri = (rej && cand > xi) ? cand : Ri;                                                   // :98
-        Li = (rej && cand < xi) ? cand : Li;                                                   // :100
-        const bool nowhere = rej && !(cand > xi) && !(cand < xi);                              // :102
-        a += rej ? 1u : 0u;
-        const bool spent = rej && a > (uint32_t)KLARA_SLICE_MAX_ATT;
-        stuck = stuck || over || nowhere || spent;
-        cur = acc ? lc : cur;                                                                  // :108 (the candidate is already in its register)
-        guard = next_stage ? 0u : guard;
-        ph = next_stage ? ph + 1 : (acc ? 0 : ph);
-        i += acc ? 1 : 0;
-        active = active && !stuck && i < p.D;
-    }
+            for (int e = 0; e < NE; ++e) xp[e] = (owner && e == eo) ? cand : xp[e];
+        },
+        [&]() { return probe(xp); });
 }
 
 // PLAIN: nothing counts proposals or tunes (VanillaMCTuner, not verbose — BASELINE cfg 3): the step is the job's scalar step0, no tuner

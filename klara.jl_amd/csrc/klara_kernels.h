@@ -959,12 +959,102 @@ KLARA_PRAGMA_UNROLL_E
     return acc;
 }
 
-// iterate!(job, SliceSampler, Multivariate) — iterate/SliceSampler.jl:60-109.
-// Coordinates are visited serially; the step-out and shrink loops have per-chain trip counts, so when
-// a wavefront carries several chains the loops run until every chain is done (wave-uniform control
-// flow via __any; finished chains are masked).
+// iterate!(job, SliceSampler, Multivariate) — iterate/SliceSampler.jl:60-109 — with THE CHAINS OF A WAVEFRONT OUT OF LOCKSTEP (round 5).
+// A probe is a full evaluation of the log-target (the reference calls logtarget! on the whole vector, :77-94), made by all chains of the wavefront
+// at once; a chain's result depends on its own vector only, and every draw is addressed by (transition, coordinate, attempt).  So nothing obliges
+// the chains to probe the same coordinate or the same stage of its update: each chain is a little machine (start of a coordinate -> step-out to the
+// left -> to the right -> shrink attempts -> next coordinate) that takes ONE probe per pass, whichever its stage asks for, and the transition ends
+// when the slowest chain of the wavefront has updated its D coordinates (probe counts add up over the coordinates, so the spread is a few per cent;
+// rounds 1-4 ran every loop until the slowest chain of the wavefront was through it, at five call sites of the evaluation).  The candidate is
+// written into the owner lane's register in place; an accepted candidate simply stays there.
+//   read_coord(i, x_i, w_i): value and width of coordinate i of the lane's chain (the same in all lanes of the chain);
+//   place(i, on, cand): the owner lane of coordinate i writes cand into its register when `on`;   probe(): log-target of the lane's chain.
+// `cur` is the chain's log-target (in: current, out: new); `stuck` is sticky (KLARA_ERR_SLICE_STUCK: the chain's state is unspecified from then on).
+template <class ReadCoord, class Place, class Probe>
+__device__ __forceinline__ void slice_free_machine(const KParams& p, bool chain_ok, unsigned long long gchain, unsigned long long t,
+                                                   double& cur, bool& stuck, ReadCoord read_coord, Place place, Probe probe)
+{
+    int i = 0, ph = 0;                                   // coordinate; stage: 0 start, 1 step-out left, 2 step-out right, 3 shrink
+    bool active = chain_ok && !stuck && p.D > 0;
+    double Li = 0.0, Ri = 0.0, logu = 0.0, xi = 0.0, wd = 0.0;
+    uint32_t a = 1, guard = 0;
+    while (__any(active)) {
+        const int ic = i < p.D ? i : p.D - 1;
+        const uint32_t base = (uint32_t)ic << KLARA_SLICE_ATT_BITS;
+        {   // a chain at the start of coordinate i (:65-73; executed by all, kept by the starting ones)
+            const bool starting = active && ph == 0;
+            double xs, ws;
+            read_coord(ic, xs, ws);
+            const kd_u32x4 b0 = kd_stream_block(p.seed, gchain, t, base);
+            const double lus = kd_log_u01(kd_uniform_xy(b0)) + cur;                            // :66
+            const double ru = kd_uniform_zw(b0);                                               // :71
+            xi = starting ? xs : xi; wd = starting ? ws : wd; logu = starting ? lus : logu;
+            Li = starting ? xs - ru * ws : Li;                                                 // :72
+            Ri = starting ? xs + (1.0 - ru) * ws : Ri;                                         // :73
+            a = starting ? 1u : a; guard = starting ? 0u : guard;
+            ph = starting ? (p.stepout ? 1 : 3) : ph;
+        }
+        const double u = kd_slice_attempt_uniform(p.seed, gchain, t, base, a);
+        const double cand = ph == 1 ? Li : (ph == 2 ? Ri : u * (Ri - Li) + Li);                // :76 / :83 / :92-93
+        place(ic, active, cand);
+        const double lc = probe();                                                             // :77 / :84 / :94
+        const bool above = lc > logu;
+        // step-out (:75-89): while the end is inside the slice, move it out by one width and probe again
+        const bool out = active && ph != 3 && above;
+        guard += out ? 1u : 0u;
+        const bool over = out && guard > (uint32_t)KLARA_SLICE_MAX_ATT;
+        Li = (out && !over && ph == 1) ? Li - wd : Li;
+        Ri = (out && !over && ph == 2) ? Ri + wd : Ri;
+        const bool next_stage = active && ph != 3 && !above;
+        // shrink (:91-106)
+        const bool shr = active && ph == 3;
+        const bool acc = shr && above;                                                         // :95
+        const bool rej = shr && !above;
+        Ri = (rej && cand > xi) ? cand : Ri;                                                   // :98
+        Li = (rej && cand < xi) ? cand : Li;                                                   // :100
+        const bool nowhere = rej && !(cand > xi) && !(cand < xi);                              // :102
+        a += rej ? 1u : 0u;
+        const bool spent = rej && a > (uint32_t)KLARA_SLICE_MAX_ATT;
+        stuck = stuck || over || nowhere || spent;
+        cur = acc ? lc : cur;                                                                  // :108 (the candidate is already in its register)
+        guard = next_stage ? 0u : guard;
+        ph = next_stage ? ph + 1 : (acc ? 0 : ph);
+        i += acc ? 1 : 0;
+        active = active && !stuck && i < p.D;
+    }
+}
+
+// the group layout: coordinate i lives on lane qo = i / E of its chain's G lanes as register eo = i - qo E
 template <class T, int E>
-__device__ __forceinline__ bool step_slice(const KParams& p, const T& tg, const LaneCtx<E>& cx,
+__device__ __forceinline__ bool step_slice_free(const KParams& p, const T& tg, const LaneCtx<E>& cx,
+                                           unsigned long long gchain, unsigned long long t,
+                                           const double (&widths)[E], double (&x)[E], double& lt,
+                                           bool& stuck)
+{
+    const int group_base = cx.lane - cx.q;
+    slice_free_machine(p, cx.chain_ok, gchain, t, lt, stuck,
+        [&](int i, double& xs, double& ws) {
+            const int qo = i / E, eo = i - qo * E;
+            double xi_l = 0.0, w_l = 0.0;
+KLARA_PRAGMA_UNROLL_E
+            for (int e = 0; e < E; ++e) { xi_l = (e == eo) ? x[e] : xi_l; w_l = (e == eo) ? widths[e] : w_l; }
+            xs = (cx.G > 1) ? lane_bcast(xi_l, group_base + qo) : xi_l;
+            ws = (cx.G > 1) ? lane_bcast(w_l, group_base + qo) : w_l;
+        },
+        [&](int i, bool on, double cand) {
+            const int qo = i / E, eo = i - qo * E;
+            const bool owner = on && cx.q == qo;
+KLARA_PRAGMA_UNROLL_E
+            for (int e = 0; e < E; ++e) x[e] = (owner && e == eo) ? cand : x[e];
+        },
+        [&]() { return eval_lt<T, E>(tg, cx, x); });
+    return true;
+}
+
+// The loops in lockstep (rounds 1-4): the step-out and shrink loops run until every chain of the wavefront is through them (wave-uniform control
+// flow via __any; finished chains are masked).  Kept for the jobs where it measures faster, see step_slice below.
+template <class T, int E>
+__device__ __forceinline__ bool step_slice_lockstep(const KParams& p, const T& tg, const LaneCtx<E>& cx,
                                            unsigned long long gchain, unsigned long long t,
                                            const double (&widths)[E], double (&x)[E], double& lt,
                                            bool& stuck)
@@ -1036,6 +1126,23 @@ KLARA_PRAGMA_UNROLL_E
         }
     }
     return true;
+}
+
+// Which form runs (same box, profiles/r5_ab_slice_group.txt): the free-running machine spends ~150 instructions per pass on its own bookkeeping (the
+// starting block and the attempt's block are formed in every pass, because some chain of the wavefront needs them in every pass), the lockstep form
+// wastes passes (the slowest of the wavefront's chains at every stage).  Without step-out (one stage: the waste is all in the shrink loop) the machine
+// wins on every target tried (+1 % .. +35 %); with step-out it wins where a probe is expensive next to the bookkeeping — the logistic regression's
+// pass over its data rows: +37 % — and loses on cheap probes (-14 % .. -28 %), which therefore keep the lockstep form.
+template <class T> struct SliceProbeCostly { static constexpr bool value = false; };
+template <int E> struct SliceProbeCostly<LogisticTarget<E>> { static constexpr bool value = true; };
+template <class T, int E>
+__device__ __forceinline__ bool step_slice(const KParams& p, const T& tg, const LaneCtx<E>& cx,
+                                           unsigned long long gchain, unsigned long long t,
+                                           const double (&widths)[E], double (&x)[E], double& lt,
+                                           bool& stuck)
+{
+    if (SliceProbeCostly<T>::value || !p.stepout) return step_slice_free<T, E>(p, tg, cx, gchain, t, widths, x, lt, stuck);
+    return step_slice_lockstep<T, E>(p, tg, cx, gchain, t, widths, x, lt, stuck);
 }
 
 // ------------------------------------------------------------------------------------------------
