@@ -139,6 +139,70 @@ __device__ __forceinline__ void mpair_normals(unsigned long long seed, unsigned 
     double u1, lg;
     kd_normal_pair_w(wa, wb, &z0, &z1, &u1, &lg);
 }
+// N Box-Muller evaluations with their statements interleaved — the same operations in the same order within each (kd_normal_pair_w, detmath.h:
+// kd_u44, kd_log_u01, kd_sqrt_radicand, kd_sincos2pi_bits written out statement by statement over an index j), so bit-identical to N separate calls.
+// A wavefront that is alone on its SIMD (klara_dense_big.h) has nothing else to fill the latencies of one evaluation's dependent chains and table
+// lookups, and the compiler does not interleave separate calls by itself (it schedules for register pressure there).
+template <int N>
+__device__ __forceinline__ void mpair_normals_n(const uint32_t (&wa)[N], const uint32_t (&wb)[N], double (&z0)[N], double (&z1)[N])
+{
+#define KD_EACH _Pragma("unroll") for (int j = 0; j < N; ++j)
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double B0 = 0x1.5555555555555p-2, B1 = -0.25, B2 = 0x1.999999999999ap-3, B3 = -0x1.5555555555555p-3,
+                 B4 = 0x1.2492492492492p-3, B5 = -0.125;
+    const double S1 = -0x1.5555555555555p-3, S2 = 0x1.1111111111111p-7, S3 = -0x1.a01a01a01a01ap-13;
+    const double C2 = 0x1.5555555555555p-5, C3 = -0x1.6c16c16c16c17p-10;
+    double u1[N], z[N], invc[N], logc[N], Ct[N], St[N], uu[N], cc[N];
+    uint32_t i[N], jt[N]; int k[N];
+    // kd_u44, kd_log_u01_reduce, the angle's bits (kd_angle_bits20) and both table lookups first: their latencies run under everything below
+    KD_EACH u1[j] = kd_u44(wa[j], wb[j]);
+    KD_EACH kd_log_u01_reduce(u1[j], &i[j], &k[j], &z[j]);
+    KD_EACH { invc[j] = KD_LOGTAB(2 * i[j]); logc[j] = KD_LOGTAB(2 * i[j] + 1); }
+    KD_EACH {
+        const uint64_t ub = kd_angle_bits20(wb[j]);
+        const uint32_t uh = (uint32_t)(ub >> 32);
+        jt[j] = (uh >> 12) & 255u;
+        uu[j] = kd_u2d(ub);
+        cc[j] = kd_u2d((uint64_t)((uh & 0xfffff000u) | 0x00000800u) << 32);
+    }
+    KD_EACH { Ct[j] = KD_SCTAB(2 * jt[j]); St[j] = KD_SCTAB(2 * jt[j] + 1); }
+    // kd_log_u01_finish
+    double r[N], dk[N], w[N], hi[N], lo[N], r2[N], q[N], lg[N];
+    KD_EACH r[j] = kd_fma(z[j], invc[j], -1.0);
+    KD_EACH dk[j] = (double)k[j];
+    KD_EACH w[j] = kd_fma(dk[j], ln2_hi, logc[j]);
+    KD_EACH hi[j] = w[j] + r[j];
+    KD_EACH lo[j] = kd_fma(dk[j], ln2_lo, (w[j] - hi[j]) + r[j]);
+    KD_EACH r2[j] = r[j] * r[j];
+    KD_EACH q[j] = kd_fma(r2[j], kd_fma(r2[j], kd_fma(r[j], B5, B4), kd_fma(r[j], B3, B2)), kd_fma(r[j], B1, B0));
+    KD_EACH lg[j] = hi[j] + kd_fma(r[j] * r2[j], q[j], kd_fma(r2[j], -0.5, lo[j]));
+    // kd_sincos2pi_bits up to the table terms (independent of the logarithm: fills the rsq's latency below)
+    double t[N], y[N], zz[N], sy[N], dc[N];
+    KD_EACH t[j] = uu[j] - cc[j];
+    KD_EACH y[j] = kd_fma(t[j], KD_TWOPI_HI, kd_fma(t[j], KD_TWOPI_LO, KD_TWOPI_2M53));
+    // kd_sqrt_radicand(-2 lg)
+    double ya[N], rs[N], g[N], h[N], e[N], d[N];
+    KD_EACH ya[j] = -2.0 * lg[j];
+    KD_EACH rs[j] = __builtin_amdgcn_rsq(ya[j]);
+    KD_EACH zz[j] = y[j] * y[j];
+    KD_EACH sy[j] = kd_fma(y[j] * zz[j], kd_fma(zz[j], kd_fma(zz[j], S3, S2), S1), y[j]);
+    KD_EACH dc[j] = zz[j] * kd_fma(zz[j], kd_fma(zz[j], C3, C2), -0.5);
+    KD_EACH { g[j] = ya[j] * rs[j]; h[j] = 0.5 * rs[j]; }
+    KD_EACH e[j] = kd_fma(-h[j], g[j], 0.5);
+    KD_EACH { g[j] = kd_fma(g[j], e[j], g[j]); h[j] = kd_fma(h[j], e[j], h[j]); }
+    KD_EACH d[j] = kd_fma(-g[j], g[j], ya[j]);
+    KD_EACH g[j] = kd_fma(d[j], h[j], g[j]);
+    KD_EACH d[j] = kd_fma(-g[j], g[j], ya[j]);
+    KD_EACH g[j] = kd_fma(d[j], h[j], g[j]);                                  // rad
+    KD_EACH {
+        const double cs = kd_fma(-St[j], sy[j], kd_fma(Ct[j], dc[j], Ct[j]));
+        const double sn = kd_fma(Ct[j], sy[j], kd_fma(St[j], dc[j], St[j]));
+        z0[j] = g[j] * cs;
+        z1[j] = g[j] * sn;
+    }
+#undef KD_EACH
+}
+
 template <int NE>
 __device__ __forceinline__ void mnormals(const MfmaCtx<NE>& c, unsigned long long seed,
                                          unsigned long long gchain, unsigned long long t,

@@ -32,6 +32,12 @@
 #ifndef KLARA_BIG_NORMALS_GROUP
 #define KLARA_BIG_NORMALS_GROUP 1     // Box-Muller pairs the scheduler may interleave (one wavefront per SIMD: nothing else hides a pair's dependent chains)
 #endif
+#ifndef KLARA_BIG_NORMALS_WAYS_MH
+#define KLARA_BIG_NORMALS_WAYS_MH 4   // Box-Muller evaluations written side by side in MH's proposal (measured at D = 256: 1 -> 52.5, 2 -> 54.0, 4 -> 54.3 TFLOP/s)
+#endif
+#ifndef KLARA_BIG_NORMALS_WAYS
+#define KLARA_BIG_NORMALS_WAYS 1      // ... in the normals HMC / MALA draw into the LDS column (MALA: 1 -> 41.5, 2 -> 35.5 (512 B of scratch), 4 -> 41.8; HMC: 4 -> -1.5 %)
+#endif
 #ifndef KLARA_BIG_RELOAD_CHUNK
 #define KLARA_BIG_RELOAD_CHUNK 8      // elements re-read per group after a rejected proposal
 #endif
@@ -82,22 +88,56 @@ __device__ __forceinline__ void dense_stream(const double* __restrict__ gP, int 
 // the momentum draw of mnormals (klara_dense.h: the even / odd lanes of a chain evaluate alternate Box-Muller pairs and swap halves),
 // written to the lane's LDS column
 // ... and the same draw handed to a callback, element by element (f(e, z_e)): MALA / MH form their proposal from it where it is drawn
-template <int NE, class F>
+template <int NE, int W, class F>
 __device__ __forceinline__ void mnormals_each(const MfmaCtx<NE>& c, unsigned long long seed, unsigned long long gchain, unsigned long long t, F f)
 {
     static_assert(NE % 8 == 0, "pairs of elements, and every block's second pair in the same lane");
     const uint32_t sh = (uint32_t)(c.q >> 1);
     const bool odd = (c.q & 1) != 0;
     const int nv = c.nv_here();
+    const uint32_t lane_slot = (odd ? 2u : 0u) + sh;
+    if constexpr (W == 1) {
     MPairStash st = { { 0u, 0u, 0u, 0u } };
 #pragma unroll
     for (int e = 0; e + 1 < NE; e += 2) {
         double z0, z1;
-        mpair_normals(seed, gchain, t, e, (odd ? 2u : 0u) + sh, st, z0, z1);
+        mpair_normals(seed, gchain, t, e, lane_slot, st, z0, z1);
         const double recv = bperm_xor(odd ? z0 : z1, c.lane, 16);
         f(e, e < nv ? (odd ? recv : z0) : 0.0);
         f(e + 1, e + 1 < nv ? (odd ? z1 : recv) : 0.0);
         if ((e / 2 + 1) % KLARA_BIG_NORMALS_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    } else {
+    // Round 5: the Box-Muller evaluations of loop slots e and e + 2 (W = 2; 4: e .. e + 6) side by side, statement by statement (mpair_normals_n):
+    // this wavefront is alone on its SIMD, where a fully dependent instruction stream issues every 10.7 cycles and four independent ones every 5.5
+    // (profiles/r3_ubench_issue_cadence.txt).  Slots e, e + 2 with (e >> 2) even form a Philox block each and leave its words (z, w) to slots
+    // e + 4, e + 6 (mpair_normals: one block per two slots).
+    static_assert(W == 2 || W == 4, "1, 2 or 4 evaluations side by side");
+    uint32_t stash[2][2] = { { 0u, 0u }, { 0u, 0u } };
+#pragma unroll
+    for (int e0 = 0; e0 < NE; e0 += 2 * W) {
+        uint32_t wa[W], wb[W];
+        double z0[W], z1[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const int e = e0 + 2 * j, si = (e >> 1) & 1;
+            if ((e >> 2) & 1) { wa[j] = stash[si][0]; wb[j] = stash[si][1]; }
+            else {
+                const uint32_t base = ((2u * (uint32_t)e) & 7u) | (((2u * (uint32_t)e) >> 4) << 3);
+                const kd_u32x4 b = kd_stream_block(seed, gchain, t, base + lane_slot);
+                wa[j] = b.x; wb[j] = b.y; stash[si][0] = b.z; stash[si][1] = b.w;
+            }
+        }
+        mpair_normals_n<W>(wa, wb, z0, z1);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const int e = e0 + 2 * j;
+            const double recv = bperm_xor(odd ? z0[j] : z1[j], c.lane, 16);
+            f(e, e < nv ? (odd ? recv : z0[j]) : 0.0);
+            f(e + 1, e + 1 < nv ? (odd ? z1[j] : recv) : 0.0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     }
 }
 
@@ -105,7 +145,7 @@ template <int NE>
 __device__ __forceinline__ void mnormals_lds(const MfmaCtx<NE>& c, unsigned long long seed, unsigned long long gchain, unsigned long long t,
                                              double* momw)
 {
-    mnormals_each<NE>(c, seed, gchain, t, [&](int e, double z) { momw[e * 64] = z; });
+    mnormals_each<NE, KLARA_BIG_NORMALS_WAYS>(c, seed, gchain, t, [&](int e, double z) { momw[e * 64] = z; });
 }
 
 // the lane's momentum column in LDS, touched in chunks of 8 elements: 8 reads in flight, then the 8 updates (one ds_read per element and a
@@ -327,7 +367,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             acc = true;                                  // the slice sampler always moves (SliceSampler.jl:108)
         } else {
             // iterate/MH.jl:72-124
-            mnormals_each<NE>(cx, p.seed, gchain, t, [&](int e, double z) {
+            mnormals_each<NE, KLARA_BIG_NORMALS_WAYS_MH>(cx, p.seed, gchain, t, [&](int e, double z) {
                 const double sg = ldsSig[4 * e + cx.q];                               // (0 past D)
                 momw[e * 64] = xp[e];                                                 // the current value: what a rejecting lane goes back to
                 xp[e] = xp[e] + sg * z;                                               // MH.jl:79
