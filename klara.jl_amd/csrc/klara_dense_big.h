@@ -21,7 +21,10 @@
 #include "klara_dense.h"
 
 #ifndef KLARA_DENSE_RING
-#define KLARA_DENSE_RING 8
+#define KLARA_DENSE_RING 8            // fragments in flight per lane (NE >= 48; at NE = 64 a ring of 12 / 16 costs HMC 5 % / 8 %: registers)
+#endif
+#ifndef KLARA_DENSE_RING_SMALL
+#define KLARA_DENSE_RING_SMALL 12     // ... at NE = 40, where the registers are there (HMC at D = 160: 58.7 -> 59.9 TFLOP/s)
 #endif
 // phase boundary of a transition: the scheduler may not move instructions across it (live ranges of one phase stay out of the next)
 #ifndef KLARA_BIG_NO_PHASES
@@ -59,7 +62,7 @@ template <int NE, bool HASMU>
 __device__ __forceinline__ void dense_stream(const double* __restrict__ gP, int lane, const double (&x)[NE], kd_double4 (&acc)[NE / 4],
                                              const double* ldsMu)
 {
-    constexpr int MT = NE / 4, S = NE * MT, RING = KLARA_DENSE_RING;
+    constexpr int MT = NE / 4, S = NE * MT, RING = NE <= 40 ? KLARA_DENSE_RING_SMALL : KLARA_DENSE_RING;
     static_assert(NE % 4 == 0 && S > RING, "whole 16-row tiles");
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };

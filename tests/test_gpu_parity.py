@@ -843,7 +843,7 @@ def _random_case(seed, wide=False):
     else:
         d = int(rng.choice([2, 5, 9, 16, 24]))
         target = K.CustomTarget(d, cases.SRC_QUARTIC_CHAIN, [float(rng.uniform(0.01, 0.2)), float(rng.uniform(0.1, 0.8))])
-    samplers = [L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC] + ([] if fam == "dense" and d > 33 else [L.SAMPLER_SLICE])   # (dense slice: D full evaluations per probe)
+    samplers = [L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC] + ([] if fam == "dense" and d > 70 else [L.SAMPLER_SLICE])   # (dense slice: D full evaluations per probe on the oracle's side)
     sampler = int(rng.choice(samplers))
     scale = 0.02 if fam == "hier" else (0.05 if fam == "logit" else (0.1 if wide else 0.3))
     c = dict(sampler=sampler, target=target, nchains=int(rng.choice([1, 2, 7, 8, 9, 33, 64, 100, 131])), x0=None, seed=int(rng.integers(1, 2 ** 40)),
