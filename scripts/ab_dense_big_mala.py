@@ -11,7 +11,7 @@ import klara_jl_amd as K
 from klara_jl_amd import _lib as L
 
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
-n, d = 65536, 256
+n, d = 65536, int(os.environ.get("AB_D", "256"))
 slow = "KLARA_DENSE_NO_STREAM" in os.environ
 drift = float(os.environ.get("AB_DRIFT", "0.002"))      # (0.002: every proposal accepted; AB_DRIFT=0.012 rejects about every third)
 for name, kw in (("MALA", dict(sampler=L.SAMPLER_MALA, driftstep=drift)), ("MH", dict(sampler=L.SAMPLER_MH, mh_sigma=np.full(d, 0.02)))):
