@@ -121,7 +121,9 @@ typedef enum klara_target {
      * Gaussian (layout kind 3: 8 / 16 / 32 lanes per chain, 17 <= D <= 512; MH, MALA, HMC with every tuner, the running sums and the
      * value / logtarget / gradlogtarget histories; klara_get_layout reports the summation order: a lane adds its pairs' terms in
      * ascending order, then the butterfly over the chain's lanes) instead of holding the whole vector in one lane: at D = 100 the
-     * README closure runs at 3.5e9 transitions/s in this form and at 2.1e8 in the whole-vector form. */
+     * README closure runs at 3.5e9 transitions/s in this form and at 2.1e8 in the whole-vector form.  A pair-form job those kernels do
+     * not serve — D < 17, or the slice sampler — is taken as a whole-vector closure whose logtarget is the sum of the pairs' terms,
+     * pair 0 first (klara_custom_compose.h; D <= 256). */
     KLARA_TARGET_CUSTOM = 4
 } klara_target;
 

@@ -153,10 +153,12 @@ static bool hiert_eligible(const klara_desc& d)
 }
 
 // a user target given as a pair closure (`#define KLARA_USER_PAIR_TARGET 1` + klara_user_pair, include/klara_hip.h)
-static bool pair_form(const klara_desc& d)
-{
-    return d.target == KLARA_TARGET_CUSTOM && d.custom_src != nullptr && strstr(d.custom_src, "KLARA_USER_PAIR_TARGET") != nullptr;
-}
+static bool pair_source(const char* src) { return src != nullptr && strstr(src, "KLARA_USER_PAIR_TARGET") != nullptr && strstr(src, "KLARA_PAIR_AS_WHOLE") == nullptr; }
+static bool pair_form(const klara_desc& d) { return d.target == KLARA_TARGET_CUSTOM && pair_source(d.custom_src); }
+// ... that the pair-transposed kernels do not serve (fewer than 9 pairs, the slice sampler): it runs as a whole-vector closure, the sum over its pairs
+// formed by klara_custom_compose.h (round 5; these jobs used to be refused)
+static bool pair_as_whole(const char* src, int sampler, int ndims) { return pair_source(src) && (ndims < 17 || sampler == KLARA_SAMPLER_SLICE); }
+static std::string pair_as_whole_source(const char* src) { return std::string("#define KLARA_PAIR_AS_WHOLE 1\n") + src; }
 
 // Whole-vector closures (klara_custom.h).  Up to 32 dimensions a lane keeps the whole vector in registers (one chain per lane); beyond,
 // the chain is spread over G lanes with E = 2 ceil(D / 2G) <= 16 elements each and evaluations read the vector from the chain's row of
@@ -516,6 +518,12 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         dd.target = KLARA_TARGET_CUSTOM; dd.custom_src = KLARA_LOGIT_WIDE_SRC; dd.custom_data = blk.data(); dd.custom_ndata = (int64_t)blk.size();
         dd.logit_X = nullptr; dd.logit_y = nullptr; dd.logit_ndata = 0;
         return create_impl(&dd, out, 1);
+    }
+    if (desc->target == KLARA_TARGET_CUSTOM && pair_as_whole(desc->custom_src, desc->sampler, desc->ndims)) {
+        const std::string src2 = pair_as_whole_source(desc->custom_src);
+        klara_desc dd = *desc;
+        dd.custom_src = src2.c_str();
+        return create_impl(&dd, out);
     }
     if (desc->target == KLARA_TARGET_GAUSS_DENSE && desc->ndims > 128 && !dense_streamed(*desc)) {
         if (desc->ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
@@ -2413,8 +2421,10 @@ extern "C" klara_status klara_check_custom_target(const char* src, int32_t sampl
 {
     if (!src || sampler < KLARA_SAMPLER_MH || sampler > KLARA_SAMPLER_SLICE || ndims <= 0) return KLARA_ERR_INVALID_ARG;
     const int modes[1] = { 0 };
-    if (strstr(src, "KLARA_USER_PAIR_TARGET")) {            // pair closure: the plain fused instantiation of its layout
-        if (ndims < 17 || ndims > 2 * 32 * KLARA_DIAGT_NP_MAX || sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
+    std::string src2;
+    if (pair_as_whole(src, sampler, ndims)) { src2 = pair_as_whole_source(src); src = src2.c_str(); }
+    if (pair_source(src)) {                                 // pair closure: the plain fused instantiation of its layout
+        if (ndims > 2 * 32 * KLARA_DIAGT_NP_MAX) return KLARA_ERR_UNSUPPORTED;
         const int Q = ndims <= 128 ? 8 : (ndims <= 256 ? 16 : 32);
         return klara_jit_create_pair(src, sampler, ndims, (ndims + 2 * Q - 1) / (2 * Q), Q, false, false, false, modes, 1, false, nullptr);
     }

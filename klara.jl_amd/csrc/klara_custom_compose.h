@@ -32,4 +32,32 @@ KLARA_USER_FN void klara_user_gradlogtarget(const double* x, int D, const double
 }
 #endif
 #endif
+/* A pair closure (`#define KLARA_USER_PAIR_TARGET 1` + klara_user_pair, include/klara_hip.h) taken as a whole-vector closure — what a job runs on that the
+ * pair-transposed kernels do not serve (fewer than 17 dimensions, or the slice sampler): klara_create prefixes the source with
+ * `#define KLARA_PAIR_AS_WHOLE 1`, and the sum over the pairs is formed here, pair 0 first, one addition per pair — the same text on the device and in the
+ * CPU oracle.  The missing half of an odd D's last pair is passed as 0 and its derivative is dropped (as on the pair kernels). */
+#if defined(KLARA_USER_PAIR_TARGET) && defined(KLARA_PAIR_AS_WHOLE)
+KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata)
+{
+    double s = 0.0;
+    for (int P = 0; P < (KLARA_D + 1) / 2; ++P) {
+        double g0, g1;
+        const int full = 2 * P + 1 < KLARA_D;
+        s = s + klara_user_pair(x[2 * P], full ? x[2 * P + 1] : 0.0, P, D, data, ndata, &g0, &g1);
+    }
+    return s;
+}
+#ifndef KLARA_CUSTOM_NOGRAD
+KLARA_USER_FN void klara_user_gradlogtarget(const double* x, int D, const double* data, long long ndata, double* g)
+{
+    for (int P = 0; P < (KLARA_D + 1) / 2; ++P) {
+        double g0 = 0.0, g1 = 0.0;
+        const int full = 2 * P + 1 < KLARA_D;
+        (void)klara_user_pair(x[2 * P], full ? x[2 * P + 1] : 0.0, P, D, data, ndata, &g0, &g1);
+        g[2 * P] = g0;
+        if (full) g[2 * P + 1] = g1;
+    }
+}
+#endif
+#endif
 #endif

@@ -584,6 +584,18 @@ def make_case(name):
     elif name == "pair_indexed_hmc_d37":       # odd D: a half pair, and padding pairs 19..23
         c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget.pairwise(37, SRC_PAIR_INDEXED, np.linspace(0.5, 2.0, 37)), nchains=35, nsteps=30, burnin=5,
                  leapstep=0.1, nleaps=5)
+    # ---- pair closures the pair-transposed kernels do not serve (fewer than 9 pairs; the slice sampler): taken as whole-vector closures (round 5; were refused)
+    elif name == "pair_quartic_mala_d9_whole":         # odd D below 17: one chain per lane
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget.pairwise(9, SRC_PAIR_QUARTIC, [0.1, 0.4]), nchains=70, nsteps=40, burnin=5, driftstep=0.05,
+                 x0=0.3 * np.random.default_rng(11).standard_normal((70, 9)))
+    elif name == "pair_banana_hmc_d16_whole":
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget.pairwise(16, SRC_PAIR_BANANA, [0.05, 9.0]), nchains=33, nsteps=30, burnin=0, leapstep=0.05, nleaps=5,
+                 tuner=L.TUNER_ACCEPT_RATE, targetrate=0.7, period=10, x0=np.random.default_rng(12).standard_normal((33, 16)) * np.tile([2.0, 1.0], 8))
+    elif name == "pair_indexed_slice_d40_whole":       # the slice sampler on a pair closure: staged whole-vector form on 4 lanes per chain
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget.pairwise(40, SRC_PAIR_INDEXED, np.linspace(0.5, 2.0, 40)), nchains=21, nsteps=6, burnin=1,
+                 slice_widths=np.linspace(0.5, 2.5, 40))
+    elif name == "pair_negdot_slice_d6_whole":
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget.pairwise(6, SRC_PAIR_NEGDOT), nchains=66, nsteps=10, burnin=2, slice_widths=np.full(6, 1.5), slice_stepout=False)
     elif name == "custom_quartic_slice_d7":
         c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget(7, SRC_QUARTIC_CHAIN, [0.1, 0.4]), nchains=66, nsteps=12, burnin=2,
                  slice_widths=np.full(7, 1.5))
@@ -617,6 +629,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "sparse_mala_d100", "sparse_mala_d100_small_step", "sparse_mh_d100", "sparse_mala_mvnormal_d30",
              "pair_negdot_mala_d100", "pair_negdot_mala_d100_big_step", "pair_quartic_hmc_d50_tuned", "pair_banana_mh_d33",
              "pair_banana_hmc_d100_dualavg", "pair_quartic_mala_d300_pooled", "pair_indexed_mala_d100", "pair_indexed_hmc_d37",
+             "pair_quartic_mala_d9_whole", "pair_banana_hmc_d16_whole", "pair_indexed_slice_d40_whole", "pair_negdot_slice_d6_whole",
              "staged_negdot_mala_d100_big_step", "staged_quartic_mh_d33_thinned", "staged_quartic_slice_d40", "staged_quartic_hmc_d200_dualavg",
              "staged_quartic_mala_d70_pooled", "staged_normal_normal_mala_d48", "staged_quartic_hmc_d256_tuned"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)

@@ -100,7 +100,7 @@ def compile_user_target(src: str, ndims: int):
         if r.returncode != 0:
             raise RuntimeError("user target did not compile on the host:\n" + r.stderr)
     lib = C.CDLL(str(so))
-    if "KLARA_USER_PAIR_TARGET" in src:        # pair closure (klara_user_pair): third entry; no whole-vector closures
+    if "KLARA_USER_PAIR_TARGET" in src and "KLARA_PAIR_AS_WHOLE" not in src:        # pair closure (klara_user_pair): third entry; no whole-vector closures
         _user_libs[key] = (lib, None, None, C.cast(lib.klara_user_pair, C.c_void_p))
         return _user_libs[key]
     lt = C.cast(lib.klara_user_logtarget, C.c_void_p)
@@ -225,6 +225,9 @@ class OracleJob:
         d.hier_prior_prec, d.hier_gamma_a, d.hier_gamma_b = float(hier_prior_prec), float(hier_gamma_a), float(hier_gamma_b)
         self._user = None
         if custom_src is not None:
+            # (a pair closure the pair-transposed kernels do not serve runs as a whole-vector closure: klara_api.hip pair_as_whole, klara_custom_compose.h)
+            if "KLARA_USER_PAIR_TARGET" in custom_src and (self.D < 17 or int(sampler) == L.SAMPLER_SLICE):
+                custom_src = "#define KLARA_PAIR_AS_WHOLE 1\n" + custom_src
             self._user = compile_user_target(custom_src, self.D)
             if custom_data is not None and np.size(custom_data):
                 d.custom_data = ptr(custom_data); d.custom_ndata = int(np.size(custom_data))
@@ -235,7 +238,7 @@ class OracleJob:
                                                                    tuner=int(tuner), tuner_mode=int(tuner_mode), verbose=bool(verbose),
                                                                    hier_nunits=int(d.hier_nunits), hier_ntimes=int(d.hier_ntimes),
                                                                    summaries=bool(want_sums), sparse_moves=bool(sparse_moves),
-                                                                   pair_form=bool(custom_src is not None and "KLARA_USER_PAIR_TARGET" in custom_src),
+                                                                   pair_form=bool(custom_src is not None and "KLARA_USER_PAIR_TARGET" in custom_src and "KLARA_PAIR_AS_WHOLE" not in custom_src),
                                                                    custom_rows=3 if (custom_src is not None and "KLARA_USER_LIKELIHOOD_PRIOR" in custom_src) else 2)
         self.layout = KoLayout(k, g, e)
         nt = 1 if tuner_mode == L.TUNE_POOLED else self.N
