@@ -531,6 +531,21 @@ def extra_measurements(K, L, n, stream):
     ex["slice_d100_roofline"]["transitions_per_launch"] = SLICE_SPL
     ex["slice_d100_roofline"]["frac_lockstep"] = 4.0 * bsl["per_wave_transition"] * (n // bsl["chains_per_wave"]) * SLICE_SPL / ls / (NSIMD * CLOCK_HZ)
 
+    # ... and on the dense 100 x 100 precision of cfg 3: a probe is a full evaluation = one matrix pass over the 16 chains of a tile, each chain taking from
+    # it the probe its own coordinate and stage ask for (round 5: slice_dense_free, klara_dense.h); beyond D = 128 on the streamed layouts
+    try:
+        for key, dd, nn in (("slice_dense_d100", NDIMS, n), ("slice_dense_d256", 256, 16384)):
+            e = K.Engine(sampler=L.SAMPLER_SLICE, target=K.GaussDenseTarget.compound_symmetric(dd, 0.5), nchains=nn, nsteps=10 ** 7, slice_widths=np.full(dd, 2.0),
+                         steps_per_launch=1, stream=stream)
+            e.init_state_normal()
+            rate, ls, _ = timed_rate(e, nn, 1, 2)
+            lay = e.layout(); e.close()
+            ex[f"{key}_chain_transitions_per_s"] = rate
+            ex[f"{key}_coordinate_updates_per_s"] = rate * dd
+            ex[f"{key}_layout"] = list(lay)
+    except Exception as exc:
+        ex["slice_dense_error"] = repr(exc)
+
     # -- the two data-model configurations of BASELINE.json at their per-GPU share (cfg 4: 262,144 / 8 chains of the swiss
     # logistic regression, MALA h = 0.1; cfg 5: 1,048,576 / 8 chains of the rats hierarchical model, HMC L = 32 with the
     # per-GPU pooled AcceptanceRate tuner).  Data: the reference's own files as committed fixtures (tests/golden/*.npz).
