@@ -10,9 +10,11 @@
 //     registers (it is the MFMA's B operand and the target of the drift), the gradient P x in the accumulators (it IS the MFMA result), and the
 //     MOMENTUM IN LDS — one private column per lane, momw[e * 64] —, touched twice per leapfrog (64 ds_read + 64 ds_write per lane against
 //     1,024 MFMAs).
-//   * HMC (Vanilla / AcceptanceRate tuners per chain or pooled, and dual averaging with its per-chain trip counts; every monitor), and — with no
-//     LDS at all — MALA and MH: their proposal overwrites the value registers as its normals are drawn, the current gradient (accumulators) is
-//     consumed by the same pass, and the current value is re-read from X for MALA's backward term, so nothing beyond x and P x is ever held.
+//   * HMC (Vanilla / AcceptanceRate tuners per chain or pooled, and dual averaging with its per-chain trip counts; every monitor), and MALA and MH:
+//     their proposal overwrites the value registers, the current gradient (accumulators, kept from transition to transition) is consumed by the same
+//     pass, and the CURRENT VALUE waits in the lane's LDS column (round 5; round 4 re-read it from X) for MALA's backward term and for a lane that
+//     rejects — so nothing inside a launch reads X, which is written once, after the last transition; of the state only MALA's gradient goes to
+//     memory per accepted transition (nt store: it is re-read after a reject only, and must not push P out of the L2).
 //   * The slice sampler (round 5): a probe is a full evaluation = one pass over P for the tile's 16 chains, each chain at its own coordinate and
 //     stage (slice_dense_free, klara_dense.h); no LDS column.
 // Same MFMA instruction, same k-ascending fma chain per output (zero-padded rows / columns add exact zeros), same merged fma leapfrog, same
@@ -288,7 +290,7 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
 
         } else if constexpr (SAMPLER == KLARA_SAMPLER_MALA) {
             // iterate/MALA.jl:78-128.  The proposal overwrites the value registers as its normals are drawn; the current gradient (accumulators) is
-            // consumed by the same pass; the current value is re-read from X for the backward term: no vector beyond x and P x is ever held.
+            // consumed by the same pass; the current value waits in the lane's LDS column for the backward term: no vector beyond x and P x is held in registers.
             const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h), half_inv_h = 0.5 * (1.0 / h);
             double s1 = 0.0;
             // the normals go through the lane's LDS column like HMC's momentum: drawn first, consumed in groups of 8 — the transform's ~40 live
