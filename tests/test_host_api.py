@@ -665,6 +665,30 @@ def test_custom_target_source_compiles_without_a_gpu():
     assert ei.value.status == L.ERR_UNSUPPORTED
 
 
+def test_pair_closure_jobs_the_pair_kernels_do_not_serve_compile_as_whole_vector_closures():
+    """A pair closure below 17 dimensions, or with the slice sampler, used to be refused (KLARA_ERR_UNSUPPORTED); now the library sums the pairs' terms itself
+    (klara_custom_compose.h) and compiles the whole-vector form — and the CPU oracle's harness composes the same text, so both sides add the terms pair 0 first."""
+    import cases, oracle_ffi as O
+    for sampler, d, src, data in ((L.SAMPLER_MALA, 9, cases.SRC_PAIR_QUARTIC, [0.1, 0.4]), (L.SAMPLER_HMC, 16, cases.SRC_PAIR_BANANA, [0.05, 9.0]),
+                                  (L.SAMPLER_SLICE, 40, cases.SRC_PAIR_INDEXED, list(np.linspace(0.5, 2.0, 40))), (L.SAMPLER_SLICE, 6, cases.SRC_PAIR_NEGDOT, None),
+                                  (L.SAMPLER_MH, 100, cases.SRC_PAIR_NEGDOT, None)):          # (the last one: still the pair-transposed kernels)
+        K.CustomTarget.pairwise(d, src, data).check(sampler)
+    # the composed closure on the host: the sum of the pairs' terms in ascending pair order, the gradient element by element
+    t = K.CustomTarget.pairwise(9, cases.SRC_PAIR_QUARTIC, [0.1, 0.4])
+    _, lt, grad, pair = O.compile_user_target("#define KLARA_PAIR_AS_WHOLE 1\n" + t.source, 9)
+    assert pair is None and lt is not None and grad is not None
+    _, lt2, _, pair2 = O.compile_user_target(t.source, 9)
+    assert pair2 is not None and lt2 is None
+    x = np.random.default_rng(5).standard_normal(9); dat = np.array([0.1, 0.4])
+    f_lt = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong)(lt.value)
+    f_pair = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.POINTER(C.c_double), C.POINTER(C.c_double))(pair2.value)
+    s = 0.0
+    for P in range(5):
+        g0, g1 = C.c_double(), C.c_double()
+        s = s + f_pair(x[2 * P], x[2 * P + 1] if 2 * P + 1 < 9 else 0.0, P, 9, dat.ctypes.data, 2, C.byref(g0), C.byref(g1))
+    assert f_lt(x.ctypes.data, 9, dat.ctypes.data, 2) == s
+
+
 def test_custom_target_disk_cache(tmp_path):
     """Run-time compiled code objects are cached on disk (KLARA_JIT_CACHE_DIR): a second process finds the entry instead of
     compiling, a damaged entry is ignored and replaced, KLARA_JIT_CACHE=0 writes nothing."""
