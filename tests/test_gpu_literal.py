@@ -13,7 +13,7 @@ own transcendental functions (detmath.h).  Two other checkers exist that do NOT 
     with detmath.h (its own Philox, libm transcendentals, NumPy sums).
 
 Here the full-size GPU jobs of BASELINE cfg 2 (h = 0.9 as stated, and a step that mixes), cfg 3, cfg 4 (one GPU's share), cfg 5 without the
-pooled tuner (one GPU's share) and the slice sampler at D = 100 are run through the C ABI, and three blocks of 16 chains (first, across the
+pooled tuner (one GPU's share), the slice sampler at D = 100 and (round 5's new kernels) the slice sampler on dense precisions of 100 and 160 dimensions are run through the C ABI, and three blocks of 16 chains (first, across the
 chain-partition boundary / middle, the ragged last wavefront group) are replayed by the literal-mode oracle; one block of 8 chains is
 replayed by the NumPy mirror.  Asserted: EVERY accept decision of every transition identical, final states / log-targets within 1e-12
 relative (literal) resp. 1e-9 (mirror: libm vs table functions, NumPy's pairwise sums).  A change of the kernels' arithmetic or of the
@@ -37,7 +37,8 @@ from klara_jl_amd import _lib as L  # noqa: E402
 
 SEED = 20260927
 BLOCK, MIRROR_CHAINS = 16, 8
-JOB_NAMES = ("cfg2_mala_h0.9", "cfg2_mala_h0.02", "cfg3_hmc_dense", "hmc_iso_d100", "cfg4_mala_swiss", "cfg5_hmc_rats_untuned", "slice_mvnormal_d100")
+JOB_NAMES = ("cfg2_mala_h0.9", "cfg2_mala_h0.02", "cfg3_hmc_dense", "hmc_iso_d100", "cfg4_mala_swiss", "cfg5_hmc_rats_untuned", "slice_mvnormal_d100",
+             "slice_dense_d100", "slice_dense_d160_stream")
 
 
 def _jobs():
@@ -46,6 +47,7 @@ def _jobs():
     d = 100
     neg = K.GaussDiagTarget.negdot(d)
     dense = K.GaussDenseTarget.compound_symmetric(d, 0.5)
+    dense160 = K.GaussDenseTarget.compound_symmetric(160, 0.3)
     X, y = cases.swiss_data()
     rats = cases.rats_target()
     n4, n5 = 32768 - 3, 131072 - 3
@@ -78,6 +80,13 @@ def _jobs():
         # literal oracle evaluates the whole log-target for every probe (SliceSampler.jl:66-95)
         "slice_mvnormal_d100": dict(kw=dict(sampler=L.SAMPLER_SLICE, target=mv, slice_widths=wid, slice_stepout=True), n=65536 - 5, nsteps=200, x0=None,
                                     mirror=("slice", M.diag_target(mv.w, mv.mu, mv.const), dict(widths=wid, stepout=True), 40)),
+        # the slice sampler on cfg 3's dense precision (round 5: the chains of a tile take their probes out of lockstep, each probe a matrix pass), and
+        # beyond D = 128 on the streamed layouts (was the closure form): a full-size launch against the serial literal procedure
+        "slice_dense_d100": dict(kw=dict(sampler=L.SAMPLER_SLICE, target=dense, slice_widths=np.linspace(0.8, 2.4, d), slice_stepout=True), n=65536 - 5, nsteps=3, x0=None,
+                                 mirror=("slice", M.dense_target(dense.precision, np.zeros(d), dense.const), dict(widths=np.linspace(0.8, 2.4, d), stepout=True), 3)),
+        "slice_dense_d160_stream": dict(kw=dict(sampler=L.SAMPLER_SLICE, target=dense160, slice_widths=np.linspace(0.8, 2.4, 160), slice_stepout=True), n=16384 - 5, nsteps=2,
+                                        x0=None, mirror=("slice", M.dense_target(dense160.precision, np.zeros(160), dense160.const),
+                                                         dict(widths=np.linspace(0.8, 2.4, 160), stepout=True), 2)),
     }
 
 
