@@ -99,17 +99,25 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
         const int thinning = (int)p.thinning;
         gdouble* const hist0 = p.hist;
         const int hist_cols = (int)p.hist_cols;
-        double red = 0.0;
         int held_out = held0;
         bool stuck_any = false;
 
-        for (int ps = 0; ps < (2 / NM) * NP; ++ps) {
-            // the lane's element(s) of this slot: NM = 2: the pair P = ps Q + q (elements 2P, 2P + 1); NM = 1: element (ps & 1) of pair (ps >> 1) Q + q
+        // NM = 1: the D elements of a chain are dealt to its Q lanes round robin — element ps Q + q in slot ps, ceil(D / Q) slots (13 at D = 100 on 8 lanes).
+        // The coordinate updates do not care which lane makes them; dealing them by the layout's pairs (lane q: pairs q, q + Q, ...: 14 slots at D = 100, the
+        // last two with work on 2 lanes of 8) was 7 % of the launch.  The new state's log-target, whose bits depend on the order of its sum, is formed in the
+        // layout's order by k_diagt_hist_lt<.., STATE> right after this kernel.
+#ifndef KLARA_SLICEF_PAIR_SLOTS
+#define KLARA_SLICEF_PAIR_SLOTS 0     // 1: the layout's pairs (A/B builds)
+#endif
+        constexpr bool RR = NM == 1 && !KLARA_SLICEF_PAIR_SLOTS;
+        const int nslots = RR ? (D + Q - 1) / Q : (2 / NM) * NP;
+        for (int ps = 0; ps < nslots; ++ps) {
+            // the lane's element(s) of this slot: NM = 2: the pair P = ps Q + q (elements 2P, 2P + 1); NM = 1: element ps Q + q
             int ei[NM]; bool eok[NM]; unsigned eoff[NM];
             double x[NM], sm[NM], sq[NM];
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                ei[m] = NM == 2 ? 2 * (ps * Q + q) + m : 2 * ((ps >> 1) * Q + q) + (ps & 1);
+                ei[m] = NM == 2 ? 2 * (ps * Q + q) + m : (RR ? ps * Q + q : 2 * ((ps >> 1) * Q + q) + (ps & 1));
                 eok[m] = chain_ok && ei[m] < D;
                 eoff[m] = eok[m] ? (unsigned)((cw * D + ei[m]) * 8) : KLARA_BUF_OOB;
                 x[m] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wx, eoff[m], 0, 0));      // (0 outside the window)
@@ -242,7 +250,7 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
                     tl[m] = (bad || full) ? nsteps + 1 : tl[m] + (done ? 1 : 0);               // stuck: the machine stops where it is (error raised below)
                 }
             }
-            // the slot is done for this launch: value and sums back to memory, its terms into the lane's partial of the new log-target
+            // the slot is done for this launch: value and sums back to memory
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, x[m]), wx, eoff[m], 0, 0);
@@ -250,15 +258,11 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sm[m]), wsum, eoff[m], 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sq[m]), wsq, eoff[m], 0, 0);
                 }
-                red = red + (ei[m] < D ? tcur[m] : 0.0);          // (ascending elements: the layout's order)
             }
             if (ps == 0) held_out = held[0];
             stuck_any = stuck_any || tl[0] > nsteps || tl[NM - 1] > nsteps;
         }
-        double r1[1] = { red };
-        group_allreduce<1>(r1, Q, lane);
         if (chain_ok && q == 0) {
-            p.LT[chain] = p.gconst - r1[0];
             p.naccept[chain] += (unsigned long long)nsteps;                                    // (every slice transition "accepts": diagnostics are all true)
             if (do_sum) p.held[chain] = (long long)held_out;
             if (p.accept != nullptr) {
@@ -275,7 +279,9 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
 // The log-target of the saved states of a launch, formed from the saved VALUES (hist columns [col0, col0 + ncols)): lt = c - sum_i w_i (x_i - mu_i)^2 in
 // the layout's order — lane partials over the lane's elements ascending, butterfly over the chain's Q lanes — i.e. the bits k_diagt<SLICE> keeps per
 // saved step (its log-target after a transition is that full evaluation).  One wavefront per (column, chain group).
-template <int Q, bool UNITW>
+// STATE: the same sum over the CURRENT state X of the chain groups of the launch, into LT (ncols = 1): k_diagt_slice_free deals a chain's elements to its
+// lanes without regard to the layout, so the state's log-target is formed here, after it.
+template <int Q, bool UNITW, bool STATE = false>
 __global__ __launch_bounds__(256) void k_diagt_hist_lt(const KParams* __restrict__ pp, const KLaunch kl, const int NP, const long long col0, const int ncols)
 {
     constexpr int CPW = 64 / Q;
@@ -287,10 +293,10 @@ __global__ __launch_bounds__(256) void k_diagt_hist_lt(const KParams* __restrict
     if (wave >= ngroups * ncols) return;
     const long long grp = kl.group0 + wave % ngroups, col = col0 + wave / ngroups;
     const long long first_chain = grp * CPW;
-    if (first_chain >= p.nchains || col >= p.hist_cols) return;
+    if (first_chain >= p.nchains || (!STATE && col >= p.hist_cols)) return;
     const long long left = p.nchains - first_chain;
     const int here = left < CPW ? (int)left : CPW;
-    const __amdgpu_buffer_rsrc_t wh = group_window(p.hist, col * p.nchains + first_chain, here, D);
+    const __amdgpu_buffer_rsrc_t wh = STATE ? group_window(p.X, first_chain, here, D) : group_window(p.hist, col * p.nchains + first_chain, here, D);
     double red[1] = { 0.0 };
     for (int ps = 0; ps < NP; ++ps) {
         const int P = ps * Q + q;
@@ -304,5 +310,8 @@ __global__ __launch_bounds__(256) void k_diagt_hist_lt(const KParams* __restrict
         red[0] = red[0] + slicef_term<UNITW>(x1, w1, m1);
     }
     group_allreduce<1>(red, Q, lane);
-    if (cw < here && q == 0) p.hist_lt[col * p.nchains + first_chain + cw] = p.gconst - red[0];
+    if (cw < here && q == 0) {
+        if (STATE) p.LT[first_chain + cw] = p.gconst - red[0];
+        else p.hist_lt[col * p.nchains + first_chain + cw] = p.gconst - red[0];
+    }
 }

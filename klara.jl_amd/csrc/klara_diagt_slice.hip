@@ -36,11 +36,12 @@ hipError_t KLARA_DIAGT_FN(klara_launch_diagt_slice_free)(const KParams* p, const
 #define KLARA_SLICEF_GO(U, S)                                                                                          \
     (nm == 1 ? klara_go(k_diagt_slice_free<KLARA_DIAGT_Q, U, S, 1>, grid, blk, 0, st, p, kl, ka, NP)                    \
              : klara_go(k_diagt_slice_free<KLARA_DIAGT_Q, U, S, 2>, grid, blk, 0, st, p, kl, ka, NP))
-    if (unitw && sums) return KLARA_SLICEF_GO(true, true);
-    if (unitw) return KLARA_SLICEF_GO(true, false);
-    if (sums) return KLARA_SLICEF_GO(false, true);
-    return KLARA_SLICEF_GO(false, false);
+    const hipError_t e = unitw ? (sums ? KLARA_SLICEF_GO(true, true) : KLARA_SLICEF_GO(true, false)) : (sums ? KLARA_SLICEF_GO(false, true) : KLARA_SLICEF_GO(false, false));
 #undef KLARA_SLICEF_GO
+    if (e != hipSuccess || klara_attr_query != nullptr) return e;
+    // the new state's log-target in the layout's order (the kernel above deals the elements to the lanes round robin): one wavefront per chain group
+    return unitw ? klara_go(k_diagt_hist_lt<KLARA_DIAGT_Q, true, true>, grid, blk, 0, st, p, kl, NP, 0LL, 1)
+                 : klara_go(k_diagt_hist_lt<KLARA_DIAGT_Q, false, true>, grid, blk, 0, st, p, kl, NP, 0LL, 1);
 }
 
 // log-target history of the `ncols` states a launch of the kernel above saved (columns col0 ...), from their saved values
