@@ -636,7 +636,9 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
 GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_swiss", "slice_d5",
                 "mala_d3_tuned", "hmc_d10_tuned_pooled", "hmc_rats", "hmc_d10_dualavg",
                 "dt_mala_d100_small_step", "dt_hmc_d100", "dt_mh_mvnormal_d20", "custom_banana_hmc",
-                "custom_quartic_mala_d20_pooled", "pair_quartic_hmc_d50_tuned"]
+                "custom_quartic_mala_d20_pooled", "pair_quartic_hmc_d50_tuned",
+                # round 5's new paths: the slice sampler on the free-running diagonal kernel, on the dense targets (chains of a tile out of lockstep; streamed layout), a pair closure run as a whole-vector closure
+                "slice_d20_stepout", "slice_dense_d20", "slice_dense_d130_stream_mean", "pair_quartic_mala_d9_whole"]
 
 
 def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):

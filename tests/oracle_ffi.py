@@ -149,8 +149,8 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
         while e < d:
             e *= 2
         return (0, 1, e)
-    if (target_kind == L.TARGET_GAUSS_DENSE and 128 < d <= 256 and sampler in (L.SAMPLER_HMC, L.SAMPLER_MALA, L.SAMPLER_MH)
-            and "KLARA_DENSE_NO_STREAM" not in os.environ):      # HMC / MALA / MH to D = 256: still the matrix cores, P streamed (klara_dense_big.h)
+    if (target_kind == L.TARGET_GAUSS_DENSE and 128 < d <= 256 and "KLARA_DENSE_NO_STREAM" not in os.environ
+            and not (sampler == L.SAMPLER_SLICE and "KLARA_DENSE_SLICE_NO_STREAM" in os.environ)):      # every sampler to D = 256: still the matrix cores, P streamed (klara_dense_big.h; round 5: the slice sampler too)
         return (1, 4, 8 * ((d + 31) // 32))
     if target_kind == L.TARGET_GAUSS_DENSE and d > 128:     # beyond the matrix-core layouts: the run-time compiled closure form
         return (0, 1, 256)
