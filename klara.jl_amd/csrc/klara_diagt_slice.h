@@ -9,11 +9,12 @@
 // slowest of 64 updates was done (4.5 shrink attempts where an update makes 1.46; issued / necessary instructions 2.55, 0.71 scalar instructions
 // per vector instruction for the votes, profiles/r4_pmc_summary.txt).
 //
-// Here the loops are turned inside out.  A lane takes ONE element pair of its chain (elements 2P, 2P + 1: two independent update machines,
-// interleaved for instruction-level parallelism) through ALL transitions of the launch before it moves to its next pair:
+// Here the loops are turned inside out.  A lane takes ONE element of its chain (NM = 1, the shipped form: element Q slot + q — the chain's elements dealt to
+// its lanes round robin, ceil(D / Q) slots; NM = 2: an element pair 2P, 2P + 1, two independent update machines interleaved for instruction-level
+// parallelism) through ALL transitions of the launch before it moves to its next one:
 //
-//     for pair slot p of the lane:                 (x, running sums, width, weight, mean of the pair: registers for the whole launch)
-//         until both machines have made nsteps transitions:      one iteration = at most one transition of each machine
+//     for element slot of the lane:                (x, running sums, width, weight, mean of the element: registers for the whole launch)
+//         until the machine(s) have made nsteps transitions:     one iteration = at most one transition of each machine
 //             block A = slot base (log(rand()), runiform): what a starting machine needs
 //             block B = base | (k + 1): the next two shrink attempts (k = 0 for a starting machine)
 //             starting machines: slice level, interval, step-out (SliceSampler.jl:66-89)      (executed by all, kept by the starting ones)
@@ -22,9 +23,10 @@
 //
 // A machine whose update needs more than two attempts (11 % of the updates on the README target) simply takes another iteration while its
 // neighbours start their next transition: nobody waits for the slowest of 64, and the only wave-wide vote left per iteration is the loop's
-// own.  What a wavefront still waits for is the slowest of its 128 machines over a whole pair slot (nsteps transitions each): a few per cent at 32
-// transitions per launch.  The new state's log-target is formed once, after the launch's last transition, in the layout's order (lane partials
-// over ascending elements, butterfly over the chain's Q lanes) — the same bits round 4's kernel and the oracle produce.
+// own.  What a wavefront still waits for is the slowest of its machines over a whole slot (nsteps transitions each): 6 % at the 128 transitions
+// per launch these jobs default to.  The new state's log-target is formed once, AFTER the launch, by k_diagt_hist_lt<.., STATE> below, in the layout's
+// order (lane partials over ascending elements, butterfly over the chain's Q lanes) — the same bits round 4's kernel and the oracle produce;
+// nothing else depends on which lane updates which element.
 //
 // Scope: untuned jobs; monitors: the accept diagnostics, the running sums and the value history (any thinning / burn-in, ring or not) are lane-local
 // like the updates themselves — a machine stores its element of a saved state when ITS transition ends; the log-target history of the saved states
