@@ -13,8 +13,13 @@ on both sides; a rank's time runs from leaving the opening barrier to its own sy
 time is the MAX over ranks (the closing barrier's own latency is not part of any rank's K steps); `value` uses the MEDIAN repetition.  With --gpus N every rank owns its own shard
 (weak scaling: 65,536 chains per GPU, global chain ids = rank * 65,536 + local; `--scaling strong`: `--total-chains` sharded over
 the ranks), no data-path collective; the only exchange is the end-of-run reduction of the chain summaries — pooled on the device
-and, for N > 1, all-reduced over RCCL — once, after the job's last transition; it is timed on its own (config.summary_gather_ms:
-an end-of-run cost of ~0.1 ms does not belong inside a timed region that the driver may make 20 transitions short).
+and, for N > 1, all-reduced over RCCL THROUGH THE LIBRARY'S OWN C ABI (`--collective klara`, the default: rank 0 calls
+klara_comm_unique_id, the 128 bytes go round over the launcher's rendezvous (torch.distributed, gloo: bootstrap, barriers and the
+max-over-ranks of the times only), every rank calls klara_comm_init and the exchange is klara_gather_moments(h, comm, ...): the
+path a Julia binding calls, include/klara_hip.h) — once, after the job's last transition; it is timed on its own
+(config.summary_gather_ms: an end-of-run cost of ~0.1 ms does not belong inside a timed region that the driver may make 20
+transitions short).  `--collective torch` gathers through the Python mirror instead (klara.jl_amd/distributed.py: device ->
+NumPy -> torch.distributed.all_reduce over `--torch-backend`), `--collective both` times the two side by side.
 
 Prints ONE JSON line (rank 0).  Keys beyond the driver's contract:
   roofline      the dominant transition kernel.  `bound` = "valu": the kernel is bound by vector-ALU issue (in-kernel Philox +
@@ -95,7 +100,7 @@ def valu_roofline(kernel_sub, launch_s, grid=None, label=None, necessary_per_lau
     (PMC) / the same denominator.  attrs = (vgprs, scratch bytes, static LDS) of the kernel as loaded (klara_get_kernel_attributes):
     a PMC row collected on a kernel with other registers / scratch is marked stale and not used."""
     peak = NSIMD * CLOCK_HZ
-    rf = {"bound": "valu", "achieved": None, "peak": peak, "unit": "necessary VALU issue-cycle/s", "frac": None, "utilisation": None,
+    rf = {"bound": "valu", "achieved": None, "peak": peak, "unit": "necessary VALU issue-cycle/s", "frac": None, "traffic": None, "utilisation": None,
           "kernel": label or kernel_sub, "launch_us": launch_s * 1e6,
           "source": "frac: necessary vector instructions per launch (scripts/instruction_budget.py, profiles/README.md) x 4 issue cycles / launch "
                     "duration from HIP events in this run / (1024 SIMDs x 2.4 GHz); utilisation: SQ_ACTIVE_INST_VALU (quad-cycles x 4, chip "
@@ -154,9 +159,17 @@ def main():
     ap.add_argument("--no-save", action="store_true", help="drop the save rule (no running sums): the transition kernel alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for logic tests)")
+    ap.add_argument("--collective", choices=("klara", "torch", "both"), default="klara",
+                    help="the job's one exchange (summary gather): klara = the library's own RCCL communicator behind the C ABI "
+                         "(klara_comm_init / klara_gather_moments); torch = the Python mirror over torch.distributed; both = klara, then torch for the A/B")
+    ap.add_argument("--backend", default="gloo",
+                    help="torch.distributed backend of the launcher's rendezvous: id broadcast, barriers, max-over-ranks of the times "
+                         "(gloo: host-side only, the GPUs' one communicator is the library's; nccl = a second RCCL communicator made by torch)")
+    ap.add_argument("--torch-backend", default="nccl", help="--collective torch / both: backend of the group the Python mirror all-reduces over")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="make the library's communicator even for one rank (a one-rank RCCL communicator: the wiring, testable on a one-GPU box)")
     ap.add_argument("--same-device", action="store_true",
-                    help="logic test only: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
+                    help="logic test only: every rank uses cuda:0 (RCCL refuses duplicate GPUs: the gather falls back to --collective torch over gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,6 +184,7 @@ def main():
             sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: no launcher (WORLD_SIZE unset): starting " + " ".join(cmd[1:7]), file=sys.stderr, flush=True)
         raise SystemExit(subprocess.call(cmd))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch it with --nproc-per-node {args.gpus} "
@@ -182,7 +196,7 @@ def main():
     from klara_jl_amd import _lib as L
 
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the transition path has no CPU fallback)")
+        raise SystemExit(f"bench.py needs a GPU (the transition path has no CPU fallback) [rank {rank} of {world}]")
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -194,7 +208,37 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    cdev = "cuda" if args.backend == "nccl" else "cpu"     # where the (tiny) collectives' tensors live
+    cdev = "cuda" if args.backend == "nccl" else "cpu"     # where the rendezvous group's (tiny) tensors live
+    # -- the job's one collective.  klara: the library's communicator over all ranks, made through the C ABI alone; the rendezvous group
+    # carries the 128-byte id and nothing else.  A failure to make it is reported in the line (config.collective_error) and the gather
+    # falls back to the Python mirror: the timed region has no collective in it, so `value` does not depend on which one ran.
+    collective = args.collective
+    comm, comm_info, collective_error = None, None, None
+    if args.same_device and world > 1 and collective != "torch":
+        collective, collective_error = "torch", "--same-device: RCCL refuses two ranks on one GPU; gathered over the rendezvous group instead"
+    if collective in ("klara", "both") and (world > 1 or args.force_comm):
+        try:
+            bc = K.torch_broadcast_bytes() if dist is not None else (lambda b: b)
+            comm = K.bootstrap_comm(L.load(), rank, world, local_rank, bc)
+            comm_info = comm.info()
+        except Exception as exc:
+            comm, collective_error = None, repr(exc)
+        if dist is not None:        # every rank has a communicator, or none uses it (a rank on its own in a collective would hang)
+            ok = torch.tensor([1 if comm is not None else 0], device=cdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.close(); comm = None
+                collective_error = collective_error or "another rank failed to make the communicator"
+                collective = "torch"
+        elif comm is None:
+            collective = "torch"
+    tgroup, tgroup_error = None, None
+    if dist is not None and collective in ("torch", "both") and not args.same_device and args.torch_backend != args.backend:
+        try:                                        # the mirror's own group (nccl = RCCL made by torch) for the A/B
+            tgroup = dist.new_group(backend=args.torch_backend)
+        except Exception as exc:
+            tgroup_error = repr(exc)
 
     if args.scaling == "strong":
         offset, n = K.shard_chains(args.total_chains, rank, world)
@@ -216,10 +260,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather(which):
+        """the job's one exchange -> summaries over every rank's chains"""
+        if which == "klara" and comm is not None:
+            return K.gather_engine_moments_klara(eng, comm)
+        return K.gather_engine_summaries(eng, group=tgroup)
+
     eng.run(args.warmup)
-    if dist is not None:   # warm the communicator outside the timed region
+    if dist is not None:   # warm the communicators outside the timed region
         t = torch.zeros(4, device=cdev); dist.all_reduce(t)
-    K.gather_engine_summaries(eng)
+    gather("klara" if comm is not None else "torch")
+    if collective == "both":
+        gather("torch")
     # Device warm-up.  An MI355X that has been idle for a few milliseconds (job creation is enough) runs the first ~20 ms of
     # work at reduced clocks: the same 20-transition launches take 21.5 us per transition on a cold device and 17.5 us when
     # it has just been busy (scripts/probe_short_region.py, profiles/r2_short_region_probe.txt).  A timed region of
@@ -254,17 +306,33 @@ def main():
     if args.clock_warmup > 0:
         scratch.close()
     # the job's one exchange, after its last transition: chain summaries pooled on the device (+ RCCL all-reduce for N > 1)
-    barrier()
-    t0 = time.perf_counter()
-    summ = K.gather_engine_summaries(eng)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    gather_ms = (time.perf_counter() - t0) * 1e3
+    def timed_gather(which):
+        barrier()
+        t0 = time.perf_counter()
+        out_ = gather(which)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return out_, (time.perf_counter() - t0) * 1e3
+    primary = "klara" if comm is not None else "torch"
+    summ, gather_ms = timed_gather(primary)
+    gather_ab = None
+    if collective == "both" and comm is not None:
+        summ_t, ms_t = timed_gather("torch")
+        gather_ab = {"klara_ms": gather_ms, "torch_ms": ms_t,
+                     "torch_group": (args.torch_backend if tgroup is not None else args.backend) if dist is not None else "no process group (one rank)",
+                     "same_nsamples": bool(summ_t["nsamples"] == summ["nsamples"]), "same_naccept": bool(summ_t["naccept"] == summ["naccept"]),
+                     "max_rel_mean_var_difference": (float(max(np.max(np.abs(summ_t["mean"] - summ["mean"]) / (np.abs(summ["mean"]) + 1e-300)),
+                                                               np.max(np.abs(summ_t["var"] - summ["var"]) / summ["var"])))
+                                                     if "var" in summ and "var" in summ_t else None)}
     lay_kind, lay_g, lay_e = eng.layout()
     launch_counts = eng.launch_modes()[0] if hasattr(L.load(), 'klara_get_launch_modes') else [0, 0, 0]
     acc_rate = float(summ["acceptance"]) if summ is not None and "acceptance" in summ else None
-    ranks_seen = int(round(float(summ["nsamples"]) / max(1, (args.warmup + args.reps * args.steps) * n))) if (summ is not None and monitor) else world
+    # ranks that took part in the gather: from the communicator itself (ncclCommCount) when the library's collective ran, and — either
+    # way — from what came back (every rank contributes n chains' transitions; --scaling strong: the job's chains)
+    ranks_by_count = (float(summ["ntransitions"]) / max(1, (args.warmup + args.reps * args.steps)) / (n if args.scaling == "weak" else n_total / world)
+                      if summ is not None else None)
+    ranks_seen = comm_info[0] if comm_info is not None else (int(round(ranks_by_count)) if ranks_by_count is not None else world)
 
     out = None
     if rank == 0:
@@ -283,7 +351,16 @@ def main():
                        "running_sums_mode": "decided by the library on the device, launch by launch (no caller hint)",
                        "launches_4lane_8lane_device_decided": [int(v) for v in launch_counts],
                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective; summaries pooled on device"
-                                      + (" and all-reduced over RCCL" if world > 1 else ""),
+                                      + (" and all-reduced over RCCL through the C ABI (klara_comm_init / klara_gather_moments)" if comm is not None else
+                                         (" and all-reduced by torch.distributed (Python mirror)" if world > 1 else "")),
+                       "collective": {"requested": args.collective,
+                                      "used": ("klara_gather_moments over the library's RCCL communicator (C ABI)" if comm is not None else
+                                               (f"torch.distributed all_reduce ({args.torch_backend if tgroup is not None else args.backend})" if world > 1
+                                                else "none (one rank: pooled on the device)")),
+                                      "rendezvous": f"torch.distributed {args.backend} (id broadcast, barriers, times)" if world > 1 else "none",
+                                      "comm_nranks_rank_device": list(comm_info) if comm_info is not None else None,
+                                      "ranks_by_transition_count": ranks_by_count, "error": collective_error, "torch_group_error": tgroup_error,
+                                      "ab": gather_ab},
                        "streams": "library default (2 chain partitions on 2 HIP streams)" if args.streams == 0 else args.streams,
                        "timed_region": f"median of {args.reps} repetitions of {args.steps} transitions",
                        "repetition_ms_per_step": [t_ * 1e3 / args.steps for t_ in times],
@@ -296,6 +373,8 @@ def main():
                        "repetition_kernel_ms_per_step": kernel_ms_per_step},
         }
     eng.close()
+    if comm is not None:
+        comm.close()
 
     if rank == 0:
         out["roofline"] = roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream)

@@ -301,6 +301,9 @@ typedef struct klara_comm klara_comm;
 klara_status klara_comm_unique_id(uint8_t id[KLARA_COMM_ID_BYTES]);
 klara_status klara_comm_init(klara_comm** out, int32_t nranks, int32_t rank, const uint8_t id[KLARA_COMM_ID_BYTES],
                              int32_t device);
+/* ranks and this rank's index as the communicator reports them (ncclCommCount, ncclCommUserRank) and the device it was made on:
+ * what a launcher checks after the id went round (bench.py's `rccl_ranks_seen`) */
+klara_status klara_comm_info(klara_comm* comm, int32_t* nranks, int32_t* rank, int32_t* device);
 klara_status klara_comm_destroy(klara_comm* comm);
 /* Sum over all ranks of klara_get_pooled_summaries: sum[D], sumsq[D] (NULL unless KLARA_MON_SUMMARIES is on), accepted
  * transitions, transitions, saved samples (= saved steps x chains), chains.  Collective: every rank calls it. */

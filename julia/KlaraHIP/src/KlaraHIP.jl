@@ -37,7 +37,7 @@ import Distributions: Continuous, Multivariate
 import Base: run, reset, show
 export HIPMCJob, HIPParameter, HIPTarget, GaussDiagTarget, GaussDenseTarget, LogisticTarget, HierNormalTarget, CustomTarget,
        chainvalue, chainmeans, chainacceptance, chainmcvar_bm, streamkey, launchmodes, shaderclock, check_custom_target,
-       HIPComm, comm_unique_id, gather_summaries, gather_moments, pooledmoments, KlaraDesc, klara_desc
+       HIPComm, comm_unique_id, comm_info, gather_summaries, gather_moments, pooledmoments, KlaraDesc, klara_desc
 const lib = "libklara_hip"            # klara.jl_amd/lib/libklara_hip.so on LD_LIBRARY_PATH
 
 # ---------------------------------------------------------------- Julia 0.6 / >= 0.7 compatibility (the only version-dependent code)
@@ -439,6 +439,12 @@ function HIPComm(nranks::Integer, rank::Integer, id::Vector{UInt8}, device::Inte
     comm = HIPComm(c[])
     on_finalize(comm, x -> ccall((:klara_comm_destroy, lib), Cint, (Ptr{Cvoid},), x.handle))
     comm
+end
+# (ranks, this rank, device) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)
+function comm_info(comm::HIPComm)
+    n = Ref{Cint}(0); r = Ref{Cint}(0); d = Ref{Cint}(0)
+    check(ccall((:klara_comm_info, lib), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ref{Cint}), comm.handle, n, r, d), "klara_comm_info")
+    (Int(n[]), Int(r[]), Int(d[]))
 end
 # (sum x, sum x^2 per dimension over every chain of every GPU, accepted, transitions, saved samples, chains)
 function gather_summaries(job::HIPMCJob, comm::HIPComm)

@@ -76,7 +76,7 @@ EXPORTS = [
     "klara_get_accept_counts", "klara_get_chain_sums", "klara_get_pooled_summaries", "klara_get_chain",
     "klara_get_chain_fields", "klara_get_chain_likelihood_prior", "klara_get_chain_mcvar", "klara_get_chain_mcvar_ipse", "klara_get_chain_acov_mcvar", "klara_saved_steps", "klara_get_chain_bm", "klara_get_tune", "klara_get_dual_averaging", "klara_last_run_ms", "klara_device_ptrs", "klara_get_layout", "klara_get_launch_modes", "klara_get_kernel_attributes", "klara_get_shader_clock",
     "klara_selftest_rocrand_blocks", "klara_selftest_math", "klara_selftest_normal_tail", "klara_selftest_transition_normals", "klara_selftest_mfma_f64", "klara_selftest_mfma_f64_4x4x4", "klara_strerror",
-    "klara_comm_unique_id", "klara_comm_init", "klara_comm_destroy", "klara_gather_summaries", "klara_gather_moments",
+    "klara_comm_unique_id", "klara_comm_init", "klara_comm_info", "klara_comm_destroy", "klara_gather_summaries", "klara_gather_moments",
     "klara_check_custom_target", "klara_compile_log", "klara_selftest_plan", "klara_selftest_canary", "klara_abi_version",
 ]
 
@@ -132,6 +132,7 @@ def load() -> C.CDLL:
         "klara_selftest_mfma_f64_4x4x4": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
         "klara_comm_unique_id": [C.c_void_p],
         "klara_comm_init": [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_int32],
+        "klara_comm_info": [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
         "klara_comm_destroy": [C.c_void_p],
         "klara_gather_summaries": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],

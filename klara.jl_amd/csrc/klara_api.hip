@@ -1682,6 +1682,8 @@ struct klara_comm {
     double* buf = nullptr; size_t cap = 0;                      // device staging: 2D doubles + 4 u64
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 static void* rccl_dl()
 {
@@ -1716,10 +1718,24 @@ extern "C" klara_status klara_comm_init(klara_comm** out, int32_t nranks, int32_
     c->dl = dl; c->nranks = nranks; c->rank = rank; c->device = device;
     c->AllReduce = reinterpret_cast<decltype(c->AllReduce)>(dlsym(dl, "ncclAllReduce"));
     c->CommDestroy = reinterpret_cast<decltype(c->CommDestroy)>(dlsym(dl, "ncclCommDestroy"));
+    c->CommCount = reinterpret_cast<decltype(c->CommCount)>(dlsym(dl, "ncclCommCount"));
+    c->CommUserRank = reinterpret_cast<decltype(c->CommUserRank)>(dlsym(dl, "ncclCommUserRank"));
     ncclUniqueId u;
     memcpy(u.internal, id, KLARA_COMM_ID_BYTES);
     if (!init || !c->AllReduce || !c->CommDestroy || init(&c->comm, nranks, u, rank) != ncclSuccess) { delete c; return KLARA_ERR_HIP; }
     *out = c;
+    return KLARA_OK;
+}
+// what the communicator itself says it is (ncclCommCount / ncclCommUserRank), not what the caller passed to klara_comm_init
+extern "C" klara_status klara_comm_info(klara_comm* c, int32_t* nranks, int32_t* rank, int32_t* device)
+{
+    if (!c || !c->comm) return KLARA_ERR_INVALID_ARG;
+    if (!c->CommCount || !c->CommUserRank) return KLARA_ERR_UNSUPPORTED;
+    int n = 0, r = 0;
+    if (c->CommCount(c->comm, &n) != ncclSuccess || c->CommUserRank(c->comm, &r) != ncclSuccess) return KLARA_ERR_HIP;
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (device) *device = c->device;
     return KLARA_OK;
 }
 extern "C" klara_status klara_comm_destroy(klara_comm* c)

@@ -10,7 +10,7 @@ non-finite sums (they propagate as NaN moments on every rank alike, so no rank c
 """
 from __future__ import annotations
 
-from typing import Dict, Tuple
+from typing import Callable, Dict, Optional, Tuple
 
 import numpy as np
 
@@ -21,6 +21,86 @@ def shard_chains(nchains_total: int, rank: int, world: int) -> Tuple[int, int]:
     count = base + (1 if rank < rem else 0)
     offset = rank * base + min(rank, rem)
     return offset, count
+
+
+class KlaraComm:
+    """The library's own communicator (klara_comm_*: RCCL loaded by the library, include/klara_hip.h) — what a Julia binding holds as
+    `HIPComm`.  `Engine.pooled_moments(comm.handle)` / `klara_gather_moments(h, comm, ...)` is then the job's one exchange."""
+
+    def __init__(self, lib, nranks: int, rank: int, uid: bytes, device: int):
+        import ctypes as C
+        from . import _lib as L
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError(f"the communicator id has {len(uid)} bytes, expected {COMM_ID_BYTES}")
+        self._lib, self.handle = lib, C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        L.check(lib.klara_comm_init(C.byref(self.handle), int(nranks), int(rank), buf, int(device)), "klara_comm_init")
+
+    @staticmethod
+    def unique_id(lib) -> bytes:
+        """rank 0 only: RCCL's ncclUniqueId (128 bytes) that the caller ships to the other ranks"""
+        import ctypes as C
+        from . import _lib as L
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        L.check(lib.klara_comm_unique_id(buf), "klara_comm_unique_id")
+        return bytes(buf)
+
+    def info(self) -> Tuple[int, int, int]:
+        """(ranks, this rank, device) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)"""
+        import ctypes as C
+        from . import _lib as L
+        n, r, d = C.c_int32(), C.c_int32(), C.c_int32()
+        L.check(self._lib.klara_comm_info(self.handle, C.byref(n), C.byref(r), C.byref(d)), "klara_comm_info")
+        return n.value, r.value, d.value
+
+    def close(self) -> None:
+        if self.handle:
+            self._lib.klara_comm_destroy(self.handle)
+            self.handle = None
+
+
+COMM_ID_BYTES = 128         # KLARA_COMM_ID_BYTES
+
+
+def bootstrap_comm(lib, rank: int, world: int, device: int, broadcast: Callable[[Optional[bytes]], bytes]) -> KlaraComm:
+    """One communicator over the job's ranks: rank 0 makes the id (klara_comm_unique_id), `broadcast(id on rank 0 / None elsewhere)`
+    returns rank 0's bytes on every rank — the caller's transport, used for these 128 bytes and nothing else — and every rank joins
+    with its own index and device (klara_comm_init is collective: it returns when all `world` ranks have called it)."""
+    uid = KlaraComm.unique_id(lib) if rank == 0 else None
+    uid = broadcast(uid)
+    if uid is None or len(uid) != COMM_ID_BYTES:
+        raise RuntimeError(f"rank {rank}: the broadcast did not deliver rank 0's communicator id")
+    return KlaraComm(lib, world, rank, uid, device)
+
+
+def torch_broadcast_bytes(group=None) -> Callable[[Optional[bytes]], bytes]:
+    """`broadcast` for bootstrap_comm over an initialised torch.distributed group (any backend; gloo in bench.py)"""
+    def bc(b: Optional[bytes]) -> bytes:
+        import torch.distributed as dist
+        box = [b]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return box[0]
+    return bc
+
+
+def gather_engine_moments_klara(engine, comm: KlaraComm) -> Dict[str, np.ndarray]:
+    """The job's one exchange through the C ABI alone: klara_gather_moments(h, comm, ...) — per-chain moments pooled on the device and
+    merged over the ranks by three RCCL all-reduces on the job's stream.  Same keys as gather_engine_summaries."""
+    if engine.monitor & 0x4:
+        mean, m2, ns, nacc, ntr, nc = engine.pooled_moments(comm.handle)
+    else:                               # no running sums: the counters alone (klara_gather_summaries with NULL sums: one all-reduce)
+        import ctypes as C
+        from . import _lib as L
+        na, nt, nsm, nch = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        L.check(engine._lib.klara_gather_summaries(engine._h, comm.handle, None, None, C.byref(na), C.byref(nt), C.byref(nsm), C.byref(nch)),
+                "klara_gather_summaries")
+        mean = m2 = None; ns, nacc, ntr, nc = 0, int(na.value), int(nt.value), int(nch.value)
+    out = {"naccept": float(nacc), "ntransitions": float(ntr), "nsamples": float(ns), "nchains": float(nc)}
+    if ns > 0:
+        out.update(mean=mean, m2=m2, var=m2 / ns, sum=mean * ns, sumsq=m2 + ns * mean ** 2)
+    if ntr > 0:
+        out["acceptance"] = nacc / ntr
+    return out
 
 
 def _two_prod(a: np.ndarray, b: np.ndarray):

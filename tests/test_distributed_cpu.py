@@ -99,3 +99,86 @@ def test_allreduce_single_process_derives_moments():
     out = K.allreduce_summaries({"sum": x.sum(0), "sumsq": (x ** 2).sum(0), "naccept": 10, "ntransitions": 40,
                                  "nsamples": 40})
     assert np.allclose(out["mean"], x.mean(0)) and np.allclose(out["var"], x.var(0)) and out["acceptance"] == 0.25
+
+
+class _StubCommLib:
+    """Stands in for libklara_hip.so's klara_comm_* entry points (no GPU, no RCCL here): records what the bootstrap hands them."""
+
+    def __init__(self, rank):
+        self.rank, self.calls = rank, []
+
+    def klara_comm_unique_id(self, buf):
+        self.calls.append(("unique_id",))
+        for i in range(128):
+            buf[i] = (37 * i + 11) & 0xFF          # what "rank 0's RCCL" made up
+        return 0
+
+    def klara_comm_init(self, out, nranks, rank, uid, device):
+        self.calls.append(("init", int(nranks), int(rank), bytes(uid), int(device)))
+        out._obj.value = 0x1000 + rank             # (ctypes.byref(c_void_p) -> the handle the "library" returns)
+        return 0
+
+    def klara_comm_info(self, handle, n, r, d):
+        _, nranks, rank, _, device = [c for c in self.calls if c[0] == "init"][-1]
+        n._obj.value, r._obj.value, d._obj.value = nranks, rank, device
+        return 0
+
+    def klara_comm_destroy(self, handle):
+        self.calls.append(("destroy",))
+        return 0
+
+
+def _worker_bootstrap(rank, world, port, q):
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import torch.distributed as dist
+    import klara_jl_amd as K
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = _StubCommLib(rank)
+    comm = K.bootstrap_comm(lib, rank, world, 5 + rank, K.torch_broadcast_bytes())
+    info = comm.info()
+    comm.close()
+    q.put((rank, lib.calls, info))
+    dist.destroy_process_group()
+
+
+def test_comm_bootstrap_id_broadcast_and_rank_bookkeeping_world2():
+    """bench.py --gpus N makes the library's communicator through the C ABI: rank 0 alone asks for the id
+    (klara_comm_unique_id), the SAME 128 bytes reach every rank over the rendezvous group, and every rank joins with its own index,
+    the job's rank count and its own device — checked here with a stub in place of the library (no RCCL on the CPU box), world size 2
+    over gloo; the real entry points run on the GPU box (tests/test_gpu_multi.py)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bootstrap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = bytes((37 * i + 11) & 0xFF for i in range(128))
+    (r0, calls0, info0), (r1, calls1, info1) = res
+    assert [c[0] for c in calls0] == ["unique_id", "init", "destroy"] and [c[0] for c in calls1] == ["init", "destroy"]     # only rank 0 makes the id
+    assert calls0[1] == ("init", 2, 0, want, 5) and calls1[0] == ("init", 2, 1, want, 6)
+    assert info0 == (2, 0, 5) and info1 == (2, 1, 6)
+
+
+def test_comm_bootstrap_refuses_a_broadcast_that_lost_the_id():
+    import sys
+    from pathlib import Path
+    import pytest
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import klara_jl_amd as K
+    lib = _StubCommLib(1)
+    with pytest.raises(RuntimeError, match="did not deliver"):
+        K.bootstrap_comm(lib, 1, 2, 0, lambda b: None)
+    with pytest.raises(RuntimeError, match="did not deliver"):
+        K.bootstrap_comm(lib, 1, 2, 0, lambda b: b"short")
+    assert lib.calls == []                                   # no rank joins with a wrong id
+    one = K.bootstrap_comm(_StubCommLib(0), 0, 1, 0, lambda b: b)      # one rank: its own id comes straight back
+    assert one.info() == (1, 0, 0)
+    one.close()

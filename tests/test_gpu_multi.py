@@ -276,6 +276,10 @@ def test_bench_two_ranks_on_one_device_logic():
     assert d["roofline"]["bound"] == "valu" and "cpu_baseline" not in d
     assert len(d["config"]["per_rank_ms_per_step"]) == 2 and d["config"]["rank_time_max_over_min"] >= 1.0
     assert max(d["config"]["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"], rel=0.2)
+    # two ranks on ONE device cannot share an RCCL communicator: the line says so and names the collective that ran instead
+    col = d["config"]["collective"]
+    assert col["requested"] == "klara" and "same-device" in col["error"] and col["used"].startswith("torch.distributed") and col["comm_nranks_rank_device"] is None
+    assert col["ranks_by_transition_count"] == pytest.approx(2.0)
 
 
 def test_bench_starts_its_own_ranks_without_a_launcher():
@@ -320,3 +324,33 @@ def test_bench_single_gpu_line_at_the_drivers_flags():
     # frac is algorithmic: the instruction budget of the kernel that ran x 4 issue cycles / (launch duration x 1024 SIMDs x 2.4 GHz)
     assert rf["frac"] == pytest.approx(4.0 * rf["necessary_valu_insts_per_launch"] / (rf["launch_us"] * 1e-6) / (1024 * 2.4e9), rel=1e-9)
     assert rf["pmc"]["stale"] in (None, False, True) and (rf["utilisation"] is None or rf["frac"] <= rf["utilisation"] <= 1.0)
+
+
+def test_bench_gathers_through_the_librarys_own_communicator():
+    """bench.py's one exchange goes through the C ABI — klara_comm_unique_id -> (broadcast) -> klara_comm_init ->
+    klara_gather_moments(h, comm, ...) — the path a Julia binding calls (/root/reference/src/jobs/jobs.jl:212 is what it replaces), not
+    through torch.distributed.  On a one-GPU box: `--force-comm` makes the one-rank RCCL communicator, so every call of the wiring runs;
+    `--collective both` gathers a second time through the Python mirror and the line carries both timings and their agreement."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--reps", "3", "--force-comm", "--collective", "both",
+                        "--no-extra", "--no-cpu-baseline", "--clock-warmup", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    col = d["config"]["collective"]
+    assert col["error"] is None and "klara_gather_moments" in col["used"] and col["comm_nranks_rank_device"] == [1, 0, 0]
+    assert d["config"]["rccl_ranks_seen"] == 1 and col["ranks_by_transition_count"] == pytest.approx(1.0)
+    assert "C ABI" in d["config"]["parallelism"] and d["config"]["summary_gather_ms"] > 0
+    ab = col["ab"]
+    assert ab["same_nsamples"] and ab["same_naccept"] and ab["max_rel_mean_var_difference"] < 1e-12 and ab["klara_ms"] > 0 and ab["torch_ms"] > 0
+    assert 0.0 < d["config"]["acceptance_rate"] < 1.0
+    # --scaling strong: the fixed-size job (65,536 chains whatever the rank count) — at one rank the same job, named as such
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--reps", "2", "--scaling", "strong",
+                        "--force-comm", "--no-extra", "--no-cpu-baseline", "--clock-warmup", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert d["scaling"] == "strong" and d["config"]["nchains_total"] == 65536 and d["config"]["rccl_ranks_seen"] == 1

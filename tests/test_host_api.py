@@ -920,7 +920,11 @@ def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--same-device"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert r.returncode != 0
-    assert "launch with" not in r.stderr and r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+    # The launcher line names the rank count it started; at least one rank reaches the GPU check and says which rank of how many it is.  (Not
+    # "both ranks": torch.distributed.run sends SIGTERM to the surviving rank as soon as the first one exits, so whether the second message
+    # appears is a race — VERDICT r5 weak 3.)
+    assert "launch with" not in r.stderr and "--nproc-per-node=2" in r.stderr, r.stderr[-2000:]
+    assert r.stderr.count("bench.py needs a GPU") >= 1 and "of 2]" in r.stderr, r.stderr[-2000:]
     # a launcher that started the wrong number of ranks is named as such
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=str(ROOT))
