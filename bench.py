@@ -54,7 +54,7 @@ CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock; 256 CUs x 4 SIMDs
 NSIMD = 1024
 # How the running sums of a moving chain are kept (4-lane kernels + atomic folds, or 8-lane kernels + resident sums) is decided by the
 # library itself, on the device, launch by launch (klara_desc.sparse_moves = 0): no caller hint.
-PMC_JSON = ROOT / "profiles" / "r5_pmc_kernels.json"
+PMC_JSON = ROOT / "profiles" / "r6_pmc_kernels.json"
 PMC_EXPECT = {}             # filled by main(): the launch length the committed counters must have been collected at
 
 
@@ -287,9 +287,10 @@ def main():
     for _ in range(args.reps):
         barrier()
         t0 = time.perf_counter()
-        eng.run(args.steps)
-        torch.cuda.synchronize()
+        eng.run_async(args.steps)                   # klara_run_async: enqueue the K steps (the launch loop of klara_run) ...
+        torch.cuda.synchronize()                    # ... and the contract's synchronisation: the device has finished them
         elapsed = time.perf_counter() - t0          # this rank's K steps; the job's time is the MAX over ranks (below)
+        eng.synchronize()                           # klara_synchronize (outside the clock; nothing left to wait for): raises what a kernel flagged
         if dist is not None:
             dist.barrier()                           # closing bracket: every rank is done before anyone goes on
             te = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
@@ -377,7 +378,15 @@ def main():
         comm.close()
 
     if rank == 0:
-        out["roofline"] = roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream)
+        out["roofline"] = rf = roofline_pass(K, L, n, spl, monitor, offset, local_rank, stream)
+        # the same fraction over the TIMED REGION itself (HIP events around each repetition's K steps on this rank): there the library runs
+        # the job as two chain partitions on two streams whose kernels overlap, so no single launch has a duration of its own — work / elapsed
+        if rf.get("necessary_valu_insts_per_launch") and rf.get("transitions_per_launch"):
+            per_step = rf["necessary_valu_insts_per_launch"] / rf["transitions_per_launch"]
+            rf["frac_timed_region"] = 4.0 * per_step / (statistics.median(kernel_ms_per_step) * 1e-3) / rf["peak"]
+            rf["frac_timed_region_source"] = ("necessary vector instructions per transition of this rank's chains x 4 / (klara_last_run_ms over the timed "
+                                              "repetitions / steps) / peak: multi-launch runs overlap two chain partitions on two streams (a launch's ramp, its last "
+                                              "round of wavefronts and the gap to the next launch are filled by the other partition), `frac` prices one launch alone")
     if rank == 0 and world == 1 and not args.no_extra:
         out["extra"] = extra_measurements(K, L, n, stream)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -496,6 +505,30 @@ def extra_measurements(K, L, n, stream):
         rate, _, _ = timed_rate(e, n, 64, 1024)
         ex[f"{key}_transitions_per_s"] = rate
         e.close()
+    # -- the same sampler at a step that MIXES (at driftstep 0.9 the headline job rejects 99 % of its proposals, so its timed region
+    # hardly runs the commit / fold path): driftstep 0.3 -> acceptance 0.56 (AcceptanceRateMCTuner's target for MALA is 0.574), running sums on, the
+    # kernel family decided by the library (resident sums on 8 lanes per chain at this acceptance)
+    e = K.Engine(sampler=L.SAMPLER_MALA, target=neg, nchains=n, nsteps=10 ** 7, driftstep=0.3, stream=stream, monitor=L.MON_SUMMARIES)
+    e.init_state_normal()
+    rate, _, _ = timed_rate(e, n, 256, 1024)
+    _, _, nacc, ntr, _ = e.pooled_summaries(with_sums=False)
+    ex["mala_d100_mixing_step_transitions_per_s"] = rate
+    ex["mala_d100_mixing_step"] = {"driftstep": 0.3, "acceptance_rate": nacc / max(ntr, 1), "save_rule": "running sums",
+                                   "launches_4lane_8lane_device_decided": [int(v) for v in e.launch_modes()[0]]}
+    e.close()
+    e = K.Engine(sampler=L.SAMPLER_MALA, target=neg, nchains=n, nsteps=10 ** 7, driftstep=0.3, stream=stream, monitor=L.MON_SUMMARIES, nstreams=1)
+    e.init_state_normal()
+    ls, _ = launch_duration(e, L.DEFAULT_STEPS_PER_LAUNCH, nlaunch=32)
+    lay_m = e.layout(); last_mode = e.launch_modes()[1]
+    four_m = last_mode[0] == 0
+    at = attrs_of(e, L.DEFAULT_STEPS_PER_LAUNCH, 0 if four_m else 1); e.close()
+    bm = bud["headline_4lane" if four_m else "headline_8lane"]
+    gm, em = (4, 2 * ((NDIMS + 7) // 8)) if four_m else (lay_m[1], lay_m[2])
+    ex["mala_d100_mixing_step_roofline"] = valu_roofline(diagt_kernel_name(1, gm, em, False, True, True), ls, grid=diagt_grid(n, gm), attrs=at, budget=bm,
+                                                         necessary_per_launch=bm["per_wave_transition"] * ((n + bm["chains_per_wave"] - 1) // bm["chains_per_wave"]) * L.DEFAULT_STEPS_PER_LAUNCH)
+    ex["mala_d100_mixing_step_roofline"]["note"] = ("the budget prices the transition (normals, proposal, ratio, accept test), not the commit of an accepted proposal nor the fold of "
+                                                    "the running sums, which this job executes on every second transition of every chain")
+
     # one launch at a time for the single-transition kernel (round 1's roofline kernel)
     e = K.Engine(sampler=L.SAMPLER_MALA, target=neg, nchains=n, nsteps=10 ** 7, driftstep=0.9, stream=stream, steps_per_launch=1,
                  monitor=0, nstreams=1)
@@ -593,7 +626,7 @@ def extra_measurements(K, L, n, stream):
 
     # -- slice sampler on the README target, D = 100: the library's own launch length for this job (KLARA_DEFAULT_STEPS_PER_LAUNCH_SLICE; the lanes run out of
     # lockstep and a wavefront waits for its slowest lane once per element slot and launch, klara_diagt_slice.h)
-    SLICE_SPL = 128
+    SLICE_SPL = L.DEFAULT_STEPS_PER_LAUNCH_SLICE
     e = K.Engine(sampler=L.SAMPLER_SLICE, target=neg, nchains=n, nsteps=10 ** 7, slice_widths=np.full(NDIMS, 1.0), steps_per_launch=0,
                  stream=stream, nstreams=1)
     e.init_state_normal()
@@ -624,6 +657,34 @@ def extra_measurements(K, L, n, stream):
             ex[f"{key}_layout"] = list(lay)
     except Exception as exc:
         ex["slice_dense_error"] = repr(exc)
+
+    # -- the slice sampler on GENERAL targets: every probe is a full evaluation of the log-target by the chain's lanes
+    # (SliceSampler.jl:77-94 as written; the difference form above exists for diagonal Gaussians only).  The swiss logistic regression
+    # (doc/examples/swiss/SliceSampler.jl: D = 4, a probe = a pass over the 200 data rows) and a pair closure (the README target written as
+    # klara_user_pair, D = 100: run as a whole-vector closure staged through LDS)
+    try:
+        gold = ROOT / "tests" / "golden"
+        sw = np.load(gold / "swiss.npz")
+        Xs = sw["measurements"]; Xs = np.ascontiguousarray((Xs - Xs.mean(axis=0)) / Xs.std(axis=0, ddof=1))
+        ys = np.ascontiguousarray(sw["status"].astype(np.float64))
+        nc = 32768
+        e = K.Engine(sampler=L.SAMPLER_SLICE, target=K.LogisticTarget(Xs, ys, 100.0), nchains=nc, nsteps=10 ** 6, slice_widths=np.full(4, 1.0), stream=stream)
+        e.set_state(0.1 * np.random.default_rng(3).standard_normal((nc, 4)))
+        rate, ls, _ = timed_rate(e, nc, 64, 128)
+        ex["slice_swiss_logistic_chain_transitions_per_s"] = rate
+        ex["slice_swiss_logistic_coordinate_updates_per_s"] = rate * 4
+        ex["slice_swiss_logistic_layout"] = list(e.layout()); e.close()
+        src_pair = ("KLARA_USER_FN double klara_user_pair(double x0, double x1, int pair, int D, const double* data, long long ndata, double* g0, double* g1)\n"
+                    "{ *g0 = -2.0 * x0; *g1 = -2.0 * x1; return -(x0 * x0) - (x1 * x1); }\n")
+        e = K.Engine(sampler=L.SAMPLER_SLICE, target=K.CustomTarget.pairwise(NDIMS, src_pair), nchains=n, nsteps=10 ** 6, slice_widths=np.full(NDIMS, 1.0),
+                     steps_per_launch=1, stream=stream)
+        e.init_state_normal()
+        rate, ls, _ = timed_rate(e, n, 1, 4)
+        ex["slice_pair_closure_d100_chain_transitions_per_s"] = rate
+        ex["slice_pair_closure_d100_coordinate_updates_per_s"] = rate * NDIMS
+        ex["slice_pair_closure_d100_layout"] = list(e.layout()); e.close()
+    except Exception as exc:
+        ex["slice_general_target_error"] = repr(exc)
 
     # -- the two data-model configurations of BASELINE.json at their per-GPU share (cfg 4: 262,144 / 8 chains of the swiss
     # logistic regression, MALA h = 0.1; cfg 5: 1,048,576 / 8 chains of the rats hierarchical model, HMC L = 32 with the

@@ -46,8 +46,10 @@ extern "C" {
 /* klara_desc.steps_per_launch = 0 selects this many transitions per kernel launch (launches also end at the pooled tuner's
  * events and at batch boundaries of the streaming batch means, whichever comes first) */
 #define KLARA_DEFAULT_STEPS_PER_LAUNCH 32
-/* ... and for slice-sampler jobs on a diagonal Gaussian whose monitors are the accept diagnostics and / or the running sums (the kernel whose lanes
- * run out of lockstep, klara.jl_amd/csrc/klara_diagt_slice.h: a wavefront waits for its slowest lane once per element slot and launch) */
+/* ... and for the slice-sampler jobs the free-running kernel serves (klara.jl_amd/csrc/klara_diagt_slice.h: the lanes run out of lockstep, a wavefront
+ * waits for its slowest lane once per element slot and launch): diagonal Gaussian, 17 <= D <= 512, untuned (VanillaMCTuner per chain, not verbose),
+ * monitors among the accept diagnostics, the running sums, the value history (ring or not), the log-target history (with the values kept) and
+ * the streaming autocovariances.  Ring planning and the cadence of the accept rows follow this length.  Every other slice job: 32. */
 #define KLARA_DEFAULT_STEPS_PER_LAUNCH_SLICE 128
 #define KLARA_LOGIT_MAX_LDS_DOUBLES 18432u   /* 144 KB of the 160 KB of LDS of a compute unit */
 
@@ -59,8 +61,9 @@ typedef enum klara_status {
     KLARA_ERR_NOMEM = 4,
     KLARA_ERR_UNSUPPORTED = 5,     /* valid Klara option that this build does not cover (see DESIGN)  */
     KLARA_ERR_STATE = 6,           /* call order (e.g. run before set_state)                          */
-    KLARA_ERR_SLICE_STUCK = 7,     /* iterate/SliceSampler.jl:102 "Shrunk to current position ..." (or 16,383 step-out / shrink attempts): the state of
-                                      the chains that raised it is unspecified afterwards (the reference throws out of run(job)); reset the job */
+    KLARA_ERR_SLICE_STUCK = 7,     /* iterate/SliceSampler.jl:102 "Shrunk to current position ..." (or 16,383 step-out / shrink attempts): a chain that
+                                      raised it stops at the state BEFORE the coordinate update that failed (its X and log-target belong together; the
+                                      reference throws out of run(job) at that point), the job's other chains go on; reset the job */
     KLARA_ERR_COMPILE = 8          /* CUSTOM target: the user's source did not compile (klara_compile_log) */
 } klara_status;
 

@@ -15,6 +15,7 @@ LIB_PATH = _HERE / "lib" / "libklara_hip.so"
 
 KLARA_ABI_VERSION = 6
 DEFAULT_STEPS_PER_LAUNCH = 32     # KLARA_DEFAULT_STEPS_PER_LAUNCH
+DEFAULT_STEPS_PER_LAUNCH_SLICE = 128   # KLARA_DEFAULT_STEPS_PER_LAUNCH_SLICE (the slice-sampler jobs the free-running kernel serves)
 LOGIT_MAX_LDS_DOUBLES = 18432     # KLARA_LOGIT_MAX_LDS_DOUBLES
 
 # klara_status

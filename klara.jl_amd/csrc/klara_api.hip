@@ -122,7 +122,10 @@ static bool slice_free_eligible(const klara_desc& d)
     static const bool lockstep = getenv("KLARA_SLICE_LOCKSTEP") != nullptr;
     const uint32_t lane_local = KLARA_MON_ACCEPT | KLARA_MON_SUMMARIES | KLARA_MON_HISTORY | KLARA_MON_HIST_LT;
     const bool values_kept = (d.monitor & KLARA_MON_HISTORY) != 0 || d.acov_maxlag > 0;       // (the log-target history is formed from the saved values)
-    return diagt_eligible(d) && d.sampler == KLARA_SAMPLER_SLICE && !cnt_predicate(d) && !lockstep &&
+    // (nothing counts AND nothing tunes — a pooled or dual-averaging tuner setting, verbose or not, runs k_diagt<SLICE> at its 32 transitions per
+    // launch: the launch length and the kernel choice come from this one predicate)
+    const bool plain = !cnt_predicate(d) && d.tuner_mode == KLARA_TUNE_PER_CHAIN && d.tuner != KLARA_TUNER_DUAL_AVERAGING;
+    return diagt_eligible(d) && d.sampler == KLARA_SAMPLER_SLICE && plain && !lockstep &&
            (d.monitor & ~lane_local) == 0 && (!(d.monitor & KLARA_MON_HIST_LT) || values_kept);
 }
 // transitions per launch when klara_desc.steps_per_launch = 0
@@ -1022,7 +1025,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
         // which kernel family runs the launch (q4_ok jobs: same bits either way)
         const bool sums = (d.monitor & KLARA_MON_SUMMARIES) != 0;
         // slice sampler: nothing counts and no history is kept -> the lanes run out of lockstep (klara_diagt_slice.h); same draws, same bits
-        const bool slice_free = !tune && slice_free_eligible(d);
+        const bool slice_free = slice_free_eligible(d);
         int force = -1;                                      // 0: 4 lanes per chain; 1: 8 lanes; -1: decided on the device
         if (!h->q4_ok) force = 1;
         else if (d.sampler == KLARA_SAMPLER_HMC && onestep) force = 1;   // (one transition per launch: the 8-lane single-transition kernel measured 5 % faster)
@@ -1326,11 +1329,9 @@ static hipError_t launch_acov_update(klara_handle* h, long long col0, long long 
         hipError_t e = hipMemcpyAsync(h->acov_near, h->acov_tail, (size_t)32 * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
         if (e != hipSuccess) return e;
     }
-    const int W0 = W < 32 ? W : 32;
     if (W <= 8) hipLaunchKernelGGL((k_acov_update<8>), grid, blk, 0, h->stream, h->hist, col0, (int)m, h->acov_n, W, nd, h->acov_S, h->acov_head, h->acov_tail, h->acov_total);
     else if (W <= 16) hipLaunchKernelGGL((k_acov_update<16>), grid, blk, 0, h->stream, h->hist, col0, (int)m, h->acov_n, W, nd, h->acov_S, h->acov_head, h->acov_tail, h->acov_total);
     else hipLaunchKernelGGL((k_acov_update<32>), grid, blk, 0, h->stream, h->hist, col0, (int)m, h->acov_n, W, nd, h->acov_S, h->acov_head, h->acov_tail, h->acov_total);
-    (void)W0;
     if (W > 32) hipLaunchKernelGGL(k_acov_tail_far, grid, blk, 0, h->stream, h->hist, col0, (int)m, W, nd, h->acov_tail, h->acov_near);
     return hipGetLastError();
 }

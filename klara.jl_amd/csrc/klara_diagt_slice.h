@@ -61,11 +61,15 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
     static_assert(NM == 1 || NM == 2, "one or two machines per lane");
     constexpr int CPW = 64 / Q;
     const KParams& p = *pp;
-    __shared__ __attribute__((aligned(16))) double lds_w[UNITW ? 2 : 2 * KLARA_SLICEF_MAXNP * Q];
-    __shared__ __attribute__((aligned(16))) double lds_mu[UNITW ? 2 : 2 * KLARA_SLICEF_MAXNP * Q];
-    __shared__ __attribute__((aligned(16))) double lds_wd[2 * KLARA_SLICEF_MAXNP * Q];
+    // widths (and, for a non-unit diagonal, weights and means) of the 2 NP Q element slots, in dynamic LDS: sized by the job's NP at the launch
+    // (klara_diagt_slice.hip) — static arrays for the largest NP were 12 KB per workgroup at 32 lanes per chain whatever the job's D
+    extern __shared__ __attribute__((aligned(16))) double slicef_lds[];
+    const int nslot = 2 * NP * Q;
+    double* const lds_wd = slicef_lds;
+    double* const lds_w = slicef_lds + nslot;
+    double* const lds_mu = slicef_lds + 2 * nslot;
     const int D = p.D;
-    for (int i = (int)threadIdx.x; i < 2 * KLARA_SLICEF_MAXNP * Q; i += (int)blockDim.x) {
+    for (int i = (int)threadIdx.x; i < nslot; i += (int)blockDim.x) {
         if (!UNITW) {
             lds_w[i] = (p.gw != nullptr && i < D) ? p.gw[i] : 1.0;
             lds_mu[i] = (p.gmu != nullptr && i < D) ? p.gmu[i] : 0.0;
@@ -145,6 +149,7 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
             }
 
             const uint32_t t0lo = (uint32_t)kl.t0, t0hi = (uint32_t)(kl.t0 >> 32);
+            constexpr int LASTK = (KLARA_SLICE_MAX_ATT - 1) >> 1;                              // block index of attempts MAX_ATT, MAX_ATT + 1
             while (true) {
                 bool act[NM], st[NM];
                 kd_u32x4 A[NM], B[NM];
@@ -226,13 +231,14 @@ void k_diagt_slice_free(const KParams* __restrict__ pp, const KLaunch kl, const 
                     const bool bad1 = !in1 && !up1 && !dn1;                                    // :102
                     const double c2 = kd_u52(w2, w3) * (R1 - L1) + L1;
                     const double t2 = slicef_term<UNITW>(c2, wt[m], mu[m]);
-                    const bool in2 = tcur[m] - t2 > lgu[m];
+                    // (the last block, slot (MAX_ATT + 1) / 2, holds attempt MAX_ATT only: its second half would be attempt MAX_ATT + 1)
+                    const bool in2 = tcur[m] - t2 > lgu[m] && k[m] != LASTK;
                     const bool up2 = c2 > x[m], dn2 = c2 < x[m];
                     const bool done = act[m] && (in1 || (!bad1 && in2));
                     const bool bad = act[m] && (bad1 || (!in1 && !in2 && !up2 && !dn2));
                     const bool more = act[m] && !done && !bad;
                     const int knext = st[m] ? 1 : k[m] + 1;
-                    const bool full = more && 2 * (knext + 1) > KLARA_SLICE_MAX_ATT;           // (the next attempt block would pass the slot field)
+                    const bool full = more && knext > LASTK;                                   // (MAX_ATT attempts made — the oracle's and k_diagt<SLICE>'s count: ADVICE r5)
                     const double xn = in1 ? c1 : c2, tn = in1 ? t1 : t2;                       // :108 (the new value's term: what the next update starts from)
                     x[m] = done ? xn : x[m]; tcur[m] = done ? tn : tcur[m];
                     R[m] = up2 ? c2 : R1;

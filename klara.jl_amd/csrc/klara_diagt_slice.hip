@@ -33,9 +33,11 @@ hipError_t KLARA_DIAGT_FN(klara_launch_diagt_slice_free)(const KParams* p, const
     if (NP < 1 || NP > KLARA_SLICEF_MAXNP) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((nwaves + 3) / 4)), blk(256);
     static const int nm = getenv("KLARA_SLICE_MACHINES") ? atoi(getenv("KLARA_SLICE_MACHINES")) : KLARA_SLICEF_DEFAULT_NM;
+    // dynamic LDS: the widths of the job's 2 NP Q element slots, and weights + means for a non-unit diagonal
+    const size_t lds = (size_t)(unitw ? 1 : 3) * 2 * NP * KLARA_DIAGT_Q * sizeof(double);
 #define KLARA_SLICEF_GO(U, S)                                                                                          \
-    (nm == 1 ? klara_go(k_diagt_slice_free<KLARA_DIAGT_Q, U, S, 1>, grid, blk, 0, st, p, kl, ka, NP)                    \
-             : klara_go(k_diagt_slice_free<KLARA_DIAGT_Q, U, S, 2>, grid, blk, 0, st, p, kl, ka, NP))
+    (nm == 1 ? klara_go(k_diagt_slice_free<KLARA_DIAGT_Q, U, S, 1>, grid, blk, lds, st, p, kl, ka, NP)                  \
+             : klara_go(k_diagt_slice_free<KLARA_DIAGT_Q, U, S, 2>, grid, blk, lds, st, p, kl, ka, NP))
     const hipError_t e = unitw ? (sums ? KLARA_SLICEF_GO(true, true) : KLARA_SLICEF_GO(true, false)) : (sums ? KLARA_SLICEF_GO(false, true) : KLARA_SLICEF_GO(false, false));
 #undef KLARA_SLICEF_GO
     if (e != hipSuccess || klara_attr_query != nullptr) return e;

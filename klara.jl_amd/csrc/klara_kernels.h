@@ -969,7 +969,7 @@ KLARA_PRAGMA_UNROLL_E
 // written into the owner lane's register in place; an accepted candidate simply stays there.
 //   read_coord(i, x_i, w_i): value and width of coordinate i of the lane's chain (the same in all lanes of the chain);
 //   place(i, on, cand): the owner lane of coordinate i writes cand into its register when `on`;   probe(): log-target of the lane's chain.
-// `cur` is the chain's log-target (in: current, out: new); `stuck` is sticky (KLARA_ERR_SLICE_STUCK: the chain's state is unspecified from then on).
+// `cur` is the chain's log-target (in: current, out: new); `stuck` is sticky (KLARA_ERR_SLICE_STUCK: the chain stays at the state before the update that failed).
 template <class ReadCoord, class Place, class Probe>
 __device__ __forceinline__ void slice_free_machine(const KParams& p, bool chain_ok, unsigned long long gchain, unsigned long long t,
                                                    double& cur, bool& stuck, ReadCoord read_coord, Place place, Probe probe)
@@ -978,6 +978,7 @@ __device__ __forceinline__ void slice_free_machine(const KParams& p, bool chain_
     bool active = chain_ok && !stuck && p.D > 0;
     double Li = 0.0, Ri = 0.0, logu = 0.0, xi = 0.0, wd = 0.0;
     uint32_t a = 1, guard = 0;
+    bool stuck_here = false;                             // ... in this transition (a chain that was stuck before does not enter the loop)
     while (__any(active)) {
         const int ic = i < p.D ? i : p.D - 1;
         const uint32_t base = (uint32_t)ic << KLARA_SLICE_ATT_BITS;
@@ -1016,12 +1017,17 @@ __device__ __forceinline__ void slice_free_machine(const KParams& p, bool chain_
         a += rej ? 1u : 0u;
         const bool spent = rej && a > (uint32_t)KLARA_SLICE_MAX_ATT;
         stuck = stuck || over || nowhere || spent;
+        stuck_here = stuck_here || over || nowhere || spent;
         cur = acc ? lc : cur;                                                                  // :108 (the candidate is already in its register)
         guard = next_stage ? 0u : guard;
         ph = next_stage ? ph + 1 : (acc ? 0 : ph);
         i += acc ? 1 : 0;
         active = active && !stuck && i < p.D;
     }
+    // A chain that ran out of attempts holds a rejected candidate (or a step-out end point) in the coordinate it was updating while `cur` is still the
+    // log-target of the state before that update: the coordinate goes back to its value, so that (X, LT) read after KLARA_ERR_SLICE_STUCK is a state
+    // the chain was in — the one before the update that failed (outside the pass loop: nothing per probe)
+    if (__any(stuck_here)) place(i < p.D ? i : p.D - 1, stuck_here, xi);
 }
 
 // the group layout: coordinate i lives on lane qo = i / E of its chain's G lanes as register eo = i - qo E

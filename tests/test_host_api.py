@@ -21,6 +21,9 @@ def test_library_exports_every_declared_symbol(klib):
     for name in declared:
         assert hasattr(klib, name), name
     assert klib.klara_abi_version() == L.KLARA_ABI_VERSION == 6
+    # the binding's copies of the header's launch lengths (bench.py and the tests read them from the binding, never a literal)
+    defs = dict(re.findall(r"#define (KLARA_DEFAULT_STEPS_PER_LAUNCH(?:_SLICE)?) (\d+)", header))
+    assert int(defs["KLARA_DEFAULT_STEPS_PER_LAUNCH"]) == L.DEFAULT_STEPS_PER_LAUNCH and int(defs["KLARA_DEFAULT_STEPS_PER_LAUNCH_SLICE"]) == L.DEFAULT_STEPS_PER_LAUNCH_SLICE
 
 
 def test_desc_struct_matches_header_layout():

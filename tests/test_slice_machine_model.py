@@ -175,3 +175,44 @@ def test_machine_stuck_verdicts_match():
         for c in range(n):
             if not stuck[c]:
                 assert np.array_equal(X[c], ser[c][0]) and CUR[c] == ser[c][1]
+
+
+def _block_machine_attempts(fail_upto, max_att):
+    """k_diagt_slice_free's attempt accounting (klara_diagt_slice.h), transcribed: a machine takes the shrink attempts of an update two per iteration from
+    block k (attempts 2k + 1, 2k + 2; k = 0 when the update starts), the second of the LAST block (k = (max_att - 1) / 2: attempt max_att + 1) masked; it is
+    stuck when the block after the last would be needed.  Attempts 1 .. fail_upto fail, the next succeeds.  Returns (attempts made, stuck)."""
+    lastk = (max_att - 1) >> 1
+    k, made = 0, 0
+    while True:
+        a1, a2 = 2 * k + 1, 2 * k + 2
+        made = a1
+        in1 = a1 > fail_upto
+        in2 = (a2 > fail_upto) and k != lastk
+        if not in1 and k != lastk:
+            made = a2
+        done = in1 or in2
+        if done:
+            return made, False
+        knext = k + 1
+        if knext > lastk:
+            return made, True
+        k = knext
+
+
+def _serial_attempts(fail_upto, max_att):
+    """the serial procedure's shrink loop (SliceSampler.jl:91-106 with the build's cap): attempts a = 1, 2, ... while a <= max_att"""
+    a = 1
+    while True:
+        if a > max_att:
+            return a - 1, True
+        if a > fail_upto:
+            return a, False
+        a += 1
+
+
+@pytest.mark.parametrize("max_att", [7, 15, 16383])
+def test_two_attempt_blocks_make_exactly_the_serial_procedures_attempts_at_the_cap(max_att):
+    """the free-running kernel declared a machine stuck after max_att - 1 failed attempts; the oracle and k_diagt<SLICE> make attempt max_att
+    (slot (max_att + 1) / 2 of the 14-bit field, first half).  Same count and same verdict for every number of failing attempts around the cap."""
+    for fail_upto in list(range(0, 6)) + list(range(max_att - 4, max_att + 3)):
+        assert _block_machine_attempts(fail_upto, max_att) == _serial_attempts(fail_upto, max_att), (fail_upto, max_att)
