@@ -166,6 +166,7 @@ def main():
                     help="torch.distributed backend of the launcher's rendezvous: id broadcast, barriers, max-over-ranks of the times "
                          "(gloo: host-side only, the GPUs' one communicator is the library's; nccl = a second RCCL communicator made by torch)")
     ap.add_argument("--torch-backend", default="nccl", help="--collective torch / both: backend of the group the Python mirror all-reduces over")
+    ap.add_argument("--comm-timeout", type=float, default=60.0, help="seconds klara_comm_init may take before this rank gives up on the library's communicator")
     ap.add_argument("--force-comm", action="store_true",
                     help="make the library's communicator even for one rank (a one-rank RCCL communicator: the wiring, testable on a one-GPU box)")
     ap.add_argument("--same-device", action="store_true",
@@ -216,11 +217,21 @@ def main():
     comm, comm_info, collective_error = None, None, None
     if args.same_device and world > 1 and collective != "torch":
         collective, collective_error = "torch", "--same-device: RCCL refuses two ranks on one GPU; gathered over the rendezvous group instead"
+    comm_abandoned = False
     if collective in ("klara", "both") and (world > 1 or args.force_comm):
+        # (one node: RCCL's bootstrap sockets over the loopback interface — the ranks are in one container whose other interfaces / host name need not be
+        # reachable from inside it; the data path is xGMI / shared memory either way)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # klara_comm_init returns when every rank has joined; a rank that cannot reach rank 0's bootstrap address would wait in there for as long as RCCL
+        # retries.  bootstrap_comm runs that one call on a helper thread with a deadline: past it this rank reports the failure, every rank falls back to
+        # the Python mirror together (the MIN all-reduce below), and the line still comes out — without the product's collective in it, and saying so.
         try:
             bc = K.torch_broadcast_bytes() if dist is not None else (lambda b: b)
-            comm = K.bootstrap_comm(L.load(), rank, world, local_rank, bc)
+            comm = K.bootstrap_comm(L.load(), rank, world, local_rank, bc, timeout=args.comm_timeout)
             comm_info = comm.info()
+        except K.CommBootstrapTimeout as exc:
+            comm, comm_abandoned, collective_error = None, True, repr(exc)
         except Exception as exc:
             comm, collective_error = None, repr(exc)
         if dist is not None:        # every rank has a communicator, or none uses it (a rank on its own in a collective would hang)
@@ -228,13 +239,13 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
                 if comm is not None:
-                    comm.close(); comm = None
+                    comm = None         # (not destroyed: a peer of this communicator never joined or failed — ncclCommDestroy could wait for it)
                 collective_error = collective_error or "another rank failed to make the communicator"
                 collective = "torch"
         elif comm is None:
             collective = "torch"
     tgroup, tgroup_error = None, None
-    if dist is not None and collective in ("torch", "both") and not args.same_device and args.torch_backend != args.backend:
+    if dist is not None and args.collective in ("torch", "both") and collective_error is None and not args.same_device and args.torch_backend != args.backend:
         try:                                        # the mirror's own group (nccl = RCCL made by torch) for the A/B
             tgroup = dist.new_group(backend=args.torch_backend)
         except Exception as exc:
@@ -396,6 +407,9 @@ def main():
     if dist is not None:
         dist.barrier()             # rank 0's roofline pass is over: every rank leaves the job together
         dist.destroy_process_group()
+    if comm_abandoned:             # a helper thread is still inside RCCL's bootstrap: leave without waiting for it
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 def diagt_kernel_name(sampler_id, lay_g, lay_e, onestep, unitw, mon, tune=False, da=False):

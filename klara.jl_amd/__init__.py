@@ -11,7 +11,7 @@ from .api import (  # noqa: F401
     MuvChains, SliceSampler, VanillaMCTuner, acceptance, chain_ess, chain_iact, chain_mcvar, erf_rate_score, likelihood_model, logistic, logistic_rate_score,
     mcvar_iid, mean, output, reset, run,
 )
-from .distributed import (KlaraComm, allreduce_moments, allreduce_summaries, bootstrap_comm, gather_engine_moments_klara,  # noqa: F401
+from .distributed import (CommBootstrapTimeout, KlaraComm, allreduce_moments, allreduce_summaries, bootstrap_comm, gather_engine_moments_klara,  # noqa: F401
                           gather_engine_summaries, shard_chains, torch_broadcast_bytes)  # noqa: F401
 from .build import build_library, build_oracle  # noqa: F401
 from . import stats  # noqa: F401

@@ -62,15 +62,46 @@ class KlaraComm:
 COMM_ID_BYTES = 128         # KLARA_COMM_ID_BYTES
 
 
-def bootstrap_comm(lib, rank: int, world: int, device: int, broadcast: Callable[[Optional[bytes]], bytes]) -> KlaraComm:
+class CommBootstrapTimeout(RuntimeError):
+    """klara_comm_init did not return by the deadline; a helper thread is still inside it (the caller should leave with os._exit)"""
+
+
+def bootstrap_comm(lib, rank: int, world: int, device: int, broadcast: Callable[[Optional[bytes]], bytes],
+                   timeout: Optional[float] = None) -> KlaraComm:
     """One communicator over the job's ranks: rank 0 makes the id (klara_comm_unique_id), `broadcast(id on rank 0 / None elsewhere)`
     returns rank 0's bytes on every rank — the caller's transport, used for these 128 bytes and nothing else — and every rank joins
-    with its own index and device (klara_comm_init is collective: it returns when all `world` ranks have called it)."""
-    uid = KlaraComm.unique_id(lib) if rank == 0 else None
+    with its own index and device (klara_comm_init is collective: it returns when all `world` ranks have called it).
+    Every rank ALWAYS takes part in the broadcast, on the calling thread (a rank 0 that could not make an id broadcasts b"": all ranks
+    raise together).  With `timeout`, klara_comm_init — the one call that waits for the other ranks inside RCCL — runs on a helper
+    thread and CommBootstrapTimeout is raised past the deadline."""
+    uid, err = None, None
+    if rank == 0:
+        try:
+            uid = KlaraComm.unique_id(lib)
+        except Exception as exc:            # the other ranks are waiting in the broadcast: tell them
+            uid, err = b"", exc
     uid = broadcast(uid)
+    if err is not None:
+        raise err
     if uid is None or len(uid) != COMM_ID_BYTES:
         raise RuntimeError(f"rank {rank}: the broadcast did not deliver rank 0's communicator id")
-    return KlaraComm(lib, world, rank, uid, device)
+    if timeout is None:
+        return KlaraComm(lib, world, rank, uid, device)
+    import threading
+    box = {}
+
+    def join():
+        try:
+            box["comm"] = KlaraComm(lib, world, rank, uid, device)
+        except Exception as exc:
+            box["error"] = exc
+    th = threading.Thread(target=join, daemon=True)
+    th.start(); th.join(timeout=timeout)
+    if th.is_alive():
+        raise CommBootstrapTimeout(f"rank {rank}: klara_comm_init did not return within {timeout:.0f} s (RCCL bootstrap)")
+    if "error" in box:
+        raise box["error"]
+    return box["comm"]
 
 
 def torch_broadcast_bytes(group=None) -> Callable[[Optional[bytes]], bytes]:

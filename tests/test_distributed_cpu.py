@@ -182,3 +182,23 @@ def test_comm_bootstrap_refuses_a_broadcast_that_lost_the_id():
     one = K.bootstrap_comm(_StubCommLib(0), 0, 1, 0, lambda b: b)      # one rank: its own id comes straight back
     assert one.info() == (1, 0, 0)
     one.close()
+    # a rank 0 that cannot make an id still broadcasts (the other ranks are waiting for it), then every rank raises
+    class NoId(_StubCommLib):
+        def klara_comm_unique_id(self, buf):
+            return 5                                            # KLARA_ERR_UNSUPPORTED: no RCCL on the box
+    sent = []
+    with pytest.raises(Exception, match="klara_comm_unique_id"):
+        K.bootstrap_comm(NoId(0), 0, 2, 0, lambda b: sent.append(b) or b)
+    assert sent == [b""]
+    # klara_comm_init that never returns (a peer never joins): the deadline, on a helper thread
+    import time
+    class Hangs(_StubCommLib):
+        def klara_comm_init(self, out, nranks, rank, uid, device):
+            time.sleep(30)
+            return 0
+    t0 = time.time()
+    with pytest.raises(K.CommBootstrapTimeout):
+        K.bootstrap_comm(Hangs(0), 0, 2, 0, lambda b: b, timeout=0.5)
+    assert time.time() - t0 < 5
+    ok = K.bootstrap_comm(_StubCommLib(0), 0, 1, 3, lambda b: b, timeout=5.0)      # the same path when the call does return
+    assert ok.info() == (1, 0, 3)
