@@ -67,6 +67,7 @@ struct klara_handle {
     KParams* d_params = nullptr;    // device copy of the handle's static kernel parameters
     double lpconst = 0.0;
     bool dense_mu = false;          // dense target with a mean: Pfrag carries mu behind the matrix fragments
+    int logit_nblocks = 0;          // layout kind 5 (klara_logit_mfma.h): row blocks of the fragment stream in Pfrag; ly holds the zero-padded responses
     // run state
     bool have_state = false;
     unsigned long long epoch = 0;   // klara_reset calls so far: the Philox key of the job is seed + epoch * KLARA_EPOCH_KEY_STRIDE
@@ -200,8 +201,18 @@ static bool dense_streamed(const klara_desc& d)
            (d.sampler != KLARA_SAMPLER_SLICE || getenv("KLARA_DENSE_SLICE_NO_STREAM") == nullptr);
 }
 
+// the logistic regression beyond 16 parameters on the matrix cores (klara_logit_mfma.h, layout kind 5): X p and X' (y - 1/(1+exp(-Xp))) of 16 chains per
+// wavefront as two MFMA passes over streamed fragments of X; MH / MALA / HMC with every tuner and the monitors of the dense layouts.  The slice sampler and
+// the likelihood / prior history keep the closure form (klara_create).
+static bool logit_mfma_eligible(const klara_desc& d)
+{
+    return d.target == KLARA_TARGET_LOGISTIC && d.ndims > 16 && d.ndims <= 128 && d.logit_ndata >= 1 && d.sampler != KLARA_SAMPLER_SLICE &&
+           !(d.monitor & KLARA_MON_HIST_LLLP) && getenv("KLARA_LOGIT_NO_MFMA") == nullptr;
+}
+
 static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E, int custom_lanes = 0, int* custom_wpb = nullptr)
 {
+    if (logit_mfma_eligible(d)) { *kind = 5; *G = 4; *E = 8 * ((d.ndims + 31) / 32); return KLARA_OK; }
     if (hiert_eligible(d)) { *kind = 4; *G = 8; *E = 8; return KLARA_OK; }
     const int D = d.ndims;
     if (d.target == KLARA_TARGET_GAUSS_DENSE) {
@@ -507,7 +518,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
     klara_status st = validate(desc);
     if (st != KLARA_OK) return st;
     // the logistic regression beyond 16 parameters — or beyond 8 when its rows, padded to 16 columns, do not fit the LDS — runs as a closure
-    if (desc->target == KLARA_TARGET_LOGISTIC &&
+    if (desc->target == KLARA_TARGET_LOGISTIC && !logit_mfma_eligible(*desc) &&
         (desc->ndims > 16 || (desc->ndims > 8 && (size_t)desc->logit_ndata * 17 > KLARA_LOGIT_MAX_LDS_DOUBLES))) {
         if (desc->ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
         if (desc->monitor & KLARA_MON_HIST_LLLP) return KLARA_ERR_UNSUPPORTED;
@@ -556,7 +567,7 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
     // the logistic kernels keep the data rows (padded to E columns, + the responses) in LDS next to the 8 KB of math tables: up to
     // 144 KB of the CU's 160 (swiss: 200 x 5 doubles = 8 KB); beyond the 56 KB a launch gets by default the launchers raise the
     // kernel's limit, and fewer workgroups share a CU
-    if (desc->target == KLARA_TARGET_LOGISTIC && (size_t)desc->logit_ndata * (size_t)(E + 1) > KLARA_LOGIT_MAX_LDS_DOUBLES)
+    if (desc->target == KLARA_TARGET_LOGISTIC && kind != 5 && (size_t)desc->logit_ndata * (size_t)(E + 1) > KLARA_LOGIT_MAX_LDS_DOUBLES)
         return KLARA_ERR_UNSUPPORTED;
 
     int ndev = 0;
@@ -569,7 +580,7 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
     h->d = *desc; h->kind = kind; h->G = G; h->E = E;
     h->custom_rows = (desc->target == KLARA_TARGET_CUSTOM && custom_lik_prior(desc->custom_src)) ? 3 : 2;
     h->custom_wpb = custom_wpb;
-    if (desc->target == KLARA_TARGET_LOGISTIC) {
+    if (desc->target == KLARA_TARGET_LOGISTIC && kind != 5) {
         // D <= 8 parameters cannot fill a wavefront's lanes usefully, the ndata-row likelihood can: RS lanes share a chain
         // and each takes every RS-th row (fixed by ndata alone, so results do not depend on how chains are sharded)
         // 4 lanes from 64 rows on (round 4; rounds 1-3: 8 from 128 rows).  With the rows of an evaluation going through their stages in batches
@@ -686,6 +697,33 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
         const int nmodes = kernel_modes(h->d, modes);           // (h->d: the monitor word with what the library turned on itself)
         CK(klara_jit_create(desc->custom_src, desc->sampler, desc->ndims, E, G, modes, nmodes, true, &h->jit));
         }
+    } else if (desc->target == KLARA_TARGET_LOGISTIC && kind == 5) {
+        // the A fragments of both MFMA passes in the order of consumption (klara_logit_mfma.h logitm_eval), zero beyond the n rows / D columns:
+        // block b = RBT tiles of 16 rows; pass 1, step kk RBT + tt: lane l holds X[16 (b RBT + tt) + (l & 15)][4 kk + (l >> 4)];
+        // pass 2, step (4 tt + j) MT + t: lane l holds X[16 (b RBT + tt) + 4 j + (l >> 4)][16 t + (l & 15)].  The responses are zero-padded to the blocks' rows.
+        const int NE = E, MT = NE / 4, RBT = klara_logit_mfma_rbt(), S1 = RBT * NE;
+        const size_t n = (size_t)desc->logit_ndata;
+        const int NT = (int)((n + 15) / 16), nb = (NT + RBT - 1) / RBT;
+        std::vector<double> frag((size_t)nb * 2 * S1 * 64, 0.0), ypad((size_t)nb * RBT * 16, 0.0);
+        for (int b = 0; b < nb; ++b) {
+            double* const f1 = frag.data() + (size_t)b * 2 * S1 * 64;
+            double* const f2 = f1 + (size_t)S1 * 64;
+            for (int sidx = 0; sidx < S1; ++sidx) {
+                const int kk = sidx / RBT, tt = sidx % RBT;
+                const int tt2 = sidx / (4 * MT), j = (sidx / MT) & 3, t = sidx % MT;
+                for (int l = 0; l < 64; ++l) {
+                    const size_t r1 = 16 * (size_t)(b * RBT + tt) + (l & 15), c1 = 4 * (size_t)kk + (l >> 4);
+                    if (r1 < n && c1 < D) f1[(size_t)sidx * 64 + l] = desc->logit_X[r1 * D + c1];
+                    const size_t r2 = 16 * (size_t)(b * RBT + tt2) + 4 * (size_t)j + (l >> 4), c2 = 16 * (size_t)t + (l & 15);
+                    if (r2 < n && c2 < D) f2[(size_t)sidx * 64 + l] = desc->logit_X[r2 * D + c2];
+                }
+            }
+        }
+        for (size_t r = 0; r < n; ++r) ypad[r] = desc->logit_y[r];
+        h->logit_nblocks = nb;
+        CK(upload(&h->Pfrag, frag.data(), frag.size()));
+        CK(upload(&h->ly, ypad.data(), ypad.size()));
+        h->lpconst = (double)desc->ndims * kd_log(2.0 * 3.141592653589793 * desc->logit_lambda);
     } else if (desc->target == KLARA_TARGET_LOGISTIC) {
         CK(upload(&h->lX, desc->logit_X, (size_t)desc->logit_ndata * D));
         CK(upload(&h->ly, desc->logit_y, (size_t)desc->logit_ndata));
@@ -777,9 +815,9 @@ static KParams make_params(klara_handle* h)
 // one wave per chain group for the init kernels and the MFMA kernels
 static dim3 grid_for(const klara_handle* h)
 {
-    const long long cpw = h->kind == 1 ? 16 : 64 / (h->G * h->RS);
+    const long long cpw = (h->kind == 1 || h->kind == 5) ? 16 : 64 / (h->G * h->RS);
     const long long waves = (h->d.nchains + cpw - 1) / cpw;
-    const long long wpb = h->kind == 1 ? (h->E > 32 ? 4 : 8) : h->custom_wpb;      // (streamed dense layouts: one wavefront per SIMD, workgroups of 4)
+    const long long wpb = h->kind == 5 ? 4 : h->kind == 1 ? (h->E > 32 ? 4 : 8) : h->custom_wpb;      // (streamed layouts: one wavefront per SIMD, workgroups of 4)
     return dim3((unsigned)((waves + wpb - 1) / wpb));
 }
 
@@ -798,7 +836,7 @@ static dim3 grid_for_transitions(const klara_handle* h)
 
 static size_t lds_for(const klara_handle* h)
 {
-    if (h->kind != 1 && h->d.target == KLARA_TARGET_LOGISTIC)        // data rows + responses + the kernel's copy of kd_log12's table (LogisticTarget::lds_bytes)
+    if (h->kind != 1 && h->kind != 5 && h->d.target == KLARA_TARGET_LOGISTIC)        // data rows + responses + the kernel's copy of kd_log12's table (LogisticTarget::lds_bytes)
         return sizeof(double) * (((size_t)h->d.logit_ndata * (size_t)(h->E + 1) + 1) / 2 * 2 + 256);
     if (h->kind == 0 && h->d.target == KLARA_TARGET_CUSTOM && h->G > 1)              // staged closure: the rows of a workgroup's chains
         return custom_stage_bytes(h->d.ndims, h->G, h->custom_rows, h->custom_wpb);
@@ -911,6 +949,7 @@ static klara_status init_common(klara_handle* h)
     KParams p = make_params(h);
     hipError_t e;
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, h->dense_mu, needgrad, grid_for(h), st);
+    else if (h->kind == 5) e = klara_launch_logit_mfma_init(p, h->E, h->Pfrag, h->ly, h->logit_nblocks, needgrad, grid_for(h), st);
     else if (h->kind == 3 && h->jit_pair) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), 0, st);
     else if (h->kind == 3)
         e = h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
@@ -1017,6 +1056,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
     int mode = (plain ? 1 : 0) | ((plain && d.monitor == 0) ? 2 : 0);         // 3: no monitors either
     if (mode == 3 && kl.nsteps == 1) mode = 7;                                 // one iterate! per launch
     if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, plain, h->E, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
+    if (h->kind == 5) return klara_launch_logit_mfma(p, kl, d.sampler, d.tuner == KLARA_TUNER_DUAL_AVERAGING, h->E, h->Pfrag, h->ly, h->logit_nblocks, grid_for(h), h->stream);
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on

@@ -34,6 +34,13 @@ hipError_t klara_launch_mfma_probe(const double* A, const double* B, const doubl
                                    hipStream_t st);
 hipError_t klara_launch_mfma4_probe(const double* A, const double* B, const double* C, double* D, hipStream_t st);
 
+// logistic regression beyond 16 parameters on the matrix cores (layout kind 5, klara_logit_mfma.h); NE in {8, 16, 24, 32}; F: the fragment stream of both
+// passes in the order of consumption, ypad: the responses zero-padded to the blocks' rows (klara_api.hip logit_mfma_stream)
+hipError_t klara_launch_logit_mfma(const KParams* p, const KLaunch& kl, int sampler, bool da, int NE, const double* F, const double* ypad, int nblocks,
+                                   dim3 grid, hipStream_t st);
+hipError_t klara_launch_logit_mfma_init(const KParams& p, int NE, const double* F, const double* ypad, int nblocks, int needgrad, dim3 grid, hipStream_t st);
+int klara_logit_mfma_rbt();      // row tiles per block the kernels were built for
+
 // pair-transposed diagonal-Gaussian kernels (layout kind 3, klara_diagt.h).  The translation units klara_diagt_*.hip are
 // compiled three times: Q = 8 lanes per chain (17 <= D <= 128, NP = ceil(D/16) in 2..8), Q = 16 (129 <= D <= 256) and Q = 32
 // (257 <= D <= 512), the latter two with NP in 5..8; the launchers of the wider variants carry a _q16 / _q32 suffix.

@@ -82,7 +82,11 @@ typedef struct ko_layout {
                      3: pair-transposed (klara_diagt.h): element pair i/2 on lane (i/2) % G, lane partials in
                         ascending element order, xor tree over the G lanes
                      4: hierarchical target, few lanes per chain (klara_hiert.h): unit r on lane r / (E/2), the
-                        hyper block on lane 0 (after its units); per-unit sums skip the other parameter's slot   */
+                        hyper block on lane 0 (after its units); per-unit sums skip the other parameter's slot
+                     5: logistic regression on the matrix cores (klara_logit_mfma.h): elements as in kind 1 (element i on
+                        lane-quarter i % 4), data row r on lane-quarter r % 4 — row sums are lane partials over ascending
+                        rows, then the tree (q0 + q1) + (q2 + q3); X p and X' (y - 1/(1+exp(-Xp))) are the fma chains of
+                        v_mfma_f64_16x16x4 (k ascending from zero), i.e. the sequential chains of the closure form        */
     int32_t G;
     int32_t E;
 } ko_layout;
@@ -90,12 +94,12 @@ typedef struct ko_layout {
 static double ko_reduce(const ko_layout* L, const double* terms, int D)
 {
     double part[64], nw[64];
-    const int G = (L->kind == 1) ? 4 : (L->kind == 2 ? 1 : L->G);
+    const int G = (L->kind == 1 || L->kind == 5) ? 4 : (L->kind == 2 ? 1 : L->G);
     for (int l = 0; l < G; ++l) part[l] = 0.0;
     for (int i = 0; i < D; ++i) {
         /* kind 3 (pair-transposed, klara_diagt.h): element pair P = i>>1 belongs to lane P % G */
         /* kind 4 (klara_hiert.h, D = 2R + 5): unit i/2 on lane (i/2) / (E/2); the five hyper elements on lane 0 */
-        const int lane = (L->kind == 1) ? (i & 3) : (L->kind == 2 ? 0 : (L->kind == 3 ? ((i >> 1) % L->G) :
+        const int lane = (L->kind == 1 || L->kind == 5) ? (i & 3) : (L->kind == 2 ? 0 : (L->kind == 3 ? ((i >> 1) % L->G) :
                          (L->kind == 4 ? (i < D - 5 ? (i >> 1) / (L->E / 2) : 0) : i / L->E)));
         part[lane] = part[lane] + terms[i];
     }
@@ -196,6 +200,28 @@ static void ko_logit_eval(const ko_target_ctx* c, const double* p, double* lt, d
     /* row split: row r belongs to lane r % RS; lane partials are then combined pairwise (xor tree) */
     const int RS = (c->L->kind == 2) ? c->L->G : 1;
     double pdot[64], plog[64], pg[64][16];
+    if (c->L->kind == 5) {                       /* on the matrix cores (klara_logit_mfma.h): the chains of the closure form, row sums over 4 lane-quarters */
+        double pd[4] = { 0.0, 0.0, 0.0, 0.0 }, pl[4] = { 0.0, 0.0, 0.0, 0.0 }, g1[KO_MAXD];
+        for (int k = 0; k < D; ++k) g1[k] = 0.0;
+        for (int r = 0; r < n; ++r) {
+            const double* row = d->logit_X + (size_t)r * D;
+            double xp = 0.0;
+            for (int k = 0; k < D; ++k) xp = kd_fma(row[k], p[k], xp);          /* pass 1: B = the lanes' parameters, k ascending */
+            double sp, lg;
+            ko_row_softplus_logistic(xp, &sp, &lg);
+            if (lt) { pd[r & 3] = pd[r & 3] + xp * d->logit_y[r]; pl[r & 3] = pl[r & 3] + sp; }
+            if (g) { const double res = d->logit_y[r] - lg; for (int k = 0; k < D; ++k) g1[k] = kd_fma(row[k], res, g1[k]); }   /* pass 2: k = data rows ascending */
+        }
+        if (lt) {
+            const double dotxy = (pd[0] + pd[1]) + (pd[2] + pd[3]), slog = (pl[0] + pl[1]) + (pl[2] + pl[3]);
+            double pp[KO_MAXD];
+            for (int k = 0; k < D; ++k) pp[k] = p[k] * p[k];
+            const double dotpp = ko_reduce(c->L, pp, D);
+            *lt = (dotxy - slog) + -0.5 * (dotpp / d->logit_lambda + c->logit_lpconst);
+        }
+        if (g) for (int k = 0; k < D; ++k) g[k] = g1[k] - p[k] / d->logit_lambda;
+        return;
+    }
     if (RS == 1 && D > 16) {                     /* beyond 16 parameters: all rows on one lane, no tree (the closure form of the library) */
         double dotxy1 = 0.0, slog1 = 0.0, g1[KO_MAXD];
         for (int k = 0; k < D; ++k) g1[k] = 0.0;

@@ -223,6 +223,19 @@ def synthetic_logit(n, d, seed=5):
     return np.ascontiguousarray(X), y
 
 
+# (D, data rows, engine settings) of the matrix-core logistic cases
+LOGIT_MFMA_CASES = {
+    "mala_logitm_d20": (20, 200, dict(sampler=L.SAMPLER_MALA, driftstep=0.35)),
+    "hmc_logitm_d33_n70": (33, 70, dict(sampler=L.SAMPLER_HMC, leapstep=0.9, nleaps=4, nchains=35)),                       # odd D: NE = 16; 70 rows: 5 tiles, the last with 6 rows
+    "mh_logitm_d64_n300": (64, 300, dict(sampler=L.SAMPLER_MH, mh_sigma=0.03, thinning=2)),
+    "mala_logitm_d128_n1100_tuned": (128, 1100, dict(sampler=L.SAMPLER_MALA, driftstep=0.3, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.574, period=5, nchains=19, nsteps=22)),
+    "hmc_logitm_d40_dualavg": (40, 131, dict(sampler=L.SAMPLER_HMC, leapstep=0.05, nleaps=4, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=15)),
+    "hmc_logitm_d17_pooled": (17, 16, dict(sampler=L.SAMPLER_HMC, leapstep=1.2, nleaps=3, tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.8, period=5)),   # one tile of rows exactly
+    "mala_logitm_d96_n17_verbose": (96, 17, dict(sampler=L.SAMPLER_MALA, driftstep=1.5, verbose=True, period=10)),         # NE = 24; a second tile with one row
+    "mh_logitm_d100_n33": (100, 33, dict(sampler=L.SAMPLER_MH, mh_sigma=0.2, nchains=70)),
+}
+
+
 def make_case(name):
     """name -> dict(engine kwargs..., target=<family object>, x0=None|array)."""
     c = {}
@@ -387,7 +400,7 @@ def make_case(name):
         # synthetic logistic data: E = 2 / 4 / 8 (D = 3, 6, 7: rows padded to E columns in LDS), with and without row split; 1,500 x 9
         # doubles = 108 KB of rows: beyond the 56 KB a launch gets by default
         d, nd = {"mala_logit_d2": (2, 90), "hmc_logit_d7": (7, 131), "mh_logit_d8_small": (8, 30), "mala_logit_d6_bigdata": (6, 1500),
-                 "slice_logit_d3": (3, 75), "mala_logit_d12_wide": (12, 150), "hmc_logit_d20_wide": (20, 400),   # D > 16: closure form
+                 "slice_logit_d3": (3, 75), "mala_logit_d12_wide": (12, 150), "hmc_logit_d20_wide": (20, 400),   # D > 16: the closure form in rounds 1-5, the matrix cores since round 6
                  # round 4: 9 .. 16 parameters on the row-split kernels (E = 16: two Philox blocks per lane, accept slots 5 .. 8), unsplit below 64
                  # rows, and back on the closure form when the rows do not fit the LDS
                  "hmc_logit_d16_rows": (16, 150), "mh_logit_d9_rows": (9, 131), "slice_logit_d13_rows": (13, 70), "mala_logit_d11_unsplit": (11, 40),
@@ -407,6 +420,18 @@ def make_case(name):
               "mala_logit_d11_unsplit": dict(sampler=L.SAMPLER_MALA, driftstep=0.02),
               "mala_logit_d12_manyrows": dict(sampler=L.SAMPLER_MALA, driftstep=0.002)}[name]
         c = dict(target=K.LogisticTarget(X, y, 10.0), nchains=45, nsteps=25, burnin=5, x0=0.1 * rng.standard_normal((45, d)), **kw)
+    elif name in LOGIT_MFMA_CASES:
+        # round 6: the logistic regression beyond 16 parameters on the matrix cores (klara_logit_mfma.h, layout kind 5): D = 17 .. 128 (NE = 8, 16, 24, 32
+        # elements per lane), data rows that do not fill their last tile of 16 / their last block of tiles, every sampler it serves, tuners, monitors
+        d, nd, kw = LOGIT_MFMA_CASES[name]
+        rng = np.random.default_rng(1000 + d + nd)
+        X = rng.standard_normal((nd, d)) / np.sqrt(d); beta = rng.standard_normal(d)
+        y = (rng.random(nd) < 1.0 / (1.0 + np.exp(-X @ beta))).astype(np.float64)
+        kw = dict(kw)
+        if kw.get("mh_sigma") is not None:
+            kw["mh_sigma"] = np.full(d, kw["mh_sigma"])
+        nch = kw.pop("nchains", 45)
+        c = dict(target=K.LogisticTarget(X, y, 10.0), nchains=nch, nsteps=kw.pop("nsteps", 25), burnin=kw.pop("burnin", 5), x0=0.1 * rng.standard_normal((nch, d)), **kw)
     elif name == "hmc_swiss":
         X, y = swiss_data()
         c = dict(sampler=L.SAMPLER_HMC, target=K.LogisticTarget(X, y, 100.0), nchains=65, nsteps=12, burnin=0,
@@ -622,7 +647,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "mala_dense_d200_stream_tuned", "mh_dense_d256_stream_mean", "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide",
              "slice_dense_d192_stream", "slice_dense_d130_stream_mean", "slice_dense_d256_stream", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
              "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide", "hmc_logit_d20_wide", "slice_d20_stepout", "mh_rats", "mala_rats_tuned",
-             "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"] + [
+             "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"] + list(LOGIT_MFMA_CASES) + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
              "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
              "custom_quartic_mala_d64", "custom_quartic_mala_d100", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh",
