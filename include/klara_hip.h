@@ -87,7 +87,10 @@ typedef enum klara_target {
      * at D = 256); beyond 256 the same closures through the run-time compiled path, one chain per lane. */
     KLARA_TARGET_GAUSS_DENSE = 1,
     /* Bayesian logistic regression of doc/examples/swiss/MALA/analytical.jl:11-18:
-     * lt = dot(Xp, y) - sum(log(1+exp(Xp))) - 0.5 (p.p/lambda + D log(2 pi lambda)). */
+     * lt = dot(Xp, y) - sum(log(1+exp(Xp))) - 0.5 (p.p/lambda + D log(2 pi lambda)).  Up to 16 parameters: the data rows in LDS, dealt to 4 lanes
+     * per chain; 17 .. 128 parameters (and 9 .. 16 with more rows than the LDS holds), MH / MALA / HMC: X p and X' (y - 1/(1+exp(-Xp))) of 16 chains
+     * per wavefront on the FP64 matrix cores, X streamed from memory — any number of rows (round 6; layout kind 5); the slice sampler and
+     * everything beyond 128 parameters: the same closures through the run-time compiled path (to 256 parameters). */
     KLARA_TARGET_LOGISTIC = 2,
     /* Hierarchical normal growth-curve model for data/rats/{weight,age}.csv (BASELINE cfg 5).  The reference
      * ships the data but no model (doc/examples/rats/Gibbs.jl:1-7 is a stub), so the target is builder-defined:
@@ -384,7 +387,9 @@ klara_status klara_device_ptrs(klara_handle* h, void** x, void** logtarget, void
  * (element i on lane-quarter i%4); kind 2 = logistic row split (every lane holds all E elements, the data
  * rows are dealt round-robin to `lanes_per_chain` lanes); kind 3 = pair-transposed layout of the diagonal Gaussian
  * (element pair P = i/2 on lane P % lanes_per_chain, elements_per_lane/2 pairs per lane; 8, 16 or 32 lanes per chain for D <= 128 / 256 / 512); kind 4 = hierarchical target
- * with few lanes per chain (unit r on lane r / (elements_per_lane/2), hyper block replicated).  See DESIGN.md section 3. */
+ * with few lanes per chain (unit r on lane r / (elements_per_lane/2), hyper block replicated); kind 5 = logistic regression on the matrix cores
+ * (elements as in kind 1; data row r on lane-quarter r % 4: row sums are lane partials over ascending rows, then (q0 + q1) + (q2 + q3); X p and
+ * X' (y - 1/(1+exp(-Xp))) are fma chains over ascending columns / rows).  See DESIGN.md section 3. */
 klara_status klara_get_layout(klara_handle* h, int32_t* kind, int32_t* lanes_per_chain,
                               int32_t* elems_per_lane);
 

@@ -206,7 +206,9 @@ static bool dense_streamed(const klara_desc& d)
 // the likelihood / prior history keep the closure form (klara_create).
 static bool logit_mfma_eligible(const klara_desc& d)
 {
-    return d.target == KLARA_TARGET_LOGISTIC && d.ndims > 16 && d.ndims <= 128 && d.logit_ndata >= 1 && d.sampler != KLARA_SAMPLER_SLICE &&
+    // (also 9 .. 16 parameters whose rows, padded to 16 columns, do not fit the LDS of the row-split kernels: the stream has no such limit)
+    const bool beyond_rowsplit = d.ndims > 16 || (d.ndims > 8 && (size_t)d.logit_ndata * 17 > KLARA_LOGIT_MAX_LDS_DOUBLES);
+    return d.target == KLARA_TARGET_LOGISTIC && beyond_rowsplit && d.ndims <= 128 && d.logit_ndata >= 1 && d.sampler != KLARA_SAMPLER_SLICE &&
            !(d.monitor & KLARA_MON_HIST_LLLP) && getenv("KLARA_LOGIT_NO_MFMA") == nullptr;
 }
 

@@ -114,17 +114,21 @@ __device__ __forceinline__ void logitm_eval(const double* __restrict__ F, const 
         }
         // -- the lane's rows of the block, ascending: tile tt, register j = row 16 (b RBT + tt) + 4 j + q
         const int row0 = b * (RBT * 16) + q;
-        {
-            double zv[RBT * 4], sp[RBT * 4], lg[RBT * 4];
+        // (R row values per staged batch: 8 where the registers are there, 4 at NE = 24 / 32 — a batch keeps ~20 registers per value alive)
+        constexpr int R = NE <= 16 ? RBT * 4 : 4;
 #pragma unroll
-            for (int i = 0; i < RBT * 4; ++i) zv[i] = z[i >> 2][i & 3];
-            logitm_rows<RBT * 4>(sL12, zv, sp, lg);
+        for (int i0 = 0; i0 < RBT * 4; i0 += R) {
+            double zv[R], sp[R], lg[R];
 #pragma unroll
-            for (int i = 0; i < RBT * 4; ++i) {                        // the accumulations last, row by row in ascending order
-                const bool valid = row0 + 16 * (i >> 2) + 4 * (i & 3) < ndata;
-                sxy = sxy + zv[i] * yv[i];                             // dot(Xp, y)   (a padding row: +0 * 0)
+            for (int i = 0; i < R; ++i) zv[i] = z[(i0 + i) >> 2][(i0 + i) & 3];
+            logitm_rows<R>(sL12, zv, sp, lg);
+#pragma unroll
+            for (int i = 0; i < R; ++i) {                              // the accumulations last, row by row in ascending order
+                const int ii = i0 + i;
+                const bool valid = row0 + 16 * (ii >> 2) + 4 * (ii & 3) < ndata;
+                sxy = sxy + zv[i] * yv[ii];                            // dot(Xp, y)   (a padding row: +0 * 0)
                 slg = slg + (valid ? sp[i] : 0.0);                     // sum(log(1 + exp(Xp)))
-                if (WANT_G) z[i >> 2][i & 3] = valid ? yv[i] - lg[i] : 0.0;      // y - 1/(1 + exp(-Xp)): pass 2's B operand, in place
+                if (WANT_G) z[ii >> 2][ii & 3] = valid ? yv[ii] - lg[i] : 0.0;   // y - 1/(1 + exp(-Xp)): pass 2's B operand, in place
             }
         }
         // -- pass 2: G += X' R

@@ -328,14 +328,30 @@ def test_logistic_target_matches_numpy():
 
 
 def test_logistic_target_with_20_parameters_matches_numpy():
-    # beyond 8 parameters the library evaluates the same closures from run-time compiled source (all rows on one lane)
+    # beyond 16 parameters: on the matrix cores since round 6 (layout kind 5: row sums over 4 lane-quarters, klara_logit_mfma.h) for MH / MALA / HMC; the
+    # slice sampler keeps the run-time compiled closure form (all rows on one lane).  The same closures either way, and the same fma chains for X p and X' r.
     X, y = cases.synthetic_logit(300, 20, seed=3)
     p = 0.3 * np.random.default_rng(1).standard_normal(20)
-    job = O.OracleJob(sampler=L.SAMPLER_MALA, target_kind=L.TARGET_LOGISTIC, nchains=1, ndims=20, nsteps=1, logit_X=X, logit_y=y, logit_lambda=10.0)
-    assert (job.layout.kind, job.layout.G, job.layout.E) == (0, 1, 32)
+    got = {}
+    for sampler, lay in ((L.SAMPLER_MALA, (5, 4, 8)), (L.SAMPLER_SLICE, (0, 1, 32))):
+        job = O.OracleJob(sampler=sampler, target_kind=L.TARGET_LOGISTIC, nchains=1, ndims=20, nsteps=1, logit_X=X, logit_y=y, logit_lambda=10.0,
+                          slice_widths=np.ones(20) if sampler == L.SAMPLER_SLICE else None)
+        assert (job.layout.kind, job.layout.G, job.layout.E) == lay
+        lt, g = job.eval_target(p)
+        xp = X @ p
+        assert lt == pytest.approx(xp @ y - np.sum(np.log(1 + np.exp(xp))) - 0.5 * (p @ p / 10.0 + 20 * np.log(2 * np.pi * 10.0)), rel=1e-12)
+        assert np.allclose(g, X.T @ (y - 1 / (1 + np.exp(-xp))) - p / 10.0, rtol=1e-11, atol=1e-12)
+        got[sampler] = (lt, g)
+    assert np.array_equal(got[L.SAMPLER_MALA][1], got[L.SAMPLER_SLICE][1])         # the gradient chains are the same in both layouts; the log-target's sums are not
+    assert got[L.SAMPLER_MALA][0] == pytest.approx(got[L.SAMPLER_SLICE][0], rel=1e-13)
+    # 128 parameters, 33 rows (a third tile with one row): the layout's largest NE
+    X, y = cases.synthetic_logit(33, 128, seed=4)
+    p = 0.1 * np.random.default_rng(2).standard_normal(128)
+    job = O.OracleJob(sampler=L.SAMPLER_HMC, target_kind=L.TARGET_LOGISTIC, nchains=1, ndims=128, nsteps=1, logit_X=X, logit_y=y, logit_lambda=10.0)
+    assert (job.layout.kind, job.layout.G, job.layout.E) == (5, 4, 32)
     lt, g = job.eval_target(p)
     xp = X @ p
-    assert lt == pytest.approx(xp @ y - np.sum(np.log(1 + np.exp(xp))) - 0.5 * (p @ p / 10.0 + 20 * np.log(2 * np.pi * 10.0)), rel=1e-12)
+    assert lt == pytest.approx(xp @ y - np.sum(np.log(1 + np.exp(xp))) - 0.5 * (p @ p / 10.0 + 128 * np.log(2 * np.pi * 10.0)), rel=1e-12)
     assert np.allclose(g, X.T @ (y - 1 / (1 + np.exp(-xp))) - p / 10.0, rtol=1e-11, atol=1e-12)
 
 
