@@ -510,6 +510,7 @@ def test_parity_with_golden_vectors(name):
     ("mala_d100", [1, 7, 42], 1), ("mala_d100", [50], 5), ("hmc_d100", [13, 17], 4),
     ("hmc_dense_d100", [5, 7], 3), ("mala_d3_tuned", [100, 60, 100], 7), ("hmc_d10_tuned_pooled", [33, 87], 16),
     ("slice_d5", [11, 19], 2), ("mala_swiss", [40], 1), ("hmc_dense_d192_stream_mean", [3, 11], 2), ("hmc_dense_d256_stream_tuned", [17, 23], 6),
+    ("mala_logitm_d20", [7, 18], 3), ("hmc_logitm_d40_dualavg", [11, 14], 4), ("mala_logitm_d128_n1100_tuned", [5, 17], 1),
 ])
 def test_launch_splitting_does_not_change_results(name, splits, spl):
     """K transitions per launch / multiple klara_run calls are invisible in the results."""
@@ -520,7 +521,7 @@ def test_launch_splitting_does_not_change_results(name, splits, spl):
 
 
 @pytest.mark.parametrize("name,monitor", [("mala_d100", L.MON_ACCEPT | L.MON_SUMMARIES), ("dt_mala_d100_small_step", L.MON_ACCEPT),
-                                          ("dt_hmc_d100", L.MON_ACCEPT)])
+                                          ("dt_hmc_d100", L.MON_ACCEPT), ("mala_logitm_d20", L.MON_ACCEPT | L.MON_SUMMARIES)])
 def test_sharding_invariance(name, monitor):
     """Rank r's shard (chain_offset) reproduces the same chains as the single-GPU job — group layout and
     pair-transposed layout (the shard boundary does not fall on a wavefront-group boundary there)."""
@@ -689,7 +690,7 @@ def test_history_layout_matches_nstate():
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["hmc_dense_d37", "mala_dense_d100", "hmc_d100", "hmc_rats", "hmc_dense_d192_stream_mean"])
+@pytest.mark.parametrize("name", ["hmc_dense_d37", "mala_dense_d100", "hmc_d100", "hmc_rats", "hmc_dense_d192_stream_mean", "hmc_logitm_d33_n70", "mala_logitm_d20"])
 def test_history_of_all_monitored_fields(name):
     case = cases.make_case(name)
     mon = L.MON_HISTORY | L.MON_HIST_LT | L.MON_HIST_GRAD | L.MON_SUMMARIES | L.MON_ACCEPT
@@ -813,13 +814,19 @@ def test_readme_flow_basic_mc_job():
 
 
 # ------------------------------------------------------------------ randomized configurations
-def _random_case(seed, wide=False):
+def _random_case(seed, wide=False, logit_mfma=False):
     """One job drawn from the whole configuration space the library accepts: target family and size, sampler, tuner,
     range, chain count (valid combinations only — the refused ones are in test_error_paths).  wide: the sizes round 4 moved onto hand-written
     kernels — dense targets of 129..256 dimensions (streamed matrix-core layouts) and logistic regressions with 9..16 parameters (row split)."""
-    rng = np.random.default_rng((5000 if wide else 1000) + seed)
-    fam = rng.choice(["dense", "logit"]) if wide else rng.choice(["diag_unit", "diag", "dense", "logit", "hier", "custom"], p=[0.2, 0.25, 0.15, 0.13, 0.14, 0.13])
-    if fam == "diag_unit":
+    rng = np.random.default_rng((9000 if logit_mfma else 5000 if wide else 1000) + seed)
+    fam = "logitm" if logit_mfma else rng.choice(["dense", "logit"]) if wide else rng.choice(["diag_unit", "diag", "dense", "logit", "hier", "custom"], p=[0.2, 0.25, 0.15, 0.13, 0.14, 0.13])
+    if fam == "logitm":       # round 6: 17 .. 128 parameters on the matrix cores (klara_logit_mfma.h): every NE, rows that end inside a tile / a block of tiles
+        d = int(rng.choice([17, 20, 31, 32, 33, 48, 64, 65, 96, 97, 128]))
+        n = int(rng.choice([1, 15, 16, 17, 32, 33, 100, 300]))
+        X, y = cases.synthetic_logit(n, d, seed=seed)
+        target = K.LogisticTarget(X / np.sqrt(d), y, float(rng.choice([1.0, 100.0])))
+        fam = "logit"
+    elif fam == "diag_unit":
         d = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 19, 31, 40, 63, 77, 100, 128, 129, 200, 300]))
         target = K.GaussDiagTarget.negdot(d)
     elif fam == "diag":
@@ -843,9 +850,9 @@ def _random_case(seed, wide=False):
     else:
         d = int(rng.choice([2, 5, 9, 16, 24]))
         target = K.CustomTarget(d, cases.SRC_QUARTIC_CHAIN, [float(rng.uniform(0.01, 0.2)), float(rng.uniform(0.1, 0.8))])
-    samplers = [L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC] + ([] if fam == "dense" and d > 70 else [L.SAMPLER_SLICE])   # (dense slice: D full evaluations per probe on the oracle's side)
+    samplers = [L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC] + ([] if (fam == "dense" and d > 70) or logit_mfma else [L.SAMPLER_SLICE])   # (dense slice: D full evaluations per probe on the oracle's side)
     sampler = int(rng.choice(samplers))
-    scale = 0.02 if fam == "hier" else (0.05 if fam == "logit" else (0.1 if wide else 0.3))
+    scale = 0.02 if fam == "hier" else (0.5 if logit_mfma else 0.05 if fam == "logit" else (0.1 if wide else 0.3))
     c = dict(sampler=sampler, target=target, nchains=int(rng.choice([1, 2, 7, 8, 9, 33, 64, 100, 131])), x0=None, seed=int(rng.integers(1, 2 ** 40)),
              name=f"random_{seed}_{fam}")
     if sampler == L.SAMPLER_MH:
@@ -929,6 +936,61 @@ def test_random_configurations_wide(seed):
     """48 more jobs from the sizes that moved onto hand-written kernels in round 4 (dense 129..256 dimensions on the streamed matrix-core layouts — HMC with
     every tuner, MALA, MH; logistic regression with 9..16 parameters), run like the others."""
     _run_random(*_random_case(seed, wide=True))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configurations_logistic_on_the_matrix_cores(seed):
+    """40 logistic regressions with 17 .. 128 parameters (layout kind 5, klara_logit_mfma.h; round 6): MH / MALA / HMC, every tuner, any range and chain count, random
+    launch splitting — run like the others."""
+    c, rng = _random_case(seed, logit_mfma=True)
+    e = K.Engine(**cases.engine_kwargs(c))
+    assert e.layout()[0] == 5
+    e.close()
+    _run_random(c, rng)
+
+
+_LOGITM = [(smp, d, n) for smp in ("mh", "mala", "mala_pooled", "hmc", "hmc_rate", "hmc_da") for d, n in ((17, 50), (40, 16), (96, 33), (128, 70))]
+
+
+@pytest.mark.parametrize("smp,d,n", _LOGITM, ids=[f"{a}-d{b}-n{c_}" for a, b, c_ in _LOGITM])
+def test_every_matrix_core_logistic_instantiation_in_one_launch(smp, d, n):
+    """Every k_logit_mfma<sampler, NE, dual averaging> instantiation (NE = 8 / 16 / 24 / 32) with ALL transitions of the job in ONE launch, a ragged second tile of
+    chains, data rows that end inside a tile (or fill one exactly), running sums and histories on, at steps where a good share of the proposals is rejected and a good
+    share accepted: the state a lane carries from one transition to the next — kept after an accept, re-read after a reject — the fragment ring across the row blocks
+    of consecutive evaluations, and the padding rows' masks."""
+    rng = np.random.default_rng(d + 7 * len(smp) + n)
+    X, y = cases.synthetic_logit(n, d, seed=d + n)
+    c = dict(target=K.LogisticTarget(X / np.sqrt(d), y, 10.0), nchains=21, x0=0.3 * rng.standard_normal((21, d)), seed=777 + d, name=f"logitm_{smp}_{d}_{n}",
+             burnin=2, thinning=2, nsteps=14)
+    if smp == "mh":
+        c.update(sampler=L.SAMPLER_MH, mh_sigma=np.full(d, 1.2 / np.sqrt(d)) * rng.uniform(0.7, 1.3, d))
+    elif smp.startswith("mala"):
+        c.update(sampler=L.SAMPLER_MALA, driftstep=3.0 / d ** (1 / 3))
+        if smp == "mala_pooled":
+            c.update(tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.574, period=4)
+    else:
+        c.update(sampler=L.SAMPLER_HMC, leapstep=1.15, nleaps=3)
+        if smp == "hmc_rate":
+            c.update(tuner=L.TUNER_ACCEPT_RATE, targetrate=0.6, period=4)
+        if smp == "hmc_da":
+            c.update(tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=9)
+    nograd = smp == "mh"
+    mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT | (0 if nograd else L.MON_HIST_GRAD)
+    eng = K.Engine(**cases.engine_kwargs(c, monitor=mon, steps_per_launch=0, nstreams=1))
+    assert eng.layout() == (5, 4, 8 * ((d + 31) // 32)), eng.layout()
+    job = O.OracleJob(**cases.oracle_kwargs(c, layout=eng.layout()), want_hist=True)
+    eng.set_state(c["x0"]); assert job.set_state(c["x0"]) == 0
+    eng.run(c["nsteps"]); assert job.run(c["nsteps"]) == 0
+    rate = job.accept.mean()
+    assert 0.05 < rate < 0.95, rate                                                          # both the commit and the re-read are exercised
+    _assert_same(eng, job, c)
+    for ch in (0, 17, 20):
+        assert np.array_equal(eng.chain(ch), job.hist[:, ch, :].T), "history differs"
+        lt, g = eng.chain_fields(ch, logtarget=True, gradlogtarget=not nograd)
+        assert np.array_equal(lt, job.hist_lt[:, ch])
+        if not nograd:
+            assert np.array_equal(g, job.hist_g[:, ch, :].T)
+    eng.close()
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("KLARA_RANDOM_FIRST", "0")), int(os.environ.get("KLARA_RANDOM_FIRST", "0")) + int(os.environ.get("KLARA_RANDOM_CASES", "96"))))
