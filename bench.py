@@ -700,6 +700,31 @@ def extra_measurements(K, L, n, stream):
     except Exception as exc:
         ex["slice_general_target_error"] = repr(exc)
 
+    # -- the logistic regression BEYOND 16 parameters (round 6, klara_logit_mfma.h): X p and X'(y - logistic(Xp)) of 16 chains per wavefront on the FP64
+    # matrix cores, X streamed from memory (rounds 1-5: a closure, one chain per lane).  64 parameters, 200 synthetic rows, 32,768 chains, running sums;
+    # algorithmic flops: 4 n D per gradient evaluation and chain (two passes of 2 n D)
+    try:
+        dl, nl, ncl = 64, 200, 32768
+        rngl = np.random.default_rng(64)
+        Xl = rngl.standard_normal((nl, dl)); bl = rngl.standard_normal(dl)
+        yl = (rngl.random(nl) < 1.0 / (1.0 + np.exp(-Xl @ bl / np.sqrt(dl)))).astype(np.float64)
+        tl_ = K.LogisticTarget(Xl / np.sqrt(dl), yl, 10.0)
+        x0l = 0.1 * rngl.standard_normal((ncl, dl))
+        for key, kw, evals in (("mala", dict(sampler=L.SAMPLER_MALA, driftstep=0.05), 1), ("hmc_L10", dict(sampler=L.SAMPLER_HMC, leapstep=0.05, nleaps=10), 10)):
+            e = K.Engine(target=tl_, nchains=ncl, nsteps=10 ** 6, monitor=L.MON_SUMMARIES, steps_per_launch=8, stream=stream, **kw)
+            e.set_state(x0l)
+            rate, ls, _ = timed_rate(e, ncl, 16, 64)
+            layl = e.layout(); e.close()
+            tfl = ncl * 8 * evals * 4.0 * nl * dl / ls / 1e12
+            ex[f"logistic_d64_n200_{key}_transitions_per_s"] = rate
+            ex[f"logistic_d64_n200_{key}_roofline"] = {"bound": "mfma", "achieved": tfl, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tfl / FP64_MFMA_PEAK_TF,
+                                                       "kernel": f"k_logit_mfma<{key.split('_')[0].upper()}, NE={layl[2]}> (v_mfma_f64_16x16x4, fragments of X streamed), 8 transitions per launch",
+                                                       "launch_us": ls * 1e6, "layout": list(layl),
+                                                       "source": "algorithmic flops (4 n D per gradient evaluation and chain) / launch duration from HIP events in this run; the rows' "
+                                                                 "transcendental arithmetic (~60 vector instructions per row and chain) shares the SIMD with the matrix passes"}
+    except Exception as exc:
+        ex["logistic_mfma_error"] = repr(exc)
+
     # -- the two data-model configurations of BASELINE.json at their per-GPU share (cfg 4: 262,144 / 8 chains of the swiss
     # logistic regression, MALA h = 0.1; cfg 5: 1,048,576 / 8 chains of the rats hierarchical model, HMC L = 32 with the
     # per-GPU pooled AcceptanceRate tuner).  Data: the reference's own files as committed fixtures (tests/golden/*.npz).

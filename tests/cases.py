@@ -663,7 +663,9 @@ GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_sw
                 "dt_mala_d100_small_step", "dt_hmc_d100", "dt_mh_mvnormal_d20", "custom_banana_hmc",
                 "custom_quartic_mala_d20_pooled", "pair_quartic_hmc_d50_tuned",
                 # round 5's new paths: the slice sampler on the free-running diagonal kernel, on the dense targets (chains of a tile out of lockstep; streamed layout), a pair closure run as a whole-vector closure
-                "slice_d20_stepout", "slice_dense_d20", "slice_dense_d130_stream_mean", "pair_quartic_mala_d9_whole"]
+                "slice_d20_stepout", "slice_dense_d20", "slice_dense_d130_stream_mean", "pair_quartic_mala_d9_whole",
+                # round 6: the logistic regression beyond 16 parameters on the matrix cores (layout kind 5)
+                "mala_logitm_d20", "hmc_logitm_d40_dualavg"]
 
 
 def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):
