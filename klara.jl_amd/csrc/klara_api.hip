@@ -208,6 +208,9 @@ static bool logit_mfma_eligible(const klara_desc& d)
 {
     // (also 9 .. 16 parameters whose rows, padded to 16 columns, do not fit the LDS of the row-split kernels: the stream has no such limit)
     const bool beyond_rowsplit = d.ndims > 16 || (d.ndims > 8 && (size_t)d.logit_ndata * 17 > KLARA_LOGIT_MAX_LDS_DOUBLES);
+    // (the kernels address the fragment stream with 32-bit byte offsets: 2 x 16 ceil(n / 16) x 4 NE doubles stay below 2 GB — 2 million rows at 128 parameters)
+    const size_t stream_bytes = 2 * 16 * (((size_t)d.logit_ndata + 31) / 32 * 2) * 4 * (8 * (((size_t)d.ndims + 31) / 32)) * sizeof(double);
+    if (stream_bytes >= ((size_t)1 << 31)) return false;
     return d.target == KLARA_TARGET_LOGISTIC && beyond_rowsplit && d.ndims <= 128 && d.logit_ndata >= 1 && d.sampler != KLARA_SAMPLER_SLICE &&
            !(d.monitor & KLARA_MON_HIST_LLLP) && getenv("KLARA_LOGIT_NO_MFMA") == nullptr;
 }

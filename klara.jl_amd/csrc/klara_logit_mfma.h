@@ -85,20 +85,25 @@ __device__ __forceinline__ void logitm_eval(const double* __restrict__ F, const 
         for (int t = 0; t < MT; ++t) ga[t] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };
     }
     double sxy = 0.0, slg = 0.0;
-    // (behind the empty asm the address is "new" in every call: the loads stay where they are written — klara_dense_big.h dense_stream)
-    const gdouble* src = (const gdouble*)F + lane;
-    __asm__ volatile("" : "+v"(src));
+    // The stream and the responses through buffer resources: the lane's byte offset is ONE register for the whole evaluation (lane x 8, q x 8), the
+    // position in the stream is a scalar offset — no vector address arithmetic per fragment.  (Behind the empty asm the offset is "new" in every call: the
+    // loads stay where they are written — klara_dense_big.h dense_stream.)
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void*)F, 0, __builtin_amdgcn_readfirstlane(nblocks) * (2 * S1 * 512), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)ypad, 0, __builtin_amdgcn_readfirstlane(nblocks) * (RBT * 16 * 8), 0x00020000);
+    unsigned voff = (unsigned)lane * 8u, yoff = (unsigned)q * 8u;
+    __asm__ volatile("" : "+v"(voff), "+v"(yoff));
+    const auto frag = [&](int sbytes) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rF, voff, sbytes, 0)); };
     double ring[RING];
 #pragma unroll
-    for (int i = 0; i < RING; ++i) ring[i] = src[(size_t)i * 64];
+    for (int i = 0; i < RING; ++i) ring[i] = frag(i * 512);
     for (int b = 0; b < nblocks; ++b) {
-        const gdouble* const blk = src + (size_t)b * (2 * S1 * 64);
+        const int blk = __builtin_amdgcn_readfirstlane(b) * (2 * S1 * 512);          // the block's first byte in the stream (scalar)
         const bool more = b + 1 < nblocks;
         // the responses of the lane's rows of this block: row 16 (b RBT + tt) + 4 j + q  (in flight under pass 1)
         double yv[RBT * 4];
-        const gdouble* const yb = ypad + (size_t)b * (RBT * 16) + q;
+        const int yblk = __builtin_amdgcn_readfirstlane(b) * (RBT * 16 * 8);
 #pragma unroll
-        for (int i = 0; i < RBT * 4; ++i) yv[i] = yb[16 * (i >> 2) + 4 * (i & 3)];
+        for (int i = 0; i < RBT * 4; ++i) yv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rY, yoff, yblk + (16 * (i >> 2) + 4 * (i & 3)) * 8, 0));
         kd_double4 z[RBT];
 #pragma unroll
         for (int tt = 0; tt < RBT; ++tt) z[tt] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };
@@ -107,15 +112,18 @@ __device__ __forceinline__ void logitm_eval(const double* __restrict__ F, const 
         for (int s = 0; s < S1; ++s) {
             const int kk = s / RBT, tt = s % RBT;
             const double a = ring[s % RING];
-            if (s + RING < SB) ring[s % RING] = blk[(size_t)(s + RING) * 64];
-            else if (more) ring[s % RING] = blk[(size_t)(2 * S1 + s + RING - SB) * 64];        // (lt only: the next block's pass 1)
+            if (s + RING < SB) ring[s % RING] = frag(blk + (s + RING) * 512);
+            else if (more) ring[s % RING] = frag(blk + (2 * S1 + s + RING - SB) * 512);        // (lt only: the next block's pass 1)
             z[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x[kk], z[tt], 0, 0, 0);
             if (tt == RBT - 1) __builtin_amdgcn_sched_barrier(0);
         }
         // -- the lane's rows of the block, ascending: tile tt, register j = row 16 (b RBT + tt) + 4 j + q
         const int row0 = b * (RBT * 16) + q;
         // (R row values per staged batch: 8 where the registers are there, 4 at NE = 24 / 32 — a batch keeps ~20 registers per value alive)
-        constexpr int R = NE <= 16 ? RBT * 4 : 4;
+#ifndef KLARA_LOGITM_ROWS_SMALL
+#define KLARA_LOGITM_ROWS_SMALL (KLARA_LOGITM_RBT * 4)
+#endif
+        constexpr int R = NE <= 16 ? KLARA_LOGITM_ROWS_SMALL : 4;
 #pragma unroll
         for (int i0 = 0; i0 < RBT * 4; i0 += R) {
             double zv[R], sp[R], lg[R];
@@ -138,8 +146,8 @@ __device__ __forceinline__ void logitm_eval(const double* __restrict__ F, const 
             for (int s2 = 0; s2 < S1; ++s2) {
                 const int s = S1 + s2, tt = s2 / (4 * MT), j = (s2 / MT) & 3, t = s2 % MT;
                 const double a = ring[s % RING];
-                if (s + RING < SB) ring[s % RING] = blk[(size_t)(s + RING) * 64];
-                else if (more) ring[s % RING] = blk[(size_t)(2 * S1 + s + RING - SB) * 64];
+                if (s + RING < SB) ring[s % RING] = frag(blk + (s + RING) * 512);
+                else if (more) ring[s % RING] = frag(blk + (2 * S1 + s + RING - SB) * 512);
                 ga[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (double)z[tt][j], ga[t], 0, 0, 0);
                 if (t == MT - 1) __builtin_amdgcn_sched_barrier(0);
             }
