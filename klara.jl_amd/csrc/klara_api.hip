@@ -202,8 +202,8 @@ static bool dense_streamed(const klara_desc& d)
 }
 
 // the logistic regression beyond 16 parameters on the matrix cores (klara_logit_mfma.h, layout kind 5): X p and X' (y - 1/(1+exp(-Xp))) of 16 chains per
-// wavefront as two MFMA passes over streamed fragments of X; MH / MALA / HMC with every tuner and the monitors of the dense layouts.  The slice sampler and
-// the likelihood / prior history keep the closure form (klara_create).
+// wavefront as two MFMA passes over streamed fragments of X; every sampler, every tuner, the monitors of the dense layouts.  The likelihood / prior
+// history keeps the closure form (klara_create).
 static bool logit_mfma_eligible(const klara_desc& d)
 {
     // (also 9 .. 16 parameters whose rows, padded to 16 columns, do not fit the LDS of the row-split kernels: the stream has no such limit)
@@ -211,7 +211,7 @@ static bool logit_mfma_eligible(const klara_desc& d)
     // (the kernels address the fragment stream with 32-bit byte offsets: 2 x 16 ceil(n / 16) x 4 NE doubles stay below 2 GB — 2 million rows at 128 parameters)
     const size_t stream_bytes = 2 * 16 * (((size_t)d.logit_ndata + 31) / 32 * 2) * 4 * (8 * (((size_t)d.ndims + 31) / 32)) * sizeof(double);
     if (stream_bytes >= ((size_t)1 << 31)) return false;
-    return d.target == KLARA_TARGET_LOGISTIC && beyond_rowsplit && d.ndims <= 128 && d.logit_ndata >= 1 && d.sampler != KLARA_SAMPLER_SLICE &&
+    return d.target == KLARA_TARGET_LOGISTIC && beyond_rowsplit && d.ndims <= 128 && d.logit_ndata >= 1 &&
            !(d.monitor & KLARA_MON_HIST_LLLP) && getenv("KLARA_LOGIT_NO_MFMA") == nullptr;
 }
 

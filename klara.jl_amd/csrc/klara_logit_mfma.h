@@ -24,8 +24,8 @@
 // respectively data rows) — the chains of the closure form, bit for bit; the row sums (X p).y and sum log(1 + exp) are lane partials over the
 // lane's rows ascending, then (q0 + q1) + (q2 + q3); p.p likewise over the lane's elements.  Padding rows (>= n) and columns (>= D) are zeros in
 // the stream: they add exact zeros to every chain; a padding row's softplus term is masked.
-// MH, MALA, HMC (Vanilla / AcceptanceRate per chain or pooled / dual averaging), every monitor of klara_dense_big.h.  The slice sampler and the
-// likelihood / prior history keep the closure form.
+// MH, MALA, HMC (Vanilla / AcceptanceRate per chain or pooled / dual averaging) and the slice sampler (a probe = pass 1 + the rows; the chains of a tile out
+// of lockstep), every monitor of klara_dense_big.h.  The likelihood / prior history keeps the closure form.
 #pragma once
 #include "klara_dense_big.h"
 
@@ -199,9 +199,11 @@ template <int SAMPLER, int NE, bool DA = false>
 __global__ __launch_bounds__(256, logitm_waves<NE>())
 void k_logit_mfma(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ F, const double* __restrict__ ypad_, int nblocks)
 {
-    static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH, "HMC, MALA, MH");
+    static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_SLICE, "HMC, MALA, MH, slice");
+    constexpr bool SLICE = SAMPLER == KLARA_SAMPLER_SLICE;
+    constexpr bool XMEM = SAMPLER == KLARA_SAMPLER_HMC || SLICE;      // the value a chain is leaving / goes back to is read from X (MALA / MH: from the lane's LDS column)
     static_assert(!DA || SAMPLER == KLARA_SAMPLER_HMC, "dual averaging is wired into HMC only (HMC.jl:124-133)");
-    constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;
+    constexpr bool NEEDG = SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_HMC;      // MH and the slice sampler carry no gradient (GR is not written)
     constexpr bool da = DA;
     const KParams& p = *pp;
     const gdouble* const ypad = (const gdouble*)ypad_;
@@ -226,6 +228,7 @@ void k_logit_mfma(const KParams* __restrict__ pp, const KLaunch kl, const double
     long long scol = kl.save_col0;
     double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
     unsigned long long nacc = 0;
+    bool stuck = false;                                  // slice sampler: step-out / shrink ran out of attempts
     const bool do_sum = p.sum != nullptr;
     long long held = do_sum ? p.held[cx.chain_ok ? cx.chain : 0] : 0;
     const __amdgpu_buffer_rsrc_t wX = mwin<NE>(cx, p.X, 0, p.D), wG = mwin<NE>(cx, p.GR, 0, p.D);
@@ -326,6 +329,16 @@ void k_logit_mfma(const KParams* __restrict__ pp, const KLaunch kl, const double
                 const double u = kd_accept_uniform(kd_stream_block(p.seed, gchain, t, (uint32_t)((p.D + 1) >> 1)));
                 acc = acc || ratio > kd_log_u01(u);
             }
+        } else if constexpr (SLICE) {
+            // iterate/SliceSampler.jl:60-109 — the 16 chains of the tile out of lockstep (slice_dense_free, klara_dense.h): a probe is a full evaluation of the
+            // log-target (:77-94) = pass 1 and the rows for the tile's 16 chains, each chain at its own coordinate and stage
+            double cur = lt;
+            slice_dense_free<NE>(p, cx, gchain, t, xp, cur, stuck, [&](const double (&xt)[NE]) {
+                double gd[NE];
+                return logitm_target<NE, false>(p, F, ypad, ldsL12, nblocks, cx.lane, xt, gd);
+            });
+            ltp = cur;
+            acc = true;                                  // the slice sampler always moves (SliceSampler.jl:108)
         } else {
             // iterate/MH.jl:72-124: the log-target alone — pass 1 and the rows, no gradient pass
             mnormals_each<NE, KLARA_BIG_NORMALS_WAYS_MH>(cx, p.seed, gchain, t, [&](int e, double z) {
@@ -351,7 +364,7 @@ void k_logit_mfma(const KParams* __restrict__ pp, const KLaunch kl, const double
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const unsigned o = fold ? cx.off(e, nv) : KLARA_BUF_OOB;
-                const double xo = SAMPLER == KLARA_SAMPLER_HMC ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0)) : momw[e * 64];
+                const double xo = XMEM ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0)) : momw[e * 64];
                 const double sv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ws, o, 0, 0));
                 const double qv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wq, o, 0, 0));
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sv + hf * xo), ws, o, 0, 0);
@@ -377,7 +390,7 @@ void k_logit_mfma(const KParams* __restrict__ pp, const KLaunch kl, const double
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const unsigned o = acc ? KLARA_BUF_OOB : cx.off(e0 + j, nv);
-                    if (SAMPLER != KLARA_SAMPLER_HMC) xc[j] = momw[(e0 + j) * 64];
+                    if (!XMEM) xc[j] = momw[(e0 + j) * 64];
                     else xc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, o, 0, 0));
                     if (NEEDG) gc[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, o, 0, 0));
                 }
@@ -392,7 +405,7 @@ void k_logit_mfma(const KParams* __restrict__ pp, const KLaunch kl, const double
             }
         }
         nacc += acc ? 1ull : 0ull;
-        tn.accepted += (p.cnt && acc) ? 1 : 0;
+        tn.accepted += (p.cnt && acc && !SLICE) ? 1 : 0;          // (the slice sampler never counts accepts)
         if (accept_out != nullptr) {
             const __amdgpu_buffer_rsrc_t wa = __builtin_amdgcn_make_buffer_rsrc((void*)(accept_out + (long long)s * p.nchains + cx.first_chain), 0,
                                                                                 __builtin_amdgcn_readfirstlane(cx.here), 0x00020000);
@@ -430,6 +443,7 @@ void k_logit_mfma(const KParams* __restrict__ pp, const KLaunch kl, const double
         }
     }
 
+    if (SLICE && stuck && cx.chain_ok && cx.q == 0) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);
     if (cx.chain_ok && cx.q == 0) {
         p.LT[cx.chain] = lt;
         p.naccept[cx.chain] += nacc;

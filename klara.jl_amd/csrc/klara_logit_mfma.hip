@@ -1,5 +1,5 @@
 // klara_logit_mfma.hip — instantiates the matrix-core logistic-regression kernels (layout kind 5: 17 <= D <= 128, NE = 8, 16, 24, 32 elements per lane;
-// MH, MALA, HMC — also with dual averaging) for gfx950.
+// MH, MALA, HMC — also with dual averaging —, slice) for gfx950.
 #include "klara_launch.h"
 #define KLARA_DENSE_NO_PROBES 1
 #include "klara_logit_mfma.h"
@@ -32,6 +32,7 @@ hipError_t klara_launch_logit_mfma(const KParams* p, const KLaunch& kl, int samp
     case KLARA_SAMPLER_HMC: return da ? go_logitm_s<KLARA_SAMPLER_HMC, true>(p, kl, NE, F, ypad, nblocks, grid, st) : go_logitm_s<KLARA_SAMPLER_HMC>(p, kl, NE, F, ypad, nblocks, grid, st);
     case KLARA_SAMPLER_MALA: return go_logitm_s<KLARA_SAMPLER_MALA>(p, kl, NE, F, ypad, nblocks, grid, st);
     case KLARA_SAMPLER_MH: return go_logitm_s<KLARA_SAMPLER_MH>(p, kl, NE, F, ypad, nblocks, grid, st);
+    case KLARA_SAMPLER_SLICE: return go_logitm_s<KLARA_SAMPLER_SLICE>(p, kl, NE, F, ypad, nblocks, grid, st);
     default: return hipErrorInvalidValue;
     }
 }

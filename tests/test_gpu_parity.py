@@ -850,7 +850,7 @@ def _random_case(seed, wide=False, logit_mfma=False):
     else:
         d = int(rng.choice([2, 5, 9, 16, 24]))
         target = K.CustomTarget(d, cases.SRC_QUARTIC_CHAIN, [float(rng.uniform(0.01, 0.2)), float(rng.uniform(0.1, 0.8))])
-    samplers = [L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC] + ([] if (fam == "dense" and d > 70) or logit_mfma else [L.SAMPLER_SLICE])   # (dense slice: D full evaluations per probe on the oracle's side)
+    samplers = [L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC] + ([] if (fam == "dense" and d > 70) or (logit_mfma and d > 48) else [L.SAMPLER_SLICE])   # (dense slice: D full evaluations per probe on the oracle's side)
     sampler = int(rng.choice(samplers))
     scale = 0.02 if fam == "hier" else (0.5 if logit_mfma else 0.05 if fam == "logit" else (0.1 if wide else 0.3))
     c = dict(sampler=sampler, target=target, nchains=int(rng.choice([1, 2, 7, 8, 9, 33, 64, 100, 131])), x0=None, seed=int(rng.integers(1, 2 ** 40)),
@@ -949,7 +949,7 @@ def test_random_configurations_logistic_on_the_matrix_cores(seed):
     _run_random(c, rng)
 
 
-_LOGITM = [(smp, d, n) for smp in ("mh", "mala", "mala_pooled", "hmc", "hmc_rate", "hmc_da") for d, n in ((17, 50), (40, 16), (96, 33), (128, 70))]
+_LOGITM = [(smp, d, n) for smp in ("mh", "mala", "mala_pooled", "hmc", "hmc_rate", "hmc_da", "slice") for d, n in ((17, 50), (40, 16), (96, 33), (128, 70))]
 
 
 @pytest.mark.parametrize("smp,d,n", _LOGITM, ids=[f"{a}-d{b}-n{c_}" for a, b, c_ in _LOGITM])
@@ -962,7 +962,9 @@ def test_every_matrix_core_logistic_instantiation_in_one_launch(smp, d, n):
     X, y = cases.synthetic_logit(n, d, seed=d + n)
     c = dict(target=K.LogisticTarget(X / np.sqrt(d), y, 10.0), nchains=21, x0=0.3 * rng.standard_normal((21, d)), seed=777 + d, name=f"logitm_{smp}_{d}_{n}",
              burnin=2, thinning=2, nsteps=14)
-    if smp == "mh":
+    if smp == "slice":               # (a probe is a full evaluation: D x ~6 of them per transition and chain on the oracle's side)
+        c.update(sampler=L.SAMPLER_SLICE, slice_widths=np.linspace(0.8, 3.0, d), slice_stepout=d != 96, nsteps=4, burnin=1)
+    elif smp == "mh":
         c.update(sampler=L.SAMPLER_MH, mh_sigma=np.full(d, 1.2 / np.sqrt(d)) * rng.uniform(0.7, 1.3, d))
     elif smp.startswith("mala"):
         c.update(sampler=L.SAMPLER_MALA, driftstep=3.0 / d ** (1 / 3))
@@ -974,7 +976,7 @@ def test_every_matrix_core_logistic_instantiation_in_one_launch(smp, d, n):
             c.update(tuner=L.TUNER_ACCEPT_RATE, targetrate=0.6, period=4)
         if smp == "hmc_da":
             c.update(tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=9)
-    nograd = smp == "mh"
+    nograd = smp in ("mh", "slice")
     mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT | (0 if nograd else L.MON_HIST_GRAD)
     eng = K.Engine(**cases.engine_kwargs(c, monitor=mon, steps_per_launch=0, nstreams=1))
     assert eng.layout() == (5, 4, 8 * ((d + 31) // 32)), eng.layout()
@@ -982,7 +984,7 @@ def test_every_matrix_core_logistic_instantiation_in_one_launch(smp, d, n):
     eng.set_state(c["x0"]); assert job.set_state(c["x0"]) == 0
     eng.run(c["nsteps"]); assert job.run(c["nsteps"]) == 0
     rate = job.accept.mean()
-    assert 0.05 < rate < 0.95, rate                                                          # both the commit and the re-read are exercised
+    assert rate == 1.0 if smp == "slice" else 0.05 < rate < 0.95, rate                       # both the commit and the re-read are exercised
     _assert_same(eng, job, c)
     for ch in (0, 17, 20):
         assert np.array_equal(eng.chain(ch), job.hist[:, ch, :].T), "history differs"

@@ -2,6 +2,8 @@
 reference's own tests hold for this path and against published vectors."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 from scipy import stats
@@ -328,12 +330,15 @@ def test_logistic_target_matches_numpy():
 
 
 def test_logistic_target_with_20_parameters_matches_numpy():
-    # beyond 16 parameters: on the matrix cores since round 6 (layout kind 5: row sums over 4 lane-quarters, klara_logit_mfma.h) for MH / MALA / HMC; the
-    # slice sampler keeps the run-time compiled closure form (all rows on one lane).  The same closures either way, and the same fma chains for X p and X' r.
+    # beyond 16 parameters: on the matrix cores since round 6 (layout kind 5: row sums over 4 lane-quarters, klara_logit_mfma.h); KLARA_LOGIT_NO_MFMA=1 gives
+    # the run-time compiled closure form of rounds 1-5 (all rows on one lane).  The same closures either way, and the same fma chains for X p and X' r.
     X, y = cases.synthetic_logit(300, 20, seed=3)
     p = 0.3 * np.random.default_rng(1).standard_normal(20)
     got = {}
+    os.environ.pop("KLARA_LOGIT_NO_MFMA", None)
     for sampler, lay in ((L.SAMPLER_MALA, (5, 4, 8)), (L.SAMPLER_SLICE, (0, 1, 32))):
+        if sampler == L.SAMPLER_SLICE:
+            os.environ["KLARA_LOGIT_NO_MFMA"] = "1"          # the closure form (every sampler of a kind-5 job is on the matrix cores; this is the library's A/B switch)
         job = O.OracleJob(sampler=sampler, target_kind=L.TARGET_LOGISTIC, nchains=1, ndims=20, nsteps=1, logit_X=X, logit_y=y, logit_lambda=10.0,
                           slice_widths=np.ones(20) if sampler == L.SAMPLER_SLICE else None)
         assert (job.layout.kind, job.layout.G, job.layout.E) == lay
@@ -342,6 +347,7 @@ def test_logistic_target_with_20_parameters_matches_numpy():
         assert lt == pytest.approx(xp @ y - np.sum(np.log(1 + np.exp(xp))) - 0.5 * (p @ p / 10.0 + 20 * np.log(2 * np.pi * 10.0)), rel=1e-12)
         assert np.allclose(g, X.T @ (y - 1 / (1 + np.exp(-xp))) - p / 10.0, rtol=1e-11, atol=1e-12)
         got[sampler] = (lt, g)
+    os.environ.pop("KLARA_LOGIT_NO_MFMA", None)
     assert np.array_equal(got[L.SAMPLER_MALA][1], got[L.SAMPLER_SLICE][1])         # the gradient chains are the same in both layouts; the log-target's sums are not
     assert got[L.SAMPLER_MALA][0] == pytest.approx(got[L.SAMPLER_SLICE][0], rel=1e-13)
     # 128 parameters, 33 rows (a third tile with one row): the layout's largest NE
