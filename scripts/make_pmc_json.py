@@ -11,7 +11,7 @@ import sys
 from collections import defaultdict
 
 prof, outp = sys.argv[1], sys.argv[2]
-KEEP = ("k_diagt", "k_transitions", "k_hiert", "k_dense", "k_init", "k_pool", "k_pooled", "k_bm_close", "k_chain")
+KEEP = ("k_diagt", "k_transitions", "k_hiert", "k_dense", "k_logit", "k_init", "k_pool", "k_pooled", "k_bm_close", "k_chain")
 agg = defaultdict(lambda: defaultdict(list))          # (kernel, grid, wg) -> counter -> values
 meta = {}
 for f in sorted(glob.glob(os.path.join(prof, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
