@@ -544,6 +544,51 @@ def test_round5_bench_lines_are_complete_and_recomputable():
         assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
 
 
+def test_round6_bench_lines_are_complete_and_recomputable():
+    """profiles/r6_bench_{default,driver_flags}.json (the round's profile pass: one box for the counters, one for the lines): the driver's keys with `roofline.traffic` among
+    the first; the headline fraction from the UNCHANGED 1,505-instruction budget and the line's own launch duration, rocprofv3's average of the same kernel within 6 %; the
+    fraction over the timed region; the collective the line names; the mixing-step, general-target slice and matrix-core logistic extras; cfg 3 at >= 0.88 of the MFMA peak."""
+    import csv, json
+    pmc = json.loads((ROOT / "profiles" / "r6_pmc_kernels.json").read_text())
+    stats = {r["Name"]: r for r in csv.DictReader((ROOT / "profiles" / "r6_bench_headline_kernel_stats.csv").open())}
+    head_avg_us = float(next(v for k, v in stats.items() if k.startswith("void k_diagt<1, 13, 4, false, true, true,"))["AverageNs"]) * 1e-3
+    for name in ("r6_bench_default.json", "r6_bench_driver_flags.json"):
+        d = json.loads((ROOT / "profiles" / name).read_text())
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in d, (name, k)
+        assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and d["unit"] == "transitions/s"
+        assert d["value"] == pytest.approx(d["config"]["nchains_total"] / (d["ms_per_step"] * 1e-3), rel=1e-9)
+        col = d["config"]["collective"]
+        assert col["requested"] == "klara" and col["used"].startswith("none") and col["error"] is None and d["config"]["rccl_ranks_seen"] == 1
+        rf = d["roofline"]
+        assert list(rf)[:6] == ["bound", "achieved", "peak", "unit", "frac", "traffic"]                 # (the driver's parse keeps the first scalar keys)
+        assert rf["bound"] == "valu" and rf["budget"]["per_wave_transition"] == 1505.0 and rf["traffic"] > 1e8
+        nec = 1505.0 * 4096 * 32
+        assert rf["necessary_valu_insts_per_launch"] == nec
+        assert rf["frac"] == pytest.approx(4.0 * nec / (rf["launch_us"] * 1e-6) / (1024 * 2.4e9), rel=1e-9) and 0.65 < rf["frac"] < 1.0
+        assert abs(rf["launch_us"] / head_avg_us - 1.0) < 0.06, (rf["launch_us"], head_avg_us)
+        assert rf["frac_timed_region"] == pytest.approx(4.0 * 1505.0 * 4096 / (d["config"]["timed_region_kernel_ms_per_step"] * 1e-3) / (1024 * 2.4e9), rel=1e-9)
+        row = next(r for r in pmc["kernels"] if r["kernel"] == rf["pmc"]["kernel"] and r.get("grid") == 262144)
+        assert rf["pmc"]["stale"] is False and rf["pmc"]["file"] == "profiles/r6_pmc_kernels.json"
+        assert rf["utilisation"] == pytest.approx(4.0 * row["counters"]["SQ_ACTIVE_INST_VALU"]["mean"] / (rf["launch_us"] * 1e-6) / (1024 * 2.4e9), rel=1e-6)
+        assert rf["issued_over_necessary"] == pytest.approx(row["counters"]["SQ_INSTS_VALU"]["mean"] / nec, rel=1e-9) and rf["issued_over_necessary"] < 1.12
+        ex = d["extra"]
+        for key in ("cfg1_roofline", "cfg3_hmc_dense_roofline", "cfg4_roofline", "cfg5_roofline", "hmc_iso_roofline", "slice_d100_roofline", "mala_one_transition_per_launch_roofline",
+                    "mala_d100_mixing_step_roofline", "logistic_d64_n200_hmc_L10_roofline"):
+            assert ex[key]["bound"] in ("valu", "mfma") and ex[key]["frac"] is not None and 0.3 < ex[key]["frac"] <= 1.0, (name, key, ex[key])
+        assert 0.5 < ex["mala_d100_mixing_step"]["acceptance_rate"] < 0.62 and ex["mala_d100_mixing_step_transitions_per_s"] > 3e9
+        assert ex["logistic_d64_n200_mala_transitions_per_s"] > 3e8 and ex["logistic_d64_n200_mala_roofline"]["layout"] == [5, 4, 16]       # (closure form: 4.7e7)
+        assert ex["slice_swiss_logistic_coordinate_updates_per_s"] > 3e8 and ex["slice_pair_closure_d100_coordinate_updates_per_s"] > 3e8
+        c3 = ex["cfg3_hmc_dense_roofline"]
+        assert c3["frac"] >= 0.88 and c3["pmc"]["loaded_scratch"] == 0
+        assert ex["cfg3_hmc_dense_leapfrog_chain_per_s"] >= 1e8 and ex["hmc_iso_leapfrog_chain_per_s"] >= 1e8          # north_star's HMC target
+        assert ex["slice_d100_coordinate_updates_per_s"] >= 1.0e11
+        cb = d["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    d = json.loads((ROOT / "profiles" / "r6_bench_default.json").read_text())
+    assert d["roofline"]["frac_timed_region"] > d["roofline"]["frac"] and d["roofline"]["frac_timed_region"] > 0.76
+
+
 def test_slice_and_dense_kernel_resources(tmp_path):
     """No GPU needed: the free-running slice kernels (one machine per lane) fit 8 / 6 wavefronts per SIMD without scratch, and the cfg 3 kernel
     (k_dense_transitions<HMC, NE = 25, PLAIN>) has no scratch (round 4: 64-80 B)."""
