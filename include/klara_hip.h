@@ -88,9 +88,9 @@ typedef enum klara_target {
     KLARA_TARGET_GAUSS_DENSE = 1,
     /* Bayesian logistic regression of doc/examples/swiss/MALA/analytical.jl:11-18:
      * lt = dot(Xp, y) - sum(log(1+exp(Xp))) - 0.5 (p.p/lambda + D log(2 pi lambda)).  Up to 16 parameters: the data rows in LDS, dealt to 4 lanes
-     * per chain; 17 .. 128 parameters (and 9 .. 16 with more rows than the LDS holds), every sampler: X p and X' (y - 1/(1+exp(-Xp))) of 16 chains
-     * per wavefront on the FP64 matrix cores, X streamed from memory — any number of rows (round 6; layout kind 5); beyond 128 parameters the
-     * same closures through the run-time compiled path (to 256 parameters). */
+     * per chain; 17 .. 256 parameters (and 9 .. 16 with more rows than the LDS holds), every sampler: X p and X' (y - 1/(1+exp(-Xp))) of 16 chains
+     * per wavefront on the FP64 matrix cores, X streamed from memory — any number of rows (round 6; layout kind 5).  (KLARA_LOGIT_NO_MFMA=1 in the
+     * environment: the same closures through the run-time compiled path, as in rounds 1-5.) */
     KLARA_TARGET_LOGISTIC = 2,
     /* Hierarchical normal growth-curve model for data/rats/{weight,age}.csv (BASELINE cfg 5).  The reference
      * ships the data but no model (doc/examples/rats/Gibbs.jl:1-7 is a stub), so the target is builder-defined:

@@ -211,7 +211,7 @@ static bool logit_mfma_eligible(const klara_desc& d)
     // (the kernels address the fragment stream with 32-bit byte offsets: 2 x 16 ceil(n / 16) x 4 NE doubles stay below 2 GB — 2 million rows at 128 parameters)
     const size_t stream_bytes = 2 * 16 * (((size_t)d.logit_ndata + 31) / 32 * 2) * 4 * (8 * (((size_t)d.ndims + 31) / 32)) * sizeof(double);
     if (stream_bytes >= ((size_t)1 << 31)) return false;
-    return d.target == KLARA_TARGET_LOGISTIC && beyond_rowsplit && d.ndims <= 128 && d.logit_ndata >= 1 &&
+    return d.target == KLARA_TARGET_LOGISTIC && beyond_rowsplit && d.ndims <= 256 && d.logit_ndata >= 1 &&
            !(d.monitor & KLARA_MON_HIST_LLLP) && getenv("KLARA_LOGIT_NO_MFMA") == nullptr;
 }
 

@@ -8,7 +8,7 @@
 // 4.7e7 at D = 64 against 9e8 at D = 16: profiles/r6_logit_mfma.txt).
 //
 // Layout: klara_dense.h's.  A wavefront carries 16 chains; lane (q = l >> 4, c = l & 15) holds the elements {4 e + q} of chain c, NE = 8,
-// 16, 24, 32 per lane (D <= 32, 64, 96, 128).  One evaluation runs over the data rows in BLOCKS of RBT tiles of 16 rows:
+// 16, 24, 32 per lane (D <= 32, 64, 96, 128) and 40, 48, 56, 64 (D <= 160 .. 256: one wavefront per SIMD).  One evaluation runs over the data rows in BLOCKS of RBT tiles of 16 rows:
 //   pass 1   Z = X P        v_mfma_f64_16x16x4:  A = X[16 T + (l & 15)][4 kk + (l >> 4)],  B = the lane's own element kk,  kk = 0 .. NE-1
 //            -> accumulator tile T, register j of lane (q, c) = (X p)[row 16 T + 4 j + q] of chain c
 //   rows     the lane's 4 RBT row values: softplus / logistic from ONE exponential (detmath.h kd_softplus_logistic_rows, the row arithmetic of
@@ -193,7 +193,8 @@ __device__ __forceinline__ double logitm_target(const KParams& p, const double* 
 #ifndef KLARA_LOGITM_WAVES_32
 #define KLARA_LOGITM_WAVES_32 2
 #endif
-template <int NE> __host__ __device__ constexpr int logitm_waves() { return NE <= 8 ? KLARA_LOGITM_WAVES_8 : NE <= 16 ? KLARA_LOGITM_WAVES_16 : NE <= 24 ? KLARA_LOGITM_WAVES_24 : KLARA_LOGITM_WAVES_32; }
+// (NE = 40 .. 64 — 129 .. 256 parameters — run one wavefront per SIMD like the streamed dense kernels: value and gradient alone are 256 registers at NE = 64)
+template <int NE> __host__ __device__ constexpr int logitm_waves() { return NE <= 8 ? KLARA_LOGITM_WAVES_8 : NE <= 16 ? KLARA_LOGITM_WAVES_16 : NE <= 24 ? KLARA_LOGITM_WAVES_24 : NE <= 32 ? KLARA_LOGITM_WAVES_32 : 1; }
 
 template <int SAMPLER, int NE, bool DA = false>
 __global__ __launch_bounds__(256, logitm_waves<NE>())

@@ -1,4 +1,4 @@
-// klara_logit_mfma.hip — instantiates the matrix-core logistic-regression kernels (layout kind 5: 17 <= D <= 128, NE = 8, 16, 24, 32 elements per lane;
+// klara_logit_mfma.hip — instantiates the matrix-core logistic-regression kernels (layout kind 5: 17 <= D <= 256, NE = 8, 16, 24, 32, 40, 48, 56, 64 elements per lane;
 // MH, MALA, HMC — also with dual averaging —, slice) for gfx950.
 #include "klara_launch.h"
 #define KLARA_DENSE_NO_PROBES 1
@@ -23,6 +23,10 @@ static hipError_t go_logitm_s(const KParams* p, const KLaunch& kl, int NE, const
     if (NE == 16) return go_logitm<S, 16, DA>(p, kl, F, ypad, nblocks, grid, st);
     if (NE == 24) return go_logitm<S, 24, DA>(p, kl, F, ypad, nblocks, grid, st);
     if (NE == 32) return go_logitm<S, 32, DA>(p, kl, F, ypad, nblocks, grid, st);
+    if (NE == 40) return go_logitm<S, 40, DA>(p, kl, F, ypad, nblocks, grid, st);
+    if (NE == 48) return go_logitm<S, 48, DA>(p, kl, F, ypad, nblocks, grid, st);
+    if (NE == 56) return go_logitm<S, 56, DA>(p, kl, F, ypad, nblocks, grid, st);
+    if (NE == 64) return go_logitm<S, 64, DA>(p, kl, F, ypad, nblocks, grid, st);
     return hipErrorInvalidValue;
 }
 
@@ -43,6 +47,10 @@ hipError_t klara_launch_logit_mfma_init(const KParams& p, int NE, const double* 
     else if (NE == 16) hipLaunchKernelGGL((k_logit_mfma_init<16>), grid, dim3(256), 0, st, p, F, ypad, nblocks, needgrad);
     else if (NE == 24) hipLaunchKernelGGL((k_logit_mfma_init<24>), grid, dim3(256), 0, st, p, F, ypad, nblocks, needgrad);
     else if (NE == 32) hipLaunchKernelGGL((k_logit_mfma_init<32>), grid, dim3(256), 0, st, p, F, ypad, nblocks, needgrad);
+    else if (NE == 40) hipLaunchKernelGGL((k_logit_mfma_init<40>), grid, dim3(256), 0, st, p, F, ypad, nblocks, needgrad);
+    else if (NE == 48) hipLaunchKernelGGL((k_logit_mfma_init<48>), grid, dim3(256), 0, st, p, F, ypad, nblocks, needgrad);
+    else if (NE == 56) hipLaunchKernelGGL((k_logit_mfma_init<56>), grid, dim3(256), 0, st, p, F, ypad, nblocks, needgrad);
+    else if (NE == 64) hipLaunchKernelGGL((k_logit_mfma_init<64>), grid, dim3(256), 0, st, p, F, ypad, nblocks, needgrad);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

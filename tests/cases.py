@@ -233,6 +233,8 @@ LOGIT_MFMA_CASES = {
     "hmc_logitm_d17_pooled": (17, 16, dict(sampler=L.SAMPLER_HMC, leapstep=1.2, nleaps=3, tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.8, period=5)),   # one tile of rows exactly
     "mala_logitm_d96_n17_verbose": (96, 17, dict(sampler=L.SAMPLER_MALA, driftstep=1.5, verbose=True, period=10)),         # NE = 24; a second tile with one row
     "mh_logitm_d100_n33": (100, 33, dict(sampler=L.SAMPLER_MH, mh_sigma=0.2, nchains=70)),
+    "mala_logitm_d200_n40": (200, 40, dict(sampler=L.SAMPLER_MALA, driftstep=0.8, nchains=19, nsteps=14)),                   # NE = 56: one wavefront per SIMD
+    "hmc_logitm_d256_n65_tuned": (256, 65, dict(sampler=L.SAMPLER_HMC, leapstep=0.9, nleaps=3, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.7, period=5, nchains=19, nsteps=14)),
     "slice_logitm_d20": (20, 50, dict(sampler=L.SAMPLER_SLICE, slice_widths=1.5, nchains=35, nsteps=8, burnin=2)),         # a probe = pass 1 + the rows; chains of a tile out of lockstep
     "slice_logitm_d40_nostepout": (40, 17, dict(sampler=L.SAMPLER_SLICE, slice_widths=2.5, slice_stepout=False, nchains=19, nsteps=6, burnin=1)),
 }

@@ -157,8 +157,8 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     if target_kind == L.TARGET_GAUSS_DENSE:
         ne = 8 if d <= 32 else 16 if d <= 64 else 25 if d <= 100 else 32
         return (1, 4, ne)
-    if (target_kind == L.TARGET_LOGISTIC and (16 < d <= 128 or (8 < d <= 16 and ndata * 17 > 18432)) and sampler is not None
-            and "KLARA_LOGIT_NO_MFMA" not in os.environ):      # round 6: on the matrix cores (klara_logit_mfma.h): kind 5, 4 lanes per chain, NE = 8 ceil(D / 32)
+    if (target_kind == L.TARGET_LOGISTIC and (16 < d <= 256 or (8 < d <= 16 and ndata * 17 > 18432)) and sampler is not None
+            and "KLARA_LOGIT_NO_MFMA" not in os.environ):      # round 6: on the matrix cores to 256 parameters (klara_logit_mfma.h): kind 5, 4 lanes per chain, NE = 8 ceil(D / 32)
         return (5, 4, 8 * ((d + 31) // 32))
     if target_kind == L.TARGET_LOGISTIC and (d > 16 or (d > 8 and ndata * 17 > 18432)):     # beyond 16 parameters (or rows that do not fit the LDS): the run-time compiled closure form, one chain per lane
         e = 16

@@ -821,7 +821,7 @@ def _random_case(seed, wide=False, logit_mfma=False):
     rng = np.random.default_rng((9000 if logit_mfma else 5000 if wide else 1000) + seed)
     fam = "logitm" if logit_mfma else rng.choice(["dense", "logit"]) if wide else rng.choice(["diag_unit", "diag", "dense", "logit", "hier", "custom"], p=[0.2, 0.25, 0.15, 0.13, 0.14, 0.13])
     if fam == "logitm":       # round 6: 17 .. 128 parameters on the matrix cores (klara_logit_mfma.h): every NE, rows that end inside a tile / a block of tiles
-        d = int(rng.choice([17, 20, 31, 32, 33, 48, 64, 65, 96, 97, 128]))
+        d = int(rng.choice([17, 20, 31, 32, 33, 48, 64, 65, 96, 97, 128, 129, 192, 256]))
         n = int(rng.choice([1, 15, 16, 17, 32, 33, 100, 300]))
         X, y = cases.synthetic_logit(n, d, seed=seed)
         target = K.LogisticTarget(X / np.sqrt(d), y, float(rng.choice([1.0, 100.0])))
@@ -949,7 +949,7 @@ def test_random_configurations_logistic_on_the_matrix_cores(seed):
     _run_random(c, rng)
 
 
-_LOGITM = [(smp, d, n) for smp in ("mh", "mala", "mala_pooled", "hmc", "hmc_rate", "hmc_da", "slice") for d, n in ((17, 50), (40, 16), (96, 33), (128, 70))]
+_LOGITM = [(smp, d, n) for smp in ("mh", "mala", "mala_pooled", "hmc", "hmc_rate", "hmc_da", "slice") for d, n in ((17, 50), (40, 16), (96, 33), (128, 70), (160, 20), (256, 33)) if not (smp == "slice" and d > 128)]
 
 
 @pytest.mark.parametrize("smp,d,n", _LOGITM, ids=[f"{a}-d{b}-n{c_}" for a, b, c_ in _LOGITM])
