@@ -47,7 +47,7 @@ extern "C" {
  * events and at batch boundaries of the streaming batch means, whichever comes first) */
 #define KLARA_DEFAULT_STEPS_PER_LAUNCH 32
 /* ... and for the slice-sampler jobs the free-running kernel serves (klara.jl_amd/csrc/klara_diagt_slice.h: the lanes run out of lockstep, a wavefront
- * waits for its slowest lane once per element slot and launch): diagonal Gaussian, 17 <= D <= 512, untuned (VanillaMCTuner per chain, not verbose),
+ * waits for its slowest lane once per element slot and launch): diagonal Gaussian, 17 <= D <= 1024, untuned (VanillaMCTuner per chain, not verbose),
  * monitors among the accept diagnostics, the running sums, the value history (ring or not), the log-target history (with the values kept) and
  * the streaming autocovariances.  Ring planning and the cadence of the accept rows follow this length.  Every other slice job: 32. */
 #define KLARA_DEFAULT_STEPS_PER_LAUNCH_SLICE 128
@@ -124,7 +124,7 @@ typedef enum klara_target {
      * with logtarget(x) = sum over pairs P of klara_user_pair(x[2P], x[2P+1], P, ...) and (*g0, *g1) the pair's two partial derivatives
      * (for the half pair of an odd D, x1 is 0 and *g1 is ignored; the function is called for the real pairs only, 0 <= pair < ceil(D/2), so it may
      * index `data` by pair or by coordinate).  Such a job runs on the few-lanes-per-chain kernels of the diagonal
-     * Gaussian (layout kind 3: 8 / 16 / 32 lanes per chain, 17 <= D <= 512; MH, MALA, HMC with every tuner, the running sums and the
+     * Gaussian (layout kind 3: 8 / 16 / 32 / 64 lanes per chain, 17 <= D <= 1024; MH, MALA, HMC with every tuner, the running sums and the
      * value / logtarget / gradlogtarget histories; klara_get_layout reports the summation order: a lane adds its pairs' terms in
      * ascending order, then the butterfly over the chain's lanes) instead of holding the whole vector in one lane: at D = 100 the
      * README closure runs at 3.5e9 transitions/s in this form and at 2.1e8 in the whole-vector form.  A pair-form job those kernels do
@@ -386,7 +386,7 @@ klara_status klara_device_ptrs(klara_handle* h, void** x, void** logtarget, void
  * order): kind 0 = contiguous E elements per lane over G lanes; kind 1 = MFMA-transposed layout
  * (element i on lane-quarter i%4); kind 2 = logistic row split (every lane holds all E elements, the data
  * rows are dealt round-robin to `lanes_per_chain` lanes); kind 3 = pair-transposed layout of the diagonal Gaussian
- * (element pair P = i/2 on lane P % lanes_per_chain, elements_per_lane/2 pairs per lane; 8, 16 or 32 lanes per chain for D <= 128 / 256 / 512); kind 4 = hierarchical target
+ * (element pair P = i/2 on lane P % lanes_per_chain, elements_per_lane/2 pairs per lane; 8, 16, 32 or 64 lanes per chain for D <= 128 / 256 / 512 / 1024); kind 4 = hierarchical target
  * with few lanes per chain (unit r on lane r / (elements_per_lane/2), hyper block replicated); kind 5 = logistic regression on the matrix cores
  * (elements as in kind 1; data row r on lane-quarter r % 4: row sums are lane partials over ascending rows, then (q0 + q1) + (q2 + q3); X p and
  * X' (y - 1/(1+exp(-Xp))) are fma chains over ascending columns / rows).  See DESIGN.md section 3. */

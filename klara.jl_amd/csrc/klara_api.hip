@@ -110,7 +110,7 @@ static bool diagt_eligible(const klara_desc& d)
 {
     if (d.target != KLARA_TARGET_GAUSS_DIAG) return false;
     // (D <= 16: the group layout already puts a chain on <= 4 lanes, 16..64 chains per wavefront)
-    if (d.ndims < 17 || d.ndims > 2 * 32 * KLARA_DIAGT_NP_MAX) return false;       // (Q = 8, 16 or 32 lanes per chain)
+    if (d.ndims < 17 || d.ndims > 2 * 64 * KLARA_DIAGT_NP_MAX) return false;       // (Q = 8, 16, 32 or 64 lanes per chain)
     if (const char* s = getenv("KLARA_LAYOUT_KIND")) { if (atoi(s) == 0) return false; }
     if (getenv("KLARA_LAYOUT_E")) return false;
     return true;
@@ -230,9 +230,9 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     *kind = 0;
     if (d.target == KLARA_TARGET_CUSTOM && pair_form(d)) {
         // pair closure (klara_diagt.h USERPAIR): the pair-transposed layout, Q = 8 / 16 / 32 lanes per chain
-        if (D < 17 || D > 2 * 32 * KLARA_DIAGT_NP_MAX) return KLARA_ERR_UNSUPPORTED;       // (fewer than 9 pairs: use the whole-vector form)
+        if (D < 17 || D > 2 * 64 * KLARA_DIAGT_NP_MAX) return KLARA_ERR_UNSUPPORTED;       // (fewer than 9 pairs: use the whole-vector form)
         if (d.sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
-        const int Q = D <= 128 ? 8 : (D <= 256 ? 16 : 32);
+        const int Q = D <= 128 ? 8 : (D <= 256 ? 16 : (D <= 512 ? 32 : 64));
         *kind = 3; *G = Q; *E = 2 * ((D + 2 * Q - 1) / (2 * Q));
         return KLARA_OK;
     }
@@ -254,7 +254,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     if (diagt_eligible(d)) {
         // lanes per chain of the layout, i.e. of the summation order klara_get_layout reports.  (Untuned MH / MALA up to D = 104 also
         // run on 4-lane kernels that reproduce the 8-lane order: q4_eligible.)
-        const int Q = D <= 128 ? 8 : (D <= 256 ? 16 : 32);
+        const int Q = D <= 128 ? 8 : (D <= 256 ? 16 : (D <= 512 ? 32 : 64));
         const int np = (D + 2 * Q - 1) / (2 * Q);                                 // NP = ceil(D/2 / Q) exactly (see klara_diagt.h)
         if (np >= 2 && np <= KLARA_DIAGT_NP_MAX) { *kind = 3; *G = Q; *E = 2 * np; return KLARA_OK; }
     }
@@ -959,7 +959,8 @@ static klara_status init_common(klara_handle* h)
     else if (h->kind == 3)
         e = h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
           : h->G == 16 ? klara_launch_diagt_init_q16(p, h->E / 2, needgrad, grid_for(h), st)
-                       : klara_launch_diagt_init_q32(p, h->E / 2, needgrad, grid_for(h), st);
+          : h->G == 32 ? klara_launch_diagt_init_q32(p, h->E / 2, needgrad, grid_for(h), st)
+                       : klara_launch_diagt_init_q64(p, h->E / 2, needgrad, grid_for(h), st);
     else if (h->kind == 4) e = klara_launch_hiert_init(p, h->E / 2, d.hier_ntimes, needgrad, grid_for(h), st);
     else if (d.target == KLARA_TARGET_CUSTOM) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), lds_for(h), st, 64 * h->custom_wpb);
     else if (d.target == KLARA_TARGET_GAUSS_DIAG)
@@ -996,14 +997,15 @@ extern "C" klara_status klara_init_state_normal(klara_handle* h)
     // use the handle's own (kind 0) or a group layout that fits the wavefront for the other kinds
     KParams p = make_params(h);
     const int D = h->d.ndims;
-    int E = D <= 128 ? 2 : (D <= 256 ? 4 : 8), G = pow2ceil((D + E - 1) / E);       // (at most 64 lanes per chain)
+    int E = D <= 128 ? 2 : (D <= 256 ? 4 : (D <= 512 ? 8 : 16)), G = pow2ceil((D + E - 1) / E);       // (at most 64 lanes per chain: D <= 1024)
     if ((h->kind == 0 || h->kind == 2) && h->d.target != KLARA_TARGET_CUSTOM) { E = h->E; G = h->G; }
     p.G = G; p.rs = 1;     // the init stream is drawn without the row split (same values, any layout)
     const long long cpw = 64 / G, waves = (h->d.nchains + cpw - 1) / cpw;
     const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
     if (E == 2) hipLaunchKernelGGL((k_init_normal<2, 0>), grid, blk, 0, h->stream, p);
     else if (E == 4) hipLaunchKernelGGL((k_init_normal<4, 0>), grid, blk, 0, h->stream, p);
-    else hipLaunchKernelGGL((k_init_normal<8, 0>), grid, blk, 0, h->stream, p);
+    else if (E == 8) hipLaunchKernelGGL((k_init_normal<8, 0>), grid, blk, 0, h->stream, p);
+    else hipLaunchKernelGGL((k_init_normal<16, 0>), grid, blk, 0, h->stream, p);
     HIPCHK(hipGetLastError());
     return init_common(h);
 }
@@ -1113,7 +1115,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
                 case KLARA_SAMPLER_MALA: return klara_launch_diagt_mala##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);    \
                 default: return klara_launch_diagt_hmc##SUFFIX(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st);                     \
                 }
-                if (lanes == 8) { KLARA_DIAGT_LAUNCH() } else if (lanes == 16) { KLARA_DIAGT_LAUNCH(_q16) } else { KLARA_DIAGT_LAUNCH(_q32) }
+                if (lanes == 8) { KLARA_DIAGT_LAUNCH() } else if (lanes == 16) { KLARA_DIAGT_LAUNCH(_q16) } else if (lanes == 32) { KLARA_DIAGT_LAUNCH(_q32) } else { KLARA_DIAGT_LAUNCH(_q64) }
 #undef KLARA_DIAGT_LAUNCH
             };
             if (force >= 0 && !(h->q4_ok && sums)) {
@@ -2486,8 +2488,8 @@ extern "C" klara_status klara_check_custom_target(const char* src, int32_t sampl
     std::string src2;
     if (pair_as_whole(src, sampler, ndims)) { src2 = pair_as_whole_source(src); src = src2.c_str(); }
     if (pair_source(src)) {                                 // pair closure: the plain fused instantiation of its layout
-        if (ndims > 2 * 32 * KLARA_DIAGT_NP_MAX) return KLARA_ERR_UNSUPPORTED;
-        const int Q = ndims <= 128 ? 8 : (ndims <= 256 ? 16 : 32);
+        if (ndims > 2 * 64 * KLARA_DIAGT_NP_MAX) return KLARA_ERR_UNSUPPORTED;
+        const int Q = ndims <= 128 ? 8 : (ndims <= 256 ? 16 : (ndims <= 512 ? 32 : 64));
         return klara_jit_create_pair(src, sampler, ndims, (ndims + 2 * Q - 1) / (2 * Q), Q, false, false, false, modes, 1, false, nullptr);
     }
     if (ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;

@@ -42,8 +42,9 @@ hipError_t klara_launch_logit_mfma_init(const KParams& p, int NE, const double* 
 int klara_logit_mfma_rbt();      // row tiles per block the kernels were built for
 
 // pair-transposed diagonal-Gaussian kernels (layout kind 3, klara_diagt.h).  The translation units klara_diagt_*.hip are
-// compiled three times: Q = 8 lanes per chain (17 <= D <= 128, NP = ceil(D/16) in 2..8), Q = 16 (129 <= D <= 256) and Q = 32
-// (257 <= D <= 512), the latter two with NP in 5..8; the launchers of the wider variants carry a _q16 / _q32 suffix.
+// compiled four times: Q = 8 lanes per chain (17 <= D <= 128, NP = ceil(D/16) in 2..8), Q = 16 (129 <= D <= 256), Q = 32
+// (257 <= D <= 512) and (round 6) Q = 64 (513 <= D <= 1024: north_star's one chain per wavefront), the latter three with NP in 5..8; the launchers of the
+// wider variants carry a _q16 / _q32 / _q64 suffix.
 #if KLARA_DIAGT_Q == 8
 #define KLARA_DIAGT_FN(name) name
 #elif KLARA_DIAGT_Q == 4
@@ -52,6 +53,8 @@ int klara_logit_mfma_rbt();      // row tiles per block the kernels were built f
 #define KLARA_DIAGT_FN(name) name##_q16
 #elif KLARA_DIAGT_Q == 32
 #define KLARA_DIAGT_FN(name) name##_q32
+#elif KLARA_DIAGT_Q == 64
+#define KLARA_DIAGT_FN(name) name##_q64
 #else
 #define KLARA_DIAGT_FN(name) name          // (experimental lane counts replace the Q = 8 set)
 #endif
@@ -66,6 +69,7 @@ int klara_logit_mfma_rbt();      // row tiles per block the kernels were built f
 KLARA_DIAGT_DECLARE()
 KLARA_DIAGT_DECLARE(_q16)
 KLARA_DIAGT_DECLARE(_q32)
+KLARA_DIAGT_DECLARE(_q64)
 // Q = 4 lanes per chain, 16 chains per wavefront, NP = ceil(D/8) in 3..13 (17 <= D <= 104): jobs in which nothing counts or tunes
 // (VanillaMCTuner, not verbose) with the MH or the MALA sampler — D = 100 occupies 50 of 52 pair slots instead of 50 of 56, the
 // per-wavefront work (reductions, accept test, addressing) is shared by 16 chains, and the running sums are folded with atomic

@@ -140,7 +140,7 @@ class CustomTarget:
 
         with logtarget(x) = sum over pairs P of klara_user_pair(x[2P], x[2P+1], P, ...) and (*g0, *g1) the pair's two partial
         derivatives (for the half pair of an odd D, x1 is 0 and *g1 is ignored).  Such a job runs on the few-lanes-per-chain
-        kernels of the diagonal Gaussian (layout kind 3: 8 / 16 / 32 lanes per chain, 17 <= D <= 512; MH, MALA, HMC with every tuner
+        kernels of the diagonal Gaussian (layout kind 3: 8 / 16 / 32 / 64 lanes per chain, 17 <= D <= 1024; MH, MALA, HMC with every tuner
         and monitor) instead of one chain per lane — the form for large D (include/klara_hip.h, KLARA_USER_PAIR_TARGET).  Below 17 dimensions, and
         with the slice sampler, the library sums the pairs' terms itself and runs the whole-vector form (D <= 256)."""
         return cls(ndims, "#define KLARA_USER_PAIR_TARGET 1\n" + pair_source, data)

@@ -281,6 +281,18 @@ def make_case(name):
     elif name == "mh_d512":            # E=8, the largest supported diagonal target
         c = dict(sampler=L.SAMPLER_MH, target=K.GaussDiagTarget.negdot(512), nchains=5, nsteps=25, burnin=0,
                  mh_sigma=np.full(512, 0.03))
+    elif name == "hmc_d1000_tuned":    # round 6: 64 lanes per chain (513 <= D <= 1024: one chain per wavefront), AcceptanceRate per chain
+        c = dict(sampler=L.SAMPLER_HMC, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, 1000), np.linspace(0.5, 1.5, 1000)), nchains=5, nsteps=40, burnin=30,
+                 leapstep=0.12, nleaps=4, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.7, period=10)
+    elif name == "mala_d777_pooled":   # odd D (a half pair), pooled tuner
+        c = dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(777), nchains=7, nsteps=50, burnin=40, thinning=3, driftstep=0.02,
+                 tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.574, period=10)
+    elif name == "slice_d600":         # the free-running slice kernel on 64 lanes per chain
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, 600), np.linspace(0.7, 1.5, 600)), nchains=3, nsteps=5, burnin=1,
+                 slice_widths=np.linspace(0.5, 2.5, 600))
+    elif name == "pair_quartic_hmc_d700_dualavg":      # a pair closure at 64 lanes per chain
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget.pairwise(700, SRC_PAIR_QUARTIC, [0.05, 0.3]), nchains=5, nsteps=30, burnin=5,
+                 leapstep=0.05, nleaps=3, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=15, x0=0.4 * np.random.default_rng(8).standard_normal((5, 700)))
     elif name == "slice_d2_mvnormal":  # G=1: one chain per lane with divergent step-out / shrink loops
         c = dict(sampler=L.SAMPLER_SLICE, target=K.GaussDiagTarget.mvnormal([1.0, -2.0], [0.5, 3.0]), nchains=130,
                  nsteps=25, burnin=5, slice_widths=[0.3, 4.0])
@@ -646,6 +658,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "mh_dense_d20", "mala_swiss", "hmc_swiss", "slice_d5", "slice_d100_nostepout", "slice_swiss",
              "hmc_rats", "hmc_rats_pooled", "mala_rats", "slice_rats", "hmc_d10_dualavg", "hmc_dense_d37_dualavg",
              "hmc_rats_dualavg", "mala_d3_tuned_erf", "mala_d1", "hmc_d128_full", "mala_d129", "mh_d512",
+             "hmc_d1000_tuned", "mala_d777_pooled", "slice_d600", "pair_quartic_hmc_d700_dualavg",
              "slice_d2_mvnormal", "mala_d20_tuned", "hmc_d100_tuned", "mala_d100_verbose", "hmc_d40_dualavg", "hmc_d100_dualavg",
              "hmc_dense_d98", "hmc_dense_d70", "hmc_dense_d128", "hmc_dense_d100_mean", "mala_dense_d37_mean", "mh_dense_d20_mean",
              "hmc_dense_d70_mean_dualavg", "slice_dense_d20", "slice_dense_d37_mean", "mh_dense_d130_wide", "hmc_dense_d130_wide",

@@ -121,15 +121,15 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     d = int(ndims)
     plain = sampler is not None      # (name kept from when the layout excluded tuned jobs)
     if (target_kind == L.TARGET_GAUSS_DIAG and sampler is not None and plain
-            and 17 <= d <= 512 and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0" and "KLARA_LAYOUT_E" not in os.environ):
-        q = 8 if d <= 128 else (16 if d <= 256 else 32)          # lanes per chain (klara_api.hip select_layout)
+            and 17 <= d <= 1024 and os.environ.get("KLARA_LAYOUT_KIND", "3") != "0" and "KLARA_LAYOUT_E" not in os.environ):
+        q = 8 if d <= 128 else (16 if d <= 256 else (32 if d <= 512 else 64))          # lanes per chain (klara_api.hip select_layout)
         # (untuned MH / MALA up to D = 104 also run on 4-lane kernels: they sum in this 8-lane order, klara_diagt.h)
         return (3, q, 2 * ((d + 2 * q - 1) // (2 * q)))
     if (target_kind == L.TARGET_HIER_NORMAL and sampler in (L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC)
             and 9 <= hier_nunits <= 32 and os.environ.get("KLARA_LAYOUT_KIND", "4") != "0"):
         return (4, 8, 8)              # klara_hiert.h: 8 lanes per chain, 4 units per lane
     if target_kind == L.TARGET_CUSTOM and pair_form:     # pair closure: the pair-transposed layout (klara_api.hip select_layout)
-        q = 8 if d <= 128 else (16 if d <= 256 else 32)
+        q = 8 if d <= 128 else (16 if d <= 256 else (32 if d <= 512 else 64))
         return (3, q, 2 * ((d + 2 * q - 1) // (2 * q)))
     if target_kind == L.TARGET_CUSTOM and d > 32 and os.environ.get("KLARA_CUSTOM_LANES", "0") != "1":
         # whole-vector closure staged through LDS (klara_api.hip custom_layout): G lanes x E = 2 ceil(D / 2G) <= 16 elements, a workgroup's

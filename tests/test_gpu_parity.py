@@ -220,15 +220,16 @@ def test_group_layout_dimension_sweep():
 def test_pair_transposed_dimension_sweep(sampler, kw, step):
     """Dimensions 17..128 (the 4-lane kernels for MH / MALA up to 104 at the odd ones — sparse_moves = 1 —, the 8-lane kernels
     otherwise), odd ones included, on the pair-transposed layout (every one for MALA, every
-    third for HMC and MH, every seventh for the slice sampler), then 129..512 (16 and 32 lanes per chain) in coarser steps:
+    third for HMC and MH, every seventh for the slice sampler), then 129..512 (16 and 32 lanes per chain) in coarser steps, then 513..1024 (round 6: 64 lanes per
+    chain — one chain per wavefront) at six sizes:
     with and without padding pairs / a half pair, i.e. every way of obtaining the accept draw and of storing the last pair."""
     wide = {1: 3, 3: 13, 7: 61}[step]
-    for d in list(range(17, 129, step)) + list(range(129, 513, wide)) + [256, 257, 511, 512]:
+    for d in list(range(17, 129, step)) + list(range(129, 513, wide)) + [256, 257, 511, 512, 513, 640, 641, 777, 1023, 1024]:
         skw = dict(slice_widths=np.full(d, 1.5)) if kw == "slice" else (kw if kw is not None else dict(mh_sigma=np.full(d, 0.2)))
         case = dict(sampler=sampler, target=K.GaussDiagTarget.mvnormal(np.linspace(-1, 1, d), np.linspace(0.7, 1.5, d)), nchains=11,
                     nsteps=6, burnin=0, x0=None, seed=d, name=f"sweep3_d{d}", sparse_moves=(1 if d % 2 == 1 else 2), **skw)
         eng, job = _run_pair(case, spl=2)
-        lanes = 8 if d <= 128 else 16 if d <= 256 else 32       # (the summation order; MH / MALA up to 104 at the odd dimensions run the
+        lanes = 8 if d <= 128 else 16 if d <= 256 else 32 if d <= 512 else 64       # (the summation order; MH / MALA up to 104 at the odd dimensions run the
         assert eng.layout()[:2] == (3, lanes)                    # 4-lane kernels — sparse_moves = 1 —, which reproduce the 8-lane order)
         if sampler in (L.SAMPLER_MH, L.SAMPLER_MALA) and d <= 104:
             assert tuple(eng.launch_modes()[0]) == ((3, 0, 0) if d % 2 == 1 else (0, 3, 0)), d
@@ -445,6 +446,24 @@ def test_dense_target_beyond_128_closure_form_still_matches(name, monkeypatch):
     monkeypatch.setenv("KLARA_DENSE_NO_STREAM", "1")
     eng, job = _run_pair(case)
     assert eng.layout() == (0, 1, 256)
+    _assert_same(eng, job, case)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["hmc_logit_d20_wide", "mala_logitm_d20", "slice_logitm_d20", "mala_logit_d12_manyrows"])
+def test_logistic_beyond_16_parameters_closure_form_still_matches(name, monkeypatch):
+    """Round 6 moved the logistic regression beyond 16 parameters (and 9 .. 16 with rows that do not fit the LDS) onto the matrix cores; the run-time compiled
+    closure form of rounds 1-5 (one chain per lane, all rows on it) remains behind KLARA_LOGIT_NO_MFMA=1: both forms against the oracle in their own summation
+    orders (layout kind 5: row sums over 4 lane-quarters; kind 0 on one lane), bit for bit — and with the SAME gradients (the fma chains are the same)."""
+    case = cases.make_case(name)
+    eng, job = _run_pair(case)
+    assert eng.layout()[0] == 5
+    _assert_same(eng, job, case)
+    g5 = eng.state()[2]
+    eng.close()
+    monkeypatch.setenv("KLARA_LOGIT_NO_MFMA", "1")
+    eng, job = _run_pair(case)
+    assert eng.layout()[:2] == (0, 1)
     _assert_same(eng, job, case)
     eng.close()
 

@@ -434,7 +434,7 @@ def test_create_validates_like_the_reference_constructors(klib):
     assert status(period=0) == L.ERR_INVALID_ARG
     assert status(tuner=L.TUNER_ACCEPT_RATE, targetrate=1.5) == L.ERR_INVALID_ARG
     assert status(nchains=0) == L.ERR_INVALID_ARG
-    assert status(target=K.GaussDiagTarget.negdot(600)) == L.ERR_UNSUPPORTED
+    assert status(target=K.GaussDiagTarget.negdot(1025)) == L.ERR_UNSUPPORTED        # (round 6: 64 lanes per chain serve 513 .. 1024 dimensions)
     # the later additions to the descriptor are validated in the same place
     assert status(bm_batchlen=10) == L.ERR_INVALID_ARG                   # streaming batch means need the running sums
     assert status(bm_batchlen=-1, monitor=L.MON_SUMMARIES) == L.ERR_INVALID_ARG
