@@ -201,6 +201,18 @@ static bool dense_streamed(const klara_desc& d)
            (d.sampler != KLARA_SAMPLER_SLICE || getenv("KLARA_DENSE_SLICE_NO_STREAM") == nullptr);
 }
 
+// the dense Gaussian beyond D = 256 (round 6): the tile of 16 chains on a WORKGROUP of W = ceil(D / 64) wavefronts, 16 elements per lane and wavefront
+// (klara_dense_split.h, layout kind 6; MH, MALA, HMC with every tuner; 257 <= D <= 1024).  KLARA_DENSE_SPLIT=1 in the environment puts the smaller
+// dense targets on it as well (measurements, tests).
+static bool dense_split(const klara_desc& d)
+{
+    if (d.target != KLARA_TARGET_GAUSS_DENSE || d.sampler == KLARA_SAMPLER_SLICE || d.ndims > 64 * 16) return false;
+    if (getenv("KLARA_DENSE_NO_SPLIT") != nullptr) return false;
+    if (d.ndims > 256) return true;
+    const char* s = getenv("KLARA_DENSE_SPLIT");
+    return s != nullptr && atoi(s) != 0;
+}
+
 // the logistic regression beyond 16 parameters on the matrix cores (klara_logit_mfma.h, layout kind 5): X p and X' (y - 1/(1+exp(-Xp))) of 16 chains per
 // wavefront as two MFMA passes over streamed fragments of X; every sampler, every tuner, the monitors of the dense layouts.  The likelihood / prior
 // history keeps the closure form (klara_create).
@@ -220,6 +232,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     if (logit_mfma_eligible(d)) { *kind = 5; *G = 4; *E = 8 * ((d.ndims + 31) / 32); return KLARA_OK; }
     if (hiert_eligible(d)) { *kind = 4; *G = 8; *E = 8; return KLARA_OK; }
     const int D = d.ndims;
+    if (dense_split(d)) { *kind = 6; *G = (D + 63) / 64; *E = 16; return KLARA_OK; }      // G: wavefronts per tile of 16 chains
     if (d.target == KLARA_TARGET_GAUSS_DENSE) {
         *kind = 1; *G = 4;
         if (D <= 32) *E = 8; else if (D <= 64) *E = 16; else if (D <= 100) *E = 25; else if (D <= 128) *E = 32;
@@ -544,7 +557,7 @@ extern "C" klara_status klara_create(const klara_desc* desc, klara_handle** out)
         dd.custom_src = src2.c_str();
         return create_impl(&dd, out);
     }
-    if (desc->target == KLARA_TARGET_GAUSS_DENSE && desc->ndims > 128 && !dense_streamed(*desc)) {
+    if (desc->target == KLARA_TARGET_GAUSS_DENSE && desc->ndims > 128 && !dense_streamed(*desc) && !dense_split(*desc)) {
         if (desc->ndims > KLARA_CUSTOM_MAXD) return KLARA_ERR_UNSUPPORTED;
         if (desc->monitor & KLARA_MON_HIST_LLLP) return KLARA_ERR_UNSUPPORTED;
         const size_t D = (size_t)desc->ndims;
@@ -736,12 +749,13 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
         h->lpconst = (double)desc->ndims * kd_log(2.0 * 3.141592653589793 * desc->logit_lambda);
     } else {
         // fragment-ordered, zero-padded P for the MFMA A operand (klara_dense.h)
-        const int NE = E, MT = (NE + 3) / 4;
-        std::vector<double> frag((size_t)MT * NE * 64, 0.0);
+        // (layout kind 6: NE = 16 W k-steps of MT = 4 W tiles, k-major, and two k-steps of zeros behind them — the ring's last prefetch, klara_dense_split.h)
+        const int NE = kind == 6 ? 16 * G : E, MT = (NE + 3) / 4;
+        std::vector<double> frag((size_t)MT * (NE + (kind == 6 ? 2 : 0)) * 64, 0.0);
         // (NE % 4 == 1: the last tile is the 4-row tail for v_mfma_f64_4x4x4_4b, A_b[i][k] on lane 16k + 4b + i)
         const bool tail = (NE % 4) == 1;
         // tile-major (t, kk) for the LDS-resident layouts; k-major (kk, t) — the order of consumption — for the streamed ones (NE > 32)
-        const bool kmajor = NE > 32;
+        const bool kmajor = NE > 32 || kind == 6;
         for (int t = 0; t < MT; ++t)
             for (int kk = 0; kk < NE; ++kk)
                 for (int l = 0; l < 64; ++l) {
@@ -751,8 +765,9 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
                 }
         h->dense_mu = desc->gauss_mu != nullptr;
         if (h->dense_mu) {                                       // the mean, [4 e + q] = mu[4 e + q], zero beyond D
-            frag.resize(frag.size() + 4 * (size_t)NE, 0.0);
-            for (int i = 0; i < D; ++i) frag[(size_t)MT * NE * 64 + i] = desc->gauss_mu[i];
+            const size_t at = frag.size();
+            frag.resize(at + 4 * (size_t)NE, 0.0);
+            for (int i = 0; i < D; ++i) frag[at + i] = desc->gauss_mu[i];
         }
         CK(upload(&h->Pfrag, frag.data(), frag.size()));
     }
@@ -820,6 +835,7 @@ static KParams make_params(klara_handle* h)
 // one wave per chain group for the init kernels and the MFMA kernels
 static dim3 grid_for(const klara_handle* h)
 {
+    if (h->kind == 6) return dim3((unsigned)((h->d.nchains + 15) / 16));          // one workgroup (G wavefronts) per tile of 16 chains
     const long long cpw = (h->kind == 1 || h->kind == 5) ? 16 : 64 / (h->G * h->RS);
     const long long waves = (h->d.nchains + cpw - 1) / cpw;
     const long long wpb = h->kind == 5 ? 4 : h->kind == 1 ? (h->E > 32 ? 4 : 8) : h->custom_wpb;      // (streamed layouts: one wavefront per SIMD, workgroups of 4)
@@ -955,6 +971,7 @@ static klara_status init_common(klara_handle* h)
     hipError_t e;
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, h->dense_mu, needgrad, grid_for(h), st);
     else if (h->kind == 5) e = klara_launch_logit_mfma_init(p, h->E, h->Pfrag, h->ly, h->logit_nblocks, needgrad, grid_for(h), st);
+    else if (h->kind == 6) e = klara_launch_dense_split_init(p, h->G, h->Pfrag, h->dense_mu, needgrad, grid_for(h), st);
     else if (h->kind == 3 && h->jit_pair) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), 0, st);
     else if (h->kind == 3)
         e = h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
@@ -1064,6 +1081,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
     if (mode == 3 && kl.nsteps == 1) mode = 7;                                 // one iterate! per launch
     if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, plain, h->E, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
     if (h->kind == 5) return klara_launch_logit_mfma(p, kl, d.sampler, d.tuner == KLARA_TUNER_DUAL_AVERAGING, h->E, h->Pfrag, h->ly, h->logit_nblocks, grid_for(h), h->stream);
+    if (h->kind == 6) return klara_launch_dense_split(p, kl, d.sampler, d.tuner == KLARA_TUNER_DUAL_AVERAGING, h->G, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on

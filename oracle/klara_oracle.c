@@ -86,7 +86,10 @@ typedef struct ko_layout {
                      5: logistic regression on the matrix cores (klara_logit_mfma.h): elements as in kind 1 (element i on
                         lane-quarter i % 4), data row r on lane-quarter r % 4 — row sums are lane partials over ascending
                         rows, then the tree (q0 + q1) + (q2 + q3); X p and X' (y - 1/(1+exp(-Xp))) are the fma chains of
-                        v_mfma_f64_16x16x4 (k ascending from zero), i.e. the sequential chains of the closure form        */
+                        v_mfma_f64_16x16x4 (k ascending from zero), i.e. the sequential chains of the closure form
+                     6: dense Gaussian on a workgroup of G wavefronts per tile of 16 chains (klara_dense_split.h): element i on
+                        lane-quarter i % 4 of wavefront (i / 4) / 16; lane partials in ascending element order, the tree
+                        (q0 + q1) + (q2 + q3) inside each wavefront, then the wavefronts' values in ascending order         */
     int32_t G;
     int32_t E;
 } ko_layout;
@@ -94,6 +97,16 @@ typedef struct ko_layout {
 static double ko_reduce(const ko_layout* L, const double* terms, int D)
 {
     double part[64], nw[64];
+    if (L->kind == 6) {
+        double tot = 0.0;
+        for (int w = 0; w < L->G; ++w) {
+            double pq[4] = { 0.0, 0.0, 0.0, 0.0 };
+            for (int i = 64 * w; i < D && i < 64 * (w + 1); ++i) pq[i & 3] = pq[i & 3] + terms[i];
+            const double v = (pq[0] + pq[1]) + (pq[2] + pq[3]);
+            tot = w == 0 ? v : tot + v;
+        }
+        return tot;
+    }
     const int G = (L->kind == 1 || L->kind == 5) ? 4 : (L->kind == 2 ? 1 : L->G);
     for (int l = 0; l < G; ++l) part[l] = 0.0;
     for (int i = 0; i < D; ++i) {

@@ -240,6 +240,25 @@ LOGIT_MFMA_CASES = {
 }
 
 
+def _split_cases():
+    return {
+        "hmc_dense_d300_split": (300, dict(sampler=L.SAMPLER_HMC, nsteps=10, burnin=2, leapstep=0.08, nleaps=3)),
+        "hmc_dense_d257_split_pooled": (257, dict(sampler=L.SAMPLER_HMC, nsteps=36, burnin=24, leapstep=0.12, nleaps=3, tuner=L.TUNER_ACCEPT_RATE,
+                                                  tuner_mode=L.TUNE_POOLED, targetrate=0.65, period=8, nchains=37)),
+        "mala_dense_d512_split_mean_tuned": (512, dict(sampler=L.SAMPLER_MALA, nsteps=30, burnin=15, driftstep=0.03, tuner=L.TUNER_ACCEPT_RATE,
+                                                       targetrate=0.574, period=5)),
+        "mh_dense_d700_split_mean": (700, dict(sampler=L.SAMPLER_MH, nsteps=24, burnin=4, thinning=2, nchains=19)),
+        "hmc_dense_d1024_split_dualavg": (1024, dict(sampler=L.SAMPLER_HMC, nsteps=12, burnin=0, leapstep=0.06, nleaps=3, tuner=L.TUNER_DUAL_AVERAGING,
+                                                     targetrate=0.8, da_nadapt=7, nchains=18)),
+        "mala_dense_d1000_split_pooled": (1000, dict(sampler=L.SAMPLER_MALA, nsteps=30, burnin=20, driftstep=0.02, tuner=L.TUNER_ACCEPT_RATE,
+                                                     tuner_mode=L.TUNE_POOLED, targetrate=0.574, period=10, nchains=33)),
+        "mh_dense_d333_split": (333, dict(sampler=L.SAMPLER_MH, nsteps=20, burnin=0, nchains=5)),
+    }
+
+
+SPLIT_CASES = {k: (v[0], dict(v[1])) for k, v in _split_cases().items()}
+
+
 def make_case(name):
     """name -> dict(engine kwargs..., target=<family object>, x0=None|array)."""
     c = {}
@@ -394,6 +413,18 @@ def make_case(name):
                                                     targetrate=0.574, period=10),
               "hmc_dense_d130_dualavg_wide": dict(sampler=L.SAMPLER_HMC, nsteps=14, burnin=0, leapstep=0.1, nleaps=3, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.8,
                                                   da_nadapt=8)}[name]
+        c = dict(target=t, nchains=n, x0=x0, **kw)
+    elif name in SPLIT_CASES:
+        # round 6: the dense Gaussian beyond D = 256 — a workgroup of W = ceil(D / 64) wavefronts per tile of 16 chains (klara_dense_split.h, layout kind 6)
+        d, kw = SPLIT_CASES[name][0], dict(SPLIT_CASES[name][1])
+        rng = np.random.default_rng(2000 + d)
+        a = rng.standard_normal((d, d)); pm = a @ a.T / d + np.eye(d)
+        mu = rng.standard_normal(d) if "_mean" in name else None
+        t = K.GaussDenseTarget(pm, const=0.75, mu=mu)
+        n = kw.pop("nchains", 21)
+        x0 = rng.standard_normal((n, d)) + (0.0 if mu is None else mu[None, :])
+        if kw.get("sampler") == L.SAMPLER_MH:
+            kw["mh_sigma"] = np.linspace(0.01, 0.04, d)
         c = dict(target=t, nchains=n, x0=x0, **kw)
     elif name == "mh_dense_d130_wide":     # (round 4: MH at D = 130 runs on the streamed matrix-core layout too; the closure form: hmc_dense_d130_dualavg_wide)
         rng = np.random.default_rng(130)
@@ -664,6 +695,8 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_dense_d70_mean_dualavg", "slice_dense_d20", "slice_dense_d37_mean", "mh_dense_d130_wide", "hmc_dense_d130_wide",
              "hmc_dense_d256_stream_tuned", "hmc_dense_d192_stream_mean", "hmc_dense_d160_stream_pooled", "hmc_dense_d129_stream", "hmc_dense_d201_stream",
              "mala_dense_d200_stream_tuned", "mh_dense_d256_stream_mean", "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide",
+             "hmc_dense_d300_split", "hmc_dense_d257_split_pooled", "mala_dense_d512_split_mean_tuned", "mh_dense_d700_split_mean",
+             "hmc_dense_d1024_split_dualavg", "mala_dense_d1000_split_pooled", "mh_dense_d333_split",
              "slice_dense_d192_stream", "slice_dense_d130_stream_mean", "slice_dense_d256_stream", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
              "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide", "hmc_logit_d20_wide", "slice_d20_stepout", "mh_rats", "mala_rats_tuned",
              "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"] + list(LOGIT_MFMA_CASES) + [

@@ -450,6 +450,37 @@ def test_dense_target_beyond_128_closure_form_still_matches(name, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("name", sorted(cases.SPLIT_CASES))
+def test_dense_target_beyond_256_on_workgroup_split_layout(name):
+    """Round 6: dense targets of 257 .. 1024 dimensions (refused in rounds 1-5) run on the matrix cores with the tile of 16 chains on a workgroup of
+    ceil(D / 64) wavefronts (klara_dense_split.h): layout kind 6, bit for bit against the oracle's kind-6 summation order, in one piece and split into launches."""
+    case = cases.make_case(name)
+    d = case["target"].ndims
+    eng, job = _run_pair(case)
+    assert eng.layout() == (6, (d + 63) // 64, 16)
+    _assert_same(eng, job, case)
+    eng.close()
+    n = case["nsteps"]
+    eng, job = _run_pair(case, splits=[1, n // 3, n - 1 - n // 3], spl=7)
+    _assert_same(eng, job, case)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["hmc_dense_d98", "hmc_dense_d128", "hmc_dense_d100_mean", "mala_dense_d37_mean", "mh_dense_d20_mean", "hmc_dense_d70_mean_dualavg",
+                                  "hmc_dense_d256_stream_tuned", "hmc_dense_d160_stream_pooled", "mala_dense_d200_stream_tuned", "mh_dense_d256_stream_mean",
+                                  "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide"])
+def test_smaller_dense_targets_on_the_split_layout(name, monkeypatch):
+    """KLARA_DENSE_SPLIT=1 puts every dense target on the workgroup-split layout (1 .. 4 wavefronts per tile below D = 257): the cases of the LDS-resident and
+    streamed layouts again, against the oracle in the kind-6 order."""
+    monkeypatch.setenv("KLARA_DENSE_SPLIT", "1")
+    case = cases.make_case(name)
+    d = case["target"].ndims
+    eng, job = _run_pair(case)
+    assert eng.layout() == (6, (d + 63) // 64, 16)
+    _assert_same(eng, job, case)
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["hmc_logit_d20_wide", "mala_logitm_d20", "slice_logitm_d20", "mala_logit_d12_manyrows"])
 def test_logistic_beyond_16_parameters_closure_form_still_matches(name, monkeypatch):
     """Round 6 moved the logistic regression beyond 16 parameters (and 9 .. 16 with rows that do not fit the LDS) onto the matrix cores; the run-time compiled
