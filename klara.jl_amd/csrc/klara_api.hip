@@ -201,8 +201,8 @@ static bool dense_streamed(const klara_desc& d)
            (d.sampler != KLARA_SAMPLER_SLICE || getenv("KLARA_DENSE_SLICE_NO_STREAM") == nullptr);
 }
 
-// the dense Gaussian beyond D = 256 (round 6): the tile of 16 chains on a WORKGROUP of W = ceil(D / 64) wavefronts, 16 elements per lane and wavefront
-// (klara_dense_split.h, layout kind 6; MH, MALA, HMC with every tuner; 257 <= D <= 1024).  KLARA_DENSE_SPLIT=1 in the environment puts the smaller
+// the dense Gaussian beyond D = 256 (round 6): the tile of 16 chains on a WORKGROUP of W = 4, 8, 12 or 16 wavefronts that deal the ceil(D / 16) row tiles
+// of P evenly, 2 .. 4 each (klara_dense_split.h, layout kind 6; MH, MALA, HMC with every tuner; 257 <= D <= 1024).  KLARA_DENSE_SPLIT=1 in the environment puts the smaller
 // dense targets on it as well (measurements, tests).
 static bool dense_split(const klara_desc& d)
 {
@@ -232,7 +232,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     if (logit_mfma_eligible(d)) { *kind = 5; *G = 4; *E = 8 * ((d.ndims + 31) / 32); return KLARA_OK; }
     if (hiert_eligible(d)) { *kind = 4; *G = 8; *E = 8; return KLARA_OK; }
     const int D = d.ndims;
-    if (dense_split(d)) { *kind = 6; *G = (D + 63) / 64; *E = 16; return KLARA_OK; }      // G: wavefronts per tile of 16 chains
+    if (dense_split(d)) { *kind = 6; *G = 4 * (((D + 15) / 16 + 15) / 16); *E = 16; return KLARA_OK; }      // G: wavefronts per tile of 16 chains (klara_split_waves)
     if (d.target == KLARA_TARGET_GAUSS_DENSE) {
         *kind = 1; *G = 4;
         if (D <= 32) *E = 8; else if (D <= 64) *E = 16; else if (D <= 100) *E = 25; else if (D <= 128) *E = 32;
@@ -749,11 +749,12 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
         h->lpconst = (double)desc->ndims * kd_log(2.0 * 3.141592653589793 * desc->logit_lambda);
     } else {
         // fragment-ordered, zero-padded P for the MFMA A operand (klara_dense.h)
-        // (layout kind 6: NE = 16 W k-steps of MT = 4 W tiles, k-major, and two k-steps of zeros behind them — the ring's last prefetch, klara_dense_split.h)
-        const int NE = kind == 6 ? 16 * G : E, MT = (NE + 3) / 4;
-        std::vector<double> frag((size_t)MT * (NE + (kind == 6 ? 2 : 0)) * 64, 0.0);
+        // (layout kind 6: ceil(D / 4) k-steps of MT = ceil(D / 16) tiles, k-major, and KLARA_SPLIT_PAD = 8 k-steps of zeros behind them — the ring's last
+        // prefetch, klara_dense_split.h)
+        const int NE = kind == 6 ? (D + 3) / 4 : E, MT = kind == 6 ? (D + 15) / 16 : (NE + 3) / 4;
+        std::vector<double> frag((size_t)MT * (NE + (kind == 6 ? 8 : 0)) * 64, 0.0);
         // (NE % 4 == 1: the last tile is the 4-row tail for v_mfma_f64_4x4x4_4b, A_b[i][k] on lane 16k + 4b + i)
-        const bool tail = (NE % 4) == 1;
+        const bool tail = kind != 6 && (NE % 4) == 1;
         // tile-major (t, kk) for the LDS-resident layouts; k-major (kk, t) — the order of consumption — for the streamed ones (NE > 32)
         const bool kmajor = NE > 32 || kind == 6;
         for (int t = 0; t < MT; ++t)
@@ -766,7 +767,7 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
         h->dense_mu = desc->gauss_mu != nullptr;
         if (h->dense_mu) {                                       // the mean, [4 e + q] = mu[4 e + q], zero beyond D
             const size_t at = frag.size();
-            frag.resize(at + 4 * (size_t)NE, 0.0);
+            frag.resize(at + 4 * (size_t)(kind == 6 ? 4 * MT : NE) + (kind == 6 ? 32 : 0), 0.0);         // (kind 6: 4 MT rows + KLARA_SPLIT_PAD the pass's last prefetch touches)
             for (int i = 0; i < D; ++i) frag[at + i] = desc->gauss_mu[i];
         }
         CK(upload(&h->Pfrag, frag.data(), frag.size()));
@@ -1081,7 +1082,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
     if (mode == 3 && kl.nsteps == 1) mode = 7;                                 // one iterate! per launch
     if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, plain, h->E, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
     if (h->kind == 5) return klara_launch_logit_mfma(p, kl, d.sampler, d.tuner == KLARA_TUNER_DUAL_AVERAGING, h->E, h->Pfrag, h->ly, h->logit_nblocks, grid_for(h), h->stream);
-    if (h->kind == 6) return klara_launch_dense_split(p, kl, d.sampler, d.tuner == KLARA_TUNER_DUAL_AVERAGING, h->G, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
+    if (h->kind == 6) return klara_launch_dense_split(p, kl, d.sampler, d.tuner == KLARA_TUNER_DUAL_AVERAGING, h->G, d.ndims, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on

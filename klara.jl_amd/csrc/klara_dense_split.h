@@ -1,40 +1,50 @@
 // klara_dense_split.h — the dense-Gaussian target beyond D = 256 on the FP64 matrix cores: a WORKGROUP carries the tile of 16 chains (layout kind 6).
 //
 // klara_dense_big.h gives one wavefront the whole vectors of its 16 chains: NE = 64 elements per lane at D = 256 is what 256 architectural + 256
-// accumulator registers hold, at one wavefront per SIMD.  Beyond that neither the value nor the gradient fits a lane.  Here the W = ceil(D / 64)
-// wavefronts of a workgroup SHARE the tile: wavefront w owns the 16 elements e = 16 w .. 16 w + 15 of every lane's column (lane (q, chain) of
-// klara_dense.h: dimension i = 4 e + q), i.e. the rows 64 w .. 64 w + 63 of the gradient  G' = P X'  — four 16-row tiles of
-// v_mfma_f64_16x16x4 — and the same rows of every element-wise update (normals, proposal, kicks, sums).  What a wavefront needs from the others is
-// the B operand of its matrix pass, the whole (x - mu) of the 16 chains: every wavefront writes its 16 elements per lane to the LDS block
-// xb[k-step][lane] (conflict-free 8-byte writes: 8 KB per wavefront), a barrier, and the pass reads one 512-byte row per k-step.  The A fragments
-// come from the same k-major stream as klara_dense_big.h's, ((kk * MT + t) * 64 + lane), MT = 4 W: the four tiles of wavefront w are 2 KB in a row per
-// k-step, taken through a ring of 8 buffer loads with scalar offsets.  The sums of a transition (x.g, the proposal terms, the kinetic energy)
-// are lane partials over the lane's 16 elements in ascending order, the 4-lane tree (q0 + q1) + (q2 + q3) inside the wavefront, then the
-// wavefronts' values in ascending order through LDS — the oracle's layout kind 6 (G = W, E = 16).
+// accumulator registers hold, at one wavefront per SIMD.  Beyond that neither the value nor the gradient fits a lane.  Here the W wavefronts of a
+// workgroup SHARE the tile.  The gradient  G' = P X'  has MT = ceil(D / 16) row tiles of v_mfma_f64_16x16x4; W = 4 ceil(MT / 16) (4, 8, 12, 16: whole
+// SIMD rounds) and wavefront w owns the T = 2 .. 4 CONSECUTIVE tiles t0 .. t0 + T - 1 of an even deal (the first MT % W wavefronts one more than the
+// rest: every SIMD carries the same number of tiles +- 1 whatever D is), i.e. the elements e = 4 t0 .. 4 (t0 + T) - 1 of every lane's column (lane
+// (q, chain) of klara_dense.h: dimension i = 4 e + q) — the rows of its tiles — in the matrix pass and in every element-wise update (normals,
+// proposal, kicks, sums).  What a wavefront needs from the others is the B operand of its pass, the whole proposal x of the 16 chains: every wavefront
+// writes its elements to the LDS block xb[k-step = element][lane] (conflict-free 8-byte writes), a barrier, and the pass reads one 512-byte row per
+// k-step (the mean is subtracted there).  The A fragments come from a k-major stream, ((kk * MT + t) * 64 + lane): the tiles of a wavefront are T x 512
+// bytes in a row per k-step, taken through a ring of 2 T buffer loads with scalar offsets.  The sums of a transition (x.g, the proposal terms, the
+// kinetic energy) are lane partials over the lane's elements in ascending order, the 4-lane tree (q0 + q1) + (q2 + q3) inside the wavefront, then the
+// wavefronts' values in ascending order through LDS — the oracle's layout kind 6 (G = W).
 //
-// A wavefront holds 16 elements per lane whatever D is: one kernel per sampler serves 257 <= D <= 1024 (W = 5 .. 16 wavefronts; the K loop and the
-// wavefront count are run-time values), at 2 .. 4 wavefronts per SIMD — the vector work of one (Box-Muller: 85 % of MALA's vector instructions) runs
-// under the matrix passes of the others, which the 512-register kernels of klara_dense_big.h cannot do.
-// The state follows klara_dense.h's k_dense_transitions: registers hold the proposal, X / GR the committed state (written at every accept,
-// re-read after a reject); MALA's backward term reads the current value from X.
+// One kernel per sampler serves 257 <= D <= 1024 (every count is a run-time value), at 3 .. 4 wavefronts per SIMD: the vector work of one (Box-Muller:
+// 85 % of MALA's vector instructions) runs under the matrix passes of the others, which the 512-register kernels of klara_dense_big.h cannot do.
+// The committed state lives in X / GR (written at every accept) and a transition reads what it needs from there, 8 elements at a time; the
+// proposal is formed in the lane's own column of xb and found there again by the element-wise passes after the matrix pass.  Registers hold the
+// pass's accumulators, its ring and, for HMC, the momentum.
 // MH, MALA, HMC (every tuner, dual averaging with per-chain trip counts), every monitor of the dense layouts.
 #pragma once
 #include "klara_dense.h"
 
 #define KLARA_SPLIT_NEW 16             // elements per lane and wavefront
 #define KLARA_SPLIT_WMAX 16            // wavefronts per workgroup (D <= 1024)
+#define KLARA_SPLIT_PAD 8              // k-steps of zeros behind the stream and rows behind the mean (>= R / 4 for every ring)
+#define KLARA_SPLIT_CH 8               // elements per group of loads (state, mean) in the element-wise passes
 
 struct SplitCtx {
-    MfmaCtx<KLARA_SPLIT_NEW> m;        // the wavefront's 16 elements per lane as a 16-element column: offsets and validity shifted by 16 w
+    MfmaCtx<KLARA_SPLIT_NEW> m;        // the wavefront's <= 16 elements per lane as a 16-element column: offsets and validity shifted by its first element
     int w, W;                          // this wavefront, wavefronts per workgroup (scalars)
-    double* xb;                        // LDS: the tile's x - mu, [k-step = element][lane]  (+ two rows the last prefetch may touch)
+    int MT, t0, T;                     // row tiles of P; this wavefront's first tile and tile count (scalars); its elements: 4 t0 .. 4 (t0 + T) - 1
+    int ksteps;                        // ceil(D / 4): the k-steps that are not all padding
+    double* col;                       // LDS: this lane's column of xb, element e at col[e * 64]
+    const double* xb;                  // LDS: the tile's proposal x, [k-step = element][lane]
     double* rbuf;                      // LDS: 2 x [value][wavefront][chain] partial sums (ping-pong)
-    const double* ldsMu;               // LDS: mu[4 e + q] at [4 e + q], zero-padded (HASMU)
-    __amdgpu_buffer_rsrc_t wP;         // the fragment stream
+    __amdgpu_buffer_rsrc_t wP;         // the fragment stream (+ the mean behind it)
+    unsigned muoff;                    // byte offset of mu[0] in the stream
     unsigned par;                      // reduction parity
+    // element e of the lane's 16-element column belongs to this wavefront (e < 4 T: a scalar test); the rows of xb behind it are the next wavefront's
+    __device__ __forceinline__ bool own(int e) const { return (e >> 2) < T; }
+    __device__ __forceinline__ double rd(int e) const { return own(e) ? col[e * 64] : 0.0; }
+    __device__ __forceinline__ void wr(int e, double v) const { if (own(e)) col[e * 64] = v; }
 };
 
-__device__ __forceinline__ SplitCtx make_sctx(const KParams& p, const double* Pfrag, char* smem, bool hasmu)
+__device__ __forceinline__ SplitCtx make_sctx(const KParams& p, const double* Pfrag, char* smem)
 {
     SplitCtx s;
     MfmaCtx<KLARA_SPLIT_NEW>& c = s.m;
@@ -48,138 +58,187 @@ __device__ __forceinline__ SplitCtx make_sctx(const KParams& p, const double* Pf
     c.here = left < 16 ? (left > 0 ? (int)left : 0) : 16;
     c.chain = c.first_chain + c.cl;
     c.chain_ok = c.cl < c.here;
-    int nv = c.chain_ok ? (p.D - c.q + 3) / 4 - KLARA_SPLIT_NEW * s.w : 0;
-    c.nv = nv < 0 ? 0 : (nv > KLARA_SPLIT_NEW ? KLARA_SPLIT_NEW : nv);
-    c.voff0 = (unsigned)((c.cl * p.D + c.q) * 8 + 32 * KLARA_SPLIT_NEW * s.w);
-    const int NE = KLARA_SPLIT_NEW * s.W;
-    s.xb = reinterpret_cast<double*>(smem);
-    s.rbuf = s.xb + (size_t)(NE + 2) * 64;
-    s.ldsMu = s.rbuf + 2 * 3 * KLARA_SPLIT_WMAX * 16;
+    s.MT = (p.D + 15) >> 4;
+    {
+        const int base = s.MT / s.W, rem = s.MT - base * s.W;
+        s.T = base + (s.w < rem ? 1 : 0);
+        s.t0 = s.w * base + (s.w < rem ? s.w : rem);
+    }
+    const int eb = 4 * s.t0;
+    int nv = c.chain_ok ? (p.D - c.q + 3) / 4 - eb : 0;
+    c.nv = nv < 0 ? 0 : (nv > 4 * s.T ? 4 * s.T : nv);
+    c.voff0 = (unsigned)((c.cl * p.D + c.q) * 8 + 32 * eb);
+    const int NE = 4 * s.MT;                                      // rows of xb: every wavefront's elements
+    double* const xb = reinterpret_cast<double*>(smem);
+    s.xb = xb;
+    s.col = xb + (size_t)eb * 64 + c.lane;
+    s.rbuf = xb + (size_t)NE * 64;
     const unsigned long long a = (unsigned long long)Pfrag;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    s.ksteps = (p.D + 3) >> 2;
+    s.muoff = (unsigned)(s.MT * (s.ksteps + KLARA_SPLIT_PAD)) * 512u;
     s.wP = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
-                                             __builtin_amdgcn_readfirstlane(4 * s.W * (NE + 2) * 512), 0x00020000);
+                                             __builtin_amdgcn_readfirstlane((int)s.muoff + 32 * (NE + KLARA_SPLIT_PAD)), 0x00020000);
     s.par = 0u;
     return s;
 }
-// LDS bytes of a workgroup of W wavefronts
-static inline size_t klara_split_lds_bytes(int W, bool hasmu)
+// wavefronts per tile of 16 chains: whole SIMD rounds, at most 4 row tiles per wavefront
+static inline int klara_split_waves(int D) { const int MT = (D + 15) / 16; return 4 * ((MT + 15) / 16); }
+// LDS bytes of a workgroup: xb (4 MT rows) + the partial sums (the 8 KB of detmath tables are static)
+static inline size_t klara_split_lds_bytes(int D)
 {
-    const size_t NE = (size_t)KLARA_SPLIT_NEW * W;
-    return sizeof(double) * ((NE + 2) * 64 + 2 * 3 * KLARA_SPLIT_WMAX * 16 + (hasmu ? 4 * NE : 0));
+    const size_t MT = ((size_t)D + 15) / 16;
+    return sizeof(double) * (4 * MT * 64 + 2 * 3 * (size_t)klara_split_waves(D) * 16);
 }
 
-// acc[j] = tile 4 w + j of +P (x - mu), from zero: the K loop over the NE = 16 W rows of xb, two k-steps (8 fragments = the ring) per trip
-__device__ __forceinline__ void split_pass(const SplitCtx& s, kd_double4 (&acc)[4])
+// mu of the lane's element e (HASMU; zero past D)
+__device__ __forceinline__ double split_mu(const SplitCtx& s, int e)
 {
-    const int NE = KLARA_SPLIT_NEW * s.W;
-    const unsigned strideK = (unsigned)(4 * s.W) * 512u;          // bytes between k-steps: MT fragments
-    const unsigned voff = (unsigned)s.m.lane * 8u;
-    unsigned soff = (unsigned)s.w * 2048u;                        // this wavefront's four tiles inside a k-step
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(s.wP, (unsigned)s.m.q * 8u, s.muoff + (unsigned)(4 * s.t0 + e) * 32u, 0));
+}
+
+// acc[j] = tile t0 + j of +P (x - mu), from zero (j < T; the others stay zero): the K loop over the ceil(D / 4) rows of xb that are not padding, two
+// k-steps per trip.  The A fragments go through a ring of 2 T buffer loads: a fragment is requested one trip (2 T x 64 matrix cycles) before its use and
+// the wavefronts of a tile read DIFFERENT tiles of a k-step, so a request is served by the L2 — or, at D = 1024, where P is 8 MB, from beyond it —, not
+// by a line a neighbour just brought into the L1: the 3 .. 4 wavefronts per SIMD cover that, a deeper ring measured slower (registers).  The B operand
+// comes one k-step ahead from LDS.  The stream ends with KLARA_SPLIT_PAD k-steps of zeros and the mean with as many rows (a scalar offset is not
+// range-checked): no guard on the last prefetch.
+template <bool HASMU, int T>
+__device__ __forceinline__ void split_pass_t(const SplitCtx& s, kd_double4 (&acc)[4])
+{
+    const unsigned strideK = (unsigned)s.MT * 512u;               // bytes between k-steps: MT fragments
+    const unsigned voff = (unsigned)s.m.lane * 8u, vq = (unsigned)s.m.q * 8u;
+    unsigned soff = (unsigned)s.t0 * 512u;                        // this wavefront's tiles inside a k-step
+    unsigned moff = s.muoff;
+    double ring[2 * T];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };
-    double ring[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        ring[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(s.wP, voff, soff + (unsigned)(i >> 2) * strideK + (unsigned)(i & 3) * 512u, 0));
+    for (int i = 0; i < 2 * T; ++i)
+        ring[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(s.wP, voff, soff + (unsigned)(i / T) * strideK + (unsigned)(i % T) * 512u, 0));
     const double* xl = s.xb + s.m.lane;
-    double b0 = xl[0], b1 = xl[64];
-    for (int k2 = 0; k2 < NE; k2 += 2) {
+    const double* const xend = xl + (size_t)(4 * s.MT - 1) * 64;
+    double bn = xl[0];
+    if (HASMU) bn = bn - __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(s.wP, vq, moff, 0));
+    for (int k0 = 0; k0 < s.ksteps; k0 += 2) {
         soff += 2u * strideK;
-        xl += 128;
-        const double n0 = xl[0], n1 = xl[64];                     // (the last trip reads the two spare rows)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const double a = ring[i];
-            // (the stream ends with two k-steps of zeros: no guard on the last trip — a scalar offset is not range-checked)
-            ring[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(s.wP, voff, soff + (unsigned)(i >> 2) * strideK + (unsigned)(i & 3) * 512u, 0));
-            acc[i & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, i < 4 ? b0 : b1, acc[i & 3], 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) {
+            const double b = bn;
+            xl = xl < xend ? xl + 64 : xl;                        // (the last k-step reads its own row again)
+            moff += 32u;
+            bn = xl[0];
+            if (HASMU) bn = bn - __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(s.wP, vq, moff, 0));
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const int i = T * kk + j;
+                // (the matrix instruction first, then the load INTO the register it has just read: written the other way round the new value needs a
+                // register of its own and the loop's back edge a copy per fragment behind a wait for every load of the trip)
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[i], b, acc[j], 0, 0, 0);
+                ring[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(s.wP, voff, soff + (unsigned)kk * strideK + (unsigned)j * 512u, 0));
+            }
         }
-        b0 = n0; b1 = n1;
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-
-// g = -+P (x - mu) for the lane's 16 elements of the proposal x: every wavefront publishes its part of x - mu, then takes its rows of the product.
-// PRE: a pass may still be reading xb (no barrier since the previous one: the leapfrog loop)
-template <bool HASMU, bool NEG, bool PRE>
-__device__ __forceinline__ void split_grad(const SplitCtx& s, const double (&x)[KLARA_SPLIT_NEW], double (&g)[KLARA_SPLIT_NEW])
+template <bool HASMU>
+__device__ __forceinline__ void split_pass(const SplitCtx& s, kd_double4 (&acc)[4])
 {
-    if (PRE) __syncthreads();
-    double* const col = s.xb + (size_t)(KLARA_SPLIT_NEW * s.w) * 64 + s.m.lane;
-    const double* const mu = s.ldsMu + 4 * KLARA_SPLIT_NEW * s.w + s.m.q;
 #pragma unroll
-    for (int e = 0; e < KLARA_SPLIT_NEW; ++e) col[e * 64] = HASMU ? x[e] - mu[4 * e] : x[e];
-    __syncthreads();
-    kd_double4 acc[4];
-    split_pass(s, acc);
-#pragma unroll
-    for (int e = 0; e < KLARA_SPLIT_NEW; ++e) g[e] = NEG ? -acc[e >> 2][e & 3] : acc[e >> 2][e & 3];
+    for (int j = 0; j < 4; ++j) acc[j] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };
+    switch (s.T) {                                                // (a scalar)
+    case 4: split_pass_t<HASMU, 4>(s, acc); break;
+    case 3: split_pass_t<HASMU, 3>(s, acc); break;
+    case 2: split_pass_t<HASMU, 2>(s, acc); break;
+    case 1: split_pass_t<HASMU, 1>(s, acc); break;
+    default: break;                                               // (fewer tiles than wavefronts: nothing of the product is this wavefront's)
+    }
 }
 
-// all-reduce of N sums over the tile's W wavefronts: 4-lane tree inside the wavefront, then the wavefronts in ascending order (oracle: layout kind 6)
+// all-reduce of N sums over the tile's W wavefronts: 4-lane tree inside the wavefront, then the wavefronts in ascending order (oracle: layout kind 6).
+// Its barrier also closes the matrix pass before it: once a wavefront is through, every wavefront of the tile has finished reading xb.
 template <int N>
 __device__ __forceinline__ void split_reduce(SplitCtx& s, double (&v)[N])
 {
     static_assert(N <= 3, "rbuf holds three values");
     mreduce<N>(v, s.m.lane);
-    double* const rb = s.rbuf + (size_t)(s.par & 1u) * 3 * KLARA_SPLIT_WMAX * 16;
+    double* const rb = s.rbuf + (size_t)(s.par & 1u) * 3 * s.W * 16;
     s.par ^= 1u;
     if (s.m.q == 0) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) rb[(i * KLARA_SPLIT_WMAX + s.w) * 16 + s.m.cl] = v[i];
+        for (int i = 0; i < N; ++i) rb[(i * s.W + s.w) * 16 + s.m.cl] = v[i];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        double t = rb[(i * KLARA_SPLIT_WMAX) * 16 + s.m.cl];
-        for (int w2 = 1; w2 < s.W; ++w2) t = t + rb[(i * KLARA_SPLIT_WMAX + w2) * 16 + s.m.cl];
+        double t = rb[(i * s.W) * 16 + s.m.cl];
+        for (int w2 = 1; w2 < s.W; ++w2) t = t + rb[(i * s.W + w2) * 16 + s.m.cl];
         v[i] = t;
     }
 }
 
-// normals of the lane's 16 elements (mnormals of klara_dense.h with the element index 16 w + e: the pair's block slot moves by 16 w)
-__device__ __forceinline__ void split_normals(const SplitCtx& s, unsigned long long seed, unsigned long long gchain, unsigned long long t,
-                                              double (&z)[KLARA_SPLIT_NEW])
+// normals of the lane's elements, handed to f(e, z) in ascending e — consumed where they are drawn: no array of them.  mnormals of klara_dense.h for
+// a column that starts at element 4 t0: the four elements of row tile G = t0 + g take their two Box-Muller pairs from half G & 1 of the blocks
+// 8 (G >> 1) + {0, 4} + lane slot (words (x, y) for an even tile, (z, w) for an odd one: one pair of blocks per two tiles, formed at the even tile or at
+// the wavefront's first).
+template <class F>
+__device__ __forceinline__ void split_normals_each(const SplitCtx& s, unsigned long long seed, unsigned long long gchain, unsigned long long t, F f)
 {
     const MfmaCtx<KLARA_SPLIT_NEW>& c = s.m;
     const uint32_t sh = (uint32_t)(c.q >> 1);
     const bool odd = (c.q & 1) != 0;
     const int nv = c.nv_here();
-    const uint32_t lane_slot = (odd ? 2u : 0u) + sh + 16u * (uint32_t)s.w;
-    MPairStash st = { { 0u, 0u, 0u, 0u } };
+    const uint32_t lane_slot = (odd ? 2u : 0u) + sh;
+    uint32_t st[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
-    for (int e = 0; e + 1 < KLARA_SPLIT_NEW; e += 2) {
-        double z0, z1;
-        mpair_normals(seed, gchain, t, e, lane_slot, st, z0, z1);
-        const double recv = bperm_xor(odd ? z0 : z1, c.lane, 16);
-        z[e] = e < nv ? (odd ? recv : z0) : 0.0;
-        z[e + 1] = e + 1 < nv ? (odd ? z1 : recv) : 0.0;
-        __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < 4; ++g) {
+        if (g < s.T) {
+            const int G = s.t0 + g;
+            const bool half = (G & 1) != 0;
+            uint32_t wa[2], wb[2];
+            if (!half || g == 0) {
+                const uint32_t slot = 8u * (uint32_t)(G >> 1) + lane_slot;
+                const kd_u32x4 b0 = kd_stream_block(seed, gchain, t, slot), b1 = kd_stream_block(seed, gchain, t, slot + 4u);
+                wa[0] = half ? b0.z : b0.x; wb[0] = half ? b0.w : b0.y; wa[1] = half ? b1.z : b1.x; wb[1] = half ? b1.w : b1.y;
+                st[0] = b0.z; st[1] = b0.w; st[2] = b1.z; st[3] = b1.w;
+            } else {
+                wa[0] = st[0]; wb[0] = st[1]; wa[1] = st[2]; wb[1] = st[3];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 4 * g + 2 * h;
+                double z0, z1, u1, lg;
+                kd_normal_pair_w(wa[h], wb[h], &z0, &z1, &u1, &lg);
+                const double recv = bperm_xor(odd ? z0 : z1, c.lane, 16);
+                f(e, e < nv ? (odd ? recv : z0) : 0.0);               // even q: cos half of pair(e);   odd q: sin half of pair(e) from the partner
+                f(e + 1, e + 1 < nv ? (odd ? z1 : recv) : 0.0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 }
 
-template <int SAMPLER, bool DA, bool HASMU, int WB>
-__global__ __launch_bounds__(64 * WB)
+// 8 elements e0 .. e0 + 7 of the lane's column of a (chains x D) array
+__device__ __forceinline__ void split_load8(const MfmaCtx<KLARA_SPLIT_NEW>& c, __amdgpu_buffer_rsrc_t w, int e0, int nv, double (&v)[KLARA_SPLIT_CH])
+{
+#pragma unroll
+    for (int j = 0; j < KLARA_SPLIT_CH; ++j) v[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(w, c.off_fresh(e0 + j, nv), 0, 0));
+}
+
+// MW: wavefronts per SIMD the registers allow (3: 168 registers, workgroups of up to 6 wavefronts; 4: 128)
+template <int SAMPLER, bool DA, bool HASMU, int MW>
+__global__ __launch_bounds__(256 * MW)
 void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
 {
     static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH, "HMC, MALA, MH");
     static_assert(!DA || SAMPLER == KLARA_SAMPLER_HMC, "dual averaging is wired into HMC only (HMC.jl:124-133)");
-    constexpr int NE = KLARA_SPLIT_NEW;
+    constexpr int NE = KLARA_SPLIT_NEW, CH = KLARA_SPLIT_CH;
+    constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;
     const KParams& p = *pp;
     guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    SplitCtx sc = make_sctx(p, Pfrag, smem, HASMU);
+    SplitCtx sc = make_sctx(p, Pfrag, smem);
     const MfmaCtx<NE>& cx = sc.m;
-    {
-        const int NEt = NE * sc.W;
-        double* const muW = const_cast<double*>(sc.ldsMu);
-        if (HASMU) { for (int i = threadIdx.x; i < 4 * NEt; i += blockDim.x) muW[i] = Pfrag[(size_t)4 * sc.W * (NEt + 2) * 64 + i]; }
-        for (int i = threadIdx.x; i < 128; i += blockDim.x) sc.xb[(size_t)NEt * 64 + i] = 0.0;        // the spare rows
-    }
-    kd_tables_to_lds();          // (also the barrier for mu)
+    kd_tables_to_lds();
     const bool w0 = sc.w == 0;
-    const auto dx = [&](const double (&v)[NE], int e) { return HASMU ? v[e] - sc.ldsMu[4 * (NE * sc.w + e) + cx.q] : v[e]; };
     const auto gch = [&]() { return (unsigned long long)(p.chain_offset + cx.chain_here()); };       // global chain id: the Philox subsequence
     const long long tix = p.pooled ? 0 : (cx.chain_ok ? cx.chain : 0);
     constexpr bool da = DA;
@@ -195,52 +254,79 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
     const bool do_sum = p.sum != nullptr;
     long long held = do_sum ? p.held[cx.chain_ok ? cx.chain : 0] : 0;        // running sums in sojourn form (KParams::held)
 
-    double xp[NE], gp[NE];
-    bool have = false;           // the registers hold the committed state (the last proposal was accepted)
+    // The committed state lives in X / GR (written at every accept); a transition reads what it needs from there in groups of 8 elements, forms its
+    // proposal in the lane's column of xb — where the matrix pass takes its B operand and the element-wise passes after it find the proposal again —
+    // and keeps only the pass's accumulators (the proposal's gradient) and, for HMC, the momentum in registers.
     for (int s = 0; s < kl.nsteps; ++s) {
         const unsigned long long t = kl.t0 + (unsigned long long)s;
         if (cnt) tune_count_proposal(p, tn);
         bool acc = false;
         double ltp = lt;
-        if (!have) mload<NE>(cx, p.X, p.D, xp);                        // current value
+        kd_double4 ga[4];                                              // +P (x' - mu) of the lane's 16 elements: element e = ga[e >> 2][e & 3]
+        const __amdgpu_buffer_rsrc_t wX = mwin<NE>(cx, p.X, 0, p.D), wG = mwin<NE>(cx, p.GR, 0, p.D);
+        // lt' = c + 1/2 (x' - mu).g' with g' = -ga: the lane's part
+        const auto lt_part = [&]() {
+            double l1 = 0.0;
+#pragma unroll
+            for (int e0 = 0; e0 < NE; e0 += CH) {
+                double xv[CH], mv[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) { xv[j] = sc.rd(e0 + j); mv[j] = HASMU ? split_mu(sc, e0 + j) : 0.0; }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) l1 = l1 + (HASMU ? xv[j] - mv[j] : xv[j]) * -(double)ga[(e0 + j) >> 2][(e0 + j) & 3];
+            }
+            return l1;
+        };
 
         if constexpr (SAMPLER == KLARA_SAMPLER_HMC) {
             // iterate/HMC.jl:124-201, leapfrog! samplers.jl:122-134 (merged fma form: DESIGN.md section 2 (7))
-            double mom[NE], red[2];
-            if (!have) mload<NE>(cx, p.GR, p.D, gp);                   // HMC.jl:140
-            split_normals(sc, p.seed, gch(), t, mom);                  // HMC.jl:135
-            double k0[1] = { 0.0 };
+            double mom[NE];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) k0[0] = k0[0] + mom[e] * mom[e];
-            split_reduce<1>(sc, k0);
-            const double H0 = lt - 0.5 * k0[0];                        // HMC.jl:137
+            for (int e = 0; e < NE; ++e) mom[e] = 0.0;                   // (elements past the wavefront's tiles: no normals are drawn for them)
             const double eps = tn.step, halfe = 0.5 * eps;
+            double k0[1] = { 0.0 };
+            split_normals_each(sc, p.seed, gch(), t, [&](int e, double z) { mom[e] = z; k0[0] = k0[0] + z * z; });        // HMC.jl:135
+            split_reduce<1>(sc, k0);                                   // (its barrier: nobody still reads xb)
+            const double H0 = lt - 0.5 * k0[0];                        // HMC.jl:137
+            {
+                const int nv = cx.nv_here();
 #pragma unroll
-            for (int e = 0; e < NE; ++e) mom[e] = kd_fma(halfe, gp[e], mom[e]);
+                for (int e0 = 0; e0 < NE; e0 += CH) {
+                    double xv[CH], gv[CH];
+                    split_load8(cx, wX, e0, nv, xv);                   // HMC.jl:139
+                    split_load8(cx, wG, e0, nv, gv);                   // HMC.jl:140
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        mom[e0 + j] = kd_fma(halfe, gv[j], mom[e0 + j]);
+                        sc.wr(e0 + j, xv[j]);
+                    }
+                }
+            }
             // dual averaging: per-chain trip count (iterate/HMC.jl:142-144); the tile runs to its longest trajectory (the same count in every
-            // wavefront: each holds all 16 chains), a finished chain's lanes keep their state
+            // wavefront: each holds all 16 chains).  A finished chain's value and momentum stop changing, so the gradient the later passes recompute
+            // for it is the one it already has, bit for bit: only the two updates are masked.
             const int nl = da ? (cx.chain_ok ? da_nleaps(p, eps) : 1) : p.nleaps;
             for (int l = 0; da ? __any(l < nl) : (l < nl); ++l) {
                 const bool go = !da || l < nl;
+                if (l > 0) __syncthreads();                            // the previous pass is over in every wavefront: xb may change
 #pragma unroll
-                for (int e = 0; e < NE; ++e) { const double v = kd_fma(eps, mom[e], xp[e]); xp[e] = go ? v : xp[e]; }
-                double gn[NE];
-                split_grad<HASMU, false, true>(sc, xp, gn);
+                for (int e0 = 0; e0 < NE; e0 += CH) {
+                    double xv[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) xv[j] = sc.rd(e0 + j);
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) { const double v = kd_fma(eps, mom[e0 + j], xv[j]); sc.wr(e0 + j, go ? v : xv[j]); }
+                }
+                __syncthreads();
+                split_pass<HASMU>(sc, ga);
                 const double nkf = l + 1 < nl ? -eps : -halfe;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    const double v = kd_fma(nkf, gn[e], mom[e]);
-                    mom[e] = go ? v : mom[e];
-                    gp[e] = go ? -gn[e] : gp[e];
-                }
+                for (int e = 0; e < NE; ++e) { const double v = kd_fma(nkf, (double)ga[e >> 2][e & 3], mom[e]); mom[e] = go ? v : mom[e]; }
             }
-            double l1 = 0.0, k1 = 0.0;
+            double red[2], k1 = 0.0;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                l1 = l1 + dx(xp, e) * gp[e];                           // lt' = c + 1/2 (x'-mu).g'   (HMC.jl:157)
-                k1 = k1 + mom[e] * mom[e];
-            }
-            red[0] = l1; red[1] = k1;
+            for (int e = 0; e < NE; ++e) k1 = k1 + mom[e] * mom[e];
+            red[0] = lt_part(); red[1] = k1;                           // lt' = c + 1/2 (x'-mu).g'   (HMC.jl:157)
             split_reduce<2>(sc, red);
             ltp = p.gconst + 0.5 * red[0];
             const double H1 = ltp - 0.5 * red[1];                      // HMC.jl:159
@@ -253,31 +339,40 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
         } else if constexpr (SAMPLER == KLARA_SAMPLER_MALA) {
             // iterate/MALA.jl:78-128
             double red[3];
-            const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h), inv_h = 1.0 / h, half_inv_h = 0.5 * inv_h;
-            if (!have) mload<NE>(cx, p.GR, p.D, gp);
+            const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h), half_inv_h = 0.5 * (1.0 / h);
             double s1 = 0.0;
             {
-                double z[NE];
-                split_normals(sc, p.seed, gch(), t, z);
-#pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    const double mu = xp[e] + halfh * gp[e];           // MALA.jl:83
-                    xp[e] = mu + sq * z[e];                            // MALA.jl:84
-                    const double q1 = mu - xp[e];
+                const int nv = cx.nv_here();
+                double xv[CH], gv[CH];
+                split_load8(cx, wX, 0, nv, xv); split_load8(cx, wG, 0, nv, gv);
+                split_normals_each(sc, p.seed, gch(), t, [&](int e, double z) {
+                    const double mu = xv[e & (CH - 1)] + halfh * gv[e & (CH - 1)];          // MALA.jl:83
+                    const double xn = mu + sq * z;                     // MALA.jl:84
+                    sc.col[e * 64] = xn;
+                    const double q1 = mu - xn;
                     s1 = s1 + (q1 * q1) * half_inv_h;                  // MALA.jl:90
-                }
+                    if (e == CH - 1) { split_load8(cx, wX, CH, nv, xv); split_load8(cx, wG, CH, nv, gv); }
+                });
             }
-            split_grad<HASMU, true, false>(sc, xp, gp);                // MALA.jl:86
+            __syncthreads();
+            split_pass<HASMU>(sc, ga);                                 // MALA.jl:86
             double l1 = 0.0, s2 = 0.0;
             {
-                double xc[NE];
-                mload<NE>(cx, p.X, p.D, xc);                           // the current value (X holds the committed state)
+                const int nv = cx.nv_here();
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    l1 = l1 + dx(xp, e) * gp[e];
-                    const double mup = xp[e] + halfh * gp[e];          // MALA.jl:91
-                    const double q2 = mup - xc[e];
-                    s2 = s2 + (q2 * q2) * half_inv_h;                  // MALA.jl:92
+                for (int e0 = 0; e0 < NE; e0 += CH) {
+                    double xc[CH], xn[CH], mv[CH];
+                    split_load8(cx, wX, e0, nv, xc);                   // the current value (X holds the committed state)
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) { xn[j] = sc.rd(e0 + j); mv[j] = HASMU ? split_mu(sc, e0 + j) : 0.0; }
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const double g = -(double)ga[(e0 + j) >> 2][(e0 + j) & 3];
+                        l1 = l1 + (HASMU ? xn[j] - mv[j] : xn[j]) * g;
+                        const double mup = xn[j] + halfh * g;          // MALA.jl:91
+                        const double q2 = mup - xc[j];
+                        s2 = s2 + (q2 * q2) * half_inv_h;              // MALA.jl:92
+                    }
                 }
             }
             red[0] = l1; red[1] = s1; red[2] = s2;
@@ -295,20 +390,24 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
             // iterate/MH.jl:72-124
             double red[1];
             {
-                double z[NE];
-                split_normals(sc, p.seed, gch(), t, z);
+                const int nv = cx.nv_here();
+                const __amdgpu_buffer_rsrc_t wS = __builtin_amdgcn_make_buffer_rsrc((void*)p.vecparam, 0, p.D * 8, 0x00020000);
+                const unsigned so = (unsigned)(16 * sc.t0 + cx.q) * 8u;
+                double xv[CH], sg[CH];
+                const auto ld = [&](int e0) {
+                    split_load8(cx, wX, e0, nv, xv);
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    const int i = 4 * (NE * sc.w + e) + cx.q;
-                    const double sg = i < p.D ? p.vecparam[i] : 0.0;
-                    xp[e] = xp[e] + sg * z[e];                         // MH.jl:79
-                }
+                    for (int j = 0; j < CH; ++j) sg[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wS, so + 32u * (unsigned)(e0 + j), 0, 0));   // (0 past D)
+                };
+                ld(0);
+                split_normals_each(sc, p.seed, gch(), t, [&](int e, double z) {
+                    sc.col[e * 64] = xv[e & (CH - 1)] + sg[e & (CH - 1)] * z;          // MH.jl:79
+                    if (e == CH - 1) ld(CH);
+                });
             }
-            split_grad<HASMU, true, false>(sc, xp, gp);                // MH.jl:81
-            double l1 = 0.0;
-#pragma unroll
-            for (int e = 0; e < NE; ++e) l1 = l1 + dx(xp, e) * gp[e];
-            red[0] = l1;
+            __syncthreads();
+            split_pass<HASMU>(sc, ga);                                 // MH.jl:81
+            red[0] = lt_part();
             split_reduce<1>(sc, red);
             ltp = p.gconst + 0.5 * red[0];
             const double ratio = ltp - lt;                             // MH.jl:83
@@ -319,30 +418,60 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
             }
         }
 
-        if (do_sum && __any(acc && held > 0)) {          // leaving a state after `held` saved steps: fold it into the sums
-            if (acc && held > 0) {
-                const double hf = (double)held;
-                double xo[NE];
-                mload<NE>(cx, p.X, p.D, xo);
-                const __amdgpu_buffer_rsrc_t ws = mwin<NE>(cx, p.sum, 0, p.D), wq = mwin<NE>(cx, p.sumsq, 0, p.D);
-                const int nv = cx.nv_here();
+        const long long i1 = (long long)t + 1;
+        const bool in_post = i1 > p.burnin && i1 <= p.nsteps_total;
+        const bool save_now = in_post && sphase == 0;
+        if (in_post) sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
+        const long long col = scol;
+        if (save_now) scol += 1;
+        const bool hist_now = save_now && col < p.hist_cols;
+        // commit, fold and history, 8 elements at a time: the state being left from X, the proposal from xb, its gradient from the accumulators
+        if (__any(acc) || (save_now && (p.hist != nullptr || (NEEDG && p.hist_g != nullptr)))) {
+            const bool fold = do_sum && acc && held > 0;               // leaving a state after `held` saved steps: fold it into the sums
+            const double hf = (double)held;
+            const __amdgpu_buffer_rsrc_t ws = mwin<NE>(cx, p.sum, 0, p.D), wq = mwin<NE>(cx, p.sumsq, 0, p.D);
+            const __amdgpu_buffer_rsrc_t wh = mwin<NE>(cx, p.hist, col * p.nchains, p.D), whg = mwin<NE>(cx, p.hist_g, col * p.nchains, p.D);
+            const int nv = cx.nv_here();
+            const bool need_old = (do_sum && __any(fold)) || (hist_now && p.hist != nullptr && !__all(acc));
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    const unsigned o = cx.off_fresh(e, nv);
-                    const double sv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ws, o, 0, 0));
-                    const double qv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wq, o, 0, 0));
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sv + hf * xo[e]), ws, o, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, qv + hf * (xo[e] * xo[e])), wq, o, 0, 0);
+            for (int e0 = 0; e0 < NE; e0 += CH) {
+                double xo[CH], xn[CH];
+                if (need_old) split_load8(cx, wX, e0, nv, xo);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) xn[j] = sc.rd(e0 + j);
+                if (fold) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const unsigned o = cx.off_fresh(e0 + j, nv);
+                        const double sv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ws, o, 0, 0));
+                        const double qv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wq, o, 0, 0));
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, sv + hf * xo[j]), ws, o, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, qv + hf * (xo[j] * xo[j])), wq, o, 0, 0);
+                    }
                 }
-                held = 0;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const unsigned o = cx.off_fresh(e0 + j, nv);
+                    const double g = -(double)ga[(e0 + j) >> 2][(e0 + j) & 3];
+                    if (acc) {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, xn[j]), wX, o, 0, 0);
+                        if (NEEDG) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, g), wG, o, 0, 0);
+                    }
+                    if (hist_now && p.hist != nullptr) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, acc ? xn[j] : xo[j]), wh, o, 0, 0);
+                    if (NEEDG && hist_now && p.hist_g != nullptr && acc) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, g), whg, o, 0, 0);
+                }
+                if (NEEDG && hist_now && p.hist_g != nullptr && !__all(acc)) {        // a rejecting chain saves its committed gradient
+                    double go_[CH];
+                    split_load8(cx, wG, e0, nv, go_);
+                    if (!acc) {
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(kd_uint2, go_[j]), whg, cx.off_fresh(e0 + j, nv), 0, 0);
+                    }
+                }
             }
+            if (fold) held = 0;
         }
-        if (acc) {
-            mstore<NE>(cx, p.X, p.D, xp);
-            if (SAMPLER != KLARA_SAMPLER_MH) mstore<NE>(cx, p.GR, p.D, gp);
-            lt = ltp;
-        }
-        have = acc;                                      // (a rejected proposal leaves the registers holding the proposal: re-read next time)
+        if (acc) lt = ltp;
         nacc += acc ? 1ull : 0ull;
         if (cnt && acc) tn.accepted += 1;
         if (accept_out != nullptr && w0 && cx.chain_ok && cx.q == 0)
@@ -351,37 +480,13 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
         else if (da && cnt && tn.phase == 0 && (long long)t + 1 <= p.da_nadapt) {
             tn.totproposed += tn.proposed; tn.accepted = 0; tn.proposed = 0;
         }
-        const long long i1 = (long long)t + 1;
-        const bool in_post = i1 > p.burnin && i1 <= p.nsteps_total;
-        const bool save_now = in_post && sphase == 0;
-        if (in_post) sphase = (sphase + 1 == (int)p.thinning) ? 0 : sphase + 1;
         if (save_now) {
-            const long long col = scol++;
             if (do_sum) held += 1;
-            if (p.hist != nullptr) {
-                double xs[NE];
-                if (acc) {
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) xs[e] = xp[e];
-                } else {
-                    mload<NE>(cx, p.X, p.D, xs);
-                }
-                if (col < p.hist_cols) mstore<NE>(cx, p.hist, p.D, xs, col * p.nchains);
-            }
-            if (p.hist_lt != nullptr && col < p.hist_cols && w0 && cx.chain_ok && cx.q == 0)
+            if (p.hist_lt != nullptr && hist_now && w0 && cx.chain_ok && cx.q == 0)
                 p.hist_lt[col * p.nchains + cx.chain_here()] = lt;
-            if (SAMPLER != KLARA_SAMPLER_MH && p.hist_g != nullptr && col < p.hist_cols) {
-                double gs[NE];
-                if (acc) {
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) gs[e] = gp[e];
-                } else {
-                    mload<NE>(cx, p.GR, p.D, gs);
-                }
-                mstore<NE>(cx, p.hist_g, p.D, gs, col * p.nchains);
-            }
         }
-        // (a chain's X / GR rows are written by all W wavefronts and read back by them after a reject, each its own elements: no hazard across wavefronts)
+        // (a chain's X / GR rows are written and read back by the wavefront that owns the elements: no hazard across wavefronts; the next
+        // transition's writes to xb come after this one's last reduction, i.e. after every wavefront's pass)
     }
 
     if (w0 && cx.lane < cx.here) {                                       // q == 0 (lanes 0..15) on an existing chain, first wavefront
@@ -407,23 +512,21 @@ __global__ __launch_bounds__(1024) void k_dense_split_init(const KParams p, cons
 {
     constexpr int NE = KLARA_SPLIT_NEW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    SplitCtx sc = make_sctx(p, Pfrag, smem, HASMU);
+    SplitCtx sc = make_sctx(p, Pfrag, smem);
     const MfmaCtx<NE>& cx = sc.m;
-    {
-        const int NEt = NE * sc.W;
-        double* const muW = const_cast<double*>(sc.ldsMu);
-        if (HASMU) { for (int i = threadIdx.x; i < 4 * NEt; i += blockDim.x) muW[i] = Pfrag[(size_t)4 * sc.W * (NEt + 2) * 64 + i]; }
-        for (int i = threadIdx.x; i < 128; i += blockDim.x) sc.xb[(size_t)NEt * 64 + i] = 0.0;
-    }
-    __syncthreads();
-    double x[NE], g[NE], red[1];
+    double x[NE], red[1];
     mload<NE>(cx, p.X, p.D, x);
-    split_grad<HASMU, true, false>(sc, x, g);
-    double l1 = 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) sc.wr(e, x[e]);
+    __syncthreads();
+    kd_double4 ga[4];
+    split_pass<HASMU>(sc, ga);
+    double l1 = 0.0, g[NE];
     bool bad = false;
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-        l1 = l1 + (HASMU ? x[e] - sc.ldsMu[4 * (NE * sc.w + e) + cx.q] : x[e]) * g[e];
+        g[e] = -(double)ga[e >> 2][e & 3];
+        l1 = l1 + (HASMU ? x[e] - split_mu(sc, e) : x[e]) * g[e];
         if (needgrad) bad = bad || !kfinite(g[e]);
     }
     red[0] = l1;

@@ -40,8 +40,8 @@ hipError_t klara_launch_logit_mfma(const KParams* p, const KLaunch& kl, int samp
                                    dim3 grid, hipStream_t st);
 hipError_t klara_launch_logit_mfma_init(const KParams& p, int NE, const double* F, const double* ypad, int nblocks, int needgrad, dim3 grid, hipStream_t st);
 int klara_logit_mfma_rbt();
-// dense Gaussian on a workgroup of W wavefronts per tile of 16 chains (layout kind 6, klara_dense_split.h): 257 <= D <= 1024; MH, MALA, HMC
-hipError_t klara_launch_dense_split(const KParams* p, const KLaunch& kl, int sampler, bool da, int W, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st);
+// dense Gaussian on a workgroup of W = 4 ceil(ceil(D / 16) / 16) wavefronts per tile of 16 chains (layout kind 6, klara_dense_split.h): 257 <= D <= 1024; MH, MALA, HMC
+hipError_t klara_launch_dense_split(const KParams* p, const KLaunch& kl, int sampler, bool da, int W, int D, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st);
 hipError_t klara_launch_dense_split_init(const KParams& p, int W, const double* Pfrag, bool hasmu, int needgrad, dim3 grid, hipStream_t st);      // row tiles per block the kernels were built for
 
 // pair-transposed diagonal-Gaussian kernels (layout kind 3, klara_diagt.h).  The translation units klara_diagt_*.hip are

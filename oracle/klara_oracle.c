@@ -88,8 +88,9 @@ typedef struct ko_layout {
                         rows, then the tree (q0 + q1) + (q2 + q3); X p and X' (y - 1/(1+exp(-Xp))) are the fma chains of
                         v_mfma_f64_16x16x4 (k ascending from zero), i.e. the sequential chains of the closure form
                      6: dense Gaussian on a workgroup of G wavefronts per tile of 16 chains (klara_dense_split.h): element i on
-                        lane-quarter i % 4 of wavefront (i / 4) / 16; lane partials in ascending element order, the tree
-                        (q0 + q1) + (q2 + q3) inside each wavefront, then the wavefronts' values in ascending order         */
+                        lane-quarter i % 4 of the wavefront that owns row tile i / 16 (an even deal of consecutive tiles); lane
+                        partials in ascending element order, the tree (q0 + q1) + (q2 + q3) inside each wavefront, then the
+                        wavefronts' values in ascending order                                                                */
     int32_t G;
     int32_t E;
 } ko_layout;
@@ -98,10 +99,13 @@ static double ko_reduce(const ko_layout* L, const double* terms, int D)
 {
     double part[64], nw[64];
     if (L->kind == 6) {
+        /* the ceil(D / 16) row tiles dealt evenly to the G wavefronts (the first MT % G one more), consecutive tiles each: klara_dense_split.h make_sctx */
+        const int MT = (D + 15) / 16, base = MT / L->G, rem = MT - base * L->G;
         double tot = 0.0;
         for (int w = 0; w < L->G; ++w) {
+            const int T = base + (w < rem ? 1 : 0), t0 = w * base + (w < rem ? w : rem);
             double pq[4] = { 0.0, 0.0, 0.0, 0.0 };
-            for (int i = 64 * w; i < D && i < 64 * (w + 1); ++i) pq[i & 3] = pq[i & 3] + terms[i];
+            for (int i = 16 * t0; i < D && i < 16 * (t0 + T); ++i) pq[i & 3] = pq[i & 3] + terms[i];
             const double v = (pq[0] + pq[1]) + (pq[2] + pq[3]);
             tot = w == 0 ? v : tot + v;
         }

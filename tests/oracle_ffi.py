@@ -151,8 +151,8 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
         return (0, 1, e)
     if (target_kind == L.TARGET_GAUSS_DENSE and sampler != L.SAMPLER_SLICE and d <= 1024 and "KLARA_DENSE_NO_SPLIT" not in os.environ
             and (d > 256 or os.environ.get("KLARA_DENSE_SPLIT", "0") not in ("", "0"))):
-        # round 6: a workgroup of ceil(D / 64) wavefronts per tile of 16 chains, 16 elements per lane and wavefront (klara_dense_split.h)
-        return (6, (d + 63) // 64, 16)
+        # round 6: a workgroup of 4, 8, 12 or 16 wavefronts per tile of 16 chains, the ceil(D / 16) row tiles dealt evenly (klara_dense_split.h)
+        return (6, 4 * (((d + 15) // 16 + 15) // 16), 16)
     if (target_kind == L.TARGET_GAUSS_DENSE and 128 < d <= 256 and "KLARA_DENSE_NO_STREAM" not in os.environ
             and not (sampler == L.SAMPLER_SLICE and "KLARA_DENSE_SLICE_NO_STREAM" in os.environ)):      # every sampler to D = 256: still the matrix cores, P streamed (klara_dense_big.h; round 5: the slice sampler too)
         return (1, 4, 8 * ((d + 31) // 32))

@@ -453,11 +453,11 @@ def test_dense_target_beyond_128_closure_form_still_matches(name, monkeypatch):
 @pytest.mark.parametrize("name", sorted(cases.SPLIT_CASES))
 def test_dense_target_beyond_256_on_workgroup_split_layout(name):
     """Round 6: dense targets of 257 .. 1024 dimensions (refused in rounds 1-5) run on the matrix cores with the tile of 16 chains on a workgroup of
-    ceil(D / 64) wavefronts (klara_dense_split.h): layout kind 6, bit for bit against the oracle's kind-6 summation order, in one piece and split into launches."""
+    4 .. 16 wavefronts that deal the row tiles of P evenly (klara_dense_split.h): layout kind 6, bit for bit against the oracle's kind-6 summation order, in one piece and split into launches."""
     case = cases.make_case(name)
     d = case["target"].ndims
     eng, job = _run_pair(case)
-    assert eng.layout() == (6, (d + 63) // 64, 16)
+    assert eng.layout() == (6, 4 * (((d + 15) // 16 + 15) // 16), 16)
     _assert_same(eng, job, case)
     eng.close()
     n = case["nsteps"]
@@ -470,13 +470,13 @@ def test_dense_target_beyond_256_on_workgroup_split_layout(name):
                                   "hmc_dense_d256_stream_tuned", "hmc_dense_d160_stream_pooled", "mala_dense_d200_stream_tuned", "mh_dense_d256_stream_mean",
                                   "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide"])
 def test_smaller_dense_targets_on_the_split_layout(name, monkeypatch):
-    """KLARA_DENSE_SPLIT=1 puts every dense target on the workgroup-split layout (1 .. 4 wavefronts per tile below D = 257): the cases of the LDS-resident and
+    """KLARA_DENSE_SPLIT=1 puts every dense target on the workgroup-split layout (4 wavefronts per tile below D = 257, 0 .. 4 row tiles each): the cases of the LDS-resident and
     streamed layouts again, against the oracle in the kind-6 order."""
     monkeypatch.setenv("KLARA_DENSE_SPLIT", "1")
     case = cases.make_case(name)
     d = case["target"].ndims
     eng, job = _run_pair(case)
-    assert eng.layout() == (6, (d + 63) // 64, 16)
+    assert eng.layout() == (6, 4 * (((d + 15) // 16 + 15) // 16), 16)
     _assert_same(eng, job, case)
     eng.close()
 
