@@ -638,6 +638,26 @@ def extra_measurements(K, L, n, stream):
     except Exception as exc:
         ex["mala_mh_dense_d256_error"] = repr(exc)
 
+    # -- dense targets beyond D = 256 (round 6; refused before): the tile of 16 chains on a workgroup of 8 / 16 wavefronts that deal the row tiles of P evenly,
+    # the proposal exchanged through LDS (klara_dense_split.h, layout kind 6); 2 D^2 flop per gradient and chain
+    try:
+        for D2 in (512, 1024):
+            for key, grads, spl, kw in (("hmc", 10, 4, dict(sampler=L.SAMPLER_HMC, leapstep=0.1 * (256 / D2) ** 0.25, nleaps=10)),
+                                        ("mala", 1, 32, dict(sampler=L.SAMPLER_MALA, driftstep=0.002 * 256 / D2))):
+                e = K.Engine(target=K.GaussDenseTarget.compound_symmetric(D2, 0.5), nchains=n, nsteps=10 ** 7, steps_per_launch=spl, stream=stream, **kw)
+                e.init_state_normal()
+                rate, ls, _ = timed_rate(e, n, spl, 2 * spl)
+                lay2 = e.layout(); e.close()
+                tf2 = n * spl * grads * 2 * D2 * D2 / ls / 1e12
+                ex[f"{key}_dense_d{D2}_" + ("leapfrog_chain_per_s" if grads > 1 else "transitions_per_s")] = rate * grads
+                ex[f"{key}_dense_d{D2}_roofline"] = {"bound": "mfma", "achieved": tf2, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf2 / FP64_MFMA_PEAK_TF,
+                                                    "kernel": f"k_dense_split<{key.upper()}> (layout kind {lay2[0]}: {lay2[1]} wavefronts per tile of 16 chains; v_mfma_f64_16x16x4, A fragments "
+                                                              f"streamed from memory, x exchanged through LDS), {spl} transitions per launch",
+                                                    "launch_us": ls * 1e6,
+                                                    "source": "algorithmic flops (2 D^2 per gradient and chain) / launch duration from HIP events in this run"}
+    except Exception as exc:
+        ex["dense_split_error"] = repr(exc)
+
     # -- slice sampler on the README target, D = 100: the library's own launch length for this job (KLARA_DEFAULT_STEPS_PER_LAUNCH_SLICE; the lanes run out of
     # lockstep and a wavefront waits for its slowest lane once per element slot and launch, klara_diagt_slice.h)
     SLICE_SPL = L.DEFAULT_STEPS_PER_LAUNCH_SLICE

@@ -206,7 +206,7 @@ static bool dense_streamed(const klara_desc& d)
 // dense targets on it as well (measurements, tests).
 static bool dense_split(const klara_desc& d)
 {
-    if (d.target != KLARA_TARGET_GAUSS_DENSE || d.sampler == KLARA_SAMPLER_SLICE || d.ndims > 64 * 16) return false;
+    if (d.target != KLARA_TARGET_GAUSS_DENSE || d.ndims > 64 * 16) return false;
     if (getenv("KLARA_DENSE_NO_SPLIT") != nullptr) return false;
     if (d.ndims > 256) return true;
     const char* s = getenv("KLARA_DENSE_SPLIT");

@@ -228,10 +228,11 @@ template <int SAMPLER, bool DA, bool HASMU, int MW>
 __global__ __launch_bounds__(256 * MW)
 void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
 {
-    static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH, "HMC, MALA, MH");
+    static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_SLICE, "HMC, MALA, MH, slice");
+    constexpr bool SLICE = SAMPLER == KLARA_SAMPLER_SLICE;
     static_assert(!DA || SAMPLER == KLARA_SAMPLER_HMC, "dual averaging is wired into HMC only (HMC.jl:124-133)");
     constexpr int NE = KLARA_SPLIT_NEW, CH = KLARA_SPLIT_CH;
-    constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH;
+    constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH && !SLICE;
     const KParams& p = *pp;
     guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -251,6 +252,7 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
     long long scol = kl.save_col0;
     double lt = cx.chain_ok ? p.LT[cx.chain] : 0.0;
     unsigned long long nacc = 0;
+    bool stuck = false;                                  // slice sampler: step-out / shrink ran out of attempts
     const bool do_sum = p.sum != nullptr;
     long long held = do_sum ? p.held[cx.chain_ok ? cx.chain : 0] : 0;        // running sums in sojourn form (KParams::held)
 
@@ -386,6 +388,51 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
                 const double u = kd_accept_uniform(kd_stream_block(p.seed, gch(), t, (uint32_t)((p.D + 1) >> 1)));
                 acc = ratio > kd_log_u01(u);
             }
+        } else if constexpr (SLICE) {
+            // iterate/SliceSampler.jl:60-109, the chains of the tile out of lockstep (slice_free_machine, klara_kernels.h): a probe is one matrix pass over the
+            // tile's 16 chains, each at its own coordinate and stage.  Every wavefront runs the 16 little machines (the same values in all of them: the
+            // probe's log-target comes out of the reduction); the first wavefront writes a chain's candidate into xb, where the pass and the owner of the
+            // element find it.  A machine reads the value of its NEXT coordinate when it starts the current one: that slot is written by nobody until the
+            // machine gets there, whereas the current one is being overwritten by the first wavefront while a slower one may not have read it yet.
+            {
+                const int nv = cx.nv_here();
+#pragma unroll
+                for (int e0 = 0; e0 < NE; e0 += CH) {
+                    double xv[CH];
+                    split_load8(cx, wX, e0, nv, xv);
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) sc.wr(e0 + j, xv[j]);
+                }
+            }
+            __syncthreads();
+            double* const xbw = const_cast<double*>(sc.xb) + cx.cl;
+            const auto slot = [&](int i) { return (i >> 2) * 64 + 16 * (i & 3); };
+            int have_i = 0;
+            double have_x = xbw[slot(0)], next_x = xbw[slot(p.D > 1 ? 1 : 0)];
+            __syncthreads();                                           // (nobody places a candidate before everybody has these)
+            double cur = lt;
+            slice_free_machine(p, cx.chain_ok, gch(), t, cur, stuck,
+                [&](int i, double& xs, double& ws) {
+                    const bool adv = i != have_i;                      // the machine has moved on to coordinate have_i + 1
+                    const int in = i + 1 < p.D ? i + 1 : i;
+                    const double nx = xbw[slot(in)];
+                    have_x = adv ? next_x : have_x;
+                    next_x = adv ? nx : next_x;
+                    have_i = i;
+                    xs = have_x;
+                    ws = p.vecparam[i];
+                },
+                [&](int i, bool on, double cand) { if (w0 && cx.q == 0 && on) xbw[slot(i)] = cand; },
+                [&]() {
+                    __syncthreads();
+                    split_pass<HASMU>(sc, ga);
+                    double r1[1] = { lt_part() };
+                    split_reduce<1>(sc, r1);                           // (its barrier closes the pass: the next candidate may be placed)
+                    return p.gconst + 0.5 * r1[0];
+                });
+            __syncthreads();                                           // (a stuck chain's coordinate was put back)
+            ltp = cur;
+            acc = true;                                                // the slice sampler always moves (SliceSampler.jl:108)
         } else {
             // iterate/MH.jl:72-124
             double red[1];
@@ -473,7 +520,7 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
         }
         if (acc) lt = ltp;
         nacc += acc ? 1ull : 0ull;
-        if (cnt && acc) tn.accepted += 1;
+        if (cnt && acc && !SLICE) tn.accepted += 1;                                // (the slice sampler never counts accepts)
         if (accept_out != nullptr && w0 && cx.chain_ok && cx.q == 0)
             accept_out[(long long)s * p.nchains + cx.chain_here()] = acc ? 1 : 0;
         if (!p.pooled && !da) tuning_block(p, tn);
@@ -489,6 +536,7 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
         // transition's writes to xb come after this one's last reduction, i.e. after every wavefront's pass)
     }
 
+    if (SLICE && stuck && w0 && cx.chain_ok && cx.q == 0) klara_raise(p.error_flag, KLARA_ERR_SLICE_STUCK);
     if (w0 && cx.lane < cx.here) {                                       // q == 0 (lanes 0..15) on an existing chain, first wavefront
         const long long chain_e = cx.first_chain + cx.lane;
         p.LT[chain_e] = lt;

@@ -1,4 +1,4 @@
-// klara_dense_split.hip — instantiates the workgroup-split dense-Gaussian kernels (layout kind 6: 257 <= D <= 1024; HMC — also with dual averaging —, MALA, MH) for gfx950.
+// klara_dense_split.hip — instantiates the workgroup-split dense-Gaussian kernels (layout kind 6: 257 <= D <= 1024; HMC — also with dual averaging —, MALA, MH, slice) for gfx950.
 #include <cstdlib>
 #include "klara_launch.h"
 #define KLARA_DENSE_NO_PROBES 1
@@ -32,6 +32,7 @@ hipError_t klara_launch_dense_split(const KParams* p, const KLaunch& kl, int sam
     case KLARA_SAMPLER_HMC: return da ? go_split_s<KLARA_SAMPLER_HMC, true>(p, kl, W, D, Pfrag, hasmu, grid, st) : go_split_s<KLARA_SAMPLER_HMC>(p, kl, W, D, Pfrag, hasmu, grid, st);
     case KLARA_SAMPLER_MALA: return go_split_s<KLARA_SAMPLER_MALA>(p, kl, W, D, Pfrag, hasmu, grid, st);
     case KLARA_SAMPLER_MH: return go_split_s<KLARA_SAMPLER_MH>(p, kl, W, D, Pfrag, hasmu, grid, st);
+    case KLARA_SAMPLER_SLICE: return go_split_s<KLARA_SAMPLER_SLICE>(p, kl, W, D, Pfrag, hasmu, grid, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -253,6 +253,8 @@ def _split_cases():
         "mala_dense_d1000_split_pooled": (1000, dict(sampler=L.SAMPLER_MALA, nsteps=30, burnin=20, driftstep=0.02, tuner=L.TUNER_ACCEPT_RATE,
                                                      tuner_mode=L.TUNE_POOLED, targetrate=0.574, period=10, nchains=33)),
         "mh_dense_d333_split": (333, dict(sampler=L.SAMPLER_MH, nsteps=20, burnin=0, nchains=5)),
+        "slice_dense_d260_split": (260, dict(sampler=L.SAMPLER_SLICE, nsteps=3, burnin=0, nchains=19)),
+        "slice_dense_d530_split_mean": (530, dict(sampler=L.SAMPLER_SLICE, nsteps=2, burnin=0, nchains=7, slice_stepout=False)),
     }
 
 
@@ -425,6 +427,8 @@ def make_case(name):
         x0 = rng.standard_normal((n, d)) + (0.0 if mu is None else mu[None, :])
         if kw.get("sampler") == L.SAMPLER_MH:
             kw["mh_sigma"] = np.linspace(0.01, 0.04, d)
+        if kw.get("sampler") == L.SAMPLER_SLICE:
+            kw["slice_widths"] = np.linspace(0.5, 2.0, d)
         c = dict(target=t, nchains=n, x0=x0, **kw)
     elif name == "mh_dense_d130_wide":     # (round 4: MH at D = 130 runs on the streamed matrix-core layout too; the closure form: hmc_dense_d130_dualavg_wide)
         rng = np.random.default_rng(130)
@@ -696,7 +700,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_dense_d256_stream_tuned", "hmc_dense_d192_stream_mean", "hmc_dense_d160_stream_pooled", "hmc_dense_d129_stream", "hmc_dense_d201_stream",
              "mala_dense_d200_stream_tuned", "mh_dense_d256_stream_mean", "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide",
              "hmc_dense_d300_split", "hmc_dense_d257_split_pooled", "mala_dense_d512_split_mean_tuned", "mh_dense_d700_split_mean",
-             "hmc_dense_d1024_split_dualavg", "mala_dense_d1000_split_pooled", "mh_dense_d333_split",
+             "hmc_dense_d1024_split_dualavg", "mala_dense_d1000_split_pooled", "mh_dense_d333_split", "slice_dense_d260_split", "slice_dense_d530_split_mean",
              "slice_dense_d192_stream", "slice_dense_d130_stream_mean", "slice_dense_d256_stream", "mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small",
              "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide", "hmc_logit_d20_wide", "slice_d20_stepout", "mh_rats", "mala_rats_tuned",
              "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"] + list(LOGIT_MFMA_CASES) + [

@@ -149,7 +149,7 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
         while e < d:
             e *= 2
         return (0, 1, e)
-    if (target_kind == L.TARGET_GAUSS_DENSE and sampler != L.SAMPLER_SLICE and d <= 1024 and "KLARA_DENSE_NO_SPLIT" not in os.environ
+    if (target_kind == L.TARGET_GAUSS_DENSE and d <= 1024 and "KLARA_DENSE_NO_SPLIT" not in os.environ
             and (d > 256 or os.environ.get("KLARA_DENSE_SPLIT", "0") not in ("", "0"))):
         # round 6: a workgroup of 4, 8, 12 or 16 wavefronts per tile of 16 chains, the ceil(D / 16) row tiles dealt evenly (klara_dense_split.h)
         return (6, 4 * (((d + 15) // 16 + 15) // 16), 16)

@@ -468,7 +468,7 @@ def test_dense_target_beyond_256_on_workgroup_split_layout(name):
 
 @pytest.mark.parametrize("name", ["hmc_dense_d98", "hmc_dense_d128", "hmc_dense_d100_mean", "mala_dense_d37_mean", "mh_dense_d20_mean", "hmc_dense_d70_mean_dualavg",
                                   "hmc_dense_d256_stream_tuned", "hmc_dense_d160_stream_pooled", "mala_dense_d200_stream_tuned", "mh_dense_d256_stream_mean",
-                                  "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide"])
+                                  "mala_dense_d130_stream_pooled", "hmc_dense_d130_dualavg_wide", "slice_dense_d20", "slice_dense_d37_mean", "slice_dense_d130_stream_mean"])
 def test_smaller_dense_targets_on_the_split_layout(name, monkeypatch):
     """KLARA_DENSE_SPLIT=1 puts every dense target on the workgroup-split layout (4 wavefronts per tile below D = 257, 0 .. 4 row tiles each): the cases of the LDS-resident and
     streamed layouts again, against the oracle in the kind-6 order."""
@@ -571,7 +571,8 @@ def test_launch_splitting_does_not_change_results(name, splits, spl):
 
 
 @pytest.mark.parametrize("name,monitor", [("mala_d100", L.MON_ACCEPT | L.MON_SUMMARIES), ("dt_mala_d100_small_step", L.MON_ACCEPT),
-                                          ("dt_hmc_d100", L.MON_ACCEPT), ("mala_logitm_d20", L.MON_ACCEPT | L.MON_SUMMARIES)])
+                                          ("dt_hmc_d100", L.MON_ACCEPT), ("mala_logitm_d20", L.MON_ACCEPT | L.MON_SUMMARIES),
+                                          ("hmc_dense_d300_split", L.MON_ACCEPT | L.MON_SUMMARIES)])
 def test_sharding_invariance(name, monitor):
     """Rank r's shard (chain_offset) reproduces the same chains as the single-GPU job — group layout and
     pair-transposed layout (the shard boundary does not fall on a wavefront-group boundary there)."""
@@ -973,6 +974,53 @@ def test_every_streamed_dense_instantiation_in_one_launch(smp, d, mu):
     assert rate == 1.0 if smp == "slice" else 0.05 < rate < 0.95, rate                    # both the commit and the re-read are exercised
     _assert_same(eng, job, c)
     for ch in (0, 17, 20):
+        assert np.array_equal(eng.chain(ch), job.hist[:, ch, :].T), "history differs"
+        lt, g = eng.chain_fields(ch, logtarget=True, gradlogtarget=not nograd)
+        assert np.array_equal(lt, job.hist_lt[:, ch])
+        if not nograd:
+            assert np.array_equal(g, job.hist_g[:, ch, :].T)
+    eng.close()
+
+
+_SPLIT = [(smp, d, mu) for smp in ("mh", "mala", "mala_pooled", "hmc", "hmc_rate", "hmc_da") for d, mu in ((270, False), (330, True), (520, False), (780, True), (1010, False))]
+_SPLIT += [("slice", 270, False), ("slice", 330, True), ("slice", 780, True)]      # (a probe is a full evaluation: D x ~6 per transition and chain on the oracle's side)
+
+
+@pytest.mark.parametrize("smp,d,mu", _SPLIT, ids=[f"{a}-d{b}-{'mean' if m else 'nomean'}" for a, b, m in _SPLIT])
+def test_every_split_dense_instantiation_in_one_launch(smp, d, mu):
+    """Every k_dense_split<sampler, dual averaging, mean, registers> instantiation (round 6: 8 / 12 / 16 wavefronts per tile, 2 .. 4 row tiles each, an odd first tile
+    in some of them), with ALL transitions of the job in ONE launch, a ragged second tile, running sums and histories on, at step sizes where a good share of the
+    proposals is rejected and a good share accepted: what a wavefront carries from one transition to the next — the proposal in its LDS column, the committed state
+    in X / GR — and every barrier between the wavefronts of a tile is what this pins."""
+    rng = np.random.default_rng(d + 7 * len(smp) + int(mu))
+    target = K.GaussDenseTarget(cases.compound_symmetric_precision(d, 0.4), const=0.3, mu=(rng.uniform(-1.5, 1.5, d) if mu else None))
+    c = dict(target=target, nchains=21, x0=None, seed=4242 + d, name=f"split_{smp}_{d}_{int(mu)}", burnin=2, thinning=2, nsteps=14)
+    sc = 256.0 / d
+    if smp == "slice":
+        c.update(sampler=L.SAMPLER_SLICE, slice_widths=np.linspace(0.5, 2.0, d), slice_stepout=not mu, nsteps=3, burnin=1, nchains=18 if d > 400 else 21)
+    elif smp == "mh":
+        c.update(sampler=L.SAMPLER_MH, mh_sigma=np.full(d, 0.07 * sc ** 0.5) * rng.uniform(0.7, 1.3, d))
+    elif smp in ("mala", "mala_pooled"):
+        c.update(sampler=L.SAMPLER_MALA, driftstep=0.3 * sc ** (1.0 / 3.0))
+        if smp == "mala_pooled":
+            c.update(tuner=L.TUNER_ACCEPT_RATE, tuner_mode=L.TUNE_POOLED, targetrate=0.574, period=4)
+    else:
+        c.update(sampler=L.SAMPLER_HMC, leapstep=0.45 * sc ** 0.25, nleaps=3)
+        if smp == "hmc_rate":
+            c.update(tuner=L.TUNER_ACCEPT_RATE, targetrate=0.6, period=4)
+        if smp == "hmc_da":
+            c.update(tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.65, da_nadapt=9)
+    nograd = smp in ("mh", "slice")
+    mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT | (0 if nograd else L.MON_HIST_GRAD)
+    eng = K.Engine(**cases.engine_kwargs(c, monitor=mon, steps_per_launch=0, nstreams=1))
+    assert eng.layout() == (6, 4 * (((d + 15) // 16 + 15) // 16), 16), eng.layout()
+    job = O.OracleJob(**cases.oracle_kwargs(c, layout=eng.layout()), want_hist=True)
+    eng.init_state_normal(); assert job.init_state_normal() == 0
+    eng.run(c["nsteps"]); assert job.run(c["nsteps"]) == 0
+    rate = job.accept.mean()
+    assert rate == 1.0 if smp == "slice" else 0.05 < rate < 0.95, rate                    # both the commit and the re-read are exercised
+    _assert_same(eng, job, c)
+    for ch in (0, 17, c["nchains"] - 1):
         assert np.array_equal(eng.chain(ch), job.hist[:, ch, :].T), "history differs"
         lt, g = eng.chain_fields(ch, logtarget=True, gradlogtarget=not nograd)
         assert np.array_equal(lt, job.hist_lt[:, ch])
