@@ -501,6 +501,37 @@ def test_layout_changes_only_the_summation_order():
     assert not np.array_equal(a.LT, b.LT)           # ...but the sums really are taken in a different order
 
 
+@pytest.mark.parametrize("d", [20, 100, 257, 300, 700, 1000])
+def test_layout_kind6_sums_in_the_order_of_the_even_tile_deal(d):
+    """Layout kind 6 (klara_dense_split.h, round 6): the ceil(D / 16) row tiles dealt evenly to W = 4 ceil(MT / 16) wavefronts (consecutive tiles, the first MT % W one more);
+    lane partials over the wavefront's elements i with i % 4 = q in ascending order, (q0 + q1) + (q2 + q3), then the wavefronts in ascending order.  The oracle's log-target
+    of a dense Gaussian under that layout against this restatement in Python floats (from the oracle's own gradient: lt = c + 1/2 sum_i (x_i - mu_i) g_i)."""
+    rng = np.random.default_rng(d)
+    a = rng.standard_normal((d, d)); prec = a @ a.T / d + np.eye(d)
+    mu = rng.standard_normal(d)
+    mt = (d + 15) // 16; w = 4 * ((mt + 15) // 16)
+    job = O.OracleJob(sampler=L.SAMPLER_HMC, target_kind=L.TARGET_GAUSS_DENSE, nchains=3, ndims=d, nsteps=4, leapstep=0.1, nleaps=2, gauss_prec=prec, gauss_mu=mu,
+                      gauss_const=0.5, layout=(6, w, 16))
+    x0 = rng.standard_normal((3, d)) + mu
+    assert job.set_state(x0) == 0
+    base, rem = divmod(mt, w)
+    for c in range(3):
+        terms = (x0[c] - mu) * job.G[c]
+        tot = None
+        for wv in range(w):
+            t = base + (1 if wv < rem else 0); t0 = wv * base + min(wv, rem)
+            pq = [0.0, 0.0, 0.0, 0.0]
+            for i in range(16 * t0, min(d, 16 * (t0 + t))):
+                pq[i & 3] = pq[i & 3] + float(terms[i])
+            v = (pq[0] + pq[1]) + (pq[2] + pq[3])
+            tot = v if tot is None else tot + v
+        assert job.LT[c] == 0.5 + 0.5 * tot, (d, c)
+    other = O.OracleJob(sampler=L.SAMPLER_HMC, target_kind=L.TARGET_GAUSS_DENSE, nchains=3, ndims=d, nsteps=4, leapstep=0.1, nleaps=2, gauss_prec=prec, gauss_mu=mu,
+                        gauss_const=0.5, layout=(1, 4, 8 * ((d + 31) // 32)))
+    assert other.set_state(x0) == 0
+    assert np.array_equal(other.G, job.G) and np.allclose(other.LT, job.LT, rtol=1e-13)          # (the gradient's fma chains do not depend on the layout)
+
+
 def test_posterior_moments_mh_readme():
     """BASELINE cfg 1: README MH example, truth mean 0, var 1/2 (lt = -|x|^2). 64 replicas x 10000 steps."""
     job = O.OracleJob(sampler=L.SAMPLER_MH, target_kind=L.TARGET_GAUSS_DIAG, nchains=64, ndims=2, nsteps=10000,
