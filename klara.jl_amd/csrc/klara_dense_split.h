@@ -25,6 +25,9 @@
 #define KLARA_SPLIT_NEW 16             // elements per lane and wavefront
 #define KLARA_SPLIT_WMAX 16            // wavefronts per workgroup (D <= 1024)
 #define KLARA_SPLIT_PAD 8              // k-steps of zeros behind the stream and rows behind the mean (>= R / 4 for every ring)
+#ifndef KLARA_SPLIT_RESIDENT
+#define KLARA_SPLIT_RESIDENT 1         // MALA / MH: the committed value stays in the lane's LDS column and MALA's committed gradient in the accumulators between transitions
+#endif
 #define KLARA_SPLIT_CH 8               // elements per group of loads (state, mean) in the element-wise passes
 
 struct SplitCtx {
@@ -259,12 +262,39 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
     // The committed state lives in X / GR (written at every accept); a transition reads what it needs from there in groups of 8 elements, forms its
     // proposal in the lane's column of xb — where the matrix pass takes its B operand and the element-wise passes after it find the proposal again —
     // and keeps only the pass's accumulators (the proposal's gradient) and, for HMC, the momentum in registers.
+    // MALA / MH (RES): no load from memory stands between two transitions of a chain that accepts.  An accepted proposal IS the next current value, and it
+    // already sits in the lane's LDS column; its gradient already sits in the accumulators.  The current value a transition needs after its pass (MALA's
+    // backward term; putting a rejected column back) is requested from X before the pass and arrives under it; only a lane that rejects re-reads its
+    // gradient from GR, and that request goes out at the accept test, ahead of the commit and of the next transition's first Philox blocks.
+    // (MH: measured slower in this form — 40.1 against 45.6 TFLOP/s at D = 320, 59.8 against 62.7 at 1,024: the scales and the requested value cost 64 registers, 270-400 B of scratch —,
+    // so MH keeps reading value and scales where it draws; KLARA_SPLIT_RESIDENT=2 builds it.)
+    constexpr bool RES = KLARA_SPLIT_RESIDENT != 0 && (SAMPLER == KLARA_SAMPLER_MALA || (SAMPLER == KLARA_SAMPLER_MH && KLARA_SPLIT_RESIDENT == 2));
+    kd_double4 ga[4];                                                  // +P (x' - mu) of the lane's 16 elements: element e = ga[e >> 2][e & 3]
+    double sg[SAMPLER == KLARA_SAMPLER_MH && RES ? NE : 1];           // MH: the proposal scales of the lane's elements (0 past D)
+    if (RES) {
+        const __amdgpu_buffer_rsrc_t wX = mwin<NE>(cx, p.X, 0, p.D), wG = mwin<NE>(cx, p.GR, 0, p.D);
+        const int nv = cx.nv_here();
+#pragma unroll
+        for (int e0 = 0; e0 < NE; e0 += CH) {
+            double xv[CH], gv[CH];
+            split_load8(cx, wX, e0, nv, xv);
+            if (NEEDG) split_load8(cx, wG, e0, nv, gv);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { sc.wr(e0 + j, xv[j]); if (NEEDG) ga[(e0 + j) >> 2][(e0 + j) & 3] = -gv[j]; }
+        }
+        if (SAMPLER == KLARA_SAMPLER_MH) {
+            const __amdgpu_buffer_rsrc_t wS = __builtin_amdgcn_make_buffer_rsrc((void*)p.vecparam, 0, p.D * 8, 0x00020000);
+            const unsigned so = (unsigned)(16 * sc.t0 + cx.q) * 8u;
+#pragma unroll
+            for (int e = 0; e < (SAMPLER == KLARA_SAMPLER_MH && RES ? NE : 1); ++e)
+                sg[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wS, so + 32u * (unsigned)e, 0, 0));       // (0 past D)
+        }
+    }
     for (int s = 0; s < kl.nsteps; ++s) {
         const unsigned long long t = kl.t0 + (unsigned long long)s;
         if (cnt) tune_count_proposal(p, tn);
         bool acc = false;
         double ltp = lt;
-        kd_double4 ga[4];                                              // +P (x' - mu) of the lane's 16 elements: element e = ga[e >> 2][e & 3]
         const __amdgpu_buffer_rsrc_t wX = mwin<NE>(cx, p.X, 0, p.D), wG = mwin<NE>(cx, p.GR, 0, p.D);
         // lt' = c + 1/2 (x' - mu).g' with g' = -ga: the lane's part
         const auto lt_part = [&]() {
@@ -343,7 +373,19 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
             double red[3];
             const double h = tn.step, halfh = 0.5 * h, sq = __builtin_sqrt(h), half_inv_h = 0.5 * (1.0 / h);
             double s1 = 0.0;
-            {
+            double xc[RES ? NE : 1];                                   // RES: the current value, from X, requested before the pass for use after it
+            if constexpr (RES) {
+                split_normals_each(sc, p.seed, gch(), t, [&](int e, double z) {
+                    const double mu = sc.col[e * 64] + halfh * -(double)ga[e >> 2][e & 3];          // MALA.jl:83
+                    const double xn = mu + sq * z;                     // MALA.jl:84
+                    sc.col[e * 64] = xn;
+                    const double q1 = mu - xn;
+                    s1 = s1 + (q1 * q1) * half_inv_h;                  // MALA.jl:90
+                });
+                const int nv = cx.nv_here();
+#pragma unroll
+                for (int e = 0; e < (RES ? NE : 1); ++e) xc[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, cx.off_fresh(e, nv), 0, 0));
+            } else {
                 const int nv = cx.nv_here();
                 double xv[CH], gv[CH];
                 split_load8(cx, wX, 0, nv, xv); split_load8(cx, wG, 0, nv, gv);
@@ -363,8 +405,8 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
                 const int nv = cx.nv_here();
 #pragma unroll
                 for (int e0 = 0; e0 < NE; e0 += CH) {
-                    double xc[CH], xn[CH], mv[CH];
-                    split_load8(cx, wX, e0, nv, xc);                   // the current value (X holds the committed state)
+                    double xo[CH], xn[CH], mv[CH];
+                    if (!RES) split_load8(cx, wX, e0, nv, xo);         // the current value (X holds the committed state)
 #pragma unroll
                     for (int j = 0; j < CH; ++j) { xn[j] = sc.rd(e0 + j); mv[j] = HASMU ? split_mu(sc, e0 + j) : 0.0; }
 #pragma unroll
@@ -372,7 +414,7 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
                         const double g = -(double)ga[(e0 + j) >> 2][(e0 + j) & 3];
                         l1 = l1 + (HASMU ? xn[j] - mv[j] : xn[j]) * g;
                         const double mup = xn[j] + halfh * g;          // MALA.jl:91
-                        const double q2 = mup - xc[j];
+                        const double q2 = mup - (RES ? xc[RES ? e0 + j : 0] : xo[j]);
                         s2 = s2 + (q2 * q2) * half_inv_h;              // MALA.jl:92
                     }
                 }
@@ -387,6 +429,18 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
             if (!acc && ratio > KD_LOG_UMIN_GUARD) {
                 const double u = kd_accept_uniform(kd_stream_block(p.seed, gch(), t, (uint32_t)((p.D + 1) >> 1)));
                 acc = ratio > kd_log_u01(u);
+            }
+            if constexpr (RES) {
+                // a lane that rejects: the current value back into its column; its gradient from GR, negated, into the accumulators.  (First the
+                // accepting lanes' gradient goes out — the commit below stores -ga, which a rejecting lane is about to overwrite: their stores are masked.)
+                if (__any(!acc)) {
+                    const int nv = cx.nv_here();
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const double gv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wG, cx.off_fresh(e, nv), 0, 0));
+                        if (!acc) { sc.wr(e, xc[RES ? e : 0]); ga[e >> 2][e & 3] = -gv; }
+                    }
+                }
             }
         } else if constexpr (SLICE) {
             // iterate/SliceSampler.jl:60-109, the chains of the tile out of lockstep (slice_free_machine, klara_kernels.h): a probe is one matrix pass over the
@@ -436,19 +490,25 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
         } else {
             // iterate/MH.jl:72-124
             double red[1];
-            {
+            double xc[RES ? NE : 1];
+            if constexpr (RES) {
+                split_normals_each(sc, p.seed, gch(), t, [&](int e, double z) { sc.col[e * 64] = sc.col[e * 64] + sg[RES ? e : 0] * z; });      // MH.jl:79
+                const int nv = cx.nv_here();
+#pragma unroll
+                for (int e = 0; e < (RES ? NE : 1); ++e) xc[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wX, cx.off_fresh(e, nv), 0, 0));
+            } else {
                 const int nv = cx.nv_here();
                 const __amdgpu_buffer_rsrc_t wS = __builtin_amdgcn_make_buffer_rsrc((void*)p.vecparam, 0, p.D * 8, 0x00020000);
                 const unsigned so = (unsigned)(16 * sc.t0 + cx.q) * 8u;
-                double xv[CH], sg[CH];
+                double xv[CH], sgv[CH];
                 const auto ld = [&](int e0) {
                     split_load8(cx, wX, e0, nv, xv);
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) sg[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wS, so + 32u * (unsigned)(e0 + j), 0, 0));   // (0 past D)
+                    for (int j = 0; j < CH; ++j) sgv[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wS, so + 32u * (unsigned)(e0 + j), 0, 0));   // (0 past D)
                 };
                 ld(0);
                 split_normals_each(sc, p.seed, gch(), t, [&](int e, double z) {
-                    sc.col[e * 64] = xv[e & (CH - 1)] + sg[e & (CH - 1)] * z;          // MH.jl:79
+                    sc.col[e * 64] = xv[e & (CH - 1)] + sgv[e & (CH - 1)] * z;          // MH.jl:79
                     if (e == CH - 1) ld(CH);
                 });
             }
@@ -462,6 +522,12 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
             if (!acc && ratio > KD_LOG_UMIN_GUARD) {
                 const double u = kd_accept_uniform(kd_stream_block(p.seed, gch(), t, (uint32_t)((p.D + 1) >> 1)));
                 acc = ratio > kd_log_u01(u);
+            }
+            if constexpr (RES) {
+                if (__any(!acc)) {                                     // a lane that rejects: the current value back into its column
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) { if (!acc) sc.wr(e, xc[RES ? e : 0]); }
+                }
             }
         }
 
