@@ -710,10 +710,11 @@ def extra_measurements(K, L, n, stream):
         ex["slice_swiss_logistic_layout"] = list(e.layout()); e.close()
         src_pair = ("KLARA_USER_FN double klara_user_pair(double x0, double x1, int pair, int D, const double* data, long long ndata, double* g0, double* g1)\n"
                     "{ *g0 = -2.0 * x0; *g1 = -2.0 * x1; return -(x0 * x0) - (x1 * x1); }\n")
+        # (round 6: on the few-lanes kernels, a probe compares the pair's own term — k_diagt<SLICE, .., USERPAIR>; round 5 summed the pairs and ran a whole-vector closure: 7.4e8)
         e = K.Engine(sampler=L.SAMPLER_SLICE, target=K.CustomTarget.pairwise(NDIMS, src_pair), nchains=n, nsteps=10 ** 6, slice_widths=np.full(NDIMS, 1.0),
-                     steps_per_launch=1, stream=stream)
+                     steps_per_launch=0, stream=stream)
         e.init_state_normal()
-        rate, ls, _ = timed_rate(e, n, 1, 4)
+        rate, ls, _ = timed_rate(e, n, 32, 64)
         ex["slice_pair_closure_d100_chain_transitions_per_s"] = rate
         ex["slice_pair_closure_d100_coordinate_updates_per_s"] = rate * NDIMS
         ex["slice_pair_closure_d100_layout"] = list(e.layout()); e.close()

@@ -161,7 +161,11 @@ static bool pair_source(const char* src) { return src != nullptr && strstr(src, 
 static bool pair_form(const klara_desc& d) { return d.target == KLARA_TARGET_CUSTOM && pair_source(d.custom_src); }
 // ... that the pair-transposed kernels do not serve (fewer than 9 pairs, the slice sampler): it runs as a whole-vector closure, the sum over its pairs
 // formed by klara_custom_compose.h (round 5; these jobs used to be refused)
-static bool pair_as_whole(const char* src, int sampler, int ndims) { return pair_source(src) && (ndims < 17 || sampler == KLARA_SAMPLER_SLICE); }
+// (round 6: the slice sampler takes pair closures on the few-lanes kernels too — k_diagt<SLICE, .., USERPAIR> —; KLARA_PAIR_SLICE_AS_WHOLE=1 keeps the whole-vector form of round 5)
+static bool pair_as_whole(const char* src, int sampler, int ndims)
+{
+    return pair_source(src) && (ndims < 17 || (sampler == KLARA_SAMPLER_SLICE && getenv("KLARA_PAIR_SLICE_AS_WHOLE") != nullptr));
+}
 static std::string pair_as_whole_source(const char* src) { return std::string("#define KLARA_PAIR_AS_WHOLE 1\n") + src; }
 
 // Whole-vector closures (klara_custom.h).  Up to 32 dimensions a lane keeps the whole vector in registers (one chain per lane); beyond,
@@ -244,7 +248,6 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     if (d.target == KLARA_TARGET_CUSTOM && pair_form(d)) {
         // pair closure (klara_diagt.h USERPAIR): the pair-transposed layout, Q = 8 / 16 / 32 lanes per chain
         if (D < 17 || D > 2 * 64 * KLARA_DIAGT_NP_MAX) return KLARA_ERR_UNSUPPORTED;       // (fewer than 9 pairs: use the whole-vector form)
-        if (d.sampler == KLARA_SAMPLER_SLICE) return KLARA_ERR_UNSUPPORTED;
         const int Q = D <= 128 ? 8 : (D <= 256 ? 16 : (D <= 512 ? 32 : 64));
         *kind = 3; *G = Q; *E = 2 * ((D + 2 * Q - 1) / (2 * Q));
         return KLARA_OK;
@@ -709,7 +712,7 @@ static klara_status create_impl(const klara_desc* desc, klara_handle** out, int 
             if (desc->monitor & KLARA_MON_HIST_LLLP) { free_all(h); delete h; return KLARA_ERR_INVALID_ARG; }
             const int modes[2] = { 0, 1 };
             h->jit_pair = true;
-            CK(klara_jit_create_pair(desc->custom_src, desc->sampler, desc->ndims, E / 2, G, mon_, tune_, da_, modes, (!mon_ && !tune_) ? 2 : 1, true, &h->jit));
+            CK(klara_jit_create_pair(desc->custom_src, desc->sampler, desc->ndims, E / 2, G, mon_, tune_, da_, modes, (!mon_ && !tune_ && desc->sampler != KLARA_SAMPLER_SLICE) ? 2 : 1, true, &h->jit));
         } else {
         int modes[2];
         const int nmodes = kernel_modes(h->d, modes);           // (h->d: the monitor word with what the library turned on itself)
@@ -1114,7 +1117,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
                 kp.group0 = c0 / cpw; kp.group_end = (c1 + cpw - 1) / cpw;
                 const long long nw = kp.group_end - kp.group0;               // one wavefront per group of cpw chains
                 const int np = lanes == 4 ? h->np4 : h->E / 2;
-                if (h->jit_pair) return klara_jit_launch_pair(h->jit, (onestep && !tune && !mon) ? 1 : 0, p, kp, nw, st);
+                if (h->jit_pair) return klara_jit_launch_pair(h->jit, (onestep && !tune && !mon && d.sampler != KLARA_SAMPLER_SLICE) ? 1 : 0, p, kp, nw, st);
                 if (lanes == 4)
                     return d.sampler == KLARA_SAMPLER_MH ? klara_launch_diagt_mh_q4(p, kp, np, onestep && !tune, unitw, mon, tune, da, ka, nw, st)
                          : d.sampler == KLARA_SAMPLER_HMC ? klara_launch_diagt_hmc_q4(p, kp, np, false, unitw, mon, tune, da, ka, nw, st)

@@ -391,7 +391,7 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
 #ifndef KLARA_USER_PAIR_TARGET
     static_assert(!USERPAIR, "pair closures exist in run-time compiled translation units only");
 #endif
-    static_assert(!USERPAIR || (UNITW && SAMPLER != KLARA_SAMPLER_SLICE && Q >= 8), "pair closures: MH / MALA / HMC on 8 or more lanes per chain");
+    static_assert(!USERPAIR || (UNITW && Q >= 8), "pair closures: 8 or more lanes per chain");
     if (ka.cell_in != nullptr && *ka.cell_in != ka.my_mode) return;       // (launch-uniform: the sibling kernel runs this launch)
     static_assert(!(ONESTEP && (MON || TUNE)), "monitored / tuned jobs run the committing kernel");
     static_assert(!DA || (TUNE && SAMPLER == KLARA_SAMPLER_HMC), "dual averaging: tuned HMC");
@@ -573,13 +573,18 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                     const double ru = kd_uniform_zw(b0);                                       // :71
                     const double wi_t = UNITW ? 1.0 : wv(e), mi_t = UNITW ? 0.0 : mv(e);
                     const double xi = x[e], wd = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wwid, (unsigned)(live ? i : 0) * 8u, 0, 0));
+                    // (round 6) a pair closure: the target is a sum of terms of ONE pair each, so an update of coordinate i = 2P (+ 1) compares the term of pair P
+                    // with the candidate in place of x_i against the pair's current term — the other pairs cancel like the other coordinates of the diagonal
+                    // target.  A lane holds whole pairs and walks its elements in ascending order: coordinate 2P + 1 sees the new x_2P (:65, :108).
                     double tcur, gd_;
-                    diag_elem<UNITW>(xi, wi_t, -2.0 * wi_t, mi_t, tcur, gd_);
+                    if constexpr (USERPAIR) { double g1_; user_pair(e >> 1, x[e & ~1], x[e | 1], tcur, gd_, g1_); }
+                    else diag_elem<UNITW>(xi, wi_t, -2.0 * wi_t, mi_t, tcur, gd_);
                     double Li = xi - ru * wd;                                                  // :72
                     double Ri = xi + (1.0 - ru) * wd;                                          // :73
                     const auto term_of = [&](double cand) -> double {
                         double tc, gd;
-                        diag_elem<UNITW>(cand, wi_t, -2.0 * wi_t, mi_t, tc, gd);
+                        if constexpr (USERPAIR) { double g1; user_pair(e >> 1, (e & 1) ? x[e & ~1] : cand, (e & 1) ? cand : x[e | 1], tc, gd, g1); }
+                        else diag_elem<UNITW>(cand, wi_t, -2.0 * wi_t, mi_t, tc, gd);
                         return tc;
                     };
                     if (p.stepout) {                                                           // :75-89
@@ -625,8 +630,13 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                     if (live && !stuck) x[e] = xprime;                                         // :108
                 }
                 red1[0] = 0.0;
+                if constexpr (USERPAIR) {
+#pragma unroll
+                    for (int pi = 0; pi < NP; ++pi) { double nt, g0_, g1_; user_pair(pi, x[2 * pi], x[2 * pi + 1], nt, g0_, g1_); red1[0] = red1[0] + nt; }
+                } else {
 #pragma unroll
                 for (int e = 0; e < E; ++e) { double te, gd; diag_elem<UNITW>(x[e], wv(e), m2wv(e), mv(e), te, gd); red1[0] = red1[0] + te; }
+                }
                 group_allreduce<1>(red1, Q, cx.lane);
                 lt = gconst - red1[0];                                                         // the new state's log-target: one full evaluation
                 ltp = lt;

@@ -706,6 +706,58 @@ static int ko_slice_diag_delta(const ko_target_ctx* c, uint64_t chain, uint64_t 
     return 1;
 }
 
+/* The same update for a PAIR CLOSURE in the pair-transposed layout (round 6: k_diagt<SLICE, .., USERPAIR>): lt = sum over pairs P of f_P(x_2P, x_2P+1), so a probe of
+ * coordinate i = 2P (+ 1) changes the term of pair P only and every comparison of the update, lt(candidate) > log(rand()) + lt, is made on that term:
+ *     n_P(current) - n_P(candidate) > log(rand())          with n_P = -f_P (the "negative term" the kernels sum)
+ * — the deviation (8) of the diagonal target, for the same reason (the other pairs cancel; a lane updates its own pairs).  Coordinate 2P + 1 sees the new
+ * x_2P (ascending coordinates, :65, :108).  The new state's log-target is one full evaluation in the layout's order.  ko_set_literal(1) takes this back. */
+static int ko_slice_pair_delta(const ko_target_ctx* c, uint64_t chain, uint64_t t, double* x, double* lt, int* stuck)
+{
+    const klara_desc* d = c->d;
+    const int D = d->ndims;
+    double scratch[KO_MAXD];
+    for (int i = 0; i < D; ++i) {                                        /* :65 */
+        const uint32_t base = (uint32_t)i << KO_SLICE_ATT_BITS;
+        const kd_u32x4 b0 = kd_stream_block(d->seed, chain, t, base);
+        const double lgu = kd_log_u01(kd_uniform_xy(b0));                /* :66 log(rand()) */
+        const double ru = kd_uniform_zw(b0);                             /* :71 */
+        const double w = d->slice_widths[i], xi = x[i];
+        const int P = i >> 1, full = 2 * P + 1 < D, second = i & 1;
+        const double other = second ? x[2 * P] : (full ? x[2 * P + 1] : 0.0);
+        double g0_, g1_;
+#define KO_TERM(v) (-ko_user_pair(second ? other : (v), second ? (v) : other, P, D, d->custom_data, (long long)d->custom_ndata, &g0_, &g1_))
+        const double tcur = KO_TERM(xi);
+        double Li = xi - ru * w;                                         /* :72 */
+        double Ri = xi + (1.0 - ru) * w;                                 /* :73 */
+        if (d->slice_stepout) {                                          /* :75-89 */
+            int guard = 0;
+            while (tcur - KO_TERM(Li) > lgu) {
+                Li -= w;
+                if (++guard > KO_SLICE_MAX_ATT) { *stuck = 1; return 0; }
+            }
+            guard = 0;
+            while (tcur - KO_TERM(Ri) > lgu) {
+                Ri += w;
+                if (++guard > KO_SLICE_MAX_ATT) { *stuck = 1; return 0; }
+            }
+        }
+        double xprime = xi;
+        for (uint32_t a = 1;; ++a) {                                     /* :91-106 */
+            if (a > KO_SLICE_MAX_ATT) { *stuck = 1; return 0; }
+            const double u = kd_slice_attempt_uniform(d->seed, chain, t, base, a);
+            xprime = u * (Ri - Li) + Li;                                 /* :92-93 */
+            if (tcur - KO_TERM(xprime) > lgu) break;                     /* :94-95 */
+            if (xprime > xi) Ri = xprime;                                /* :98 */
+            else if (xprime < xi) Li = xprime;                           /* :100 */
+            else { *stuck = 1; return 0; }                               /* :102 */
+        }
+#undef KO_TERM
+        x[i] = xprime;                                                   /* :108 */
+    }
+    *lt = ko_logtarget(c, x, scratch);
+    return 1;
+}
+
 /* Streaming batch means (klara_desc.bm_batchlen): mcvar(v, Val{:bm}) of src/stats/variance/mcvar.jl:35-41 takes
  * var(batch means); the history-free form closes a batch from the running sums at its two boundaries and updates the mean
  * and the sum of squared deviations of the batch means in place (Welford).  n = nchains * D series, count = batches closed
@@ -796,6 +848,7 @@ static int ko_transition(const ko_target_ctx* c, uint64_t gchain, uint64_t t, do
     case KLARA_SAMPLER_HMC: return ko_hmc(c, gchain, t, step, nleaps, x, g, lt, a_out);
     default:
         if (c->L->kind == 3 && d->target == KLARA_TARGET_GAUSS_DIAG && !ko_is_literal()) return ko_slice_diag_delta(c, gchain, t, x, lt, stuck);
+        if (c->L->kind == 3 && d->target == KLARA_TARGET_CUSTOM && ko_user_pair && !ko_is_literal()) return ko_slice_pair_delta(c, gchain, t, x, lt, stuck);
         return ko_slice(c, gchain, t, x, lt, stuck);
     }
 }

@@ -669,11 +669,21 @@ def make_case(name):
     elif name == "pair_banana_hmc_d16_whole":
         c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget.pairwise(16, SRC_PAIR_BANANA, [0.05, 9.0]), nchains=33, nsteps=30, burnin=0, leapstep=0.05, nleaps=5,
                  tuner=L.TUNER_ACCEPT_RATE, targetrate=0.7, period=10, x0=np.random.default_rng(12).standard_normal((33, 16)) * np.tile([2.0, 1.0], 8))
-    elif name == "pair_indexed_slice_d40_whole":       # the slice sampler on a pair closure: staged whole-vector form on 4 lanes per chain
+    elif name == "pair_indexed_slice_d40_whole":       # the slice sampler on a pair closure (round 5: staged whole-vector form on 4 lanes per chain; round 6: the few-lanes kernels, the whole-vector form under KLARA_PAIR_SLICE_AS_WHOLE=1)
         c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget.pairwise(40, SRC_PAIR_INDEXED, np.linspace(0.5, 2.0, 40)), nchains=21, nsteps=6, burnin=1,
                  slice_widths=np.linspace(0.5, 2.5, 40))
     elif name == "pair_negdot_slice_d6_whole":
         c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget.pairwise(6, SRC_PAIR_NEGDOT), nchains=66, nsteps=10, burnin=2, slice_widths=np.full(6, 1.5), slice_stepout=False)
+    # ---- round 6: the slice sampler on a pair closure runs on the few-lanes kernels (k_diagt<SLICE, .., USERPAIR>: a probe compares the pair's own term)
+    elif name == "pair_quartic_slice_d100":            # coupled within the pair: coordinate 2P + 1 sees the new x_2P; step-out on
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget.pairwise(100, SRC_PAIR_QUARTIC, [0.1, 0.4]), nchains=37, nsteps=8, burnin=2,
+                 slice_widths=np.linspace(0.5, 2.5, 100), x0=0.5 * np.random.default_rng(21).standard_normal((37, 100)))
+    elif name == "pair_banana_slice_d37":              # odd D: a half pair (x1 = 0) and padding pairs; no step-out; thinning
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget.pairwise(37, SRC_PAIR_BANANA, [0.05, 9.0]), nchains=21, nsteps=12, burnin=3, thinning=2,
+                 slice_widths=np.full(37, 2.0), slice_stepout=False, x0=np.random.default_rng(22).standard_normal((21, 37)))
+    elif name == "pair_indexed_slice_d300":            # 32 lanes per chain
+        c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget.pairwise(300, SRC_PAIR_INDEXED, np.linspace(0.5, 2.0, 300)), nchains=9, nsteps=5, burnin=1,
+                 slice_widths=np.linspace(0.5, 2.5, 300))
     elif name == "custom_quartic_slice_d7":
         c = dict(sampler=L.SAMPLER_SLICE, target=K.CustomTarget(7, SRC_QUARTIC_CHAIN, [0.1, 0.4]), nchains=66, nsteps=12, burnin=2,
                  slice_widths=np.full(7, 1.5))
@@ -711,6 +721,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "pair_negdot_mala_d100", "pair_negdot_mala_d100_big_step", "pair_quartic_hmc_d50_tuned", "pair_banana_mh_d33",
              "pair_banana_hmc_d100_dualavg", "pair_quartic_mala_d300_pooled", "pair_indexed_mala_d100", "pair_indexed_hmc_d37",
              "pair_quartic_mala_d9_whole", "pair_banana_hmc_d16_whole", "pair_indexed_slice_d40_whole", "pair_negdot_slice_d6_whole",
+             "pair_quartic_slice_d100", "pair_banana_slice_d37", "pair_indexed_slice_d300",
              "staged_negdot_mala_d100_big_step", "staged_quartic_mh_d33_thinned", "staged_quartic_slice_d40", "staged_quartic_hmc_d200_dualavg",
              "staged_quartic_mala_d70_pooled", "staged_normal_normal_mala_d48", "staged_quartic_hmc_d256_tuned"]
 # cases whose oracle output is also committed as a golden fixture (tests/golden/<name>.npz)

@@ -233,7 +233,7 @@ class OracleJob:
         self._user = None
         if custom_src is not None:
             # (a pair closure the pair-transposed kernels do not serve runs as a whole-vector closure: klara_api.hip pair_as_whole, klara_custom_compose.h)
-            if "KLARA_USER_PAIR_TARGET" in custom_src and (self.D < 17 or int(sampler) == L.SAMPLER_SLICE):
+            if "KLARA_USER_PAIR_TARGET" in custom_src and (self.D < 17 or (int(sampler) == L.SAMPLER_SLICE and "KLARA_PAIR_SLICE_AS_WHOLE" in os.environ)):
                 custom_src = "#define KLARA_PAIR_AS_WHOLE 1\n" + custom_src
             self._user = compile_user_target(custom_src, self.D)
             if custom_data is not None and np.size(custom_data):

@@ -481,6 +481,33 @@ def test_smaller_dense_targets_on_the_split_layout(name, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["pair_quartic_slice_d100", "pair_banana_slice_d37", "pair_indexed_slice_d300", "pair_indexed_slice_d40_whole"])
+def test_slice_sampler_on_pair_closures_runs_on_the_few_lanes_kernels(name, monkeypatch):
+    """Round 6: a pair closure under the slice sampler (rounds 1-4: refused; round 5: summed by the library and run as a whole-vector closure, every probe a full
+    evaluation) runs on the pair-transposed layout: a lane updates the coordinates of its own pairs and a probe compares the PAIR's term (oracle: ko_slice_pair_delta).
+    Both forms against the oracle in their own orders, bit for bit; the new state's log-target is one full evaluation in the layout's order in both."""
+    case = cases.make_case(name)
+    d = case["target"].ndims
+    eng, job = _run_pair(case)
+    assert eng.layout()[0] == 3 and eng.layout()[1] == (8 if d <= 128 else 16 if d <= 256 else 32), eng.layout()
+    _assert_same(eng, job, case)
+    x_pair = eng.state()[0]
+    eng.close()
+    n = case["nsteps"]
+    eng, job = _run_pair(case, splits=[1, n - 1], spl=3)
+    _assert_same(eng, job, case)
+    eng.close()
+    if d > 256:
+        return                       # (whole-vector closures stop at 256 dimensions: the few-lanes form is the only one there)
+    monkeypatch.setenv("KLARA_PAIR_SLICE_AS_WHOLE", "1")
+    eng, job = _run_pair(case)
+    assert eng.layout()[0] == 0
+    _assert_same(eng, job, case)
+    # the two forms draw the same uniforms and differ in how a comparison is rounded (a term against a total): the same states up to the rare flip
+    assert np.mean(np.abs(eng.state()[0] - x_pair) < 1e-9) > 0.95
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["hmc_logit_d20_wide", "mala_logitm_d20", "slice_logitm_d20", "mala_logit_d12_manyrows"])
 def test_logistic_beyond_16_parameters_closure_form_still_matches(name, monkeypatch):
     """Round 6 moved the logistic regression beyond 16 parameters (and 9 .. 16 with rows that do not fit the LDS) onto the matrix cores; the run-time compiled
