@@ -732,7 +732,9 @@ GOLDEN_CASES = ["mh_readme", "mala_d100", "hmc_d100", "hmc_dense_d100", "mala_sw
                 # round 5's new paths: the slice sampler on the free-running diagonal kernel, on the dense targets (chains of a tile out of lockstep; streamed layout), a pair closure run as a whole-vector closure
                 "slice_d20_stepout", "slice_dense_d20", "slice_dense_d130_stream_mean", "pair_quartic_mala_d9_whole",
                 # round 6: the logistic regression beyond 16 parameters on the matrix cores (layout kind 5)
-                "mala_logitm_d20", "hmc_logitm_d40_dualavg"]
+                "mala_logitm_d20", "hmc_logitm_d40_dualavg",
+                # ... dense targets beyond D = 256 on the workgroup-split layout (kind 6: the even tile deal) and the slice sampler on a pair closure (the pair's own term)
+                "hmc_dense_d300_split", "mala_dense_d512_split_mean_tuned", "slice_dense_d260_split", "pair_quartic_slice_d100"]
 
 
 def oracle_kwargs(case, layout=None, chain_offset=0, nchains=None):
