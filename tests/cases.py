@@ -420,7 +420,12 @@ def make_case(name):
         # round 6: the dense Gaussian beyond D = 256 — a workgroup of W = ceil(D / 64) wavefronts per tile of 16 chains (klara_dense_split.h, layout kind 6)
         d, kw = SPLIT_CASES[name][0], dict(SPLIT_CASES[name][1])
         rng = np.random.default_rng(2000 + d)
-        a = rng.standard_normal((d, d)); pm = a @ a.T / d + np.eye(d)
+        # (a precision matrix built from element-wise operations only: a matrix product takes whatever summation order the box's BLAS has, and the golden
+        # fixtures of these cases must not depend on the box — diagonal + three dense rank-one terms: every entry non-zero, positive definite)
+        pm = np.diag(1.0 + rng.random(d))
+        for _ in range(3):
+            u = rng.standard_normal(d)
+            pm = pm + np.outer(u, u) * (0.4 / d)
         mu = rng.standard_normal(d) if "_mean" in name else None
         t = K.GaussDenseTarget(pm, const=0.75, mu=mu)
         n = kw.pop("nchains", 21)
