@@ -713,7 +713,7 @@ def test_error_paths():
         eng.chain(0)                                           # history not monitored
     assert ei.value.status == L.ERR_STATE
     eng.close()
-    for kw in (dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(np.eye(257))),                 # the matrix-core layouts end at D = 128, the closure form at 256
+    for kw in (dict(sampler=L.SAMPLER_HMC, target=K.GaussDenseTarget(np.eye(1025))),                # the matrix-core layouts end at D = 1,024 (round 6: the workgroup-split layout; 256 before)
                dict(sampler=L.SAMPLER_MALA, target=K.GaussDiagTarget.negdot(4), tuner=L.TUNER_DUAL_AVERAGING,
                     targetrate=0.6, da_nadapt=10),
                dict(sampler=L.SAMPLER_SLICE, slice_widths=np.ones(4), target=K.GaussDiagTarget.negdot(4),
