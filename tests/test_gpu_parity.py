@@ -892,18 +892,23 @@ def test_readme_flow_basic_mc_job():
 
 
 # ------------------------------------------------------------------ randomized configurations
-def _random_case(seed, wide=False, logit_mfma=False):
+def _random_case(seed, wide=False, logit_mfma=False, split=False):
     """One job drawn from the whole configuration space the library accepts: target family and size, sampler, tuner,
     range, chain count (valid combinations only — the refused ones are in test_error_paths).  wide: the sizes round 4 moved onto hand-written
     kernels — dense targets of 129..256 dimensions (streamed matrix-core layouts) and logistic regressions with 9..16 parameters (row split)."""
-    rng = np.random.default_rng((9000 if logit_mfma else 5000 if wide else 1000) + seed)
-    fam = "logitm" if logit_mfma else rng.choice(["dense", "logit"]) if wide else rng.choice(["diag_unit", "diag", "dense", "logit", "hier", "custom"], p=[0.2, 0.25, 0.15, 0.13, 0.14, 0.13])
+    rng = np.random.default_rng((13000 if split else 9000 if logit_mfma else 5000 if wide else 1000) + seed)
+    fam = "dense_split" if split else "logitm" if logit_mfma else rng.choice(["dense", "logit"]) if wide else rng.choice(["diag_unit", "diag", "dense", "logit", "hier", "custom"], p=[0.2, 0.25, 0.15, 0.13, 0.14, 0.13])
     if fam == "logitm":       # round 6: 17 .. 128 parameters on the matrix cores (klara_logit_mfma.h): every NE, rows that end inside a tile / a block of tiles
         d = int(rng.choice([17, 20, 31, 32, 33, 48, 64, 65, 96, 97, 128, 129, 192, 256]))
         n = int(rng.choice([1, 15, 16, 17, 32, 33, 100, 300]))
         X, y = cases.synthetic_logit(n, d, seed=seed)
         target = K.LogisticTarget(X / np.sqrt(d), y, float(rng.choice([1.0, 100.0])))
         fam = "logit"
+    elif fam == "dense_split":    # round 6: dense targets of 257 .. 1,024 dimensions on the workgroup-split layout (8 / 12 / 16 wavefronts per tile, every tile deal)
+        d = int(rng.choice([257, 272, 289, 320, 333, 384, 385, 448, 512, 513, 576, 641, 700, 768, 769, 900, 1000, 1024]))
+        target = K.GaussDenseTarget(cases.compound_symmetric_precision(d, float(rng.uniform(0.1, 0.7))), const=float(rng.uniform(-2, 2)),
+                                    mu=(rng.uniform(-1.5, 1.5, d) if rng.integers(0, 2) else None))
+        fam = "dense"
     elif fam == "diag_unit":
         d = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 19, 31, 40, 63, 77, 100, 128, 129, 200, 300]))
         target = K.GaussDiagTarget.negdot(d)
@@ -930,8 +935,8 @@ def _random_case(seed, wide=False, logit_mfma=False):
         target = K.CustomTarget(d, cases.SRC_QUARTIC_CHAIN, [float(rng.uniform(0.01, 0.2)), float(rng.uniform(0.1, 0.8))])
     samplers = [L.SAMPLER_MH, L.SAMPLER_MALA, L.SAMPLER_HMC] + ([] if (fam == "dense" and d > 70) or (logit_mfma and d > 48) else [L.SAMPLER_SLICE])   # (dense slice: D full evaluations per probe on the oracle's side)
     sampler = int(rng.choice(samplers))
-    scale = 0.02 if fam == "hier" else (0.5 if logit_mfma else 0.05 if fam == "logit" else (0.1 if wide else 0.3))
-    c = dict(sampler=sampler, target=target, nchains=int(rng.choice([1, 2, 7, 8, 9, 33, 64, 100, 131])), x0=None, seed=int(rng.integers(1, 2 ** 40)),
+    scale = 0.02 if fam == "hier" else (0.5 if logit_mfma else 0.05 if fam == "logit" else (0.06 if split else 0.1 if wide else 0.3))
+    c = dict(sampler=sampler, target=target, nchains=int(rng.choice([1, 2, 7, 8, 9, 33, 64, 100, 131] if not split else [1, 7, 16, 17, 33, 50])), x0=None, seed=int(rng.integers(1, 2 ** 40)),
              name=f"random_{seed}_{fam}")
     if sampler == L.SAMPLER_MH:
         c["mh_sigma"] = np.full(d, scale) * rng.uniform(0.5, 1.5, d)
@@ -943,6 +948,8 @@ def _random_case(seed, wide=False, logit_mfma=False):
         c["slice_widths"] = np.full(d, 4 * scale) * rng.uniform(0.5, 1.5, d); c["slice_stepout"] = bool(rng.integers(0, 2))
     c["burnin"] = int(rng.choice([0, 3, 20])); c["thinning"] = int(rng.choice([1, 1, 2, 5]))
     c["nsteps"] = c["burnin"] + int(rng.integers(6, 40))
+    if split:                          # (the oracle's side: D^2 flop per gradient on one core per chain)
+        c["burnin"] = min(c["burnin"], 3); c["nsteps"] = c["burnin"] + int(rng.integers(4, 14))
     tun = rng.choice(["vanilla", "verbose", "rate", "rate_erf", "pooled", "da"])
     if tun == "verbose":
         c.update(verbose=True, period=int(rng.integers(3, 12)))
@@ -1061,6 +1068,17 @@ def test_random_configurations_wide(seed):
     """48 more jobs from the sizes that moved onto hand-written kernels in round 4 (dense 129..256 dimensions on the streamed matrix-core layouts — HMC with
     every tuner, MALA, MH; logistic regression with 9..16 parameters), run like the others."""
     _run_random(*_random_case(seed, wide=True))
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_configurations_dense_on_the_split_layout(seed):
+    """32 dense targets of 257 .. 1,024 dimensions (layout kind 6, klara_dense_split.h; round 6): MH / MALA / HMC, every tuner, any range and chain count, random launch
+    splitting, a shard's chain offset — run like the others."""
+    c, rng = _random_case(seed, split=True)
+    e = K.Engine(**cases.engine_kwargs(c))
+    assert e.layout()[0] == 6
+    e.close()
+    _run_random(c, rng)
 
 
 @pytest.mark.parametrize("seed", range(40))
