@@ -106,7 +106,7 @@ typedef enum klara_target {
      *   KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata);
      *   KLARA_USER_FN void   klara_user_gradlogtarget(const double* x, int D, const double* data, long long ndata,
      *                                                 double* g);           (needed by MALA / HMC only)
-     * and is compiled for gfx950 at klara_create (hiprtc) into the group-layout transition kernels (D <= 256; KLARA_D is predefined
+     * and is compiled for gfx950 at klara_create (hiprtc) into the group-layout transition kernels (D <= 1024 — round 6: up to 64 lanes x 16 elements of the staged form; 256 before —; KLARA_D is predefined
      * to D so that loops unroll): up to D = 32 one chain per lane, the whole vector in the lane's registers; beyond, 4 .. 32 lanes per
      * chain — normals, sampler arithmetic and sums spread over them — and for an evaluation the closure reads the vector from the chain's
      * row of LDS, every lane of the chain evaluating it identically (KLARA_CUSTOM_LANES=1 in the environment keeps one chain per lane
@@ -130,7 +130,7 @@ typedef enum klara_target {
      * ascending order, then the butterfly over the chain's lanes) instead of holding the whole vector in one lane: at D = 100 the
      * README closure runs at 3.5e9 transitions/s in this form and at 2.1e8 in the whole-vector form.  A pair-form job those kernels do
      * not serve — D < 17, or the slice sampler — is taken as a whole-vector closure whose logtarget is the sum of the pairs' terms,
-     * pair 0 first (klara_custom_compose.h; D <= 256). */
+     * pair 0 first (klara_custom_compose.h; D <= 1024). */
     KLARA_TARGET_CUSTOM = 4
 } klara_target;
 

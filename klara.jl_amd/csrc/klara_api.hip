@@ -15,7 +15,7 @@
 
 // user-defined targets keep the whole vector in one lane (klara_custom.h): pow2ceil(D) elements per lane
 #ifndef KLARA_CUSTOM_MAXD
-#define KLARA_CUSTOM_MAXD 256
+#define KLARA_CUSTOM_MAXD 1024           // (round 6: 64 lanes x 16 elements of the staged form; 256 before)
 #endif
 
 // device-decided kernel choice (KAuto): launches shorter than this are issued as one kernel chosen on the host
@@ -184,15 +184,15 @@ static size_t custom_stage_bytes(int D, int G, int nrows, int wpb)        // (kl
 static void custom_layout(int D, int lanes, bool lik_prior, int* G, int* E, int* wpb)
 {
     *wpb = 4;
-    if (const char* s = getenv("KLARA_CUSTOM_LANES")) { const int v = atoi(s); if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) lanes = v; }
+    if (const char* s = getenv("KLARA_CUSTOM_LANES")) { const int v = atoi(s); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) lanes = v; }
     if (lanes == 1 || (lanes == 0 && D <= 32)) { *G = 1; *E = pow2ceil(D < 2 ? 2 : D); return; }
     int g = lanes > 1 ? lanes : 4;
-    while (g < 32 && (D + 2 * g - 1) / (2 * g) > 8) g *= 2;                      // at most 16 elements per lane
+    while (g < 64 && (D + 2 * g - 1) / (2 * g) > 8) g *= 2;                      // at most 16 elements per lane (round 6: up to 64 lanes — one chain per wavefront —: D <= 1024)
     const int nrows = lik_prior ? 3 : 2;
     int w = 4;
     if (const char* s = getenv("KLARA_CUSTOM_WPB")) { const int v = atoi(s); if (v == 2 || v == 4) w = v; }
     else if (g >= 8 && custom_stage_bytes(D, g, nrows, 4) > KLARA_LDS_DEFAULT_DYNAMIC) w = 2;     // (measured: D = 128 +20 %, D = 256 +21 %; at 4 lanes x 16 elements the kernels spill and 8 x 8 on four wavefronts is faster)
-    while (g < 32 && custom_stage_bytes(D, g, nrows, w) > KLARA_LDS_DEFAULT_DYNAMIC) g *= 2;
+    while (g < 64 && custom_stage_bytes(D, g, nrows, w) > KLARA_LDS_DEFAULT_DYNAMIC) g *= 2;
     *G = g; *E = 2 * ((D + 2 * g - 1) / (2 * g)); *wpb = w;
 }
 static bool custom_lik_prior(const char* src) { return src != nullptr && strstr(src, "KLARA_USER_LIKELIHOOD_PRIOR") != nullptr; }

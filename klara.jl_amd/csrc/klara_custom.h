@@ -11,7 +11,7 @@
 // device, libm calls are not).  `data` is the job's read-only block (klara_desc.custom_data) in device memory.  Two forms of the layout:
 //  * D <= 32: one chain per lane (G = 1, E = pow2ceil(D) elements in registers): the user's function sees the lane's registers, no
 //    cross-lane reduction exists.  (Also every D <= 256 on request, KLARA_CUSTOM_LANES=1: the vector then lives in scratch beyond 32.)
-//  * D > 32, STAGED: G = 4 .. 32 lanes per chain, E = 2 ceil(D / 2G) <= 16 elements per lane in registers.  Proposal normals, sampler
+//  * D > 32, STAGED: G = 4 .. 64 lanes per chain (round 6: 64 — one chain per wavefront — for 513 <= D <= 1024), E = 2 ceil(D / 2G) <= 16 elements per lane in registers.  Proposal normals, sampler
 //    arithmetic, running sums and monitors are spread over the chain's lanes like in the built-in group layout; for an evaluation the
 //    lanes write their elements into the chain's row of LDS, every lane of the chain calls the user's function on that row (the G
 //    evaluations are identical — a wavefront serves 64 / G chains per evaluation instead of 64 — but the vector never sees scratch), the

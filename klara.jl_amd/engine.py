@@ -142,7 +142,7 @@ class CustomTarget:
         derivatives (for the half pair of an odd D, x1 is 0 and *g1 is ignored).  Such a job runs on the few-lanes-per-chain
         kernels of the diagonal Gaussian (layout kind 3: 8 / 16 / 32 / 64 lanes per chain, 17 <= D <= 1024; MH, MALA, HMC with every tuner
         and monitor) instead of one chain per lane — the form for large D (include/klara_hip.h, KLARA_USER_PAIR_TARGET).  Below 17 dimensions, and
-        the library sums the pairs' terms itself and runs the whole-vector form (D <= 256); the slice sampler runs on them too (round 6: a probe compares the pair's own term)."""
+        the library sums the pairs' terms itself and runs the whole-vector form (D <= 1024); the slice sampler runs on them too (round 6: a probe compares the pair's own term)."""
         return cls(ndims, "#define KLARA_USER_PAIR_TARGET 1\n" + pair_source, data)
 
     @property

@@ -610,6 +610,15 @@ def make_case(name):
     elif name == "custom_quartic_mala_d100":  # a user-defined target at the BASELINE dimension: 8 lanes per chain, staged through LDS
         c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(100, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=70, nsteps=12, burnin=2,
                  driftstep=0.04)
+    # ---- round 6: whole-vector closures beyond 256 dimensions (refused before): the staged form on 32 / 64 lanes per chain, 16 elements per lane
+    elif name == "custom_quartic_hmc_d300":   # 32 lanes per chain
+        c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(300, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=9, nsteps=10, burnin=2,
+                 leapstep=0.06, nleaps=3, tuner=L.TUNER_ACCEPT_RATE, targetrate=0.7, period=4)
+    elif name == "custom_quartic_mala_d700":  # 64 lanes per chain: one chain per wavefront
+        c = dict(sampler=L.SAMPLER_MALA, target=K.CustomTarget(700, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=7, nsteps=10, burnin=2, thinning=2,
+                 driftstep=0.01)
+    elif name == "custom_negdot_mh_d1024":    # the largest
+        c = dict(sampler=L.SAMPLER_MH, target=K.CustomTarget(1024, SRC_NEGDOT), nchains=5, nsteps=12, burnin=0, mh_sigma=np.full(1024, 0.03))
     elif name == "custom_quartic_hmc_d50":
         c = dict(sampler=L.SAMPLER_HMC, target=K.CustomTarget(50, SRC_QUARTIC_CHAIN, [0.02, 0.5]), nchains=33, nsteps=12, burnin=2,
                  leapstep=0.08, nleaps=5)
@@ -721,7 +730,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"] + list(LOGIT_MFMA_CASES) + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
              "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
-             "custom_quartic_mala_d64", "custom_quartic_mala_d100", "custom_quartic_hmc_d50", "custom_normal_normal_mala", "custom_normal_normal_mh",
+             "custom_quartic_mala_d64", "custom_quartic_mala_d100", "custom_quartic_hmc_d50", "custom_quartic_hmc_d300", "custom_quartic_mala_d700", "custom_negdot_mh_d1024", "custom_normal_normal_mala", "custom_normal_normal_mh",
              "sparse_mala_d100", "sparse_mala_d100_small_step", "sparse_mh_d100", "sparse_mala_mvnormal_d30",
              "pair_negdot_mala_d100", "pair_negdot_mala_d100_big_step", "pair_quartic_hmc_d50_tuned", "pair_banana_mh_d33",
              "pair_banana_hmc_d100_dualavg", "pair_quartic_mala_d300_pooled", "pair_indexed_mala_d100", "pair_indexed_hmc_d37",

@@ -138,10 +138,10 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
         rows = custom_rows
         stride = rows * ((d + 1) & ~1) + 2
         stride += 2 if (2 * stride) % 64 == 0 else 0
-        while g < 32 and (d + 2 * g - 1) // (2 * g) > 8:          # at most 16 elements per lane
+        while g < 64 and (d + 2 * g - 1) // (2 * g) > 8:          # at most 16 elements per lane (round 6: up to 64 lanes, D <= 1024)
             g *= 2
         wpb = int(os.environ.get("KLARA_CUSTOM_WPB", "0")) or (2 if (g >= 8 and 4 * (64 // g) * stride * 8 > 57344) else 4)   # wavefronts per workgroup
-        while g < 32 and wpb * (64 // g) * stride * 8 > 57344:
+        while g < 64 and wpb * (64 // g) * stride * 8 > 57344:
             g *= 2
         return (0, g, 2 * ((d + 2 * g - 1) // (2 * g)))
     if target_kind == L.TARGET_CUSTOM:        # one chain per lane, pow2ceil(D) elements in registers (klara_custom.h)

@@ -497,8 +497,6 @@ def test_slice_sampler_on_pair_closures_runs_on_the_few_lanes_kernels(name, monk
     eng, job = _run_pair(case, splits=[1, n - 1], spl=3)
     _assert_same(eng, job, case)
     eng.close()
-    if d > 256:
-        return                       # (whole-vector closures stop at 256 dimensions: the few-lanes form is the only one there)
     monkeypatch.setenv("KLARA_PAIR_SLICE_AS_WHOLE", "1")
     eng, job = _run_pair(case)
     assert eng.layout()[0] == 0
@@ -1301,7 +1299,7 @@ def test_custom_target_compile_error_and_limits():
         K.Engine(sampler=L.SAMPLER_MALA, target=K.CustomTarget(2, cases.SRC_BANANA_LT_ONLY), nchains=4, nsteps=5, driftstep=0.1)
     assert ei.value.status == L.ERR_COMPILE and "klara_user_gradlogtarget" in ei.value.log
     with pytest.raises(K.KlaraError) as ei:               # D <= 256: the whole vector lives in one lane
-        K.Engine(sampler=L.SAMPLER_MH, target=K.CustomTarget(257, cases.SRC_NEGDOT), nchains=4, nsteps=5, mh_sigma=np.ones(257))
+        K.Engine(sampler=L.SAMPLER_MH, target=K.CustomTarget(1025, cases.SRC_NEGDOT), nchains=4, nsteps=5, mh_sigma=np.ones(1025))
     assert ei.value.status == L.ERR_UNSUPPORTED
     # a closure that is not finite at the start: the reference's initialize! assert (MH.jl:83)
     src = "KLARA_USER_FN double klara_user_logtarget(const double* x, int D, const double* data, long long ndata) { return kd_log(x[0]); }"

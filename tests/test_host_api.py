@@ -443,7 +443,7 @@ def test_create_validates_like_the_reference_constructors(klib):
     assert status(sampler=L.SAMPLER_HMC, tuner=L.TUNER_DUAL_AVERAGING, targetrate=0.6, da_nadapt=0) == L.ERR_INVALID_ARG
     assert status(sampler=L.SAMPLER_MH, mh_sigma=[1.0, 1.0], monitor=L.MON_HIST_GRAD) in (L.ERR_INVALID_ARG, L.ERR_HIP)
     import cases
-    assert status(target=K.CustomTarget(257, cases.SRC_NEGDOT)) == L.ERR_UNSUPPORTED                   # one lane holds the vector: D <= 256
+    assert status(target=K.CustomTarget(1025, cases.SRC_NEGDOT)) == L.ERR_UNSUPPORTED                  # 64 lanes x 16 elements: D <= 1024 (round 6; 256 before)
     assert status(target=K.CustomTarget(2, cases.SRC_NEGDOT, data=np.zeros(0))) in (0, L.ERR_HIP)       # empty data block is fine
     rng = np.random.default_rng(0)
     big = K.LogisticTarget(rng.standard_normal((3687, 4)), np.zeros(3687))
@@ -710,7 +710,7 @@ def test_custom_target_source_compiles_without_a_gpu():
         K.CustomTarget(2, cases.SRC_BANANA_LT_ONLY).check(L.SAMPLER_HMC)
     assert ei.value.status == L.ERR_COMPILE and "klara_user_gradlogtarget" in ei.value.log
     with pytest.raises(K.KlaraError) as ei:
-        K.CustomTarget(257, cases.SRC_NEGDOT).check(L.SAMPLER_MH)
+        K.CustomTarget(1025, cases.SRC_NEGDOT).check(L.SAMPLER_MH)
     assert ei.value.status == L.ERR_UNSUPPORTED
 
 
