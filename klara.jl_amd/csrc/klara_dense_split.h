@@ -336,10 +336,19 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
             }
             // dual averaging: per-chain trip count (iterate/HMC.jl:142-144); the tile runs to its longest trajectory (the same count in every
             // wavefront: each holds all 16 chains).  A finished chain's value and momentum stop changing, so the gradient the later passes recompute
-            // for it is the one it already has, bit for bit: only the two updates are masked.
+            // for it is the one it already has, bit for bit: only the two updates are masked — by their STEP: fma(0, p, x) = x and fma(0, g, p) = p
+            // exactly for finite p, g (one select per update instead of one per element and both versions of every element alive: the element-wise
+            // selects cost this kernel 100 scratch accesses per leapfrog, matrix pipes 0.64 busy against the plain kernel's 0.86).
             const int nl = da ? (cx.chain_ok ? da_nleaps(p, eps) : 1) : p.nleaps;
-            for (int l = 0; da ? __any(l < nl) : (l < nl); ++l) {
+            int nlmax = nl;                                            // the tile's longest trajectory: a scalar trip count (a vote per trip cost the loop its registers)
+            if (da) {
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) { const int o = __builtin_amdgcn_ds_bpermute((cx.lane ^ m) << 2, nlmax); nlmax = o > nlmax ? o : nlmax; }
+                nlmax = __builtin_amdgcn_readfirstlane(nlmax);
+            }
+            for (int l = 0; l < nlmax; ++l) {
                 const bool go = !da || l < nl;
+                const double eps_l = go ? eps : 0.0;
                 if (l > 0) __syncthreads();                            // the previous pass is over in every wavefront: xb may change
 #pragma unroll
                 for (int e0 = 0; e0 < NE; e0 += CH) {
@@ -347,13 +356,13 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
 #pragma unroll
                     for (int j = 0; j < CH; ++j) xv[j] = sc.rd(e0 + j);
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) { const double v = kd_fma(eps, mom[e0 + j], xv[j]); sc.wr(e0 + j, go ? v : xv[j]); }
+                    for (int j = 0; j < CH; ++j) sc.wr(e0 + j, kd_fma(eps_l, mom[e0 + j], xv[j]));
                 }
                 __syncthreads();
                 split_pass<HASMU>(sc, ga);
-                const double nkf = l + 1 < nl ? -eps : -halfe;
+                const double nkf = go ? (l + 1 < nl ? -eps : -halfe) : 0.0;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) { const double v = kd_fma(nkf, (double)ga[e >> 2][e & 3], mom[e]); mom[e] = go ? v : mom[e]; }
+                for (int e = 0; e < NE; ++e) mom[e] = kd_fma(nkf, (double)ga[e >> 2][e & 3], mom[e]);
             }
             double red[2], k1 = 0.0;
 #pragma unroll
