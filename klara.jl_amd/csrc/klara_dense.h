@@ -398,7 +398,8 @@ void k_dense_transitions(const KParams* __restrict__ pp, const KLaunch kl, const
                 for (int e = 0; e < NG; ++e) gp[e] = -gp[e];
             } else {
                 const int nl = cx.chain_ok ? da_nleaps(p, eps) : 1;      // (a padding lane must not set the wavefront's trip count)
-                for (int l = 0; __any(l < nl); ++l) {
+                const int nlmax = wave_max_int(nl);
+                for (int l = 0; l < nlmax; ++l) {
                     const bool go = l < nl;
                     if (go) {
 #pragma unroll

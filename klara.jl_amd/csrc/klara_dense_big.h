@@ -262,7 +262,8 @@ void k_dense_big(const KParams* __restrict__ pp, const KLaunch kl, const double*
             // chain's value and momentum stop changing, so the gradient the later passes recompute for it is the one it already has, bit for bit:
             // only the two updates are masked, the accumulators need no second copy.
             const int nl = da ? (cx.chain_ok ? da_nleaps(p, eps) : 1) : p.nleaps;        // (a padding lane must not set the wavefront's trip count)
-            for (int l = 0; da ? __any(l < nl) : (l < nl); ++l) {
+            const int nlmax = da ? wave_max_int(nl) : nl;
+            for (int l = 0; l < nlmax; ++l) {
                 const bool go = !da || l < nl;
                 mom_read<NE>(momw, [&](int e, double m) { const double v = kd_fma(eps, m, xp[e]); xp[e] = go ? v : xp[e]; });
                 dense_stream<NE, HASMU>(Pfrag, cx.lane, xp, ga, ldsMu);              // ga = +P (x - mu)

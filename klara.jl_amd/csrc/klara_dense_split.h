@@ -340,12 +340,7 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
             // exactly for finite p, g (one select per update instead of one per element and both versions of every element alive: the element-wise
             // selects cost this kernel 100 scratch accesses per leapfrog, matrix pipes 0.64 busy against the plain kernel's 0.86).
             const int nl = da ? (cx.chain_ok ? da_nleaps(p, eps) : 1) : p.nleaps;
-            int nlmax = nl;                                            // the tile's longest trajectory: a scalar trip count (a vote per trip cost the loop its registers)
-            if (da) {
-#pragma unroll
-                for (int m = 1; m < 64; m <<= 1) { const int o = __builtin_amdgcn_ds_bpermute((cx.lane ^ m) << 2, nlmax); nlmax = o > nlmax ? o : nlmax; }
-                nlmax = __builtin_amdgcn_readfirstlane(nlmax);
-            }
+            const int nlmax = da ? wave_max_int(nl) : nl;              // the tile's longest trajectory: a scalar trip count (a vote per trip cost the loop its registers)
             for (int l = 0; l < nlmax; ++l) {
                 const bool go = !da || l < nl;
                 const double eps_l = go ? eps : 0.0;

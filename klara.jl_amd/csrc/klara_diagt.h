@@ -757,7 +757,8 @@ void k_diagt(const KParams* __restrict__ pp, const KLaunch kl, const KAuto ka)
                 // mirrored by the oracle): adjacent half-kicks are one update, every update is one fma
 #pragma unroll
                 for (int e = 0; e < E; ++e) mom[e] = kd_fma(halfe, gp[e], mom[e]);
-                for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {
+                const int nlmax = DA ? wave_max_int(nl) : nl;
+                for (int l = 0; l < nlmax; ++l) {
                     const bool go = !DA || l < nl;
                     const double kf = l + 1 < nl ? eps : halfe;
                     if constexpr (USERPAIR) {

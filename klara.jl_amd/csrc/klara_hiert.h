@@ -295,7 +295,8 @@ void k_hiert(const KParams* __restrict__ pp, const KLaunch kl)
             for (int k = 0; k < RPL; ++k) { mom.a[k] = kd_fma(halfe, gp.a[k], mom.a[k]); mom.b[k] = kd_fma(halfe, gp.b[k], mom.b[k]); }
     #pragma unroll
             for (int k = 0; k < 5; ++k) mom.h[k] = kd_fma(halfe, gp.h[k], mom.h[k]);
-            for (int l = 0; DA ? __any(l < nl) : (l < nl); ++l) {
+            const int nlmax = DA ? wave_max_int(nl) : nl;
+            for (int l = 0; l < nlmax; ++l) {
                 const bool go = !DA || l < nl;                                            // (a finished chain keeps its state)
     #pragma unroll
                 for (int k = 0; k < RPL; ++k) {

@@ -165,6 +165,15 @@ __device__ __forceinline__ double bperm_xor(double v, int lane, int m)
     const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(u >> 32));
     return kd_u2d(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
+// the largest value of v over the wavefront, as a scalar: the trip count of a loop in which every lane has its own (dual averaging: a vote per
+// trip — for (l = 0; __any(l < nl); ++l) — costs the register allocator the loop: 100 scratch accesses per leapfrog in k_dense_split, round 6)
+__device__ __forceinline__ int wave_max_int(int v)
+{
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, v); v = o > v ? o : v; }
+    return __builtin_amdgcn_readfirstlane(v);
+}
 __device__ __forceinline__ double lane_bcast(double v, int src_lane)
 {
     const uint64_t u = kd_d2u(v);
@@ -914,7 +923,8 @@ KLARA_PRAGMA_UNROLL_E
         // dual averaging: the trip count differs per chain (iterate/HMC.jl:142-144); the wavefront runs to the
         // longest trajectory it carries and finished chains keep their state (the target evaluation may use
         // cross-lane collectives, so control flow stays wave-uniform)
-        for (int l = 0; __any(l < nleaps); ++l) {
+        const int nlmax = wave_max_int(nleaps);
+        for (int l = 0; l < nlmax; ++l) {
             const bool go = l < nleaps;
             double gn[E];
 KLARA_PRAGMA_UNROLL_E

@@ -263,7 +263,8 @@ void k_logit_mfma(const KParams* __restrict__ pp, const KLaunch kl, const double
             // dual averaging: per-chain trip count (iterate/HMC.jl:142-144); the tile runs to its longest trajectory.  A finished chain's value and
             // momentum stop changing, so the later evaluations recompute for it the gradient and the log-target it already has, bit for bit.
             const int nl = da ? (cx.chain_ok ? da_nleaps(p, eps) : 1) : p.nleaps;    // (a padding lane must not set the wavefront's trip count)
-            for (int l = 0; da ? __any(l < nl) : (l < nl); ++l) {
+            const int nlmax = da ? wave_max_int(nl) : nl;
+            for (int l = 0; l < nlmax; ++l) {
                 const bool go = !da || l < nl;
                 mom_read<NE>(momw, [&](int e, double m) { const double v = kd_fma(eps, m, xp[e]); xp[e] = go ? v : xp[e]; });
                 ltp = logitm_target<NE, true>(p, F, ypad, ldsL12, nblocks, cx.lane, xp, gp);       // samplers.jl:132 (the last one is also HMC.jl:157)
