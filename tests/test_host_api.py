@@ -548,7 +548,7 @@ def test_round5_bench_lines_are_complete_and_recomputable():
 def test_round6_bench_lines_are_complete_and_recomputable():
     """profiles/r6_bench_{default,driver_flags}.json (the round's profile pass: one box for the counters, one for the lines): the driver's keys with `roofline.traffic` among
     the first; the headline fraction from the UNCHANGED 1,505-instruction budget and the line's own launch duration, rocprofv3's average of the same kernel within 6 %; the
-    fraction over the timed region; the collective the line names; the mixing-step, general-target slice and matrix-core logistic extras; cfg 3 at >= 0.88 of the MFMA peak."""
+    fraction over the timed region; the collective the line names; the mixing-step, general-target slice, matrix-core logistic and split-dense extras; cfg 3 at >= 0.88 of the MFMA peak."""
     import csv, json
     pmc = json.loads((ROOT / "profiles" / "r6_pmc_kernels.json").read_text())
     stats = {r["Name"]: r for r in csv.DictReader((ROOT / "profiles" / "r6_bench_headline_kernel_stats.csv").open())}
@@ -579,7 +579,12 @@ def test_round6_bench_lines_are_complete_and_recomputable():
             assert ex[key]["bound"] in ("valu", "mfma") and ex[key]["frac"] is not None and 0.3 < ex[key]["frac"] <= 1.0, (name, key, ex[key])
         assert 0.5 < ex["mala_d100_mixing_step"]["acceptance_rate"] < 0.62 and ex["mala_d100_mixing_step_transitions_per_s"] > 3e9
         assert ex["logistic_d64_n200_mala_transitions_per_s"] > 3e8 and ex["logistic_d64_n200_mala_roofline"]["layout"] == [5, 4, 16]       # (closure form: 4.7e7)
-        assert ex["slice_swiss_logistic_coordinate_updates_per_s"] > 3e8 and ex["slice_pair_closure_d100_coordinate_updates_per_s"] > 3e8
+        assert ex["slice_swiss_logistic_coordinate_updates_per_s"] > 3e8
+        assert ex["slice_pair_closure_d100_coordinate_updates_per_s"] > 3e10 and ex["slice_pair_closure_d100_layout"][0] == 3       # (round 6: the few-lanes kernels; the whole-vector form ran at 7.4e8)
+        # dense targets beyond D = 256 on the workgroup-split layout (round 6; refused before): HMC >= 0.8 of the FP64-MFMA peak, MALA >= 0.55
+        for dd, lo_h, lo_m in ((512, 0.80, 0.55), (1024, 0.82, 0.65)):
+            assert ex[f"hmc_dense_d{dd}_roofline"]["frac"] >= lo_h and ex[f"mala_dense_d{dd}_roofline"]["frac"] >= lo_m, dd
+            assert "layout kind 6" in ex[f"hmc_dense_d{dd}_roofline"]["kernel"]
         c3 = ex["cfg3_hmc_dense_roofline"]
         assert c3["frac"] >= 0.88 and c3["pmc"]["loaded_scratch"] == 0
         assert ex["cfg3_hmc_dense_leapfrog_chain_per_s"] >= 1e8 and ex["hmc_iso_leapfrog_chain_per_s"] >= 1e8          # north_star's HMC target
