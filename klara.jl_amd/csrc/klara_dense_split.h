@@ -20,6 +20,7 @@
 // pass's accumulators, its ring and, for HMC, the momentum.
 // MH, MALA, HMC (every tuner, dual averaging with per-chain trip counts), every monitor of the dense layouts.
 #pragma once
+#include <stdlib.h>
 #include "klara_dense.h"
 
 #define KLARA_SPLIT_NEW 16             // elements per lane and wavefront
@@ -86,7 +87,12 @@ __device__ __forceinline__ SplitCtx make_sctx(const KParams& p, const double* Pf
     return s;
 }
 // wavefronts per tile of 16 chains: whole SIMD rounds, at most 4 row tiles per wavefront
-static inline int klara_split_waves(int D) { const int MT = (D + 15) / 16; return 4 * ((MT + 15) / 16); }
+static inline int klara_split_waves(int D)
+{
+    const int MT = (D + 15) / 16, w = 4 * ((MT + 15) / 16);
+    if (const char* e = getenv("KLARA_SPLIT_W")) { const int v = atoi(e); if (v >= w && v <= 16 && v % 4 == 0) return v; }      // (measurements: more wavefronts, fewer tiles each)
+    return w;
+}
 // LDS bytes of a workgroup: xb (4 MT rows) + the partial sums (the 8 KB of detmath tables are static)
 static inline size_t klara_split_lds_bytes(int D)
 {
