@@ -208,12 +208,6 @@ static bool dense_streamed(const klara_desc& d)
 // the dense Gaussian beyond D = 256 (round 6): the tile of 16 chains on a WORKGROUP of W = 4, 8, 12 or 16 wavefronts that deal the ceil(D / 16) row tiles
 // of P evenly, 2 .. 4 each (klara_dense_split.h, layout kind 6; MH, MALA, HMC with every tuner; 257 <= D <= 1024).  KLARA_DENSE_SPLIT=1 in the environment puts the smaller
 // dense targets on it as well (measurements, tests).
-static int klara_split_waves_host(int D)
-{
-    const int MT = (D + 15) / 16, w = 4 * ((MT + 15) / 16);
-    if (const char* e = getenv("KLARA_SPLIT_W")) { const int v = atoi(e); if (v >= w && v <= 16 && v % 4 == 0) return v; }
-    return w;
-}
 static bool dense_split(const klara_desc& d)
 {
     if (d.target != KLARA_TARGET_GAUSS_DENSE || d.ndims > 64 * 16) return false;
@@ -242,7 +236,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     if (logit_mfma_eligible(d)) { *kind = 5; *G = 4; *E = 8 * ((d.ndims + 31) / 32); return KLARA_OK; }
     if (hiert_eligible(d)) { *kind = 4; *G = 8; *E = 8; return KLARA_OK; }
     const int D = d.ndims;
-    if (dense_split(d)) { *kind = 6; *G = klara_split_waves_host(D); *E = 16; return KLARA_OK; }      // G: wavefronts per tile of 16 chains (klara_dense_split.h klara_split_waves)
+    if (dense_split(d)) { *kind = 6; *G = klara_split_waves(D); *E = 16; return KLARA_OK; }      // G: wavefronts per tile of 16 chains (klara_dense_split.h klara_split_waves)
     if (d.target == KLARA_TARGET_GAUSS_DENSE) {
         *kind = 1; *G = 4;
         if (D <= 32) *E = 8; else if (D <= 64) *E = 16; else if (D <= 100) *E = 25; else if (D <= 128) *E = 32;

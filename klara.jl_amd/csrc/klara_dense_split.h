@@ -20,7 +20,6 @@
 // pass's accumulators, its ring and, for HMC, the momentum.
 // MH, MALA, HMC (every tuner, dual averaging with per-chain trip counts), every monitor of the dense layouts.
 #pragma once
-#include <stdlib.h>
 #include "klara_dense.h"
 
 #define KLARA_SPLIT_NEW 16             // elements per lane and wavefront
@@ -86,20 +85,7 @@ __device__ __forceinline__ SplitCtx make_sctx(const KParams& p, const double* Pf
     s.par = 0u;
     return s;
 }
-// wavefronts per tile of 16 chains: whole SIMD rounds, at most 4 row tiles per wavefront
-static inline int klara_split_waves(int D)
-{
-    const int MT = (D + 15) / 16, w = 4 * ((MT + 15) / 16);
-    if (const char* e = getenv("KLARA_SPLIT_W")) { const int v = atoi(e); if (v >= w && v <= 16 && v % 4 == 0) return v; }      // (measurements: more wavefronts, fewer tiles each)
-    return w;
-}
-// LDS bytes of a workgroup: xb (4 MT rows) + the partial sums (the 8 KB of detmath tables are static)
-static inline size_t klara_split_lds_bytes(int D)
-{
-    const size_t MT = ((size_t)D + 15) / 16;
-    return sizeof(double) * (4 * MT * 64 + 2 * 3 * (size_t)klara_split_waves(D) * 16);
-}
-
+// (klara_split_waves / klara_split_lds_bytes: klara_launch.h — the host's launch planning and the launcher share them)
 // mu of the lane's element e (HASMU; zero past D)
 __device__ __forceinline__ double split_mu(const SplitCtx& s, int e)
 {

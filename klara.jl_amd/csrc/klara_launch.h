@@ -1,5 +1,6 @@
 // klara_launch.h — launcher prototypes implemented by the per-sampler translation units
 #pragma once
+#include <stdlib.h>
 #include "klara_kernels.h"
 #include "klara_diagt.h"
 
@@ -41,6 +42,19 @@ hipError_t klara_launch_logit_mfma(const KParams* p, const KLaunch& kl, int samp
 hipError_t klara_launch_logit_mfma_init(const KParams& p, int NE, const double* F, const double* ypad, int nblocks, int needgrad, dim3 grid, hipStream_t st);
 int klara_logit_mfma_rbt();
 // dense Gaussian on a workgroup of W = 4 ceil(ceil(D / 16) / 16) wavefronts per tile of 16 chains (layout kind 6, klara_dense_split.h): 257 <= D <= 1024; MH, MALA, HMC
+// wavefronts per tile of 16 chains: whole SIMD rounds, at most 4 row tiles of P per wavefront
+static inline int klara_split_waves(int D)
+{
+    const int MT = (D + 15) / 16, w = 4 * ((MT + 15) / 16);
+    if (const char* e = getenv("KLARA_SPLIT_W")) { const int v = atoi(e); if (v >= w && v <= 16 && v % 4 == 0) return v; }      // (measurements: more wavefronts, fewer tiles each)
+    return w;
+}
+// LDS bytes of a workgroup: xb (4 MT rows of 64 doubles) + the partial sums (the 8 KB of detmath tables are static)
+static inline size_t klara_split_lds_bytes(int D)
+{
+    const size_t MT = ((size_t)D + 15) / 16;
+    return sizeof(double) * (4 * MT * 64 + 2 * 3 * (size_t)klara_split_waves(D) * 16);
+}
 hipError_t klara_launch_dense_split(const KParams* p, const KLaunch& kl, int sampler, bool da, int W, int D, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st);
 hipError_t klara_launch_dense_split_init(const KParams& p, int W, const double* Pfrag, bool hasmu, int needgrad, dim3 grid, hipStream_t st);      // row tiles per block the kernels were built for
 
