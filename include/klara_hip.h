@@ -91,7 +91,8 @@ typedef enum klara_target {
      * lt = dot(Xp, y) - sum(log(1+exp(Xp))) - 0.5 (p.p/lambda + D log(2 pi lambda)).  Up to 16 parameters: the data rows in LDS, dealt to 4 lanes
      * per chain; 17 .. 256 parameters (and 9 .. 16 with more rows than the LDS holds), every sampler: X p and X' (y - 1/(1+exp(-Xp))) of 16 chains
      * per wavefront on the FP64 matrix cores, X streamed from memory — any number of rows (round 6; layout kind 5).  (KLARA_LOGIT_NO_MFMA=1 in the
-     * environment: the same closures through the run-time compiled path, as in rounds 1-5.) */
+     * environment: the same closures through the run-time compiled path, as in rounds 1-5.)  257 .. 1024 parameters: that closure form, one chain
+     * per lane with the vector in scratch (correct, slow; round 6 — refused before). */
     KLARA_TARGET_LOGISTIC = 2,
     /* Hierarchical normal growth-curve model for data/rats/{weight,age}.csv (BASELINE cfg 5).  The reference
      * ships the data but no model (doc/examples/rats/Gibbs.jl:1-7 is a stub), so the target is builder-defined:

@@ -452,7 +452,7 @@ def make_case(name):
         c = dict(sampler=L.SAMPLER_MALA, target=K.LogisticTarget(X, y, 100.0), nchains=70, nsteps=40, burnin=10,
                  driftstep=0.1, x0=x0[None, :] + 0.1 * np.random.default_rng(1).standard_normal((70, 4)))
     elif name in ("mala_logit_d2", "hmc_logit_d7", "mh_logit_d8_small", "mala_logit_d6_bigdata", "slice_logit_d3", "mala_logit_d12_wide",
-                  "hmc_logit_d20_wide", "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"):
+                  "hmc_logit_d20_wide", "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows", "mala_logit_d300_closure"):
         # synthetic logistic data: E = 2 / 4 / 8 (D = 3, 6, 7: rows padded to E columns in LDS), with and without row split; 1,500 x 9
         # doubles = 108 KB of rows: beyond the 56 KB a launch gets by default
         d, nd = {"mala_logit_d2": (2, 90), "hmc_logit_d7": (7, 131), "mh_logit_d8_small": (8, 30), "mala_logit_d6_bigdata": (6, 1500),
@@ -460,7 +460,9 @@ def make_case(name):
                  # round 4: 9 .. 16 parameters on the row-split kernels (E = 16: two Philox blocks per lane, accept slots 5 .. 8), unsplit below 64
                  # rows, and back on the closure form when the rows do not fit the LDS
                  "hmc_logit_d16_rows": (16, 150), "mh_logit_d9_rows": (9, 131), "slice_logit_d13_rows": (13, 70), "mala_logit_d11_unsplit": (11, 40),
-                 "mala_logit_d12_manyrows": (12, 1100)}[name]
+                 "mala_logit_d12_manyrows": (12, 1100),
+                 # round 6: beyond the matrix-core layout's 256 parameters the closure form (one chain per lane, the vector in scratch), to 1,024 since whole-vector closures go there
+                 "mala_logit_d300_closure": (300, 40)}[name]
         rng = np.random.default_rng(d)
         X = rng.standard_normal((nd, d)); beta = rng.standard_normal(d)
         y = (rng.random(nd) < 1.0 / (1.0 + np.exp(-X @ beta))).astype(np.float64)
@@ -474,7 +476,8 @@ def make_case(name):
               "mh_logit_d9_rows": dict(sampler=L.SAMPLER_MH, mh_sigma=np.full(9, 0.15)),
               "slice_logit_d13_rows": dict(sampler=L.SAMPLER_SLICE, slice_widths=np.full(13, 0.7)),
               "mala_logit_d11_unsplit": dict(sampler=L.SAMPLER_MALA, driftstep=0.02),
-              "mala_logit_d12_manyrows": dict(sampler=L.SAMPLER_MALA, driftstep=0.002)}[name]
+              "mala_logit_d12_manyrows": dict(sampler=L.SAMPLER_MALA, driftstep=0.002),
+              "mala_logit_d300_closure": dict(sampler=L.SAMPLER_MALA, driftstep=0.002)}[name]
         c = dict(target=K.LogisticTarget(X, y, 10.0), nchains=45, nsteps=25, burnin=5, x0=0.1 * rng.standard_normal((45, d)), **kw)
     elif name in LOGIT_MFMA_CASES:
         # round 6: the logistic regression beyond 16 parameters on the matrix cores (klara_logit_mfma.h, layout kind 5): D = 17 .. 128 (NE = 8, 16, 24, 32
@@ -730,7 +733,7 @@ ALL_CASES = ["mh_readme", "mh_d100", "mh_mvnormal_d7", "mala_d100", "mala_d100_s
              "hmc_logit_d16_rows", "mh_logit_d9_rows", "slice_logit_d13_rows", "mala_logit_d11_unsplit", "mala_logit_d12_manyrows"] + list(LOGIT_MFMA_CASES) + [
              "custom_negdot_mala_d3", "custom_banana_mh", "custom_banana_hmc", "custom_banana_slice", "custom_logit_mala_d4",
              "custom_quartic_hmc_d10_dualavg", "custom_quartic_mala_d20_pooled", "custom_quartic_hmc_d32", "custom_quartic_slice_d7",
-             "custom_quartic_mala_d64", "custom_quartic_mala_d100", "custom_quartic_hmc_d50", "custom_quartic_hmc_d300", "custom_quartic_mala_d700", "custom_negdot_mh_d1024", "custom_normal_normal_mala", "custom_normal_normal_mh",
+             "custom_quartic_mala_d64", "custom_quartic_mala_d100", "custom_quartic_hmc_d50", "mala_logit_d300_closure", "custom_quartic_hmc_d300", "custom_quartic_mala_d700", "custom_negdot_mh_d1024", "custom_normal_normal_mala", "custom_normal_normal_mh",
              "sparse_mala_d100", "sparse_mala_d100_small_step", "sparse_mh_d100", "sparse_mala_mvnormal_d30",
              "pair_negdot_mala_d100", "pair_negdot_mala_d100_big_step", "pair_quartic_hmc_d50_tuned", "pair_banana_mh_d33",
              "pair_banana_hmc_d100_dualavg", "pair_quartic_mala_d300_pooled", "pair_indexed_mala_d100", "pair_indexed_hmc_d37",
