@@ -259,7 +259,8 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
     // backward term; putting a rejected column back) is requested from X before the pass and arrives under it; only a lane that rejects re-reads its
     // gradient from GR, and that request goes out at the accept test, ahead of the commit and of the next transition's first Philox blocks.
     // (MH: measured slower in this form — 40.1 against 45.6 TFLOP/s at D = 320, 59.8 against 62.7 at 1,024: the scales and the requested value cost 64 registers, 270-400 B of scratch —,
-    // so MH keeps reading value and scales where it draws; KLARA_SPLIT_RESIDENT=2 builds it.)
+    // so MH keeps reading value and scales where it draws; KLARA_SPLIT_RESIDENT=2 builds it.  With the value resident and the scales still read where they are
+    // used: 42.1 / 53.7 / 58.8 against 45.6 / 55.8 / 62.4 at D = 320 / 512 / 1,024 — at MH's 0.79 acceptance nearly every wavefront puts a rejected column back.)
     constexpr bool RES = KLARA_SPLIT_RESIDENT != 0 && (SAMPLER == KLARA_SAMPLER_MALA || (SAMPLER == KLARA_SAMPLER_MH && KLARA_SPLIT_RESIDENT == 2));
     kd_double4 ga[4];                                                  // +P (x' - mu) of the lane's 16 elements: element e = ga[e >> 2][e & 3]
     double sg[SAMPLER == KLARA_SAMPLER_MH && RES ? NE : 1];           // MH: the proposal scales of the lane's elements (0 past D)
