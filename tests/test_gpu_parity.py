@@ -506,6 +506,24 @@ def test_slice_sampler_on_pair_closures_runs_on_the_few_lanes_kernels(name, monk
     eng.close()
 
 
+@pytest.mark.parametrize("extra", [dict(verbose=True, period=4), dict(tuner=L.TUNER_ACCEPT_RATE, targetrate=0.5, period=3)], ids=["verbose", "rate"])
+def test_slice_sampler_on_pair_closures_with_counting_tuners_and_histories(extra):
+    """The same kernel family with something that counts proposals (the TUNE instantiation) and every saved-sample monitor on: state, sums, tuner state, one chain's
+    value and log-target histories against the oracle."""
+    c = dict(cases.make_case("pair_quartic_slice_d100"), **extra)
+    mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT
+    eng = K.Engine(**cases.engine_kwargs(c, monitor=mon, steps_per_launch=3))
+    assert eng.layout()[0] == 3
+    job = O.OracleJob(**cases.oracle_kwargs(c, layout=eng.layout()), want_hist=True)
+    eng.set_state(c["x0"]); assert job.set_state(c["x0"]) == 0
+    eng.run(c["nsteps"]); assert job.run(c["nsteps"]) == 0
+    _assert_same(eng, job, c)
+    assert np.array_equal(eng.chain(5), job.hist[:, 5, :].T)
+    lt, _ = eng.chain_fields(5, logtarget=True, gradlogtarget=False)
+    assert np.array_equal(lt, job.hist_lt[:, 5])
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["hmc_logit_d20_wide", "mala_logitm_d20", "slice_logitm_d20", "mala_logit_d12_manyrows"])
 def test_logistic_beyond_16_parameters_closure_form_still_matches(name, monkeypatch):
     """Round 6 moved the logistic regression beyond 16 parameters (and 9 .. 16 with rows that do not fit the LDS) onto the matrix cores; the run-time compiled
