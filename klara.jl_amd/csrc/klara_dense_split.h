@@ -17,8 +17,10 @@
 // 85 % of MALA's vector instructions) runs under the matrix passes of the others, which the 512-register kernels of klara_dense_big.h cannot do.
 // The committed state lives in X / GR (written at every accept) and a transition reads what it needs from there, 8 elements at a time; the
 // proposal is formed in the lane's own column of xb and found there again by the element-wise passes after the matrix pass.  Registers hold the
-// pass's accumulators, its ring and, for HMC, the momentum.
-// MH, MALA, HMC (every tuner, dual averaging with per-chain trip counts), every monitor of the dense layouts.
+// pass's accumulators, its ring and, for HMC, the momentum.  MALA keeps the committed value in the LDS column and the committed gradient in the
+// accumulators between transitions (no load between two transitions of a chain that accepts: RES below).
+// MH, MALA, HMC (every tuner, dual averaging with per-chain trip counts), the slice sampler (the tile's 16 machines in every wavefront, the first one
+// places candidates in xb), every monitor of the dense layouts.  Measurements and the steps that got here: profiles/r6_dense_split.txt.
 #pragma once
 #include "klara_dense.h"
 
