@@ -1217,7 +1217,7 @@ def test_dual_averaging_padding_lanes_do_not_set_the_trip_count():
 # ------------------------------------------------------------------ streaming batch means
 @pytest.mark.parametrize("name,batchlen,streams", [("mala_d100", 7, 0), ("dt_hmc_d100", 5, 2), ("hmc_dense_d37", 6, 0),
                                                     ("mala_swiss", 9, 0), ("hmc_rats", 4, 0), ("slice_d5", 3, 0),
-                                                    ("custom_banana_hmc", 8, 0)])
+                                                    ("custom_banana_hmc", 8, 0), ("mala_dense_d512_split_mean_tuned", 5, 0), ("pair_quartic_slice_d100", 2, 0)])
 def test_streaming_batch_means(name, batchlen, streams):
     """klara_desc.bm_batchlen: mcvar(:bm) (mcvar.jl:35-41) without stored history.  Bit-exact against the oracle closing the
     same batches from the same running sums, and equal (to rounding) to the post-hoc estimator over the stored history —
@@ -1354,7 +1354,8 @@ def test_custom_target_through_the_job_api():
     job.close()
 
 
-@pytest.mark.parametrize("name,ring,pieces", [("mala_swiss", 7, [13, 20, 7]), ("dt_hmc_d100", 4, [20]), ("hmc_dense_d37", 5, [3, 12]), ("hmc_rats", 6, [30])])
+@pytest.mark.parametrize("name,ring,pieces", [("mala_swiss", 7, [13, 20, 7]), ("dt_hmc_d100", 4, [20]), ("hmc_dense_d37", 5, [3, 12]), ("hmc_rats", 6, [30]),
+                                              ("hmc_dense_d300_split", 3, [4, 6]), ("mala_dense_d512_split_mean_tuned", 4, [11, 19])])
 def test_history_ring_keeps_the_last_saved_steps(name, ring, pieces):
     """klara_desc.hist_ring_cols: the history monitors keep a ring of the last R saved steps — after any sequence of runs the
     read-back equals the last R columns of the same job's full history, for value, logtarget and gradlogtarget."""
@@ -1384,7 +1385,8 @@ def test_history_ring_keeps_the_last_saved_steps(name, ring, pieces):
 @pytest.mark.parametrize("name,maxlag,spl,mon", [("mala_d3_tuned", 9, 7, 0), ("hmc_d10_tuned_pooled", 6, 7, 0), ("dt_mala_d100_small_step", 15, 7, 0), ("mh_readme", 31, 7, 0),
                                                  # windows beyond 32 lags (lag blocks of 32; round 5): the estimator's own 32-column ring (launches of <= 32 saved samples: the delayed
                                                  # sequence comes from the kept tail), and with a value history and 50-transition launches (it comes from the launch's own columns too)
-                                                 ("mh_readme", 100, 7, 0), ("mh_readme", 127, 50, L.MON_HISTORY), ("mala_d3_tuned", 40, 50, L.MON_HISTORY)])
+                                                 ("mh_readme", 100, 7, 0), ("mh_readme", 127, 50, L.MON_HISTORY), ("mala_d3_tuned", 40, 50, L.MON_HISTORY),
+                                                 ("mala_dense_d512_split_mean_tuned", 5, 7, 0)])
 def test_streaming_autocovariance_estimators(name, maxlag, spl, mon):
     """klara_desc.acov_maxlag: mcvar(:imse, maxlag) and mcvar(:ipse, maxlag) (mcvar.jl:75-105, 137-158) of every (chain, dimension)
     series from cross-products accumulated while sampling — no stored history — against (a) the NumPy restatement
