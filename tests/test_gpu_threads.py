@@ -38,13 +38,13 @@ def _with_nonce(case, nonce):
 
 
 THREAD_CASES = ("mala_d100", "hmc_dense_d100", "slice_d20_stepout", "custom_quartic_mala_d64", "custom_banana_hmc", "mh_readme", "hmc_rats", "mala_swiss",
-                "hmc_logitm_d33_n70")
+                "hmc_logitm_d33_n70", "hmc_dense_d300_split", "pair_quartic_slice_d100")      # (round 6: a tile on a workgroup; a run-time compiled k_diagt<SLICE, .., USERPAIR>)
 
 
 def test_distinct_handles_driven_from_distinct_host_threads_bit_exact():
-    """Nine host threads, each the single owner of one handle — MALA and MH on diagonal Gaussians, HMC on the dense target (FP64 MFMA kernels), the
+    """Eleven host threads, each the single owner of one handle — MALA and MH on diagonal Gaussians, HMC on the dense target (FP64 MFMA kernels), the
     free-running slice kernel, HMC on the hierarchical model, MALA on the swiss logistic regression, HMC on a 33-parameter logistic regression (matrix cores,
-    streamed) and TWO user closures whose sources nothing has
+    streamed), HMC on a 300-dimensional dense target (a workgroup per tile), the slice sampler on a pair closure and TWO more user closures whose sources nothing has
     compiled before (both threads are inside hiprtc / the JIT cache at once) — created, run in ragged pieces (klara_run, and klara_run_async +
     klara_synchronize) and read back concurrently, three times over; each compared bit for bit with the oracle run alone on the main thread."""
     import os
