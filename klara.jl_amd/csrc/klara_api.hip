@@ -236,7 +236,7 @@ static klara_status select_layout(const klara_desc& d, int* kind, int* G, int* E
     if (logit_mfma_eligible(d)) { *kind = 5; *G = 4; *E = 8 * ((d.ndims + 31) / 32); return KLARA_OK; }
     if (hiert_eligible(d)) { *kind = 4; *G = 8; *E = 8; return KLARA_OK; }
     const int D = d.ndims;
-    if (dense_split(d)) { *kind = 6; *G = klara_split_waves(D); *E = 16; return KLARA_OK; }      // G: wavefronts per tile of 16 chains (klara_dense_split.h klara_split_waves)
+    if (dense_split(d)) { *kind = 6; *G = klara_split_waves(D); *E = klara_split_new(D); return KLARA_OK; }      // G: wavefronts per tile of 16 chains (klara_dense_split.h klara_split_waves)
     if (d.target == KLARA_TARGET_GAUSS_DENSE) {
         *kind = 1; *G = 4;
         if (D <= 32) *E = 8; else if (D <= 64) *E = 16; else if (D <= 100) *E = 25; else if (D <= 128) *E = 32;
@@ -975,7 +975,7 @@ static klara_status init_common(klara_handle* h)
     hipError_t e;
     if (h->kind == 1) e = klara_launch_dense_init(p, h->E, h->Pfrag, h->dense_mu, needgrad, grid_for(h), st);
     else if (h->kind == 5) e = klara_launch_logit_mfma_init(p, h->E, h->Pfrag, h->ly, h->logit_nblocks, needgrad, grid_for(h), st);
-    else if (h->kind == 6) e = klara_launch_dense_split_init(p, h->G, h->Pfrag, h->dense_mu, needgrad, grid_for(h), st);
+    else if (h->kind == 6) e = klara_launch_dense_split_init(p, h->G, h->E, h->Pfrag, h->dense_mu, needgrad, grid_for(h), st);
     else if (h->kind == 3 && h->jit_pair) e = klara_jit_launch_init(h->jit, p, needgrad, grid_for(h), 0, st);
     else if (h->kind == 3)
         e = h->G == 8 ? klara_launch_diagt_init(p, h->E / 2, needgrad, grid_for(h), st)
@@ -1085,7 +1085,7 @@ static hipError_t launch_steps(klara_handle* h, const KLaunch& kl, int nparts)
     if (mode == 3 && kl.nsteps == 1) mode = 7;                                 // one iterate! per launch
     if (h->kind == 1) return klara_launch_dense(p, kl, d.sampler, d.tuner, plain, h->E, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
     if (h->kind == 5) return klara_launch_logit_mfma(p, kl, d.sampler, d.tuner == KLARA_TUNER_DUAL_AVERAGING, h->E, h->Pfrag, h->ly, h->logit_nblocks, grid_for(h), h->stream);
-    if (h->kind == 6) return klara_launch_dense_split(p, kl, d.sampler, d.tuner == KLARA_TUNER_DUAL_AVERAGING, h->G, d.ndims, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
+    if (h->kind == 6) return klara_launch_dense_split(p, kl, d.sampler, d.tuner == KLARA_TUNER_DUAL_AVERAGING, h->G, h->E, d.ndims, h->Pfrag, h->dense_mu, grid_for(h), h->stream);
     if (h->kind == 3) {
         const bool unitw = h->gw == nullptr && h->gmu == nullptr, onestep = kl.nsteps == 1;   // (device copies; the host pointers are dropped at create)
         const bool mon = (d.monitor & ~(uint32_t)KLARA_MON_ACCEPT) != 0;                      // a saved-sample monitor is on

@@ -24,7 +24,8 @@
 #pragma once
 #include "klara_dense.h"
 
-#define KLARA_SPLIT_NEW 16             // elements per lane and wavefront
+// NEW (template parameter of everything below): elements per lane and wavefront, 4 per row tile a wavefront can own — 16, or 24 where that takes a third of the
+// wavefronts off a tile (klara_launch.h klara_split_new: 257 <= D <= 384 and 513 <= D <= 768; the fewest wavefronts that hold the tile measured fastest)
 #define KLARA_SPLIT_WMAX 16            // wavefronts per workgroup (D <= 1024)
 #define KLARA_SPLIT_PAD 8              // k-steps of zeros behind the stream and rows behind the mean (>= R / 4 for every ring)
 #ifndef KLARA_SPLIT_RESIDENT
@@ -32,8 +33,9 @@
 #endif
 #define KLARA_SPLIT_CH 8               // elements per group of loads (state, mean) in the element-wise passes
 
+template <int NEW>
 struct SplitCtx {
-    MfmaCtx<KLARA_SPLIT_NEW> m;        // the wavefront's <= 16 elements per lane as a 16-element column: offsets and validity shifted by its first element
+    MfmaCtx<NEW> m;        // the wavefront's <= 16 elements per lane as a 16-element column: offsets and validity shifted by its first element
     int w, W;                          // this wavefront, wavefronts per workgroup (scalars)
     int MT, t0, T;                     // row tiles of P; this wavefront's first tile and tile count (scalars); its elements: 4 t0 .. 4 (t0 + T) - 1
     int ksteps;                        // ceil(D / 4): the k-steps that are not all padding
@@ -49,10 +51,11 @@ struct SplitCtx {
     __device__ __forceinline__ void wr(int e, double v) const { if (own(e)) col[e * 64] = v; }
 };
 
-__device__ __forceinline__ SplitCtx make_sctx(const KParams& p, const double* Pfrag, char* smem)
+template <int NEW>
+__device__ __forceinline__ SplitCtx<NEW> make_sctx(const KParams& p, const double* Pfrag, char* smem)
 {
-    SplitCtx s;
-    MfmaCtx<KLARA_SPLIT_NEW>& c = s.m;
+    SplitCtx<NEW> s;
+    MfmaCtx<NEW>& c = s.m;
     s.W = (int)(blockDim.x >> 6);
     s.w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     c.lane = threadIdx.x & 63;
@@ -89,7 +92,8 @@ __device__ __forceinline__ SplitCtx make_sctx(const KParams& p, const double* Pf
 }
 // (klara_split_waves / klara_split_lds_bytes: klara_launch.h — the host's launch planning and the launcher share them)
 // mu of the lane's element e (HASMU; zero past D)
-__device__ __forceinline__ double split_mu(const SplitCtx& s, int e)
+template <int NEW>
+__device__ __forceinline__ double split_mu(const SplitCtx<NEW>& s, int e)
 {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(s.wP, (unsigned)s.m.q * 8u, s.muoff + (unsigned)(4 * s.t0 + e) * 32u, 0));
 }
@@ -100,8 +104,8 @@ __device__ __forceinline__ double split_mu(const SplitCtx& s, int e)
 // by a line a neighbour just brought into the L1: the 3 .. 4 wavefronts per SIMD cover that, a deeper ring measured slower (registers).  The B operand
 // comes one k-step ahead from LDS.  The stream ends with KLARA_SPLIT_PAD k-steps of zeros and the mean with as many rows (a scalar offset is not
 // range-checked): no guard on the last prefetch.
-template <bool HASMU, int T>
-__device__ __forceinline__ void split_pass_t(const SplitCtx& s, kd_double4 (&acc)[4])
+template <bool HASMU, int T, int NEW>
+__device__ __forceinline__ void split_pass_t(const SplitCtx<NEW>& s, kd_double4 (&acc)[NEW / 4])
 {
     const unsigned strideK = (unsigned)s.MT * 512u;               // bytes between k-steps: MT fragments
     const unsigned voff = (unsigned)s.m.lane * 8u, vq = (unsigned)s.m.q * 8u;
@@ -136,12 +140,14 @@ __device__ __forceinline__ void split_pass_t(const SplitCtx& s, kd_double4 (&acc
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-template <bool HASMU>
-__device__ __forceinline__ void split_pass(const SplitCtx& s, kd_double4 (&acc)[4])
+template <bool HASMU, int NEW>
+__device__ __forceinline__ void split_pass(const SplitCtx<NEW>& s, kd_double4 (&acc)[NEW / 4])
 {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };
+    for (int j = 0; j < NEW / 4; ++j) acc[j] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };
     switch (s.T) {                                                // (a scalar)
+    case 6: if constexpr (NEW >= 24) split_pass_t<HASMU, 6>(s, acc); break;
+    case 5: if constexpr (NEW >= 24) split_pass_t<HASMU, 5>(s, acc); break;
     case 4: split_pass_t<HASMU, 4>(s, acc); break;
     case 3: split_pass_t<HASMU, 3>(s, acc); break;
     case 2: split_pass_t<HASMU, 2>(s, acc); break;
@@ -152,8 +158,8 @@ __device__ __forceinline__ void split_pass(const SplitCtx& s, kd_double4 (&acc)[
 
 // all-reduce of N sums over the tile's W wavefronts: 4-lane tree inside the wavefront, then the wavefronts in ascending order (oracle: layout kind 6).
 // Its barrier also closes the matrix pass before it: once a wavefront is through, every wavefront of the tile has finished reading xb.
-template <int N>
-__device__ __forceinline__ void split_reduce(SplitCtx& s, double (&v)[N])
+template <int N, int NEW>
+__device__ __forceinline__ void split_reduce(SplitCtx<NEW>& s, double (&v)[N])
 {
     static_assert(N <= 3, "rbuf holds three values");
     mreduce<N>(v, s.m.lane);
@@ -176,17 +182,17 @@ __device__ __forceinline__ void split_reduce(SplitCtx& s, double (&v)[N])
 // a column that starts at element 4 t0: the four elements of row tile G = t0 + g take their two Box-Muller pairs from half G & 1 of the blocks
 // 8 (G >> 1) + {0, 4} + lane slot (words (x, y) for an even tile, (z, w) for an odd one: one pair of blocks per two tiles, formed at the even tile or at
 // the wavefront's first).
-template <class F>
-__device__ __forceinline__ void split_normals_each(const SplitCtx& s, unsigned long long seed, unsigned long long gchain, unsigned long long t, F f)
+template <int NEW, class F>
+__device__ __forceinline__ void split_normals_each(const SplitCtx<NEW>& s, unsigned long long seed, unsigned long long gchain, unsigned long long t, F f)
 {
-    const MfmaCtx<KLARA_SPLIT_NEW>& c = s.m;
+    const MfmaCtx<NEW>& c = s.m;
     const uint32_t sh = (uint32_t)(c.q >> 1);
     const bool odd = (c.q & 1) != 0;
     const int nv = c.nv_here();
     const uint32_t lane_slot = (odd ? 2u : 0u) + sh;
     uint32_t st[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < NEW / 4; ++g) {
         if (g < s.T) {
             const int G = s.t0 + g;
             const bool half = (G & 1) != 0;
@@ -214,26 +220,27 @@ __device__ __forceinline__ void split_normals_each(const SplitCtx& s, unsigned l
 }
 
 // 8 elements e0 .. e0 + 7 of the lane's column of a (chains x D) array
-__device__ __forceinline__ void split_load8(const MfmaCtx<KLARA_SPLIT_NEW>& c, __amdgpu_buffer_rsrc_t w, int e0, int nv, double (&v)[KLARA_SPLIT_CH])
+template <int NEW>
+__device__ __forceinline__ void split_load8(const MfmaCtx<NEW>& c, __amdgpu_buffer_rsrc_t w, int e0, int nv, double (&v)[KLARA_SPLIT_CH])
 {
 #pragma unroll
     for (int j = 0; j < KLARA_SPLIT_CH; ++j) v[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(w, c.off_fresh(e0 + j, nv), 0, 0));
 }
 
 // MW: wavefronts per SIMD the registers allow (3: 168 registers, workgroups of up to 6 wavefronts; 4: 128)
-template <int SAMPLER, bool DA, bool HASMU, int MW>
+template <int SAMPLER, bool DA, bool HASMU, int MW, int NEW>
 __global__ __launch_bounds__(256 * MW)
 void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const double* __restrict__ Pfrag)
 {
     static_assert(SAMPLER == KLARA_SAMPLER_HMC || SAMPLER == KLARA_SAMPLER_MALA || SAMPLER == KLARA_SAMPLER_MH || SAMPLER == KLARA_SAMPLER_SLICE, "HMC, MALA, MH, slice");
     constexpr bool SLICE = SAMPLER == KLARA_SAMPLER_SLICE;
     static_assert(!DA || SAMPLER == KLARA_SAMPLER_HMC, "dual averaging is wired into HMC only (HMC.jl:124-133)");
-    constexpr int NE = KLARA_SPLIT_NEW, CH = KLARA_SPLIT_CH;
+    constexpr int NE = NEW, CH = KLARA_SPLIT_CH;
     constexpr bool NEEDG = SAMPLER != KLARA_SAMPLER_MH && !SLICE;
     const KParams& p = *pp;
     guchar* const accept_out = p.accept != nullptr ? p.accept + kl.t0 * (unsigned long long)p.nchains : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    SplitCtx sc = make_sctx(p, Pfrag, smem);
+    SplitCtx<NEW> sc = make_sctx<NEW>(p, Pfrag, smem);
     const MfmaCtx<NE>& cx = sc.m;
     kd_tables_to_lds();
     const bool w0 = sc.w == 0;
@@ -264,7 +271,7 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
     // so MH keeps reading value and scales where it draws; KLARA_SPLIT_RESIDENT=2 builds it.  With the value resident and the scales still read where they are
     // used: 42.1 / 53.7 / 58.8 against 45.6 / 55.8 / 62.4 at D = 320 / 512 / 1,024 — at MH's 0.79 acceptance nearly every wavefront puts a rejected column back.)
     constexpr bool RES = KLARA_SPLIT_RESIDENT != 0 && (SAMPLER == KLARA_SAMPLER_MALA || (SAMPLER == KLARA_SAMPLER_MH && KLARA_SPLIT_RESIDENT == 2));
-    kd_double4 ga[4];                                                  // +P (x' - mu) of the lane's 16 elements: element e = ga[e >> 2][e & 3]
+    kd_double4 ga[NEW / 4];                                            // +P (x' - mu) of the lane's 16 elements: element e = ga[e >> 2][e & 3]
     double sg[SAMPLER == KLARA_SAMPLER_MH && RES ? NE : 1];           // MH: the proposal scales of the lane's elements (0 past D)
     if (RES) {
         const __amdgpu_buffer_rsrc_t wX = mwin<NE>(cx, p.X, 0, p.D), wG = mwin<NE>(cx, p.GR, 0, p.D);
@@ -394,7 +401,7 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
                     sc.col[e * 64] = xn;
                     const double q1 = mu - xn;
                     s1 = s1 + (q1 * q1) * half_inv_h;                  // MALA.jl:90
-                    if (e == CH - 1) { split_load8(cx, wX, CH, nv, xv); split_load8(cx, wG, CH, nv, gv); }
+                    if ((e & (CH - 1)) == CH - 1 && e + 1 < NE) { split_load8(cx, wX, e + 1, nv, xv); split_load8(cx, wG, e + 1, nv, gv); }
                 });
             }
             __syncthreads();
@@ -508,7 +515,7 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
                 ld(0);
                 split_normals_each(sc, p.seed, gch(), t, [&](int e, double z) {
                     sc.col[e * 64] = xv[e & (CH - 1)] + sgv[e & (CH - 1)] * z;          // MH.jl:79
-                    if (e == CH - 1) ld(CH);
+                    if ((e & (CH - 1)) == CH - 1 && e + 1 < NE) ld(e + 1);
                 });
             }
             __syncthreads();
@@ -620,19 +627,19 @@ void k_dense_split(const KParams* __restrict__ pp, const KLaunch kl, const doubl
 }
 
 // initialize! for the dense target on the split layout: g = -P (x - mu), lt = c + 1/2 (x - mu).g, finiteness asserts
-template <bool HASMU>
+template <bool HASMU, int NEW>
 __global__ __launch_bounds__(1024) void k_dense_split_init(const KParams p, const double* __restrict__ Pfrag, int needgrad)
 {
-    constexpr int NE = KLARA_SPLIT_NEW;
+    constexpr int NE = NEW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    SplitCtx sc = make_sctx(p, Pfrag, smem);
+    SplitCtx<NEW> sc = make_sctx<NEW>(p, Pfrag, smem);
     const MfmaCtx<NE>& cx = sc.m;
     double x[NE], red[1];
     mload<NE>(cx, p.X, p.D, x);
 #pragma unroll
     for (int e = 0; e < NE; ++e) sc.wr(e, x[e]);
     __syncthreads();
-    kd_double4 ga[4];
+    kd_double4 ga[NEW / 4];
     split_pass<HASMU>(sc, ga);
     double l1 = 0.0, g[NE];
     bool bad = false;

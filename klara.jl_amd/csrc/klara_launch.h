@@ -42,10 +42,19 @@ hipError_t klara_launch_logit_mfma(const KParams* p, const KLaunch& kl, int samp
 hipError_t klara_launch_logit_mfma_init(const KParams& p, int NE, const double* F, const double* ypad, int nblocks, int needgrad, dim3 grid, hipStream_t st);
 int klara_logit_mfma_rbt();
 // dense Gaussian on a workgroup of W = 4 ceil(ceil(D / 16) / 16) wavefronts per tile of 16 chains (layout kind 6, klara_dense_split.h): 257 <= D <= 1024; MH, MALA, HMC
-// wavefronts per tile of 16 chains: whole SIMD rounds, at most 4 row tiles of P per wavefront
+// elements per lane and wavefront of the split dense layout (4 per row tile of P a wavefront can own): 16, or 24 where that takes a third of the wavefronts
+// off a tile — 257 <= D <= 384 (4 instead of 8) and 513 <= D <= 768 (8 instead of 12): the fewest wavefronts that hold the tile measured fastest
+// (profiles/r6_dense_split.txt); at 769 .. 1024 (12 instead of 16, 168 registers with scratch) it measured slower.  KLARA_SPLIT_NEW=16|24 forces one.
+static inline int klara_split_new(int D)
+{
+    const int MT = (D + 15) / 16, w16 = 4 * ((MT + 15) / 16), w24 = 4 * ((MT + 23) / 24);
+    if (const char* e = getenv("KLARA_SPLIT_NEW")) { const int v = atoi(e); if (v == 16 || v == 24) return v; }
+    return (w24 < w16 && w24 <= 8) ? 24 : 16;
+}
+// wavefronts per tile of 16 chains: whole SIMD rounds, at most klara_split_new / 4 row tiles of P per wavefront
 static inline int klara_split_waves(int D)
 {
-    const int MT = (D + 15) / 16, w = 4 * ((MT + 15) / 16);
+    const int MT = (D + 15) / 16, n = klara_split_new(D), w = 4 * ((MT + n - 1) / n);
     if (const char* e = getenv("KLARA_SPLIT_W")) { const int v = atoi(e); if (v >= w && v <= 16 && v % 4 == 0) return v; }      // (measurements: more wavefronts, fewer tiles each)
     return w;
 }
@@ -55,8 +64,8 @@ static inline size_t klara_split_lds_bytes(int D)
     const size_t MT = ((size_t)D + 15) / 16;
     return sizeof(double) * (4 * MT * 64 + 2 * 3 * (size_t)klara_split_waves(D) * 16);
 }
-hipError_t klara_launch_dense_split(const KParams* p, const KLaunch& kl, int sampler, bool da, int W, int D, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st);
-hipError_t klara_launch_dense_split_init(const KParams& p, int W, const double* Pfrag, bool hasmu, int needgrad, dim3 grid, hipStream_t st);      // row tiles per block the kernels were built for
+hipError_t klara_launch_dense_split(const KParams* p, const KLaunch& kl, int sampler, bool da, int W, int NEW, int D, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st);
+hipError_t klara_launch_dense_split_init(const KParams& p, int W, int NEW, const double* Pfrag, bool hasmu, int needgrad, dim3 grid, hipStream_t st);      // row tiles per block the kernels were built for
 
 // pair-transposed diagonal-Gaussian kernels (layout kind 3, klara_diagt.h).  The translation units klara_diagt_*.hip are
 // compiled four times: Q = 8 lanes per chain (17 <= D <= 128, NP = ceil(D/16) in 2..8), Q = 16 (129 <= D <= 256), Q = 32

@@ -113,6 +113,18 @@ DIAGT_NP_MENU = (2, 3, 4, 5, 6, 7, 8)      # klara_launch.h KLARA_DIAGT_NP_MENU_
 DIAGT_Q = 8
 
 
+def split_dense_layout(d: int):
+    """(6, wavefronts per tile, elements per lane and wavefront) of the workgroup-split dense layout: klara_launch.h klara_split_new / klara_split_waves —
+    16 elements (4 row tiles) per lane and wavefront, or 24 where that takes a third of the wavefronts off a tile (257 .. 384 and 513 .. 768 dimensions)."""
+    mt = (d + 15) // 16
+    w16, w24 = 4 * ((mt + 15) // 16), 4 * ((mt + 23) // 24)
+    new = int(os.environ["KLARA_SPLIT_NEW"]) if os.environ.get("KLARA_SPLIT_NEW") in ("16", "24") else (24 if (w24 < w16 and w24 <= 8) else 16)
+    w = 4 * ((mt + new - 1) // new)
+    if os.environ.get("KLARA_SPLIT_W", "").isdigit() and int(os.environ["KLARA_SPLIT_W"]) >= w and int(os.environ["KLARA_SPLIT_W"]) % 4 == 0 and int(os.environ["KLARA_SPLIT_W"]) <= 16:
+        w = int(os.environ["KLARA_SPLIT_W"])
+    return (6, w, new)
+
+
 def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, tuner=0, tuner_mode=0, verbose=False,
                    hier_nunits: int = 0, hier_ntimes: int = 0, summaries: bool = True, sparse_moves: bool = False, pair_form: bool = False, custom_rows: int = 2):
     """Mirror of the product's layout choice (klara_get_layout reports the real one on the GPU box).  `sampler`, `tuner`,
@@ -152,7 +164,7 @@ def default_layout(target_kind: int, ndims: int, ndata: int = 0, sampler=None, t
     if (target_kind == L.TARGET_GAUSS_DENSE and d <= 1024 and "KLARA_DENSE_NO_SPLIT" not in os.environ
             and (d > 256 or os.environ.get("KLARA_DENSE_SPLIT", "0") not in ("", "0"))):
         # round 6: a workgroup of 4, 8, 12 or 16 wavefronts per tile of 16 chains, the ceil(D / 16) row tiles dealt evenly (klara_dense_split.h)
-        return (6, 4 * (((d + 15) // 16 + 15) // 16), 16)
+        return split_dense_layout(d)
     if (target_kind == L.TARGET_GAUSS_DENSE and 128 < d <= 256 and "KLARA_DENSE_NO_STREAM" not in os.environ
             and not (sampler == L.SAMPLER_SLICE and "KLARA_DENSE_SLICE_NO_STREAM" in os.environ)):      # every sampler to D = 256: still the matrix cores, P streamed (klara_dense_big.h; round 5: the slice sampler too)
         return (1, 4, 8 * ((d + 31) // 32))

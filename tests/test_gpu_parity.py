@@ -457,7 +457,7 @@ def test_dense_target_beyond_256_on_workgroup_split_layout(name):
     case = cases.make_case(name)
     d = case["target"].ndims
     eng, job = _run_pair(case)
-    assert eng.layout() == (6, 4 * (((d + 15) // 16 + 15) // 16), 16)
+    assert eng.layout() == O.split_dense_layout(d)
     _assert_same(eng, job, case)
     eng.close()
     n = case["nsteps"]
@@ -476,7 +476,7 @@ def test_smaller_dense_targets_on_the_split_layout(name, monkeypatch):
     case = cases.make_case(name)
     d = case["target"].ndims
     eng, job = _run_pair(case)
-    assert eng.layout() == (6, 4 * (((d + 15) // 16 + 15) // 16), 16)
+    assert eng.layout() == O.split_dense_layout(d)
     _assert_same(eng, job, case)
     eng.close()
 
@@ -1063,7 +1063,7 @@ def test_every_split_dense_instantiation_in_one_launch(smp, d, mu):
     nograd = smp in ("mh", "slice")
     mon = L.MON_ACCEPT | L.MON_SUMMARIES | L.MON_HISTORY | L.MON_HIST_LT | (0 if nograd else L.MON_HIST_GRAD)
     eng = K.Engine(**cases.engine_kwargs(c, monitor=mon, steps_per_launch=0, nstreams=1))
-    assert eng.layout() == (6, 4 * (((d + 15) // 16 + 15) // 16), 16), eng.layout()
+    assert eng.layout() == O.split_dense_layout(d), eng.layout()
     job = O.OracleJob(**cases.oracle_kwargs(c, layout=eng.layout()), want_hist=True)
     eng.init_state_normal(); assert job.init_state_normal() == 0
     eng.run(c["nsteps"]); assert job.run(c["nsteps"]) == 0
