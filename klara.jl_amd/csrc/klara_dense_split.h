@@ -2,8 +2,8 @@
 //
 // klara_dense_big.h gives one wavefront the whole vectors of its 16 chains: NE = 64 elements per lane at D = 256 is what 256 architectural + 256
 // accumulator registers hold, at one wavefront per SIMD.  Beyond that neither the value nor the gradient fits a lane.  Here the W wavefronts of a
-// workgroup SHARE the tile.  The gradient  G' = P X'  has MT = ceil(D / 16) row tiles of v_mfma_f64_16x16x4; W = 4 ceil(MT / 16) (4, 8, 12, 16: whole
-// SIMD rounds) and wavefront w owns the T = 2 .. 4 CONSECUTIVE tiles t0 .. t0 + T - 1 of an even deal (the first MT % W wavefronts one more than the
+// workgroup SHARE the tile.  The gradient  G' = P X'  has MT = ceil(D / 16) row tiles of v_mfma_f64_16x16x4; W = 4 ceil(MT / (NEW / 4)) (4, 8, 12, 16: whole
+// SIMD rounds; NEW = 16 or 24 elements per lane and wavefront, below) and wavefront w owns the T = 2 .. NEW / 4 CONSECUTIVE tiles t0 .. t0 + T - 1 of an even deal (the first MT % W wavefronts one more than the
 // rest: every SIMD carries the same number of tiles +- 1 whatever D is), i.e. the elements e = 4 t0 .. 4 (t0 + T) - 1 of every lane's column (lane
 // (q, chain) of klara_dense.h: dimension i = 4 e + q) — the rows of its tiles — in the matrix pass and in every element-wise update (normals,
 // proposal, kicks, sums).  What a wavefront needs from the others is the B operand of its pass, the whole proposal x of the 16 chains: every wavefront
