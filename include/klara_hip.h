@@ -84,8 +84,8 @@ typedef enum klara_target {
     KLARA_TARGET_GAUSS_DIAG = 0,
     /* lt = c - 1/2 (x-mu)' P (x-mu) ; grad = -P (x-mu).  P = dense precision matrix (D x D).  D <= 128: FP64 matrix cores (all four
      * samplers; P in LDS); D = 129..256: all four stay on the matrix cores (P streamed from memory; HMC's momentum in LDS: 64 TFLOP/s
-     * at D = 256); D = 257..1024 (round 6; refused before): all four samplers with the tile of 16 chains on a workgroup of 8 / 12 / 16 wavefronts that
-     * deal the row tiles of P evenly (layout kind 6, klara_dense_split.h: HMC L = 10 at 56 .. 69 TFLOP/s); D > 1024 is KLARA_ERR_UNSUPPORTED. */
+     * at D = 256); D = 257..1024 (round 6; refused before): all four samplers with the tile of 16 chains on a workgroup of 4 / 8 wavefronts that
+     * deal the row tiles of P evenly (layout kind 6, klara_dense_split.h: HMC L = 10 at 56 .. 71 TFLOP/s); D > 1024 is KLARA_ERR_UNSUPPORTED. */
     KLARA_TARGET_GAUSS_DENSE = 1,
     /* Bayesian logistic regression of doc/examples/swiss/MALA/analytical.jl:11-18:
      * lt = dot(Xp, y) - sum(log(1+exp(Xp))) - 0.5 (p.p/lambda + D log(2 pi lambda)).  Up to 16 parameters: the data rows in LDS, dealt to 4 lanes
@@ -392,7 +392,7 @@ klara_status klara_device_ptrs(klara_handle* h, void** x, void** logtarget, void
  * with few lanes per chain (unit r on lane r / (elements_per_lane/2), hyper block replicated); kind 5 = logistic regression on the matrix cores
  * (elements as in kind 1; data row r on lane-quarter r % 4: row sums are lane partials over ascending rows, then (q0 + q1) + (q2 + q3); X p and
  * X' (y - 1/(1+exp(-Xp))) are fma chains over ascending columns / rows); kind 6 = dense Gaussian beyond D = 256 on a workgroup of `lanes_per_chain`
- * WAVEFRONTS per tile of 16 chains (`elems_per_lane` = 16 or 24: the elements of a lane's column a wavefront can own) (element i on lane-quarter i % 4 of the wavefront that owns row tile i / 16 — the ceil(D / 16) tiles dealt evenly,
+ * WAVEFRONTS per tile of 16 chains (`elems_per_lane` = 16, 24 or 32: the elements of a lane's column a wavefront can own) (element i on lane-quarter i % 4 of the wavefront that owns row tile i / 16 — the ceil(D / 16) tiles dealt evenly,
  * consecutive tiles each, the first ceil(D/16) % W wavefronts one more —; lane partials in ascending order, (q0 + q1) + (q2 + q3) inside a wavefront, then
  * the wavefronts in ascending order).  See DESIGN.md section 3. */
 klara_status klara_get_layout(klara_handle* h, int32_t* kind, int32_t* lanes_per_chain,

@@ -3,7 +3,7 @@
 // klara_dense_big.h gives one wavefront the whole vectors of its 16 chains: NE = 64 elements per lane at D = 256 is what 256 architectural + 256
 // accumulator registers hold, at one wavefront per SIMD.  Beyond that neither the value nor the gradient fits a lane.  Here the W wavefronts of a
 // workgroup SHARE the tile.  The gradient  G' = P X'  has MT = ceil(D / 16) row tiles of v_mfma_f64_16x16x4; W = 4 ceil(MT / (NEW / 4)) (4, 8, 12, 16: whole
-// SIMD rounds; NEW = 16 or 24 elements per lane and wavefront, below) and wavefront w owns the T = 2 .. NEW / 4 CONSECUTIVE tiles t0 .. t0 + T - 1 of an even deal (the first MT % W wavefronts one more than the
+// SIMD rounds; NEW = 16, 24 or 32 elements per lane and wavefront, below) and wavefront w owns the T = 2 .. NEW / 4 CONSECUTIVE tiles t0 .. t0 + T - 1 of an even deal (the first MT % W wavefronts one more than the
 // rest: every SIMD carries the same number of tiles +- 1 whatever D is), i.e. the elements e = 4 t0 .. 4 (t0 + T) - 1 of every lane's column (lane
 // (q, chain) of klara_dense.h: dimension i = 4 e + q) — the rows of its tiles — in the matrix pass and in every element-wise update (normals,
 // proposal, kicks, sums).  What a wavefront needs from the others is the B operand of its pass, the whole proposal x of the 16 chains: every wavefront
@@ -13,7 +13,7 @@
 // kinetic energy) are lane partials over the lane's elements in ascending order, the 4-lane tree (q0 + q1) + (q2 + q3) inside the wavefront, then the
 // wavefronts' values in ascending order through LDS — the oracle's layout kind 6 (G = W).
 //
-// One kernel per sampler serves 257 <= D <= 1024 (every count is a run-time value), at 3 .. 4 wavefronts per SIMD: the vector work of one (Box-Muller:
+// One kernel per sampler and NEW serves 257 <= D <= 1024 (every other count is a run-time value), at 2 .. 4 wavefronts per SIMD: the vector work of one (Box-Muller:
 // 85 % of MALA's vector instructions) runs under the matrix passes of the others, which the 512-register kernels of klara_dense_big.h cannot do.
 // The committed state lives in X / GR (written at every accept) and a transition reads what it needs from there, 8 elements at a time; the
 // proposal is formed in the lane's own column of xb and found there again by the element-wise passes after the matrix pass.  Registers hold the
@@ -24,8 +24,8 @@
 #pragma once
 #include "klara_dense.h"
 
-// NEW (template parameter of everything below): elements per lane and wavefront, 4 per row tile a wavefront can own — 16, or 24 where that takes a third of the
-// wavefronts off a tile (klara_launch.h klara_split_new: 257 <= D <= 384 and 513 <= D <= 768; the fewest wavefronts that hold the tile measured fastest)
+// NEW (template parameter of everything below): elements per lane and wavefront, 4 per row tile a wavefront can own — 16, 24 or 32, whichever puts the fewest
+// wavefronts on a tile (klara_launch.h klara_split_new: 4 wavefronts to D = 512, 8 beyond; the fewest wavefronts that hold the tile measured fastest)
 #define KLARA_SPLIT_WMAX 16            // wavefronts per workgroup (D <= 1024)
 #define KLARA_SPLIT_PAD 8              // k-steps of zeros behind the stream and rows behind the mean (>= R / 4 for every ring)
 #ifndef KLARA_SPLIT_RESIDENT
@@ -146,6 +146,8 @@ __device__ __forceinline__ void split_pass(const SplitCtx<NEW>& s, kd_double4 (&
 #pragma unroll
     for (int j = 0; j < NEW / 4; ++j) acc[j] = (kd_double4){ 0.0, 0.0, 0.0, 0.0 };
     switch (s.T) {                                                // (a scalar)
+    case 8: if constexpr (NEW >= 32) split_pass_t<HASMU, 8>(s, acc); break;
+    case 7: if constexpr (NEW >= 32) split_pass_t<HASMU, 7>(s, acc); break;
     case 6: if constexpr (NEW >= 24) split_pass_t<HASMU, 6>(s, acc); break;
     case 5: if constexpr (NEW >= 24) split_pass_t<HASMU, 5>(s, acc); break;
     case 4: split_pass_t<HASMU, 4>(s, acc); break;

@@ -34,6 +34,7 @@ template <int S, bool DA = false>
 static hipError_t go_split_s(const KParams* p, const KLaunch& kl, int W, int NEW, int D, const double* Pfrag, bool hasmu, dim3 grid, hipStream_t st)
 {
     if (W > KLARA_SPLIT_WMAX || W * (NEW / 4) < (D + 15) / 16) return hipErrorInvalidValue;
+    if (NEW == 32) return go_split_n<S, DA, 32>(p, kl, W, D, Pfrag, hasmu, grid, st);
     if (NEW == 24) return go_split_n<S, DA, 24>(p, kl, W, D, Pfrag, hasmu, grid, st);
     if (NEW == 16) return go_split_n<S, DA, 16>(p, kl, W, D, Pfrag, hasmu, grid, st);
     return hipErrorInvalidValue;
@@ -65,6 +66,7 @@ static hipError_t go_split_init(const KParams& p, int W, const double* Pfrag, in
 hipError_t klara_launch_dense_split_init(const KParams& p, int W, int NEW, const double* Pfrag, bool hasmu, int needgrad, dim3 grid, hipStream_t st)
 {
     if (W > KLARA_SPLIT_WMAX || W * (NEW / 4) < (p.D + 15) / 16) return hipErrorInvalidValue;
+    if (NEW == 32) return hasmu ? go_split_init<true, 32>(p, W, Pfrag, needgrad, grid, st) : go_split_init<false, 32>(p, W, Pfrag, needgrad, grid, st);
     if (NEW == 24) return hasmu ? go_split_init<true, 24>(p, W, Pfrag, needgrad, grid, st) : go_split_init<false, 24>(p, W, Pfrag, needgrad, grid, st);
     if (NEW == 16) return hasmu ? go_split_init<true, 16>(p, W, Pfrag, needgrad, grid, st) : go_split_init<false, 16>(p, W, Pfrag, needgrad, grid, st);
     return hipErrorInvalidValue;

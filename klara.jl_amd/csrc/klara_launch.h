@@ -42,14 +42,17 @@ hipError_t klara_launch_logit_mfma(const KParams* p, const KLaunch& kl, int samp
 hipError_t klara_launch_logit_mfma_init(const KParams& p, int NE, const double* F, const double* ypad, int nblocks, int needgrad, dim3 grid, hipStream_t st);
 int klara_logit_mfma_rbt();
 // dense Gaussian on a workgroup of W = 4 ceil(ceil(D / 16) / 16) wavefronts per tile of 16 chains (layout kind 6, klara_dense_split.h): 257 <= D <= 1024; MH, MALA, HMC
-// elements per lane and wavefront of the split dense layout (4 per row tile of P a wavefront can own): 16, or 24 where that takes a third of the wavefronts
-// off a tile — 257 <= D <= 384 (4 instead of 8) and 513 <= D <= 768 (8 instead of 12): the fewest wavefronts that hold the tile measured fastest
-// (profiles/r6_dense_split.txt); at 769 .. 1024 (12 instead of 16, 168 registers with scratch) it measured slower.  KLARA_SPLIT_NEW=16|24 forces one.
+// elements per lane and wavefront of the split dense layout (4 per row tile of P a wavefront can own): 16, 24 or 32 — whichever puts the FEWEST wavefronts on a
+// tile (the smaller one on a tie): the fewest wavefronts that hold the tile measured fastest at every size (profiles/r6_dense_split.txt), as long as their
+// registers are not short — so 257 <= D <= 384: 24 (4 wavefronts), 385 .. 512: 32 (4), 513 .. 768: 24 (8), 769 .. 1024: 32 (8; 24 there would be 12 wavefronts at
+// 168 registers with scratch: measured slower than 16).  KLARA_SPLIT_NEW=16|24|32 forces one.
 static inline int klara_split_new(int D)
 {
-    const int MT = (D + 15) / 16, w16 = 4 * ((MT + 15) / 16), w24 = 4 * ((MT + 23) / 24);
-    if (const char* e = getenv("KLARA_SPLIT_NEW")) { const int v = atoi(e); if (v == 16 || v == 24) return v; }
-    return (w24 < w16 && w24 <= 8) ? 24 : 16;
+    const int MT = (D + 15) / 16;
+    if (const char* e = getenv("KLARA_SPLIT_NEW")) { const int v = atoi(e); if (v == 16 || v == 24 || v == 32) return v; }
+    int best = 16, wbest = 4 * ((MT + 15) / 16);
+    for (int n = 24; n <= 32; n += 8) { const int w = 4 * ((MT + n - 1) / n); if (w < wbest && w <= 8) { best = n; wbest = w; } }
+    return best;
 }
 // wavefronts per tile of 16 chains: whole SIMD rounds, at most klara_split_new / 4 row tiles of P per wavefront
 static inline int klara_split_waves(int D)

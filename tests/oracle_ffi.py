@@ -115,10 +115,15 @@ DIAGT_Q = 8
 
 def split_dense_layout(d: int):
     """(6, wavefronts per tile, elements per lane and wavefront) of the workgroup-split dense layout: klara_launch.h klara_split_new / klara_split_waves —
-    16 elements (4 row tiles) per lane and wavefront, or 24 where that takes a third of the wavefronts off a tile (257 .. 384 and 513 .. 768 dimensions)."""
+    16, 24 or 32 elements (4 / 6 / 8 row tiles) per lane and wavefront: whichever puts the fewest wavefronts on a tile (24: 257 .. 384 and 513 .. 768 dimensions; 32: 385 .. 512 and 769 .. 1024)."""
     mt = (d + 15) // 16
-    w16, w24 = 4 * ((mt + 15) // 16), 4 * ((mt + 23) // 24)
-    new = int(os.environ["KLARA_SPLIT_NEW"]) if os.environ.get("KLARA_SPLIT_NEW") in ("16", "24") else (24 if (w24 < w16 and w24 <= 8) else 16)
+    new, wbest = 16, 4 * ((mt + 15) // 16)
+    for n in (24, 32):                     # the fewest wavefronts on a tile, the smaller element count on a tie
+        wn = 4 * ((mt + n - 1) // n)
+        if wn < wbest and wn <= 8:
+            new, wbest = n, wn
+    if os.environ.get("KLARA_SPLIT_NEW") in ("16", "24", "32"):
+        new = int(os.environ["KLARA_SPLIT_NEW"])
     w = 4 * ((mt + new - 1) // new)
     if os.environ.get("KLARA_SPLIT_W", "").isdigit() and int(os.environ["KLARA_SPLIT_W"]) >= w and int(os.environ["KLARA_SPLIT_W"]) % 4 == 0 and int(os.environ["KLARA_SPLIT_W"]) <= 16:
         w = int(os.environ["KLARA_SPLIT_W"])
