@@ -582,7 +582,7 @@ def test_round6_bench_lines_are_complete_and_recomputable():
         assert ex["slice_swiss_logistic_coordinate_updates_per_s"] > 3e8
         assert ex["slice_pair_closure_d100_coordinate_updates_per_s"] > 3e10 and ex["slice_pair_closure_d100_layout"][0] == 3       # (round 6: the few-lanes kernels; the whole-vector form ran at 7.4e8)
         # dense targets beyond D = 256 on the workgroup-split layout (round 6; refused before): HMC >= 0.8 of the FP64-MFMA peak, MALA >= 0.55
-        for dd, lo_h, lo_m in ((512, 0.80, 0.55), (1024, 0.82, 0.65)):
+        for dd, lo_h, lo_m in ((512, 0.84, 0.58), (1024, 0.86, 0.68)):
             assert ex[f"hmc_dense_d{dd}_roofline"]["frac"] >= lo_h and ex[f"mala_dense_d{dd}_roofline"]["frac"] >= lo_m, dd
             assert "layout kind 6" in ex[f"hmc_dense_d{dd}_roofline"]["kernel"]
         c3 = ex["cfg3_hmc_dense_roofline"]
